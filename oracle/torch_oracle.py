@@ -1,0 +1,413 @@
+"""CPU oracle for SAMBLE's attention-score downsampling path (TEST INFRASTRUCTURE ONLY).
+
+This file is a staged, pure-torch CPU restatement of the reference algorithm
+(stevenczwu/SAMBLE: models/downsample.py:112-344, utils/ops.py:17-44, 125-133,
+174-236, 385-619).  It exists so that `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` have something to check / time the HIP path
+against.  Nothing under `samble_amd/` may import it: the product path has no CPU
+fallback and fails loudly when the HIP library is missing.
+
+Pinning: every stage below is checked bit-for-bit against the imported reference
+in the build container by `tests/golden/make_golden.py` (same torch build, same
+ATen kernels) and the outputs are committed as fixtures under `tests/golden/`;
+`tests/test_oracle_golden.py` re-checks the oracle against those fixtures on any
+box.  The reference ships no tests of its own, so those
+generated fixtures are the only pin there is.
+
+Every stage is a free function so that a test can inject the oracle's stage
+inputs into the matching HIP kernel (stage-wise integer exactness) as well as
+compare end to end.
+"""
+from __future__ import annotations
+
+import math
+import numbers
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- #
+# configuration
+# --------------------------------------------------------------------------- #
+@dataclass
+class SamplerSpec:
+    """Flat view of one layer of the reference's `config.downsample` subtree
+    (configs/default.yaml:183-220 + configs/cls.yaml:119-158)."""
+
+    M: int = 1024
+    K: int = 32
+    C: int = 128
+    num_bins: int = 6
+    asm: str = "dot"
+    idx_mode: str = "sparse_col_sqr"
+    sample_mode: str = "random"
+    boltzmann_T: object = 0.1
+    relu_mean_order: str = "mean_relu"
+    token_mode: str = "multi_token"
+    dynamic_boundaries: bool = True
+    momentum: float = 0.99
+    static_boundaries: Optional[List[float]] = None  # nb-1 descending values
+
+
+# --------------------------------------------------------------------------- #
+# neighbour ops  (utils/ops.py:17-44, 125-133)
+# --------------------------------------------------------------------------- #
+def knn(a: torch.Tensor, b: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k nearest rows of `b` for each row of `a`; a (B,N,C), b (B,M,C).
+
+    Follows utils/ops.py:23-43: both sets are centred on a's mean over points and
+    divided by one scalar per cloud (mean over channels of a's unbiased per-channel
+    std), distances come from torch.cdist, and the k largest of the negated
+    distances are returned nearest first (self included when a is b).
+    Returns (negated distance (B,N,k), index (B,N,k) int64)."""
+    centre = a.mean(dim=1, keepdim=True)
+    a0 = a - centre
+    b0 = b - centre
+    scale = torch.std(a0, dim=1, keepdim=True).mean(dim=2, keepdim=True)
+    a0 = a0 / scale
+    b0 = b0 / scale
+    neg = -torch.cdist(a0, b0)
+    return neg.topk(k=k, dim=-1)
+
+
+def knn_mask(x: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense 0/1 neighbour mask of the layer input x (B,C,N) -> (B,N,N) and the
+    index tensor it was scattered from (utils/ops.py:125-133).  Row i has ones at
+    the k nearest neighbours of point i in *feature* space."""
+    pts = x.permute(0, 2, 1)
+    _, idx = knn(pts, pts, k)
+    B, N, _ = idx.shape
+    mask = torch.zeros(B, N, N, dtype=torch.float32)
+    mask.scatter_(2, idx, 1.0)
+    return mask, idx
+
+
+def index_rows(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """points (B,N,C), idx (B,M,K) -> (B,M,K,C)  (utils/ops.py:5-14)."""
+    shape = idx.shape
+    flat = idx.reshape(shape[0], -1)
+    out = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1]))
+    return out.view(*shape, -1)
+
+
+def group_neighbors(x: torch.Tensor, k: int, group_type: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """utils/ops.py:47-112 for the four layouts; x (B,C,N) -> ((B,C|2C,N,k), idx)."""
+    pts = x.permute(0, 2, 1)
+    _, idx = knn(pts, pts, k)
+    nb = index_rows(pts, idx)  # (B,N,k,C)
+    if group_type in ("neighbor", "center_neighbor"):
+        g = nb.permute(0, 3, 1, 2)
+    elif group_type in ("diff", "center_diff"):
+        g = (nb - pts[:, :, None, :]).permute(0, 3, 1, 2)
+    else:
+        raise ValueError(f"unknown group_type {group_type}")
+    if group_type.startswith("center_"):
+        g = torch.cat([x[:, :, :, None].repeat(1, 1, 1, k), g], dim=1)
+    return g, idx
+
+
+def gather_points(pcd: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """pcd (B,C,N), idx (B,1,M) -> (B,C,M)  (utils/ops.py:136-145)."""
+    return torch.gather(pcd, 2, idx.expand(-1, pcd.shape[1], -1))
+
+
+def interpolate_neighbors(unknown, known, known_feature, k=3):
+    """utils/ops.py:68-80: cross-set kNN; returns (neighbours (B,C,N,k), idx, +distance)."""
+    kn = known.permute(0, 2, 1)
+    kf = known_feature.permute(0, 2, 1)
+    un = unknown.permute(0, 2, 1)
+    d, idx = knn(un, kn, k)
+    nb = index_rows(kf, idx).permute(0, 3, 1, 2)
+    return nb, idx, -1 * d
+
+
+# --------------------------------------------------------------------------- #
+# attention map  (models/downsample.py:116-153)
+# --------------------------------------------------------------------------- #
+def project_qkv(x, tokens, wq, wk, wv):
+    """x (B,C,N), tokens (1,C,nb|1), w* (C,C,1).  Returns q (B,1,N,D),
+    k (B,1,D,N+nt), v (B,1,D,N+nt) exactly as downsample.py:116-137 (H=1)."""
+    B = x.shape[0]
+    xt = torch.cat((x, tokens.expand(B, -1, -1)), dim=2)
+    q = F.conv1d(x, wq)
+    k = F.conv1d(xt, wk)
+    v = F.conv1d(xt, wv)
+    q = q.view(B, 1, q.shape[1], q.shape[2]).permute(0, 1, 3, 2)
+    k = k.view(B, 1, k.shape[1], k.shape[2])
+    v = v.view(B, 1, v.shape[1], v.shape[2])
+    return q, k, v
+
+
+def attention_map(q, k, n_points: int):
+    """energy = q@k / sqrt(D); softmax over all N+nt columns (downsample.py:139-153).
+    Returns (A (B,1,N,N+nt), A_points (B,1,N,N), token logits (B,1,N,nt))."""
+    logits = (q @ k) / math.sqrt(q.shape[-1])
+    A = torch.softmax(logits, dim=-1)
+    _, tok_logits = torch.split(logits, n_points, dim=-1)
+    A_pts, _ = torch.split(A, n_points, dim=-1)
+    return A, A_pts, tok_logits
+
+
+# --------------------------------------------------------------------------- #
+# per-point score  (models/downsample.py:300-344)
+# --------------------------------------------------------------------------- #
+def point_score(x, A_pts, k: int, idx_mode: str):
+    """Sampling score (B,1,N) from the point-to-point attention block and the
+    feature-space kNN mask.  Returns (score, knn idx (B,N,k), in-degree (B,N))."""
+    mask, idx = knn_mask(x, k)
+    mask4 = mask.unsqueeze(1).expand(-1, A_pts.shape[1], -1, -1)
+    sparse = A_pts * mask4
+    indeg = torch.sum(mask4, dim=-2) + 1e-8
+    if idx_mode == "col_sum":
+        s = torch.sum(A_pts, dim=-2)
+    elif idx_mode == "row_std":
+        s = torch.std(A_pts, dim=-1)
+    elif idx_mode == "sparse_row_sum":
+        s = torch.sum(sparse, dim=-1)
+    elif idx_mode == "sparse_row_std":
+        picked = sparse.masked_select(mask4 != 0).view(sparse.shape[:-1] + (k,))
+        s = torch.std(picked, dim=-1)
+    elif idx_mode == "sparse_col_sum":
+        s = torch.sum(sparse, dim=-2)
+    elif idx_mode == "sparse_col_avg":
+        s = torch.sum(sparse, dim=-2) / indeg
+    elif idx_mode == "sparse_col_sqr":
+        s = torch.sum(sparse, dim=-2) / indeg / indeg
+    else:
+        raise ValueError("Please check the setting of idx mode!")
+    s[torch.isnan(s)] = 0
+    return s, idx, mask.sum(dim=-2)
+
+
+# --------------------------------------------------------------------------- #
+# bins  (utils/ops.py:174-236, 435-464; models/downsample.py:264-284)
+# --------------------------------------------------------------------------- #
+def zscore(score):
+    """Per-cloud z-score with population std (utils/ops.py:450-452, 517-520)."""
+    return (score - score.mean(dim=2, keepdim=True)) / score.std(dim=2, unbiased=False, keepdim=True)
+
+
+def quantile_ranks(num_bins: int, numel: int) -> torch.Tensor:
+    """Ranks (into the descending sort) of the nb-1 boundaries: fp32 arithmetic
+    then truncation, utils/ops.py:182-183."""
+    return (torch.arange(1, num_bins) / num_bins * numel).int()
+
+
+def batch_quantiles(z, num_bins: int) -> torch.Tensor:
+    """nb-1 order statistics of ALL B*H*N z-scores, descending (utils/ops.py:180-189)."""
+    ranks = quantile_ranks(num_bins, z.nelement())
+    ordered, _ = torch.sort(z.flatten(), dim=0, descending=True)
+    return ordered[ranks.long()]
+
+
+def blend_boundaries(state, quant, num_bins: int, momentum: float):
+    """utils/ops.py:201-233.  state is None (first call: raw quantiles) or
+    [upper, lower] (1,1,1,nb) tensors which are UPDATED IN PLACE, as the reference
+    does.  Returns the [upper, lower] pair."""
+    if state is not None:
+        up, lo = state[0].detach(), state[1].detach()
+        mixed = up[0, 0, 0, 1:] * momentum + (1 - momentum) * quant
+        up[0, 0, 0, 1:] = mixed
+        lo[0, 0, 0, :-1] = mixed
+        return [up, lo]
+    up = torch.empty((num_bins,))
+    up[0] = float("inf")
+    up[1:] = quant
+    lo = torch.empty((num_bins,))
+    lo[-1] = float("-inf")
+    lo[:-1] = quant
+    return [up.reshape(1, 1, 1, num_bins), lo.reshape(1, 1, 1, num_bins)]
+
+
+def static_boundary_state(values: List[float], num_bins: int):
+    """models/downsample.py:96-103."""
+    up = torch.asarray([float("inf")] + list(values)).reshape(1, 1, 1, num_bins)
+    lo = torch.asarray(list(values) + [float("-inf")]).reshape(1, 1, 1, num_bins)
+    return [up, lo]
+
+
+def bin_membership(z, state):
+    """(B,1,N) z-scores against [upper, lower] -> bool (B,1,N,nb); bin t holds
+    lower[t] <= z < upper[t]  (utils/ops.py:454-463)."""
+    z4 = z.reshape(z.shape[0], z.shape[1], z.shape[2], 1)
+    return (z4 < state[0]) & (z4 >= state[1])
+
+
+def bin_weights(tok_logits, member, order: str):
+    """Masked mean of the token logits per bin (models/downsample.py:264-284).
+    Returns (weights (B,nb), weights before relu (B,nb))."""
+    masked = tok_logits * member
+    if order == "mean_relu":
+        pre = torch.sum(masked, dim=2) / (torch.count_nonzero(member, dim=2) + 1e-8)
+        pre = pre.squeeze(1)
+        return F.relu(pre), pre
+    if order == "relu_mean":
+        masked = F.relu(masked)
+        pre = torch.sum(masked, dim=2) / (torch.count_nonzero(member, dim=2) + 1e-8)
+        pre = pre.squeeze(1)
+        return pre, pre
+    raise NotImplementedError
+
+
+def allocate_counts(weights, cap, total: int):
+    """Water-filling of `total` picks over the bins of each cloud
+    (utils/ops.py:385-432): weights (B,nb) fp32, cap (B,nb) int64 -> (B,nb) int32.
+    The early exit is a whole-batch condition, as in the reference."""
+    B, nb = weights.shape
+    p = weights * cap
+    p += 1e-10
+    chosen = torch.zeros_like(p)
+    for _ in range(nb):
+        p = p / torch.sum(p, dim=1, keepdim=True)
+        left = total - torch.sum(chosen, dim=1, keepdim=True)
+        if torch.all(left == 0):
+            break
+        chosen += p * left
+        chosen = torch.where(chosen >= cap, cap, chosen)
+        p = p * torch.where(chosen >= cap, 0, 1)
+    chosen = chosen.int()
+    fix = torch.argmax(cap - chosen, dim=1)
+    chosen[torch.arange(0, B), fix] += total - torch.sum(chosen, dim=1)
+    return chosen
+
+
+def selection_probabilities(score, member, sample_mode: str, boltzmann_T):
+    """Per-(cloud,bin) sampling weights (B*nb, N), rows ordered b*nb+t
+    (utils/ops.py:507-592).  `topk` has no probabilities; see selection_keys."""
+    B, _, N, nb = member.shape
+    if sample_mode == "uniform":
+        p = member.float().squeeze(dim=1)
+        p = p + (torch.sum(p, dim=1, keepdim=True) == 0)
+    elif sample_mode == "random":
+        t = torch.tanh(zscore(score))
+        if boltzmann_T == "mode_1":
+            inv_t = torch.sum(member, dim=2, keepdim=True).float() / 100.0
+        elif boltzmann_T == "mode_2":
+            inv_t = N / (100.0 * nb)
+        elif boltzmann_T == "mode_3":
+            inv_t = torch.sum(member, dim=2, keepdim=True).float() / 200.0
+        elif boltzmann_T == "mode_4":
+            inv_t = N / (200.0 * nb)
+        elif isinstance(boltzmann_T, numbers.Number):
+            inv_t = 1 / boltzmann_T
+        else:
+            raise NotImplementedError
+        p = torch.exp(t.unsqueeze(3) * inv_t) * member
+        p = p / torch.sum(p, dim=2, keepdim=True)
+        p = p.squeeze(dim=1)
+        p[torch.isnan(p)] = 1e-8
+    else:
+        raise ValueError("sample mode must be topk, uniform or random")
+    return p.permute(0, 2, 1).reshape(-1, N)
+
+
+def draw_noise(rows: int, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """The Exp(1) tensor torch.multinomial draws internally (same generator
+    consumption: one exponential_ over a (rows, n) fp32 tensor)."""
+    return torch.empty(rows, n, dtype=torch.float32).exponential_(1, generator=generator)
+
+
+def select_indices(score, member, counts, M: int, sample_mode: str, boltzmann_T, noise=None):
+    """utils/ops.py:467-619 -> idx (B,1,M) int64: bins in ascending order, inside a
+    bin by descending key.  For uniform/random the key is p/noise, which is what
+    torch.multinomial(p, M) without replacement evaluates (topk of p / Exp(1));
+    `noise` (B*nb, N) makes the draw an explicit input."""
+    B, _, N, nb = member.shape
+    if sample_mode == "topk":
+        keyed = (score + 1e-8).unsqueeze(3) * member
+        _, order = torch.sort(keyed, dim=2, descending=True)
+        order = order.squeeze(dim=1)  # (B,N,nb)
+        rows = [
+            torch.cat([order[b, : counts[b, t], t] for t in range(nb)]) for b in range(B)
+        ]
+        return torch.stack(rows).reshape(B, 1, M)
+    p = selection_probabilities(score, member, sample_mode, boltzmann_T)
+    if noise is None:
+        picked = torch.multinomial(p, M)
+    else:
+        _, picked = torch.topk(p / noise, M, dim=1)
+    picked = picked.reshape(B, nb, M)
+    rows = [torch.cat([picked[b, t, : counts[b, t]] for t in range(nb)]) for b in range(B)]
+    return torch.stack(rows).reshape(B, 1, M)
+
+
+def gather_attend(A, v, idx):
+    """Rows idx of the attention map times V^T -> x_ds (B,C,M)  (downsample.py:242-252)."""
+    rows = torch.gather(A, dim=2, index=idx.unsqueeze(3).expand(-1, -1, -1, A.shape[-1]))
+    out = (rows @ v.permute(0, 1, 3, 2)).permute(0, 2, 1, 3)
+    return out.reshape(out.shape[0], out.shape[1], -1).permute(0, 2, 1)
+
+
+# --------------------------------------------------------------------------- #
+# the layer
+# --------------------------------------------------------------------------- #
+@dataclass
+class SamplerState:
+    """Learnable tensors + the persistent boundary state of one layer."""
+
+    wq: torch.Tensor
+    wk: torch.Tensor
+    wv: torch.Tensor
+    tokens: torch.Tensor
+    boundaries: Optional[List[torch.Tensor]] = None
+    trace: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+
+def sampler_forward(spec: SamplerSpec, st: SamplerState, x: torch.Tensor,
+                    noise: Optional[torch.Tensor] = None,
+                    world_mean=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One DownSampleToken.forward (models/downsample.py:112-262), H=1, asm=dot.
+
+    `noise` is the (B*nb, N) Exp(1) draw (None: torch.multinomial draws it from the
+    global generator, exactly like the reference).  `world_mean` stands in for the
+    all_reduce/world_size of utils/ops.py:191-199: a callable applied to the raw
+    quantiles (None = single process).  Every intermediate lands in st.trace."""
+    if spec.asm != "dot":
+        raise NotImplementedError("oracle covers asm=dot (the shipped configs)")
+    B, C, N = x.shape
+    nb = spec.num_bins
+    q, k, v = project_qkv(x, st.tokens, st.wq, st.wk, st.wv)
+    A, A_pts, tok_logits = attention_map(q, k, N)
+    score, nn_idx, indeg = point_score(x, A_pts, spec.K, spec.idx_mode)
+
+    z = zscore(score)
+    if spec.dynamic_boundaries:
+        quant = batch_quantiles(z.reshape(B, 1, N, 1), nb)
+        if world_mean is not None:
+            quant = world_mean(quant)
+        st.boundaries = blend_boundaries(st.boundaries, quant, nb, spec.momentum)
+    else:
+        quant = None
+        if st.boundaries is None:
+            st.boundaries = static_boundary_state(spec.static_boundaries, nb)
+    member = bin_membership(z, st.boundaries)
+    w, w_pre = bin_weights(tok_logits, member, spec.relu_mean_order)
+    cap = torch.sum(member.squeeze(dim=1), dim=1)
+    counts = allocate_counts(w, cap, spec.M)
+    idx = select_indices(score, member, counts, spec.M, spec.sample_mode, spec.boltzmann_T, noise)
+    x_ds = gather_attend(A, v, idx)
+
+    st.trace = dict(
+        q=q, k=k, v=v, tok_logits=tok_logits, score=score, knn_idx=nn_idx, indeg=indeg,
+        z=z, quantiles=quant, upper=st.boundaries[0].clone(), lower=st.boundaries[1].clone(),
+        member=member, w=w, w_pre=w_pre, cap=cap, counts=counts, idx=idx, x_ds=x_ds,
+        lse=torch.logsumexp((q @ k) / math.sqrt(q.shape[-1]), dim=-1),
+    )
+    return x_ds, idx
+
+
+def sampler_grads(spec: SamplerSpec, st: SamplerState, x: torch.Tensor, g: torch.Tensor,
+                  noise: Optional[torch.Tensor] = None):
+    """Forward + autograd backward for an upstream gradient g (B,C,M).
+    Returns dict(dx, dwq, dwk, dwv, dtokens, x_ds, idx)."""
+    leaves = [t.detach().clone().requires_grad_(True) for t in (x, st.wq, st.wk, st.wv, st.tokens)]
+    st2 = SamplerState(leaves[1], leaves[2], leaves[3], leaves[4],
+                       None if st.boundaries is None else [b.clone() for b in st.boundaries])
+    x_ds, idx = sampler_forward(spec, st2, leaves[0], noise)
+    x_ds.backward(g)
+    return dict(dx=leaves[0].grad, dwq=leaves[1].grad, dwk=leaves[2].grad, dwv=leaves[3].grad,
+                dtokens=leaves[4].grad, x_ds=x_ds.detach(), idx=idx, boundaries=st2.boundaries,
+                trace=st2.trace)
