@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: point-clouds/sec of ONE DownSampleToken layer, forward + backward
+(+ SGD step), on the metric configuration of BASELINE.json / SURVEY.md section 8(d):
+ModelNet40-shaped synthetic input, B=32 clouds per GPU, C=128, N=2048 -> M=1024, 6 bin tokens,
+K=32 feature-space kNN, sparse_col_sqr score, dynamic boundaries, Boltzmann-random selection.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; batches shard over ranks (weak scaling, 32 clouds per rank); the only
+data-path collective is the reference's own all-reduce of the nb-1 boundary quantiles, plus DDP's
+gradient all-reduce (RCCL over xGMI).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+B_PER_GPU, C, N, M, NB, KNN = 32, 128, 2048, 1024, 6, 32
+
+
+def algorithmic_flops_per_cloud():
+    """proj 2C^2(3N+2nb), dist 2N^2C, qk 2N(N+nb)D, av 2M(N+nb)D forward;
+    backward 4*av + 2*proj.  Recomputation is not counted."""
+    proj = 2 * C * C * (3 * N + 2 * NB)
+    dist_ = 2 * N * N * C
+    qk = 2 * N * (N + NB) * C
+    av = 2 * M * (N + NB) * C
+    return dict(proj=proj, dist=dist_, qk=qk, av=av, fwd=proj + dist_ + qk + av, bwd=4 * av + 2 * proj)
+
+
+def time_region(fn, iters):
+    """Average milliseconds per call of fn(), HIP events on torch's current stream (the stream
+    every kernel of the path is enqueued on)."""
+    start = torch.cuda.Event(enable_timing=True)
+    stop = torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def kernel_breakdown(mod, x, noise, g, iters=5):
+    """Per-stage device time (ms) of one step, each stage timed alone with events."""
+    import math
+    from samble_amd import ops
+    with torch.no_grad():
+        B = x.shape[0]
+        nt = mod.bin_tokens.shape[2]
+        tokens = mod.bin_tokens.expand(B, -1, -1)
+        xt = torch.cat((x, tokens), dim=2)
+        w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight), 0).squeeze(-1)
+        qkv = torch.matmul(xt.transpose(1, 2), w.t())
+        q, k, v = qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+        out = {}
+        out["proj_qkv(torch)"] = time_region(lambda: torch.matmul(xt.transpose(1, 2), w.t()), iters)
+        out["knn"] = time_region(lambda: ops.stage_knn(x, x, KNN), iters)
+        nn_idx = ops.stage_knn(x, x, KNN)
+        out["attn_fwd"] = time_region(lambda: ops.stage_attn_fwd(q, k, v, N, nt), iters)
+        O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
+        out["sparse_score"] = time_region(lambda: ops.stage_sparse_score(q, k, lse, nn_idx, "sparse_col_sqr"), iters)
+        score, z, _ = ops.stage_sparse_score(q, k, lse, nn_idx, "sparse_col_sqr")
+        out["batch_quantiles"] = time_region(lambda: ops.stage_batch_quantiles(z, NB), iters)
+        up, lo = mod.bin_boundaries
+        out["bin_assign"] = time_region(lambda: ops.stage_bin_assign(z, tok, up, lo, False), iters)
+        member, cap, w_pre, wts = ops.stage_bin_assign(z, tok, up, lo, False)
+        out["alloc_counts"] = time_region(lambda: ops.stage_alloc_counts(wts, cap, M), iters)
+        counts = ops.stage_alloc_counts(wts, cap, M)
+        out["bin_select"] = time_region(
+            lambda: ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise), iters)
+        idx = ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise)
+        out["gather_rows"] = time_region(lambda: ops.stage_gather_rows(O, idx), iters)
+        dqkv = torch.empty_like(qkv)
+        out["attn_bwd"] = time_region(
+            lambda: ops.stage_attn_bwd(q, k, v, O, lse, idx, g, N, nt, dqkv[:, :N, :C], dqkv[:, :, C:2 * C],
+                                       dqkv[:, :, 2 * C:]), iters)
+    return out
+
+
+def cpu_baseline(seed):
+    """The CPU oracle (pure-torch restatement, bit-identical to the reference in the build
+    container) timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import torch_oracle as O
+    from samble_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    sample_b = 8
+    spec = O.SamplerSpec(M=M, K=KNN, C=C, num_bins=NB)
+    wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
+    st = O.SamplerState(*(torch.from_numpy(a) for a in (wq, wk, wv, tok)))
+    x = torch.from_numpy(synth.features(sample_b, C, N, seed + 1))
+    g = torch.from_numpy(synth.normal((sample_b, C, M), seed + 2))
+    noise = torch.from_numpy(synth.exp1((sample_b * NB, N), seed + 3))
+    O.sampler_grads(spec, st, x[:2], g[:2], noise[: 2 * NB])  # warm-up
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.sampler_grads(spec, st, x, g, noise)
+    dt = (time.perf_counter() - t0) / reps
+    return dict(value=round(sample_b / dt, 3), unit="clouds/s", cores=cores, kind="port",
+                sample=f"{reps} x fwd+bwd of {sample_b} clouds (N={N}->{M}), torch CPU oracle, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from samble_amd import sampler_config, synth
+    from samble_amd.downsample import DownSampleToken
+
+    seed = 1000 * 2
+    mod = DownSampleToken(sampler_config("cls"), 0)
+    wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(torch.from_numpy(wq))
+        mod.k_conv.weight.copy_(torch.from_numpy(wk))
+        mod.v_conv.weight.copy_(torch.from_numpy(wv))
+        mod.bin_tokens.copy_(torch.from_numpy(tok))
+    mod = mod.to(dev)
+    model = mod
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(mod, device_ids=[local])
+    opt = torch.optim.SGD(mod.parameters(), lr=1e-4)
+
+    # this rank's shard of the global batch (cloud ids rank*32 .. rank*32+31), resident in HBM
+    x = torch.from_numpy(synth.features(B_PER_GPU, C, N, seed + 1, first_cloud=rank * B_PER_GPU)).to(dev)
+    g = torch.from_numpy(synth.normal((B_PER_GPU, C, M), seed + 2 + rank)).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        xin = x.detach().requires_grad_(True)  # the layer sits mid-network: dL/dx is part of the work
+        (x_ds, idx), _ = model(xin)
+        x_ds.backward(g)
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        total_clouds = B_PER_GPU * world * args.steps
+        value = total_clouds / elapsed
+        fl = algorithmic_flops_per_cloud()
+        result = {
+            "metric": "point-clouds/sec (downsample fwd+bwd), ModelNet40 B=32 N=2048->1024",
+            "value": round(value, 2),
+            "unit": "clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (hash-generated N(0,1) features, random-init weights; no ModelNet40 files offline)",
+            "config": {"workload": "one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B=32/GPU C=128 N=2048->M=1024 "
+                                   "nb=6 K=32 sparse_col_sqr random T=0.1 dynamic boundaries",
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
+            "step_fraction_of_mfma_roofline": round(
+                (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        }
+        if not args.no_breakdown:
+            noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
+            br = kernel_breakdown(mod, x, noise, g)
+            result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
+            # dominant kernel group: flash attention forward (one launch)
+            alg = (fl["qk"] + fl["av"]) * B_PER_GPU
+            ach = alg / (br["attn_fwd"] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
+                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                  "algorithmic_flops_per_launch": alg}
+            bwd_alg = 4 * fl["av"] * B_PER_GPU
+            bach = bwd_alg / (br["attn_bwd"] * 1e-3) / 1e12
+            result["roofline_bwd"] = {"kernel": "bwd_prep+bwd_dq+bwd_dkdv+bwd_tokens", "bound": "mfma",
+                                      "achieved": round(bach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(bach / PEAK_FP32_MFMA_TFLOPS, 4)}
+            knn_alg = fl["dist"] * B_PER_GPU
+            kach = knn_alg / (br["knn"] * 1e-3) / 1e12
+            result["roofline_knn"] = {"kernel": "rownorm+gram_keys+select_rows", "bound": "mfma",
+                                      "achieved": round(kach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(kach / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(seed)
+            result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+/* samble.h - C ABI of libsamble_hip.so: the MI355X (gfx950) kernels behind SAMBLE's
+ * attention-score downsampling path.
+ *
+ * The reference (stevenczwu/SAMBLE) is pure Python on PyTorch: it has no native boundary, so
+ * each entry point below replaces a chain of ATen calls made by one reference function (cited
+ * per entry as file:line).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add and how models/downsample.py / utils/ops.py call sites map onto it.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless stated otherwise;
+ *   - nothing is allocated, freed or synchronised: inputs, outputs and workspace belong to the
+ *     caller, every kernel (and memset) is enqueued on `stream` (a hipStream_t, may be NULL);
+ *   - return 0 on success, a negative code otherwise (SAMBLE_E_*); the message of the last
+ *     failure on the calling thread is available from samble_last_error();
+ *   - re-entrant and thread-safe; the current HIP device is the caller's business;
+ *   - strides are in ELEMENTS; "bs" = batch stride, "rs" = row stride;
+ *   - fp32 everywhere, indices int32 (neighbour lists) or int64 (sampled indices, as the
+ *     reference's (B,1,M) int64 tensor).  Attention kernels require D == 128 in this round.
+ */
+#ifndef SAMBLE_H
+#define SAMBLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMBLE_OK 0
+#define SAMBLE_E_INVALID (-22)     /* bad argument / unsupported shape */
+#define SAMBLE_E_WORKSPACE (-12)   /* workspace too small */
+#define SAMBLE_E_HIP_BASE (-1000)  /* -1000 - hipError_t */
+
+/* score modes (reference models/downsample.py:315-340) */
+#define SAMBLE_SCORE_SPARSE_COL_SUM 0
+#define SAMBLE_SCORE_SPARSE_COL_AVG 1
+#define SAMBLE_SCORE_SPARSE_COL_SQR 2
+#define SAMBLE_SCORE_SPARSE_ROW_SUM 3
+#define SAMBLE_SCORE_SPARSE_ROW_STD 4
+/* sample modes (reference utils/ops.py:476, 507) */
+#define SAMBLE_SAMPLE_TOPK 0
+#define SAMBLE_SAMPLE_UNIFORM 1
+#define SAMBLE_SAMPLE_RANDOM 2
+/* Boltzmann temperature: fixed inverse temperature, or members_in_bin / divisor
+ * (reference utils/ops.py:524-548: mode_1 -> divisor 100, mode_3 -> divisor 200) */
+#define SAMBLE_TEMP_FIXED 0
+#define SAMBLE_TEMP_COUNT 1
+
+const char* samble_version(void);
+const char* samble_last_error(void);
+
+/* ---- utils/ops.py:17-44  knn(a, b, k) -------------------------------------------------------
+ * xq (B,C,Nq), xk (B,C,Nk) channel-major (the layout the reference's callers hold before
+ * their permute(0,2,1)).  idx_out (B,Nq,K) int32, nearest first, self included when xq == xk.
+ * dist_out (B,Nq,K) or NULL: POSITIVE distance of the reference-normalised points (centred on
+ * xq's mean, divided by the mean unbiased per-channel std), i.e. -1 * the reference's first
+ * return value.  K in {1,3,8,16,20,32,40,64}. */
+size_t samble_knn_workspace_bytes(int B, int Nq, int Nk, int K);
+int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C, int K,
+                   int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
+ * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
+ * the N point rows).  O (B,N,D) contiguous: row i = softmax(Q_i K^T / sqrt(D)) V, the row the
+ * reference gathers if i is sampled; lse (B,N) log-sum-exp of the scaled logits over all N+nt
+ * columns; tok (B,N,nt) = attention_bins_beforesoftmax. */
+int samble_attn_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                        const float* V, int64_t v_bs, int64_t v_rs, int B, int N, int nt, int D, float* O, float* lse,
+                        float* tok, void* stream);
+
+/* ---- models/downsample.py:300-344  calculate_attention_score (sparse_* modes) ----------------
+ * nn (B,N,KN) int32 = neighbour lists from samble_knn_f32 on the layer input.  score (B,N),
+ * z (B,N) = per-cloud z-score of the score (utils/ops.py:450-452), indeg_out (B,N) int32 or NULL
+ * = kNN in-degree (sparse_num without its 1e-8). */
+size_t samble_score_workspace_bytes(int B, int N);
+int samble_sparse_score_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                            const float* lse, const int32_t* nn, int B, int N, int KN, int D, int mode, float* score,
+                            float* z, int32_t* indeg_out, void* ws, size_t ws_bytes, void* stream);
+
+/* z-score alone (utils/ops.py:450-452 / 517-520) */
+int samble_zscore_f32(const float* score, int B, int N, float* z, void* stream);
+
+/* ---- utils/ops.py:180-189  the nb-1 batch quantiles of all B*N z-scores ----------------------
+ * out (nb-1) floats, descending.  The caller then averages over ranks (ops.py:191-199) and
+ * blends with momentum (ops.py:201-233): five floats, host-side. */
+int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* stream);
+
+/* ---- utils/ops.py:454-463 + models/downsample.py:264-284  bin membership and bin weights ------
+ * upper/lower (nb) = the two (1,1,1,nb) boundary tensors.  tok (B,N,nt), nt == nb or 1.
+ * member (B,N) uint8 bit t = point in bin t; cap (B,nb) int32; w_pre (B,nb) = weights before
+ * relu; w (B,nb).  relu_first = 1 for relu_mean_order == "relu_mean". */
+int samble_bin_assign_f32(const float* z, const float* tok, int nt, const float* upper, const float* lower, int B,
+                          int N, int nb, int relu_first, uint8_t* member, int32_t* cap, float* w_pre, float* w,
+                          void* stream);
+
+/* ---- utils/ops.py:385-432  calculate_num_points_to_choose ------------------------------------ */
+int samble_alloc_counts_f32(const float* w, const int32_t* cap, int B, int nb, int M, int32_t* counts, void* stream);
+
+/* ---- utils/ops.py:467-619  generating_downsampled_index --------------------------------------
+ * noise (B*nb, N) = the Exp(1) draw torch.multinomial makes internally (row b*nb+t); NULL for
+ * topk.  temp: inverse temperature (TEMP_FIXED) or divisor (TEMP_COUNT).  idx_out (B,M) int64. */
+int samble_bin_select_f32(const float* score, const float* z, const uint8_t* member, const int32_t* counts,
+                          const float* noise, int B, int N, int nb, int M, int sample_mode, int temp_mode, float temp,
+                          int64_t* idx_out, void* stream);
+
+/* ---- models/downsample.py:242-252  gather of the sampled rows -> x_ds (B,D,M) ---------------- */
+int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int64_t* idx, int B, int M, int D,
+                           float* x_ds, void* stream);
+
+/* ---- utils/ops.py:136-145  gather_by_idx(pcd (B,C,N), idx (B,1,M)) -> (B,C,M) ---------------- */
+int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_t* idx, int M, float* out,
+                             void* stream);
+
+/* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
+ * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows
+ * 0..N+nt-1, each with its own strides. */
+size_t samble_attn_bwd_workspace_bytes(int B, int M, int D);
+int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                        const float* V, int64_t v_bs, int64_t v_rs, const float* O, const float* lse,
+                        const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,
+                        int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
+                        int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMBLE_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of libsamble_hip.so (include/samble.h).
+
+There is no CPU or eager fallback: if the library is missing or a call fails, a
+`SambleError` is raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+(or `make -C samble_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsamble_hip.so")
+
+
+class SambleError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "samble_version": (c_char_p, []),
+    "samble_last_error": (c_char_p, []),
+    "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_score_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "samble_sparse_score_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    "samble_zscore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "samble_batch_quantiles_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "samble_bin_assign_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_alloc_counts_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "samble_bin_select_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_float, c_void_p, c_void_p]),
+    "samble_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "samble_gather_points_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "samble_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "samble_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                    c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once; raise SambleError (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SambleError(
+            f"{LIB_PATH} not found: the HIP kernels are not built. Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` or `make -C samble_amd/csrc`. "
+            "samble_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point and turn a failure into SambleError."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.samble_last_error().decode(errors="replace")
+        raise SambleError(f"{name} failed with code {rc}: {msg}")
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))

@@ -1,0 +1,205 @@
+// extern "C" boundary of libsamble_hip.so (include/samble.h): argument checks, workspace carving,
+// error reporting.  Never throws, allocates, frees or synchronises.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "../../include/samble.h"
+
+#define SAMBLE_API extern "C" __attribute__((visibility("default")))
+
+// kernel launchers (one per .hip file)
+extern "C" {
+size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K);
+int samble_launch_knn(const float*, long, int, const float*, long, int, int, int, int, int*, float*, float*, hipStream_t);
+int samble_launch_attn_fwd(const float*, long, long, const float*, long, long, const float*, long, long, int, int, int,
+                           float, float*, float*, float*, int, hipStream_t);
+size_t samble_score_ws_bytes(int B, int N);
+int samble_launch_sparse_score(const float*, long, long, const float*, long, long, const float*, const int*, int, int,
+                               int, float, int, float*, float*, int*, void*, hipStream_t);
+int samble_launch_zscore(const float*, int, int, float*, hipStream_t);
+int samble_launch_batch_quantiles(const float*, long, int, float*, hipStream_t);
+int samble_launch_bin_assign(const float*, const float*, int, const float*, const float*, int, int, int, int,
+                             unsigned char*, int*, float*, float*, hipStream_t);
+int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hipStream_t);
+int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, int, int, int,
+                             int, int, int, float, long long*, hipStream_t);
+int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
+int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
+int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
+                           const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
+                           float*, float*, float*, long, long, float*, long, long, float*, long, long, hipStream_t);
+}
+
+namespace {
+thread_local char g_err[256] = "";
+
+__global__ void zero_rows_kernel(float* p, long bs, long rs, int N, int quads_per_row, long total) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = (int)(e % quads_per_row);
+  const long row = e / quads_per_row;
+  const long b = row / N, n = row % N;
+  float4 z = {0.f, 0.f, 0.f, 0.f};
+  *reinterpret_cast<float4*>(p + b * bs + n * rs + 4 * c4) = z;
+}
+
+int fail(int code, const char* what) {
+  snprintf(g_err, sizeof(g_err), "%s", what);
+  return code;
+}
+int done(int hip_code, const char* where) {
+  if (hip_code == 0) return SAMBLE_OK;
+  snprintf(g_err, sizeof(g_err), "%s: HIP error %d (%s)", where, hip_code, hipGetErrorString((hipError_t)hip_code));
+  return hip_code < 0 ? hip_code : SAMBLE_E_HIP_BASE - hip_code;
+}
+float inv_sqrt_d(int D) { return (float)(1.0 / sqrt((double)D)); }
+}  // namespace
+
+SAMBLE_API const char* samble_version(void) { return "samble-hip 0.1 (gfx950)"; }
+SAMBLE_API const char* samble_last_error(void) { return g_err; }
+
+SAMBLE_API size_t samble_knn_workspace_bytes(int B, int Nq, int Nk, int K) {
+  return samble_knn_ws_floats(B, Nq, Nk, K) * sizeof(float);
+}
+
+SAMBLE_API int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C,
+                              int K, int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream) {
+  if (!xq || !xk || !idx_out || !ws) return fail(SAMBLE_E_INVALID, "samble_knn_f32: null pointer");
+  if (B <= 0 || C <= 0 || Nq <= 0 || Nk <= 0 || K <= 0 || K > Nk)
+    return fail(SAMBLE_E_INVALID, "samble_knn_f32: need B,C,Nq,Nk > 0 and 0 < K <= Nk");
+  if (ws_bytes < samble_knn_workspace_bytes(B, Nq, Nk, K))
+    return fail(SAMBLE_E_WORKSPACE, "samble_knn_f32: workspace too small (samble_knn_workspace_bytes)");
+  int rc = samble_launch_knn(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, idx_out, dist_out, (float*)ws, (hipStream_t)stream);
+  if (rc == -22) return fail(SAMBLE_E_INVALID, "samble_knn_f32: K must be one of 1,3,8,16,20,32,40,64");
+  return done(rc, "samble_knn_f32");
+}
+
+SAMBLE_API int samble_attn_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                   int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, int B, int N, int nt, int D,
+                                   float* O, float* lse, float* tok, void* stream) {
+  if (!Q || !K || !V || !O || !lse) return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: D must be 128");
+  if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (nt > 0 && !tok))
+    return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: bad B/N/nt");
+  if ((q_rs & 3) || (k_rs & 3) || (v_rs & 3) || (q_bs & 3) || (k_bs & 3) || (v_bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: strides must be multiples of 4 elements (16-byte rows)");
+  return done(samble_launch_attn_fwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, B, N, N + nt, inv_sqrt_d(D), O, lse,
+                                     tok, nt, (hipStream_t)stream),
+              "samble_attn_fwd_f32");
+}
+
+SAMBLE_API size_t samble_score_workspace_bytes(int B, int N) { return samble_score_ws_bytes(B, N); }
+
+SAMBLE_API int samble_sparse_score_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                       int64_t k_rs, const float* lse, const int32_t* nn, int B, int N, int KN, int D,
+                                       int mode, float* score, float* z, int32_t* indeg_out, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!Q || !K || !lse || !nn || !score || !z || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: D must be 128");
+  if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: unknown score mode");
+  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: N too large for LDS");
+  if (ws_bytes < samble_score_ws_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_f32: workspace too small");
+  return done(samble_launch_sparse_score(Q, q_bs, q_rs, K, k_bs, k_rs, lse, nn, B, N, KN, inv_sqrt_d(D), mode, score, z,
+                                         indeg_out, ws, (hipStream_t)stream),
+              "samble_sparse_score_f32");
+}
+
+SAMBLE_API int samble_zscore_f32(const float* score, int B, int N, float* z, void* stream) {
+  if (!score || !z || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_zscore_f32: bad argument");
+  return done(samble_launch_zscore(score, B, N, z, (hipStream_t)stream), "samble_zscore_f32");
+}
+
+SAMBLE_API int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* stream) {
+  if (!z || !out || n <= 0) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: bad argument");
+  if (nb < 2 || nb > 8) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: need 2 <= num_bins <= 8");
+  if (n >= (1ll << 31)) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: n must be < 2^31");
+  return done(samble_launch_batch_quantiles(z, n, nb, out, (hipStream_t)stream), "samble_batch_quantiles_f32");
+}
+
+SAMBLE_API int samble_bin_assign_f32(const float* z, const float* tok, int nt, const float* upper, const float* lower,
+                                     int B, int N, int nb, int relu_first, uint8_t* member, int32_t* cap, float* w_pre,
+                                     float* w, void* stream) {
+  if (!z || !tok || !upper || !lower || !member || !cap || !w_pre || !w)
+    return fail(SAMBLE_E_INVALID, "samble_bin_assign_f32: null pointer");
+  if (nb < 1 || nb > 8 || (nt != 1 && nt != nb))
+    return fail(SAMBLE_E_INVALID, "samble_bin_assign_f32: need 1 <= num_bins <= 8 and nt in {1, num_bins}");
+  return done(samble_launch_bin_assign(z, tok, nt, upper, lower, B, N, nb, relu_first, member, cap, w_pre, w,
+                                       (hipStream_t)stream),
+              "samble_bin_assign_f32");
+}
+
+SAMBLE_API int samble_alloc_counts_f32(const float* w, const int32_t* cap, int B, int nb, int M, int32_t* counts,
+                                       void* stream) {
+  if (!w || !cap || !counts) return fail(SAMBLE_E_INVALID, "samble_alloc_counts_f32: null pointer");
+  if (B < 1 || B > 1024 || nb < 1 || nb > 8 || M < 0)
+    return fail(SAMBLE_E_INVALID, "samble_alloc_counts_f32: need 1 <= B <= 1024, 1 <= num_bins <= 8");
+  return done(samble_launch_alloc_counts(w, cap, B, nb, M, counts, (hipStream_t)stream), "samble_alloc_counts_f32");
+}
+
+SAMBLE_API int samble_bin_select_f32(const float* score, const float* z, const uint8_t* member, const int32_t* counts,
+                                     const float* noise, int B, int N, int nb, int M, int sample_mode, int temp_mode,
+                                     float temp, int64_t* idx_out, void* stream) {
+  if (!score || !z || !member || !counts || !idx_out)
+    return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: null pointer");
+  if (sample_mode < 0 || sample_mode > SAMBLE_SAMPLE_RANDOM)
+    return fail(SAMBLE_E_INVALID, "Please check the setting of bin sample mode. It must be topk, uniform or random!");
+  if (sample_mode != SAMBLE_SAMPLE_TOPK && !noise)
+    return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: uniform/random need the Exp(1) noise tensor");
+  if (nb < 1 || nb > 8 || N > 16384) return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: need num_bins <= 8, N <= 16384");
+  return done(samble_launch_bin_select(score, z, member, counts, noise, B, N, nb, M, sample_mode, temp_mode, temp,
+                                       (long long*)idx_out, (hipStream_t)stream),
+              "samble_bin_select_f32");
+}
+
+SAMBLE_API int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int64_t* idx, int B, int M, int D,
+                                      float* x_ds, void* stream) {
+  if (!O || !idx || !x_ds) return fail(SAMBLE_E_INVALID, "samble_gather_rows_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_gather_rows_f32: D must be 128");
+  return done(samble_launch_gather_rows(O, o_bs, o_rs, (const long long*)idx, B, M, x_ds, (hipStream_t)stream),
+              "samble_gather_rows_f32");
+}
+
+SAMBLE_API int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_t* idx, int M, float* out,
+                                        void* stream) {
+  if (!pcd || !idx || !out) return fail(SAMBLE_E_INVALID, "samble_gather_points_f32: null pointer");
+  return done(samble_launch_gather_points(pcd, B, C, N, (const long long*)idx, M, out, (hipStream_t)stream),
+              "samble_gather_points_f32");
+}
+
+SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int M, int D) {
+  return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + 64) * sizeof(float);
+}
+
+SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                   int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* O,
+                                   const float* lse, const int64_t* idx, const float* g, int B, int N, int nt, int M,
+                                   int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
+                                   int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!Q || !K || !V || !O || !lse || !idx || !g || !dQ || !dK || !dV || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: D must be 128");
+  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, M, D))
+    return fail(SAMBLE_E_WORKSPACE, "samble_attn_bwd_f32: workspace too small");
+  if ((dq_rs & 3) || (dk_rs & 3) || (dv_rs & 3) || (q_rs & 3) || (k_rs & 3) || (v_rs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: row strides must be multiples of 4 elements");
+  hipStream_t s = (hipStream_t)stream;
+  // rows of dQ that were not sampled carry no gradient: one strided zero-fill launch
+  {
+    const long quads = (long)B * N * (D / 4);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, dQ, (long)dq_bs,
+                       (long)dq_rs, N, D / 4, quads);
+  }
+  float* Qs = (float*)ws;
+  float* dOb = Qs + (size_t)B * M * D;
+  float* lse_s = dOb + (size_t)B * M * D;
+  float* delta = lse_s + (size_t)B * M;
+  return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, lse, (const long long*)idx, g, B, N,
+                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs,
+                                     dV, dv_bs, dv_rs, s),
+              "samble_attn_bwd_f32");
+}

@@ -1,0 +1,344 @@
+// Flash-style attention backward for the SAMBLE sampler.  Autograd of the reference
+// (models/downsample.py:139-147 + 242-252) reduces exactly to an M-query cross-attention over the
+// N point keys + nt token keys (SURVEY.md section 3 iii): only the M sampled rows of the attention
+// map receive gradient.  With S = scale * Q K^T, P = exp(S - lse), dP = dO V^T,
+// delta_i = sum_d dO_id O_id, dS = P o (dP - delta):
+//     dQ_i = scale * sum_j dS_ij K_j      dK_j = scale * sum_i dS_ij Q_i      dV_j = sum_i P_ij dO_i
+//
+// Four kernels, all deterministic (no float atomics):
+//   bwd_prep        gather the sampled Q rows / lse, transpose the upstream gradient (B,D,M)->(B,M,D),
+//                   delta = rowsum(dO o O_sampled)
+//   bwd_dq          query-stationary: one wave = 32 sampled rows, K/V stream through LDS; recomputes
+//                   S and dP per tile (2x64 MFMA) and accumulates dQ^T (64 MFMA); scatters rows to dQ
+//   bwd_dkdv        key-stationary over the N POINT keys: one wave = 32 keys with K,V rows and the
+//                   dK^T/dV^T accumulators in registers; sampled Q / dO tiles stream through LDS
+//                   (S, dP, dV^T, dK^T = 4x64 MFMA per tile)
+//   bwd_tokens      the nt (<= 8) token keys: tiny VALU kernel (keeps the MFMA grids a whole number
+//                   of rounds: N/32 key waves per cloud instead of N/32 + 1)
+#include "samble_dev.h"
+
+namespace samble {
+
+// ------------------------------------------------------------------------------------------------
+// prep: one workgroup = 32 sampled rows of one cloud
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                       const float* __restrict__ O, const float* __restrict__ lse,
+                                                       const long long* __restrict__ idx,
+                                                       const float* __restrict__ g,  // (B,128,M)
+                                                       int N, int M, float* __restrict__ Qs, float* __restrict__ dO,
+                                                       float* __restrict__ lse_s, float* __restrict__ delta) {
+  __shared__ float gt[128 * 33];
+  const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
+  const float* gb = g + (long)b * 128 * M;
+  for (int e = tid; e < 128 * 32; e += 256) {
+    int d = e >> 5, mm = e & 31;
+    gt[d * 33 + mm] = (m0 + mm < M) ? gb[(long)d * M + m0 + mm] : 0.f;
+  }
+  __syncthreads();
+  const int sub = tid >> 5, l32 = tid & 31;  // 8 half-waves, each one row at a time
+  for (int rr = sub; rr < 32; rr += 8) {
+    const int m = m0 + rr;
+    if (m >= M) continue;  // uniform per half-wave
+    const long row = idx[(long)b * M + m];
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + row * q_rs + 4 * l32);
+    const f32x4 ov = *reinterpret_cast<const f32x4*>(O + ((long)b * N + row) * 128 + 4 * l32);
+    f32x4 dv = {gt[(4 * l32 + 0) * 33 + rr], gt[(4 * l32 + 1) * 33 + rr], gt[(4 * l32 + 2) * 33 + rr],
+                gt[(4 * l32 + 3) * 33 + rr]};
+    *reinterpret_cast<f32x4*>(Qs + ((long)b * M + m) * 128 + 4 * l32) = qv;
+    *reinterpret_cast<f32x4*>(dO + ((long)b * M + m) * 128 + 4 * l32) = dv;
+    float part = dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (l32 == 0) {
+      delta[(long)b * M + m] = part;
+      lse_s[(long)b * M + m] = lse[(long)b * N + row];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: query-stationary
+// ------------------------------------------------------------------------------------------------
+constexpr int kDqLdsFloats = 2 * (2 * kTile * kLdsPad);
+
+__global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
+                                                        const float* __restrict__ lse_s,
+                                                        const float* __restrict__ delta,
+                                                        const float* __restrict__ K, long k_bs, long k_rs,
+                                                        const float* __restrict__ V, long v_bs, long v_rs,
+                                                        const long long* __restrict__ idx, int N, int NK, int M,
+                                                        float scale, float* __restrict__ dQ, long dq_bs, long dq_rs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = 2 * kTile * kLdsPad;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int m = blockIdx.x * 128 + wave * 32 + lo;
+  const bool mvalid = m < M;
+  const float* Kb = K + (long)b * k_bs;
+  const float* Vb = V + (long)b * v_bs;
+
+  float q[64], go[64];
+  float my_lse = 0.f, my_delta = 0.f;
+  if (mvalid) {
+    load_row_half(Qs + ((long)b * M + m) * 128, h, q);
+    load_row_half(dO + ((long)b * M + m) * 128, h, go);
+    my_lse = lse_s[(long)b * M + m];
+    my_delta = delta[(long)b * M + m];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      q[i] = 0.f;
+      go[i] = 0.f;
+    }
+  }
+  f32x16 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = zero16();
+
+  const int ntiles = (NK + kTile - 1) / kTile;
+  TileRegs kr, vr;
+  tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
+  tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
+  tile_store_lds(kr, smem, kLdsPad, tid);
+  tile_store_lds(vr, smem + kTile * kLdsPad, kLdsPad, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    float* Kc = smem + (t & 1) * kBuf;
+    float* Vc = Kc + kTile * kLdsPad;
+    float* Kn = smem + ((t & 1) ^ 1) * kBuf;
+    float* Vn = Kn + kTile * kLdsPad;
+    const int j0 = t * kTile;
+    if (t + 1 < ntiles) {
+      tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
+      tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
+    }
+    f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());    // S^T  (keys x queries)
+    f32x16 dp = mma_rows_x_regs(Vc, kLdsPad, lo, h, go, zero16());  // dP^T
+    const bool tail = (j0 + kTile > NK);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = __expf(s[r] * scale - my_lse);
+      if (tail && (j0 + crow(r, h) >= NK)) p = 0.f;
+      s[r] = p * (dp[r] - my_delta) * scale;  // dS^T, scale of S folded in
+    }
+    mma_tileT_x_acc(Kc, kLdsPad, lo, h, s, dq);  // dQ^T[d][i] += sum_j K[j][d] dS[i][j]
+    if (t + 1 < ntiles) {
+      tile_store_lds(kr, Kn, kLdsPad, tid);
+      tile_store_lds(vr, Vn, kLdsPad, tid);
+    }
+    __syncthreads();
+  }
+  if (mvalid) {
+    const long row = idx[(long)b * M + m];
+    float* orow = dQ + (long)b * dq_bs + row * dq_rs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 o = {dq[dt][4 * gq], dq[dt][4 * gq + 1], dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV for the N point keys: key-stationary
+// ------------------------------------------------------------------------------------------------
+constexpr int kDkvLdsFloats = 2 * (2 * kTile * kLdsPad + 2 * kTile);
+
+__global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
+                                                          const float* __restrict__ lse_s,
+                                                          const float* __restrict__ delta,
+                                                          const float* __restrict__ K, long k_bs, long k_rs,
+                                                          const float* __restrict__ V, long v_bs, long v_rs, int N,
+                                                          int M, float scale, float* __restrict__ dK, long dk_bs,
+                                                          long dk_rs, float* __restrict__ dV, long dv_bs,
+                                                          long dv_rs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = 2 * kTile * kLdsPad + 2 * kTile;  // Q tile, dO tile, lse[32], delta[32]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 128 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  const float* Qb = Qs + (long)b * M * 128;
+  const float* Gb = dO + (long)b * M * 128;
+
+  float kreg[64], vreg[64];
+  if (jvalid) {
+    load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, kreg);
+    load_row_half(V + (long)b * v_bs + (long)j * v_rs, h, vreg);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      kreg[i] = 0.f;
+      vreg[i] = 0.f;
+    }
+  }
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    dk[dt] = zero16();
+    dv[dt] = zero16();
+  }
+
+  const int ntiles = (M + kTile - 1) / kTile;
+  TileRegs qr, gr;
+  float st = 0.f;  // threads 0..31 stage lse, 32..63 stage delta of the next query tile
+  auto issue = [&](int i0) {
+    tile_load_issue(qr, Qb, 128, i0, M, tid);
+    tile_load_issue(gr, Gb, 128, i0, M, tid);
+    if (tid < 64) {
+      const int ii = i0 + (tid & 31);
+      const float* src = (tid < 32) ? lse_s : delta;
+      st = (ii < M) ? src[(long)b * M + ii] : 0.f;
+    }
+  };
+  auto commit = [&](float* buf) {
+    tile_store_lds(qr, buf, kLdsPad, tid);
+    tile_store_lds(gr, buf + kTile * kLdsPad, kLdsPad, tid);
+    if (tid < 64) buf[2 * kTile * kLdsPad + tid] = st;
+  };
+  issue(0);
+  commit(smem);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    float* cur = smem + (t & 1) * kBuf;
+    float* nxt = smem + ((t & 1) ^ 1) * kBuf;
+    const float* Qt = cur;
+    const float* Gt = cur + kTile * kLdsPad;
+    const float* Lt = cur + 2 * kTile * kLdsPad;
+    const float* Dt = Lt + kTile;
+    const int i0 = t * kTile;
+    if (t + 1 < ntiles) issue(i0 + kTile);
+
+    f32x16 s = mma_rows_x_regs(Qt, kLdsPad, lo, h, kreg, zero16());   // S  (queries x keys)
+    f32x16 dp = mma_rows_x_regs(Gt, kLdsPad, lo, h, vreg, zero16());  // dP
+    f32x16 ds;
+    const bool tail = (i0 + kTile > M);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ir = crow(r, h);
+      float p = __expf(s[r] * scale - Lt[ir]);
+      if (tail && (i0 + ir >= M)) p = 0.f;
+      s[r] = p;
+      ds[r] = p * (dp[r] - Dt[ir]) * scale;
+    }
+    mma_tileT_x_acc(Gt, kLdsPad, lo, h, s, dv);   // dV^T[d][j] += sum_i dO[i][d] P[i][j]
+    mma_tileT_x_acc(Qt, kLdsPad, lo, h, ds, dk);  // dK^T[d][j] += sum_i Q[i][d] dS[i][j]
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  if (jvalid) {
+    float* krow = dK + (long)b * dk_bs + (long)j * dk_rs;
+    float* vrow = dV + (long)b * dv_bs + (long)j * dv_rs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 a = {dk[dt][4 * gq], dk[dt][4 * gq + 1], dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]};
+        f32x4 c = {dv[dt][4 * gq], dv[dt][4 * gq + 1], dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]};
+        *reinterpret_cast<f32x4*>(krow + 32 * dt + 8 * gq + 4 * h) = a;
+        *reinterpret_cast<f32x4*>(vrow + 32 * dt + 8 * gq + 4 * h) = c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token keys: one workgroup (256 threads) per (cloud, token)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_tokens_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
+                                                         const float* __restrict__ lse_s,
+                                                         const float* __restrict__ delta,
+                                                         const float* __restrict__ K, long k_bs, long k_rs,
+                                                         const float* __restrict__ V, long v_bs, long v_rs, int N,
+                                                         int M, float scale, float* __restrict__ dK, long dk_bs,
+                                                         long dk_rs, float* __restrict__ dV, long dv_bs,
+                                                         long dv_rs) {
+  __shared__ float kt[128], vt[128], pbuf[256], dsbuf[256];
+  __shared__ float red[2][2][128];
+  const int b = blockIdx.y, tok = blockIdx.x, tid = threadIdx.x;
+  const long jrow = (long)N + tok;
+  if (tid < 128) {
+    kt[tid] = K[(long)b * k_bs + jrow * k_rs + tid];
+    vt[tid] = V[(long)b * v_bs + jrow * v_rs + tid];
+  }
+  __syncthreads();
+  // thread (d = tid & 127, half = tid >> 7) accumulates over the rows of its half of each chunk
+  const int d = tid & 127, half = tid >> 7;
+  float acc_k = 0.f, acc_v = 0.f;
+  for (int i0 = 0; i0 < M; i0 += 256) {
+    const int i = i0 + tid;
+    float p = 0.f, ds = 0.f;
+    if (i < M) {
+      const f32x4* qp = reinterpret_cast<const f32x4*>(Qs + ((long)b * M + i) * 128);
+      const f32x4* gp = reinterpret_cast<const f32x4*>(dO + ((long)b * M + i) * 128);
+      float s = 0.f, dp = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < 32; ++c) {
+        f32x4 qv = qp[c], gv = gp[c];
+        s += qv[0] * kt[4 * c] + qv[1] * kt[4 * c + 1] + qv[2] * kt[4 * c + 2] + qv[3] * kt[4 * c + 3];
+        dp += gv[0] * vt[4 * c] + gv[1] * vt[4 * c + 1] + gv[2] * vt[4 * c + 2] + gv[3] * vt[4 * c + 3];
+      }
+      p = __expf(s * scale - lse_s[(long)b * M + i]);
+      ds = p * (dp - delta[(long)b * M + i]) * scale;
+    }
+    pbuf[tid] = p;
+    dsbuf[tid] = ds;
+    __syncthreads();
+    const int lim = min(256, M - i0);
+    for (int r = half * 128; r < min(lim, half * 128 + 128); ++r) {
+      const long ro = ((long)b * M + i0 + r) * 128 + d;
+      acc_v += pbuf[r] * dO[ro];
+      acc_k += dsbuf[r] * Qs[ro];
+    }
+    __syncthreads();
+  }
+  red[half][0][d] = acc_k;
+  red[half][1][d] = acc_v;
+  __syncthreads();
+  if (tid < 128) {
+    dK[(long)b * dk_bs + jrow * dk_rs + tid] = red[0][0][tid] + red[1][0][tid];
+    dV[(long)b * dv_bs + jrow * dv_rs + tid] = red[0][1][tid] + red[1][1][tid];
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
+                                      const float* V, long v_bs, long v_rs, const float* O, const float* lse,
+                                      const long long* idx, const float* g, int B, int N, int nt, int M, float scale,
+                                      float* Qs, float* dOb, float* lse_s, float* delta, float* dQ, long dq_bs,
+                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
+                                      hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int NK = N + nt;
+  hipLaunchKernelGGL(bwd_prep_kernel, dim3((M + 31) / 32, B), dim3(256), 0, stream, Q, q_bs, q_rs, O, lse, idx, g, N, M,
+                     Qs, dOb, lse_s, delta);
+  hipLaunchKernelGGL(bwd_dq_kernel, dim3((M + 127) / 128, B), dim3(256), lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs,
+                     k_rs, V, v_bs, v_rs, idx, N, NK, M, scale, dQ, dq_bs, dq_rs);
+  hipLaunchKernelGGL(bwd_dkdv_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K,
+                     k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
+  if (nt > 0)
+    hipLaunchKernelGGL(bwd_tokens_kernel, dim3(nt, B), dim3(256), 0, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs, V,
+                       v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
+  return (int)hipGetLastError();
+}

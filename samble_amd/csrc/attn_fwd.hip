@@ -1,0 +1,143 @@
+// Flash-style attention forward for the SAMBLE sampler (reference models/downsample.py:139-153,
+// 242-252): for every one of the N query points, softmax over the N point keys AND the nt bin-token
+// keys of (Q K^T / sqrt(D)), times V.  The (B,1,N,N+nt) map of the reference is never materialised;
+// per row the kernel keeps the running max / sum-exp and writes
+//     O   (B,N,D)   = softmax(S) V          (row i is what the reference gathers for a sampled i)
+//     lse (B,N)     = log sum_j exp(S_ij)   (lets later kernels rebuild any A_ij = exp(S_ij - lse_i))
+//     tok (B,N,nt)  = S[:, N:N+nt]          (attention_bins_beforesoftmax, downsample.py:149-152)
+//
+// Mapping: one workgroup = 4 waves = 128 query rows, one wave = 32 rows.  Keys/values stream through
+// LDS in 32-row tiles shared by the 4 waves (double buffered, loads for tile t+1 issued before the
+// MFMAs of tile t).  Per tile and wave: S^T = K_tile Q^T (64 MFMA, queries on the lane axis so the
+// row statistics are lane-local), softmax in registers, O^T += V_tile^T P^T (64 MFMA) with the S
+// accumulator registers fed back directly as MFMA B operands.  Bound: fp32 MFMA (157 TFLOP/s).
+#include "samble_dev.h"
+
+namespace samble {
+
+constexpr int kFwdLdsFloats = 2 * (kTile * kLdsPad + kTile * 128);
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+    const float* __restrict__ Q, long q_bs, long q_rs, const float* __restrict__ K, long k_bs, long k_rs,
+    const float* __restrict__ V, long v_bs, long v_rs, int N, int NK, float scale, float* __restrict__ O,
+    float* __restrict__ lse, float* __restrict__ tok, int nt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = kTile * kLdsPad + kTile * 128;  // one K tile + one V tile
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + lo;
+  const bool qvalid = qrow < N;
+
+  const float* Kb = K + (long)b * k_bs;
+  const float* Vb = V + (long)b * v_bs;
+
+  float q[64];
+  if (qvalid) {
+    load_row_half(Q + (long)b * q_bs + (long)qrow * q_rs, h, q);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) q[i] = 0.f;
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+  float m = kNegInf, l = 0.f;
+
+  const int ntiles = (NK + kTile - 1) / kTile;
+  TileRegs kr, vr;
+  tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
+  tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
+  tile_store_lds(kr, smem, kLdsPad, tid);
+  tile_store_lds(vr, smem + kTile * kLdsPad, 128, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    float* Kc = smem + (t & 1) * kBuf;
+    float* Vc = Kc + kTile * kLdsPad;
+    float* Kn = smem + ((t & 1) ^ 1) * kBuf;
+    float* Vn = Kn + kTile * kLdsPad;
+    const int j0 = t * kTile;
+    if (t + 1 < ntiles) {
+      tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
+      tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
+    }
+    // S^T tile: rows = keys of this tile, cols = this wave's 32 queries
+    f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());
+
+    const bool tail = (j0 + kTile > N);  // tile holds token keys and/or padding (wave-uniform)
+    float mt = kNegInf;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = s[r] * scale;
+      if (tail) {
+        const int j = j0 + crow(r, h);
+        if (j >= NK) v = kNegInf;
+        if (j >= N && j < NK && qvalid) tok[((long)b * N + qrow) * nt + (j - N)] = v;
+      }
+      s[r] = v;
+      mt = fmaxf(mt, v);
+    }
+    mt = fmaxf(mt, wave_xor32(mt));
+    const float mnew = fmaxf(m, mt);
+    const float alpha = __expf(m - mnew);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = __expf(s[r] - mnew);
+      s[r] = p;
+      ps += p;
+    }
+    l = l * alpha + ps;
+    m = mnew;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+    // O^T += V_tile^T P^T : the P registers are the B operands
+    mma_tileT_x_acc(Vc, 128, lo, h, s, oacc);
+
+    if (t + 1 < ntiles) {
+      tile_store_lds(kr, Kn, kLdsPad, tid);
+      tile_store_lds(vr, Vn, 128, tid);
+    }
+    __syncthreads();
+  }
+
+  const float ltot = l + wave_xor32(l);
+  const float inv = 1.f / ltot;
+  if (qvalid) {
+    float* orow = O + ((long)b * N + qrow) * 128;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv,
+                   oacc[dt][4 * g + 3] * inv};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g + 4 * h) = o;
+      }
+    }
+    if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
+                                      const float* V, long v_bs, long v_rs, int B, int N, int NK, float scale, float* O,
+                                      float* lse, float* tok, int nt, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds = kFwdLdsFloats * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((N + 127) / 128, B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK,
+                     scale, O, lse, tok, nt);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,302 @@
+// Pairwise distance + k-nearest-neighbour build (reference utils/ops.py:17-44).
+//
+// The reference centres both sets on the query set's mean, divides by one positive scalar per
+// cloud and takes topk of -cdist.  Centring and an isotropic positive scale do not change the
+// ranking, so neighbours are ranked on  key(i,j) = |b_j|^2 - 2 <a_i, b_j>  (= d^2 - |a_i|^2) of the
+// raw channel-major inputs; the reference-normalised distance is rebuilt only for the K winners.
+//
+//   rownorm       |x_n|^2 per point (also per-cloud channel sums for the reference's scale)
+//   gram_keys     key matrix, fp32 MFMA: workgroup = 128 keys x 128 queries, wave = 64 x 64,
+//                 channels staged through LDS 32 at a time straight from the (B,C,N) layout
+//                 (rows of 128 consecutive points = 512 contiguous bytes).  Written key-major so
+//                 the select kernel reads it coalesced.
+//   select_rows   one lane per query streams its column of keys: candidates below the lane's
+//                 current K-th best go to a per-lane LDS queue; when a lane's queue fills the wave
+//                 drains queues into per-lane sorted K-lists held in registers.
+// Bound: gram_keys fp32 MFMA; select_rows VALU.  (Round-1 structure: the key matrix round-trips
+// through HBM; DESIGN.md lists fusing the select into the MFMA tile loop as the next step.)
+#include "samble_dev.h"
+
+namespace samble {
+
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, long bs, int C, int N,
+                                                      float* __restrict__ norms) {
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* p = x + (long)b * bs + n;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float v = p[(long)c * N];
+    acc = fmaf(v, v, acc);
+  }
+  norms[(long)b * N + n] = acc;
+}
+
+// keyT[b][j][i] = bnorm[j] - 2 * sum_c xk[b][c][j] * xq[b][c][i]
+__global__ __launch_bounds__(256, 2) void gram_keys_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                           const float* __restrict__ xk, long k_bs, int Nk, int C,
+                                                           const float* __restrict__ knorm,
+                                                           float* __restrict__ keyT) {
+  __shared__ __attribute__((aligned(16))) float As[32 * 128];  // [channel][key]
+  __shared__ __attribute__((aligned(16))) float Bs[32 * 128];  // [channel][query]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.z;
+  const int j0 = blockIdx.y * 128, i0 = blockIdx.x * 128;
+  const int wj = (wave >> 1) * 64, wi = (wave & 1) * 64;
+  const float* xkb = xk + (long)b * k_bs;
+  const float* xqb = xq + (long)b * q_bs;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = zero16();
+
+  const bool k_vec = ((Nk & 3) == 0) && (j0 + 128 <= Nk);
+  const bool q_vec = ((Nq & 3) == 0) && (i0 + 128 <= Nq);
+  for (int c0 = 0; c0 < C; c0 += 32) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 256 * it;  // float4 slot: 32 channels x 32 float4
+      const int c = e >> 5, p4 = (e & 31) * 4;
+      f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + c < C) {
+        const float* ar = xkb + (long)(c0 + c) * Nk + j0 + p4;
+        const float* br = xqb + (long)(c0 + c) * Nq + i0 + p4;
+        if (k_vec) {
+          av = *reinterpret_cast<const f32x4*>(ar);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (j0 + p4 + u < Nk) av[u] = ar[u];
+        }
+        if (q_vec) {
+          bv = *reinterpret_cast<const f32x4*>(br);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (i0 + p4 + u < Nq) bv[u] = br[u];
+        }
+      }
+      *reinterpret_cast<f32x4*>(&As[c * 128 + p4]) = av;
+      *reinterpret_cast<f32x4*>(&Bs[c * 128 + p4]) = bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int c = 2 * kk + h;
+      const float a0 = As[c * 128 + wj + lo], a1 = As[c * 128 + wj + 32 + lo];
+      const float b0 = Bs[c * 128 + wi + lo], b1 = Bs[c * 128 + wi + 32 + lo];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  float* out = keyT + (long)b * Nk * Nq;
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + wj + 32 * jt + crow(r, h);
+      if (j >= Nk) continue;
+      const float bn = knorm[(long)b * Nk + j];
+#pragma unroll
+      for (int itq = 0; itq < 2; ++itq) {
+        const int i = i0 + wi + 32 * itq + lo;
+        if (i < Nq) out[(long)j * Nq + i] = fmaf(-2.f, acc[jt][itq][r], bn);
+      }
+    }
+  }
+}
+
+// Exact (a-b)^2 keys for tiny channel counts (xyz: C = 3): no cancellation, no MFMA.
+__global__ __launch_bounds__(256) void smallc_keys_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                          const float* __restrict__ xk, long k_bs, int Nk, int C,
+                                                          float* __restrict__ keyT) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i >= Nq) return;
+  float acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = xq[(long)b * q_bs + (long)c * Nq + i] - xk[(long)b * k_bs + (long)c * Nk + j];
+    acc = fmaf(d, d, acc);
+  }
+  keyT[((long)b * Nk + j) * Nq + i] = acc;
+}
+
+constexpr int kQueue = 16;
+
+template <int KN>
+__device__ __forceinline__ void sorted_insert(float (&bk)[KN], int (&bi)[KN], float v, int j) {
+#pragma unroll
+  for (int s = KN - 1; s > 0; --s) {
+    const bool shift = v < bk[s - 1];
+    const bool here = (!shift) && (v < bk[s]);
+    bk[s] = shift ? bk[s - 1] : (here ? v : bk[s]);
+    bi[s] = shift ? bi[s - 1] : (here ? j : bi[s]);
+  }
+  if (v < bk[0]) {
+    bk[0] = v;
+    bi[0] = j;
+  }
+}
+
+// One lane per query.  idx_out (B,Nq,KN) nearest first; key_out optional (B,Nq,KN) raw keys.
+template <int KN>
+__global__ __launch_bounds__(256) void select_rows_kernel(const float* __restrict__ keyT, int Nq, int Nk,
+                                                          int* __restrict__ idx_out, float* __restrict__ key_out) {
+  __shared__ float qk[kQueue * 256];
+  __shared__ int qi[kQueue * 256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + tid;
+  const bool valid = i < Nq;
+  const float* col = keyT + (long)b * Nk * Nq + (valid ? i : 0);
+
+  float bk[KN];
+  int bi[KN];
+#pragma unroll
+  for (int s = 0; s < KN; ++s) {
+    bk[s] = __builtin_huge_valf();
+    bi[s] = 0;
+  }
+  int cnt = 0;
+  auto drain = [&]() {
+    for (int s = 0; s < kQueue; ++s) {
+      if (!__any(s < cnt)) break;
+      const float v = (s < cnt) ? qk[s * 256 + tid] : __builtin_huge_valf();
+      const int j = qi[s * 256 + tid];
+      sorted_insert<KN>(bk, bi, v, j);
+    }
+    cnt = 0;
+  };
+  for (int j = 0; j < Nk; ++j) {
+    const float v = valid ? col[(long)j * Nq] : __builtin_huge_valf();
+    if (v < bk[KN - 1]) {
+      qk[cnt * 256 + tid] = v;
+      qi[cnt * 256 + tid] = j;
+      ++cnt;
+    }
+    if (__any(cnt == kQueue)) drain();
+  }
+  drain();
+  if (valid) {
+    int* io = idx_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+    for (int s = 0; s < KN; ++s) io[s] = bi[s];
+    if (key_out) {
+      float* ko = key_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+      for (int s = 0; s < KN; ++s) ko[s] = bk[s];
+    }
+  }
+}
+
+// Per-cloud scale of the reference (utils/ops.py:27): mean over channels of the unbiased std over
+// points of the query set.  One workgroup per cloud; double accumulation, fixed order.
+__global__ __launch_bounds__(256) void knn_scale_kernel(const float* __restrict__ x, long bs, int C, int N,
+                                                        float* __restrict__ scale_out) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double total = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const float* p = x + (long)b * bs + (long)c * N;
+    double s = 0.0, ss = 0.0;
+    for (int n = tid; n < N; n += 256) {
+      const double v = p[n];
+      s += v;
+      ss += v * v;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const double sum = red[0];
+    __syncthreads();
+    red[tid] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const double sumsq = red[0];
+    __syncthreads();
+    const double mean = sum / N;
+    double var = (sumsq - N * mean * mean) / (N - 1);
+    if (var < 0) var = 0;
+    total += sqrt(var);
+  }
+  if (tid == 0) scale_out[b] = (float)(total / C);
+}
+
+// dist_out[b][i][s] = sqrt(max(key + |a_i|^2, 0)) / scale_b   (positive, reference-normalised)
+__global__ void knn_dist_kernel(const float* __restrict__ keys, const float* __restrict__ qnorm,
+                                const float* __restrict__ scale, int Nq, int KN, int add_norm,
+                                float* __restrict__ dist) {
+  const int b = blockIdx.y;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)Nq * KN) return;
+  const int i = (int)(e / KN);
+  float d2 = keys[(long)b * Nq * KN + e] + (add_norm ? qnorm[(long)b * Nq + i] : 0.f);
+  d2 = fmaxf(d2, 0.f);
+  dist[(long)b * Nq * KN + e] = sqrtf(d2) / scale[b];
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+template <int KN>
+static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, float* keys, hipStream_t s) {
+  hipLaunchKernelGGL(select_rows_kernel<KN>, dim3((Nq + 255) / 256, B), dim3(256), 0, s, keyT, Nq, Nk, idx, keys);
+}
+
+// workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
+extern "C" size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K) {
+  return (size_t)B * Nk * Nq + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
+}
+
+extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
+                                 int K, int* idx_out, float* dist_out, float* ws, hipStream_t stream) {
+  float* keyT = ws;
+  float* knorm = keyT + (size_t)B * Nk * Nq;
+  float* qnorm = knorm + (size_t)B * Nk;
+  float* scale = qnorm + (size_t)B * Nq;
+  float* keys = scale + B;
+  const bool smallc = C <= 8;
+  if (smallc) {
+    hipLaunchKernelGGL(smallc_keys_kernel, dim3((Nq + 255) / 256, Nk, B), dim3(256), 0, stream, xq, q_bs, Nq, xk, k_bs,
+                       Nk, C, keyT);
+  } else {
+    hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
+    hipLaunchKernelGGL(gram_keys_kernel, dim3((Nq + 127) / 128, (Nk + 127) / 128, B), dim3(256), 0, stream, xq, q_bs,
+                       Nq, xk, k_bs, Nk, C, knorm, keyT);
+  }
+  float* kout = dist_out ? keys : nullptr;
+  switch (K) {
+    case 1: launch_select<1>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 3: launch_select<3>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 8: launch_select<8>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 16: launch_select<16>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 20: launch_select<20>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 32: launch_select<32>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 40: launch_select<40>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    case 64: launch_select<64>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+    default: return -22;
+  }
+  if (dist_out) {
+    if (!smallc) hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
+    hipLaunchKernelGGL(knn_scale_kernel, dim3(B), dim3(256), 0, stream, xq, q_bs, C, Nq, scale);
+    const long tot = (long)Nq * K;
+    hipLaunchKernelGGL(knn_dist_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, stream, keys, qnorm, scale,
+                       Nq, K, smallc ? 0 : 1, dist_out);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,136 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the SAMBLE sampler path.
+//
+// All matrix work uses v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate, exact fp32):
+//   A operand: lane l holds A[row = l & 31][k = l >> 5]
+//   B operand: lane l holds B[k = l >> 5][col = l & 31]
+//   C/D:       lane l, register r (0..15) holds D[row = crow(r, l >> 5)][col = l & 31],
+//              crow(r, h) = (r & 3) + 8 * (r >> 2) + 4 * h
+// Two idioms used everywhere (validated against a lane-level emulation before being written):
+//   * k-permutation: MFMA step kk (0..63) of a 128-deep contraction consumes channel
+//     kperm(kk, h) = 64 * h + kk in lane half h, for BOTH operands, so a lane's operand
+//     registers are 64 consecutive floats of its row (16-byte global loads).
+//   * accumulator-as-operand: with the reduced index on the accumulator's ROW (register)
+//     axis, register t of a 32x32 tile is directly the B operand of step t of the next
+//     product (its k pair is rows crow(t,0), crow(t,1)); the other operand is read from LDS
+//     at those rows.  No transpose, no LDS round trip for P / dS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace samble {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kTile = 32;           // MFMA tile edge
+constexpr int kLdsPad = 129;        // row stride (floats) of a [row][128] LDS tile read by rows
+constexpr float kNegInf = -__builtin_huge_valf();
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// Load this lane's 64 operand floats of row `row_ptr` (128 contiguous floats): channels
+// 64*h .. 64*h+63, as sixteen 16-byte loads.
+__device__ __forceinline__ void load_row_half(const float* __restrict__ row_ptr, int h, float (&dst)[64]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(row_ptr + 64 * h);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    f32x4 v = p[i];
+    dst[4 * i + 0] = v[0];
+    dst[4 * i + 1] = v[1];
+    dst[4 * i + 2] = v[2];
+    dst[4 * i + 3] = v[3];
+  }
+}
+
+// Cooperative copy of a [32][128] fp32 tile (rows `row0..row0+31` of a point-major matrix
+// with `row_stride` floats per row) into LDS with row stride `lds_stride`.  256 threads,
+// 16-byte global loads (a row is 512 contiguous bytes), scalar LDS stores (the odd stride
+// that makes row-wise ds_read_b32 conflict-free rules out wider stores).  Rows >= n_rows
+// are filled with zeros.  Split in two so the global loads can be issued a phase early.
+struct TileRegs {
+  f32x4 v[4];
+};
+
+__device__ __forceinline__ void tile_load_issue(TileRegs& t, const float* __restrict__ base, long row_stride,
+                                                int row0, int n_rows, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int e = tid + 256 * i;        // float4 index in the tile: 32 rows x 32 float4
+    int r = e >> 5, c4 = e & 31;
+    int row = row0 + r;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    t.v[i] = (row < n_rows) ? *reinterpret_cast<const f32x4*>(base + (long)row * row_stride + 4 * c4) : z;
+  }
+}
+
+__device__ __forceinline__ void tile_store_lds(const TileRegs& t, float* __restrict__ lds, int lds_stride, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int e = tid + 256 * i;
+    int r = e >> 5, c4 = e & 31;
+    float* d = lds + r * lds_stride + 4 * c4;
+    d[0] = t.v[i][0];
+    d[1] = t.v[i][1];
+    d[2] = t.v[i][2];
+    d[3] = t.v[i][3];
+  }
+}
+
+// acc(32x32) += Ltile(rows from LDS, read row-wise) x Rreg(64 register-resident floats)^T
+//   D[row][col] += sum_c L[row][c] * R[col][c]; lane (x, h) supplies L[x][kperm] and R[x][kperm].
+__device__ __forceinline__ f32x16 mma_rows_x_regs(const float* __restrict__ lds_tile, int lds_stride, int lane_lo,
+                                                  int h, const float (&reg)[64], f32x16 acc) {
+  const float* lp = lds_tile + lane_lo * lds_stride + 64 * h;
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) acc = mfma32(lp[kk], reg[kk], acc);
+  return acc;
+}
+
+// Same contraction with the register operand on the A side (rows) and LDS on the B side.
+__device__ __forceinline__ f32x16 mma_regs_x_rows(const float (&reg)[64], const float* __restrict__ lds_tile,
+                                                  int lds_stride, int lane_lo, int h, f32x16 acc) {
+  const float* lp = lds_tile + lane_lo * lds_stride + 64 * h;
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) acc = mfma32(reg[kk], lp[kk], acc);
+  return acc;
+}
+
+// out[dt](32 x 32) += T(:, 32dt..)^T x P  with P = a 32x32 accumulator whose ROW axis is the
+// reduced index:  out[dt][d][col] += sum_row T[row][32dt + d] * P[row][col].
+// T is an LDS [32][stride] tile; lane (d, h) reads T[crow(t,h)][32dt + d].
+__device__ __forceinline__ void mma_tileT_x_acc(const float* __restrict__ lds_tile, int lds_stride, int lane_lo, int h,
+                                                const f32x16& p, f32x16 (&out)[4]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const float* row = lds_tile + crow(t, h) * lds_stride + lane_lo;
+    float b = p[t];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(row[32 * dt], b, out[dt]);
+  }
+}
+
+__device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+// order-preserving float -> uint32 (larger float -> larger uint); NaN sorts above +inf
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+}  // namespace samble

@@ -1,0 +1,205 @@
+// Per-point sampling score from the kNN-sparsified attention map
+// (reference models/downsample.py:300-344) and the per-cloud z-score (utils/ops.py:450-452).
+//
+// The reference builds two dense (B,N,N) tensors (mask, A*mask) and reduces them.  Only K entries
+// per row are non-zero, so here each (row i, neighbour j) pair recomputes
+//     A_ij = exp(scale * <Q_i, K_j> - lse_i)
+// from the forward's log-sum-exp and the column sums are accumulated EXACTLY: A_ij in [0,1] is
+// converted to 44-bit fixed point and added with integer atomics (LDS first, then one coalesced
+// flush per workgroup), so the result does not depend on arrival order and the final conversion
+// back to fp32 is the single rounding of the exact sum.  The kNN in-degree (sparse_num,
+// downsample.py:311) is counted in the same pass.
+#include "samble_dev.h"
+#pragma clang fp contract(off)
+
+namespace samble {
+
+constexpr float kFix = 17592186044416.f;      // 2^44
+constexpr float kUnfix = 1.f / 17592186044416.f;
+
+enum ScoreMode { kColSum = 0, kColAvg = 1, kColSqr = 2, kRowSum = 3, kRowStd = 4 };
+
+// grid (ceil(N/64), B), 256 threads: 8 half-waves, each walks rows r0+hw, r0+hw+8, ...
+__global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                           const float* __restrict__ K, long k_bs, long k_rs,
+                                                           const float* __restrict__ lse,
+                                                           const int* __restrict__ nn, int N, int KN, float scale,
+                                                           unsigned long long* __restrict__ colacc,
+                                                           int* __restrict__ indeg, float* __restrict__ rowstat,
+                                                           int row_mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(sraw);
+  int* cnt = reinterpret_cast<int*>(acc + N);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int n = tid; n < N; n += 256) {
+    acc[n] = 0ull;
+    cnt[n] = 0;
+  }
+  __syncthreads();
+  const int hw = tid >> 5, c = tid & 31;
+  const int r0 = blockIdx.x * 64;
+  const float* Qb = Q + (long)b * q_bs;
+  const float* Kb = K + (long)b * k_bs;
+  for (int i = r0 + hw; i < min(r0 + 64, N); i += 8) {
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(Qb + (long)i * q_rs + 4 * c);
+    const float li = lse[(long)b * N + i];
+    const int* ni = nn + ((long)b * N + i) * KN;
+    float rs = 0.f, rss = 0.f;
+    for (int k0 = 0; k0 < KN; k0 += 4) {
+      int j[4];
+      f32x4 kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        j[u] = (k0 + u < KN) ? ni[k0 + u] : ni[0];
+        kv[u] = *reinterpret_cast<const f32x4*>(Kb + (long)j[u] * k_rs + 4 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float s = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (k0 + u < KN) {
+          const float a = __expf(s * scale - li);
+          rs += a;
+          rss += a * a;
+          if (c == 0) {
+            atomicAdd(&acc[j[u]], (unsigned long long)__float2ll_rn(a * kFix));
+            atomicAdd(&cnt[j[u]], 1);
+          }
+        }
+      }
+    }
+    if (rowstat && c == 0) {
+      float v = rs;
+      if (row_mode == kRowStd) {  // unbiased std over the K picked entries (torch.std default)
+        const float mean = rs / KN;
+        v = sqrtf(fmaxf((rss - KN * mean * mean) / (KN - 1), 0.f));
+      }
+      rowstat[(long)b * N + i] = v;
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    const int cn = cnt[n];
+    if (cn) {
+      atomicAdd(&colacc[(long)b * N + n], acc[n]);
+      atomicAdd(&indeg[(long)b * N + n], cn);
+    }
+  }
+}
+
+// One workgroup per cloud: score from the exact column sums, NaN -> 0, then z-score with the
+// reference's operation order  z = (s - mean) / std  (population std), mean and std each the
+// correctly rounded fp32 of a double-precision two-pass reduction in a fixed tree order.
+__global__ __launch_bounds__(256) void finalize_score_kernel(const unsigned long long* __restrict__ colacc,
+                                                             const int* __restrict__ indeg,
+                                                             const float* __restrict__ rowstat, int N, int mode,
+                                                             float* __restrict__ score, float* __restrict__ z) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double part = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    float s;
+    if (mode >= kRowSum) {
+      s = rowstat[(long)b * N + n];
+    } else {
+      const float sum = __ll2float_rn((long long)colacc[(long)b * N + n]) * kUnfix;
+      const float num = (float)indeg[(long)b * N + n] + 1e-8f;
+      s = sum;
+      if (mode == kColAvg) s = sum / num;
+      if (mode == kColSqr) s = sum / num / num;
+    }
+    if (s != s) s = 0.f;
+    score[(long)b * N + n] = s;
+    part += (double)s;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double mean_d = red[0] / N;
+  __syncthreads();
+  part = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const double d = (double)score[(long)b * N + n] - mean_d;
+    part += d * d;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float mean_f = (float)mean_d;
+  const float std_f = (float)sqrt(red[0] / N);
+  for (int n = tid; n < N; n += 256) z[(long)b * N + n] = (score[(long)b * N + n] - mean_f) / std_f;
+}
+
+// z-score only (a caller that already has the score, e.g. a stage-wise parity test)
+__global__ __launch_bounds__(256) void zscore_kernel(const float* __restrict__ score, int N, float* __restrict__ z) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double part = 0.0;
+  for (int n = tid; n < N; n += 256) part += (double)score[(long)b * N + n];
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double mean_d = red[0] / N;
+  __syncthreads();
+  part = 0.0;
+  for (int n = tid; n < N; n += 256) {
+    const double d = (double)score[(long)b * N + n] - mean_d;
+    part += d * d;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float mean_f = (float)mean_d;
+  const float std_f = (float)sqrt(red[0] / N);
+  for (int n = tid; n < N; n += 256) z[(long)b * N + n] = (score[(long)b * N + n] - mean_f) / std_f;
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+// ws: [colacc B*N u64][indeg B*N i32][rowstat B*N f32]
+extern "C" size_t samble_score_ws_bytes(int B, int N) { return (size_t)B * N * 16 + 64; }
+
+extern "C" int samble_launch_sparse_score(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
+                                          const float* lse, const int* nn, int B, int N, int KN, float scale, int mode,
+                                          float* score, float* z, int* indeg_out, void* ws, hipStream_t stream) {
+  if (mode < 0 || mode > kRowStd) return -22;
+  unsigned long long* colacc = reinterpret_cast<unsigned long long*>(ws);
+  int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
+  float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = (size_t)N * 12;
+  if (lds > 64 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(sparse_score_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
+                     lse, nn, N, KN, scale, colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
+  hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
+  if (indeg_out) {
+    e = hipMemcpyAsync(indeg_out, indeg, (size_t)B * N * sizeof(int), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_zscore(const float* score, int B, int N, float* z, hipStream_t stream) {
+  hipLaunchKernelGGL(zscore_kernel, dim3(B), dim3(256), 0, stream, score, N, z);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,433 @@
+// Score-bin partition, per-bin count allocation and the top-k / Boltzmann-random / uniform
+// selection that produces the sampled index set (reference utils/ops.py:174-236, 385-619;
+// models/downsample.py:264-284), plus the row gather that emits x_ds (downsample.py:242-252).
+//
+//   batch_quantiles   nb-1 order statistics of ALL B*N z-scores (the reference sorts the whole
+//                     batch, ops.py:185-189): 4-pass 8-bit radix select, all ranks at once.
+//   bin_assign        per cloud: membership bits (lower[t] <= z < upper[t]), per-bin counts,
+//                     masked mean of the token logits -> bin weights.
+//   alloc_counts      the reference's float water-filling, same operation order and the same
+//                     WHOLE-BATCH early exit (ops.py:403-430), one workgroup for the batch,
+//                     no host sync.
+//   bin_select        per (cloud, bin): selection key per member, bitonic sort of 64-bit
+//                     (descending key, ascending index) composites in LDS, first k emitted.
+//   gather_rows       x_ds[b,:,m] = O[b, idx[b,m], :]  (LDS transpose to the (B,C,M) layout).
+// All integer outputs are exact functions of the fp32 inputs; every reduction has a fixed order.
+#include "samble_dev.h"
+#pragma clang fp contract(off)
+
+namespace samble {
+
+// ------------------------------------------------------------------------------------------------
+// batch quantiles
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxBins = 8;
+
+// inclusive scan of one value per thread over the 1024-thread block (buf: 1024 words of LDS)
+__device__ __forceinline__ unsigned int block_scan_incl(unsigned int v, unsigned int* buf, int tid) {
+  buf[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned int a = (tid >= o) ? buf[tid - o] : 0u;
+    __syncthreads();
+    buf[tid] += a;
+    __syncthreads();
+  }
+  return buf[tid];
+}
+
+// Radix select, digits of 12 / 10 / 10 bits from the top of the order-preserving key (the wide first
+// digit spreads z-scores, whose sign+exponent bits are nearly constant, over many LDS counters).
+// Histograms are indexed by the REVERSED digit so that ascending bin order = descending value.
+__global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __restrict__ z, long n, int nb,
+                                                               float* __restrict__ out) {
+  __shared__ unsigned int hist[(kMaxBins - 1) * 1024];
+  __shared__ unsigned int scanbuf[1024];
+  __shared__ unsigned int prefix[kMaxBins];
+  __shared__ unsigned int rem[kMaxBins];
+  const int tid = threadIdx.x;
+  const int nq = nb - 1;
+  if (tid < nq) {
+    // rank into the DESCENDING order: fp32 arithmetic then truncation (utils/ops.py:182-183)
+    const float frac = (float)(tid + 1) / (float)nb;
+    rem[tid] = (unsigned int)(int)(frac * (float)n);
+    prefix[tid] = 0u;
+  }
+  // ---- pass 0: top 12 bits, one histogram shared by every rank
+  for (int e = tid; e < 4096; e += 1024) hist[e] = 0u;
+  __syncthreads();
+  for (long e = tid; e < n; e += 1024) atomicAdd(&hist[4095u - (ordered_bits(z[e]) >> 20)], 1u);
+  __syncthreads();
+  {
+    unsigned int loc[4], ts = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      loc[u] = hist[4 * tid + u];
+      ts += loc[u];
+    }
+    const unsigned int excl = block_scan_incl(ts, scanbuf, tid) - ts;
+    for (int t = 0; t < nq; ++t) {
+      const unsigned int r = rem[t];
+      unsigned int c = excl;
+      int found = -1;
+      unsigned int newrem = 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (found < 0 && c <= r && r < c + loc[u]) {
+          found = 4 * tid + u;
+          newrem = r - c;
+        }
+        c += loc[u];
+      }
+      __syncthreads();
+      if (found >= 0) {
+        prefix[t] = (4095u - (unsigned int)found) << 20;
+        rem[t] = newrem;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- passes 1, 2: 10 bits each, one 1024-bin histogram per rank
+  for (int pass = 1; pass <= 2; ++pass) {
+    const int shift = (pass == 1) ? 10 : 0;
+    for (int e = tid; e < nq * 1024; e += 1024) hist[e] = 0u;
+    __syncthreads();
+    for (long e = tid; e < n; e += 1024) {
+      const unsigned int key = ordered_bits(z[e]);
+      const unsigned int hi = key >> (shift + 10);
+      const unsigned int dig = 1023u - ((key >> shift) & 1023u);
+      for (int t = 0; t < nq; ++t)
+        if (hi == (prefix[t] >> (shift + 10))) atomicAdd(&hist[t * 1024 + dig], 1u);
+    }
+    __syncthreads();
+    for (int t = 0; t < nq; ++t) {
+      const unsigned int mine = hist[t * 1024 + tid];
+      const unsigned int incl = block_scan_incl(mine, scanbuf, tid);
+      const unsigned int r = rem[t];
+      const bool hit = (incl - mine) <= r && r < incl;
+      __syncthreads();
+      if (hit) {
+        prefix[t] |= (1023u - (unsigned int)tid) << shift;
+        rem[t] = r - (incl - mine);
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < nq) out[tid] = from_ordered_bits(prefix[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bin membership + weights: one workgroup per cloud
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bin_assign_kernel(const float* __restrict__ z, const float* __restrict__ tok,
+                                                         int nt, const float* __restrict__ upper,
+                                                         const float* __restrict__ lower, int N, int nb,
+                                                         int relu_first, unsigned char* __restrict__ member,
+                                                         int* __restrict__ cap, float* __restrict__ w_pre,
+                                                         float* __restrict__ w) {
+  __shared__ double rsum[kMaxBins][256];
+  __shared__ int rcnt[kMaxBins][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float up[kMaxBins], lo[kMaxBins];
+  double ps[kMaxBins];
+  int pc[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    up[t] = (t < nb) ? upper[t] : 0.f;
+    lo[t] = (t < nb) ? lower[t] : 0.f;
+    ps[t] = 0.0;
+    pc[t] = 0;
+  }
+  for (int n = tid; n < N; n += 256) {
+    const float zv = z[(long)b * N + n];
+    unsigned int bits = 0;
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      if (t < nb && zv < up[t] && zv >= lo[t]) {
+        bits |= 1u << t;
+        float lg = tok[((long)b * N + n) * nt + (nt == 1 ? 0 : t)];
+        if (relu_first) lg = fmaxf(lg, 0.f);
+        ps[t] += (double)lg;
+        pc[t] += 1;
+      }
+    }
+    member[(long)b * N + n] = (unsigned char)bits;
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    rsum[t][tid] = ps[t];
+    rcnt[t][tid] = pc[t];
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int t = 0; t < kMaxBins; ++t) {
+        rsum[t][tid] += rsum[t][tid + o];
+        rcnt[t][tid] += rcnt[t][tid + o];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nb) {
+    const int c = rcnt[tid][0];
+    const float pre = (float)rsum[tid][0] / ((float)c + 1e-8f);
+    cap[b * nb + tid] = c;
+    w_pre[b * nb + tid] = pre;
+    w[b * nb + tid] = relu_first ? pre : fmaxf(pre, 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// count allocation: ONE workgroup, thread b = cloud b (B <= 1024)
+// ------------------------------------------------------------------------------------------------
+// Sum of n <= 8 floats in the order ATen's scalar reduction path uses for a short contiguous row
+// (4 interleaved partial sums, tail onto partial 0, partials folded left to right).
+__device__ __forceinline__ float short_row_sum(const float (&a)[kMaxBins], int n) {
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  const int q = n >> 2;
+  for (int i = 0; i < q; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[k] = __fadd_rn(part[k], a[4 * i + k]);
+  for (int i = 4 * q; i < n; ++i) part[0] = __fadd_rn(part[0], a[i]);
+  float s = part[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) s = __fadd_rn(s, part[k]);
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void alloc_counts_kernel(const float* __restrict__ w, const int* __restrict__ cap,
+                                                            int B, int nb, int M, int* __restrict__ counts) {
+  const int b = threadIdx.x;
+  const bool live = b < B;
+  float p[kMaxBins], chosen[kMaxBins], capf[kMaxBins];
+  int capi[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    capi[t] = (live && t < nb) ? cap[b * nb + t] : 0;
+    capf[t] = (float)capi[t];
+    const float wt = (live && t < nb) ? w[b * nb + t] : 0.f;
+    p[t] = __fadd_rn(__fmul_rn(wt, capf[t]), 1e-10f);
+    chosen[t] = 0.f;
+  }
+  for (int round = 0; round < nb; ++round) {
+    const float s = short_row_sum(p, nb);
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) p[t] = __fdiv_rn(p[t], s);
+    const float left = __fsub_rn((float)M, short_row_sum(chosen, nb));
+    const int done = (!live) || (left == 0.f);
+    if (__syncthreads_and(done)) break;  // whole-batch early exit (utils/ops.py:409)
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      float c = __fadd_rn(chosen[t], __fmul_rn(p[t], left));
+      const bool sat = c >= capf[t];
+      chosen[t] = sat ? capf[t] : c;
+      p[t] = __fmul_rn(p[t], sat ? 0.f : 1.f);
+    }
+  }
+  if (!live) return;
+  int k[kMaxBins];
+  int total = 0, best = 0;
+  long bestv = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    k[t] = (t < nb) ? (int)chosen[t] : 0;
+    total += k[t];
+  }
+  for (int t = 0; t < nb; ++t) {
+    const long room = (long)capi[t] - k[t];
+    if (t == 0 || room > bestv) {
+      bestv = room;
+      best = t;
+    }
+  }
+  for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-(cloud, bin) selection
+// ------------------------------------------------------------------------------------------------
+enum SampleMode { kTopk = 0, kUniform = 1, kRandom = 2 };
+enum TempMode { kTempFixed = 0, kTempCount = 1 };  // count: inv_T = members / temp_div
+
+// dynamic LDS: NP composites (u64) ; grid (nb, B), 1024 threads
+__global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restrict__ score, const float* __restrict__ z,
+                                                          const unsigned char* __restrict__ member,
+                                                          const int* __restrict__ counts,
+                                                          const float* __restrict__ noise, int N, int NP, int nb,
+                                                          int M, int mode, int temp_mode, float temp,
+                                                          long long* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long comp[];
+  __shared__ double red[1024];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const unsigned int bit = 1u << t;
+  const unsigned char* mb = member + (long)b * N;
+
+  // Boltzmann normaliser: sum over members of exp(tanh(z) * inv_T), fixed-order double tree
+  float inv_t = temp;
+  float psum = 1.f;
+  int members = 0;
+  if (mode == kRandom || mode == kUniform) {
+    double part = 0.0;
+    int pc = 0;
+    if (temp_mode == kTempCount) {
+      for (int n = tid; n < N; n += 1024) pc += (mb[n] & bit) ? 1 : 0;
+      red[tid] = (double)pc;
+      __syncthreads();
+      for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+      }
+      members = (int)red[0];
+      __syncthreads();
+      inv_t = (float)members / temp;
+    }
+    if (mode == kRandom) {
+      for (int n = tid; n < N; n += 1024)
+        if (mb[n] & bit) part += (double)expf(tanhf(z[(long)b * N + n]) * inv_t);
+      red[tid] = part;
+      __syncthreads();
+      for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+      }
+      psum = (float)red[0];
+      __syncthreads();
+    }
+  }
+  const float* nz = noise ? noise + ((long)b * nb + t) * N : nullptr;
+  for (int n = tid; n < NP; n += 1024) {
+    unsigned long long c = ~0ull;
+    if (n < N && (mb[n] & bit)) {
+      float key;
+      if (mode == kTopk) {
+        key = score[(long)b * N + n] + 1e-8f;
+      } else if (mode == kUniform) {
+        key = 1.f / nz[n];
+      } else {
+        float p = expf(tanhf(z[(long)b * N + n]) * inv_t) / psum;
+        if (p != p) p = 1e-8f;
+        key = p / nz[n];
+      }
+      c = ((unsigned long long)(~ordered_bits(key)) << 32) | (unsigned int)n;
+    }
+    comp[n] = c;
+  }
+  __syncthreads();
+  // bitonic sort ascending
+  for (int k = 2; k <= NP; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int e = tid; e < NP; e += 1024) {
+        const int partner = e ^ j;
+        if (partner > e) {
+          const unsigned long long a = comp[e], c2 = comp[partner];
+          const bool up = ((e & k) == 0);
+          if ((a > c2) == up) {
+            comp[e] = c2;
+            comp[partner] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  int off = 0;
+  for (int u = 0; u < t; ++u) off += counts[b * nb + u];
+  const int kt = counts[b * nb + t];
+  for (int s = tid; s < kt; s += 1024) {
+    if (off + s < M) idx_out[(long)b * M + off + s] = (long long)(comp[s] & 0xFFFFFFFFull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row gather with transpose to (B, 128, M)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ O, long o_bs, long o_rs,
+                                                          const long long* __restrict__ idx, int M,
+                                                          float* __restrict__ out) {
+  __shared__ float tile[128 * 33];
+  const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
+  const int sub = tid >> 5, l32 = tid & 31;
+  for (int rr = sub; rr < 32; rr += 8) {
+    const int m = m0 + rr;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const long row = idx[(long)b * M + m];
+      v = *reinterpret_cast<const f32x4*>(O + (long)b * o_bs + row * o_rs + 4 * l32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tile[(4 * l32 + u) * 33 + rr] = v[u];
+  }
+  __syncthreads();
+  float* ob = out + (long)b * 128 * M;
+  for (int e = tid; e < 128 * 32; e += 256) {
+    const int d = e >> 5, mm = e & 31;
+    if (m0 + mm < M) ob[(long)d * M + m0 + mm] = tile[d * 33 + mm];
+  }
+}
+
+// point-set gather by sampled index: out[b][c][m] = pcd[b][c][idx[b][m]]  (utils/ops.py:136-145)
+__global__ void gather_points_kernel(const float* __restrict__ pcd, int C, int N, const long long* __restrict__ idx,
+                                     int M, float* __restrict__ out) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  out[((long)b * C + c) * M + m] = pcd[((long)b * C + c) * N + idx[(long)b * M + m]];
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, float* out, hipStream_t s) {
+  if (nb < 2 || nb > kMaxBins) return -22;
+  hipLaunchKernelGGL(batch_quantiles_kernel, dim3(1), dim3(1024), 0, s, z, n, nb, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt, const float* upper,
+                                        const float* lower, int B, int N, int nb, int relu_first,
+                                        unsigned char* member, int* cap, float* w_pre, float* w, hipStream_t s) {
+  if (nb < 1 || nb > kMaxBins || (nt != 1 && nt != nb)) return -22;
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(B), dim3(256), 0, s, z, tok, nt, upper, lower, N, nb, relu_first, member,
+                     cap, w_pre, w);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_alloc_counts(const float* w, const int* cap, int B, int nb, int M, int* counts,
+                                          hipStream_t s) {
+  if (B > 1024 || nb > kMaxBins) return -22;
+  hipLaunchKernelGGL(alloc_counts_kernel, dim3(1), dim3(1024), 0, s, w, cap, B, nb, M, counts);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bin_select(const float* score, const float* z, const unsigned char* member,
+                                        const int* counts, const float* noise, int B, int N, int nb, int M, int mode,
+                                        int temp_mode, float temp, long long* idx_out, hipStream_t s) {
+  if (mode < 0 || mode > kRandom) return -22;
+  if (mode != kTopk && noise == nullptr) return -22;
+  int NP = 1;
+  while (NP < N) NP <<= 1;
+  const size_t lds = (size_t)NP * 8;
+  if (lds > 144 * 1024) return -27;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise, N, NP, nb, M,
+                     mode, temp_mode, temp, idx_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_gather_rows(const float* O, long o_bs, long o_rs, const long long* idx, int B, int M,
+                                         float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((M + 31) / 32, B), dim3(256), 0, s, O, o_bs, o_rs, idx, M, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_gather_points(const float* pcd, int B, int C, int N, const long long* idx, int M,
+                                           float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gather_points_kernel, dim3((M + 255) / 256, C, B), dim3(256), 0, s, pcd, C, N, idx, M, out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,220 @@
+"""Drop-in `DownSampleToken` (reference models/downsample.py:15-378) on the MI355X kernels.
+
+Same constructor (`Cls(config.downsample, layer)`), `forward(x, x_xyz=None)` contract
+(`((x_ds (B,C,M), idx (B,1,M) int64), (None, None))`), parameter names / state_dict keys
+(`bin_tokens`, `q_conv.weight`, `k_conv.weight`, `v_conv.weight`, + `bn1/ffn/bn2` with `res`) and
+side-effect attributes (`attention_point_score`, `bin_boundaries`, `bin_points_mask`,
+`bin_weights_beforerelu`, `k_point_to_choose`, `idx`, `attention_bins_beforesoftmax`) as the
+reference, so `cls_model` / `seg_model` can use it unchanged and reference checkpoints load.
+
+What differs is how the work is done: the QKV projection is one torch matmul (hipBLASLt) producing
+point-major rows, and everything after it is a single autograd node over hand-written HIP kernels:
+kNN build -> flash attention over all rows (no N x N tensor) -> exact sparse column score ->
+batch quantiles -> [RCCL all-reduce of nb-1 floats] -> bins / counts / per-bin selection -> row
+gather; backward is a flash-attention backward over the M sampled rows only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+class _SamplerCore(torch.autograd.Function):
+    """qkv (B,N+nt,3D) [differentiable], x (B,C,N) [kNN only] -> x_ds (B,D,M), token logits (B,N,nt)
+    [both differentiable] + the integer / score by-products."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, mod, noise):
+        B, C, N = x.shape
+        D = mod.q_depth
+        nt = qkv.shape[1] - N
+        nb = mod.num_bins
+        q = qkv[:, :N, 0:D]
+        k = qkv[:, :, D:2 * D]
+        v = qkv[:, :, 2 * D:3 * D]
+
+        nn_idx = ops.stage_knn(x, x, mod.K)
+        O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
+        score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
+
+        if mod.bin_boundaries is not None:
+            mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
+        if mod.dynamic_boundaries_enable:
+            quant = ops.world_average(ops.stage_batch_quantiles(z, nb))
+            mod.bin_boundaries = ops.blend_boundaries(mod.bin_boundaries, quant, nb, mod.momentum_update_factor)
+        member, cap, w_pre, w = ops.stage_bin_assign(z, tok, mod.bin_boundaries[0], mod.bin_boundaries[1],
+                                                     mod.relu_mean_order == "relu_mean")
+        counts = ops.stage_alloc_counts(w, cap, mod.M)
+        idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
+        x_ds = ops.stage_gather_rows(O, idx)
+
+        ctx.save_for_backward(qkv, O, lse, idx)
+        ctx.dims = (N, nt, D)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(idx, score, z, member, cap, w_pre, counts, indeg, nn_idx)
+        return x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx
+
+    @staticmethod
+    def backward(ctx, g_xds, g_tok, *_):
+        qkv, O, lse, idx = ctx.saved_tensors
+        N, nt, D = ctx.dims
+        q = qkv[:, :N, 0:D]
+        k = qkv[:, :, D:2 * D]
+        v = qkv[:, :, 2 * D:3 * D]
+        if g_xds is not None:
+            dqkv = torch.empty_like(qkv)
+            ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
+                               dqkv[:, :, 2 * D:3 * D])
+            if nt:
+                dqkv[:, N:, 0:D].zero_()
+        else:
+            dqkv = torch.zeros_like(qkv)
+        if g_tok is not None and nt:
+            # token logits = scale * Q K_tok^T (attention_bins_beforesoftmax feeds the optional
+            # token loss, reference utils/loss.py:17-27): tiny (N x nt) products
+            scale = 1.0 / math.sqrt(D)
+            dqkv[:, :N, 0:D] += scale * torch.matmul(g_tok, k[:, N:, :])
+            dqkv[:, N:, D:2 * D] += scale * torch.matmul(g_tok.transpose(1, 2), q)
+        return dqkv, None, None, None
+
+
+class DownSampleToken(nn.Module):
+    """Shape-specific point cloud downsampling (SAMBLE) — see module docstring.
+
+    Inputs:  x (B, C, N) features; x_xyz unused (as in the reference).
+    Outputs: ((x_ds (B, C, M), index_down (B, H=1, M) int64), (None, None))."""
+
+    def __init__(self, config_ds, layer):
+        super().__init__()
+        self.M = config_ds.M[layer]
+        self.K = config_ds.K
+        self.asm = config_ds.asm[layer]
+        self.res = config_ds.res.enable[layer]
+        self.ff = config_ds.res.ff[layer]
+        self.num_heads = config_ds.num_heads[layer]
+        self.idx_mode = config_ds.idx_mode[layer]
+        self.relu_mean_order = config_ds.bin.relu_mean_order[layer]
+        self.num_bins = config_ds.bin.num_bins[layer]
+
+        q_in, q_out = config_ds.q_in[layer], config_ds.q_out[layer]
+        k_in, k_out = config_ds.k_in[layer], config_ds.k_out[layer]
+        v_in, v_out = config_ds.v_in[layer], config_ds.v_out[layer]
+        self.q_depth = int(q_out / self.num_heads)
+        self.k_depth = int(k_out / self.num_heads)
+        self.v_depth = int(v_out / self.num_heads)
+        self.q_conv = nn.Conv1d(q_in, q_out, 1, bias=False)
+        self.k_conv = nn.Conv1d(k_in, k_out, 1, bias=False)
+        self.v_conv = nn.Conv1d(v_in, v_out, 1, bias=False)
+
+        self.token_mode = config_ds.bin.token_mode[layer]
+        if self.token_mode == "multi_token":
+            self.bin_tokens = nn.Parameter(torch.normal(mean=0, std=1 / math.sqrt(q_in), size=(1, q_in, self.num_bins)))
+        elif self.token_mode == "one_token":
+            self.bin_tokens = nn.Parameter(torch.normal(mean=0, std=1 / math.sqrt(q_in), size=(1, q_in, 1)))
+        else:
+            raise NotImplementedError
+
+        if self.res:
+            self.bn1 = nn.BatchNorm1d(v_out)
+            if self.ff:
+                self.ffn = nn.Sequential(nn.Conv1d(128, 512, 1, bias=False), nn.LeakyReLU(negative_slope=0.2),
+                                         nn.Conv1d(512, 128, 1, bias=False))
+                self.bn2 = nn.BatchNorm1d(v_out)
+
+        self.scaling_factor = config_ds.bin.scaling_factor[layer]
+        self.bin_sample_mode = config_ds.bin.sample_mode[layer]
+        self.bin_norm_mode = config_ds.bin.norm_mode[layer]
+        self.momentum_update_factor = config_ds.bin.momentum_update_factor[layer]
+        self.dynamic_boundaries_enable = config_ds.bin.dynamic_boundaries_enable
+        if config_ds.bin.dynamic_boundaries_enable:
+            self.bin_boundaries = None
+        else:
+            values = list(config_ds.bin.bin_boundaries[layer])
+            self.bin_boundaries = [
+                torch.asarray([float("inf")] + values).reshape(1, 1, 1, self.num_bins),
+                torch.asarray(values + [float("-inf")]).reshape(1, 1, 1, self.num_bins),
+            ]
+        self.boltzmann_enable = config_ds.boltzmann.enable[layer]
+        self.boltzmann_T = config_ds.bin.boltzmann_T[layer]
+        self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
+        self.token_orthognonal_loss_factor = config_ds.bin.token_orthognonal_loss_factor
+
+        if self.asm != "dot":
+            raise NotImplementedError(f"asm={self.asm!r}: only the shipped 'dot' scoring is built on HIP so far")
+        if self.num_heads != 1:
+            raise NotImplementedError("DownSampleToken requires num_heads == 1 (reference utils/check_config.py:158)")
+        self._member_bits = None
+
+    # -- reference-visible state ---------------------------------------------------------------
+    @property
+    def bin_points_mask(self):
+        """(B,1,N,nb) bool, built on demand from the kernel's membership bits."""
+        if self._member_bits is None:
+            return None
+        return ops._member_to_mask(self._member_bits, self.num_bins)
+
+    def forward(self, x, x_xyz=None, noise: Optional[torch.Tensor] = None):
+        B, C, N = x.shape
+        if not x.is_cuda:
+            raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
+        tokens = self.bin_tokens.expand(B, -1, -1)
+        x_and_token = torch.cat((x, tokens), dim=2)  # (B, C, N+nt)
+        w_qkv = torch.cat((self.q_conv.weight, self.k_conv.weight, self.v_conv.weight), dim=0).squeeze(-1)
+        qkv = torch.matmul(x_and_token.transpose(1, 2), w_qkv.t())  # (B, N+nt, 3D) point-major rows
+
+        (x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx) = _SamplerCore.apply(
+            qkv, x.detach(), self, noise)
+
+        index_down = idx.unsqueeze(1)
+        if self.res is True:
+            x_ds = self.res_block(x, x_ds, index_down)
+
+        self.attention_point_score = score.unsqueeze(1)
+        self._member_bits = member
+        self.bin_weights_beforerelu = w_pre
+        self.k_point_to_choose = counts
+        self.idx = index_down
+        self.attention_bins_beforesoftmax = tok.unsqueeze(1)
+        self.knn_idx = nn_idx
+        self.knn_indegree = indeg
+        self.normalized_score = z
+        self.max_num_points = cap
+        return (x_ds, index_down), (None, None)
+
+    def res_block(self, x, x_ds, idx):
+        """models/downsample.py:292-298 (the gather picks channel 0 only, as in the reference)."""
+        x_tmp = torch.gather(x, dim=-1, index=idx)
+        x_res = self.bn1(x_ds + x_tmp)
+        if self.ff == True:  # noqa: E712  (reference semantics)
+            x_tmp = self.ffn(x_res)
+            x_res = self.bn2(x_ds + x_tmp)
+        return x_res
+
+    def output_variable_calculatio(self):
+        """models/downsample.py:346-362 (name kept, typo included: scripts call it)."""
+        mask = self.bin_points_mask
+        B, _, _, num_bins = mask.shape
+        index_batch, _, index_point, index_bin = torch.where(mask)
+        self.idx_chunks = [
+            [index_point[(index_bin == i) & (index_batch == j)].reshape(1, -1) for j in range(B)]
+            for i in range(num_bins)
+        ]
+        self.bin_prob = self.bin_weights_beforerelu
+
+    def output_variables(self, *args):
+        """models/downsample.py:364-378."""
+        variables = None
+        for i, key in enumerate(args):
+            if i == 0:
+                variables = getattr(self, key)
+            elif i == 1:
+                variables = (variables,) + (getattr(self, key),)
+            else:
+                variables = variables + (getattr(self, key),)
+        return variables

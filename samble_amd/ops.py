@@ -1,0 +1,379 @@
+"""Host-side mirror of the reference's `utils/ops.py` for the sampler path, on the HIP kernels.
+
+Same function names, argument meaning and error behaviour as the reference (file:line cited per
+function) so call sites and tests read alike; the arithmetic runs in libsamble_hip.so through
+`samble_amd._lib` (no CPU path: tensors must live on the GPU).  The lower half of the file holds
+the stage-level wrappers (`stage_*`) that `samble_amd.downsample` chains without materialising the
+reference's dense (B,N,N) tensors.
+"""
+from __future__ import annotations
+
+import numbers
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+SCORE_MODES = {"sparse_col_sum": 0, "sparse_col_avg": 1, "sparse_col_sqr": 2, "sparse_row_sum": 3,
+               "sparse_row_std": 4}
+SAMPLE_MODES = {"topk": 0, "uniform": 1, "random": 2}
+KNN_SIZES = (1, 3, 8, 16, 20, 32, 40, 64)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.SambleError("samble_amd ops need GPU tensors (there is no CPU fallback)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t if t.dtype == torch.float32 else t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# stage wrappers
+# ------------------------------------------------------------------------------------------------
+def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = False):
+    """xq (B,C,Nq), xk (B,C,Nk) channel-major -> idx (B,Nq,k) int32 nearest first
+    [, positive reference-normalised distance (B,Nq,k)]."""
+    _need_gpu(xq, xk)
+    xq, xk = _f32c(xq), _f32c(xk)
+    B, C, Nq = xq.shape
+    Nk = xk.shape[2]
+    if xk.shape[0] != B or xk.shape[1] != C:
+        raise ValueError("knn: the two point sets must share batch and channel sizes")
+    with torch.cuda.device(xq.device):
+        idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xq.device)
+        dist = torch.empty((B, Nq, k), dtype=torch.float32, device=xq.device) if want_dist else None
+        nbytes = _lib.query("samble_knn_workspace_bytes", B, Nq, Nk, k)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xq.device)
+        _lib.call("samble_knn_f32", xq.data_ptr(), C * Nq, Nq, xk.data_ptr(), C * Nk, Nk, B, C, k, idx.data_ptr(),
+                  _p(dist), ws.data_ptr(), nbytes, _stream())
+    return (idx, dist) if want_dist else idx
+
+
+def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int):
+    """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->
+    O (B,N,D), lse (B,N), token logits (B,N,nt)."""
+    _need_gpu(q, k, v)
+    B, N, D = q.shape
+    assert N == n_points and k.shape[1] == n_points + n_tokens and v.shape[1] == k.shape[1]
+    for t in (q, k, v):
+        if t.stride(2) != 1 or t.dtype != torch.float32:
+            raise ValueError("attention operands must be fp32 with unit channel stride")
+    with torch.cuda.device(q.device):
+        O = torch.empty((B, N, D), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        tok = torch.empty((B, N, max(n_tokens, 1)), dtype=torch.float32, device=q.device)
+        _lib.call("samble_attn_fwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), B, N, n_tokens, D, O.data_ptr(),
+                  lse.data_ptr(), tok.data_ptr(), _stream())
+    return O, lse, tok[:, :, :n_tokens]
+
+
+def stage_sparse_score(q, k, lse, nn_idx, idx_mode: str):
+    """-> score (B,N), z (B,N), in-degree (B,N) int32 for the sparse_* idx modes."""
+    if idx_mode not in SCORE_MODES:
+        if idx_mode in ("col_sum", "row_std"):
+            raise NotImplementedError(f"idx_mode {idx_mode} (dense map statistics) is not built yet")
+        raise ValueError("Please check the setting of idx mode!")
+    _need_gpu(q, k, lse, nn_idx)
+    B, N, D = q.shape
+    with torch.cuda.device(q.device):
+        score = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        z = torch.empty_like(score)
+        indeg = torch.empty((B, N), dtype=torch.int32, device=q.device)
+        nbytes = _lib.query("samble_score_workspace_bytes", B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("samble_sparse_score_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), lse.data_ptr(), nn_idx.data_ptr(), B, N, nn_idx.shape[2], D, SCORE_MODES[idx_mode],
+                  score.data_ptr(), z.data_ptr(), indeg.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return score, z, indeg
+
+
+def stage_zscore(score: torch.Tensor) -> torch.Tensor:
+    _need_gpu(score)
+    score = _f32c(score)
+    B, N = score.shape
+    with torch.cuda.device(score.device):
+        z = torch.empty_like(score)
+        _lib.call("samble_zscore_f32", score.data_ptr(), B, N, z.data_ptr(), _stream())
+    return z
+
+
+def stage_batch_quantiles(z: torch.Tensor, num_bins: int) -> torch.Tensor:
+    _need_gpu(z)
+    z = _f32c(z)
+    with torch.cuda.device(z.device):
+        out = torch.empty((num_bins - 1,), dtype=torch.float32, device=z.device)
+        _lib.call("samble_batch_quantiles_f32", z.data_ptr(), z.numel(), num_bins, out.data_ptr(), _stream())
+    return out
+
+
+def stage_bin_assign(z, tok_logits, upper, lower, relu_first: bool):
+    """-> member bits (B,N) uint8, cap (B,nb) int32, w_pre (B,nb), w (B,nb)."""
+    _need_gpu(z, tok_logits, upper, lower)
+    z, tok_logits = _f32c(z), _f32c(tok_logits)
+    upper = _f32c(upper.reshape(-1))
+    lower = _f32c(lower.reshape(-1))
+    B, N = z.shape
+    nb = upper.numel()
+    with torch.cuda.device(z.device):
+        member = torch.empty((B, N), dtype=torch.uint8, device=z.device)
+        cap = torch.empty((B, nb), dtype=torch.int32, device=z.device)
+        w_pre = torch.empty((B, nb), dtype=torch.float32, device=z.device)
+        w = torch.empty_like(w_pre)
+        _lib.call("samble_bin_assign_f32", z.data_ptr(), tok_logits.data_ptr(), tok_logits.shape[-1], upper.data_ptr(),
+                  lower.data_ptr(), B, N, nb, int(bool(relu_first)), member.data_ptr(), cap.data_ptr(),
+                  w_pre.data_ptr(), w.data_ptr(), _stream())
+    return member, cap, w_pre, w
+
+
+def stage_alloc_counts(w: torch.Tensor, cap: torch.Tensor, total: int) -> torch.Tensor:
+    _need_gpu(w, cap)
+    w = _f32c(w)
+    cap = cap.to(torch.int32).contiguous()
+    B, nb = w.shape
+    with torch.cuda.device(w.device):
+        counts = torch.empty((B, nb), dtype=torch.int32, device=w.device)
+        _lib.call("samble_alloc_counts_f32", w.data_ptr(), cap.data_ptr(), B, nb, int(total), counts.data_ptr(),
+                  _stream())
+    return counts
+
+
+def boltzmann_temperature(boltzmann_t, n_points: int, num_bins: int) -> Tuple[int, float]:
+    """(temp_mode, temp) for samble_bin_select_f32 from the reference's boltzmann_T setting
+    (utils/ops.py:524-550)."""
+    if boltzmann_t == "mode_1":
+        return 1, 100.0
+    if boltzmann_t == "mode_3":
+        return 1, 200.0
+    if boltzmann_t == "mode_2":
+        return 0, n_points / (100.0 * num_bins)
+    if boltzmann_t == "mode_4":
+        return 0, n_points / (200.0 * num_bins)
+    if isinstance(boltzmann_t, numbers.Number):
+        return 0, 1 / boltzmann_t
+    raise NotImplementedError
+
+
+def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzmann_t, noise=None):
+    """-> idx (B,M) int64: bins ascending, inside a bin by descending key."""
+    if sample_mode not in SAMPLE_MODES:
+        raise ValueError("Please check the setting of bin sample mode. It must be topk, multinomial or random!")
+    _need_gpu(score, z, member, counts, noise)
+    B, N = score.shape
+    nb = counts.shape[1]
+    temp_mode, temp = (0, 1.0)
+    if sample_mode == "random":
+        temp_mode, temp = boltzmann_temperature(boltzmann_t, N, nb)
+    if sample_mode != "topk":
+        if noise is None:
+            noise = torch.empty((B * nb, N), dtype=torch.float32, device=score.device).exponential_(1)
+        noise = _f32c(noise)
+        if noise.shape != (B * nb, N):
+            raise ValueError(f"noise must be (B*num_bins, N) = {(B * nb, N)}, got {tuple(noise.shape)}")
+    with torch.cuda.device(score.device):
+        idx = torch.zeros((B, M), dtype=torch.int64, device=score.device)
+        _lib.call("samble_bin_select_f32", score.data_ptr(), z.data_ptr(), member.data_ptr(), counts.data_ptr(),
+                  _p(noise), B, N, nb, M, SAMPLE_MODES[sample_mode], temp_mode, float(temp), idx.data_ptr(),
+                  _stream())
+    return idx
+
+
+def stage_gather_rows(O: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """O (B,N,D), idx (B,M) int64 -> (B,D,M)."""
+    _need_gpu(O, idx)
+    B, N, D = O.shape
+    M = idx.shape[1]
+    with torch.cuda.device(O.device):
+        out = torch.empty((B, D, M), dtype=torch.float32, device=O.device)
+        _lib.call("samble_gather_rows_f32", O.data_ptr(), O.stride(0), O.stride(1), idx.data_ptr(), B, M, D,
+                  out.data_ptr(), _stream())
+    return out
+
+
+def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk, dv) -> None:
+    """Fills dq (rows idx, other rows zeroed), dk, dv (views with their own strides)."""
+    _need_gpu(q, k, v, O, lse, idx, g)
+    B, N, D = q.shape
+    M = idx.shape[1]
+    g = _f32c(g)
+    with torch.cuda.device(q.device):
+        nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, M, D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("samble_attn_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), O.data_ptr(), lse.data_ptr(), idx.data_ptr(),
+                  g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(), dq.stride(0), dq.stride(1),
+                  dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1),
+                  ws.data_ptr(), nbytes, _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# reference-named functions (utils/ops.py)
+# ------------------------------------------------------------------------------------------------
+def _channel_major(a: torch.Tensor) -> torch.Tensor:
+    """(B,N,C) -> contiguous (B,C,N); free when `a` is the usual permute(0,2,1) view."""
+    return _f32c(a.permute(0, 2, 1))
+
+
+def knn(a: torch.Tensor, b: torch.Tensor, k: int):
+    """utils/ops.py:17-44: a (B,N,C), b (B,M,C) -> (distance (B,N,k) NEGATED like the
+    reference's topk of -cdist, idx (B,N,k) int64)."""
+    idx, dist = stage_knn(_channel_major(a), _channel_major(b), k, want_dist=True)
+    return -dist, idx.long()
+
+
+def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """utils/ops.py:5-14: points (B,N,C), idx (B,M,K) -> (B,M,K,C)."""
+    shape = idx.shape
+    flat = idx.reshape(shape[0], -1).long()
+    res = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1]))
+    return res.view(*shape, -1)
+
+
+def select_neighbors(pcd, K, neighbor_type, normal_channel=False):
+    """utils/ops.py:47-65: pcd (B,C,N) -> (neighbours (B,C,N,K), idx (B,N,K))."""
+    src = pcd[:, :3, :] if (normal_channel and pcd.shape[1] == 6) else pcd
+    idx = stage_knn(src, src, K).long()
+    pts = pcd.permute(0, 2, 1)
+    neighbors = index_points(pts, idx)
+    if neighbor_type == "neighbor":
+        neighbors = neighbors.permute(0, 3, 1, 2)
+    elif neighbor_type == "diff":
+        neighbors = (neighbors - pts[:, :, None, :]).permute(0, 3, 1, 2)
+    else:
+        raise ValueError(f'neighbor_type should be "neighbor" or "diff", but got {neighbor_type}')
+    return neighbors, idx
+
+
+def select_neighbors_interpolate(unknown, known, known_feature, K=3):
+    """utils/ops.py:68-80: cross-set kNN with positive distances."""
+    idx, d = stage_knn(unknown, known, K, want_dist=True)
+    idx = idx.long()
+    neighbors = index_points(known_feature.permute(0, 2, 1), idx).permute(0, 3, 1, 2)
+    return neighbors, idx, d
+
+
+def group(pcd, K, group_type, normal_channel=False):
+    """utils/ops.py:83-112."""
+    if group_type == "neighbor":
+        return select_neighbors(pcd, K, "neighbor", normal_channel)
+    if group_type == "diff":
+        return select_neighbors(pcd, K, "diff", normal_channel)
+    if group_type == "center_neighbor":
+        nb, idx = select_neighbors(pcd, K, "neighbor", normal_channel)
+        return torch.cat([pcd[:, :, :, None].repeat(1, 1, 1, K), nb], dim=1), idx
+    if group_type == "center_diff":
+        nb, idx = select_neighbors(pcd, K, "diff", normal_channel)
+        return torch.cat([pcd[:, :, :, None].repeat(1, 1, 1, K), nb], dim=1), idx
+    raise ValueError(
+        f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {group_type}")
+
+
+def neighbor_mask(pcd, K):
+    """utils/ops.py:125-133: dense 0/1 (B,N,N) mask.  Kept for API parity only; the sampler
+    itself never builds it."""
+    idx = stage_knn(pcd, pcd, K).long()
+    B, N, _ = idx.shape
+    mask = torch.zeros(B, N, N, dtype=torch.float32, device=idx.device)
+    mask.scatter_(2, idx, 1.0)
+    return mask
+
+
+def gather_by_idx(pcd, idx):
+    """utils/ops.py:136-145: pcd (B,C,N), idx (B,H=1,K) -> (B,C,K)."""
+    _need_gpu(pcd, idx)
+    pcd = _f32c(pcd)
+    B, C, N = pcd.shape
+    idx2 = idx.reshape(B, -1).long().contiguous()
+    M = idx2.shape[1]
+    with torch.cuda.device(pcd.device):
+        out = torch.empty((B, C, M), dtype=torch.float32, device=pcd.device)
+        _lib.call("samble_gather_points_f32", pcd.data_ptr(), B, C, N, idx2.data_ptr(), M, out.data_ptr(), _stream())
+    return out
+
+
+def world_average(t: torch.Tensor) -> torch.Tensor:
+    """The exchange step of utils/ops.py:191-199: all_reduce(SUM) / world_size when a process
+    group exists (RCCL on the GPU, gloo in the CPU tests), identity otherwise."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(t)
+        t = t / torch.distributed.get_world_size()
+    return t
+
+
+def blend_boundaries(old: Optional[List[torch.Tensor]], quantiles: torch.Tensor, num_bins: int,
+                     momentum_update_factor: float) -> List[torch.Tensor]:
+    """utils/ops.py:201-233 on the (already rank-averaged) nb-1 quantiles: first call stores them,
+    later calls blend `old * mu + (1 - mu) * new` IN PLACE into both (1,1,1,nb) tensors."""
+    if old is not None:
+        new = [old[0].detach(), old[1].detach()]
+        mixed = new[0][0, 0, 0, 1:] * momentum_update_factor + (1 - momentum_update_factor) * quantiles
+        new[0][0, 0, 0, 1:] = mixed
+        new[1][0, 0, 0, :-1] = mixed
+        return new
+    upper = torch.empty((num_bins,), device=quantiles.device)
+    upper[0] = float("inf")
+    upper[1:] = quantiles
+    lower = torch.empty((num_bins,), device=quantiles.device)
+    lower[-1] = float("-inf")
+    lower[:-1] = quantiles
+    return [upper.reshape(1, 1, 1, num_bins), lower.reshape(1, 1, 1, num_bins)]
+
+
+def update_sampling_score_bin_boundary(old_bin_boundaries, attention_point_score, num_bins, momentum_update_factor):
+    """utils/ops.py:174-236 (the argument is the z-scored score, any shape)."""
+    q = stage_batch_quantiles(attention_point_score.reshape(-1), num_bins)
+    q = world_average(q)
+    return blend_boundaries(old_bin_boundaries, q, num_bins, momentum_update_factor)
+
+
+def _member_to_mask(member: torch.Tensor, num_bins: int) -> torch.Tensor:
+    bits = torch.arange(num_bins, device=member.device, dtype=torch.uint8)
+    return ((member.unsqueeze(-1) >> bits) & 1).bool().unsqueeze(1)  # (B,1,N,nb)
+
+
+def bin_partition(attention_point_score, bin_boundaries, dynamic_boundaries_enable, momentum_update_factor,
+                  num_bins):
+    """utils/ops.py:435-464: score (B,1,N) -> (boundaries, bool mask (B,1,N,nb))."""
+    B, H, N = attention_point_score.shape
+    if bin_boundaries is not None:
+        bin_boundaries = [item.to(attention_point_score.device) for item in bin_boundaries]
+    z = stage_zscore(attention_point_score.reshape(B * H, N))
+    if dynamic_boundaries_enable:
+        bin_boundaries = update_sampling_score_bin_boundary(bin_boundaries, z, num_bins, momentum_update_factor)
+    dummy = torch.zeros((B * H, N, 1), dtype=torch.float32, device=z.device)
+    member, _, _, _ = stage_bin_assign(z, dummy, bin_boundaries[0], bin_boundaries[1], False)
+    return bin_boundaries, _member_to_mask(member, num_bins).reshape(B, H, N, num_bins)
+
+
+def calculate_num_points_to_choose(bin_prob, max_num_points, total_points_to_choose):
+    """utils/ops.py:385-432."""
+    return stage_alloc_counts(bin_prob, max_num_points, total_points_to_choose)
+
+
+def generating_downsampled_index(M, attention_point_score, bin_points_mask, bin_sample_mode, boltzmann_t,
+                                 k_point_to_choose, noise=None):
+    """utils/ops.py:467-619: score (B,1,N), mask (B,1,N,nb) bool, k (B,nb) -> idx (B,1,M) int64.
+    `noise` (B*nb, N) is the Exp(1) draw of torch.multinomial; drawn on the device when None."""
+    if bin_sample_mode not in SAMPLE_MODES:
+        raise ValueError("Please check the setting of bin sample mode. It must be topk, multinomial or random!")
+    B, _, N, nb = bin_points_mask.shape
+    weights = (1 << torch.arange(nb, device=bin_points_mask.device, dtype=torch.int32))
+    member = (bin_points_mask.reshape(B, N, nb).to(torch.int32) * weights).sum(-1).to(torch.uint8)
+    score = _f32c(attention_point_score.reshape(B, N))
+    z = stage_zscore(score)
+    idx = stage_bin_select(score, z, member, k_point_to_choose.to(torch.int32).contiguous(), M, bin_sample_mode,
+                           boltzmann_t, noise)
+    return idx.reshape(B, 1, M)

@@ -1,0 +1,104 @@
+"""CPU: the C-ABI library loads and exports every symbol include/samble.h declares (no compute
+calls), and the host-side logic that needs no GPU (config, boundary state, error behaviour)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from samble_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def test_header_symbols_are_exported(lib):
+    header = open(os.path.join(ROOT, "include", "samble.h")).read()
+    declared = set(re.findall(r"\b(samble_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (samble_[a-z0-9_]+)", out))
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert exported <= declared, f"exported but not declared in samble.h: {sorted(exported - declared)}"
+    assert set(lib.EXPORTS) == declared
+
+
+def test_library_loads_and_reports_version(lib):
+    handle = lib.load()
+    assert b"gfx950" in handle.samble_version()
+    assert lib.query("samble_knn_workspace_bytes", 32, 2048, 2048, 32) >= 32 * 2048 * 2048 * 4
+
+
+def test_argument_errors_do_not_need_a_gpu(lib):
+    # validation happens before any HIP call: null pointers / bad sizes come back as SambleError
+    with pytest.raises(lib.SambleError, match="null pointer"):
+        lib.call("samble_zscore_f32", None, 1, 1, None, None) if False else \
+            lib.call("samble_attn_fwd_f32", None, 0, 0, None, 0, 0, None, 0, 0, 1, 1, 0, 128, None, None, None, None)
+    with pytest.raises(lib.SambleError, match="D must be 128"):
+        lib.call("samble_gather_rows_f32", 1, 0, 0, 1, 1, 1, 64, 1, None)
+    with pytest.raises(lib.SambleError, match="num_bins"):
+        lib.call("samble_batch_quantiles_f32", 1, 10, 9, 1, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch, lib):
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libsamble_hip.so")
+    with pytest.raises(lib.SambleError, match="no CPU fallback"):
+        lib.load()
+
+
+def test_cpu_tensors_are_refused():
+    from samble_amd import _lib, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    mod = DownSampleToken(sampler_config("cls"), 0)
+    with pytest.raises(_lib.SambleError, match="GPU only"):
+        mod(torch.zeros(1, 128, 64))
+
+
+def test_constructor_contract_matches_reference():
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    cfg = sampler_config("seg")
+    mod = DownSampleToken(cfg, 1)
+    assert (mod.M, mod.K, mod.num_bins, mod.idx_mode, mod.bin_sample_mode) == (512, 32, 4, "sparse_col_sqr", "random")
+    assert sorted(mod.state_dict()) == ["bin_tokens", "k_conv.weight", "q_conv.weight", "v_conv.weight"]
+    assert mod.bin_tokens.shape == (1, 128, 4) and mod.bin_boundaries is None
+    cfg = sampler_config("cls", bin__dynamic_boundaries_enable=False)
+    mod = DownSampleToken(cfg, 0)
+    up, lo = mod.bin_boundaries
+    assert up.shape == (1, 1, 1, 6) and up[0, 0, 0, 0] == float("inf") and lo[0, 0, 0, -1] == float("-inf")
+    with pytest.raises(NotImplementedError):
+        DownSampleToken(sampler_config("cls", bin__token_mode=["bogus", "bogus"]), 0)
+    res = DownSampleToken(sampler_config("cls", res__enable=[True, True], res__ff=[True, True]), 0)
+    assert {"bn1.weight", "ffn.0.weight", "ffn.2.weight", "bn2.weight"} <= set(res.state_dict())
+
+
+def test_boundary_blend_matches_oracle():
+    from oracle import torch_oracle as O
+    from samble_amd import ops
+    q1 = torch.tensor([0.5, 0.1, -0.2, -0.4, -0.6])
+    q2 = torch.tensor([0.55, 0.05, -0.25, -0.35, -0.65])
+    a = ops.blend_boundaries(None, q1.clone(), 6, 0.99)
+    b = O.blend_boundaries(None, q1.clone(), 6, 0.99)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a2 = ops.blend_boundaries(a, q2.clone(), 6, 0.99)
+    b2 = O.blend_boundaries(b, q2.clone(), 6, 0.99)
+    assert torch.equal(a2[0], b2[0]) and torch.equal(a2[1], b2[1])
+    assert a2[0].data_ptr() == a[0].data_ptr(), "state is updated in place, like the reference"
+
+
+def test_temperature_modes():
+    from samble_amd import ops
+    assert ops.boltzmann_temperature(0.1, 2048, 6) == (0, 10.0)
+    assert ops.boltzmann_temperature("mode_1", 2048, 6) == (1, 100.0)
+    assert ops.boltzmann_temperature("mode_4", 2048, 6) == (0, 2048 / 1200.0)
+    with pytest.raises(NotImplementedError):
+        ops.boltzmann_temperature("mode_9", 1, 1)
