@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
     const f32x4 qv = *reinterpret_cast<const f32x4*>(Qb + (long)i * q_rs + 4 * c);
     const float li = lse[(long)b * N + i];
     const int* ni = nn + ((long)b * N + i) * KN;
-    float rs = 0.f, rss = 0.f;
+    float rs = 0.f;
+    double rs_d = 0.0, rss_d = 0.0;
     for (int k0 = 0; k0 < KN; k0 += 4) {
       int j[4];
       f32x4 kv[4];
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
         if (k0 + u < KN) {
           const float a = __expf(s * scale - li);
           rs += a;
-          rss += a * a;
+          rs_d += (double)a;
+          rss_d += (double)a * (double)a;
           if (c == 0) {
             atomicAdd(&acc[j[u]], (unsigned long long)__float2ll_rn(a * kFix));
             atomicAdd(&cnt[j[u]], 1);
@@ -72,8 +74,8 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
     if (rowstat && c == 0) {
       float v = rs;
       if (row_mode == kRowStd) {  // unbiased std over the K picked entries (torch.std default)
-        const float mean = rs / KN;
-        v = sqrtf(fmaxf((rss - KN * mean * mean) / (KN - 1), 0.f));
+        const double mean = rs_d / KN;
+        v = (float)sqrt(fmax((rss_d - KN * mean * mean) / (KN - 1), 0.0));
       }
       rowstat[(long)b * N + i] = v;
     }

@@ -222,7 +222,10 @@ def test_alloc_counts_exact_random_trials():
 def test_bin_select_exact_vs_oracle_full_size(mode):
     """topk / uniform keys involve no transcendental: exact at the metric size."""
     B, N, nb, M = 8, 2048, 6, 1024
-    score = torch.from_numpy(np.abs(synth.normal((B, 1, N), 21)) * 1e-4)
+    raw = np.abs(synth.normal((B, 1, N), 21)).astype(np.float64)
+    raw += np.arange(N) * 1e-9  # exact ties have no defined order in torch.sort: keep the scores distinct
+    score = torch.from_numpy((raw * 1e-4).astype(np.float32))
+    assert all(len(np.unique((score[b, 0] + 1e-8).numpy())) == N for b in range(B))
     z = O.zscore(score)
     state = O.blend_boundaries(None, O.batch_quantiles(z.reshape(B, 1, N, 1), nb), nb, 0.99)
     member = O.bin_membership(z, state)
@@ -235,6 +238,17 @@ def test_bin_select_exact_vs_oracle_full_size(mode):
     got = ops().stage_bin_select(score.reshape(B, N).to(DEV), z.reshape(B, N).to(DEV), bits.to(DEV),
                                  counts.to(DEV), M, mode, 0.1, noise.to(DEV))
     assert torch.equal(got.cpu(), ref.reshape(B, M))
+
+
+def test_bin_select_ties_break_by_ascending_index():
+    """torch.sort leaves the order of exactly equal keys unspecified; ours is defined."""
+    B, N, nb, M = 1, 256, 2, 64
+    score = torch.full((B, N), 1e-4)
+    z = torch.zeros(B, N)
+    member = torch.ones(B, N, dtype=torch.uint8)  # everyone in bin 0
+    counts = torch.tensor([[M, 0]], dtype=torch.int32)
+    got = ops().stage_bin_select(score.to(DEV), z.to(DEV), member.to(DEV), counts.to(DEV), M, "topk", 0.1)
+    assert torch.equal(got.cpu(), torch.arange(M).reshape(1, M))
 
 
 def test_gather_rows_and_points():
