@@ -96,16 +96,26 @@ def cpu_baseline(seed):
     container) timed on this host's cores on a bounded sample of the same workload."""
     from oracle import torch_oracle as O
     from samble_amd import synth
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
-    sample_b = 8
     spec = O.SamplerSpec(M=M, K=KNN, C=C, num_bins=NB)
     wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
     st = O.SamplerState(*(torch.from_numpy(a) for a in (wq, wk, wv, tok)))
+    sample_b = 8
     x = torch.from_numpy(synth.features(sample_b, C, N, seed + 1))
     g = torch.from_numpy(synth.normal((sample_b, C, M), seed + 2))
     noise = torch.from_numpy(synth.exp1((sample_b * NB, N), seed + 3))
-    O.sampler_grads(spec, st, x[:2], g[:2], noise[: 2 * NB])  # warm-up
+    # give the CPU path its best thread count (all cores is slower than fewer on many-core hosts)
+    ncpu = os.cpu_count() or 1
+    best = None
+    for threads in sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu}):
+        torch.set_num_threads(threads)
+        O.sampler_grads(spec, st, x[:1], g[:1], noise[:NB])  # warm-up
+        t0 = time.perf_counter()
+        O.sampler_grads(spec, st, x[:2], g[:2], noise[: 2 * NB])
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    cores = best[1]
+    torch.set_num_threads(cores)
     reps = 2
     t0 = time.perf_counter()
     for _ in range(reps):

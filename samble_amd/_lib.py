@@ -56,6 +56,10 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (the one
+    # that owns the tensors' device context), so it has to be loaded before our library binds to
+    # that SONAME.  Loaded the other way round, /opt/rocm's copy wins and sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise SambleError(
             f"{LIB_PATH} not found: the HIP kernels are not built. Run "

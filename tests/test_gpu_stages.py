@@ -222,9 +222,10 @@ def test_alloc_counts_exact_random_trials():
 def test_bin_select_exact_vs_oracle_full_size(mode):
     """topk / uniform keys involve no transcendental: exact at the metric size."""
     B, N, nb, M = 8, 2048, 6, 1024
-    raw = np.abs(synth.normal((B, 1, N), 21)).astype(np.float64)
-    raw += np.arange(N) * 1e-9  # exact ties have no defined order in torch.sort: keep the scores distinct
-    score = torch.from_numpy((raw * 1e-4).astype(np.float32))
+    # exact ties have no defined order in torch.sort / topk: build scores that are distinct by
+    # construction (a permutation of N levels, spaced far above one fp32 ulp)
+    levels = np.stack([np.random.default_rng(b).permutation(N) for b in range(B)]).astype(np.float64)
+    score = torch.from_numpy(((levels + 1.0) * 3.7e-7).astype(np.float32)).reshape(B, 1, N)
     assert all(len(np.unique((score[b, 0] + 1e-8).numpy())) == N for b in range(B))
     z = O.zscore(score)
     state = O.blend_boundaries(None, O.batch_quantiles(z.reshape(B, 1, N, 1), nb), nb, 0.99)
