@@ -60,6 +60,10 @@ size_t samble_knn_workspace_bytes(int B, int Nq, int Nk, int K);
 int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C, int K,
                    int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Debug / A-B hook: non-zero forces the two-kernel kNN path (key matrix through HBM) instead of the
+ * fused Gram + top-K kernel.  Process-wide; not for production use. */
+void samble_knn_force_unfused(int on);
+
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
  * the N point rows).  O (B,N,D) contiguous: row i = softmax(Q_i K^T / sqrt(D)) V, the row the

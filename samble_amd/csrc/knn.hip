@@ -26,7 +26,15 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   if (n >= N) return;
   const float* p = x + (long)b * bs + n;
   float acc = 0.f;
-  for (int c = 0; c < C; ++c) {
+  int c = 0;
+  for (; c + 8 <= C; c += 8) {  // 8 independent loads in flight; the sum keeps channel order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long)(c + u) * N];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(v[u], v[u], acc);
+  }
+  for (; c < C; ++c) {
     float v = p[(long)c * N];
     acc = fmaf(v, v, acc);
   }
@@ -197,6 +205,191 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused Gram + top-K: the key matrix never leaves the chip.
+//
+// Workgroup = 4 waves = 128 queries; a wave holds its 32 queries' channels in registers (MFMA B
+// operand) and streams 32-key tiles of the channel-major key set through LDS (A operand), so the
+// accumulator of lane (i, h) holds G[j][i] - |b_j|^2/2 for 16 keys j of query i (the norm enters as
+// one extra MFMA step with B = -1/2).  w = |a_i|^2/2 - acc = d^2/2 >= 0 is the ranking key.
+//
+// Selection is per lane (each lane owns one query and the half of the key stream that lands on its
+// lane half): candidates with w <= the lane's current bound go to a per-lane LDS queue; when any
+// lane's queue is nearly full the wave drains queues into per-lane sorted K-lists held in
+// registers as DOUBLES whose high bits are (double)w and low 29 bits the key index: positive
+// doubles order like (w, j) pairs, so an insertion is one v_max_f64 + v_min_f64 per slot and ties
+// break by ascending index.  The bound of a lane is min(own K-th, max of the two halves'
+// ceil(K/2)-th): both halves together then already hold K keys at or below it.  The two halves'
+// lists are merged at the end.  (Algorithm checked element-for-element against a sort on the CPU.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kFQueue = 24;  // queue slots per lane; a tile adds at most 16
+
+template <int KN>
+__device__ __forceinline__ void insert_packed(double (&L)[KN], double x) {
+#pragma unroll
+  for (int s = KN - 1; s > 0; --s) L[s] = fmin(L[s], fmax(L[s - 1], x));
+  L[0] = fmin(L[0], x);
+}
+
+__device__ __forceinline__ double pack_wj(float w, unsigned int j) {
+  return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
+}
+
+template <int C, int KN>
+__global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                           const float* __restrict__ xk, long k_bs, int Nk,
+                                                           const float* __restrict__ knorm,
+                                                           int* __restrict__ idx_out, float* __restrict__ d2_out) {
+  constexpr int H = C / 2;            // MFMA steps; lane half h consumes channels H*h .. H*h+H-1
+  constexpr int TILE = C * 32;        // floats per key tile, [channel][32 keys]
+  constexpr int LOADS = TILE / 4 / 256;
+  constexpr int KH = (KN + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;                               // 2 x TILE
+  float* bns = smem + 2 * TILE;                      // 2 x 32 key norms
+  float* qw = bns + 64;                              // kFQueue x 256
+  unsigned short* qj = reinterpret_cast<unsigned short*>(qw + kFQueue * 256);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 128 + wave * 32 + lo;
+  const bool ivalid = i < Nq;
+  const float* xkb = xk + (long)b * k_bs;
+  const float* knb = knorm + (long)b * Nk;
+
+  float q[H];
+  float an = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < H; ++kk) {
+    q[kk] = ivalid ? xq[(long)b * q_bs + (long)(H * h + kk) * Nq + i] : 0.f;
+    an = fmaf(q[kk], q[kk], an);
+  }
+  an += wave_xor32(an);
+  const float half_an = 0.5f * an;
+
+  double L[KN];
+#pragma unroll
+  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
+  float thr = __builtin_huge_valf();
+  int cnt = 0;
+
+  const bool vec = (Nk & 3) == 0;
+  f32x4 stage[LOADS];
+  float stage_bn = 0.f;
+  auto issue = [&](int j0) {
+#pragma unroll
+    for (int it = 0; it < LOADS; ++it) {
+      const int e = tid + 256 * it;
+      const int c = e >> 3, p4 = (e & 7) * 4;
+      const float* src = xkb + (long)c * Nk + j0 + p4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (vec && j0 + p4 + 3 < Nk) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + p4 + u < Nk) v[u] = src[u];
+      }
+      stage[it] = v;
+    }
+    if (tid < 32) stage_bn = (j0 + tid < Nk) ? knb[j0 + tid] : 0.f;
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < LOADS; ++it) {
+      const int e = tid + 256 * it;
+      *reinterpret_cast<f32x4*>(tiles + buf * TILE + (e >> 3) * 32 + (e & 7) * 4) = stage[it];
+    }
+    if (tid < 32) bns[buf * 32 + tid] = stage_bn;
+  };
+  auto drain = [&]() {
+    for (int s = 0; s < kFQueue; ++s) {
+      if (!__any(s < cnt)) break;
+      const double xd = (s < cnt) ? pack_wj(qw[s * 256 + tid], qj[s * 256 + tid]) : __builtin_huge_val();
+      insert_packed<KN>(L, xd);
+    }
+    cnt = 0;
+    const double mid = L[KH - 1];
+    const double pmid = __shfl_xor(mid, 32, 64);
+    const double lim = fmin(L[KN - 1], fmax(mid, pmid));
+    thr = (float)lim;  // the index bits are far below half a float ulp: this is exactly lim's w
+  };
+
+  const int ntiles = (Nk + 31) / 32;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    const int j0 = t * 32;
+    if (t + 1 < ntiles) issue(j0 + 32);
+    const float* xs = tiles + cur * TILE + (H * h) * 32 + lo;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) acc = mfma32(xs[kk * 32], q[kk], acc);
+    acc = mfma32(h == 0 ? bns[cur * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
+    const bool tail = j0 + 32 > Nk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + crow(r, h);
+      const float w = fmaxf(half_an - acc[r], 0.f);
+      bool pass = w <= thr;
+      if (tail) pass = pass && (j < Nk);
+      if (pass) {
+        qw[cnt * 256 + tid] = w;
+        qj[cnt * 256 + tid] = (unsigned short)j;
+        ++cnt;
+      }
+    }
+    if (__any(cnt > kFQueue - 16)) drain();
+    if (t + 1 < ntiles) commit(cur ^ 1);
+    __syncthreads();
+  }
+  drain();
+  // merge the two halves of every query through LDS (the whole dynamic region is free now)
+  double* mg = reinterpret_cast<double*>(smem);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KN; ++s) mg[s * 256 + tid] = L[s];
+  __syncthreads();
+  if (h == 0 && ivalid) {
+    int pa = 0, pb = 0;
+    double va = mg[tid], vb = mg[tid + 32];
+    int* io = idx_out + ((long)b * Nq + i) * KN;
+    float* dout = d2_out ? d2_out + ((long)b * Nq + i) * KN : nullptr;
+    for (int k = 0; k < KN; ++k) {
+      const bool take = va <= vb;
+      const double o = take ? va : vb;
+      io[k] = (int)(__double_as_longlong(o) & 0x1FFFFFFFll);
+      if (dout) dout[k] = 2.f * (float)o;
+      if (take) {
+        ++pa;
+        va = (pa < KN) ? mg[pa * 256 + tid] : __builtin_huge_val();
+      } else {
+        ++pb;
+        vb = (pb < KN) ? mg[pb * 256 + tid + 32] : __builtin_huge_val();
+      }
+    }
+  }
+}
+
+template <int C, int KN>
+static int launch_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                        const float* knorm, int* idx, float* d2, hipStream_t s) {
+  size_t lds = (size_t)(2 * C * 32 + 64 + kFQueue * 256) * 4 + (size_t)kFQueue * 256 * 2;
+  const size_t merge = (size_t)KN * 256 * 8;
+  if (merge > lds) lds = merge;
+  auto kern = knn_fused_kernel<C, KN>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((Nq + 127) / 128, B), dim3(256), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm, idx, d2);
+  return 0;
+}
+
 // Per-cloud scale of the reference (utils/ops.py:27): mean over channels of the unbiased std over
 // points of the query set.  One workgroup per cloud; double accumulation, fixed order.
 __global__ __launch_bounds__(256) void knn_scale_kernel(const float* __restrict__ x, long bs, int C, int N,
@@ -258,6 +451,10 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
   hipLaunchKernelGGL(select_rows_kernel<KN>, dim3((Nq + 255) / 256, B), dim3(256), 0, s, keyT, Nq, Nk, idx, keys);
 }
 
+// test hook: force the round-1 two-kernel path (key matrix through HBM) for A/B checks
+static bool g_force_unfused = false;
+extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) { g_force_unfused = on != 0; }
+
 // workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
 extern "C" size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K) {
   return (size_t)B * Nk * Nq + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
@@ -271,32 +468,43 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   float* scale = qnorm + (size_t)B * Nq;
   float* keys = scale + B;
   const bool smallc = C <= 8;
-  if (smallc) {
-    hipLaunchKernelGGL(smallc_keys_kernel, dim3((Nq + 255) / 256, Nk, B), dim3(256), 0, stream, xq, q_bs, Nq, xk, k_bs,
-                       Nk, C, keyT);
-  } else {
-    hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
-    hipLaunchKernelGGL(gram_keys_kernel, dim3((Nq + 127) / 128, (Nk + 127) / 128, B), dim3(256), 0, stream, xq, q_bs,
-                       Nq, xk, k_bs, Nk, C, knorm, keyT);
-  }
+  const bool fused = !g_force_unfused && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
   float* kout = dist_out ? keys : nullptr;
-  switch (K) {
-    case 1: launch_select<1>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 3: launch_select<3>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 8: launch_select<8>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 16: launch_select<16>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 20: launch_select<20>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 32: launch_select<32>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 40: launch_select<40>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    case 64: launch_select<64>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
-    default: return -22;
+  if (fused) {
+    hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
+    int rc = 0;
+    if (C == 128 && K == 32) rc = launch_fused<128, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    else if (C == 128) rc = launch_fused<128, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    else if (K == 32) rc = launch_fused<64, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    else rc = launch_fused<64, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    if (rc) return rc;
+  } else {
+    if (smallc) {
+      hipLaunchKernelGGL(smallc_keys_kernel, dim3((Nq + 255) / 256, Nk, B), dim3(256), 0, stream, xq, q_bs, Nq, xk,
+                         k_bs, Nk, C, keyT);
+    } else {
+      hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
+      hipLaunchKernelGGL(gram_keys_kernel, dim3((Nq + 127) / 128, (Nk + 127) / 128, B), dim3(256), 0, stream, xq,
+                         q_bs, Nq, xk, k_bs, Nk, C, knorm, keyT);
+    }
+    switch (K) {
+      case 1: launch_select<1>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 3: launch_select<3>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 8: launch_select<8>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 16: launch_select<16>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 20: launch_select<20>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 32: launch_select<32>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 40: launch_select<40>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      case 64: launch_select<64>(keyT, B, Nq, Nk, idx_out, kout, stream); break;
+      default: return -22;
+    }
   }
   if (dist_out) {
-    if (!smallc) hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
+    if (!smallc && !fused) hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
     hipLaunchKernelGGL(knn_scale_kernel, dim3(B), dim3(256), 0, stream, xq, q_bs, C, Nq, scale);
     const long tot = (long)Nq * K;
     hipLaunchKernelGGL(knn_dist_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, stream, keys, qnorm, scale,
-                       Nq, K, smallc ? 0 : 1, dist_out);
+                       Nq, K, (smallc || fused) ? 0 : 1, dist_out);
   }
   return (int)hipGetLastError();
 }

@@ -37,6 +37,38 @@ def test_knn_feature_space(B, C, N, K):
     assert agree >= 0.9995, agree
 
 
+def test_knn_fused_and_two_kernel_paths_agree():
+    """A/B of the fused Gram+top-K kernel against the round-1 path that writes the key matrix."""
+    from samble_amd import _lib
+    B, C, N, K = 2, 128, 1024, 32
+    x = torch.from_numpy(synth.features(B, C, N, 77)).to(DEV)
+    fused_i, fused_d = ops().stage_knn(x, x, K, want_dist=True)
+    _lib.load().samble_knn_force_unfused(1)
+    try:
+        plain_i, plain_d = ops().stage_knn(x, x, K, want_dist=True)
+    finally:
+        _lib.load().samble_knn_force_unfused(0)
+    assert set_agreement(fused_i.cpu(), plain_i.cpu()) >= 0.9998
+    pts = x.cpu().permute(0, 2, 1)
+    ref_d, ref_i = O.knn(pts, pts, K)
+    assert set_agreement(fused_i.cpu(), ref_i) >= 0.9995
+    torch.testing.assert_close(fused_d.cpu()[:, :, 1:], -ref_d[:, :, 1:], rtol=1e-3, atol=1e-3)
+    # nearest first: distances ascending along K
+    assert bool((fused_d[:, :, 1:] >= fused_d[:, :, :-1] - 1e-6).all())
+
+
+def test_knn_ragged_sizes_fused():
+    B, C, K = 2, 128, 32
+    for Nq, Nk in ((200, 330), (129, 97), (1000, 1000)):
+        a = torch.from_numpy(synth.features(B, C, Nq, Nq)).to(DEV)
+        bset = torch.from_numpy(synth.features(B, C, Nk, Nk + 1)).to(DEV)
+        idx = ops().stage_knn(a, bset, K).cpu()
+        assert int(idx.min()) >= 0 and int(idx.max()) < Nk
+        _, ref_i = O.knn(a.cpu().permute(0, 2, 1), bset.cpu().permute(0, 2, 1), K)
+        assert set_agreement(idx, ref_i) >= 0.999, (Nq, Nk)
+        assert all(len(set(r.tolist())) == K for r in idx.reshape(-1, K)[::17])
+
+
 def test_knn_xyz_cross_set_with_distance():
     B, Nq, Nk, K = 2, 700, 300, 3
     a = torch.from_numpy(synth.xyz_clouds(B, Nq, 11))
