@@ -28,7 +28,8 @@ int samble_launch_gather_rows(const float*, long, long, const long long*, int, i
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
-                           float*, float*, float*, long, long, float*, long, long, float*, long, long, hipStream_t);
+                           float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
+                           hipStream_t);
 }
 
 namespace {
@@ -171,7 +172,8 @@ SAMBLE_API int samble_gather_points_f32(const float* pcd, int B, int C, int N, c
 }
 
 SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int M, int D) {
-  return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + 64) * sizeof(float);
+  const size_t tok_part = (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
+  return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + tok_part + 64) * sizeof(float);
 }
 
 SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
@@ -198,8 +200,10 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
   float* dOb = Qs + (size_t)B * M * D;
   float* lse_s = dOb + (size_t)B * M * D;
   float* delta = lse_s + (size_t)B * M;
+  float* tok_part = delta + (size_t)B * M;
+  if (nt < 0 || nt > 8) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: need 0 <= nt <= 8");
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, lse, (const long long*)idx, g, B, N,
-                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs,
-                                     dV, dv_bs, dv_rs, s),
+                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part, dQ, dq_bs, dq_rs, dK, dk_bs,
+                                     dk_rs, dV, dv_bs, dv_rs, s),
               "samble_attn_bwd_f32");
 }

@@ -7,14 +7,15 @@
 //
 // Four kernels, all deterministic (no float atomics):
 //   bwd_prep        gather the sampled Q rows / lse, transpose the upstream gradient (B,D,M)->(B,M,D),
-//                   delta = rowsum(dO o O_sampled)
+//                   delta = rowsum(dO o O_sampled); while the rows are in registers, also P / dS
+//                   against the nt (<= 8) token keys -> per-workgroup partial dK_tok / dV_tok
 //   bwd_dq          query-stationary: one wave = 32 sampled rows, K/V stream through LDS; recomputes
 //                   S and dP per tile (2x64 MFMA) and accumulates dQ^T (64 MFMA); scatters rows to dQ
 //   bwd_dkdv        key-stationary over the N POINT keys: one wave = 32 keys with K,V rows and the
 //                   dK^T/dV^T accumulators in registers; sampled Q / dO tiles stream through LDS
 //                   (S, dP, dV^T, dK^T = 4x64 MFMA per tile)
-//   bwd_tokens      the nt (<= 8) token keys: tiny VALU kernel (keeps the MFMA grids a whole number
-//                   of rounds: N/32 key waves per cloud instead of N/32 + 1)
+//   bwd_tokens_reduce  fixed-order sum of those partials (token keys stay out of the MFMA grids,
+//                   which keeps them a whole number of rounds: N/32 key waves per cloud, not N/32 + 1)
 #include "samble_dev.h"
 
 namespace samble {
@@ -23,12 +24,16 @@ namespace samble {
 // prep: one workgroup = 32 sampled rows of one cloud
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                       const float* __restrict__ K, long k_bs, long k_rs,
+                                                       const float* __restrict__ V, long v_bs, long v_rs,
                                                        const float* __restrict__ O, const float* __restrict__ lse,
                                                        const long long* __restrict__ idx,
                                                        const float* __restrict__ g,  // (B,128,M)
-                                                       int N, int M, float* __restrict__ Qs, float* __restrict__ dO,
-                                                       float* __restrict__ lse_s, float* __restrict__ delta) {
+                                                       int N, int nt, int M, float scale, float* __restrict__ Qs,
+                                                       float* __restrict__ dO, float* __restrict__ lse_s,
+                                                       float* __restrict__ delta, float* __restrict__ tok_part) {
   __shared__ float gt[128 * 33];
+  __shared__ float red[4][2][8][128];  // [wave][dK|dV][token][channel]
   const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
   const float* gb = g + (long)b * 128 * M;
   for (int e = tid; e < 128 * 32; e += 256) {
@@ -37,12 +42,23 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
   }
   __syncthreads();
   const int sub = tid >> 5, l32 = tid & 31;  // 8 half-waves, each one row at a time
+  // token keys / values: this lane's 4 channels of each of the nt (<= 8) rows
+  f32x4 kt[8], vt[8], ak[8], av[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    kt[t] = (t < nt) ? *reinterpret_cast<const f32x4*>(K + (long)b * k_bs + (long)(N + t) * k_rs + 4 * l32) : z4;
+    vt[t] = (t < nt) ? *reinterpret_cast<const f32x4*>(V + (long)b * v_bs + (long)(N + t) * v_rs + 4 * l32) : z4;
+    ak[t] = z4;
+    av[t] = z4;
+  }
   for (int rr = sub; rr < 32; rr += 8) {
     const int m = m0 + rr;
     if (m >= M) continue;  // uniform per half-wave
     const long row = idx[(long)b * M + m];
     const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + row * q_rs + 4 * l32);
     const f32x4 ov = *reinterpret_cast<const f32x4*>(O + ((long)b * N + row) * 128 + 4 * l32);
+    const float lrow = lse[(long)b * N + row];
     f32x4 dv = {gt[(4 * l32 + 0) * 33 + rr], gt[(4 * l32 + 1) * 33 + rr], gt[(4 * l32 + 2) * 33 + rr],
                 gt[(4 * l32 + 3) * 33 + rr]};
     *reinterpret_cast<f32x4*>(Qs + ((long)b * M + m) * 128 + 4 * l32) = qv;
@@ -52,8 +68,67 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
     if (l32 == 0) {
       delta[(long)b * M + m] = part;
-      lse_s[(long)b * M + m] = lse[(long)b * N + row];
+      lse_s[(long)b * M + m] = lrow;
     }
+    // token keys: P and dS of this row against each token, accumulated into this lane's channels
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < nt) {
+        float st = qv[0] * kt[t][0] + qv[1] * kt[t][1] + qv[2] * kt[t][2] + qv[3] * kt[t][3];
+        float dpt = dv[0] * vt[t][0] + dv[1] * vt[t][1] + dv[2] * vt[t][2] + dv[3] * vt[t][3];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) {
+          st += __shfl_xor(st, off, 64);
+          dpt += __shfl_xor(dpt, off, 64);
+        }
+        const float p = __expf(st * scale - lrow);
+        const float ds = p * (dpt - part) * scale;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[t][u] = fmaf(p, dv[u], av[t][u]);
+          ak[t][u] = fmaf(ds, qv[u], ak[t][u]);
+        }
+      }
+    }
+  }
+  if (nt > 0) {
+    // the two half-waves of a wave first (register exchange), then the 4 waves through LDS, in a
+    // fixed order; one partial per workgroup
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float k2 = ak[t][u] + __shfl_xor(ak[t][u], 32, 64);
+        const float v2 = av[t][u] + __shfl_xor(av[t][u], 32, 64);
+        if ((tid & 32) == 0) {
+          red[tid >> 6][0][t][4 * l32 + u] = k2;
+          red[tid >> 6][1][t][4 * l32 + u] = v2;
+        }
+      }
+    }
+    __syncthreads();
+    float* outp = tok_part + ((long)b * gridDim.x + blockIdx.x) * 2 * 8 * 128;
+    for (int e = tid; e < 2 * 8 * 128; e += 256) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) sacc += (&red[w4][0][0][0])[e];
+      outp[e] = sacc;
+    }
+  }
+}
+
+// dK / dV of the nt token rows: fixed-order sum of the per-workgroup partials of bwd_prep
+__global__ __launch_bounds__(256) void bwd_tokens_reduce_kernel(const float* __restrict__ tok_part, int nparts, int N,
+                                                                int nt, float* __restrict__ dK, long dk_bs, long dk_rs,
+                                                                float* __restrict__ dV, long dv_bs, long dv_rs) {
+  const int b = blockIdx.x;
+  for (int e = threadIdx.x; e < 2 * 8 * 128; e += 256) {
+    const int which = e / (8 * 128), t = (e / 128) & 7, d = e & 127;
+    if (t >= nt) continue;
+    float sacc = 0.f;
+    for (int p = 0; p < nparts; ++p) sacc += tok_part[((long)b * nparts + p) * 2 * 8 * 128 + e];
+    if (which == 0) dK[(long)b * dk_bs + (long)(N + t) * dk_rs + d] = sacc;
+    else dV[(long)b * dv_bs + (long)(N + t) * dv_rs + d] = sacc;
   }
 }
 
@@ -250,65 +325,6 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// token keys: one workgroup (256 threads) per (cloud, token)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_tokens_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
-                                                         const float* __restrict__ lse_s,
-                                                         const float* __restrict__ delta,
-                                                         const float* __restrict__ K, long k_bs, long k_rs,
-                                                         const float* __restrict__ V, long v_bs, long v_rs, int N,
-                                                         int M, float scale, float* __restrict__ dK, long dk_bs,
-                                                         long dk_rs, float* __restrict__ dV, long dv_bs,
-                                                         long dv_rs) {
-  __shared__ float kt[128], vt[128], pbuf[256], dsbuf[256];
-  __shared__ float red[2][2][128];
-  const int b = blockIdx.y, tok = blockIdx.x, tid = threadIdx.x;
-  const long jrow = (long)N + tok;
-  if (tid < 128) {
-    kt[tid] = K[(long)b * k_bs + jrow * k_rs + tid];
-    vt[tid] = V[(long)b * v_bs + jrow * v_rs + tid];
-  }
-  __syncthreads();
-  // thread (d = tid & 127, half = tid >> 7) accumulates over the rows of its half of each chunk
-  const int d = tid & 127, half = tid >> 7;
-  float acc_k = 0.f, acc_v = 0.f;
-  for (int i0 = 0; i0 < M; i0 += 256) {
-    const int i = i0 + tid;
-    float p = 0.f, ds = 0.f;
-    if (i < M) {
-      const f32x4* qp = reinterpret_cast<const f32x4*>(Qs + ((long)b * M + i) * 128);
-      const f32x4* gp = reinterpret_cast<const f32x4*>(dO + ((long)b * M + i) * 128);
-      float s = 0.f, dp = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < 32; ++c) {
-        f32x4 qv = qp[c], gv = gp[c];
-        s += qv[0] * kt[4 * c] + qv[1] * kt[4 * c + 1] + qv[2] * kt[4 * c + 2] + qv[3] * kt[4 * c + 3];
-        dp += gv[0] * vt[4 * c] + gv[1] * vt[4 * c + 1] + gv[2] * vt[4 * c + 2] + gv[3] * vt[4 * c + 3];
-      }
-      p = __expf(s * scale - lse_s[(long)b * M + i]);
-      ds = p * (dp - delta[(long)b * M + i]) * scale;
-    }
-    pbuf[tid] = p;
-    dsbuf[tid] = ds;
-    __syncthreads();
-    const int lim = min(256, M - i0);
-    for (int r = half * 128; r < min(lim, half * 128 + 128); ++r) {
-      const long ro = ((long)b * M + i0 + r) * 128 + d;
-      acc_v += pbuf[r] * dO[ro];
-      acc_k += dsbuf[r] * Qs[ro];
-    }
-    __syncthreads();
-  }
-  red[half][0][d] = acc_k;
-  red[half][1][d] = acc_v;
-  __syncthreads();
-  if (tid < 128) {
-    dK[(long)b * dk_bs + jrow * dk_rs + tid] = red[0][0][tid] + red[1][0][tid];
-    dV[(long)b * dv_bs + jrow * dv_rs + tid] = red[0][1][tid] + red[1][1][tid];
-  }
-}
-
 }  // namespace samble
 
 using namespace samble;
@@ -316,9 +332,9 @@ using namespace samble;
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, const float* O, const float* lse,
                                       const long long* idx, const float* g, int B, int N, int nt, int M, float scale,
-                                      float* Qs, float* dOb, float* lse_s, float* delta, float* dQ, long dq_bs,
-                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                      hipStream_t stream) {
+                                      float* Qs, float* dOb, float* lse_s, float* delta, float* tok_part, float* dQ,
+                                      long dq_bs, long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs,
+                                      long dv_rs, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
   if (!attr_set) {
@@ -331,14 +347,15 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     attr_set = true;
   }
   const int NK = N + nt;
-  hipLaunchKernelGGL(bwd_prep_kernel, dim3((M + 31) / 32, B), dim3(256), 0, stream, Q, q_bs, q_rs, O, lse, idx, g, N, M,
-                     Qs, dOb, lse_s, delta);
+  const int nparts = (M + 31) / 32;
+  hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
+                     O, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part);
   hipLaunchKernelGGL(bwd_dq_kernel, dim3((M + 127) / 128, B), dim3(256), lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs,
                      k_rs, V, v_bs, v_rs, idx, N, NK, M, scale, dQ, dq_bs, dq_rs);
   hipLaunchKernelGGL(bwd_dkdv_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K,
                      k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
   if (nt > 0)
-    hipLaunchKernelGGL(bwd_tokens_kernel, dim3(nt, B), dim3(256), 0, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs, V,
-                       v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
+    hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(B), dim3(256), 0, stream, tok_part, nparts, N, nt, dK, dk_bs,
+                       dk_rs, dV, dv_bs, dv_rs);
   return (int)hipGetLastError();
 }

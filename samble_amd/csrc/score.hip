@@ -30,14 +30,24 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(sraw);
   int* cnt = reinterpret_cast<int*>(acc + N);
-  const int tid = threadIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB
+  // L2), so give every XCD its own clouds: the K rows a cloud's workgroups gather (1 MB) are then
+  // re-read from that XCD's L2 instead of the Infinity Cache.  Speed only; any mapping is correct.
+  int b = blockIdx.y, chunk = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, slot = lin >> 3, per = gridDim.y >> 3;
+    b = xcd * per + slot % per;
+    chunk = slot / per;
+  }
   for (int n = tid; n < N; n += 256) {
     acc[n] = 0ull;
     cnt[n] = 0;
   }
   __syncthreads();
   const int hw = tid >> 5, c = tid & 31;
-  const int r0 = blockIdx.x * 64;
+  const int r0 = chunk * 64;
   const float* Qb = Q + (long)b * q_bs;
   const float* Kb = K + (long)b * k_bs;
   for (int i = r0 + hw; i < min(r0 + 64, N); i += 8) {

@@ -56,7 +56,17 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
   // ---- pass 0: top 12 bits, one histogram shared by every rank
   for (int e = tid; e < 4096; e += 1024) hist[e] = 0u;
   __syncthreads();
-  for (long e = tid; e < n; e += 1024) atomicAdd(&hist[4095u - (ordered_bits(z[e]) >> 20)], 1u);
+  for (long e0 = 0; e0 < n; e0 += 8 * 1024) {  // 8 loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long e = e0 + u * 1024 + tid;
+      v[u] = (e < n) ? z[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * 1024 + tid < n) atomicAdd(&hist[4095u - (ordered_bits(v[u]) >> 20)], 1u);
+  }
   __syncthreads();
   {
     unsigned int loc[4], ts = 0u;
@@ -92,12 +102,26 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
     const int shift = (pass == 1) ? 10 : 0;
     for (int e = tid; e < nq * 1024; e += 1024) hist[e] = 0u;
     __syncthreads();
-    for (long e = tid; e < n; e += 1024) {
-      const unsigned int key = ordered_bits(z[e]);
-      const unsigned int hi = key >> (shift + 10);
-      const unsigned int dig = 1023u - ((key >> shift) & 1023u);
-      for (int t = 0; t < nq; ++t)
-        if (hi == (prefix[t] >> (shift + 10))) atomicAdd(&hist[t * 1024 + dig], 1u);
+    unsigned int want[kMaxBins];
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) want[t] = (t < nq) ? (prefix[t] >> (shift + 10)) : 0xFFFFFFFFu;
+    for (long e0 = 0; e0 < n; e0 += 8 * 1024) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long e = e0 + u * 1024 + tid;
+        v[u] = (e < n) ? z[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (e0 + u * 1024 + tid >= n) continue;
+        const unsigned int key = ordered_bits(v[u]);
+        const unsigned int hi = key >> (shift + 10);
+        const unsigned int dig = 1023u - ((key >> shift) & 1023u);
+#pragma unroll
+        for (int t = 0; t < kMaxBins; ++t)
+          if (t < nq && hi == want[t]) atomicAdd(&hist[t * 1024 + dig], 1u);
+      }
     }
     __syncthreads();
     for (int t = 0; t < nq; ++t) {
