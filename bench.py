@@ -61,13 +61,12 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
     with torch.no_grad():
         B = x.shape[0]
         nt = mod.bin_tokens.shape[2]
-        tokens = mod.bin_tokens.expand(B, -1, -1)
-        xt = torch.cat((x, tokens), dim=2)
         w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight), 0).squeeze(-1)
-        qkv = torch.matmul(xt.transpose(1, 2), w.t())
+        tokm = mod.bin_tokens[0]
+        qkv = ops.stage_proj_fwd(x, tokm, w)
         q, k, v = qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
         out = {}
-        out["proj_qkv(torch)"] = time_region(lambda: torch.matmul(xt.transpose(1, 2), w.t()), iters)
+        out["proj_fwd"] = time_region(lambda: ops.stage_proj_fwd(x, tokm, w), iters)
         out["knn"] = time_region(lambda: ops.stage_knn(x, x, KNN), iters)
         nn_idx = ops.stage_knn(x, x, KNN)
         out["attn_fwd"] = time_region(lambda: ops.stage_attn_fwd(q, k, v, N, nt), iters)
@@ -88,6 +87,7 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
         out["attn_bwd"] = time_region(
             lambda: ops.stage_attn_bwd(q, k, v, O, lse, idx, g, N, nt, dqkv[:, :N, :C], dqkv[:, :, C:2 * C],
                                        dqkv[:, :, 2 * C:]), iters)
+        out["proj_bwd"] = time_region(lambda: ops.stage_proj_bwd(dqkv, x, tokm, w, True, True), iters)
     return out
 
 

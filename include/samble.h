@@ -64,6 +64,19 @@ int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64
  * fused Gram + top-K kernel.  Process-wide; not for production use. */
 void samble_knn_force_unfused(int on);
 
+/* ---- models/downsample.py:116-137  q_conv / k_conv / v_conv (bias-free 1x1 Conv1d) ------------
+ * x (B,C,N) channel-major, tokens (C,nt) = bin_tokens[0], W (3C,C) row-major = [Wq; Wk; Wv]
+ * (each conv weight (C,C,1) squeezed).  qkv (B,N+nt,3C) point-major rows [Q|K|V] with the given
+ * strides: rows 0..N-1 project the points, rows N.. the bin tokens (Q of a token row is unused).
+ * C = 128 in this round.  The backward writes dx (B,C,N) (NULL to skip), dW (3C,C) and
+ * dtokens (C,nt) (dW NULL skips both), all deterministic. */
+size_t samble_proj_workspace_bytes(int B, int N);
+int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt, const float* W,
+                        float* qkv, int64_t o_bs, int64_t o_rs, void* ws, size_t ws_bytes, void* stream);
+int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
+                        int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
+                        float* dtokens, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
  * the N point rows).  O (B,N,D) contiguous: row i = softmax(Q_i K^T / sqrt(D)) V, the row the

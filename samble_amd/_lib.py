@@ -25,6 +25,12 @@ _SIGNATURES = {
     "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_proj_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "samble_proj_fwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "samble_proj_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
+                                    c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
     "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_score_workspace_bytes": (c_size_t, [c_int, c_int]),

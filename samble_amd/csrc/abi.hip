@@ -26,6 +26,11 @@ int samble_launch_bin_select(const float*, const float*, const unsigned char*, c
                              int, int, int, float, long long*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
+int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
+                           hipStream_t);
+size_t samble_proj_bwd_ws_floats(int B, int N);
+int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
+                           float*, long, float*, float*, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
                            float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
@@ -206,4 +211,37 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
                                      nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part, dQ, dq_bs, dq_rs, dK, dk_bs,
                                      dk_rs, dV, dv_bs, dv_rs, s),
               "samble_attn_bwd_f32");
+}
+
+SAMBLE_API size_t samble_proj_workspace_bytes(int B, int N) {
+  const size_t fwd = 8 * 384 * sizeof(float);
+  const size_t bwd = samble_proj_bwd_ws_floats(B, N) * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+SAMBLE_API int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
+                                   const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  if (!x || !W || !qkv || !ws || (nt > 0 && !tokens)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: null pointer");
+  if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: C = D must be 128");
+  if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: bad B/N/nt");
+  if ((o_rs & 3) || (o_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: output strides must be multiples of 4");
+  if (ws_bytes < 8 * 384 * sizeof(float)) return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_f32: workspace too small");
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, (hipStream_t)stream),
+              "samble_proj_fwd_f32");
+}
+
+SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
+                                   int C, int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs,
+                                   float* dW, float* dtokens, void* ws, size_t ws_bytes, void* stream) {
+  if (!dqkv || !x || !W || !ws) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: null pointer");
+  if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: C = D must be 128");
+  if (nt < 0 || nt > 8) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: need 0 <= nt <= 8");
+  if (dW && nt > 0 && (!dtokens || !tokens)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: dtokens/tokens missing");
+  if ((g_rs & 3) || (g_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: strides must be multiples of 4");
+  if (ws_bytes < samble_proj_bwd_ws_floats(B, N) * sizeof(float))
+    return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_f32: workspace too small");
+  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws,
+                                     (hipStream_t)stream),
+              "samble_proj_bwd_f32");
 }

@@ -1,0 +1,326 @@
+// QKV projection of the sampler (reference models/downsample.py:116-137: three bias-free 1x1 Conv1d
+// on x and on x || bin_tokens) and its backward, fp32 MFMA.
+//
+//   qkv[b][n][o] = sum_c W[o][c] * xt[b][c][n]     o in [0,3D): rows of W = [Wq; Wk; Wv], D = C = 128
+//                                                   n < N: point n of x (B,C,N channel-major)
+//                                                   n >= N: bin token n-N (tokens (C,nt), shared by the batch)
+//   proj_fwd     wave = 32 points held in registers (coalesced channel-major loads), W streams
+//                through LDS in 32-row tiles; output rows are point-major [Q|K|V] (what the
+//                attention kernels read).  The nt token rows are batch-independent: computed once
+//                (proj_tok_fwd) and copied into each cloud by its first workgroup, so x is never
+//                concatenated or copied and the MFMA grid stays N/128 workgroups per cloud.
+//   proj_dx      dx[b][c][n] = sum_o W[o][c] dqkv[b][n][o]: wave = 32 points, dqkv rows in registers
+//                128 outputs at a time, W^T from LDS; writes channel-major dx directly.
+//   proj_dw      dW[o][c] = sum_{b,n} dqkv[b][n][o] xt[b][c][n]: workgroup = 256 points of one cloud,
+//                full 384x128 partial in registers (4 waves x 12 tiles), partials summed in a fixed
+//                order by proj_dw_reduce (deterministic, no float atomics).
+//   proj_tok_bwd dtokens[c][t] and the token rows' share of dW (nt <= 8 rows: VALU).
+#include "samble_dev.h"
+
+namespace samble {
+
+constexpr int kC = 128;
+constexpr int kO = 384;
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+constexpr int kProjLdsFloats = 2 * kTile * kLdsPad;
+
+// token rows are the same for every cloud: tokqkv[t][o] = sum_c W[o][c] tokens[c][t], computed once
+__global__ __launch_bounds__(384) void proj_tok_fwd_kernel(const float* __restrict__ tokens, int nt,
+                                                           const float* __restrict__ W, float* __restrict__ tokqkv) {
+  __shared__ float tk[kC * 8];
+  const int o = threadIdx.x;
+  for (int e = o; e < kC * nt; e += 384) tk[e] = tokens[e];
+  __syncthreads();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f32x4* wrow = reinterpret_cast<const f32x4*>(W + (long)o * kC);
+  for (int c4 = 0; c4 < kC / 4; ++c4) {
+    const f32x4 w = wrow[c4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      for (int t = 0; t < nt; ++t) acc[t] = fmaf(w[u], tk[(4 * c4 + u) * nt + t], acc[t]);
+  }
+  for (int t = 0; t < nt; ++t) tokqkv[t * kO + o] = acc[t];
+}
+
+__global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restrict__ x, long x_bs, int N,
+                                                          const float* __restrict__ tokqkv, int nt,
+                                                          const float* __restrict__ W,  // (384,128) row-major
+                                                          float* __restrict__ qkv, long o_bs, long o_rs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 128 + wave * 32 + lo;
+  const bool nvalid = n < N;
+
+  if (blockIdx.x == 0) {  // this cloud's copy of the token rows
+    for (int e = tid; e < nt * kO; e += 256)
+      qkv[(long)b * o_bs + (long)(N + e / kO) * o_rs + (e % kO)] = tokqkv[e];
+  }
+  float xr[64];
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) xr[kk] = nvalid ? x[(long)b * x_bs + (long)(64 * h + kk) * N + n] : 0.f;
+  TileRegs wr;
+  tile_load_issue(wr, W, kC, 0, kO, tid);
+  tile_store_lds(wr, smem, kLdsPad, tid);
+  __syncthreads();
+  float* orow = qkv + (long)b * o_bs + (long)n * o_rs;
+  for (int t = 0; t < kO / kTile; ++t) {
+    float* cur = smem + (t & 1) * kTile * kLdsPad;
+    float* nxt = smem + ((t & 1) ^ 1) * kTile * kLdsPad;
+    if (t + 1 < kO / kTile) tile_load_issue(wr, W, kC, (t + 1) * kTile, kO, tid);
+    // D[row = output o][col = point n]
+    f32x16 acc = mma_rows_x_regs(cur, kLdsPad, lo, h, xr, zero16());
+    if (nvalid) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + t * kTile + 8 * g + 4 * h) = o;
+      }
+    }
+    if (t + 1 < kO / kTile) tile_store_lds(wr, nxt, kLdsPad, tid);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dx
+// ------------------------------------------------------------------------------------------------
+constexpr int kDxLdsFloats = 128 * 128;  // one 128-output chunk of W, [o][c]
+
+__global__ __launch_bounds__(256, 2) void proj_dx_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
+                                                         const float* __restrict__ W, int N,
+                                                         float* __restrict__ dx, long dx_bs) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int n = blockIdx.x * 128 + wave * 32 + lo;
+  const bool nvalid = n < N;
+  const float* grow = dqkv + (long)b * g_bs + (long)n * g_rs;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
+  for (int chunk = 0; chunk < 3; ++chunk) {
+    __syncthreads();  // previous chunk fully consumed
+    for (int e = tid; e < 128 * 32; e += 256) {
+      const int r = e >> 5, c4 = (e & 31) * 4;
+      *reinterpret_cast<f32x4*>(Ws + r * 128 + c4) =
+          *reinterpret_cast<const f32x4*>(W + (long)(chunk * 128 + r) * kC + c4);
+    }
+    float gr[64];
+    if (nvalid) {
+      load_row_half(grow + chunk * 128, h, gr);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) gr[i] = 0.f;
+    }
+    __syncthreads();
+    // D[row = channel c][col = point n] += sum_o W[o][c] * dqkv[n][o];  o = 64h + kk within the chunk
+    const float* wp = Ws + (64 * h) * 128 + lo;
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      const float bval = gr[kk];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(wp[kk * 128 + 32 * ct], bval, acc[ct]);
+    }
+  }
+  if (nvalid) {
+    float* out = dx + (long)b * dx_bs + n;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW partials: workgroup = (cloud b, 256-point chunk); wave w owns output rows 96w .. 96w+95
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwPts = 256;
+constexpr int kDwLdsFloats = 2 * (kTile * 388 + kC * 33);  // dqkv tile [32 n][384 o] + x tile [128 c][32 n]
+
+__global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
+                                                         const float* __restrict__ x, long x_bs, int N,
+                                                         float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int GS = 388;  // row stride of the dqkv tile (rows 16-byte aligned, column reads conflict-free)
+  constexpr int XS = 33;
+  constexpr int BUF = kTile * GS + kC * XS;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * kDwPts;
+
+  f32x16 acc[3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = zero16();
+
+  f32x4 gst[12];  // 32 rows x 96 float4 = 3072 float4 / 256 threads
+  float xst[16];  // 128 channels x 32 points = 4096 floats / 256 threads
+  auto issue = [&](int nn0) {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int e = tid + 256 * it;
+      const int r = e / 96, c4 = (e % 96) * 4;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      gst[it] = (nn0 + r < N) ? *reinterpret_cast<const f32x4*>(dqkv + (long)b * g_bs + (long)(nn0 + r) * g_rs + c4) : z4;
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = tid + 256 * it;
+      const int c = e >> 5, p = e & 31;
+      xst[it] = (nn0 + p < N) ? x[(long)b * x_bs + (long)c * N + nn0 + p] : 0.f;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int e = tid + 256 * it;
+      const int r = e / 96, c4 = (e % 96) * 4;
+      *reinterpret_cast<f32x4*>(buf + r * GS + c4) = gst[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = tid + 256 * it;
+      buf[kTile * GS + (e >> 5) * XS + (e & 31)] = xst[it];
+    }
+  };
+  const int ntiles = kDwPts / kTile;
+  issue(n0);
+  commit(smem);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    float* cur = smem + (t & 1) * BUF;
+    float* nxt = smem + ((t & 1) ^ 1) * BUF;
+    if (t + 1 < ntiles) issue(n0 + (t + 1) * kTile);
+    const float* gt = cur;
+    const float* xt = cur + kTile * GS;
+    // D[row = o][col = c] += sum_n dqkv[n][o] * x[c][n];  n = 16h + kk within the tile
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int nn = 16 * h + kk;
+      float a[3], bb[4];
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot) a[ot] = gt[nn * GS + 96 * wave + 32 * ot + lo];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bb[ct] = xt[(32 * ct + lo) * XS + nn];
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ot][ct] = mfma32(a[ot], bb[ct], acc[ot][ct]);
+    }
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * kO * kC;
+#pragma unroll
+  for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 96 * wave + 32 * ot + crow(r, h);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) out[(long)o * kC + 32 * ct + lo] = acc[ot][ct][r];
+    }
+}
+
+// dW[e] = sum over partials (fixed order) + token-row contribution
+__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nparts,
+                                                             const float* __restrict__ dw_tok,
+                                                             float* __restrict__ dW) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= kO * kC) return;
+  float s = dw_tok ? dw_tok[e] : 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * kO * kC + e];
+  dW[e] = s;
+}
+
+// token rows: gsum[t][o] = sum_b dqkv[b][N+t][o];  dtok[c][t] = sum_o W[o][c] gsum[t][o];
+// dw_tok[o][c] = sum_t gsum[t][o] * tokens[c][t].   One workgroup.
+__global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs, int B,
+                                                           int N, int nt, const float* __restrict__ W,
+                                                           const float* __restrict__ tokens,
+                                                           float* __restrict__ dtok, float* __restrict__ dw_tok) {
+  __shared__ float gsum[8][kO];
+  const int o = threadIdx.x;  // 384 threads
+  for (int t = 0; t < nt; ++t) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
+    gsum[t][o] = s;
+  }
+  __syncthreads();
+  for (int c = 0; c < kC; ++c) {
+    float s = 0.f;
+    for (int t = 0; t < nt; ++t) s += gsum[t][o] * tokens[c * nt + t];
+    dw_tok[(long)o * kC + c] = s;
+  }
+  if (o < kC) {  // thread = channel: W[oo][c] is read coalesced
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int oo = 0; oo < kO; ++oo) {
+      const float w = W[(long)oo * kC + o];
+      for (int t = 0; t < nt; ++t) acc[t] = fmaf(w, gsum[t][oo], acc[t]);
+    }
+    for (int t = 0; t < nt; ++t) dtok[o * nt + t] = acc[t];
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, const float* tokens, int nt,
+                                      const float* W, float* qkv, long o_bs, long o_rs, float* ws, hipStream_t s) {
+  const size_t lds = kProjLdsFloats * sizeof(float);
+  float* tokqkv = ws;  // 8 x 384 floats
+  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(1), dim3(384), 0, s, tokens, nt, W, tokqkv);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(proj_fwd_kernel, dim3((N + 127) / 128, B), dim3(256), lds, s, x, x_bs, N, tokqkv, nt, W, qkv, o_bs,
+                     o_rs);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
+  const size_t nparts = (size_t)B * ((N + kDwPts - 1) / kDwPts);
+  return nparts * kO * kC + (size_t)kO * kC + 64;
+}
+
+extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
+                                      const float* tokens, int nt, const float* W, float* dx, long dx_bs, float* dW,
+                                      float* dtok, float* ws, hipStream_t s) {
+  static bool attr_set = false;
+  const size_t lds_dx = kDxLdsFloats * sizeof(float), lds_dw = kDwLdsFloats * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dw_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dx);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int chunks = (N + kDwPts - 1) / kDwPts;
+  float* part = ws;
+  float* dw_tok = ws + (size_t)B * chunks * kO * kC;
+  if (dx) hipLaunchKernelGGL(proj_dx_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dx, s, dqkv, g_bs, g_rs, W, N, dx, dx_bs);
+  if (dW) {
+    hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
+    if (nt > 0)
+      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(1), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, tokens, dtok,
+                         dw_tok);
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((kO * kC + 255) / 256), dim3(256), 0, s, part, B * chunks,
+                       nt > 0 ? dw_tok : nullptr, dW);
+  }
+  return (int)hipGetLastError();
+}

@@ -7,8 +7,9 @@ side-effect attributes (`attention_point_score`, `bin_boundaries`, `bin_points_m
 `bin_weights_beforerelu`, `k_point_to_choose`, `idx`, `attention_bins_beforesoftmax`) as the
 reference, so `cls_model` / `seg_model` can use it unchanged and reference checkpoints load.
 
-What differs is how the work is done: the QKV projection is one torch matmul (hipBLASLt) producing
-point-major rows, and everything after it is a single autograd node over hand-written HIP kernels:
+What differs is how the work is done: two autograd nodes over hand-written HIP kernels, the QKV
+projection (one fp32-MFMA kernel producing point-major rows; backward dx / dW / dtokens) and the
+sampler core:
 kNN build -> flash attention over all rows (no N x N tensor) -> exact sparse column score ->
 batch quantiles -> [RCCL all-reduce of nb-1 floats] -> bins / counts / per-bin selection -> row
 gather; backward is a flash-attention backward over the M sampled rows only.
@@ -23,6 +24,30 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+
+
+class _Projection(torch.autograd.Function):
+    """q_conv / k_conv / v_conv of the reference (bias-free 1x1 Conv1d, models/downsample.py:54-56,
+    124-137) as ONE fp32-MFMA kernel producing point-major [Q|K|V] rows for x and the bin tokens."""
+
+    @staticmethod
+    def forward(ctx, x, tokens, wq, wk, wv):
+        w = torch.cat((wq, wk, wv), dim=0).squeeze(-1)  # (3C, C)
+        tok = tokens[0]                                  # (C, nt)
+        ctx.save_for_backward(x, tok, w)
+        ctx.splits = (wq.shape[0], wk.shape[0], wv.shape[0])
+        return ops.stage_proj_fwd(x, tok, w)
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        x, tok, w = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[1:])
+        dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw)
+        if not need_dw:
+            return dx, None, None, None, None
+        a, b, c = ctx.splits
+        return (dx, dtok.unsqueeze(0), dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1))
 
 
 class _SamplerCore(torch.autograd.Function):
@@ -163,10 +188,10 @@ class DownSampleToken(nn.Module):
         B, C, N = x.shape
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
-        tokens = self.bin_tokens.expand(B, -1, -1)
-        x_and_token = torch.cat((x, tokens), dim=2)  # (B, C, N+nt)
-        w_qkv = torch.cat((self.q_conv.weight, self.k_conv.weight, self.v_conv.weight), dim=0).squeeze(-1)
-        qkv = torch.matmul(x_and_token.transpose(1, 2), w_qkv.t())  # (B, N+nt, 3D) point-major rows
+        if C != 128 or self.q_depth != 128 or self.k_depth != 128 or self.v_depth != 128:
+            raise NotImplementedError("the HIP kernels are built for C = q_out = k_out = v_out = 128 (shipped configs)")
+        # (B, N+nt, 3D) point-major rows [Q|K|V]; rows N.. are the bin tokens
+        qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
 
         (x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx) = _SamplerCore.apply(
             qkv, x.detach(), self, noise)

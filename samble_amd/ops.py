@@ -62,6 +62,41 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     return (idx, dist) if want_dist else idx
 
 
+def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor) -> torch.Tensor:
+    """x (B,C,N), tokens (C,nt), w_qkv (3C,C) -> qkv (B,N+nt,3C) point-major rows [Q|K|V]."""
+    _need_gpu(x, tokens, w_qkv)
+    x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
+    B, C, N = x.shape
+    nt = tokens.shape[1]
+    with torch.cuda.device(x.device):
+        qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)
+        nbytes = 8 * 384 * 4
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call("samble_proj_fwd_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
+                  qkv.data_ptr(), qkv.stride(0), qkv.stride(1), ws.data_ptr(), nbytes, _stream())
+    return qkv
+
+
+def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
+    """-> (dx (B,C,N) | None, dW (3C,C) | None, dtokens (C,nt) | None)."""
+    _need_gpu(dqkv, x, tokens, w_qkv)
+    x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
+    if dqkv.stride(2) != 1:
+        dqkv = dqkv.contiguous()
+    B, C, N = x.shape
+    nt = tokens.shape[1]
+    with torch.cuda.device(x.device):
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w_qkv) if need_dw else None
+        dtok = torch.empty_like(tokens) if need_dw else None
+        nbytes = _lib.query("samble_proj_workspace_bytes", B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call("samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
+                  tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
+                  _stream())
+    return dx, dw, dtok
+
+
 def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int):
     """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->
     O (B,N,D), lse (B,N), token logits (B,N,nt)."""

@@ -92,6 +92,31 @@ def test_knn_reference_named_wrapper():
 
 
 # ---------------------------------------------------------------------------------------------
+# QKV projection
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,nt", [(2, 256, 6), (3, 1000, 4), (2, 2048, 6), (1, 100, 1)])
+def test_projection_forward_backward(B, N, nt):
+    C = 128
+    x = torch.from_numpy(synth.features(B, C, N, 40 + N))
+    tok = torch.from_numpy(synth.normal((C, nt), 41)) * 0.1
+    w = torch.from_numpy(synth.normal((3 * C, C), 42)) * 0.09
+    g = torch.from_numpy(synth.normal((B, N + nt, 3 * C), 43))
+    xd, td, wd = (t.double().requires_grad_(True) for t in (x, tok, w))
+    xt = torch.cat((xd, td.unsqueeze(0).expand(B, -1, -1)), dim=2)
+    ref = torch.matmul(xt.transpose(1, 2), wd.t())
+    ref.backward(g.double())
+    got = ops().stage_proj_fwd(x.to(DEV), tok.to(DEV), w.to(DEV))
+    torch.testing.assert_close(got.cpu().double(), ref.detach(), rtol=2e-5, atol=2e-5)
+    dx, dw, dtok = ops().stage_proj_bwd(g.to(DEV), x.to(DEV), tok.to(DEV), w.to(DEV), True, True)
+    for a, r, name in ((dx, xd.grad, "dx"), (dw, wd.grad, "dW"), (dtok, td.grad, "dtokens")):
+        err = (a.cpu().double() - r).abs().max().item()
+        assert err <= 3e-5 * r.abs().max().item() + 1e-6, (name, err)
+    # run-to-run identical (fixed-order reductions)
+    dx2, dw2, dtok2 = ops().stage_proj_bwd(g.to(DEV), x.to(DEV), tok.to(DEV), w.to(DEV), True, True)
+    assert torch.equal(dw, dw2) and torch.equal(dx, dx2) and torch.equal(dtok, dtok2)
+
+
+# ---------------------------------------------------------------------------------------------
 # attention forward / backward
 # ---------------------------------------------------------------------------------------------
 def _qkv(B, N, nt, seed, D=128):
