@@ -117,19 +117,26 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
   }
 }
 
-// dK / dV of the nt token rows: fixed-order sum of the per-workgroup partials of bwd_prep
-__global__ __launch_bounds__(256) void bwd_tokens_reduce_kernel(const float* __restrict__ tok_part, int nparts, int N,
+// dK / dV of the nt token rows: fixed-order sum of the per-workgroup partials of bwd_prep.
+// grid (16 = dK|dV x token, B), 128 threads = channels
+__global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __restrict__ tok_part, int nparts, int N,
                                                                 int nt, float* __restrict__ dK, long dk_bs, long dk_rs,
                                                                 float* __restrict__ dV, long dv_bs, long dv_rs) {
-  const int b = blockIdx.x;
-  for (int e = threadIdx.x; e < 2 * 8 * 128; e += 256) {
-    const int which = e / (8 * 128), t = (e / 128) & 7, d = e & 127;
-    if (t >= nt) continue;
-    float sacc = 0.f;
-    for (int p = 0; p < nparts; ++p) sacc += tok_part[((long)b * nparts + p) * 2 * 8 * 128 + e];
-    if (which == 0) dK[(long)b * dk_bs + (long)(N + t) * dk_rs + d] = sacc;
-    else dV[(long)b * dv_bs + (long)(N + t) * dv_rs + d] = sacc;
+  const int b = blockIdx.y, which = blockIdx.x >> 3, t = blockIdx.x & 7, d = threadIdx.x;
+  if (t >= nt) return;
+  const float* src = tok_part + (long)b * nparts * 2 * 8 * 128 + (which * 8 + t) * 128 + d;
+  float sacc = 0.f;
+  int p = 0;
+  for (; p + 8 <= nparts; p += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long)(p + u) * 2 * 8 * 128];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sacc += v[u];
   }
+  for (; p < nparts; ++p) sacc += src[(long)p * 2 * 8 * 128];
+  if (which == 0) dK[(long)b * dk_bs + (long)(N + t) * dk_rs + d] = sacc;
+  else dV[(long)b * dv_bs + (long)(N + t) * dv_rs + d] = sacc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,7 +362,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   hipLaunchKernelGGL(bwd_dkdv_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K,
                      k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
   if (nt > 0)
-    hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(B), dim3(256), 0, stream, tok_part, nparts, N, nt, dK, dk_bs,
+    hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(16, B), dim3(128), 0, stream, tok_part, nparts, N, nt, dK, dk_bs,
                        dk_rs, dV, dv_bs, dv_rs);
   return (int)hipGetLastError();
 }

@@ -27,22 +27,28 @@ constexpr int kO = 384;
 // ------------------------------------------------------------------------------------------------
 constexpr int kProjLdsFloats = 2 * kTile * kLdsPad;
 
-// token rows are the same for every cloud: tokqkv[t][o] = sum_c W[o][c] tokens[c][t], computed once
-__global__ __launch_bounds__(384) void proj_tok_fwd_kernel(const float* __restrict__ tokens, int nt,
-                                                           const float* __restrict__ W, float* __restrict__ tokqkv) {
-  __shared__ float tk[kC * 8];
-  const int o = threadIdx.x;
-  for (int e = o; e < kC * nt; e += 384) tk[e] = tokens[e];
-  __syncthreads();
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const f32x4* wrow = reinterpret_cast<const f32x4*>(W + (long)o * kC);
-  for (int c4 = 0; c4 < kC / 4; ++c4) {
-    const f32x4 w = wrow[c4];
+// token rows are the same for every cloud: tokqkv[t][o] = sum_c W[o][c] tokens[c][t], computed once.
+// One wave per 8 outputs; lanes span the channels (coalesced 512-byte reads of W rows).
+__global__ __launch_bounds__(64) void proj_tok_fwd_kernel(const float* __restrict__ tokens, int nt,
+                                                          const float* __restrict__ W, float* __restrict__ tokqkv) {
+  const int lane = threadIdx.x;
+  float tk0[8], tk1[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      for (int t = 0; t < nt; ++t) acc[t] = fmaf(w[u], tk[(4 * c4 + u) * nt + t], acc[t]);
+  for (int t = 0; t < 8; ++t) {
+    tk0[t] = (t < nt) ? tokens[lane * nt + t] : 0.f;
+    tk1[t] = (t < nt) ? tokens[(lane + 64) * nt + t] : 0.f;
   }
-  for (int t = 0; t < nt; ++t) tokqkv[t * kO + o] = acc[t];
+  for (int oo = 0; oo < 8; ++oo) {
+    const int o = blockIdx.x * 8 + oo;
+    const float w0 = W[(long)o * kC + lane], w1 = W[(long)o * kC + lane + 64];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float p = fmaf(w0, tk0[t], w1 * tk1[t]);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+      if (lane == 0 && t < nt) tokqkv[t * kO + o] = p;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restrict__ x, long x_bs, int N,
@@ -230,43 +236,45 @@ __global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict
     }
 }
 
-// dW[e] = sum over partials (fixed order) + token-row contribution
+// dW[o][c] = sum over the per-chunk partials (fixed order) + the token rows' share
+//            sum_t gsum[t][o] * tokens[c][t]
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nparts,
-                                                             const float* __restrict__ dw_tok,
+                                                             const float* __restrict__ gsum,
+                                                             const float* __restrict__ tokens, int nt,
                                                              float* __restrict__ dW) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= kO * kC) return;
-  float s = dw_tok ? dw_tok[e] : 0.f;
-  for (int p = 0; p < nparts; ++p) s += part[(long)p * kO * kC + e];
+  float s = 0.f;
+  int p = 0;
+  for (; p + 8 <= nparts; p += 8) {  // 8 loads in flight, summed in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(long)(p + u) * kO * kC + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < nparts; ++p) s += part[(long)p * kO * kC + e];
+  const int o = e / kC, c = e % kC;
+  for (int t = 0; t < nt; ++t) s = fmaf(gsum[t * kO + o], tokens[c * nt + t], s);
   dW[e] = s;
 }
 
-// token rows: gsum[t][o] = sum_b dqkv[b][N+t][o];  dtok[c][t] = sum_o W[o][c] gsum[t][o];
-// dw_tok[o][c] = sum_t gsum[t][o] * tokens[c][t].   One workgroup.
+// token rows, one workgroup per token t: gsum[t][o] = sum_b dqkv[b][N+t][o] (fixed order), then
+// dtokens[c][t] = sum_o W[o][c] gsum[t][o] (thread = channel, W read coalesced)
 __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs, int B,
                                                            int N, int nt, const float* __restrict__ W,
-                                                           const float* __restrict__ tokens,
-                                                           float* __restrict__ dtok, float* __restrict__ dw_tok) {
-  __shared__ float gsum[8][kO];
-  const int o = threadIdx.x;  // 384 threads
-  for (int t = 0; t < nt; ++t) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
-    gsum[t][o] = s;
-  }
+                                                           float* __restrict__ gsum, float* __restrict__ dtok) {
+  __shared__ float gs[kO];
+  const int t = blockIdx.x, o = threadIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
+  gs[o] = s;
+  gsum[t * kO + o] = s;
   __syncthreads();
-  for (int c = 0; c < kC; ++c) {
-    float s = 0.f;
-    for (int t = 0; t < nt; ++t) s += gsum[t][o] * tokens[c * nt + t];
-    dw_tok[(long)o * kC + c] = s;
-  }
-  if (o < kC) {  // thread = channel: W[oo][c] is read coalesced
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int oo = 0; oo < kO; ++oo) {
-      const float w = W[(long)oo * kC + o];
-      for (int t = 0; t < nt; ++t) acc[t] = fmaf(w, gsum[t][oo], acc[t]);
-    }
-    for (int t = 0; t < nt; ++t) dtok[o * nt + t] = acc[t];
+  if (o < kC) {
+    float acc = 0.f;
+    for (int oo = 0; oo < kO; ++oo) acc = fmaf(W[(long)oo * kC + o], gs[oo], acc);
+    dtok[o * nt + t] = acc;
   }
 }
 
@@ -278,7 +286,7 @@ extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, c
                                       const float* W, float* qkv, long o_bs, long o_rs, float* ws, hipStream_t s) {
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
-  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(1), dim3(384), 0, s, tokens, nt, W, tokqkv);
+  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 8), dim3(64), 0, s, tokens, nt, W, tokqkv);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
@@ -312,15 +320,14 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   }
   const int chunks = (N + kDwPts - 1) / kDwPts;
   float* part = ws;
-  float* dw_tok = ws + (size_t)B * chunks * kO * kC;
+  float* gsum = ws + (size_t)B * chunks * kO * kC;  // 8 x 384
   if (dx) hipLaunchKernelGGL(proj_dx_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dx, s, dqkv, g_bs, g_rs, W, N, dx, dx_bs);
   if (dW) {
     hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     if (nt > 0)
-      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(1), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, tokens, dtok,
-                         dw_tok);
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((kO * kC + 255) / 256), dim3(256), 0, s, part, B * chunks,
-                       nt > 0 ? dw_tok : nullptr, dW);
+      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, gsum, dtok);
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((kO * kC + 255) / 256), dim3(256), 0, s, part, B * chunks, gsum,
+                       tokens, nt, dW);
   }
   return (int)hipGetLastError();
 }
