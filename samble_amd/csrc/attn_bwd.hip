@@ -155,8 +155,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict_
   constexpr int kBuf = 2 * kTile * kLdsPad;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int m = blockIdx.x * 128 + wave * 32 + lo;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int m = chunk * 128 + wave * 32 + lo;
   const bool mvalid = m < M;
   const float* Kb = K + (long)b * k_bs;
   const float* Vb = V + (long)b * v_bs;
@@ -244,8 +245,9 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
   constexpr int kBuf = 2 * kTile * kLdsPad + 2 * kTile;  // Q tile, dO tile, lse[32], delta[32]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int j = blockIdx.x * 128 + wave * 32 + lo;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int j = chunk * 128 + wave * 32 + lo;
   const bool jvalid = j < N;
   const float* Qb = Qs + (long)b * M * 128;
   const float* Gb = dO + (long)b * M * 128;

@@ -26,8 +26,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + lo;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int qrow = chunk * 128 + wave * 32 + lo;
   const bool qvalid = qrow < N;
 
   const float* Kb = K + (long)b * k_bs;

@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * 128 + wave * 32 + lo;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int i = chunk * 128 + wave * 32 + lo;
   const bool ivalid = i < Nq;
   const float* xkb = xk + (long)b * k_bs;
   const float* knb = knorm + (long)b * Nk;
@@ -342,9 +343,10 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
         ++cnt;
       }
     }
-    if (__any(cnt > kFQueue - 16)) drain();
     if (t + 1 < ntiles) commit(cur ^ 1);
-    __syncthreads();
+    // the tile barrier doubles as the drain vote: all 4 waves drain together, so no wave sits at
+    // the barrier while another one works through its queues
+    if (__syncthreads_or(cnt > kFQueue - 16)) drain();
   }
   drain();
   // merge the two halves of every query through LDS (the whole dynamic region is free now)

@@ -58,11 +58,12 @@ __global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  const int n = blockIdx.x * 128 + wave * 32 + lo;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int n = chunk * 128 + wave * 32 + lo;
   const bool nvalid = n < N;
 
-  if (blockIdx.x == 0) {  // this cloud's copy of the token rows
+  if (chunk == 0) {  // this cloud's copy of the token rows
     for (int e = tid; e < nt * kO; e += 256)
       qkv[(long)b * o_bs + (long)(N + e / kO) * o_rs + (e % kO)] = tokqkv[e];
   }

@@ -121,6 +121,22 @@ __device__ __forceinline__ void mma_tileT_x_acc(const float* __restrict__ lds_ti
   }
 }
 
+// XCD-aware (chunk, cloud) assignment for a grid (chunks, clouds): workgroups are dealt round-robin
+// over the 8 XCDs, each with a private 4 MB L2.  Give every XCD its own clouds so that the K/V (or
+// key-set) tiles all of a cloud's workgroups stream are re-read from that XCD's L2 rather than
+// across the fabric.  Placement only changes speed: any bijection is correct, and grids whose
+// cloud count is not a multiple of 8 keep the identity mapping.
+__device__ __forceinline__ void xcd_assign(int& chunk, int& cloud) {
+  chunk = blockIdx.x;
+  cloud = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, slot = lin >> 3, per = gridDim.y >> 3;
+    cloud = xcd * per + slot % per;
+    chunk = slot / per;
+  }
+}
+
 __device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // order-preserving float -> uint32 (larger float -> larger uint); NaN sorts above +inf

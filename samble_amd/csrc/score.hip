@@ -34,13 +34,8 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB
   // L2), so give every XCD its own clouds: the K rows a cloud's workgroups gather (1 MB) are then
   // re-read from that XCD's L2 instead of the Infinity Cache.  Speed only; any mapping is correct.
-  int b = blockIdx.y, chunk = blockIdx.x;
-  if ((gridDim.y & 7) == 0) {
-    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
-    const int xcd = lin & 7, slot = lin >> 3, per = gridDim.y >> 3;
-    b = xcd * per + slot % per;
-    chunk = slot / per;
-  }
+  int b, chunk;
+  xcd_assign(chunk, b);
   for (int n = tid; n < N; n += 256) {
     acc[n] = 0ull;
     cnt[n] = 0;
