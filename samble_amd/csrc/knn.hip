@@ -235,7 +235,7 @@ __device__ __forceinline__ double pack_wj(float w, unsigned int j) {
   return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
 }
 
-template <int C, int KN>
+template <int C, int KN, bool SELECT = true>
 __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restrict__ xq, long q_bs, int Nq,
                                                            const float* __restrict__ xk, long k_bs, int Nk,
                                                            const float* __restrict__ knorm,
@@ -331,6 +331,12 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
     for (int kk = 0; kk < H; ++kk) acc = mfma32(xs[kk * 32], q[kk], acc);
     acc = mfma32(h == 0 ? bns[cur * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
     const bool tail = j0 + 32 > Nk;
+    if (!SELECT) {  // ablation build: keep the accumulator live, skip the selection
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[r];
+      thr = fminf(thr, sum);
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + crow(r, h);
@@ -342,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
         qj[cnt * 256 + tid] = (unsigned short)j;
         ++cnt;
       }
+    }
     }
     if (t + 1 < ntiles) commit(cur ^ 1);
     // the tile barrier doubles as the drain vote: all 4 waves drain together, so no wave sits at
@@ -355,7 +362,8 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
 #pragma unroll
   for (int s = 0; s < KN; ++s) mg[s * 256 + tid] = L[s];
   __syncthreads();
-  if (h == 0 && ivalid) {
+  if (!SELECT && ivalid && h == 0) idx_out[((long)b * Nq + i) * KN] = (int)thr;
+  if (SELECT && h == 0 && ivalid) {
     int pa = 0, pb = 0;
     double va = mg[tid], vb = mg[tid + 32];
     int* io = idx_out + ((long)b * Nq + i) * KN;
@@ -382,7 +390,7 @@ static int launch_fused(const float* xq, long q_bs, int Nq, const float* xk, lon
   size_t lds = (size_t)(2 * C * 32 + 64 + kFQueue * 256) * 4 + (size_t)kFQueue * 256 * 2;
   const size_t merge = (size_t)KN * 256 * 8;
   if (merge > lds) lds = merge;
-  auto kern = knn_fused_kernel<C, KN>;
+  auto kern = g_ablate_select ? knn_fused_kernel<C, KN, false> : knn_fused_kernel<C, KN, true>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -455,7 +463,11 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
 
 // test hook: force the round-1 two-kernel path (key matrix through HBM) for A/B checks
 static bool g_force_unfused = false;
-extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) { g_force_unfused = on != 0; }
+static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
+extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
+  g_force_unfused = on == 1;
+  g_ablate_select = on == 2;
+}
 
 // workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
 extern "C" size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K) {
