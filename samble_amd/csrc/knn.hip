@@ -384,6 +384,14 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
   }
 }
 
+// test hooks: 1 forces the round-1 two-kernel path (key matrix through HBM) for A/B checks
+static bool g_force_unfused = false;
+static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
+extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
+  g_force_unfused = on == 1;
+  g_ablate_select = on == 2;
+}
+
 template <int C, int KN>
 static int launch_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                         const float* knorm, int* idx, float* d2, hipStream_t s) {
@@ -461,13 +469,6 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
   hipLaunchKernelGGL(select_rows_kernel<KN>, dim3((Nq + 255) / 256, B), dim3(256), 0, s, keyT, Nq, Nk, idx, keys);
 }
 
-// test hook: force the round-1 two-kernel path (key matrix through HBM) for A/B checks
-static bool g_force_unfused = false;
-static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
-extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
-  g_force_unfused = on == 1;
-  g_ablate_select = on == 2;
-}
 
 // workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
 extern "C" size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K) {
