@@ -332,10 +332,8 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
     acc = mfma32(h == 0 ? bns[cur * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
     const bool tail = j0 + 32 > Nk;
     if (!SELECT) {  // ablation build: keep the accumulator live, skip the selection
-      float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sum += acc[r];
-      thr = fminf(thr, sum);
+      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
     } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
