@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -140,11 +141,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    local = local % max(torch.cuda.device_count(), 1)  # (gloo smoke test: ranks may share one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     from samble_amd import sampler_config, synth
     from samble_amd.downsample import DownSampleToken
@@ -211,7 +216,7 @@ def main():
             "data": "synthetic (hash-generated N(0,1) features, random-init weights; no ModelNet40 files offline)",
             "config": {"workload": "one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B=32/GPU C=128 N=2048->M=1024 "
                                    "nb=6 K=32 sparse_col_sqr random T=0.1 dynamic boundaries",
-                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}"},
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None},
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
