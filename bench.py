@@ -227,10 +227,19 @@ def main():
             # dominant kernel group: flash attention forward (one launch)
             alg = (fl["qk"] + fl["av"]) * B_PER_GPU
             ach = alg / (br["attn_fwd"] * 1e-3) / 1e12
+            # fabric-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc.json:
+            # (2*FETCH_SIZE + WRITE_SIZE)*1024, collected in their own runs as the counters require)
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+                traffic = pmc["kernels"]["samble::attn_fwd_kernel"]["traffic_bytes_per_launch"]
+            except Exception:
+                pass
             result["roofline"] = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
                                   "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                                  "algorithmic_flops_per_launch": alg}
+                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                                  "algorithmic_flops_per_launch": alg,
+                                  "executed_flops_per_launch": 2 * fl["qk"] * B_PER_GPU}
             bwd_alg = 4 * fl["av"] * B_PER_GPU
             bach = bwd_alg / (br["attn_bwd"] * 1e-3) / 1e12
             result["roofline_bwd"] = {"kernel": "bwd_prep+bwd_dq+bwd_dkdv+bwd_tokens", "bound": "mfma",
