@@ -129,6 +129,15 @@ int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int
 int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_t* idx, int M, float* out,
                              void* stream);
 
+/* ---- models/attention.py:165-250  Neighbor2PointAttention, attention part (scalar_dot, asm dot) --
+ * qkv (B,N,3C) point-major rows [Q|K|V] = samble_proj_fwd_f32 of the layer input with the three
+ * Conv2d 1x1 weights (nt = 0); nn (B,N,KN) neighbour lists of the layer input.  diff != 0:
+ * group_type "diff" (keys/values are neighbour minus centre: by linearity (Wx)_j - (Wx)_i), else
+ * "neighbor".  out (B,C,N) = sum_j softmax_j(q_i . k_ij / sqrt(C/heads)) v_ij, heads laid out
+ * head-major along C as the reference's split_heads.  C = 128, heads = 4 in this round. */
+int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN, int C,
+                            int heads, int diff, float* out, void* stream);
+
 /* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows
  * 0..N+nt-1, each with its own strides. */

@@ -411,3 +411,57 @@ def sampler_grads(spec: SamplerSpec, st: SamplerState, x: torch.Tensor, g: torch
     return dict(dx=leaves[0].grad, dwq=leaves[1].grad, dwk=leaves[2].grad, dwv=leaves[3].grad,
                 dtokens=leaves[4].grad, x_ds=x_ds.detach(), idx=idx, boundaries=st2.boundaries,
                 trace=st2.trace)
+
+
+# --------------------------------------------------------------------------- #
+# Neighbor2PointAttention  (models/attention.py:130-250)
+# --------------------------------------------------------------------------- #
+@dataclass
+class N2PState:
+    """Learnable tensors of one Neighbor2PointAttention layer (Conv2d 1x1 weights (C,C,1,1),
+    FFN Conv1d weights, two BatchNorm1d)."""
+
+    wq: torch.Tensor
+    wk: torch.Tensor
+    wv: torch.Tensor
+    ff1: torch.Tensor
+    ff2: torch.Tensor
+    bn1_w: torch.Tensor
+    bn1_b: torch.Tensor
+    bn2_w: torch.Tensor
+    bn2_b: torch.Tensor
+
+
+def n2p_attention(x, wq, wk, wv, k: int, heads: int, group_type: str = "diff"):
+    """The attention part of Neighbor2PointAttention.forward (models/attention.py:167-185,
+    203-250; scalar_dot / asm dot): x (B,C,N) -> (B,C,N) before the residual BatchNorm."""
+    neighbors, idx = group_neighbors(x, k, group_type)
+    B, C, N = x.shape
+    D = wq.shape[0] // heads
+
+    def split(t):  # (B,C,N,K') -> (B,H,N,K',D)
+        return t.view(t.shape[0], heads, D, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2)
+
+    q = split(F.conv2d(x[:, :, :, None], wq))
+    kk = split(F.conv2d(neighbors, wk)).permute(0, 1, 2, 4, 3)
+    v = split(F.conv2d(neighbors, wv))
+    att = torch.softmax((q @ kk) / math.sqrt(q.shape[-1]), dim=-1)
+    out = (att @ v)[:, :, :, 0, :].permute(0, 2, 1, 3)
+    return out.reshape(out.shape[0], out.shape[1], -1).permute(0, 2, 1), idx
+
+
+def n2p_forward(st: N2PState, x, k: int, heads: int, group_type: str = "diff", training: bool = True):
+    """Whole layer (models/attention.py:165-193): attention, bn1(x + .), FFN, bn2(x + .)."""
+    a, idx = n2p_attention(x, st.wq, st.wk, st.wv, k, heads, group_type)
+    y = F.batch_norm(x + a, None, None, st.bn1_w, st.bn1_b, training=True if training else False)
+    f = F.conv1d(F.leaky_relu(F.conv1d(y, st.ff1), negative_slope=0.2), st.ff2)
+    return F.batch_norm(y + f, None, None, st.bn2_w, st.bn2_b, training=True if training else False), a, idx
+
+
+def edgeconv_forward(x, k: int, group_type: str, w1, bn1, w2, bn2):
+    """models/embedding.py:7-39 (training-mode BatchNorm2d): group -> 2x(Conv2d 1x1 + BN + LeakyReLU)
+    -> max over K.  bn* = (weight, bias)."""
+    g, _ = group_neighbors(x, k, group_type)
+    y = F.leaky_relu(F.batch_norm(F.conv2d(g, w1), None, None, bn1[0], bn1[1], training=True), negative_slope=0.2)
+    y = F.leaky_relu(F.batch_norm(F.conv2d(y, w2), None, None, bn2[0], bn2[1], training=True), negative_slope=0.2)
+    return y.max(dim=-1, keepdim=False)[0]

@@ -1,0 +1,140 @@
+"""Drop-in `Neighbor2PointAttention` (reference models/attention.py:130-250) on the MI355X kernels.
+
+Same constructor (`Cls(config.attention, layer)`), `forward(x (B,C,N)) -> (B,C,N)` and state_dict
+keys (`q_conv/k_conv/v_conv.weight` (C,C,1,1), `ff.0/ff.2.weight`, `bn1.*`, `bn2.*`) as the
+reference.  The neighbour build is the fused Gram + top-K HIP kernel, the three 1x1 Conv2d collapse
+(by linearity) into one per-point fp32-MFMA projection, and the K-neighbour softmax attention is
+one HIP gather kernel: the (B,C,N,K) tensors of the reference are never built in forward.
+BatchNorm / FFN around it are stock torch modules (they are not neighbour ops).
+
+Backward of the attention part re-derives the same expression with torch ops on the saved
+projections (gather-based, chunked over clouds) and routes the result through the HIP projection
+backward; a fused HIP backward (inverted neighbour lists) is listed in DESIGN.md as next.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _attention_from_projection(qkv, nn_idx, heads: int, diff: bool):
+    """Differentiable torch restatement used only for the backward pass: qkv (b,N,3C) -> (b,C,N)."""
+    b, N, C3 = qkv.shape
+    C = C3 // 3
+    D = C // heads
+    K = nn_idx.shape[2]
+    q, kp, vp = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    gi = nn_idx.long().reshape(b, N * K, 1).expand(-1, -1, C)
+    kg = torch.gather(kp, 1, gi).view(b, N, K, C)
+    vg = torch.gather(vp, 1, gi).view(b, N, K, C)
+    if diff:
+        kg = kg - kp[:, :, None, :]
+        vg = vg - vp[:, :, None, :]
+    logits = (q.view(b, N, 1, heads, D) * kg.view(b, N, K, heads, D)).sum(-1) / math.sqrt(D)
+    att = torch.softmax(logits, dim=2)
+    out = (att.unsqueeze(-1) * vg.view(b, N, K, heads, D)).sum(2).reshape(b, N, C)
+    return out.permute(0, 2, 1)
+
+
+class _N2PCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, K, heads, diff):
+        C = x.shape[1]
+        w = torch.cat((wq, wk, wv), dim=0).reshape(3 * C, C)
+        no_tokens = x.new_zeros((C, 0))
+        qkv = ops.stage_proj_fwd(x, no_tokens, w)
+        nn_idx = ops.stage_knn(x, x, K)
+        out = ops.stage_n2p_attn_fwd(qkv, nn_idx, heads, diff)
+        ctx.save_for_backward(x, w, qkv, nn_idx)
+        ctx.cfg = (heads, diff, wq.shape[0], wk.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, qkv, nn_idx = ctx.saved_tensors
+        heads, diff, a, b = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        step = 4  # clouds per chunk: bounds the (b,N,K,C) gather temporaries
+        for s in range(0, qkv.shape[0], step):
+            with torch.enable_grad():
+                part = qkv[s:s + step].detach().requires_grad_(True)
+                out = _attention_from_projection(part, nn_idx[s:s + step], heads, diff)
+            dqkv[s:s + step] = torch.autograd.grad(out, part, g[s:s + step])[0]
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[1:4])
+        dx, dw, _ = ops.stage_proj_bwd(dqkv, x, x.new_zeros((x.shape[1], 0)), w, need_dx, need_dw)
+        if not need_dw:
+            return dx, None, None, None, None, None, None
+        C = x.shape[1]
+        return (dx, dw[:a].reshape(a, C, 1, 1), dw[a:a + b].reshape(b, C, 1, 1), dw[a + b:].reshape(-1, C, 1, 1),
+                None, None, None)
+
+
+class Neighbor2PointAttention(nn.Module):
+    def __init__(self, config_attention, layer):
+        super().__init__()
+        self.K = config_attention.K[layer]
+        self.group_type = config_attention.group_type[layer]
+        self.num_heads = config_attention.num_heads[layer]
+        self.attention_mode = config_attention.attention_mode[layer]
+        q_in, q_out = config_attention.q_in[layer], config_attention.q_out[layer]
+        k_in, k_out = config_attention.k_in[layer], config_attention.k_out[layer]
+        v_in, v_out = config_attention.v_in[layer], config_attention.v_out[layer]
+        self.asm = config_attention.asm[layer]
+        self.q_depth = int(q_out / self.num_heads)
+        self.k_depth = int(k_out / self.num_heads)
+        self.v_depth = int(v_out / self.num_heads)
+        self.q_conv = nn.Conv2d(q_in, q_out, 1, bias=False)
+        self.k_conv = nn.Conv2d(k_in, k_out, 1, bias=False)
+        self.v_conv = nn.Conv2d(v_in, v_out, 1, bias=False)
+        self.softmax = nn.Softmax(dim=-1)
+        self.ff = nn.Sequential(
+            nn.Conv1d(config_attention.ff_conv1_channels_in[layer], config_attention.ff_conv1_channels_out[layer], 1,
+                      bias=False),
+            nn.LeakyReLU(negative_slope=0.2),
+            nn.Conv1d(config_attention.ff_conv2_channels_in[layer], config_attention.ff_conv2_channels_out[layer], 1,
+                      bias=False),
+        )
+        self.bn1 = nn.BatchNorm1d(v_out)
+        self.bn2 = nn.BatchNorm1d(v_out)
+        if self.attention_mode != "scalar_dot":
+            if self.attention_mode == "vector_sub":
+                raise NotImplementedError("attention_mode 'vector_sub' is not built on HIP (shipped configs use scalar_dot)")
+            raise ValueError(f"attention_mode can only be scalar_dot or vector_sub, but got: {self.attention_mode}")
+        if self.asm != "dot":
+            if self.asm == "dot-sub":
+                raise NotImplementedError("asm 'dot-sub' is not built on HIP (shipped configs use dot)")
+            raise ValueError("Please check the setting of asm in feature learning layer!")
+        if self.group_type not in ("diff", "neighbor"):
+            if self.group_type in ("center_neighbor", "center_diff"):
+                raise NotImplementedError(f"group_type {self.group_type!r} is not built on HIP for N2P (shipped: diff)")
+            raise ValueError(
+                f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {self.group_type}")
+        if not (q_in == q_out == k_in == k_out == v_in == v_out == 128 and self.num_heads == 4):
+            raise NotImplementedError("the HIP N2P kernels are built for 128 channels, 4 heads (shipped cls/seg configs)")
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise ops._lib.SambleError("samble_amd.Neighbor2PointAttention runs on the GPU only (no CPU fallback)")
+        x_tmp = _N2PCore.apply(x, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.K, self.num_heads,
+                               self.group_type == "diff")
+        x = self.bn1(x + x_tmp)
+        x_tmp = self.ff(x)
+        x = self.bn2(x + x_tmp)
+        return x
+
+
+def attention_config(preset: str = "cls"):
+    """`config.feature_learning_block.attention` of the shipped presets (three N2P layers, K=32,
+    diff grouping, 4 heads, 128 channels, FFN 128-512-128)."""
+    from .config import to_attr
+    n = 3 if preset == "cls" else 5
+    rep = lambda v: [v] * n  # noqa: E731
+    return to_attr(dict(K=rep(32), attention_mode=rep("scalar_dot"), group_type=rep("diff"), q_in=rep(128),
+                        q_out=rep(128), k_in=rep(128), k_out=rep(128), v_in=rep(128), v_out=rep(128),
+                        num_heads=rep(4), ff_conv1_channels_in=rep(128), ff_conv1_channels_out=rep(512),
+                        ff_conv2_channels_in=rep(512), ff_conv2_channels_out=rep(128), asm=rep("dot")))

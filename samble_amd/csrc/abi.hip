@@ -31,6 +31,7 @@ int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, cons
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
                            float*, long, float*, float*, float*, hipStream_t);
+int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
                            float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
@@ -244,4 +245,15 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
   return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws,
                                      (hipStream_t)stream),
               "samble_proj_bwd_f32");
+}
+
+SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN,
+                                       int C, int heads, int diff, float* out, void* stream) {
+  if (!qkv || !nn || !out) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: null pointer");
+  if (C != 128 || heads != 4) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128, 4 heads of 32");
+  if ((rs & 3) || (bs & 3) || rs < 3 * C) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad strides");
+  if (B <= 0 || N <= 0 || KN <= 0) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad sizes");
+  return done(samble_launch_n2p_fwd(qkv, bs, rs, nn, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), out,
+                                    (hipStream_t)stream),
+              "samble_n2p_attn_fwd_f32");
 }

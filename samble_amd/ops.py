@@ -97,6 +97,18 @@ def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
     return dx, dw, dtok
 
 
+def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff: bool) -> torch.Tensor:
+    """qkv (B,N,3C) point-major [Q|K|V], nn_idx (B,N,K) int32 -> (B,C,N) attention output."""
+    _need_gpu(qkv, nn_idx)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    with torch.cuda.device(qkv.device):
+        out = torch.empty((B, C, N), dtype=torch.float32, device=qkv.device)
+        _lib.call("samble_n2p_attn_fwd_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), nn_idx.data_ptr(), B, N,
+                  nn_idx.shape[2], C, heads, int(bool(diff)), out.data_ptr(), _stream())
+    return out
+
+
 def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int):
     """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->
     O (B,N,D), lse (B,N), token logits (B,N,nt)."""

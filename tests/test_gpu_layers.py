@@ -1,0 +1,100 @@
+"""GPU parity of the layers around the sampler that share its neighbour ops: Neighbor2PointAttention
+(reference models/attention.py:130-250) and EdgeConv (models/embedding.py:7-39) against fixtures the
+reference produced (tests/golden/layer_*.npz, make_golden_layers.py)."""
+import numpy as np
+import pytest
+import torch
+
+from samble_amd import synth
+from tests.util import layer_fixture, set_agreement
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _w(shape, seed, scale):
+    return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
+
+
+def _n2p_module(seed, group_type):
+    from samble_amd.attention import Neighbor2PointAttention, attention_config
+    cfg = attention_config("cls")
+    cfg.group_type[0] = group_type
+    mod = Neighbor2PointAttention(cfg, 0)
+    C = 128
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, C, 1, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, C, 1, 1), seed + 3, 0.09))
+        mod.ff[0].weight.copy_(_w((4 * C, C, 1), seed + 4, 0.09))
+        mod.ff[2].weight.copy_(_w((C, 4 * C, 1), seed + 5, 0.045))
+        mod.bn1.weight.copy_(1 + _w((C,), seed + 6, 0.1)); mod.bn1.bias.copy_(_w((C,), seed + 7, 0.1))
+        mod.bn2.weight.copy_(1 + _w((C,), seed + 8, 0.1)); mod.bn2.bias.copy_(_w((C,), seed + 9, 0.1))
+    return mod.to(DEV).train()
+
+
+@pytest.mark.parametrize("name,group_type", [("layer_n2p_diff", "diff"), ("layer_n2p_neighbor", "neighbor")])
+def test_n2p_against_reference_fixture(name, group_type):
+    from samble_amd import ops
+    d = layer_fixture(name)
+    B, C, N, K, H, seed = [int(v) for v in d["meta"]]
+    mod = _n2p_module(seed, group_type)
+    assert sorted(mod.state_dict()) == sorted(
+        ["q_conv.weight", "k_conv.weight", "v_conv.weight", "ff.0.weight", "ff.2.weight", "bn1.weight", "bn1.bias",
+         "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked", "bn2.weight", "bn2.bias",
+         "bn2.running_mean", "bn2.running_var", "bn2.num_batches_tracked"])
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    # attention part alone (HIP projection + kNN + gather-attention kernels)
+    w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight)).reshape(3 * C, C)
+    qkv = ops.stage_proj_fwd(x.detach(), x.new_zeros((C, 0)), w)
+    nn_idx = ops.stage_knn(x.detach(), x.detach(), K)
+    assert set_agreement(nn_idx.cpu(), torch.from_numpy(d["knn_sorted"].astype(np.int64))) >= 0.9995
+    att = ops.stage_n2p_attn_fwd(qkv, nn_idx, H, group_type == "diff")
+    torch.testing.assert_close(att.cpu(), torch.from_numpy(d["att"]), rtol=1e-4, atol=2e-5)
+    # whole layer, forward + backward
+    y = mod(x)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
+    y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    for got, key in ((x.grad, "dx"), (mod.q_conv.weight.grad, "dwq"), (mod.k_conv.weight.grad, "dwk"),
+                     (mod.v_conv.weight.grad, "dwv"), (mod.ff[0].weight.grad, "dff1")):
+        ref = torch.from_numpy(d[key])
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
+
+
+def test_n2p_metric_size_runs_and_matches_torch_restatement():
+    """B=8, N=2048: the HIP gather-attention against the differentiable torch restatement on the GPU."""
+    from samble_amd import ops
+    from samble_amd.attention import _attention_from_projection
+    B, C, N, K, H = 8, 128, 2048, 32, 4
+    x = torch.from_numpy(synth.features(B, C, N, 5)).to(DEV)
+    w = _w((3 * C, C), 6, 0.09).to(DEV)
+    qkv = ops.stage_proj_fwd(x, x.new_zeros((C, 0)), w)
+    nn_idx = ops.stage_knn(x, x, K)
+    for diff in (True, False):
+        got = ops.stage_n2p_attn_fwd(qkv, nn_idx, H, diff)
+        ref = torch.cat([_attention_from_projection(qkv[s:s + 2], nn_idx[s:s + 2], H, diff) for s in range(0, B, 2)])
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["layer_edgeconv_xyz", "layer_edgeconv_feat"])
+def test_edgeconv_against_reference_fixture(name):
+    from samble_amd.embedding import EdgeConv, embedding_config
+    d = layer_fixture(name)
+    B, cin, N, K, c1, c2, seed, layer = [int(v) for v in d["meta"]]
+    mod = EdgeConv(embedding_config("cls"), layer)
+    with torch.no_grad():
+        mod.conv1[0].weight.copy_(_w((c1, 2 * cin, 1, 1), seed + 1, 0.3))
+        mod.conv2[0].weight.copy_(_w((c2, c1, 1, 1), seed + 2, 0.12))
+        mod.conv1[1].weight.copy_(1 + _w((c1,), seed + 3, 0.1)); mod.conv1[1].bias.copy_(_w((c1,), seed + 4, 0.1))
+        mod.conv2[1].weight.copy_(1 + _w((c2,), seed + 5, 0.1)); mod.conv2[1].bias.copy_(_w((c2,), seed + 6, 0.1))
+    mod = mod.to(DEV).train()
+    x_np = synth.xyz_clouds(B, N, seed) if cin == 3 else synth.features(B, cin, N, seed)
+    x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
+    y = mod(x)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
+    y.backward(torch.from_numpy(synth.normal(tuple(y.shape), seed + 20)).to(DEV))
+    for got, key in ((x.grad, "dx"), (mod.conv1[0].weight.grad, "dw1")):
+        ref = torch.from_numpy(d[key])
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err)

@@ -66,3 +66,22 @@ def test_short_row_sum_order_matches_aten():
         for k in range(1, 4):
             s = (s + part[k]).astype(f32)
         assert np.array_equal(s, torch.from_numpy(a).sum(1).numpy())
+
+
+def test_oracle_reproduces_layer_fixtures():
+    """N2P / EdgeConv restatements against what the reference produced (make_golden_layers.py)."""
+    from samble_amd import synth
+    from tests.util import layer_fixture
+
+    def w(shape, seed, scale):
+        return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
+
+    for name, gt in (("layer_n2p_diff", "diff"), ("layer_n2p_neighbor", "neighbor")):
+        d = layer_fixture(name)
+        B, C, N, K, H, seed = [int(v) for v in d["meta"]]
+        st = O.N2PState(w((C, C, 1, 1), seed + 1, 0.09), w((C, C, 1, 1), seed + 2, 0.09), w((C, C, 1, 1), seed + 3, 0.09),
+                        w((4 * C, C, 1), seed + 4, 0.09), w((C, 4 * C, 1), seed + 5, 0.045), 1 + w((C,), seed + 6, 0.1),
+                        w((C,), seed + 7, 0.1), 1 + w((C,), seed + 8, 0.1), w((C,), seed + 9, 0.1))
+        y, att, idx = O.n2p_forward(st, torch.from_numpy(synth.features(B, C, N, seed)), K, H, gt)
+        torch.testing.assert_close(y, torch.from_numpy(d["y"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(att, torch.from_numpy(d["att"]), rtol=1e-4, atol=1e-6)
