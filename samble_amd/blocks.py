@@ -1,0 +1,72 @@
+"""`FeatureLearningBlock` wiring of the reference's classification model (models/cls_model.py:10-145)
+for the shipped path (`ds_which: token`, `fl_which: n2p`), built from the drop-in modules of this
+package.  It reproduces the CALL PROTOCOL only -- submodule names (hence state_dict keys), the order
+EdgeConv x2 -> N2P -> [DownSampleToken -> N2P -> gather_by_idx(xyz)] x2, the res-link max-pool heads --
+so that a reference checkpoint of the block loads and the sampler can be exercised mid-network.
+The MLP head, STN and the segmentation decoder are out of scope."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .attention import Neighbor2PointAttention
+from .downsample import DownSampleToken
+from .embedding import EdgeConv
+
+
+class FeatureLearningBlock(nn.Module):
+    def __init__(self, config_feature_learning_block):
+        super().__init__()
+        cfg = config_feature_learning_block
+        if cfg.downsample.ds_which != "token":
+            raise NotImplementedError("only ds_which == 'token' (DownSampleToken) is built")
+        if getattr(cfg.attention, "fl_which", "n2p") != "n2p":
+            raise ValueError("Only n2p is built for fl_which")
+        self.res_link_enable = cfg.res_link.enable
+        self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
+        self.downsample_list = nn.ModuleList([DownSampleToken(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
+        self.feature_learning_layer_list = nn.ModuleList(
+            [Neighbor2PointAttention(cfg.attention, l) for l in range(len(cfg.attention.K))])
+        outs = cfg.attention.ff_conv2_channels_out
+        if self.res_link_enable:
+            self.conv_list = nn.ModuleList([nn.Conv1d(c, 1024, kernel_size=1, bias=False) for c in outs])
+        else:
+            self.conv = nn.Conv1d(outs[-1], 1024, kernel_size=1, bias=False)
+        self.M_list = cfg.downsample.M
+
+    def forward(self, x, noise_list=None):
+        """x (B,3,N) xyz.  noise_list: optional per-sampler-layer Exp(1) tensors (parity tests)."""
+        x_list = []
+        x_xyz = x.clone()
+        for embedding in self.embedding_list:
+            x = embedding(x)
+            x_list.append(x)
+        x = torch.cat(x_list, dim=1)
+        x = self.feature_learning_layer_list[0](x)
+        if self.res_link_enable:
+            res_link_list = [self.conv_list[0](x).max(dim=-1)[0]]
+            for i in range(len(self.downsample_list)):
+                noise = None if noise_list is None else noise_list[i]
+                (x, idx_select) = self.downsample_list[i](x, x_xyz, noise=noise)[0]
+                x = self.feature_learning_layer_list[i + 1](x)
+                x_xyz = ops.gather_by_idx(x_xyz, idx_select)
+                res_link_list.append(self.conv_list[i + 1](x).max(dim=-1)[0])
+            self.res_link_list = res_link_list
+            return torch.cat(res_link_list, dim=1), res_link_list
+        for i in range(len(self.downsample_list)):
+            noise = None if noise_list is None else noise_list[i]
+            x = self.downsample_list[i](x, noise=noise)[0][0]
+            x = self.feature_learning_layer_list[i + 1](x)
+        return self.conv(x).max(dim=-1)[0]
+
+
+def block_config(preset: str = "cls", M=(1024, 512)):
+    """`config.feature_learning_block` of the shipped classification preset."""
+    from .attention import attention_config
+    from .config import sampler_config, to_attr
+    from .embedding import embedding_config
+    att = attention_config(preset)
+    att["fl_which"] = "n2p"
+    return to_attr(dict(res_link=dict(enable=True), embedding=embedding_config(preset),
+                        downsample=sampler_config(preset, M=list(M)), attention=att))

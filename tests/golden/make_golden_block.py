@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Golden fixture for the classification FeatureLearningBlock call protocol (BASELINE.json
+configs[1] at a small size): the UNMODIFIED reference block (models/cls_model.py:10-145, cls.yaml)
+on CPU with deterministic parameters.  Run from the repo root:
+    python tests/golden/make_golden_block.py"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SAMBLE_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+from samble_amd import synth
+from oracle import torch_oracle as O
+from tests.golden.make_golden_layers import block_config
+
+from models import cls_model as ref_cls  # noqa: E402
+
+
+from tests.util import fill_parameters  # noqa: E402  (same deterministic fill as the GPU test)
+
+
+def main():
+    torch.set_num_threads(8)
+    B, N, M, seed = 2, 256, [128, 64], 9100
+    cfg = block_config("cls")
+    cfg.downsample.M = list(M)
+    blk = ref_cls.FeatureLearningBlock(cfg)
+    fill_parameters(blk, seed)
+    blk.train()
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500))
+    nb = cfg.downsample.bin.num_bins[0]
+    torch.manual_seed(seed)
+    feat, res = blk(xyz)
+    torch.manual_seed(seed)
+    noise0 = O.draw_noise(B * nb, N)
+    noise1 = O.draw_noise(B * nb, M[0])
+    out = dict(meta=np.array([B, N, M[0], M[1], nb, seed], dtype=np.int64), feat=feat.detach().numpy(),
+               noise0=noise0.numpy(), noise1=noise1.numpy(),
+               idx0=blk.downsample_list[0].idx.numpy(), idx1=blk.downsample_list[1].idx.numpy(),
+               score0=blk.downsample_list[0].attention_point_score.detach().numpy(),
+               names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__))
+    path = os.path.join(HERE, "block_cls_small.npz")
+    np.savez_compressed(path, **out)
+    print("block_cls_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()))
+
+
+if __name__ == "__main__":
+    main()

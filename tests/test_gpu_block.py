@@ -1,0 +1,56 @@
+"""BASELINE.json configs[1] (full classification feature block, 2048->1024->512) at a small size:
+the reference's FeatureLearningBlock call protocol with this package's modules dropped in, against a
+fixture produced by the unmodified reference block (tests/golden/make_golden_block.py)."""
+import numpy as np
+import pytest
+import torch
+
+from samble_amd import synth
+from tests.util import fill_parameters, layer_fixture, set_agreement
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_cls_block_protocol_against_reference():
+    from samble_amd.blocks import FeatureLearningBlock, block_config
+    d = layer_fixture("block_cls_small")
+    B, N, M0, M1, nb, seed = [int(v) for v in d["meta"]]
+    blk = FeatureLearningBlock(block_config("cls", M=(M0, M1)))
+    assert [n for n, _ in blk.named_parameters()] == [str(n) for n in d["names"]], "state_dict layout differs"
+    fill_parameters(blk, seed)
+    blk = blk.to(DEV).train()
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500)).to(DEV)
+    noise = [torch.from_numpy(d["noise0"]).to(DEV), torch.from_numpy(d["noise1"]).to(DEV)]
+    feat, res = blk(xyz, noise_list=noise)
+    assert feat.shape == (B, 3 * 1024) and len(res) == 3
+    ds0, ds1 = blk.downsample_list
+    torch.testing.assert_close(ds0.attention_point_score.cpu(), torch.from_numpy(d["score0"]), rtol=2e-3, atol=1e-8)
+    idx0, idx1 = ds0.idx.cpu()[:, 0], ds1.idx.cpu()[:, 0]
+    ref0, ref1 = torch.from_numpy(d["idx0"])[:, 0], torch.from_numpy(d["idx1"])[:, 0]
+    assert idx0.shape == (B, M0) and idx1.shape == (B, M1)
+    # three layers of fp32 arithmetic feed the first sampler, five the second: sets agree, order mostly
+    assert set_agreement(idx0, ref0) >= 0.97, set_agreement(idx0, ref0)
+    if bool((idx0 == ref0).all()):
+        assert set_agreement(idx1, ref1) >= 0.9
+        if bool((idx1 == ref1).all()):
+            torch.testing.assert_close(feat.detach().cpu(), torch.from_numpy(d["feat"]), rtol=2e-3, atol=2e-3)
+    # the block trains: gradients reach the first EdgeConv through both samplers
+    feat.sum().backward()
+    g = blk.embedding_list[0].conv1[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    for ds in (ds0, ds1):
+        assert ds.bin_tokens.grad is not None and torch.isfinite(ds.bin_tokens.grad).all()
+
+
+def test_cls_block_metric_size_forward_backward():
+    """configs[1] proper: B=32 clouds of N=2048 xyz through the whole block (2048 -> 1024 -> 512)."""
+    from samble_amd.blocks import FeatureLearningBlock, block_config
+    torch.manual_seed(0)
+    blk = FeatureLearningBlock(block_config("cls")).to(DEV).train()
+    xyz = torch.from_numpy(synth.xyz_clouds(32, 2048, 77)).to(DEV)
+    feat, res = blk(xyz)
+    assert feat.shape == (32, 3072) and torch.isfinite(feat).all()
+    assert blk.downsample_list[0].idx.shape == (32, 1, 1024) and blk.downsample_list[1].idx.shape == (32, 1, 512)
+    feat.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())

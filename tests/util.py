@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(HERE, "golden")
 def golden_names():
     """Sampler fixtures (make_golden.py); the layer_* fixtures come from make_golden_layers.py."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("layer_")]
+    return [n for n in names if not n.startswith(("layer_", "block_"))]
 
 
 def layer_fixture(name):
@@ -95,3 +95,20 @@ def set_agreement(a: torch.Tensor, b: torch.Tensor) -> float:
     for r in range(a2.shape[0]):
         hits += len(np.intersect1d(a2[r], b2[r], assume_unique=False))
     return hits / a2.size
+
+
+def fill_parameters(module, seed):
+    """Deterministic values for every parameter, keyed by its position in named_parameters() order;
+    identical to tests/golden/make_golden_block.py (which fills the reference block)."""
+    from samble_amd import synth
+    with torch.no_grad():
+        for i, (name, p) in enumerate(module.named_parameters()):
+            n = synth.normal(tuple(p.shape), seed + i).astype(np.float64)
+            if name.endswith("bn1.weight") or name.endswith("bn2.weight") or (p.dim() == 1 and "weight" in name):
+                v = 1.0 + 0.1 * n
+            elif p.dim() == 1:
+                v = 0.1 * n
+            else:
+                fan_in = int(np.prod(p.shape[1:]))
+                v = n / np.sqrt(fan_in)
+            p.copy_(torch.from_numpy(v.astype(np.float32)))
