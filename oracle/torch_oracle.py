@@ -465,3 +465,16 @@ def edgeconv_forward(x, k: int, group_type: str, w1, bn1, w2, bn2):
     y = F.leaky_relu(F.batch_norm(F.conv2d(g, w1), None, None, bn1[0], bn1[1], training=True), negative_slope=0.2)
     y = F.leaky_relu(F.batch_norm(F.conv2d(y, w2), None, None, bn2[0], bn2[1], training=True), negative_slope=0.2)
     return y.max(dim=-1, keepdim=False)[0]
+
+
+def upsample_interpolation(pcd_up, points_select, pcd_up_xyz, points_select_xyz, k, conv_w, conv_bn, res_w, res_bn):
+    """models/upsample.py:164-213 with distance_type xyz, training-mode BatchNorm1d; *_bn = (weight, bias)."""
+    sel = F.leaky_relu(F.batch_norm(F.conv1d(points_select, conv_w), None, None, conv_bn[0], conv_bn[1], training=True),
+                       negative_slope=0.2)
+    nb, _, d = interpolate_neighbors(pcd_up_xyz, points_select_xyz, sel, k)
+    wts = 1.0 / (d + 1e-8)
+    wts = wts / torch.sum(wts, dim=-1, keepdim=True)
+    interp = torch.sum(nb * wts.unsqueeze(dim=1), dim=-1)
+    x = torch.concat([pcd_up, interp], dim=1)
+    return F.leaky_relu(F.batch_norm(F.conv1d(x, res_w), None, None, res_bn[0], res_bn[1], training=True),
+                        negative_slope=0.2)

@@ -102,3 +102,25 @@ def test_temperature_modes():
     assert ops.boltzmann_temperature("mode_4", 2048, 6) == (0, 2048 / 1200.0)
     with pytest.raises(NotImplementedError):
         ops.boltzmann_temperature("mode_9", 1, 1)
+
+
+def test_checkpoint_round_trip_keeps_reference_format():
+    """{'model_state_dict', 'bin_boundaries': [[upper, lower], ...]} as train_modelnet.py:493-509
+    writes it; freeze=True is what test_modelnet.py:161-171 does for evaluation."""
+    from samble_amd import checkpoint, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    net = torch.nn.ModuleList([DownSampleToken(sampler_config("cls"), l) for l in range(2)])
+    for i, layer in enumerate(net):
+        q = torch.tensor([0.5, 0.1, -0.2, -0.4, -0.6]) + 0.01 * i
+        layer.bin_boundaries = [torch.cat([torch.tensor([float("inf")]), q]).reshape(1, 1, 1, 6),
+                                torch.cat([q, torch.tensor([float("-inf")])]).reshape(1, 1, 1, 6)]
+    state = checkpoint.checkpoint_dict(net)
+    assert set(state) == {"model_state_dict", "bin_boundaries"} and len(state["bin_boundaries"]) == 2
+    other = torch.nn.ModuleList([DownSampleToken(sampler_config("cls"), l) for l in range(2)])
+    checkpoint.load_checkpoint(other, state, freeze=True)
+    for a, b in zip(net, other):
+        assert torch.equal(a.bin_boundaries[0], b.bin_boundaries[0]) and not b.dynamic_boundaries_enable
+        assert a.bin_boundaries[0].data_ptr() != b.bin_boundaries[0].data_ptr()
+        assert torch.equal(a.q_conv.weight, b.q_conv.weight)
+    vals = checkpoint.static_boundary_values(state)
+    assert len(vals) == 2 and len(vals[0]) == 5 and abs(vals[1][0] - 0.51) < 1e-6

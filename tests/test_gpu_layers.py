@@ -98,3 +98,27 @@ def test_edgeconv_against_reference_fixture(name):
         ref = torch.from_numpy(d[key])
         err = (got.cpu() - ref).abs().max().item()
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err)
+
+
+def test_upsample_interpolation_against_reference_fixture():
+    from samble_amd.upsample import UpSampleInterpolation, upsample_config
+    d = layer_fixture("layer_upsample_xyz")
+    B, C, N, M, seed = [int(v) for v in d["meta"]]
+    mod = UpSampleInterpolation(upsample_config("seg"), 0)
+    with torch.no_grad():
+        mod.conv[0].weight.copy_(_w((C, C, 1), seed + 1, 0.09))
+        mod.res_conv[0].weight.copy_(_w((C, 2 * C, 1), seed + 2, 0.06))
+        mod.conv[1].weight.copy_(1 + _w((C,), seed + 3, 0.1)); mod.conv[1].bias.copy_(_w((C,), seed + 4, 0.1))
+        mod.res_conv[1].weight.copy_(1 + _w((C,), seed + 5, 0.1)); mod.res_conv[1].bias.copy_(_w((C,), seed + 6, 0.1))
+    mod = mod.to(DEV).train()
+    up_xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed)).to(DEV)
+    sel_idx = torch.from_numpy(d["sel_idx"]).to(DEV)
+    down_xyz = torch.gather(up_xyz, 2, sel_idx[:, None, :].expand(-1, 3, -1))
+    up = torch.from_numpy(synth.features(B, C, N, seed + 10)).to(DEV).requires_grad_(True)
+    down = torch.from_numpy(synth.features(B, C, M, seed + 11)).to(DEV).requires_grad_(True)
+    y = mod(up, ((down, sel_idx.unsqueeze(1), down_xyz), (None, None)), up_xyz)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
+    y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    for got, key in ((up.grad, "dup"), (down.grad, "ddown")):
+        ref = torch.from_numpy(d[key])
+        assert (got.cpu() - ref).abs().max().item() <= 5e-4 * ref.abs().max().item() + 1e-6, key
