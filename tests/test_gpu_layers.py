@@ -128,6 +128,14 @@ def test_upsample_interpolation_against_reference_fixture():
         torch.testing.assert_close(yc[b][:, ~coincide[b]], yr[b][:, ~coincide[b]], rtol=2e-4, atol=2e-4)
         torch.testing.assert_close(yc[b][:, coincide[b]], yr[b][:, coincide[b]], rtol=0, atol=5e-2)
     y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    # gradients: the coinciding columns above perturb LeakyReLU kinks / BatchNorm statistics, so compare
+    # the non-coinciding columns of d(pcd_up) element-wise and everything in relative L2
+    dup, dup_ref = up.grad.cpu(), torch.from_numpy(d["dup"])
+    for b in range(B):
+        ref = dup_ref[b][:, ~coincide[b]]
+        err = (dup[b][:, ~coincide[b]] - ref).abs().max().item()
+        assert err <= 2e-3 * ref.abs().max().item(), ("dup", err)
     for got, key in ((up.grad, "dup"), (down.grad, "ddown")):
         ref = torch.from_numpy(d[key])
-        assert (got.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item() + 1e-6, key
+        rel = ((got.cpu() - ref).norm() / ref.norm()).item()
+        assert rel <= 5e-2, (key, rel)
