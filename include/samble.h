@@ -56,7 +56,7 @@ const char* samble_last_error(void);
  * dist_out (B,Nq,K) or NULL: POSITIVE distance of the reference-normalised points (centred on
  * xq's mean, divided by the mean unbiased per-channel std), i.e. -1 * the reference's first
  * return value.  K in {1,3,8,16,20,32,40,64}. */
-size_t samble_knn_workspace_bytes(int B, int Nq, int Nk, int K);
+size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K);
 int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C, int K,
                    int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream);
 

@@ -10,7 +10,7 @@
 
 // kernel launchers (one per .hip file)
 extern "C" {
-size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K);
+size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K);
 int samble_launch_knn(const float*, long, int, const float*, long, int, int, int, int, int*, float*, float*, hipStream_t);
 int samble_launch_attn_fwd(const float*, long, long, const float*, long, long, const float*, long, long, int, int, int,
                            float, float*, float*, float*, int, hipStream_t);
@@ -66,8 +66,8 @@ float inv_sqrt_d(int D) { return (float)(1.0 / sqrt((double)D)); }
 SAMBLE_API const char* samble_version(void) { return "samble-hip 0.1 (gfx950)"; }
 SAMBLE_API const char* samble_last_error(void) { return g_err; }
 
-SAMBLE_API size_t samble_knn_workspace_bytes(int B, int Nq, int Nk, int K) {
-  return samble_knn_ws_floats(B, Nq, Nk, K) * sizeof(float);
+SAMBLE_API size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K) {
+  return samble_knn_ws_floats(B, C, Nq, Nk, K) * sizeof(float);
 }
 
 SAMBLE_API int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C,
@@ -75,7 +75,7 @@ SAMBLE_API int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float
   if (!xq || !xk || !idx_out || !ws) return fail(SAMBLE_E_INVALID, "samble_knn_f32: null pointer");
   if (B <= 0 || C <= 0 || Nq <= 0 || Nk <= 0 || K <= 0 || K > Nk)
     return fail(SAMBLE_E_INVALID, "samble_knn_f32: need B,C,Nq,Nk > 0 and 0 < K <= Nk");
-  if (ws_bytes < samble_knn_workspace_bytes(B, Nq, Nk, K))
+  if (ws_bytes < samble_knn_workspace_bytes(B, C, Nq, Nk, K))
     return fail(SAMBLE_E_WORKSPACE, "samble_knn_f32: workspace too small (samble_knn_workspace_bytes)");
   int rc = samble_launch_knn(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, idx_out, dist_out, (float*)ws, (hipStream_t)stream);
   if (rc == -22) return fail(SAMBLE_E_INVALID, "samble_knn_f32: K must be one of 1,3,8,16,20,32,40,64");

@@ -469,19 +469,25 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
 
 
 // workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
-extern "C" size_t samble_knn_ws_floats(int B, int Nq, int Nk, int K) {
-  return (size_t)B * Nk * Nq + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
+static bool knn_uses_fused(int C, int K, int Nk) {
+  return !g_force_unfused && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
+}
+
+// the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path
+extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K) {
+  const size_t key_matrix = knn_uses_fused(C, K, Nk) ? 0 : (size_t)B * Nk * Nq;
+  return key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
 }
 
 extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
                                  int K, int* idx_out, float* dist_out, float* ws, hipStream_t stream) {
+  const bool fused = knn_uses_fused(C, K, Nk);
   float* keyT = ws;
-  float* knorm = keyT + (size_t)B * Nk * Nq;
+  float* knorm = keyT + (fused ? 0 : (size_t)B * Nk * Nq);
   float* qnorm = knorm + (size_t)B * Nk;
   float* scale = qnorm + (size_t)B * Nq;
   float* keys = scale + B;
   const bool smallc = C <= 8;
-  const bool fused = !g_force_unfused && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
   float* kout = dist_out ? keys : nullptr;
   if (fused) {
     hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);

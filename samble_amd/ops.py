@@ -55,7 +55,7 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     with torch.cuda.device(xq.device):
         idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xq.device)
         dist = torch.empty((B, Nq, k), dtype=torch.float32, device=xq.device) if want_dist else None
-        nbytes = _lib.query("samble_knn_workspace_bytes", B, Nq, Nk, k)
+        nbytes = _lib.query("samble_knn_workspace_bytes", B, C, Nq, Nk, k)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xq.device)
         _lib.call("samble_knn_f32", xq.data_ptr(), C * Nq, Nq, xk.data_ptr(), C * Nk, Nk, B, C, k, idx.data_ptr(),
                   _p(dist), ws.data_ptr(), nbytes, _stream())
