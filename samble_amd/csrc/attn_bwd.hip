@@ -201,13 +201,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict_
     f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());    // S^T  (keys x queries)
     f32x16 dp = mma_rows_x_regs(Vc, kLdsPad, lo, h, go, zero16());  // dP^T
     const bool tail = (j0 + kTile > NK);
+    // dQ^T[d][i] += sum_j K[j][d] dS[i][j]; dS of register r is produced right before its MFMAs
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float p = __expf(s[r] * scale - my_lse);
       if (tail && (j0 + crow(r, h) >= NK)) p = 0.f;
-      s[r] = p * (dp[r] - my_delta) * scale;  // dS^T, scale of S folded in
+      const float ds = p * (dp[r] - my_delta) * scale;  // dS^T, scale of S folded in
+      mma_tileT_step(Kc, kLdsPad, lo, h, r, ds, dq);
     }
-    mma_tileT_x_acc(Kc, kLdsPad, lo, h, s, dq);  // dQ^T[d][i] += sum_j K[j][d] dS[i][j]
     if (t + 1 < ntiles) {
       tile_store_lds(kr, Kn, kLdsPad, tid);
       tile_store_lds(vr, Vn, kLdsPad, tid);
@@ -303,18 +304,18 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
 
     f32x16 s = mma_rows_x_regs(Qt, kLdsPad, lo, h, kreg, zero16());   // S  (queries x keys)
     f32x16 dp = mma_rows_x_regs(Gt, kLdsPad, lo, h, vreg, zero16());  // dP
-    f32x16 ds;
     const bool tail = (i0 + kTile > M);
+    // dV^T[d][j] += sum_i dO[i][d] P[i][j];  dK^T[d][j] += sum_i Q[i][d] dS[i][j]: P / dS of register r
+    // are produced right before the eight MFMAs that consume them
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ir = crow(r, h);
       float p = __expf(s[r] * scale - Lt[ir]);
       if (tail && (i0 + ir >= M)) p = 0.f;
-      s[r] = p;
-      ds[r] = p * (dp[r] - Dt[ir]) * scale;
+      const float ds = p * (dp[r] - Dt[ir]) * scale;
+      mma_tileT_step(Gt, kLdsPad, lo, h, r, p, dv);
+      mma_tileT_step(Qt, kLdsPad, lo, h, r, ds, dk);
     }
-    mma_tileT_x_acc(Gt, kLdsPad, lo, h, s, dv);   // dV^T[d][j] += sum_i dO[i][d] P[i][j]
-    mma_tileT_x_acc(Qt, kLdsPad, lo, h, ds, dk);  // dK^T[d][j] += sum_i Q[i][d] dS[i][j]
     if (t + 1 < ntiles) commit(nxt);
     __syncthreads();
   }

@@ -83,20 +83,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     }
     mt = fmaxf(mt, wave_xor32(mt));
     const float mnew = fmaxf(m, mt);
-    const float alpha = __expf(m - mnew);
+    if (__any(mnew != m)) {  // the running max moved for some row of this wave: rescale (rare after the first tiles)
+      const float alpha = __expf(m - mnew);
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+      m = mnew;
+    }
+    // O^T += V_tile^T P^T, one accumulator register (= 2 key rows) at a time: the exp of register
+    // t+1 issues while the four MFMAs of register t run
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = __expf(s[r] - mnew);
-      s[r] = p;
+    for (int t16 = 0; t16 < 16; ++t16) {
+      const float p = __expf(s[t16] - m);
       ps += p;
+      mma_tileT_step(Vc, 128, lo, h, t16, p, oacc);
     }
-    l = l * alpha + ps;
-    m = mnew;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
-    // O^T += V_tile^T P^T : the P registers are the B operands
-    mma_tileT_x_acc(Vc, 128, lo, h, s, oacc);
+    l += ps;
 
     if (t + 1 < ntiles) {
       tile_store_lds(kr, Kn, kLdsPad, tid);

@@ -121,6 +121,15 @@ __device__ __forceinline__ void mma_tileT_x_acc(const float* __restrict__ lds_ti
   }
 }
 
+// One step t of mma_tileT_x_acc (rows crow(t,0), crow(t,1) of the tile): lets the caller interleave
+// the VALU that produces register t of P / dS with the MFMAs that consume it.
+__device__ __forceinline__ void mma_tileT_step(const float* __restrict__ lds_tile, int lds_stride, int lane_lo, int h,
+                                               int t, float b, f32x16 (&out)[4]) {
+  const float* row = lds_tile + crow(t, h) * lds_stride + lane_lo;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(row[32 * dt], b, out[dt]);
+}
+
 // XCD-aware (chunk, cloud) assignment for a grid (chunks, clouds): workgroups are dealt round-robin
 // over the 8 XCDs, each with a private 4 MB L2.  Give every XCD its own clouds so that the K/V (or
 // key-set) tiles all of a cloud's workgroups stream are re-read from that XCD's L2 rather than
