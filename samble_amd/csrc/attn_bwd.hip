@@ -202,18 +202,12 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict_
     f32x16 dp = mma_rows_x_regs(Vc, kLdsPad, lo, h, go, zero16());  // dP^T
     const bool tail = (j0 + kTile > NK);
     // dQ^T[d][i] += sum_j K[j][d] dS[i][j]; dS of register r is produced right before its MFMAs
-    TileTOperands ka[3];
-    ka[0] = tileT_read(Kc, kLdsPad, lo, h, 0);
-    ka[1] = tileT_read(Kc, kLdsPad, lo, h, 1);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (r + 2 < 16) ka[(r + 2) % 3] = tileT_read(Kc, kLdsPad, lo, h, r + 2);  // K rows two steps ahead
       float p = __expf(s[r] * scale - my_lse);
       if (tail && (j0 + crow(r, h) >= NK)) p = 0.f;
       const float ds = p * (dp[r] - my_delta) * scale;  // dS^T, scale of S folded in
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      tileT_mma(ka[r % 3], ds, dq);
+      mma_tileT_step(Kc, kLdsPad, lo, h, r, ds, dq);
     }
     if (t + 1 < ntiles) {
       tile_store_lds(kr, Kn, kLdsPad, tid);
@@ -313,23 +307,14 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
     const bool tail = (i0 + kTile > M);
     // dV^T[d][j] += sum_i dO[i][d] P[i][j];  dK^T[d][j] += sum_i Q[i][d] dS[i][j]: P / dS of register r
     // are produced right before the eight MFMAs that consume them
-    TileTOperands ga[2], qa[2];
-    ga[0] = tileT_read(Gt, kLdsPad, lo, h, 0);
-    qa[0] = tileT_read(Qt, kLdsPad, lo, h, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (r + 1 < 16) {  // dO / Q rows of the next step (8 MFMAs = 512 cycles ahead)
-        ga[(r + 1) & 1] = tileT_read(Gt, kLdsPad, lo, h, r + 1);
-        qa[(r + 1) & 1] = tileT_read(Qt, kLdsPad, lo, h, r + 1);
-      }
       const int ir = crow(r, h);
       float p = __expf(s[r] * scale - Lt[ir]);
       if (tail && (i0 + ir >= M)) p = 0.f;
       const float ds = p * (dp[r] - Dt[ir]) * scale;
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-      tileT_mma(ga[r & 1], p, dv);
-      tileT_mma(qa[r & 1], ds, dk);
+      mma_tileT_step(Gt, kLdsPad, lo, h, r, p, dv);
+      mma_tileT_step(Qt, kLdsPad, lo, h, r, ds, dk);
     }
     if (t + 1 < ntiles) commit(nxt);
     __syncthreads();

@@ -93,17 +93,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     // O^T += V_tile^T P^T, one accumulator register (= 2 key rows) at a time: the exp of register
     // t+1 issues while the four MFMAs of register t run
     float ps = 0.f;
-    TileTOperands va[3];
-    va[0] = tileT_read(Vc, 128, lo, h, 0);
-    va[1] = tileT_read(Vc, 128, lo, h, 1);
 #pragma unroll
     for (int t16 = 0; t16 < 16; ++t16) {
-      if (t16 + 2 < 16) va[(t16 + 2) % 3] = tileT_read(Vc, 128, lo, h, t16 + 2);  // V rows two steps ahead
       const float p = __expf(s[t16] - m);
       ps += p;
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      tileT_mma(va[t16 % 3], p, oacc);
+      mma_tileT_step(Vc, 128, lo, h, t16, p, oacc);
     }
     l += ps;
 

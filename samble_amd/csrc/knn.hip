@@ -326,7 +326,9 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
     const int j0 = t * 32;
     if (t + 1 < ntiles) issue(j0 + 32);
     const float* xs = tiles + cur * TILE + (H * h) * 32 + lo;
-    f32x16 acc = mma_strided_x_regs<H, 32>(xs, q, zero16());
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) acc = mfma32(xs[kk * 32], q[kk], acc);
     acc = mfma32(h == 0 ? bns[cur * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
     const bool tail = j0 + 32 > Nk;
     if (!SELECT) {  // ablation build: keep the accumulator live, skip the selection

@@ -129,21 +129,11 @@ __global__ __launch_bounds__(256, 2) void proj_dx_kernel(const float* __restrict
     __syncthreads();
     // D[row = channel c][col = point n] += sum_o W[o][c] * dqkv[n][o];  o = 64h + kk within the chunk
     const float* wp = Ws + (64 * h) * 128 + lo;
-    TileTOperands wa[3];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      wa[0].v[ct] = wp[32 * ct];
-      wa[1].v[ct] = wp[128 + 32 * ct];
-    }
 #pragma unroll
     for (int kk = 0; kk < 64; ++kk) {
-      if (kk + 2 < 64) {
+      const float bval = gr[kk];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) wa[(kk + 2) % 3].v[ct] = wp[(kk + 2) * 128 + 32 * ct];
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-      tileT_mma(wa[kk % 3], gr[kk], acc);
+      for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(wp[kk * 128 + 32 * ct], bval, acc[ct]);
     }
   }
   if (nvalid) {
@@ -220,24 +210,18 @@ __global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict
     const float* gt = cur;
     const float* xt = cur + kTile * GS;
     // D[row = o][col = c] += sum_n dqkv[n][o] * x[c][n];  n = 16h + kk within the tile
-    float a[2][3], bb[2][4];
-    auto rd = [&](int kk, int slot) {
-      const int nn = 16 * h + kk;
-#pragma unroll
-      for (int ot = 0; ot < 3; ++ot) a[slot][ot] = gt[nn * GS + 96 * wave + 32 * ot + lo];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) bb[slot][ct] = xt[(32 * ct + lo) * XS + nn];
-    };
-    rd(0, 0);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      if (kk + 1 < 16) rd(kk + 1, (kk + 1) & 1);  // operands of the next k-step (12 MFMAs ahead)
-      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      const int nn = 16 * h + kk;
+      float a[3], bb[4];
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot) a[ot] = gt[nn * GS + 96 * wave + 32 * ot + lo];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bb[ct] = xt[(32 * ct + lo) * XS + nn];
 #pragma unroll
       for (int ot = 0; ot < 3; ++ot)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ot][ct] = mfma32(a[kk & 1][ot], bb[kk & 1][ct], acc[ot][ct]);
+        for (int ct = 0; ct < 4; ++ct) acc[ot][ct] = mfma32(a[ot], bb[ct], acc[ot][ct]);
     }
     if (t + 1 < ntiles) commit(nxt);
     __syncthreads();

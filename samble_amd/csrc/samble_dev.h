@@ -90,47 +90,11 @@ __device__ __forceinline__ void tile_store_lds(const TileRegs& t, float* __restr
 
 // acc(32x32) += Ltile(rows from LDS, read row-wise) x Rreg(64 register-resident floats)^T
 //   D[row][col] += sum_c L[row][c] * R[col][c]; lane (x, h) supplies L[x][kperm] and R[x][kperm].
-// The LDS operand is read in chunks of 8 k-steps, one chunk AHEAD of the MFMAs that consume it
-// (two register sets): a v_mfma_f32_32x32x2 occupies the pipe for 64 cycles, an LDS read takes
-// longer than that to return, and left to itself hipcc issues each read right before its MFMA.
 __device__ __forceinline__ f32x16 mma_rows_x_regs(const float* __restrict__ lds_tile, int lds_stride, int lane_lo,
                                                   int h, const float (&reg)[64], f32x16 acc) {
   const float* lp = lds_tile + lane_lo * lds_stride + 64 * h;
-  float a[2][8];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) a[0][u] = lp[u];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    if (c + 1 < 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[(c + 1) & 1][u] = lp[8 * (c + 1) + u];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the next chunk's DS reads first ...
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // ... then this chunk's 8 MFMAs
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc = mfma32(a[c & 1][u], reg[8 * c + u], acc);
-  }
-  return acc;
-}
-
-// Same pipelining for an LDS operand whose k-steps are STEP floats apart (channel-major key tiles of
-// the kNN kernel: element kk of this lane at lp[kk * STEP]); N k-steps, N a multiple of 8.
-template <int N, int STEP>
-__device__ __forceinline__ f32x16 mma_strided_x_regs(const float* __restrict__ lp, const float (&reg)[N], f32x16 acc) {
-  float a[2][8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) a[0][u] = lp[u * STEP];
-#pragma unroll
-  for (int c = 0; c < N / 8; ++c) {
-    if (c + 1 < N / 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[(c + 1) & 1][u] = lp[(8 * (c + 1) + u) * STEP];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) acc = mfma32(a[c & 1][u], reg[8 * c + u], acc);
-  }
+  for (int kk = 0; kk < 64; ++kk) acc = mfma32(lp[kk], reg[kk], acc);
   return acc;
 }
 
@@ -157,23 +121,13 @@ __device__ __forceinline__ void mma_tileT_x_acc(const float* __restrict__ lds_ti
   }
 }
 
-// One step t of mma_tileT_x_acc (rows crow(t,0), crow(t,1) of the tile), split into the LDS read of
-// the four A operands and the four MFMAs, so that a caller can read step t+2 before issuing step t
-// and produce register t of P / dS in between.
-struct TileTOperands {
-  float v[4];
-};
-__device__ __forceinline__ TileTOperands tileT_read(const float* __restrict__ lds_tile, int lds_stride, int lane_lo,
-                                                    int h, int t) {
+// One step t of mma_tileT_x_acc (rows crow(t,0), crow(t,1) of the tile): lets the caller interleave
+// the VALU that produces register t of P / dS with the MFMAs that consume it.
+__device__ __forceinline__ void mma_tileT_step(const float* __restrict__ lds_tile, int lds_stride, int lane_lo, int h,
+                                               int t, float b, f32x16 (&out)[4]) {
   const float* row = lds_tile + crow(t, h) * lds_stride + lane_lo;
-  TileTOperands o;
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o.v[dt] = row[32 * dt];
-  return o;
-}
-__device__ __forceinline__ void tileT_mma(const TileTOperands& a, float b, f32x16 (&out)[4]) {
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(a.v[dt], b, out[dt]);
+  for (int dt = 0; dt < 4; ++dt) out[dt] = mfma32(row[32 * dt], b, out[dt]);
 }
 
 // XCD-aware (chunk, cloud) assignment for a grid (chunks, clouds): workgroups are dealt round-robin
