@@ -77,6 +77,10 @@ int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const flo
                         int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
                         float* dtokens, void* ws, size_t ws_bytes, void* stream);
 
+/* Debug hook for timing ablations (tools/ablate_*.py): which = 0 selects attn_fwd, mode 1..3 a
+ * timing-only build (wrong outputs), 0 the real kernel.  Process-wide; not for production use. */
+void samble_debug_ablate(int which, int mode);
+
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
  * the N point rows).  O (B,N,D) contiguous: row i = softmax(Q_i K^T / sqrt(D)) V, the row the

@@ -17,6 +17,9 @@ namespace samble {
 
 constexpr int kFwdLdsFloats = 2 * (kTile * kLdsPad + kTile * 128);
 
+// ABL (timing-only ablation builds, wrong outputs): 0 = real kernel, 1 = softmax skipped,
+// 2 = tile staging skipped (no global loads / LDS commits), 3 = staging and barrier skipped
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const float* __restrict__ Q, long q_bs, long q_rs, const float* __restrict__ K, long k_bs, long k_rs,
     const float* __restrict__ V, long v_bs, long v_rs, int N, int NK, float scale, float* __restrict__ O,
@@ -61,13 +64,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     float* Kn = smem + ((t & 1) ^ 1) * kBuf;
     float* Vn = Kn + kTile * kLdsPad;
     const int j0 = t * kTile;
-    if (t + 1 < ntiles) {
+    if (ABL < 2 && t + 1 < ntiles) {
       tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
       tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
     }
     // S^T tile: rows = keys of this tile, cols = this wave's 32 queries
     f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());
 
+    if (ABL == 1) {
+#pragma unroll
+      for (int t16 = 0; t16 < 16; ++t16) mma_tileT_step(Vc, 128, lo, h, t16, s[t16], oacc);
+    } else {
     const bool tail = (j0 + kTile > N);  // tile holds token keys and/or padding (wave-uniform)
     float mt = kNegInf;
 #pragma unroll
@@ -100,12 +107,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
       mma_tileT_step(Vc, 128, lo, h, t16, p, oacc);
     }
     l += ps;
+    }
 
-    if (t + 1 < ntiles) {
+    if (ABL < 2 && t + 1 < ntiles) {
       tile_store_lds(kr, Kn, kLdsPad, tid);
       tile_store_lds(vr, Vn, 128, tid);
     }
-    __syncthreads();
+    if (ABL < 3) __syncthreads();
   }
 
   const float ltot = l + wave_xor32(l);
@@ -129,19 +137,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
 
 using namespace samble;
 
+static int g_fwd_ablate = 0;
+extern "C" __attribute__((visibility("default"))) void samble_debug_ablate(int which, int mode) {
+  if (which == 0) g_fwd_ablate = mode;
+}
+
 extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, int B, int N, int NK, float scale, float* O,
                                       float* lse, float* tok, int nt, hipStream_t stream) {
-  static bool attr_set = false;
   const size_t lds = kFwdLdsFloats * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kern = g_fwd_ablate == 1 ? attn_fwd_kernel<1> : g_fwd_ablate == 2 ? attn_fwd_kernel<2>
+            : g_fwd_ablate == 3 ? attn_fwd_kernel<3> : attn_fwd_kernel<0>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
   dim3 grid((N + 127) / 128, B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK,
-                     scale, O, lse, tok, nt);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
+                     lse, tok, nt);
   return (int)hipGetLastError();
 }
