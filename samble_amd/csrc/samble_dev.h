@@ -24,7 +24,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 constexpr int kTile = 32;           // MFMA tile edge
-constexpr int kLdsPad = 129;        // row stride (floats) of a [row][128] LDS tile read by rows
+// Row stride (floats) of a [row][128] LDS tile that is read by rows (lane = row, 16 bytes = 4 k-steps
+// per ds_read_b128): 132 = 33 x 16 B keeps rows 16-byte aligned, and 33 being odd makes both the
+// 16-byte row reads (16-lane groups) and the 16-byte staging writes bank-conflict free (checked
+// against the bank rules of MI355X_MICROARCH.md).  Column-wise reads (lane = channel) are
+// conflict free for any stride.
+constexpr int kLdsPad = 132;
 constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -56,9 +61,8 @@ __device__ __forceinline__ void load_row_half(const float* __restrict__ row_ptr,
 
 // Cooperative copy of a [32][128] fp32 tile (rows `row0..row0+31` of a point-major matrix
 // with `row_stride` floats per row) into LDS with row stride `lds_stride`.  256 threads,
-// 16-byte global loads (a row is 512 contiguous bytes), scalar LDS stores (the odd stride
-// that makes row-wise ds_read_b32 conflict-free rules out wider stores).  Rows >= n_rows
-// are filled with zeros.  Split in two so the global loads can be issued a phase early.
+// 16-byte global loads (a row is 512 contiguous bytes) and 16-byte LDS stores (lds_stride must be
+// a multiple of 4).  Rows >= n_rows are filled with zeros.  Split in two so the global loads can be issued a phase early.
 struct TileRegs {
   f32x4 v[4];
 };
@@ -80,11 +84,7 @@ __device__ __forceinline__ void tile_store_lds(const TileRegs& t, float* __restr
   for (int i = 0; i < 4; ++i) {
     int e = tid + 256 * i;
     int r = e >> 5, c4 = e & 31;
-    float* d = lds + r * lds_stride + 4 * c4;
-    d[0] = t.v[i][0];
-    d[1] = t.v[i][1];
-    d[2] = t.v[i][2];
-    d[3] = t.v[i][3];
+    *reinterpret_cast<f32x4*>(lds + r * lds_stride + 4 * c4) = t.v[i];
   }
 }
 
@@ -92,18 +92,26 @@ __device__ __forceinline__ void tile_store_lds(const TileRegs& t, float* __restr
 //   D[row][col] += sum_c L[row][c] * R[col][c]; lane (x, h) supplies L[x][kperm] and R[x][kperm].
 __device__ __forceinline__ f32x16 mma_rows_x_regs(const float* __restrict__ lds_tile, int lds_stride, int lane_lo,
                                                   int h, const float (&reg)[64], f32x16 acc) {
-  const float* lp = lds_tile + lane_lo * lds_stride + 64 * h;
+  const f32x4* lp = reinterpret_cast<const f32x4*>(lds_tile + lane_lo * lds_stride + 64 * h);
 #pragma unroll
-  for (int kk = 0; kk < 64; ++kk) acc = mfma32(lp[kk], reg[kk], acc);
+  for (int q4 = 0; q4 < 16; ++q4) {
+    const f32x4 a = lp[q4];  // one ds_read_b128 feeds four MFMA steps
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = mfma32(a[e], reg[4 * q4 + e], acc);
+  }
   return acc;
 }
 
 // Same contraction with the register operand on the A side (rows) and LDS on the B side.
 __device__ __forceinline__ f32x16 mma_regs_x_rows(const float (&reg)[64], const float* __restrict__ lds_tile,
                                                   int lds_stride, int lane_lo, int h, f32x16 acc) {
-  const float* lp = lds_tile + lane_lo * lds_stride + 64 * h;
+  const f32x4* lp = reinterpret_cast<const f32x4*>(lds_tile + lane_lo * lds_stride + 64 * h);
 #pragma unroll
-  for (int kk = 0; kk < 64; ++kk) acc = mfma32(reg[kk], lp[kk], acc);
+  for (int q4 = 0; q4 < 16; ++q4) {
+    const f32x4 b = lp[q4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = mfma32(reg[4 * q4 + e], b[e], acc);
+  }
   return acc;
 }
 
