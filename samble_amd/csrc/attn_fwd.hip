@@ -18,7 +18,8 @@ namespace samble {
 constexpr int kFwdLdsFloats = 2 * (kTile * kLdsPad + kTile * 128);
 
 // ABL (timing-only ablation builds, wrong outputs): 0 = real kernel, 1 = softmax skipped,
-// 2 = tile staging skipped (no global loads / LDS commits), 3 = staging and barrier skipped
+// 2 = tile staging skipped (no global loads / LDS commits), 3 = staging and barrier skipped,
+// 4 = global loads kept but LDS commit skipped, 5 = LDS commit kept but global loads skipped
 template <int ABL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     const float* __restrict__ Q, long q_bs, long q_rs, const float* __restrict__ K, long k_bs, long k_rs,
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     float* Kn = smem + ((t & 1) ^ 1) * kBuf;
     float* Vn = Kn + kTile * kLdsPad;
     const int j0 = t * kTile;
-    if (ABL < 2 && t + 1 < ntiles) {
+    if ((ABL < 2 || ABL == 4) && t + 1 < ntiles) {
       tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
       tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
     }
@@ -109,7 +110,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
     l += ps;
     }
 
-    if (ABL < 2 && t + 1 < ntiles) {
+    if (ABL == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(kr.v[i][0]), "v"(vr.v[i][0]));
+    }
+    if ((ABL < 2 || ABL == 5) && t + 1 < ntiles) {
       tile_store_lds(kr, Kn, kLdsPad, tid);
       tile_store_lds(vr, Vn, 128, tid);
     }
@@ -147,7 +152,8 @@ extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, cons
                                       float* lse, float* tok, int nt, hipStream_t stream) {
   const size_t lds = kFwdLdsFloats * sizeof(float);
   auto kern = g_fwd_ablate == 1 ? attn_fwd_kernel<1> : g_fwd_ablate == 2 ? attn_fwd_kernel<2>
-            : g_fwd_ablate == 3 ? attn_fwd_kernel<3> : attn_fwd_kernel<0>;
+            : g_fwd_ablate == 3 ? attn_fwd_kernel<3> : g_fwd_ablate == 4 ? attn_fwd_kernel<4>
+            : g_fwd_ablate == 5 ? attn_fwd_kernel<5> : attn_fwd_kernel<0>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;

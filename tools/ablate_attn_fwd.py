@@ -16,7 +16,8 @@ def t(fn, it=20):
     return a.elapsed_time(b) / it
 lib = _lib.load()
 flops = 2 * 2 * N * (N + nt) * D * B
-for mode, name in ((0, "real kernel"), (1, "softmax skipped"), (2, "tile staging skipped"), (3, "staging + barrier skipped")):
+for mode, name in ((0, "real kernel"), (1, "softmax skipped"), (2, "tile staging skipped"), (3, "staging + barrier skipped"),
+                   (4, "global loads only (no LDS commit)"), (5, "LDS commit only (no global loads)")):
     lib.samble_debug_ablate(0, mode)
     ms = t(lambda: ops.stage_attn_fwd(q, k, v, N, nt))
     print(f"{name:28s} {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s executed")
