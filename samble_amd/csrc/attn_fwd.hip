@@ -6,8 +6,10 @@
 //     lse (B,N)     = log sum_j exp(S_ij)   (lets later kernels rebuild any A_ij = exp(S_ij - lse_i))
 //     tok (B,N,nt)  = S[:, N:N+nt]          (attention_bins_beforesoftmax, downsample.py:149-152)
 //
-// Mapping: one workgroup = 4 waves = 128 query rows, one wave = 32 rows.  Keys/values stream through
-// LDS in 32-row tiles shared by the 4 waves (double buffered, loads for tile t+1 issued before the
+// Mapping: one workgroup = 8 waves = 256 query rows (one workgroup per CU, two waves per SIMD), one
+// wave = 32 rows.  Keys/values stream through LDS in 32-row tiles shared by the 8 waves (the tile
+// reads of a launch are 16 MB per cloud x its 8 workgroups; with 4-wave workgroups twice that, and
+// the ablation of tools/ablate_attn_fwd.py showed the tile load latency exposed) (double buffered, loads for tile t+1 issued before the
 // MFMAs of tile t).  Per tile and wave: S^T = K_tile Q^T (64 MFMA, queries on the lane axis so the
 // row statistics are lane-local), softmax in registers, O^T += V_tile^T P^T (64 MFMA) with the S
 // accumulator registers fed back directly as MFMA B operands.  Bound: fp32 MFMA (157 TFLOP/s).
@@ -20,8 +22,8 @@ constexpr int kFwdLdsFloats = 2 * (kTile * kLdsPad + kTile * 128);
 // ABL (timing-only ablation builds, wrong outputs): 0 = real kernel, 1 = softmax skipped,
 // 2 = tile staging skipped (no global loads / LDS commits), 3 = staging and barrier skipped,
 // 4 = global loads kept but LDS commit skipped, 5 = LDS commit kept but global loads skipped
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
+template <int ABL, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
     const float* __restrict__ Q, long q_bs, long q_rs, const float* __restrict__ K, long k_bs, long k_rs,
     const float* __restrict__ V, long v_bs, long v_rs, int N, int NK, float scale, float* __restrict__ O,
     float* __restrict__ lse, float* __restrict__ tok, int nt) {
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int qrow = chunk * 128 + wave * 32 + lo;
+  const int qrow = chunk * (32 * NW) + wave * 32 + lo;
   const bool qvalid = qrow < N;
 
   const float* Kb = K + (long)b * k_bs;
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(
   float m = kNegInf, l = 0.f;
 
   const int ntiles = (NK + kTile - 1) / kTile;
-  TileRegs kr, vr;
+  TileRegsT<64 * NW> kr, vr;
   tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
   tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
   tile_store_lds(kr, smem, kLdsPad, tid);
@@ -157,8 +159,8 @@ extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, cons
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
-  dim3 grid((N + 127) / 128, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
+  dim3 grid((N + 255) / 256, B);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
                      lse, tok, nt);
   return (int)hipGetLastError();
 }

@@ -63,15 +63,19 @@ __device__ __forceinline__ void load_row_half(const float* __restrict__ row_ptr,
 // with `row_stride` floats per row) into LDS with row stride `lds_stride`.  256 threads,
 // 16-byte global loads (a row is 512 contiguous bytes) and 16-byte LDS stores (lds_stride must be
 // a multiple of 4).  Rows >= n_rows are filled with zeros.  Split in two so the global loads can be issued a phase early.
-struct TileRegs {
-  f32x4 v[4];
+template <int NTHREADS = 256>
+struct TileRegsT {
+  static constexpr int kPer = 1024 / NTHREADS;  // float4 per thread: 32 rows x 32 float4 per tile
+  f32x4 v[kPer];
 };
+using TileRegs = TileRegsT<256>;
 
-__device__ __forceinline__ void tile_load_issue(TileRegs& t, const float* __restrict__ base, long row_stride,
-                                                int row0, int n_rows, int tid) {
+template <int NTHREADS>
+__device__ __forceinline__ void tile_load_issue(TileRegsT<NTHREADS>& t, const float* __restrict__ base,
+                                                long row_stride, int row0, int n_rows, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int e = tid + 256 * i;        // float4 index in the tile: 32 rows x 32 float4
+  for (int i = 0; i < TileRegsT<NTHREADS>::kPer; ++i) {
+    int e = tid + NTHREADS * i;   // float4 index in the tile: 32 rows x 32 float4
     int r = e >> 5, c4 = e & 31;
     int row = row0 + r;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -79,10 +83,12 @@ __device__ __forceinline__ void tile_load_issue(TileRegs& t, const float* __rest
   }
 }
 
-__device__ __forceinline__ void tile_store_lds(const TileRegs& t, float* __restrict__ lds, int lds_stride, int tid) {
+template <int NTHREADS>
+__device__ __forceinline__ void tile_store_lds(const TileRegsT<NTHREADS>& t, float* __restrict__ lds, int lds_stride,
+                                               int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int e = tid + 256 * i;
+  for (int i = 0; i < TileRegsT<NTHREADS>::kPer; ++i) {
+    int e = tid + NTHREADS * i;
     int r = e >> 5, c4 = e & 31;
     *reinterpret_cast<f32x4*>(lds + r * lds_stride + 4 * c4) = t.v[i];
   }
