@@ -85,10 +85,19 @@ void samble_debug_ablate(int which, int mode);
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
  * the N point rows).  O (B,N,D) contiguous: row i = softmax(Q_i K^T / sqrt(D)) V, the row the
  * reference gathers if i is sampled; lse (B,N) log-sum-exp of the scaled logits over all N+nt
- * columns; tok (B,N,nt) = attention_bins_beforesoftmax. */
+ * columns; tok (B,N,nt) = attention_bins_beforesoftmax; row_std (B,N) or NULL = unbiased std of each
+ * row of the point-to-point block A[:, :N] (idx_mode "row_std", models/downsample.py:319-320). */
 int samble_attn_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                         const float* V, int64_t v_bs, int64_t v_rs, int B, int N, int nt, int D, float* O, float* lse,
-                        float* tok, void* stream);
+                        float* tok, float* row_std, void* stream);
+
+/* idx_mode "col_sum" (models/downsample.py:315-318): colsum (B,N) = column sums of A[:, :N], from Q, the
+ * point rows of K and the forward's lse. */
+int samble_attn_colsum_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                           const float* lse, int B, int N, int D, float* colsum, void* stream);
+
+/* score = stat with NaN -> 0 (models/downsample.py:342) and its per-cloud z-score, for the dense modes */
+int samble_stat_score_f32(const float* stat, int B, int N, float* score, float* z, void* stream);
 
 /* ---- models/downsample.py:300-344  calculate_attention_score (sparse_* modes) ----------------
  * nn (B,N,KN) int32 = neighbour lists from samble_knn_f32 on the layer input.  score (B,N),

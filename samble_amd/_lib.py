@@ -33,7 +33,10 @@ _SIGNATURES = {
                                     c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
     "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_attn_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
+                                       c_int, c_void_p, c_void_p]),
+    "samble_stat_score_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_score_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_sparse_score_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

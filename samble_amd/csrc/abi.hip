@@ -13,7 +13,10 @@ extern "C" {
 size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K);
 int samble_launch_knn(const float*, long, int, const float*, long, int, int, int, int, int*, float*, float*, hipStream_t);
 int samble_launch_attn_fwd(const float*, long, long, const float*, long, long, const float*, long, long, int, int, int,
-                           float, float*, float*, float*, int, hipStream_t);
+                           float, float*, float*, float*, int, float*, hipStream_t);
+int samble_launch_attn_colsum(const float*, long, long, const float*, long, long, const float*, int, int, float, float*,
+                              hipStream_t);
+int samble_launch_stat_score(const float*, int, int, float*, float*, hipStream_t);
 size_t samble_score_ws_bytes(int B, int N);
 int samble_launch_sparse_score(const float*, long, long, const float*, long, long, const float*, const int*, int, int,
                                int, float, int, float*, float*, int*, void*, hipStream_t);
@@ -84,7 +87,7 @@ SAMBLE_API int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float
 
 SAMBLE_API int samble_attn_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
                                    int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, int B, int N, int nt, int D,
-                                   float* O, float* lse, float* tok, void* stream) {
+                                   float* O, float* lse, float* tok, float* row_std, void* stream) {
   if (!Q || !K || !V || !O || !lse) return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: D must be 128");
   if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (nt > 0 && !tok))
@@ -92,7 +95,7 @@ SAMBLE_API int samble_attn_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
   if ((q_rs & 3) || (k_rs & 3) || (v_rs & 3) || (q_bs & 3) || (k_bs & 3) || (v_bs & 3))
     return fail(SAMBLE_E_INVALID, "samble_attn_fwd_f32: strides must be multiples of 4 elements (16-byte rows)");
   return done(samble_launch_attn_fwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, B, N, N + nt, inv_sqrt_d(D), O, lse,
-                                     tok, nt, (hipStream_t)stream),
+                                     tok, nt, row_std, (hipStream_t)stream),
               "samble_attn_fwd_f32");
 }
 
@@ -256,4 +259,20 @@ SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs,
   return done(samble_launch_n2p_fwd(qkv, bs, rs, nn, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), out,
                                     (hipStream_t)stream),
               "samble_n2p_attn_fwd_f32");
+}
+
+SAMBLE_API int samble_attn_colsum_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                      int64_t k_rs, const float* lse, int B, int N, int D, float* colsum, void* stream) {
+  if (!Q || !K || !lse || !colsum) return fail(SAMBLE_E_INVALID, "samble_attn_colsum_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_colsum_f32: D must be 128");
+  if ((q_rs & 3) || (k_rs & 3) || (q_bs & 3) || (k_bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_attn_colsum_f32: strides must be multiples of 4 elements");
+  return done(samble_launch_attn_colsum(Q, q_bs, q_rs, K, k_bs, k_rs, lse, B, N, inv_sqrt_d(D), colsum,
+                                        (hipStream_t)stream),
+              "samble_attn_colsum_f32");
+}
+
+SAMBLE_API int samble_stat_score_f32(const float* stat, int B, int N, float* score, float* z, void* stream) {
+  if (!stat || !score || !z || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_stat_score_f32: bad argument");
+  return done(samble_launch_stat_score(stat, B, N, score, z, (hipStream_t)stream), "samble_stat_score_f32");
 }

@@ -26,7 +26,7 @@ template <int ABL, int NW = 8>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
     const float* __restrict__ Q, long q_bs, long q_rs, const float* __restrict__ K, long k_bs, long k_rs,
     const float* __restrict__ V, long v_bs, long v_rs, int N, int NK, float scale, float* __restrict__ O,
-    float* __restrict__ lse, float* __restrict__ tok, int nt) {
+    float* __restrict__ lse, float* __restrict__ tok, int nt, float* __restrict__ row_std) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kBuf = kTile * kLdsPad + kTile * 128;  // one K tile + one V tile
 
@@ -52,6 +52,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
   float m = kNegInf, l = 0.f;
+  // idx_mode row_std (models/downsample.py:319-320): first and second moments of the POINT columns
+  // of each row, kept relative to the running max like l
+  const bool want_std = row_std != nullptr;
+  float sp1 = 0.f, sp2 = 0.f;
 
   const int ntiles = (NK + kTile - 1) / kTile;
   TileRegsT<64 * NW> kr, vr;
@@ -96,6 +100,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
     if (__any(mnew != m)) {  // the running max moved for some row of this wave: rescale (rare after the first tiles)
       const float alpha = __expf(m - mnew);
       l *= alpha;
+      sp1 *= alpha;
+      sp2 *= alpha * alpha;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
       m = mnew;
@@ -107,6 +113,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
     for (int t16 = 0; t16 < 16; ++t16) {
       const float p = __expf(s[t16] - m);
       ps += p;
+      if (want_std && (j0 + crow(t16, h) < N)) {
+        sp1 += p;
+        sp2 = fmaf(p, p, sp2);
+      }
       mma_tileT_step(Vc, 128, lo, h, t16, p, oacc);
     }
     l += ps;
@@ -137,12 +147,86 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(
       }
     }
     if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+    if (want_std) {  // unbiased std over the N point columns of A = p / l  (torch.std default)
+      const float s1 = (sp1 + wave_xor32(sp1)) * inv, s2 = (sp2 + wave_xor32(sp2)) * inv * inv;
+      const float mean = s1 / N;
+      if (h == 0) row_std[(long)b * N + qrow] = sqrtf(fmaxf((s2 - N * mean * mean) / (N - 1), 0.f));
+    }
   }
+}
+
+// idx_mode col_sum (models/downsample.py:315-318): column sums of the point-to-point attention block,
+// colsum_j = sum_i exp(scale <Q_i, K_j> - lse_i).  Key-stationary: one wave = 32 keys (rows in
+// registers), the N query rows stream through LDS; needs the forward's lse.  Fixed summation order.
+__global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                             const float* __restrict__ K, long k_bs, long k_rs,
+                                                             const float* __restrict__ lse, int N, float scale,
+                                                             float* __restrict__ colsum) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = kTile * kLdsPad + kTile;  // Q tile + lse[32]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int j = chunk * 128 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  float kreg[64];
+  if (jvalid) {
+    load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, kreg);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) kreg[i] = 0.f;
+  }
+  const float* Qb = Q + (long)b * q_bs;
+  const int ntiles = (N + kTile - 1) / kTile;
+  TileRegs qr;
+  float st = 0.f;
+  auto issue = [&](int i0) {
+    tile_load_issue(qr, Qb, q_rs, i0, N, tid);
+    if (tid < 32) st = (i0 + tid < N) ? lse[(long)b * N + i0 + tid] : 0.f;
+  };
+  auto commit = [&](float* buf) {
+    tile_store_lds(qr, buf, kLdsPad, tid);
+    if (tid < 32) buf[kTile * kLdsPad + tid] = st;
+  };
+  issue(0);
+  commit(smem);
+  __syncthreads();
+  float sum = 0.f;
+  for (int t = 0; t < ntiles; ++t) {
+    float* cur = smem + (t & 1) * kBuf;
+    float* nxt = smem + ((t & 1) ^ 1) * kBuf;
+    const float* Lt = cur + kTile * kLdsPad;
+    const int i0 = t * kTile;
+    if (t + 1 < ntiles) issue(i0 + kTile);
+    f32x16 s = mma_rows_x_regs(cur, kLdsPad, lo, h, kreg, zero16());  // S (queries x keys)
+    const bool tail = i0 + kTile > N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ir = crow(r, h);
+      float p = __expf(s[r] * scale - Lt[ir]);
+      if (tail && (i0 + ir >= N)) p = 0.f;
+      sum += p;
+    }
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  sum += wave_xor32(sum);
+  if (jvalid && h == 0) colsum[(long)b * N + j] = sum;
 }
 
 }  // namespace samble
 
 using namespace samble;
+
+extern "C" int samble_launch_attn_colsum(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
+                                         const float* lse, int B, int N, float scale, float* colsum,
+                                         hipStream_t stream) {
+  const size_t lds = 2 * (kTile * kLdsPad + kTile) * sizeof(float);
+  hipLaunchKernelGGL(attn_colsum_kernel, dim3((N + 127) / 128, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
+                     lse, N, scale, colsum);
+  return (int)hipGetLastError();
+}
 
 static int g_fwd_ablate = 0;
 extern "C" __attribute__((visibility("default"))) void samble_debug_ablate(int which, int mode) {
@@ -151,7 +235,7 @@ extern "C" __attribute__((visibility("default"))) void samble_debug_ablate(int w
 
 extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, int B, int N, int NK, float scale, float* O,
-                                      float* lse, float* tok, int nt, hipStream_t stream) {
+                                      float* lse, float* tok, int nt, float* row_std, hipStream_t stream) {
   const size_t lds = kFwdLdsFloats * sizeof(float);
   auto kern = g_fwd_ablate == 1 ? attn_fwd_kernel<1> : g_fwd_ablate == 2 ? attn_fwd_kernel<2>
             : g_fwd_ablate == 3 ? attn_fwd_kernel<3> : g_fwd_ablate == 4 ? attn_fwd_kernel<4>
@@ -161,6 +245,6 @@ extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, cons
   if (e != hipSuccess) return (int)e;
   dim3 grid((N + 255) / 256, B);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
-                     lse, tok, nt);
+                     lse, tok, nt, row_std);
   return (int)hipGetLastError();
 }

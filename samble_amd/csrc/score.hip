@@ -206,6 +206,22 @@ extern "C" int samble_launch_sparse_score(const float* Q, long q_bs, long q_rs, 
   return (int)hipGetLastError();
 }
 
+// score = stat with NaN -> 0 (models/downsample.py:342), then the z-score
+__global__ __launch_bounds__(256) void clean_kernel(const float* __restrict__ stat, long n, float* __restrict__ score) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) {
+    const float v = stat[e];
+    score[e] = (v != v) ? 0.f : v;
+  }
+}
+
+extern "C" int samble_launch_stat_score(const float* stat, int B, int N, float* score, float* z, hipStream_t stream) {
+  const long n = (long)B * N;
+  hipLaunchKernelGGL(clean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, stat, n, score);
+  hipLaunchKernelGGL(zscore_kernel, dim3(B), dim3(256), 0, stream, score, N, z);
+  return (int)hipGetLastError();
+}
+
 extern "C" int samble_launch_zscore(const float* score, int B, int N, float* z, hipStream_t stream) {
   hipLaunchKernelGGL(zscore_kernel, dim3(B), dim3(256), 0, stream, score, N, z);
   return (int)hipGetLastError();

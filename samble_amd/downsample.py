@@ -64,9 +64,20 @@ class _SamplerCore(torch.autograd.Function):
         k = qkv[:, :, D:2 * D]
         v = qkv[:, :, 2 * D:3 * D]
 
-        nn_idx = ops.stage_knn(x, x, mod.K)
-        O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
-        score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
+        if mod.idx_mode in ("col_sum", "row_std"):
+            # dense statistics of the attention map: no neighbour lists involved
+            if mod.idx_mode == "row_std":
+                O, lse, tok, stat = ops.stage_attn_fwd(q, k, v, N, nt, want_row_std=True)
+            else:
+                O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
+                stat = ops.stage_attn_colsum(q, k, lse)
+            score, z = ops.stage_stat_score(stat)
+            nn_idx = torch.empty((B, N, 0), dtype=torch.int32, device=x.device)
+            indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
+        else:
+            nn_idx = ops.stage_knn(x, x, mod.K)
+            O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
+            score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
 
         if mod.bin_boundaries is not None:
             mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]

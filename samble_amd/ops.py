@@ -109,9 +109,10 @@ def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff
     return out
 
 
-def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int):
+def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int,
+                   want_row_std: bool = False):
     """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->
-    O (B,N,D), lse (B,N), token logits (B,N,nt)."""
+    O (B,N,D), lse (B,N), token logits (B,N,nt) [, row_std (B,N) when want_row_std]."""
     _need_gpu(q, k, v)
     B, N, D = q.shape
     assert N == n_points and k.shape[1] == n_points + n_tokens and v.shape[1] == k.shape[1]
@@ -122,17 +123,41 @@ def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: 
         O = torch.empty((B, N, D), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
         tok = torch.empty((B, N, max(n_tokens, 1)), dtype=torch.float32, device=q.device)
+        rstd = torch.empty((B, N), dtype=torch.float32, device=q.device) if want_row_std else None
         _lib.call("samble_attn_fwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
                   k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), B, N, n_tokens, D, O.data_ptr(),
-                  lse.data_ptr(), tok.data_ptr(), _stream())
+                  lse.data_ptr(), tok.data_ptr(), _p(rstd), _stream())
+    if want_row_std:
+        return O, lse, tok[:, :, :n_tokens], rstd
     return O, lse, tok[:, :, :n_tokens]
+
+
+def stage_attn_colsum(q: torch.Tensor, k: torch.Tensor, lse: torch.Tensor) -> torch.Tensor:
+    """Column sums (B,N) of the point-to-point attention block (idx_mode col_sum)."""
+    _need_gpu(q, k, lse)
+    B, N, D = q.shape
+    with torch.cuda.device(q.device):
+        out = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        _lib.call("samble_attn_colsum_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), lse.data_ptr(), B, N, D, out.data_ptr(), _stream())
+    return out
+
+
+def stage_stat_score(stat: torch.Tensor):
+    """Dense-mode statistic (B,N) -> (score with NaN -> 0, z-score)."""
+    _need_gpu(stat)
+    stat = _f32c(stat)
+    B, N = stat.shape
+    with torch.cuda.device(stat.device):
+        score = torch.empty_like(stat)
+        z = torch.empty_like(stat)
+        _lib.call("samble_stat_score_f32", stat.data_ptr(), B, N, score.data_ptr(), z.data_ptr(), _stream())
+    return score, z
 
 
 def stage_sparse_score(q, k, lse, nn_idx, idx_mode: str):
     """-> score (B,N), z (B,N), in-degree (B,N) int32 for the sparse_* idx modes."""
     if idx_mode not in SCORE_MODES:
-        if idx_mode in ("col_sum", "row_std"):
-            raise NotImplementedError(f"idx_mode {idx_mode} (dense map statistics) is not built yet")
         raise ValueError("Please check the setting of idx mode!")
     _need_gpu(q, k, lse, nn_idx)
     B, N, D = q.shape

@@ -42,7 +42,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     # validation happens before any HIP call: null pointers / bad sizes come back as SambleError
     with pytest.raises(lib.SambleError, match="null pointer"):
         lib.call("samble_zscore_f32", None, 1, 1, None, None) if False else \
-            lib.call("samble_attn_fwd_f32", None, 0, 0, None, 0, 0, None, 0, 0, 1, 1, 0, 128, None, None, None, None)
+            lib.call("samble_attn_fwd_f32", None, 0, 0, None, 0, 0, None, 0, 0, 1, 1, 0, 128, None, None, None, None, None)
     with pytest.raises(lib.SambleError, match="D must be 128"):
         lib.call("samble_gather_rows_f32", 1, 0, 0, 1, 1, 1, 64, 1, None)
     with pytest.raises(lib.SambleError, match="num_bins"):

@@ -138,6 +138,23 @@ def test_attn_fwd(B, N, nt):
     torch.testing.assert_close(tok.cpu().double(), s[:, :, N:], rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,N,nt", [(2, 256, 6), (1, 1000, 4)])
+def test_dense_map_statistics(B, N, nt):
+    """idx_mode col_sum / row_std: column sums and row std of the point-to-point block A[:, :N]."""
+    q, k, v = _qkv(B, N, nt, 700 + N)
+    q, k = q * 0.4, k * 0.4
+    s = (q.double() @ k.double().transpose(1, 2)) / math.sqrt(128)
+    A = torch.softmax(s, -1)[:, :, :N]
+    O_, lse, tok, rstd = ops().stage_attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), N, nt, want_row_std=True)
+    torch.testing.assert_close(rstd.cpu().double(), A.std(dim=-1), rtol=2e-4, atol=1e-9)
+    col = ops().stage_attn_colsum(q.to(DEV), k.to(DEV), lse)
+    torch.testing.assert_close(col.cpu().double(), A.sum(dim=-2), rtol=2e-5, atol=1e-9)
+    score, z = ops().stage_stat_score(col)
+    assert torch.equal(score, col)
+    zr = (A.sum(-2) - A.sum(-2).mean(-1, keepdim=True)) / A.sum(-2).std(-1, unbiased=False, keepdim=True)
+    torch.testing.assert_close(z.cpu().double(), zr, rtol=1e-3, atol=1e-4)
+
+
 def test_attn_fwd_strided_views():
     """The module hands q/k/v as column slices of one (B, N+nt, 3D) projection."""
     B, N, nt, D = 2, 256, 6, 128
