@@ -143,8 +143,10 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
 // dQ: query-stationary
 // ------------------------------------------------------------------------------------------------
 constexpr int kDqLdsFloats = 2 * (2 * kTile * kLdsPad);
+constexpr int kDqWaves = 8;  // 8 waves = 256 sampled rows per workgroup, two waves per SIMD
 
-__global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void bwd_dq_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
                                                         const float* __restrict__ lse_s,
                                                         const float* __restrict__ delta,
                                                         const float* __restrict__ K, long k_bs, long k_rs,
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict_
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int m = chunk * 128 + wave * 32 + lo;
+  const int m = chunk * (32 * NW) + wave * 32 + lo;
   const bool mvalid = m < M;
   const float* Kb = K + (long)b * k_bs;
   const float* Vb = V + (long)b * v_bs;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void bwd_dq_kernel(const float* __restrict_
   for (int dt = 0; dt < 4; ++dt) dq[dt] = zero16();
 
   const int ntiles = (NK + kTile - 1) / kTile;
-  TileRegs kr, vr;
+  TileRegsT<64 * NW> kr, vr;
   tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
   tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
   tile_store_lds(kr, smem, kLdsPad, tid);
@@ -348,7 +350,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   static bool attr_set = false;
   const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel<kDqWaves>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_kernel),
@@ -360,7 +362,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   const int nparts = (M + 31) / 32;
   hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part);
-  hipLaunchKernelGGL(bwd_dq_kernel, dim3((M + 127) / 128, B), dim3(256), lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs,
+  hipLaunchKernelGGL(bwd_dq_kernel<kDqWaves>, dim3((M + 32 * kDqWaves - 1) / (32 * kDqWaves), B), dim3(64 * kDqWaves),
+                     lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs,
                      k_rs, V, v_bs, v_rs, idx, N, NK, M, scale, dQ, dq_bs, dq_rs);
   hipLaunchKernelGGL(bwd_dkdv_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K,
                      k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
