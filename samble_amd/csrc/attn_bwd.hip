@@ -143,7 +143,7 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
 // dQ: query-stationary
 // ------------------------------------------------------------------------------------------------
 constexpr int kDqLdsFloats = 2 * (2 * kTile * kLdsPad);
-constexpr int kDqWaves = 8;  // 8 waves = 256 sampled rows per workgroup, two waves per SIMD
+constexpr int kDqWaves = 4;  // 4 waves = 128 sampled rows per workgroup (8 waves at 2 per SIMD spill: 1.54 vs 1.07 ms)
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void bwd_dq_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
