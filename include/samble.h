@@ -154,7 +154,9 @@ int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
 /* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows
  * 0..N+nt-1, each with its own strides. */
-size_t samble_attn_bwd_workspace_bytes(int B, int M, int D);
+size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D);
+/* debug / A-B hook: non-zero selects the two-kernel backward (7 MFMA products) instead of the fused one (5) */
+void samble_debug_bwd_split(int on);
 int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                         const float* V, int64_t v_bs, int64_t v_rs, const float* O, const float* lse,
                         const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,

@@ -37,8 +37,9 @@ int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, in
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
-                           float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
+                           float*, float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
                            hipStream_t);
+size_t samble_attn_bwd_slab_floats(int B, int N, int M);
 }
 
 namespace {
@@ -180,9 +181,10 @@ SAMBLE_API int samble_gather_points_f32(const float* pcd, int B, int C, int N, c
               "samble_gather_points_f32");
 }
 
-SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int M, int D) {
+SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D) {
   const size_t tok_part = (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
-  return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + tok_part + 64) * sizeof(float);
+  return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + tok_part + samble_attn_bwd_slab_floats(B, N, M) + 64) *
+         sizeof(float);
 }
 
 SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
@@ -194,7 +196,7 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
   if (!Q || !K || !V || !O || !lse || !idx || !g || !dQ || !dK || !dV || !ws)
     return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: D must be 128");
-  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, M, D))
+  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, N, M, D))
     return fail(SAMBLE_E_WORKSPACE, "samble_attn_bwd_f32: workspace too small");
   if ((dq_rs & 3) || (dk_rs & 3) || (dv_rs & 3) || (q_rs & 3) || (k_rs & 3) || (v_rs & 3))
     return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: row strides must be multiples of 4 elements");
@@ -210,9 +212,10 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
   float* lse_s = dOb + (size_t)B * M * D;
   float* delta = lse_s + (size_t)B * M;
   float* tok_part = delta + (size_t)B * M;
+  float* slab = tok_part + (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
   if (nt < 0 || nt > 8) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: need 0 <= nt <= 8");
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, lse, (const long long*)idx, g, B, N,
-                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part, dQ, dq_bs, dq_rs, dK, dk_bs,
+                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part, slab, dQ, dq_bs, dq_rs, dK, dk_bs,
                                      dk_rs, dV, dv_bs, dv_rs, s),
               "samble_attn_bwd_f32");
 }

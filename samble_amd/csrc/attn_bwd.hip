@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
                                                        const float* __restrict__ g,  // (B,128,M)
                                                        int N, int nt, int M, float scale, float* __restrict__ Qs,
                                                        float* __restrict__ dO, float* __restrict__ lse_s,
-                                                       float* __restrict__ delta, float* __restrict__ tok_part) {
+                                                       float* __restrict__ delta, float* __restrict__ tok_part,
+                                                       float* __restrict__ slab, int nslab, int tok_slab) {
   __shared__ float gt[128 * 33];
   __shared__ float red[4][2][8][128];  // [wave][dK|dV][token][channel]
   const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
       delta[(long)b * M + m] = part;
       lse_s[(long)b * M + m] = lrow;
     }
-    // token keys: P and dS of this row against each token, accumulated into this lane's channels
+    // token keys: P and dS of this row against each token, accumulated into this lane's channels;
+    // their share of dQ of this row (sum_t dS_t K_tok[t]) goes to the extra dQ slab
+    f32x4 dqt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t < nt) {
@@ -87,9 +90,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
         for (int u = 0; u < 4; ++u) {
           av[t][u] = fmaf(p, dv[u], av[t][u]);
           ak[t][u] = fmaf(ds, qv[u], ak[t][u]);
+          dqt[u] = fmaf(ds, kt[t][u], dqt[u]);
         }
       }
     }
+    if (slab)  // slab (b, tok_slab): the token keys' share of dQ
+      *reinterpret_cast<f32x4*>(slab + (((long)b * nslab + tok_slab) * M + m) * 128 + 4 * l32) = dqt;
   }
   if (nt > 0) {
     // the two half-waves of a wave first (register exchange), then the 4 waves through LDS, in a
@@ -137,6 +143,166 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
   for (; p < nparts; ++p) sacc += src[(long)p * 2 * 8 * 128];
   if (which == 0) dK[(long)b * dk_bs + (long)(N + t) * dk_rs + d] = sacc;
   else dV[(long)b * dv_bs + (long)(N + t) * dv_rs + d] = sacc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward over the N point keys: S, dP, dV, dK and dQ from ONE recomputation of S / dP
+// (5 MFMA products per tile instead of the 7 of bwd_dq + bwd_dkdv).
+//
+// Key-stationary like bwd_dkdv (wave = 32 keys, K/V rows and dK^T/dV^T accumulators in registers).
+// For dQ the four waves write their 32x32 dS sub-tiles side by side into one LDS tile
+// dS_all[32 queries][128 keys]; wave w then computes the 32-channel slice
+//     dQ[:, 32w..32w+31] = dS_all x K[keys of this workgroup][32w..32w+31]
+// with that slice of K in registers (64 MFMA, reduced index = the workgroup's 128 keys), so no
+// cross-wave reduction exists.  The dS tile is double buffered and consumed one iteration later,
+// which costs no extra barrier.  Each key block writes its dQ contribution to its own slab;
+// bwd_dq_reduce sums the slabs (and the token-key slab from bwd_prep) in a fixed order and scatters
+// the rows: deterministic, no float atomics.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFusedTile = 2 * kTile * kLdsPad + 2 * kTile;  // Q tile, dO tile, lse[32], delta[32]
+constexpr int kFusedLdsFloats = 2 * kFusedTile + 2 * kTile * kLdsPad;
+
+__global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
+                                                           const float* __restrict__ lse_s,
+                                                           const float* __restrict__ delta,
+                                                           const float* __restrict__ K, long k_bs, long k_rs,
+                                                           const float* __restrict__ V, long v_bs, long v_rs, int N,
+                                                           int M, float scale, float* __restrict__ dK, long dk_bs,
+                                                           long dk_rs, float* __restrict__ dV, long dv_bs, long dv_rs,
+                                                           float* __restrict__ slab, int nslab) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dsbuf = smem + 2 * kFusedTile;  // 2 x [32][kLdsPad]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int j = chunk * 128 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  const float* Qb = Qs + (long)b * M * 128;
+  const float* Gb = dO + (long)b * M * 128;
+
+  float kreg[64], vreg[64], kcol[64];
+  if (jvalid) {
+    load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, kreg);
+    load_row_half(V + (long)b * v_bs + (long)j * v_rs, h, vreg);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      kreg[i] = 0.f;
+      vreg[i] = 0.f;
+    }
+  }
+  // this wave's channel slice of the workgroup's 128 K rows: lane (d, h) holds K[key 64h+kk][32w + d]
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) {
+    const int jj = chunk * 128 + 64 * h + kk;
+    kcol[kk] = (jj < N) ? K[(long)b * k_bs + (long)jj * k_rs + 32 * wave + lo] : 0.f;
+  }
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    dk[dt] = zero16();
+    dv[dt] = zero16();
+  }
+
+  const int ntiles = (M + kTile - 1) / kTile;
+  TileRegs qr, gr;
+  float st = 0.f;
+  auto issue = [&](int i0) {
+    tile_load_issue(qr, Qb, 128, i0, M, tid);
+    tile_load_issue(gr, Gb, 128, i0, M, tid);
+    if (tid < 64) {
+      const int ii = i0 + (tid & 31);
+      const float* src = (tid < 32) ? lse_s : delta;
+      st = (ii < M) ? src[(long)b * M + ii] : 0.f;
+    }
+  };
+  auto commit = [&](float* buf) {
+    tile_store_lds(qr, buf, kLdsPad, tid);
+    tile_store_lds(gr, buf + kTile * kLdsPad, kLdsPad, tid);
+    if (tid < 64) buf[2 * kTile * kLdsPad + tid] = st;
+  };
+  issue(0);
+  commit(smem);
+  __syncthreads();
+
+  float* myslab = slab + ((long)b * nslab + chunk) * M * 128;
+  for (int t = 0; t <= ntiles; ++t) {
+    float* cur = smem + (t & 1) * kFusedTile;
+    float* nxt = smem + ((t & 1) ^ 1) * kFusedTile;
+    const int i0 = t * kTile;
+    if (t + 1 < ntiles) issue(i0 + kTile);
+    if (t < ntiles) {
+      const float* Qt = cur;
+      const float* Gt = cur + kTile * kLdsPad;
+      const float* Lt = cur + 2 * kTile * kLdsPad;
+      const float* Dt = Lt + kTile;
+      float* dsw = dsbuf + (t & 1) * kTile * kLdsPad + 32 * wave + lo;
+      f32x16 s = mma_rows_x_regs(Qt, kLdsPad, lo, h, kreg, zero16());   // S  (queries x keys)
+      f32x16 dp = mma_rows_x_regs(Gt, kLdsPad, lo, h, vreg, zero16());  // dP
+      const bool tail = (i0 + kTile > M);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ir = crow(r, h);
+        float p = __expf(s[r] * scale - Lt[ir]);
+        if (tail && (i0 + ir >= M)) p = 0.f;
+        const float ds = p * (dp[r] - Dt[ir]) * scale;
+        dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
+        mma_tileT_step(Gt, kLdsPad, lo, h, r, p, dv);
+        mma_tileT_step(Qt, kLdsPad, lo, h, r, ds, dk);
+      }
+    }
+    if (t > 0) {
+      // dQ slice of the previous tile: rows = its 32 queries, reduced index = this workgroup's 128 keys
+      const float* dsr = dsbuf + ((t - 1) & 1) * kTile * kLdsPad;
+      const f32x16 dqa = mma_rows_x_regs(dsr, kLdsPad, lo, h, kcol, zero16());
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (t - 1) * kTile + crow(r, h);
+        if (m < M) myslab[(long)m * 128 + 32 * wave + lo] = dqa[r];
+      }
+    }
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  if (jvalid) {
+    float* krow = dK + (long)b * dk_bs + (long)j * dk_rs;
+    float* vrow = dV + (long)b * dv_bs + (long)j * dv_rs;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 a = {dk[dt][4 * gq], dk[dt][4 * gq + 1], dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]};
+        f32x4 c = {dv[dt][4 * gq], dv[dt][4 * gq + 1], dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]};
+        *reinterpret_cast<f32x4*>(krow + 32 * dt + 8 * gq + 4 * h) = a;
+        *reinterpret_cast<f32x4*>(vrow + 32 * dt + 8 * gq + 4 * h) = c;
+      }
+    }
+  }
+}
+
+// dQ row of sampled point m = sum over the key-block slabs (+ the token slab), fixed order; scattered
+// to row idx[m] of dQ.  grid (ceil(M*32/256), B): one thread per (row, 4-channel group)
+__global__ __launch_bounds__(256) void bwd_dq_reduce_kernel(const float* __restrict__ slab, int nslab,
+                                                            const long long* __restrict__ idx, int M,
+                                                            float* __restrict__ dQ, long dq_bs, long dq_rs) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int m = e >> 5, c4 = e & 31;
+  if (m >= M) return;
+  const float* src = slab + (long)b * nslab * M * 128 + (long)m * 128 + 4 * c4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int sidx = 0;
+  for (; sidx + 4 <= nslab; sidx += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (long)(sidx + u) * M * 128);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += v[u];
+  }
+  for (; sidx < nslab; ++sidx) acc += *reinterpret_cast<const f32x4*>(src + (long)sidx * M * 128);
+  const long row = idx[(long)b * M + m];
+  *reinterpret_cast<f32x4*>(dQ + (long)b * dq_bs + row * dq_rs + 4 * c4) = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,14 +507,22 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
 
 using namespace samble;
 
+static int g_bwd_split = 0;  // debug: 1 = the two-kernel backward (bwd_dq + bwd_dkdv) for A/B checks
+extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_split(int on) { g_bwd_split = on; }
+
+extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
+  return (size_t)B * ((N + 127) / 128 + 1) * M * 128;
+}
+
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, const float* O, const float* lse,
                                       const long long* idx, const float* g, int B, int N, int nt, int M, float scale,
-                                      float* Qs, float* dOb, float* lse_s, float* delta, float* tok_part, float* dQ,
-                                      long dq_bs, long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs,
-                                      long dv_rs, hipStream_t stream) {
+                                      float* Qs, float* dOb, float* lse_s, float* delta, float* tok_part, float* slab,
+                                      float* dQ, long dq_bs, long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV,
+                                      long dv_bs, long dv_rs, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
+  const size_t lds_fused = kFusedLdsFloats * sizeof(float);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel<kDqWaves>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
@@ -356,17 +530,34 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
+    if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int NK = N + nt;
   const int nparts = (M + 31) / 32;
+  const int kb = (N + 127) / 128;
+  const bool fused = !g_bwd_split;
+  float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
+  // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
+  //  only, so give it a view with the cloud stride folded in below)
   hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
-                     O, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part);
-  hipLaunchKernelGGL(bwd_dq_kernel<kDqWaves>, dim3((M + 32 * kDqWaves - 1) / (32 * kDqWaves), B), dim3(64 * kDqWaves),
-                     lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs,
-                     k_rs, V, v_bs, v_rs, idx, N, NK, M, scale, dQ, dq_bs, dq_rs);
-  hipLaunchKernelGGL(bwd_dkdv_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K,
-                     k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
+                     O, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
+                     fused ? kb + 1 : 0, kb);
+  if (fused) {
+    hipLaunchKernelGGL(bwd_fused_kernel, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs,
+                       V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab, kb + 1);
+    hipLaunchKernelGGL(bwd_dq_reduce_kernel, dim3((M * 32 + 255) / 256, B), dim3(256), 0, stream, slab, kb + 1, idx, M,
+                       dQ, dq_bs, dq_rs);
+  } else {
+    hipLaunchKernelGGL(bwd_dq_kernel<kDqWaves>, dim3((M + 32 * kDqWaves - 1) / (32 * kDqWaves), B), dim3(64 * kDqWaves),
+                       lds_dq, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, idx, N, NK, M, scale, dQ,
+                       dq_bs, dq_rs);
+    hipLaunchKernelGGL(bwd_dkdv_kernel, dim3(kb, B), dim3(256), lds_dkv, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs, V,
+                       v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs);
+  }
+  (void)tok_slab;
   if (nt > 0)
     hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(16, B), dim3(128), 0, stream, tok_part, nparts, N, nt, dK, dk_bs,
                        dk_rs, dV, dv_bs, dv_rs);

@@ -282,7 +282,7 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
     M = idx.shape[1]
     g = _f32c(g)
     with torch.cuda.device(q.device):
-        nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, M, D)
+        nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         _lib.call("samble_attn_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
                   k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), O.data_ptr(), lse.data_ptr(), idx.data_ptr(),

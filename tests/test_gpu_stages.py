@@ -183,12 +183,25 @@ def test_attn_bwd(B, N, nt, M):
     dq = torch.full((B, N, D), float("nan"), device=DEV)
     dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
     dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    from samble_amd import _lib
+    for split in (0, 1):  # fused 5-product backward, then the two-kernel (7-product) path
+        _lib.load().samble_debug_bwd_split(split)
+        try:
+            dq.fill_(float("nan")); dk.fill_(float("nan")); dv.fill_(float("nan"))
+            o_.stage_attn_bwd(qg, kg, vg, O_, lse, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
+        finally:
+            _lib.load().samble_debug_bwd_split(0)
+        for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
+            assert torch.isfinite(got).all(), (name, split)
+            scale = ref.abs().max().item()
+            err = (got.cpu().double() - ref).abs().max().item()
+            assert err <= 3e-5 * scale + 1e-7, (name, split, err, scale)
+    # the fused path is run-to-run identical (slabs are summed in a fixed order)
+    a = dq.clone()
     o_.stage_attn_bwd(qg, kg, vg, O_, lse, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
-    for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
-        assert torch.isfinite(got).all(), name
-        scale = ref.abs().max().item()
-        err = (got.cpu().double() - ref).abs().max().item()
-        assert err <= 3e-5 * scale + 1e-7, (name, err, scale)
+    b2 = dq.clone()
+    o_.stage_attn_bwd(qg, kg, vg, O_, lse, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
+    assert torch.equal(b2, dq)
 
 
 # ---------------------------------------------------------------------------------------------
