@@ -42,6 +42,10 @@ extern "C" {
 #define SAMBLE_SAMPLE_TOPK 0
 #define SAMBLE_SAMPLE_UNIFORM 1
 #define SAMBLE_SAMPLE_RANDOM 2
+/* plain top-k of the score without the +1e-8 (DownSampleGlobal, models/downsample.py:1403) and
+ * bottom-k (topk(.., largest=False), models/downsample.py:1299-1301) */
+#define SAMBLE_SAMPLE_TOP_RAW 3
+#define SAMBLE_SAMPLE_BOTTOM_RAW 4
 /* Boltzmann temperature: fixed inverse temperature, or members_in_bin / divisor
  * (reference utils/ops.py:524-548: mode_1 -> divisor 100, mode_3 -> divisor 200) */
 #define SAMBLE_TEMP_FIXED 0

@@ -478,3 +478,26 @@ def upsample_interpolation(pcd_up, points_select, pcd_up_xyz, points_select_xyz,
     x = torch.concat([pcd_up, interp], dim=1)
     return F.leaky_relu(F.batch_norm(F.conv1d(x, res_w), None, None, res_bn[0], res_bn[1], training=True),
                         negative_slope=0.2)
+
+
+def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum"):
+    """DownSampleGlobal.forward (models/downsample.py:1281-1330, asm dot, H=1, no res block).
+    Returns ((x_ds, idx (B,1,M)), (x_dropped, idx_dropped (B,1,N-M)), score (B,1,N))."""
+    B, C, N = x.shape
+    q = F.conv1d(x, wq).view(B, 1, C, N).permute(0, 1, 3, 2)
+    k = F.conv1d(x, wk).view(B, 1, C, N)
+    v = F.conv1d(x, wv).view(B, 1, C, N)
+    A = torch.softmax((q @ k) / math.sqrt(q.shape[-1]), dim=-1)
+    if idx_mode == "col_sum":
+        score = torch.sum(A, dim=-2)
+    elif idx_mode == "row_std":
+        score = torch.std(A, dim=-1)
+    else:
+        raise NotImplementedError
+    idx = score.topk(M, dim=-1)[1]
+    idx_dropped = torch.sum(A, dim=-2).topk(N - M, dim=-1, largest=False)[1]
+    def rows(ix):
+        a = torch.gather(A, dim=2, index=ix[..., None].expand(-1, -1, -1, N))
+        o = (a @ v.permute(0, 1, 3, 2)).permute(0, 2, 1, 3)
+        return o.reshape(o.shape[0], o.shape[1], -1).permute(0, 2, 1)
+    return (rows(idx), idx), (rows(idx_dropped), idx_dropped), score

@@ -156,9 +156,9 @@ SAMBLE_API int samble_bin_select_f32(const float* score, const float* z, const u
                                      float temp, int64_t* idx_out, void* stream) {
   if (!score || !z || !member || !counts || !idx_out)
     return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: null pointer");
-  if (sample_mode < 0 || sample_mode > SAMBLE_SAMPLE_RANDOM)
+  if (sample_mode < 0 || sample_mode > SAMBLE_SAMPLE_BOTTOM_RAW)
     return fail(SAMBLE_E_INVALID, "Please check the setting of bin sample mode. It must be topk, uniform or random!");
-  if (sample_mode != SAMBLE_SAMPLE_TOPK && !noise)
+  if ((sample_mode == SAMBLE_SAMPLE_UNIFORM || sample_mode == SAMBLE_SAMPLE_RANDOM) && !noise)
     return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: uniform/random need the Exp(1) noise tensor");
   if (nb < 1 || nb > 8 || N > 16384) return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: need num_bins <= 8, N <= 16384");
   return done(samble_launch_bin_select(score, z, member, counts, noise, B, N, nb, M, sample_mode, temp_mode, temp,

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(1024) void alloc_counts_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // per-(cloud, bin) selection
 // ------------------------------------------------------------------------------------------------
-enum SampleMode { kTopk = 0, kUniform = 1, kRandom = 2 };
+enum SampleMode { kTopk = 0, kUniform = 1, kRandom = 2, kTopRaw = 3, kBottomRaw = 4 };
 enum TempMode { kTempFixed = 0, kTempCount = 1 };  // count: inv_T = members / temp_div
 
 // dynamic LDS: NP composites (u64) ; grid (nb, B), 1024 threads
@@ -324,7 +324,11 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
     unsigned long long c = ~0ull;
     if (n < N && (mb[n] & bit)) {
       float key;
-      if (mode == kTopk) {
+      if (mode == kTopRaw) {
+        key = score[(long)b * N + n];  // plain topk(M) of the score (DownSampleGlobal)
+      } else if (mode == kBottomRaw) {
+        key = -score[(long)b * N + n];  // topk(.., largest=False)
+      } else if (mode == kTopk) {
         key = score[(long)b * N + n] + 1e-8f;
       } else if (mode == kUniform) {
         key = 1.f / nz[n];
@@ -428,8 +432,8 @@ extern "C" int samble_launch_alloc_counts(const float* w, const int* cap, int B,
 extern "C" int samble_launch_bin_select(const float* score, const float* z, const unsigned char* member,
                                         const int* counts, const float* noise, int B, int N, int nb, int M, int mode,
                                         int temp_mode, float temp, long long* idx_out, hipStream_t s) {
-  if (mode < 0 || mode > kRandom) return -22;
-  if (mode != kTopk && noise == nullptr) return -22;
+  if (mode < 0 || mode > kBottomRaw) return -22;
+  if ((mode == kUniform || mode == kRandom) && noise == nullptr) return -22;
   int NP = 1;
   while (NP < N) NP <<= 1;
   const size_t lds = (size_t)NP * 8;

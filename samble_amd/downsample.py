@@ -47,7 +47,8 @@ class _Projection(torch.autograd.Function):
         if not need_dw:
             return dx, None, None, None, None
         a, b, c = ctx.splits
-        return (dx, dtok.unsqueeze(0), dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1))
+        dtokens = dtok.unsqueeze(0) if ctx.needs_input_grad[1] else None
+        return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1))
 
 
 class _SamplerCore(torch.autograd.Function):
@@ -254,3 +255,113 @@ class DownSampleToken(nn.Module):
             else:
                 variables = variables + (getattr(self, key),)
         return variables
+
+
+class _GlobalCore(torch.autograd.Function):
+    """qkv (B,N,3D) -> x_ds (B,D,M), x_dropped (B,D,N-M) + indices, for DownSampleGlobal."""
+
+    @staticmethod
+    def forward(ctx, qkv, x, mod):
+        B, C, N = x.shape
+        D = mod.q_depth
+        q, k, v = qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:3 * D]
+        if mod.idx_mode == "row_std":
+            O, lse, _, stat = ops.stage_attn_fwd(q, k, v, N, 0, want_row_std=True)
+            col = ops.stage_attn_colsum(q, k, lse)
+        else:
+            O, lse, _ = ops.stage_attn_fwd(q, k, v, N, 0)
+            col = ops.stage_attn_colsum(q, k, lse)
+            if mod.idx_mode == "col_sum":
+                stat = col
+            elif mod.idx_mode in ops.SCORE_MODES:
+                nn_idx = ops.stage_knn(x, x, mod.K)
+                stat, _, _ = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
+            else:
+                raise ValueError("Please check the setting of idx mode!")
+        idx = ops.stage_topk_indices(stat, mod.M, largest=True)
+        idx_dropped = ops.stage_topk_indices(col, N - mod.M, largest=False)
+        x_ds = ops.stage_gather_rows(O, idx)
+        x_dropped = ops.stage_gather_rows(O, idx_dropped)
+        ctx.save_for_backward(qkv, O, lse, idx, idx_dropped)
+        ctx.dims = (N, D)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(idx, idx_dropped, stat)
+        return x_ds, x_dropped, idx, idx_dropped, stat
+
+    @staticmethod
+    def backward(ctx, g_ds, g_dropped, *_):
+        qkv, O, lse, idx, idx_dropped = ctx.saved_tensors
+        N, D = ctx.dims
+        B = qkv.shape[0]
+        # both outputs gather rows of the same attention output: fold their gradients into one
+        # (B,D,N) gradient over all rows (a row can be in both sets unless idx_mode is col_sum)
+        g_all = torch.zeros((B, D, N), dtype=torch.float32, device=qkv.device)
+        if g_ds is not None:
+            g_all.scatter_add_(2, idx.unsqueeze(1).expand(-1, D, -1), g_ds)
+        if g_dropped is not None:
+            g_all.scatter_add_(2, idx_dropped.unsqueeze(1).expand(-1, D, -1), g_dropped)
+        rows = torch.arange(N, device=qkv.device, dtype=torch.int64).unsqueeze(0).expand(B, -1).contiguous()
+        dqkv = torch.empty_like(qkv)
+        ops.stage_attn_bwd(qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], O, lse, rows, g_all, N, 0,
+                           dqkv[:, :, 0:D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:])
+        return dqkv, None, None
+
+
+class DownSampleGlobal(nn.Module):
+    """Drop-in for the reference's APES-style global sampler (models/downsample.py:1232-1405, asm
+    'dot'): softmax(QK^T/sqrt(D)) over the N points, score per `idx_mode`, top-M rows kept and the
+    N-M rows with the smallest column sum returned as the dropped set.
+    Outputs: ((x_ds (B,C,M), idx (B,1,M)), (x_dropped (B,C,N-M), idx_dropped (B,1,N-M)))."""
+
+    def __init__(self, config_ds, layer):
+        super().__init__()
+        self.M = config_ds.M[layer]
+        self.K = 32
+        self.asm = config_ds.asm[layer]
+        self.res = config_ds.res.enable[layer]
+        self.ff = config_ds.res.ff[layer]
+        self.num_heads = config_ds.num_heads[layer]
+        self.idx_mode = config_ds.idx_mode[layer]
+        q_in, q_out = config_ds.q_in[layer], config_ds.q_out[layer]
+        k_in, k_out = config_ds.k_in[layer], config_ds.k_out[layer]
+        v_in, v_out = config_ds.v_in[layer], config_ds.v_out[layer]
+        self.q_depth = int(q_out / self.num_heads)
+        self.k_depth = int(k_out / self.num_heads)
+        self.v_depth = int(v_out / self.num_heads)
+        if self.res:
+            self.bn1 = nn.BatchNorm1d(v_out)
+            if self.ff:
+                self.ffn = nn.Sequential(nn.Conv1d(128, 512, 1, bias=False), nn.LeakyReLU(negative_slope=0.2),
+                                         nn.Conv1d(512, 128, 1, bias=False))
+                self.bn2 = nn.BatchNorm1d(v_out)
+        self.q_conv = nn.Conv1d(q_in, q_out, 1, bias=False)
+        self.k_conv = nn.Conv1d(k_in, k_out, 1, bias=False)
+        self.v_conv = nn.Conv1d(v_in, v_out, 1, bias=False)
+        self.softmax = nn.Softmax(dim=-1)
+        if self.asm != "dot":
+            if self.asm in ("dot-sub", "l2", "l2+"):
+                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (only 'dot')")
+            raise ValueError("Please check the setting of asm!")
+        if self.num_heads != 1 or not (q_in == q_out == k_out == v_out == 128):
+            raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
+
+    def forward(self, x, x_xyz=None):
+        if not x.is_cuda:
+            raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
+        no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
+        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
+        x_ds, x_dropped, idx, idx_dropped, stat = _GlobalCore.apply(qkv, x.detach(), self)
+        self.idx = idx.unsqueeze(1)
+        self.attention = stat.unsqueeze(1)
+        idx_dropped = idx_dropped.unsqueeze(1)
+        if self.res == True:  # noqa: E712
+            x_ds = self.res_block(x, x_ds)
+        return (x_ds, self.idx), (x_dropped, idx_dropped)
+
+    def res_block(self, x, x_ds):
+        x_tmp = torch.gather(x, dim=-1, index=self.idx)
+        x_res = self.bn1(x_ds + x_tmp)
+        if self.ff == True:  # noqa: E712
+            x_tmp = self.ffn(x_res)
+            x_res = self.bn2(x_ds + x_tmp)
+        return x_res

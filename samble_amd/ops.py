@@ -17,7 +17,7 @@ from . import _lib
 
 SCORE_MODES = {"sparse_col_sum": 0, "sparse_col_avg": 1, "sparse_col_sqr": 2, "sparse_row_sum": 3,
                "sparse_row_std": 4}
-SAMPLE_MODES = {"topk": 0, "uniform": 1, "random": 2}
+SAMPLE_MODES = {"topk": 0, "uniform": 1, "random": 2, "top_raw": 3, "bottom_raw": 4}
 KNN_SIZES = (1, 3, 8, 16, 20, 32, 40, 64)
 
 
@@ -249,7 +249,7 @@ def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzma
     temp_mode, temp = (0, 1.0)
     if sample_mode == "random":
         temp_mode, temp = boltzmann_temperature(boltzmann_t, N, nb)
-    if sample_mode != "topk":
+    if sample_mode in ("uniform", "random"):
         if noise is None:
             noise = torch.empty((B * nb, N), dtype=torch.float32, device=score.device).exponential_(1)
         noise = _f32c(noise)
@@ -261,6 +261,17 @@ def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzma
                   _p(noise), B, N, nb, M, SAMPLE_MODES[sample_mode], temp_mode, float(temp), idx.data_ptr(),
                   _stream())
     return idx
+
+
+def stage_topk_indices(score: torch.Tensor, k: int, largest: bool = True) -> torch.Tensor:
+    """(B,N) score -> (B,k) int64 indices of the k largest (or smallest) entries, best first;
+    exact ties break by ascending index (torch.topk leaves them unspecified)."""
+    _need_gpu(score)
+    score = _f32c(score)
+    B, N = score.shape
+    member = torch.ones((B, N), dtype=torch.uint8, device=score.device)
+    counts = torch.full((B, 1), k, dtype=torch.int32, device=score.device)
+    return stage_bin_select(score, score, member, counts, k, "top_raw" if largest else "bottom_raw", None)
 
 
 def stage_gather_rows(O: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -139,3 +139,37 @@ def test_upsample_interpolation_against_reference_fixture():
         ref = torch.from_numpy(d[key])
         rel = ((got.cpu() - ref).norm() / ref.norm()).item()
         assert rel <= 5e-2, (key, rel)
+
+
+def test_downsample_global_against_reference_fixture():
+    """APES-style global sampler (reference models/downsample.py:1232-1405), idx_mode col_sum."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleGlobal
+    d = layer_fixture("layer_global_colsum")
+    B, C, N, M, seed = [int(v) for v in d["meta"]]
+    cfg = sampler_config("cls", M=[M, M // 2], idx_mode=["col_sum", "col_sum"])
+    mod = DownSampleGlobal(cfg, 0)
+    assert sorted(mod.state_dict()) == ["k_conv.weight", "q_conv.weight", "v_conv.weight"]
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, C, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, C, 1), seed + 3, 0.09))
+    mod = mod.to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    (x_ds, idx), (x_dr, idx_dr) = mod(x)
+    assert idx.shape == (B, 1, M) and idx_dr.shape == (B, 1, N - M) and idx.dtype == torch.int64
+    torch.testing.assert_close(mod.attention.cpu(), torch.from_numpy(d["score"]), rtol=2e-5, atol=1e-7)
+    ref_idx, ref_idr = torch.from_numpy(d["idx"]), torch.from_numpy(d["idx_dropped"])
+    # kept and dropped sets partition the cloud; order follows the column sums (near-ties may swap neighbours)
+    assert set_agreement(idx.cpu()[:, 0], ref_idx[:, 0]) >= 0.99 and set_agreement(idx_dr.cpu()[:, 0], ref_idr[:, 0]) >= 0.99
+    for b in range(B):
+        assert sorted(idx[b, 0].tolist() + idx_dr[b, 0].tolist()) == list(range(N))
+    if torch.equal(idx.cpu(), ref_idx) and torch.equal(idx_dr.cpu(), ref_idr):
+        torch.testing.assert_close(x_ds.detach().cpu(), torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(x_dr.detach().cpu(), torch.from_numpy(d["x_dropped"]), rtol=1e-4, atol=2e-5)
+        g1 = torch.from_numpy(synth.normal((B, C, M), seed + 20)).to(DEV)
+        g2 = torch.from_numpy(synth.normal((B, C, N - M), seed + 21)).to(DEV)
+        ((x_ds * g1).sum() + (x_dr * g2).sum()).backward()
+        for got, key in ((x.grad, "dx"), (mod.q_conv.weight.grad, "dwq")):
+            ref = torch.from_numpy(d[key])
+            assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
