@@ -155,6 +155,13 @@ int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_
 int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN, int C,
                             int heads, int diff, float* out, void* stream);
 
+/* Backward of samble_n2p_attn_fwd_f32: g (B,C,N) = gradient of its output -> dqkv (B,N,3C) point-major
+ * rows [dQ|dK|dV] (feed it to samble_proj_bwd_f32).  Deterministic (no atomics).  K <= 32. */
+size_t samble_n2p_attn_bwd_workspace_bytes(int B, int N, int KN);
+int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, const float* g, int B, int N,
+                            int KN, int C, int heads, int diff, float* dqkv, int64_t dbs, int64_t drs, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows
  * 0..N+nt-1, each with its own strides. */

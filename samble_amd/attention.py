@@ -7,9 +7,8 @@ reference.  The neighbour build is the fused Gram + top-K HIP kernel, the three 
 one HIP gather kernel: the (B,C,N,K) tensors of the reference are never built in forward.
 BatchNorm / FFN around it are stock torch modules (they are not neighbour ops).
 
-Backward of the attention part re-derives the same expression with torch ops on the saved
-projections (gather-based, chunked over clouds) and routes the result through the HIP projection
-backward; a fused HIP backward (inverted neighbour lists) is listed in DESIGN.md as next.
+Backward of the attention part is two HIP kernels (per-point pass, then an ordered gather over
+64-row target blocks: no atomics, run-to-run identical) followed by the HIP projection backward.
 """
 from __future__ import annotations
 
@@ -57,13 +56,16 @@ class _N2PCore(torch.autograd.Function):
     def backward(ctx, g):
         x, w, qkv, nn_idx = ctx.saved_tensors
         heads, diff, a, b = ctx.cfg
-        dqkv = torch.empty_like(qkv)
-        step = 4  # clouds per chunk: bounds the (b,N,K,C) gather temporaries
-        for s in range(0, qkv.shape[0], step):
-            with torch.enable_grad():
-                part = qkv[s:s + step].detach().requires_grad_(True)
-                out = _attention_from_projection(part, nn_idx[s:s + step], heads, diff)
-            dqkv[s:s + step] = torch.autograd.grad(out, part, g[s:s + step])[0]
+        if nn_idx.shape[2] <= 32:
+            dqkv = ops.stage_n2p_attn_bwd(qkv, nn_idx, g, heads, diff)  # HIP, deterministic
+        else:  # K > 32: torch restatement, chunked over clouds
+            dqkv = torch.empty_like(qkv)
+            step = 4
+            for s in range(0, qkv.shape[0], step):
+                with torch.enable_grad():
+                    part = qkv[s:s + step].detach().requires_grad_(True)
+                    out = _attention_from_projection(part, nn_idx[s:s + step], heads, diff)
+                dqkv[s:s + step] = torch.autograd.grad(out, part, g[s:s + step])[0]
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:4])
         dx, dw, _ = ops.stage_proj_bwd(dqkv, x, x.new_zeros((x.shape[1], 0)), w, need_dx, need_dw)

@@ -34,6 +34,9 @@ int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, cons
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
                            float*, long, float*, float*, float*, hipStream_t);
+size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
+int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
+                          long, float*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
@@ -278,4 +281,23 @@ SAMBLE_API int samble_attn_colsum_f32(const float* Q, int64_t q_bs, int64_t q_rs
 SAMBLE_API int samble_stat_score_f32(const float* stat, int B, int N, float* score, float* z, void* stream) {
   if (!stat || !score || !z || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_stat_score_f32: bad argument");
   return done(samble_launch_stat_score(stat, B, N, score, z, (hipStream_t)stream), "samble_stat_score_f32");
+}
+
+SAMBLE_API size_t samble_n2p_attn_bwd_workspace_bytes(int B, int N, int KN) {
+  return samble_n2p_bwd_ws_floats(B, N, KN) * sizeof(float);
+}
+
+SAMBLE_API int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, const float* g,
+                                       int B, int N, int KN, int C, int heads, int diff, float* dqkv, int64_t dbs,
+                                       int64_t drs, void* ws, size_t ws_bytes, void* stream) {
+  if (!qkv || !nn || !g || !dqkv || !ws) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: null pointer");
+  if (C != 128 || heads != 4) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128, 4 heads of 32");
+  if (KN < 1 || KN > 32) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: need 1 <= K <= 32");
+  if ((rs & 3) || (bs & 3) || (drs & 3) || (dbs & 3) || rs < 3 * C || drs < 3 * C)
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: bad strides");
+  if (ws_bytes < samble_n2p_attn_bwd_workspace_bytes(B, N, KN))
+    return fail(SAMBLE_E_WORKSPACE, "samble_n2p_attn_bwd_f32: workspace too small");
+  return done(samble_launch_n2p_bwd(qkv, bs, rs, nn, g, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), dqkv,
+                                    dbs, drs, (float*)ws, (hipStream_t)stream),
+              "samble_n2p_attn_bwd_f32");
 }

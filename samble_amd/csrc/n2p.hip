@@ -97,3 +97,264 @@ extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const i
                      out);
   return (int)hipGetLastError();
 }
+
+// ================================================================================================
+// Backward of the gather-attention.  With k_ij = Kp[j] - d*Kp[i], v_ij = Vp[j] - d*Vp[i] (d = diff),
+// a_ij = softmax_j(scale q_i.k_ij) per head, out_i = sum_j a_ij v_ij and g_i = dL/dout_i:
+//     da_ij = g_i . Vp[j],  delta_i = sum_j a_ij da_ij,  dl_ij = scale a_ij (da_ij - delta_i)
+//     dQ[i]  = sum_j dl_ij k_ij
+//     dKp[j] += dl_ij q_i      dKp[i] -= d (sum_j dl_ij) q_i
+//     dVp[j] += a_ij g_i       dVp[i] -= d g_i
+// Pass 1 (n2p_bwd_point): half-wave per point like the forward; writes dQ[i], the two "self" rows
+//   and the per-pair coefficients a_ij, dl_ij (B,N,K,4 heads).
+// Pass 2 (n2p_bwd_scatter): the scatter-add over neighbours as a GATHER with a fixed order: a
+//   workgroup owns 64 target rows j (accumulators in LDS) and walks the cloud's rows i in order, 128
+//   at a time; hits (nn[i][k] in the block) get their slot in an ordered list from a block-wide
+//   prefix sum (thread order = (i,k) order), and are then applied one after the other.  No atomics,
+//   run-to-run identical.
+// ================================================================================================
+namespace samble {
+
+// (B,C,N) -> (B,N,C), C = 128
+__global__ __launch_bounds__(256) void transpose_cn_kernel(const float* __restrict__ in, int N, float* __restrict__ out) {
+  __shared__ float tile[128 * 33];
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int tid = threadIdx.x, n0 = chunk * 32;
+  const float* ib = in + (long)b * 128 * N;
+  for (int e = tid; e < 128 * 32; e += 256) {
+    const int c = e >> 5, p = e & 31;
+    tile[c * 33 + p] = (n0 + p < N) ? ib[(long)c * N + n0 + p] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * 32; e += 256) {
+    const int p = e >> 5, c4 = (e & 31) * 4;
+    if (n0 + p < N) {
+      f32x4 v = {tile[(c4 + 0) * 33 + p], tile[(c4 + 1) * 33 + p], tile[(c4 + 2) * 33 + p], tile[(c4 + 3) * 33 + p]};
+      *reinterpret_cast<f32x4*>(out + ((long)b * N + n0 + p) * 128 + c4) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restrict__ qkv, long bs, long rs,
+                                                            const int* __restrict__ nn,
+                                                            const float* __restrict__ gt,  // (B,N,128)
+                                                            int N, int KN, int diff, float scale,
+                                                            float* __restrict__ dqkv, long dbs, long drs,
+                                                            float* __restrict__ A, float* __restrict__ DL) {
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
+  const float* base = qkv + (long)b * bs;
+  for (int pp = 0; pp < 4; ++pp) {
+    const int i = chunk * 32 + hw * 4 + pp;
+    if (i >= N) continue;  // uniform per half-wave
+    const float* row = base + (long)i * rs + 4 * c;
+    const f32x4 q = *reinterpret_cast<const f32x4*>(row);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gt + ((long)b * N + i) * 128 + 4 * c);
+    f32x4 kc = {0.f, 0.f, 0.f, 0.f};
+    float qkc = 0.f;
+    if (diff) {
+      kc = *reinterpret_cast<const f32x4*>(row + 128);
+      qkc = head_sum(dot4(q, kc));
+    }
+    const int* ni = nn + ((long)b * N + i) * KN;
+    float lg[32], da[32];
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+      f32x4 kv[4], vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = (k0 + u < KN) ? ni[k0 + u] : ni[0];
+        const float* jr = base + (long)j * rs + 4 * c;
+        kv[u] = *reinterpret_cast<const f32x4*>(jr + 128);
+        vv[u] = *reinterpret_cast<const f32x4*>(jr + 256);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lg[k0 + u] = (k0 + u < KN) ? (head_sum(dot4(q, kv[u])) - qkc) * scale : kNegInf;
+        da[k0 + u] = head_sum(dot4(g, vv[u]));
+      }
+    }
+    float m = kNegInf;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) m = fmaxf(m, lg[k]);
+    float l = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      lg[k] = __expf(lg[k] - m);  // masked slots: exp(-inf) = 0
+      l += lg[k];
+    }
+    const float inv = 1.f / l;
+    float delta = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      lg[k] *= inv;  // a_ij
+      delta = fmaf(lg[k], da[k], delta);
+    }
+    float sdl = 0.f;
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+    float* Ai = A + ((long)b * N + i) * KN * 4;
+    float* Di = DL + ((long)b * N + i) * KN * 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+      f32x4 kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = (k0 + u < KN) ? ni[k0 + u] : ni[0];
+        kv[u] = *reinterpret_cast<const f32x4*>(base + (long)j * rs + 4 * c + 128);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        if (k < KN) {
+          const float dl = lg[k] * (da[k] - delta) * scale;
+          sdl += dl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dq[e] = fmaf(dl, kv[u][e] - kc[e], dq[e]);
+          if ((c & 7) == 0) {
+            Ai[k * 4 + (c >> 3)] = lg[k];
+            Di[k * 4 + (c >> 3)] = dl;
+          }
+        }
+      }
+    }
+    float* drow = dqkv + (long)b * dbs + (long)i * drs + 4 * c;
+    *reinterpret_cast<f32x4*>(drow) = dq;
+    f32x4 sk = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+    if (diff) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sk[e] = -sdl * q[e];
+        sv[e] = -g[e];
+      }
+    }
+    *reinterpret_cast<f32x4*>(drow + 128) = sk;
+    *reinterpret_cast<f32x4*>(drow + 256) = sv;
+  }
+}
+
+constexpr int kScatRows = 64;    // target rows per workgroup
+constexpr int kScatChunk = 128;  // source rows scanned per chunk
+constexpr int kScatHits = 1024;  // capacity of the per-chunk hit list (longer lists are consumed in rounds)
+
+__global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __restrict__ qkv, long bs, long rs,
+                                                                 const int* __restrict__ nn,
+                                                                 const float* __restrict__ gt,
+                                                                 const float* __restrict__ A,
+                                                                 const float* __restrict__ DL, int N, int KN,
+                                                                 float* __restrict__ dqkv, long dbs, long drs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* acc = smem;                                              // [2][64][128]
+  int* hits = reinterpret_cast<int*>(smem + 2 * kScatRows * 128);  // packed (i_local << 16) | (k << 8) | j_local
+  int* scan = hits + kScatHits;                                   // 256
+  __shared__ int nhits_s;
+  int blk, b;
+  xcd_assign(blk, b);
+  const int tid = threadIdx.x;
+  const int c = tid & 127, which = tid >> 7, head = c >> 5;
+  const int j0 = blk * kScatRows;
+  for (int e = tid; e < 2 * kScatRows * 128; e += 256) acc[e] = 0.f;
+  const float* coef = which ? A : DL;
+  const float* valbase = which ? gt + (long)b * N * 128 + c : qkv + (long)b * bs + c;
+  const long valrs = which ? 128 : rs;
+  const int per = (kScatChunk * KN + 255) / 256;  // idx entries per thread per chunk, in (i,k) order
+  for (int i0 = 0; i0 < N; i0 += kScatChunk) {
+    const int rows = min(kScatChunk, N - i0);
+    const int total = rows * KN;
+    int first = tid * per;
+    // ---- ordered hit list: count, block prefix sum, fill
+    int my = 0;
+    for (int e = first; e < min(first + per, total); ++e) {
+      const int j = nn[((long)b * N + i0) * KN + e];
+      my += (j >= j0 && j < j0 + kScatRows) ? 1 : 0;
+    }
+    __syncthreads();  // previous chunk's list fully consumed
+    scan[tid] = my;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int a = (tid >= o) ? scan[tid - o] : 0;
+      __syncthreads();
+      scan[tid] += a;
+      __syncthreads();
+    }
+    const int slot0 = scan[tid] - my;
+    if (tid == 255) nhits_s = scan[255];
+    __syncthreads();
+    const int nh_total = nhits_s;
+    // index-local clouds can put thousands of hits into one chunk: consume the list in rounds of kScatHits
+    for (int hb = 0; hb < nh_total; hb += kScatHits) {
+    if (hb > 0) __syncthreads();  // previous round's list fully consumed
+    int slot = slot0;
+    for (int e = first; e < min(first + per, total); ++e) {
+      const int j = nn[((long)b * N + i0) * KN + e];
+      if (j >= j0 && j < j0 + kScatRows) {
+        if (slot >= hb && slot < hb + kScatHits) hits[slot - hb] = ((e / KN) << 16) | ((e % KN) << 8) | (j - j0);
+        ++slot;
+      }
+    }
+    __syncthreads();
+    const int nh = min(nh_total - hb, kScatHits);
+    // ---- apply in list order; 4 hits' loads in flight
+    for (int e0 = 0; e0 < nh; e0 += 4) {
+      float cf[4], vl[4];
+      int jl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int hcode = hits[min(e0 + u, nh - 1)];
+        const int il = hcode >> 16, k = (hcode >> 8) & 255;
+        jl[u] = hcode & 255;
+        const long i = i0 + il;
+        cf[u] = coef[(((long)b * N + i) * KN + k) * 4 + head];
+        vl[u] = valbase[i * valrs];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (e0 + u < nh) {
+          float* a = acc + (which * kScatRows + jl[u]) * 128 + c;
+          *a = fmaf(cf[u], vl[u], *a);
+        }
+      }
+    }
+    }
+  }
+  __syncthreads();
+  // add to the self rows written by pass 1
+  for (int e = tid; e < kScatRows * 128; e += 256) {
+    const int jr = e >> 7, cc = e & 127;
+    if (j0 + jr < N) {
+      float* drow = dqkv + (long)b * dbs + (long)(j0 + jr) * drs;
+      drow[128 + cc] += acc[jr * 128 + cc];
+      drow[256 + cc] += acc[(kScatRows + jr) * 128 + cc];
+    }
+  }
+}
+
+}  // namespace samble
+
+extern "C" size_t samble_n2p_bwd_ws_floats(int B, int N, int KN) {
+  return (size_t)B * N * 128 + 2 * (size_t)B * N * KN * 4 + 64;
+}
+
+extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const int* nn, const float* g, int B, int N,
+                                     int KN, int diff, float scale, float* dqkv, long dbs, long drs, float* ws,
+                                     hipStream_t s) {
+  using namespace samble;
+  float* gt = ws;
+  float* A = gt + (size_t)B * N * 128;
+  float* DL = A + (size_t)B * N * KN * 4;
+  const size_t lds = (size_t)(2 * kScatRows * 128) * 4 + (size_t)(kScatHits + 256) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(n2p_bwd_scatter_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
+  hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
+                     scale, dqkv, dbs, drs, A, DL);
+  hipLaunchKernelGGL(n2p_bwd_scatter_kernel, dim3((N + kScatRows - 1) / kScatRows, B), dim3(256), lds, s, qkv, bs, rs,
+                     nn, gt, A, DL, N, KN, dqkv, dbs, drs);
+  return (int)hipGetLastError();
+}

@@ -109,6 +109,22 @@ def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff
     return out
 
 
+def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor, heads: int, diff: bool) -> torch.Tensor:
+    """g (B,C,N) -> dqkv (B,N,3C) of the gather-attention (deterministic)."""
+    _need_gpu(qkv, nn_idx, g)
+    g = _f32c(g)
+    B, N, C3 = qkv.shape
+    K = nn_idx.shape[2]
+    with torch.cuda.device(qkv.device):
+        dqkv = torch.empty_like(qkv)
+        nbytes = _lib.query("samble_n2p_attn_bwd_workspace_bytes", B, N, K)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        _lib.call("samble_n2p_attn_bwd_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), nn_idx.data_ptr(),
+                  g.data_ptr(), B, N, K, C3 // 3, heads, int(bool(diff)), dqkv.data_ptr(), dqkv.stride(0),
+                  dqkv.stride(1), ws.data_ptr(), nbytes, _stream())
+    return dqkv
+
+
 def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int,
                    want_row_std: bool = False):
     """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->

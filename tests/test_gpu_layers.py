@@ -62,6 +62,29 @@ def test_n2p_against_reference_fixture(name, group_type):
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
 
 
+def test_n2p_backward_kernels_match_autograd_of_the_restatement():
+    """HIP backward of the gather-attention vs torch autograd of the same expression, incl. an
+    index-local neighbour pattern (every neighbour inside one 64-row block) that fills the hit list."""
+    from samble_amd import ops
+    from samble_amd.attention import _attention_from_projection
+    B, C, N, K, H = 3, 128, 1000, 32, 4
+    qkv = torch.from_numpy(synth.normal((B, N, 3 * C), 31) * 0.5).to(DEV)
+    g = torch.from_numpy(synth.normal((B, C, N), 32)).to(DEV)
+    rnd = torch.stack([torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b * N + i))[:K]
+                                    for i in range(N)]) for b in range(B)]).int()
+    local = ((torch.arange(N)[:, None] // 64) * 64 + torch.arange(K)[None, :]).clamp(max=N - 1).int()
+    local = local.unsqueeze(0).expand(B, -1, -1).contiguous()
+    for nn_idx in (rnd.to(DEV), local.to(DEV)):
+        for diff in (True, False):
+            part = qkv.detach().clone().requires_grad_(True)
+            out = _attention_from_projection(part, nn_idx, H, diff)
+            ref = torch.autograd.grad(out, part, g)[0]
+            got = ops.stage_n2p_attn_bwd(qkv, nn_idx, g, H, diff)
+            err = (got - ref).abs().max().item()
+            assert err <= 2e-5 * ref.abs().max().item() + 1e-7, (diff, err, ref.abs().max().item())
+            assert torch.equal(got, ops.stage_n2p_attn_bwd(qkv, nn_idx, g, H, diff)), "run-to-run identical"
+
+
 def test_n2p_metric_size_runs_and_matches_torch_restatement():
     """B=8, N=2048: the HIP gather-attention against the differentiable torch restatement on the GPU."""
     from samble_amd import ops
