@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
     }
     __syncthreads();
     const int nh = min(nh_total - hb, kScatHits);
-    // ---- apply in list order; 4 hits' loads in flight
+    // ---- apply in list order.  Loads of 4 hits are issued together; the accumulators live in
+    // registers for the run of hits (the compiler must not reorder LDS read-modify-writes of
+    // possibly equal rows, so each update is an explicit read / fma / write in order)
     for (int e0 = 0; e0 < nh; e0 += 4) {
       float cf[4], vl[4];
       int jl[4];
@@ -305,15 +307,14 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
         const int il = hcode >> 16, k = (hcode >> 8) & 255;
         jl[u] = hcode & 255;
         const long i = i0 + il;
-        cf[u] = coef[(((long)b * N + i) * KN + k) * 4 + head];
+        cf[u] = (e0 + u < nh) ? coef[(((long)b * N + i) * KN + k) * 4 + head] : 0.f;
         vl[u] = valbase[i * valrs];
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (e0 + u < nh) {
-          float* a = acc + (which * kScatRows + jl[u]) * 128 + c;
-          *a = fmaf(cf[u], vl[u], *a);
-        }
+        volatile float* a = acc + (which * kScatRows + jl[u]) * 128 + c;
+        const float cur = *a;
+        *a = fmaf(cf[u], vl[u], cur);
       }
     }
     }
