@@ -227,11 +227,12 @@ def main():
             # dominant kernel group: flash attention forward (one launch)
             alg = (fl["qk"] + fl["av"]) * B_PER_GPU
             ach = alg / (br["attn_fwd"] * 1e-3) / 1e12
-            # fabric-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc.json:
+            # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary (profiles/*_pmc.json:
             # (2*FETCH_SIZE + WRITE_SIZE)*1024, collected in their own runs as the counters require)
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+                import glob
+                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]))
                 traffic = pmc["kernels"]["samble::attn_fwd_kernel"]["traffic_bytes_per_launch"]
             except Exception:
                 pass
