@@ -174,6 +174,34 @@ int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float*
                         int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
                         int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- two-pass forward with the logit map kept in HBM (same reference lines as samble_attn_fwd_f32) ---
+ * In exact fp32 on MI355X reloading a logit (4 bytes) is ~3x cheaper than recomputing it (2*D flop),
+ * so S = Q K^T / sqrt(D) is computed once and kept: smap (B, N, ld) row-major,
+ * ld >= samble_attn_map_row_stride(N, nt) = 32 * ceil((N+nt)/32), columns N..N+nt-1 = token logits,
+ * columns >= N+nt = -inf.  Caller-owned like every other buffer (538 MB at B=32, N=2048).
+ *   samble_attn_stats_f32       pass 1, all N rows: smap, lse (B,N), tok (B,N,nt)
+ *                               replaces q@k, /sqrt(D), the softmax normaliser and the token split
+ *                               (models/downsample.py:139-153)
+ *   samble_sparse_score_map_f32 = samble_sparse_score_f32 reading A_ij = exp(S_ij - lse_i) from the map
+ *                               (models/downsample.py:300-344)
+ *   samble_attn_rows_fwd_f32    pass 2, the M sampled rows: x_ds (B,D,M) = softmax(S[idx]) V
+ *                               replaces gather + @v + permute (models/downsample.py:242-252)
+ *   samble_attn_rows_bwd_f32    = samble_attn_bwd_f32 reading S from the map (4 matrix products per
+ *                               tile instead of 5) and O from x_ds (B,D,M) */
+int samble_attn_map_row_stride(int N, int nt);
+int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs, int B,
+                          int N, int nt, int D, float* smap, int ld, float* lse, float* tok, void* stream);
+int samble_sparse_score_map_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N, int KN,
+                                int mode, float* score, float* z, int32_t* indeg_out, void* ws, size_t ws_bytes,
+                                void* stream);
+int samble_attn_rows_fwd_f32(const float* smap, int ld, const float* lse, const float* V, int64_t v_bs, int64_t v_rs,
+                             const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds, void* stream);
+int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                             const float* V, int64_t v_bs, int64_t v_rs, const float* smap, int ld, const float* lse,
+                             const float* x_ds, const int64_t* idx, const float* g, int B, int N, int nt, int M, int D,
+                             float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
+                             int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,9 +39,16 @@ int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, in
                           long, float*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
-                           const float*, const long long*, const float*, int, int, int, int, float, float*, float*,
-                           float*, float*, float*, float*, float*, long, long, float*, long, long, float*, long, long,
-                           hipStream_t);
+                           const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
+                           int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
+                           long, float*, long, long, hipStream_t);
+int samble_attn_map_ld(int N, int nt);
+int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
+                             float*, float*, hipStream_t);
+int samble_launch_attn_rows(const float*, int, const float*, const float*, long, long, const long long*, int, int, int,
+                            int, float*, hipStream_t);
+int samble_launch_sparse_score_map(const float*, int, const float*, const int*, int, int, int, int, float*, float*, int*,
+                                   void*, hipStream_t);
 size_t samble_attn_bwd_slab_floats(int B, int N, int M);
 }
 
@@ -190,19 +197,33 @@ SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D) {
          sizeof(float);
 }
 
-SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
-                                   int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* O,
-                                   const float* lse, const int64_t* idx, const float* g, int B, int N, int nt, int M,
-                                   int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
-                                   int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
-                                   void* stream) {
-  if (!Q || !K || !V || !O || !lse || !idx || !g || !dQ || !dK || !dV || !ws)
-    return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: null pointer");
-  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: D must be 128");
-  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, N, M, D))
-    return fail(SAMBLE_E_WORKSPACE, "samble_attn_bwd_f32: workspace too small");
-  if ((dq_rs & 3) || (dk_rs & 3) || (dv_rs & 3) || (q_rs & 3) || (k_rs & 3) || (v_rs & 3))
-    return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: row strides must be multiples of 4 elements");
+static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                           int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* O, const float* Oc,
+                           const float* smap, int ld, const float* lse, const int64_t* idx, const float* g, int B, int N,
+                           int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
+                           int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
+                           void* stream) {
+  char msg[160];
+  if (!Q || !K || !V || (!O && !Oc) || !lse || !idx || !g || !dQ || !dK || !dV || !ws) {
+    snprintf(msg, sizeof msg, "%s: null pointer", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (D != 128 || nt < 0 || nt > 8 || B <= 0 || N <= 0 || M <= 0) {
+    snprintf(msg, sizeof msg, "%s: need D == 128, 0 <= nt <= 8, positive B/N/M", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, N, M, D)) {
+    snprintf(msg, sizeof msg, "%s: workspace too small", who);
+    return fail(SAMBLE_E_WORKSPACE, msg);
+  }
+  if ((dq_rs & 3) || (dk_rs & 3) || (dv_rs & 3) || (q_rs & 3) || (k_rs & 3) || (v_rs & 3)) {
+    snprintf(msg, sizeof msg, "%s: row strides must be multiples of 4 elements", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (smap && (ld < samble_attn_map_ld(N, nt) || M > 14000)) {
+    snprintf(msg, sizeof msg, "%s: map row stride below samble_attn_map_ld(N, nt), or M > 14000", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
   hipStream_t s = (hipStream_t)stream;
   // rows of dQ that were not sampled carry no gradient: one strided zero-fill launch
   {
@@ -216,11 +237,80 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
   float* delta = lse_s + (size_t)B * M;
   float* tok_part = delta + (size_t)B * M;
   float* slab = tok_part + (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
-  if (nt < 0 || nt > 8) return fail(SAMBLE_E_INVALID, "samble_attn_bwd_f32: need 0 <= nt <= 8");
-  return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, lse, (const long long*)idx, g, B, N,
-                                     nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part, slab, dQ, dq_bs, dq_rs, dK, dk_bs,
-                                     dk_rs, dV, dv_bs, dv_rs, s),
-              "samble_attn_bwd_f32");
+  return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
+                                     (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
+                                     slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, s),
+              who);
+}
+
+SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                   int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* O,
+                                   const float* lse, const int64_t* idx, const float* g, int B, int N, int nt, int M,
+                                   int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
+                                   int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  return attn_bwd_common("samble_attn_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, nullptr, nullptr, 0, lse,
+                         idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
+                         stream);
+}
+
+SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                        int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* smap,
+                                        int ld, const float* lse, const float* x_ds, const int64_t* idx, const float* g,
+                                        int B, int N, int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs,
+                                        float* dK, int64_t dk_bs, int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  if (!smap || !x_ds) return fail(SAMBLE_E_INVALID, "samble_attn_rows_bwd_f32: null pointer");
+  return attn_bwd_common("samble_attn_rows_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap, ld,
+                         lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
+                         stream);
+}
+
+SAMBLE_API int samble_attn_map_row_stride(int N, int nt) { return samble_attn_map_ld(N, nt); }
+
+SAMBLE_API int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                     int64_t k_rs, int B, int N, int nt, int D, float* smap, int ld, float* lse,
+                                     float* tok, void* stream) {
+  if (!Q || !K || !smap || !lse) return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: D must be 128");
+  if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (nt > 0 && !tok))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: bad B/N/nt");
+  if ((q_rs & 3) || (k_rs & 3) || (q_bs & 3) || (k_bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: strides must be multiples of 4 elements (16-byte rows)");
+  if (ld < samble_attn_map_ld(N, nt) || (ld & 3) || (long)N * ld >= (1l << 31))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: map row stride must be >= samble_attn_map_row_stride(N, nt), "
+                                  "a multiple of 4, and N * ld < 2^31");
+  return done(samble_launch_attn_stats(Q, q_bs, q_rs, K, k_bs, k_rs, B, N, nt, inv_sqrt_d(D), smap, ld, lse, tok,
+                                       (hipStream_t)stream),
+              "samble_attn_stats_f32");
+}
+
+SAMBLE_API int samble_attn_rows_fwd_f32(const float* smap, int ld, const float* lse, const float* V, int64_t v_bs,
+                                        int64_t v_rs, const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds,
+                                        void* stream) {
+  if (!smap || !lse || !V || !idx || !x_ds) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_f32: D must be 128");
+  if (B <= 0 || N <= 0 || M <= 0 || nt < 0 || nt > 8) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_f32: bad sizes");
+  if ((v_rs & 3) || (v_bs & 3) || (ld & 3) || ld < samble_attn_map_ld(N, nt))
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_f32: bad strides");
+  return done(samble_launch_attn_rows(smap, ld, lse, V, v_bs, v_rs, (const long long*)idx, B, N, nt, M, x_ds,
+                                      (hipStream_t)stream),
+              "samble_attn_rows_fwd_f32");
+}
+
+SAMBLE_API int samble_sparse_score_map_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,
+                                           int KN, int mode, float* score, float* z, int32_t* indeg_out, void* ws,
+                                           size_t ws_bytes, void* stream) {
+  if (!smap || !lse || !nn || !score || !z || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: null pointer");
+  if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: unknown score mode");
+  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: N too large for LDS");
+  if (ws_bytes < samble_score_ws_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_map_f32: workspace too small");
+  return done(samble_launch_sparse_score_map(smap, ld, lse, nn, B, N, KN, mode, score, z, indeg_out, ws,
+                                             (hipStream_t)stream),
+              "samble_sparse_score_map_f32");
 }
 
 SAMBLE_API size_t samble_proj_workspace_bytes(int B, int N) {

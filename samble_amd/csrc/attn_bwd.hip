@@ -26,7 +26,8 @@ namespace samble {
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                        const float* __restrict__ K, long k_bs, long k_rs,
                                                        const float* __restrict__ V, long v_bs, long v_rs,
-                                                       const float* __restrict__ O, const float* __restrict__ lse,
+                                                       const float* __restrict__ O, const float* __restrict__ Oc,
+                                                       const float* __restrict__ lse,
                                                        const long long* __restrict__ idx,
                                                        const float* __restrict__ g,  // (B,128,M)
                                                        int N, int nt, int M, float scale, float* __restrict__ Qs,
@@ -35,12 +36,20 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
                                                        float* __restrict__ slab, int nslab, int tok_slab) {
   __shared__ float gt[128 * 33];
   __shared__ float red[4][2][8][128];  // [wave][dK|dV][token][channel]
+  __shared__ float dred[8][32];
   const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
   const float* gb = g + (long)b * 128 * M;
+  // O either as rows of the all-rows forward output (O, gathered by idx below) or as the sampled rows'
+  // channel-major output of attn_rows (Oc = x_ds, (B,128,M)): then delta is reduced right here, each
+  // thread over its 16 channels of one row, the 8 channel groups in a fixed order afterwards
+  float dpart = 0.f;
   for (int e = tid; e < 128 * 32; e += 256) {
     int d = e >> 5, mm = e & 31;
-    gt[d * 33 + mm] = (m0 + mm < M) ? gb[(long)d * M + m0 + mm] : 0.f;
+    const float gv = (m0 + mm < M) ? gb[(long)d * M + m0 + mm] : 0.f;
+    gt[d * 33 + mm] = gv;
+    if (Oc && m0 + mm < M) dpart = fmaf(gv, Oc[(long)b * 128 * M + (long)d * M + m0 + mm], dpart);
   }
+  dred[tid >> 5][tid & 31] = dpart;
   __syncthreads();
   const int sub = tid >> 5, l32 = tid & 31;  // 8 half-waves, each one row at a time
   // token keys / values: this lane's 4 channels of each of the nt (<= 8) rows
@@ -58,7 +67,8 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     if (m >= M) continue;  // uniform per half-wave
     const long row = idx[(long)b * M + m];
     const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + row * q_rs + 4 * l32);
-    const f32x4 ov = *reinterpret_cast<const f32x4*>(O + ((long)b * N + row) * 128 + 4 * l32);
+    const f32x4 z4r = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ov = Oc ? z4r : *reinterpret_cast<const f32x4*>(O + ((long)b * N + row) * 128 + 4 * l32);
     const float lrow = lse[(long)b * N + row];
     f32x4 dv = {gt[(4 * l32 + 0) * 33 + rr], gt[(4 * l32 + 1) * 33 + rr], gt[(4 * l32 + 2) * 33 + rr],
                 gt[(4 * l32 + 3) * 33 + rr]};
@@ -67,6 +77,11 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     float part = dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (Oc) {
+      part = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) part += dred[w8][rr];
+    }
     if (l32 == 0) {
       delta[(long)b * M + m] = part;
       lse_s[(long)b * M + m] = lrow;
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
 constexpr int kFusedTile = 2 * kTile * kLdsPad + 2 * kTile;  // Q tile, dO tile, lse[32], delta[32]
 constexpr int kFusedLdsFloats = 2 * kFusedTile + 2 * kTile * kLdsPad;
 
+template <bool MAP>
 __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
                                                            const float* __restrict__ lse_s,
                                                            const float* __restrict__ delta,
@@ -169,9 +185,12 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ V, long v_bs, long v_rs, int N,
                                                            int M, float scale, float* __restrict__ dK, long dk_bs,
                                                            long dk_rs, float* __restrict__ dV, long dv_bs, long dv_rs,
-                                                           float* __restrict__ slab, int nslab) {
+                                                           float* __restrict__ slab, int nslab,
+                                                           const float* __restrict__ smap, int ld,
+                                                           const long long* __restrict__ idx) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dsbuf = smem + 2 * kFusedTile;  // 2 x [32][kLdsPad]
+  int* sel = reinterpret_cast<int*>(dsbuf + 2 * kTile * kLdsPad);  // MAP: the cloud's M sampled row ids
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
@@ -181,16 +200,27 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
   const float* Qb = Qs + (long)b * M * 128;
   const float* Gb = dO + (long)b * M * 128;
 
-  float kreg[64], vreg[64], kcol[64];
+  float kreg[MAP ? 1 : 64], vreg[64], kcol[64];
   if (jvalid) {
-    load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, kreg);
+    if (!MAP) load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, reinterpret_cast<float(&)[64]>(kreg));
     load_row_half(V + (long)b * v_bs + (long)j * v_rs, h, vreg);
   } else {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
-      kreg[i] = 0.f;
+      if (!MAP) kreg[i] = 0.f;
       vreg[i] = 0.f;
     }
+  }
+  // MAP: S is not recomputed; this lane's key column of the sampled rows is read from the logit map
+  // (for register r: row sel[i0 + crow(r,h)], column j; the 32 lanes of a half read one 128-byte run)
+  const float* scol = MAP ? smap + (long)b * N * ld + min(j, ld - 1) : nullptr;
+  float sv[16], sn[16];
+  auto load_s = [&](int i0, float (&dst)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = scol[sel[min(i0 + crow(r, h), M - 1)] * ld];
+  };
+  if (MAP) {
+    for (int i = tid; i < M; i += 256) sel[i] = (int)idx[(long)b * M + i];
   }
   // this wave's channel slice of the workgroup's 128 K rows: lane (d, h) holds K[key 64h+kk][32w + d]
 #pragma unroll
@@ -225,26 +255,38 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
   issue(0);
   commit(smem);
   __syncthreads();
+  if (MAP) load_s(0, sv);
 
   float* myslab = slab + ((long)b * nslab + chunk) * M * 128;
   for (int t = 0; t <= ntiles; ++t) {
     float* cur = smem + (t & 1) * kFusedTile;
     float* nxt = smem + ((t & 1) ^ 1) * kFusedTile;
     const int i0 = t * kTile;
-    if (t + 1 < ntiles) issue(i0 + kTile);
+    if (t + 1 < ntiles) {
+      issue(i0 + kTile);
+      if (MAP) load_s(i0 + kTile, sn);
+    }
     if (t < ntiles) {
       const float* Qt = cur;
       const float* Gt = cur + kTile * kLdsPad;
       const float* Lt = cur + 2 * kTile * kLdsPad;
       const float* Dt = Lt + kTile;
       float* dsw = dsbuf + (t & 1) * kTile * kLdsPad + 32 * wave + lo;
-      f32x16 s = mma_rows_x_regs(Qt, kLdsPad, lo, h, kreg, zero16());   // S  (queries x keys)
+      f32x16 s;
+      if (MAP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = sv[r];
+      } else {
+        s = mma_rows_x_regs(Qt, kLdsPad, lo, h, reinterpret_cast<const float(&)[64]>(kreg), zero16());  // S (queries x keys)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= scale;
+      }
       f32x16 dp = mma_rows_x_regs(Gt, kLdsPad, lo, h, vreg, zero16());  // dP
       const bool tail = (i0 + kTile > M);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ir = crow(r, h);
-        float p = __expf(s[r] * scale - Lt[ir]);
+        float p = __expf(s[r] - Lt[ir]);
         if (tail && (i0 + ir >= M)) p = 0.f;
         const float ds = p * (dp[r] - Dt[ir]) * scale;
         dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
@@ -262,7 +304,13 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
         if (m < M) myslab[(long)m * 128 + 32 * wave + lo] = dqa[r];
       }
     }
-    if (t + 1 < ntiles) commit(nxt);
+    if (t + 1 < ntiles) {
+      commit(nxt);
+      if (MAP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = sn[r];
+      }
+    }
     __syncthreads();
   }
   if (jvalid) {
@@ -515,11 +563,14 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
 }
 
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
-                                      const float* V, long v_bs, long v_rs, const float* O, const float* lse,
-                                      const long long* idx, const float* g, int B, int N, int nt, int M, float scale,
-                                      float* Qs, float* dOb, float* lse_s, float* delta, float* tok_part, float* slab,
-                                      float* dQ, long dq_bs, long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV,
-                                      long dv_bs, long dv_rs, hipStream_t stream) {
+                                      const float* V, long v_bs, long v_rs, const float* O, const float* Oc,
+                                      const float* smap, int ld, const float* lse, const long long* idx,
+                                      const float* g, int B, int N, int nt, int M, float scale, float* Qs, float* dOb,
+                                      float* lse_s, float* delta, float* tok_part, float* slab, float* dQ, long dq_bs,
+                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
+                                      hipStream_t stream) {
+  // O (B,N,128) rows of the single-pass forward, or Oc (B,128,M) = x_ds of attn_rows; smap (B,N,ld) =
+  // the logit map of attn_stats (then S is read, not recomputed) or null
   static bool attr_set = false;
   const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
   const size_t lds_fused = kFusedLdsFloats * sizeof(float);
@@ -530,24 +581,34 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int NK = N + nt;
   const int nparts = (M + 31) / 32;
   const int kb = (N + 127) / 128;
-  const bool fused = !g_bwd_split;
+  const bool fused = !g_bwd_split || smap;
+  if (smap && lds_fused + (size_t)M * 4 > 160 * 1024) return -22;
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
   hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
-                     O, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
+                     O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
                      fused ? kb + 1 : 0, kb);
   if (fused) {
-    hipLaunchKernelGGL(bwd_fused_kernel, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs,
-                       V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab, kb + 1);
+    if (smap)
+      hipLaunchKernelGGL(bwd_fused_kernel<true>, dim3(kb, B), dim3(256), lds_fused + (size_t)M * 4, stream, Qs, dOb,
+                         lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab,
+                         kb + 1, smap, ld, idx);
+    else
+      hipLaunchKernelGGL(bwd_fused_kernel<false>, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K,
+                         k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab, kb + 1,
+                         (const float*)nullptr, 0, idx);
     hipLaunchKernelGGL(bwd_dq_reduce_kernel, dim3((M * 32 + 255) / 256, B), dim3(256), 0, stream, slab, kb + 1, idx, M,
                        dQ, dq_bs, dq_rs);
   } else {

@@ -1,0 +1,198 @@
+// Two-pass attention forward with the logit map kept in HBM (reference models/downsample.py:139-153
+// and 242-252).
+//
+// Why materialise what flash attention avoids: on MI355X the path runs in exact fp32, where the
+// matrix cores give 157 TFLOP/s against 8 TB/s of HBM3E, i.e. 20 flop per byte.  Recomputing one
+// logit costs 2*D = 256 flop, reloading it costs 4 bytes = 80 flop-equivalents, and the 288 GB of
+// HBM make the (B,N,N+nt) map (538 MB at B=32, N=2048; 4.3 GB for the N=8192 stress case) a
+// non-issue.  So S = scale * Q K^T is computed ONCE:
+//   pass 1  attn_stats   all N rows: S tiles -> HBM, running max / sum-exp -> lse, token logits
+//   (score, bins, selection run on lse / S; they decide WHICH M rows are sampled)
+//   pass 2  attn_rows    the M sampled rows only: P = exp(S - lse) straight from the map, O = P V,
+//                        written channel-major as the module output x_ds (B, D, M)
+//   backward             reads the same M rows again instead of recomputing S (attn_bwd.hip)
+// Matrix work per cloud: 2N(N+nt)D + 2M(N+nt)D forward (= the algorithmic count of SURVEY 8d; the
+// single-pass kernel of attn_fwd.hip executes 4N(N+nt)D), 4 products instead of 5 backward.
+//
+// Map layout: row-major (B, N, ld), ld = 32 * ceil((N+nt)/32); columns N..N+nt-1 are the token
+// logits, columns >= N+nt hold -inf so consumers need no tail masks (exp(-inf - lse) = 0).
+#include "samble_dev.h"
+
+namespace samble {
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: one workgroup = NW waves = 32*NW query rows; K tiles (32 keys) double-buffered in LDS.
+// S^T orientation (keys on the accumulator's register axis, queries on lanes): the row statistics
+// are lane-local, and a lane's registers 4g..4g+3 are 4 consecutive keys of its query's row, so the
+// map is written with 16-byte stores (the 4 g-stores of the two lane halves fill one 128-byte line).
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                                const float* __restrict__ K, long k_bs, long k_rs,
+                                                                int N, int NK, float scale, float* __restrict__ smap,
+                                                                int ld, float* __restrict__ lse,
+                                                                float* __restrict__ tok, int nt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = kTile * kLdsPad;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int qrow = chunk * (32 * NW) + wave * 32 + lo;
+  const bool qvalid = qrow < N;
+  const float* Kb = K + (long)b * k_bs;
+
+  float q[64];
+  if (qvalid) {
+    load_row_half(Q + (long)b * q_bs + (long)qrow * q_rs, h, q);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) q[i] = 0.f;
+  }
+  float* srow = smap + ((long)b * N + (qvalid ? qrow : 0)) * ld + 4 * h;
+  float m = kNegInf, l = 0.f;
+
+  const int ntiles = (NK + kTile - 1) / kTile;
+  TileRegsT<64 * NW> kr;
+  tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
+  tile_store_lds(kr, smem, kLdsPad, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    float* Kc = smem + (t & 1) * kBuf;
+    float* Kn = smem + ((t & 1) ^ 1) * kBuf;
+    const int j0 = t * kTile;
+    if (t + 1 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
+    f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());
+    const bool tail = (j0 + kTile > N);  // tile holds token keys and/or padding (wave-uniform)
+    float mt = kNegInf;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = s[r] * scale;
+      if (tail) {
+        const int j = j0 + crow(r, h);
+        if (j >= NK) v = kNegInf;
+        if (j >= N && j < NK && qvalid) tok[((long)b * N + qrow) * nt + (j - N)] = v;
+      }
+      s[r] = v;
+      mt = fmaxf(mt, v);
+    }
+    if (qvalid) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(srow + j0 + 8 * g) = o;
+      }
+    }
+    mt = fmaxf(mt, wave_xor32(mt));
+    const float mnew = fmaxf(m, mt);
+    if (__any(mnew != m)) {
+      l *= __expf(m - mnew);
+      m = mnew;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m);
+    l += ps;
+    if (t + 1 < ntiles) tile_store_lds(kr, Kn, kLdsPad, tid);
+    __syncthreads();
+  }
+  const float ltot = l + wave_xor32(l);
+  if (qvalid && h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: one workgroup = NW waves = 32*NW SAMPLED rows of one cloud; V tiles (32 keys) double-
+// buffered in LDS.  Lane (i, h) reads its row's 4 x 16 bytes of the map per tile (prefetched one
+// tile ahead), P = exp(S - lse) lands in the accumulator layout the product wants (reduced index =
+// keys on the register axis) and feeds O^T += V_tile^T P^T (64 MFMA).  O^T registers are channels
+// x queries-on-lanes: the channel-major module output (B, D, M) is written with 128-byte runs.
+// ------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_rows_kernel(const float* __restrict__ smap, int ld,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ V, long v_bs, long v_rs,
+                                                               const long long* __restrict__ idx, int N, int NK,
+                                                               int M, float* __restrict__ xds) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kBuf = kTile * 128;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int mrow = chunk * (32 * NW) + wave * 32 + lo;
+  const bool mvalid = mrow < M;
+  const long row = idx[(long)b * M + (mvalid ? mrow : M - 1)];
+  const float my_lse = lse[(long)b * N + row];
+  const float* srow = smap + ((long)b * N + row) * ld + 4 * h;
+  const float* Vb = V + (long)b * v_bs;
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+
+  const int ntiles = (NK + kTile - 1) / kTile;
+  TileRegsT<64 * NW> vr;
+  f32x4 sv[4], sn[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(srow + 8 * g);
+  tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
+  tile_store_lds(vr, smem, 128, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    float* Vc = smem + (t & 1) * kBuf;
+    float* Vn = smem + ((t & 1) ^ 1) * kBuf;
+    const int j0 = t * kTile;
+    if (t + 1 < ntiles) {
+      tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sn[g] = *reinterpret_cast<const f32x4*>(srow + j0 + kTile + 8 * g);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(sv[r >> 2][r & 3] - my_lse);
+      mma_tileT_step(Vc, 128, lo, h, r, p, oacc);
+    }
+    if (t + 1 < ntiles) {
+      tile_store_lds(vr, Vn, 128, tid);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sv[g] = sn[g];
+    }
+    __syncthreads();
+  }
+  if (mvalid) {
+    float* ob = xds + (long)b * 128 * M + mrow;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long)(32 * dt + crow(r, h)) * M] = oacc[dt][r];
+    }
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_attn_map_ld(int N, int nt) { return 32 * ((N + nt + 31) / 32); }
+
+extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs, int B,
+                                        int N, int nt, float scale, float* smap, int ld, float* lse, float* tok,
+                                        hipStream_t stream) {
+  constexpr int NW = 8;
+  const size_t lds = 2 * kTile * kLdsPad * sizeof(float);
+  hipLaunchKernelGGL(attn_stats_kernel<NW>, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs,
+                     q_rs, K, k_bs, k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_attn_rows(const float* smap, int ld, const float* lse, const float* V, long v_bs, long v_rs,
+                                       const long long* idx, int B, int N, int nt, int M, float* xds,
+                                       hipStream_t stream) {
+  constexpr int NW = 4;
+  const size_t lds = 2 * kTile * 128 * sizeof(float);
+  hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, smap, ld,
+                     lse, V, v_bs, v_rs, idx, N, N + nt, M, xds);
+  return (int)hipGetLastError();
+}

@@ -95,6 +95,71 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
   }
 }
 
+// Same statistics with A_ij read from the logit map of attn_stats (attn_map.hip) instead of being
+// recomputed: A_ij = exp(S_ij - lse_i), one lane per (row, neighbour) pair.  The reference gathers these
+// very entries from its dense map (downsample.py:300-307), so this is also the closer restatement.
+// grid (ceil(N/64), B), 256 threads: 8 half-waves, each walks rows r0+hw, r0+hw+8, ...
+__global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __restrict__ smap, int ld,
+                                                               const float* __restrict__ lse,
+                                                               const int* __restrict__ nn, int N, int KN,
+                                                               unsigned long long* __restrict__ colacc,
+                                                               int* __restrict__ indeg, float* __restrict__ rowstat,
+                                                               int row_mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(sraw);
+  int* cnt = reinterpret_cast<int*>(acc + N);
+  const int tid = threadIdx.x;
+  int b, chunk;
+  xcd_assign(chunk, b);
+  for (int n = tid; n < N; n += 256) {
+    acc[n] = 0ull;
+    cnt[n] = 0;
+  }
+  __syncthreads();
+  const int hw = tid >> 5, c = tid & 31;
+  const int r0 = chunk * 64;
+  for (int i = r0 + hw; i < min(r0 + 64, N); i += 8) {
+    const float li = lse[(long)b * N + i];
+    const int* ni = nn + ((long)b * N + i) * KN;
+    const float* srow = smap + ((long)b * N + i) * ld;
+    double rs_d = 0.0, rss_d = 0.0;
+    for (int k0 = 0; k0 < KN; k0 += 32) {
+      const int k = k0 + c;
+      if (k < KN) {
+        const int j = ni[k];
+        const float a = __expf(srow[j] - li);
+        atomicAdd(&acc[j], (unsigned long long)__float2ll_rn(a * kFix));
+        atomicAdd(&cnt[j], 1);
+        rs_d += (double)a;
+        rss_d += (double)a * (double)a;
+      }
+    }
+    if (rowstat) {
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        rs_d += __shfl_xor(rs_d, off, 64);
+        rss_d += __shfl_xor(rss_d, off, 64);
+      }
+      if (c == 0) {
+        float v = (float)rs_d;
+        if (row_mode == kRowStd) {  // unbiased std over the K picked entries (torch.std default)
+          const double mean = rs_d / KN;
+          v = (float)sqrt(fmax((rss_d - KN * mean * mean) / (KN - 1), 0.0));
+        }
+        rowstat[(long)b * N + i] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 256) {
+    const int cn = cnt[n];
+    if (cn) {
+      atomicAdd(&colacc[(long)b * N + n], acc[n]);
+      atomicAdd(&indeg[(long)b * N + n], cn);
+    }
+  }
+}
+
 // One workgroup per cloud: score from the exact column sums, NaN -> 0, then z-score with the
 // reference's operation order  z = (s - mean) / std  (population std), mean and std each the
 // correctly rounded fp32 of a double-precision two-pass reduction in a fixed tree order.
@@ -198,6 +263,31 @@ extern "C" int samble_launch_sparse_score(const float* Q, long q_bs, long q_rs, 
   }
   hipLaunchKernelGGL(sparse_score_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
                      lse, nn, N, KN, scale, colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
+  hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
+  if (indeg_out) {
+    e = hipMemcpyAsync(indeg_out, indeg, (size_t)B * N * sizeof(int), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const float* lse, const int* nn, int B, int N,
+                                              int KN, int mode, float* score, float* z, int* indeg_out, void* ws,
+                                              hipStream_t stream) {
+  if (mode < 0 || mode > kRowStd) return -22;
+  unsigned long long* colacc = reinterpret_cast<unsigned long long*>(ws);
+  int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
+  float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = (size_t)N * 12;
+  if (lds > 64 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_map_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(sparse_score_map_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN,
+                     colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
   if (indeg_out) {
     e = hipMemcpyAsync(indeg_out, indeg, (size_t)B * N * sizeof(int), hipMemcpyDeviceToDevice, stream);

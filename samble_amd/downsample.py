@@ -51,6 +51,11 @@ class _Projection(torch.autograd.Function):
         return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1))
 
 
+# Two-pass forward with the logit map kept in HBM (csrc/attn_map.hip) for the sparse_* score modes;
+# False selects the single-pass flash kernel (csrc/attn_fwd.hip) for A/B runs.
+TWO_PASS = True
+
+
 class _SamplerCore(torch.autograd.Function):
     """qkv (B,N+nt,3D) [differentiable], x (B,C,N) [kNN only] -> x_ds (B,D,M), token logits (B,N,nt)
     [both differentiable] + the integer / score by-products."""
@@ -65,6 +70,7 @@ class _SamplerCore(torch.autograd.Function):
         k = qkv[:, :, D:2 * D]
         v = qkv[:, :, 2 * D:3 * D]
 
+        smap = None
         if mod.idx_mode in ("col_sum", "row_std"):
             # dense statistics of the attention map: no neighbour lists involved
             if mod.idx_mode == "row_std":
@@ -77,8 +83,13 @@ class _SamplerCore(torch.autograd.Function):
             indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
         else:
             nn_idx = ops.stage_knn(x, x, mod.K)
-            O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
-            score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
+            if TWO_PASS:
+                # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
+                smap, lse, tok = ops.stage_attn_stats(q, k, N, nt)
+                score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
+            else:
+                O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
+                score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
 
         if mod.bin_boundaries is not None:
             mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
@@ -89,9 +100,12 @@ class _SamplerCore(torch.autograd.Function):
                                                      mod.relu_mean_order == "relu_mean")
         counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
-        x_ds = ops.stage_gather_rows(O, idx)
-
-        ctx.save_for_backward(qkv, O, lse, idx)
+        if smap is not None:
+            x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt)
+            ctx.save_for_backward(qkv, x_ds, lse, idx, smap)
+        else:
+            x_ds = ops.stage_gather_rows(O, idx)
+            ctx.save_for_backward(qkv, O, lse, idx)
         ctx.dims = (N, nt, D)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(idx, score, z, member, cap, w_pre, counts, indeg, nn_idx)
@@ -99,15 +113,20 @@ class _SamplerCore(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_xds, g_tok, *_):
-        qkv, O, lse, idx = ctx.saved_tensors
+        qkv, O, lse, idx = ctx.saved_tensors[:4]
+        smap = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
         N, nt, D = ctx.dims
         q = qkv[:, :N, 0:D]
         k = qkv[:, :, D:2 * D]
         v = qkv[:, :, 2 * D:3 * D]
         if g_xds is not None:
             dqkv = torch.empty_like(qkv)
-            ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
-                               dqkv[:, :, 2 * D:3 * D])
+            if smap is not None:  # O is x_ds (B,D,M) here
+                ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
+                                        dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D])
+            else:
+                ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
+                                   dqkv[:, :, 2 * D:3 * D])
             if nt:
                 dqkv[:, N:, 0:D].zero_()
         else:

@@ -318,6 +318,74 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
                   ws.data_ptr(), nbytes, _stream())
 
 
+def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int):
+    """Pass 1 of the two-pass forward: q (B,N,D), k (B,N+nt,D) -> logit map (B,N,ld) kept in HBM,
+    lse (B,N), token logits (B,N,nt).  Columns >= N+nt of the map are -inf."""
+    _need_gpu(q, k)
+    B, N, D = q.shape
+    assert N == n_points and k.shape[1] == n_points + n_tokens
+    for t in (q, k):
+        if t.stride(2) != 1 or t.dtype != torch.float32:
+            raise ValueError("attention operands must be fp32 with unit channel stride")
+    with torch.cuda.device(q.device):
+        ld = _lib.query("samble_attn_map_row_stride", N, n_tokens)
+        smap = torch.empty((B, N, ld), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        tok = torch.empty((B, N, max(n_tokens, 1)), dtype=torch.float32, device=q.device)
+        _lib.call("samble_attn_stats_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), B, N, n_tokens, D, smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _stream())
+    return smap, lse, tok[:, :, :n_tokens]
+
+
+def stage_attn_rows(smap: torch.Tensor, lse: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, n_points: int,
+                    n_tokens: int) -> torch.Tensor:
+    """Pass 2: the M sampled rows idx (B,M) of softmax(map) times v (B,N+nt,D) -> x_ds (B,D,M)."""
+    _need_gpu(smap, lse, v, idx)
+    B, N, ld = smap.shape
+    M, D = idx.shape[1], v.shape[2]
+    assert N == n_points and v.shape[1] == n_points + n_tokens and idx.dtype == torch.int64 and idx.is_contiguous()
+    with torch.cuda.device(smap.device):
+        out = torch.empty((B, D, M), dtype=torch.float32, device=smap.device)
+        _lib.call("samble_attn_rows_fwd_f32", smap.data_ptr(), ld, lse.data_ptr(), v.data_ptr(), v.stride(0),
+                  v.stride(1), idx.data_ptr(), B, N, n_tokens, M, D, out.data_ptr(), _stream())
+    return out
+
+
+def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
+    """stage_sparse_score with A_ij read from the logit map instead of recomputed."""
+    if idx_mode not in SCORE_MODES:
+        raise ValueError("Please check the setting of idx mode!")
+    _need_gpu(smap, lse, nn_idx)
+    B, N, ld = smap.shape
+    with torch.cuda.device(smap.device):
+        score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
+        z = torch.empty_like(score)
+        indeg = torch.empty((B, N), dtype=torch.int32, device=smap.device)
+        nbytes = _lib.query("samble_score_workspace_bytes", B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=smap.device)
+        _lib.call("samble_sparse_score_map_f32", smap.data_ptr(), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
+                  nn_idx.shape[2], SCORE_MODES[idx_mode], score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
+                  ws.data_ptr(), nbytes, _stream())
+    return score, z, indeg
+
+
+def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv) -> None:
+    """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M)."""
+    _need_gpu(q, k, v, smap, lse, x_ds, idx, g)
+    B, N, D = q.shape
+    M = idx.shape[1]
+    g = _f32c(g)
+    x_ds = _f32c(x_ds)
+    with torch.cuda.device(q.device):
+        nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.call("samble_attn_rows_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                  k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), smap.data_ptr(), smap.shape[2], lse.data_ptr(),
+                  x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(),
+                  dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0),
+                  dv.stride(1), ws.data_ptr(), nbytes, _stream())
+
+
 # ------------------------------------------------------------------------------------------------
 # reference-named functions (utils/ops.py)
 # ------------------------------------------------------------------------------------------------

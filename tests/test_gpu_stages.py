@@ -205,6 +205,101 @@ def test_attn_bwd(B, N, nt, M):
 
 
 # ---------------------------------------------------------------------------------------------
+# two-pass forward with the logit map in HBM (attn_stats / attn_rows / sparse_score_map / rows_bwd)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,nt,M", [(2, 256, 6, 128), (1, 1000, 4, 333), (2, 1024, 6, 512), (1, 96, 1, 50),
+                                      (1, 1025, 6, 700)])
+def test_two_pass_forward(B, N, nt, M):
+    D = 128
+    q, k, v = _qkv(B, N, nt, 900 + N)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)])
+    s = (q.double() @ k.double().transpose(1, 2)) / math.sqrt(D)
+    o_ = ops()
+    smap, lse, tok = o_.stage_attn_stats(q.to(DEV), k.to(DEV), N, nt)
+    ld = smap.shape[2]
+    assert ld % 32 == 0 and ld >= N + nt
+    # a logit is one fp32 MFMA chain of length 128: 1e-6 relative to |q||k|
+    torch.testing.assert_close(smap[:, :, :N + nt].cpu().double(), s, rtol=1e-5, atol=2e-5)
+    assert torch.isneginf(smap[:, :, N + nt:]).all()
+    torch.testing.assert_close(lse.cpu().double(), torch.logsumexp(s, -1), rtol=1e-5, atol=1e-5)
+    assert torch.equal(tok, smap[:, :, N:N + nt])
+    x_ds = o_.stage_attn_rows(smap, lse, v.to(DEV), idx.to(DEV), N, nt)
+    ref = torch.gather(torch.softmax(s, -1) @ v.double(), 1, idx[..., None].expand(-1, -1, D)).permute(0, 2, 1)
+    torch.testing.assert_close(x_ds.cpu().double(), ref, rtol=2e-4, atol=2e-5)
+    # the single-pass kernel computes the same logits with the same MFMA chain
+    O1, lse1, tok1 = o_.stage_attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), N, nt)
+    assert torch.equal(tok1, tok)
+    torch.testing.assert_close(lse1, lse, rtol=0, atol=2e-6)
+    torch.testing.assert_close(o_.stage_gather_rows(O1, idx.to(DEV)), x_ds, rtol=1e-5, atol=2e-6)
+
+
+def test_two_pass_strided_views():
+    B, N, nt, D, M = 2, 256, 6, 128, 100
+    qkv = torch.from_numpy(synth.normal((B, N + nt, 3 * D), 19)).to(DEV)
+    q, k, v = qkv[:, :N, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)]).to(DEV)
+    smap, lse, tok = ops().stage_attn_stats(q, k, N, nt)
+    x_ds = ops().stage_attn_rows(smap, lse, v, idx, N, nt)
+    s = (q.double() @ k.double().transpose(1, 2)) / math.sqrt(D)
+    ref = torch.gather(torch.softmax(s, -1) @ v.double(), 1, idx[..., None].expand(-1, -1, D)).permute(0, 2, 1)
+    torch.testing.assert_close(x_ds.double(), ref, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", ["sparse_col_sqr", "sparse_col_sum", "sparse_col_avg", "sparse_row_sum",
+                                  "sparse_row_std"])
+def test_sparse_score_from_map(mode):
+    B, N, nt, K = 2, 512, 6, 32
+    q, k, v = _qkv(B, N, nt, 55)
+    q, k = q * 0.3, k * 0.3
+    nn = torch.stack([torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b * N + i))[:K]
+                                   for i in range(N)]) for b in range(B)]).int()
+    s = (q.double() @ k.double().transpose(1, 2)) / math.sqrt(128)
+    A = torch.softmax(s, -1)[:, :, :N]
+    mask = torch.zeros(B, N, N, dtype=torch.float64).scatter_(2, nn.long(), 1.0)
+    sparse = A * mask
+    num = mask.sum(-2) + 1e-8
+    ref = {"sparse_col_sum": sparse.sum(-2), "sparse_col_avg": sparse.sum(-2) / num,
+           "sparse_col_sqr": sparse.sum(-2) / num / num, "sparse_row_sum": sparse.sum(-1),
+           "sparse_row_std": torch.std(sparse.masked_select(mask != 0).view(B, N, K), dim=-1)}[mode]
+    ref[torch.isnan(ref)] = 0
+    smap, lse, _ = ops().stage_attn_stats(q.to(DEV), k.to(DEV), N, nt)
+    score, z, indeg = ops().stage_sparse_score_map(smap, lse, nn.to(DEV), mode)
+    assert torch.equal(indeg.cpu().long(), mask.sum(-2).long())
+    torch.testing.assert_close(score.cpu().double(), ref, rtol=2e-5, atol=1e-9)
+    again = ops().stage_sparse_score_map(smap, lse, nn.to(DEV), mode)[0]
+    assert torch.equal(score, again)  # integer accumulation: order independent
+
+
+@pytest.mark.parametrize("B,N,nt,M", [(2, 256, 6, 128), (1, 1000, 4, 333), (2, 1024, 6, 512), (1, 1025, 6, 77)])
+def test_attn_rows_bwd(B, N, nt, M):
+    D = 128
+    q, k, v = _qkv(B, N, nt, 300 + N)
+    g = torch.from_numpy(synth.normal((B, D, M), 7))
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)])
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(1, 2)) / math.sqrt(D)
+    o = torch.softmax(s, -1) @ vd
+    rows = torch.gather(o, 1, idx[..., None].expand(-1, -1, D))
+    rows.permute(0, 2, 1).backward(g.double())
+    o_ = ops()
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    smap, lse, _ = o_.stage_attn_stats(qg, kg, N, nt)
+    x_ds = o_.stage_attn_rows(smap, lse, vg, idx.to(DEV), N, nt)
+    dq = torch.full((B, N, D), float("nan"), device=DEV)
+    dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
+    for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
+        assert torch.isfinite(got).all(), name
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 3e-5 * scale + 1e-7, (name, err, scale)
+    a = (dq.clone(), dk.clone(), dv.clone())
+    o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
+    assert torch.equal(a[0], dq) and torch.equal(a[1], dk) and torch.equal(a[2], dv)  # deterministic
+
+
+# ---------------------------------------------------------------------------------------------
 # sparse score
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["sparse_col_sqr", "sparse_col_sum", "sparse_col_avg", "sparse_row_sum",
