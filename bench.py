@@ -69,10 +69,10 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
         out["proj_fwd"] = time_region(lambda: ops.stage_proj_fwd(x, tokm, w), iters)
         out["knn"] = time_region(lambda: ops.stage_knn(x, x, KNN), iters)
         nn_idx = ops.stage_knn(x, x, KNN)
-        out["attn_fwd"] = time_region(lambda: ops.stage_attn_fwd(q, k, v, N, nt), iters)
-        O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
-        out["sparse_score"] = time_region(lambda: ops.stage_sparse_score(q, k, lse, nn_idx, "sparse_col_sqr"), iters)
-        score, z, _ = ops.stage_sparse_score(q, k, lse, nn_idx, "sparse_col_sqr")
+        out["attn_stats"] = time_region(lambda: ops.stage_attn_stats(q, k, N, nt), iters)
+        smap, lse, tok = ops.stage_attn_stats(q, k, N, nt)
+        out["sparse_score"] = time_region(lambda: ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr"), iters)
+        score, z, _ = ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr")
         out["batch_quantiles"] = time_region(lambda: ops.stage_batch_quantiles(z, NB), iters)
         up, lo = mod.bin_boundaries
         out["bin_assign"] = time_region(lambda: ops.stage_bin_assign(z, tok, up, lo, False), iters)
@@ -82,11 +82,12 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
         out["bin_select"] = time_region(
             lambda: ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise), iters)
         idx = ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise)
-        out["gather_rows"] = time_region(lambda: ops.stage_gather_rows(O, idx), iters)
+        out["attn_rows"] = time_region(lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt), iters)
+        x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt)
         dqkv = torch.empty_like(qkv)
         out["attn_bwd"] = time_region(
-            lambda: ops.stage_attn_bwd(q, k, v, O, lse, idx, g, N, nt, dqkv[:, :N, :C], dqkv[:, :, C:2 * C],
-                                       dqkv[:, :, 2 * C:]), iters)
+            lambda: ops.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, N, nt, dqkv[:, :N, :C],
+                                            dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:]), iters)
         out["proj_bwd"] = time_region(lambda: ops.stage_proj_bwd(dqkv, x, tokm, w, True, True), iters)
     return out
 
@@ -226,7 +227,7 @@ def main():
             result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
             # dominant kernel group: flash attention forward (one launch)
             alg = (fl["qk"] + fl["av"]) * B_PER_GPU
-            ach = alg / (br["attn_fwd"] * 1e-3) / 1e12
+            ach = alg / ((br["attn_stats"] + br["attn_rows"]) * 1e-3) / 1e12
             # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary (profiles/*_pmc.json:
             # (2*FETCH_SIZE + WRITE_SIZE)*1024, collected in their own runs as the counters require)
             traffic = None
