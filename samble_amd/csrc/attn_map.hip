@@ -26,6 +26,54 @@ namespace samble {
 // are lane-local, and a lane's registers 4g..4g+3 are 4 consecutive keys of its query's row, so the
 // map is written with 16-byte stores (the 4 g-stores of the two lane halves fill one 128-byte line).
 // ------------------------------------------------------------------------------------------------
+// Software pipeline: the 64 MFMAs of tile t+1's S product are issued with the softmax / map-store
+// work of tile t placed between them (an MFMA occupies the matrix pipe for 64 cycles and the wave
+// issues in order, so ~14 VALU cycles per MFMA are free).  Without it both waves of a SIMD sit in
+// their softmax phase at the same time (they are barrier-locked) and the pipe idles ~30% of a tile.
+// K tiles are triple-buffered: tile t+1 is resident while tile t+2 is being staged.
+template <bool TAIL>
+__device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo, int h, const float (&q)[64],
+                                           f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ srow_t,
+                                           bool qvalid, int j0, int N, int NK, float* __restrict__ tokrow, float& m,
+                                           float& l) {
+  const f32x4* lp = reinterpret_cast<const f32x4*>(Kn + lo * kLdsPad + 64 * h);
+  float mt = kNegInf, ps = 0.f;
+  s_nxt = zero16();
+#pragma unroll
+  for (int q4 = 0; q4 < 16; ++q4) {
+    const f32x4 a = lp[q4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_nxt = mfma32(a[e], q[4 * q4 + e], s_nxt);
+    if (q4 < 4) {  // scale, tile max and the 16-byte map store of registers 4*q4 .. 4*q4+3
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q4 + e;
+        float v = s_cur[r] * scale;
+        if (TAIL) {
+          const int j = j0 + crow(r, h);
+          if (j >= NK) v = kNegInf;
+          if (j >= N && j < NK && qvalid) tokrow[j - N] = v;
+        }
+        s_cur[r] = v;
+        mt = fmaxf(mt, v);
+      }
+      if (qvalid) {
+        const f32x4 o = {s_cur[4 * q4], s_cur[4 * q4 + 1], s_cur[4 * q4 + 2], s_cur[4 * q4 + 3]};
+        *reinterpret_cast<f32x4*>(srow_t + 8 * q4) = o;
+      }
+    } else if (q4 == 4) {  // running max (branch-free rescale of the running sum)
+      mt = fmaxf(mt, wave_xor32(mt));
+      const float mnew = fmaxf(m, mt);
+      l *= __expf(m - mnew);
+      m = mnew;
+    } else if (q4 < 13) {  // two exps per step
+      ps += __expf(s_cur[2 * (q4 - 5)] - m);
+      ps += __expf(s_cur[2 * (q4 - 5) + 1] - m);
+    }
+  }
+  l += ps;
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                                 const float* __restrict__ K, long k_bs, long k_rs,
@@ -50,52 +98,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
     for (int i = 0; i < 64; ++i) q[i] = 0.f;
   }
   float* srow = smap + ((long)b * N + (qvalid ? qrow : 0)) * ld + 4 * h;
+  float* tokrow = tok + ((long)b * N + (qvalid ? qrow : 0)) * nt;
   float m = kNegInf, l = 0.f;
 
   const int ntiles = (NK + kTile - 1) / kTile;
   TileRegsT<64 * NW> kr;
   tile_load_issue(kr, Kb, k_rs, 0, NK, tid);
   tile_store_lds(kr, smem, kLdsPad, tid);
+  tile_load_issue(kr, Kb, k_rs, kTile, NK, tid);  // rows >= NK read as zeros
+  tile_store_lds(kr, smem + kBuf, kLdsPad, tid);
   __syncthreads();
+  f32x16 s_cur = mma_rows_x_regs(smem, kLdsPad, lo, h, q, zero16());
+  f32x16 s_nxt;
 
+  int cur = 0;  // LDS buffer of tile t
   for (int t = 0; t < ntiles; ++t) {
-    float* Kc = smem + (t & 1) * kBuf;
-    float* Kn = smem + ((t & 1) ^ 1) * kBuf;
+    const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
     const int j0 = t * kTile;
-    if (t + 1 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + kTile, NK, tid);
-    f32x16 s = mma_rows_x_regs(Kc, kLdsPad, lo, h, q, zero16());
-    const bool tail = (j0 + kTile > N);  // tile holds token keys and/or padding (wave-uniform)
-    float mt = kNegInf;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = s[r] * scale;
-      if (tail) {
-        const int j = j0 + crow(r, h);
-        if (j >= NK) v = kNegInf;
-        if (j >= N && j < NK && qvalid) tok[((long)b * N + qrow) * nt + (j - N)] = v;
-      }
-      s[r] = v;
-      mt = fmaxf(mt, v);
-    }
-    if (qvalid) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(srow + j0 + 8 * g) = o;
-      }
-    }
-    mt = fmaxf(mt, wave_xor32(mt));
-    const float mnew = fmaxf(m, mt);
-    if (__any(mnew != m)) {
-      l *= __expf(m - mnew);
-      m = mnew;
-    }
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ps += __expf(s[r] - m);
-    l += ps;
-    if (t + 1 < ntiles) tile_store_lds(kr, Kn, kLdsPad, tid);
+    if (t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
+    if (j0 + kTile > N)  // tile holds token keys and/or padding (wave-uniform)
+      stats_step<true>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
+    else
+      stats_step<false>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
+    if (t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
     __syncthreads();
+    s_cur = s_nxt;
+    cur = nxt;
   }
   const float ltot = l + wave_xor32(l);
   if (qvalid && h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
@@ -181,7 +209,7 @@ extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, co
                                         int N, int nt, float scale, float* smap, int ld, float* lse, float* tok,
                                         hipStream_t stream) {
   constexpr int NW = 8;
-  const size_t lds = 2 * kTile * kLdsPad * sizeof(float);
+  const size_t lds = 3 * kTile * kLdsPad * sizeof(float);
   hipLaunchKernelGGL(attn_stats_kernel<NW>, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs,
                      q_rs, K, k_bs, k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
   return (int)hipGetLastError();
