@@ -229,8 +229,10 @@ extern "C" int samble_launch_attn_colsum(const float* Q, long q_bs, long q_rs, c
 }
 
 static int g_fwd_ablate = 0;
+extern int g_stats_ablate;
 extern "C" __attribute__((visibility("default"))) void samble_debug_ablate(int which, int mode) {
   if (which == 0) g_fwd_ablate = mode;
+  if (which == 1) g_stats_ablate = mode;
 }
 
 extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,

@@ -31,7 +31,7 @@ namespace samble {
 // issues in order, so ~14 VALU cycles per MFMA are free).  Without it both waves of a SIMD sit in
 // their softmax phase at the same time (they are barrier-locked) and the pipe idles ~30% of a tile.
 // K tiles are triple-buffered: tile t+1 is resident while tile t+2 is being staged.
-template <bool TAIL>
+template <bool TAIL, int ABL>
 __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo, int h, const float (&q)[64],
                                            f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ srow_t,
                                            bool qvalid, int j0, int N, int NK, float* __restrict__ tokrow, float& m,
@@ -57,7 +57,7 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
         s_cur[r] = v;
         mt = fmaxf(mt, v);
       }
-      if (qvalid) {
+      if (qvalid && ABL != 1) {
         const f32x4 o = {s_cur[4 * q4], s_cur[4 * q4 + 1], s_cur[4 * q4 + 2], s_cur[4 * q4 + 3]};
         *reinterpret_cast<f32x4*>(srow_t + 8 * q4) = o;
       }
@@ -74,7 +74,8 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
   l += ps;
 }
 
-template <int NW>
+// ABL (timing-only ablations, wrong outputs): 1 = no map stores, 2 = no tile staging
+template <int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                                 const float* __restrict__ K, long k_bs, long k_rs,
                                                                 int N, int NK, float scale, float* __restrict__ smap,
@@ -115,12 +116,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
   for (int t = 0; t < ntiles; ++t) {
     const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
     const int j0 = t * kTile;
-    if (t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
+    if (ABL != 2 && t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
     if (j0 + kTile > N)  // tile holds token keys and/or padding (wave-uniform)
-      stats_step<true>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
+      stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
     else
-      stats_step<false>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
-    if (t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
+      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
+    if (ABL != 2 && t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
     __syncthreads();
     s_cur = s_nxt;
     cur = nxt;
@@ -203,6 +204,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_rows_kernel(const float* __re
 
 using namespace samble;
 
+int g_stats_ablate = 0;  // set by samble_debug_ablate(1, mode)
+
 extern "C" int samble_attn_map_ld(int N, int nt) { return 32 * ((N + nt + 31) / 32); }
 
 extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs, int B,
@@ -210,8 +213,10 @@ extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, co
                                         hipStream_t stream) {
   constexpr int NW = 8;
   const size_t lds = 3 * kTile * kLdsPad * sizeof(float);
-  hipLaunchKernelGGL(attn_stats_kernel<NW>, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs,
-                     q_rs, K, k_bs, k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
+  auto kern = g_stats_ablate == 1 ? attn_stats_kernel<NW, 1> : g_stats_ablate == 2 ? attn_stats_kernel<NW, 2>
+                                                                                     : attn_stats_kernel<NW, 0>;
+  hipLaunchKernelGGL(kern, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs, q_rs, K, k_bs,
+                     k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
   return (int)hipGetLastError();
 }
 
