@@ -34,8 +34,7 @@ namespace samble {
 template <bool TAIL, int ABL>
 __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo, int h, const float (&q)[64],
                                            f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ srow_t,
-                                           bool qvalid, int j0, int N, int NK, float* __restrict__ tokrow, float& m,
-                                           float& l) {
+                                           int j0, int N, int NK, float* __restrict__ tokrow, float& m, float& l) {
   const f32x4* lp = reinterpret_cast<const f32x4*>(Kn + lo * kLdsPad + 64 * h);
   float mt = kNegInf, ps = 0.f;
   s_nxt = zero16();
@@ -52,12 +51,12 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
         if (TAIL) {
           const int j = j0 + crow(r, h);
           if (j >= NK) v = kNegInf;
-          if (j >= N && j < NK && qvalid) tokrow[j - N] = v;
+          if (j >= N && j < NK) tokrow[j - N] = v;
         }
         s_cur[r] = v;
         mt = fmaxf(mt, v);
       }
-      if (qvalid && ABL != 1) {
+      if (ABL != 1) {
         const f32x4 o = {s_cur[4 * q4], s_cur[4 * q4 + 1], s_cur[4 * q4 + 2], s_cur[4 * q4 + 3]};
         *reinterpret_cast<f32x4*>(srow_t + 8 * q4) = o;
       }
@@ -87,19 +86,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int qrow = chunk * (32 * NW) + wave * 32 + lo;
-  const bool qvalid = qrow < N;
+  // rows past N (last workgroup of a ragged cloud) are clamped to row N-1: those lanes recompute and
+  // rewrite row N-1's values bit for bit, which keeps every store unpredicated -- the loop body is
+  // one basic block, so the compiler can wait for the staged tile with a COUNTED vmcnt instead of
+  // draining the map stores too (stores share vmcnt on gfx9; the drain cost 20% of this kernel)
+  const int qrow = min(chunk * (32 * NW) + wave * 32 + lo, N - 1);
   const float* Kb = K + (long)b * k_bs;
 
   float q[64];
-  if (qvalid) {
-    load_row_half(Q + (long)b * q_bs + (long)qrow * q_rs, h, q);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) q[i] = 0.f;
-  }
-  float* srow = smap + ((long)b * N + (qvalid ? qrow : 0)) * ld + 4 * h;
-  float* tokrow = tok + ((long)b * N + (qvalid ? qrow : 0)) * nt;
+  load_row_half(Q + (long)b * q_bs + (long)qrow * q_rs, h, q);
+  float* srow = smap + ((long)b * N + qrow) * ld + 4 * h;
+  float* tokrow = tok + ((long)b * N + qrow) * nt;
   float m = kNegInf, l = 0.f;
 
   const int ntiles = (NK + kTile - 1) / kTile;
@@ -113,21 +110,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
   f32x16 s_nxt;
 
   int cur = 0;  // LDS buffer of tile t
-  for (int t = 0; t < ntiles; ++t) {
+  const int n_main = max(min(N / kTile, ntiles - 2), 0);  // full point tiles that still have a tile t+2 to stage
+  int t = 0;
+  for (; t < n_main; ++t) {
     const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
     const int j0 = t * kTile;
-    if (ABL != 2 && t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
-    if (j0 + kTile > N)  // tile holds token keys and/or padding (wave-uniform)
-      stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
-    else
-      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, qvalid, j0, N, NK, tokrow, m, l);
-    if (ABL != 2 && t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
+    if (ABL != 2) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
+    stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, j0, N, NK, tokrow, m, l);
+    if (ABL != 2) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
+    __syncthreads();
+    s_cur = s_nxt;
+    cur = nxt;
+  }
+  for (; t < ntiles; ++t) {  // the last point tiles, token keys and padding
+    const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
+    const int j0 = t * kTile;
+    if (t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
+    stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, j0, N, NK, tokrow, m, l);
+    if (t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
     __syncthreads();
     s_cur = s_nxt;
     cur = nxt;
   }
   const float ltot = l + wave_xor32(l);
-  if (qvalid && h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+  if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
 }
 
 // ------------------------------------------------------------------------------------------------
