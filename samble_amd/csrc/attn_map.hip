@@ -31,11 +31,21 @@ namespace samble {
 // issues in order, so ~14 VALU cycles per MFMA are free).  Without it both waves of a SIMD sit in
 // their softmax phase at the same time (they are barrier-locked) and the pipe idles ~30% of a tile.
 // K tiles are triple-buffered: tile t+1 is resident while tile t+2 is being staged.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SAMBLE_MAP_STORE_AUX
+#define SAMBLE_MAP_STORE_AUX 0
+#endif
+constexpr int kStoreAux = SAMBLE_MAP_STORE_AUX;  // cache policy of the map stores: 0 plain, 2 nt, 16 sc1, 18 nt sc1
+constexpr int kStPad = 36;  // row stride (floats) of a wave's 32x32 transpose tile: 16-byte aligned, 9 x 16 B (odd)
+
 template <bool TAIL, int ABL>
 __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo, int h, const float (&q)[64],
-                                           f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ srow_t,
-                                           int j0, int N, int NK, float* __restrict__ tokrow, float& m, float& l) {
+                                           f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ xt,
+                                           float* __restrict__ gdst, __amdgpu_buffer_rsrc_t rsrc,
+                                           const int (&roff)[4], int j0, int N, int NK,
+                                           float* __restrict__ tokrow, float& m, float& l) {
   const f32x4* lp = reinterpret_cast<const f32x4*>(Kn + lo * kLdsPad + 64 * h);
+  const int lane = lo + 32 * h;
   float mt = kNegInf, ps = 0.f;
   s_nxt = zero16();
 #pragma unroll
@@ -43,7 +53,7 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
     const f32x4 a = lp[q4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) s_nxt = mfma32(a[e], q[4 * q4 + e], s_nxt);
-    if (q4 < 4) {  // scale, tile max and the 16-byte map store of registers 4*q4 .. 4*q4+3
+    if (q4 < 4) {  // scale, tile max; registers 4*q4 .. 4*q4+3 (4 consecutive keys of this lane's row) -> transpose tile
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * q4 + e;
@@ -56,18 +66,32 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
         s_cur[r] = v;
         mt = fmaxf(mt, v);
       }
-      if (ABL != 1) {
-        const f32x4 o = {s_cur[4 * q4], s_cur[4 * q4 + 1], s_cur[4 * q4 + 2], s_cur[4 * q4 + 3]};
-        *reinterpret_cast<f32x4*>(srow_t + 8 * q4) = o;
-      }
+      const f32x4 o = {s_cur[4 * q4], s_cur[4 * q4 + 1], s_cur[4 * q4 + 2], s_cur[4 * q4 + 3]};
+      *reinterpret_cast<f32x4*>(xt + lo * kStPad + 8 * q4 + 4 * h) = o;
     } else if (q4 == 4) {  // running max (branch-free rescale of the running sum)
       mt = fmaxf(mt, wave_xor32(mt));
       const float mnew = fmaxf(m, mt);
       l *= __expf(m - mnew);
       m = mnew;
-    } else if (q4 < 13) {  // two exps per step
-      ps += __expf(s_cur[2 * (q4 - 5)] - m);
-      ps += __expf(s_cur[2 * (q4 - 5) + 1] - m);
+    } else if (q4 == 5) {
+      // map store, row-major: 8 lanes cover one row's 32 keys (128 contiguous bytes), 8 rows per
+      // instruction.  Written straight from the accumulator layout (lane = row, 16 bytes each) a store
+      // instruction touches 64 different lines and the L1's per-line write requests delayed the K-tile
+      // loads of the whole CU (20% of the kernel).
+      if (ABL != 1) {
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+          const int row = (lane >> 3) + 8 * k8;
+          const f32x4 o = *reinterpret_cast<const f32x4*>(xt + row * kStPad + 4 * (lane & 7));
+          if (ABL == 3) *reinterpret_cast<f32x4*>(gdst - j0 + roff[k8]) = o;  // same lines every tile
+          else if (ABL == 4) *reinterpret_cast<f32x4*>(gdst - j0 + (roff[k8] / 4) % 8192 * 4) = o;  // compact scratch
+          else if (kStoreAux == 0) *reinterpret_cast<f32x4*>(gdst + roff[k8]) = o;
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsrc, (roff[k8] + j0) * 4, 0, kStoreAux);
+        }
+      }
+    } else if (q4 < 14) {  // two exps per step
+      ps += __expf(s_cur[2 * (q4 - 6)] - m);
+      ps += __expf(s_cur[2 * (q4 - 6) + 1] - m);
     }
   }
   l += ps;
@@ -95,7 +119,9 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
 
   float q[64];
   load_row_half(Q + (long)b * q_bs + (long)qrow * q_rs, h, q);
-  float* srow = smap + ((long)b * N + qrow) * ld + 4 * h;
+  // rows of this wave, clamped like qrow: row index of the wave's first row, then min() per row
+  const int row0 = chunk * (32 * NW) + wave * 32;
+  float* xt = smem + 3 * kBuf + wave * (kTile * kStPad);
   float* tokrow = tok + ((long)b * N + qrow) * nt;
   float m = kNegInf, l = 0.f;
 
@@ -109,24 +135,58 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
   f32x16 s_cur = mma_rows_x_regs(smem, kLdsPad, lo, h, q, zero16());
   f32x16 s_nxt;
 
+  // destination of the transposed store: lane L writes rows (L>>3)+8k of the wave's 32; rows past N-1
+  // carry row N-1's values (clamped q above) and are folded onto row N-1
+  int roff[4];
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) roff[k8] = min(row0 + (lane >> 3) + 8 * k8, N - 1) * ld + 4 * (lane & 7);
+  float* gdst = smap + (long)b * N * ld;
+  // the same cloud as a buffer resource (wave-uniform by construction), for stores with a cache policy
+  const unsigned long long gaddr = reinterpret_cast<unsigned long long>(gdst);
+  const unsigned ghi = (unsigned)__builtin_amdgcn_readfirstlane((int)(gaddr >> 32));
+  const unsigned glo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gaddr);
+  float* gu = reinterpret_cast<float*>(((unsigned long long)ghi << 32) | (unsigned long long)glo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(gu, 0, (unsigned)((long)N * ld * 4), 0x00020000);
   int cur = 0;  // LDS buffer of tile t
-  const int n_main = max(min(N / kTile, ntiles - 2), 0);  // full point tiles that still have a tile t+2 to stage
+  // K tiles are fetched TWO iterations ahead (registers kr2 / kr, alternating) and committed to LDS one
+  // iteration before use: with the 538 MB map streaming out through the L2 the tile loads take longer
+  // than one iteration (tools/ablate_attn_stats.py), and a stalled tile stalls all 8 waves at the barrier.
+  TileRegsT<64 * NW> kr2;
+  tile_load_issue(kr, Kb, k_rs, 2 * kTile, NK, tid);  // tile 2 in flight
+  // main loop: pairs of full point tiles whose prefetches (up to tile t+4) are full tiles too
+  const int n_main = max(min(N / kTile, ntiles - 4), 0) & ~1;
   int t = 0;
-  for (; t < n_main; ++t) {
-    const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
-    const int j0 = t * kTile;
-    if (ABL != 2) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
-    stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, j0, N, NK, tokrow, m, l);
-    if (ABL != 2) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
-    __syncthreads();
-    s_cur = s_nxt;
-    cur = nxt;
+  for (; t < n_main; t += 2) {
+    {
+      const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
+      const int j0 = t * kTile;
+      if (ABL != 2) tile_load_issue(kr2, Kb, k_rs, j0 + 3 * kTile, NK, tid);
+      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      if (ABL != 2) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
+      __syncthreads();
+      s_cur = s_nxt;
+      cur = nxt;
+    }
+    {
+      const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
+      const int j0 = (t + 1) * kTile;
+      if (ABL != 2) tile_load_issue(kr, Kb, k_rs, j0 + 3 * kTile, NK, tid);
+      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      if (ABL != 2) tile_store_lds(kr2, smem + nn2 * kBuf, kLdsPad, tid);
+      __syncthreads();
+      s_cur = s_nxt;
+      cur = nxt;
+    }
   }
-  for (; t < ntiles; ++t) {  // the last point tiles, token keys and padding
+  const int t_end = t;
+  for (; t < ntiles; ++t) {  // the last point tiles, token keys and padding: fetch distance 1 again
     const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
     const int j0 = t * kTile;
-    if (t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);
-    stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, srow + j0, j0, N, NK, tokrow, m, l);
+    if (t > t_end && t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);  // t_end + 2 is in kr already
+    if (j0 + kTile > N)
+      stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+    else
+      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
     if (t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
     __syncthreads();
     s_cur = s_nxt;
@@ -218,8 +278,9 @@ extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, co
                                         int N, int nt, float scale, float* smap, int ld, float* lse, float* tok,
                                         hipStream_t stream) {
   constexpr int NW = 8;
-  const size_t lds = 3 * kTile * kLdsPad * sizeof(float);
+  const size_t lds = (3 * kTile * kLdsPad + NW * kTile * kStPad) * sizeof(float);
   auto kern = g_stats_ablate == 1 ? attn_stats_kernel<NW, 1> : g_stats_ablate == 2 ? attn_stats_kernel<NW, 2>
+            : g_stats_ablate == 3 ? attn_stats_kernel<NW, 3> : g_stats_ablate == 4 ? attn_stats_kernel<NW, 4>
                                                                                      : attn_stats_kernel<NW, 0>;
   hipLaunchKernelGGL(kern, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs, q_rs, K, k_bs,
                      k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);

@@ -16,7 +16,8 @@ def t(fn, it=20):
     return a.elapsed_time(b) / it
 lib = _lib.load()
 flops = 2 * N * (N + nt) * D * B
-for mode, name in ((0, "real kernel"), (1, "map stores skipped"), (2, "tile staging skipped")):
+for mode, name in ((0, "real kernel"), (1, "map stores skipped"), (2, "tile staging skipped"),
+                   (3, "stores hit the same lines each tile"), (4, "stores into a compact 128 KB scratch")):
     lib.samble_debug_ablate(1, mode)
     ms = t(lambda: ops.stage_attn_stats(q, k, N, nt))
     print(f"{name:28s} {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s")
