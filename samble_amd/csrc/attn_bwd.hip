@@ -177,7 +177,6 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
 constexpr int kFusedTile = 2 * kTile * kLdsPad + 2 * kTile;  // Q tile, dO tile, lse[32], delta[32]
 constexpr int kFusedLdsFloats = 2 * kFusedTile + 2 * kTile * kLdsPad;
 
-template <bool MAP>
 __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restrict__ Qs, const float* __restrict__ dO,
                                                            const float* __restrict__ lse_s,
                                                            const float* __restrict__ delta,
@@ -185,12 +184,9 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ V, long v_bs, long v_rs, int N,
                                                            int M, float scale, float* __restrict__ dK, long dk_bs,
                                                            long dk_rs, float* __restrict__ dV, long dv_bs, long dv_rs,
-                                                           float* __restrict__ slab, int nslab,
-                                                           const float* __restrict__ smap, int ld,
-                                                           const long long* __restrict__ idx) {
+                                                           float* __restrict__ slab, int nslab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dsbuf = smem + 2 * kFusedTile;  // 2 x [32][kLdsPad]
-  int* sel = reinterpret_cast<int*>(dsbuf + 2 * kTile * kLdsPad);  // MAP: the cloud's M sampled row ids
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
@@ -200,27 +196,16 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
   const float* Qb = Qs + (long)b * M * 128;
   const float* Gb = dO + (long)b * M * 128;
 
-  float kreg[MAP ? 1 : 64], vreg[64], kcol[64];
+  float kreg[64], vreg[64], kcol[64];
   if (jvalid) {
-    if (!MAP) load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, reinterpret_cast<float(&)[64]>(kreg));
+    load_row_half(K + (long)b * k_bs + (long)j * k_rs, h, kreg);
     load_row_half(V + (long)b * v_bs + (long)j * v_rs, h, vreg);
   } else {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
-      if (!MAP) kreg[i] = 0.f;
+      kreg[i] = 0.f;
       vreg[i] = 0.f;
     }
-  }
-  // MAP: S is not recomputed; this lane's key column of the sampled rows is read from the logit map
-  // (for register r: row sel[i0 + crow(r,h)], column j; the 32 lanes of a half read one 128-byte run)
-  const float* scol = MAP ? smap + (long)b * N * ld + min(j, ld - 1) : nullptr;
-  float sv[16], sn[16];
-  auto load_s = [&](int i0, float (&dst)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[r] = scol[sel[min(i0 + crow(r, h), M - 1)] * ld];
-  };
-  if (MAP) {
-    for (int i = tid; i < M; i += 256) sel[i] = (int)idx[(long)b * M + i];
   }
   // this wave's channel slice of the workgroup's 128 K rows: lane (d, h) holds K[key 64h+kk][32w + d]
 #pragma unroll
@@ -255,38 +240,26 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
   issue(0);
   commit(smem);
   __syncthreads();
-  if (MAP) load_s(0, sv);
 
   float* myslab = slab + ((long)b * nslab + chunk) * M * 128;
   for (int t = 0; t <= ntiles; ++t) {
     float* cur = smem + (t & 1) * kFusedTile;
     float* nxt = smem + ((t & 1) ^ 1) * kFusedTile;
     const int i0 = t * kTile;
-    if (t + 1 < ntiles) {
-      issue(i0 + kTile);
-      if (MAP) load_s(i0 + kTile, sn);
-    }
+    if (t + 1 < ntiles) issue(i0 + kTile);
     if (t < ntiles) {
       const float* Qt = cur;
       const float* Gt = cur + kTile * kLdsPad;
       const float* Lt = cur + 2 * kTile * kLdsPad;
       const float* Dt = Lt + kTile;
       float* dsw = dsbuf + (t & 1) * kTile * kLdsPad + 32 * wave + lo;
-      f32x16 s;
-      if (MAP) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = sv[r];
-      } else {
-        s = mma_rows_x_regs(Qt, kLdsPad, lo, h, reinterpret_cast<const float(&)[64]>(kreg), zero16());  // S (queries x keys)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= scale;
-      }
+      f32x16 s = mma_rows_x_regs(Qt, kLdsPad, lo, h, kreg, zero16());   // S  (queries x keys)
       f32x16 dp = mma_rows_x_regs(Gt, kLdsPad, lo, h, vreg, zero16());  // dP
       const bool tail = (i0 + kTile > M);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ir = crow(r, h);
-        float p = __expf(s[r] - Lt[ir]);
+        float p = __expf(s[r] * scale - Lt[ir]);
         if (tail && (i0 + ir >= M)) p = 0.f;
         const float ds = p * (dp[r] - Dt[ir]) * scale;
         dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
@@ -304,13 +277,7 @@ __global__ __launch_bounds__(256, 1) void bwd_fused_kernel(const float* __restri
         if (m < M) myslab[(long)m * 128 + 32 * wave + lo] = dqa[r];
       }
     }
-    if (t + 1 < ntiles) {
-      commit(nxt);
-      if (MAP) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = sn[r];
-      }
-    }
+    if (t + 1 < ntiles) commit(nxt);
     __syncthreads();
   }
   if (jvalid) {
@@ -555,6 +522,10 @@ __global__ __launch_bounds__(256, 1) void bwd_dkdv_kernel(const float* __restric
 
 using namespace samble;
 
+extern "C" int samble_launch_bwd_rows(const float*, const float*, const float*, const float*, const float*, long, long,
+                                      const float*, long, long, int, int, int, float, float*, long, long, float*, long,
+                                      long, float*, int, const float*, int, const long long*, hipStream_t);
+
 static int g_bwd_split = 0;  // debug: 1 = the two-kernel backward (bwd_dq + bwd_dkdv) for A/B checks
 extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_split(int on) { g_bwd_split = on; }
 
@@ -581,11 +552,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -593,7 +561,6 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   const int nparts = (M + 31) / 32;
   const int kb = (N + 127) / 128;
   const bool fused = !g_bwd_split || smap;
-  if (smap && lds_fused + (size_t)M * 4 > 160 * 1024) return -22;
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
@@ -601,14 +568,14 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
                      fused ? kb + 1 : 0, kb);
   if (fused) {
-    if (smap)
-      hipLaunchKernelGGL(bwd_fused_kernel<true>, dim3(kb, B), dim3(256), lds_fused + (size_t)M * 4, stream, Qs, dOb,
-                         lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab,
-                         kb + 1, smap, ld, idx);
-    else
-      hipLaunchKernelGGL(bwd_fused_kernel<false>, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K,
-                         k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab, kb + 1,
-                         (const float*)nullptr, 0, idx);
+    if (smap) {
+      const int rc = samble_launch_bwd_rows(Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, B, N, M, scale, dK, dk_bs,
+                                            dk_rs, dV, dv_bs, dv_rs, slab, kb + 1, smap, ld, idx, stream);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(bwd_fused_kernel, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs,
+                         V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, slab, kb + 1);
+    }
     hipLaunchKernelGGL(bwd_dq_reduce_kernel, dim3((M * 32 + 255) / 256, B), dim3(256), 0, stream, slab, kb + 1, idx, M,
                        dQ, dq_bs, dq_rs);
   } else {
