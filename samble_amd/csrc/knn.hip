@@ -385,10 +385,14 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
 // test hooks: 1 forces the round-1 two-kernel path (key matrix through HBM) for A/B checks
 static bool g_force_unfused = false;
 static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
+static bool g_no_stream = false;      // on = 3: the non-pipelined fused kernel of this file instead of knn_stream.hip
 extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
   g_force_unfused = on == 1;
   g_ablate_select = on == 2;
+  g_no_stream = on == 3;
 }
+extern "C" int samble_launch_knn_stream(const float*, long, int, const float*, long, int, int, int, int, const float*,
+                                        int*, float*, hipStream_t);
 
 template <int C, int KN>
 static int launch_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
@@ -492,7 +496,9 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   if (fused) {
     hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
     int rc = 0;
-    if (C == 128 && K == 32) rc = launch_fused<128, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    if (!g_no_stream && !g_ablate_select)
+      rc = samble_launch_knn_stream(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, knorm, idx_out, kout, stream);
+    else if (C == 128 && K == 32) rc = launch_fused<128, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
     else if (C == 128) rc = launch_fused<128, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
     else if (K == 32) rc = launch_fused<64, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
     else rc = launch_fused<64, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);

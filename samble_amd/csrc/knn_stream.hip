@@ -1,0 +1,260 @@
+// Fused Gram + top-K kNN, software-pipelined (reference utils/ops.py:35-43: cdist + topk).
+//
+// Same algorithm and the same exact (w, index) ordering as knn_fused_kernel (knn.hip) -- the
+// accumulator of lane (i, h) holds G[j][i] - |b_j|^2/2 for 16 keys of query i, w = |a_i|^2/2 - acc
+// is the ranking key, per-lane sorted K-lists of packed doubles (w bits | index), bound =
+// min(own K-th, max of the two halves' ceil(K/2)-th), halves merged at the end -- but scheduled so
+// that the matrix pipe does not wait for the selection:
+//   * the 65 MFMAs of tile t+1 are issued with the candidate filter of tile t AND a few list
+//     insertions placed between them (the wave issues in order; an MFMA holds the pipe for 64 cycles,
+//     so ~14 VALU cycles per MFMA are free).  The filter is branch-free (unconditional ring-buffer
+//     write, tail += pass), so a tile is one basic block;
+//   * candidates wait in a per-lane LDS ring; kInline insertions per tile keep up with the arrival
+//     rate after the first few tiles, a workgroup-wide vote triggers a full drain when a ring could
+//     overflow (the early tiles, where every key is a candidate);
+//   * workgroup = 8 waves = 256 queries (one per CU, two waves per SIMD): a cloud's key tiles are
+//     staged half as often as with 128-query workgroups; tiles are triple-buffered.
+#include <type_traits>
+
+#include "samble_dev.h"
+
+namespace samble {
+
+constexpr int kCap = 32;     // ring slots per lane (power of two); a tile adds at most 16
+constexpr int kInline = 4;   // list insertions issued under each tile's MFMAs
+
+template <int KN>
+__device__ __forceinline__ void insert_packed2(double (&L)[KN], double x) {
+#pragma unroll
+  for (int s = KN - 1; s > 0; --s) L[s] = fmin(L[s], fmax(L[s - 1], x));
+  L[0] = fmin(L[0], x);
+}
+
+__device__ __forceinline__ double pack_wj2(float w, unsigned int j) {
+  return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
+}
+
+template <int C, int KN, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                                const float* __restrict__ xk, long k_bs, int Nk,
+                                                                const float* __restrict__ knorm,
+                                                                int* __restrict__ idx_out, float* __restrict__ d2_out) {
+  constexpr int H = C / 2;            // MFMA steps; lane half h consumes channels H*h .. H*h+H-1
+  constexpr int TILE = C * 32;        // floats per key tile, [channel][32 keys]
+  constexpr int NT = 64 * NW;
+  constexpr int LOADS = TILE / 4 / NT;
+  constexpr int KH = (KN + 1) / 2;
+  static_assert(LOADS >= 1 && TILE % (4 * NT) == 0, "tile must split evenly over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem;                               // 3 x TILE
+  float* bns = smem + 3 * TILE;                      // 3 x 32 key norms
+  float* qw = bns + 96;                              // kCap x NT
+  unsigned short* qj = reinterpret_cast<unsigned short*>(qw + kCap * NT);
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int i = chunk * (32 * NW) + wave * 32 + lo;
+  const bool ivalid = i < Nq;
+  const float* xkb = xk + (long)b * k_bs;
+  const float* knb = knorm + (long)b * Nk;
+
+  float q[H];
+  float an = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < H; ++kk) {
+    q[kk] = xq[(long)b * q_bs + (long)(H * h + kk) * Nq + min(i, Nq - 1)];
+    an = fmaf(q[kk], q[kk], an);
+  }
+  an += wave_xor32(an);
+  const float half_an = 0.5f * an;
+
+  double L[KN];
+#pragma unroll
+  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
+  float thr = __builtin_huge_valf();
+  int head = 0, tail = 0;  // ring positions of this lane (monotonic; slot = position & (kCap-1))
+
+  const bool vec = (Nk & 3) == 0;
+  f32x4 stage[LOADS];
+  float stage_bn = 0.f;
+  auto issue = [&](int j0, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;  // whole tile inside the key set and 16-byte aligned rows
+#pragma unroll
+    for (int it = 0; it < LOADS; ++it) {
+      const int e = tid + NT * it;
+      const int c = e >> 3, p4 = (e & 7) * 4;
+      const float* src = xkb + (long)c * Nk + j0 + p4;
+      if (FULL) {
+        stage[it] = *reinterpret_cast<const f32x4*>(src);
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec && j0 + p4 + 3 < Nk) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (j0 + p4 + u < Nk) v[u] = src[u];
+        }
+        stage[it] = v;
+      }
+    }
+    const int jn = j0 + (tid & 31);
+    stage_bn = FULL ? knb[jn] : ((jn < Nk) ? knb[jn] : 0.f);
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < LOADS; ++it) {
+      const int e = tid + NT * it;
+      *reinterpret_cast<f32x4*>(tiles + buf * TILE + (e >> 3) * 32 + (e & 7) * 4) = stage[it];
+    }
+    bns[buf * 32 + (tid & 31)] = stage_bn;  // every wave writes the same 32 values
+  };
+  auto product = [&](int buf) {
+    const float* xs = tiles + buf * TILE + (H * h) * 32 + lo;
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) acc = mfma32(xs[kk * 32], q[kk], acc);
+    return mfma32(h == 0 ? bns[buf * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
+  };
+  auto insert_step = [&]() {
+    const bool valid = head < tail;
+    const int slot = (head & (kCap - 1)) * NT + tid;
+    const double xd = valid ? pack_wj2(qw[slot], qj[slot]) : __builtin_huge_val();
+    insert_packed2<KN>(L, xd);
+    head += valid ? 1 : 0;
+  };
+  auto update_thr = [&]() {
+    const double mid = L[KH - 1];
+    const double pmid = __shfl_xor(mid, 32, 64);
+    const double lim = fmin(L[KN - 1], fmax(mid, pmid));
+    thr = (float)lim;  // the index bits are far below half a float ulp: this is exactly lim's w
+  };
+  auto full_drain = [&]() {
+    while (__any(head < tail)) insert_step();
+    update_thr();
+  };
+
+  const int ntiles = (Nk + 31) / 32;
+  using T = std::true_type;
+  using F = std::false_type;
+  issue(0, F{});
+  commit(0);
+  if (ntiles > 1) {
+    issue(32, F{});
+    commit(1);
+  }
+  __syncthreads();
+  f32x16 acc_cur = product(0);
+  f32x16 acc_nxt = zero16();
+
+  // one tile: MFMAs of tile t+1 (if any) with the filter of tile t and kInline insertions between them
+  auto body = [&](int t, int cur, auto next_c, auto fast_c) {
+    constexpr bool NEXT = decltype(next_c)::value, FAST = decltype(fast_c)::value;
+    const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
+    const int j0 = t * 32;
+    if (FAST) issue(j0 + 64, T{});
+    else if (t + 2 < ntiles) issue(j0 + 64, F{});
+    const float* xs = tiles + nxt * TILE + (H * h) * 32 + lo;
+    acc_nxt = zero16();
+    constexpr int kStride = (H - 16) / kInline;  // insertions spread over the MFMAs after the filter
+#pragma unroll
+    for (int kk = 0; kk < H; ++kk) {
+      if (NEXT) acc_nxt = mfma32(xs[kk * 32], q[kk], acc_nxt);
+      if (kk < 16) {  // candidate filter of accumulator register kk
+        const int j = j0 + crow(kk, h);
+        const float w = fmaxf(half_an - acc_cur[kk], 0.f);
+        bool pass = w <= thr;
+        if (!FAST) pass = pass && (j < Nk);
+        const int slot = (tail & (kCap - 1)) * NT + tid;
+        qw[slot] = w;
+        qj[slot] = (unsigned short)j;
+        tail += pass ? 1 : 0;
+      } else if ((kk - 16) % kStride == 0 && (kk - 16) / kStride < kInline) {
+        insert_step();
+      }
+    }
+    if (NEXT) acc_nxt = mfma32(h == 0 ? bns[nxt * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc_nxt);
+    update_thr();
+    if (FAST || t + 2 < ntiles) commit(nn2);
+    // the tile barrier doubles as the overflow vote: a ring may take 16 more entries next tile
+    if (__syncthreads_or(tail - head > kCap - 16)) full_drain();
+    acc_cur = acc_nxt;
+  };
+  // fast iterations: tile t is a full tile and so is tile t+2 (unguarded loads, no index checks)
+  const int n_fast = vec ? max(Nk / 32 - 2, 0) : 0;
+  int t = 0, cur = 0;
+  for (; t < n_fast; ++t) {
+    body(t, cur, T{}, T{});
+    cur = (cur == 2) ? 0 : cur + 1;
+  }
+  for (; t < ntiles; ++t) {
+    if (t + 1 < ntiles) body(t, cur, T{}, F{});
+    else body(t, cur, F{}, F{});
+    cur = (cur == 2) ? 0 : cur + 1;
+  }
+  full_drain();
+
+  // merge the two halves of every query through LDS (the whole dynamic region is free now)
+  double* mg = reinterpret_cast<double*>(smem);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < KN; ++s) mg[s * NT + tid] = L[s];
+  __syncthreads();
+  if (h == 0 && ivalid) {
+    int pa = 0, pb = 0;
+    double va = mg[tid], vb = mg[tid + 32];
+    int* io = idx_out + ((long)b * Nq + i) * KN;
+    float* dout = d2_out ? d2_out + ((long)b * Nq + i) * KN : nullptr;
+    for (int k = 0; k < KN; ++k) {
+      const bool take = va <= vb;
+      const double o = take ? va : vb;
+      io[k] = (int)(__double_as_longlong(o) & 0x1FFFFFFFll);
+      if (dout) dout[k] = 2.f * (float)o;
+      if (take) {
+        ++pa;
+        va = (pa < KN) ? mg[pa * NT + tid] : __builtin_huge_val();
+      } else {
+        ++pb;
+        vb = (pb < KN) ? mg[pb * NT + tid + 32] : __builtin_huge_val();
+      }
+    }
+  }
+}
+
+template <int C, int KN, int NW>
+static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                         const float* knorm, int* idx, float* d2, hipStream_t s) {
+  constexpr int NT = 64 * NW;
+  size_t lds = (size_t)(3 * C * 32 + 96 + kCap * NT) * 4 + (size_t)kCap * NT * 2;
+  const size_t merge = (size_t)KN * NT * 8;
+  if (merge > lds) lds = merge;
+  auto kern = knn_stream_kernel<C, KN, NW>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((Nq + 32 * NW - 1) / (32 * NW), B), dim3(NT), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm,
+                     idx, d2);
+  return (int)hipGetLastError();
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+// C in {64,128}, K in {16,32}; 256-query workgroups when they still fill the chip, else 128-query ones
+extern "C" int samble_launch_knn_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                                        int C, int K, const float* knorm, int* idx, float* d2, hipStream_t s) {
+  const bool big = (long)B * ((Nq + 255) / 256) >= 200;
+#define SAMBLE_KS(CC, KK)                                                                                       \
+  if (C == CC && K == KK)                                                                                       \
+    return big ? launch_stream<CC, KK, 8>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s)                     \
+               : launch_stream<CC, KK, 4>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+  SAMBLE_KS(128, 32)
+  SAMBLE_KS(128, 16)
+  SAMBLE_KS(64, 32)
+  SAMBLE_KS(64, 16)
+#undef SAMBLE_KS
+  return -22;
+}
