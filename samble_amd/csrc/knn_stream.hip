@@ -21,7 +21,8 @@
 namespace samble {
 
 constexpr int kCap = 32;     // ring slots per lane (power of two); a tile adds at most 16
-constexpr int kInline = 4;   // list insertions issued under each tile's MFMAs
+int g_knn_keep = 6;  // drain policy (see full_drain)
+constexpr int kInlineDefault = 0;   // list insertions issued under each tile's MFMAs
 
 template <int KN>
 __device__ __forceinline__ void insert_packed2(double (&L)[KN], double x) {
@@ -34,11 +35,12 @@ __device__ __forceinline__ double pack_wj2(float w, unsigned int j) {
   return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
 }
 
-template <int C, int KN, int NW>
+template <int C, int KN, int NW, int kInline = kInlineDefault>
 __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __restrict__ xq, long q_bs, int Nq,
                                                                 const float* __restrict__ xk, long k_bs, int Nk,
                                                                 const float* __restrict__ knorm,
-                                                                int* __restrict__ idx_out, float* __restrict__ d2_out) {
+                                                                int* __restrict__ idx_out, float* __restrict__ d2_out,
+                                                                int g_keep) {
   constexpr int H = C / 2;            // MFMA steps; lane half h consumes channels H*h .. H*h+H-1
   constexpr int TILE = C * 32;        // floats per key tile, [channel][32 keys]
   constexpr int NT = 64 * NW;
@@ -131,8 +133,14 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
     const double lim = fmin(L[KN - 1], fmax(mid, pmid));
     thr = (float)lim;  // the index bits are far below half a float ulp: this is exactly lim's w
   };
-  auto full_drain = [&]() {
-    while (__any(head < tail)) insert_step();
+  // Lanes insert in lockstep, so a step is only well used while most lanes still have candidates:
+  // drain down to `keep` entries in the fullest ring, not to empty (the rest waits for the next vote).
+  auto full_drain = [&](int keep) {
+    if (keep < 0) {  // timing ablation: no insertions at all (wrong results)
+      head = tail;
+      return;
+    }
+    while (__any(tail - head > keep)) insert_step();
     update_thr();
   };
 
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
     else if (t + 2 < ntiles) issue(j0 + 64, F{});
     const float* xs = tiles + nxt * TILE + (H * h) * 32 + lo;
     acc_nxt = zero16();
-    constexpr int kStride = (H - 16) / kInline;  // insertions spread over the MFMAs after the filter
+    constexpr int kStride = kInline ? (H - 16) / (kInline ? kInline : 1) : H;  // insertions spread over the MFMAs after the filter
 #pragma unroll
     for (int kk = 0; kk < H; ++kk) {
       if (NEXT) acc_nxt = mfma32(xs[kk * 32], q[kk], acc_nxt);
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
         qw[slot] = w;
         qj[slot] = (unsigned short)j;
         tail += pass ? 1 : 0;
-      } else if ((kk - 16) % kStride == 0 && (kk - 16) / kStride < kInline) {
+      } else if (kInline && (kk - 16) % kStride == 0 && (kk - 16) / kStride < kInline) {
         insert_step();
       }
     }
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
     update_thr();
     if (FAST || t + 2 < ntiles) commit(nn2);
     // the tile barrier doubles as the overflow vote: a ring may take 16 more entries next tile
-    if (__syncthreads_or(tail - head > kCap - 16)) full_drain();
+    if (__syncthreads_or(tail - head > kCap - 16)) full_drain(g_keep);
     acc_cur = acc_nxt;
   };
   // fast iterations: tile t is a full tile and so is tile t+2 (unguarded loads, no index checks)
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
     else body(t, cur, F{}, F{});
     cur = (cur == 2) ? 0 : cur + 1;
   }
-  full_drain();
+  full_drain(g_keep < 0 ? -1 : 0);
 
   // merge the two halves of every query through LDS (the whole dynamic region is free now)
   double* mg = reinterpret_cast<double*>(smem);
@@ -223,19 +231,19 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
   }
 }
 
-template <int C, int KN, int NW>
+template <int C, int KN, int NW, int INL = kInlineDefault>
 static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                          const float* knorm, int* idx, float* d2, hipStream_t s) {
   constexpr int NT = 64 * NW;
   size_t lds = (size_t)(3 * C * 32 + 96 + kCap * NT) * 4 + (size_t)kCap * NT * 2;
   const size_t merge = (size_t)KN * NT * 8;
   if (merge > lds) lds = merge;
-  auto kern = knn_stream_kernel<C, KN, NW>;
+  auto kern = knn_stream_kernel<C, KN, NW, INL>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((Nq + 32 * NW - 1) / (32 * NW), B), dim3(NT), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm,
-                     idx, d2);
+                     idx, d2, g_knn_keep);
   return (int)hipGetLastError();
 }
 
@@ -243,10 +251,25 @@ static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, lo
 
 using namespace samble;
 
+namespace samble {
+int g_knn_inline = -1;
+}
+
 // C in {64,128}, K in {16,32}; 256-query workgroups when they still fill the chip, else 128-query ones
 extern "C" int samble_launch_knn_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                                         int C, int K, const float* knorm, int* idx, float* d2, hipStream_t s) {
   const bool big = (long)B * ((Nq + 255) / 256) >= 200;
+  if (g_knn_inline >= 0 && C == 128 && K == 32) {  // experiment hook
+    switch (g_knn_inline) {
+      case 0: return launch_stream<128, 32, 8, 0>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      case 1: return launch_stream<128, 32, 8, 1>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      case 2: return launch_stream<128, 32, 8, 2>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      case 10: return launch_stream<128, 32, 4, 0>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      case 12: return launch_stream<128, 32, 4, 2>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      case 14: return launch_stream<128, 32, 4, 4>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
+      default: break;
+    }
+  }
 #define SAMBLE_KS(CC, KK)                                                                                       \
   if (C == CC && K == KK)                                                                                       \
     return big ? launch_stream<CC, KK, 8>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s)                     \
