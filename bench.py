@@ -54,6 +54,23 @@ def time_region(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
+KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4}
+
+
+def kernel_ms(kernel, fn, iters=5):
+    """Mean duration (ms) of one named kernel inside fn(), from the library's own HIP events."""
+    from samble_amd import _lib
+    lib = _lib.load()
+    fn()
+    lib.samble_debug_time_kernel(KERNEL_IDS[kernel])
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    ms = float(lib.samble_debug_kernel_ms())
+    lib.samble_debug_time_kernel(0)
+    return ms
+
+
 def kernel_breakdown(mod, x, noise, g, iters=5):
     """Per-stage device time (ms) of one step, each stage timed alone with events."""
     import math
@@ -182,6 +199,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # HIP events around every launch of the dominant kernel (bwd_rows) during the timed steps, recorded
+    # by the library on the stream it launches on (two event records per step: no host sync, no effect
+    # on the timed region); read back after the final synchronize
+    from samble_amd import _lib
+    lib = _lib.load()
+    lib.samble_debug_time_kernel(KERNEL_IDS["bwd_rows"])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -192,6 +215,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    dominant_ms = float(lib.samble_debug_kernel_ms())
+    lib.samble_debug_time_kernel(0)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,37 +246,48 @@ def main():
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
-        if not args.no_breakdown:
-            noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
-            br = kernel_breakdown(mod, x, noise, g)
-            result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
-            # dominant kernel group: flash attention forward (one launch)
-            alg = (fl["qk"] + fl["av"]) * B_PER_GPU
-            ach = alg / ((br["attn_stats"] + br["attn_rows"]) * 1e-3) / 1e12
-            # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary (profiles/*_pmc.json:
-            # (2*FETCH_SIZE + WRITE_SIZE)*1024, collected in their own runs as the counters require)
-            traffic = None
+        # dominant kernel: bwd_rows (attention backward over the N point keys: dP, dV, dK, dQ = 4 products of
+        # 2*M*N*D flop per cloud); duration = mean over the timed steps' launches, HIP events on its stream
+        def pmc_traffic(kernel):
+            # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary
+            # (profiles/*_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require)
             try:
                 import glob
                 pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]))
-                traffic = pmc["kernels"]["samble::attn_fwd_kernel"]["traffic_bytes_per_launch"]
+                return pmc["kernels"][kernel]["traffic_bytes_per_launch"]
             except Exception:
-                pass
-            result["roofline"] = {"kernel": "attn_fwd_kernel", "bound": "mfma", "achieved": round(ach, 2),
-                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                                  "algorithmic_flops_per_launch": alg,
-                                  "executed_flops_per_launch": 2 * fl["qk"] * B_PER_GPU}
-            bwd_alg = 4 * fl["av"] * B_PER_GPU
-            bach = bwd_alg / (br["attn_bwd"] * 1e-3) / 1e12
-            result["roofline_bwd"] = {"kernel": "bwd_prep+bwd_dq+bwd_dkdv+bwd_tokens", "bound": "mfma",
-                                      "achieved": round(bach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(bach / PEAK_FP32_MFMA_TFLOPS, 4)}
-            knn_alg = fl["dist"] * B_PER_GPU
-            kach = knn_alg / (br["knn"] * 1e-3) / 1e12
-            result["roofline_knn"] = {"kernel": "rownorm+gram_keys+select_rows", "bound": "mfma",
-                                      "achieved": round(kach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": round(kach / PEAK_FP32_MFMA_TFLOPS, 4)}
+                return None
+
+        def roof(kernel, alg_flops, ms, pmc_name):
+            ach = alg_flops / (ms * 1e-3) / 1e12
+            return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(pmc_name),
+                    "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops}
+
+        bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
+        result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
+        if not args.no_breakdown:
+            from samble_amd import ops
+            noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
+            br = kernel_breakdown(mod, x, noise, g)
+            result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
+            with torch.no_grad():
+                nt = mod.bin_tokens.shape[2]
+                w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight), 0).squeeze(-1)
+                qkv = ops.stage_proj_fwd(x, mod.bin_tokens[0], w)
+                q, k, v = qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+                smap, lse, _ = ops.stage_attn_stats(q, k, N, nt)
+                idx = torch.stack([torch.randperm(N, device=dev)[:M] for _ in range(B_PER_GPU)])
+                others = {
+                    "attn_stats_kernel": (fl["qk"] * B_PER_GPU, kernel_ms("attn_stats", lambda: ops.stage_attn_stats(q, k, N, nt)),
+                                          "void samble::attn_stats_kernel<8, 0>"),
+                    "attn_rows_kernel": (fl["av"] * B_PER_GPU,
+                                         kernel_ms("attn_rows", lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt)),
+                                         "void samble::attn_rows_kernel<4>"),
+                    "knn_stream_kernel": (fl["dist"] * B_PER_GPU, kernel_ms("knn_stream", lambda: ops.stage_knn(x, x, KNN)),
+                                          "void samble::knn_stream_kernel<128, 32, 8, 0>"),
+                }
+            result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seed)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)

@@ -168,6 +168,12 @@ int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
 size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D);
 /* debug / A-B hook: non-zero selects the two-kernel backward (7 MFMA products) instead of the fused one (5) */
 void samble_debug_bwd_split(int on);
+/* measurement hook (bench.py): record HIP events around the launches of one kernel, on the stream it
+ * is launched on.  id: 0 off, 1 attn_stats, 2 attn_rows, 3 bwd_rows, 4 knn_stream, 5 attn_fwd (single
+ * pass).  samble_debug_kernel_ms() waits for the timed launches (the last 64 at most) and returns
+ * their mean duration, -1 if none was recorded.  Not thread-safe; for benchmarks only. */
+int samble_debug_time_kernel(int id);
+float samble_debug_kernel_ms(void);
 int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                         const float* V, int64_t v_bs, int64_t v_rs, const float* O, const float* lse,
                         const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,

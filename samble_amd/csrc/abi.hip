@@ -77,6 +77,47 @@ int done(int hip_code, const char* where) {
 float inv_sqrt_d(int D) { return (float)(1.0 / sqrt((double)D)); }
 }  // namespace
 
+// ---- measurement hook: HIP events around the launches of ONE chosen kernel, on the stream it is
+// launched on; up to kTimeSlots launches are kept (round robin), samble_debug_kernel_ms averages them
+constexpr int kTimeSlots = 64;
+static int g_time_id = 0;
+static hipEvent_t g_time_ev[kTimeSlots][2];
+static bool g_time_have_events = false;
+static int g_time_count = 0;
+extern "C" void samble_time_begin(int id, hipStream_t s) {
+  if (id == g_time_id && g_time_have_events) (void)hipEventRecord(g_time_ev[g_time_count % kTimeSlots][0], s);
+}
+extern "C" void samble_time_end(int id, hipStream_t s) {
+  if (id == g_time_id && g_time_have_events) {
+    (void)hipEventRecord(g_time_ev[g_time_count % kTimeSlots][1], s);
+    ++g_time_count;
+  }
+}
+SAMBLE_API int samble_debug_time_kernel(int id) {
+  if (id && !g_time_have_events) {
+    for (int i = 0; i < kTimeSlots; ++i)
+      for (int k = 0; k < 2; ++k)
+        if (hipEventCreate(&g_time_ev[i][k]) != hipSuccess)
+          return fail(SAMBLE_E_INVALID, "samble_debug_time_kernel: cannot create events");
+    g_time_have_events = true;
+  }
+  g_time_id = id;
+  g_time_count = 0;
+  return SAMBLE_OK;
+}
+SAMBLE_API float samble_debug_kernel_ms(void) {
+  const int n = g_time_count < kTimeSlots ? g_time_count : kTimeSlots;
+  if (n == 0) return -1.f;
+  double total = 0.0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_time_ev[i][1]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, g_time_ev[i][0], g_time_ev[i][1]) != hipSuccess) return -1.f;
+    total += ms;
+  }
+  return (float)(total / n);
+}
+
 SAMBLE_API const char* samble_version(void) { return "samble-hip 0.1 (gfx950)"; }
 SAMBLE_API const char* samble_last_error(void) { return g_err; }
 

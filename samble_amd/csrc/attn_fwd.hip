@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const float* __rest
 
 }  // namespace samble
 
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 
 extern "C" int samble_launch_attn_colsum(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
@@ -246,7 +248,9 @@ extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, cons
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((N + 255) / 256, B);
+  samble_time_begin(5, stream);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
                      lse, tok, nt, row_std);
+  samble_time_end(5, stream);
   return (int)hipGetLastError();
 }

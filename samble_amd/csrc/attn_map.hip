@@ -268,6 +268,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_rows_kernel(const float* __re
 
 }  // namespace samble
 
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 
 int g_stats_ablate = 0;  // set by samble_debug_ablate(1, mode)
@@ -282,8 +284,10 @@ extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, co
   auto kern = g_stats_ablate == 1 ? attn_stats_kernel<NW, 1> : g_stats_ablate == 2 ? attn_stats_kernel<NW, 2>
             : g_stats_ablate == 3 ? attn_stats_kernel<NW, 3> : g_stats_ablate == 4 ? attn_stats_kernel<NW, 4>
                                                                                      : attn_stats_kernel<NW, 0>;
+  samble_time_begin(1, stream);
   hipLaunchKernelGGL(kern, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs, q_rs, K, k_bs,
                      k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
+  samble_time_end(1, stream);
   return (int)hipGetLastError();
 }
 
@@ -292,7 +296,9 @@ extern "C" int samble_launch_attn_rows(const float* smap, int ld, const float* l
                                        hipStream_t stream) {
   constexpr int NW = 4;
   const size_t lds = 2 * kTile * 128 * sizeof(float);
+  samble_time_begin(2, stream);
   hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, smap, ld,
                      lse, V, v_bs, v_rs, idx, N, N + nt, M, xds);
+  samble_time_end(2, stream);
   return (int)hipGetLastError();
 }

@@ -199,6 +199,8 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
 
 }  // namespace samble
 
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 
 extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const float* lse_s, const float* delta,
@@ -217,6 +219,8 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
   if (lds > 160 * 1024) return -22;
   RowsBwdArgs a{Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs,
                 dV, dv_bs, dv_rs, slab, nslab, smap, ld, idx};
+  samble_time_begin(3, stream);
   hipLaunchKernelGGL(bwd_rows_kernel, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
+  samble_time_end(3, stream);
   return (int)hipGetLastError();
 }

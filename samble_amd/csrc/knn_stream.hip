@@ -18,6 +18,9 @@
 
 #include "samble_dev.h"
 
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
+
 namespace samble {
 
 constexpr int kCap = 32;     // ring slots per lane (power of two); a tile adds at most 16
@@ -242,8 +245,10 @@ static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, lo
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
+  samble_time_begin(4, s);
   hipLaunchKernelGGL(kern, dim3((Nq + 32 * NW - 1) / (32 * NW), B), dim3(NT), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm,
                      idx, d2, g_knn_keep);
+  samble_time_end(4, s);
   return (int)hipGetLastError();
 }
 
