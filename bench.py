@@ -267,26 +267,24 @@ def main():
         bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
         result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
         if not args.no_breakdown:
-            from samble_amd import ops
             noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
             br = kernel_breakdown(mod, x, noise, g)
             result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
-            with torch.no_grad():
-                nt = mod.bin_tokens.shape[2]
-                w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight), 0).squeeze(-1)
-                qkv = ops.stage_proj_fwd(x, mod.bin_tokens[0], w)
-                q, k, v = qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
-                smap, lse, _ = ops.stage_attn_stats(q, k, N, nt)
-                idx = torch.stack([torch.randperm(N, device=dev)[:M] for _ in range(B_PER_GPU)])
-                others = {
-                    "attn_stats_kernel": (fl["qk"] * B_PER_GPU, kernel_ms("attn_stats", lambda: ops.stage_attn_stats(q, k, N, nt)),
-                                          "void samble::attn_stats_kernel<8, 0>"),
-                    "attn_rows_kernel": (fl["av"] * B_PER_GPU,
-                                         kernel_ms("attn_rows", lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt)),
-                                         "void samble::attn_rows_kernel<4>"),
-                    "knn_stream_kernel": (fl["dist"] * B_PER_GPU, kernel_ms("knn_stream", lambda: ops.stage_knn(x, x, KNN)),
-                                          "void samble::knn_stream_kernel<128, 32, 8, 0>"),
-                }
+            # the other MFMA kernels, each timed the same way over 5 more full steps (same cache state as the timed region)
+            def in_step_ms(kernel):
+                lib.samble_debug_time_kernel(KERNEL_IDS[kernel])
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                ms = float(lib.samble_debug_kernel_ms())
+                lib.samble_debug_time_kernel(0)
+                return ms
+            others = {
+                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "void samble::attn_stats_kernel<8, 0>"),
+                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "void samble::attn_rows_kernel<4>"),
+                "knn_stream_kernel": (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
+                                      "void samble::knn_stream_kernel<128, 32, 8, 0>"),
+            }
             result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seed)
