@@ -358,6 +358,27 @@ def test_batch_quantiles_exact(n, nb):
     assert torch.equal(got, O.batch_quantiles(z, nb))
 
 
+@pytest.mark.parametrize("kind", ["constant", "two_values", "outliers", "wide", "tiny_spread"])
+def test_batch_quantiles_exact_on_awkward_distributions(kind):
+    """Inputs that overflow or defeat the linear histogram of the fast path must still be exact
+    (the kernel falls back to its radix select)."""
+    n, nb = 65536, 6
+    z = torch.from_numpy(synth.normal((n,), 77))
+    if kind == "constant":
+        z = torch.full((n,), 0.25)
+    elif kind == "two_values":
+        z = torch.where(z > 0, torch.tensor(1.5), torch.tensor(-0.5))
+    elif kind == "outliers":
+        z[:100] = 1e6
+        z[100:200] = -1e6
+    elif kind == "wide":
+        z = z * 100.0
+    elif kind == "tiny_spread":
+        z = 1.0 + z * 1e-6
+    got = ops().stage_batch_quantiles(z.to(DEV), nb).cpu()
+    assert torch.equal(got, O.batch_quantiles(z, nb))
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_select_stages_exact_on_golden(name):
     g = Golden(name)
