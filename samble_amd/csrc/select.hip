@@ -36,13 +36,23 @@ __device__ __forceinline__ unsigned int block_scan_incl(unsigned int v, unsigned
   return buf[tid];
 }
 
-// Radix select, digits of 12 / 10 / 10 bits from the top of the order-preserving key (the wide first
-// digit spreads z-scores, whose sign+exponent bits are nearly constant, over many LDS counters).
-// Histograms are indexed by the REVERSED digit so that ascending bin order = descending value.
-__device__ void batch_quantiles_radix(const float* __restrict__ z, long n, int nb, float* __restrict__ out,
-                                      unsigned int* hist, unsigned int* scanbuf, unsigned int* prefix,
-                                      unsigned int* rem) {
+// Radix select on the order-preserving key, digits of 11 / 11 / 10 bits from the top, all nb-1 ranks
+// at once.  z-scores cluster (sign and exponent bits nearly constant), so most lanes of a wave hit the
+// same few counters and same-address LDS atomics serialise: every counter is therefore kept in kRep
+// copies on consecutive banks, lane l adds to copy l % kRep (8x fewer collisions), and the scans sum
+// the copies.  Histograms are indexed by the REVERSED digit so that ascending bin order = descending
+// value.  A thread's loads of a sweep are all in flight together.
+constexpr int kRep = 8;
+
+__global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __restrict__ z, long n, int nb,
+                                                               float* __restrict__ out) {
+  extern __shared__ unsigned int qsm[];
+  unsigned int* hist = qsm;                       // max(2048, (nb-1) * 1024 / 2 ...) x kRep, see launcher
+  __shared__ unsigned int scanbuf[1024];
+  __shared__ unsigned int prefix[kMaxBins];
+  __shared__ unsigned int rem[kMaxBins];
   const int tid = threadIdx.x;
+  const int rep = tid & (kRep - 1);
   const int nq = nb - 1;
   if (tid < nq) {
     // rank into the DESCENDING order: fp32 arithmetic then truncation (utils/ops.py:182-183)
@@ -50,27 +60,30 @@ __device__ void batch_quantiles_radix(const float* __restrict__ z, long n, int n
     rem[tid] = (unsigned int)(int)(frac * (float)n);
     prefix[tid] = 0u;
   }
-  // ---- pass 0: top 12 bits, one histogram shared by every rank
-  for (int e = tid; e < 4096; e += 1024) hist[e] = 0u;
+  // ---- pass 0: top 11 bits, one histogram shared by every rank
+  for (int e = tid; e < 2048 * kRep; e += 1024) hist[e] = 0u;
   __syncthreads();
-  for (long e0 = 0; e0 < n; e0 += 8 * 1024) {  // 8 loads in flight per thread
-    float v[8];
+  for (long e0 = 0; e0 < n; e0 += 16 * 1024) {  // 16 loads in flight per thread
+    float v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const long e = e0 + u * 1024 + tid;
       v[u] = (e < n) ? z[e] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (e0 + u * 1024 + tid < n) atomicAdd(&hist[4095u - (ordered_bits(v[u]) >> 20)], 1u);
+    for (int u = 0; u < 16; ++u)
+      if (e0 + u * 1024 + tid < n) atomicAdd(&hist[(2047u - (ordered_bits(v[u]) >> 21)) * kRep + rep], 1u);
   }
   __syncthreads();
   {
-    unsigned int loc[4], ts = 0u;
+    unsigned int loc[2], ts = 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      loc[u] = hist[4 * tid + u];
-      ts += loc[u];
+    for (int u = 0; u < 2; ++u) {
+      unsigned int c = 0u;
+#pragma unroll
+      for (int r8 = 0; r8 < kRep; ++r8) c += hist[(2 * tid + u) * kRep + r8];
+      loc[u] = c;
+      ts += c;
     }
     const unsigned int excl = block_scan_incl(ts, scanbuf, tid) - ts;
     for (int t = 0; t < nq; ++t) {
@@ -79,195 +92,83 @@ __device__ void batch_quantiles_radix(const float* __restrict__ z, long n, int n
       int found = -1;
       unsigned int newrem = 0u;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         if (found < 0 && c <= r && r < c + loc[u]) {
-          found = 4 * tid + u;
+          found = 2 * tid + u;
           newrem = r - c;
         }
         c += loc[u];
       }
       __syncthreads();
       if (found >= 0) {
-        prefix[t] = (4095u - (unsigned int)found) << 20;
+        prefix[t] = (2047u - (unsigned int)found) << 21;
         rem[t] = newrem;
       }
       __syncthreads();
     }
   }
-  // ---- passes 1, 2: 10 bits each, one 1024-bin histogram per rank
+  // ---- pass 1: next 11 bits (2048 bins), pass 2: last 10 bits (1024 bins); one histogram per rank, kRep2 copies
   for (int pass = 1; pass <= 2; ++pass) {
     const int shift = (pass == 1) ? 10 : 0;
-    for (int e = tid; e < nq * 1024; e += 1024) hist[e] = 0u;
+    const int bits = (pass == 1) ? 11 : 10;
+    const int nbin = 1 << bits;
+    constexpr int kRep2 = 2;
+    for (int e = tid; e < nq * nbin * kRep2; e += 1024) hist[e] = 0u;
     __syncthreads();
     unsigned int want[kMaxBins];
 #pragma unroll
-    for (int t = 0; t < kMaxBins; ++t) want[t] = (t < nq) ? (prefix[t] >> (shift + 10)) : 0xFFFFFFFFu;
-    for (long e0 = 0; e0 < n; e0 += 8 * 1024) {
-      float v[8];
+    for (int t = 0; t < kMaxBins; ++t) want[t] = (t < nq) ? (prefix[t] >> (shift + bits)) : 0xFFFFFFFFu;
+    for (long e0 = 0; e0 < n; e0 += 16 * 1024) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const long e = e0 + u * 1024 + tid;
         v[u] = (e < n) ? z[e] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (e0 + u * 1024 + tid >= n) continue;
         const unsigned int key = ordered_bits(v[u]);
-        const unsigned int hi = key >> (shift + 10);
-        const unsigned int dig = 1023u - ((key >> shift) & 1023u);
+        const unsigned int hi = key >> (shift + bits);
+        const unsigned int dig = (unsigned int)(nbin - 1) - ((key >> shift) & (unsigned int)(nbin - 1));
 #pragma unroll
         for (int t = 0; t < kMaxBins; ++t)
-          if (t < nq && hi == want[t]) atomicAdd(&hist[t * 1024 + dig], 1u);
+          if (t < nq && hi == want[t]) atomicAdd(&hist[(t * nbin + dig) * kRep2 + (tid & (kRep2 - 1))], 1u);
       }
     }
     __syncthreads();
     for (int t = 0; t < nq; ++t) {
-      const unsigned int mine = hist[t * 1024 + tid];
-      const unsigned int incl = block_scan_incl(mine, scanbuf, tid);
+      // nbin / 1024 bins per thread (2 in pass 1, 1 in pass 2)
+      unsigned int loc[2] = {0u, 0u}, ts = 0u;
+      const int per = nbin >> 10;
+      for (int u = 0; u < per; ++u) {
+        unsigned int c = 0u;
+#pragma unroll
+        for (int r2 = 0; r2 < kRep2; ++r2) c += hist[(t * nbin + per * tid + u) * kRep2 + r2];
+        loc[u] = c;
+        ts += c;
+      }
+      const unsigned int incl = block_scan_incl(ts, scanbuf, tid);
       const unsigned int r = rem[t];
-      const bool hit = (incl - mine) <= r && r < incl;
+      unsigned int c = incl - ts;
+      int found = -1;
+      unsigned int newrem = 0u;
+      for (int u = 0; u < per; ++u) {
+        if (found < 0 && c <= r && r < c + loc[u]) {
+          found = per * tid + u;
+          newrem = r - c;
+        }
+        c += loc[u];
+      }
       __syncthreads();
-      if (hit) {
-        prefix[t] |= (1023u - (unsigned int)tid) << shift;
-        rem[t] = r - (incl - mine);
+      if (found >= 0) {
+        prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)found) << shift;
+        rem[t] = newrem;
       }
       __syncthreads();
     }
   }
   if (tid < nq) out[tid] = from_ordered_bits(prefix[tid]);
-}
-
-// Two-pass exact select (the default): z-scores live in a narrow range, so a LINEAR 4096-bin histogram
-// over [-8, 8) (monotone in the value, ends clamped) isolates each wanted rank in a bin of ~n/400
-// candidates or fewer; the candidates of the nb-1 bins are collected in LDS and the rank is resolved
-// exactly by counting (value v is the answer iff #{c > v} <= r < #{c > v} + #{c == v}).  Two sweeps
-// over the data with 8 loads in flight per thread instead of three, short scans.  Anything unusual
-// (NaN, a bin with more candidates than the LDS lists hold) falls back to the radix select above,
-// which is exact for every input.
-constexpr int kQCand = 2048;  // candidates kept per rank
-
-__device__ __forceinline__ int linear_bin_desc(float v) {  // bin 0 = largest values
-  const int b = (int)floorf((v + 8.f) * 256.f);
-  return 4095 - min(max(b, 0), 4095);
-}
-
-__global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __restrict__ z, long n, int nb,
-                                                               float* __restrict__ out) {
-  __shared__ unsigned int hist[(kMaxBins - 1) * 1024];  // pass A: 4096 bins; then reused by the fallback
-  __shared__ unsigned int scanbuf[1024];
-  __shared__ unsigned int prefix[kMaxBins];
-  __shared__ unsigned int rem[kMaxBins];
-  __shared__ float cand[(kMaxBins - 1) * kQCand];
-  __shared__ unsigned int ccnt[kMaxBins];
-  __shared__ int target[kMaxBins];
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  const int nq = nb - 1;
-  if (tid < kMaxBins) {
-    const float frac = (float)(tid + 1) / (float)nb;  // fp32 arithmetic then truncation (utils/ops.py:182-183)
-    rem[tid] = (tid < nq) ? (unsigned int)(int)(frac * (float)n) : 0u;
-    ccnt[tid] = 0u;
-    target[tid] = -1;
-  }
-  if (tid == 0) bad = 0;
-  for (int e = tid; e < 4096; e += 1024) hist[e] = 0u;
-  __syncthreads();
-  // ---- pass A: histogram
-  int nan_seen = 0;
-  for (long e0 = 0; e0 < n; e0 += 8 * 1024) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long e = e0 + u * 1024 + tid;
-      v[u] = (e < n) ? z[e] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (e0 + u * 1024 + tid < n) {
-        nan_seen |= (v[u] != v[u]);
-        atomicAdd(&hist[linear_bin_desc(v[u])], 1u);
-      }
-    }
-  }
-  if (nan_seen) bad = 1;
-  __syncthreads();
-  // ---- scan: 4 bins per thread, wave scan by shuffles, 16 wave totals through LDS
-  {
-    unsigned int loc[4], ts = 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      loc[u] = hist[4 * tid + u];
-      ts += loc[u];
-    }
-    unsigned int incl = ts;
-    const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned int up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) scanbuf[wv] = incl;
-    __syncthreads();
-    unsigned int base = 0u;
-    for (int w2 = 0; w2 < wv; ++w2) base += scanbuf[w2];
-    const unsigned int excl = base + incl - ts;
-    for (int t = 0; t < nq; ++t) {
-      const unsigned int r = rem[t];
-      unsigned int c = excl;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (c <= r && r < c + loc[u]) {  // exactly one thread / bin matches
-          target[t] = 4 * tid + u;
-          prefix[t] = r - c;             // rank inside the bin (descending)
-          if (loc[u] > (unsigned int)kQCand) bad = 1;
-        }
-        c += loc[u];
-      }
-    }
-  }
-  __syncthreads();
-  if (bad) {  // uniform
-    __syncthreads();
-    batch_quantiles_radix(z, n, nb, out, hist, scanbuf, prefix, rem);
-    return;
-  }
-  // ---- pass B: collect the candidates of the nq target bins
-  int tg[kMaxBins];
-#pragma unroll
-  for (int t = 0; t < kMaxBins; ++t) tg[t] = (t < nq) ? target[t] : -2;
-  for (long e0 = 0; e0 < n; e0 += 8 * 1024) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long e = e0 + u * 1024 + tid;
-      v[u] = (e < n) ? z[e] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (e0 + u * 1024 + tid >= n) continue;
-      const int bn = linear_bin_desc(v[u]);
-#pragma unroll
-      for (int t = 0; t < kMaxBins; ++t)
-        if (bn == tg[t]) cand[t * kQCand + atomicAdd(&ccnt[t], 1u)] = v[u];  // (two ranks may share a bin)
-    }
-  }
-  __syncthreads();
-  // ---- exact rank inside each candidate list
-  for (int t = 0; t < nq; ++t) {
-    const int cn = (int)ccnt[t];
-    const unsigned int r = prefix[t];
-    const float* ct = cand + t * kQCand;
-    for (int e = tid; e < cn; e += 1024) {
-      const float v = ct[e];
-      unsigned int gt = 0u, eq = 0u;
-      for (int c = 0; c < cn; ++c) {
-        const float o = ct[c];
-        gt += (o > v);
-        eq += (o == v);
-      }
-      if (gt <= r && r < gt + eq) out[t] = v;  // every duplicate writes the same value
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -539,7 +440,18 @@ using namespace samble;
 
 extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, float* out, hipStream_t s) {
   if (nb < 2 || nb > kMaxBins) return -22;
-  hipLaunchKernelGGL(batch_quantiles_kernel, dim3(1), dim3(1024), 0, s, z, n, nb, out);
+  // dynamic LDS: max(pass 0: 2048 bins x 8 copies, pass 1: (nb-1) x 2048 bins x 2 copies) counters
+  size_t words = 2048 * 8;
+  if ((size_t)(nb - 1) * 2048 * 2 > words) words = (size_t)(nb - 1) * 2048 * 2;
+  const size_t lds = words * sizeof(unsigned int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch_quantiles_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(batch_quantiles_kernel, dim3(1), dim3(1024), lds, s, z, n, nb, out);
   return (int)hipGetLastError();
 }
 
