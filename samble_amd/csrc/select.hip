@@ -23,17 +23,22 @@ namespace samble {
 // ------------------------------------------------------------------------------------------------
 constexpr int kMaxBins = 8;
 
-// inclusive scan of one value per thread over the 1024-thread block (buf: 1024 words of LDS)
+// inclusive scan of one value per thread over the 1024-thread block: shuffles inside a wave, the 16
+// wave totals through LDS (buf: >= 16 words); two barriers
 __device__ __forceinline__ unsigned int block_scan_incl(unsigned int v, unsigned int* buf, int tid) {
-  buf[tid] = v;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const unsigned int a = (tid >= o) ? buf[tid - o] : 0u;
-    __syncthreads();
-    buf[tid] += a;
-    __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  unsigned int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
   }
-  return buf[tid];
+  __syncthreads();  // previous users of buf are done
+  if (lane == 63) buf[wv] = incl;
+  __syncthreads();
+  unsigned int base = 0u;
+  for (int w2 = 0; w2 < wv; ++w2) base += buf[w2];
+  return base + incl;
 }
 
 // Radix select on the order-preserving key, digits of 11 / 11 / 10 bits from the top, all nb-1 ranks
@@ -86,26 +91,24 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
       ts += c;
     }
     const unsigned int excl = block_scan_incl(ts, scanbuf, tid) - ts;
-    for (int t = 0; t < nq; ++t) {
-      const unsigned int r = rem[t];
+    unsigned int rr[kMaxBins];
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) rr[t] = (t < nq) ? rem[t] : 0u;
+    __syncthreads();  // every thread has read the ranks before the (single) owner of each rewrites it
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      if (t >= nq) continue;
       unsigned int c = excl;
-      int found = -1;
-      unsigned int newrem = 0u;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        if (found < 0 && c <= r && r < c + loc[u]) {
-          found = 2 * tid + u;
-          newrem = r - c;
+        if (c <= rr[t] && rr[t] < c + loc[u]) {  // exactly one (thread, u) matches
+          prefix[t] = (2047u - (unsigned int)(2 * tid + u)) << 21;
+          rem[t] = rr[t] - c;
         }
         c += loc[u];
       }
-      __syncthreads();
-      if (found >= 0) {
-        prefix[t] = (2047u - (unsigned int)found) << 21;
-        rem[t] = newrem;
-      }
-      __syncthreads();
     }
+    __syncthreads();
   }
   // ---- pass 1: next 11 bits (2048 bins), pass 2: last 10 bits (1024 bins); one histogram per rank, kRep2 copies
   for (int pass = 1; pass <= 2; ++pass) {
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
       }
     }
     __syncthreads();
+    unsigned int rr[kMaxBins];
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) rr[t] = (t < nq) ? rem[t] : 0u;
     for (int t = 0; t < nq; ++t) {
       // nbin / 1024 bins per thread (2 in pass 1, 1 in pass 2)
       unsigned int loc[2] = {0u, 0u}, ts = 0u;
@@ -149,24 +155,16 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
         ts += c;
       }
       const unsigned int incl = block_scan_incl(ts, scanbuf, tid);
-      const unsigned int r = rem[t];
       unsigned int c = incl - ts;
-      int found = -1;
-      unsigned int newrem = 0u;
       for (int u = 0; u < per; ++u) {
-        if (found < 0 && c <= r && r < c + loc[u]) {
-          found = per * tid + u;
-          newrem = r - c;
+        if (c <= rr[t] && rr[t] < c + loc[u]) {  // exactly one (thread, u) matches; rem/prefix[t] are read by nobody else now
+          prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
+          rem[t] = rr[t] - c;
         }
         c += loc[u];
       }
-      __syncthreads();
-      if (found >= 0) {
-        prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)found) << shift;
-        rem[t] = newrem;
-      }
-      __syncthreads();
     }
+    __syncthreads();
   }
   if (tid < nq) out[tid] = from_ordered_bits(prefix[tid]);
 }
