@@ -118,7 +118,8 @@ int samble_zscore_f32(const float* score, int B, int N, float* z, void* stream);
 /* ---- utils/ops.py:180-189  the nb-1 batch quantiles of all B*N z-scores ----------------------
  * out (nb-1) floats, descending.  The caller then averages over ranks (ops.py:191-199) and
  * blends with momentum (ops.py:201-233): five floats, host-side. */
-int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* stream);
+size_t samble_quantiles_workspace_bytes(void);
+int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- utils/ops.py:454-463 + models/downsample.py:264-284  bin membership and bin weights ------
  * upper/lower (nb) = the two (1,1,1,nb) boundary tensors.  tok (B,N,nt), nt == nb or 1.

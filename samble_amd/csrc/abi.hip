@@ -21,7 +21,8 @@ size_t samble_score_ws_bytes(int B, int N);
 int samble_launch_sparse_score(const float*, long, long, const float*, long, long, const float*, const int*, int, int,
                                int, float, int, float*, float*, int*, void*, hipStream_t);
 int samble_launch_zscore(const float*, int, int, float*, hipStream_t);
-int samble_launch_batch_quantiles(const float*, long, int, float*, hipStream_t);
+int samble_launch_batch_quantiles(const float*, long, int, float*, void*, hipStream_t);
+size_t samble_quantiles_ws_bytes(void);
 int samble_launch_bin_assign(const float*, const float*, int, const float*, const float*, int, int, int, int,
                              unsigned char*, int*, float*, float*, hipStream_t);
 int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hipStream_t);
@@ -175,11 +176,16 @@ SAMBLE_API int samble_zscore_f32(const float* score, int B, int N, float* z, voi
   return done(samble_launch_zscore(score, B, N, z, (hipStream_t)stream), "samble_zscore_f32");
 }
 
-SAMBLE_API int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* stream) {
+SAMBLE_API size_t samble_quantiles_workspace_bytes(void) { return samble_quantiles_ws_bytes(); }
+
+SAMBLE_API int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  if (ws && ws_bytes < samble_quantiles_ws_bytes())
+    return fail(SAMBLE_E_WORKSPACE, "samble_batch_quantiles_f32: workspace too small");
   if (!z || !out || n <= 0) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: bad argument");
   if (nb < 2 || nb > 8) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: need 2 <= num_bins <= 8");
   if (n >= (1ll << 31)) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: n must be < 2^31");
-  return done(samble_launch_batch_quantiles(z, n, nb, out, (hipStream_t)stream), "samble_batch_quantiles_f32");
+  return done(samble_launch_batch_quantiles(z, n, nb, out, ws, (hipStream_t)stream), "samble_batch_quantiles_f32");
 }
 
 SAMBLE_API int samble_bin_assign_f32(const float* z, const float* tok, int nt, const float* upper, const float* lower,

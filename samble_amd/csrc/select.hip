@@ -169,6 +169,116 @@ __global__ __launch_bounds__(1024) void batch_quantiles_kernel(const float* __re
   if (tid < nq) out[tid] = from_ordered_bits(prefix[tid]);
 }
 
+// ---- multi-workgroup version of the same radix select (one CU sweeping B*N values is VALU-bound:
+// ~30 instructions per value on 4 SIMDs).  Three sweep kernels of G workgroups + a one-workgroup
+// finish; level L's sweep first resolves level L-1 from its global histogram (every workgroup does
+// that redundantly and writes the identical result: no tickets, no fences), then histograms its own
+// slice in LDS and adds the non-empty counters to the global histogram of level L.
+// ws (uint32): hist0[2048] | hist1[7*2048] | hist2[7*1024] | 3 x state {prefix[8], rem[8]}; zeroed by the launcher.
+constexpr int kQH0 = 0, kQH1 = 2048, kQH2 = 2048 + 7 * 2048, kQState = kQH2 + 7 * 1024, kQWords = kQState + 3 * 16;  // state: one slot per resolved level
+
+// resolve the ranks of level `level` (0,1,2) from its global histogram; all 1024 threads; result in prefix/rem (LDS)
+__device__ void qsel_resolve(int level, const unsigned int* __restrict__ ws, int nq, long n, int nb,
+                             unsigned int* prefix, unsigned int* rem, unsigned int* scanbuf) {
+  const int tid = threadIdx.x;
+  if (level == 0) {
+    if (tid < kMaxBins) {
+      const float frac = (float)(tid + 1) / (float)nb;  // fp32 arithmetic then truncation (utils/ops.py:182-183)
+      rem[tid] = (tid < nq) ? (unsigned int)(int)(frac * (float)n) : 0u;
+      prefix[tid] = 0u;
+    }
+  } else if (tid < kMaxBins) {
+    prefix[tid] = ws[kQState + 16 * (level - 1) + tid];  // published by block 0 of the previous sweep
+    rem[tid] = ws[kQState + 16 * (level - 1) + 8 + tid];
+  }
+  __syncthreads();
+  const int bits = (level == 2) ? 10 : 11, nbin = 1 << bits, per = nbin >> 10;
+  const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
+  unsigned int rr[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) rr[t] = rem[t];
+  for (int t = 0; t < nq; ++t) {
+    const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
+    unsigned int loc[2] = {0u, 0u}, ts = 0u;
+    for (int u = 0; u < per; ++u) {
+      loc[u] = h[per * tid + u];
+      ts += loc[u];
+    }
+    const unsigned int incl = block_scan_incl(ts, scanbuf, tid);
+    unsigned int c = incl - ts;
+    for (int u = 0; u < per; ++u) {
+      if (c <= rr[t] && rr[t] < c + loc[u]) {
+        prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
+        rem[t] = rr[t] - c;
+      }
+      c += loc[u];
+    }
+  }
+  __syncthreads();
+}
+
+// LEVEL 0: histogram of the top 11 bits.  LEVEL 1/2: resolve the previous level, publish it, histogram the next digit
+// of the values that match each rank's prefix.  LEVEL 3: resolve level 2 and write the answers.
+template <int LEVEL>
+__global__ __launch_bounds__(1024) void qsel_kernel(const float* __restrict__ z, long n, int nb,
+                                                    unsigned int* __restrict__ ws, float* __restrict__ out) {
+  extern __shared__ unsigned int qsm[];  // LDS histogram of this level
+  __shared__ unsigned int scanbuf[16];
+  __shared__ unsigned int prefix[kMaxBins];
+  __shared__ unsigned int rem[kMaxBins];
+  const int tid = threadIdx.x;
+  const int nq = nb - 1;
+  if (LEVEL > 0) {
+    qsel_resolve(LEVEL - 1, ws, nq, n, nb, prefix, rem, scanbuf);
+    if (blockIdx.x == 0 && tid < kMaxBins) {  // identical in every workgroup; one publishes
+      ws[kQState + 16 * (LEVEL - 1) + tid] = prefix[tid];
+      ws[kQState + 16 * (LEVEL - 1) + 8 + tid] = rem[tid];
+    }
+    if (LEVEL == 3) {
+      if (tid < nq) out[tid] = from_ordered_bits(prefix[tid]);
+      return;
+    }
+  }
+  constexpr int bits = (LEVEL == 2) ? 10 : 11, nbin = 1 << bits;
+  constexpr int shift = (LEVEL == 0) ? 21 : (LEVEL == 1) ? 10 : 0;
+  const int nh = (LEVEL == 0) ? 1 : nq;
+  for (int e = tid; e < nh * nbin; e += 1024) qsm[e] = 0u;
+  unsigned int want[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) want[t] = (LEVEL > 0 && t < nq) ? (prefix[t] >> (shift + bits)) : 0xFFFFFFFFu;
+  __syncthreads();
+  const long per_wg = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = blockIdx.x * per_wg, hi_e = min(n, lo + per_wg);
+  for (long e0 = lo; e0 < hi_e; e0 += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long e = e0 + u * 1024 + tid;
+      v[u] = (e < hi_e) ? z[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (e0 + u * 1024 + tid >= hi_e) continue;
+      const unsigned int key = ordered_bits(v[u]);
+      const unsigned int dig = (unsigned int)(nbin - 1) - ((key >> shift) & (unsigned int)(nbin - 1));
+      if (LEVEL == 0) {
+        atomicAdd(&qsm[dig], 1u);
+      } else {
+        const unsigned int hi = key >> (shift + bits);
+#pragma unroll
+        for (int t = 0; t < kMaxBins; ++t)
+          if (t < nq && hi == want[t]) atomicAdd(&qsm[t * nbin + dig], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  unsigned int* gh = ws + (LEVEL == 0 ? kQH0 : LEVEL == 1 ? kQH1 : kQH2);
+  for (int e = tid; e < nh * nbin; e += 1024) {
+    const unsigned int c = qsm[e];
+    if (c) atomicAdd(&gh[(LEVEL == 2) ? (e / nbin) * 1024 + (e % nbin) : (LEVEL == 1) ? (e / nbin) * 2048 + (e % nbin) : e], c);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // bin membership + weights: one workgroup per cloud
 // ------------------------------------------------------------------------------------------------
@@ -436,8 +546,28 @@ __global__ void gather_points_kernel(const float* __restrict__ pcd, int C, int N
 
 using namespace samble;
 
-extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, float* out, hipStream_t s) {
+extern "C" size_t samble_quantiles_ws_bytes(void) { return (size_t)kQWords * sizeof(unsigned int); }
+
+extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, float* out, void* ws, hipStream_t s) {
   if (nb < 2 || nb > kMaxBins) return -22;
+  if (ws && n >= 16384) {  // multi-workgroup select
+    unsigned int* w = reinterpret_cast<unsigned int*>(ws);
+    hipError_t e = hipMemsetAsync(w, 0, (size_t)kQWords * sizeof(unsigned int), s);
+    if (e != hipSuccess) return (int)e;
+    const int G = (int)((n + 2047) / 2048 > 128 ? 128 : (n + 2047) / 2048);
+    static bool attr2 = false;
+    if (!attr2) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(qsel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              64 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(qsel_kernel<0>, dim3(G), dim3(1024), 2048 * 4, s, z, n, nb, w, out);
+    hipLaunchKernelGGL(qsel_kernel<1>, dim3(G), dim3(1024), (size_t)(nb - 1) * 2048 * 4, s, z, n, nb, w, out);
+    hipLaunchKernelGGL(qsel_kernel<2>, dim3(G), dim3(1024), (size_t)(nb - 1) * 1024 * 4, s, z, n, nb, w, out);
+    hipLaunchKernelGGL(qsel_kernel<3>, dim3(1), dim3(1024), 16, s, z, n, nb, w, out);
+    return (int)hipGetLastError();
+  }
   // dynamic LDS: max(pass 0: 2048 bins x 8 copies, pass 1: (nb-1) x 2048 bins x 2 copies) counters
   size_t words = 2048 * 8;
   if ((size_t)(nb - 1) * 2048 * 2 > words) words = (size_t)(nb - 1) * 2048 * 2;

@@ -204,7 +204,10 @@ def stage_batch_quantiles(z: torch.Tensor, num_bins: int) -> torch.Tensor:
     z = _f32c(z)
     with torch.cuda.device(z.device):
         out = torch.empty((num_bins - 1,), dtype=torch.float32, device=z.device)
-        _lib.call("samble_batch_quantiles_f32", z.data_ptr(), z.numel(), num_bins, out.data_ptr(), _stream())
+        nbytes = _lib.query("samble_quantiles_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+        _lib.call("samble_batch_quantiles_f32", z.data_ptr(), z.numel(), num_bins, out.data_ptr(), ws.data_ptr(), nbytes,
+                  _stream())
     return out
 
 

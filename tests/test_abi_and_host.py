@@ -46,7 +46,7 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     with pytest.raises(lib.SambleError, match="D must be 128"):
         lib.call("samble_gather_rows_f32", 1, 0, 0, 1, 1, 1, 64, 1, None)
     with pytest.raises(lib.SambleError, match="num_bins"):
-        lib.call("samble_batch_quantiles_f32", 1, 10, 9, 1, None)
+        lib.call("samble_batch_quantiles_f32", 1, 10, 9, 1, None, 0, None)
 
 
 def test_missing_library_fails_loudly(monkeypatch, lib):
