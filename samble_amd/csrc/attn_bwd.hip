@@ -62,27 +62,14 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     ak[t] = z4;
     av[t] = z4;
   }
-  // the 4 rows of a half-wave: index loads, then the gathers that depend on them, issued together
-  long rows[4];
-  f32x4 qvs[4], ovs[4];
-  float lrows[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) rows[u] = idx[(long)b * M + min(m0 + sub + 8 * u, M - 1)];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const f32x4 z4r = {0.f, 0.f, 0.f, 0.f};
-    qvs[u] = *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + rows[u] * q_rs + 4 * l32);
-    ovs[u] = Oc ? z4r : *reinterpret_cast<const f32x4*>(O + ((long)b * N + rows[u]) * 128 + 4 * l32);
-    lrows[u] = lse[(long)b * N + rows[u]];
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int rr = sub + 8 * u;
+  for (int rr = sub; rr < 32; rr += 8) {
     const int m = m0 + rr;
     if (m >= M) continue;  // uniform per half-wave
-    const f32x4 qv = qvs[u];
-    const f32x4 ov = ovs[u];
-    const float lrow = lrows[u];
+    const long row = idx[(long)b * M + m];
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + row * q_rs + 4 * l32);
+    const f32x4 z4r = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 ov = Oc ? z4r : *reinterpret_cast<const f32x4*>(O + ((long)b * N + row) * 128 + 4 * l32);
+    const float lrow = lse[(long)b * N + row];
     f32x4 dv = {gt[(4 * l32 + 0) * 33 + rr], gt[(4 * l32 + 1) * 33 + rr], gt[(4 * l32 + 2) * 33 + rr],
                 gt[(4 * l32 + 3) * 33 + rr]};
     *reinterpret_cast<f32x4*>(Qs + ((long)b * M + m) * 128 + 4 * l32) = qv;
@@ -115,10 +102,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
         const float p = __expf(st * scale - lrow);
         const float ds = p * (dpt - part) * scale;
 #pragma unroll
-        for (int u2 = 0; u2 < 4; ++u2) {
-          av[t][u2] = fmaf(p, dv[u2], av[t][u2]);
-          ak[t][u2] = fmaf(ds, qv[u2], ak[t][u2]);
-          dqt[u2] = fmaf(ds, kt[t][u2], dqt[u2]);
+        for (int u = 0; u < 4; ++u) {
+          av[t][u] = fmaf(p, dv[u], av[t][u]);
+          ak[t][u] = fmaf(ds, qv[u], ak[t][u]);
+          dqt[u] = fmaf(ds, kt[t][u], dqt[u]);
         }
       }
     }
