@@ -148,11 +148,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress"],
+                    help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
     args = ap.parse_args()
 
+    global B_PER_GPU, N, M
+    if args.workload == "stress":
+        B_PER_GPU, N, M = 16, 8192, 4096
+        args.no_cpu_baseline = True  # the CPU oracle needs minutes per cloud at this size
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -173,7 +179,7 @@ def main():
     from samble_amd.downsample import DownSampleToken
 
     seed = 1000 * 2
-    mod = DownSampleToken(sampler_config("cls"), 0)
+    mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0)
     wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
     with torch.no_grad():
         mod.q_conv.weight.copy_(torch.from_numpy(wq))
@@ -228,7 +234,8 @@ def main():
         value = total_clouds / elapsed
         fl = algorithmic_flops_per_cloud()
         result = {
-            "metric": "point-clouds/sec (downsample fwd+bwd), ModelNet40 B=32 N=2048->1024",
+            "metric": ("point-clouds/sec (downsample fwd+bwd), ModelNet40 B=32 N=2048->1024" if args.workload == "metric"
+                       else "point-clouds/sec (downsample fwd+bwd), synthetic dense clouds B=16 N=8192->4096"),
             "value": round(value, 2),
             "unit": "clouds/s",
             "n_gpus": world,
@@ -240,7 +247,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (hash-generated N(0,1) features, random-init weights; no ModelNet40 files offline)",
-            "config": {"workload": "one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B=32/GPU C=128 N=2048->M=1024 "
+            "config": {"workload": f"one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B={B_PER_GPU}/GPU C=128 N={N}->M={M} "
                                    "nb=6 K=32 sparse_col_sqr random T=0.1 dynamic boundaries",
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None},
             "step_fraction_of_mfma_roofline": round(
