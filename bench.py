@@ -287,10 +287,10 @@ def main():
                 lib.samble_debug_time_kernel(0)
                 return ms
             others = {
-                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "void samble::attn_stats_kernel<8, 0>"),
-                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "void samble::attn_rows_kernel<4>"),
+                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats_kernel<8, 0>"),
+                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows_kernel<4>"),
                 "knn_stream_kernel": (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
-                                      "void samble::knn_stream_kernel<128, 32, 8, 0>"),
+                                      "samble::knn_stream_kernel<128, 32, 8, 0>"),
             }
             result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:

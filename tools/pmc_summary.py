@@ -22,7 +22,8 @@ N_SIMD = 1024
 
 
 def short(name):
-    return name.split("(")[0]
+    n = name.split("(")[0]
+    return n[5:] if n.startswith("void ") else n
 
 
 def main(tag):
