@@ -147,6 +147,12 @@ int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int
 int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_t* idx, int M, float* out,
                              void* stream);
 
+/* ---- utils/ops.py:622-643  farthest_point_sample -------------------------------------------
+ * xyz (B,3,N) channel-major (the layout the models hold; the reference permutes to (B,N,3) first),
+ * start (B) = the first centroid of each cloud (the reference draws it with torch.randint), out
+ * (B,npoint) int64 in selection order.  N <= 8192. */
+int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out, void* stream);
+
 /* ---- models/attention.py:165-250  Neighbor2PointAttention, attention part (scalar_dot, asm dot) --
  * qkv (B,N,3C) point-major rows [Q|K|V] = samble_proj_fwd_f32 of the layer input with the three
  * Conv2d 1x1 weights (nt = 0); nn (B,N,KN) neighbour lists of the layer input.  diff != 0:

@@ -480,6 +480,24 @@ def upsample_interpolation(pcd_up, points_select, pcd_up_xyz, points_select_xyz,
                         negative_slope=0.2)
 
 
+def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -> torch.Tensor:
+    """reference utils/ops.py:622-643 with the random first centroid made an input (`start`, (B,)
+    int64; the reference draws it with torch.randint).  xyz (B,N,3) -> (B,npoint) int64."""
+    B, N, _ = xyz.shape
+    centroids = torch.zeros(B, npoint, dtype=torch.long)
+    distance = torch.ones(B, N) * 1e10
+    farthest = start.clone().long()
+    batch = torch.arange(B, dtype=torch.long)
+    for i in range(npoint):
+        centroids[:, i] = farthest
+        centroid = xyz[batch, farthest, :].view(B, 1, 3)
+        dist = torch.sum((xyz - centroid) ** 2, -1)
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        farthest = torch.max(distance, -1)[1]
+    return centroids
+
+
 def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum"):
     """DownSampleGlobal.forward (models/downsample.py:1281-1330, asm dot, H=1, no res block).
     Returns ((x_ds, idx (B,1,M)), (x_dropped, idx_dropped (B,1,N-M)), score (B,1,N))."""

@@ -29,6 +29,7 @@ int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hi
 int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, int, int, int,
                              int, int, int, float, long long*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
+int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
                            hipStream_t);
@@ -236,6 +237,15 @@ SAMBLE_API int samble_gather_points_f32(const float* pcd, int B, int C, int N, c
   if (!pcd || !idx || !out) return fail(SAMBLE_E_INVALID, "samble_gather_points_f32: null pointer");
   return done(samble_launch_gather_points(pcd, B, C, N, (const long long*)idx, M, out, (hipStream_t)stream),
               "samble_gather_points_f32");
+}
+
+SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out,
+                              void* stream) {
+  if (!xyz || !start || !out) return fail(SAMBLE_E_INVALID, "samble_fps_f32: null pointer");
+  if (B <= 0 || N <= 0 || N > 8192 || npoint <= 0 || npoint > N)
+    return fail(SAMBLE_E_INVALID, "samble_fps_f32: need 1 <= npoint <= N <= 8192");
+  return done(samble_launch_fps(xyz, (const long long*)start, B, N, npoint, (long long*)out, (hipStream_t)stream),
+              "samble_fps_f32");
 }
 
 SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D) {

@@ -542,6 +542,84 @@ __global__ void gather_points_kernel(const float* __restrict__ pcd, int C, int N
   out[((long)b * C + c) * M + m] = pcd[((long)b * C + c) * N + idx[(long)b * M + m]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// farthest point sampling (reference utils/ops.py:622-643): npoint rounds of {record the current
+// farthest point, distance[n] = min(distance[n], |xyz_n - c|^2), farthest = argmax(distance)}.
+// One workgroup per cloud, the cloud's points and running distances in registers (<= 8 per thread),
+// the argmax by wave shuffles + one LDS exchange; ties go to the smallest index (torch.max on the
+// CPU returns the first maximum).  The squared distance is summed in the reference's order
+// ((dx^2 + dy^2) + dz^2, no FMA contraction: this file is built with -ffp-contract=off).
+// ------------------------------------------------------------------------------------------------
+constexpr int kFpsPer = 8;  // points per thread: N <= 8192
+
+__global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz,  // (B,3,N) channel-major
+                                                   const long long* __restrict__ start, int N, int npoint,
+                                                   long long* __restrict__ out) {
+  __shared__ float wbest[16];
+  __shared__ int widx[16];
+  __shared__ int cur_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* xb = xyz + (long)b * 3 * N;
+  float px[kFpsPer], py[kFpsPer], pz[kFpsPer], dist[kFpsPer];
+#pragma unroll
+  for (int u = 0; u < kFpsPer; ++u) {
+    const int n = tid + 1024 * u;
+    const bool v = n < N;
+    px[u] = v ? xb[n] : 0.f;
+    py[u] = v ? xb[N + n] : 0.f;
+    pz[u] = v ? xb[2 * N + n] : 0.f;
+    dist[u] = v ? 1e10f : -1.f;  // padding can never win the argmax (distances are >= 0)
+  }
+  int cur = (int)start[b];
+  for (int it = 0; it < npoint; ++it) {
+    if (tid == 0) out[(long)b * npoint + it] = cur;
+    const float cx = xb[cur], cy = xb[N + cur], cz = xb[2 * N + cur];
+    float best = -2.f;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < kFpsPer; ++u) {
+      const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d < dist[u]) dist[u] = d;
+      const int n = tid + 1024 * u;
+      if (dist[u] > best) {  // ascending n inside a thread: strict > keeps the smallest index
+        best = dist[u];
+        bidx = n;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bidx, off, 64);
+      if (ob > best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+      }
+    }
+    if (lane == 0) {
+      wbest[wv] = best;
+      widx[wv] = bidx;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float b2 = (tid < 16) ? wbest[tid] : -2.f;
+      int i2 = (tid < 16) ? widx[tid] : 0x7fffffff;
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(b2, off, 64);
+        const int oi = __shfl_xor(i2, off, 64);
+        if (ob > b2 || (ob == b2 && oi < i2)) {
+          b2 = ob;
+          i2 = oi;
+        }
+      }
+      if (tid == 0) cur_s = i2;
+    }
+    __syncthreads();
+    cur = cur_s;
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -615,6 +693,13 @@ extern "C" int samble_launch_bin_select(const float* score, const float* z, cons
   }
   hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise, N, NP, nb, M,
                      mode, temp_mode, temp, idx_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_fps(const float* xyz, const long long* start, int B, int N, int npoint, long long* out,
+                                 hipStream_t s) {
+  if (N > 1024 * kFpsPer) return -22;
+  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(1024), 0, s, xyz, start, N, npoint, out);
   return (int)hipGetLastError();
 }
 

@@ -461,6 +461,24 @@ def neighbor_mask(pcd, K):
     return mask
 
 
+def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """utils/ops.py:622-643: xyz (B,N,3) -> centroid indices (B,npoint) int64 in selection order.
+    `start` (B,) int64 is the first centroid per cloud; the reference draws it with torch.randint,
+    which is what happens here too when it is omitted."""
+    _need_gpu(xyz)
+    B, N, C = xyz.shape
+    if C != 3:
+        raise ValueError("farthest_point_sample expects (B, N, 3) coordinates")
+    if start is None:
+        start = torch.randint(0, N, (B,), dtype=torch.long, device=xyz.device)
+    start = start.to(device=xyz.device, dtype=torch.long).contiguous()
+    cm = _channel_major(xyz)  # (B,3,N); free when xyz is the usual permute(0,2,1) view
+    with torch.cuda.device(xyz.device):
+        out = torch.empty((B, npoint), dtype=torch.long, device=xyz.device)
+        _lib.call("samble_fps_f32", cm.data_ptr(), start.data_ptr(), B, N, npoint, out.data_ptr(), _stream())
+    return out
+
+
 def gather_by_idx(pcd, idx):
     """utils/ops.py:136-145: pcd (B,C,N), idx (B,H=1,K) -> (B,C,K)."""
     _need_gpu(pcd, idx)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import torch_oracle as O
 from samble_amd import synth
 from tests.util import layer_fixture, set_agreement
 
@@ -196,3 +197,24 @@ def test_downsample_global_against_reference_fixture():
         for got, key in ((x.grad, "dx"), (mod.q_conv.weight.grad, "dwq")):
             ref = torch.from_numpy(d[key])
             assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
+
+
+def test_farthest_point_sample_exact():
+    """utils/ops.py:622-643 on the HIP kernel: bit-exact index sequence on the reference's fixture,
+    and against the oracle at a ragged size and at N=8192 (the kernel's register-resident maximum)."""
+    from samble_amd import ops
+    d = layer_fixture("layer_fps")
+    B, N, npoint, seed = [int(v) for v in d["meta"]]
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed)).permute(0, 2, 1)  # (B,N,3) view of (B,3,N)
+    got = ops.farthest_point_sample(xyz.to(DEV), npoint, torch.from_numpy(d["start"]).to(DEV))
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), torch.from_numpy(d["idx"]))
+    for (B2, N2, np2, sd) in ((2, 777, 300, 11), (1, 8192, 512, 12)):
+        x2 = torch.from_numpy(synth.xyz_clouds(B2, N2, sd)).permute(0, 2, 1).contiguous()
+        x2[0, 5] = x2[0, 9]  # duplicate points: equal distances, the first index must win
+        st = torch.arange(B2) * 7 % N2
+        ref = O.farthest_point_sample(x2, np2, st)
+        got = ops.farthest_point_sample(x2.to(DEV), np2, st.to(DEV))
+        assert torch.equal(got.cpu(), ref), (N2,)
+    # without `start` the first centroid is drawn like the reference does; the rest is determined by it
+    r = ops.farthest_point_sample(xyz.to(DEV), 16)
+    assert torch.equal(r.cpu(), O.farthest_point_sample(xyz.contiguous(), 16, r[:, 0].cpu()))

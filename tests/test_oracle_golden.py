@@ -85,3 +85,14 @@ def test_oracle_reproduces_layer_fixtures():
         y, att, idx = O.n2p_forward(st, torch.from_numpy(synth.features(B, C, N, seed)), K, H, gt)
         torch.testing.assert_close(y, torch.from_numpy(d["y"]), rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(att, torch.from_numpy(d["att"]), rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_fps_reproduces_reference_fixture():
+    """farthest_point_sample restatement vs the indices the reference produced (layer_fps.npz)."""
+    from samble_amd import synth
+    from tests.util import layer_fixture
+    d = layer_fixture("layer_fps")
+    B, N, npoint, seed = [int(v) for v in d["meta"]]
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed)).permute(0, 2, 1).contiguous()
+    got = O.farthest_point_sample(xyz, npoint, torch.from_numpy(d["start"]))
+    assert torch.equal(got, torch.from_numpy(d["idx"]))
