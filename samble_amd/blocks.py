@@ -16,9 +16,11 @@ from .embedding import EdgeConv
 
 
 class FeatureLearningBlock(nn.Module):
-    def __init__(self, config_feature_learning_block):
+    def __init__(self, config_feature_learning_block, fps=False):
         super().__init__()
         cfg = config_feature_learning_block
+        self.fps = fps  # reference cls_model.py:100,117-131: FPS pre-selection of 2M points before each sampler
+        self.M_list = cfg.downsample.M
         if cfg.downsample.ds_which != "token":
             raise NotImplementedError("only ds_which == 'token' (DownSampleToken) is built")
         if getattr(cfg.attention, "fl_which", "n2p") != "n2p":
@@ -48,7 +50,14 @@ class FeatureLearningBlock(nn.Module):
             res_link_list = [self.conv_list[0](x).max(dim=-1)[0]]
             for i in range(len(self.downsample_list)):
                 noise = None if noise_list is None else noise_list[i]
-                (x, idx_select) = self.downsample_list[i](x, x_xyz, noise=noise)[0]
+                if self.fps:
+                    x_idx = ops.farthest_point_sample(torch.permute(x_xyz, (0, 2, 1)), self.M_list[i] * 2)
+                    x = torch.gather(x, 2, x_idx.unsqueeze(1).expand(-1, x.shape[1], -1))
+                    x_xyz_down = torch.gather(x_xyz, 2, x_idx.unsqueeze(1).expand(-1, 3, -1))
+                    (x, idx_select) = self.downsample_list[i](x, x_xyz_down, noise=noise)[0]
+                    idx_select = torch.gather(x_idx.unsqueeze(1), 2, idx_select)
+                else:
+                    (x, idx_select) = self.downsample_list[i](x, x_xyz, noise=noise)[0]
                 x = self.feature_learning_layer_list[i + 1](x)
                 x_xyz = ops.gather_by_idx(x_xyz, idx_select)
                 res_link_list.append(self.conv_list[i + 1](x).max(dim=-1)[0])
