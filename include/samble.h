@@ -158,9 +158,11 @@ int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npo
  * Conv2d 1x1 weights (nt = 0); nn (B,N,KN) neighbour lists of the layer input.  diff != 0:
  * group_type "diff" (keys/values are neighbour minus centre: by linearity (Wx)_j - (Wx)_i), else
  * "neighbor".  out (B,C,N) = sum_j softmax_j(q_i . k_ij / sqrt(C/heads)) v_ij, heads laid out
- * head-major along C as the reference's split_heads.  C = 128, heads = 4 in this round. */
+ * head-major along C as the reference's split_heads.  C = 128; heads = 4 (N2P) or 1 (the local
+ * attention of DownSampleLocal, models/downsample.py:885-963).  att: optional (B,N,KN) softmax
+ * probabilities of the single head (the reference's attention_map), heads == 1 and KN <= 64 only. */
 int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN, int C,
-                            int heads, int diff, float* out, void* stream);
+                            int heads, int diff, float* out, float* att, void* stream);
 
 /* Backward of samble_n2p_attn_fwd_f32: g (B,C,N) = gradient of its output -> dqkv (B,N,3C) point-major
  * rows [dQ|dK|dV] (feed it to samble_proj_bwd_f32).  Deterministic (no atomics).  K <= 32. */

@@ -480,6 +480,67 @@ def upsample_interpolation(pcd_up, points_select, pcd_up_xyz, points_select_xyz,
                         negative_slope=0.2)
 
 
+def norm_range(x, dim=-1, n_min=0.0, n_max=1.0, mode="minmax"):
+    """reference utils/ops.py:148-171."""
+    if mode == "minmax":
+        lo = torch.min(x, dim=dim, keepdim=True)[0]
+        xn = (x - lo) / (torch.max(x, dim=dim, keepdim=True)[0] - lo + 1e-8)
+    elif mode == "sigmoid":
+        xn = torch.sigmoid(x)
+    elif mode == "tanh":
+        xn = (torch.tanh(x) + 1.0) / 2
+    elif mode == "z-score":
+        return (x - torch.mean(x, dim=dim, keepdim=True)) / torch.std(x, dim=dim, unbiased=False, keepdim=True) + n_min
+    else:
+        raise ValueError(f"norm_range mode should be minmax, sigmoid or tanh, but got {mode}")
+    return xn * (n_max - n_min) + n_min
+
+
+def local_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "local_std", k: int = 32, asm: str = "dot"):
+    """DownSampleLocal (reference models/downsample.py:818-1229) for one head, no boltzmann draw:
+    local 1 x K attention of every point over its K nearest neighbours (in feature space), a per-point
+    score from that map, top-M kept, bottom-(N-M) by the map's std dropped.  wq/wk/wv (C,C,1,1).
+    -> (x_ds (B,C,M), idx (B,1,M)), (x_dropped (B,C,N-M), idx_dropped (B,1,N-M)), score (B,1,N), att (B,1,N,1,K)"""
+    B, C, N = x.shape
+    group_type = "diff" if asm == "dot" else "neighbor"
+    neighbors, nidx = group_neighbors(x, k, group_type)          # (B,C,N,K), (B,N,K)
+    q = torch.nn.functional.conv2d(x[:, :, :, None], wq)          # (B,C,N,1)
+    kk = torch.nn.functional.conv2d(neighbors, wk)                # (B,C,N,K)
+    vv = torch.nn.functional.conv2d(neighbors, wv)
+
+    def heads(t):  # (B,C,N,K) -> (B,1,N,K,D)
+        return t.view(B, 1, C, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2)
+    q, kk, vv = heads(q), heads(kk), heads(vv)
+    energy = q @ kk.permute(0, 1, 2, 4, 3)                         # (B,1,N,1,K)
+    att = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)
+    a2 = att.squeeze(-2)                                           # (B,1,N,K)
+    idx4 = nidx.view(B, 1, N, k)
+    sparse = torch.zeros(B, 1, N, N, dtype=torch.float32).scatter_(-1, idx4, a2)
+    mask = torch.zeros(B, 1, N, N, dtype=torch.float32).scatter_(-1, idx4, 1.0)
+    num = torch.sum(mask, dim=-2) + 1e-8
+    if idx_mode == "local_std":
+        score = torch.std(att, dim=-1, unbiased=False)[:, :, :, 0]
+    elif idx_mode == "sparse_row_std":
+        score = torch.std(sparse.masked_select(mask != 0).view(B, 1, N, k), dim=-1)
+    elif idx_mode == "sparse_col_sum":
+        score = torch.sum(sparse, dim=-2)
+    elif idx_mode == "sparse_col_avg":
+        score = torch.sum(sparse, dim=-2) / num
+    elif idx_mode == "sparse_col_sqr":
+        score = torch.sum(sparse, dim=-2) / num / num
+    else:
+        raise ValueError("Please check the setting of idx mode!")
+    idx = score.topk(M, dim=-1)[1]
+    idx_dropped = torch.std(att, dim=-1, unbiased=False)[:, :, :, 0].topk(N - M, dim=-1, largest=False)[1]
+
+    def attend(sel):
+        a = torch.gather(att, 2, sel[..., None, None].expand(-1, -1, -1, -1, k))
+        v = torch.gather(vv, 2, sel[..., None, None].expand(-1, -1, -1, k, C))
+        o = (a @ v)[:, :, :, 0, :].permute(0, 2, 1, 3)             # (B,M,1,D)
+        return o.reshape(B, o.shape[1], -1).permute(0, 2, 1)
+    return (attend(idx), idx), (attend(idx_dropped), idx_dropped), score, att
+
+
 def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -> torch.Tensor:
     """reference utils/ops.py:622-643 with the random first centroid made an input (`start`, (B,)
     int64; the reference draws it with torch.randint).  xyz (B,N,3) -> (B,npoint) int64."""

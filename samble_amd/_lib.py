@@ -52,7 +52,7 @@ _SIGNATURES = {
     "samble_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_gather_points_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_n2p_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                        c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p]),
     "samble_n2p_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_n2p_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),

@@ -11,7 +11,7 @@ from torch import nn
 
 from . import ops
 from .attention import Neighbor2PointAttention
-from .downsample import DownSampleToken
+from .downsample import DownSampleGlobal, DownSampleLocal, DownSampleToken
 from .embedding import EdgeConv
 
 
@@ -21,13 +21,14 @@ class FeatureLearningBlock(nn.Module):
         cfg = config_feature_learning_block
         self.fps = fps  # reference cls_model.py:100,117-131: FPS pre-selection of 2M points before each sampler
         self.M_list = cfg.downsample.M
-        if cfg.downsample.ds_which != "token":
-            raise NotImplementedError("only ds_which == 'token' (DownSampleToken) is built")
+        sampler = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}.get(cfg.downsample.ds_which)
+        if sampler is None:
+            raise NotImplementedError
         if getattr(cfg.attention, "fl_which", "n2p") != "n2p":
             raise ValueError("Only n2p is built for fl_which")
         self.res_link_enable = cfg.res_link.enable
         self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
-        self.downsample_list = nn.ModuleList([DownSampleToken(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
+        self.downsample_list = nn.ModuleList([sampler(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
         self.feature_learning_layer_list = nn.ModuleList(
             [Neighbor2PointAttention(cfg.attention, l) for l in range(len(cfg.attention.K))])
         outs = cfg.attention.ff_conv2_channels_out
@@ -36,6 +37,12 @@ class FeatureLearningBlock(nn.Module):
         else:
             self.conv = nn.Conv1d(outs[-1], 1024, kernel_size=1, bias=False)
         self.M_list = cfg.downsample.M
+
+    def _sample(self, i, x, x_xyz, noise):
+        layer = self.downsample_list[i]
+        if isinstance(layer, DownSampleToken):
+            return layer(x, x_xyz, noise=noise)[0]
+        return layer(x, x_xyz)[0]
 
     def forward(self, x, noise_list=None):
         """x (B,3,N) xyz.  noise_list: optional per-sampler-layer Exp(1) tensors (parity tests)."""
@@ -54,10 +61,10 @@ class FeatureLearningBlock(nn.Module):
                     x_idx = ops.farthest_point_sample(torch.permute(x_xyz, (0, 2, 1)), self.M_list[i] * 2)
                     x = torch.gather(x, 2, x_idx.unsqueeze(1).expand(-1, x.shape[1], -1))
                     x_xyz_down = torch.gather(x_xyz, 2, x_idx.unsqueeze(1).expand(-1, 3, -1))
-                    (x, idx_select) = self.downsample_list[i](x, x_xyz_down, noise=noise)[0]
+                    (x, idx_select) = self._sample(i, x, x_xyz_down, noise)
                     idx_select = torch.gather(x_idx.unsqueeze(1), 2, idx_select)
                 else:
-                    (x, idx_select) = self.downsample_list[i](x, x_xyz, noise=noise)[0]
+                    (x, idx_select) = self._sample(i, x, x_xyz, noise)
                 x = self.feature_learning_layer_list[i + 1](x)
                 x_xyz = ops.gather_by_idx(x_xyz, idx_select)
                 res_link_list.append(self.conv_list[i + 1](x).max(dim=-1)[0])
@@ -65,7 +72,7 @@ class FeatureLearningBlock(nn.Module):
             return torch.cat(res_link_list, dim=1), res_link_list
         for i in range(len(self.downsample_list)):
             noise = None if noise_list is None else noise_list[i]
-            x = self.downsample_list[i](x, noise=noise)[0][0]
+            x = self._sample(i, x, None, noise)[0]
             x = self.feature_learning_layer_list[i + 1](x)
         return self.conv(x).max(dim=-1)[0]
 

@@ -38,8 +38,9 @@ int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, in
                            float*, long, float*, float*, float*, hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
-                          long, float*, hipStream_t);
-int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, hipStream_t);
+                          long, float*, int, hipStream_t);
+int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
+                          hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
@@ -404,13 +405,16 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
 }
 
 SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN,
-                                       int C, int heads, int diff, float* out, void* stream) {
+                                       int C, int heads, int diff, float* out, float* att, void* stream) {
   if (!qkv || !nn || !out) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: null pointer");
-  if (C != 128 || heads != 4) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128, 4 heads of 32");
+  if (C != 128 || (heads != 4 && heads != 1))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128 with 4 heads of 32 or 1 head of 128");
+  if (att && (heads != 1 || KN > 64))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: the probability output needs heads == 1 and K <= 64");
   if ((rs & 3) || (bs & 3) || rs < 3 * C) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad strides");
   if (B <= 0 || N <= 0 || KN <= 0) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad sizes");
   return done(samble_launch_n2p_fwd(qkv, bs, rs, nn, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), out,
-                                    (hipStream_t)stream),
+                                    heads, att, (hipStream_t)stream),
               "samble_n2p_attn_fwd_f32");
 }
 
@@ -438,13 +442,14 @@ SAMBLE_API int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs,
                                        int B, int N, int KN, int C, int heads, int diff, float* dqkv, int64_t dbs,
                                        int64_t drs, void* ws, size_t ws_bytes, void* stream) {
   if (!qkv || !nn || !g || !dqkv || !ws) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: null pointer");
-  if (C != 128 || heads != 4) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128, 4 heads of 32");
+  if (C != 128 || (heads != 4 && heads != 1))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128 with 4 heads of 32 or 1 head of 128");
   if (KN < 1 || KN > 32) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: need 1 <= K <= 32");
   if ((rs & 3) || (bs & 3) || (drs & 3) || (dbs & 3) || rs < 3 * C || drs < 3 * C)
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: bad strides");
   if (ws_bytes < samble_n2p_attn_bwd_workspace_bytes(B, N, KN))
     return fail(SAMBLE_E_WORKSPACE, "samble_n2p_attn_bwd_f32: workspace too small");
   return done(samble_launch_n2p_bwd(qkv, bs, rs, nn, g, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), dqkv,
-                                    dbs, drs, (float*)ws, (hipStream_t)stream),
+                                    dbs, drs, (float*)ws, heads, (hipStream_t)stream),
               "samble_n2p_attn_bwd_f32");
 }

@@ -12,10 +12,16 @@
 
 namespace samble {
 
-__device__ __forceinline__ float head_sum(float v) {
+// sum over the lanes of one head: hl = lanes per head = 32 / heads (8 for the 4 heads of N2P, 32 for
+// the single head of DownSampleLocal); wave-uniform
+__device__ __forceinline__ float head_sum(float v, int hl) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 4, 64);
+  if (hl > 8) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+  }
   return v;
 }
 
@@ -26,8 +32,11 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 // grid (ceil(N/32), B), 256 threads = 8 half-waves x 4 points each
 __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restrict__ qkv, long bs, long rs,
                                                            const int* __restrict__ nn, int N, int KN, int diff,
-                                                           float scale, float* __restrict__ out) {
+                                                           float scale, float* __restrict__ out, int heads,
+                                                           float* __restrict__ att) {
   __shared__ float tile[128 * 33];
+  __shared__ float lgs[8][64];  // att output: the logits of a half-wave's point (this lane's head), K <= 64
+  const int hl = 32 / heads;
   int chunk, b;
   xcd_assign(chunk, b);
   const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
@@ -44,7 +53,7 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
       if (diff) {
         kc = *reinterpret_cast<const f32x4*>(row + 128);
         vc = *reinterpret_cast<const f32x4*>(row + 256);
-        qkc = head_sum(dot4(q, kc));
+        qkc = head_sum(dot4(q, kc), hl);
       }
       const int* ni = nn + ((long)b * N + i) * KN;
       float m = kNegInf, l = 0.f;
@@ -60,9 +69,10 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float s = head_sum(dot4(q, kv[u]));
+          const float s = head_sum(dot4(q, kv[u]), hl);
           if (k0 + u < KN) {
             const float logit = (s - qkc) * scale;
+            if (att && heads == 1) lgs[hw][k0 + u] = logit;
             const float mn = fmaxf(m, logit);
             const float al = __expf(m - mn), p = __expf(logit - mn);
             l = l * al + p;
@@ -75,6 +85,9 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
       const float inv = 1.f / l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = acc[e] * inv - vc[e];
+      if (att && heads == 1) {  // (B,1,N,K) probabilities (reference attention_map of DownSampleLocal)
+        for (int k = c; k < KN; k += 32) att[((long)b * N + i) * KN + k] = __expf(lgs[hw][k] - m) * inv;
+      }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[(4 * c + e) * 33 + lp] = o[e];
@@ -92,9 +105,10 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
 using namespace samble;
 
 extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const int* nn, int B, int N, int KN, int diff,
-                                     float scale, float* out, hipStream_t s) {
+                                     float scale, float* out, int heads, float* att, hipStream_t s) {
+  if ((heads != 1 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
   hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
-                     out);
+                     out, heads, att);
   return (int)hipGetLastError();
 }
 
@@ -141,10 +155,11 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
                                                             const float* __restrict__ gt,  // (B,N,128)
                                                             int N, int KN, int diff, float scale,
                                                             float* __restrict__ dqkv, long dbs, long drs,
-                                                            float* __restrict__ A, float* __restrict__ DL) {
+                                                            float* __restrict__ A, float* __restrict__ DL, int heads) {
   int chunk, b;
   xcd_assign(chunk, b);
   const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
+  const int hl = 32 / heads;
   const float* base = qkv + (long)b * bs;
   for (int pp = 0; pp < 4; ++pp) {
     const int i = chunk * 32 + hw * 4 + pp;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
     float qkc = 0.f;
     if (diff) {
       kc = *reinterpret_cast<const f32x4*>(row + 128);
-      qkc = head_sum(dot4(q, kc));
+      qkc = head_sum(dot4(q, kc), hl);
     }
     const int* ni = nn + ((long)b * N + i) * KN;
     float lg[32], da[32];
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        lg[k0 + u] = (k0 + u < KN) ? (head_sum(dot4(q, kv[u])) - qkc) * scale : kNegInf;
-        da[k0 + u] = head_sum(dot4(g, vv[u]));
+        lg[k0 + u] = (k0 + u < KN) ? (head_sum(dot4(q, kv[u]), hl) - qkc) * scale : kNegInf;
+        da[k0 + u] = head_sum(dot4(g, vv[u]), hl);
       }
     }
     float m = kNegInf;
@@ -212,9 +227,9 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
           sdl += dl;
 #pragma unroll
           for (int e = 0; e < 4; ++e) dq[e] = fmaf(dl, kv[u][e] - kc[e], dq[e]);
-          if ((c & 7) == 0) {
-            Ai[k * 4 + (c >> 3)] = lg[k];
-            Di[k * 4 + (c >> 3)] = dl;
+          if ((c & (hl - 1)) == 0) {
+            Ai[k * 4 + c / hl] = lg[k];
+            Di[k * 4 + c / hl] = dl;
           }
         }
       }
@@ -243,7 +258,8 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
                                                                  const float* __restrict__ gt,
                                                                  const float* __restrict__ A,
                                                                  const float* __restrict__ DL, int N, int KN,
-                                                                 float* __restrict__ dqkv, long dbs, long drs) {
+                                                                 float* __restrict__ dqkv, long dbs, long drs,
+                                                                 int heads) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* acc = smem;                                              // [2][64][128]
   int* hits = reinterpret_cast<int*>(smem + 2 * kScatRows * 128);  // packed (i_local << 16) | (k << 8) | j_local
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
   int blk, b;
   xcd_assign(blk, b);
   const int tid = threadIdx.x;
-  const int c = tid & 127, which = tid >> 7, head = c >> 5;
+  const int c = tid & 127, which = tid >> 7, head = (heads == 4) ? c >> 5 : 0;
   const int j0 = blk * kScatRows;
   for (int e = tid; e < 2 * kScatRows * 128; e += 256) acc[e] = 0.f;
   const float* coef = which ? A : DL;
@@ -339,8 +355,9 @@ extern "C" size_t samble_n2p_bwd_ws_floats(int B, int N, int KN) {
 
 extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const int* nn, const float* g, int B, int N,
                                      int KN, int diff, float scale, float* dqkv, long dbs, long drs, float* ws,
-                                     hipStream_t s) {
+                                     int heads, hipStream_t s) {
   using namespace samble;
+  if (heads != 1 && heads != 4) return -22;
   float* gt = ws;
   float* A = gt + (size_t)B * N * 128;
   float* DL = A + (size_t)B * N * KN * 4;
@@ -354,8 +371,8 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
   }
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
   hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
-                     scale, dqkv, dbs, drs, A, DL);
+                     scale, dqkv, dbs, drs, A, DL, heads);
   hipLaunchKernelGGL(n2p_bwd_scatter_kernel, dim3((N + kScatRows - 1) / kScatRows, B), dim3(256), lds, s, qkv, bs, rs,
-                     nn, gt, A, DL, N, KN, dqkv, dbs, drs);
+                     nn, gt, A, DL, N, KN, dqkv, dbs, drs, heads);
   return (int)hipGetLastError();
 }

@@ -384,3 +384,148 @@ class DownSampleGlobal(nn.Module):
             x_tmp = self.ffn(x_res)
             x_res = self.bn2(x_ds + x_tmp)
         return x_res
+
+
+class _LocalCore(torch.autograd.Function):
+    """x (B,C,N), Conv2d weights -> local-attention output of EVERY point (B,C,N) [differentiable],
+    the (B,N,K) attention probabilities and the neighbour lists, for DownSampleLocal."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, K, diff):
+        C = x.shape[1]
+        w = torch.cat((wq, wk, wv), dim=0).reshape(3 * C, C)
+        qkv = ops.stage_proj_fwd(x, x.new_zeros((C, 0)), w)
+        nn_idx = ops.stage_knn(x, x, K)
+        out, att = ops.stage_n2p_attn_fwd(qkv, nn_idx, 1, diff, want_att=True)
+        ctx.save_for_backward(x, w, qkv, nn_idx)
+        ctx.cfg = (diff, wq.shape[0], wk.shape[0])
+        ctx.mark_non_differentiable(att, nn_idx)
+        return out, att, nn_idx
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        x, w, qkv, nn_idx = ctx.saved_tensors
+        diff, a, b = ctx.cfg
+        dqkv = ops.stage_n2p_attn_bwd(qkv, nn_idx, g, 1, diff)
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[1:4])
+        dx, dw, _ = ops.stage_proj_bwd(dqkv, x, x.new_zeros((x.shape[1], 0)), w, need_dx, need_dw)
+        if not need_dw:
+            return dx, None, None, None, None, None
+        C = x.shape[1]
+        return (dx, dw[:a].reshape(a, C, 1, 1), dw[a:a + b].reshape(b, C, 1, 1), dw[a + b:].reshape(-1, C, 1, 1),
+                None, None)
+
+
+class DownSampleLocal(nn.Module):
+    """Drop-in for the reference's local-attention sampler (models/downsample.py:818-1229): 1 x K
+    attention of every point over its K = 32 nearest neighbours in feature space, a per-point score
+    from that map (`local_std` or the sparse_* statistics), the top-M points kept and the N-M points
+    with the smallest map std returned as the dropped set.
+
+    On the kernels of Neighbor2PointAttention run with one head of 128 channels: one projection per
+    point (linearity of the 1x1 convs), the gather-attention kernel (which also emits the
+    probabilities), its atomics-free backward.  Because both outputs gather rows of the same
+    per-point attention result, x_ds / x_dropped are column gathers of one (B,C,N) tensor.
+    Outputs: ((x_ds (B,C,M), idx (B,1,M)), (x_dropped (B,C,N-M), idx_dropped (B,1,N-M)))."""
+
+    def __init__(self, config_ds, layer):
+        super().__init__()
+        self.M = config_ds.M[layer]
+        self.K = 32
+        self.asm = config_ds.asm[layer]
+        self.res = config_ds.res.enable[layer]
+        self.ff = config_ds.res.ff[layer]
+        self.num_heads = config_ds.num_heads[layer]
+        self.idx_mode = config_ds.idx_mode[layer]
+        q_in, q_out = config_ds.q_in[layer], config_ds.q_out[layer]
+        k_in, k_out = config_ds.k_in[layer], config_ds.k_out[layer]
+        v_in, v_out = config_ds.v_in[layer], config_ds.v_out[layer]
+        self.group_type = "diff" if self.asm == "dot" else "neighbor"
+        self.q_depth = int(q_out / self.num_heads)
+        self.k_depth = int(k_out / self.num_heads)
+        self.v_depth = int(v_out / self.num_heads)
+        self.q_conv = nn.Conv2d(q_in, q_out, 1, bias=False)
+        self.k_conv = nn.Conv2d(k_in, k_out, 1, bias=False)
+        self.v_conv = nn.Conv2d(v_in, v_out, 1, bias=False)
+        self.softmax = nn.Softmax(dim=-1)
+        if self.res:
+            self.bn1 = nn.BatchNorm1d(v_out)
+            if self.ff:
+                self.ffn = nn.Sequential(nn.Conv1d(128, 512, 1, bias=False), nn.LeakyReLU(negative_slope=0.2),
+                                         nn.Conv1d(512, 128, 1, bias=False))
+                self.bn2 = nn.BatchNorm1d(v_out)
+        self.num_bins = config_ds.bin.num_bins[layer]
+        self.scaling_factor = config_ds.bin.scaling_factor[layer]
+        self.bin_sample_mode = config_ds.bin.sample_mode[layer]
+        self.bin_norm_mode = config_ds.bin.norm_mode[layer]
+        self.boltzmann_enable = config_ds.boltzmann.enable[layer]
+        self.boltzmann_T = config_ds.boltzmann.boltzmann_T[layer]
+        self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
+        if self.asm not in ("dot", "dot-neighbor"):
+            if self.asm in ("dot-sub", "l2", "l2+"):
+                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (dot / dot-neighbor are)")
+            raise ValueError("Please check the setting of asm!")
+        if self.num_heads != 1 or not (q_in == q_out == k_in == k_out == v_in == v_out == 128):
+            raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
+        if self.idx_mode not in ("local_std", "sparse_row_std", "sparse_col_sum", "sparse_col_avg", "sparse_col_sqr"):
+            raise ValueError("Please check the setting of idx mode!")
+
+    def forward(self, x, x_xyz=None):
+        if not x.is_cuda:
+            raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
+        B, C, N = x.shape
+        x_all, att, nn_idx = _LocalCore.apply(x, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.K,
+                                              self.group_type == "diff")
+        self.neighbors_idx = nn_idx.long()
+        self.attention_map = att.view(B, 1, N, 1, self.K)
+        std = torch.std(att, dim=-1, unbiased=False)                      # (B,N)
+        if self.idx_mode == "local_std":
+            score = std
+        elif self.idx_mode == "sparse_row_std":
+            score = torch.std(att, dim=-1)                                   # the K scattered entries of the row
+        else:
+            flat = self.neighbors_idx.reshape(B, N * self.K)
+            colsum = torch.zeros((B, N), dtype=torch.float32, device=x.device).scatter_add_(1, flat, att.reshape(B, -1))
+            num = torch.zeros((B, N), dtype=torch.float32, device=x.device).scatter_add_(
+                1, flat, torch.ones_like(flat, dtype=torch.float32)) + 1e-8
+            score = {"sparse_col_sum": colsum, "sparse_col_avg": colsum / num,
+                     "sparse_col_sqr": colsum / num / num}[self.idx_mode]
+        self.attention_point_score = score.unsqueeze(1)
+        idx = ops.stage_topk_indices(score, self.M, largest=True)
+        if self.boltzmann_enable:
+            idx = self.boltzmann_idx_selection()[:, 0]
+        idx_dropped = ops.stage_topk_indices(std, N - self.M, largest=False)
+        self.idx = idx.unsqueeze(1)
+        x_ds = torch.gather(x_all, 2, self.idx.expand(-1, C, -1))
+        x_dropped = torch.gather(x_all, 2, idx_dropped.unsqueeze(1).expand(-1, C, -1))
+        if self.res == True:  # noqa: E712
+            x_ds = self.res_block(x, x_ds)
+        return (x_ds, self.idx), (x_dropped, idx_dropped.unsqueeze(1))
+
+    def boltzmann_idx_selection(self):
+        """reference models/downsample.py:1205-1229: softmax(norm_range(score) / T) -> multinomial without replacement."""
+        s = self.attention_point_score
+        mode = self.boltzmann_norm_mode
+        if mode == "minmax":
+            lo = torch.min(s, dim=-1, keepdim=True)[0]
+            sn = (s - lo) / (torch.max(s, dim=-1, keepdim=True)[0] - lo + 1e-8)
+        elif mode == "z-score":
+            sn = (s - torch.mean(s, dim=-1, keepdim=True)) / torch.std(s, dim=-1, unbiased=False, keepdim=True)
+        elif mode == "sigmoid":
+            sn = torch.sigmoid(s)
+        elif mode == "tanh":
+            sn = (torch.tanh(s) + 1.0) / 2
+        else:
+            raise ValueError(f"norm_range mode should be minmax, sigmoid or tanh, but got {mode}")
+        p = F.softmax(sn / self.boltzmann_T, dim=-1)
+        B, H, N = p.shape
+        return torch.multinomial(p.reshape(B * H, N), self.M, replacement=False).view(B, H, self.M)
+
+    def res_block(self, x, x_ds):
+        x_tmp = torch.gather(x, dim=-1, index=self.idx)
+        x_res = self.bn1(x_ds + x_tmp)
+        if self.ff == True:  # noqa: E712
+            x_tmp = self.ffn(x_res)
+            x_res = self.bn2(x_ds + x_tmp)
+        return x_res

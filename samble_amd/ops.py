@@ -97,16 +97,18 @@ def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
     return dx, dw, dtok
 
 
-def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff: bool) -> torch.Tensor:
-    """qkv (B,N,3C) point-major [Q|K|V], nn_idx (B,N,K) int32 -> (B,C,N) attention output."""
+def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff: bool, want_att: bool = False):
+    """qkv (B,N,3C) point-major [Q|K|V], nn_idx (B,N,K) int32 -> (B,C,N) attention output
+    [, (B,N,K) softmax probabilities when want_att (single head only)]."""
     _need_gpu(qkv, nn_idx)
     B, N, C3 = qkv.shape
     C = C3 // 3
     with torch.cuda.device(qkv.device):
         out = torch.empty((B, C, N), dtype=torch.float32, device=qkv.device)
+        att = torch.empty((B, N, nn_idx.shape[2]), dtype=torch.float32, device=qkv.device) if want_att else None
         _lib.call("samble_n2p_attn_fwd_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), nn_idx.data_ptr(), B, N,
-                  nn_idx.shape[2], C, heads, int(bool(diff)), out.data_ptr(), _stream())
-    return out
+                  nn_idx.shape[2], C, heads, int(bool(diff)), out.data_ptr(), _p(att), _stream())
+    return (out, att) if want_att else out
 
 
 def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor, heads: int, diff: bool) -> torch.Tensor:
