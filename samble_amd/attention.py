@@ -130,6 +130,91 @@ class Neighbor2PointAttention(nn.Module):
         return x
 
 
+class _P2PCore(torch.autograd.Function):
+    """qkv (B,N,3D) point-major -> softmax(QK^T/sqrt(D)) V for every row, (B,D,N): the single-pass flash
+    kernels of the sampler (no N x N tensor), backward over all N rows."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        B, N, D3 = qkv.shape
+        D = D3 // 3
+        q, k, v = qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:]
+        O, lse, _ = ops.stage_attn_fwd(q, k, v, N, 0)
+        ctx.save_for_backward(qkv, O, lse)
+        return O.permute(0, 2, 1).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, O, lse = ctx.saved_tensors
+        B, N, D3 = qkv.shape
+        D = D3 // 3
+        rows = torch.arange(N, device=qkv.device, dtype=torch.int64).unsqueeze(0).expand(B, -1).contiguous()
+        dqkv = torch.empty_like(qkv)
+        ops.stage_attn_bwd(qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], O, lse, rows, g, N, 0,
+                           dqkv[:, :, 0:D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:])
+        return dqkv
+
+
+class Point2PointAttention(nn.Module):
+    """Drop-in for the reference's global self-attention layer (models/attention.py:253-355, asm 'dot'):
+    same constructor, state_dict keys (`q_conv/k_conv/v_conv.weight` (C,C,1), `ff.*`, `bn1/bn2.*`) and
+    forward (B,C,N) -> (B,C,N).  Built on the sampler's kernels for ONE head of 128 channels (the
+    fp32-MFMA projection and the flash attention forward / backward); the reference default of 4 heads
+    of 32 channels needs a D = 32 kernel that does not exist yet."""
+
+    def __init__(self, config_attention, layer):
+        num_heads = config_attention.num_heads[layer]
+        q_in, q_out = config_attention.q_in[layer], config_attention.q_out[layer]
+        k_in, k_out = config_attention.k_in[layer], config_attention.k_out[layer]
+        v_in, v_out = config_attention.v_in[layer], config_attention.v_out[layer]
+        super().__init__()
+        self.attention_mode = config_attention.attention_mode[layer]
+        self.asm = config_attention.asm[layer]
+        if q_in != k_in or q_in != v_in or k_in != v_in:
+            raise ValueError(f"q_in, k_in and v_in should be the same! Got q_in:{q_in}, k_in:{k_in}, v_in:{v_in}")
+        if q_out != k_out:
+            raise ValueError("q_out should be equal to k_out!")
+        if q_out % num_heads != 0 or k_out % num_heads != 0 or v_out % num_heads != 0:
+            raise ValueError("please set another value for num_heads!")
+        if q_in != v_out:
+            raise ValueError(f"q_in should be equal to v_out due to ResLink! Got q_in: {q_in}, v_out: {v_out}")
+        self.num_heads = num_heads
+        self.q_depth = int(q_out / num_heads)
+        self.k_depth = int(k_out / num_heads)
+        self.v_depth = int(v_out / num_heads)
+        self.q_conv = nn.Conv1d(q_in, q_out, 1, bias=False)
+        self.k_conv = nn.Conv1d(k_in, k_out, 1, bias=False)
+        self.v_conv = nn.Conv1d(v_in, v_out, 1, bias=False)
+        self.softmax = nn.Softmax(dim=-1)
+        self.ff = nn.Sequential(
+            nn.Conv1d(config_attention.ff_conv1_channels_in[layer], config_attention.ff_conv1_channels_out[layer], 1,
+                      bias=False),
+            nn.LeakyReLU(negative_slope=0.2),
+            nn.Conv1d(config_attention.ff_conv2_channels_in[layer], config_attention.ff_conv2_channels_out[layer], 1,
+                      bias=False),
+        )
+        self.bn1 = nn.BatchNorm1d(v_out)
+        self.bn2 = nn.BatchNorm1d(v_out)
+        if self.asm != "dot":
+            if self.asm in ("l2", "l2+"):
+                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (only 'dot')")
+            raise ValueError("Please check the setting of asm in feature learning layer!")
+        if num_heads != 1 or not (q_in == q_out == v_out == 128):
+            raise NotImplementedError("the HIP attention kernels are built for one head of 128 channels")
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise ops._lib.SambleError("samble_amd.Point2PointAttention runs on the GPU only (no CPU fallback)")
+        from .downsample import _Projection
+        no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
+        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
+        x_tmp = _P2PCore.apply(qkv)
+        x = self.bn1(x + x_tmp)
+        x_tmp = self.ff(x)
+        x = self.bn2(x + x_tmp)
+        return x
+
+
 def attention_config(preset: str = "cls"):
     """`config.feature_learning_block.attention` of the shipped presets (three N2P layers, K=32,
     diff grouping, 4 heads, 128 channels, FFN 128-512-128)."""

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .attention import Neighbor2PointAttention
+from .attention import Neighbor2PointAttention, Point2PointAttention
 from .downsample import DownSampleGlobal, DownSampleLocal, DownSampleToken
 from .embedding import EdgeConv
 
@@ -24,13 +24,15 @@ class FeatureLearningBlock(nn.Module):
         sampler = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}.get(cfg.downsample.ds_which)
         if sampler is None:
             raise NotImplementedError
-        if getattr(cfg.attention, "fl_which", "n2p") != "n2p":
-            raise ValueError("Only n2p is built for fl_which")
+        fl_which = getattr(cfg.attention, "fl_which", "n2p")
+        if fl_which not in ("n2p", "p2p"):
+            raise ValueError("Only n2p and p2p are valid for fl_which")
+        layer_cls = Neighbor2PointAttention if fl_which == "n2p" else Point2PointAttention
         self.res_link_enable = cfg.res_link.enable
         self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
         self.downsample_list = nn.ModuleList([sampler(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
         self.feature_learning_layer_list = nn.ModuleList(
-            [Neighbor2PointAttention(cfg.attention, l) for l in range(len(cfg.attention.K))])
+            [layer_cls(cfg.attention, l) for l in range(len(cfg.attention.K))])
         outs = cfg.attention.ff_conv2_channels_out
         if self.res_link_enable:
             self.conv_list = nn.ModuleList([nn.Conv1d(c, 1024, kernel_size=1, bias=False) for c in outs])

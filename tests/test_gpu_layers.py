@@ -259,3 +259,38 @@ def test_downsample_local_against_reference_fixture(name):
             assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
     else:
         pytest.skip("index order differs at a near-tie; sets agree")
+
+
+def test_point2point_attention_matches_torch_restatement():
+    """Point2PointAttention (reference models/attention.py:253-355) with one head of 128 channels against
+    the same expression in fp64 torch (conv1d -> softmax(QK^T/sqrt D) V -> bn1 -> ff -> bn2), fwd + bwd."""
+    from samble_amd.attention import Point2PointAttention, attention_config
+    from samble_amd.config import to_attr
+    cfg = attention_config("cls")
+    cfg["num_heads"] = [1, 1, 1]
+    mod = Point2PointAttention(to_attr(cfg), 0)
+    assert sorted(k for k in mod.state_dict() if k.endswith("conv.weight")) == ["k_conv.weight", "q_conv.weight", "v_conv.weight"]
+    B, C, N = 2, 128, 300
+    with torch.no_grad():
+        for i, p in enumerate(mod.parameters()):
+            if p.dim() > 1:
+                p.copy_(_w(tuple(p.shape), 8100 + i, 0.09))
+    mod = mod.to(DEV).train()
+    x = torch.from_numpy(synth.features(B, C, N, 8200)).to(DEV).requires_grad_(True)
+    g = torch.from_numpy(synth.normal((B, C, N), 8201)).to(DEV)
+    y = mod(x)
+    y.backward(g)
+    # restatement in fp64 on the CPU with the same parameters
+    import copy
+    ref = copy.deepcopy(mod).cpu().double().train()
+    xd = x.detach().cpu().double().requires_grad_(True)
+    q, k, v = ref.q_conv(xd), ref.k_conv(xd), ref.v_conv(xd)
+    att = torch.softmax(q.permute(0, 2, 1) @ k / np.sqrt(128.0), dim=-1)
+    xt = (att @ v.permute(0, 2, 1)).permute(0, 2, 1)
+    h = ref.bn1(xd + xt)
+    yr = ref.bn2(h + ref.ff(h))
+    yr.backward(g.cpu().double())
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), rtol=2e-4, atol=2e-4)
+    assert (x.grad.cpu().double() - xd.grad).abs().max().item() <= 5e-4 * xd.grad.abs().max().item()
+    for (n1, p1), (_, p2) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert (p1.grad.cpu().double() - p2.grad).abs().max().item() <= 1e-3 * p2.grad.abs().max().item() + 1e-6, n1

@@ -96,3 +96,23 @@ def test_oracle_fps_reproduces_reference_fixture():
     xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed)).permute(0, 2, 1).contiguous()
     got = O.farthest_point_sample(xyz, npoint, torch.from_numpy(d["start"]))
     assert torch.equal(got, torch.from_numpy(d["idx"]))
+
+
+def test_oracle_local_sampler_reproduces_reference_fixtures():
+    """DownSampleLocal restatement vs what the reference produced (layer_local_*.npz)."""
+    from samble_amd import synth
+    from tests.util import layer_fixture
+
+    def w(shape, seed, scale):
+        return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
+
+    for name in ("layer_local_std", "layer_local_colsqr"):
+        d = layer_fixture(name)
+        B, C, N, M, seed = [int(v) for v in d["meta"]]
+        x = torch.from_numpy(synth.features(B, C, N, seed))
+        (x_ds, idx), (x_dr, idx_dr), score, att = O.local_sampler_forward(
+            x, w((C, C, 1, 1), seed + 1, 0.09), w((C, C, 1, 1), seed + 2, 0.09), w((C, C, 1, 1), seed + 3, 0.09), M,
+            str(d["idx_mode"]))
+        torch.testing.assert_close(score, torch.from_numpy(d["score"]), rtol=1e-4, atol=1e-7)
+        assert torch.equal(idx, torch.from_numpy(d["idx"])) and torch.equal(idx_dr, torch.from_numpy(d["idx_dropped"]))
+        torch.testing.assert_close(x_ds, torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=1e-5)
