@@ -194,7 +194,9 @@ int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float*
  * so S = Q K^T / sqrt(D) is computed once and kept: smap (B, N, ld) row-major,
  * ld >= samble_attn_map_row_stride(N, nt) = 32 * ceil((N+nt)/32), columns N..N+nt-1 = token logits,
  * columns >= N+nt = -inf.  Caller-owned like every other buffer (538 MB at B=32, N=2048).
- *   samble_attn_stats_f32       pass 1, all N rows: smap, lse (B,N), tok (B,N,nt)
+ *   samble_attn_stats_f32       pass 1, all N rows: smap, lse (B,N), tok (B,N,nt).  asm "dot": q_sqnorm =
+ *                               k_sqnorm = NULL.  asm "l2" (downsample.py:154-175, S = -|q-k|^2/sqrt(D)):
+ *                               q_sqnorm (B,N) = |q_i|^2 and k_sqnorm (B,ld), zero padded, = |k_j|^2
  *                               replaces q@k, /sqrt(D), the softmax normaliser and the token split
  *                               (models/downsample.py:139-153)
  *   samble_sparse_score_map_f32 = samble_sparse_score_f32 reading A_ij = exp(S_ij - lse_i) from the map
@@ -202,10 +204,15 @@ int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float*
  *   samble_attn_rows_fwd_f32    pass 2, the M sampled rows: x_ds (B,D,M) = softmax(S[idx]) V
  *                               replaces gather + @v + permute (models/downsample.py:242-252)
  *   samble_attn_rows_bwd_f32    = samble_attn_bwd_f32 reading S from the map (4 matrix products per
- *                               tile instead of 5) and O from x_ds (B,D,M) */
+ *                               tile instead of 5) and O from x_ds (B,D,M).  ds_colsum: NULL for asm "dot".
+ *                               For "l2" pass a (B, N+nt) buffer: it receives c_j = sum_i dS_ij, the token
+ *                               logits are taken as -|q-k|^2, and dQ / dK come out as for "dot"; the caller
+ *                               finishes with dQ *= 2, dK_j = 2 dK_j - 2 c_j k_j (dS rows sum to zero, so
+ *                               the |q|^2 term drops out) */
 int samble_attn_map_row_stride(int N, int nt);
 int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs, int B,
-                          int N, int nt, int D, float* smap, int ld, float* lse, float* tok, void* stream);
+                          int N, int nt, int D, float* smap, int ld, float* lse, float* tok, const float* q_sqnorm,
+                          const float* k_sqnorm, void* stream);
 int samble_sparse_score_map_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N, int KN,
                                 int mode, float* score, float* z, int32_t* indeg_out, void* ws, size_t ws_bytes,
                                 void* stream);
@@ -215,7 +222,7 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
                              const float* V, int64_t v_bs, int64_t v_rs, const float* smap, int ld, const float* lse,
                              const float* x_ds, const int64_t* idx, const float* g, int B, int N, int nt, int M, int D,
                              float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
-                             int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes, void* stream);
+                             int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,10 +141,28 @@ def project_qkv(x, tokens, wq, wk, wv):
     return q, k, v
 
 
-def attention_map(q, k, n_points: int):
-    """energy = q@k / sqrt(D); softmax over all N+nt columns (downsample.py:139-153).
+def l2_global(q, k):
+    """reference utils/ops.py:115-122: q (B,H,N,D), k (B,H,D,N') -> |q_i - k_j|^2 (B,H,N,N')."""
+    inner = -2 * torch.matmul(q, k)
+    qq = torch.sum(q ** 2, dim=-1, keepdim=True)
+    kk = torch.sum(k.transpose(-2, -1) ** 2, dim=-1, keepdim=True)
+    return qq + inner + kk.transpose(-2, -1)
+
+
+def attention_logits(q, k, asm: str = "dot"):
+    """downsample.py:139-143 (dot) / 154-175 (l2: -|q-k|^2; the reference also projects the token
+    columns through q_conv and drops those rows again, which changes nothing for rows :N)."""
+    if asm == "dot":
+        return (q @ k) / math.sqrt(q.shape[-1])
+    if asm == "l2":
+        return (-1 * l2_global(q, k)) / math.sqrt(q.shape[-1])
+    raise NotImplementedError
+
+
+def attention_map(q, k, n_points: int, asm: str = "dot"):
+    """energy / sqrt(D); softmax over all N+nt columns (downsample.py:139-153, 154-189).
     Returns (A (B,1,N,N+nt), A_points (B,1,N,N), token logits (B,1,N,nt))."""
-    logits = (q @ k) / math.sqrt(q.shape[-1])
+    logits = attention_logits(q, k, asm)
     A = torch.softmax(logits, dim=-1)
     _, tok_logits = torch.split(logits, n_points, dim=-1)
     A_pts, _ = torch.split(A, n_points, dim=-1)
@@ -365,12 +383,12 @@ def sampler_forward(spec: SamplerSpec, st: SamplerState, x: torch.Tensor,
     global generator, exactly like the reference).  `world_mean` stands in for the
     all_reduce/world_size of utils/ops.py:191-199: a callable applied to the raw
     quantiles (None = single process).  Every intermediate lands in st.trace."""
-    if spec.asm != "dot":
-        raise NotImplementedError("oracle covers asm=dot (the shipped configs)")
+    if spec.asm not in ("dot", "l2"):
+        raise NotImplementedError("oracle covers asm=dot (the shipped configs) and l2")
     B, C, N = x.shape
     nb = spec.num_bins
     q, k, v = project_qkv(x, st.tokens, st.wq, st.wk, st.wv)
-    A, A_pts, tok_logits = attention_map(q, k, N)
+    A, A_pts, tok_logits = attention_map(q, k, N, spec.asm)
     score, nn_idx, indeg = point_score(x, A_pts, spec.K, spec.idx_mode)
 
     z = zscore(score)
@@ -394,7 +412,7 @@ def sampler_forward(spec: SamplerSpec, st: SamplerState, x: torch.Tensor,
         q=q, k=k, v=v, tok_logits=tok_logits, score=score, knn_idx=nn_idx, indeg=indeg,
         z=z, quantiles=quant, upper=st.boundaries[0].clone(), lower=st.boundaries[1].clone(),
         member=member, w=w, w_pre=w_pre, cap=cap, counts=counts, idx=idx, x_ds=x_ds,
-        lse=torch.logsumexp((q @ k) / math.sqrt(q.shape[-1]), dim=-1),
+        lse=torch.logsumexp(attention_logits(q, k, spec.asm), dim=-1),
     )
     return x_ds, idx
 

@@ -67,7 +67,7 @@ _SIGNATURES = {
     "samble_debug_kernel_ms": (c_float, []),
     "samble_attn_map_row_stride": (c_int, [c_int, c_int]),
     "samble_attn_stats_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
-                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_sparse_score_map_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_attn_rows_fwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,
@@ -75,7 +75,7 @@ _SIGNATURES = {
     "samble_attn_rows_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                          c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-                                         c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -44,10 +44,10 @@ int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, i
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
-                           long, float*, long, long, hipStream_t);
+                           long, float*, long, long, int, float*, float*, hipStream_t);
 int samble_attn_map_ld(int N, int nt);
 int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
-                             float*, float*, hipStream_t);
+                             float*, float*, const float*, const float*, hipStream_t);
 int samble_launch_attn_rows(const float*, int, const float*, const float*, long, long, const long long*, int, int, int,
                             int, float*, hipStream_t);
 int samble_launch_sparse_score_map(const float*, int, const float*, const int*, int, int, int, int, float*, float*, int*,
@@ -250,7 +250,7 @@ SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int
 }
 
 SAMBLE_API size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D) {
-  const size_t tok_part = (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
+  const size_t tok_part = (size_t)B * ((M + 31) / 32) * (2 * 8 * 128 + 8);  // + 8: dS column sums per token (l2)
   return ((size_t)B * M * D * 2 + (size_t)B * M * 2 + tok_part + samble_attn_bwd_slab_floats(B, N, M) + 64) *
          sizeof(float);
 }
@@ -260,7 +260,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
                            const float* smap, int ld, const float* lse, const int64_t* idx, const float* g, int B, int N,
                            int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
                            int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
-                           void* stream) {
+                           void* stream, int l2 = 0, float* cs = nullptr) {
   char msg[160];
   if (!Q || !K || !V || (!O && !Oc) || !lse || !idx || !g || !dQ || !dK || !dV || !ws) {
     snprintf(msg, sizeof msg, "%s: null pointer", who);
@@ -294,10 +294,11 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   float* lse_s = dOb + (size_t)B * M * D;
   float* delta = lse_s + (size_t)B * M;
   float* tok_part = delta + (size_t)B * M;
-  float* slab = tok_part + (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
+  float* cs_part = tok_part + (size_t)B * ((M + 31) / 32) * 2 * 8 * 128;
+  float* slab = cs_part + (size_t)B * ((M + 31) / 32) * 8;
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
                                      (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
-                                     slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, s),
+                                     slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part, s),
               who);
 }
 
@@ -317,18 +318,20 @@ SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_
                                         int ld, const float* lse, const float* x_ds, const int64_t* idx, const float* g,
                                         int B, int N, int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs,
                                         float* dK, int64_t dk_bs, int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs,
-                                        void* ws, size_t ws_bytes, void* stream) {
+                                        float* ds_colsum, void* ws, size_t ws_bytes, void* stream) {
   if (!smap || !x_ds) return fail(SAMBLE_E_INVALID, "samble_attn_rows_bwd_f32: null pointer");
   return attn_bwd_common("samble_attn_rows_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap, ld,
                          lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
-                         stream);
+                         stream, ds_colsum ? 1 : 0, ds_colsum);
 }
 
 SAMBLE_API int samble_attn_map_row_stride(int N, int nt) { return samble_attn_map_ld(N, nt); }
 
 SAMBLE_API int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
                                      int64_t k_rs, int B, int N, int nt, int D, float* smap, int ld, float* lse,
-                                     float* tok, void* stream) {
+                                     float* tok, const float* q_sqnorm, const float* k_sqnorm, void* stream) {
+  if ((q_sqnorm == nullptr) != (k_sqnorm == nullptr))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: l2 scoring needs both squared-norm arrays");
   if (!Q || !K || !smap || !lse) return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: D must be 128");
   if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (nt > 0 && !tok))
@@ -339,7 +342,7 @@ SAMBLE_API int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs,
     return fail(SAMBLE_E_INVALID, "samble_attn_stats_f32: map row stride must be >= samble_attn_map_row_stride(N, nt), "
                                   "a multiple of 4, and N * ld < 2^31");
   return done(samble_launch_attn_stats(Q, q_bs, q_rs, K, k_bs, k_rs, B, N, nt, inv_sqrt_d(D), smap, ld, lse, tok,
-                                       (hipStream_t)stream),
+                                       q_sqnorm, k_sqnorm, (hipStream_t)stream),
               "samble_attn_stats_f32");
 }
 

@@ -33,10 +33,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
                                                        int N, int nt, int M, float scale, float* __restrict__ Qs,
                                                        float* __restrict__ dO, float* __restrict__ lse_s,
                                                        float* __restrict__ delta, float* __restrict__ tok_part,
-                                                       float* __restrict__ slab, int nslab, int tok_slab) {
+                                                       float* __restrict__ slab, int nslab, int tok_slab, int l2,
+                                                       float* __restrict__ cs_part) {
   __shared__ float gt[128 * 33];
   __shared__ float red[4][2][8][128];  // [wave][dK|dV][token][channel]
   __shared__ float dred[8][32];
+  __shared__ float csred[8][8];
   const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
   const float* gb = g + (long)b * 128 * M;
   // O either as rows of the all-rows forward output (O, gathered by idx below) or as the sampled rows'
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
   const int sub = tid >> 5, l32 = tid & 31;  // 8 half-waves, each one row at a time
   // token keys / values: this lane's 4 channels of each of the nt (<= 8) rows
   f32x4 kt[8], vt[8], ak[8], av[8];
+  float ktt[8], acs[8];  // l2 scoring: |k_tok|^2; column sums of dS over this half-wave's rows
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -61,6 +64,11 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     vt[t] = (t < nt) ? *reinterpret_cast<const f32x4*>(V + (long)b * v_bs + (long)(N + t) * v_rs + 4 * l32) : z4;
     ak[t] = z4;
     av[t] = z4;
+    acs[t] = 0.f;
+    float kk = kt[t][0] * kt[t][0] + kt[t][1] * kt[t][1] + kt[t][2] * kt[t][2] + kt[t][3] * kt[t][3];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) kk += __shfl_xor(kk, off, 64);
+    ktt[t] = kk;
   }
   for (int rr = sub; rr < 32; rr += 8) {
     const int m = m0 + rr;
@@ -89,6 +97,9 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     // token keys: P and dS of this row against each token, accumulated into this lane's channels;
     // their share of dQ of this row (sum_t dS_t K_tok[t]) goes to the extra dQ slab
     f32x4 dqt = {0.f, 0.f, 0.f, 0.f};
+    float qq = qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) qq += __shfl_xor(qq, off, 64);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t < nt) {
@@ -99,8 +110,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
           st += __shfl_xor(st, off, 64);
           dpt += __shfl_xor(dpt, off, 64);
         }
+        if (l2) st = 2.f * st - qq - ktt[t];  // -|q - k_tok|^2
         const float p = __expf(st * scale - lrow);
         const float ds = p * (dpt - part) * scale;
+        acs[t] += ds;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           av[t][u] = fmaf(p, dv[u], av[t][u]);
@@ -127,6 +140,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
         }
       }
     }
+    if (cs_part && l32 == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) csred[sub][t] = acs[t];
+    }
     __syncthreads();
     float* outp = tok_part + ((long)b * gridDim.x + blockIdx.x) * 2 * 8 * 128;
     for (int e = tid; e < 2 * 8 * 128; e += 256) {
@@ -135,6 +152,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
       for (int w4 = 0; w4 < 4; ++w4) sacc += (&red[w4][0][0][0])[e];
       outp[e] = sacc;
     }
+    if (cs_part && tid < 8) {  // column sums of dS over this workgroup's rows, per token
+      float sacc = 0.f;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) sacc += csred[s8][tid];
+      cs_part[((long)b * gridDim.x + blockIdx.x) * 8 + tid] = sacc;
+    }
   }
 }
 
@@ -142,8 +165,18 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
 // grid (16 = dK|dV x token, B), 128 threads = channels
 __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __restrict__ tok_part, int nparts, int N,
                                                                 int nt, float* __restrict__ dK, long dk_bs, long dk_rs,
-                                                                float* __restrict__ dV, long dv_bs, long dv_rs) {
+                                                                float* __restrict__ dV, long dv_bs, long dv_rs,
+                                                                const float* __restrict__ cs_part,
+                                                                float* __restrict__ cs) {
   const int b = blockIdx.y, which = blockIdx.x >> 3, t = blockIdx.x & 7, d = threadIdx.x;
+  if (blockIdx.x == 16) {  // l2 scoring: column sums of dS for the token keys -> cs[b][N + t]
+    if (cs && d < nt) {
+      float sacc = 0.f;
+      for (int p = 0; p < nparts; ++p) sacc += cs_part[((long)b * nparts + p) * 8 + d];
+      cs[(long)b * (N + nt) + N + d] = sacc;
+    }
+    return;
+  }
   if (t >= nt) return;
   const float* src = tok_part + (long)b * nparts * 2 * 8 * 128 + (which * 8 + t) * 128 + d;
   float sacc = 0.f;
@@ -524,7 +557,7 @@ using namespace samble;
 
 extern "C" int samble_launch_bwd_rows(const float*, const float*, const float*, const float*, const float*, long, long,
                                       const float*, long, long, int, int, int, float, float*, long, long, float*, long,
-                                      long, float*, int, const float*, int, const long long*, hipStream_t);
+                                      long, float*, int, const float*, int, const long long*, float*, int, hipStream_t);
 
 static int g_bwd_split = 0;  // debug: 1 = the two-kernel backward (bwd_dq + bwd_dkdv) for A/B checks
 extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_split(int on) { g_bwd_split = on; }
@@ -539,7 +572,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                                       const float* g, int B, int N, int nt, int M, float scale, float* Qs, float* dOb,
                                       float* lse_s, float* delta, float* tok_part, float* slab, float* dQ, long dq_bs,
                                       long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                      hipStream_t stream) {
+                                      int l2, float* cs, float* cs_part, hipStream_t stream) {
+  // l2 != 0 (map path only): token logits are -|q-k|^2 and cs (B, N+nt) receives the column sums of dS
   // O (B,N,128) rows of the single-pass forward, or Oc (B,128,M) = x_ds of attn_rows; smap (B,N,ld) =
   // the logit map of attn_stats (then S is read, not recomputed) or null
   static bool attr_set = false;
@@ -566,11 +600,12 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   //  only, so give it a view with the cloud stride folded in below)
   hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
-                     fused ? kb + 1 : 0, kb);
+                     fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr);
   if (fused) {
     if (smap) {
       const int rc = samble_launch_bwd_rows(Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, B, N, M, scale, dK, dk_bs,
-                                            dk_rs, dV, dv_bs, dv_rs, slab, kb + 1, smap, ld, idx, stream);
+                                            dk_rs, dV, dv_bs, dv_rs, slab, kb + 1, smap, ld, idx, l2 ? cs : nullptr, nt,
+                                            stream);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(bwd_fused_kernel, dim3(kb, B), dim3(256), lds_fused, stream, Qs, dOb, lse_s, delta, K, k_bs, k_rs,
@@ -587,7 +622,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   }
   (void)tok_slab;
   if (nt > 0)
-    hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(16, B), dim3(128), 0, stream, tok_part, nparts, N, nt, dK, dk_bs,
-                       dk_rs, dV, dv_bs, dv_rs);
+    hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(l2 ? 17 : 16, B), dim3(128), 0, stream, tok_part, nparts, N, nt, dK,
+                       dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs_part : nullptr, l2 ? cs : nullptr);
   return (int)hipGetLastError();
 }

@@ -38,12 +38,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kStoreAux = SAMBLE_MAP_STORE_AUX;  // cache policy of the map stores: 0 plain, 2 nt, 16 sc1, 18 nt sc1
 constexpr int kStPad = 36;  // row stride (floats) of a wave's 32x32 transpose tile: 16-byte aligned, 9 x 16 B (odd)
 
-template <bool TAIL, int ABL>
+template <bool TAIL, int ABL, bool L2>
 __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo, int h, const float (&q)[64],
                                            f32x16& s_cur, f32x16& s_nxt, float scale, float* __restrict__ xt,
                                            float* __restrict__ gdst, __amdgpu_buffer_rsrc_t rsrc,
                                            const int (&roff)[4], int j0, int N, int NK,
-                                           float* __restrict__ tokrow, float& m, float& l) {
+                                           float* __restrict__ tokrow, float& m, float& l, float qb,
+                                           const float (&kb)[16]) {
   const f32x4* lp = reinterpret_cast<const f32x4*>(Kn + lo * kLdsPad + 64 * h);
   const int lane = lo + 32 * h;
   float mt = kNegInf, ps = 0.f;
@@ -57,7 +58,8 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * q4 + e;
-        float v = s_cur[r] * scale;
+        // dot: <q,k>/sqrt(D);  l2: -|q-k|^2/sqrt(D) = (2<q,k> - |q|^2 - |k|^2)/sqrt(D), qb / kb = the norms x scale
+        float v = L2 ? fmaf(s_cur[r], 2.f * scale, -qb) - kb[r] : s_cur[r] * scale;
         if (TAIL) {
           const int j = j0 + crow(r, h);
           if (j >= NK) v = kNegInf;
@@ -98,12 +100,14 @@ __device__ __forceinline__ void stats_step(const float* __restrict__ Kn, int lo,
 }
 
 // ABL (timing-only ablations, wrong outputs): 1 = no map stores, 2 = no tile staging
-template <int NW, int ABL = 0>
+template <int NW, int ABL = 0, bool L2 = false>
 __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                                 const float* __restrict__ K, long k_bs, long k_rs,
                                                                 int N, int NK, float scale, float* __restrict__ smap,
                                                                 int ld, float* __restrict__ lse,
-                                                                float* __restrict__ tok, int nt) {
+                                                                float* __restrict__ tok, int nt,
+                                                                const float* __restrict__ qn,
+                                                                const float* __restrict__ kn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kBuf = kTile * kLdsPad;
   const int tid = threadIdx.x;
@@ -134,6 +138,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
   __syncthreads();
   f32x16 s_cur = mma_rows_x_regs(smem, kLdsPad, lo, h, q, zero16());
   f32x16 s_nxt;
+  // l2 scoring: |q_i|^2 x scale of this lane's row and |k_j|^2 x scale of its 16 keys per tile (kn is
+  // zero-padded to ld columns by the caller), the next tile's fetched one iteration ahead
+  float qb = 0.f, kb_cur[16], kb_nxt[16];
+  const float* knb = L2 ? kn + (long)b * ld + 4 * h : nullptr;
+  auto load_kb = [&](int tile, float (&dst)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(knb + tile * kTile + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[4 * g + e] = v4[e] * scale;
+    }
+  };
+  if (L2) {
+    qb = qn[(long)b * N + qrow] * scale;
+    load_kb(0, kb_cur);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kb_cur[r] = kb_nxt[r] = 0.f;
+  }
 
   // destination of the transposed store: lane L writes rows (L>>3)+8k of the wave's 32; rows past N-1
   // carry row N-1's values (clamped q above) and are folded onto row N-1
@@ -161,21 +184,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
       const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
       const int j0 = t * kTile;
       if (ABL != 2) tile_load_issue(kr2, Kb, k_rs, j0 + 3 * kTile, NK, tid);
-      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      if (L2) load_kb(t + 1, kb_nxt);
+      stats_step<false, ABL, L2>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l, qb, kb_cur);
       if (ABL != 2) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
       __syncthreads();
       s_cur = s_nxt;
       cur = nxt;
+      if (L2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kb_cur[r] = kb_nxt[r];
+      }
     }
     {
       const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
       const int j0 = (t + 1) * kTile;
       if (ABL != 2) tile_load_issue(kr, Kb, k_rs, j0 + 3 * kTile, NK, tid);
-      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      if (L2) load_kb(t + 2, kb_nxt);
+      stats_step<false, ABL, L2>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l, qb, kb_cur);
       if (ABL != 2) tile_store_lds(kr2, smem + nn2 * kBuf, kLdsPad, tid);
       __syncthreads();
       s_cur = s_nxt;
       cur = nxt;
+      if (L2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kb_cur[r] = kb_nxt[r];
+      }
     }
   }
   const int t_end = t;
@@ -183,14 +216,19 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
     const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
     const int j0 = t * kTile;
     if (t > t_end && t + 2 < ntiles) tile_load_issue(kr, Kb, k_rs, j0 + 2 * kTile, NK, tid);  // t_end + 2 is in kr already
+    if (L2 && t + 1 < ntiles) load_kb(t + 1, kb_nxt);
     if (j0 + kTile > N)
-      stats_step<true, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      stats_step<true, ABL, L2>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l, qb, kb_cur);
     else
-      stats_step<false, ABL>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l);
+      stats_step<false, ABL, L2>(smem + nxt * kBuf, lo, h, q, s_cur, s_nxt, scale, xt, gdst + j0, rsrc, roff, j0, N, NK, tokrow, m, l, qb, kb_cur);
     if (t + 2 < ntiles) tile_store_lds(kr, smem + nn2 * kBuf, kLdsPad, tid);
     __syncthreads();
     s_cur = s_nxt;
     cur = nxt;
+    if (L2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kb_cur[r] = kb_nxt[r];
+    }
   }
   const float ltot = l + wave_xor32(l);
   if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
@@ -278,15 +316,16 @@ extern "C" int samble_attn_map_ld(int N, int nt) { return 32 * ((N + nt + 31) / 
 
 extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs, int B,
                                         int N, int nt, float scale, float* smap, int ld, float* lse, float* tok,
-                                        hipStream_t stream) {
+                                        const float* qn, const float* kn, hipStream_t stream) {
   constexpr int NW = 8;
   const size_t lds = (3 * kTile * kLdsPad + NW * kTile * kStPad) * sizeof(float);
   auto kern = g_stats_ablate == 1 ? attn_stats_kernel<NW, 1> : g_stats_ablate == 2 ? attn_stats_kernel<NW, 2>
             : g_stats_ablate == 3 ? attn_stats_kernel<NW, 3> : g_stats_ablate == 4 ? attn_stats_kernel<NW, 4>
                                                                                      : attn_stats_kernel<NW, 0>;
+  if (qn && kn) kern = attn_stats_kernel<NW, 0, true>;
   samble_time_begin(1, stream);
   hipLaunchKernelGGL(kern, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs, q_rs, K, k_bs,
-                     k_rs, N, N + nt, scale, smap, ld, lse, tok, nt);
+                     k_rs, N, N + nt, scale, smap, ld, lse, tok, nt, qn, kn);
   samble_time_end(1, stream);
   return (int)hipGetLastError();
 }

@@ -43,6 +43,8 @@ struct RowsBwdArgs {
   const float* smap;
   int ld;
   const long long* idx;
+  float* cs;  // optional (B, N+nt): column sums of dS over the sampled rows (needed by l2 scoring)
+  int nt;
 };
 
 __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
   if (roleA) load_s(0, sv);
 
   float* myslab = a.slab + ((long)b * a.nslab + chunk) * M * 128 + 32 * kw + lo;
+  float csum = 0.f;  // role A: sum over the sampled rows of dS for this lane's key (its half of the rows)
   const float scale = a.scale;
 
   // iteration `it`: role A works on tile it (ACUR), role B on tile it-1 (BPREV); tile it+1 is staged (NEXT)
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
           p = (i0 + ir < M) ? p : 0.f;
           const float ds = jvalid ? p * (dp[r] - Dt[ir]) * scale : 0.f;
           dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
+          csum += ds;
           mma_tileT_step(Gt, kLdsPad, lo, h, r, p, acc);  // dV^T += dO^T P
         }
       }
@@ -184,6 +188,10 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
   }
   body(ntiles, bufA, F{}, T{}, F{});
 
+  if (a.cs && roleA) {
+    const float ctot = csum + wave_xor32(csum);
+    if (jvalid && h == 0) a.cs[(long)b * (N + a.nt) + j] = ctot;
+  }
   if (jvalid) {
     float* orow = roleA ? a.dV + (long)b * a.dv_bs + (long)j * a.dv_rs : a.dK + (long)b * a.dk_bs + (long)j * a.dk_rs;
 #pragma unroll
@@ -207,7 +215,7 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
                                       const float* K, long k_bs, long k_rs, const float* V, long v_bs, long v_rs, int B,
                                       int N, int M, float scale, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs,
                                       long dv_rs, float* slab, int nslab, const float* smap, int ld,
-                                      const long long* idx, hipStream_t stream) {
+                                      const long long* idx, float* cs, int nt, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel),
@@ -218,7 +226,7 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
   const size_t lds = kRbLdsFloats * sizeof(float) + (size_t)M * 4;
   if (lds > 160 * 1024) return -22;
   RowsBwdArgs a{Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs,
-                dV, dv_bs, dv_rs, slab, nslab, smap, ld, idx};
+                dV, dv_bs, dv_rs, slab, nslab, smap, ld, idx, cs, nt};
   samble_time_begin(3, stream);
   hipLaunchKernelGGL(bwd_rows_kernel, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
   samble_time_end(3, stream);

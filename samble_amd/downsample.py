@@ -83,9 +83,9 @@ class _SamplerCore(torch.autograd.Function):
             indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
         else:
             nn_idx = ops.stage_knn(x, x, mod.K)
-            if TWO_PASS:
+            if TWO_PASS or mod.asm == "l2":
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
-                smap, lse, tok = ops.stage_attn_stats(q, k, N, nt)
+                smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm)
                 score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
                 O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
@@ -107,6 +107,7 @@ class _SamplerCore(torch.autograd.Function):
             x_ds = ops.stage_gather_rows(O, idx)
             ctx.save_for_backward(qkv, O, lse, idx)
         ctx.dims = (N, nt, D)
+        ctx.asm = mod.asm
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(idx, score, z, member, cap, w_pre, counts, indeg, nn_idx)
         return x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx
@@ -123,7 +124,7 @@ class _SamplerCore(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             if smap is not None:  # O is x_ds (B,D,M) here
                 ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
-                                        dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D])
+                                        dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm)
             else:
                 ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
                                    dqkv[:, :, 2 * D:3 * D])
@@ -135,8 +136,13 @@ class _SamplerCore(torch.autograd.Function):
             # token logits = scale * Q K_tok^T (attention_bins_beforesoftmax feeds the optional
             # token loss, reference utils/loss.py:17-27): tiny (N x nt) products
             scale = 1.0 / math.sqrt(D)
-            dqkv[:, :N, 0:D] += scale * torch.matmul(g_tok, k[:, N:, :])
-            dqkv[:, N:, D:2 * D] += scale * torch.matmul(g_tok.transpose(1, 2), q)
+            if ctx.asm == "l2":  # logits -|q - k_tok|^2 / sqrt(D)
+                dqkv[:, :N, 0:D] += 2 * scale * (torch.matmul(g_tok, k[:, N:, :]) - q * g_tok.sum(-1, keepdim=True))
+                dqkv[:, N:, D:2 * D] += 2 * scale * (torch.matmul(g_tok.transpose(1, 2), q)
+                                                     - k[:, N:, :] * g_tok.sum(1).unsqueeze(-1))
+            else:
+                dqkv[:, :N, 0:D] += scale * torch.matmul(g_tok, k[:, N:, :])
+                dqkv[:, N:, D:2 * D] += scale * torch.matmul(g_tok.transpose(1, 2), q)
         return dqkv, None, None, None
 
 
@@ -201,8 +207,10 @@ class DownSampleToken(nn.Module):
         self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
         self.token_orthognonal_loss_factor = config_ds.bin.token_orthognonal_loss_factor
 
-        if self.asm != "dot":
-            raise NotImplementedError(f"asm={self.asm!r}: only the shipped 'dot' scoring is built on HIP so far")
+        if self.asm not in ("dot", "l2"):
+            raise NotImplementedError
+        if self.asm == "l2" and self.idx_mode in ("col_sum", "row_std"):
+            raise NotImplementedError("asm='l2' is built for the sparse_* idx modes (the logit-map path)")
         if self.num_heads != 1:
             raise NotImplementedError("DownSampleToken requires num_heads == 1 (reference utils/check_config.py:158)")
         self._member_bits = None

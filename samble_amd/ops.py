@@ -323,9 +323,10 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
                   ws.data_ptr(), nbytes, _stream())
 
 
-def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int):
+def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int, asm: str = "dot"):
     """Pass 1 of the two-pass forward: q (B,N,D), k (B,N+nt,D) -> logit map (B,N,ld) kept in HBM,
-    lse (B,N), token logits (B,N,nt).  Columns >= N+nt of the map are -inf."""
+    lse (B,N), token logits (B,N,nt).  Columns >= N+nt of the map are -inf.
+    asm "dot": S = <q,k>/sqrt(D); "l2": S = -|q-k|^2/sqrt(D) (reference downsample.py:154-175)."""
     _need_gpu(q, k)
     B, N, D = q.shape
     assert N == n_points and k.shape[1] == n_points + n_tokens
@@ -337,8 +338,16 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
         smap = torch.empty((B, N, ld), dtype=torch.float32, device=q.device)
         lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
         tok = torch.empty((B, N, max(n_tokens, 1)), dtype=torch.float32, device=q.device)
+        qn = kn = None
+        if asm == "l2":
+            qn = (q * q).sum(-1).contiguous()
+            kn = torch.zeros((B, ld), dtype=torch.float32, device=q.device)
+            kn[:, :n_points + n_tokens] = (k * k).sum(-1)
+        elif asm != "dot":
+            raise NotImplementedError
         _lib.call("samble_attn_stats_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
-                  k.stride(1), B, N, n_tokens, D, smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _stream())
+                  k.stride(1), B, N, n_tokens, D, smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn),
+                  _stream())
     return smap, lse, tok[:, :, :n_tokens]
 
 
@@ -374,8 +383,11 @@ def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
     return score, z, indeg
 
 
-def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv) -> None:
-    """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M)."""
+def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv,
+                        asm: str = "dot") -> None:
+    """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M).
+    asm "l2": the kernels also return the column sums of dS and the gradients are finished here:
+    dS/dq_i = scale (2 k_j - 2 q_i), dS/dk_j = scale (2 q_i - 2 k_j), rows of dS sum to zero."""
     _need_gpu(q, k, v, smap, lse, x_ds, idx, g)
     B, N, D = q.shape
     M = idx.shape[1]
@@ -384,11 +396,15 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
     with torch.cuda.device(q.device):
         nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        cs = torch.zeros((B, n_points + n_tokens), dtype=torch.float32, device=q.device) if asm == "l2" else None
         _lib.call("samble_attn_rows_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
                   k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), smap.data_ptr(), smap.shape[2], lse.data_ptr(),
                   x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(),
                   dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0),
-                  dv.stride(1), ws.data_ptr(), nbytes, _stream())
+                  dv.stride(1), _p(cs), ws.data_ptr(), nbytes, _stream())
+        if asm == "l2":
+            dq.mul_(2.0)
+            dk.mul_(2.0).sub_(2.0 * cs.unsqueeze(-1) * k)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -79,6 +79,7 @@ CASES = [
     dict(name="cls_random_cfg1", cfg="cls", B=8, N=1024, M=512, calls=1, big=False),
     dict(name="cls_colsum_topk", cfg="cls", B=2, N=256, M=128, calls=1, big=False,
          sample_mode="topk", idx_mode="col_sum"),
+    dict(name="cls_l2_random", cfg="cls", B=2, N=256, M=128, calls=1, big=True, asm="l2"),
 ]
 
 
@@ -89,6 +90,8 @@ def build_reference(case, seed):
         cfg.bin.sample_mode[layer] = case["sample_mode"]
     if "idx_mode" in case:
         cfg.idx_mode[layer] = case["idx_mode"]
+    if "asm" in case:
+        cfg.asm[layer] = case["asm"]
     if "static" in case:
         cfg.bin.dynamic_boundaries_enable = False
         cfg.bin.bin_boundaries[layer] = list(case["static"])
@@ -129,7 +132,7 @@ def run_case(case, case_id):
     out = dict(
         meta=np.array([B, C, N, M, nb, spec.K, case["calls"], seed], dtype=np.int64),
         torch_version=np.array(torch.__version__),
-        sample_mode=np.array(spec.sample_mode), idx_mode=np.array(spec.idx_mode),
+        sample_mode=np.array(spec.sample_mode), idx_mode=np.array(spec.idx_mode), asm=np.array(spec.asm),
         boltzmann_T=np.array(float(spec.boltzmann_T)), momentum=np.array(spec.momentum),
         dynamic=np.array(spec.dynamic_boundaries),
         static=np.array(case.get("static", []), dtype=np.float32),
@@ -194,7 +197,7 @@ def run_case(case, case_id):
                          dwv=mod.v_conv.weight.grad, dtokens=mod.bin_tokens.grad)
             leaves = [t.detach().clone().requires_grad_(True) for t in (x, st.wq, st.wk, st.wv, st.tokens)]
             q, k, v = O.project_qkv(leaves[0], leaves[4], leaves[1], leaves[2], leaves[3])
-            A, _, _ = O.attention_map(q, k, N)
+            A, _, _ = O.attention_map(q, k, N, spec.asm)
             O.gather_attend(A, v, idx_r).backward(torch.from_numpy(g_np))
             for name, leaf in zip(("dx", "dwq", "dwk", "dwv", "dtokens"), leaves):
                 same(leaf.grad, grads[name], name)

@@ -233,6 +233,38 @@ def test_two_pass_forward(B, N, nt, M):
     torch.testing.assert_close(o_.stage_gather_rows(O1, idx.to(DEV)), x_ds, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("B,N,nt,M", [(2, 256, 6, 128), (1, 1000, 4, 333)])
+def test_two_pass_l2_forward_backward(B, N, nt, M):
+    """asm 'l2' (reference downsample.py:154-175): S = -|q - k|^2 / sqrt(D) through the same kernels."""
+    D = 128
+    q, k, v = _qkv(B, N, nt, 1300 + N)
+    q, k = q * 0.3, k * 0.3
+    g = torch.from_numpy(synth.normal((B, D, M), 17))
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)])
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = -((qd ** 2).sum(-1, keepdim=True) - 2 * qd @ kd.transpose(1, 2) + (kd ** 2).sum(-1).unsqueeze(1)) / math.sqrt(D)
+    o = torch.softmax(s, -1) @ vd
+    rows = torch.gather(o, 1, idx[..., None].expand(-1, -1, D))
+    rows.permute(0, 2, 1).backward(g.double())
+    o_ = ops()
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    smap, lse, tok = o_.stage_attn_stats(qg, kg, N, nt, "l2")
+    torch.testing.assert_close(smap[:, :, :N + nt].cpu().double(), s.detach(), rtol=1e-5, atol=3e-5)
+    torch.testing.assert_close(lse.cpu().double(), torch.logsumexp(s.detach(), -1), rtol=1e-5, atol=2e-5)
+    assert torch.equal(tok, smap[:, :, N:N + nt])
+    x_ds = o_.stage_attn_rows(smap, lse, vg, idx.to(DEV), N, nt)
+    torch.testing.assert_close(x_ds.cpu().double(), rows.detach().permute(0, 2, 1), rtol=2e-4, atol=2e-5)
+    dq = torch.full((B, N, D), float("nan"), device=DEV)
+    dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv, "l2")
+    for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
+        assert torch.isfinite(got).all(), name
+        scale = ref.abs().max().item()
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err <= 5e-5 * scale + 1e-7, (name, err, scale)
+
+
 def test_two_pass_strided_views():
     B, N, nt, D, M = 2, 256, 6, 128, 100
     qkv = torch.from_numpy(synth.normal((B, N + nt, 3 * D), 19)).to(DEV)

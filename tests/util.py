@@ -28,6 +28,7 @@ class Golden:
         (self.B, self.C, self.N, self.M, self.nb, self.K, self.calls, self.seed) = [int(v) for v in self.d["meta"]]
         self.sample_mode = str(self.d["sample_mode"])
         self.idx_mode = str(self.d["idx_mode"])
+        self.asm = str(self.d["asm"]) if "asm" in self.d else "dot"
         self.boltzmann_T = float(self.d["boltzmann_T"])
         self.momentum = float(self.d["momentum"])
         self.dynamic = bool(self.d["dynamic"])
@@ -53,7 +54,7 @@ class Golden:
 
     def spec(self):
         from oracle import torch_oracle as O
-        return O.SamplerSpec(M=self.M, K=self.K, C=self.C, num_bins=self.nb, idx_mode=self.idx_mode,
+        return O.SamplerSpec(M=self.M, K=self.K, C=self.C, num_bins=self.nb, idx_mode=self.idx_mode, asm=self.asm,
                              sample_mode=self.sample_mode, boltzmann_T=self.boltzmann_T,
                              dynamic_boundaries=self.dynamic, momentum=self.momentum,
                              static_boundaries=self.static or None)
@@ -68,6 +69,7 @@ class Golden:
         cfg = sampler_config(preset, M=[self.M, max(self.M // 2, 1)])
         cfg.bin.sample_mode = [self.sample_mode] * 2
         cfg.idx_mode = [self.idx_mode] * 2
+        cfg.asm = [self.asm] * 2
         cfg.bin.boltzmann_T = [self.boltzmann_T] * 2
         cfg.bin.momentum_update_factor = [self.momentum] * 2
         if not self.dynamic:
