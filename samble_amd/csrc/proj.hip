@@ -15,6 +15,8 @@
 //                full 384x128 partial in registers (4 waves x 12 tiles), partials summed in a fixed
 //                order by proj_dw_reduce (deterministic, no float atomics).
 //   proj_tok_bwd dtokens[c][t] and the token rows' share of dW (nt <= 8 rows: VALU).
+#include <type_traits>
+
 #include "samble_dev.h"
 
 namespace samble {
@@ -60,8 +62,10 @@ __global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restric
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int n = chunk * 128 + wave * 32 + lo;
-  const bool nvalid = n < N;
+  // points past N-1 (last workgroup of a ragged cloud) are clamped: those lanes recompute and rewrite
+  // point N-1's row bit for bit, so no store is predicated, the tile loop has no branch and the staged
+  // W tile is awaited with a counted vmcnt instead of draining the output stores as well
+  const int n = min(chunk * 128 + wave * 32 + lo, N - 1);
 
   if (chunk == 0) {  // this cloud's copy of the token rows
     for (int e = tid; e < nt * kO; e += 256)
@@ -69,35 +73,46 @@ __global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restric
   }
   float xr[64];
 #pragma unroll
-  for (int kk = 0; kk < 64; ++kk) xr[kk] = nvalid ? x[(long)b * x_bs + (long)(64 * h + kk) * N + n] : 0.f;
+  for (int kk = 0; kk < 64; ++kk) xr[kk] = x[(long)b * x_bs + (long)(64 * h + kk) * N + n];
   TileRegs wr;
   tile_load_issue(wr, W, kC, 0, kO, tid);
   tile_store_lds(wr, smem, kLdsPad, tid);
   __syncthreads();
-  float* orow = qkv + (long)b * o_bs + (long)n * o_rs;
-  for (int t = 0; t < kO / kTile; ++t) {
+  float* orow = qkv + (long)b * o_bs + (long)n * o_rs + 4 * h;
+  auto body = [&](int t, auto next_c) {
+    constexpr bool NEXT = decltype(next_c)::value;
     float* cur = smem + (t & 1) * kTile * kLdsPad;
     float* nxt = smem + ((t & 1) ^ 1) * kTile * kLdsPad;
-    if (t + 1 < kO / kTile) tile_load_issue(wr, W, kC, (t + 1) * kTile, kO, tid);
-    // D[row = output o][col = point n]
-    f32x16 acc = mma_rows_x_regs(cur, kLdsPad, lo, h, xr, zero16());
-    if (nvalid) {
+    if (NEXT) {  // rows (t+1)*32 .. +31 of W always exist: unguarded loads
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(orow + t * kTile + 8 * g + 4 * h) = o;
+      for (int i = 0; i < TileRegs::kPer; ++i) {
+        const int e = tid + 256 * i, r = e >> 5, c4 = e & 31;
+        wr.v[i] = *reinterpret_cast<const f32x4*>(W + (long)((t + 1) * kTile + r) * kC + 4 * c4);
       }
     }
-    if (t + 1 < kO / kTile) tile_store_lds(wr, nxt, kLdsPad, tid);
+    // D[row = output o][col = point n]
+    f32x16 acc = mma_rows_x_regs(cur, kLdsPad, lo, h, xr, zero16());
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(orow + t * kTile + 8 * g) = o;
+    }
+    if (NEXT) tile_store_lds(wr, nxt, kLdsPad, tid);
     __syncthreads();
-  }
+  };
+  for (int t = 0; t + 1 < kO / kTile; ++t) body(t, std::true_type{});
+  body(kO / kTile - 1, std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
 // dx
 // ------------------------------------------------------------------------------------------------
-constexpr int kDxLdsFloats = 128 * 128;  // one 128-output chunk of W, [o][c]
+constexpr int kDxStage = 64;                       // outputs (rows of W) per pipeline stage
+constexpr int kDxLdsFloats = 2 * kDxStage * 128;   // two stages of W, [o][c]
 
+// dx[b][c][n] = sum_o W[o][c] dqkv[b][n][o]: wave = 32 points, the 384-long contraction in 6 stages of
+// 64 outputs.  W stage s+1 and the points' dqkv slice for it are fetched (registers) while stage s
+// multiplies; one barrier per stage; clamped points instead of predicates (branch-free stage loop).
 __global__ __launch_bounds__(256, 2) void proj_dx_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
                                                          const float* __restrict__ W, int N,
                                                          float* __restrict__ dx, long dx_bs) {
@@ -105,44 +120,58 @@ __global__ __launch_bounds__(256, 2) void proj_dx_kernel(const float* __restrict
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  const int n = blockIdx.x * 128 + wave * 32 + lo;
-  const bool nvalid = n < N;
-  const float* grow = dqkv + (long)b * g_bs + (long)n * g_rs;
+  const int n = min(blockIdx.x * 128 + wave * 32 + lo, N - 1);
+  const float* grow = dqkv + (long)b * g_bs + (long)n * g_rs + 32 * h;  // this lane half's 32 outputs of a stage
 
   f32x16 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
-  for (int chunk = 0; chunk < 3; ++chunk) {
-    __syncthreads();  // previous chunk fully consumed
-    for (int e = tid; e < 128 * 32; e += 256) {
-      const int r = e >> 5, c4 = (e & 31) * 4;
-      *reinterpret_cast<f32x4*>(Ws + r * 128 + c4) =
-          *reinterpret_cast<const f32x4*>(W + (long)(chunk * 128 + r) * kC + c4);
-    }
-    float gr[64];
-    if (nvalid) {
-      load_row_half(grow + chunk * 128, h, gr);
-    } else {
+  f32x4 wreg[8], gcur[8], gnxt[8];
+  auto issue = [&](int st, f32x4 (&g)[8]) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) gr[i] = 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, c4 = (e & 31) * 4;  // 64 rows x 32 float4
+      wreg[i] = *reinterpret_cast<const f32x4*>(W + (long)(st * kDxStage + r) * kC + c4);
+      g[i] = *reinterpret_cast<const f32x4*>(grow + st * kDxStage + 4 * i);
     }
-    __syncthreads();
-    // D[row = channel c][col = point n] += sum_o W[o][c] * dqkv[n][o];  o = 64h + kk within the chunk
-    const float* wp = Ws + (64 * h) * 128 + lo;
+  };
+  auto commit = [&](float* buf) {
 #pragma unroll
-    for (int kk = 0; kk < 64; ++kk) {
-      const float bval = gr[kk];
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i, r = e >> 5, c4 = (e & 31) * 4;
+      *reinterpret_cast<f32x4*>(buf + r * 128 + c4) = wreg[i];
+    }
+  };
+  issue(0, gcur);
+  commit(Ws);
+  __syncthreads();
+  auto body = [&](int st, auto next_c) {
+    constexpr bool NEXT = decltype(next_c)::value;
+    const float* cur = Ws + (st & 1) * kDxStage * 128;
+    if (NEXT) issue(st + 1, gnxt);
+    // D[row = channel c][col = point n] += sum_o W[o][c] * dqkv[n][o];  o = 32h + kk within the stage
+    const float* wp = cur + (32 * h) * 128 + lo;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      const float bval = gcur[kk >> 2][kk & 3];
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma32(wp[kk * 128 + 32 * ct], bval, acc[ct]);
     }
-  }
-  if (nvalid) {
-    float* out = dx + (long)b * dx_bs + n;
+    if (NEXT) {
+      commit(Ws + ((st & 1) ^ 1) * kDxStage * 128);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int i = 0; i < 8; ++i) gcur[i] = gnxt[i];
+    }
+    __syncthreads();
+  };
+  constexpr int kStages = kO / kDxStage;
+  for (int st = 0; st + 1 < kStages; ++st) body(st, std::true_type{});
+  body(kStages - 1, std::false_type{});
+  float* out = dx + (long)b * dx_bs + n;  // clamped points rewrite point N-1's values
 #pragma unroll
-      for (int r = 0; r < 16; ++r) out[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
-  }
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
 }
 
 // ------------------------------------------------------------------------------------------------
