@@ -23,6 +23,7 @@ namespace samble {
 // ------------------------------------------------------------------------------------------------
 // prep: one workgroup = 32 sampled rows of one cloud
 // ------------------------------------------------------------------------------------------------
+template <bool L2>  // L2: token logits are -|q-k|^2 and the dS column sums of the token keys are produced
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                        const float* __restrict__ K, long k_bs, long k_rs,
                                                        const float* __restrict__ V, long v_bs, long v_rs,
@@ -65,10 +66,13 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     ak[t] = z4;
     av[t] = z4;
     acs[t] = 0.f;
-    float kk = kt[t][0] * kt[t][0] + kt[t][1] * kt[t][1] + kt[t][2] * kt[t][2] + kt[t][3] * kt[t][3];
+    ktt[t] = 0.f;
+    if (L2) {
+      float kk = kt[t][0] * kt[t][0] + kt[t][1] * kt[t][1] + kt[t][2] * kt[t][2] + kt[t][3] * kt[t][3];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) kk += __shfl_xor(kk, off, 64);
-    ktt[t] = kk;
+      for (int off = 16; off >= 1; off >>= 1) kk += __shfl_xor(kk, off, 64);
+      ktt[t] = kk;
+    }
   }
   for (int rr = sub; rr < 32; rr += 8) {
     const int m = m0 + rr;
@@ -97,9 +101,12 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     // token keys: P and dS of this row against each token, accumulated into this lane's channels;
     // their share of dQ of this row (sum_t dS_t K_tok[t]) goes to the extra dQ slab
     f32x4 dqt = {0.f, 0.f, 0.f, 0.f};
-    float qq = qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3];
+    float qq = 0.f;
+    if (L2) {
+      qq = qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2] + qv[3] * qv[3];
 #pragma unroll
-    for (int off = 16; off >= 1; off >>= 1) qq += __shfl_xor(qq, off, 64);
+      for (int off = 16; off >= 1; off >>= 1) qq += __shfl_xor(qq, off, 64);
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (t < nt) {
@@ -110,10 +117,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
           st += __shfl_xor(st, off, 64);
           dpt += __shfl_xor(dpt, off, 64);
         }
-        if (l2) st = 2.f * st - qq - ktt[t];  // -|q - k_tok|^2
+        if (L2) st = 2.f * st - qq - ktt[t];  // -|q - k_tok|^2
         const float p = __expf(st * scale - lrow);
         const float ds = p * (dpt - part) * scale;
-        acs[t] += ds;
+        if (L2) acs[t] += ds;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           av[t][u] = fmaf(p, dv[u], av[t][u]);
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
         }
       }
     }
-    if (cs_part && l32 == 0) {
+    if (L2 && l32 == 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) csred[sub][t] = acs[t];
     }
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
       for (int w4 = 0; w4 < 4; ++w4) sacc += (&red[w4][0][0][0])[e];
       outp[e] = sacc;
     }
-    if (cs_part && tid < 8) {  // column sums of dS over this workgroup's rows, per token
+    if (L2 && tid < 8) {  // column sums of dS over this workgroup's rows, per token
       float sacc = 0.f;
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8) sacc += csred[s8][tid];
@@ -598,7 +605,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
-  hipLaunchKernelGGL(bwd_prep_kernel, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
+  hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
                      fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr);
   if (fused) {

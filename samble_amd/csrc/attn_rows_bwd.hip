@@ -47,6 +47,7 @@ struct RowsBwdArgs {
   int nt;
 };
 
+template <bool CS>  // CS: also accumulate the column sums of dS (asm "l2")
 __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dsbuf = smem + 3 * kRbTile;                                 // 2 x [32][kLdsPad]
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
           p = (i0 + ir < M) ? p : 0.f;
           const float ds = jvalid ? p * (dp[r] - Dt[ir]) * scale : 0.f;
           dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
-          csum += ds;
+          if (CS) csum += ds;
           mma_tileT_step(Gt, kLdsPad, lo, h, r, p, acc);  // dV^T += dO^T P
         }
       }
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
   }
   body(ntiles, bufA, F{}, T{}, F{});
 
-  if (a.cs && roleA) {
+  if (CS && roleA) {
     const float ctot = csum + wave_xor32(csum);
     if (jvalid && h == 0) a.cs[(long)b * (N + a.nt) + j] = ctot;
   }
@@ -218,8 +219,11 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
                                       const long long* idx, float* cs, int nt, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -228,7 +232,8 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
   RowsBwdArgs a{Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs,
                 dV, dv_bs, dv_rs, slab, nslab, smap, ld, idx, cs, nt};
   samble_time_begin(3, stream);
-  hipLaunchKernelGGL(bwd_rows_kernel, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
+  if (cs) hipLaunchKernelGGL(bwd_rows_kernel<true>, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
+  else hipLaunchKernelGGL(bwd_rows_kernel<false>, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
   samble_time_end(3, stream);
   return (int)hipGetLastError();
 }
