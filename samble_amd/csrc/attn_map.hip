@@ -262,8 +262,18 @@ __global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __r
   const bool mvalid = mrow < M;
   const long row = idx[(long)b * M + (mvalid ? mrow : M - 1)];
   const float my_lse = lse[(long)b * N + row];
-  const float* srow = smap + ((long)b * N + row) * ld + 4 * h + half * kTile;
   const float* Vb = V + (long)b * v_bs;
+  // the map rows are read with full 128-byte lines (8 lanes x 16 bytes per row, 8 rows per load: lane-per-
+  // row loads would put 64 partial-line requests per instruction on the L2) and turned into the accumulator
+  // layout (lane = row, 4 consecutive keys per register group) through a wave-private LDS tile
+  float* xt = smem + 2 * 2 * kTile * 128 + wave * (kTile * kStPad);
+  const float* sbase = smap + (long)b * N * ld + 4 * (lane & 7);
+  int roff[4];
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) {
+    const int mr = chunk * (32 * NW) + rw * 32 + (lane >> 3) + 8 * k8;
+    roff[k8] = (int)idx[(long)b * M + min(mr, M - 1)] * ld;
+  }
 
   f32x16 oacc[4];
 #pragma unroll
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __r
   auto load_s = [&](int step, f32x4 (&dst)[4]) {
     const int t = min(2 * step + half, ntiles - 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dst[g] = *reinterpret_cast<const f32x4*>(srow + (t - half) * kTile + 8 * g);
+    for (int k8 = 0; k8 < 4; ++k8) dst[k8] = *reinterpret_cast<const f32x4*>(sbase + roff[k8] + t * kTile);
   };
   load_s(0, sv);
   issue(0);
@@ -312,9 +322,16 @@ __global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __r
       load_s(s + 1, sn);
     }
     const bool live = 2 * s + half < ntiles;  // wave-uniform
+    // transpose: rows (lane>>3)+8k, 16-byte chunk lane&7  ->  row lo, chunks 2g+h
+#pragma unroll
+    for (int k8 = 0; k8 < 4; ++k8)
+      *reinterpret_cast<f32x4*>(xt + ((lane >> 3) + 8 * k8) * kStPad + 4 * (lane & 7)) = sv[k8];
+    f32x4 st[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st[g] = *reinterpret_cast<const f32x4*>(xt + lo * kStPad + 8 * g + 4 * h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float p = __expf(sv[r >> 2][r & 3] - my_lse);
+      float p = __expf(st[r >> 2][r & 3] - my_lse);
       p = live ? p : 0.f;
       mma_tileT_step(Vc, 128, lo, h, r, p, oacc);
     }
@@ -374,7 +391,15 @@ extern "C" int samble_launch_attn_rows(const float* smap, int ld, const float* l
                                        const long long* idx, int B, int N, int nt, int M, float* xds,
                                        hipStream_t stream) {
   constexpr int NW = 4;
-  const size_t lds = 2 * 2 * kTile * 128 * sizeof(float);  // also >= NW x 64 x 64 floats for the final exchange
+  // V steps (also >= NW x 64 x 64 floats for the final exchange) + one 32 x 36 transpose tile per wave
+  const size_t lds = (2 * 2 * kTile * 128 + 2 * NW * kTile * kStPad) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rows_kernel<NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
   samble_time_begin(2, stream);
   hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(128 * NW), lds, stream, smap, ld,
                      lse, V, v_bs, v_rs, idx, N, N + nt, M, xds);
