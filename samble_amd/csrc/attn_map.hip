@@ -333,7 +333,10 @@ __global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __r
     for (int r = 0; r < 16; ++r) {
       float p = __expf(st[r >> 2][r & 3] - my_lse);
       p = live ? p : 0.f;
-      mma_tileT_step(Vc, 128, lo, h, r, p, oacc);
+      // O^T tile dt, row rho <-> channel 4 rho + dt: lane lo's four A operands are one 16-byte LDS read
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(Vc + crow(r, h) * 128 + 4 * lo);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma32(a4[dt], p, oacc[dt]);
     }
     if (s + 1 < nsteps) {
       commit(Vn);
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __r
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ob[(long)(32 * dt + crow(r, h)) * M] = oacc[dt][r] + xch[(16 * dt + r) * 64 + lane];
+      for (int r = 0; r < 16; ++r) ob[(long)(4 * crow(r, h) + dt) * M] = oacc[dt][r] + xch[(16 * dt + r) * 64 + lane];
     }
   }
 }
