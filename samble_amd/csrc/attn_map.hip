@@ -242,124 +242,67 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_stats_kernel(const float* __r
 // x queries-on-lanes: the channel-major module output (B, D, M) is written with 128-byte runs.
 // ------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(128 * NW, 2) void attn_rows_kernel(const float* __restrict__ smap, int ld,
-                                                                const float* __restrict__ lse,
-                                                                const float* __restrict__ V, long v_bs, long v_rs,
-                                                                const long long* __restrict__ idx, int N, int NK,
-                                                                int M, float* __restrict__ xds) {
-  // 2*NW waves: wave w and wave w+NW own the same 32 sampled rows and split the key tiles (even / odd), so
-  // every SIMD runs two waves (fp32 MFMA and VALU share the SIMD's lanes: a lone wave pays ~8% MFMA issue
-  // bubbles and ~7.5 instead of ~4.3 cycles per VALU instruction).  Their partial O^T are added through LDS.
+__global__ __launch_bounds__(64 * NW, 2) void attn_rows_kernel(const float* __restrict__ smap, int ld,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ V, long v_bs, long v_rs,
+                                                               const long long* __restrict__ idx, int N, int NK,
+                                                               int M, float* __restrict__ xds) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kBuf = 2 * kTile * 128;  // one step = two V tiles (even, odd)
-  constexpr int NT = 128 * NW;
+  constexpr int kBuf = kTile * 128;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const int rw = wave % NW, half = wave / NW;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int mrow = chunk * (32 * NW) + rw * 32 + lo;
+  const int mrow = chunk * (32 * NW) + wave * 32 + lo;
   const bool mvalid = mrow < M;
   const long row = idx[(long)b * M + (mvalid ? mrow : M - 1)];
   const float my_lse = lse[(long)b * N + row];
+  const float* srow = smap + ((long)b * N + row) * ld + 4 * h;
   const float* Vb = V + (long)b * v_bs;
-  // the map rows are read with full 128-byte lines (8 lanes x 16 bytes per row, 8 rows per load: lane-per-
-  // row loads would put 64 partial-line requests per instruction on the L2) and turned into the accumulator
-  // layout (lane = row, 4 consecutive keys per register group) through a wave-private LDS tile
-  float* xt = smem + 2 * 2 * kTile * 128 + wave * (kTile * kStPad);
-  const float* sbase = smap + (long)b * N * ld + 4 * (lane & 7);
-  int roff[4];
-#pragma unroll
-  for (int k8 = 0; k8 < 4; ++k8) {
-    const int mr = chunk * (32 * NW) + rw * 32 + (lane >> 3) + 8 * k8;
-    roff[k8] = (int)idx[(long)b * M + min(mr, M - 1)] * ld;
-  }
 
   f32x16 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
 
   const int ntiles = (NK + kTile - 1) / kTile;
-  const int nsteps = (ntiles + 1) / 2;
-  // staging: 2 tiles x 1024 float4 per step over NT threads (rows >= NK are zero rows: P there is exp(-inf) = 0)
-  constexpr int kPer = 2048 / NT;
-  f32x4 vst[kPer];
-  auto issue = [&](int step) {
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int e = tid + NT * i;
-      const int r = e >> 5, c4 = e & 31;  // r in 0..63: both tiles of the step
-      const int rowk = step * 2 * kTile + r;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      vst[i] = (rowk < NK) ? *reinterpret_cast<const f32x4*>(Vb + (long)rowk * v_rs + 4 * c4) : z;
-    }
-  };
-  auto commit = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-      const int e = tid + NT * i;
-      *reinterpret_cast<f32x4*>(buf + (e >> 5) * 128 + 4 * (e & 31)) = vst[i];
-    }
-  };
+  TileRegsT<64 * NW> vr;
   f32x4 sv[4], sn[4];
-  // this wave's tile of step s is tile 2s + half; the map row is ld >= 32*ntiles wide, but tile `ntiles` (odd
-  // ntiles, half 1, last step) lies outside: clamp the column offset and zero its P below
-  auto load_s = [&](int step, f32x4 (&dst)[4]) {
-    const int t = min(2 * step + half, ntiles - 1);
 #pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8) dst[k8] = *reinterpret_cast<const f32x4*>(sbase + roff[k8] + t * kTile);
-  };
-  load_s(0, sv);
-  issue(0);
-  commit(smem);
+  for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const f32x4*>(srow + 8 * g);
+  tile_load_issue(vr, Vb, v_rs, 0, NK, tid);
+  tile_store_lds(vr, smem, 128, tid);
   __syncthreads();
 
-  for (int s = 0; s < nsteps; ++s) {
-    float* Vc = smem + (s & 1) * kBuf + half * (kTile * 128);
-    float* Vn = smem + ((s & 1) ^ 1) * kBuf;
-    if (s + 1 < nsteps) {
-      issue(s + 1);
-      load_s(s + 1, sn);
+  for (int t = 0; t < ntiles; ++t) {
+    float* Vc = smem + (t & 1) * kBuf;
+    float* Vn = smem + ((t & 1) ^ 1) * kBuf;
+    const int j0 = t * kTile;
+    if (t + 1 < ntiles) {
+      tile_load_issue(vr, Vb, v_rs, j0 + kTile, NK, tid);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sn[g] = *reinterpret_cast<const f32x4*>(srow + j0 + kTile + 8 * g);
     }
-    const bool live = 2 * s + half < ntiles;  // wave-uniform
-    // transpose: rows (lane>>3)+8k, 16-byte chunk lane&7  ->  row lo, chunks 2g+h
-#pragma unroll
-    for (int k8 = 0; k8 < 4; ++k8)
-      *reinterpret_cast<f32x4*>(xt + ((lane >> 3) + 8 * k8) * kStPad + 4 * (lane & 7)) = sv[k8];
-    f32x4 st[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) st[g] = *reinterpret_cast<const f32x4*>(xt + lo * kStPad + 8 * g + 4 * h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float p = __expf(st[r >> 2][r & 3] - my_lse);
-      p = live ? p : 0.f;
+      const float p = __expf(sv[r >> 2][r & 3] - my_lse);
       // O^T tile dt, row rho <-> channel 4 rho + dt: lane lo's four A operands are one 16-byte LDS read
       const f32x4 a4 = *reinterpret_cast<const f32x4*>(Vc + crow(r, h) * 128 + 4 * lo);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma32(a4[dt], p, oacc[dt]);
     }
-    if (s + 1 < nsteps) {
-      commit(Vn);
+    if (t + 1 < ntiles) {
+      tile_store_lds(vr, Vn, 128, tid);
 #pragma unroll
       for (int g = 0; g < 4; ++g) sv[g] = sn[g];
     }
     __syncthreads();
   }
-  // combine the two key halves: waves NW.. park their accumulators in LDS (the V buffers are free now)
-  float* xch = smem + (size_t)rw * (64 * 64);
-  if (half == 1) {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xch[(16 * dt + r) * 64 + lane] = oacc[dt][r];
-  }
-  __syncthreads();
-  if (half == 0 && mvalid) {
+  if (mvalid) {
     float* ob = xds + (long)b * 128 * M + mrow;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ob[(long)(4 * crow(r, h) + dt) * M] = oacc[dt][r] + xch[(16 * dt + r) * 64 + lane];
+      for (int r = 0; r < 16; ++r) ob[(long)(4 * crow(r, h) + dt) * M] = oacc[dt][r];
     }
   }
 }
@@ -394,17 +337,9 @@ extern "C" int samble_launch_attn_rows(const float* smap, int ld, const float* l
                                        const long long* idx, int B, int N, int nt, int M, float* xds,
                                        hipStream_t stream) {
   constexpr int NW = 4;
-  // V steps (also >= NW x 64 x 64 floats for the final exchange) + one 32 x 36 transpose tile per wave
-  const size_t lds = (2 * 2 * kTile * 128 + 2 * NW * kTile * kStPad) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rows_kernel<NW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const size_t lds = 2 * kTile * 128 * sizeof(float);
   samble_time_begin(2, stream);
-  hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(128 * NW), lds, stream, smap, ld,
+  hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, smap, ld,
                      lse, V, v_bs, v_rs, idx, N, N + nt, M, xds);
   samble_time_end(2, stream);
   return (int)hipGetLastError();
