@@ -142,7 +142,11 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
           const float ds = jvalid ? p * (dp[r] - Dt[ir]) * scale : 0.f;
           dsw[ir * kLdsPad] = ds;  // dS_all[query][this wave's 32 key columns]
           if (CS) csum += ds;
-          mma_tileT_step(Gt, kLdsPad, lo, h, r, p, acc);  // dV^T += dO^T P
+          {  // dV^T += dO^T P; accumulator tile dt, row rho <-> channel 4 rho + dt: one 16-byte LDS read per step
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Gt + ir * kLdsPad + 4 * lo);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma32(a4[dt], p, acc[dt]);
+          }
         }
       }
     } else {
@@ -163,7 +167,12 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
         // dK^T += Q^T dS, dS of this wave's 32 keys read back from the LDS tile
         const float* dsc = dsr + 32 * kw + lo;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mma_tileT_step(Qt, kLdsPad, lo, h, r, dsc[crow(r, h) * kLdsPad], acc);
+        for (int r = 0; r < 16; ++r) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(Qt + crow(r, h) * kLdsPad + 4 * lo);
+          const float dsv = dsc[crow(r, h) * kLdsPad];
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma32(a4[dt], dsv, acc[dt]);
+        }
       }
     }
     if (NEXT) commit(smem + bufN * kRbTile);
@@ -196,12 +205,9 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
   if (jvalid) {
     float* orow = roleA ? a.dV + (long)b * a.dv_bs + (long)j * a.dv_rs : a.dK + (long)b * a.dk_bs + (long)j * a.dk_rs;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        f32x4 x = {acc[dt][4 * gq], acc[dt][4 * gq + 1], acc[dt][4 * gq + 2], acc[dt][4 * gq + 3]};
-        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * gq + 4 * h) = x;
-      }
+    for (int r = 0; r < 16; ++r) {  // acc[dt][r] = channel 4 crow(r,h) + dt of this lane's key
+      f32x4 x = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      *reinterpret_cast<f32x4*>(orow + 4 * crow(r, h)) = x;
     }
   }
 }
