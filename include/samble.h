@@ -121,6 +121,15 @@ int samble_zscore_f32(const float* score, int B, int N, float* z, void* stream);
 size_t samble_quantiles_workspace_bytes(void);
 int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- utils/ops.py:201-233  boundary state from the (rank-averaged) quantiles ------------------
+ * upper / lower: the two (nb) boundary vectors of the module state (upper[0] = +inf, lower[nb-1] = -inf).
+ * first != 0 initialises them from the quantiles; otherwise blended in place,
+ * old * momentum + one_minus_momentum * q, as two fp32 products and a sum (no FMA), the reference's order.
+ * one_minus_momentum is passed separately because the reference forms it in double (1 - 0.99) before the
+ * fp32 multiply. */
+int samble_blend_boundaries_f32(const float* quantiles, float* upper, float* lower, int nb, float momentum,
+                                float one_minus_momentum, int first, void* stream);
+
 /* ---- utils/ops.py:454-463 + models/downsample.py:264-284  bin membership and bin weights ------
  * upper/lower (nb) = the two (1,1,1,nb) boundary tensors.  tok (B,N,nt), nt == nb or 1.
  * member (B,N) uint8 bit t = point in bin t; cap (B,nb) int32; w_pre (B,nb) = weights before

@@ -44,6 +44,7 @@ _SIGNATURES = {
     "samble_zscore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "samble_quantiles_workspace_bytes": (c_size_t, []),
     "samble_batch_quantiles_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_blend_boundaries_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
     "samble_bin_assign_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_alloc_counts_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

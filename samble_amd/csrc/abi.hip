@@ -29,6 +29,7 @@ int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hi
 int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, int, int, int,
                              int, int, int, float, long long*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
+int samble_launch_blend_boundaries(const float*, float*, float*, int, float, float, int, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
@@ -188,6 +189,15 @@ SAMBLE_API int samble_batch_quantiles_f32(const float* z, int64_t n, int nb, flo
   if (nb < 2 || nb > 8) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: need 2 <= num_bins <= 8");
   if (n >= (1ll << 31)) return fail(SAMBLE_E_INVALID, "samble_batch_quantiles_f32: n must be < 2^31");
   return done(samble_launch_batch_quantiles(z, n, nb, out, ws, (hipStream_t)stream), "samble_batch_quantiles_f32");
+}
+
+SAMBLE_API int samble_blend_boundaries_f32(const float* quantiles, float* upper, float* lower, int nb, float momentum,
+                                           float one_minus_momentum, int first, void* stream) {
+  if (!quantiles || !upper || !lower) return fail(SAMBLE_E_INVALID, "samble_blend_boundaries_f32: null pointer");
+  if (nb < 2 || nb > 8) return fail(SAMBLE_E_INVALID, "samble_blend_boundaries_f32: need 2 <= num_bins <= 8");
+  return done(samble_launch_blend_boundaries(quantiles, upper, lower, nb, momentum, one_minus_momentum, first,
+                                             (hipStream_t)stream),
+              "samble_blend_boundaries_f32");
 }
 
 SAMBLE_API int samble_bin_assign_f32(const float* z, const float* tok, int nt, const float* upper, const float* lower,

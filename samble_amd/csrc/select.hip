@@ -280,6 +280,30 @@ __global__ __launch_bounds__(1024) void qsel_kernel(const float* __restrict__ z,
 }
 
 // ------------------------------------------------------------------------------------------------
+// boundary state update (reference utils/ops.py:201-233) in one launch instead of five tiny tensor ops:
+// first != 0: upper = [+inf, q...], lower = [q..., -inf]; else both are blended IN PLACE,
+// mixed = old * mu + one_minus_mu * q (two fp32 products, then the sum: this file is built without
+// FMA contraction, like the reference's separate multiply / add kernels)
+// ------------------------------------------------------------------------------------------------
+__global__ void blend_boundaries_kernel(const float* __restrict__ quant, float* __restrict__ upper,
+                                        float* __restrict__ lower, int nb, float mu, float one_minus_mu, int first) {
+  const int t = threadIdx.x;
+  if (t >= nb - 1) return;
+  float v = quant[t];
+  if (!first) {
+    const float a = upper[t + 1] * mu;
+    const float b = one_minus_mu * v;
+    v = a + b;
+  }
+  upper[t + 1] = v;
+  lower[t] = v;
+  if (first && t == 0) {
+    upper[0] = __builtin_huge_valf();
+    lower[nb - 1] = -__builtin_huge_valf();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bin membership + weights: one workgroup per cloud
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bin_assign_kernel(const float* __restrict__ z, const float* __restrict__ tok,
@@ -658,6 +682,12 @@ extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, flo
     attr_set = true;
   }
   hipLaunchKernelGGL(batch_quantiles_kernel, dim3(1), dim3(1024), lds, s, z, n, nb, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_blend_boundaries(const float* quant, float* upper, float* lower, int nb, float mu,
+                                              float one_minus_mu, int first, hipStream_t s) {
+  hipLaunchKernelGGL(blend_boundaries_kernel, dim3(1), dim3(64), 0, s, quant, upper, lower, nb, mu, one_minus_mu, first);
   return (int)hipGetLastError();
 }
 

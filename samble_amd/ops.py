@@ -523,6 +523,19 @@ def blend_boundaries(old: Optional[List[torch.Tensor]], quantiles: torch.Tensor,
                      momentum_update_factor: float) -> List[torch.Tensor]:
     """utils/ops.py:201-233 on the (already rank-averaged) nb-1 quantiles: first call stores them,
     later calls blend `old * mu + (1 - mu) * new` IN PLACE into both (1,1,1,nb) tensors."""
+    if quantiles.is_cuda:  # one HIP launch instead of five tiny tensor ops
+        first = old is None
+        if first:
+            new = [torch.empty((1, 1, 1, num_bins), dtype=torch.float32, device=quantiles.device) for _ in range(2)]
+        else:
+            new = [old[0].detach(), old[1].detach()]
+            if not (new[0].is_contiguous() and new[1].is_contiguous() and new[0].dtype == torch.float32):
+                new = [t.float().contiguous() for t in new]
+        q = _f32c(quantiles)
+        with torch.cuda.device(q.device):
+            _lib.call("samble_blend_boundaries_f32", q.data_ptr(), new[0].data_ptr(), new[1].data_ptr(), num_bins,
+                      float(momentum_update_factor), float(1 - momentum_update_factor), int(first), _stream())
+        return new
     if old is not None:
         new = [old[0].detach(), old[1].detach()]
         mixed = new[0][0, 0, 0, 1:] * momentum_update_factor + (1 - momentum_update_factor) * quantiles

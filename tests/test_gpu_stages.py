@@ -508,3 +508,22 @@ def test_abi_rejects_bad_arguments():
                                torch.zeros(1, 2, dtype=torch.int32, device=DEV), 4, "bogus", 0.1)
     with pytest.raises(_lib.SambleError):
         ops().stage_knn(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8), 3)  # CPU tensors: no fallback
+
+
+def test_blend_boundaries_kernel_is_bitwise_the_reference_expression():
+    """utils/ops.py:201-233: first call stores the quantiles, later calls blend in place; the fused kernel
+    must round exactly like the reference's separate fp32 multiply / multiply / add."""
+    o_ = ops()
+    nb, mu = 6, 0.99
+    q1 = torch.from_numpy(synth.normal((nb - 1,), 41)).to(DEV)
+    st = o_.blend_boundaries(None, q1, nb, mu)
+    assert st[0].shape == (1, 1, 1, nb) and torch.isposinf(st[0][0, 0, 0, 0]) and torch.isneginf(st[1][0, 0, 0, -1])
+    assert torch.equal(st[0][0, 0, 0, 1:], q1) and torch.equal(st[1][0, 0, 0, :-1], q1)
+    ref = st[0][0, 0, 0, 1:].cpu().clone()
+    up_ptr = st[0].data_ptr()
+    for k in range(5):
+        qk = torch.from_numpy(synth.normal((nb - 1,), 42 + k)).to(DEV)
+        st = o_.blend_boundaries(st, qk, nb, mu)
+        ref = ref * mu + (1 - mu) * qk.cpu()  # the reference's expression, fp32 on the CPU
+        assert st[0].data_ptr() == up_ptr, "blended in place"
+        assert torch.equal(st[0][0, 0, 0, 1:].cpu(), ref) and torch.equal(st[1][0, 0, 0, :-1].cpu(), ref)
