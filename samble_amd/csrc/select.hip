@@ -306,15 +306,17 @@ __global__ void blend_boundaries_kernel(const float* __restrict__ quant, float* 
 // ------------------------------------------------------------------------------------------------
 // bin membership + weights: one workgroup per cloud
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bin_assign_kernel(const float* __restrict__ z, const float* __restrict__ tok,
-                                                         int nt, const float* __restrict__ upper,
-                                                         const float* __restrict__ lower, int N, int nb,
-                                                         int relu_first, unsigned char* __restrict__ member,
-                                                         int* __restrict__ cap, float* __restrict__ w_pre,
-                                                         float* __restrict__ w) {
-  __shared__ double rsum[kMaxBins][256];
-  __shared__ int rcnt[kMaxBins][256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void bin_assign_kernel(const float* __restrict__ z, const float* __restrict__ tok,
+                                                          int nt, const float* __restrict__ upper,
+                                                          const float* __restrict__ lower, int N, int nb,
+                                                          int relu_first, unsigned char* __restrict__ member,
+                                                          int* __restrict__ cap, float* __restrict__ w_pre,
+                                                          float* __restrict__ w) {
+  // 1024 threads per cloud (two points each at N = 2048: the per-point token-logit loads are latency
+  // bound); per-bin sums in double: lane tree inside a wave, then the 16 wave partials in index order
+  __shared__ double rsum[kMaxBins][16];
+  __shared__ int rcnt[kMaxBins][16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float up[kMaxBins], lo[kMaxBins];
   double ps[kMaxBins];
   int pc[kMaxBins];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256) void bin_assign_kernel(const float* __restrict
     ps[t] = 0.0;
     pc[t] = 0;
   }
-  for (int n = tid; n < N; n += 256) {
+  for (int n = tid; n < N; n += 1024) {
     const float zv = z[(long)b * N + n];
     unsigned int bits = 0;
 #pragma unroll
@@ -342,27 +344,32 @@ __global__ __launch_bounds__(256) void bin_assign_kernel(const float* __restrict
   }
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) {
-    rsum[t][tid] = ps[t];
-    rcnt[t][tid] = pc[t];
+    double v = ps[t];
+    int c = pc[t];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      v += __shfl_xor(v, off, 64);
+      c += __shfl_xor(c, off, 64);
+    }
+    if (lane == 0) {
+      rsum[t][wv] = v;
+      rcnt[t][wv] = c;
+    }
   }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
-#pragma unroll
-      for (int t = 0; t < kMaxBins; ++t) {
-        rsum[t][tid] += rsum[t][tid + o];
-        rcnt[t][tid] += rcnt[t][tid + o];
-      }
-    }
-    __syncthreads();
-  }
   if (tid < nb) {
-    const int c = rcnt[tid][0];
-    const float pre = (float)rsum[tid][0] / ((float)c + 1e-8f);
+    double v = 0.0;
+    int c = 0;
+    for (int w2 = 0; w2 < 16; ++w2) {
+      v += rsum[tid][w2];
+      c += rcnt[tid][w2];
+    }
+    const float pre = (float)v / ((float)c + 1e-8f);
     cap[b * nb + tid] = c;
     w_pre[b * nb + tid] = pre;
     w[b * nb + tid] = relu_first ? pre : fmaxf(pre, 0.f);
   }
+}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -695,7 +702,7 @@ extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt
                                         const float* lower, int B, int N, int nb, int relu_first,
                                         unsigned char* member, int* cap, float* w_pre, float* w, hipStream_t s) {
   if (nb < 1 || nb > kMaxBins || (nt != 1 && nt != nb)) return -22;
-  hipLaunchKernelGGL(bin_assign_kernel, dim3(B), dim3(256), 0, s, z, tok, nt, upper, lower, N, nb, relu_first, member,
+  hipLaunchKernelGGL(bin_assign_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, upper, lower, N, nb, relu_first, member,
                      cap, w_pre, w);
   return (int)hipGetLastError();
 }
@@ -703,7 +710,7 @@ extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt
 extern "C" int samble_launch_alloc_counts(const float* w, const int* cap, int B, int nb, int M, int* counts,
                                           hipStream_t s) {
   if (B > 1024 || nb > kMaxBins) return -22;
-  hipLaunchKernelGGL(alloc_counts_kernel, dim3(1), dim3(1024), 0, s, w, cap, B, nb, M, counts);
+  hipLaunchKernelGGL(alloc_counts_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, w, cap, B, nb, M, counts);  // thread = cloud
   return (int)hipGetLastError();
 }
 
