@@ -370,7 +370,6 @@ __global__ __launch_bounds__(1024) void bin_assign_kernel(const float* __restric
     w[b * nb + tid] = relu_first ? pre : fmaxf(pre, 0.f);
   }
 }
-}
 
 // ------------------------------------------------------------------------------------------------
 // count allocation: ONE workgroup, thread b = cloud b (B <= 1024)
