@@ -156,6 +156,26 @@ int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int
 int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_t* idx, int M, float* out,
                              void* stream);
 
+/* ---- models/embedding.py:7-39  EdgeConv body: conv1 + BN + LReLU + conv2 + BN + LReLU + max over K ------
+ * A 1x1 conv over [x_i ; x_j - x_i] is a_i + b_j with two per-point projections; the caller folds
+ * BatchNorm-1 into them (ap, bp: (B*N, 64) point-major).  nn (B,N,32) neighbour lists.  64 channels, K = 32.
+ *   samble_edge_gather_sums_f32   S[p] = sum_k bp[j(p,k)], Q[p] = sum_k bp[j(p,k)]^2  (BN1 batch statistics and
+ *                                 the backward's closed forms are built from these per-point sums)
+ *   samble_edge_mlp_fwd_f32       y = W2 LReLU(ap_i + bp_j) per edge on the MFMA units; returns per (point,
+ *                                 channel) max_k y and min_k y (LReLU o BN2 is monotone, so max_k commutes with
+ *                                 it) and samble_edge_partial_count() x (2,64) double partial sums of y, y^2
+ *   samble_edge_mlp_bwd_f32       recomputes the edge tensors; dy = c0 + c1 y + [edge is the arg-ext] sdv;
+ *                                 writes du (B*N, 32, 64) = gradient of the pre-activation ap_i + bp_j per
+ *                                 edge and samble_edge_partial_count() x (64,64) partials of dW2 */
+int samble_edge_partial_count(void);
+int samble_edge_gather_sums_f32(const float* bp, const int32_t* nn, int B, int N, int K, int C, float* S, float* Q,
+                                void* stream);
+int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, int B, int N, int K,
+                            int C, float* ymax, float* ymin, double* partials, void* stream);
+int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, const float* yext,
+                            const float* sdv, const float* c0c1, int B, int N, int K, int C, float* du,
+                            float* dw2_partials, void* stream);
+
 /* ---- utils/ops.py:622-643  farthest_point_sample -------------------------------------------
  * xyz (B,3,N) channel-major (the layout the models hold; the reference permutes to (B,N,3) first),
  * start (B) = the first centroid of each cloud (the reference draws it with torch.randint), out

@@ -30,6 +30,12 @@ int samble_launch_bin_select(const float*, const float*, const unsigned char*, c
                              int, int, int, float, long long*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
 int samble_launch_blend_boundaries(const float*, float*, float*, int, float, float, int, hipStream_t);
+int samble_edge_waves(void);
+int samble_launch_edge_gather_sums(const float*, const int*, int, int, float*, float*, hipStream_t);
+int samble_launch_edge_mlp_fwd(const float*, const float*, const int*, const float*, int, int, float*, float*, double*,
+                               hipStream_t);
+int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const float*, const float*, const float*,
+                               const float*, int, int, float*, float*, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
@@ -248,6 +254,37 @@ SAMBLE_API int samble_gather_points_f32(const float* pcd, int B, int C, int N, c
   if (!pcd || !idx || !out) return fail(SAMBLE_E_INVALID, "samble_gather_points_f32: null pointer");
   return done(samble_launch_gather_points(pcd, B, C, N, (const long long*)idx, M, out, (hipStream_t)stream),
               "samble_gather_points_f32");
+}
+
+SAMBLE_API int samble_edge_partial_count(void) { return samble_edge_waves(); }
+
+SAMBLE_API int samble_edge_gather_sums_f32(const float* bp, const int32_t* nn, int B, int N, int K, int C, float* S,
+                                           float* Q, void* stream) {
+  if (!bp || !nn || !S || !Q) return fail(SAMBLE_E_INVALID, "samble_edge_gather_sums_f32: null pointer");
+  if (K != 32 || C != 64 || B <= 0 || N <= 0)
+    return fail(SAMBLE_E_INVALID, "samble_edge_gather_sums_f32: built for K = 32 neighbours, 64 channels");
+  return done(samble_launch_edge_gather_sums(bp, nn, B, N, S, Q, (hipStream_t)stream), "samble_edge_gather_sums_f32");
+}
+
+SAMBLE_API int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, int B, int N,
+                                       int K, int C, float* ymax, float* ymin, double* partials, void* stream) {
+  if (!ap || !bp || !nn || !W2 || !ymax || !ymin || !partials)
+    return fail(SAMBLE_E_INVALID, "samble_edge_mlp_fwd_f32: null pointer");
+  if (K != 32 || C != 64 || B <= 0 || N <= 0)
+    return fail(SAMBLE_E_INVALID, "samble_edge_mlp_fwd_f32: built for K = 32 neighbours, 64 channels");
+  return done(samble_launch_edge_mlp_fwd(ap, bp, nn, W2, B, N, ymax, ymin, partials, (hipStream_t)stream),
+              "samble_edge_mlp_fwd_f32");
+}
+
+SAMBLE_API int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2,
+                                       const float* yext, const float* sdv, const float* c0c1, int B, int N, int K, int C,
+                                       float* du, float* dw2_partials, void* stream) {
+  if (!ap || !bp || !nn || !W2 || !yext || !sdv || !c0c1 || !du || !dw2_partials)
+    return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: null pointer");
+  if (K != 32 || C != 64 || B <= 0 || N <= 0)
+    return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: built for K = 32 neighbours, 64 channels");
+  return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, yext, sdv, c0c1, B, N, du, dw2_partials, (hipStream_t)stream),
+              "samble_edge_mlp_bwd_f32");
 }
 
 SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out,

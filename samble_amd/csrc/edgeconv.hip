@@ -1,0 +1,304 @@
+// Fused EdgeConv body (reference models/embedding.py:7-39): for every point i and its K = 32 nearest
+// neighbours j,   out_i = max_k LReLU(BN2(W2 . LReLU(BN1(W1 . [x_i ; x_j - x_i])))).
+//
+// The reference materialises five (B, 64, N, K) tensors per layer (537 MB each at B = 32, N = 2048).
+// Here none exists in the forward pass:
+//   * a 1x1 conv is linear, so  W1 . [x_i ; x_j - x_i] = a_i + b_j  with two per-POINT projections
+//     a = (W1c - W1d) x, b = W1d x (every group_type of utils/ops.py:83-112 has this form); the caller
+//     folds the BatchNorm-1 affine into them (a', b'), so an edge's hidden vector is LReLU(a'_i + b'_j);
+//   * BatchNorm-1's batch statistics over all B.N.K edges follow from per-point sums: the caller needs
+//     S_i = sum_k b_j and Q_i = sum_k b_j^2 (edge_gather_sums), the rest is closed form;
+//   * the 64 -> 64 conv2 is the one real GEMM over edges: one wave = one point = 32 edges, 64 fp32 MFMAs;
+//   * LReLU o BN2 is monotone per channel, so max_k commutes with it: only max_k / min_k of the raw
+//     conv2 output per (point, channel) and the channel sums for BN2's statistics leave the kernel.
+// Backward (edge_mlp_bwd) recomputes the edge tensors tile by tile and emits the gradient of the
+// pre-activation (a'_i + b'_j) per edge plus the dW2 partials; everything else is closed form on
+// per-point tensors (samble_amd/embedding.py).
+#include "samble_dev.h"
+
+namespace samble {
+
+constexpr int kEC = 64;   // channels of the hidden and output features
+constexpr int kEK = 32;   // neighbours per point = edges per wave
+
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
+
+// S[p][c] = sum_k bp[j(p,k)][c],  Q[p][c] = sum_k bp[j(p,k)][c]^2     (p = b*N + i)
+// half-wave per point, lane = 2 channels; grid-stride over points
+__global__ __launch_bounds__(256) void edge_gather_sums_kernel(const float* __restrict__ bp, const int* __restrict__ nn,
+                                                               int N, long npoints, float* __restrict__ S,
+                                                               float* __restrict__ Q) {
+  const int hw = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+  for (long p = (long)blockIdx.x * 8 + hw; p < npoints; p += (long)gridDim.x * 8) {
+    const long cloud = p / N;
+    const int* ni = nn + p * kEK;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < kEK; ++k) {
+      const int j = ni[k];
+      const float2 v = *reinterpret_cast<const float2*>(bp + (cloud * N + j) * kEC + 2 * c2);
+      s0 += v.x;
+      s1 += v.y;
+      q0 = fmaf(v.x, v.x, q0);
+      q1 = fmaf(v.y, v.y, q1);
+    }
+    *reinterpret_cast<float2*>(S + p * kEC + 2 * c2) = make_float2(s0, s1);
+    *reinterpret_cast<float2*>(Q + p * kEC + 2 * c2) = make_float2(q0, q1);
+  }
+}
+
+// forward sweep.  ap/bp (npoints, 64): BN1-folded projections; W2 (64 out, 64 in) row-major.
+// ymax/ymin (npoints, 64): max_k / min_k of y = W2 h over the point's edges; part (nwaves, 2, 64) doubles:
+// per-wave sums of y and y^2 (BN2 batch statistics), summed by the caller in a fixed order.
+__global__ __launch_bounds__(256, 2) void edge_mlp_fwd_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
+                                                              const int* __restrict__ nn,
+                                                              const float* __restrict__ W2, int N, long npoints,
+                                                              float* __restrict__ ymax, float* __restrict__ ymin,
+                                                              double* __restrict__ part) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  // B operand: lane (o = lo, h) holds W2[32 ot + lo][32 h + kk]
+  float w2r[2][32];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(W2 + (long)(32 * ot + lo) * kEC + 32 * h);
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+      const f32x4 v = wp[q4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w2r[ot][4 * q4 + e] = v[e];
+    }
+  }
+  double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+  for (long p = gw; p < npoints; p += nw) {
+    const long cloud = p / N;
+    const int j = nn[p * kEK + lo];
+    const f32x4* av = reinterpret_cast<const f32x4*>(ap + p * kEC + 32 * h);
+    const f32x4* bv = reinterpret_cast<const f32x4*>(bp + (cloud * N + j) * kEC + 32 * h);
+    float hv[32];
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+      const f32x4 a4 = av[q4], b4 = bv[q4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[4 * q4 + e] = lrelu(a4[e] + b4[e]);
+    }
+    // D[row = edge][col = out channel] = sum_c h[edge][c] W2[o][c]
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      acc[0] = mfma32(hv[kk], w2r[0][kk], acc[0]);
+      acc[1] = mfma32(hv[kk], w2r[1][kk], acc[1]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      float mx = acc[ot][0], mn = acc[ot][0], s = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        mx = fmaxf(mx, acc[ot][r]);
+        mn = fminf(mn, acc[ot][r]);
+        s += acc[ot][r];
+        q = fmaf(acc[ot][r], acc[ot][r], q);
+      }
+      mx = fmaxf(mx, wave_xor32(mx));
+      mn = fminf(mn, wave_xor32(mn));
+      s += wave_xor32(s);
+      q += wave_xor32(q);
+      if (h == 0) {
+        ymax[p * kEC + 32 * ot + lo] = mx;
+        ymin[p * kEC + 32 * ot + lo] = mn;
+      }
+      s1[ot] += (double)s;
+      s2[ot] += (double)q;
+    }
+  }
+  if (h == 0 && gw < nw) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      part[(gw * 2 + 0) * kEC + 32 * ot + lo] = s1[ot];
+      part[(gw * 2 + 1) * kEC + 32 * ot + lo] = s2[ot];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward sweep.  Per point (wave) it recomputes h and y^T = W2 h^T (edges on lanes), forms
+//     dy[k][o] = c0[o] + c1[o] y[k][o] + (k == argext(i,o) ? sdv[i][o] : 0)
+// (BatchNorm-2's dense correction plus the gradient that arrives at the arg-max / arg-min edge; c0,
+// c1 are per-channel constants and sdv = sc2 * LReLU'(v) * g per (point, channel), from the caller),
+// then  dh^T = W2^T dy^T  (accumulator-as-operand), du = dh * LReLU'(u)  -> written per edge
+// (npoints, 32, 64), and  dW2 += dy^T h  through two LDS tiles.  dW2 partials per wave.
+// ------------------------------------------------------------------------------------------------
+constexpr int kEwPad = 68;  // LDS row stride of 64-float rows (16-byte aligned, odd multiple of 16 bytes)
+
+__global__ __launch_bounds__(256, 1) void edge_mlp_bwd_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
+                                                              const int* __restrict__ nn,
+                                                              const float* __restrict__ W2,
+                                                              const float* __restrict__ yext,   // (npoints,64) max or min per the sign of gamma2
+                                                              const float* __restrict__ sdv,    // (npoints,64)
+                                                              const float* __restrict__ c0c1,   // (2,64)
+                                                              int N, long npoints, float* __restrict__ du,
+                                                              float* __restrict__ dw2part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w2s = smem;                         // [64 o][kEwPad]   W2, read as rows (A operand) and as columns
+  float* cst = w2s + kEC * kEwPad;           // c0[64], c1[64]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  float* hts = cst + 2 * kEC + wave * (2 * kEK * kEwPad);  // this wave's [32 edges][68] h tile
+  float* dys = hts + kEK * kEwPad;                         // and [32 edges][68] dy tile
+  for (int e = tid; e < kEC * kEC; e += 256) w2s[(e >> 6) * kEwPad + (e & 63)] = W2[e];
+  if (tid < 2 * kEC) cst[tid] = c0c1[tid];
+  __syncthreads();
+  const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  f32x16 dw[2][2];  // dW2 tile [ot][ct]: rows = o (lanes of A), cols = c
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) dw[a][c] = zero16();
+
+  for (long p = gw; p < npoints; p += nw) {
+    const long cloud = p / N;
+    const int j = nn[p * kEK + lo];
+    const float* arow = ap + p * kEC;
+    const float* brow = bp + (cloud * N + j) * kEC;
+    // B operand of y^T: lane (edge k = lo, h) holds h[k][32 h + kk]; also parked in LDS as h[k][c]
+    float hv[32];
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 32 * h + 4 * q4);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 32 * h + 4 * q4);
+      f32x4 h4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h4[e] = lrelu(a4[e] + b4[e]);
+        hv[4 * q4 + e] = h4[e];
+      }
+      *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * h + 4 * q4) = h4;
+    }
+    // y^T tile ot: D[row = o][col = edge] = sum_c W2[o][c] h[edge][c]; A = W2 rows from LDS
+    f32x16 yt[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      const f32x4* wp = reinterpret_cast<const f32x4*>(w2s + (32 * ot + lo) * kEwPad + 32 * h);
+#pragma unroll
+      for (int q4 = 0; q4 < 8; ++q4) {
+        const f32x4 w4 = wp[q4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yt[ot] = mfma32(w4[e], hv[4 * q4 + e], yt[ot]);
+      }
+    }
+    // dy^T in place: register r of tile ot <-> channel o = 32 ot + crow(r, h), lane <-> edge
+    // the arg-ext edge of (point, o): the first edge whose y equals the stored extremum
+    f32x16 dyt[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ext4 = *reinterpret_cast<const f32x4*>(yext + p * kEC + 32 * ot + 8 * g + 4 * h);
+        const f32x4 sdv4 = *reinterpret_cast<const f32x4*>(sdv + p * kEC + 32 * ot + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int o = 32 * ot + 8 * g + 4 * h + e;
+          const float y = yt[ot][r];
+          // first matching edge among this half's 32 lanes (edges = lanes here): lowest lane wins
+          const unsigned long long m = __ballot(y == ext4[e]);
+          const unsigned int mh = (unsigned int)(h ? (m >> 32) : m);
+          const bool first = (y == ext4[e]) && ((mh & ((1u << lo) - 1u)) == 0u);
+          dyt[ot][r] = fmaf(cst[kEC + o], y, cst[o]) + (first ? sdv4[e] : 0.f);
+        }
+      }
+      // park dy as [edge][o] for the dW2 product
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 d4 = {dyt[ot][4 * g], dyt[ot][4 * g + 1], dyt[ot][4 * g + 2], dyt[ot][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(dys + lo * kEwPad + 32 * ot + 8 * g + 4 * h) = d4;
+      }
+    }
+    // dh^T tile ct: D[row = c][col = edge] = sum_o W2[o][c] dy[edge][o]; reduced index o = the register axis of dy^T
+    f32x16 dht[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float* wrow = w2s + (32 * ot + crow(t, h)) * kEwPad + lo;
+        dht[0] = mfma32(wrow[0], dyt[ot][t], dht[0]);
+        dht[1] = mfma32(wrow[32], dyt[ot][t], dht[1]);
+      }
+    }
+    // du = dh * LReLU'(u), u = a' + b' at channel c = 32 ct + crow(r, h); written per edge
+    float* durow = du + (p * kEK + lo) * kEC;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 32 * ct + 8 * g + 4 * h);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + 32 * ct + 8 * g + 4 * h);
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = dht[ct][4 * g + e] * ((a4[e] + b4[e]) > 0.f ? 1.f : 0.2f);
+        *reinterpret_cast<f32x4*>(durow + 32 * ct + 8 * g + 4 * h) = o4;
+      }
+    }
+    // dW2[o][c] += sum_edge dy[edge][o] h[edge][c]: both operands read from the wave's LDS tiles by rows
+    // (edge pair of MFMA step t = rows crow(t,0), crow(t,1)); same-wave LDS traffic needs no barrier
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float* dr = dys + crow(t, h) * kEwPad + lo;
+      const float* hr = hts + crow(t, h) * kEwPad + lo;
+      const float d0 = dr[0], d1 = dr[32], h0 = hr[0], h1 = hr[32];
+      dw[0][0] = mfma32(d0, h0, dw[0][0]);
+      dw[0][1] = mfma32(d0, h1, dw[0][1]);
+      dw[1][0] = mfma32(d1, h0, dw[1][0]);
+      dw[1][1] = mfma32(d1, h1, dw[1][1]);
+    }
+  }
+  // per-wave dW2 partial (64 x 64): tile [ot][ct] register r, lane (c = lo, h) <-> o = 32 ot + crow(r,h)
+  if (gw < nw) {
+    float* outp = dw2part + gw * kEC * kEC;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outp[(32 * ot + crow(r, h)) * kEC + 32 * ct + lo] = dw[ot][ct][r];
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_edge_waves(void) { return 2048; }  // persistent waves per sweep (512 workgroups x 4)
+
+extern "C" int samble_launch_edge_gather_sums(const float* bp, const int* nn, int B, int N, float* S, float* Q,
+                                              hipStream_t s) {
+  const long np = (long)B * N;
+  hipLaunchKernelGGL(edge_gather_sums_kernel, dim3(2048), dim3(256), 0, s, bp, nn, N, np, S, Q);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_edge_mlp_fwd(const float* ap, const float* bp, const int* nn, const float* W2, int B, int N,
+                                          float* ymax, float* ymin, double* part, hipStream_t s) {
+  const long np = (long)B * N;
+  hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), 0, s, ap, bp, nn, W2, N, np, ymax, ymin,
+                     part);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, const int* nn, const float* W2,
+                                          const float* yext, const float* sdv, const float* c0c1, int B, int N, float* du,
+                                          float* dw2part, hipStream_t s) {
+  const long np = (long)B * N;
+  const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 4 * 2 * kEK * kEwPad) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_mlp_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
+                     N, np, du, dw2part);
+  return (int)hipGetLastError();
+}

@@ -1,11 +1,155 @@
-"""Drop-in `EdgeConv` (reference models/embedding.py:7-39): the neighbour build (`ops.group`) runs on
-the HIP kNN kernels (exact (a-b)^2 path for xyz, fused MFMA Gram + top-K for 64-d features); the two
-1x1 Conv2d + BatchNorm2d + LeakyReLU blocks and the max over K are stock torch."""
+"""Drop-in `EdgeConv` (reference models/embedding.py:7-39).
+
+The neighbour build (`ops.group`'s kNN) runs on the HIP kNN kernels (exact (a-b)^2 path for xyz, fused
+MFMA Gram + top-K for 64-d features).  For the shipped shape (K = 32 neighbours, 64 hidden / output
+channels) the body -- conv1 + BN + LReLU + conv2 + BN + LReLU + max over K -- runs fused on HIP
+(csrc/edgeconv.hip) without any (B, C, N, K) tensor in the forward pass:
+
+* the 1x1 conv1 over [x_i ; x_j - x_i] is `a_i + b_j` with two per-point projections (plain torch
+  matmuls, so autograd delivers dx and dW1 from da, db);
+* BatchNorm-1's batch statistics over the B.N.K edges are closed forms of per-point sums;
+* conv2 is one fp32-MFMA sweep over the edges (wave = point = 32 edges);
+* LReLU o BN2 is monotone per channel, so max_k is taken on the raw conv2 output (max or min per the
+  sign of gamma2) and the activation applied afterwards.
+
+Backward recomputes the edge tensors in a second sweep (gradient of the pre-activation per edge +
+dW2 partials); the BatchNorm corrections, d gamma / d beta and the per-point gradients da, db are closed
+forms.  Other shapes (K != 32, other widths) use the stock torch composition.
+"""
 from __future__ import annotations
 
+import torch
 from torch import nn
 
 from . import ops
+from . import _lib
+
+
+def _edge_weights(w1: torch.Tensor, group_type: str):
+    """conv1 weight (Cout, Cin_total, 1, 1) -> (Wa, Wb) with conv1(group(x))_ij = Wa x_i + Wb x_j."""
+    w = w1[:, :, 0, 0]
+    if group_type == "neighbor":
+        return torch.zeros_like(w), w
+    if group_type == "diff":
+        return -w, w
+    c = w.shape[1] // 2
+    if group_type == "center_neighbor":
+        return w[:, :c], w[:, c:]
+    if group_type == "center_diff":
+        return w[:, :c] - w[:, c:], w[:, c:]
+    raise ValueError(f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {group_type}")
+
+
+class _EdgeMLP(torch.autograd.Function):
+    """a, b (B,N,64) per-point projections, nn (B,N,32) -> (B,64,N)."""
+
+    @staticmethod
+    def forward(ctx, a, b, nn_idx, g1, b1, w2, g2, b2, bn1, bn2, training):
+        B, N, C = a.shape
+        K = nn_idx.shape[2]
+        E = B * N * K
+        dev = a.device
+        a = a.contiguous()
+        b = b.contiguous()
+        w2m = w2[:, :, 0, 0].contiguous()
+        with torch.cuda.device(dev):
+            S = torch.empty_like(b)
+            Q = torch.empty_like(b)
+            _lib.call("samble_edge_gather_sums_f32", b.data_ptr(), nn_idx.data_ptr(), B, N, K, C, S.data_ptr(),
+                      Q.data_ptr(), ops._stream())
+            if training:
+                ad, Sd = a.double(), S.double()
+                sum_z = K * ad.sum((0, 1)) + Sd.sum((0, 1))
+                sum_z2 = (K * ad * ad + 2 * ad * Sd + Q.double()).sum((0, 1))
+                mu1 = sum_z / E
+                var1 = (sum_z2 / E - mu1 * mu1).clamp_min(0)
+            else:
+                mu1, var1 = bn1.running_mean.double(), bn1.running_var.double()
+            sig1 = torch.sqrt(var1 + bn1.eps)
+            sc1 = (g1.double() / sig1)
+            ap = (a * sc1.float() + (b1.double() - mu1 * sc1).float()).contiguous()
+            bp = (b * sc1.float()).contiguous()
+            nparts = _lib.query("samble_edge_partial_count")
+            ymax = torch.empty_like(a)
+            ymin = torch.empty_like(a)
+            part = torch.empty((nparts, 2, C), dtype=torch.float64, device=dev)
+            _lib.call("samble_edge_mlp_fwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(), B, N, K,
+                      C, ymax.data_ptr(), ymin.data_ptr(), part.data_ptr(), ops._stream())
+            if training:
+                tot = part.sum(0)
+                mu2 = tot[0] / E
+                var2 = (tot[1] / E - mu2 * mu2).clamp_min(0)
+            else:
+                mu2, var2 = bn2.running_mean.double(), bn2.running_var.double()
+            sig2 = torch.sqrt(var2 + bn2.eps)
+            sc2 = g2.double() / sig2
+            ext = torch.where(g2 >= 0, ymax, ymin)
+            v = ((ext - mu2.float()) * sc2.float() + b2).contiguous()
+            out = torch.maximum(v, 0.2 * v)
+            if training:
+                with torch.no_grad():
+                    for bn, mu, var in ((bn1, mu1, var1), (bn2, mu2, var2)):
+                        if bn.track_running_stats and bn.running_mean is not None:
+                            bn.num_batches_tracked += 1
+                            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                            bn.running_mean.mul_(1 - m).add_(m * mu.to(bn.running_mean.dtype))
+                            bn.running_var.mul_(1 - m).add_(m * (var * E / (E - 1)).to(bn.running_var.dtype))
+        ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2)
+        ctx.stats = (mu1, sig1, sc1, mu2, sig2, sc2)
+        ctx.training = training
+        return out.permute(0, 2, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2 = ctx.saved_tensors
+        mu1, sig1, sc1, mu2, sig2, sc2 = ctx.stats
+        B, N, C = a.shape
+        K = nn_idx.shape[2]
+        E = B * N * K
+        dev = a.device
+        gt = g.permute(0, 2, 1)
+        dv = (gt * torch.where(v > 0, 1.0, 0.2)).contiguous()
+        yhat = (ext.double() - mu2) / sig2
+        sum_dv = dv.double().sum((0, 1))
+        sum_dvy = (dv.double() * yhat).sum((0, 1))
+        dbeta2, dgamma2 = sum_dv, sum_dvy
+        if ctx.training:
+            m1, m2 = sum_dv / E, sum_dvy / E
+        else:
+            m1 = m2 = torch.zeros_like(sum_dv)
+        c1 = -sc2 * m2 / sig2
+        c0 = -sc2 * m1 - c1 * mu2
+        c0c1 = torch.stack((c0, c1)).float().contiguous()
+        sdv = (dv * sc2.float()).contiguous()
+        with torch.cuda.device(dev):
+            nparts = _lib.query("samble_edge_partial_count")
+            du = torch.empty((B, N, K, C), dtype=torch.float32, device=dev)
+            dwp = torch.empty((nparts, C, C), dtype=torch.float32, device=dev)
+            _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
+                      ext.data_ptr(), sdv.data_ptr(), c0c1.data_ptr(), B, N, K, C, du.data_ptr(), dwp.data_ptr(),
+                      ops._stream())
+        dw2 = dwp.sum(0)
+        dusum = du.sum(2)                                                # sum_k du_ik
+        flat_j = (nn_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).reshape(-1)
+        D = torch.zeros((B * N, C), dtype=torch.float32, device=dev).index_add_(0, flat_j, du.view(-1, C)).view(B, N, C)
+        sum_du = dusum.double().sum((0, 1))
+        sum_duz = ((a.double() * dusum).sum((0, 1)) + (b.double() * D).sum((0, 1)) - mu1 * sum_du) / sig1
+        dbeta1, dgamma1 = sum_du, sum_duz
+        if ctx.training:
+            m1p, m2p = (sum_du / E).float(), (sum_duz / E).float()
+            indeg = torch.bincount(flat_j, minlength=B * N).view(B, N, 1).float()
+            R = torch.zeros((B * N, C), dtype=torch.float32, device=dev).index_add_(
+                0, flat_j, a.unsqueeze(2).expand(B, N, K, C).reshape(-1, C)).view(B, N, C)
+            mu1f, sig1f = mu1.float(), sig1.float()
+            Zs = (K * a + S - K * mu1f) / sig1f
+            Zr = (R + indeg * (b - mu1f)) / sig1f
+            da = sc1.float() * (dusum - K * m1p - m2p * Zs)
+            db = sc1.float() * (D - indeg * m1p - m2p * Zr)
+        else:
+            da = sc1.float() * dusum
+            db = sc1.float() * D
+        return (da, db, None, dgamma1.to(g1.dtype), dbeta1.to(g1.dtype), dw2.view(C, C, 1, 1), dgamma2.to(g2.dtype),
+                dbeta2.to(g2.dtype), None, None, None)
 
 
 class EdgeConv(nn.Module):
@@ -20,12 +164,30 @@ class EdgeConv(nn.Module):
                                    nn.LeakyReLU(negative_slope=0.2))
         self.conv2 = nn.Sequential(nn.Conv2d(c2_in, c2_out, kernel_size=1, bias=False), nn.BatchNorm2d(c2_out),
                                    nn.LeakyReLU(negative_slope=0.2))
+        self.fused = True  # False: the stock torch composition (A/B checks)
+
+    def _fusable(self, x):
+        bn1, bn2 = self.conv1[1], self.conv2[1]
+        return (self.fused and x.is_cuda and self.K == 32 and self.conv1[0].out_channels == 64
+                and self.conv2[0].in_channels == 64 and self.conv2[0].out_channels == 64 and bn1.affine and bn2.affine
+                and not (self.normal_channel and x.shape[1] == 6)
+                and (self.training or (bn1.running_mean is not None and bn2.running_mean is not None)))
 
     def forward(self, x):
-        x, _ = ops.group(x, self.K, self.group_type, self.normal_channel)
-        x = self.conv1(x)
-        x = self.conv2(x)
-        return x.max(dim=-1, keepdim=False)[0]
+        if not self._fusable(x):
+            x, _ = ops.group(x, self.K, self.group_type, self.normal_channel)
+            x = self.conv1(x)
+            x = self.conv2(x)
+            return x.max(dim=-1, keepdim=False)[0]
+        nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
+        wa, wb = _edge_weights(self.conv1[0].weight, self.group_type)
+        xt = x.permute(0, 2, 1)
+        a = torch.matmul(xt, wa.t())
+        b = torch.matmul(xt, wb.t())
+        bn1, bn2 = self.conv1[1], self.conv2[1]
+        use_batch_stats = self.training or not bn1.track_running_stats
+        return _EdgeMLP.apply(a, b, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias, bn1, bn2,
+                              use_batch_stats)
 
 
 def embedding_config(preset: str = "cls"):

@@ -124,6 +124,49 @@ def test_edgeconv_against_reference_fixture(name):
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err)
 
 
+@pytest.mark.parametrize("layer,B,N", [(0, 2, 256), (1, 2, 256), (1, 3, 1000), (0, 1, 2048)])
+@pytest.mark.parametrize("train", [True, False])
+def test_edgeconv_fused_matches_stock_composition(layer, B, N, train):
+    """The fused HIP EdgeConv body (no (B,C,N,K) tensor, BatchNorm statistics in closed form, max taken before
+    the monotone BN2 + LReLU) against the stock torch composition of the same module: output, running
+    statistics, and every gradient.  Negative gammas exercise the min branch."""
+    import copy
+    from samble_amd.embedding import EdgeConv, embedding_config
+    cfg = embedding_config("cls")
+    cin = cfg.conv1_in[layer] // 2
+    seed = 9100 + 10 * layer + N
+    mod = EdgeConv(cfg, layer)
+    with torch.no_grad():
+        mod.conv1[0].weight.copy_(_w(tuple(mod.conv1[0].weight.shape), seed + 1, 0.3 if cin == 3 else 0.1))
+        mod.conv2[0].weight.copy_(_w((64, 64, 1, 1), seed + 2, 0.12))
+        g1 = 1 + _w((64,), seed + 3, 0.1); g2 = 1 + _w((64,), seed + 5, 0.1)
+        g1[::7] *= -1; g2[::5] *= -1
+        mod.conv1[1].weight.copy_(g1); mod.conv1[1].bias.copy_(_w((64,), seed + 4, 0.1))
+        mod.conv2[1].weight.copy_(g2); mod.conv2[1].bias.copy_(_w((64,), seed + 6, 0.1))
+        if not train:  # give eval mode non-trivial running statistics
+            for bn, sd in ((mod.conv1[1], 7), (mod.conv2[1], 8)):
+                bn.running_mean.copy_(_w((64,), seed + sd, 0.2)); bn.running_var.copy_(1 + _w((64,), seed + sd + 2, 0.1).abs())
+    mod = mod.to(DEV)
+    ref = copy.deepcopy(mod)
+    ref.fused = False
+    (mod.train() if train else mod.eval()); (ref.train() if train else ref.eval())
+    x_np = synth.xyz_clouds(B, N, seed) if cin == 3 else synth.features(B, cin, N, seed)
+    x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
+    xr = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
+    g = torch.from_numpy(synth.normal((B, 64, N), seed + 20)).to(DEV)
+    y = mod(x); yr = ref(xr)
+    torch.testing.assert_close(y, yr, rtol=2e-4, atol=2e-4)
+    y.backward(g); yr.backward(g)
+    def close(got, want, tol, what):
+        err = (got - want).abs().max().item()
+        assert err <= tol * want.abs().max().item() + 1e-6, (what, err, want.abs().max().item())
+    close(x.grad, xr.grad, 2e-3, "dx")
+    for (n1, p1), (_, p2) in zip(mod.named_parameters(), ref.named_parameters()):
+        close(p1.grad, p2.grad, 2e-3, n1)
+    for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
+
+
 def test_upsample_interpolation_against_reference_fixture():
     from samble_amd.upsample import UpSampleInterpolation, upsample_config
     d = layer_fixture("layer_upsample_xyz")
