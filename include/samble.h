@@ -163,16 +163,18 @@ int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_
  *                                 the backward's closed forms are built from these per-point sums)
  *   samble_edge_mlp_fwd_f32       y = W2 LReLU(ap_i + bp_j) per edge on the MFMA units; returns per (point,
  *                                 channel) max_k y and min_k y (LReLU o BN2 is monotone, so max_k commutes with
- *                                 it) and samble_edge_partial_count() x (2,64) double partial sums of y, y^2
- *   samble_edge_mlp_bwd_f32       recomputes the edge tensors; dy = c0 + c1 y + [edge is the arg-ext] sdv;
+ *                                 it), the edge index that attains each (kmax, kmin; first one on ties) and
+ *                                 samble_edge_partial_count() x (2,64) double partial sums of y, y^2
+ *   samble_edge_mlp_bwd_f32       recomputes the edge tensors; dy = c0 + c1 y + [edge == kext] sdv;
  *                                 writes du (B*N, 32, 64) = gradient of the pre-activation ap_i + bp_j per
  *                                 edge and samble_edge_partial_count() x (64,64) partials of dW2 */
 int samble_edge_partial_count(void);
 int samble_edge_gather_sums_f32(const float* bp, const int32_t* nn, int B, int N, int K, int C, float* S, float* Q,
                                 void* stream);
 int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, int B, int N, int K,
-                            int C, float* ymax, float* ymin, double* partials, void* stream);
-int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, const float* yext,
+                            int C, float* ymax, float* ymin, uint8_t* kmax, uint8_t* kmin, double* partials,
+                            void* stream);
+int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, const uint8_t* kext,
                             const float* sdv, const float* c0c1, int B, int N, int K, int C, float* du,
                             float* dw2_partials, void* stream);
 

@@ -66,7 +66,7 @@ _SIGNATURES = {
     "samble_edge_partial_count": (c_int, []),
     "samble_edge_gather_sums_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_edge_mlp_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                        c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_edge_mlp_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                         c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_fps_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -32,9 +32,9 @@ int samble_launch_gather_rows(const float*, long, long, const long long*, int, i
 int samble_launch_blend_boundaries(const float*, float*, float*, int, float, float, int, hipStream_t);
 int samble_edge_waves(void);
 int samble_launch_edge_gather_sums(const float*, const int*, int, int, float*, float*, hipStream_t);
-int samble_launch_edge_mlp_fwd(const float*, const float*, const int*, const float*, int, int, float*, float*, double*,
-                               hipStream_t);
-int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const float*, const float*, const float*,
+int samble_launch_edge_mlp_fwd(const float*, const float*, const int*, const float*, int, int, float*, float*,
+                               unsigned char*, unsigned char*, double*, hipStream_t);
+int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const float*, const unsigned char*, const float*,
                                const float*, int, int, float*, float*, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
@@ -267,23 +267,24 @@ SAMBLE_API int samble_edge_gather_sums_f32(const float* bp, const int32_t* nn, i
 }
 
 SAMBLE_API int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, int B, int N,
-                                       int K, int C, float* ymax, float* ymin, double* partials, void* stream) {
-  if (!ap || !bp || !nn || !W2 || !ymax || !ymin || !partials)
+                                       int K, int C, float* ymax, float* ymin, uint8_t* kmax, uint8_t* kmin,
+                                       double* partials, void* stream) {
+  if (!ap || !bp || !nn || !W2 || !ymax || !ymin || !kmax || !kmin || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_fwd_f32: null pointer");
   if (K != 32 || C != 64 || B <= 0 || N <= 0)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_fwd_f32: built for K = 32 neighbours, 64 channels");
-  return done(samble_launch_edge_mlp_fwd(ap, bp, nn, W2, B, N, ymax, ymin, partials, (hipStream_t)stream),
+  return done(samble_launch_edge_mlp_fwd(ap, bp, nn, W2, B, N, ymax, ymin, kmax, kmin, partials, (hipStream_t)stream),
               "samble_edge_mlp_fwd_f32");
 }
 
 SAMBLE_API int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2,
-                                       const float* yext, const float* sdv, const float* c0c1, int B, int N, int K, int C,
+                                       const uint8_t* kext, const float* sdv, const float* c0c1, int B, int N, int K, int C,
                                        float* du, float* dw2_partials, void* stream) {
-  if (!ap || !bp || !nn || !W2 || !yext || !sdv || !c0c1 || !du || !dw2_partials)
+  if (!ap || !bp || !nn || !W2 || !kext || !sdv || !c0c1 || !du || !dw2_partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: null pointer");
   if (K != 32 || C != 64 || B <= 0 || N <= 0)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: built for K = 32 neighbours, 64 channels");
-  return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, yext, sdv, c0c1, B, N, du, dw2_partials, (hipStream_t)stream),
+  return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, kext, sdv, c0c1, B, N, du, dw2_partials, (hipStream_t)stream),
               "samble_edge_mlp_bwd_f32");
 }
 

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_fwd_kernel(const float* __res
                                                               const int* __restrict__ nn,
                                                               const float* __restrict__ W2, int N, long npoints,
                                                               float* __restrict__ ymax, float* __restrict__ ymin,
+                                                              unsigned char* __restrict__ kmax,
+                                                              unsigned char* __restrict__ kmin,
                                                               double* __restrict__ part) {
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
@@ -104,9 +106,20 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_fwd_kernel(const float* __res
       mn = fminf(mn, wave_xor32(mn));
       s += wave_xor32(s);
       q += wave_xor32(q);
+      // the edge that attains the extremum (first one on ties): the backward routes the gradient by index
+      int kx = 99, kn = 99;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        kx = min(kx, acc[ot][r] == mx ? crow(r, h) : 99);
+        kn = min(kn, acc[ot][r] == mn ? crow(r, h) : 99);
+      }
+      kx = min(kx, __shfl_xor(kx, 32, 64));
+      kn = min(kn, __shfl_xor(kn, 32, 64));
       if (h == 0) {
         ymax[p * kEC + 32 * ot + lo] = mx;
         ymin[p * kEC + 32 * ot + lo] = mn;
+        kmax[p * kEC + 32 * ot + lo] = (unsigned char)kx;
+        kmin[p * kEC + 32 * ot + lo] = (unsigned char)kn;
       }
       s1[ot] += (double)s;
       s2[ot] += (double)q;
@@ -134,7 +147,7 @@ constexpr int kEwPad = 68;  // LDS row stride of 64-float rows (16-byte aligned,
 __global__ __launch_bounds__(256, 1) void edge_mlp_bwd_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
                                                               const int* __restrict__ nn,
                                                               const float* __restrict__ W2,
-                                                              const float* __restrict__ yext,   // (npoints,64) max or min per the sign of gamma2
+                                                              const unsigned char* __restrict__ kext,  // (npoints,64) arg-max or arg-min edge per the sign of gamma2
                                                               const float* __restrict__ sdv,    // (npoints,64)
                                                               const float* __restrict__ c0c1,   // (2,64)
                                                               int N, long npoints, float* __restrict__ du,
@@ -188,24 +201,20 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_bwd_kernel(const float* __res
       }
     }
     // dy^T in place: register r of tile ot <-> channel o = 32 ot + crow(r, h), lane <-> edge
-    // the arg-ext edge of (point, o): the first edge whose y equals the stored extremum
     f32x16 dyt[2];
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 ext4 = *reinterpret_cast<const f32x4*>(yext + p * kEC + 32 * ot + 8 * g + 4 * h);
+        const uchar4 k4 = *reinterpret_cast<const uchar4*>(kext + p * kEC + 32 * ot + 8 * g + 4 * h);
+        const int kk4[4] = {k4.x, k4.y, k4.z, k4.w};
         const f32x4 sdv4 = *reinterpret_cast<const f32x4*>(sdv + p * kEC + 32 * ot + 8 * g + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const int o = 32 * ot + 8 * g + 4 * h + e;
           const float y = yt[ot][r];
-          // first matching edge among this half's 32 lanes (edges = lanes here): lowest lane wins
-          const unsigned long long m = __ballot(y == ext4[e]);
-          const unsigned int mh = (unsigned int)(h ? (m >> 32) : m);
-          const bool first = (y == ext4[e]) && ((mh & ((1u << lo) - 1u)) == 0u);
-          dyt[ot][r] = fmaf(cst[kEC + o], y, cst[o]) + (first ? sdv4[e] : 0.f);
+          dyt[ot][r] = fmaf(cst[kEC + o], y, cst[o]) + (lo == kk4[e] ? sdv4[e] : 0.f);  // edges = lanes here
         }
       }
       // park dy as [edge][o] for the dW2 product
@@ -279,15 +288,16 @@ extern "C" int samble_launch_edge_gather_sums(const float* bp, const int* nn, in
 }
 
 extern "C" int samble_launch_edge_mlp_fwd(const float* ap, const float* bp, const int* nn, const float* W2, int B, int N,
-                                          float* ymax, float* ymin, double* part, hipStream_t s) {
+                                          float* ymax, float* ymin, unsigned char* kmax, unsigned char* kmin,
+                                          double* part, hipStream_t s) {
   const long np = (long)B * N;
   hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), 0, s, ap, bp, nn, W2, N, np, ymax, ymin,
-                     part);
+                     kmax, kmin, part);
   return (int)hipGetLastError();
 }
 
 extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, const int* nn, const float* W2,
-                                          const float* yext, const float* sdv, const float* c0c1, int B, int N, float* du,
+                                          const unsigned char* yext, const float* sdv, const float* c0c1, int B, int N, float* du,
                                           float* dw2part, hipStream_t s) {
   const long np = (long)B * N;
   const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 4 * 2 * kEK * kEwPad) * sizeof(float);

@@ -72,9 +72,12 @@ class _EdgeMLP(torch.autograd.Function):
             nparts = _lib.query("samble_edge_partial_count")
             ymax = torch.empty_like(a)
             ymin = torch.empty_like(a)
+            kmax = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
+            kmin = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
             part = torch.empty((nparts, 2, C), dtype=torch.float64, device=dev)
             _lib.call("samble_edge_mlp_fwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(), B, N, K,
-                      C, ymax.data_ptr(), ymin.data_ptr(), part.data_ptr(), ops._stream())
+                      C, ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(), part.data_ptr(),
+                      ops._stream())
             if training:
                 tot = part.sum(0)
                 mu2 = tot[0] / E
@@ -84,6 +87,7 @@ class _EdgeMLP(torch.autograd.Function):
             sig2 = torch.sqrt(var2 + bn2.eps)
             sc2 = g2.double() / sig2
             ext = torch.where(g2 >= 0, ymax, ymin)
+            kext = torch.where(g2 >= 0, kmax, kmin).contiguous()
             v = ((ext - mu2.float()) * sc2.float() + b2).contiguous()
             out = torch.maximum(v, 0.2 * v)
             if training:
@@ -94,14 +98,14 @@ class _EdgeMLP(torch.autograd.Function):
                             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                             bn.running_mean.mul_(1 - m).add_(m * mu.to(bn.running_mean.dtype))
                             bn.running_var.mul_(1 - m).add_(m * (var * E / (E - 1)).to(bn.running_var.dtype))
-        ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2)
+        ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2, kext)
         ctx.stats = (mu1, sig1, sc1, mu2, sig2, sc2)
         ctx.training = training
         return out.permute(0, 2, 1)
 
     @staticmethod
     def backward(ctx, g):
-        a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2 = ctx.saved_tensors
+        a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2, kext = ctx.saved_tensors
         mu1, sig1, sc1, mu2, sig2, sc2 = ctx.stats
         B, N, C = a.shape
         K = nn_idx.shape[2]
@@ -126,7 +130,7 @@ class _EdgeMLP(torch.autograd.Function):
             du = torch.empty((B, N, K, C), dtype=torch.float32, device=dev)
             dwp = torch.empty((nparts, C, C), dtype=torch.float32, device=dev)
             _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
-                      ext.data_ptr(), sdv.data_ptr(), c0c1.data_ptr(), B, N, K, C, du.data_ptr(), dwp.data_ptr(),
+                      kext.data_ptr(), sdv.data_ptr(), c0c1.data_ptr(), B, N, K, C, du.data_ptr(), dwp.data_ptr(),
                       ops._stream())
         dw2 = dwp.sum(0)
         dusum = du.sum(2)                                                # sum_k du_ik
