@@ -128,8 +128,12 @@ def test_edgeconv_against_reference_fixture(name):
 @pytest.mark.parametrize("train", [True, False])
 def test_edgeconv_fused_matches_stock_composition(layer, B, N, train):
     """The fused HIP EdgeConv body (no (B,C,N,K) tensor, BatchNorm statistics in closed form, max taken before
-    the monotone BN2 + LReLU) against the stock torch composition of the same module: output, running
-    statistics, and every gradient.  Negative gammas exercise the min branch."""
+    the monotone BN2 + LReLU) against the stock torch composition of the same module run in fp64: output,
+    running statistics, and every gradient.  Negative gammas exercise the min branch.
+    max over K is discontinuous: where two edges tie to within rounding the arg-max (and with it a few
+    gradient entries) may differ between ANY two fp32 evaluations -- the stock fp32 path deviates from its
+    own fp64 run the same way -- so gradients are compared in the relative L2 norm, with the stock fp32
+    path's own deviation as the yardstick."""
     import copy
     from samble_amd.embedding import EdgeConv, embedding_config
     cfg = embedding_config("cls")
@@ -147,24 +151,32 @@ def test_edgeconv_fused_matches_stock_composition(layer, B, N, train):
             for bn, sd in ((mod.conv1[1], 7), (mod.conv2[1], 8)):
                 bn.running_mean.copy_(_w((64,), seed + sd, 0.2)); bn.running_var.copy_(1 + _w((64,), seed + sd + 2, 0.1).abs())
     mod = mod.to(DEV)
-    ref = copy.deepcopy(mod)
-    ref.fused = False
-    (mod.train() if train else mod.eval()); (ref.train() if train else ref.eval())
+    ref32 = copy.deepcopy(mod); ref32.fused = False
+    ref64 = copy.deepcopy(mod).double(); ref64.fused = False
+    for m_ in (mod, ref32, ref64):
+        m_.train() if train else m_.eval()
     x_np = synth.xyz_clouds(B, N, seed) if cin == 3 else synth.features(B, cin, N, seed)
-    x = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
-    xr = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
     g = torch.from_numpy(synth.normal((B, 64, N), seed + 20)).to(DEV)
-    y = mod(x); yr = ref(xr)
-    torch.testing.assert_close(y, yr, rtol=2e-4, atol=2e-4)
-    y.backward(g); yr.backward(g)
-    def close(got, want, tol, what):
-        err = (got - want).abs().max().item()
-        assert err <= tol * want.abs().max().item() + 1e-6, (what, err, want.abs().max().item())
-    close(x.grad, xr.grad, 2e-3, "dx")
-    for (n1, p1), (_, p2) in zip(mod.named_parameters(), ref.named_parameters()):
-        close(p1.grad, p2.grad, 2e-3, n1)
-    for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
-        torch.testing.assert_close(b1.float(), b2.float(), rtol=1e-4, atol=1e-5, msg=n1)
+    outs = []
+    for m_, dt in ((mod, torch.float32), (ref32, torch.float32), (ref64, torch.float64)):
+        x = torch.from_numpy(x_np).to(DEV, dt).requires_grad_(True)
+        y = m_(x)
+        y.backward(g.to(dt))
+        outs.append((x, y))
+    (x, y), (x32, y32), (x64, y64) = outs
+    assert y.dtype == torch.float32 and y.shape == (B, 64, N)
+    torch.testing.assert_close(y.double(), y64, rtol=2e-4, atol=2e-4)
+
+    def rel(got, want):
+        return ((got.double() - want).norm() / want.norm().clamp_min(1e-30)).item()
+    checks = [("dx", x.grad, x32.grad, x64.grad)]
+    for (n1, p1), (_, p2), (_, p3) in zip(mod.named_parameters(), ref32.named_parameters(), ref64.named_parameters()):
+        checks.append((n1, p1.grad, p2.grad, p3.grad))
+    for name, got, stock32, stock64 in checks:
+        mine, theirs = rel(got, stock64), rel(stock32, stock64)
+        assert mine <= max(3e-4, 4 * theirs), (name, mine, theirs)
+    for (n1, b1), (_, b3) in zip(mod.named_buffers(), ref64.named_buffers()):
+        torch.testing.assert_close(b1.double(), b3.double(), rtol=1e-4, atol=1e-5, msg=n1)
 
 
 def test_upsample_interpolation_against_reference_fixture():
