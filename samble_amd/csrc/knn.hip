@@ -382,6 +382,87 @@ __global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused exact-distance + top-K for tiny channel counts (xyz, C <= 8): EdgeConv's first layer and the
+// interpolation upsampling.  Lane = one query with its coordinates in registers; the key set streams
+// through LDS in chunks (every lane reads the same key: LDS broadcast); d^2 = sum_c (a_c - b_c)^2 is
+// accumulated exactly like smallc_keys_kernel; candidates below the lane's bound go to a per-lane LDS
+// queue and are inserted into the packed-double sorted list (w bits | index: ties by ascending index)
+// when any lane's queue is full.  No (B, Nk, Nq) key matrix (537 MB at B = 32, N = 2048).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallChunk = 512;  // keys per LDS chunk
+constexpr int kSmallQueue = 16;
+
+template <int KN>
+__global__ __launch_bounds__(256) void knn_smallc_fused_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                               const float* __restrict__ xk, long k_bs, int Nk, int C,
+                                                               int* __restrict__ idx_out, float* __restrict__ key_out) {
+  __shared__ float kx[8 * kSmallChunk];
+  __shared__ float qw[kSmallQueue * 256];
+  __shared__ unsigned short qj[kSmallQueue * 256];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int i = blockIdx.x * 256 + tid;
+  const bool valid = i < Nq;
+  float q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) q[c] = (c < C && valid) ? xq[(long)b * q_bs + (long)c * Nq + i] : 0.f;
+  double L[KN];
+#pragma unroll
+  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
+  float thr = __builtin_huge_valf();
+  int cnt = 0;
+  auto drain = [&]() {
+    for (int s = 0; s < kSmallQueue; ++s) {
+      if (!__any(s < cnt)) break;
+      const double xd = (s < cnt) ? pack_wj(qw[s * 256 + tid], qj[s * 256 + tid]) : __builtin_huge_val();
+      insert_packed<KN>(L, xd);
+    }
+    cnt = 0;
+    thr = (float)L[KN - 1];  // index bits are far below half a float ulp: exactly the K-th w (or +inf)
+  };
+  for (int j0 = 0; j0 < Nk; j0 += kSmallChunk) {
+    const int nj = min(kSmallChunk, Nk - j0);
+    __syncthreads();  // previous chunk fully consumed
+    for (int c = 0; c < C; ++c)
+      for (int e = tid; e < nj; e += 256) kx[c * kSmallChunk + e] = xk[(long)b * k_bs + (long)c * Nk + j0 + e];
+    __syncthreads();
+    for (int jj = 0; jj < nj; ++jj) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+          const float d = q[c] - kx[c * kSmallChunk + jj];
+          acc = fmaf(d, d, acc);
+        }
+      }
+      if (valid && acc <= thr) {
+        qw[cnt * 256 + tid] = acc;
+        qj[cnt * 256 + tid] = (unsigned short)(j0 + jj);
+        ++cnt;
+      }
+      if (__any(cnt == kSmallQueue)) drain();
+    }
+  }
+  drain();
+  if (valid) {
+    int* io = idx_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+    for (int s = 0; s < KN; ++s) io[s] = (int)(__double_as_longlong(L[s]) & 0x1FFFFFFFll);
+    if (key_out) {
+      float* ko = key_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+      for (int s = 0; s < KN; ++s) ko[s] = (float)L[s];
+    }
+  }
+}
+
+template <int KN>
+static void launch_smallc_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
+                                int* idx, float* keys, hipStream_t s) {
+  hipLaunchKernelGGL(knn_smallc_fused_kernel<KN>, dim3((Nq + 255) / 256, B), dim3(256), 0, s, xq, q_bs, Nq, xk, k_bs, Nk,
+                     C, idx, keys);
+}
+
 // test hooks: 1 forces the round-1 two-kernel path (key matrix through HBM) for A/B checks
 static bool g_force_unfused = false;
 static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
@@ -484,7 +565,8 @@ static bool knn_uses_fused(int C, int K, int Nk) {
 
 // the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path
 extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K) {
-  const size_t key_matrix = knn_uses_fused(C, K, Nk) ? 0 : (size_t)B * Nk * Nq;
+  const bool small_fused = C <= 8 && !g_force_unfused && Nk <= 65536 && Nk >= K;
+  const size_t key_matrix = (knn_uses_fused(C, K, Nk) || small_fused) ? 0 : (size_t)B * Nk * Nq;
   return key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
 }
 
@@ -492,7 +574,8 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
                                  int K, int* idx_out, float* dist_out, float* ws, hipStream_t stream) {
   const bool fused = knn_uses_fused(C, K, Nk);
   float* keyT = ws;
-  float* knorm = keyT + (fused ? 0 : (size_t)B * Nk * Nq);
+  const bool small_fused = C <= 8 && !g_force_unfused && Nk <= 65536 && Nk >= K;
+  float* knorm = keyT + ((fused || small_fused) ? 0 : (size_t)B * Nk * Nq);
   float* qnorm = knorm + (size_t)B * Nk;
   float* scale = qnorm + (size_t)B * Nq;
   float* keys = scale + B;
@@ -509,6 +592,22 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
     else rc = launch_fused<64, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
     if (rc) return rc;
   } else {
+    if (smallc && !g_force_unfused && Nk <= 65536 && Nk >= K) {
+      bool ok = true;
+      switch (K) {
+        case 1: launch_smallc_fused<1>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 3: launch_smallc_fused<3>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 8: launch_smallc_fused<8>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 16: launch_smallc_fused<16>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 20: launch_smallc_fused<20>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 32: launch_smallc_fused<32>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 40: launch_smallc_fused<40>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        case 64: launch_smallc_fused<64>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
+        default: ok = false;
+      }
+      if (!ok) return -22;
+      goto selected;
+    }
     if (smallc) {
       hipLaunchKernelGGL(smallc_keys_kernel, dim3((Nq + 255) / 256, Nk, B), dim3(256), 0, stream, xq, q_bs, Nq, xk,
                          k_bs, Nk, C, keyT);
@@ -529,6 +628,7 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
       default: return -22;
     }
   }
+selected:
   if (dist_out) {
     if (!smallc && !fused) hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
     hipLaunchKernelGGL(knn_scale_kernel, dim3(B), dim3(256), 0, stream, xq, q_bs, C, Nq, scale);
