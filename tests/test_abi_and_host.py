@@ -34,7 +34,8 @@ def test_header_symbols_are_exported(lib):
 def test_library_loads_and_reports_version(lib):
     handle = lib.load()
     assert b"gfx950" in handle.samble_version()
-    assert lib.query("samble_knn_workspace_bytes", 32, 3, 2048, 2048, 3) >= 32 * 2048 * 2048 * 4  # two-kernel path
+    assert lib.query("samble_knn_workspace_bytes", 32, 3, 2048, 2048, 3) < 32 * 2048 * 64 * 4  # xyz: fused, no key matrix
+    assert lib.query("samble_knn_workspace_bytes", 4, 32, 512, 512, 8) >= 4 * 512 * 512 * 4  # C = 32: two-kernel path
     assert lib.query("samble_knn_workspace_bytes", 32, 128, 2048, 2048, 32) < 32 * 2048 * 64 * 4  # fused: no key matrix
 
 
