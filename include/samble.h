@@ -199,8 +199,19 @@ int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
  * rows [dQ|dK|dV] (feed it to samble_proj_bwd_f32).  Deterministic (no atomics).  K <= 32. */
 size_t samble_n2p_attn_bwd_workspace_bytes(int B, int N, int KN);
 int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, const float* g, int B, int N,
-                            int KN, int C, int heads, int diff, float* dqkv, int64_t dbs, int64_t drs, void* ws,
-                            size_t ws_bytes, void* stream);
+                            int KN, int C, int heads, int diff, float* dqkv, int64_t dbs, int64_t drs,
+                            const int32_t* inv_order, const int32_t* inv_offsets, void* ws, size_t ws_bytes,
+                            void* stream);
+
+/* Inverse neighbour lists (optional input above, required below): inv_order (B*N*K) = the edge ids
+ * e = (b*N + i)*K + k sorted by target b*N + nn[e], ties in ascending e (a STABLE sort of the neighbour
+ * table; the host builds it once per kNN), inv_offsets (B*N + 1) = the group boundaries.  With them the
+ * scatter-add over neighbours becomes a gather in a fixed order: deterministic, no atomics, no table scan.
+ * samble_segment_sum_rows_f32: out[t][0:C] = sum over the incoming edges e of target t of
+ * src[per_edge ? e : e / K][0:C]  (C = 64): EdgeConv's backward (sum of per-edge gradients / of the
+ * sources' per-point rows over a point's reverse neighbours). */
+int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K, int C,
+                                int per_edge, int64_t n_targets, float* out, void* stream);
 
 /* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows

@@ -45,7 +45,8 @@ int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, in
                            float*, long, float*, float*, float*, hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
-                          long, float*, int, hipStream_t);
+                          long, float*, int, const int*, const int*, hipStream_t);
+int samble_launch_seg_sum_rows64(const float*, const int*, const int*, int, int, long, float*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
                           hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
@@ -288,6 +289,16 @@ SAMBLE_API int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const i
               "samble_edge_mlp_bwd_f32");
 }
 
+SAMBLE_API int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K,
+                                           int C, int per_edge, int64_t n_targets, float* out, void* stream) {
+  if (!src || !inv_order || !inv_offsets || !out)
+    return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_f32: null pointer");
+  if (C != 64 || K <= 0 || n_targets <= 0) return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_f32: built for 64 channels");
+  return done(samble_launch_seg_sum_rows64(src, inv_order, inv_offsets, K, per_edge, (long)n_targets, out,
+                                           (hipStream_t)stream),
+              "samble_segment_sum_rows_f32");
+}
+
 SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out,
                               void* stream) {
   if (!xyz || !start || !out) return fail(SAMBLE_E_INVALID, "samble_fps_f32: null pointer");
@@ -491,7 +502,10 @@ SAMBLE_API size_t samble_n2p_attn_bwd_workspace_bytes(int B, int N, int KN) {
 
 SAMBLE_API int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, const float* g,
                                        int B, int N, int KN, int C, int heads, int diff, float* dqkv, int64_t dbs,
-                                       int64_t drs, void* ws, size_t ws_bytes, void* stream) {
+                                       int64_t drs, const int32_t* inv_order, const int32_t* inv_offsets, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if ((inv_order == nullptr) != (inv_offsets == nullptr))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: inverse lists need both arrays");
   if (!qkv || !nn || !g || !dqkv || !ws) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: null pointer");
   if (C != 128 || (heads != 4 && heads != 1))
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128 with 4 heads of 32 or 1 head of 128");
@@ -501,6 +515,6 @@ SAMBLE_API int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs,
   if (ws_bytes < samble_n2p_attn_bwd_workspace_bytes(B, N, KN))
     return fail(SAMBLE_E_WORKSPACE, "samble_n2p_attn_bwd_f32: workspace too small");
   return done(samble_launch_n2p_bwd(qkv, bs, rs, nn, g, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), dqkv,
-                                    dbs, drs, (float*)ws, heads, (hipStream_t)stream),
+                                    dbs, drs, (float*)ws, heads, inv_order, inv_offsets, (hipStream_t)stream),
               "samble_n2p_attn_bwd_f32");
 }

@@ -347,7 +347,90 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pass 2 as a segment gather over INVERSE neighbour lists.  `order` lists the edge ids e = i*K + k
+// (per cloud-global point index) grouped by target j = nn[e], inside a group in ascending e (a stable
+// sort of the neighbour table: built once per kNN by the host), `offs` the group boundaries.  A
+// half-wave owns one target and sums its incoming edges in list order: no scan of the whole table,
+// no atomics, run-to-run identical, and the work is the forward's gather volume.
+//   dK[j] += sum_e DL[e][head] q[i(e)],   dV[j] += sum_e A[e][head] g[i(e)]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float* __restrict__ qkv, long bs, long rs,
+                                                             const float* __restrict__ gt, const float* __restrict__ A,
+                                                             const float* __restrict__ DL,
+                                                             const int* __restrict__ order,
+                                                             const int* __restrict__ offs, int N, int KN, long ntargets,
+                                                             float* __restrict__ dqkv, long dbs, long drs, int heads) {
+  const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;  // lane = channels 4c .. 4c+3
+  const int head = (heads == 4) ? (c >> 3) : 0;
+  for (long t = (long)blockIdx.x * 8 + hw; t < ntargets; t += (long)gridDim.x * 8) {
+    const long cloud = t / N;
+    const int j = (int)(t - cloud * N);
+    f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+    const int e0 = offs[t], e1 = offs[t + 1];
+    for (int s = e0; s < e1; ++s) {
+      const long e = order[s];            // global edge id: (cloud*N + i)*KN + k
+      const long pi = e / KN;             // cloud*N + i
+      const long i = pi - cloud * N;
+      const float dl = DL[e * 4 + head], aa = A[e * 4 + head];
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qkv + cloud * bs + i * rs + 4 * c);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + pi * 128 + 4 * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ak[u] = fmaf(dl, qv[u], ak[u]);
+        av[u] = fmaf(aa, gv[u], av[u]);
+      }
+    }
+    float* drow = dqkv + cloud * dbs + (long)j * drs + 4 * c;
+    f32x4 k0 = *reinterpret_cast<f32x4*>(drow + 128), v0 = *reinterpret_cast<f32x4*>(drow + 256);
+    k0 += ak;
+    v0 += av;
+    *reinterpret_cast<f32x4*>(drow + 128) = k0;  // the self rows of pass 1 + the gathered share
+    *reinterpret_cast<f32x4*>(drow + 256) = v0;
+  }
+}
+
+// out[t][0:C] = sum over the incoming edges e of target t of src[per_edge ? e : e / K][0:C]  (C = 64),
+// in list order: the deterministic replacement of index_add_ for EdgeConv's backward
+__global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __restrict__ src, const int* __restrict__ order,
+                                                             const int* __restrict__ offs, int KN, int per_edge,
+                                                             long ntargets, float* __restrict__ out) {
+  const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;  // lane = channels 2c, 2c+1
+  for (long t = (long)blockIdx.x * 8 + hw; t < ntargets; t += (long)gridDim.x * 8) {
+    float s0 = 0.f, s1 = 0.f;
+    const int e0 = offs[t], e1 = offs[t + 1];
+    int s = e0;
+    for (; s + 4 <= e1; s += 4) {  // four rows in flight
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long e = order[s + u];
+        v[u] = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * 64 + 2 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0 += v[u].x;
+        s1 += v[u].y;
+      }
+    }
+    for (; s < e1; ++s) {
+      const long e = order[s];
+      const float2 v = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * 64 + 2 * c);
+      s0 += v.x;
+      s1 += v.y;
+    }
+    *reinterpret_cast<float2*>(out + t * 64 + 2 * c) = make_float2(s0, s1);
+  }
+}
+
 }  // namespace samble
+
+extern "C" int samble_launch_seg_sum_rows64(const float* src, const int* order, const int* offs, int KN, int per_edge,
+                                            long ntargets, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(samble::seg_sum_rows64_kernel, dim3(2048), dim3(256), 0, s, src, order, offs, KN, per_edge, ntargets,
+                     out);
+  return (int)hipGetLastError();
+}
 
 extern "C" size_t samble_n2p_bwd_ws_floats(int B, int N, int KN) {
   return (size_t)B * N * 128 + 2 * (size_t)B * N * KN * 4 + 64;
@@ -355,7 +438,7 @@ extern "C" size_t samble_n2p_bwd_ws_floats(int B, int N, int KN) {
 
 extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const int* nn, const float* g, int B, int N,
                                      int KN, int diff, float scale, float* dqkv, long dbs, long drs, float* ws,
-                                     int heads, hipStream_t s) {
+                                     int heads, const int* order, const int* offs, hipStream_t s) {
   using namespace samble;
   if (heads != 1 && heads != 4) return -22;
   float* gt = ws;
@@ -372,7 +455,11 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
   hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
                      scale, dqkv, dbs, drs, A, DL, heads);
-  hipLaunchKernelGGL(n2p_bwd_scatter_kernel, dim3((N + kScatRows - 1) / kScatRows, B), dim3(256), lds, s, qkv, bs, rs,
-                     nn, gt, A, DL, N, KN, dqkv, dbs, drs, heads);
+  if (order && offs)
+    hipLaunchKernelGGL(n2p_bwd_gather_kernel, dim3(2048), dim3(256), 0, s, qkv, bs, rs, gt, A, DL, order, offs, N, KN,
+                       (long)B * N, dqkv, dbs, drs, heads);
+  else
+    hipLaunchKernelGGL(n2p_bwd_scatter_kernel, dim3((N + kScatRows - 1) / kScatRows, B), dim3(256), lds, s, qkv, bs, rs,
+                       nn, gt, A, DL, N, KN, dqkv, dbs, drs, heads);
   return (int)hipGetLastError();
 }

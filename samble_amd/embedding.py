@@ -134,16 +134,16 @@ class _EdgeMLP(torch.autograd.Function):
                       ops._stream())
         dw2 = dwp.sum(0)
         dusum = du.sum(2)                                                # sum_k du_ik
-        flat_j = (nn_idx.long() + (torch.arange(B, device=dev) * N).view(B, 1, 1)).reshape(-1)
-        D = torch.zeros((B * N, C), dtype=torch.float32, device=dev).index_add_(0, flat_j, du.view(-1, C)).view(B, N, C)
+        # reverse-neighbour sums in a fixed order (inverse lists from a stable sort), not index_add_'s atomics
+        order, offsets, counts = ops.inverse_neighbors(nn_idx)
+        D = ops.stage_segment_sum_rows(du.view(-1, C), order, offsets, K, per_edge=True).view(B, N, C)
         sum_du = dusum.double().sum((0, 1))
         sum_duz = ((a.double() * dusum).sum((0, 1)) + (b.double() * D).sum((0, 1)) - mu1 * sum_du) / sig1
         dbeta1, dgamma1 = sum_du, sum_duz
         if ctx.training:
             m1p, m2p = (sum_du / E).float(), (sum_duz / E).float()
-            indeg = torch.bincount(flat_j, minlength=B * N).view(B, N, 1).float()
-            R = torch.zeros((B * N, C), dtype=torch.float32, device=dev).index_add_(
-                0, flat_j, a.unsqueeze(2).expand(B, N, K, C).reshape(-1, C)).view(B, N, C)
+            indeg = counts.view(B, N, 1).float()
+            R = ops.stage_segment_sum_rows(a.view(-1, C), order, offsets, K, per_edge=False).view(B, N, C)
             mu1f, sig1f = mu1.float(), sig1.float()
             Zs = (K * a + S - K * mu1f) / sig1f
             Zr = (R + indeg * (b - mu1f)) / sig1f

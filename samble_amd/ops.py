@@ -111,7 +111,34 @@ def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff
     return (out, att) if want_att else out
 
 
-def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor, heads: int, diff: bool) -> torch.Tensor:
+def inverse_neighbors(nn_idx: torch.Tensor):
+    """Inverse neighbour lists of a kNN table nn_idx (B,N,K): (order (B*N*K) int32 = edge ids
+    e = (b*N + i)*K + k grouped by target b*N + nn[e], ascending e inside a group; offsets (B*N + 1) int32).
+    A stable sort of the table: radix sort on the GPU, deterministic."""
+    B, N, K = nn_idx.shape
+    flat = (nn_idx.long() + (torch.arange(B, device=nn_idx.device) * N).view(B, 1, 1)).reshape(-1)
+    order = torch.sort(flat, stable=True)[1].to(torch.int32)
+    counts = torch.bincount(flat, minlength=B * N)
+    offsets = torch.zeros(B * N + 1, dtype=torch.int32, device=nn_idx.device)
+    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return order.contiguous(), offsets, counts
+
+
+def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torch.Tensor, K: int, per_edge: bool):
+    """out[t] = sum over the incoming edges e of target t of src[e] (per_edge) or src[e // K]; src (*, 64),
+    list order: deterministic replacement of index_add_."""
+    _need_gpu(src, order, offsets)
+    src = _f32c(src)
+    T = offsets.numel() - 1
+    with torch.cuda.device(src.device):
+        out = torch.empty((T, 64), dtype=torch.float32, device=src.device)
+        _lib.call("samble_segment_sum_rows_f32", src.data_ptr(), order.data_ptr(), offsets.data_ptr(), K, 64,
+                  int(bool(per_edge)), T, out.data_ptr(), _stream())
+    return out
+
+
+def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor, heads: int, diff: bool,
+                       use_inverse_lists: bool = True) -> torch.Tensor:
     """g (B,C,N) -> dqkv (B,N,3C) of the gather-attention (deterministic)."""
     _need_gpu(qkv, nn_idx, g)
     g = _f32c(g)
@@ -121,9 +148,12 @@ def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor,
         dqkv = torch.empty_like(qkv)
         nbytes = _lib.query("samble_n2p_attn_bwd_workspace_bytes", B, N, K)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        order = offsets = None
+        if use_inverse_lists:
+            order, offsets, _ = inverse_neighbors(nn_idx)
         _lib.call("samble_n2p_attn_bwd_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), nn_idx.data_ptr(),
                   g.data_ptr(), B, N, K, C3 // 3, heads, int(bool(diff)), dqkv.data_ptr(), dqkv.stride(0),
-                  dqkv.stride(1), ws.data_ptr(), nbytes, _stream())
+                  dqkv.stride(1), _p(order), _p(offsets), ws.data_ptr(), nbytes, _stream())
     return dqkv
 
 

@@ -84,6 +84,8 @@ def test_n2p_backward_kernels_match_autograd_of_the_restatement():
             err = (got - ref).abs().max().item()
             assert err <= 2e-5 * ref.abs().max().item() + 1e-7, (diff, err, ref.abs().max().item())
             assert torch.equal(got, ops.stage_n2p_attn_bwd(qkv, nn_idx, g, H, diff)), "run-to-run identical"
+            # the table-scan scatter kernel and the inverse-list gather sum the same edges in the same order
+            assert torch.equal(got, ops.stage_n2p_attn_bwd(qkv, nn_idx, g, H, diff, use_inverse_lists=False))
 
 
 def test_n2p_metric_size_runs_and_matches_torch_restatement():
