@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_fwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 constexpr int kEwPad = 68;  // LDS row stride of 64-float rows (16-byte aligned, odd multiple of 16 bytes)
 
-__global__ __launch_bounds__(256, 1) void edge_mlp_bwd_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
+__global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
                                                               const int* __restrict__ nn,
                                                               const float* __restrict__ W2,
                                                               const unsigned char* __restrict__ kext,  // (npoints,64) arg-max or arg-min edge per the sign of gamma2
@@ -159,10 +159,10 @@ __global__ __launch_bounds__(256, 1) void edge_mlp_bwd_kernel(const float* __res
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   float* hts = cst + 2 * kEC + wave * (2 * kEK * kEwPad);  // this wave's [32 edges][68] h tile
   float* dys = hts + kEK * kEwPad;                         // and [32 edges][68] dy tile
-  for (int e = tid; e < kEC * kEC; e += 256) w2s[(e >> 6) * kEwPad + (e & 63)] = W2[e];
+  for (int e = tid; e < kEC * kEC; e += 512) w2s[(e >> 6) * kEwPad + (e & 63)] = W2[e];
   if (tid < 2 * kEC) cst[tid] = c0c1[tid];
   __syncthreads();
-  const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+  const long gw = (long)blockIdx.x * 8 + wave, nw = (long)gridDim.x * 8;  // 8 waves: two per SIMD
   f32x16 dw[2][2];  // dW2 tile [ot][ct]: rows = o (lanes of A), cols = c
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -300,7 +300,7 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
                                           const unsigned char* yext, const float* sdv, const float* c0c1, int B, int N, float* du,
                                           float* dw2part, hipStream_t s) {
   const long np = (long)B * N;
-  const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 4 * 2 * kEK * kEwPad) * sizeof(float);
+  const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 8 * 2 * kEK * kEwPad) * sizeof(float);  // 157 KB: one workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_mlp_bwd_kernel),
@@ -308,7 +308,7 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
+  hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
                      N, np, du, dw2part);
   return (int)hipGetLastError();
 }
