@@ -36,9 +36,19 @@ class UpSampleInterpolation(nn.Module):
             neighbors, _, d_neighbors = ops.select_neighbors_interpolate(pcd_up_xyz, points_select_xyz,
                                                                          points_select_conv, K=K)
         elif distance_type == "feature":
-            # the reference back-propagates through cdist of the features here; the HIP kNN returns
-            # distances as plain values, so this mode is not offered rather than silently different
-            raise NotImplementedError("distance_type 'feature' (differentiable distances) is not built; shipped: xyz")
+            # the reference back-propagates through cdist of the (normalised) features: the neighbour SEARCH
+            # runs on the HIP kNN kernels (indices carry no gradient), the K distances per point are then
+            # recomputed differentiably for the selected pairs only (utils/ops.py:17-44 normalisation)
+            _, idx, _ = ops.select_neighbors_interpolate(pcd_up.detach(), points_select.detach(),
+                                                         points_select_conv.detach(), K=K)
+            a = pcd_up.permute(0, 2, 1)
+            b = points_select.permute(0, 2, 1)
+            a_mean = torch.mean(a, dim=1, keepdim=True)
+            a, b = a - a_mean, b - a_mean
+            a_std = torch.mean(torch.std(a, dim=1, keepdim=True), dim=2, keepdim=True)
+            a, b = a / a_std, b / a_std
+            d_neighbors = torch.linalg.vector_norm(a.unsqueeze(2) - ops.index_points(b, idx), dim=-1)  # (B,N,K)
+            neighbors = ops.index_points(points_select_conv.permute(0, 2, 1), idx).permute(0, 3, 1, 2)
         else:
             raise ValueError(f"upsample interpolation distance type can only be feature or xyz! Got: {distance_type}")
         weights = 1.0 / (d_neighbors + 1e-8)

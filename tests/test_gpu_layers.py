@@ -355,3 +355,40 @@ def test_point2point_attention_matches_torch_restatement():
     assert (x.grad.cpu().double() - xd.grad).abs().max().item() <= 5e-4 * xd.grad.abs().max().item()
     for (n1, p1), (_, p2) in zip(mod.named_parameters(), ref.named_parameters()):
         assert (p1.grad.cpu().double() - p2.grad).abs().max().item() <= 1e-3 * p2.grad.abs().max().item() + 1e-6, n1
+
+
+def test_upsample_feature_distance_is_differentiable_like_the_reference_expression():
+    """distance_type 'feature' (reference models/upsample.py:186-189 -> utils/ops.py:17-44, 68-80): the
+    neighbour search runs on HIP, the K distances are recomputed differentiably.  Checked against the
+    reference's own expression (normalise, cdist, topk, inverse-distance weights) in fp64 torch."""
+    from samble_amd.upsample import UpSampleInterpolation, upsample_config
+    cfg = upsample_config("seg")
+    cfg.interpolation.distance_type = ["feature", "feature"]
+    mod = UpSampleInterpolation(cfg, 0).to(DEV).train()
+    B, C, N, M, K = 2, 128, 384, 96, 3
+    up = torch.from_numpy(synth.features(B, C, N, 8801)).to(DEV).requires_grad_(True)
+    down = torch.from_numpy(synth.features(B, C, M, 8802)).to(DEV).requires_grad_(True)
+    xyz_up = torch.from_numpy(synth.xyz_clouds(B, N, 8803)).to(DEV)
+    xyz_dn = xyz_up[:, :, :M].contiguous()
+    got = mod.interpolate(up, down, xyz_up, xyz_dn, distance_type="feature", K=K)
+    g = torch.from_numpy(synth.normal((B, C, N), 8804)).to(DEV)
+    got.backward(g)
+    # reference expression in fp64 with the module's own conv (train-mode BN)
+    import copy
+    ref = copy.deepcopy(mod).double()
+    u64 = up.detach().double().requires_grad_(True)
+    d64 = down.detach().double().requires_grad_(True)
+    conv = ref.conv(d64)
+    a = u64.permute(0, 2, 1); b = d64.permute(0, 2, 1)
+    am = a.mean(1, keepdim=True); a = a - am; b = b - am
+    sd = torch.std(a, dim=1, keepdim=True).mean(2, keepdim=True); a = a / sd; b = b / sd
+    dist, idx = (-torch.cdist(a, b)).topk(K, dim=-1)
+    d = -dist
+    nbr = torch.gather(conv.permute(0, 2, 1), 1, idx.reshape(B, -1, 1).expand(-1, -1, C)).view(B, N, K, C).permute(0, 3, 1, 2)
+    w = 1.0 / (d + 1e-8); w = w / w.sum(-1, keepdim=True)
+    want = (nbr * w.unsqueeze(1)).sum(-1)
+    want.backward(g.double())
+    torch.testing.assert_close(got.double(), want, rtol=2e-4, atol=2e-4)
+    for gg, ww, name in ((up.grad, u64.grad, "d pcd_up"), (down.grad, d64.grad, "d points_select")):
+        rel = ((gg.double() - ww).norm() / ww.norm()).item()
+        assert rel <= 2e-3, (name, rel)
