@@ -79,6 +79,75 @@ class FeatureLearningBlock(nn.Module):
         return self.conv(x).max(dim=-1)[0]
 
 
+class SegFeatureLearningBlock(nn.Module):
+    """The segmentation block (reference models/seg_model.py:7-133, seg.yaml): EdgeConv x2 -> N2P ->
+    [sampler -> N2P -> gather xyz] x2 -> [UpSampleInterpolation -> N2P] x2, returning per-point features
+    (B,128,N).  Wiring only; same submodule names and state_dict keys as the reference block."""
+
+    def __init__(self, config_feature_learning_block):
+        super().__init__()
+        cfg = config_feature_learning_block
+        sampler = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}.get(cfg.downsample.ds_which)
+        if sampler is None:
+            raise ValueError("Only global_carve and local_insert are valid for ds_which!")
+        if cfg.upsample.us_which != "interpolation":
+            if cfg.upsample.us_which in ("crossA", "selfA"):
+                raise NotImplementedError("us_which crossA / selfA are not built (shipped seg.yaml: interpolation)")
+            raise ValueError("Only crossA and selfA are valid for us_which!")
+        from .upsample import UpSampleInterpolation
+        self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
+        self.downsample_list = nn.ModuleList([sampler(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
+        self.feature_learning_layer_list = nn.ModuleList(
+            [Neighbor2PointAttention(cfg.attention, l) for l in range(len(cfg.attention.K))])
+        self.upsample_list = nn.ModuleList([UpSampleInterpolation(cfg.upsample, l) for l in range(len(cfg.upsample.q_in))])
+
+    def forward(self, x, noise_list=None):
+        x_xyz = x[:, :3, :]
+        x_list = []
+        for embedding in self.embedding_list:
+            x = embedding(x)
+            x_list.append(x)
+        x = torch.cat(x_list, dim=1)
+        x = self.feature_learning_layer_list[0](x)
+        x_list = [x]
+        points_drop_list, idx_select_list, idx_drop_list = [], [], []
+        x_xyz_list = [x_xyz]
+        for i in range(len(self.downsample_list)):
+            layer = self.downsample_list[i]
+            if isinstance(layer, DownSampleToken):
+                noise = None if noise_list is None else noise_list[i]
+                (x, idx_select), (points_drop, idx_drop) = layer(x, x_xyz, noise=noise)
+            else:
+                (x, idx_select), (points_drop, idx_drop) = layer(x, x_xyz)
+            x = self.feature_learning_layer_list[i + 1](x)
+            x_xyz = ops.gather_by_idx(x_xyz, idx_select)
+            x_list.append(x)
+            x_xyz_list.append(x_xyz)
+            points_drop_list.append(points_drop)
+            idx_select_list.append(idx_select)
+            idx_drop_list.append(idx_drop)
+        split = int((len(self.feature_learning_layer_list) - 1) / 2)
+        x = ((x_list.pop(), idx_select_list.pop(), x_xyz_list.pop()), (points_drop_list.pop(), idx_drop_list.pop()))
+        for j in range(len(self.upsample_list)):
+            x_tmp = x_list.pop()
+            x_xyz_tmp = x_xyz_list[-1 - j]
+            x = self.upsample_list[j](x_tmp, x, x_xyz_tmp)
+            x = self.feature_learning_layer_list[j + 1 + split](x)
+            if j < len(self.upsample_list) - 1:
+                x = ((x, idx_select_list.pop(), x_xyz_list[-1 - j]), (points_drop_list.pop(), idx_drop_list.pop()))
+        return x
+
+
+def seg_block_config(M=(1024, 512)):
+    """`config.feature_learning_block` of the shipped segmentation preset (seg.yaml)."""
+    from .attention import attention_config
+    from .config import sampler_config, to_attr
+    from .embedding import embedding_config
+    from .upsample import upsample_config
+    return to_attr(dict(embedding=embedding_config("seg"), downsample=sampler_config("seg", M=list(M)),
+                        attention=attention_config("seg"), upsample=upsample_config("seg")))
+
+
 def block_config(preset: str = "cls", M=(1024, 512)):
     """`config.feature_learning_block` of the shipped classification preset."""
     from .attention import attention_config

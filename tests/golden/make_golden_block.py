@@ -51,5 +51,32 @@ def main():
     print("block_cls_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()))
 
 
+def seg_main():
+    """The segmentation block (models/seg_model.py:7-133, seg.yaml: down 256 -> 128 -> 64, interpolation up)."""
+    from models import seg_model as ref_seg
+    torch.set_num_threads(8)
+    B, N, M, seed = 2, 256, [128, 64], 9300
+    cfg = block_config("seg")
+    cfg.downsample.M = list(M)
+    blk = ref_seg.FeatureLearningBlock(cfg)
+    fill_parameters(blk, seed)
+    blk.train()
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500))
+    nb = cfg.downsample.bin.num_bins[0]
+    torch.manual_seed(seed)
+    feat = blk(xyz)
+    torch.manual_seed(seed)
+    noise0 = O.draw_noise(B * nb, N)
+    noise1 = O.draw_noise(B * nb, M[0])
+    out = dict(meta=np.array([B, N, M[0], M[1], nb, seed], dtype=np.int64), feat=feat.detach().numpy(),
+               noise0=noise0.numpy(), noise1=noise1.numpy(),
+               idx0=blk.downsample_list[0].idx.numpy(), idx1=blk.downsample_list[1].idx.numpy(),
+               names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__))
+    path = os.path.join(HERE, "block_seg_small.npz")
+    np.savez_compressed(path, **out)
+    print("block_seg_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()))
+
+
 if __name__ == "__main__":
     main()
+    seg_main()

@@ -54,3 +54,42 @@ def test_cls_block_metric_size_forward_backward():
     assert blk.downsample_list[0].idx.shape == (32, 1, 1024) and blk.downsample_list[1].idx.shape == (32, 1, 512)
     feat.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+
+
+def test_seg_block_protocol_against_reference():
+    """BASELINE.json configs[2] geometry at a small size: the segmentation block (down 256 -> 128 -> 64 with
+    4 bins, interpolation upsampling back to 256) against the unmodified reference block's fixture."""
+    from samble_amd.blocks import SegFeatureLearningBlock, seg_block_config
+    d = layer_fixture("block_seg_small")
+    B, N, M0, M1, nb, seed = [int(v) for v in d["meta"]]
+    blk = SegFeatureLearningBlock(seg_block_config(M=(M0, M1)))
+    assert [n for n, _ in blk.named_parameters()] == [str(n) for n in d["names"]], "state_dict layout differs"
+    fill_parameters(blk, seed)
+    blk = blk.to(DEV).train()
+    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500)).to(DEV)
+    noise = [torch.from_numpy(d["noise0"]).to(DEV), torch.from_numpy(d["noise1"]).to(DEV)]
+    feat = blk(xyz, noise_list=noise)
+    assert feat.shape == (B, 128, N) and torch.isfinite(feat).all()
+    idx0, idx1 = blk.downsample_list[0].idx.cpu()[:, 0], blk.downsample_list[1].idx.cpu()[:, 0]
+    ref0, ref1 = torch.from_numpy(d["idx0"])[:, 0], torch.from_numpy(d["idx1"])[:, 0]
+    assert set_agreement(idx0, ref0) >= 0.97, set_agreement(idx0, ref0)
+    if bool((idx0 == ref0).all()) and bool((idx1 == ref1).all()):
+        # interpolation weights 1/(d+1e-8) are huge at coinciding points, where the reference's cdist
+        # (mm path) returns rounding noise instead of 0: compare away from the sampled points
+        ref_feat = torch.from_numpy(d["feat"])
+        err = (feat.detach().cpu() - ref_feat).abs()
+        assert float(err.median()) <= 5e-3 and float((err > 0.1).float().mean()) <= 0.05
+    feat.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+
+
+def test_seg_block_metric_size_forward_backward():
+    """configs[2] proper: B=32, N=2048, seg preset (4 bins), down to 512 and back up to 2048 points."""
+    from samble_amd.blocks import SegFeatureLearningBlock, seg_block_config
+    torch.manual_seed(0)
+    blk = SegFeatureLearningBlock(seg_block_config()).to(DEV).train()
+    xyz = torch.from_numpy(synth.xyz_clouds(32, 2048, 78)).to(DEV)
+    feat = blk(xyz)
+    assert feat.shape == (32, 128, 2048) and torch.isfinite(feat).all()
+    feat.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
