@@ -51,9 +51,9 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
   constexpr int KH = (KN + 1) / 2;
   static_assert(LOADS >= 1 && TILE % (4 * NT) == 0, "tile must split evenly over the workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tiles = smem;                               // 3 x TILE
-  float* bns = smem + 3 * TILE;                      // 3 x 32 key norms
-  float* qw = bns + 96;                              // kCap x NT
+  float* tiles = smem;                               // 2 x TILE
+  float* bns = smem + 2 * TILE;                      // 2 x 32 key norms
+  float* qw = bns + 64;                              // kCap x NT
   unsigned short* qj = reinterpret_cast<unsigned short*>(qw + kCap * NT);
 
   const int tid = threadIdx.x;
@@ -152,58 +152,43 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
   using F = std::false_type;
   issue(0, F{});
   commit(0);
-  if (ntiles > 1) {
-    issue(32, F{});
-    commit(1);
-  }
   __syncthreads();
-  f32x16 acc_cur = product(0);
-  f32x16 acc_nxt = zero16();
 
-  // one tile: MFMAs of tile t+1 (if any) with the filter of tile t and kInline insertions between them
-  auto body = [&](int t, int cur, auto next_c, auto fast_c) {
-    constexpr bool NEXT = decltype(next_c)::value, FAST = decltype(fast_c)::value;
-    const int nxt = (cur == 2) ? 0 : cur + 1, nn2 = (nxt == 2) ? 0 : nxt + 1;
+  // one tile: Gram product (64 + 1 MFMAs), branch-free candidate filter, staging of tile t+1, vote.
+  // (A software pipeline that issued tile t+1's MFMAs over this filter bought nothing: fp32 MFMA and
+  // VALU do not overlap on gfx950, and the second accumulator pushed the kernel into scratch spills.)
+  auto body = [&](int t, int cur, auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    const int nxt = cur ^ 1;
     const int j0 = t * 32;
-    if (FAST) issue(j0 + 64, T{});
-    else if (t + 2 < ntiles) issue(j0 + 64, F{});
-    const float* xs = tiles + nxt * TILE + (H * h) * 32 + lo;
-    acc_nxt = zero16();
-    constexpr int kStride = kInline ? (H - 16) / (kInline ? kInline : 1) : H;  // insertions spread over the MFMAs after the filter
+    if (FAST) issue(j0 + 32, T{});
+    else if (t + 1 < ntiles) issue(j0 + 32, F{});
+    const f32x16 acc = product(cur);
 #pragma unroll
-    for (int kk = 0; kk < H; ++kk) {
-      if (NEXT) acc_nxt = mfma32(xs[kk * 32], q[kk], acc_nxt);
-      if (kk < 16) {  // candidate filter of accumulator register kk
-        const int j = j0 + crow(kk, h);
-        const float w = fmaxf(half_an - acc_cur[kk], 0.f);
-        bool pass = w <= thr;
-        if (!FAST) pass = pass && (j < Nk);
-        const int slot = (tail & (kCap - 1)) * NT + tid;
-        qw[slot] = w;
-        qj[slot] = (unsigned short)j;
-        tail += pass ? 1 : 0;
-      } else if (kInline && (kk - 16) % kStride == 0 && (kk - 16) / kStride < kInline) {
-        insert_step();
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + crow(r, h);
+      const float w = fmaxf(half_an - acc[r], 0.f);
+      bool pass = w <= thr;
+      if (!FAST) pass = pass && (j < Nk);
+      const int slot = (tail & (kCap - 1)) * NT + tid;
+      qw[slot] = w;
+      qj[slot] = (unsigned short)j;
+      tail += pass ? 1 : 0;
     }
-    if (NEXT) acc_nxt = mfma32(h == 0 ? bns[nxt * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc_nxt);
-    update_thr();
-    if (FAST || t + 2 < ntiles) commit(nn2);
+    if (FAST || t + 1 < ntiles) commit(nxt);
     // the tile barrier doubles as the overflow vote: a ring may take 16 more entries next tile
     if (__syncthreads_or(tail - head > kCap - 16)) full_drain(g_keep);
-    acc_cur = acc_nxt;
   };
-  // fast iterations: tile t is a full tile and so is tile t+2 (unguarded loads, no index checks)
-  const int n_fast = vec ? max(Nk / 32 - 2, 0) : 0;
+  // fast iterations: tiles t and t+1 are full tiles (unguarded loads, no index checks)
+  const int n_fast = vec ? max(Nk / 32 - 1, 0) : 0;
   int t = 0, cur = 0;
   for (; t < n_fast; ++t) {
-    body(t, cur, T{}, T{});
-    cur = (cur == 2) ? 0 : cur + 1;
+    body(t, cur, T{});
+    cur ^= 1;
   }
   for (; t < ntiles; ++t) {
-    if (t + 1 < ntiles) body(t, cur, T{}, F{});
-    else body(t, cur, F{}, F{});
-    cur = (cur == 2) ? 0 : cur + 1;
+    body(t, cur, F{});
+    cur ^= 1;
   }
   full_drain(g_keep < 0 ? -1 : 0);
 
@@ -238,7 +223,7 @@ template <int C, int KN, int NW, int INL = kInlineDefault>
 static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                          const float* knorm, int* idx, float* d2, hipStream_t s) {
   constexpr int NT = 64 * NW;
-  size_t lds = (size_t)(3 * C * 32 + 96 + kCap * NT) * 4 + (size_t)kCap * NT * 2;
+  size_t lds = (size_t)(2 * C * 32 + 64 + kCap * NT) * 4 + (size_t)kCap * NT * 2;
   const size_t merge = (size_t)KN * NT * 8;
   if (merge > lds) lds = merge;
   auto kern = knn_stream_kernel<C, KN, NW, INL>;
