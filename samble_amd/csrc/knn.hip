@@ -466,14 +466,12 @@ static void launch_smallc_fused(const float* xq, long q_bs, int Nq, const float*
 // test hooks: 1 forces the round-1 two-kernel path (key matrix through HBM) for A/B checks
 static bool g_force_unfused = false;
 static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
-extern int g_knn_inline;
 extern int g_knn_keep;
 static bool g_no_stream = false;      // on = 3: the non-pipelined fused kernel of this file instead of knn_stream.hip
 extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
   g_force_unfused = on == 1;
   g_ablate_select = on == 2;
   g_no_stream = on == 3;
-  g_knn_inline = (on >= 100 && on < 200) ? on - 100 : -1;
   if (on >= 200) g_knn_keep = on - 200;
   if (on == 99) g_knn_keep = -1;
 }

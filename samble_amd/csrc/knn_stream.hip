@@ -4,16 +4,15 @@
 // accumulator of lane (i, h) holds G[j][i] - |b_j|^2/2 for 16 keys of query i, w = |a_i|^2/2 - acc
 // is the ranking key, per-lane sorted K-lists of packed doubles (w bits | index), bound =
 // min(own K-th, max of the two halves' ceil(K/2)-th), halves merged at the end -- but scheduled so
-// that the matrix pipe does not wait for the selection:
-//   * the 65 MFMAs of tile t+1 are issued with the candidate filter of tile t AND a few list
-//     insertions placed between them (the wave issues in order; an MFMA holds the pipe for 64 cycles,
-//     so ~14 VALU cycles per MFMA are free).  The filter is branch-free (unconditional ring-buffer
-//     write, tail += pass), so a tile is one basic block;
-//   * candidates wait in a per-lane LDS ring; kInline insertions per tile keep up with the arrival
-//     rate after the first few tiles, a workgroup-wide vote triggers a full drain when a ring could
-//     overflow (the early tiles, where every key is a candidate);
+// for this chip:
+//   * the candidate filter is branch-free (unconditional ring-buffer write, tail += pass);
+//   * candidates wait in a per-lane LDS ring; lanes insert in lockstep, so the rings are drained on a
+//     workgroup-wide vote (a ring could overflow) and only down to a few entries: an insertion step is
+//     well used while most lanes still have candidates, the stragglers wait for the next vote;
 //   * workgroup = 8 waves = 256 queries (one per CU, two waves per SIMD): a cloud's key tiles are
-//     staged half as often as with 128-query workgroups; tiles are triple-buffered.
+//     staged half as often as with 128-query workgroups.
+// fp32 MFMA and VALU do not overlap on gfx950, so nothing is gained by issuing the next tile's MFMAs
+// over the selection (tried: it only cost registers); the selection's VALU time is what is left.
 #include <type_traits>
 
 #include "samble_dev.h"
@@ -25,7 +24,6 @@ namespace samble {
 
 constexpr int kCap = 32;     // ring slots per lane (power of two); a tile adds at most 16
 int g_knn_keep = 6;  // drain policy (see full_drain)
-constexpr int kInlineDefault = 0;   // list insertions issued under each tile's MFMAs
 
 template <int KN>
 __device__ __forceinline__ void insert_packed2(double (&L)[KN], double x) {
@@ -38,7 +36,7 @@ __device__ __forceinline__ double pack_wj2(float w, unsigned int j) {
   return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
 }
 
-template <int C, int KN, int NW, int kInline = kInlineDefault>
+template <int C, int KN, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __restrict__ xq, long q_bs, int Nq,
                                                                 const float* __restrict__ xk, long k_bs, int Nk,
                                                                 const float* __restrict__ knorm,
@@ -219,14 +217,14 @@ __global__ __launch_bounds__(64 * NW, 2) void knn_stream_kernel(const float* __r
   }
 }
 
-template <int C, int KN, int NW, int INL = kInlineDefault>
+template <int C, int KN, int NW>
 static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                          const float* knorm, int* idx, float* d2, hipStream_t s) {
   constexpr int NT = 64 * NW;
   size_t lds = (size_t)(2 * C * 32 + 64 + kCap * NT) * 4 + (size_t)kCap * NT * 2;
   const size_t merge = (size_t)KN * NT * 8;
   if (merge > lds) lds = merge;
-  auto kern = knn_stream_kernel<C, KN, NW, INL>;
+  auto kern = knn_stream_kernel<C, KN, NW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -241,25 +239,10 @@ static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, lo
 
 using namespace samble;
 
-namespace samble {
-int g_knn_inline = -1;
-}
-
 // C in {64,128}, K in {16,32}; 256-query workgroups when they still fill the chip, else 128-query ones
 extern "C" int samble_launch_knn_stream(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
                                         int C, int K, const float* knorm, int* idx, float* d2, hipStream_t s) {
   const bool big = (long)B * ((Nq + 255) / 256) >= 200;
-  if (g_knn_inline >= 0 && C == 128 && K == 32) {  // experiment hook
-    switch (g_knn_inline) {
-      case 0: return launch_stream<128, 32, 8, 0>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      case 1: return launch_stream<128, 32, 8, 1>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      case 2: return launch_stream<128, 32, 8, 2>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      case 10: return launch_stream<128, 32, 4, 0>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      case 12: return launch_stream<128, 32, 4, 2>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      case 14: return launch_stream<128, 32, 4, 4>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s);
-      default: break;
-    }
-  }
 #define SAMBLE_KS(CC, KK)                                                                                       \
   if (C == CC && K == KK)                                                                                       \
     return big ? launch_stream<CC, KK, 8>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx, d2, s)                     \

@@ -14,8 +14,9 @@ def t(fn, it=10):
     b.record(); b.synchronize()
     return a.elapsed_time(b) / it
 lib = _lib.load()
-for mode, name in ((206, "stream keep 6"), (0, "  same"), (99, "stream, no insertions (filter + ring only)"), (0, "  same"), (206, "keep 6"),
-                   (3, "fused (non-pipelined)"), (2, "fused, selection ablated"), (1, "two-kernel (key matrix via HBM)")):
+for mode, name in ((0, "stream (default, drains keep 6 entries)"), (200, "stream, drains to empty"), (206, "stream keep 6"),
+                   (99, "stream, no insertions (filter + ring only; wrong results)"), (206, "keep 6"),
+                   (3, "fused (previous generation)"), (2, "fused, selection ablated"), (1, "two-kernel (key matrix via HBM)")):
     lib.samble_knn_force_unfused(mode)
     print(f"{name:35s} {t(lambda: ops.stage_knn(x, x, 32)):.3f} ms")
 lib.samble_knn_force_unfused(0)
