@@ -21,16 +21,15 @@
 namespace samble {
 
 // ------------------------------------------------------------------------------------------------
-// pass 1: one workgroup = NW waves = 32*NW query rows; K tiles (32 keys) double-buffered in LDS.
-// S^T orientation (keys on the accumulator's register axis, queries on lanes): the row statistics
-// are lane-local, and a lane's registers 4g..4g+3 are 4 consecutive keys of its query's row, so the
-// map is written with 16-byte stores (the 4 g-stores of the two lane halves fill one 128-byte line).
+// pass 1: one workgroup = NW waves = 32*NW query rows; K tiles (32 keys) triple-buffered in LDS and
+// fetched two tiles ahead.  S^T orientation (keys on the accumulator's register axis, queries on lanes):
+// the row statistics are lane-local.  The S tile is transposed through a wave-private LDS tile and
+// written to the map as full 128-byte lines (8 lanes per row).
 // ------------------------------------------------------------------------------------------------
-// Software pipeline: the 64 MFMAs of tile t+1's S product are issued with the softmax / map-store
-// work of tile t placed between them (an MFMA occupies the matrix pipe for 64 cycles and the wave
-// issues in order, so ~14 VALU cycles per MFMA are free).  Without it both waves of a SIMD sit in
-// their softmax phase at the same time (they are barrier-locked) and the pipe idles ~30% of a tile.
-// K tiles are triple-buffered: tile t+1 is resident while tile t+2 is being staged.
+// Order of work inside a tile step: the 64 MFMAs of tile t+1's S product are issued BEFORE the softmax /
+// map-store work of tile t, so the latency of their LDS operand reads and of the accumulator is not
+// exposed (VALU work itself does not overlap fp32 MFMAs on gfx950: tools/micro/coissue_bench.hip; the
+// gain measured for this ordering was 8%).  Tile t+1 is resident while tile t+2 is being staged.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SAMBLE_MAP_STORE_AUX
 #define SAMBLE_MAP_STORE_AUX 0
