@@ -80,6 +80,11 @@ CASES = [
     dict(name="cls_colsum_topk", cfg="cls", B=2, N=256, M=128, calls=1, big=False,
          sample_mode="topk", idx_mode="col_sum"),
     dict(name="cls_l2_random", cfg="cls", B=2, N=256, M=128, calls=1, big=True, asm="l2"),
+    dict(name="cls_onetoken_relumean", cfg="cls", B=2, N=256, M=128, calls=1, big=False,
+         token_mode="one_token", relu_mean_order="relu_mean"),
+    dict(name="cls_mode1_random", cfg="cls", B=2, N=256, M=128, calls=1, big=False, boltzmann_T="mode_1"),
+    dict(name="seg_mode2_rowstd", cfg="seg", B=2, N=256, M=128, calls=1, big=False, boltzmann_T="mode_2",
+         idx_mode="sparse_row_std"),
 ]
 
 
@@ -92,6 +97,12 @@ def build_reference(case, seed):
         cfg.idx_mode[layer] = case["idx_mode"]
     if "asm" in case:
         cfg.asm[layer] = case["asm"]
+    if "token_mode" in case:
+        cfg.bin.token_mode[layer] = case["token_mode"]
+    if "relu_mean_order" in case:
+        cfg.bin.relu_mean_order[layer] = case["relu_mean_order"]
+    if "boltzmann_T" in case:
+        cfg.bin.boltzmann_T[layer] = case["boltzmann_T"]
     if "static" in case:
         cfg.bin.dynamic_boundaries_enable = False
         cfg.bin.bin_boundaries[layer] = list(case["static"])
@@ -99,7 +110,7 @@ def build_reference(case, seed):
     mod.M = case["M"]
     nb = mod.num_bins
     C = cfg.q_in[layer]
-    wq, wk, wv, tok = synth.sampler_weights(C, nb, seed)
+    wq, wk, wv, tok = synth.sampler_weights(C, nb if cfg.bin.token_mode[layer] == "multi_token" else 1, seed)
     with torch.no_grad():
         mod.q_conv.weight.copy_(torch.from_numpy(wq))
         mod.k_conv.weight.copy_(torch.from_numpy(wk))
@@ -133,7 +144,9 @@ def run_case(case, case_id):
         meta=np.array([B, C, N, M, nb, spec.K, case["calls"], seed], dtype=np.int64),
         torch_version=np.array(torch.__version__),
         sample_mode=np.array(spec.sample_mode), idx_mode=np.array(spec.idx_mode), asm=np.array(spec.asm),
-        boltzmann_T=np.array(float(spec.boltzmann_T)), momentum=np.array(spec.momentum),
+        boltzmann_T=np.array(spec.boltzmann_T if isinstance(spec.boltzmann_T, str) else float(spec.boltzmann_T)),
+        token_mode=np.array(spec.token_mode), relu_mean_order=np.array(spec.relu_mean_order),
+        momentum=np.array(spec.momentum),
         dynamic=np.array(spec.dynamic_boundaries),
         static=np.array(case.get("static", []), dtype=np.float32),
     )

@@ -29,7 +29,10 @@ class Golden:
         self.sample_mode = str(self.d["sample_mode"])
         self.idx_mode = str(self.d["idx_mode"])
         self.asm = str(self.d["asm"]) if "asm" in self.d else "dot"
-        self.boltzmann_T = float(self.d["boltzmann_T"])
+        bt = self.d["boltzmann_T"]
+        self.boltzmann_T = str(bt) if bt.dtype.kind in "US" else float(bt)
+        self.token_mode = str(self.d["token_mode"]) if "token_mode" in self.d else "multi_token"
+        self.relu_mean_order = str(self.d["relu_mean_order"]) if "relu_mean_order" in self.d else "mean_relu"
         self.momentum = float(self.d["momentum"])
         self.dynamic = bool(self.d["dynamic"])
         self.static = [float(v) for v in self.d["static"]]
@@ -42,7 +45,7 @@ class Golden:
 
     def weights(self):
         from samble_amd import synth
-        return synth.sampler_weights(self.C, self.nb, self.seed)
+        return synth.sampler_weights(self.C, self.nb if self.token_mode == "multi_token" else 1, self.seed)
 
     def x(self, call=0):
         from samble_amd import synth
@@ -55,6 +58,7 @@ class Golden:
     def spec(self):
         from oracle import torch_oracle as O
         return O.SamplerSpec(M=self.M, K=self.K, C=self.C, num_bins=self.nb, idx_mode=self.idx_mode, asm=self.asm,
+                             token_mode=self.token_mode, relu_mean_order=self.relu_mean_order,
                              sample_mode=self.sample_mode, boltzmann_T=self.boltzmann_T,
                              dynamic_boundaries=self.dynamic, momentum=self.momentum,
                              static_boundaries=self.static or None)
@@ -70,6 +74,8 @@ class Golden:
         cfg.bin.sample_mode = [self.sample_mode] * 2
         cfg.idx_mode = [self.idx_mode] * 2
         cfg.asm = [self.asm] * 2
+        cfg.bin.token_mode = [self.token_mode] * 2
+        cfg.bin.relu_mean_order = [self.relu_mean_order] * 2
         cfg.bin.boltzmann_T = [self.boltzmann_T] * 2
         cfg.bin.momentum_update_factor = [self.momentum] * 2
         if not self.dynamic:
