@@ -423,7 +423,7 @@ def test_select_stages_exact_on_golden(name):
             q = o_.stage_batch_quantiles(z, g.nb).cpu()
             assert torch.equal(q, g.t("quantiles", call)), "batch quantiles"
         upper, lower = g.t("upper", call).to(DEV), g.t("lower", call).to(DEV)
-        member, cap, w_pre, w = o_.stage_bin_assign(z, tok, upper, lower, False)
+        member, cap, w_pre, w = o_.stage_bin_assign(z, tok, upper, lower, g.relu_mean_order == "relu_mean")
         bits = member.cpu().long()
         assert bool((bits > 0).all()) and bool(((bits & (bits - 1)) == 0).all()), "one bin per point"
         bin_id = torch.log2(bits.float()).round().to(torch.int8)
