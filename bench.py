@@ -260,8 +260,9 @@ def main():
             # (profiles/*_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require)
             try:
                 import glob
-                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]))
-                return pmc["kernels"][kernel]["traffic_bytes_per_launch"]
+                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]))["kernels"]
+                key = next(k for k in pmc if k == kernel or k.startswith(kernel + "<"))  # template arguments vary
+                return pmc[key]["traffic_bytes_per_launch"]
             except Exception:
                 return None
 
@@ -287,10 +288,10 @@ def main():
                 lib.samble_debug_time_kernel(0)
                 return ms
             others = {
-                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats_kernel<8, 0>"),
-                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows_kernel<4>"),
+                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats_kernel"),
+                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows_kernel"),
                 "knn_stream_kernel": (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
-                                      "samble::knn_stream_kernel<128, 32, 8, 0>"),
+                                      "samble::knn_stream_kernel"),
             }
             result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:
