@@ -178,6 +178,11 @@ int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn,
                             const float* sdv, const float* c0c1, int B, int N, int K, int C, float* du,
                             float* dw2_partials, void* stream);
 
+/* ---- utils/ops.py:47-65, 83-112  select_neighbors / group: gather of the neighbour tensor -----
+ * x (B,C,N), nn (B,N,K) -> out (B, C or 2C, N, K).  mode: 0 neighbor, 1 diff, 2 center_neighbor, 3 center_diff. */
+int samble_group_gather_f32(const float* x, const int32_t* nn, int B, int C, int N, int K, int mode, float* out,
+                            void* stream);
+
 /* ---- utils/ops.py:622-643  farthest_point_sample -------------------------------------------
  * xyz (B,3,N) channel-major (the layout the models hold; the reference permutes to (B,N,3) first),
  * start (B) = the first centroid of each cloud (the reference draws it with torch.randint), out

@@ -70,6 +70,7 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_edge_mlp_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                         c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "samble_group_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_fps_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_debug_time_kernel": (c_int, [c_int]),
     "samble_debug_kernel_ms": (c_float, []),

@@ -36,6 +36,7 @@ int samble_launch_edge_mlp_fwd(const float*, const float*, const int*, const flo
                                unsigned char*, unsigned char*, double*, hipStream_t);
 int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const float*, const unsigned char*, const float*,
                                const float*, int, int, float*, float*, hipStream_t);
+int samble_launch_group_gather(const float*, const int*, int, int, int, int, int, float*, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
@@ -297,6 +298,14 @@ SAMBLE_API int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_
   return done(samble_launch_seg_sum_rows64(src, inv_order, inv_offsets, K, per_edge, (long)n_targets, out,
                                            (hipStream_t)stream),
               "samble_segment_sum_rows_f32");
+}
+
+SAMBLE_API int samble_group_gather_f32(const float* x, const int32_t* nn, int B, int C, int N, int K, int mode, float* out,
+                                       void* stream) {
+  if (!x || !nn || !out) return fail(SAMBLE_E_INVALID, "samble_group_gather_f32: null pointer");
+  if (B <= 0 || C <= 0 || C > 65535 || N <= 0 || K <= 0 || mode < 0 || mode > 3)
+    return fail(SAMBLE_E_INVALID, "samble_group_gather_f32: bad sizes or mode");
+  return done(samble_launch_group_gather(x, nn, B, C, N, K, mode, out, (hipStream_t)stream), "samble_group_gather_f32");
 }
 
 SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out,

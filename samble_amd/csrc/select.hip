@@ -650,6 +650,34 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// neighbour grouping (reference utils/ops.py:47-65, 83-112): out (B, C or 2C, N, K) from x (B,C,N) and
+// the neighbour lists nn (B,N,K).  mode 0 neighbor: x_j; 1 diff: x_j - x_i; 2 center_neighbor: [x_i ; x_j];
+// 3 center_diff: [x_i ; x_j - x_i].  One thread per output element of the neighbour half, K innermost
+// (coalesced writes, 4-byte gathers served by the L2); the centre half is a broadcast of x.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_gather_kernel(const float* __restrict__ x, const int* __restrict__ nn,
+                                                           int C, int N, int K, int mode, float* __restrict__ out) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;  // n * K + k
+  if (e >= (long)N * K) return;
+  const int n = (int)(e / K);
+  const float* xc = x + ((long)b * C + c) * N;
+  const int j = nn[(long)b * N * K + e];
+  const float ctr = xc[n];
+  float v = xc[j];
+  if (mode == 1 || mode == 3) v -= ctr;
+  const int CO = (mode >= 2) ? 2 * C : C;
+  const long plane = (long)N * K;
+  float* ob = out + (long)b * CO * plane;
+  if (mode >= 2) {
+    ob[(long)c * plane + e] = ctr;
+    ob[(long)(C + c) * plane + e] = v;
+  } else {
+    ob[(long)c * plane + e] = v;
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -729,6 +757,13 @@ extern "C" int samble_launch_bin_select(const float* score, const float* z, cons
   }
   hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise, N, NP, nb, M,
                      mode, temp_mode, temp, idx_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_group_gather(const float* x, const int* nn, int B, int C, int N, int K, int mode, float* out,
+                                          hipStream_t s) {
+  hipLaunchKernelGGL(group_gather_kernel, dim3((unsigned)(((long)N * K + 255) / 256), C, B), dim3(256), 0, s, x, nn, C, N,
+                     K, mode, out);
   return (int)hipGetLastError();
 }
 

@@ -460,19 +460,64 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return res.view(*shape, -1)
 
 
+GROUP_MODES = {"neighbor": 0, "diff": 1, "center_neighbor": 2, "center_diff": 3}
+
+
+def _group_apply(pcd, nn_idx, mode):
+    """fp32 -> the HIP gather; any other dtype (the fp64 verification runs of the tests) -> the same
+    expression in torch on the same device."""
+    if pcd.dtype == torch.float32:
+        return _GroupGather.apply(pcd, nn_idx, mode)
+    pts = pcd.permute(0, 2, 1)
+    nb = index_points(pts, nn_idx)
+    g = (nb - pts[:, :, None, :] if mode in (1, 3) else nb).permute(0, 3, 1, 2)
+    if mode >= 2:
+        g = torch.cat([pcd[:, :, :, None].expand(-1, -1, -1, nn_idx.shape[2]), g], dim=1)
+    return g
+
+
+class _GroupGather(torch.autograd.Function):
+    """x (B,C,N), nn (B,N,K) int32 -> (B, C or 2C, N, K) on the HIP gather kernel; backward = the transpose
+    (scatter-add over neighbours, centre terms summed over K)."""
+
+    @staticmethod
+    def forward(ctx, x, nn_idx, mode):
+        _need_gpu(x, nn_idx)
+        x = _f32c(x)
+        nn_idx = nn_idx.to(torch.int32).contiguous()
+        B, C, N = x.shape
+        K = nn_idx.shape[2]
+        with torch.cuda.device(x.device):
+            out = torch.empty((B, 2 * C if mode >= 2 else C, N, K), dtype=torch.float32, device=x.device)
+            _lib.call("samble_group_gather_f32", x.data_ptr(), nn_idx.data_ptr(), B, C, N, K, mode, out.data_ptr(),
+                      _stream())
+        ctx.save_for_backward(nn_idx)
+        ctx.mode = mode
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (nn_idx,) = ctx.saved_tensors
+        mode, C = ctx.mode, ctx.C
+        B, _, N, K = g.shape
+        gn = g[:, C:] if mode >= 2 else g                      # gradient of the neighbour half
+        dx = torch.zeros((B, C, N), dtype=g.dtype, device=g.device)
+        dx.scatter_add_(2, nn_idx.long().view(B, 1, N * K).expand(-1, C, -1), gn.reshape(B, C, N * K))
+        if mode in (1, 3):
+            dx -= gn.sum(-1)
+        if mode >= 2:
+            dx += g[:, :C].sum(-1)
+        return dx, None, None
+
+
 def select_neighbors(pcd, K, neighbor_type, normal_channel=False):
     """utils/ops.py:47-65: pcd (B,C,N) -> (neighbours (B,C,N,K), idx (B,N,K))."""
-    src = pcd[:, :3, :] if (normal_channel and pcd.shape[1] == 6) else pcd
-    idx = stage_knn(src, src, K).long()
-    pts = pcd.permute(0, 2, 1)
-    neighbors = index_points(pts, idx)
-    if neighbor_type == "neighbor":
-        neighbors = neighbors.permute(0, 3, 1, 2)
-    elif neighbor_type == "diff":
-        neighbors = (neighbors - pts[:, :, None, :]).permute(0, 3, 1, 2)
-    else:
+    if neighbor_type not in ("neighbor", "diff"):
         raise ValueError(f'neighbor_type should be "neighbor" or "diff", but got {neighbor_type}')
-    return neighbors, idx
+    src = pcd[:, :3, :] if (normal_channel and pcd.shape[1] == 6) else pcd
+    nn_idx = stage_knn(src.detach(), src.detach(), K)
+    return _group_apply(pcd, nn_idx, GROUP_MODES[neighbor_type]), nn_idx.long()
 
 
 def select_neighbors_interpolate(unknown, known, known_feature, K=3):
@@ -485,18 +530,12 @@ def select_neighbors_interpolate(unknown, known, known_feature, K=3):
 
 def group(pcd, K, group_type, normal_channel=False):
     """utils/ops.py:83-112."""
-    if group_type == "neighbor":
-        return select_neighbors(pcd, K, "neighbor", normal_channel)
-    if group_type == "diff":
-        return select_neighbors(pcd, K, "diff", normal_channel)
-    if group_type == "center_neighbor":
-        nb, idx = select_neighbors(pcd, K, "neighbor", normal_channel)
-        return torch.cat([pcd[:, :, :, None].repeat(1, 1, 1, K), nb], dim=1), idx
-    if group_type == "center_diff":
-        nb, idx = select_neighbors(pcd, K, "diff", normal_channel)
-        return torch.cat([pcd[:, :, :, None].repeat(1, 1, 1, K), nb], dim=1), idx
-    raise ValueError(
-        f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {group_type}")
+    if group_type not in GROUP_MODES:
+        raise ValueError(
+            f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {group_type}")
+    src = pcd[:, :3, :] if (normal_channel and pcd.shape[1] == 6) else pcd
+    nn_idx = stage_knn(src.detach(), src.detach(), K)
+    return _group_apply(pcd, nn_idx, GROUP_MODES[group_type]), nn_idx.long()
 
 
 def neighbor_mask(pcd, K):

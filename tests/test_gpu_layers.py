@@ -392,3 +392,30 @@ def test_upsample_feature_distance_is_differentiable_like_the_reference_expressi
     for gg, ww, name in ((up.grad, u64.grad, "d pcd_up"), (down.grad, d64.grad, "d points_select")):
         rel = ((gg.double() - ww).norm() / ww.norm()).item()
         assert rel <= 2e-3, (name, rel)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group_type", ["neighbor", "diff", "center_neighbor", "center_diff"])
+@pytest.mark.parametrize("B,C,N,K", [(2, 3, 257, 8), (3, 64, 512, 32)])
+def test_group_gather_kernel_is_the_reference_expression(group_type, B, C, N, K):
+    """utils/ops.py:83-112 through samble_group_gather_f32: values bit-exact (pure data movement and
+    one subtraction), gradient equal to autograd of the oracle expression."""
+    from samble_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + C + N + K)
+    x = torch.randn(B, C, N, generator=g).to(dev).requires_grad_(True)
+    out, idx = ops.group(x, K, group_type)
+    xr = x.detach().clone().requires_grad_(True)
+    pts = xr.permute(0, 2, 1)
+    nb = O.index_rows(pts, idx)  # the oracle's gather on the same neighbour lists
+    ref = (nb - pts[:, :, None, :] if group_type.endswith("diff") else nb).permute(0, 3, 1, 2)
+    if group_type.startswith("center_"):
+        ref = torch.cat([xr[:, :, :, None].repeat(1, 1, 1, K), ref], dim=1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    w = torch.randn(out.shape, generator=g).to(dev)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-4, atol=1e-4)  # summation order only (hub points gather hundreds of terms)
+    if group_type in ("neighbor", "diff"):
+        out2, idx2 = ops.select_neighbors(x.detach(), K, group_type)
+        assert torch.equal(out2, out.detach()) and torch.equal(idx2, idx)
