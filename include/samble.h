@@ -67,6 +67,9 @@ int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64
 /* Debug / A-B hook: non-zero forces the two-kernel kNN path (key matrix through HBM) instead of the
  * fused Gram + top-K kernel.  Process-wide; not for production use. */
 void samble_knn_force_unfused(int on);
+/* debug / A-B switch of the feature-space kNN (C = 128): enabled 1 = bf16 matrix cores on split fp32
+ * operands (default), 0 = fp32 MFMA kernel; insert_steps > 0 sets the insertion steps per key tile */
+void samble_knn_tri_config(int enabled, int insert_steps);
 
 /* ---- models/downsample.py:116-137  q_conv / k_conv / v_conv (bias-free 1x1 Conv1d) ------------
  * x (B,C,N) channel-major, tokens (C,nt) = bin_tokens[0], W (3C,C) row-major = [Wq; Wk; Wv]
@@ -270,6 +273,22 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
                              const float* x_ds, const int64_t* idx, const float* g, int B, int N, int nt, int M, int D,
                              float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
                              int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- the same passes on the bf16 matrix cores with split fp32 operands ------------------------------
+ * An fp32 operand is carried as three bf16 planes h + m + l (all 24 significand bits); a product keeps
+ * the six partial products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm), each one bf16 MFMA with fp32
+ * accumulation: error vs fp64 equal to the fp32 MFMA's (tools/micro/split_mfma_bench.hip) at 2.6x its
+ * rate.  Operands are handed over as IMAGES (layout: samble_amd/csrc/tri_dev.h), caller-owned:
+ *   samble_tri_image_bytes(B, rows, transposed)   size of an image of a (B, rows, 128) matrix
+ *   samble_tri_split_f32     fp32 rows -> row image (contraction over channels: Q, K) and / or transposed
+ *                            image (contraction over rows: V in P V); either pointer may be NULL
+ *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows) */
+size_t samble_tri_image_bytes(int B, int rows, int transposed);
+int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
+                         void* tr_image, void* stream);
+int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D, float* smap,
+                              int ld, float* lse, float* tok, const float* q_sqnorm, const float* k_sqnorm,
+                              void* stream);
 
 #ifdef __cplusplus
 }

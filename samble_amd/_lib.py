@@ -22,6 +22,7 @@ _SIGNATURES = {
     "samble_version": (c_char_p, []),
     "samble_last_error": (c_char_p, []),
     "samble_knn_force_unfused": (None, [c_int]),
+    "samble_knn_tri_config": (None, [c_int, c_int]),
     "samble_debug_ablate": (None, [c_int, c_int]),
     "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
@@ -75,6 +76,10 @@ _SIGNATURES = {
     "samble_debug_time_kernel": (c_int, [c_int]),
     "samble_debug_kernel_ms": (c_float, []),
     "samble_attn_map_row_stride": (c_int, [c_int, c_int]),
+    "samble_tri_image_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "samble_tri_split_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "samble_attn_stats_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_attn_stats_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                       c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_sparse_score_map_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,

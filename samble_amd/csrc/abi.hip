@@ -55,6 +55,10 @@ int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, c
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
                            long, float*, long, long, int, float*, float*, hipStream_t);
 int samble_attn_map_ld(int N, int nt);
+size_t samble_tri_image_size(int, int, int);
+int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
+int samble_launch_attn_stats_tri(const void*, const void*, int, int, int, float, float*, int, float*, float*, const float*,
+                                 const float*, hipStream_t);
 int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
                              float*, float*, const float*, const float*, hipStream_t);
 int samble_launch_attn_rows(const float*, int, const float*, const float*, long, long, const long long*, int, int, int,
@@ -412,6 +416,37 @@ SAMBLE_API int samble_attn_stats_f32(const float* Q, int64_t q_bs, int64_t q_rs,
   return done(samble_launch_attn_stats(Q, q_bs, q_rs, K, k_bs, k_rs, B, N, nt, inv_sqrt_d(D), smap, ld, lse, tok,
                                        q_sqnorm, k_sqnorm, (hipStream_t)stream),
               "samble_attn_stats_f32");
+}
+
+SAMBLE_API size_t samble_tri_image_bytes(int B, int rows, int transposed) {
+  return (B > 0 && rows > 0) ? samble_tri_image_size(B, rows, transposed) : 0;
+}
+
+SAMBLE_API int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
+                                    void* tr_image, void* stream) {
+  if (!src || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_tri_split_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_tri_split_f32: D must be 128");
+  if (B <= 0 || rows <= 0 || (rs & 3) || (bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_tri_split_f32: bad sizes (strides must be multiples of 4 elements)");
+  return done(samble_launch_tri_split(src, bs, rs, B, rows, rm_image, tr_image, (hipStream_t)stream),
+              "samble_tri_split_f32");
+}
+
+SAMBLE_API int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
+                                         float* smap, int ld, float* lse, float* tok, const float* q_sqnorm,
+                                         const float* k_sqnorm, void* stream) {
+  if ((q_sqnorm == nullptr) != (k_sqnorm == nullptr))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_tri_f32: l2 scoring needs both squared-norm arrays");
+  if (!q_image || !k_image || !smap || !lse) return fail(SAMBLE_E_INVALID, "samble_attn_stats_tri_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_tri_f32: D must be 128");
+  if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (nt > 0 && !tok))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_tri_f32: bad B/N/nt");
+  if (ld < samble_attn_map_ld(N, nt) || (ld & 3) || (long)N * ld >= (1l << 31))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_tri_f32: map row stride must be >= "
+                                  "samble_attn_map_row_stride(N, nt), a multiple of 4, and N * ld < 2^31");
+  return done(samble_launch_attn_stats_tri(q_image, k_image, B, N, nt, inv_sqrt_d(D), smap, ld, lse, tok, q_sqnorm,
+                                           k_sqnorm, (hipStream_t)stream),
+              "samble_attn_stats_tri_f32");
 }
 
 SAMBLE_API int samble_attn_rows_fwd_f32(const float* smap, int ld, const float* lse, const float* V, int64_t v_bs,

@@ -1,0 +1,291 @@
+// The attention passes of attn_map.hip on the bf16 matrix cores with split ("tri") fp32 operands
+// (tri_dev.h): same map layout, same statistics, same orientation of every tile, 2.6x the matrix
+// rate and the vector ALU free under the MFMAs.  Q, K (and V) arrive as operand images written by
+// tri_split_kernel (or by the projection's epilogue).
+#include <type_traits>
+
+#include "tri_dev.h"
+
+namespace samble {
+
+// ------------------------------------------------------------------------------------------------
+// fp32 rows (B, R, 128) with strides -> RM and / or TR operand images, one workgroup per 32-row tile.
+// Rows >= R of the last tile are zeros.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tri_split_kernel(const float* __restrict__ src, long bs, long rs, int R,
+                                                        char* __restrict__ rm, char* __restrict__ tr) {
+  const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x, tid = threadIdx.x;
+  const float* sb = src + (long)b * bs;
+  if (rm) {
+    char* img = rm + ((long)b * ntiles + tile) * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int r = e & 31, g = e >> 5, row = tile * 32 + r;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = 0.f;
+      if (row < R) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(sb + (long)row * rs + 8 * g);
+        const f32x4 a = p[0], bb = p[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = a[i]; x[4 + i] = bb[i]; }
+      }
+      const Tri t = tri_split8(x);
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t.h;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t.m;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t.l;
+    }
+  }
+  if (tr) {
+    char* img = tr + ((long)b * ntiles + tile) * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = tile * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
+        x[i] = (row < R) ? sb[(long)row * rs + d] : 0.f;
+      }
+      const Tri t = tri_split8(x);
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t.h;
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = t.m;
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = t.l;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1 (attn_stats_kernel of attn_map.hip, same structure): one workgroup = 8 waves = 256 query rows,
+// K image tiles triple-buffered in LDS and fetched two tiles ahead, S^T orientation (keys on the
+// register axis, queries on lanes), wave-private transpose tile for 128-byte map stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStPadT = 36;
+
+// One tile step = the 48 MFMAs of tile t+1's S product + the softmax statistics / map store of tile t.
+// The loop body must stay ONE basic block: the staged tile is waited for with a counted vmcnt (stores
+// share the counter on gfx9), and any branch in the body makes the compiler fall back to waiting for
+// the loads it has just issued (measured: 2900 cycles per tile instead of the MFMA time).
+// ABL (timing-only ablations, wrong outputs): 1 = no map stores, 2 = no matrix products
+template <int ABL>
+__device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int lo, int h, const u32x4 (&q)[24],
+                                               f32x16& s_nxt) {
+  const u32x4* lp = reinterpret_cast<const u32x4*>(Kn + tri_rm_off(lo, h, 0));  // group 2 ks + h: + ks * 192 chunks
+  s_nxt = zero16();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
+    const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+    if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
+    else s_nxt = mfma_tri(a, bq, s_nxt);
+  }
+}
+
+template <bool TAIL, bool L2, int ABL>
+__device__ __forceinline__ void stats_epilogue(int lo, int h, f32x16& s_cur, float scale, float* __restrict__ xt,
+                                               float* __restrict__ gdst, const int (&roff)[4], int j0, int N, int NK,
+                                               float* __restrict__ tokrow, float& m, float& l, float qb,
+                                               const float (&kb)[16]) {
+  const int lane = lo + 32 * h;
+  float mt = kNegInf, ps = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {  // scale, tile max; registers 4g .. 4g+3 (4 consecutive keys of this lane's row) -> transpose tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      // dot: <q,k>/sqrt(D);  l2: -|q-k|^2/sqrt(D) = (2<q,k> - |q|^2 - |k|^2)/sqrt(D), qb / kb = the norms x scale
+      float v = L2 ? fmaf(s_cur[r], 2.f * scale, -qb) - kb[r] : s_cur[r] * scale;
+      if (TAIL) {
+        const int j = j0 + crow(r, h);
+        if (j >= NK) v = kNegInf;
+        if (j >= N && j < NK) tokrow[j - N] = v;
+      }
+      s_cur[r] = v;
+      mt = fmaxf(mt, v);
+    }
+    const f32x4 o = {s_cur[4 * g], s_cur[4 * g + 1], s_cur[4 * g + 2], s_cur[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(xt + lo * kStPadT + 8 * g + 4 * h) = o;
+  }
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) {  // map store: 8 lanes cover one row's 32 keys (128 contiguous bytes)
+    const int row = (lane >> 3) + 8 * k8;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(xt + row * kStPadT + 4 * (lane & 7));
+    if (!(ABL & 1)) *reinterpret_cast<f32x4*>(gdst + roff[k8]) = o;
+    else if (o[0] == 12345.f) gdst[roff[k8]] = o[1];
+  }
+  mt = fmaxf(mt, wave_xor32(mt));  // running max (branch-free rescale of the running sum)
+  const float mnew = fmaxf(m, mt);
+  l *= __expf(m - mnew);
+  m = mnew;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ps += __expf(s_cur[r] - m);
+  l += ps;
+}
+
+// K tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers), kStatsDepth tiles
+// ahead, into a ring of kStatsDepth buffers.  Why so deep: loads, LDS-DMA and stores retire in issue
+// order on one counter (vmcnt), so waiting for a tile also waits for every OLDER map store -- and the map
+// stream (545 MB at B=32, N=2048) keeps ~3 tiles of stores per CU in flight at HBM write latency.  With
+// the tile issued 4 iterations before it is needed the wait is `vmcnt(18)`: only stores at least two
+// iterations old have to have landed.  (Register staging one tile ahead made every wave wait for its
+// previous tile's stores: 54% of wave time in s_waitcnt, matrix pipe 56% busy.)
+constexpr int kStatsDepth = 4;
+
+__device__ __forceinline__ void glds_tile(const char* __restrict__ gtile, char* lds_tile, int tid, int wave) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const char* g = gtile + (tid + 512 * i) * 16;
+    char* l = lds_tile + (wave * 64 + 512 * i) * 16;  // wave-uniform base; the hardware adds lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+}
+
+template <bool L2, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __restrict__ Qimg, const char* __restrict__ Kimg,
+                                                                int N, int NK, float scale, float* __restrict__ smap,
+                                                                int ld, float* __restrict__ lse, float* __restrict__ tok,
+                                                                int nt, const float* __restrict__ qn,
+                                                                const float* __restrict__ kn) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 8, D = kStatsDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int qtiles = (N + kTile - 1) / kTile, ntiles = (NK + kTile - 1) / kTile;
+  // rows past N are clamped to row N-1 (they recompute and rewrite its values bit for bit): every store
+  // stays unpredicated
+  const int qrow = min(chunk * (32 * NW) + wave * 32 + lo, N - 1);
+  const char* Kb = Kimg + (long)b * ntiles * kTriTile;
+  auto tile_ptr = [&](int t) { return Kb + (long)((ABL & 8) ? (t & 1) : min(t, ntiles - 1)) * kTriTile; };  // past the end: the last tile again, unused
+  auto buf_ptr = [&](int t) { return smem_c + (t & (D - 1)) * kTriTile; };
+  static_assert((D & (D - 1)) == 0, "ring size must be a power of two");
+#pragma unroll
+  for (int t = 0; t < D; ++t) glds_tile(tile_ptr(t), buf_ptr(t), tid, wave);
+
+  u32x4 q[24];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * kTriTile +
+                                                     tri_rm_off(qrow & 31, h, 0));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      q[3 * ks] = qp[192 * ks];
+      q[3 * ks + 1] = qp[192 * ks + 32];
+      q[3 * ks + 2] = qp[192 * ks + 64];
+    }
+  }
+  const int row0 = chunk * (32 * NW) + wave * 32;
+  float* xt = reinterpret_cast<float*>(smem_c + D * kTriTile) + wave * (kTile * kStPadT);
+  float* knl = reinterpret_cast<float*>(smem_c + D * kTriTile) + NW * kTile * kStPadT;  // l2: |k_j|^2 scale, ld floats
+  float* tokrow = tok + ((long)b * N + qrow) * nt;
+  float m = kNegInf, l = 0.f;
+  float qb = 0.f, kb[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kb[r] = 0.f;
+  if (L2) {
+    qb = qn[(long)b * N + qrow] * scale;
+    for (int j = tid; j < ld; j += 512) knl[j] = kn[(long)b * ld + j] * scale;
+  }
+  auto load_kb = [&](int tile) {
+    if (L2) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(knl + tile * kTile + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kb[4 * g + e] = v4[e];
+      }
+    }
+  };
+
+  int roff[4];
+#pragma unroll
+  for (int k8 = 0; k8 < 4; ++k8) roff[k8] = min(row0 + (lane >> 3) + 8 * k8, N - 1) * ld + 4 * (lane & 7);
+  float* gdst = smap + (long)b * N * ld;
+
+  // all D prologue tiles (and this wave's Q rows) have landed; from here on the waits are counted
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  f32x16 s_cur, s_nxt;
+  stats_products<ABL>(buf_ptr(0), lo, h, q, s_cur);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
+
+  // iteration t: restage the buffer of tile t (read one iteration ago) with tile t+D, products of tile
+  // t+1, statistics / map store of tile t, then retire tile t+2's DMA.  VM operations issued after that
+  // DMA: stores of iteration t+2-D, then (3 DMA + 4 stores) per later iteration = 4 + 7 (D - 2).
+  const bool pfirst = wave < 4;
+  auto step = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    const int j0 = t * kTile;
+    glds_tile(tile_ptr(t + D), buf_ptr(t), tid, wave);
+    load_kb(t);
+    // the two waves of a SIMD (w and w + 4) take the two phases in opposite order, so one's vector work
+    // and stores run under the other's MFMAs (same order: both in the MFMA phase, then both out of it)
+    if (pfirst || (ABL & 4)) {
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
+    } else {
+      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
+      __builtin_amdgcn_sched_barrier(0);
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, q, s_nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((ABL & 1) ? 3 * (D - 2) : 4 + 7 * (D - 2))
+                 : "memory");
+    s_cur = s_nxt;
+  };
+  const int n_full = min(N / kTile, ntiles);  // tiles without token / padding columns
+  int t = 0;
+  for (; t < n_full; ++t) step(t, std::false_type{});
+  for (; t < ntiles; ++t) step(t, std::true_type{});
+  const float ltot = l + wave_xor32(l);
+  if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+}
+
+}  // namespace samble
+
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
+using namespace samble;
+extern int g_stats_ablate;
+
+extern "C" size_t samble_tri_image_size(int B, int rows, int transposed) {
+  const size_t tiles = (size_t)B * ((rows + 31) / 32);
+  (void)transposed;
+  return tiles * kTriTile;
+}
+
+extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
+                                       hipStream_t stream) {
+  hipLaunchKernelGGL(tri_split_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, stream, src, bs, rs, rows, (char*)rm,
+                     (char*)tr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_attn_stats_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
+                                            float* smap, int ld, float* lse, float* tok, const float* qn, const float* kn,
+                                            hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* f : {reinterpret_cast<const void*>(attn_stats_tri_kernel<false>),
+                          reinterpret_cast<const void*>(attn_stats_tri_kernel<true>)}) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
+    attr_set = true;
+  }
+  const size_t lds = kStatsDepth * kTriTile + 8 * kTile * kStPadT * sizeof(float) + ((qn && kn) ? (size_t)ld * 4 : 0);
+  if (lds > 160 * 1024) return -22;
+  auto kern = (qn && kn) ? attn_stats_tri_kernel<true> : attn_stats_tri_kernel<false>;
+  if (g_stats_ablate == 1) kern = attn_stats_tri_kernel<false, 1>;
+  if (g_stats_ablate == 2) kern = attn_stats_tri_kernel<false, 2>;
+  if (g_stats_ablate == 3) kern = attn_stats_tri_kernel<false, 3>;
+  if (g_stats_ablate == 4) kern = attn_stats_tri_kernel<false, 4>;
+  if (g_stats_ablate == 5) kern = attn_stats_tri_kernel<false, 5>;
+  if (g_stats_ablate == 8) kern = attn_stats_tri_kernel<false, 8>;
+  if (g_stats_ablate == 9) kern = attn_stats_tri_kernel<false, 9>;
+  if (g_stats_ablate == 10) kern = attn_stats_tri_kernel<false, 10>;
+  if (g_stats_ablate == 11) kern = attn_stats_tri_kernel<false, 11>;
+  samble_time_begin(1, stream);
+  hipLaunchKernelGGL(kern, dim3((N + 255) / 256, B), dim3(512), lds, stream, (const char*)qimg, (const char*)kimg, N,
+                     N + nt, scale, smap, ld, lse, tok, nt, qn, kn);
+  samble_time_end(1, stream);
+  return (int)hipGetLastError();
+}

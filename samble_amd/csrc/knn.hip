@@ -562,10 +562,25 @@ static bool knn_uses_fused(int C, int K, int Nk) {
 }
 
 // the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path
-extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K) {
+extern "C" int samble_knn_tri_enabled();
+extern "C" size_t samble_knn_tri_image_bytes(int B, int N);
+extern "C" int samble_launch_tri_split_cm(const float* x, long bs, int B, int N, void* img, hipStream_t s);
+extern "C" int samble_launch_knn_tri(const void* qimg, int Nq, const void* kimg, int Nk, int B, int K, const float* qnorm,
+                                     const float* knorm, int* idx, float* d2, hipStream_t s);
+
+static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K) {
   const bool small_fused = C <= 8 && !g_force_unfused && Nk <= 65536 && Nk >= K;
   const size_t key_matrix = (knn_uses_fused(C, K, Nk) || small_fused) ? 0 : (size_t)B * Nk * Nq;
-  return key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
+  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
+  return (n + 63) & ~(size_t)63;  // what follows (operand images) stays 256-byte aligned
+}
+
+// C = 128 fused: + the split-bf16 operand images of the two point sets (knn_tri.hip)
+extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K) {
+  size_t n = knn_base_floats(B, C, Nq, Nk, K);
+  if (C == 128 && knn_uses_fused(C, K, Nk))
+    n += (samble_knn_tri_image_bytes(B, Nq) + samble_knn_tri_image_bytes(B, Nk)) / 4;
+  return n;
 }
 
 extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
@@ -582,7 +597,18 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   if (fused) {
     hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
     int rc = 0;
-    if (!g_no_stream && !g_ablate_select)
+    if (C == 128 && samble_knn_tri_enabled() && !g_no_stream && !g_ablate_select) {
+      // bf16 matrix cores on split fp32 operands: images of the point sets first (one if the sets coincide)
+      char* kimg = reinterpret_cast<char*>(ws + knn_base_floats(B, C, Nq, Nk, K));
+      const bool same = xq == xk && Nq == Nk && q_bs == k_bs;
+      char* qimg = same ? kimg : kimg + samble_knn_tri_image_bytes(B, Nk);
+      rc = samble_launch_tri_split_cm(xk, k_bs, B, Nk, kimg, stream);
+      if (!rc && !same) {
+        rc = samble_launch_tri_split_cm(xq, q_bs, B, Nq, qimg, stream);
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
+      }
+      if (!rc) rc = samble_launch_knn_tri(qimg, Nq, kimg, Nk, B, K, same ? knorm : qnorm, knorm, idx_out, kout, stream);
+    } else if (!g_no_stream && !g_ablate_select)
       rc = samble_launch_knn_stream(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, knorm, idx_out, kout, stream);
     else if (C == 128 && K == 32) rc = launch_fused<128, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
     else if (C == 128) rc = launch_fused<128, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);

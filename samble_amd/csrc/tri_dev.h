@@ -1,0 +1,111 @@
+// fp32-equivalent matrix products on the bf16 matrix cores of gfx950 ("tri" operands).
+//
+// An fp32 value a is carried as three bf16 pieces a = h + m + l (h = bf16(a), m = bf16(a - h),
+// l = bf16(a - h - m); the two subtractions are exact in fp32, so the three pieces hold all 24
+// significand bits).  A product of two such operands keeps the six partial products whose weight is
+// >= 2^-16 of the leading one:
+//     a b ~= hh + (hm + mh) + (hl + lh + mm)          dropped: ml, lm, ll  (<= 2^-23 |a||b|)
+// each of them one v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Measured against fp64 on random
+// data (tools/micro/split_mfma_bench.hip): rms error 1.5e-7 of rms(C) for a 128-deep contraction, the
+// fp32 instruction v_mfma_f32_32x32x2_f32 gives 2.0e-7 -- the scheme IS fp32 arithmetic for this
+// path's purposes, at 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512,
+// and unlike the fp32 MFMA the bf16 MFMA leaves the vector ALU free while it runs.
+//
+// Operand maps of v_mfma_f32_32x32x16_bf16 (cdna_hip_programming.md, fragment layout): lane l = (x =
+// l & 31, h = l >> 5) holds A[row x][k = 8h + e] and B[k = 8h + e][col x], e = 0..7 (16 bytes);
+// C/D as the fp32 instruction: D[row crow(r, h)][col x] in register r.
+//
+// Operand IMAGES in memory (HBM and LDS use the same bytes, tiles are copied verbatim).  A tile covers
+// 32 rows of the matrix and is kTriTile = 24576 bytes = 1536 chunks of 16 bytes (8 bf16), CHUNK-MAJOR:
+// chunk (c, r) at (c * R + r) * 16, so the 64 lanes of an operand read (r = lane & 31 or the channel)
+// touch consecutive 16-byte words: conflict-free ds_read_b128 without padding, coalesced global reads.
+//   RM image of a (rows x 128) matrix, contraction over the 128 channels: R = 32 tile rows,
+//     c = 3 (channel / 8) + piece (48 per tile).  k-step ks (0..7) of a lane in half h uses channel
+//     group 2 ks + h: three ds_read_b128 (h, m, l).
+//   TR image of the same matrix, contraction over the 32 ROWS of a tile (P V, dS^T Q ...): R = 128
+//     channels, c = 3 (2 s + h) + piece (12 per tile); the 8 elements of chunk group 2 s + h are the
+//     tile rows j = 16 s + 8 (e >> 2) + 4 h + (e & 3), e = 0..7 -- the order in which a 32x32
+//     accumulator presents its rows when it is used as the other operand (accumulator-as-operand).
+#pragma once
+#include "samble_dev.h"
+
+namespace samble {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTriTile = 32 * 128 * 6;          // bytes per 32-row tile, either image kind
+constexpr int kTriTileChunks = kTriTile / 16;   // 1536
+// byte offset inside an RM tile of (row r, channel group g = channel / 8, piece p)
+__host__ __device__ constexpr int tri_rm_off(int r, int g, int p) { return ((3 * g + p) * 32 + r) * 16; }
+// byte offset inside a TR tile of (channel d, chunk group cg = 2 s + h, piece p)
+__host__ __device__ constexpr int tri_tr_off(int d, int cg, int p) { return ((3 * cg + p) * 128 + d) * 16; }
+
+struct Tri {
+  u32x4 h, m, l;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// c += a b over one 16-deep k-step, six partial products, smallest first
+__device__ __forceinline__ f32x16 mfma_tri(const Tri& a, const Tri& b, f32x16 c) {
+  c = mfma_bf(a.m, b.m, c);
+  c = mfma_bf(a.h, b.l, c);
+  c = mfma_bf(a.l, b.h, c);
+  c = mfma_bf(a.h, b.m, c);
+  c = mfma_bf(a.m, b.h, c);
+  c = mfma_bf(a.h, b.h, c);
+  return c;
+}
+
+__device__ __forceinline__ unsigned bf16_bits(float x) {  // round to nearest even
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
+}
+__device__ __forceinline__ float bf16_value(unsigned bits) { return __uint_as_float(bits << 16); }
+
+// split two fp32 values into the packed (lo = x0, hi = x1) words of the three planes
+__device__ __forceinline__ void tri_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned h0 = bf16_bits(x0), h1 = bf16_bits(x1);
+  const float r0 = x0 - bf16_value(h0), r1 = x1 - bf16_value(h1);
+  const unsigned m0 = bf16_bits(r0), m1 = bf16_bits(r1);
+  const float q0 = r0 - bf16_value(m0), q1 = r1 - bf16_value(m1);
+  h = h0 | (h1 << 16);
+  m = m0 | (m1 << 16);
+  l = bf16_bits(q0) | (bf16_bits(q1) << 16);
+}
+
+__device__ __forceinline__ Tri tri_split8(const float (&x)[8]) {
+  Tri t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h, m, l;
+    tri_split2(x[2 * i], x[2 * i + 1], h, m, l);
+    t.h[i] = h;
+    t.m[i] = m;
+    t.l[i] = l;
+  }
+  return t;
+}
+
+// Staging of one image tile (1536 16-byte chunks, copied verbatim) by NT threads: loads issued early,
+// committed to LDS later.  Conflict-free 16-byte LDS stores (consecutive lanes, consecutive chunks).
+template <int NT>
+struct TriStage {
+  static constexpr int kPer = kTriTileChunks / NT;
+  static_assert(kPer * NT == kTriTileChunks, "thread count must divide the tile");
+  u32x4 v[kPer];
+  __device__ __forceinline__ void issue(const char* __restrict__ tile, int tid) {
+    const u32x4* s = reinterpret_cast<const u32x4*>(tile);
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) v[i] = s[tid + NT * i];
+  }
+  __device__ __forceinline__ void commit(char* __restrict__ lds, int tid) const {
+    u32x4* d = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) d[tid + NT * i] = v[i];
+  }
+};
+
+}  // namespace samble

@@ -9,6 +9,7 @@ reference's dense (B,N,N) tensors.
 from __future__ import annotations
 
 import numbers
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -55,6 +56,7 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     with torch.cuda.device(xq.device):
         idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xq.device)
         dist = torch.empty((B, Nq, k), dtype=torch.float32, device=xq.device) if want_dist else None
+        _lib.load().samble_knn_tri_config(int(MATRIX_MODE == "tri"), 0)  # feature-space kNN (C = 128) follows the mode
         nbytes = _lib.query("samble_knn_workspace_bytes", B, C, Nq, Nk, k)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xq.device)
         _lib.call("samble_knn_f32", xq.data_ptr(), C * Nq, Nq, xk.data_ptr(), C * Nk, Nk, B, C, k, idx.data_ptr(),
@@ -353,10 +355,36 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
                   ws.data_ptr(), nbytes, _stream())
 
 
-def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int, asm: str = "dot"):
+# Matrix instruction of the attention passes: "tri" = bf16 MFMAs on split fp32 operands (three bf16
+# planes, six partial products, fp32 accumulation: fp32-equivalent, csrc/tri_dev.h), "f32" = the
+# fp32 MFMA kernels.  Both produce the same map layout; the tests run both against the oracle.
+MATRIX_MODE = os.environ.get("SAMBLE_MATRIX_MODE", "tri")
+
+
+def stage_tri_split(rows: torch.Tensor, want_rm: bool = True, want_tr: bool = False):
+    """fp32 rows (B,R,128) (any row / batch stride) -> operand images (uint8 tensors) for the tri
+    kernels: rm (contraction over channels), tr (contraction over the rows of a 32-row tile)."""
+    _need_gpu(rows)
+    B, R, D = rows.shape
+    if rows.stride(2) != 1 or rows.dtype != torch.float32:
+        raise ValueError("operands must be fp32 with unit channel stride")
+    with torch.cuda.device(rows.device):
+        rm = tr = None
+        if want_rm:
+            rm = torch.empty(_lib.query("samble_tri_image_bytes", B, R, 0), dtype=torch.uint8, device=rows.device)
+        if want_tr:
+            tr = torch.empty(_lib.query("samble_tri_image_bytes", B, R, 1), dtype=torch.uint8, device=rows.device)
+        _lib.call("samble_tri_split_f32", rows.data_ptr(), rows.stride(0), rows.stride(1), B, R, D, _p(rm), _p(tr),
+                  _stream())
+    return rm, tr
+
+
+def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int, asm: str = "dot",
+                     images=None):
     """Pass 1 of the two-pass forward: q (B,N,D), k (B,N+nt,D) -> logit map (B,N,ld) kept in HBM,
     lse (B,N), token logits (B,N,nt).  Columns >= N+nt of the map are -inf.
-    asm "dot": S = <q,k>/sqrt(D); "l2": S = -|q-k|^2/sqrt(D) (reference downsample.py:154-175)."""
+    asm "dot": S = <q,k>/sqrt(D); "l2": S = -|q-k|^2/sqrt(D) (reference downsample.py:154-175).
+    images: optional (q_image, k_image) already split (MATRIX_MODE "tri")."""
     _need_gpu(q, k)
     B, N, D = q.shape
     assert N == n_points and k.shape[1] == n_points + n_tokens
@@ -375,9 +403,14 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
             kn[:, :n_points + n_tokens] = (k * k).sum(-1)
         elif asm != "dot":
             raise NotImplementedError
-        _lib.call("samble_attn_stats_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
-                  k.stride(1), B, N, n_tokens, D, smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn),
-                  _stream())
+        if MATRIX_MODE == "tri":
+            q_img, k_img = images if images is not None else (stage_tri_split(q)[0], stage_tri_split(k)[0])
+            _lib.call("samble_attn_stats_tri_f32", q_img.data_ptr(), k_img.data_ptr(), B, N, n_tokens, D,
+                      smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn), _stream())
+        else:
+            _lib.call("samble_attn_stats_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                      k.stride(1), B, N, n_tokens, D, smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn),
+                      _p(kn), _stream())
     return smap, lse, tok[:, :, :n_tokens]
 
 

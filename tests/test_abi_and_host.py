@@ -36,7 +36,8 @@ def test_library_loads_and_reports_version(lib):
     assert b"gfx950" in handle.samble_version()
     assert lib.query("samble_knn_workspace_bytes", 32, 3, 2048, 2048, 3) < 32 * 2048 * 64 * 4  # xyz: fused, no key matrix
     assert lib.query("samble_knn_workspace_bytes", 4, 32, 512, 512, 8) >= 4 * 512 * 512 * 4  # C = 32: two-kernel path
-    assert lib.query("samble_knn_workspace_bytes", 32, 128, 2048, 2048, 32) < 32 * 2048 * 64 * 4  # fused: no key matrix
+    # C = 128: fused, no key matrix (537 MB); the workspace holds the two split-bf16 operand images (6 B / element)
+    assert lib.query("samble_knn_workspace_bytes", 32, 128, 2048, 2048, 32) < 2 * 32 * 2048 * 128 * 6 + 32 * 2048 * 64 * 4
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):

@@ -146,9 +146,13 @@ def test_stress_size_properties():
         x_ds1.backward(g)
     finally:
         D.TWO_PASS = True
-    same = (idx1 == idx).all(-1).all(-1)
-    assert int(same.sum()) >= B - 1, "score rounding differs between the two paths only at near-ties"
-    torch.testing.assert_close(x_ds1[same], x_ds[same], rtol=1e-4, atol=2e-5)
+    # the two paths round the logits differently (split-bf16 products vs one fp32 MFMA chain): a sampled
+    # index may flip only where two scores tie to the last bits
+    assert set_agreement(idx1[:, 0].cpu(), idx[:, 0].cpu()) >= 0.999
+    same = idx1[:, 0] == idx[:, 0]                     # (B, M) positions holding the same point
+    assert float(same.float().mean()) >= 0.99
+    keep = same[:, None, :].expand_as(x_ds)
+    torch.testing.assert_close(x_ds1[keep], x_ds[keep], rtol=1e-4, atol=2e-5)
     if bool(same.all()):
         scale = float(dx2.abs().max())
         assert float((x1.grad - dx2).abs().max()) <= 2e-4 * scale
