@@ -282,13 +282,21 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  *   samble_tri_image_bytes(B, rows, transposed)   size of an image of a (B, rows, 128) matrix
  *   samble_tri_split_f32     fp32 rows -> row image (contraction over channels: Q, K) and / or transposed
  *                            image (contraction over rows: V in P V); either pointer may be NULL
- *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows) */
+ *   samble_tri_split_qkv_f32 one launch for the projection output (B, N+nt, 3*128) = [Q|K|V]: row image of Q (N
+ *                            rows), row image of K and transposed image of V (N+nt rows)
+ *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows)
+ *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows) */
 size_t samble_tri_image_bytes(int B, int rows, int transposed);
 int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
                          void* tr_image, void* stream);
 int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D, float* smap,
                               int ld, float* lse, float* tok, const float* q_sqnorm, const float* k_sqnorm,
                               void* stream);
+
+int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, int N, int nt, int D, void* q_image,
+                             void* k_image, void* v_tr_image, void* stream);
+int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, const void* v_tr_image,
+                                 const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,9 @@ int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, c
 int samble_attn_map_ld(int N, int nt);
 size_t samble_tri_image_size(int, int, int);
 int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
+int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, hipStream_t);
+int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
+                                hipStream_t);
 int samble_launch_attn_stats_tri(const void*, const void*, int, int, int, float, float*, int, float*, float*, const float*,
                                  const float*, hipStream_t);
 int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
@@ -432,6 +435,16 @@ SAMBLE_API int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, in
               "samble_tri_split_f32");
 }
 
+SAMBLE_API int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, int N, int nt, int D, void* q_image,
+                                        void* k_image, void* v_tr_image, void* stream) {
+  if (!qkv || !q_image || !k_image || !v_tr_image) return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: D must be 128");
+  if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (rs & 3) || (bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: bad sizes (strides must be multiples of 4 elements)");
+  return done(samble_launch_tri_split_qkv(qkv, bs, rs, B, N, nt, q_image, k_image, v_tr_image, (hipStream_t)stream),
+              "samble_tri_split_qkv_f32");
+}
+
 SAMBLE_API int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
                                          float* smap, int ld, float* lse, float* tok, const float* q_sqnorm,
                                          const float* k_sqnorm, void* stream) {
@@ -447,6 +460,20 @@ SAMBLE_API int samble_attn_stats_tri_f32(const void* q_image, const void* k_imag
   return done(samble_launch_attn_stats_tri(q_image, k_image, B, N, nt, inv_sqrt_d(D), smap, ld, lse, tok, q_sqnorm,
                                            k_sqnorm, (hipStream_t)stream),
               "samble_attn_stats_tri_f32");
+}
+
+SAMBLE_API int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, const void* v_tr_image,
+                                            const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds,
+                                            void* stream) {
+  if (!smap || !lse || !v_tr_image || !idx || !x_ds)
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_tri_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_tri_f32: D must be 128");
+  if (B <= 0 || N <= 0 || M <= 0 || nt < 0 || nt > 8)
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_tri_f32: bad sizes");
+  if ((ld & 3) || ld < samble_attn_map_ld(N, nt)) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_tri_f32: bad strides");
+  return done(samble_launch_attn_rows_tri(smap, ld, lse, v_tr_image, (const long long*)idx, B, N, nt, M, x_ds,
+                                          (hipStream_t)stream),
+              "samble_attn_rows_fwd_tri_f32");
 }
 
 SAMBLE_API int samble_attn_rows_fwd_f32(const float* smap, int ld, const float* lse, const float* V, int64_t v_bs,

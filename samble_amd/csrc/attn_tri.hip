@@ -53,6 +53,49 @@ __global__ __launch_bounds__(256) void tri_split_kernel(const float* __restrict_
   }
 }
 
+// One launch for the three operands of the attention passes: qkv rows (B, N+nt, 384) = [Q | K | V] ->
+// RM image of Q (tiles of the N point rows), RM image of K and TR image of V (N+nt rows).  One workgroup
+// per 32-row tile; every qkv row is read once.
+__global__ __launch_bounds__(256) void tri_split_qkv_kernel(const float* __restrict__ qkv, long bs, long rs, int N,
+                                                            int NK, char* __restrict__ qimg, char* __restrict__ kimg,
+                                                            char* __restrict__ vimg) {
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int qtiles = (N + 31) / 32, ntiles = (NK + 31) / 32;
+  const float* sb = qkv + (long)b * bs;
+  for (int e = tid; e < 1024; e += 256) {  // RM chunks of Q (e < 512) and K
+    const int which = e >> 9, r = e & 31, g = (e >> 5) & 15, row = tile * 32 + r;
+    if (which == 0 && tile >= qtiles) continue;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (row < NK) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(sb + (long)row * rs + 128 * which + 8 * g);
+      const f32x4 a = p[0], bb = p[1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[i] = a[i]; x[4 + i] = bb[i]; }
+    }
+    const Tri t = tri_split8(x);
+    char* img = which ? kimg + ((long)b * ntiles + tile) * kTriTile : qimg + ((long)b * qtiles + tile) * kTriTile;
+    *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t.h;
+    *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t.m;
+    *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t.l;
+  }
+  char* img = vimg + ((long)b * ntiles + tile) * kTriTile;
+  for (int e = tid; e < 512; e += 256) {  // TR chunks of V
+    const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = tile * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
+      x[i] = (row < NK) ? sb[(long)row * rs + 256 + d] : 0.f;
+    }
+    const Tri t = tri_split8(x);
+    *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t.h;
+    *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = t.m;
+    *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = t.l;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pass 1 (attn_stats_kernel of attn_map.hip, same structure): one workgroup = 8 waves = 256 query rows,
 // K image tiles triple-buffered in LDS and fetched two tiles ahead, S^T orientation (keys on the
@@ -239,6 +282,108 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
   if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 2 (attn_rows_kernel of attn_map.hip): one workgroup = 4 waves = 128 SAMPLED rows of one cloud.
+// Lane (i, h) takes its row's 16 logits per key tile from the map, P = exp(S - lse) lands in the
+// accumulator layout, is split into three bf16 planes in registers (accumulator-as-operand: registers
+// 8s .. 8s+7 are the fragment of k-step s) and feeds O^T += V_tile^T P^T: 48 MFMAs per tile against the
+// TR image of V (LDS ring filled by LDS-DMA, two tiles ahead).  The logits go through LDS-DMA as well
+// (a wave-private 4 KB slot per tile, read back by the lane that addressed it), so that every in-flight
+// memory operation of the loop is on the one hand-counted vmcnt queue.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowsDepth = 3;                                        // tiles in LDS: t (in use), t+1, t+2 (in flight)
+constexpr int kRowsLds = kRowsDepth * (kTriTile + 4 * 4096);         // V ring + S slots of the 4 waves
+
+__global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restrict__ smap, int ld,
+                                                            const float* __restrict__ lse,
+                                                            const char* __restrict__ Vtr,
+                                                            const long long* __restrict__ idx, int N, int NK, int M,
+                                                            float* __restrict__ xds) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 4, D = kRowsDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int mrow = chunk * (32 * NW) + wave * 32 + lo;
+  const bool mvalid = mrow < M;
+  const long row = idx[(long)b * M + (mvalid ? mrow : M - 1)];
+  const float my_lse = lse[(long)b * N + row];
+  const float* srow = smap + ((long)b * N + row) * ld + 4 * h;
+  const int ntiles = (NK + kTile - 1) / kTile;
+  const char* Vb = Vtr + (long)b * ntiles * kTriTile;
+  char* sslot = smem_c + D * kTriTile + wave * (D * 4096);  // this wave's S slots
+
+  // tile t -> ring slot t % D: 6 DMA pieces of the V image per thread + 4 of this wave's logits
+  auto stage = [&](int t) {
+    const int tt = min(t, ntiles - 1);  // past the end: the last tile again, unused
+    const int slot = t % D;
+    const char* gt = Vb + (long)tt * kTriTile;
+    char* lt = smem_c + slot * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gt + (tid + 256 * k) * 16),
+                                       (__attribute__((address_space(3))) void*)(lt + (wave * 64 + 256 * k) * 16), 16, 0,
+                                       0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srow + tt * kTile + 8 * g),
+                                       (__attribute__((address_space(3))) void*)(sslot + slot * 4096 + g * 1024), 16, 0,
+                                       0);
+  };
+  stage(0);
+  stage(1);
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+  asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // tile 0 landed
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int slot = t % D;
+    stage(t + 2);  // into the slot of tile t-1, whose reads ended before the last barrier
+    const f32x4* sp = reinterpret_cast<const f32x4*>(sslot + slot * 4096 + lane * 16);
+    float p[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = sp[64 * g];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p[4 * g + e] = __expf(v4[e] - my_lse);
+    }
+    const char* vt = smem_c + slot * kTriTile;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Tri bp;  // P^T fragment of k-step ks: elements e <-> registers 8 ks + e
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned hh, mm, ll;
+        tri_split2(p[8 * ks + 2 * w], p[8 * ks + 2 * w + 1], hh, mm, ll);
+        bp.h[w] = hh;
+        bp.m[w] = mm;
+        bp.l[w] = ll;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char* ap = vt + tri_tr_off(32 * dt + lo, 2 * ks + h, 0);
+        const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                       *reinterpret_cast<const u32x4*>(ap + 4096)};
+        oacc[dt] = mfma_tri(a, bp, oacc[dt]);
+      }
+    }
+    // tile t+1 (staged one iteration ago) must have landed before anyone reads it; the 10 pieces issued
+    // in this iteration stay in flight
+    asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (mvalid) {
+    float* ob = xds + (long)b * 128 * M + mrow;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long)(32 * dt + crow(r, h)) * M] = oacc[dt][r];
+    }
+  }
+}
+
 }  // namespace samble
 
 extern "C" void samble_time_begin(int, hipStream_t);
@@ -287,5 +432,29 @@ extern "C" int samble_launch_attn_stats_tri(const void* qimg, const void* kimg, 
   hipLaunchKernelGGL(kern, dim3((N + 255) / 256, B), dim3(512), lds, stream, (const char*)qimg, (const char*)kimg, N,
                      N + nt, scale, smap, ld, lse, tok, nt, qn, kn);
   samble_time_end(1, stream);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_attn_rows_tri(const float* smap, int ld, const float* lse, const void* v_tr_image,
+                                           const long long* idx, int B, int N, int nt, int M, float* xds,
+                                           hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rows_tri_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRowsLds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  samble_time_begin(2, stream);
+  hipLaunchKernelGGL(attn_rows_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kRowsLds, stream, smap, ld, lse,
+                     (const char*)v_tr_image, idx, N, N + nt, M, xds);
+  samble_time_end(2, stream);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, int B, int N, int nt, void* qimg, void* kimg,
+                                           void* vimg, hipStream_t stream) {
+  hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
+                     (char*)qimg, (char*)kimg, (char*)vimg);
   return (int)hipGetLastError();
 }

@@ -85,7 +85,8 @@ class _SamplerCore(torch.autograd.Function):
             nn_idx = ops.stage_knn(x, x, mod.K)
             if TWO_PASS or mod.asm == "l2":
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
-                smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm)
+                imgs = ops.stage_tri_split_qkv(qkv, N) if ops.MATRIX_MODE == "tri" else None
+                smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
                 score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
                 O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
@@ -101,7 +102,7 @@ class _SamplerCore(torch.autograd.Function):
         counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
         if smap is not None:
-            x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt)
+            x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=imgs[2] if imgs else None)
             ctx.save_for_backward(qkv, x_ds, lse, idx, smap)
         else:
             x_ds = ops.stage_gather_rows(O, idx)

@@ -379,6 +379,22 @@ def stage_tri_split(rows: torch.Tensor, want_rm: bool = True, want_tr: bool = Fa
     return rm, tr
 
 
+def stage_tri_split_qkv(qkv: torch.Tensor, n_points: int):
+    """qkv (B,N+nt,3*128) point-major rows [Q|K|V] -> (q_image, k_image, v_tr_image) in one launch."""
+    _need_gpu(qkv)
+    B, NK, D3 = qkv.shape
+    D = D3 // 3
+    if qkv.stride(2) != 1 or qkv.dtype != torch.float32:
+        raise ValueError("operands must be fp32 with unit channel stride")
+    with torch.cuda.device(qkv.device):
+        q_img = torch.empty(_lib.query("samble_tri_image_bytes", B, n_points, 0), dtype=torch.uint8, device=qkv.device)
+        k_img = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 0), dtype=torch.uint8, device=qkv.device)
+        v_img = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 1), dtype=torch.uint8, device=qkv.device)
+        _lib.call("samble_tri_split_qkv_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), B, n_points, NK - n_points, D,
+                  q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(), _stream())
+    return q_img, k_img, v_img
+
+
 def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int, asm: str = "dot",
                      images=None):
     """Pass 1 of the two-pass forward: q (B,N,D), k (B,N+nt,D) -> logit map (B,N,ld) kept in HBM,
@@ -403,7 +419,8 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
             kn[:, :n_points + n_tokens] = (k * k).sum(-1)
         elif asm != "dot":
             raise NotImplementedError
-        if MATRIX_MODE == "tri":
+        # l2 scoring keeps the cloud's scaled key norms in LDS beside the tile ring: very long clouds use the fp32 kernel
+        if MATRIX_MODE == "tri" and not (asm == "l2" and ld * 4 > 24 * 1024):
             q_img, k_img = images if images is not None else (stage_tri_split(q)[0], stage_tri_split(k)[0])
             _lib.call("samble_attn_stats_tri_f32", q_img.data_ptr(), k_img.data_ptr(), B, N, n_tokens, D,
                       smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn), _stream())
@@ -415,16 +432,23 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
 
 
 def stage_attn_rows(smap: torch.Tensor, lse: torch.Tensor, v: torch.Tensor, idx: torch.Tensor, n_points: int,
-                    n_tokens: int) -> torch.Tensor:
-    """Pass 2: the M sampled rows idx (B,M) of softmax(map) times v (B,N+nt,D) -> x_ds (B,D,M)."""
+                    n_tokens: int, v_image=None) -> torch.Tensor:
+    """Pass 2: the M sampled rows idx (B,M) of softmax(map) times v (B,N+nt,D) -> x_ds (B,D,M).
+    v_image: optional transposed operand image of v already split (MATRIX_MODE "tri")."""
     _need_gpu(smap, lse, v, idx)
     B, N, ld = smap.shape
     M, D = idx.shape[1], v.shape[2]
     assert N == n_points and v.shape[1] == n_points + n_tokens and idx.dtype == torch.int64 and idx.is_contiguous()
     with torch.cuda.device(smap.device):
         out = torch.empty((B, D, M), dtype=torch.float32, device=smap.device)
-        _lib.call("samble_attn_rows_fwd_f32", smap.data_ptr(), ld, lse.data_ptr(), v.data_ptr(), v.stride(0),
-                  v.stride(1), idx.data_ptr(), B, N, n_tokens, M, D, out.data_ptr(), _stream())
+        if MATRIX_MODE == "tri":
+            if v_image is None:
+                v_image = stage_tri_split(v, want_rm=False, want_tr=True)[1]
+            _lib.call("samble_attn_rows_fwd_tri_f32", smap.data_ptr(), ld, lse.data_ptr(), v_image.data_ptr(),
+                      idx.data_ptr(), B, N, n_tokens, M, D, out.data_ptr(), _stream())
+        else:
+            _lib.call("samble_attn_rows_fwd_f32", smap.data_ptr(), ld, lse.data_ptr(), v.data_ptr(), v.stride(0),
+                      v.stride(1), idx.data_ptr(), B, N, n_tokens, M, D, out.data_ptr(), _stream())
     return out
 
 

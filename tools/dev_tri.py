@@ -39,3 +39,22 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10):
     ops.stage_tri_split(q); ops.stage_tri_split(k)
 torch.cuda.synchronize(); print("split q+k %.1f us" % ((time.perf_counter() - t0) / 10 * 1e6))
+# pass 2
+M = 1024
+idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(bb))[:M] for bb in range(B)]).to(dev)
+outs = {}
+for mode in ("f32", "tri"):
+    ops.MATRIX_MODE = mode
+    smap, lse, _ = res[mode]
+    vimg = ops.stage_tri_split(v, want_rm=False, want_tr=True)[1] if mode == "tri" else None
+    outs[mode] = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(mode, "attn_rows %.1f us" % (dt * 1e6))
+ref = torch.gather(torch.softmax(s64, -1) @ v[:2].double(), 1, idx[:2, :, None].expand(-1, -1, D)).permute(0, 2, 1)
+for mode in outs:
+    d = outs[mode][:2].double() - ref
+    print(mode, "x_ds rms err", d.pow(2).mean().sqrt().item(), "max", d.abs().max().item())
