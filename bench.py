@@ -24,6 +24,10 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+# split-bf16 kernels (samble_amd/csrc/tri_dev.h): every fp32 product is 6 bf16 MFMA products, so the
+# ceiling for ALGORITHMIC (fp32) flops is the dense bf16 peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_TRI_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
 PEAK_HBM_GBS = 8000.0
 
 B_PER_GPU, C, N, M, NB, KNN = 32, 128, 2048, 1024, 6, 32
@@ -54,7 +58,9 @@ def time_region(fn, iters):
     return start.elapsed_time(stop) / iters
 
 
-KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4}
+# ids of the library's timing hook (samble_debug_time_kernel); both matrix modes use the same ids for the
+# kernels that play the same part (3 = dominant backward kernel: bwd_rows or bwd_dkdv_tri)
+KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4, "bwd_dq": 6}
 
 
 def kernel_ms(kernel, fn, iters=5):
@@ -86,8 +92,12 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
         out["proj_fwd"] = time_region(lambda: ops.stage_proj_fwd(x, tokm, w), iters)
         out["knn"] = time_region(lambda: ops.stage_knn(x, x, KNN), iters)
         nn_idx = ops.stage_knn(x, x, KNN)
-        out["attn_stats"] = time_region(lambda: ops.stage_attn_stats(q, k, N, nt), iters)
-        smap, lse, tok = ops.stage_attn_stats(q, k, N, nt)
+        imgs = None
+        if ops.MATRIX_MODE == "tri":  # the module splits Q, K, V into operand images once per step
+            out["split_qkv"] = time_region(lambda: ops.stage_tri_split_qkv(qkv, N, for_backward=True), iters)
+            imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=True)
+        out["attn_stats"] = time_region(lambda: ops.stage_attn_stats(q, k, N, nt, images=imgs[:2] if imgs else None), iters)
+        smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, images=imgs[:2] if imgs else None)
         out["sparse_score"] = time_region(lambda: ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr"), iters)
         score, z, _ = ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr")
         out["batch_quantiles"] = time_region(lambda: ops.stage_batch_quantiles(z, NB), iters)
@@ -99,12 +109,14 @@ def kernel_breakdown(mod, x, noise, g, iters=5):
         out["bin_select"] = time_region(
             lambda: ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise), iters)
         idx = ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise)
-        out["attn_rows"] = time_region(lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt), iters)
-        x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt)
+        vimg = imgs[2] if imgs else None
+        out["attn_rows"] = time_region(lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg), iters)
+        x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg)
         dqkv = torch.empty_like(qkv)
         out["attn_bwd"] = time_region(
             lambda: ops.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, N, nt, dqkv[:, :N, :C],
-                                            dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:]), iters)
+                                            dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:],
+                                            images=imgs[3:] if imgs else None), iters)
         out["proj_bwd"] = time_region(lambda: ops.stage_proj_bwd(dqkv, x, tokm, w, True, True), iters)
     return out
 
@@ -266,14 +278,29 @@ def main():
             except Exception:
                 return None
 
+        from samble_amd import ops as _ops
+        tri = _ops.MATRIX_MODE == "tri"
+        peak = PEAK_TRI_TFLOPS if tri else PEAK_FP32_MFMA_TFLOPS
+
         def roof(kernel, alg_flops, ms, pmc_name):
             ach = alg_flops / (ms * 1e-3) / 1e12
-            return {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(pmc_name),
-                    "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops}
+            out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                   "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_name),
+                   "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops}
+            if tri:
+                out["peak_note"] = ("fp32 products as 6 bf16 MFMA products (3 bf16 planes per operand, fp32 accumulate): "
+                                    "peak = dense bf16 2500 TFLOP/s / 6; executed bf16 flop = 6 x algorithmic")
+                out["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
+            return out
 
-        bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
-        result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
+        if tri:
+            # dominant kernel: bwd_dkdv_tri (dP, dV, dK over the N point keys = 3 of the backward's 4 products)
+            bwd_alg = 3 * 2 * M * N * C * B_PER_GPU
+            result["roofline"] = roof("bwd_dkdv_tri_kernel", bwd_alg, dominant_ms, "samble::bwd_dkdv_tri_kernel")
+        else:
+            bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
+            result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
+        result["matrix_mode"] = _ops.MATRIX_MODE
         if not args.no_breakdown:
             noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
             br = kernel_breakdown(mod, x, noise, g)
@@ -287,12 +314,16 @@ def main():
                 ms = float(lib.samble_debug_kernel_ms())
                 lib.samble_debug_time_kernel(0)
                 return ms
+            sfx = "_tri_kernel" if tri else "_kernel"
             others = {
-                "attn_stats_kernel": (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats_kernel"),
-                "attn_rows_kernel": (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows_kernel"),
-                "knn_stream_kernel": (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
-                                      "samble::knn_stream_kernel"),
+                "attn_stats" + sfx: (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats" + sfx),
+                "attn_rows" + sfx: (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows" + sfx),
+                ("knn_tri_kernel" if tri else "knn_stream_kernel"): (
+                    fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
+                    "samble::knn_tri_kernel" if tri else "samble::knn_stream_kernel"),
             }
+            if tri:  # dQ: the 4th product of the backward (its kernel forms dP a second time: not counted)
+                others["bwd_dq_tri_kernel"] = (fl["av"] * B_PER_GPU, in_step_ms("bwd_dq"), "samble::bwd_dq_tri_kernel")
             result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seed)

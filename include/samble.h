@@ -283,9 +283,13 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  *   samble_tri_split_f32     fp32 rows -> row image (contraction over channels: Q, K) and / or transposed
  *                            image (contraction over rows: V in P V); either pointer may be NULL
  *   samble_tri_split_qkv_f32 one launch for the projection output (B, N+nt, 3*128) = [Q|K|V]: row image of Q (N
- *                            rows), row image of K and transposed image of V (N+nt rows)
+ *                            rows), row image of K and transposed image of V (N+nt rows); optionally (non-NULL)
+ *                            the two images the backward wants: transposed K, row V
  *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows)
- *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows) */
+ *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows)
+ *   samble_attn_rows_bwd_tri_f32 = samble_attn_rows_bwd_f32 (same outputs, same ds_colsum contract) as two
+ *                            kernels, dK/dV key-stationary and dQ query-stationary, 5 products per tile, no dQ
+ *                            slabs; workspace: samble_attn_rows_bwd_tri_workspace_bytes */
 size_t samble_tri_image_bytes(int B, int rows, int transposed);
 int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
                          void* tr_image, void* stream);
@@ -294,7 +298,14 @@ int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, i
                               void* stream);
 
 int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, int N, int nt, int D, void* q_image,
-                             void* k_image, void* v_tr_image, void* stream);
+                             void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, void* stream);
+size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D);
+int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                                 const float* V, int64_t v_bs, int64_t v_rs, const void* k_tr_image,
+                                 const void* v_rm_image, const float* smap, int ld, const float* lse, const float* x_ds,
+                                 const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,
+                                 int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
+                                 int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
 int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, const void* v_tr_image,
                                  const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds, void* stream);
 

@@ -53,11 +53,11 @@ int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, i
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
-                           long, float*, long, long, int, float*, float*, hipStream_t);
+                           long, float*, long, long, int, float*, float*, const void*, const void*, void*, hipStream_t);
 int samble_attn_map_ld(int N, int nt);
 size_t samble_tri_image_size(int, int, int);
 int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
-int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, hipStream_t);
+int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, void*, void*, hipStream_t);
 int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
                                 hipStream_t);
 int samble_launch_attn_stats_tri(const void*, const void*, int, int, int, float, float*, int, float*, float*, const float*,
@@ -335,7 +335,8 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
                            const float* smap, int ld, const float* lse, const int64_t* idx, const float* g, int B, int N,
                            int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
                            int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
-                           void* stream, int l2 = 0, float* cs = nullptr) {
+                           void* stream, int l2 = 0, float* cs = nullptr, const void* k_tr_image = nullptr,
+                           const void* v_rm_image = nullptr) {
   char msg[160];
   if (!Q || !K || !V || (!O && !Oc) || !lse || !idx || !g || !dQ || !dK || !dV || !ws) {
     snprintf(msg, sizeof msg, "%s: null pointer", who);
@@ -345,7 +346,9 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
     snprintf(msg, sizeof msg, "%s: need D == 128, 0 <= nt <= 8, positive B/N/M", who);
     return fail(SAMBLE_E_INVALID, msg);
   }
-  if (ws_bytes < samble_attn_bwd_workspace_bytes(B, N, M, D)) {
+  const bool tri = k_tr_image && v_rm_image;
+  const size_t base_bytes = samble_attn_bwd_workspace_bytes(B, N, M, D);
+  if (ws_bytes < base_bytes + (tri ? 3 * samble_tri_image_size(B, M, 0) : 0)) {
     snprintf(msg, sizeof msg, "%s: workspace too small", who);
     return fail(SAMBLE_E_WORKSPACE, msg);
   }
@@ -373,7 +376,8 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   float* slab = cs_part + (size_t)B * ((M + 31) / 32) * 8;
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
                                      (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
-                                     slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part, s),
+                                     slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part,
+                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, s),
               who);
 }
 
@@ -398,6 +402,25 @@ SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_
   return attn_bwd_common("samble_attn_rows_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap, ld,
                          lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
                          stream, ds_colsum ? 1 : 0, ds_colsum);
+}
+
+SAMBLE_API size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D) {
+  if (B <= 0 || N <= 0 || M <= 0) return 0;
+  return samble_attn_bwd_workspace_bytes(B, N, M, D) + 3 * samble_tri_image_size(B, M, 0);
+}
+
+SAMBLE_API int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                            int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs,
+                                            const void* k_tr_image, const void* v_rm_image, const float* smap, int ld,
+                                            const float* lse, const float* x_ds, const int64_t* idx, const float* g, int B,
+                                            int N, int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK,
+                                            int64_t dk_bs, int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs,
+                                            float* ds_colsum, void* ws, size_t ws_bytes, void* stream) {
+  if (!smap || !x_ds || !k_tr_image || !v_rm_image)
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_bwd_tri_f32: null pointer");
+  return attn_bwd_common("samble_attn_rows_bwd_tri_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap,
+                         ld, lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws,
+                         ws_bytes, stream, ds_colsum ? 1 : 0, ds_colsum, k_tr_image, v_rm_image);
 }
 
 SAMBLE_API int samble_attn_map_row_stride(int N, int nt) { return samble_attn_map_ld(N, nt); }
@@ -436,12 +459,14 @@ SAMBLE_API int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, in
 }
 
 SAMBLE_API int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, int N, int nt, int D, void* q_image,
-                                        void* k_image, void* v_tr_image, void* stream) {
+                                        void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image,
+                                        void* stream) {
   if (!qkv || !q_image || !k_image || !v_tr_image) return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: D must be 128");
   if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || (rs & 3) || (bs & 3))
     return fail(SAMBLE_E_INVALID, "samble_tri_split_qkv_f32: bad sizes (strides must be multiples of 4 elements)");
-  return done(samble_launch_tri_split_qkv(qkv, bs, rs, B, N, nt, q_image, k_image, v_tr_image, (hipStream_t)stream),
+  return done(samble_launch_tri_split_qkv(qkv, bs, rs, B, N, nt, q_image, k_image, v_tr_image, k_tr_image, v_rm_image,
+                                          (hipStream_t)stream),
               "samble_tri_split_qkv_f32");
 }
 

@@ -573,13 +573,21 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
   return (size_t)B * ((N + 127) / 128 + 1) * M * 128;
 }
 
+extern "C" size_t samble_tri_image_size(int, int, int);
+extern "C" int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
+extern "C" int samble_launch_bwd_tri(const float*, int, const float*, const float*, const void*, const void*, const void*,
+                                     const void*, const void*, const long long*, int, int, int, int, float, float*, long,
+                                     long, float*, long, long, float*, long, long, float*, hipStream_t);
+
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, const float* O, const float* Oc,
                                       const float* smap, int ld, const float* lse, const long long* idx,
                                       const float* g, int B, int N, int nt, int M, float scale, float* Qs, float* dOb,
                                       float* lse_s, float* delta, float* tok_part, float* slab, float* dQ, long dq_bs,
                                       long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                      int l2, float* cs, float* cs_part, hipStream_t stream) {
+                                      int l2, float* cs, float* cs_part, const void* k_tr_image, const void* v_rm_image,
+                                      void* img_ws, hipStream_t stream) {
+  // k_tr_image / v_rm_image / img_ws != null (map path only): the split-bf16 kernels of attn_bwd_tri.hip
   // l2 != 0 (map path only): token logits are -|q-k|^2 and cs (B, N+nt) receives the column sums of dS
   // O (B,N,128) rows of the single-pass forward, or Oc (B,128,M) = x_ds of attn_rows; smap (B,N,ld) =
   // the logit map of attn_stats (then S is read, not recomputed) or null
@@ -601,14 +609,27 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   const int NK = N + nt;
   const int nparts = (M + 31) / 32;
   const int kb = (N + 127) / 128;
-  const bool fused = !g_bwd_split || smap;
+  const bool tri = smap && k_tr_image && v_rm_image && img_ws;
+  const bool fused = (!g_bwd_split || smap) && !tri;
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
   hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
                      fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr);
-  if (fused) {
+  if (tri) {
+    // images of the sampled rows: dO (row + transposed) and Q (transposed), whole tiles of 32 rows
+    const size_t img = samble_tri_image_size(B, M, 0);
+    char* dO_rm = (char*)img_ws;
+    char* dO_tr = dO_rm + img;
+    char* Q_tr = dO_tr + img;
+    int rc = samble_launch_tri_split(dOb, (long)M * 128, 128, B, M, dO_rm, dO_tr, stream);
+    if (!rc) rc = samble_launch_tri_split(Qs, (long)M * 128, 128, B, M, nullptr, Q_tr, stream);
+    if (!rc)
+      rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M, scale,
+                                 dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr, stream);
+    if (rc) return rc;
+  } else if (fused) {
     if (smap) {
       const int rc = samble_launch_bwd_rows(Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, B, N, M, scale, dK, dk_bs,
                                             dk_rs, dV, dv_bs, dv_rs, slab, kb + 1, smap, ld, idx, l2 ? cs : nullptr, nt,

@@ -1,0 +1,354 @@
+// Backward of the two-pass attention on the bf16 matrix cores with split fp32 operands (tri_dev.h),
+// reading S from the logit map.  Two kernels, each with every product in its natural orientation (no
+// transposition of dS, no partial-dQ slabs and no reduction pass as in attn_rows_bwd.hip):
+//
+//   bwd_dkdv_tri   key-stationary, wave = 32 point keys (lane = key).  Per tile of 32 sampled rows:
+//                    dP   = dO_tile V_keys^T          A: dO RM image (LDS), B: V rows (registers)
+//                    P    = exp(S - lse), dS = P (dP - delta) scale           [rows on registers]
+//                    dV^T += dO_tile^T P              A: dO TR image (LDS), B: P  (accumulator-as-operand)
+//                    dK^T += Q_tile^T  dS             A: Q  TR image (LDS), B: dS (accumulator-as-operand)
+//   bwd_dq_tri     query-stationary, wave = 32 sampled rows (lane = row).  Per tile of 32 keys (points AND
+//                  token keys: the map holds their logits, the images their rows):
+//                    dP^T = V_tile dO_rows^T          A: V RM image (LDS), B: dO rows (registers)
+//                    dS^T = P^T (dP^T - delta) scale                          [keys on registers]
+//                    dQ^T += K_tile^T dS^T            A: K TR image (LDS), B: dS^T (accumulator-as-operand)
+// 5 matrix products per (rows x keys) tile instead of 4 -- dP is formed in both orientations -- which
+// the 2.6x matrix rate pays for several times over; dQ rows are written once, in place.
+// Operand tiles arrive by LDS-DMA; all waits are counted by hand (see attn_tri.hip).
+#include "tri_dev.h"
+
+namespace samble {
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+
+// registers 8 ks .. 8 ks + 7 of a 32x32 accumulator-layout tile -> the tri fragment of k-step ks
+__device__ __forceinline__ Tri tri_from_acc(const float (&x)[16], int ks) {
+  Tri t;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned hh, mm, ll;
+    tri_split2(x[8 * ks + 2 * w], x[8 * ks + 2 * w + 1], hh, mm, ll);
+    t.h[w] = hh;
+    t.m[w] = mm;
+    t.l[w] = ll;
+  }
+  return t;
+}
+
+// out[dt] (channels 32 dt .. 32 dt + 31 x this lane's column) += TRtile^T x frag, both k-steps
+__device__ __forceinline__ void mma_tr_x_acc(const char* __restrict__ tr_tile, int lo, int h, const float (&x)[16],
+                                             f32x16 (&out)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const Tri bp = tri_from_acc(x, ks);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const char* ap = tr_tile + tri_tr_off(32 * dt + lo, 2 * ks + h, 0);
+      const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                     *reinterpret_cast<const u32x4*>(ap + 4096)};
+      out[dt] = mfma_tri(a, bp, out[dt]);
+    }
+  }
+}
+
+// acc(32x32) = RMtile(rows from LDS) x reg(24 operand registers of this lane's row)^T
+__device__ __forceinline__ f32x16 mma_rm_x_regs(const char* __restrict__ rm_tile, int lo, int h, const u32x4 (&q)[24]) {
+  const u32x4* lp = reinterpret_cast<const u32x4*>(rm_tile + tri_rm_off(lo, h, 0));
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
+    const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+    acc = mfma_tri(a, bq, acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void load_rm_row(const char* __restrict__ img, long tiles_per_cloud, int b, int row, int h,
+                                            u32x4 (&q)[24]) {
+  const u32x4* qp = reinterpret_cast<const u32x4*>(img + ((long)b * tiles_per_cloud + (row >> 5)) * kTriTile +
+                                                   tri_rm_off(row & 31, h, 0));
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    q[3 * ks] = qp[192 * ks];
+    q[3 * ks + 1] = qp[192 * ks + 32];
+    q[3 * ks + 2] = qp[192 * ks + 64];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: one workgroup = 4 waves = 128 sampled rows; key tiles (V RM + K TR images, 48 KB) double-buffered
+// ------------------------------------------------------------------------------------------------
+constexpr int kDqStage = 2 * kTriTile + 4 * 4096;  // V RM tile, K TR tile, S slots of the 4 waves
+constexpr int kDqLds = 2 * kDqStage;
+
+struct DqTriArgs {
+  const float* smap;
+  int ld;
+  const float* lse_s;   // (B, M) of the sampled rows
+  const float* delta;   // (B, M)
+  const char* dO_rm;    // image of the sampled rows' dO (M rows)
+  const char* V_rm;     // image of V (N + nt rows)
+  const char* K_tr;     // image of K (N + nt rows)
+  const long long* idx;
+  int N, NK, M;
+  float scale;
+  float* dQ;
+  long dq_bs, dq_rs;
+};
+
+template <int ABL>  // timing-only ablations (wrong results): 1 = tiles staged once, 2 = no matrix products
+__global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 4;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int M = a.M, N = a.N;
+  const int mrow = chunk * (32 * NW) + wave * 32 + lo;
+  const bool mvalid = mrow < M;
+  const int mc = mvalid ? mrow : M - 1;
+  const long row = a.idx[(long)b * M + mc];
+  const float my_lse = a.lse_s[(long)b * M + mc], my_delta = a.delta[(long)b * M + mc];
+  const float* srow = a.smap + ((long)b * N + row) * a.ld + 4 * h;
+  const int ntiles = (a.NK + kTile - 1) / kTile, mtiles = (M + kTile - 1) / kTile;
+  const char* Vb = a.V_rm + (long)b * ntiles * kTriTile;
+  const char* Kb = a.K_tr + (long)b * ntiles * kTriTile;
+
+  auto stage = [&](int t) {  // 16 DMA pieces per thread
+    const int tt = min(t, ntiles - 1);
+    char* st = smem_c + (t & 1) * kDqStage;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      glds16(Vb + (long)tt * kTriTile + (tid + 256 * k) * 16, st + (wave * 64 + 256 * k) * 16);
+      glds16(Kb + (long)tt * kTriTile + (tid + 256 * k) * 16, st + kTriTile + (wave * 64 + 256 * k) * 16);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) glds16(srow + tt * kTile + 8 * g, st + 2 * kTriTile + wave * 4096 + g * 1024);
+  };
+  stage(0);
+  u32x4 go[24];
+  load_rm_row(a.dO_rm, mtiles, b, mc, h, go);
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+  const float scale = a.scale;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* st = smem_c + (t & 1) * kDqStage;
+    if (!(ABL & 1)) stage(t + 1);  // into the other stage, whose reads ended before the last barrier
+    f32x16 dp;
+    if (ABL & 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = __uint_as_float(go[r][0]);
+    } else dp = mma_rm_x_regs(st, lo, h, go);  // dP^T: rows = keys crow(r, h), column = this lane's row
+    const f32x4* sp = reinterpret_cast<const f32x4*>(st + 2 * kTriTile + wave * 4096 + lane * 16);
+    float ds[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = sp[64 * g];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        ds[r] = __expf(v4[e] - my_lse) * (dp[r] - my_delta) * scale;  // columns past N + nt hold -inf: P = 0
+      }
+    }
+    if (ABL & 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r & 3][r] += ds[r];
+    } else mma_tr_x_acc(st + kTriTile, lo, h, ds, oacc);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (mvalid) {
+    float* orow = a.dQ + (long)b * a.dq_bs + row * a.dq_rs + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {oacc[dt][4 * g], oacc[dt][4 * g + 1], oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV (and the column sums of dS): one workgroup = 4 waves = 128 point keys; tiles of 32 sampled rows
+// (dO RM, dO TR, Q TR images, 72 KB) double-buffered, their lse / delta / row ids in three small slots
+// ------------------------------------------------------------------------------------------------
+constexpr int kKvStage = 3 * kTriTile;
+constexpr int kKvMeta = 512;  // per slot: lse[32], delta[32], idx[32] (int64)
+constexpr int kKvLds = 2 * kKvStage + 3 * kKvMeta;
+
+struct KvTriArgs {
+  const float* smap;
+  int ld;
+  const float* lse_s;
+  const float* delta;
+  const char* dO_rm;
+  const char* dO_tr;
+  const char* Q_tr;   // images of the sampled rows (M rows, zero padded to whole tiles)
+  const char* V_rm;   // image of V (N + nt rows)
+  const long long* idx;
+  int N, NK, M;
+  float scale;
+  float* dK;
+  long dk_bs, dk_rs;
+  float* dV;
+  long dv_bs, dv_rs;
+  float* cs;  // optional (B, N + nt)
+};
+
+template <bool CS>
+__global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int N = a.N, M = a.M, ld = a.ld;
+  const int j = chunk * 128 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  const int jc = min(j, N - 1);
+  const int ktiles = (a.NK + kTile - 1) / kTile, mtiles = (M + kTile - 1) / kTile;
+  const char* Gr = a.dO_rm + (long)b * mtiles * kTriTile;
+  const char* Gt = a.dO_tr + (long)b * mtiles * kTriTile;
+  const char* Qt = a.Q_tr + (long)b * mtiles * kTriTile;
+  char* meta = smem_c + 2 * kKvStage;
+  const float* scol = a.smap + (long)b * N * ld + jc;
+
+  auto stage_tiles = [&](int t) {  // 18 DMA pieces per thread
+    const int tt = min(t, mtiles - 1);
+    char* st = smem_c + (t & 1) * kKvStage;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int off = (tid + 256 * k) * 16, loff = (wave * 64 + 256 * k) * 16;
+      glds16(Gr + (long)tt * kTriTile + off, st + loff);
+      glds16(Gt + (long)tt * kTriTile + off, st + kTriTile + loff);
+      glds16(Qt + (long)tt * kTriTile + off, st + 2 * kTriTile + loff);
+    }
+  };
+  auto stage_meta = [&](int t) {  // 2 pieces per thread; the four waves write the same bytes
+    const int i0 = min(t, mtiles - 1) * 32;
+    char* ms = meta + (t % 3) * kKvMeta;
+    const int ii = min(i0 + lo, M - 1);
+    glds4((h ? a.delta : a.lse_s) + (long)b * M + ii, ms);                        // lane -> float lane
+    glds4(reinterpret_cast<const int*>(a.idx + (long)b * M + min(i0 + (lane >> 1), M - 1)) + (lane & 1), ms + 256);
+  };
+  stage_tiles(0);
+  stage_meta(0);
+  stage_meta(1);
+  u32x4 vr[24];
+  load_rm_row(a.V_rm, ktiles, b, jc, h, vr);
+  f32x16 dv[4], dk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = zero16();
+  float csum = 0.f;
+  const float scale = a.scale;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float sv[16];
+  auto load_s = [&](int t, float (&dst)[16]) {  // S[sampled row][this lane's key] of tile t (its meta has landed)
+    const long long* sel = reinterpret_cast<const long long*>(meta + (t % 3) * kKvMeta + 256);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = scol[sel[crow(r, h)] * ld];
+  };
+  load_s(0, sv);
+
+  for (int t = 0; t < mtiles; ++t) {
+    const char* st = smem_c + (t & 1) * kKvStage;
+    const float* Lt = reinterpret_cast<const float*>(meta + (t % 3) * kKvMeta);
+    stage_tiles(t + 1);
+    stage_meta(t + 2);
+    float sn[16];
+    load_s(t + 1, sn);  // rows past M-1 are clamped in the meta slot; their P is masked below
+    const f32x16 dp = mma_rm_x_regs(st, lo, h, vr);  // dP: rows = sampled rows crow(r, h), column = this lane's key
+    float p[16], ds[16];
+    const int i0 = t * kTile;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ir = crow(r, h);
+      float pv = __expf(sv[r] - Lt[ir]);
+      pv = (i0 + ir < M) ? pv : 0.f;
+      p[r] = pv;
+      ds[r] = jvalid ? pv * (dp[r] - Lt[32 + ir]) * scale : 0.f;
+      if (CS) csum += ds[r];
+    }
+    mma_tr_x_acc(st + kTriTile, lo, h, p, dv);
+    mma_tr_x_acc(st + 2 * kTriTile, lo, h, ds, dk);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sn[r];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (CS) {
+    const float ctot = csum + wave_xor32(csum);
+    if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
+  }
+  if (jvalid) {
+    float* vrow = a.dV + (long)b * a.dv_bs + (long)j * a.dv_rs + 4 * h;
+    float* krow = a.dK + (long)b * a.dk_bs + (long)j * a.dk_rs + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ov = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        const f32x4 ok = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(vrow + 32 * dt + 8 * g) = ov;
+        *reinterpret_cast<f32x4*>(krow + 32 * dt + 8 * g) = ok;
+      }
+    }
+  }
+}
+
+}  // namespace samble
+
+extern "C" void samble_time_begin(int, hipStream_t);
+extern "C" void samble_time_end(int, hipStream_t);
+using namespace samble;
+extern int g_stats_ablate;
+
+extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse_s, const float* delta, const void* dO_rm,
+                                     const void* dO_tr, const void* Q_tr, const void* V_rm, const void* K_tr,
+                                     const long long* idx, int B, int N, int nt, int M, float scale, float* dQ, long dq_bs,
+                                     long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
+                                     float* cs, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipSuccess;
+    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0>), reinterpret_cast<const void*>(bwd_dq_tri_kernel<1>),
+                          reinterpret_cast<const void*>(bwd_dq_tri_kernel<2>), reinterpret_cast<const void*>(bwd_dq_tri_kernel<3>)}) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
+      if (e != hipSuccess) return (int)e;
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
+                     idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};
+  samble_time_begin(3, stream);
+  if (cs) hipLaunchKernelGGL(bwd_dkdv_tri_kernel<true>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
+  else hipLaunchKernelGGL(bwd_dkdv_tri_kernel<false>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
+  samble_time_end(3, stream);
+  const DqTriArgs dq{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)V_rm, (const char*)K_tr, idx, N, N + nt, M,
+                     scale, dQ, dq_bs, dq_rs};
+  samble_time_begin(6, stream);
+  auto dqk = g_stats_ablate == 21 ? bwd_dq_tri_kernel<1> : g_stats_ablate == 22 ? bwd_dq_tri_kernel<2>
+           : g_stats_ablate == 23 ? bwd_dq_tri_kernel<3> : bwd_dq_tri_kernel<0>;
+  hipLaunchKernelGGL(dqk, dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+  samble_time_end(6, stream);
+  return (int)hipGetLastError();
+}

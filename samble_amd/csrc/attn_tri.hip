@@ -58,13 +58,15 @@ __global__ __launch_bounds__(256) void tri_split_kernel(const float* __restrict_
 // per 32-row tile; every qkv row is read once.
 __global__ __launch_bounds__(256) void tri_split_qkv_kernel(const float* __restrict__ qkv, long bs, long rs, int N,
                                                             int NK, char* __restrict__ qimg, char* __restrict__ kimg,
-                                                            char* __restrict__ vimg) {
+                                                            char* __restrict__ vimg, char* __restrict__ ktr,
+                                                            char* __restrict__ vrm) {
   const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int qtiles = (N + 31) / 32, ntiles = (NK + 31) / 32;
   const float* sb = qkv + (long)b * bs;
-  for (int e = tid; e < 1024; e += 256) {  // RM chunks of Q (e < 512) and K
+  for (int e = tid; e < 1536; e += 256) {  // RM chunks of Q (e < 512), K and (for the backward) V
     const int which = e >> 9, r = e & 31, g = (e >> 5) & 15, row = tile * 32 + r;
     if (which == 0 && tile >= qtiles) continue;
+    if (which == 2 && !vrm) continue;
     float x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = 0.f;
@@ -75,19 +77,21 @@ __global__ __launch_bounds__(256) void tri_split_qkv_kernel(const float* __restr
       for (int i = 0; i < 4; ++i) { x[i] = a[i]; x[4 + i] = bb[i]; }
     }
     const Tri t = tri_split8(x);
-    char* img = which ? kimg + ((long)b * ntiles + tile) * kTriTile : qimg + ((long)b * qtiles + tile) * kTriTile;
+    char* img = which == 0 ? qimg + ((long)b * qtiles + tile) * kTriTile
+                           : (which == 1 ? kimg : vrm) + ((long)b * ntiles + tile) * kTriTile;
     *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t.h;
     *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t.m;
     *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t.l;
   }
-  char* img = vimg + ((long)b * ntiles + tile) * kTriTile;
-  for (int e = tid; e < 512; e += 256) {  // TR chunks of V
-    const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
+  for (int e = tid; e < 1024; e += 256) {  // TR chunks of V (e < 512) and (for the backward) K
+    const int which = e >> 9, d = e & 127, cg = (e >> 7) & 3, s = cg >> 1, hh = cg & 1;
+    if (which == 1 && !ktr) continue;
+    char* img = (which ? ktr : vimg) + ((long)b * ntiles + tile) * kTriTile;
     float x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = tile * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
-      x[i] = (row < NK) ? sb[(long)row * rs + 256 + d] : 0.f;
+      x[i] = (row < NK) ? sb[(long)row * rs + (which ? 128 : 256) + d] : 0.f;
     }
     const Tri t = tri_split8(x);
     *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t.h;
@@ -453,8 +457,8 @@ extern "C" int samble_launch_attn_rows_tri(const float* smap, int ld, const floa
 }
 
 extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, int B, int N, int nt, void* qimg, void* kimg,
-                                           void* vimg, hipStream_t stream) {
+                                           void* vimg, void* ktr, void* vrm, hipStream_t stream) {
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
-                     (char*)qimg, (char*)kimg, (char*)vimg);
+                     (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm);
   return (int)hipGetLastError();
 }

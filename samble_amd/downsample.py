@@ -85,7 +85,7 @@ class _SamplerCore(torch.autograd.Function):
             nn_idx = ops.stage_knn(x, x, mod.K)
             if TWO_PASS or mod.asm == "l2":
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
-                imgs = ops.stage_tri_split_qkv(qkv, N) if ops.MATRIX_MODE == "tri" else None
+                imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
                 smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
                 score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
@@ -104,6 +104,7 @@ class _SamplerCore(torch.autograd.Function):
         if smap is not None:
             x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=imgs[2] if imgs else None)
             ctx.save_for_backward(qkv, x_ds, lse, idx, smap)
+            ctx.bwd_images = (imgs[3], imgs[4]) if imgs is not None and len(imgs) == 5 else None
         else:
             x_ds = ops.stage_gather_rows(O, idx)
             ctx.save_for_backward(qkv, O, lse, idx)
@@ -125,7 +126,8 @@ class _SamplerCore(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             if smap is not None:  # O is x_ds (B,D,M) here
                 ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
-                                        dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm)
+                                        dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm,
+                                        images=getattr(ctx, "bwd_images", None))
             else:
                 ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
                                    dqkv[:, :, 2 * D:3 * D])

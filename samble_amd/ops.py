@@ -379,8 +379,9 @@ def stage_tri_split(rows: torch.Tensor, want_rm: bool = True, want_tr: bool = Fa
     return rm, tr
 
 
-def stage_tri_split_qkv(qkv: torch.Tensor, n_points: int):
-    """qkv (B,N+nt,3*128) point-major rows [Q|K|V] -> (q_image, k_image, v_tr_image) in one launch."""
+def stage_tri_split_qkv(qkv: torch.Tensor, n_points: int, for_backward: bool = False):
+    """qkv (B,N+nt,3*128) point-major rows [Q|K|V] -> (q_image, k_image, v_tr_image[, k_tr_image, v_rm_image])
+    in one launch; the last two are what the backward kernels read."""
     _need_gpu(qkv)
     B, NK, D3 = qkv.shape
     D = D3 // 3
@@ -390,9 +391,13 @@ def stage_tri_split_qkv(qkv: torch.Tensor, n_points: int):
         q_img = torch.empty(_lib.query("samble_tri_image_bytes", B, n_points, 0), dtype=torch.uint8, device=qkv.device)
         k_img = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 0), dtype=torch.uint8, device=qkv.device)
         v_img = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 1), dtype=torch.uint8, device=qkv.device)
+        k_tr = v_rm = None
+        if for_backward:
+            k_tr = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 1), dtype=torch.uint8, device=qkv.device)
+            v_rm = torch.empty(_lib.query("samble_tri_image_bytes", B, NK, 0), dtype=torch.uint8, device=qkv.device)
         _lib.call("samble_tri_split_qkv_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), B, n_points, NK - n_points, D,
-                  q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(), _stream())
-    return q_img, k_img, v_img
+                  q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(), _p(k_tr), _p(v_rm), _stream())
+    return (q_img, k_img, v_img, k_tr, v_rm) if for_backward else (q_img, k_img, v_img)
 
 
 def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: int, asm: str = "dot",
@@ -471,24 +476,36 @@ def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
 
 
 def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv,
-                        asm: str = "dot") -> None:
+                        asm: str = "dot", images=None) -> None:
     """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M).
     asm "l2": the kernels also return the column sums of dS and the gradients are finished here:
-    dS/dq_i = scale (2 k_j - 2 q_i), dS/dk_j = scale (2 q_i - 2 k_j), rows of dS sum to zero."""
+    dS/dq_i = scale (2 k_j - 2 q_i), dS/dk_j = scale (2 q_i - 2 k_j), rows of dS sum to zero.
+    images: optional (k_tr_image, v_rm_image) of the forward's split (MATRIX_MODE "tri")."""
     _need_gpu(q, k, v, smap, lse, x_ds, idx, g)
     B, N, D = q.shape
     M = idx.shape[1]
     g = _f32c(g)
     x_ds = _f32c(x_ds)
     with torch.cuda.device(q.device):
-        nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
         cs = torch.zeros((B, n_points + n_tokens), dtype=torch.float32, device=q.device) if asm == "l2" else None
-        _lib.call("samble_attn_rows_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
-                  k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), smap.data_ptr(), smap.shape[2], lse.data_ptr(),
-                  x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(),
-                  dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0),
-                  dv.stride(1), _p(cs), ws.data_ptr(), nbytes, _stream())
+        if MATRIX_MODE == "tri":
+            if images is None:
+                images = (stage_tri_split(k, want_rm=False, want_tr=True)[1], stage_tri_split(v)[0])
+            nbytes = _lib.query("samble_attn_rows_bwd_tri_workspace_bytes", B, n_points, M, D)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            _lib.call("samble_attn_rows_bwd_tri_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                      k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), images[0].data_ptr(), images[1].data_ptr(),
+                      smap.data_ptr(), smap.shape[2], lse.data_ptr(), x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B,
+                      n_points, n_tokens, M, D, dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0),
+                      dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1), _p(cs), ws.data_ptr(), nbytes, _stream())
+        else:
+            nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            _lib.call("samble_attn_rows_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
+                      k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), smap.data_ptr(), smap.shape[2], lse.data_ptr(),
+                      x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(),
+                      dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0),
+                      dv.stride(1), _p(cs), ws.data_ptr(), nbytes, _stream())
         if asm == "l2":
             dq.mul_(2.0)
             dk.mul_(2.0).sub_(2.0 * cs.unsqueeze(-1) * k)
