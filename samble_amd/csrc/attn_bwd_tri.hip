@@ -256,6 +256,15 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
   const float scale = a.scale;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+  // this lane's 16 rows crow(r, h) = 8g + 4h + e of a [32]-float array: four 16-byte LDS reads
+  auto rows16 = [&](const float* base, float (&dst)[16]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(base + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[4 * g + e] = v4[e];
+    }
+  };
   float sv[16];
   auto load_s = [&](int t, float (&dst)[16]) {  // S[sampled row][this lane's key] of tile t (its meta has landed)
     const long long* sel = reinterpret_cast<const long long*>(meta + (t % 3) * kKvMeta + 256);
@@ -272,15 +281,16 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
     float sn[16];
     load_s(t + 1, sn);  // rows past M-1 are clamped in the meta slot; their P is masked below
     const f32x16 dp = mma_rm_x_regs(st, lo, h, vr);  // dP: rows = sampled rows crow(r, h), column = this lane's key
-    float p[16], ds[16];
+    float p[16], ds[16], lv[16], dl[16];
+    rows16(Lt, lv);
+    rows16(Lt + 32, dl);
     const int i0 = t * kTile;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ir = crow(r, h);
-      float pv = __expf(sv[r] - Lt[ir]);
-      pv = (i0 + ir < M) ? pv : 0.f;
+      float pv = __expf(sv[r] - lv[r]);
+      pv = (i0 + crow(r, h) < M) ? pv : 0.f;
       p[r] = pv;
-      ds[r] = jvalid ? pv * (dp[r] - Lt[32 + ir]) * scale : 0.f;
+      ds[r] = jvalid ? pv * (dp[r] - dl[r]) * scale : 0.f;
       if (CS) csum += ds[r];
     }
     mma_tr_x_acc(st + kTriTile, lo, h, p, dv);
