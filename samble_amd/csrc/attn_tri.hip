@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void tri_split_qkv_kernel(const float* __restr
     float x[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = 0.f;
-    if (row < NK) {
+    if (row < (which == 0 ? N : NK)) {  // the Q image covers the N point rows only
       const f32x4* p = reinterpret_cast<const f32x4*>(sb + (long)row * rs + 128 * which + 8 * g);
       const f32x4 a = p[0], bb = p[1];
 #pragma unroll

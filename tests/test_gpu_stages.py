@@ -559,3 +559,77 @@ def test_blend_boundaries_kernel_is_bitwise_the_reference_expression():
         ref = ref * mu + (1 - mu) * qk.cpu()  # the reference's expression, fp32 on the CPU
         assert st[0].data_ptr() == up_ptr, "blended in place"
         assert torch.equal(st[0][0, 0, 0, 1:].cpu(), ref) and torch.equal(st[1][0, 0, 0, :-1].cpu(), ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# split-bf16 operand images (csrc/tri_dev.h) and the kernels that only exist in that mode
+# ---------------------------------------------------------------------------------------------
+def _bf16_planes_to_f64(words: np.ndarray) -> np.ndarray:
+    """uint16 bf16 bit patterns -> float64 values."""
+    return (words.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def test_operand_images_hold_every_significand_bit():
+    """Decode the two image layouts on the host exactly as tri_dev.h documents them: the three bf16 planes
+    of every element sum to the fp32 value (all 24 bits), rows past the end are zeros."""
+    B, R, D = 2, 77, 128
+    x = torch.from_numpy(synth.normal((B, R, D), 31) * np.exp(synth.normal((B, R, 1), 32) * 3)).float().to(DEV)
+    rm, tr = ops().stage_tri_split(x, want_rm=True, want_tr=True)
+    ntiles = (R + 31) // 32
+    xpad = np.zeros((B, ntiles * 32, D), np.float64)
+    xpad[:, :R] = x.cpu().numpy().astype(np.float64)
+    # RM: tile -> [chunk c = 3 * (channel / 8) + piece][row r][8 bf16]
+    a = rm.cpu().numpy().view(np.uint16).reshape(B, ntiles, 16, 3, 32, 8)
+    val = _bf16_planes_to_f64(a).sum(3)                      # (B, tile, group, row, e)
+    got = val.transpose(0, 1, 3, 2, 4).reshape(B, ntiles * 32, D)
+    assert np.array_equal(got, xpad)
+    # TR: tile -> [chunk c = 3 * (2 s + h) + piece][channel d][8 bf16], element e = tile row 16 s + 8 (e >> 2) + 4 h + (e & 3)
+    t = tr.cpu().numpy().view(np.uint16).reshape(B, ntiles, 4, 3, 128, 8)
+    tv = _bf16_planes_to_f64(t).sum(3)                       # (B, tile, cg, d, e)
+    rows = np.empty((4, 8), np.int64)
+    for cg in range(4):
+        for e in range(8):
+            rows[cg, e] = 16 * (cg >> 1) + 8 * (e >> 2) + 4 * (cg & 1) + (e & 3)
+    got_t = np.zeros_like(xpad).reshape(B, ntiles, 32, D)
+    for cg in range(4):
+        for e in range(8):
+            got_t[:, :, rows[cg, e], :] = tv[:, :, cg, :, e]
+    assert np.array_equal(got_t.reshape(B, ntiles * 32, D), xpad)
+
+
+def test_qkv_split_matches_the_single_operand_splits():
+    B, N, nt, D = 2, 200, 6, 128
+    qkv = torch.from_numpy(synth.normal((B, N + nt, 3 * D), 77)).to(DEV)
+    o_ = ops()
+    q_img, k_img, v_tr, k_tr, v_rm = o_.stage_tri_split_qkv(qkv, N, for_backward=True)
+    assert torch.equal(q_img, o_.stage_tri_split(qkv[:, :N, :D])[0])
+    k_rm_ref, k_tr_ref = o_.stage_tri_split(qkv[:, :, D:2 * D], want_rm=True, want_tr=True)
+    v_rm_ref, v_tr_ref = o_.stage_tri_split(qkv[:, :, 2 * D:], want_rm=True, want_tr=True)
+    assert torch.equal(k_img, k_rm_ref) and torch.equal(k_tr, k_tr_ref)
+    assert torch.equal(v_rm, v_rm_ref) and torch.equal(v_tr, v_tr_ref)
+
+
+@pytest.mark.parametrize("Nq,Nk,K", [(512, 512, 32), (333, 1500, 16), (2048, 2048, 32)])
+def test_knn_split_bf16_kernel_agrees_with_the_fp32_kernel(Nq, Nk, K):
+    """Same selection, different rounding of the Gram entries: the neighbour SETS agree except at
+    near-ties, and both agree with fp64."""
+    from samble_amd import _lib
+    lib = _lib.load()
+    B, C = 2, 128
+    a = torch.from_numpy(synth.normal((B, C, Nq), 5)).to(DEV)
+    bb = a if Nq == Nk else torch.from_numpy(synth.normal((B, C, Nk), 6)).to(DEV)
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    try:
+        o_.MATRIX_MODE = "f32"
+        ref = o_.stage_knn(a, bb, K)
+        o_.MATRIX_MODE = "tri"
+        got, dist = o_.stage_knn(a, bb, K, want_dist=True)
+    finally:
+        o_.MATRIX_MODE = old
+        lib.samble_knn_tri_config(int(old == "tri"), 0)
+    assert set_agreement(got.cpu(), ref.cpu()) >= 0.9995
+    d = ((a.double().permute(0, 2, 1)[:, :, None, :] - bb.double().permute(0, 2, 1)[:, None, :, :]) ** 2).sum(-1)
+    want = d.topk(K, dim=-1, largest=False)[1]
+    assert set_agreement(got.cpu(), want.cpu()) >= 0.9995
+    assert bool((dist[:, :, 1:] >= dist[:, :, :-1]).all()), "nearest first"
