@@ -45,29 +45,25 @@ __device__ __forceinline__ Tri tri_from_acc(const float (&x)[16], int ks) {
 // out[dt] (channels 32 dt .. 32 dt + 31 x this lane's column) += TRtile^T x frag, both k-steps
 __device__ __forceinline__ void mma_tr_x_acc(const char* __restrict__ tr_tile, int lo, int h, const float (&x)[16],
                                              f32x16 (&out)[4]) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const Tri bp = tri_from_acc(x, ks);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const char* ap = tr_tile + tri_tr_off(32 * dt + lo, 2 * ks + h, 0);
-      const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
-                     *reinterpret_cast<const u32x4*>(ap + 4096)};
-      out[dt] = mfma_tri(a, bp, out[dt]);
-    }
-  }
+  const Tri b0 = tri_from_acc(x, 0), b1 = tri_from_acc(x, 1);
+  tri_pipelined<8>(
+      [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+        const char* ap = tr_tile + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+        return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                   *reinterpret_cast<const u32x4*>(ap + 4096)};
+      },
+      [&](int i, const Tri& a) { out[i & 3] = mfma_tri(a, (i >> 2) ? b1 : b0, out[i & 3]); });
 }
 
 // acc(32x32) = RMtile(rows from LDS) x reg(24 operand registers of this lane's row)^T
 __device__ __forceinline__ f32x16 mma_rm_x_regs(const char* __restrict__ rm_tile, int lo, int h, const u32x4 (&q)[24]) {
   const u32x4* lp = reinterpret_cast<const u32x4*>(rm_tile + tri_rm_off(lo, h, 0));
   f32x16 acc = zero16();
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
-    const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-    acc = mfma_tri(a, bq, acc);
-  }
+  tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; },
+                   [&](int ks, const Tri& a) {
+                     const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+                     acc = mfma_tri(a, bq, acc);
+                   });
   return acc;
 }
 
@@ -265,38 +261,88 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
       for (int e = 0; e < 4; ++e) dst[4 * g + e] = v4[e];
     }
   };
-  float sv[16];
   auto load_s = [&](int t, float (&dst)[16]) {  // S[sampled row][this lane's key] of tile t (its meta has landed)
     const long long* sel = reinterpret_cast<const long long*>(meta + (t % 3) * kKvMeta + 256);
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[r] = scol[sel[crow(r, h)] * ld];
   };
-  load_s(0, sv);
+  // One block of 48 MFMAs: out[dt] += TRtile^T x frag (8 steps of six MFMAs, operands fetched two steps
+  // ahead), with `fill(i)` -- about 24 vector instructions of OTHER work -- placed in the MFMAs' shadow
+  // step by step: this wave is alone on its SIMD, nothing else would run there.
+  auto block = [&](const char* tr_tile, const Tri (&f)[2], f32x16 (&out)[4], auto fill) {
+    tri_pipelined<8>(
+        [&](int i) {
+          const char* ap = tr_tile + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+          return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                     *reinterpret_cast<const u32x4*>(ap + 4096)};
+        },
+        [&](int i, const Tri& aa) {
+          out[i & 3] = mfma_tri(aa, f[i >> 2], out[i & 3]);
+          fill(i);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        });
+  };
+  float p[16], lv[16], dl[16];
+  Tri pf[2];
+  {  // P of tile 0 and its planes
+    float s0[16];
+    load_s(0, s0);
+    rows16(reinterpret_cast<const float*>(meta), lv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __expf(s0[r] - lv[r]);
+      p[r] = (crow(r, h) < M) ? pv : 0.f;
+    }
+    pf[0] = tri_from_acc(p, 0);
+    pf[1] = tri_from_acc(p, 1);
+  }
 
+  // tile t:  dP (48 MFMAs)  |  dV += dO^T P (48) under which dS and its planes are formed  |
+  //          dK += Q^T dS (48) under which the NEXT tile's P and its planes are formed (logits fetched a tile ahead)
   for (int t = 0; t < mtiles; ++t) {
     const char* st = smem_c + (t & 1) * kKvStage;
     const float* Lt = reinterpret_cast<const float*>(meta + (t % 3) * kKvMeta);
-    stage_tiles(t + 1);
-    stage_meta(t + 2);
+    const float* Ln = reinterpret_cast<const float*>(meta + ((t + 1) % 3) * kKvMeta);
     float sn[16];
     load_s(t + 1, sn);  // rows past M-1 are clamped in the meta slot; their P is masked below
-    const f32x16 dp = mma_rm_x_regs(st, lo, h, vr);  // dP: rows = sampled rows crow(r, h), column = this lane's key
-    float p[16], ds[16], lv[16], dl[16];
-    rows16(Lt, lv);
+    stage_tiles(t + 1);
+    stage_meta(t + 2);
     rows16(Lt + 32, dl);
-    const int i0 = t * kTile;
+    rows16(Ln, lv);
+    const f32x16 dp = mma_rm_x_regs(st, lo, h, vr);  // dP: rows = sampled rows crow(r, h), column = this lane's key
+    Tri df[2];
+    float ds[16];
+    block(st + kTriTile, pf, dv, [&](int i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float pv = __expf(sv[r] - lv[r]);
-      pv = (i0 + crow(r, h) < M) ? pv : 0.f;
-      p[r] = pv;
-      ds[r] = jvalid ? pv * (dp[r] - dl[r]) * scale : 0.f;
-      if (CS) csum += ds[r];
-    }
-    mma_tr_x_acc(st + kTriTile, lo, h, p, dv);
-    mma_tr_x_acc(st + 2 * kTriTile, lo, h, ds, dk);
+      for (int e = 0; e < 2; ++e) {
+        const int r = 2 * i + e;
+        ds[r] = jvalid ? p[r] * (dp[r] - dl[r]) * scale : 0.f;
+        if (CS) csum += ds[r];
+      }
+      unsigned hh, mm, ll;
+      tri_split2(ds[2 * i], ds[2 * i + 1], hh, mm, ll);
+      df[i >> 2].h[i & 3] = hh;
+      df[i >> 2].m[i & 3] = mm;
+      df[i >> 2].l[i & 3] = ll;
+    });
+    const int i1 = (t + 1) * kTile;
+    block(st + 2 * kTriTile, df, dk, [&](int i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = sn[r];
+      for (int e = 0; e < 2; ++e) {
+        const int r = 2 * i + e;
+        const float pv = __expf(sn[r] - lv[r]);
+        p[r] = (i1 + crow(r, h) < M) ? pv : 0.f;
+      }
+      unsigned hh, mm, ll;
+      tri_split2(p[2 * i], p[2 * i + 1], hh, mm, ll);
+      pf[i >> 2].h[i & 3] = hh;
+      pf[i >> 2].m[i & 3] = mm;
+      pf[i >> 2].l[i & 3] = ll;
+    });
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (CS) {

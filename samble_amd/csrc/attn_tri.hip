@@ -355,25 +355,25 @@ __global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restr
       for (int e = 0; e < 4; ++e) p[4 * g + e] = __expf(v4[e] - my_lse);
     }
     const char* vt = smem_c + slot * kTriTile;
+    Tri bp[2];  // P^T fragments of the two k-steps: elements e <-> registers 8 ks + e
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Tri bp;  // P^T fragment of k-step ks: elements e <-> registers 8 ks + e
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         unsigned hh, mm, ll;
         tri_split2(p[8 * ks + 2 * w], p[8 * ks + 2 * w + 1], hh, mm, ll);
-        bp.h[w] = hh;
-        bp.m[w] = mm;
-        bp.l[w] = ll;
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const char* ap = vt + tri_tr_off(32 * dt + lo, 2 * ks + h, 0);
-        const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
-                       *reinterpret_cast<const u32x4*>(ap + 4096)};
-        oacc[dt] = mfma_tri(a, bp, oacc[dt]);
+        bp[ks].h[w] = hh;
+        bp[ks].m[w] = mm;
+        bp[ks].l[w] = ll;
       }
     }
+    tri_pipelined<8>(
+        [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+          const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+          return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                     *reinterpret_cast<const u32x4*>(ap + 4096)};
+        },
+        [&](int i, const Tri& a) { oacc[i & 3] = mfma_tri(a, bp[i >> 2], oacc[i & 3]); });
     // tile t+1 (staged one iteration ago) must have landed before anyone reads it; the 10 pieces issued
     // in this iteration stay in flight
     asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -89,6 +89,25 @@ __device__ __forceinline__ Tri tri_split8(const float (&x)[8]) {
   return t;
 }
 
+// A run of NSTEP k-steps whose LDS operand `fetch(i)` is requested two steps before `use(i, operand)`
+// issues its six MFMAs.  For kernels that run ONE wave per SIMD: nothing else hides the LDS latency
+// between a ds_read and the MFMA that consumes it, and left to itself the compiler places each read
+// right in front of its use (62 s_waitcnt per 144 MFMAs in the first build of the dK/dV kernel).
+template <int NSTEP, class Fetch, class Use>
+__device__ __forceinline__ void tri_pipelined(Fetch fetch, Use use) {
+  Tri a0 = fetch(0), a1 = fetch(NSTEP > 1 ? 1 : 0);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    Tri a2 = a1;
+    if (i + 2 < NSTEP) a2 = fetch(i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    use(i, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = a1;
+    a1 = a2;
+  }
+}
+
 // Staging of one image tile (1536 16-byte chunks, copied verbatim) by NT threads: loads issued early,
 // committed to LDS later.  Conflict-free 16-byte LDS stores (consecutive lanes, consecutive chunks).
 template <int NT>
