@@ -60,7 +60,7 @@ def time_region(fn, iters):
 
 # ids of the library's timing hook (samble_debug_time_kernel); both matrix modes use the same ids for the
 # kernels that play the same part (3 = dominant backward kernel: bwd_rows or bwd_dkdv_tri)
-KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4, "bwd_dq": 6}
+KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4, "bwd_dq": 6, "bwd_dk": 7}
 
 
 def kernel_ms(kernel, fn, iters=5):
@@ -222,7 +222,9 @@ def main():
     # on the timed region); read back after the final synchronize
     from samble_amd import _lib
     lib = _lib.load()
-    lib.samble_debug_time_kernel(KERNEL_IDS["bwd_rows"])
+    from samble_amd import ops as _ops0
+    dominant = "knn_stream" if _ops0.MATRIX_MODE == "tri" else "bwd_rows"  # id 4 is knn_tri in the split-bf16 mode
+    lib.samble_debug_time_kernel(KERNEL_IDS[dominant])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -294,9 +296,8 @@ def main():
             return out
 
         if tri:
-            # dominant kernel: bwd_dkdv_tri (dP, dV, dK over the N point keys = 3 of the backward's 4 products)
-            bwd_alg = 3 * 2 * M * N * C * B_PER_GPU
-            result["roofline"] = roof("bwd_dkdv_tri_kernel", bwd_alg, dominant_ms, "samble::bwd_dkdv_tri_kernel")
+            # dominant kernel: knn_tri (fused Gram + top-K of the feature-space kNN; algorithmic flops = the Gram)
+            result["roofline"] = roof("knn_tri_kernel", fl["dist"] * B_PER_GPU, dominant_ms, "samble::knn_tri_kernel")
         else:
             bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
             result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
@@ -318,12 +319,16 @@ def main():
             others = {
                 "attn_stats" + sfx: (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats" + sfx),
                 "attn_rows" + sfx: (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows" + sfx),
-                ("knn_tri_kernel" if tri else "knn_stream_kernel"): (
-                    fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"),
-                    "samble::knn_tri_kernel" if tri else "samble::knn_stream_kernel"),
             }
-            if tri:  # dQ: the 4th product of the backward (its kernel forms dP a second time: not counted)
-                others["bwd_dq_tri_kernel"] = (fl["av"] * B_PER_GPU, in_step_ms("bwd_dq"), "samble::bwd_dq_tri_kernel")
+            if tri:
+                # backward: dQ kernel = dP + dQ (2 products over N + nt keys), then dV and dK (1 product each, N keys)
+                others["bwd_dq_tri_kernel"] = (2 * fl["av"] * B_PER_GPU, in_step_ms("bwd_dq"), "samble::bwd_dq_tri_kernel")
+                others["bwd_kacc_tri_kernel<0> (dV)"] = (2 * M * N * C * B_PER_GPU, in_step_ms("bwd_rows"),
+                                                        "samble::bwd_kacc_tri_kernel<0, false>")
+                others["bwd_kacc_tri_kernel<1> (dK)"] = (2 * M * N * C * B_PER_GPU, in_step_ms("bwd_dk"),
+                                                        "samble::bwd_kacc_tri_kernel<1, false>")
+            else:
+                others["knn_stream_kernel"] = (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"), "samble::knn_stream_kernel")
             result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seed)

@@ -70,6 +70,9 @@ void samble_knn_force_unfused(int on);
 /* debug / A-B switch of the feature-space kNN (C = 128): enabled 1 = bf16 matrix cores on split fp32
  * operands (default), 0 = fp32 MFMA kernel; insert_steps > 0 sets the insertion steps per key tile */
 void samble_knn_tri_config(int enabled, int insert_steps);
+/* A-B switch of the split-bf16 backward: 1 (default) = dQ kernel writes a dS map and dV / dK accumulate from
+ * the maps (4 products per tile), 0 = fused dP / dV / dK kernel (5 products, no dS map) */
+void samble_debug_bwd_tri_mode(int use_ds_map);
 
 /* ---- models/downsample.py:116-137  q_conv / k_conv / v_conv (bias-free 1x1 Conv1d) ------------
  * x (B,C,N) channel-major, tokens (C,nt) = bin_tokens[0], W (3C,C) row-major = [Wq; Wk; Wv]

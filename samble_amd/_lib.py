@@ -23,6 +23,7 @@ _SIGNATURES = {
     "samble_last_error": (c_char_p, []),
     "samble_knn_force_unfused": (None, [c_int]),
     "samble_knn_tri_config": (None, [c_int, c_int]),
+    "samble_debug_bwd_tri_mode": (None, [c_int]),
     "samble_debug_ablate": (None, [c_int, c_int]),
     "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,

@@ -56,6 +56,7 @@ int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, c
                            long, float*, long, long, int, float*, float*, const void*, const void*, void*, hipStream_t);
 int samble_attn_map_ld(int N, int nt);
 size_t samble_tri_image_size(int, int, int);
+size_t samble_bwd_tri_dsmap_bytes(int, int, int);
 int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
 int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, void*, void*, hipStream_t);
 int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
@@ -348,7 +349,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   }
   const bool tri = k_tr_image && v_rm_image;
   const size_t base_bytes = samble_attn_bwd_workspace_bytes(B, N, M, D);
-  if (ws_bytes < base_bytes + (tri ? 3 * samble_tri_image_size(B, M, 0) : 0)) {
+  if (ws_bytes < base_bytes + (tri ? 3 * samble_tri_image_size(B, M, 0) + samble_bwd_tri_dsmap_bytes(B, N, M) : 0)) {
     snprintf(msg, sizeof msg, "%s: workspace too small", who);
     return fail(SAMBLE_E_WORKSPACE, msg);
   }
@@ -406,7 +407,7 @@ SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_
 
 SAMBLE_API size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D) {
   if (B <= 0 || N <= 0 || M <= 0) return 0;
-  return samble_attn_bwd_workspace_bytes(B, N, M, D) + 3 * samble_tri_image_size(B, M, 0);
+  return samble_attn_bwd_workspace_bytes(B, N, M, D) + 3 * samble_tri_image_size(B, M, 0) + samble_bwd_tri_dsmap_bytes(B, N, M);
 }
 
 SAMBLE_API int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,

@@ -83,7 +83,8 @@ __device__ __forceinline__ void load_rm_row(const char* __restrict__ img, long t
 // dQ: one workgroup = 4 waves = 128 sampled rows; key tiles (V RM + K TR images, 48 KB) double-buffered
 // ------------------------------------------------------------------------------------------------
 constexpr int kDqStage = 2 * kTriTile + 4 * 4096;  // V RM tile, K TR tile, S slots of the 4 waves
-constexpr int kDqLds = 2 * kDqStage;
+constexpr int kDqXt = 36;                          // row stride (floats) of a wave's 32x32 transpose tile
+constexpr int kDqLds = 2 * kDqStage + 4 * 32 * kDqXt * 4;
 
 struct DqTriArgs {
   const float* smap;
@@ -98,6 +99,7 @@ struct DqTriArgs {
   float scale;
   float* dQ;
   long dq_bs, dq_rs;
+  float* dsmap;  // optional (B, M, ld): dS of the sampled rows, for the key-stationary kernels
 };
 
 template <int ABL>  // timing-only ablations (wrong results): 1 = tiles staged once, 2 = no matrix products
@@ -156,6 +158,22 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
         ds[r] = __expf(v4[e] - my_lse) * (dp[r] - my_delta) * scale;  // columns past N + nt hold -inf: P = 0
+      }
+    }
+    if (a.dsmap) {  // dS tile -> map rows as full 128-byte lines (8 lanes per row), through the wave's LDS tile
+      float* xt = reinterpret_cast<float*>(smem_c + 2 * kDqStage) + wave * (32 * kDqXt);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {ds[4 * g], ds[4 * g + 1], ds[4 * g + 2], ds[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(xt + lo * kDqXt + 8 * g + 4 * h) = o;
+      }
+      const int m0 = chunk * (32 * NW) + wave * 32;
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+        const int rr = (lane >> 3) + 8 * k8;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xt + rr * kDqXt + 4 * (lane & 7));
+        const int mr = min(m0 + rr, M - 1);  // rows past M-1 rewrite row M-1's values of this wave (same bytes)
+        *reinterpret_cast<f32x4*>(a.dsmap + ((long)b * M + mr) * a.ld + t * kTile + 4 * (lane & 7)) = o;
       }
     }
     if (ABL & 2) {
@@ -365,6 +383,142 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Key-stationary accumulation with dS taken from the map bwd_dq_tri wrote (4 products per tile in all,
+// nothing formed twice):   MODE 0: dV^T += dO^T P,  P = exp(S - lse) from the logit map
+//                          MODE 1: dK^T += Q^T dS,  dS read back (and its column sums for l2 scoring)
+// One workgroup = 8 waves = 256 point keys, two waves per SIMD; per tile of 32 sampled rows one
+// transposed image tile (24 KB, ring of 4 by LDS-DMA, three tiles ahead) and 16 map values per lane,
+// fetched one tile ahead.  48 MFMAs per tile and wave, 64 accumulator registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAccDepth = 4;
+constexpr int kAccMeta = 512;  // per slot: lse[32] twice (MODE 0), idx[32] (int64) at +256
+constexpr int kAccLds = kAccDepth * kTriTile + kAccDepth * kAccMeta;
+
+struct KaccArgs {
+  const float* map;    // MODE 0: smap (B, N, ld);  MODE 1: dsmap (B, M, ld)
+  int ld;
+  const float* lse_s;  // MODE 0
+  const char* tr;      // transposed image of the sampled rows: dO (MODE 0) / Q (MODE 1)
+  const long long* idx;
+  int N, NK, M;
+  float* out;          // dV / dK rows
+  long o_bs, o_rs;
+  float* cs;           // MODE 1, optional (B, N + nt)
+};
+
+template <int MODE, bool CS>
+__global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kAccDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int N = a.N, M = a.M, ld = a.ld;
+  const int j = chunk * 256 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  const int jc = min(j, N - 1);
+  const int mtiles = (M + kTile - 1) / kTile;
+  const char* Tb = a.tr + (long)b * mtiles * kTriTile;
+  char* meta = smem_c + D * kTriTile;
+  const float* mapb = a.map + (long)b * (MODE == 0 ? N : M) * ld + jc;
+
+  auto stage_tile = [&](int t) {  // 3 DMA pieces per thread
+    const int tt = min(t, mtiles - 1);
+    char* st = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) glds16(Tb + (long)tt * kTriTile + (tid + 512 * k) * 16, st + (wave * 64 + 512 * k) * 16);
+  };
+  auto stage_meta = [&](int t) {  // MODE 0 only: 2 pieces per thread, the eight waves write the same bytes
+    const int i0 = min(t, mtiles - 1) * 32;
+    char* ms = meta + (t % D) * kAccMeta;
+    glds4(a.lse_s + (long)b * M + min(i0 + lo, M - 1), ms);  // lanes 32..63 repeat lanes 0..31: slot floats 0..63
+    glds4(reinterpret_cast<const int*>(a.idx + (long)b * M + min(i0 + (lane >> 1), M - 1)) + (lane & 1), ms + 128 + 128);
+  };
+  // this lane's 16 map values of tile t: rows = the tile's sampled rows crow(r, h), column = its key
+  auto load_x = [&](int t, float (&dst)[16]) {
+    if (MODE == 0) {
+      const long long* sel = reinterpret_cast<const long long*>(meta + (t % D) * kAccMeta + 256);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r] = mapb[sel[crow(r, h)] * ld];
+    } else {
+      const int i0 = min(t, mtiles - 1) * kTile;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r] = mapb[(long)min(i0 + crow(r, h), M - 1) * ld];
+    }
+  };
+  if (MODE == 0) {
+    stage_meta(0);
+    stage_meta(1);
+    stage_meta(2);
+  }
+  stage_tile(0);
+  stage_tile(1);
+  stage_tile(2);
+  f32x16 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
+  float csum = 0.f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // The map values are requested TWO tiles ahead (three register sets in rotation: one iteration is
+  // shorter than an HBM round trip under load; one tile ahead the loop ran at the load latency).
+  auto iter = [&](int t, const float (&xv)[16], float (&xfill)[16]) {
+    const char* st = smem_c + (t % D) * kTriTile;
+    if (MODE == 0) stage_meta(t + 3);  // older than this iteration's 19 youngest operations: landed at the end of it
+    load_x(t + 2, xfill);
+    stage_tile(t + 3);
+    const int i0 = t * kTile;
+    float x[16];
+    if (MODE == 0) {
+      const float* Lt = reinterpret_cast<const float*>(meta + (t % D) * kAccMeta);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Lt + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pv = __expf(xv[r] - l4[e]);
+          x[r] = (i0 + crow(r, h) < M) ? pv : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        x[r] = (jvalid && i0 + crow(r, h) < M) ? xv[r] : 0.f;
+        if (CS) csum += x[r];
+      }
+    }
+    mma_tr_x_acc(st, lo, h, x, acc);
+    // all but this iteration's 16 map loads and 3 tile pieces have landed: the next tile's map values, the
+    // tiles t+1 and t+2, the meta slots up to t+3
+    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  float xa[16], xb[16], xc[16];
+  load_x(0, xa);
+  load_x(1, xb);
+  for (int t = 0; t < mtiles; t += 3) {
+    iter(t, xa, xc);
+    if (t + 1 < mtiles) iter(t + 1, xb, xa);
+    if (t + 2 < mtiles) iter(t + 2, xc, xb);
+  }
+  if (MODE == 1 && CS) {
+    const float ctot = csum + wave_xor32(csum);
+    if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
+  }
+  if (jvalid) {
+    float* orow = a.out + (long)b * a.o_bs + (long)j * a.o_rs + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
+      }
+    }
+  }
+}
+
 }  // namespace samble
 
 extern "C" void samble_time_begin(int, hipStream_t);
@@ -372,11 +526,18 @@ extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 extern int g_stats_ablate;
 
+int g_bwd_tri_dsmap = 1;  // 1: dQ kernel writes dS, dV / dK accumulate from the maps; 0: fused dP/dV/dK kernel
+extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_tri_mode(int use_ds_map) { g_bwd_tri_dsmap = use_ds_map; }
+
+extern "C" size_t samble_bwd_tri_dsmap_bytes(int B, int N, int M) {
+  return (size_t)B * M * (32 * ((N + 8 + 31) / 32)) * sizeof(float);
+}
+
 extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse_s, const float* delta, const void* dO_rm,
                                      const void* dO_tr, const void* Q_tr, const void* V_rm, const void* K_tr,
                                      const long long* idx, int B, int N, int nt, int M, float scale, float* dQ, long dq_bs,
                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                     float* cs, hipStream_t stream) {
+                                     float* cs, float* dsmap, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipSuccess;
@@ -385,26 +546,42 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
       if (e != hipSuccess) return (int)e;
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
-    if (e != hipSuccess) return (int)e;
+    for (const void* f : {reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<false>), reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<true>)}) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
+      if (e != hipSuccess) return (int)e;
+    }
+    for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_tri_kernel<0, false>), reinterpret_cast<const void*>(bwd_kacc_tri_kernel<1, false>),
+                          reinterpret_cast<const void*>(bwd_kacc_tri_kernel<1, true>)}) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_set = true;
   }
-  const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
-                     idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};
-  samble_time_begin(3, stream);
-  if (cs) hipLaunchKernelGGL(bwd_dkdv_tri_kernel<true>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
-  else hipLaunchKernelGGL(bwd_dkdv_tri_kernel<false>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
-  samble_time_end(3, stream);
+  const bool use_map = g_bwd_tri_dsmap && dsmap;
   const DqTriArgs dq{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)V_rm, (const char*)K_tr, idx, N, N + nt, M,
-                     scale, dQ, dq_bs, dq_rs};
-  samble_time_begin(6, stream);
+                     scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
   auto dqk = g_stats_ablate == 21 ? bwd_dq_tri_kernel<1> : g_stats_ablate == 22 ? bwd_dq_tri_kernel<2>
            : g_stats_ablate == 23 ? bwd_dq_tri_kernel<3> : bwd_dq_tri_kernel<0>;
+  samble_time_begin(6, stream);
   hipLaunchKernelGGL(dqk, dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
   samble_time_end(6, stream);
+  if (use_map) {
+    const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr};
+    const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs};
+    samble_time_begin(3, stream);
+    hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+    samble_time_end(3, stream);
+    samble_time_begin(7, stream);
+    if (cs) hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, true>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
+    else hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
+    samble_time_end(7, stream);
+  } else {
+    const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
+                       idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};
+    samble_time_begin(3, stream);
+    if (cs) hipLaunchKernelGGL(bwd_dkdv_tri_kernel<true>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
+    else hipLaunchKernelGGL(bwd_dkdv_tri_kernel<false>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
+    samble_time_end(3, stream);
+  }
   return (int)hipGetLastError();
 }
