@@ -20,7 +20,8 @@ extern "C" void samble_time_end(int, hipStream_t);
 namespace samble {
 
 constexpr int kCapT = 32;  // ring slots per lane (power of two); a tile adds at most 16
-int g_knn_tri_steps = 48;  // 1..4: fixed insertion steps per tile; >= 8: step budget (tile t gets budget / (t + 1)); 101.. = ablations
+int g_knn_tri_steps = 205;  // 1..4: fixed insertion steps per tile; 8..99: step budget (tile t gets budget / (t + 1));
+                            // 101..: timing ablations; >= 200: per-wave drain down to (value - 200) entries [default]
 int g_knn_tri = 1;         // 0: use the fp32-MFMA stream kernel
 
 // channel-major fp32 (B, 128, N) -> RM operand image of the points (rows = points, contraction = channels)
@@ -53,9 +54,11 @@ __device__ __forceinline__ double pack_wj_t(float w, unsigned int j) {
 }
 
 // ABL (timing-only ablations, wrong results): 1 = no matrix products, 2 = no insertions
-// STEPS > 0: that many insertion steps per tile; STEPS == 0: budget / (t + 1) steps in tile t (at least 1, at
-// most 32) -- a new key enters a K-list that has seen n keys with probability ~K/n, so the candidates per
-// tile fall like 1/t; the ring smooths the bursts and the overflow vote catches the rest
+// STEPS > 0: that many insertion steps per tile.  STEPS == 0, budget >= 200 (default): every tile each WAVE
+// inserts until its fullest ring holds at most budget - 200 entries (lanes insert in lockstep, so a step is
+// well used only while most lanes have a candidate: measured optimum 4-6 left over; a workgroup-wide
+// drain loop or a fixed per-tile count both cost ~10 %).  STEPS == 0, budget < 200: budget / (t + 1) steps
+// in tile t (a new key enters a K-list that has seen n keys with probability ~K/n).
 template <int KN, int STEPS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict__ Qimg, int Nq,
                                                          const char* __restrict__ Kimg, int Nk,
@@ -152,8 +155,13 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
 #pragma unroll
           for (int s = 0; s < STEPS; ++s) insert_step();
         } else {
-          const int n = max(min(budget / (t + 1), 32), 1);
-          for (int s = 0; s < n; ++s) insert_step();
+          if (budget >= 200) {  // adaptive: this wave inserts until its fullest ring is down to budget - 200 entries
+            const int keep = budget - 200;
+            while (__any(tail - head > keep)) insert_step();
+          } else {
+            const int n = max(min(budget / (t + 1), 32), 1);
+            for (int s = 0; s < n; ++s) insert_step();
+          }
         }
         update_cut();
       }

@@ -31,7 +31,7 @@ for rep in range(2):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print("fp32 knn %.1f us" % (dt * 1e6))
 # ragged sizes and cross sets
-lib.samble_knn_tri_config(1, 24)
+lib.samble_knn_tri_config(1, 205)
 for (Nq, Nk) in ((1000, 1000), (333, 1500), (96, 64)):
     a = torch.randn(2, C, Nq, generator=torch.Generator().manual_seed(Nq)).to(dev)
     bb = a if Nq == Nk else torch.randn(2, C, Nk, generator=torch.Generator().manual_seed(Nk)).to(dev)
