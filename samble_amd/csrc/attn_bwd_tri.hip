@@ -391,9 +391,10 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
 // transposed image tile (24 KB, ring of 4 by LDS-DMA, three tiles ahead) and 16 map values per lane,
 // fetched one tile ahead.  48 MFMAs per tile and wave, 64 accumulator registers.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAccDepth = 4;
-constexpr int kAccMeta = 512;  // per slot: lse[32] twice (MODE 0), idx[32] (int64) at +256
-constexpr int kAccLds = kAccDepth * kTriTile + kAccDepth * kAccMeta;
+constexpr int kAccMapSlots = 3, kAccTrSlots = 2, kAccMetaSlots = 4;
+constexpr int kAccMap = 32 * 256 * 4;  // 32 sampled rows x the workgroup's 256 keys, fp32
+constexpr int kAccMeta = 512;          // per slot: lse[32] twice (MODE 0), idx[32] (int64) at +256
+constexpr int kAccLds = kAccTrSlots * kTriTile + kAccMapSlots * kAccMap + kAccMetaSlots * kAccMeta;
 
 struct KaccArgs {
   const float* map;    // MODE 0: smap (B, N, ld);  MODE 1: dsmap (B, M, ld)
@@ -407,10 +408,14 @@ struct KaccArgs {
   float* cs;           // MODE 1, optional (B, N + nt)
 };
 
+// The map block of a tile (32 rows x 256 keys = 32 pieces of 1 KB, each one contiguous kilobyte of a map
+// row) comes by LDS-DMA two tiles ahead, the image tile one tile ahead (it is shared by the cloud's
+// workgroups: L2).  Every operation of the loop is a DMA piece, all waits are counted: per iteration a
+// thread issues 3 image pieces, (MODE 0) 2 meta pieces, then 4 map pieces -- `vmcnt(4)` at the end
+// leaves exactly the next-but-one map block in flight.
 template <int MODE, bool CS>
 __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  constexpr int D = kAccDepth;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
@@ -418,89 +423,84 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
   const int N = a.N, M = a.M, ld = a.ld;
   const int j = chunk * 256 + wave * 32 + lo;
   const bool jvalid = j < N;
-  const int jc = min(j, N - 1);
   const int mtiles = (M + kTile - 1) / kTile;
   const char* Tb = a.tr + (long)b * mtiles * kTriTile;
-  char* meta = smem_c + D * kTriTile;
-  const float* mapb = a.map + (long)b * (MODE == 0 ? N : M) * ld + jc;
+  char* mapring = smem_c + kAccTrSlots * kTriTile;
+  char* meta = mapring + kAccMapSlots * kAccMap;
+  // this lane's 16 bytes of a 1 KB row piece; past the row's end the piece is pulled back inside it (those
+  // keys are >= N: masked below)
+  const float* mapb = a.map + (long)b * (MODE == 0 ? N : M) * ld + min(chunk * 256 + lane * 4, ld - 4);
 
-  auto stage_tile = [&](int t) {  // 3 DMA pieces per thread
+  auto stage_tr = [&](int t) {  // 3 pieces per thread
     const int tt = min(t, mtiles - 1);
-    char* st = smem_c + (t % D) * kTriTile;
+    char* st = smem_c + (t % kAccTrSlots) * kTriTile;
 #pragma unroll
     for (int k = 0; k < 3; ++k) glds16(Tb + (long)tt * kTriTile + (tid + 512 * k) * 16, st + (wave * 64 + 512 * k) * 16);
   };
   auto stage_meta = [&](int t) {  // MODE 0 only: 2 pieces per thread, the eight waves write the same bytes
     const int i0 = min(t, mtiles - 1) * 32;
-    char* ms = meta + (t % D) * kAccMeta;
-    glds4(a.lse_s + (long)b * M + min(i0 + lo, M - 1), ms);  // lanes 32..63 repeat lanes 0..31: slot floats 0..63
-    glds4(reinterpret_cast<const int*>(a.idx + (long)b * M + min(i0 + (lane >> 1), M - 1)) + (lane & 1), ms + 128 + 128);
+    char* ms = meta + (t % kAccMetaSlots) * kAccMeta;
+    glds4(a.lse_s + (long)b * M + min(i0 + lo, M - 1), ms);  // lanes 32..63 repeat lanes 0..31
+    glds4(reinterpret_cast<const int*>(a.idx + (long)b * M + min(i0 + (lane >> 1), M - 1)) + (lane & 1), ms + 256);
   };
-  // this lane's 16 map values of tile t: rows = the tile's sampled rows crow(r, h), column = its key
-  auto load_x = [&](int t, float (&dst)[16]) {
-    if (MODE == 0) {
-      const long long* sel = reinterpret_cast<const long long*>(meta + (t % D) * kAccMeta + 256);
+  auto stage_map = [&](int t) {  // 4 pieces per thread: wave w brings rows 4w .. 4w+3 of the tile
+    const int tt = min(t, mtiles - 1);
+    char* ms = mapring + (t % kAccMapSlots) * kAccMap;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = mapb[sel[crow(r, h)] * ld];
-    } else {
-      const int i0 = min(t, mtiles - 1) * kTile;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = mapb[(long)min(i0 + crow(r, h), M - 1) * ld];
+    for (int q = 0; q < 4; ++q) {
+      const int i = 4 * wave + q;
+      long row;
+      if (MODE == 0) row = reinterpret_cast<const long long*>(meta + (tt % kAccMetaSlots) * kAccMeta + 256)[i];
+      else row = min(tt * 32 + i, M - 1);
+      glds16(mapb + row * ld, ms + i * 1024);
     }
   };
   if (MODE == 0) {
     stage_meta(0);
     stage_meta(1);
     stage_meta(2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
-  stage_tile(0);
-  stage_tile(1);
-  stage_tile(2);
+  stage_tr(0);
+  stage_map(0);
+  stage_map(1);
   f32x16 acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
   float csum = 0.f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  // The map values are requested TWO tiles ahead (three register sets in rotation: one iteration is
-  // shorter than an HBM round trip under load; one tile ahead the loop ran at the load latency).
-  auto iter = [&](int t, const float (&xv)[16], float (&xfill)[16]) {
-    const char* st = smem_c + (t % D) * kTriTile;
-    if (MODE == 0) stage_meta(t + 3);  // older than this iteration's 19 youngest operations: landed at the end of it
-    load_x(t + 2, xfill);
-    stage_tile(t + 3);
+
+  for (int t = 0; t < mtiles; ++t) {
+    const char* st = smem_c + (t % kAccTrSlots) * kTriTile;
+    stage_tr(t + 1);                     // slot of tile t-1
+    if (MODE == 0) stage_meta(t + 3);    // slot of tile t-1; needed by stage_map(t + 3) in the next iteration
+    stage_map(t + 2);                    // slot of tile t-1; the 4 youngest operations
+    const float* mp = reinterpret_cast<const float*>(mapring + (t % kAccMapSlots) * kAccMap) + wave * 32 + lo;
     const int i0 = t * kTile;
     float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = mp[crow(r, h) * 256];
     if (MODE == 0) {
-      const float* Lt = reinterpret_cast<const float*>(meta + (t % D) * kAccMeta);
+      const float* Lt = reinterpret_cast<const float*>(meta + (t % kAccMetaSlots) * kAccMeta);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(Lt + 8 * g + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pv = __expf(xv[r] - l4[e]);
+          const float pv = __expf(x[r] - l4[e]);
           x[r] = (i0 + crow(r, h) < M) ? pv : 0.f;
         }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        x[r] = (jvalid && i0 + crow(r, h) < M) ? xv[r] : 0.f;
+        x[r] = (jvalid && i0 + crow(r, h) < M) ? x[r] : 0.f;
         if (CS) csum += x[r];
       }
     }
     mma_tr_x_acc(st, lo, h, x, acc);
-    // all but this iteration's 16 map loads and 3 tile pieces have landed: the next tile's map values, the
-    // tiles t+1 and t+2, the meta slots up to t+3
-    asm volatile("s_waitcnt vmcnt(19) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  float xa[16], xb[16], xc[16];
-  load_x(0, xa);
-  load_x(1, xb);
-  for (int t = 0; t < mtiles; t += 3) {
-    iter(t, xa, xc);
-    if (t + 1 < mtiles) iter(t + 1, xb, xa);
-    if (t + 2 < mtiles) iter(t + 2, xc, xb);
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   if (MODE == 1 && CS) {
     const float ctot = csum + wave_xor32(csum);
