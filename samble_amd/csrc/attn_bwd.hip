@@ -574,7 +574,8 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
 }
 
 extern "C" size_t samble_tri_image_size(int, int, int);
-extern "C" int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
+extern "C" int samble_launch_tri_split2(const float*, const float*, long, long, int, int, void*, void*, void*, void*,
+                                        hipStream_t);
 extern "C" int samble_launch_bwd_tri(const float*, int, const float*, const float*, const void*, const void*, const void*,
                                      const void*, const void*, const long long*, int, int, int, int, float, float*, long,
                                      long, float*, long, long, float*, long, long, float*, float*, hipStream_t);
@@ -624,8 +625,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     char* dO_tr = dO_rm + img;
     char* Q_tr = dO_tr + img;
     float* dsmap = reinterpret_cast<float*>(Q_tr + img);  // (B, M, ld) after the three images
-    int rc = samble_launch_tri_split(dOb, (long)M * 128, 128, B, M, dO_rm, dO_tr, stream);
-    if (!rc) rc = samble_launch_tri_split(Qs, (long)M * 128, 128, B, M, nullptr, Q_tr, stream);
+    int rc = samble_launch_tri_split2(dOb, Qs, (long)M * 128, 128, B, M, dO_rm, dO_tr, nullptr, Q_tr, stream);
     if (!rc)
       rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M, scale,
                                  dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr, dsmap, stream);
