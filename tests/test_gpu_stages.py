@@ -633,3 +633,36 @@ def test_knn_split_bf16_kernel_agrees_with_the_fp32_kernel(Nq, Nk, K):
     want = d.topk(K, dim=-1, largest=False)[1]
     assert set_agreement(got.cpu(), want.cpu()) >= 0.9995
     assert bool((dist[:, :, 1:] >= dist[:, :, :-1]).all()), "nearest first"
+
+
+def test_split_bf16_backward_variants_agree():
+    """dS-map backward (4 products per tile, default) vs the fused dP/dV/dK kernel (5 products, no dS map):
+    same gradients up to summation order."""
+    from samble_amd import _lib
+    lib = _lib.load()
+    B, N, nt, M, D = 2, 1000, 6, 333, 128
+    q, k, v = _qkv(B, N, nt, 4321)
+    g = torch.from_numpy(synth.normal((B, D, M), 9)).to(DEV)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)]).to(DEV)
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    out = {}
+    try:
+        o_.MATRIX_MODE = "tri"
+        qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+        smap, lse, _ = o_.stage_attn_stats(qg, kg, N, nt)
+        x_ds = o_.stage_attn_rows(smap, lse, vg, idx, N, nt)
+        for use_map in (1, 0):
+            lib.samble_debug_bwd_tri_mode(use_map)
+            dq = torch.full((B, N, D), float("nan"), device=DEV)
+            dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
+            dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
+            o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx, g, N, nt, dq, dk, dv)
+            out[use_map] = (dq, dk, dv)
+    finally:
+        lib.samble_debug_bwd_tri_mode(1)
+        o_.MATRIX_MODE = old
+    for a, b2, name in zip(out[1], out[0], ("dq", "dk", "dv")):
+        assert torch.isfinite(a).all() and torch.isfinite(b2).all(), name
+        scale = float(a.abs().max())
+        assert float((a - b2).abs().max()) <= 2e-5 * scale + 1e-7, name
