@@ -666,3 +666,30 @@ def test_split_bf16_backward_variants_agree():
         assert torch.isfinite(a).all() and torch.isfinite(b2).all(), name
         scale = float(a.abs().max())
         assert float((a - b2).abs().max()) <= 2e-5 * scale + 1e-7, name
+
+
+@pytest.mark.parametrize("B,N,nt,M", [(1, 64, 0, 32), (3, 257, 0, 100), (5, 96, 2, 96), (2, 33, 6, 1), (9, 512, 6, 200)])
+def test_split_bf16_edge_shapes(B, N, nt, M, matrix_mode):
+    """No token keys, clouds smaller than a workgroup, a single sampled row, batch sizes that are not a
+    multiple of the 8 XCDs: forward + backward against fp64 autograd."""
+    D = 128
+    q, k, v = _qkv(B, N, nt, 7000 + N + nt)
+    g = torch.from_numpy(synth.normal((B, D, M), 70)).to(DEV)
+    idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)])
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = (qd @ kd.transpose(1, 2)) / math.sqrt(D)
+    rows = torch.gather(torch.softmax(s, -1) @ vd, 1, idx[..., None].expand(-1, -1, D))
+    rows.permute(0, 2, 1).backward(g.double().cpu())
+    o_ = ops()
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    smap, lse, _ = o_.stage_attn_stats(qg, kg, N, nt)
+    x_ds = o_.stage_attn_rows(smap, lse, vg, idx.to(DEV), N, nt)
+    torch.testing.assert_close(x_ds.cpu().double(), rows.detach().permute(0, 2, 1), rtol=2e-4, atol=2e-5)
+    dq = torch.full((B, N, D), float("nan"), device=DEV)
+    dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
+    o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx.to(DEV), g, N, nt, dq, dk, dv)
+    for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
+        assert torch.isfinite(got).all(), name
+        scale = ref.abs().max().item()
+        assert (got.cpu().double() - ref).abs().max().item() <= 3e-5 * scale + 1e-7, name
