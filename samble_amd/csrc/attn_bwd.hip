@@ -16,7 +16,7 @@
 //                   (S, dP, dV^T, dK^T = 4x64 MFMA per tile)
 //   bwd_tokens_reduce  fixed-order sum of those partials (token keys stay out of the MFMA grids,
 //                   which keeps them a whole number of rounds: N/32 key waves per cloud, not N/32 + 1)
-#include "samble_dev.h"
+#include "tri_dev.h"
 
 namespace samble {
 
@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
                                                        float* __restrict__ dO, float* __restrict__ lse_s,
                                                        float* __restrict__ delta, float* __restrict__ tok_part,
                                                        float* __restrict__ slab, int nslab, int tok_slab, int l2,
-                                                       float* __restrict__ cs_part) {
+                                                       float* __restrict__ cs_part, char* __restrict__ dO_rm,
+                                                       char* __restrict__ dO_tr, char* __restrict__ Q_tr) {
+  // dO_rm / dO_tr / Q_tr != null (split-bf16 backward): the operand images of this tile of 32 sampled rows
+  // are written from the LDS tiles right here, and the fp32 copies Qs / dO are not
   __shared__ float gt[128 * 33];
   __shared__ float red[4][2][8][128];  // [wave][dK|dV][token][channel]
   __shared__ float dred[8][32];
@@ -53,7 +56,37 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     if (Oc && m0 + mm < M) dpart = fmaf(gv, Oc[(long)b * 128 * M + (long)d * M + m0 + mm], dpart);
   }
   dred[tid >> 5][tid & 31] = dpart;
+  float* qt = &red[0][0][0][0];  // [channel][33]: the gathered Q rows, transposed (red is not in use before the end)
+  if (Q_tr)
+    for (int e = tid; e < 128 * 33; e += 256) qt[e] = 0.f;
   __syncthreads();
+  const int ntiles_m = gridDim.x;
+  if (dO_rm) {  // dO tile -> row image and transposed image (layouts: tri_dev.h), rows past M-1 are zeros in gt
+    char* irm = dO_rm + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    char* itr = dO_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      {
+        const int r = e & 31, gq = e >> 5;
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = gt[(8 * gq + i) * 33 + r];
+        const Tri t3 = tri_split8(x);
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 2)) = t3.l;
+      }
+      {
+        const int d = e & 127, cg = e >> 7;
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = gt[d * 33 + 16 * (cg >> 1) + 8 * (i >> 2) + 4 * (cg & 1) + (i & 3)];
+        const Tri t3 = tri_split8(x);
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 2)) = t3.l;
+      }
+    }
+  }
   const int sub = tid >> 5, l32 = tid & 31;  // 8 half-waves, each one row at a time
   // token keys / values: this lane's 4 channels of each of the nt (<= 8) rows
   f32x4 kt[8], vt[8], ak[8], av[8];
@@ -84,8 +117,13 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     const float lrow = lse[(long)b * N + row];
     f32x4 dv = {gt[(4 * l32 + 0) * 33 + rr], gt[(4 * l32 + 1) * 33 + rr], gt[(4 * l32 + 2) * 33 + rr],
                 gt[(4 * l32 + 3) * 33 + rr]};
-    *reinterpret_cast<f32x4*>(Qs + ((long)b * M + m) * 128 + 4 * l32) = qv;
-    *reinterpret_cast<f32x4*>(dO + ((long)b * M + m) * 128 + 4 * l32) = dv;
+    if (Q_tr) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qt[(4 * l32 + u) * 33 + rr] = qv[u];
+    } else {
+      *reinterpret_cast<f32x4*>(Qs + ((long)b * M + m) * 128 + 4 * l32) = qv;
+      *reinterpret_cast<f32x4*>(dO + ((long)b * M + m) * 128 + 4 * l32) = dv;
+    }
     float part = dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
@@ -131,6 +169,21 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__
     }
     if (slab)  // slab (b, tok_slab): the token keys' share of dQ
       *reinterpret_cast<f32x4*>(slab + (((long)b * nslab + tok_slab) * M + m) * 128 + 4 * l32) = dqt;
+  }
+  if (Q_tr) {  // the gathered Q tile -> transposed image, then the LDS region goes back to `red`
+    __syncthreads();
+    char* itr = Q_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int d = e & 127, cg = e >> 7;
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = qt[d * 33 + 16 * (cg >> 1) + 8 * (i >> 2) + 4 * (cg & 1) + (i & 3)];
+      const Tri t3 = tri_split8(x);
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = t3.h;
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = t3.m;
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 2)) = t3.l;
+    }
+    __syncthreads();
   }
   if (nt > 0) {
     // the two half-waves of a wave first (register exchange), then the 4 waves through LDS, in a
@@ -574,8 +627,6 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
 }
 
 extern "C" size_t samble_tri_image_size(int, int, int);
-extern "C" int samble_launch_tri_split2(const float*, const float*, long, long, int, int, void*, void*, void*, void*,
-                                        hipStream_t);
 extern "C" int samble_launch_bwd_tri(const float*, int, const float*, const float*, const void*, const void*, const void*,
                                      const void*, const void*, const long long*, int, int, int, int, float, float*, long,
                                      long, float*, long, long, float*, long, long, float*, float*, hipStream_t);
@@ -615,20 +666,20 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
+  // split-bf16 backward: images of the sampled rows (dO row + transposed, Q transposed, whole tiles of 32 rows),
+  // written by bwd_prep itself; then the dS map
+  const size_t img = tri ? samble_tri_image_size(B, M, 0) : 0;
+  char* dO_rm = tri ? (char*)img_ws : nullptr;
+  char* dO_tr = tri ? dO_rm + img : nullptr;
+  char* Q_tr = tri ? dO_tr + img : nullptr;
   hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
-                     fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr);
+                     fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr);
   if (tri) {
-    // images of the sampled rows: dO (row + transposed) and Q (transposed), whole tiles of 32 rows
-    const size_t img = samble_tri_image_size(B, M, 0);
-    char* dO_rm = (char*)img_ws;
-    char* dO_tr = dO_rm + img;
-    char* Q_tr = dO_tr + img;
     float* dsmap = reinterpret_cast<float*>(Q_tr + img);  // (B, M, ld) after the three images
-    int rc = samble_launch_tri_split2(dOb, Qs, (long)M * 128, 128, B, M, dO_rm, dO_tr, nullptr, Q_tr, stream);
-    if (!rc)
-      rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M, scale,
-                                 dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr, dsmap, stream);
+    const int rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M,
+                                         scale, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr,
+                                         dsmap, stream);
     if (rc) return rc;
   } else if (fused) {
     if (smap) {

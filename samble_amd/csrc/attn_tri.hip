@@ -12,18 +12,9 @@ namespace samble {
 // fp32 rows (B, R, 128) with strides -> RM and / or TR operand images, one workgroup per 32-row tile.
 // Rows >= R of the last tile are zeros.
 // ------------------------------------------------------------------------------------------------
-// blockIdx.z = 1 selects the second source / image pair (the backward splits dO and Q of the sampled rows in
-// one launch)
 __global__ __launch_bounds__(256) void tri_split_kernel(const float* __restrict__ src, long bs, long rs, int R,
-                                                        char* __restrict__ rm, char* __restrict__ tr,
-                                                        const float* __restrict__ src2, char* __restrict__ rm2,
-                                                        char* __restrict__ tr2) {
+                                                        char* __restrict__ rm, char* __restrict__ tr) {
   const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x, tid = threadIdx.x;
-  if (blockIdx.z == 1) {
-    src = src2;
-    rm = rm2;
-    tr = tr2;
-  }
   const float* sb = src + (long)b * bs;
   if (rm) {
     char* img = rm + ((long)b * ntiles + tile) * kTriTile;
@@ -413,17 +404,10 @@ extern "C" size_t samble_tri_image_size(int B, int rows, int transposed) {
 extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
                                        hipStream_t stream) {
   hipLaunchKernelGGL(tri_split_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, stream, src, bs, rs, rows, (char*)rm,
-                     (char*)tr, nullptr, nullptr, nullptr);
+                     (char*)tr);
   return (int)hipGetLastError();
 }
 
-// two matrices of the same shape and strides in one launch
-extern "C" int samble_launch_tri_split2(const float* src, const float* src2, long bs, long rs, int B, int rows, void* rm,
-                                        void* tr, void* rm2, void* tr2, hipStream_t stream) {
-  hipLaunchKernelGGL(tri_split_kernel, dim3((rows + 31) / 32, B, 2), dim3(256), 0, stream, src, bs, rs, rows, (char*)rm,
-                     (char*)tr, src2, (char*)rm2, (char*)tr2);
-  return (int)hipGetLastError();
-}
 
 extern "C" int samble_launch_attn_stats_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
                                             float* smap, int ld, float* lse, float* tok, const float* qn, const float* kn,
