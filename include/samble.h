@@ -86,6 +86,17 @@ int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const
 int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
                         int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
                         float* dtokens, void* ws, size_t ws_bytes, void* stream);
+/* The same two entries with the forward and dx on the bf16 matrix cores (fp32 operands split into three bf16
+ * planes, six products each, fp32 accumulation: see the "split fp32 operands" block below); dW stays fp32 MFMA.
+ * Same arguments; the workspaces also hold an operand image of W. */
+size_t samble_proj_fwd_tri_workspace_bytes(void);
+int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
+                            const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* ws, size_t ws_bytes,
+                            void* stream);
+size_t samble_proj_bwd_tri_workspace_bytes(int B, int N);
+int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
+                            int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
+                            float* dtokens, void* ws, size_t ws_bytes, void* stream);
 
 /* Debug hook for timing ablations (tools/ablate_*.py): which = 0 selects attn_fwd, mode 1..3 a
  * timing-only build (wrong outputs), 0 the real kernel.  Process-wide; not for production use. */

@@ -34,6 +34,13 @@ _SIGNATURES = {
     "samble_proj_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
                                     c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
+    "samble_proj_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "samble_proj_bwd_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
+                                    c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_void_p]),
+    "samble_proj_fwd_tri_workspace_bytes": (c_size_t, []),
+    "samble_proj_bwd_tri_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_attn_colsum_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int, c_int,

@@ -39,11 +39,12 @@ int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const flo
 int samble_launch_group_gather(const float*, const int*, int, int, int, int, int, float*, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
-int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*,
+size_t samble_proj_tri_image_bytes();
+int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*, void*,
                            hipStream_t);
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
-                           float*, long, float*, float*, float*, hipStream_t);
+                           float*, long, float*, float*, float*, void*, hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
@@ -544,8 +545,27 @@ SAMBLE_API int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, i
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: bad B/N/nt");
   if ((o_rs & 3) || (o_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: output strides must be multiples of 4");
   if (ws_bytes < 8 * 384 * sizeof(float)) return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_f32: workspace too small");
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, (hipStream_t)stream),
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr,
+                                     (hipStream_t)stream),
               "samble_proj_fwd_f32");
+}
+
+/* the same projection on the bf16 matrix cores with split fp32 operands: the workspace also holds W's image */
+SAMBLE_API size_t samble_proj_fwd_tri_workspace_bytes(void) { return 8 * 384 * sizeof(float) + 256 + samble_proj_tri_image_bytes(); }
+
+SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
+                                       const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!x || !W || !qkv || !ws || (nt > 0 && !tokens)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_tri_f32: null pointer");
+  if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_tri_f32: C = D must be 128");
+  if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_tri_f32: bad B/N/nt");
+  if ((o_rs & 3) || (o_bs & 3))
+    return fail(SAMBLE_E_INVALID, "samble_proj_fwd_tri_f32: output strides must be multiples of 4");
+  if (ws_bytes < samble_proj_fwd_tri_workspace_bytes())
+    return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_tri_f32: workspace too small");
+  char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, (hipStream_t)stream),
+              "samble_proj_fwd_tri_f32");
 }
 
 SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
@@ -558,9 +578,31 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
   if ((g_rs & 3) || (g_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: strides must be multiples of 4");
   if (ws_bytes < samble_proj_bwd_ws_floats(B, N) * sizeof(float))
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_f32: workspace too small");
-  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws,
+  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, nullptr,
                                      (hipStream_t)stream),
               "samble_proj_bwd_f32");
+}
+
+/* the same backward with dx on the bf16 matrix cores (split fp32 operands); the workspace also holds W's transposed image */
+SAMBLE_API size_t samble_proj_bwd_tri_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return ((samble_proj_bwd_ws_floats(B, N) * sizeof(float) + 255) & ~(size_t)255) + samble_proj_tri_image_bytes();
+}
+
+SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
+                                       int C, int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs,
+                                       float* dW, float* dtokens, void* ws, size_t ws_bytes, void* stream) {
+  if (!dqkv || !x || !W || !ws) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: null pointer");
+  if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: C = D must be 128");
+  if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: bad B/N/nt");
+  if (dW && nt > 0 && (!dtokens || !tokens)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: dtokens/tokens missing");
+  if ((g_rs & 3) || (g_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: strides must be multiples of 4");
+  if (ws_bytes < samble_proj_bwd_tri_workspace_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_tri_f32: workspace too small");
+  char* wtr = (char*)ws + ((samble_proj_bwd_ws_floats(B, N) * sizeof(float) + 255) & ~(size_t)255);
+  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, wtr,
+                                     (hipStream_t)stream),
+              "samble_proj_bwd_tri_f32");
 }
 
 SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN,

@@ -312,11 +312,18 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
 
 using namespace samble;
 
+extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, int, const float*, void*, float*, long,
+                                          long, hipStream_t);
+extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, float*, long, hipStream_t);
+
+// wimg != null: room for the row image of W -> the split-bf16 kernel (proj_tri.hip)
 extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, const float* tokens, int nt,
-                                      const float* W, float* qkv, long o_bs, long o_rs, float* ws, hipStream_t s) {
+                                      const float* W, float* qkv, long o_bs, long o_rs, float* ws, void* wimg,
+                                      hipStream_t s) {
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
   if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 8), dim3(64), 0, s, tokens, nt, W, tokqkv);
+  if (wimg) return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, s);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
@@ -336,7 +343,7 @@ extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
 
 extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
                                       const float* tokens, int nt, const float* W, float* dx, long dx_bs, float* dW,
-                                      float* dtok, float* ws, hipStream_t s) {
+                                      float* dtok, float* ws, void* wtr, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds_dx = kDxLdsFloats * sizeof(float), lds_dw = kDwLdsFloats * sizeof(float);
   if (!attr_set) {
@@ -351,7 +358,12 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   const int chunks = (N + kDwPts - 1) / kDwPts;
   float* part = ws;
   float* gsum = ws + (size_t)B * chunks * kO * kC;  // 8 x 384
-  if (dx) hipLaunchKernelGGL(proj_dx_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dx, s, dqkv, g_bs, g_rs, W, N, dx, dx_bs);
+  if (dx && wtr) {  // room for the transposed image of W -> the split-bf16 kernel
+    const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr, B, N, dx, dx_bs, s);
+    if (rc) return rc;
+  } else if (dx) {
+    hipLaunchKernelGGL(proj_dx_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dx, s, dqkv, g_bs, g_rs, W, N, dx, dx_bs);
+  }
   if (dW) {
     hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     if (nt > 0)

@@ -1,0 +1,191 @@
+// QKV projection forward and its input gradient on the bf16 matrix cores with split fp32 operands
+// (tri_dev.h); same results contract as proj_fwd_kernel / proj_dx_kernel of proj.hip (fp32-equivalent
+// products, other rounding).  dW stays on the fp32 MFMA kernel (its contraction runs over the points: both
+// operands would have to be transposed on the fly).
+//
+//   forward   qkv[n][o] = sum_c W[o][c] x[c][n]      A: W row image tile (32 outputs, LDS ring), B: the point's
+//                                                    128 channels, read channel-major and split in registers
+//   dx        dx[c][n]  = sum_o W[o][c] dqkv[n][o]   A: W transposed image tile (32 outputs = the contraction
+//                                                    rows), B: 16 outputs of the point's gradient row per k-step,
+//                                                    read in the image's element order and split in registers
+// One workgroup = 8 waves = 256 points, two waves per SIMD; the 12 W tiles (295 KB as an image) stream through
+// a ring of 4 LDS slots by LDS-DMA, three tiles ahead, every wait counted.
+#include "tri_dev.h"
+
+namespace samble {
+
+constexpr int kPO = 384, kPTiles = kPO / 32, kPDepth = 4;
+constexpr int kProjTriLds = kPDepth * kTriTile;
+
+__device__ __forceinline__ void pglds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int N,
+                                                              const float* __restrict__ tokqkv, int nt,
+                                                              const char* __restrict__ Wimg,  // row image of W (384 rows)
+                                                              float* __restrict__ qkv, long o_bs, long o_rs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kPDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  // points past N-1 are clamped: those lanes recompute and rewrite point N-1's row bit for bit (no predicated store)
+  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  auto stage = [&](int t) {
+    const char* gt = Wimg + (long)min(t, kPTiles - 1) * kTriTile;
+    char* lt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pglds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) stage(t);
+  if (chunk == 0) {  // this cloud's copy of the token rows
+    for (int e = tid; e < nt * kPO; e += 512) qkv[(long)b * o_bs + (long)(N + e / kPO) * o_rs + (e % kPO)] = tokqkv[e];
+  }
+  u32x4 xq[24];  // this point's channels as the B operand: k-step ks, half h <-> channels 16 ks + 8 h + e
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[(long)b * x_bs + (long)(16 * ks + 8 * h + e) * N + n];
+    const Tri t3 = tri_split8(v);
+    xq[3 * ks] = t3.h;
+    xq[3 * ks + 1] = t3.m;
+    xq[3 * ks + 2] = t3.l;
+  }
+  float* orow = qkv + (long)b * o_bs + (long)n * o_rs + 4 * h;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // iteration t: tile t+3 into the slot of tile t-1, product of tile t, its 4 row stores; VM operations
+  // younger than tile t+1's DMA at the end of the iteration: stores(t-2) 4 + 2 x (3 + 4) = 18
+  for (int t = 0; t < kPTiles; ++t) {
+    stage(t + D - 1);
+    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
+    f32x16 acc = zero16();  // D[row = output 32 t + crow(r, h)][col = point]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
+      const Tri bq = {xq[3 * ks], xq[3 * ks + 1], xq[3 * ks + 2]};
+      acc = mfma_tri(a, bq, acc);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
+    }
+    asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
+                                                             const char* __restrict__ Wtr,  // transposed image of W
+                                                             int N, float* __restrict__ dx, long dx_bs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kPDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int n = min(blockIdx.x * 256 + wave * 32 + lo, N - 1);
+  const float* grow = dqkv + (long)b * g_bs + (long)n * g_rs + 4 * h;
+  auto stage = [&](int t) {
+    const char* gt = Wtr + (long)min(t, kPTiles - 1) * kTriTile;
+    char* lt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pglds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+  };
+  // this lane's 16 gradient values of tile t in the transposed image's element order:
+  // k-step s, element e <-> output 32 t + 16 s + 8 (e >> 2) + 4 h + (e & 3)
+  auto load_g = [&](int t, f32x4 (&dst)[4]) {
+    const float* p = grow + min(t, kPTiles - 1) * 32;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      dst[2 * s] = *reinterpret_cast<const f32x4*>(p + 16 * s);
+      dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(p + 16 * s + 8);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) stage(t);
+  f32x16 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
+  f32x4 gc[4], gn[4];
+  load_g(0, gc);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  for (int t = 0; t < kPTiles; ++t) {
+    load_g(t + 1, gn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    stage(t + D - 1);
+    const char* wt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float v[8] = {gc[2 * ks][0], gc[2 * ks][1], gc[2 * ks][2], gc[2 * ks][3],
+                          gc[2 * ks + 1][0], gc[2 * ks + 1][1], gc[2 * ks + 1][2], gc[2 * ks + 1][3]};
+      const Tri bg = tri_split8(v);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const char* ap = wt + tri_tr_off(32 * ct + lo, 2 * ks + h, 0);
+        const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                       *reinterpret_cast<const u32x4*>(ap + 4096)};
+        acc[ct] = mfma_tri(a, bg, acc[ct]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gc[i] = gn[i];
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // rows past N-1 hold point N-1's column again: same values to the same address
+  float* ob = dx + (long)b * dx_bs + n;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
+                                       hipStream_t stream);
+
+// image bytes of W (384 x 128), either kind
+extern "C" size_t samble_proj_tri_image_bytes() { return (size_t)kPTiles * kTriTile; }
+
+extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokqkv, int nt,
+                                          const float* W, void* wimg, float* qkv, long o_bs, long o_rs, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kProjTriLds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, wimg, nullptr, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(proj_fwd_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, x, x_bs, N, tokqkv, nt,
+                     (const char*)wimg, qkv, o_bs, o_rs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int B, int N,
+                                         float* dx, long dx_bs, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, nullptr, wtr, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(proj_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, dqkv, g_bs, g_rs,
+                     (const char*)wtr, N, dx, dx_bs);
+  return (int)hipGetLastError();
+}

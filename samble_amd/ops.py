@@ -72,10 +72,12 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor) -
     nt = tokens.shape[1]
     with torch.cuda.device(x.device):
         qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)
-        nbytes = 8 * 384 * 4
+        tri = MATRIX_MODE == "tri"
+        nbytes = _lib.query("samble_proj_fwd_tri_workspace_bytes") if tri else 8 * 384 * 4
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        _lib.call("samble_proj_fwd_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
-                  qkv.data_ptr(), qkv.stride(0), qkv.stride(1), ws.data_ptr(), nbytes, _stream())
+        _lib.call("samble_proj_fwd_tri_f32" if tri else "samble_proj_fwd_f32", x.data_ptr(), C * N, B, C, N,
+                  tokens.data_ptr(), nt, w_qkv.data_ptr(), qkv.data_ptr(), qkv.stride(0), qkv.stride(1), ws.data_ptr(),
+                  nbytes, _stream())
     return qkv
 
 
@@ -91,9 +93,10 @@ def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
         dx = torch.empty_like(x) if need_dx else None
         dw = torch.empty_like(w_qkv) if need_dw else None
         dtok = torch.empty_like(tokens) if need_dw else None
-        nbytes = _lib.query("samble_proj_workspace_bytes", B, N)
+        tri = MATRIX_MODE == "tri"
+        nbytes = _lib.query("samble_proj_bwd_tri_workspace_bytes" if tri else "samble_proj_workspace_bytes", B, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        _lib.call("samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
+        _lib.call("samble_proj_bwd_tri_f32" if tri else "samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
                   tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
                   _stream())
     return dx, dw, dtok
