@@ -12,8 +12,18 @@ from tests.util import Golden, golden_names, set_agreement
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+@pytest.fixture(params=["tri", "f32"])
+def matrix_mode(request):
+    """Both matrix-instruction families (split-bf16 default, fp32 MFMA) behind the same module."""
+    from samble_amd import ops
+    old = ops.MATRIX_MODE
+    ops.MATRIX_MODE = request.param
+    yield request.param
+    ops.MATRIX_MODE = old
+
+
 @pytest.mark.parametrize("name", golden_names())
-def test_module_against_reference_fixture(name):
+def test_module_against_reference_fixture(name, matrix_mode):
     g = Golden(name)
     mod = g.module(DEV)
     for call in range(g.calls):
