@@ -293,6 +293,9 @@ def main():
                 out["peak_note"] = ("fp32 products as 6 bf16 MFMA products (3 bf16 planes per operand, fp32 accumulate): "
                                     "peak = dense bf16 2500 TFLOP/s / 6; executed bf16 flop = 6 x algorithmic")
                 out["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
+                # register-resident loop of the same 6-product scheme on random operands (tools/micro/split_mfma_bench.hip):
+                # 1771 TFLOP/s executed at the 1.69 GHz the chip holds under that load
+                out["frac_of_sustained_scheme_rate_295"] = round(ach / 295.0, 4)
             return out
 
         if tri:

@@ -99,6 +99,56 @@ __global__ __launch_bounds__(512) void rate_kernel(float* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Same loop on RANDOM operands (the chip lowers its clock under bf16 MFMA load on random data), for the two
+// bf16 shapes: 6 MFMAs of 32x32x16 (32 cycles each) vs 12 of 16x16x32 (16 cycles each) per iteration.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool SMALL>
+__global__ __launch_bounds__(512) void rate_random_kernel(const unsigned* seed, float* out, int iters) {
+  f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+  f32x4v acs[4] = {{0}, {0}, {0}, {0}};
+  bf16x8 a[4], b[4];
+  unsigned h = seed[threadIdx.x & 255] ^ (blockIdx.x * 2654435761u);
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 8; ++i) {
+      h = h * 1664525u + 1013904223u;
+      a[k][i] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+      h = h * 1664525u + 1013904223u;
+      b[k][i] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+    }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < (SMALL ? 12 : 6); ++m) {
+      if (SMALL) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acs[m & 3]) : "v"(a[m & 3]), "v"(b[(m + 1) & 3]));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(a[m & 3]), "v"(b[(m + 1) & 3]));
+    }
+  }
+  float s = 0;
+  for (int m = 0; m < 4; ++m) {
+    for (int i = 0; i < 16; ++i) s += acc[m][i];
+    for (int i = 0; i < 4; ++i) s += acs[m][i];
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <bool SMALL>
+void run_rate_random(const unsigned* seed, int waves_per_simd, float* out) {
+  const int iters = 200000;  // long enough for the clock governor to settle
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  dim3 grid(256), block(256 * waves_per_simd);
+  rate_random_kernel<SMALL><<<grid, block>>>(seed, out, 1000);
+  hipEventRecord(e0);
+  rate_random_kernel<SMALL><<<grid, block>>>(seed, out, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double flop = (double)iters * 6 * 32768.0 * 256 * 4 * waves_per_simd;  // both shapes: 6 x 32768 flop per iteration
+  const double cyc = (double)iters * 6 * 32;                                     // matrix-pipe cycles per wave
+  printf("random data, %s, waves/SIMD=%d: %.2f ms  %.0f TFLOP/s executed (%.0f fp32-equivalent at 6 products)  pipe clock >= %.2f GHz\n",
+         SMALL ? "16x16x32" : "32x32x16", waves_per_simd, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 6,
+         cyc * waves_per_simd / (ms * 1e-3) / 1e9);
+}
+
 template <bool F16, int NV, int NACC = 4>
 void run_rate(const char* name, int waves_per_simd, float* out) {
   const int iters = 20000;
@@ -189,6 +239,15 @@ int main() {
     run_rate<false, 8, 2>("bf16", w, out);
     run_rate<true, 0>("f16", w, out);
     run_rate<true, 6>("f16", w, out);
+  }
+  unsigned* seed;
+  hipMalloc(&seed, 256 * 4);
+  std::vector<unsigned> hs(256);
+  for (int i = 0; i < 256; ++i) hs[i] = (unsigned)rand() * 2654435761u + (unsigned)i;
+  hipMemcpy(seed, hs.data(), 256 * 4, hipMemcpyHostToDevice);
+  for (int w = 1; w <= 2; ++w) {
+    run_rate_random<false>(seed, w, out);
+    run_rate_random<true>(seed, w, out);
   }
   return 0;
 }
