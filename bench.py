@@ -4,7 +4,7 @@
 ModelNet40-shaped synthetic input, B=32 clouds per GPU, C=128, N=2048 -> M=1024, 6 bin tokens,
 K=32 feature-space kNN, sparse_col_sqr score, dynamic boundaries, Boltzmann-random selection.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU; batches shard over ranks (weak scaling, 32 clouds per rank); the only
@@ -14,6 +14,9 @@ gradient all-reduce (RCCL over xGMI).  Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -43,82 +46,67 @@ def algorithmic_flops_per_cloud():
     return dict(proj=proj, dist=dist_, qk=qk, av=av, fwd=proj + dist_ + qk + av, bwd=4 * av + 2 * proj)
 
 
-def time_region(fn, iters):
-    """Average milliseconds per call of fn(), HIP events on torch's current stream (the stream
-    every kernel of the path is enqueued on)."""
-    start = torch.cuda.Event(enable_timing=True)
-    stop = torch.cuda.Event(enable_timing=True)
-    fn()
-    torch.cuda.synchronize()
-    start.record()
-    for _ in range(iters):
-        fn()
-    stop.record()
-    stop.synchronize()
-    return start.elapsed_time(stop) / iters
+def algorithmic_bytes_per_cloud():
+    """SURVEY.md section 8(d) per-kernel algorithmic HBM bytes (fp32 inputs read once, outputs written once)."""
+    return dict(
+        knn=4 * N * C + 4 * N * KNN,                          # points in, neighbour lists out
+        select=4 * N + 4 * N * NB + 4 * NB + 8 * M,           # score, Exp(1) noise, boundaries in; idx out
+        sparse_score=8 * N * KNN + 4 * N + 12 * N,            # neighbour ids + one logit each, lse in; score, z, in-degree out
+        knn_prep=4 * N * C + 6 * N * C + 4 * N,               # points in; operand image (6 B / element) + norms out
+        tri_split=4 * 3 * C * (N + NB) + 5 * 6 * C * (N + NB),  # [Q|K|V] rows in; five operand images out
+        bwd_prep=8 * M + 8 * M * C + 3 * 6 * M * C,           # idx, Q rows, dO in; three operand images of the sampled rows out
+        fused_step=4 * N * C + 4 * M * C + 8 * M + 4 * M * C + 8 * N * C,  # ideal fused layer: x, x_ds, idx; g, dx(+x)
+    )
 
 
-# ids of the library's timing hook (samble_debug_time_kernel); both matrix modes use the same ids for the
-# kernels that play the same part (3 = dominant backward kernel: bwd_rows or bwd_dkdv_tri)
-KERNEL_IDS = {"attn_stats": 1, "attn_rows": 2, "bwd_rows": 3, "knn_stream": 4, "bwd_dq": 6, "bwd_dk": 7}
+# ------------------------------------------------------------------------------------------------
+# N > 1 without torch.distributed.run: start the ranks ourselves, BEFORE anything touches the GPU
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def kernel_ms(kernel, fn, iters=5):
-    """Mean duration (ms) of one named kernel inside fn(), from the library's own HIP events."""
-    from samble_amd import _lib
-    lib = _lib.load()
-    fn()
-    lib.samble_debug_time_kernel(KERNEL_IDS[kernel])
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    ms = float(lib.samble_debug_kernel_ms())
-    lib.samble_debug_time_kernel(0)
-    return ms
+def launch_ranks(n: int, argv) -> int:
+    """Parent of `python bench.py --gpus N` (N > 1, no RANK in the environment): one child process per
+    rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would.  The parent never
+    initialises the GPU (device_count() does not); rank 0's stdout is the JSON line."""
+    ndev = torch.cuda.device_count()
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if "--backend" not in " ".join(argv) and ndev < n:
+        # RCCL refuses two ranks on one device: on a box with fewer GPUs than ranks the ranks share GPUs over gloo
+        # (a functional check of the N > 1 path, flagged in the JSON line; never a scaling number)
+        argv = list(argv) + ["--backend", "gloo"]
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0:
+                rc = rc or code
+                for o in alive:  # a dead rank would leave the others waiting at the rendezvous / next collective
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
 
 
-def kernel_breakdown(mod, x, noise, g, iters=5):
-    """Per-stage device time (ms) of one step, each stage timed alone with events."""
-    import math
-    from samble_amd import ops
-    with torch.no_grad():
-        B = x.shape[0]
-        nt = mod.bin_tokens.shape[2]
-        w = torch.cat((mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight), 0).squeeze(-1)
-        tokm = mod.bin_tokens[0]
-        qkv = ops.stage_proj_fwd(x, tokm, w)
-        q, k, v = qkv[:, :N, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
-        out = {}
-        out["proj_fwd"] = time_region(lambda: ops.stage_proj_fwd(x, tokm, w), iters)
-        out["knn"] = time_region(lambda: ops.stage_knn(x, x, KNN), iters)
-        nn_idx = ops.stage_knn(x, x, KNN)
-        imgs = None
-        if ops.MATRIX_MODE == "tri":  # the module splits Q, K, V into operand images once per step
-            out["split_qkv"] = time_region(lambda: ops.stage_tri_split_qkv(qkv, N, for_backward=True), iters)
-            imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=True)
-        out["attn_stats"] = time_region(lambda: ops.stage_attn_stats(q, k, N, nt, images=imgs[:2] if imgs else None), iters)
-        smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, images=imgs[:2] if imgs else None)
-        out["sparse_score"] = time_region(lambda: ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr"), iters)
-        score, z, _ = ops.stage_sparse_score_map(smap, lse, nn_idx, "sparse_col_sqr")
-        out["batch_quantiles"] = time_region(lambda: ops.stage_batch_quantiles(z, NB), iters)
-        up, lo = mod.bin_boundaries
-        out["bin_assign"] = time_region(lambda: ops.stage_bin_assign(z, tok, up, lo, False), iters)
-        member, cap, w_pre, wts = ops.stage_bin_assign(z, tok, up, lo, False)
-        out["alloc_counts"] = time_region(lambda: ops.stage_alloc_counts(wts, cap, M), iters)
-        counts = ops.stage_alloc_counts(wts, cap, M)
-        out["bin_select"] = time_region(
-            lambda: ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise), iters)
-        idx = ops.stage_bin_select(score, z, member, counts, M, "random", 0.1, noise)
-        vimg = imgs[2] if imgs else None
-        out["attn_rows"] = time_region(lambda: ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg), iters)
-        x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=vimg)
-        dqkv = torch.empty_like(qkv)
-        out["attn_bwd"] = time_region(
-            lambda: ops.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, N, nt, dqkv[:, :N, :C],
-                                            dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:],
-                                            images=imgs[3:] if imgs else None), iters)
-        out["proj_bwd"] = time_region(lambda: ops.stage_proj_bwd(dqkv, x, tokm, w, True, True), iters)
-    return out
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(seed):
@@ -129,7 +117,7 @@ def cpu_baseline(seed):
     spec = O.SamplerSpec(M=M, K=KNN, C=C, num_bins=NB)
     wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
     st = O.SamplerState(*(torch.from_numpy(a) for a in (wq, wk, wv, tok)))
-    sample_b = 8
+    sample_b = B_PER_GPU
     x = torch.from_numpy(synth.features(sample_b, C, N, seed + 1))
     g = torch.from_numpy(synth.normal((sample_b, C, M), seed + 2))
     noise = torch.from_numpy(synth.exp1((sample_b * NB, N), seed + 3))
@@ -146,13 +134,18 @@ def cpu_baseline(seed):
             best = (dt, threads)
     cores = best[1]
     torch.set_num_threads(cores)
-    reps = 2
-    t0 = time.perf_counter()
+    reps = 3
+    O.sampler_grads(spec, st, x, g, noise)  # warm-up at the full batch (first-touch of the 2 x 538 MB maps)
+    times = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         O.sampler_grads(spec, st, x, g, noise)
-    dt = (time.perf_counter() - t0) / reps
-    return dict(value=round(sample_b / dt, 3), unit="clouds/s", cores=cores, kind="port",
-                sample=f"{reps} x fwd+bwd of {sample_b} clouds (N={N}->{M}), torch CPU oracle, {cores} threads")
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    return dict(value=round(sample_b / dt, 3), unit="clouds/s", cores=cores, kind="port", cpu=cpu_model(),
+                host_cpus=ncpu,
+                sample=f"median of {reps} x fwd+bwd of {sample_b} clouds (N={N}->{M}) after 1 warm-up, torch CPU oracle "
+                       f"(bit-identical restatement of the reference), {cores} threads")
 
 
 def main():
@@ -164,8 +157,12 @@ def main():
                     help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU smoke test of the N>1 path)")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     global B_PER_GPU, N, M
     if args.workload == "stress":
@@ -175,9 +172,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    local = local % max(torch.cuda.device_count(), 1)  # (gloo smoke test: ranks may share one GPU)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_gpus = world > ndev
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -187,7 +185,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from samble_amd import sampler_config, synth
+    from samble_amd import _lib, ops, sampler_config, synth
     from samble_amd.downsample import DownSampleToken
 
     seed = 1000 * 2
@@ -217,26 +215,28 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP events around every launch of the dominant kernel (bwd_rows) during the timed steps, recorded
-    # by the library on the stream it launches on (two event records per step: no host sync, no effect
-    # on the timed region); read back after the final synchronize
-    from samble_amd import _lib
-    lib = _lib.load()
-    from samble_amd import ops as _ops0
-    dominant = "knn_stream" if _ops0.MATRIX_MODE == "tri" else "bwd_rows"  # id 4 is knn_tri in the split-bf16 mode
-    lib.samble_debug_time_kernel(KERNEL_IDS[dominant])
+    tri = ops.MATRIX_MODE == "tri"
+    # HIP events around every launch of the dominant kernel during the timed steps, recorded by the
+    # library on the stream it launches on (two event records per step: no host sync); read back after
+    # the final synchronize
+    dominant = "knn" if tri else "bwd_rows_f32"
+    _lib.timing_select([dominant])
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    dominant_ms = float(lib.samble_debug_kernel_ms())
-    lib.samble_debug_time_kernel(0)
+    dom = _lib.timing_read(dominant)
+    _lib.timing_select([])
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -247,6 +247,7 @@ def main():
         total_clouds = B_PER_GPU * world * args.steps
         value = total_clouds / elapsed
         fl = algorithmic_flops_per_cloud()
+        by = algorithmic_bytes_per_cloud()
         result = {
             "metric": ("point-clouds/sec (downsample fwd+bwd), ModelNet40 B=32 N=2048->1024" if args.workload == "metric"
                        else "point-clouds/sec (downsample fwd+bwd), synthetic dense clouds B=16 N=8192->4096"),
@@ -256,6 +257,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(statistics.median(step_ms), 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -263,76 +265,121 @@ def main():
             "data": "synthetic (hash-generated N(0,1) features, random-init weights; no ModelNet40 files offline)",
             "config": {"workload": f"one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B={B_PER_GPU}/GPU C=128 N={N}->M={M} "
                                    "nb=6 K=32 sparse_col_sqr random T=0.1 dynamic boundaries",
-                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "backend": args.backend if world > 1 else None},
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
+                       "backend": (dist.get_backend() if world > 1 else None),
+                       "ranks": (dist.get_world_size() if world > 1 else 1),
+                       "visible_gpus": ndev},
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
-        # dominant kernel: bwd_rows (attention backward over the N point keys: dP, dV, dK, dQ = 4 products of
-        # 2*M*N*D flop per cloud); duration = mean over the timed steps' launches, HIP events on its stream
+        if shared_gpus:
+            result["note"] = (f"{world} ranks share {ndev} GPU(s) over {args.backend}: functional check of the N>1 path "
+                              "(DDP + boundary all-reduce), not a scaling measurement")
+
         def pmc_traffic(kernel):
             # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary
             # (profiles/*_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require)
             try:
                 import glob
-                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]))["kernels"]
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
+                pmc = json.load(open(path))["kernels"]
                 key = next(k for k in pmc if k == kernel or k.startswith(kernel + "<"))  # template arguments vary
-                return pmc[key]["traffic_bytes_per_launch"]
+                return pmc[key]["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
             except Exception:
-                return None
+                return None, None
 
-        from samble_amd import ops as _ops
-        tri = _ops.MATRIX_MODE == "tri"
         peak = PEAK_TRI_TFLOPS if tri else PEAK_FP32_MFMA_TFLOPS
 
         def roof(kernel, alg_flops, ms, pmc_name):
             ach = alg_flops / (ms * 1e-3) / 1e12
+            traffic, src = pmc_traffic(pmc_name)
             out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                   "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": pmc_traffic(pmc_name),
+                   "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                   "traffic_source": (f"{src} (rocprofv3 --pmc of an earlier run of this command, not measured in this run)"
+                                      if src else None),
                    "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops}
             if tri:
                 out["peak_note"] = ("fp32 products as 6 bf16 MFMA products (3 bf16 planes per operand, fp32 accumulate): "
                                     "peak = dense bf16 2500 TFLOP/s / 6; executed bf16 flop = 6 x algorithmic")
                 out["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
-                # register-resident loop of the same 6-product scheme on random operands (tools/micro/split_mfma_bench.hip):
-                # 1771 TFLOP/s executed at the 1.69 GHz the chip holds under that load
-                out["frac_of_sustained_scheme_rate_295"] = round(ach / 295.0, 4)
             return out
 
+        def hbm(kernel, alg_bytes, ms, pmc_name):
+            ach = alg_bytes / (ms * 1e-3) / 1e9
+            traffic, src = pmc_traffic(pmc_name)
+            return {"kernel": kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "traffic_source": (f"{src} (earlier rocprofv3 --pmc run)" if src else None),
+                    "us_per_launch": round(ms * 1e3, 1), "algorithmic_bytes_per_launch": alg_bytes}
+
+        dominant_ms = dom[0] if dom else float("nan")
         if tri:
             # dominant kernel: knn_tri (fused Gram + top-K of the feature-space kNN; algorithmic flops = the Gram)
             result["roofline"] = roof("knn_tri_kernel", fl["dist"] * B_PER_GPU, dominant_ms, "samble::knn_tri_kernel")
         else:
             bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
             result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
-        result["matrix_mode"] = _ops.MATRIX_MODE
+        result["roofline"]["launches_timed"] = dom[2] if dom else 0
+        result["matrix_mode"] = ops.MATRIX_MODE
         if not args.no_breakdown:
-            noise = torch.from_numpy(synth.exp1((B_PER_GPU * NB, N), seed + 3)).to(dev)
-            br = kernel_breakdown(mod, x, noise, g)
-            result["stage_ms"] = {k: round(v, 4) for k, v in br.items()}
-            # the other MFMA kernels, each timed the same way over 5 more full steps (same cache state as the timed region)
-            def in_step_ms(kernel):
-                lib.samble_debug_time_kernel(KERNEL_IDS[kernel])
-                for _ in range(5):
-                    step()
-                torch.cuda.synchronize()
-                ms = float(lib.samble_debug_kernel_ms())
-                lib.samble_debug_time_kernel(0)
-                return ms
+            # every other kernel of the step, timed the same way (library-side HIP events on the launch stream)
+            # over 5 further full steps: same cache state as the timed region
+            names = [n for n in _lib.TIMED_KERNELS if n != "attn_fwd"]
+            _lib.timing_select(names)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            kt = {n: _lib.timing_read(n) for n in names}
+            _lib.timing_select([])
+            result["kernel_us"] = {n: round(v[1] * 1e3, 1) for n, v in kt.items() if v}
             sfx = "_tri_kernel" if tri else "_kernel"
-            others = {
-                "attn_stats" + sfx: (fl["qk"] * B_PER_GPU, in_step_ms("attn_stats"), "samble::attn_stats" + sfx),
-                "attn_rows" + sfx: (fl["av"] * B_PER_GPU, in_step_ms("attn_rows"), "samble::attn_rows" + sfx),
-            }
+            mf = []
+            if kt.get("attn_stats"):
+                mf.append(roof("attn_stats" + sfx, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::attn_stats" + sfx))
+            if kt.get("attn_rows"):
+                mf.append(roof("attn_rows" + sfx, fl["av"] * B_PER_GPU, kt["attn_rows"][0], "samble::attn_rows" + sfx))
             if tri:
                 # backward: dQ kernel = dP + dQ (2 products over N + nt keys), then dV and dK (1 product each, N keys)
-                others["bwd_dq_tri_kernel"] = (2 * fl["av"] * B_PER_GPU, in_step_ms("bwd_dq"), "samble::bwd_dq_tri_kernel")
-                others["bwd_kacc_tri_kernel<0> (dV)"] = (2 * M * N * C * B_PER_GPU, in_step_ms("bwd_rows"),
-                                                        "samble::bwd_kacc_tri_kernel<0, false>")
-                others["bwd_kacc_tri_kernel<1> (dK)"] = (2 * M * N * C * B_PER_GPU, in_step_ms("bwd_dk"),
-                                                        "samble::bwd_kacc_tri_kernel<1, false>")
-            else:
-                others["knn_stream_kernel"] = (fl["dist"] * B_PER_GPU, in_step_ms("knn_stream"), "samble::knn_stream_kernel")
-            result["roofline_other_kernels"] = [roof(kk, a_, ms_, pn) for kk, (a_, ms_, pn) in others.items()]
+                if kt.get("bwd_dq"):
+                    mf.append(roof("bwd_dq_tri_kernel", 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::bwd_dq_tri_kernel"))
+                if kt.get("bwd_dv"):
+                    mf.append(roof("bwd_kacc_tri_kernel<0> (dV)", 2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
+                                   "samble::bwd_kacc_tri_kernel<0, false>"))
+                if kt.get("bwd_dk"):
+                    mf.append(roof("bwd_kacc_tri_kernel<1> (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
+                                   "samble::bwd_kacc_tri_kernel<1, false>"))
+            elif kt.get("knn"):
+                mf.append(roof("knn_stream_kernel", fl["dist"] * B_PER_GPU, kt["knn"][0], "samble::knn_stream_kernel"))
+            pj = 2 * C * C * 3 * N * B_PER_GPU
+            for n_, name, flops in (("proj_fwd", "proj_fwd" + sfx, pj), ("proj_dx", "proj_dx" + sfx, pj),
+                                    ("proj_dw", "proj_dw_kernel (+ reduce; fp32 MFMA)", pj)):
+                if kt.get(n_):
+                    r_ = roof(name, flops, kt[n_][0], "samble::" + name.split(" ")[0])
+                    if n_ == "proj_dw":
+                        r_["peak"], r_["frac"] = PEAK_FP32_MFMA_TFLOPS, round(r_["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
+                        r_.pop("peak_note", None)
+                    mf.append(r_)
+            result["roofline_other_kernels"] = mf
+            # HBM-bound kernels: algorithmic bytes / launch duration against 8 TB/s
+            hb = []
+            if kt.get("sparse_score"):
+                hb.append(hbm("sparse_score_map + finalize_score", by["sparse_score"] * B_PER_GPU, kt["sparse_score"][0],
+                              "samble::sparse_score_map_kernel"))
+            sel = [kt.get(n_) for n_ in ("quantiles", "bin_assign", "alloc_counts", "bin_select")]
+            if all(sel):
+                hb.append(hbm("select chain (quantiles + bin_assign + alloc_counts + bin_select)",
+                              by["select"] * B_PER_GPU, sum(v[0] for v in sel), "samble::bin_select_kernel"))
+            for n_, label, key in (("knn_prep", "cloud_mean + tri_split_cm (kNN operand image + norms)", "knn_prep"),
+                                   ("tri_split", "tri_split_qkv (operand images of Q, K, V)", "tri_split"),
+                                   ("bwd_prep", "bwd_prep (gather of the sampled rows + their operand images)", "bwd_prep")):
+                if kt.get(n_):
+                    hb.append(hbm(label, by[key] * B_PER_GPU, kt[n_][0], "samble::" + label.split(" ")[0]))
+            if kt.get("knn"):
+                hb.append(hbm("knn (SURVEY 8d per-kernel bytes; compute-bound by construction)", by["knn"] * B_PER_GPU,
+                              kt["knn"][0], "samble::knn_tri_kernel"))
+            hb.append(hbm("whole step vs the ideal fused layer's bytes (4.20 MB/cloud)", by["fused_step"] * B_PER_GPU,
+                          ms_per_step, "-"))
+            result["roofline_hbm_kernels"] = hb
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(seed)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)

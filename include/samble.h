@@ -59,20 +59,17 @@ const char* samble_last_error(void);
  * their permute(0,2,1)).  idx_out (B,Nq,K) int32, nearest first, self included when xq == xk.
  * dist_out (B,Nq,K) or NULL: POSITIVE distance of the reference-normalised points (centred on
  * xq's mean, divided by the mean unbiased per-channel std), i.e. -1 * the reference's first
- * return value.  K in {1,3,8,16,20,32,40,64}. */
-size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K);
+ * return value.  K in {1,3,8,16,20,32,40,64}.
+ * variant (stateless kernel choice, same results contract): 0 = the default for the shape (C = 128,
+ * K in {16,32}: fused Gram + top-K on the bf16 matrix cores with split fp32 operands, points centred
+ * on xq's mean as the reference does; C = 64: fused fp32-MFMA kernel; C <= 8: exact sum (a-b)^2 on
+ * the vector ALU); SAMBLE_KNN_FP32_MFMA = fused fp32-MFMA kernel also for C = 128;
+ * SAMBLE_KNN_TWO_KERNEL = key matrix through HBM + row select (what every other shape falls back to). */
+#define SAMBLE_KNN_FP32_MFMA 1
+#define SAMBLE_KNN_TWO_KERNEL 2
+size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K, int variant);
 int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C, int K,
-                   int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream);
-
-/* Debug / A-B hook: non-zero forces the two-kernel kNN path (key matrix through HBM) instead of the
- * fused Gram + top-K kernel.  Process-wide; not for production use. */
-void samble_knn_force_unfused(int on);
-/* debug / A-B switch of the feature-space kNN (C = 128): enabled 1 = bf16 matrix cores on split fp32
- * operands (default), 0 = fp32 MFMA kernel; insert_steps > 0 sets the insertion steps per key tile */
-void samble_knn_tri_config(int enabled, int insert_steps);
-/* A-B switch of the split-bf16 backward: 1 (default) = dQ kernel writes a dS map and dV / dK accumulate from
- * the maps (4 products per tile), 0 = fused dP / dV / dK kernel (5 products, no dS map) */
-void samble_debug_bwd_tri_mode(int use_ds_map);
+                   int variant, int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- models/downsample.py:116-137  q_conv / k_conv / v_conv (bias-free 1x1 Conv1d) ------------
  * x (B,C,N) channel-major, tokens (C,nt) = bin_tokens[0], W (3C,C) row-major = [Wq; Wk; Wv]
@@ -97,10 +94,6 @@ size_t samble_proj_bwd_tri_workspace_bytes(int B, int N);
 int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
                             int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
                             float* dtokens, void* ws, size_t ws_bytes, void* stream);
-
-/* Debug hook for timing ablations (tools/ablate_*.py): which = 0 selects attn_fwd, mode 1..3 a
- * timing-only build (wrong outputs), 0 the real kernel.  Process-wide; not for production use. */
-void samble_debug_ablate(int which, int mode);
 
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
@@ -239,19 +232,13 @@ int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, cons
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows
  * 0..N+nt-1, each with its own strides. */
 size_t samble_attn_bwd_workspace_bytes(int B, int N, int M, int D);
-/* debug / A-B hook: non-zero selects the two-kernel backward (7 MFMA products) instead of the fused one (5) */
-void samble_debug_bwd_split(int on);
-/* measurement hook (bench.py): record HIP events around the launches of one kernel, on the stream it
- * is launched on.  id: 0 off, 1 attn_stats, 2 attn_rows, 3 bwd_rows, 4 knn_stream, 5 attn_fwd (single
- * pass).  samble_debug_kernel_ms() waits for the timed launches (the last 64 at most) and returns
- * their mean duration, -1 if none was recorded.  Not thread-safe; for benchmarks only. */
-int samble_debug_time_kernel(int id);
-float samble_debug_kernel_ms(void);
+/* variant (stateless kernel choice, same results): 0 = fused kernel (5 matrix products per tile),
+ * 1 = two kernels, dQ query-stationary + dK/dV key-stationary (7 products) */
 int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                         const float* V, int64_t v_bs, int64_t v_rs, const float* O, const float* lse,
                         const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,
                         int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
-                        int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes, void* stream);
+                        int64_t dv_bs, int64_t dv_rs, int variant, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- two-pass forward with the logit map kept in HBM (same reference lines as samble_attn_fwd_f32) ---
  * In exact fp32 on MI355X reloading a logit (4 bytes) is ~3x cheaper than recomputing it (2*D flop),
@@ -301,9 +288,11 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  *                            the two images the backward wants: transposed K, row V
  *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows)
  *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows)
- *   samble_attn_rows_bwd_tri_f32 = samble_attn_rows_bwd_f32 (same outputs, same ds_colsum contract) as two
- *                            kernels, dK/dV key-stationary and dQ query-stationary, 5 products per tile, no dQ
- *                            slabs; workspace: samble_attn_rows_bwd_tri_workspace_bytes */
+ *   samble_attn_rows_bwd_tri_f32 = samble_attn_rows_bwd_f32 (same outputs, same ds_colsum contract).  variant 0:
+ *                            query-stationary dQ kernel that also writes a dS map, then dV and dK accumulated
+ *                            key-stationary from the two maps (4 products per tile, no dQ slabs); variant 1: fused
+ *                            dP / dV / dK kernel (5 products, no dS map).  Workspace:
+ *                            samble_attn_rows_bwd_tri_workspace_bytes */
 size_t samble_tri_image_bytes(int B, int rows, int transposed);
 int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
                          void* tr_image, void* stream);
@@ -319,9 +308,39 @@ int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, con
                                  const void* v_rm_image, const float* smap, int ld, const float* lse, const float* x_ds,
                                  const int64_t* idx, const float* g, int B, int N, int nt, int M, int D, float* dQ,
                                  int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
-                                 int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
+                                 int64_t dv_bs, int64_t dv_rs, float* ds_colsum, int variant, void* ws, size_t ws_bytes,
+                                 void* stream);
 int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, const void* v_tr_image,
                                  const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds, void* stream);
+
+/* ---- measurement hook (bench.py; the only entry points that are not part of the path) ------------------
+ * The library records HIP events around its own launches of the selected kernels, on the stream each is
+ * launched on.  samble_timing_select(mask): bit SAMBLE_T_x set = time kernel x (0 = off; resets the samples);
+ * samble_timing_read(id, ...) waits for that kernel's recorded launches (the last 32 at most) and returns
+ * their mean / median duration in ms and how many launches were seen.  Process-wide, not thread-safe, no
+ * effect on results; nothing on the data path reads it. */
+#define SAMBLE_T_ATTN_STATS 1   /* attn_stats(_tri): QK^T + softmax statistics over all rows */
+#define SAMBLE_T_ATTN_ROWS 2    /* attn_rows(_tri): P V of the sampled rows */
+#define SAMBLE_T_BWD_DV 3       /* bwd_kacc_tri<0> (dV) */
+#define SAMBLE_T_KNN 4          /* knn_tri / knn_stream: fused Gram + top-K */
+#define SAMBLE_T_ATTN_FWD 5     /* attn_fwd: single-pass flash forward */
+#define SAMBLE_T_BWD_DQ 6       /* bwd_dq_tri (dP, dS map, dQ) */
+#define SAMBLE_T_BWD_DK 7       /* bwd_kacc_tri<1> (dK) */
+#define SAMBLE_T_PROJ_FWD 8
+#define SAMBLE_T_PROJ_DX 9
+#define SAMBLE_T_PROJ_DW 10
+#define SAMBLE_T_TRI_SPLIT 11   /* operand images of Q, K, V */
+#define SAMBLE_T_KNN_PREP 12    /* cloud means + centred operand image + norms of the points */
+#define SAMBLE_T_SPARSE_SCORE 13
+#define SAMBLE_T_QUANTILES 14
+#define SAMBLE_T_BIN_ASSIGN 15
+#define SAMBLE_T_ALLOC_COUNTS 16
+#define SAMBLE_T_BIN_SELECT 17
+#define SAMBLE_T_BWD_PREP 18
+#define SAMBLE_T_GATHER 19
+#define SAMBLE_T_BWD_ROWS_F32 22 /* bwd_rows (fp32-MFMA backward over the key blocks) */
+int samble_timing_select(uint64_t kernel_mask);
+int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsamble_hip.so")
@@ -21,12 +21,8 @@ class SambleError(RuntimeError):
 _SIGNATURES = {
     "samble_version": (c_char_p, []),
     "samble_last_error": (c_char_p, []),
-    "samble_knn_force_unfused": (None, [c_int]),
-    "samble_knn_tri_config": (None, [c_int, c_int]),
-    "samble_debug_bwd_tri_mode": (None, [c_int]),
-    "samble_debug_ablate": (None, [c_int, c_int]),
-    "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+    "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_proj_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_proj_fwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
@@ -68,11 +64,10 @@ _SIGNATURES = {
                                         c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_segment_sum_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "samble_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "samble_debug_bwd_split": (None, [c_int]),
     "samble_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
-                                    c_void_p, c_size_t, c_void_p]),
+                                    c_int, c_void_p, c_size_t, c_void_p]),
     "samble_edge_partial_count": (c_int, []),
     "samble_edge_gather_sums_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_edge_mlp_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
@@ -81,8 +76,8 @@ _SIGNATURES = {
                                         c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_group_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_fps_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "samble_debug_time_kernel": (c_int, [c_int]),
-    "samble_debug_kernel_ms": (c_float, []),
+    "samble_timing_select": (c_int, [c_uint64]),
+    "samble_timing_read": (c_int, [c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int)]),
     "samble_attn_map_row_stride": (c_int, [c_int, c_int]),
     "samble_tri_image_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_tri_split_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -92,8 +87,8 @@ _SIGNATURES = {
     "samble_attn_rows_bwd_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                              c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64,
-                                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
-                                             c_size_t, c_void_p]),
+                                             c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int,
+                                             c_void_p, c_size_t, c_void_p]),
     "samble_attn_rows_fwd_tri_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p, c_void_p]),
     "samble_attn_stats_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
@@ -149,3 +144,28 @@ def call(name: str, *args) -> None:
 
 def query(name: str, *args) -> int:
     return int(getattr(load(), name)(*args))
+
+
+# ids of the measurement hook (include/samble.h SAMBLE_T_*)
+TIMED_KERNELS = {
+    "attn_stats": 1, "attn_rows": 2, "bwd_dv": 3, "knn": 4, "attn_fwd": 5, "bwd_dq": 6, "bwd_dk": 7, "proj_fwd": 8,
+    "proj_dx": 9, "proj_dw": 10, "tri_split": 11, "knn_prep": 12, "sparse_score": 13, "quantiles": 14, "bin_assign": 15,
+    "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22,
+}
+
+
+def timing_select(names) -> None:
+    """Record HIP events around the library's launches of the named kernels (empty = off)."""
+    mask = 0
+    for n in names:
+        mask |= 1 << TIMED_KERNELS[n]
+    call("samble_timing_select", mask)
+
+
+def timing_read(name):
+    """(mean ms, median ms, launches seen) of one selected kernel; None if it never ran."""
+    mean, med, cnt = c_float(), c_float(), c_int()
+    rc = load().samble_timing_read(TIMED_KERNELS[name], ctypes.byref(mean), ctypes.byref(med), ctypes.byref(cnt))
+    if rc != 0:
+        return None
+    return float(mean.value), float(med.value), int(cnt.value)

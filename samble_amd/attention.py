@@ -41,6 +41,7 @@ def _attention_from_projection(qkv, nn_idx, heads: int, diff: bool):
 
 class _N2PCore(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, wq, wk, wv, K, heads, diff):
         C = x.shape[1]
         w = torch.cat((wq, wk, wv), dim=0).reshape(3 * C, C)
@@ -53,6 +54,7 @@ class _N2PCore(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         x, w, qkv, nn_idx = ctx.saved_tensors
         heads, diff, a, b = ctx.cfg
@@ -135,6 +137,7 @@ class _P2PCore(torch.autograd.Function):
     kernels of the sampler (no N x N tensor), backward over all N rows."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, qkv):
         B, N, D3 = qkv.shape
         D = D3 // 3
@@ -144,6 +147,7 @@ class _P2PCore(torch.autograd.Function):
         return O.permute(0, 2, 1).contiguous()
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         qkv, O, lse = ctx.saved_tensors
         B, N, D3 = qkv.shape

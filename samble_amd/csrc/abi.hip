@@ -10,8 +10,8 @@
 
 // kernel launchers (one per .hip file)
 extern "C" {
-size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K);
-int samble_launch_knn(const float*, long, int, const float*, long, int, int, int, int, int*, float*, float*, hipStream_t);
+size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K, int variant);
+int samble_launch_knn(const float*, long, int, const float*, long, int, int, int, int, int, int*, float*, float*, hipStream_t);
 int samble_launch_attn_fwd(const float*, long, long, const float*, long, long, const float*, long, long, int, int, int,
                            float, float*, float*, float*, int, float*, hipStream_t);
 int samble_launch_attn_colsum(const float*, long, long, const float*, long, long, const float*, int, int, float, float*,
@@ -54,7 +54,7 @@ int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, i
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
-                           long, float*, long, long, int, float*, float*, const void*, const void*, void*, hipStream_t);
+                           long, float*, long, long, int, float*, float*, const void*, const void*, void*, int, hipStream_t);
 int samble_attn_map_ld(int N, int nt);
 size_t samble_tri_image_size(int, int, int);
 size_t samble_bwd_tri_dsmap_bytes(int, int, int);
@@ -98,62 +98,83 @@ int done(int hip_code, const char* where) {
 float inv_sqrt_d(int D) { return (float)(1.0 / sqrt((double)D)); }
 }  // namespace
 
-// ---- measurement hook: HIP events around the launches of ONE chosen kernel, on the stream it is
-// launched on; up to kTimeSlots launches are kept (round robin), samble_debug_kernel_ms averages them
-constexpr int kTimeSlots = 64;
-static int g_time_id = 0;
-static hipEvent_t g_time_ev[kTimeSlots][2];
-static bool g_time_have_events = false;
-static int g_time_count = 0;
+// ---- measurement hook (the only entry points that are not part of the path): HIP events around the
+// library's own launches of the SELECTED kernels, on the stream each is launched on.  Kernel ids are
+// listed in include/samble.h (SAMBLE_T_*).  Up to kTimeSlots launches per kernel are kept (round robin).
+// Process-wide and not thread-safe by design: a benchmark selects, runs its steps, then reads.
+constexpr int kTimeSlots = 32;
+constexpr int kTimeIds = 48;
+static unsigned long long g_time_mask = 0;
+static hipEvent_t g_time_ev[kTimeIds][kTimeSlots][2];
+static bool g_time_have[kTimeIds];
+static int g_time_count[kTimeIds];
 extern "C" void samble_time_begin(int id, hipStream_t s) {
-  if (id == g_time_id && g_time_have_events) (void)hipEventRecord(g_time_ev[g_time_count % kTimeSlots][0], s);
+  if ((g_time_mask >> id) & 1ull) (void)hipEventRecord(g_time_ev[id][g_time_count[id] % kTimeSlots][0], s);
 }
 extern "C" void samble_time_end(int id, hipStream_t s) {
-  if (id == g_time_id && g_time_have_events) {
-    (void)hipEventRecord(g_time_ev[g_time_count % kTimeSlots][1], s);
-    ++g_time_count;
+  if ((g_time_mask >> id) & 1ull) {
+    (void)hipEventRecord(g_time_ev[id][g_time_count[id] % kTimeSlots][1], s);
+    ++g_time_count[id];
   }
 }
-SAMBLE_API int samble_debug_time_kernel(int id) {
-  if (id && !g_time_have_events) {
+SAMBLE_API int samble_timing_select(uint64_t kernel_mask) {
+  g_time_mask = 0;
+  for (int id = 1; id < kTimeIds; ++id) {
+    g_time_count[id] = 0;
+    if (!((kernel_mask >> id) & 1ull) || g_time_have[id]) continue;
     for (int i = 0; i < kTimeSlots; ++i)
       for (int k = 0; k < 2; ++k)
-        if (hipEventCreate(&g_time_ev[i][k]) != hipSuccess)
-          return fail(SAMBLE_E_INVALID, "samble_debug_time_kernel: cannot create events");
-    g_time_have_events = true;
+        if (hipEventCreate(&g_time_ev[id][i][k]) != hipSuccess)
+          return fail(SAMBLE_E_INVALID, "samble_timing_select: cannot create events");
+    g_time_have[id] = true;
   }
-  g_time_id = id;
-  g_time_count = 0;
+  g_time_mask = kernel_mask & ~1ull & ((1ull << kTimeIds) - 1);
   return SAMBLE_OK;
 }
-SAMBLE_API float samble_debug_kernel_ms(void) {
-  const int n = g_time_count < kTimeSlots ? g_time_count : kTimeSlots;
-  if (n == 0) return -1.f;
+SAMBLE_API int samble_timing_read(int id, float* mean_ms, float* median_ms, int* launches) {
+  if (id < 1 || id >= kTimeIds) return fail(SAMBLE_E_INVALID, "samble_timing_read: unknown kernel id");
+  const int seen = g_time_count[id];
+  const int n = seen < kTimeSlots ? seen : kTimeSlots;
+  if (launches) *launches = seen;
+  if (n == 0) return fail(SAMBLE_E_INVALID, "samble_timing_read: no launch of that kernel was recorded");
+  float ms[kTimeSlots];
   double total = 0.0;
   for (int i = 0; i < n; ++i) {
-    float ms = 0.f;
-    if (hipEventSynchronize(g_time_ev[i][1]) != hipSuccess) return -1.f;
-    if (hipEventElapsedTime(&ms, g_time_ev[i][0], g_time_ev[i][1]) != hipSuccess) return -1.f;
-    total += ms;
+    if (hipEventSynchronize(g_time_ev[id][i][1]) != hipSuccess ||
+        hipEventElapsedTime(&ms[i], g_time_ev[id][i][0], g_time_ev[id][i][1]) != hipSuccess)
+      return fail(SAMBLE_E_INVALID, "samble_timing_read: event query failed");
+    total += ms[i];
   }
-  return (float)(total / n);
+  for (int i = 1; i < n; ++i)  // insertion sort of <= 32 samples
+    for (int j = i; j > 0 && ms[j] < ms[j - 1]; --j) {
+      const float t = ms[j];
+      ms[j] = ms[j - 1];
+      ms[j - 1] = t;
+    }
+  if (mean_ms) *mean_ms = (float)(total / n);
+  if (median_ms) *median_ms = (n & 1) ? ms[n / 2] : 0.5f * (ms[n / 2 - 1] + ms[n / 2]);
+  return SAMBLE_OK;
 }
 
 SAMBLE_API const char* samble_version(void) { return "samble-hip 0.1 (gfx950)"; }
 SAMBLE_API const char* samble_last_error(void) { return g_err; }
 
-SAMBLE_API size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K) {
-  return samble_knn_ws_floats(B, C, Nq, Nk, K) * sizeof(float);
+SAMBLE_API size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K, int variant) {
+  return samble_knn_ws_floats(B, C, Nq, Nk, K, variant) * sizeof(float);
 }
 
 SAMBLE_API int samble_knn_f32(const float* xq, int64_t q_bs, int Nq, const float* xk, int64_t k_bs, int Nk, int B, int C,
-                              int K, int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes, void* stream) {
+                              int K, int variant, int32_t* idx_out, float* dist_out, void* ws, size_t ws_bytes,
+                              void* stream) {
   if (!xq || !xk || !idx_out || !ws) return fail(SAMBLE_E_INVALID, "samble_knn_f32: null pointer");
   if (B <= 0 || C <= 0 || Nq <= 0 || Nk <= 0 || K <= 0 || K > Nk)
     return fail(SAMBLE_E_INVALID, "samble_knn_f32: need B,C,Nq,Nk > 0 and 0 < K <= Nk");
-  if (ws_bytes < samble_knn_workspace_bytes(B, C, Nq, Nk, K))
+  if (variant < 0 || variant > (SAMBLE_KNN_FP32_MFMA | SAMBLE_KNN_TWO_KERNEL))
+    return fail(SAMBLE_E_INVALID, "samble_knn_f32: unknown variant bits");
+  if (ws_bytes < samble_knn_workspace_bytes(B, C, Nq, Nk, K, variant))
     return fail(SAMBLE_E_WORKSPACE, "samble_knn_f32: workspace too small (samble_knn_workspace_bytes)");
-  int rc = samble_launch_knn(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, idx_out, dist_out, (float*)ws, (hipStream_t)stream);
+  int rc = samble_launch_knn(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, variant, idx_out, dist_out, (float*)ws,
+                             (hipStream_t)stream);
   if (rc == -22) return fail(SAMBLE_E_INVALID, "samble_knn_f32: K must be one of 1,3,8,16,20,32,40,64");
   return done(rc, "samble_knn_f32");
 }
@@ -337,11 +358,15 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
                            const float* smap, int ld, const float* lse, const int64_t* idx, const float* g, int B, int N,
                            int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
                            int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
-                           void* stream, int l2 = 0, float* cs = nullptr, const void* k_tr_image = nullptr,
-                           const void* v_rm_image = nullptr) {
+                           void* stream, int variant = 0, int l2 = 0, float* cs = nullptr,
+                           const void* k_tr_image = nullptr, const void* v_rm_image = nullptr) {
   char msg[160];
   if (!Q || !K || !V || (!O && !Oc) || !lse || !idx || !g || !dQ || !dK || !dV || !ws) {
     snprintf(msg, sizeof msg, "%s: null pointer", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (variant < 0 || variant > 1) {
+    snprintf(msg, sizeof msg, "%s: unknown variant", who);
     return fail(SAMBLE_E_INVALID, msg);
   }
   if (D != 128 || nt < 0 || nt > 8 || B <= 0 || N <= 0 || M <= 0) {
@@ -379,7 +404,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
                                      (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
                                      slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part,
-                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, s),
+                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, variant, s),
               who);
 }
 
@@ -387,11 +412,11 @@ SAMBLE_API int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, c
                                    int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* O,
                                    const float* lse, const int64_t* idx, const float* g, int B, int N, int nt, int M,
                                    int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs,
-                                   int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, void* ws, size_t ws_bytes,
-                                   void* stream) {
+                                   int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs, int variant, void* ws,
+                                   size_t ws_bytes, void* stream) {
   return attn_bwd_common("samble_attn_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, nullptr, nullptr, 0, lse,
                          idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
-                         stream);
+                         stream, variant);
 }
 
 SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
@@ -403,7 +428,7 @@ SAMBLE_API int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_
   if (!smap || !x_ds) return fail(SAMBLE_E_INVALID, "samble_attn_rows_bwd_f32: null pointer");
   return attn_bwd_common("samble_attn_rows_bwd_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap, ld,
                          lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws, ws_bytes,
-                         stream, ds_colsum ? 1 : 0, ds_colsum);
+                         stream, 0, ds_colsum ? 1 : 0, ds_colsum);
 }
 
 SAMBLE_API size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D) {
@@ -417,12 +442,12 @@ SAMBLE_API int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_
                                             const float* lse, const float* x_ds, const int64_t* idx, const float* g, int B,
                                             int N, int nt, int M, int D, float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK,
                                             int64_t dk_bs, int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs,
-                                            float* ds_colsum, void* ws, size_t ws_bytes, void* stream) {
+                                            float* ds_colsum, int variant, void* ws, size_t ws_bytes, void* stream) {
   if (!smap || !x_ds || !k_tr_image || !v_rm_image)
     return fail(SAMBLE_E_INVALID, "samble_attn_rows_bwd_tri_f32: null pointer");
   return attn_bwd_common("samble_attn_rows_bwd_tri_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap,
                          ld, lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws,
-                         ws_bytes, stream, ds_colsum ? 1 : 0, ds_colsum, k_tr_image, v_rm_image);
+                         ws_bytes, stream, variant, ds_colsum ? 1 : 0, ds_colsum, k_tr_image, v_rm_image);
 }
 
 SAMBLE_API int samble_attn_map_row_stride(int N, int nt) { return samble_attn_map_ld(N, nt); }

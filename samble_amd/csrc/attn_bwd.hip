@@ -619,9 +619,6 @@ extern "C" int samble_launch_bwd_rows(const float*, const float*, const float*, 
                                       const float*, long, long, int, int, int, float, float*, long, long, float*, long,
                                       long, float*, int, const float*, int, const long long*, float*, int, hipStream_t);
 
-static int g_bwd_split = 0;  // debug: 1 = the two-kernel backward (bwd_dq + bwd_dkdv) for A/B checks
-extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_split(int on) { g_bwd_split = on; }
-
 extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
   return (size_t)B * ((N + 127) / 128 + 1) * M * 128;
 }
@@ -629,7 +626,7 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
 extern "C" size_t samble_tri_image_size(int, int, int);
 extern "C" int samble_launch_bwd_tri(const float*, int, const float*, const float*, const void*, const void*, const void*,
                                      const void*, const void*, const long long*, int, int, int, int, float, float*, long,
-                                     long, float*, long, long, float*, long, long, float*, float*, hipStream_t);
+                                     long, float*, long, long, float*, long, long, float*, float*, int, hipStream_t);
 
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, const float* O, const float* Oc,
@@ -638,15 +635,16 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                                       float* lse_s, float* delta, float* tok_part, float* slab, float* dQ, long dq_bs,
                                       long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
                                       int l2, float* cs, float* cs_part, const void* k_tr_image, const void* v_rm_image,
-                                      void* img_ws, hipStream_t stream) {
+                                      void* img_ws, int variant, hipStream_t stream) {
+  // variant (include/samble.h): single-pass path: 1 = the two-kernel backward (bwd_dq + bwd_dkdv, 7 products)
+  // instead of the fused one (5); split-bf16 map path: 1 = fused dP / dV / dK kernel instead of the dS map
   // k_tr_image / v_rm_image / img_ws != null (map path only): the split-bf16 kernels of attn_bwd_tri.hip
   // l2 != 0 (map path only): token logits are -|q-k|^2 and cs (B, N+nt) receives the column sums of dS
   // O (B,N,128) rows of the single-pass forward, or Oc (B,128,M) = x_ds of attn_rows; smap (B,N,ld) =
   // the logit map of attn_stats (then S is read, not recomputed) or null
-  static bool attr_set = false;
   const size_t lds_dq = kDqLdsFloats * sizeof(float), lds_dkv = kDkvLdsFloats * sizeof(float);
   const size_t lds_fused = kFusedLdsFloats * sizeof(float);
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_kernel<kDqWaves>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
     if (e != hipSuccess) return (int)e;
@@ -656,13 +654,12 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int NK = N + nt;
   const int nparts = (M + 31) / 32;
   const int kb = (N + 127) / 128;
   const bool tri = smap && k_tr_image && v_rm_image && img_ws;
-  const bool fused = (!g_bwd_split || smap) && !tri;
+  const bool fused = (!(variant & 1) || smap) && !tri;
   float* tok_slab = (fused && nt > 0) ? slab + (size_t)kb * M * 128 : nullptr;  // per cloud: slab index kb
   // (the token slab of cloud b sits at slab + (b * (kb + 1) + kb) * M * 128: pass the base, prep adds b * M * 128
   //  only, so give it a view with the cloud stride folded in below)
@@ -672,14 +669,17 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   char* dO_rm = tri ? (char*)img_ws : nullptr;
   char* dO_tr = tri ? dO_rm + img : nullptr;
   char* Q_tr = tri ? dO_tr + img : nullptr;
-  hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
+  {
+    Timed timed(kT_bwd_prep, stream);
+    hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
                      fused ? kb + 1 : 0, kb, l2, l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr);
+  }
   if (tri) {
     float* dsmap = reinterpret_cast<float*>(Q_tr + img);  // (B, M, ld) after the three images
     const int rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M,
                                          scale, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr,
-                                         dsmap, stream);
+                                         dsmap, variant & 1, stream);
     if (rc) return rc;
   } else if (fused) {
     if (smap) {

@@ -521,13 +521,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
 
 }  // namespace samble
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
-extern int g_stats_ablate;
-
-int g_bwd_tri_dsmap = 1;  // 1: dQ kernel writes dS, dV / dK accumulate from the maps; 0: fused dP/dV/dK kernel
-extern "C" __attribute__((visibility("default"))) void samble_debug_bwd_tri_mode(int use_ds_map) { g_bwd_tri_dsmap = use_ds_map; }
 
 extern "C" size_t samble_bwd_tri_dsmap_bytes(int B, int N, int M) {
   return (size_t)B * M * (32 * ((N + 8 + 31) / 32)) * sizeof(float);
@@ -537,12 +531,12 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
                                      const void* dO_tr, const void* Q_tr, const void* V_rm, const void* K_tr,
                                      const long long* idx, int B, int N, int nt, int M, float scale, float* dQ, long dq_bs,
                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                     float* cs, float* dsmap, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+                                     float* cs, float* dsmap, int fused_dkdv, hipStream_t stream) {
+  // fused_dkdv == 0 (default): the dQ kernel writes a dS map and dV / dK accumulate from the maps (4 products per
+  // tile); != 0: fused dP / dV / dK kernel (5 products, no dS map)
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipSuccess;
-    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0>), reinterpret_cast<const void*>(bwd_dq_tri_kernel<1>),
-                          reinterpret_cast<const void*>(bwd_dq_tri_kernel<2>), reinterpret_cast<const void*>(bwd_dq_tri_kernel<3>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0>)}) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
       if (e != hipSuccess) return (int)e;
     }
@@ -555,33 +549,30 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
       if (e != hipSuccess) return (int)e;
     }
-    attr_set = true;
   }
-  const bool use_map = g_bwd_tri_dsmap && dsmap;
+  const bool use_map = !fused_dkdv && dsmap;
   const DqTriArgs dq{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)V_rm, (const char*)K_tr, idx, N, N + nt, M,
                      scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
-  auto dqk = g_stats_ablate == 21 ? bwd_dq_tri_kernel<1> : g_stats_ablate == 22 ? bwd_dq_tri_kernel<2>
-           : g_stats_ablate == 23 ? bwd_dq_tri_kernel<3> : bwd_dq_tri_kernel<0>;
-  samble_time_begin(6, stream);
-  hipLaunchKernelGGL(dqk, dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
-  samble_time_end(6, stream);
+  {
+    Timed timed(kT_bwd_dq, stream);
+    hipLaunchKernelGGL(bwd_dq_tri_kernel<0>, dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+  }
   if (use_map) {
     const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr};
     const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs};
-    samble_time_begin(3, stream);
-    hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
-    samble_time_end(3, stream);
-    samble_time_begin(7, stream);
+    {
+      Timed timed(kT_bwd_dv, stream);
+      hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+    }
+    Timed timed(kT_bwd_dk, stream);
     if (cs) hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, true>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
     else hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
-    samble_time_end(7, stream);
   } else {
     const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
                        idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};
-    samble_time_begin(3, stream);
+    Timed timed(kT_bwd_dv, stream);
     if (cs) hipLaunchKernelGGL(bwd_dkdv_tri_kernel<true>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
     else hipLaunchKernelGGL(bwd_dkdv_tri_kernel<false>, dim3((N + 127) / 128, B), dim3(256), kKvLds, stream, kv);
-    samble_time_end(3, stream);
   }
   return (int)hipGetLastError();
 }

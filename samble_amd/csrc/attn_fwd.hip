@@ -217,8 +217,6 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const float* __rest
 
 }  // namespace samble
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 
 extern "C" int samble_launch_attn_colsum(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
@@ -230,27 +228,17 @@ extern "C" int samble_launch_attn_colsum(const float* Q, long q_bs, long q_rs, c
   return (int)hipGetLastError();
 }
 
-static int g_fwd_ablate = 0;
-extern int g_stats_ablate;
-extern "C" __attribute__((visibility("default"))) void samble_debug_ablate(int which, int mode) {
-  if (which == 0) g_fwd_ablate = mode;
-  if (which == 1) g_stats_ablate = mode;
-}
-
 extern "C" int samble_launch_attn_fwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, int B, int N, int NK, float scale, float* O,
                                       float* lse, float* tok, int nt, float* row_std, hipStream_t stream) {
   const size_t lds = kFwdLdsFloats * sizeof(float);
-  auto kern = g_fwd_ablate == 1 ? attn_fwd_kernel<1> : g_fwd_ablate == 2 ? attn_fwd_kernel<2>
-            : g_fwd_ablate == 3 ? attn_fwd_kernel<3> : g_fwd_ablate == 4 ? attn_fwd_kernel<4>
-            : g_fwd_ablate == 5 ? attn_fwd_kernel<5> : attn_fwd_kernel<0>;
+  auto kern = attn_fwd_kernel<0>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
   dim3 grid((N + 255) / 256, B);
-  samble_time_begin(5, stream);
+  Timed timed(kT_attn_fwd, stream);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, N, NK, scale, O,
                      lse, tok, nt, row_std);
-  samble_time_end(5, stream);
   return (int)hipGetLastError();
 }

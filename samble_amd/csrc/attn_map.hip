@@ -308,11 +308,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_rows_kernel(const float* __re
 
 }  // namespace samble
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
-
-int g_stats_ablate = 0;  // set by samble_debug_ablate(1, mode)
 
 extern "C" int samble_attn_map_ld(int N, int nt) { return 32 * ((N + nt + 31) / 32); }
 
@@ -321,14 +317,10 @@ extern "C" int samble_launch_attn_stats(const float* Q, long q_bs, long q_rs, co
                                         const float* qn, const float* kn, hipStream_t stream) {
   constexpr int NW = 8;
   const size_t lds = (3 * kTile * kLdsPad + NW * kTile * kStPad) * sizeof(float);
-  auto kern = g_stats_ablate == 1 ? attn_stats_kernel<NW, 1> : g_stats_ablate == 2 ? attn_stats_kernel<NW, 2>
-            : g_stats_ablate == 3 ? attn_stats_kernel<NW, 3> : g_stats_ablate == 4 ? attn_stats_kernel<NW, 4>
-                                                                                     : attn_stats_kernel<NW, 0>;
-  if (qn && kn) kern = attn_stats_kernel<NW, 0, true>;
-  samble_time_begin(1, stream);
+  auto kern = (qn && kn) ? attn_stats_kernel<NW, 0, true> : attn_stats_kernel<NW, 0>;
+  Timed timed(kT_attn_stats, stream);
   hipLaunchKernelGGL(kern, dim3((N + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, Q, q_bs, q_rs, K, k_bs,
                      k_rs, N, N + nt, scale, smap, ld, lse, tok, nt, qn, kn);
-  samble_time_end(1, stream);
   return (int)hipGetLastError();
 }
 
@@ -337,9 +329,8 @@ extern "C" int samble_launch_attn_rows(const float* smap, int ld, const float* l
                                        hipStream_t stream) {
   constexpr int NW = 4;
   const size_t lds = 2 * kTile * 128 * sizeof(float);
-  samble_time_begin(2, stream);
+  Timed timed(kT_attn_rows, stream);
   hipLaunchKernelGGL(attn_rows_kernel<NW>, dim3((M + 32 * NW - 1) / (32 * NW), B), dim3(64 * NW), lds, stream, smap, ld,
                      lse, V, v_bs, v_rs, idx, N, N + nt, M, xds);
-  samble_time_end(2, stream);
   return (int)hipGetLastError();
 }

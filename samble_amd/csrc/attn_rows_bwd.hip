@@ -214,8 +214,6 @@ __global__ __launch_bounds__(512, 2) void bwd_rows_kernel(const RowsBwdArgs a) {
 
 }  // namespace samble
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
 
 extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const float* lse_s, const float* delta,
@@ -223,23 +221,20 @@ extern "C" int samble_launch_bwd_rows(const float* Qs, const float* dOb, const f
                                       int N, int M, float scale, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs,
                                       long dv_rs, float* slab, int nslab, const float* smap, int ld,
                                       const long long* idx, float* cs, int nt, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_rows_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const size_t lds = kRbLdsFloats * sizeof(float) + (size_t)M * 4;
   if (lds > 160 * 1024) return -22;
   RowsBwdArgs a{Qs, dOb, lse_s, delta, K, k_bs, k_rs, V, v_bs, v_rs, N, M, scale, dK, dk_bs, dk_rs,
                 dV, dv_bs, dv_rs, slab, nslab, smap, ld, idx, cs, nt};
-  samble_time_begin(3, stream);
+  Timed timed(kT_bwd_rows_f32, stream);
   if (cs) hipLaunchKernelGGL(bwd_rows_kernel<true>, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
   else hipLaunchKernelGGL(bwd_rows_kernel<false>, dim3((N + 127) / 128, B), dim3(512), lds, stream, a);
-  samble_time_end(3, stream);
   return (int)hipGetLastError();
 }

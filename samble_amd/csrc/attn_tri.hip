@@ -390,10 +390,7 @@ __global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restr
 
 }  // namespace samble
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
 using namespace samble;
-extern int g_stats_ablate;
 
 extern "C" size_t samble_tri_image_size(int B, int rows, int transposed) {
   const size_t tiles = (size_t)B * ((rows + 31) / 32);
@@ -403,6 +400,7 @@ extern "C" size_t samble_tri_image_size(int B, int rows, int transposed) {
 
 extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
                                        hipStream_t stream) {
+  Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, stream, src, bs, rs, rows, (char*)rm,
                      (char*)tr);
   return (int)hipGetLastError();
@@ -412,53 +410,39 @@ extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B
 extern "C" int samble_launch_attn_stats_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
                                             float* smap, int ld, float* lse, float* tok, const float* qn, const float* kn,
                                             hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     for (const void* f : {reinterpret_cast<const void*>(attn_stats_tri_kernel<false>),
                           reinterpret_cast<const void*>(attn_stats_tri_kernel<true>)}) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
     }
-    attr_set = true;
   }
   const size_t lds = kStatsDepth * kTriTile + 8 * kTile * kStPadT * sizeof(float) + ((qn && kn) ? (size_t)ld * 4 : 0);
   if (lds > 160 * 1024) return -22;
   auto kern = (qn && kn) ? attn_stats_tri_kernel<true> : attn_stats_tri_kernel<false>;
-  if (g_stats_ablate == 1) kern = attn_stats_tri_kernel<false, 1>;
-  if (g_stats_ablate == 2) kern = attn_stats_tri_kernel<false, 2>;
-  if (g_stats_ablate == 3) kern = attn_stats_tri_kernel<false, 3>;
-  if (g_stats_ablate == 4) kern = attn_stats_tri_kernel<false, 4>;
-  if (g_stats_ablate == 5) kern = attn_stats_tri_kernel<false, 5>;
-  if (g_stats_ablate == 8) kern = attn_stats_tri_kernel<false, 8>;
-  if (g_stats_ablate == 9) kern = attn_stats_tri_kernel<false, 9>;
-  if (g_stats_ablate == 10) kern = attn_stats_tri_kernel<false, 10>;
-  if (g_stats_ablate == 11) kern = attn_stats_tri_kernel<false, 11>;
-  samble_time_begin(1, stream);
+  Timed timed(kT_attn_stats, stream);
   hipLaunchKernelGGL(kern, dim3((N + 255) / 256, B), dim3(512), lds, stream, (const char*)qimg, (const char*)kimg, N,
                      N + nt, scale, smap, ld, lse, tok, nt, qn, kn);
-  samble_time_end(1, stream);
   return (int)hipGetLastError();
 }
 
 extern "C" int samble_launch_attn_rows_tri(const float* smap, int ld, const float* lse, const void* v_tr_image,
                                            const long long* idx, int B, int N, int nt, int M, float* xds,
                                            hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_rows_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kRowsLds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
-  samble_time_begin(2, stream);
+  Timed timed(kT_attn_rows, stream);
   hipLaunchKernelGGL(attn_rows_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kRowsLds, stream, smap, ld, lse,
                      (const char*)v_tr_image, idx, N, N + nt, M, xds);
-  samble_time_end(2, stream);
   return (int)hipGetLastError();
 }
 
 extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, int B, int N, int nt, void* qimg, void* kimg,
                                            void* vimg, void* ktr, void* vrm, hipStream_t stream) {
+  Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm);
   return (int)hipGetLastError();

@@ -301,12 +301,10 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
                                           float* dw2part, hipStream_t s) {
   const long np = (long)B * N;
   const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 8 * 2 * kEK * kEwPad) * sizeof(float);  // 157 KB: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_mlp_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
                      N, np, du, dw2part);

@@ -41,6 +41,28 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   norms[(long)b * N + n] = acc;
 }
 
+// per-cloud channel means of a channel-major (B, C, N) set (the reference centres both sets on the QUERY
+// set's mean, utils/ops.py:23-25): one wave per (cloud, channel), fixed order
+__global__ __launch_bounds__(256) void cloud_mean_kernel(const float* __restrict__ x, long bs, int C, int N,
+                                                         float* __restrict__ mean) {
+  const int b = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float* p = x + (long)b * bs + (long)c * N;
+  float s = 0.f;
+  for (int n = lane; n < N; n += 64) s += p[n];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) mean[b * C + c] = s / (float)N;
+}
+
+// centred copy xc[b][c][n] = x[b][c][n] - mean[b][c] (contiguous (B, C, N)): the Gram form of the squared
+// distance, |a|^2 + |b|^2 - 2 a.b, cancels catastrophically when the cloud sits far from the origin
+__global__ __launch_bounds__(256) void center_cm_kernel(const float* __restrict__ x, long bs, int C, int N,
+                                                        const float* __restrict__ mean, float* __restrict__ xc) {
+  const int b = blockIdx.z, c = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) xc[((long)b * C + c) * N + n] = x[(long)b * bs + (long)c * N + n] - mean[b * C + c];
+}
+
 // keyT[b][j][i] = bnorm[j] - 2 * sum_c xk[b][c][j] * xq[b][c][i]
 __global__ __launch_bounds__(256, 2) void gram_keys_kernel(const float* __restrict__ xq, long q_bs, int Nq,
                                                            const float* __restrict__ xk, long k_bs, int Nk, int C,
@@ -205,25 +227,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const float* __restric
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused Gram + top-K: the key matrix never leaves the chip.
-//
-// Workgroup = 4 waves = 128 queries; a wave holds its 32 queries' channels in registers (MFMA B
-// operand) and streams 32-key tiles of the channel-major key set through LDS (A operand), so the
-// accumulator of lane (i, h) holds G[j][i] - |b_j|^2/2 for 16 keys j of query i (the norm enters as
-// one extra MFMA step with B = -1/2).  w = |a_i|^2/2 - acc = d^2/2 >= 0 is the ranking key.
-//
-// Selection is per lane (each lane owns one query and the half of the key stream that lands on its
-// lane half): candidates with w <= the lane's current bound go to a per-lane LDS queue; when any
-// lane's queue is nearly full the wave drains queues into per-lane sorted K-lists held in
-// registers as DOUBLES whose high bits are (double)w and low 29 bits the key index: positive
-// doubles order like (w, j) pairs, so an insertion is one v_max_f64 + v_min_f64 per slot and ties
-// break by ascending index.  The bound of a lane is min(own K-th, max of the two halves'
-// ceil(K/2)-th): both halves together then already hold K keys at or below it.  The two halves'
-// lists are merged at the end.  (Algorithm checked element-for-element against a sort on the CPU.)
-// ------------------------------------------------------------------------------------------------
-constexpr int kFQueue = 24;  // queue slots per lane; a tile adds at most 16
-
+// packed (w bits | index) doubles: a sorted K-list step is one v_max_f64 + v_min_f64 per slot, ties by index
 template <int KN>
 __device__ __forceinline__ void insert_packed(double (&L)[KN], double x) {
 #pragma unroll
@@ -233,153 +237,6 @@ __device__ __forceinline__ void insert_packed(double (&L)[KN], double x) {
 
 __device__ __forceinline__ double pack_wj(float w, unsigned int j) {
   return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
-}
-
-template <int C, int KN, bool SELECT = true>
-__global__ __launch_bounds__(256, 2) void knn_fused_kernel(const float* __restrict__ xq, long q_bs, int Nq,
-                                                           const float* __restrict__ xk, long k_bs, int Nk,
-                                                           const float* __restrict__ knorm,
-                                                           int* __restrict__ idx_out, float* __restrict__ d2_out) {
-  constexpr int H = C / 2;            // MFMA steps; lane half h consumes channels H*h .. H*h+H-1
-  constexpr int TILE = C * 32;        // floats per key tile, [channel][32 keys]
-  constexpr int LOADS = TILE / 4 / 256;
-  constexpr int KH = (KN + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tiles = smem;                               // 2 x TILE
-  float* bns = smem + 2 * TILE;                      // 2 x 32 key norms
-  float* qw = bns + 64;                              // kFQueue x 256
-  unsigned short* qj = reinterpret_cast<unsigned short*>(qw + kFQueue * 256);
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  int chunk, b;
-  xcd_assign(chunk, b);
-  const int i = chunk * 128 + wave * 32 + lo;
-  const bool ivalid = i < Nq;
-  const float* xkb = xk + (long)b * k_bs;
-  const float* knb = knorm + (long)b * Nk;
-
-  float q[H];
-  float an = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < H; ++kk) {
-    q[kk] = ivalid ? xq[(long)b * q_bs + (long)(H * h + kk) * Nq + i] : 0.f;
-    an = fmaf(q[kk], q[kk], an);
-  }
-  an += wave_xor32(an);
-  const float half_an = 0.5f * an;
-
-  double L[KN];
-#pragma unroll
-  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
-  float thr = __builtin_huge_valf();
-  int cnt = 0;
-
-  const bool vec = (Nk & 3) == 0;
-  f32x4 stage[LOADS];
-  float stage_bn = 0.f;
-  auto issue = [&](int j0) {
-#pragma unroll
-    for (int it = 0; it < LOADS; ++it) {
-      const int e = tid + 256 * it;
-      const int c = e >> 3, p4 = (e & 7) * 4;
-      const float* src = xkb + (long)c * Nk + j0 + p4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (vec && j0 + p4 + 3 < Nk) {
-        v = *reinterpret_cast<const f32x4*>(src);
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + p4 + u < Nk) v[u] = src[u];
-      }
-      stage[it] = v;
-    }
-    if (tid < 32) stage_bn = (j0 + tid < Nk) ? knb[j0 + tid] : 0.f;
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < LOADS; ++it) {
-      const int e = tid + 256 * it;
-      *reinterpret_cast<f32x4*>(tiles + buf * TILE + (e >> 3) * 32 + (e & 7) * 4) = stage[it];
-    }
-    if (tid < 32) bns[buf * 32 + tid] = stage_bn;
-  };
-  auto drain = [&]() {
-    for (int s = 0; s < kFQueue; ++s) {
-      if (!__any(s < cnt)) break;
-      const double xd = (s < cnt) ? pack_wj(qw[s * 256 + tid], qj[s * 256 + tid]) : __builtin_huge_val();
-      insert_packed<KN>(L, xd);
-    }
-    cnt = 0;
-    const double mid = L[KH - 1];
-    const double pmid = __shfl_xor(mid, 32, 64);
-    const double lim = fmin(L[KN - 1], fmax(mid, pmid));
-    thr = (float)lim;  // the index bits are far below half a float ulp: this is exactly lim's w
-  };
-
-  const int ntiles = (Nk + 31) / 32;
-  issue(0);
-  commit(0);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const int j0 = t * 32;
-    if (t + 1 < ntiles) issue(j0 + 32);
-    const float* xs = tiles + cur * TILE + (H * h) * 32 + lo;
-    f32x16 acc = zero16();
-#pragma unroll
-    for (int kk = 0; kk < H; ++kk) acc = mfma32(xs[kk * 32], q[kk], acc);
-    acc = mfma32(h == 0 ? bns[cur * 32 + lo] : 0.f, h == 0 ? -0.5f : 0.f, acc);
-    const bool tail = j0 + 32 > Nk;
-    if (!SELECT) {  // ablation build: keep the accumulator live, skip the selection
-#pragma unroll
-      for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
-    } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = j0 + crow(r, h);
-      const float w = fmaxf(half_an - acc[r], 0.f);
-      bool pass = w <= thr;
-      if (tail) pass = pass && (j < Nk);
-      if (pass) {
-        qw[cnt * 256 + tid] = w;
-        qj[cnt * 256 + tid] = (unsigned short)j;
-        ++cnt;
-      }
-    }
-    }
-    if (t + 1 < ntiles) commit(cur ^ 1);
-    // the tile barrier doubles as the drain vote: all 4 waves drain together, so no wave sits at
-    // the barrier while another one works through its queues
-    if (__syncthreads_or(cnt > kFQueue - 16)) drain();
-  }
-  drain();
-  // merge the two halves of every query through LDS (the whole dynamic region is free now)
-  double* mg = reinterpret_cast<double*>(smem);
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < KN; ++s) mg[s * 256 + tid] = L[s];
-  __syncthreads();
-  if (!SELECT && ivalid && h == 0) idx_out[((long)b * Nq + i) * KN] = (int)thr;
-  if (SELECT && h == 0 && ivalid) {
-    int pa = 0, pb = 0;
-    double va = mg[tid], vb = mg[tid + 32];
-    int* io = idx_out + ((long)b * Nq + i) * KN;
-    float* dout = d2_out ? d2_out + ((long)b * Nq + i) * KN : nullptr;
-    for (int k = 0; k < KN; ++k) {
-      const bool take = va <= vb;
-      const double o = take ? va : vb;
-      io[k] = (int)(__double_as_longlong(o) & 0x1FFFFFFFll);
-      if (dout) dout[k] = 2.f * (float)o;
-      if (take) {
-        ++pa;
-        va = (pa < KN) ? mg[pa * 256 + tid] : __builtin_huge_val();
-      } else {
-        ++pb;
-        vb = (pb < KN) ? mg[pb * 256 + tid + 32] : __builtin_huge_val();
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,36 +320,8 @@ static void launch_smallc_fused(const float* xq, long q_bs, int Nq, const float*
                      C, idx, keys);
 }
 
-// test hooks: 1 forces the round-1 two-kernel path (key matrix through HBM) for A/B checks
-static bool g_force_unfused = false;
-static bool g_ablate_select = false;  // on = 2: timing-only build of the fused kernel without selection (wrong outputs)
-extern int g_knn_keep;
-static bool g_no_stream = false;      // on = 3: the non-pipelined fused kernel of this file instead of knn_stream.hip
-extern "C" __attribute__((visibility("default"))) void samble_knn_force_unfused(int on) {
-  g_force_unfused = on == 1;
-  g_ablate_select = on == 2;
-  g_no_stream = on == 3;
-  if (on >= 200) g_knn_keep = on - 200;
-  if (on == 99) g_knn_keep = -1;
-}
 extern "C" int samble_launch_knn_stream(const float*, long, int, const float*, long, int, int, int, int, const float*,
                                         int*, float*, hipStream_t);
-
-template <int C, int KN>
-static int launch_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
-                        const float* knorm, int* idx, float* d2, hipStream_t s) {
-  size_t lds = (size_t)(2 * C * 32 + 64 + kFQueue * 256) * 4 + (size_t)kFQueue * 256 * 2;
-  const size_t merge = (size_t)KN * 256 * 8;
-  if (merge > lds) lds = merge;
-  auto kern = g_ablate_select ? knn_fused_kernel<C, KN, false> : knn_fused_kernel<C, KN, true>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(kern, dim3((Nq + 127) / 128, B), dim3(256), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm, idx, d2);
-  return 0;
-}
 
 // Per-cloud scale of the reference (utils/ops.py:27): mean over channels of the unbiased std over
 // points of the query set.  One workgroup per cloud; double accumulation, fixed order.
@@ -556,67 +385,99 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
 }
 
 
-// workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K]
-static bool knn_uses_fused(int C, int K, int Nk) {
-  return !g_force_unfused && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
+// variant (include/samble.h SAMBLE_KNN_*): bit 0 = fp32-MFMA stream kernel instead of the split-bf16 one,
+// bit 1 = the two-kernel path (key matrix through HBM) -- also the fallback for shapes the fused kernels
+// do not take
+constexpr int kVarF32 = 1, kVarTwoKernel = 2;
+
+// workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K][mean B*C][operand images]
+static bool knn_uses_fused(int C, int K, int Nk, int variant) {
+  return !(variant & kVarTwoKernel) && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
+}
+static bool knn_uses_small_fused(int C, int K, int Nk, int variant) {
+  return C <= 8 && !(variant & kVarTwoKernel) && Nk <= 65536 && Nk >= K;
+}
+static bool knn_uses_tri(int C, int K, int Nk, int variant) {
+  return C == 128 && !(variant & kVarF32) && knn_uses_fused(C, K, Nk, variant);
 }
 
-// the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path
-extern "C" int samble_knn_tri_enabled();
 extern "C" size_t samble_knn_tri_image_bytes(int B, int N);
-extern "C" int samble_launch_tri_split_cm(const float* x, long bs, int B, int N, void* img, hipStream_t s);
+extern "C" int samble_launch_knn_tri_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                                          float* mean, void* qimg, void* kimg, float* qnorm, float* knorm, hipStream_t s);
 extern "C" int samble_launch_knn_tri(const void* qimg, int Nq, const void* kimg, int Nk, int B, int K, const float* qnorm,
                                      const float* knorm, int* idx, float* d2, hipStream_t s);
 
-static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K) {
-  const bool small_fused = C <= 8 && !g_force_unfused && Nk <= 65536 && Nk >= K;
-  const size_t key_matrix = (knn_uses_fused(C, K, Nk) || small_fused) ? 0 : (size_t)B * Nk * Nq;
-  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + 64;
+extern "C" int samble_launch_cloud_mean(const float* x, long bs, int C, int N, int B, float* mean, hipStream_t s) {
+  hipLaunchKernelGGL(cloud_mean_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, x, bs, C, N, mean);
+  return (int)hipGetLastError();
+}
+
+// the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path; the MFMA paths that form the Gram in
+// fp32 (C >= 16) work on centred copies of the two sets
+static bool knn_centres_copy(int C, int K, int Nk, int variant) { return C > 8 && !knn_uses_tri(C, K, Nk, variant); }
+static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K, int variant) {
+  const size_t key_matrix =
+      (knn_uses_fused(C, K, Nk, variant) || knn_uses_small_fused(C, K, Nk, variant)) ? 0 : (size_t)B * Nk * Nq;
+  const size_t centred = knn_centres_copy(C, K, Nk, variant) ? (size_t)B * C * ((size_t)Nq + Nk) : 0;
+  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + (size_t)B * C +
+                   centred + 64;
   return (n + 63) & ~(size_t)63;  // what follows (operand images) stays 256-byte aligned
 }
 
 // C = 128 fused: + the split-bf16 operand images of the two point sets (knn_tri.hip)
-extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K) {
-  size_t n = knn_base_floats(B, C, Nq, Nk, K);
-  if (C == 128 && knn_uses_fused(C, K, Nk))
-    n += (samble_knn_tri_image_bytes(B, Nq) + samble_knn_tri_image_bytes(B, Nk)) / 4;
+extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K, int variant) {
+  size_t n = knn_base_floats(B, C, Nq, Nk, K, variant);
+  if (knn_uses_tri(C, K, Nk, variant)) n += (samble_knn_tri_image_bytes(B, Nq) + samble_knn_tri_image_bytes(B, Nk)) / 4;
   return n;
 }
 
 extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
-                                 int K, int* idx_out, float* dist_out, float* ws, hipStream_t stream) {
-  const bool fused = knn_uses_fused(C, K, Nk);
+                                 int K, int variant, int* idx_out, float* dist_out, float* ws, hipStream_t stream) {
+  const bool fused = knn_uses_fused(C, K, Nk, variant);
+  const bool small_fused = knn_uses_small_fused(C, K, Nk, variant);
   float* keyT = ws;
-  const bool small_fused = C <= 8 && !g_force_unfused && Nk <= 65536 && Nk >= K;
   float* knorm = keyT + ((fused || small_fused) ? 0 : (size_t)B * Nk * Nq);
   float* qnorm = knorm + (size_t)B * Nk;
   float* scale = qnorm + (size_t)B * Nq;
   float* keys = scale + B;
+  float* mean = keys + (size_t)B * Nq * K;
   const bool smallc = C <= 8;
+  const float* xq0 = xq;  // the reference-normalised distances are rebuilt from the caller's points
+  const long q_bs0 = q_bs;
+  if (knn_centres_copy(C, K, Nk, variant)) {
+    float* cq = mean + (size_t)B * C;
+    const bool same = xq == xk && Nq == Nk && q_bs == k_bs;
+    float* ck = same ? cq : cq + (size_t)B * C * Nq;
+    int rc = samble_launch_cloud_mean(xq, q_bs, C, Nq, B, mean, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(center_cm_kernel, dim3((Nq + 255) / 256, C, B), dim3(256), 0, stream, xq, q_bs, C, Nq, mean, cq);
+    if (!same)
+      hipLaunchKernelGGL(center_cm_kernel, dim3((Nk + 255) / 256, C, B), dim3(256), 0, stream, xk, k_bs, C, Nk, mean, ck);
+    xq = cq;
+    q_bs = (long)C * Nq;
+    xk = ck;
+    k_bs = (long)C * Nk;
+  }
   float* kout = dist_out ? keys : nullptr;
+  bool have_qnorm = false;
   if (fused) {
-    hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
     int rc = 0;
-    if (C == 128 && samble_knn_tri_enabled() && !g_no_stream && !g_ablate_select) {
-      // bf16 matrix cores on split fp32 operands: images of the point sets first (one if the sets coincide)
-      char* kimg = reinterpret_cast<char*>(ws + knn_base_floats(B, C, Nq, Nk, K));
+    if (knn_uses_tri(C, K, Nk, variant)) {
+      // bf16 matrix cores on split fp32 operands: centred images + norms of the point sets first (one
+      // image if the sets coincide)
+      char* kimg = reinterpret_cast<char*>(ws + knn_base_floats(B, C, Nq, Nk, K, variant));
       const bool same = xq == xk && Nq == Nk && q_bs == k_bs;
       char* qimg = same ? kimg : kimg + samble_knn_tri_image_bytes(B, Nk);
-      rc = samble_launch_tri_split_cm(xk, k_bs, B, Nk, kimg, stream);
-      if (!rc && !same) {
-        rc = samble_launch_tri_split_cm(xq, q_bs, B, Nq, qimg, stream);
-        hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
-      }
+      rc = samble_launch_knn_tri_prep(xq, q_bs, Nq, same ? nullptr : xk, k_bs, Nk, B, mean, qimg, kimg, qnorm, knorm, stream);
+      have_qnorm = true;
       if (!rc) rc = samble_launch_knn_tri(qimg, Nq, kimg, Nk, B, K, same ? knorm : qnorm, knorm, idx_out, kout, stream);
-    } else if (!g_no_stream && !g_ablate_select)
+    } else {
+      hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
       rc = samble_launch_knn_stream(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, knorm, idx_out, kout, stream);
-    else if (C == 128 && K == 32) rc = launch_fused<128, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
-    else if (C == 128) rc = launch_fused<128, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
-    else if (K == 32) rc = launch_fused<64, 32>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
-    else rc = launch_fused<64, 16>(xq, q_bs, Nq, xk, k_bs, Nk, B, knorm, idx_out, kout, stream);
+    }
     if (rc) return rc;
   } else {
-    if (smallc && !g_force_unfused && Nk <= 65536 && Nk >= K) {
+    if (small_fused) {
       bool ok = true;
       switch (K) {
         case 1: launch_smallc_fused<1>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;
@@ -654,8 +515,10 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   }
 selected:
   if (dist_out) {
-    if (!smallc && !fused) hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
-    hipLaunchKernelGGL(knn_scale_kernel, dim3(B), dim3(256), 0, stream, xq, q_bs, C, Nq, scale);
+    // keys of the fused kernels are full squared distances d^2; the two-kernel path returns d^2 - |a|^2
+    if (!smallc && !fused && !have_qnorm)
+      hipLaunchKernelGGL(rownorm_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, xq, q_bs, C, Nq, qnorm);
+    hipLaunchKernelGGL(knn_scale_kernel, dim3(B), dim3(256), 0, stream, xq0, q_bs0, C, Nq, scale);
     const long tot = (long)Nq * K;
     hipLaunchKernelGGL(knn_dist_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, stream, keys, qnorm, scale,
                        Nq, K, (smallc || fused) ? 0 : 1, dist_out);

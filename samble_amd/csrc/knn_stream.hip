@@ -17,13 +17,10 @@
 
 #include "samble_dev.h"
 
-extern "C" void samble_time_begin(int, hipStream_t);
-extern "C" void samble_time_end(int, hipStream_t);
-
 namespace samble {
 
 constexpr int kCap = 32;     // ring slots per lane (power of two); a tile adds at most 16
-int g_knn_keep = 6;  // drain policy (see full_drain)
+constexpr int kKeepStream = 6;  // drain policy (see full_drain)
 
 template <int KN>
 __device__ __forceinline__ void insert_packed2(double (&L)[KN], double x) {
@@ -228,10 +225,9 @@ static int launch_stream(const float* xq, long q_bs, int Nq, const float* xk, lo
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
-  samble_time_begin(4, s);
+  Timed timed(kT_knn, s);
   hipLaunchKernelGGL(kern, dim3((Nq + 32 * NW - 1) / (32 * NW), B), dim3(NT), lds, s, xq, q_bs, Nq, xk, k_bs, Nk, knorm,
-                     idx, d2, g_knn_keep);
-  samble_time_end(4, s);
+                     idx, d2, kKeepStream);
   return (int)hipGetLastError();
 }
 

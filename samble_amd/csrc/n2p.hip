@@ -445,12 +445,10 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
   float* A = gt + (size_t)B * N * 128;
   float* DL = A + (size_t)B * N * KN * 4;
   const size_t lds = (size_t)(2 * kScatRows * 128) * 4 + (size_t)(kScatHits + 256) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(n2p_bwd_scatter_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
   hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,

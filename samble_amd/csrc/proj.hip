@@ -324,13 +324,12 @@ extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, c
   float* tokqkv = ws;  // 8 x 384 floats
   if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 8), dim3(64), 0, s, tokens, nt, W, tokqkv);
   if (wimg) return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, s);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
+  Timed timed(kT_proj_fwd, s);
   hipLaunchKernelGGL(proj_fwd_kernel, dim3((N + 127) / 128, B), dim3(256), lds, s, x, x_bs, N, tokqkv, nt, W, qkv, o_bs,
                      o_rs);
   return (int)hipGetLastError();
@@ -344,16 +343,14 @@ extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
 extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
                                       const float* tokens, int nt, const float* W, float* dx, long dx_bs, float* dW,
                                       float* dtok, float* ws, void* wtr, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds_dx = kDxLdsFloats * sizeof(float), lds_dw = kDwLdsFloats * sizeof(float);
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dw);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dx);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int chunks = (N + kDwPts - 1) / kDwPts;
   float* part = ws;
@@ -362,9 +359,11 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
     const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr, B, N, dx, dx_bs, s);
     if (rc) return rc;
   } else if (dx) {
+    Timed timed(kT_proj_dx, s);
     hipLaunchKernelGGL(proj_dx_kernel, dim3((N + 127) / 128, B), dim3(256), lds_dx, s, dqkv, g_bs, g_rs, W, N, dx, dx_bs);
   }
   if (dW) {
+    Timed timed(kT_proj_dw, s);
     hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     if (nt > 0)
       hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, gsum, dtok);

@@ -157,18 +157,17 @@ extern "C" size_t samble_proj_tri_image_bytes() { return (size_t)kPTiles * kTriT
 
 extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokqkv, int nt,
                                           const float* W, void* wimg, float* qkv, long o_bs, long o_rs, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kProjTriLds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, wimg, nullptr, s);
   if (rc) return rc;
+  Timed timed(kT_proj_fwd, s);
   hipLaunchKernelGGL(proj_fwd_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, x, x_bs, N, tokqkv, nt,
                      (const char*)wimg, qkv, o_bs, o_rs);
   return (int)hipGetLastError();
@@ -176,15 +175,14 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
 
 extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int B, int N,
                                          float* dx, long dx_bs, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, nullptr, wtr, s);
   if (rc) return rc;
+  Timed timed(kT_proj_dx, s);
   hipLaunchKernelGGL(proj_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, dqkv, g_bs, g_rs,
                      (const char*)wtr, N, dx, dx_bs);
   return (int)hipGetLastError();

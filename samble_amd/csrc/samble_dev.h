@@ -17,7 +17,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// measurement hook (abi.hip): HIP events around a launch when its kernel id is selected
+// (samble_timing_select / samble_timing_read, ids = SAMBLE_T_* of include/samble.h)
+extern "C" void samble_time_begin(int id, hipStream_t s);
+extern "C" void samble_time_end(int id, hipStream_t s);
+
 namespace samble {
+
+enum TimedKernel {
+  kT_attn_stats = 1, kT_attn_rows = 2, kT_bwd_dv = 3, kT_knn = 4, kT_attn_fwd = 5, kT_bwd_dq = 6, kT_bwd_dk = 7,
+  kT_proj_fwd = 8, kT_proj_dx = 9, kT_proj_dw = 10, kT_tri_split = 11, kT_knn_prep = 12, kT_sparse_score = 13,
+  kT_quantiles = 14, kT_bin_assign = 15, kT_alloc_counts = 16, kT_bin_select = 17, kT_bwd_prep = 18,
+  kT_gather = 19, kT_knn_seed = 20, kT_select_chain = 21, kT_bwd_rows_f32 = 22,
+};
+struct Timed {  // brackets the launches made during its lifetime
+  int id;
+  hipStream_t s;
+  Timed(int i, hipStream_t st) : id(i), s(st) { samble_time_begin(i, st); }
+  ~Timed() { samble_time_end(id, s); }
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

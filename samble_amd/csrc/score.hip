@@ -285,6 +285,7 @@ extern "C" int samble_launch_sparse_score(const float* Q, long q_bs, long q_rs, 
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  Timed timed(kT_sparse_score, stream);
   hipLaunchKernelGGL(sparse_score_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
                      lse, nn, N, KN, scale, colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
@@ -310,6 +311,7 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  Timed timed(kT_sparse_score, stream);
   hipLaunchKernelGGL(sparse_score_map_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN,
                      colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);

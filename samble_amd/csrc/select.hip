@@ -490,7 +490,10 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
   }
   const float* nz = noise ? noise + ((long)b * nb + t) * N : nullptr;
   for (int n = tid; n < NP; n += 1024) {
-    unsigned long long c = ~0ull;
+    // non-members sort behind every member, in index order: if a count ever exceeds its bin's population (a
+    // degenerate cloud: NaN scores leave every bin empty and bin 0 is handed all M picks) the surplus slots
+    // receive valid, distinct point indices, as the reference's sort of the masked zeros does (utils/ops.py:486-503)
+    unsigned long long c = (n < N) ? (0xFFFFFFFF00000000ull | (unsigned int)n) : ~0ull;
     if (n < N && (mb[n] & bit)) {
       float key;
       if (mode == kTopRaw) {
@@ -691,13 +694,12 @@ extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, flo
     hipError_t e = hipMemsetAsync(w, 0, (size_t)kQWords * sizeof(unsigned int), s);
     if (e != hipSuccess) return (int)e;
     const int G = (int)((n + 2047) / 2048 > 128 ? 128 : (n + 2047) / 2048);
-    static bool attr2 = false;
-    if (!attr2) {
+    {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(qsel_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               64 * 1024);
       if (e != hipSuccess) return (int)e;
-      attr2 = true;
     }
+    Timed timed(kT_quantiles, s);
     hipLaunchKernelGGL(qsel_kernel<0>, dim3(G), dim3(1024), 2048 * 4, s, z, n, nb, w, out);
     hipLaunchKernelGGL(qsel_kernel<1>, dim3(G), dim3(1024), (size_t)(nb - 1) * 2048 * 4, s, z, n, nb, w, out);
     hipLaunchKernelGGL(qsel_kernel<2>, dim3(G), dim3(1024), (size_t)(nb - 1) * 1024 * 4, s, z, n, nb, w, out);
@@ -708,13 +710,12 @@ extern "C" int samble_launch_batch_quantiles(const float* z, long n, int nb, flo
   size_t words = 2048 * 8;
   if ((size_t)(nb - 1) * 2048 * 2 > words) words = (size_t)(nb - 1) * 2048 * 2;
   const size_t lds = words * sizeof(unsigned int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch_quantiles_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
+  Timed timed(kT_quantiles, s);
   hipLaunchKernelGGL(batch_quantiles_kernel, dim3(1), dim3(1024), lds, s, z, n, nb, out);
   return (int)hipGetLastError();
 }
@@ -729,6 +730,7 @@ extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt
                                         const float* lower, int B, int N, int nb, int relu_first,
                                         unsigned char* member, int* cap, float* w_pre, float* w, hipStream_t s) {
   if (nb < 1 || nb > kMaxBins || (nt != 1 && nt != nb)) return -22;
+  Timed timed(kT_bin_assign, s);
   hipLaunchKernelGGL(bin_assign_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, upper, lower, N, nb, relu_first, member,
                      cap, w_pre, w);
   return (int)hipGetLastError();
@@ -737,6 +739,7 @@ extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt
 extern "C" int samble_launch_alloc_counts(const float* w, const int* cap, int B, int nb, int M, int* counts,
                                           hipStream_t s) {
   if (B > 1024 || nb > kMaxBins) return -22;
+  Timed timed(kT_alloc_counts, s);
   hipLaunchKernelGGL(alloc_counts_kernel, dim3(1), dim3(((B + 63) / 64) * 64), 0, s, w, cap, B, nb, M, counts);  // thread = cloud
   return (int)hipGetLastError();
 }
@@ -755,6 +758,7 @@ extern "C" int samble_launch_bin_select(const float* score, const float* z, cons
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  Timed timed(kT_bin_select, s);
   hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise, N, NP, nb, M,
                      mode, temp_mode, temp, idx_out);
   return (int)hipGetLastError();
@@ -782,6 +786,7 @@ extern "C" int samble_launch_gather_rows(const float* O, long o_bs, long o_rs, c
 
 extern "C" int samble_launch_gather_points(const float* pcd, int B, int C, int N, const long long* idx, int M,
                                            float* out, hipStream_t s) {
+  Timed timed(kT_gather, s);
   hipLaunchKernelGGL(gather_points_kernel, dim3((M + 255) / 256, C, B), dim3(256), 0, s, pcd, C, N, idx, M, out);
   return (int)hipGetLastError();
 }

@@ -31,6 +31,7 @@ class _Projection(torch.autograd.Function):
     124-137) as ONE fp32-MFMA kernel producing point-major [Q|K|V] rows for x and the bin tokens."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, tokens, wq, wk, wv):
         w = torch.cat((wq, wk, wv), dim=0).squeeze(-1)  # (3C, C)
         tok = tokens[0]                                  # (C, nt)
@@ -39,6 +40,7 @@ class _Projection(torch.autograd.Function):
         return ops.stage_proj_fwd(x, tok, w)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dqkv):
         x, tok, w = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0]
@@ -61,6 +63,7 @@ class _SamplerCore(torch.autograd.Function):
     [both differentiable] + the integer / score by-products."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, qkv, x, mod, noise):
         B, C, N = x.shape
         D = mod.q_depth
@@ -115,6 +118,7 @@ class _SamplerCore(torch.autograd.Function):
         return x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_xds, g_tok, *_):
         qkv, O, lse, idx = ctx.saved_tensors[:4]
         smap = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
@@ -291,6 +295,7 @@ class _GlobalCore(torch.autograd.Function):
     """qkv (B,N,3D) -> x_ds (B,D,M), x_dropped (B,D,N-M) + indices, for DownSampleGlobal."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, qkv, x, mod):
         B, C, N = x.shape
         D = mod.q_depth
@@ -319,6 +324,7 @@ class _GlobalCore(torch.autograd.Function):
         return x_ds, x_dropped, idx, idx_dropped, stat
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_ds, g_dropped, *_):
         qkv, O, lse, idx, idx_dropped = ctx.saved_tensors
         N, D = ctx.dims
@@ -402,6 +408,7 @@ class _LocalCore(torch.autograd.Function):
     the (B,N,K) attention probabilities and the neighbour lists, for DownSampleLocal."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, wq, wk, wv, K, diff):
         C = x.shape[1]
         w = torch.cat((wq, wk, wv), dim=0).reshape(3 * C, C)
@@ -414,6 +421,7 @@ class _LocalCore(torch.autograd.Function):
         return out, att, nn_idx
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g, *_):
         x, w, qkv, nn_idx = ctx.saved_tensors
         diff, a, b = ctx.cfg

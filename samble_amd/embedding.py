@@ -25,6 +25,21 @@ from . import ops
 from . import _lib
 
 
+def _sync_group(bn):
+    """The process group over which `bn` pools its statistics, or None: nn.SyncBatchNorm in training with an
+    initialised group of more than one rank (the reference trainer converts every BatchNorm, train_modelnet.py:245-246)."""
+    if not isinstance(bn, nn.SyncBatchNorm) or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else torch.distributed.group.WORLD
+    return group if torch.distributed.get_world_size(group) > 1 else None
+
+
+def _all_sum(t: torch.Tensor, group) -> torch.Tensor:
+    if group is not None:
+        torch.distributed.all_reduce(t, group=group)
+    return t
+
+
 def _edge_weights(w1: torch.Tensor, group_type: str):
     """conv1 weight (Cout, Cin_total, 1, 1) -> (Wa, Wb) with conv1(group(x))_ij = Wa x_i + Wb x_j."""
     w = w1[:, :, 0, 0]
@@ -44,11 +59,16 @@ class _EdgeMLP(torch.autograd.Function):
     """a, b (B,N,64) per-point projections, nn (B,N,32) -> (B,64,N)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, a, b, nn_idx, g1, b1, w2, g2, b2, bn1, bn2, training):
         B, N, C = a.shape
         K = nn_idx.shape[2]
         E = B * N * K
         dev = a.device
+        # SyncBatchNorm: the edge statistics (and, backward, the gradient sums) are pooled over the ranks
+        grp1 = _sync_group(bn1) if training else None
+        grp2 = _sync_group(bn2) if training else None
+        E1 = E2 = float(E)
         a = a.contiguous()
         b = b.contiguous()
         w2m = w2[:, :, 0, 0].contiguous()
@@ -61,8 +81,11 @@ class _EdgeMLP(torch.autograd.Function):
                 ad, Sd = a.double(), S.double()
                 sum_z = K * ad.sum((0, 1)) + Sd.sum((0, 1))
                 sum_z2 = (K * ad * ad + 2 * ad * Sd + Q.double()).sum((0, 1))
-                mu1 = sum_z / E
-                var1 = (sum_z2 / E - mu1 * mu1).clamp_min(0)
+                if grp1 is not None:
+                    pooled = _all_sum(torch.cat((sum_z, sum_z2, sum_z.new_tensor([float(E)]))), grp1)
+                    sum_z, sum_z2, E1 = pooled[:C], pooled[C:2 * C], pooled[2 * C]  # 0-d tensor: no host sync
+                mu1 = sum_z / E1
+                var1 = (sum_z2 / E1 - mu1 * mu1).clamp_min(0)
             else:
                 mu1, var1 = bn1.running_mean.double(), bn1.running_var.double()
             sig1 = torch.sqrt(var1 + bn1.eps)
@@ -80,8 +103,11 @@ class _EdgeMLP(torch.autograd.Function):
                       ops._stream())
             if training:
                 tot = part.sum(0)
-                mu2 = tot[0] / E
-                var2 = (tot[1] / E - mu2 * mu2).clamp_min(0)
+                if grp2 is not None:
+                    pooled = _all_sum(torch.cat((tot.reshape(-1), tot.new_tensor([float(E)]))), grp2)
+                    tot, E2 = pooled[:2 * C].view(2, C), pooled[2 * C]
+                mu2 = tot[0] / E2
+                var2 = (tot[1] / E2 - mu2 * mu2).clamp_min(0)
             else:
                 mu2, var2 = bn2.running_mean.double(), bn2.running_var.double()
             sig2 = torch.sqrt(var2 + bn2.eps)
@@ -92,21 +118,24 @@ class _EdgeMLP(torch.autograd.Function):
             out = torch.maximum(v, 0.2 * v)
             if training:
                 with torch.no_grad():
-                    for bn, mu, var in ((bn1, mu1, var1), (bn2, mu2, var2)):
+                    for bn, mu, var, En in ((bn1, mu1, var1, E1), (bn2, mu2, var2, E2)):
                         if bn.track_running_stats and bn.running_mean is not None:
                             bn.num_batches_tracked += 1
                             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                             bn.running_mean.mul_(1 - m).add_(m * mu.to(bn.running_mean.dtype))
-                            bn.running_var.mul_(1 - m).add_(m * (var * E / (E - 1)).to(bn.running_var.dtype))
+                            bn.running_var.mul_(1 - m).add_(m * (var * En / (En - 1)).to(bn.running_var.dtype))
         ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2, kext)
         ctx.stats = (mu1, sig1, sc1, mu2, sig2, sc2)
+        ctx.pool = (grp1, E1, grp2, E2)
         ctx.training = training
         return out.permute(0, 2, 1)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         a, b, nn_idx, S, ap, bp, w2m, ext, v, g1, g2, kext = ctx.saved_tensors
         mu1, sig1, sc1, mu2, sig2, sc2 = ctx.stats
+        grp1, E1, grp2, E2 = ctx.pool
         B, N, C = a.shape
         K = nn_idx.shape[2]
         E = B * N * K
@@ -116,9 +145,13 @@ class _EdgeMLP(torch.autograd.Function):
         yhat = (ext.double() - mu2) / sig2
         sum_dv = dv.double().sum((0, 1))
         sum_dvy = (dv.double() * yhat).sum((0, 1))
-        dbeta2, dgamma2 = sum_dv, sum_dvy
+        dbeta2, dgamma2 = sum_dv, sum_dvy  # local sums: DDP averages parameter gradients over the ranks
         if ctx.training:
-            m1, m2 = sum_dv / E, sum_dvy / E
+            if grp2 is not None:
+                pooled = _all_sum(torch.cat((sum_dv, sum_dvy)), grp2)
+                m1, m2 = pooled[:C] / E2, pooled[C:] / E2
+            else:
+                m1, m2 = sum_dv / E, sum_dvy / E
         else:
             m1 = m2 = torch.zeros_like(sum_dv)
         c1 = -sc2 * m2 / sig2
@@ -141,7 +174,11 @@ class _EdgeMLP(torch.autograd.Function):
         sum_duz = ((a.double() * dusum).sum((0, 1)) + (b.double() * D).sum((0, 1)) - mu1 * sum_du) / sig1
         dbeta1, dgamma1 = sum_du, sum_duz
         if ctx.training:
-            m1p, m2p = (sum_du / E).float(), (sum_duz / E).float()
+            if grp1 is not None:
+                pooled = _all_sum(torch.cat((sum_du, sum_duz)), grp1)
+                m1p, m2p = (pooled[:C] / E1).float(), (pooled[C:] / E1).float()
+            else:
+                m1p, m2p = (sum_du / E).float(), (sum_duz / E).float()
             indeg = counts.view(B, N, 1).float()
             R = ops.stage_segment_sum_rows(a.view(-1, C), order, offsets, K, per_edge=False).view(B, N, C)
             mu1f, sig1f = mu1.float(), sig1.float()

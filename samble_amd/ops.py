@@ -44,9 +44,13 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # stage wrappers
 # ------------------------------------------------------------------------------------------------
-def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = False):
+KNN_FP32_MFMA, KNN_TWO_KERNEL = 1, 2  # include/samble.h SAMBLE_KNN_*
+
+
+def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = False, variant: Optional[int] = None):
     """xq (B,C,Nq), xk (B,C,Nk) channel-major -> idx (B,Nq,k) int32 nearest first
-    [, positive reference-normalised distance (B,Nq,k)]."""
+    [, positive reference-normalised distance (B,Nq,k)].  variant: kernel choice (KNN_*); None = the
+    feature-space kNN (C = 128) follows MATRIX_MODE."""
     _need_gpu(xq, xk)
     xq, xk = _f32c(xq), _f32c(xk)
     B, C, Nq = xq.shape
@@ -56,11 +60,12 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     with torch.cuda.device(xq.device):
         idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xq.device)
         dist = torch.empty((B, Nq, k), dtype=torch.float32, device=xq.device) if want_dist else None
-        _lib.load().samble_knn_tri_config(int(MATRIX_MODE == "tri"), 0)  # feature-space kNN (C = 128) follows the mode
-        nbytes = _lib.query("samble_knn_workspace_bytes", B, C, Nq, Nk, k)
+        if variant is None:
+            variant = 0 if MATRIX_MODE == "tri" else KNN_FP32_MFMA
+        nbytes = _lib.query("samble_knn_workspace_bytes", B, C, Nq, Nk, k, variant)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xq.device)
-        _lib.call("samble_knn_f32", xq.data_ptr(), C * Nq, Nq, xk.data_ptr(), C * Nk, Nk, B, C, k, idx.data_ptr(),
-                  _p(dist), ws.data_ptr(), nbytes, _stream())
+        _lib.call("samble_knn_f32", xq.data_ptr(), C * Nq, Nq, xk.data_ptr(), C * Nk, Nk, B, C, k, variant,
+                  idx.data_ptr(), _p(dist), ws.data_ptr(), nbytes, _stream())
     return (idx, dist) if want_dist else idx
 
 
@@ -342,8 +347,9 @@ def stage_gather_rows(O: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk, dv) -> None:
-    """Fills dq (rows idx, other rows zeroed), dk, dv (views with their own strides)."""
+def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk, dv, variant: int = 0) -> None:
+    """Fills dq (rows idx, other rows zeroed), dk, dv (views with their own strides).
+    variant 1: two kernels (7 matrix products per tile) instead of the fused one (5)."""
     _need_gpu(q, k, v, O, lse, idx, g)
     B, N, D = q.shape
     M = idx.shape[1]
@@ -354,7 +360,7 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
         _lib.call("samble_attn_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
                   k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), O.data_ptr(), lse.data_ptr(), idx.data_ptr(),
                   g.data_ptr(), B, n_points, n_tokens, M, D, dq.data_ptr(), dq.stride(0), dq.stride(1),
-                  dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1),
+                  dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1), int(variant),
                   ws.data_ptr(), nbytes, _stream())
 
 
@@ -479,7 +485,7 @@ def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
 
 
 def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv,
-                        asm: str = "dot", images=None) -> None:
+                        asm: str = "dot", images=None, variant: int = 0) -> None:
     """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M).
     asm "l2": the kernels also return the column sums of dS and the gradients are finished here:
     dS/dq_i = scale (2 k_j - 2 q_i), dS/dk_j = scale (2 q_i - 2 k_j), rows of dS sum to zero.
@@ -500,7 +506,8 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
                       k.stride(1), v.data_ptr(), v.stride(0), v.stride(1), images[0].data_ptr(), images[1].data_ptr(),
                       smap.data_ptr(), smap.shape[2], lse.data_ptr(), x_ds.data_ptr(), idx.data_ptr(), g.data_ptr(), B,
                       n_points, n_tokens, M, D, dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0),
-                      dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1), _p(cs), ws.data_ptr(), nbytes, _stream())
+                      dk.stride(1), dv.data_ptr(), dv.stride(0), dv.stride(1), _p(cs), int(variant), ws.data_ptr(),
+                      nbytes, _stream())
         else:
             nbytes = _lib.query("samble_attn_bwd_workspace_bytes", B, n_points, M, D)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
@@ -558,6 +565,7 @@ class _GroupGather(torch.autograd.Function):
     (scatter-add over neighbours, centre terms summed over K)."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, x, nn_idx, mode):
         _need_gpu(x, nn_idx)
         x = _f32c(x)
@@ -574,6 +582,7 @@ class _GroupGather(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         (nn_idx,) = ctx.saved_tensors
         mode, C = ctx.mode, ctx.C

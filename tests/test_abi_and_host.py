@@ -29,15 +29,17 @@ def test_header_symbols_are_exported(lib):
     assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
     assert exported <= declared, f"exported but not declared in samble.h: {sorted(exported - declared)}"
     assert set(lib.EXPORTS) == declared
+    # the product ABI carries no debug / ablation / process-wide configuration switches
+    assert not [n for n in exported if re.search(r"debug|force|config|ablate", n)]
 
 
 def test_library_loads_and_reports_version(lib):
     handle = lib.load()
     assert b"gfx950" in handle.samble_version()
-    assert lib.query("samble_knn_workspace_bytes", 32, 3, 2048, 2048, 3) < 32 * 2048 * 64 * 4  # xyz: fused, no key matrix
-    assert lib.query("samble_knn_workspace_bytes", 4, 32, 512, 512, 8) >= 4 * 512 * 512 * 4  # C = 32: two-kernel path
+    assert lib.query("samble_knn_workspace_bytes", 32, 3, 2048, 2048, 3, 0) < 32 * 2048 * 64 * 4  # xyz: fused, no key matrix
+    assert lib.query("samble_knn_workspace_bytes", 4, 32, 512, 512, 8, 0) >= 4 * 512 * 512 * 4  # C = 32: two-kernel path
     # C = 128: fused, no key matrix (537 MB); the workspace holds the two split-bf16 operand images (6 B / element)
-    assert lib.query("samble_knn_workspace_bytes", 32, 128, 2048, 2048, 32) < 2 * 32 * 2048 * 128 * 6 + 32 * 2048 * 64 * 4
+    assert lib.query("samble_knn_workspace_bytes", 32, 128, 2048, 2048, 32, 0) < 2 * 32 * 2048 * 128 * 6 + 32 * 2048 * 64 * 4
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):

@@ -1,0 +1,125 @@
+"""Two ranks through torch.nn.parallel.DistributedDataParallel(DownSampleToken) on the GPU: the N>1 path of
+BASELINE.json configs[3] (reference train_modelnet.py:66-71, 162-166, 245-250; utils/ops.py:191-199).
+
+The GPU box has one device, so the two ranks share cuda:0 over gloo; on an 8-GPU node the same code runs
+over RCCL (backend "nccl").  Checked: both ranks end every step with IDENTICAL bin boundaries equal to the
+blend of the rank-averaged batch quantiles; the sampled indices of each rank equal a single-process run of
+its shard under those boundaries; parameter gradients on both ranks equal the MEAN of the two single-process
+gradients (DDP's bucketed all-reduce); bench.py --gpus 2 starts its own ranks and reports n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(tmp_path, world=2, backend="gloo", what="sampler"):
+    env0 = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path), backend, what],
+                              env=dict(env0, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+    prefix = "rank" if what == "sampler" else "edge"
+    return [torch.load(os.path.join(tmp_path, f"{prefix}{r}.pt")) for r in range(world)]
+
+
+def test_ddp_two_ranks_boundaries_indices_and_gradients(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_worker as W
+    from samble_amd import ops
+    res = _run_ranks(tmp_path)
+    assert res[0]["world"] == 2 and res[1]["world"] == 2
+    state = None
+    for call in range(2):
+        r0, r1 = res[0]["log"][call], res[1]["log"][call]
+        # identical state on both ranks, = blend of the MEAN of the two local quantile vectors
+        assert torch.equal(r0["upper"], r1["upper"]) and torch.equal(r0["lower"], r1["lower"])
+        assert not torch.equal(r0["local_q"], r1["local_q"]), "ranks hold different shards"
+        mean_q = ((r0["local_q"] + r1["local_q"]) / 2).to(DEV)
+        state = ops.blend_boundaries(state, mean_q, W.NB, 0.99)
+        torch.cuda.synchronize()
+        assert torch.equal(state[0].cpu(), r0["upper"]) and torch.equal(state[1].cpu(), r0["lower"])
+        # single-process runs of each shard under those boundaries
+        grads = []
+        for rank, rr in enumerate((r0, r1)):
+            mod = W.build_module(DEV)
+            mod.dynamic_boundaries_enable = False
+            mod.bin_boundaries = [rr["upper"].to(DEV).clone(), rr["lower"].to(DEV).clone()]
+            x, noise, g = W.shard(rank, DEV)
+            xin = x.detach().requires_grad_(True)
+            (x_ds, idx), _ = mod(xin, noise=noise)
+            x_ds.backward(g)
+            assert torch.equal(idx.cpu(), rr["idx"]), f"rank {rank}: sampled indices differ from the single-process run"
+            torch.testing.assert_close(x_ds.detach().cpu(), rr["x_ds"], rtol=0, atol=0)
+            torch.testing.assert_close(xin.grad.cpu(), rr["dx"], rtol=0, atol=0)  # dx is per shard, not averaged
+            grads.append({n: p.grad.detach().cpu() for n, p in mod.named_parameters()})
+        for name in grads[0]:
+            want = (grads[0][name] + grads[1][name]) / 2
+            for rr in (r0, r1):
+                got = rr["grads"][name]
+                err = float((got - want).abs().max())
+                assert err <= 1e-6 * float(want.abs().max()) + 1e-9, (name, err)
+            assert torch.equal(r0["grads"][name], r1["grads"][name]), "DDP leaves the same gradient on every rank"
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher): the parent spawns the ranks before touching the GPU and rank 0
+    prints the JSON line with n_gpus = 2 (on this 1-GPU box the ranks share the device over gloo)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--no-breakdown", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2 and rec["config"]["global_batch"] == 64
+    assert rec["value"] > 0 and rec["scaling"] == "weak"
+
+
+def test_fused_edgeconv_pools_syncbatchnorm_statistics(tmp_path):
+    """the fused EdgeConv computed BatchNorm statistics from this rank's edges only.  Under
+    nn.SyncBatchNorm with 2 ranks it must equal the stock composition under nn.SyncBatchNorm: outputs, dx, every
+    parameter gradient and the running buffers."""
+    res = _run_ranks(tmp_path, what="edgeconv")
+    for rank, r in enumerate(res):
+        f, s_ = r["fused"], r["stock"]
+        scale = float(s_["y"].abs().max())
+        # arg-max flips at near-ties are inherent to any fp32 evaluation: compare in relative L2
+        rel = float((f["y"] - s_["y"]).norm() / s_["y"].norm())
+        assert rel <= 1e-4, (rank, rel, scale)
+        rel = float((f["dx"] - s_["dx"]).norm() / s_["dx"].norm())
+        assert rel <= 2e-3, (rank, "dx", rel)
+        for n in s_["grads"]:
+            a, b2 = f["grads"][n], s_["grads"][n]
+            assert float((a - b2).norm()) <= 2e-3 * float(b2.norm()) + 1e-7, (rank, n)
+        for n in s_["bufs"]:
+            if s_["bufs"][n].dtype.is_floating_point:
+                torch.testing.assert_close(f["bufs"][n], s_["bufs"][n], rtol=1e-4, atol=1e-6)
+    # pooled statistics: both ranks hold the same running buffers
+    for n in res[0]["fused"]["bufs"]:
+        assert torch.equal(res[0]["fused"]["bufs"][n], res[1]["fused"]["bufs"][n]), n

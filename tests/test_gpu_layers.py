@@ -419,3 +419,33 @@ def test_group_gather_kernel_is_the_reference_expression(group_type, B, C, N, K)
     if group_type in ("neighbor", "diff"):
         out2, idx2 = ops.select_neighbors(x.detach(), K, group_type)
         assert torch.equal(out2, out.detach()) and torch.equal(idx2, idx)
+
+
+def test_modules_are_safe_under_autocast():
+    """under torch.autocast the per-point projections of EdgeConv came back fp16 and the fp32 kernels
+    read / wrote past them.  Every autograd.Function now casts its inputs to fp32 (custom_fwd): results under
+    autocast must be finite and equal to the fp32 run up to the fp16 rounding of the surrounding matmuls."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    from samble_amd.embedding import EdgeConv, embedding_config
+    torch.manual_seed(3)
+    conv = EdgeConv(embedding_config("cls"), 1).to(DEV).train()
+    x = torch.from_numpy(synth.features(2, 64, 512, 808)).to(DEV)
+    ref = conv(x)
+    with torch.autocast("cuda", dtype=torch.float16):
+        got = conv(x.detach().requires_grad_(True))
+        got.float().sum().backward()
+    assert torch.isfinite(got).all() and got.shape == ref.shape
+    assert float((got.float() - ref).norm() / ref.norm()) <= 2e-2
+    mod = DownSampleToken(sampler_config("cls", M=[128, 64]), 0).to(DEV)
+    xs = torch.from_numpy(synth.features(2, 128, 256, 809)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((2 * 6, 256), 810)).to(DEV)
+    (r_ds, r_idx), _ = mod(xs, noise=noise)
+    mod.bin_boundaries = None
+    with torch.autocast("cuda", dtype=torch.float16):
+        xin = xs.detach().requires_grad_(True)
+        (a_ds, a_idx), _ = mod(xin, noise=noise)
+        a_ds.float().sum().backward()
+    # the sampler's own arithmetic stays fp32 end to end (its projection is a HIP kernel, not an autocast matmul)
+    assert torch.equal(a_idx, r_idx) and torch.equal(a_ds.float(), r_ds)
+    assert torch.isfinite(xin.grad).all()

@@ -125,12 +125,12 @@ def test_metric_size_properties_and_determinism():
 
 
 def test_stress_size_properties():
-    """BASELINE.json configs[4] geometry (N=8192 -> 4096; B reduced to 4 to keep the test short): the
-    4.3 GB-per-16-clouds logit map, 64-key-tile kNN and 4096-row backward paths at full width.
+    """BASELINE.json configs[4] at full size: B=16 clouds, N=8192 -> 4096 (the 16-cloud batch changes the XCD
+    placement and allocates the whole multi-GB map the way the bench's stress workload does).
     Size-independent properties + agreement of the two-pass path with the single-pass flash path."""
     import samble_amd.downsample as D
     from samble_amd import sampler_config
-    B, C, N, M, nb = 4, 128, 8192, 4096, 6
+    B, C, N, M, nb = 16, 128, 8192, 4096, 6
     cfg = sampler_config("cls", M=[M, M // 2])
     mod = D.DownSampleToken(cfg, 0).to(DEV)
     x = torch.from_numpy(synth.features(B, C, N, 5001)).to(DEV).requires_grad_(True)
@@ -198,3 +198,42 @@ def test_token_logits_stay_differentiable():
     ref = tok.grad
     err = (mod.bin_tokens.grad.cpu() - ref).abs().max().item()
     assert err <= 1e-3 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("name", ["layer_res_ff_topk", "layer_res_noff_random"])
+def test_res_block_against_reference_fixture(name, matrix_mode):
+    """res.enable (and res.ff): the residual link of reference models/downsample.py:75-83, 292-298 -- a gather of
+    CHANNEL 0 of x at the sampled indices broadcast-added to x_ds, BatchNorm, optional FFN + BatchNorm --
+    against a fixture from the unmodified reference (tests/golden/make_golden_res.py): output, every parameter
+    gradient, dx and the BatchNorm buffers after one training step."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    from tests.util import fill_parameters, layer_fixture
+    d = layer_fixture(name)
+    B, C, N, M, nb, seed = [int(v) for v in d["meta"]]
+    cfg = sampler_config("cls", M=[M, M // 2])
+    cfg.res.enable = [True, True]
+    cfg.res.ff = [bool(d["ff"]), bool(d["ff"])]
+    cfg.bin.sample_mode = [str(d["sample_mode"])] * 2
+    mod = DownSampleToken(cfg, 0)
+    fill_parameters(mod, seed)
+    mod = mod.to(DEV).train()
+    ref_names = sorted(k[len("grad__"):] for k in d.files if k.startswith("grad__"))
+    assert sorted(n for n, _ in mod.named_parameters()) == ref_names, "state_dict keys of the residual link"
+    x = torch.from_numpy(synth.features(B, C, N, seed + 10)).to(DEV).requires_grad_(True)
+    (x_ds, idx), _ = mod(x, noise=torch.from_numpy(d["noise"]).to(DEV))
+    assert torch.equal(idx.cpu(), torch.from_numpy(d["idx"])), "sampled indices"
+    torch.testing.assert_close(x_ds.detach().cpu(), torch.from_numpy(d["x_ds"]), rtol=2e-4, atol=2e-5)
+    x_ds.backward(torch.from_numpy(synth.normal((B, C, M), seed + 99)).to(DEV))
+    for pname, p in mod.named_parameters():
+        ref = torch.from_numpy(d["grad__" + pname])
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 3e-4 * float(ref.abs().max()) + 1e-6, (pname, err)
+    ref = torch.from_numpy(d["dx"])
+    assert float((x.grad.cpu() - ref).abs().max()) <= 3e-4 * float(ref.abs().max()) + 1e-6
+    for bname, b in mod.named_buffers():
+        refb = torch.from_numpy(d["buf__" + bname])
+        if refb.dtype.is_floating_point:
+            torch.testing.assert_close(b.cpu(), refb, rtol=2e-4, atol=1e-6)
+        else:
+            assert torch.equal(b.cpu(), refb)

@@ -39,15 +39,10 @@ def test_knn_feature_space(B, C, N, K):
 
 def test_knn_fused_and_two_kernel_paths_agree():
     """A/B of the fused Gram+top-K kernel against the round-1 path that writes the key matrix."""
-    from samble_amd import _lib
     B, C, N, K = 2, 128, 1024, 32
     x = torch.from_numpy(synth.features(B, C, N, 77)).to(DEV)
     fused_i, fused_d = ops().stage_knn(x, x, K, want_dist=True)
-    _lib.load().samble_knn_force_unfused(1)
-    try:
-        plain_i, plain_d = ops().stage_knn(x, x, K, want_dist=True)
-    finally:
-        _lib.load().samble_knn_force_unfused(0)
+    plain_i, plain_d = ops().stage_knn(x, x, K, want_dist=True, variant=ops().KNN_TWO_KERNEL)
     assert set_agreement(fused_i.cpu(), plain_i.cpu()) >= 0.9998
     pts = x.cpu().permute(0, 2, 1)
     ref_d, ref_i = O.knn(pts, pts, K)
@@ -55,6 +50,48 @@ def test_knn_fused_and_two_kernel_paths_agree():
     torch.testing.assert_close(fused_d.cpu()[:, :, 1:], -ref_d[:, :, 1:], rtol=1e-3, atol=1e-3)
     # nearest first: distances ascending along K
     assert bool((fused_d[:, :, 1:] >= fused_d[:, :, :-1] - 1e-6).all())
+
+
+@pytest.mark.parametrize("variant", ["default", "fp32_mfma", "two_kernel"])
+def test_knn_offset_and_anisotropic_clouds(variant):
+    """A cloud far from the origin (per-cloud offset of 50 sigma) with channel scales over two decades: the
+    reference centres on the cloud mean before cdist (utils/ops.py:23-25); a Gram-form kernel that does not
+    loses the neighbour ordering to cancellation.  Truth = exact fp64 distances."""
+    B, C, N, K = 2, 128, 1024, 32
+    x = torch.from_numpy(synth.features(B, C, N, 4711)).double()
+    scale = torch.from_numpy(10.0 ** (2.0 * synth.uniform((1, C, 1), 4712).astype(np.float64) - 1.0))  # 0.1 .. 10
+    off = torch.from_numpy(synth.normal((B, C, 1), 4713)).double() * 50.0
+    xs = ((x + off) * scale).float()
+    pts = xs.double().permute(0, 2, 1)
+    d = ((pts[:, :, None, :] - pts[:, None, :, :]) ** 2).sum(-1)
+    want = d.topk(K, dim=-1, largest=False)[1]
+    o_ = ops()
+    v = {"default": 0, "fp32_mfma": o_.KNN_FP32_MFMA, "two_kernel": o_.KNN_TWO_KERNEL}[variant]
+    got, dist = o_.stage_knn(xs.to(DEV), xs.to(DEV), K, want_dist=True, variant=v)
+    assert bool((got[:, :, 0].cpu() == torch.arange(N)).all()), "nearest neighbour of a point is itself"
+    assert set_agreement(got.cpu(), want) >= 0.9995
+    # the oracle (ATen cdist on the centred, scaled points) under the same test, for calibration of the bar
+    _, ref_i = O.knn(xs.permute(0, 2, 1), xs.permute(0, 2, 1), K)
+    assert set_agreement(ref_i, want) >= 0.999
+    # reference-normalised distances of the winners
+    ref_d, _ = O.knn(xs.permute(0, 2, 1), xs.permute(0, 2, 1), K)
+    torch.testing.assert_close(dist.cpu()[:, :, 1:], -ref_d[:, :, 1:], rtol=2e-3, atol=2e-3)
+
+
+def test_knn_degenerate_clouds():
+    """All points identical / two clusters of duplicates: every distance ties.  The seed bound of the split-bf16
+    kernel is useless here (everything passes): the result must still be a valid neighbour list (distinct
+    indices, ties by ascending index) and the kernel must not overflow its candidate rings."""
+    B, C, N, K = 2, 128, 512, 32
+    x = torch.zeros(B, C, N)
+    x[1, :, N // 2:] = 1.0  # cloud 1: two clusters of 256 duplicates
+    got = ops().stage_knn(x.to(DEV), x.to(DEV), K).cpu()
+    assert int(got.min()) >= 0 and int(got.max()) < N
+    assert all(len(set(r.tolist())) == K for r in got.reshape(-1, K))
+    assert torch.equal(got[0], torch.arange(K, dtype=torch.int32).expand(N, K)), "all ties: ascending index"
+    lo, hi = got[1, : N // 2], got[1, N // 2:]
+    assert torch.equal(lo, torch.arange(K, dtype=torch.int32).expand(N // 2, K))
+    assert torch.equal(hi, (N // 2 + torch.arange(K, dtype=torch.int32)).expand(N // 2, K))
 
 
 def test_knn_ragged_sizes_fused():
@@ -183,14 +220,9 @@ def test_attn_bwd(B, N, nt, M):
     dq = torch.full((B, N, D), float("nan"), device=DEV)
     dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
     dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
-    from samble_amd import _lib
     for split in (0, 1):  # fused 5-product backward, then the two-kernel (7-product) path
-        _lib.load().samble_debug_bwd_split(split)
-        try:
-            dq.fill_(float("nan")); dk.fill_(float("nan")); dv.fill_(float("nan"))
-            o_.stage_attn_bwd(qg, kg, vg, O_, lse, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv)
-        finally:
-            _lib.load().samble_debug_bwd_split(0)
+        dq.fill_(float("nan")); dk.fill_(float("nan")); dv.fill_(float("nan"))
+        o_.stage_attn_bwd(qg, kg, vg, O_, lse, idx.to(DEV), g.to(DEV), N, nt, dq, dk, dv, variant=split)
         for got, ref, name in ((dq, qd.grad, "dq"), (dk, kd.grad, "dk"), (dv, vd.grad, "dv")):
             assert torch.isfinite(got).all(), (name, split)
             scale = ref.abs().max().item()
@@ -508,6 +540,42 @@ def test_bin_select_exact_vs_oracle_full_size(mode):
     assert torch.equal(got.cpu(), ref.reshape(B, M))
 
 
+def test_bin_select_random_mode_full_size_vs_oracle():
+    """`random` (Boltzmann) selection at the metric size from the oracle's stage inputs.  Its key
+    exp(tanh(z)/T) / sum / q goes through tanh and exp: Sleef on the CPU (the oracle = torch), ocml on the GPU,
+    each within 1 ulp of the true value but not of each other, so two keys closer than a few ulp may trade
+    places.  Pinned here: every position where the two index tensors differ is such a near-tie (the two keys
+    involved agree to 1e-6 relative), there are at most a handful of them, and the per-bin SETS differ only by
+    such near-ties at the cut."""
+    B, N, nb, M = 8, 2048, 6, 1024
+    score = torch.from_numpy(np.abs(synth.normal((B, 1, N), 31)) * 1e-4 + 1e-6)
+    z = O.zscore(score)
+    state = O.blend_boundaries(None, O.batch_quantiles(z.reshape(B, 1, N, 1), nb), nb, 0.99)
+    member = O.bin_membership(z, state)
+    cap = member.squeeze(1).sum(1)
+    w = torch.rand(B, nb, generator=torch.Generator().manual_seed(5))
+    counts = O.allocate_counts(w, cap, M)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 32))
+    ref = O.select_indices(score, member, counts, M, "random", 0.1, noise).reshape(B, M)
+    bits = (member.squeeze(1).long() * (1 << torch.arange(nb))).sum(-1).to(torch.uint8)
+    got = ops().stage_bin_select(score.reshape(B, N).to(DEV), z.reshape(B, N).to(DEV), bits.to(DEV),
+                                 counts.to(DEV), M, "random", 0.1, noise.to(DEV)).cpu()
+    diff = got != ref
+    assert int(diff.sum()) <= 8, int(diff.sum())
+    if bool(diff.any()):
+        # the keys of the oracle (fp32, as the reference forms them) for the points involved
+        zz = O.zscore(score).reshape(B, N)
+        p = torch.exp(torch.tanh(zz) / 0.1)
+        bin_of = member.squeeze(1).float().argmax(-1)
+        for b, pos in diff.nonzero().tolist():
+            i, j = int(got[b, pos]), int(ref[b, pos])
+            assert int(bin_of[b, i]) == int(bin_of[b, j]), "a swap never crosses bins"
+            t = int(bin_of[b, i])
+            ki = float(p[b, i] / noise[b * nb + t, i])
+            kj = float(p[b, j] / noise[b * nb + t, j])
+            assert abs(ki - kj) <= 1e-6 * max(ki, kj), (b, pos, ki, kj)
+
+
 def test_bin_select_ties_break_by_ascending_index():
     """torch.sort leaves the order of exactly equal keys unspecified; ours is defined."""
     B, N, nb, M = 1, 256, 2, 64
@@ -613,21 +681,12 @@ def test_qkv_split_matches_the_single_operand_splits():
 def test_knn_split_bf16_kernel_agrees_with_the_fp32_kernel(Nq, Nk, K):
     """Same selection, different rounding of the Gram entries: the neighbour SETS agree except at
     near-ties, and both agree with fp64."""
-    from samble_amd import _lib
-    lib = _lib.load()
     B, C = 2, 128
     a = torch.from_numpy(synth.normal((B, C, Nq), 5)).to(DEV)
     bb = a if Nq == Nk else torch.from_numpy(synth.normal((B, C, Nk), 6)).to(DEV)
     o_ = ops()
-    old = o_.MATRIX_MODE
-    try:
-        o_.MATRIX_MODE = "f32"
-        ref = o_.stage_knn(a, bb, K)
-        o_.MATRIX_MODE = "tri"
-        got, dist = o_.stage_knn(a, bb, K, want_dist=True)
-    finally:
-        o_.MATRIX_MODE = old
-        lib.samble_knn_tri_config(int(old == "tri"), 0)
+    ref = o_.stage_knn(a, bb, K, variant=o_.KNN_FP32_MFMA)
+    got, dist = o_.stage_knn(a, bb, K, want_dist=True, variant=0)
     assert set_agreement(got.cpu(), ref.cpu()) >= 0.9995
     d = ((a.double().permute(0, 2, 1)[:, :, None, :] - bb.double().permute(0, 2, 1)[:, None, :, :]) ** 2).sum(-1)
     want = d.topk(K, dim=-1, largest=False)[1]
@@ -638,8 +697,6 @@ def test_knn_split_bf16_kernel_agrees_with_the_fp32_kernel(Nq, Nk, K):
 def test_split_bf16_backward_variants_agree():
     """dS-map backward (4 products per tile, default) vs the fused dP/dV/dK kernel (5 products, no dS map):
     same gradients up to summation order."""
-    from samble_amd import _lib
-    lib = _lib.load()
     B, N, nt, M, D = 2, 1000, 6, 333, 128
     q, k, v = _qkv(B, N, nt, 4321)
     g = torch.from_numpy(synth.normal((B, D, M), 9)).to(DEV)
@@ -653,14 +710,12 @@ def test_split_bf16_backward_variants_agree():
         smap, lse, _ = o_.stage_attn_stats(qg, kg, N, nt)
         x_ds = o_.stage_attn_rows(smap, lse, vg, idx, N, nt)
         for use_map in (1, 0):
-            lib.samble_debug_bwd_tri_mode(use_map)
             dq = torch.full((B, N, D), float("nan"), device=DEV)
             dk = torch.full((B, N + nt, D), float("nan"), device=DEV)
             dv = torch.full((B, N + nt, D), float("nan"), device=DEV)
-            o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx, g, N, nt, dq, dk, dv)
+            o_.stage_attn_rows_bwd(qg, kg, vg, smap, lse, x_ds, idx, g, N, nt, dq, dk, dv, variant=1 - use_map)
             out[use_map] = (dq, dk, dv)
     finally:
-        lib.samble_debug_bwd_tri_mode(1)
         o_.MATRIX_MODE = old
     for a, b2, name in zip(out[1], out[0], ("dq", "dk", "dv")):
         assert torch.isfinite(a).all() and torch.isfinite(b2).all(), name
