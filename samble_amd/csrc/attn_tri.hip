@@ -400,7 +400,6 @@ extern "C" size_t samble_tri_image_size(int B, int rows, int transposed) {
 
 extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
                                        hipStream_t stream) {
-  Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_kernel, dim3((rows + 31) / 32, B), dim3(256), 0, stream, src, bs, rs, rows, (char*)rm,
                      (char*)tr);
   return (int)hipGetLastError();

@@ -23,9 +23,9 @@
 
 namespace samble {
 
-constexpr int kCapT = 32;   // ring slots per lane (power of two); a tile adds at most 16
-constexpr int kKeepT = 5;   // a wave inserts (all lanes in lockstep) until its fullest ring holds <= kKeepT entries
-constexpr int kSeedDepth = 4;            // LDS ring of the seed pass: tiles of the h plane (8 KB each)
+constexpr int kCapT = 32;   // ring slots per lane (power of two, >= 16: a tile adds at most 16)
+constexpr int kKeepT = 8;   // extra insertion steps (all lanes in lockstep) only while a ring of the wave holds more
+constexpr int kSeedDepth = 6;            // LDS ring of the seed pass: tiles of the h plane (8 KB each), 2 used + 4 ahead
 constexpr int kSeedTile = kTriTile / 3;  // bytes of one plane of a tile
 // |approximate - exact| <= kSeedErr |a| max_j |b_j|: bf16 rounding of both operands (2 x 2^-8 + 2^-16, summed over
 // the channels by Cauchy-Schwarz) + fp32 accumulation of either product (< 2^-15); 0.0085 leaves 8 % of slack
@@ -76,7 +76,24 @@ __device__ __forceinline__ double pack_wj_t(float w, unsigned int j) {
   return __longlong_as_double(__double_as_longlong((double)w) | (long long)j);
 }
 
-// SEED: run the seed pass (Nk * 4 bytes of key norms must fit the candidate ring's LDS: Nk <= 16384)
+// value held by the partner half-lane (lane ^ 32): v_permlane32_swap exchanges the upper half of its first
+// register with the lower half of its second one -- no LDS crossbar, no wait (h = lane >> 5)
+__device__ __forceinline__ unsigned partner32(unsigned v, int h) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return h ? r[0] : r[1];
+}
+__device__ __forceinline__ double partner64(double v, int h) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = partner32((unsigned)u, h), hi = partner32((unsigned)(u >> 32), h);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// SEED: run the seed pass (Nk * 4 bytes of key norms must fit the candidate ring's LDS).
+// Workgroup = 8 waves = 256 queries, two waves per SIMD (w and w + 4).  The two waves of a SIMD run the tile's two
+// phases in OPPOSITE order: the low wave [Gram product of tile t][filter + insertion step of tile t], the high
+// wave [filter + insertion step of tile t-1][Gram product of tile t] -- each wave's vector work runs while its
+// partner owns the matrix pipe, a wave needs one accumulator, and every wave does the same fixed amount of
+// selection work per tile (no wave waits at the tile barrier for another one's drain).
 template <int KN, bool SEED>
 __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict__ Qimg, int Nq,
                                                          const char* __restrict__ Kimg, int Nk,
@@ -86,8 +103,7 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
   constexpr int NT = 512, NW = 8;
   constexpr int KH = (KN + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  float* bns = reinterpret_cast<float*>(smem_c + 2 * kTriTile);  // 2 x 32 key norms
-  int* vote = reinterpret_cast<int*>(bns + 64);                  // 2 overflow flags (tile parity), padded to 16 B
+  float* bns = reinterpret_cast<float*>(smem_c + 2 * kTriTile);  // 2 x 32 accumulator start values -|b_j|^2/2
   float* qa = bns + 68;                                          // kCapT x NT ring: accumulator values
   unsigned short* qj = reinterpret_cast<unsigned short*>(qa + kCapT * NT);  // ring: key codes 16 t + r
 
@@ -102,6 +118,19 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
   const char* Kb = Kimg + (long)b * ntiles * kTriTile;
   const float* knb = knorm + (long)b * Nk;
 
+#ifdef SAMBLE_KNN_STAMP
+  long long st_t0 = clock64(), st_seed = 0, st_prod = 0, st_drain = 0, st_bar = 0, st_steps = 0, st_tmp;
+  long long st_f = 0, st_a = 0, st_i = 0, st_c = 0, st_x;
+#define XB() st_x = clock64()
+#define XE(acc) acc += clock64() - st_x
+#define STAMP_BEGIN() st_tmp = clock64()
+#define STAMP_END(acc) acc += clock64() - st_tmp
+#else
+#define STAMP_BEGIN()
+#define STAMP_END(acc)
+#define XB()
+#define XE(acc)
+#endif
   u32x4 q[24];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * kTriTile +
@@ -117,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
   const float half_an = 0.5f * an;
 
   // ---- seed pass: lower bound of this query's K-th best accumulator value --------------------------------
-  float cut0 = -__builtin_huge_valf();
+  float cut = -__builtin_huge_valf();
   if (SEED) {
     float* nrm = qa;                                   // all Nk key norms (the ring is not in use yet)
     float* red = bns;                                  // 8 partial maxima
@@ -125,16 +154,16 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     // tid = 32 g + r fetches it, the plane lands compact (chunk tid at tid * 16)
     auto glds_h = [&](int t) {
       const char* gt = Kb + (long)min(t, ntiles - 1) * kTriTile + ((3 * (tid >> 5)) * 32 + (tid & 31)) * 16;
-      char* lt = smem_c + (t & (kSeedDepth - 1)) * kSeedTile + wave * 1024;
+      char* lt = smem_c + (t % kSeedDepth) * kSeedTile + wave * 1024;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gt,
                                        (__attribute__((address_space(3))) void*)lt, 16, 0, 0);
     };
 #pragma unroll
-    for (int t = 0; t < kSeedDepth - 1; ++t) glds_h(t);
+    for (int t = 0; t < kSeedDepth - 2; ++t) glds_h(t);
     float bmax = 0.f;
     for (int j = tid; j < ntiles * 32; j += NT) {
       const float v = (j < Nk) ? knb[j] : 0.f;
-      nrm[j] = v;
+      nrm[j] = -0.5f * v;  // the accumulator's start value
       bmax = fmaxf(bmax, v);
     }
 #pragma unroll
@@ -144,16 +173,16 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
 #pragma unroll
     for (int s = 0; s < KH; ++s) G[s] = -__builtin_huge_valf();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int t = 0; t < ntiles; ++t) {
-      glds_h(t + kSeedDepth - 1);  // its slot was read one iteration ago
+    // one tile of the seed pass: leading partial product, maximum over the lane's 16 keys, sorted insertion
+    auto seed_tile = [&](int t) {
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 v4 = *reinterpret_cast<const f32x4*>(nrm + t * 32 + 8 * g + 4 * h);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = -0.5f * v4[e];
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
       }
-      const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t & (kSeedDepth - 1)) * kSeedTile) + 32 * h + lo;
+      const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % kSeedDepth) * kSeedTile) + 32 * h + lo;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) acc = mfma_bf(lp[64 * ks], q[3 * ks], acc);
       if ((t + 1) * 32 > Nk) {
@@ -161,14 +190,23 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
         for (int r = 0; r < 16; ++r)
           if (t * 32 + crow(r, h) >= Nk) acc[r] = -__builtin_huge_valf();
       }
-      float gm = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+      float gm = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);  // v_max3_f32
 #pragma unroll
-      for (int r = 4; r < 16; r += 4) gm = fmaxf(gm, fmaxf(fmaxf(acc[r], acc[r + 1]), fmaxf(acc[r + 2], acc[r + 3])));
+      for (int r = 3; r < 15; r += 2) gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[r]), acc[r + 1]);
+      gm = fmaxf(gm, acc[15]);
+      // sorted insertion into the descending list: G[s] <- max(G[s], min(G[s-1], gm)) = median(G[s-1], G[s], gm)
 #pragma unroll
-      for (int s = KH - 1; s > 0; --s) G[s] = fmaxf(G[s], fminf(G[s - 1], gm));
+      for (int s = KH - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
       G[0] = fmaxf(G[0], gm);
-      // tile t+1 has landed for this wave once at most the two youngest DMAs (t+2, t+3) are in flight
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kSeedDepth - 2) : "memory");
+    };
+    // two tiles per barrier; tiles 2i+2 .. 2i+5 are in flight or landed while 2i, 2i+1 are used
+    for (int t = 0; t < ntiles; t += 2) {
+      glds_h(t + kSeedDepth - 2);  // their slots were read one iteration ago
+      glds_h(t + kSeedDepth - 1);
+      seed_tile(t);
+      if (t + 1 < ntiles) seed_tile(t + 1);  // (uniform branch)
+      // tiles t+2, t+3 have landed for this wave once at most the two youngest DMAs remain
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     float bm = red[0];
 #pragma unroll
@@ -176,9 +214,12 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     const float T = fminf(G[KH - 1], __shfl_xor(G[KH - 1], 32, 64));
     const float err = kSeedErr * sqrtf(an) * sqrtf(bm) * 1.0001f;
     const float c = T - err;
-    cut0 = c - fabsf(c) * 0x1p-21f - 0x1p-100f;  // (-inf stays -inf: fewer than KH tiles per half)
+    cut = c - fabsf(c) * 0x1p-21f - 0x1p-100f;  // (-inf stays -inf: fewer than KH tiles per half)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // seed ring, norms, red are free
   }
+#ifdef SAMBLE_KNN_STAMP
+  st_seed = clock64() - st_t0;
+#endif
 
   auto glds = [&](int t, int buf) {
     const char* gt = Kb + (long)min(t, ntiles - 1) * kTriTile;
@@ -190,125 +231,183 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
                                        0);
   };
   glds(0, 0);
-  if (tid < 32) bns[tid] = (tid < Nk) ? knb[tid] : 0.f;
-  if (tid < 2) vote[tid] = 0;
+  if (tid < 32) bns[tid] = (tid < Nk) ? -0.5f * knb[tid] : 0.f;
 
-  double L[KN];
+  // The K-list of a query is ONE sorted list split by rank over its two half-lanes: lane (i, 0) keeps the KH best
+  // (ranks 0 .. KH-1), lane (i, 1) ranks KH .. 2 KH - 1 (32 registers per lane instead of 64).  Packed doubles
+  // (w bits | index: one v_max_f64 + v_min_f64 per slot, ties by index).  An insertion step handles one candidate
+  // of the ROW (the low half's ring first): lane 0 inserts it, the element that falls off lane 0's list goes to
+  // lane 1, which inserts it one step later (`pend`).  No merge at the end; the row's K-th best is lane 1's last.
+  double L[KH];
 #pragma unroll
-  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
+  for (int s = 0; s < KH; ++s) L[s] = __builtin_huge_val();
+  double pend = __builtin_huge_val();
   // A candidate passes when acc >= cut, cut a shade BELOW |a|^2/2 - bound: the filter lets through a
   // superset of {w <= bound} whatever the rounding of the two subtractions (an extra candidate only costs
   // an insertion that falls off the list); w itself is formed when a candidate is inserted.
-  float cut = cut0;
   int head = 0, tail = 0;  // ring positions of this lane (monotonic; slot = position & (kCapT-1))
 
   auto insert_step = [&]() {
-    const bool valid = head < tail;
+    const bool v_own = head < tail;
     const int slot = (head & (kCapT - 1)) * NT + tid;
     const unsigned code = qj[slot];
     const float w = fmaxf(half_an - qa[slot], 0.f);
     const unsigned j = (code >> 4) * 32 + crow(code & 15, h);
-    const double xd = valid ? pack_wj_t(w, j) : __builtin_huge_val();
-    insert_packed_t<KN>(L, xd);
-    head += valid ? 1 : 0;
+    const double x_own = v_own ? pack_wj_t(w, j) : __builtin_huge_val();
+    const double x_p = partner64(x_own, h);                // the partner half-lane's candidate (+inf: none)
+    const bool v_p = x_p < __builtin_huge_val();
+    // lane 0 inserts the row's candidate (its own first), lane 1 the element that left lane 0 last step
+    const double ins = h == 0 ? (v_own ? x_own : x_p) : pend;
+    const double y = fmax(L[KH - 1], ins);                 // what leaves this lane's list
+    insert_packed_t<KH>(L, ins);
+    const double y_p = partner64(y, h);
+    pend = h == 1 ? y_p : __builtin_huge_val();
+    head += (h == 0 ? v_own : (v_own && !v_p)) ? 1 : 0;
   };
   auto update_cut = [&]() {
-    const double mid = L[KH - 1];
-    const double pmid = __shfl_xor(mid, 32, 64);
-    const double lim = fmin(L[KN - 1], fmax(mid, pmid));
-    const float thr = (float)lim;  // the index bits are far below half a float ulp: this is exactly lim's w
+    // lane 1's last entry bounds the row's K-th best from above (exactly it, once `pend` has been inserted)
+    const double mine = L[KH - 1];
+    const double theirs = partner64(mine, h);
+    const float thr = (float)(h == 1 ? mine : theirs);  // the index bits are far below half a float ulp
     const float c = half_an - thr;
-    cut = fmaxf(cut0, c - fabsf(c) * 0x1p-21f - 0x1p-100f);
+    cut = fmaxf(cut, c - fabsf(c) * 0x1p-21f - 0x1p-100f);
   };
-  __syncthreads();  // tile 0 and its norms have landed
-
-  // The two waves of a SIMD (w and w + 4) run the tile's two phases in opposite order -- insertion steps
-  // (vector ALU) first in one, Gram product (matrix pipe) first in the other -- so the pipes overlap
-  // although every wave issues in order and the workgroup meets at a barrier every tile.
-  const bool mfma_first = wave < 4;
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1, nxt = cur ^ 1;
-    const int j0 = t * 32;
-    glds(t + 1, nxt);  // buffer nxt was last read one iteration ago
-    const int jn = j0 + 32 + (tid & 31);
-    const float nb = (jn < Nk) ? knb[jn] : 0.f;
-    // every tile each WAVE inserts until its fullest ring holds at most kKeepT entries (lanes insert in
-    // lockstep, so a step is well used only while most lanes have a candidate)
-    auto drain_steps = [&]() {
-      if (__any(tail - head > kKeepT)) {
-        do insert_step();
-        while (__any(tail - head > kKeepT));
-        update_cut();
-      }
-    };
-    if (!mfma_first) {
-      drain_steps();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // accumulator starts at -|b_j|^2/2 of its 16 keys (rows crow(r, h))
+  // Gram product of the tile in buffer `buf` (norm slot `buf`): accumulator starts at -|b_j|^2/2 of its 16 keys
+  auto products = [&](int buf) {
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(bns + cur * 32 + 8 * g + 4 * h);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(bns + buf * 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * g + e] = -0.5f * v4[e];
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
     }
-    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + cur * kTriTile + tri_rm_off(lo, h, 0));
+    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + buf * kTriTile + tri_rm_off(lo, h, 0));
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
       const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
       acc = mfma_tri(a, bq, acc);
     }
-    const bool tail_tile = j0 + 32 > Nk;
+    return acc;
+  };
+  // filter of tile tt's accumulator into the ring + ONE insertion step (~0.8 candidates per row and tile arrive
+  // against the one served) + the bound; extra steps only while a ring of the wave is filling up
+  // Selection work of one tile (accumulator `acc` of tile tt):
+  //   filter  d_r = acc_r - cut, sign bits collected by v_alignbit: two vector instructions per element, no
+  //           per-element address arithmetic (~2.5 % of the elements pass after the seed);
+  //   append  only the lanes that have passing elements copy them (value picked out of the 16 registers by a
+  //           select tree -- no LDS round trip -- + key code) into their candidate ring, one per lane and
+  //           iteration (typically 2-3 iterations per tile);
+  //   insert  ONE insertion step (~0.8 candidates per row and tile arrive against the one served), more only
+  //           while a ring of the wave is filling up; then the bound.
+  const unsigned validbits_last = [&]() {  // bit (15 - r) set: key crow(r, h) of the LAST tile exists
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= ((ntiles - 1) * 32 + crow(r, h) < Nk) ? (1u << (15 - r)) : 0u;
+    return m;
+  }();
+  auto select = [&](const f32x16 acc, int tt) {
+    XB();
+    unsigned sb = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      bool pass = acc[r] >= cut;
-      if (tail_tile) pass = pass && (j0 + crow(r, h) < Nk);
-      const int slot = (tail & (kCapT - 1)) * NT + tid;
-      qa[slot] = acc[r];
-      qj[slot] = (unsigned short)(16 * t + r);
-      tail += pass ? 1 : 0;
+      const float d = acc[r] - cut;  // >= 0 (sign bit clear) <=> passes; exact in sign
+      sb = __builtin_amdgcn_alignbit(sb, __float_as_uint(d), 31);  // sb = (sb << 1) | sign(d)
     }
-    if (mfma_first) {
-      __builtin_amdgcn_sched_barrier(0);
-      drain_steps();
+    unsigned bits = ~sb & 0xFFFFu;  // bit (15 - r): element r passes
+    if (tt == ntiles - 1) bits &= validbits_last;
+    // room for this tile's candidates (at most 16 of them)
+    while (__any(tail - head + (int)__popc(bits) > kCapT)) insert_step();
+    XE(st_f);
+    XB();
+    while (__any(bits != 0)) {
+      const int pos = __builtin_ctz(bits | 0x10000u);
+      const int r = 15 - pos;  // (-1 for a lane without candidates: it writes nothing)
+      // acc[r] by a select tree over the four bits of r
+      const bool b0 = r & 1, b1 = r & 2, b2 = r & 4;
+      const float e0 = b0 ? acc[1] : acc[0], e1 = b0 ? acc[3] : acc[2], e2 = b0 ? acc[5] : acc[4];
+      const float e3 = b0 ? acc[7] : acc[6], e4 = b0 ? acc[9] : acc[8], e5 = b0 ? acc[11] : acc[10];
+      const float e6 = b0 ? acc[13] : acc[12], e7 = b0 ? acc[15] : acc[14];
+      const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+      const float v2[2] = {b2 ? f1 : f0, b2 ? f3 : f2};
+      const float val = (r & 8) ? v2[1] : v2[0];
+      if (bits != 0) {
+        const int slot = (tail & (kCapT - 1)) * NT + tid;
+        qa[slot] = val;
+        qj[slot] = (unsigned short)(16 * tt + r);
+        ++tail;
+      }
+      bits &= bits - 1;
     }
-    if (tid < 32) bns[nxt * 32 + tid] = nb;
-    // the tile barrier doubles as the overflow vote (a ring may take 16 more entries next tile): one flag
-    // per tile parity, set by any wave that has a full ring, cleared two tiles later
-    if (__any(tail - head > kCapT - 16)) vote[cur] = 1;
-    if (tid == 0) vote[nxt] = 0;
-    __syncthreads();
-    if (vote[cur]) {
-      while (__any(tail - head > 4)) insert_step();
-      update_cut();
+    XE(st_a);
+    XB();
+    insert_step();  // (a fixed step per tile beats purely adaptive drains: 262 vs 288-302 us -- every wave does the same work)
+    while (__any(tail - head > kKeepT)) {
+      insert_step();
+#ifdef SAMBLE_KNN_STAMP
+      ++st_steps;
+#endif
     }
-  }
-  while (__any(tail > head)) insert_step();
+    XE(st_i);
+    XB();
+    update_cut();
+    XE(st_c);
+  };
+  __syncthreads();  // tile 0 and its norms have landed
 
-  // merge the two halves of every query through LDS (the whole dynamic region is free now)
-  double* mg = reinterpret_cast<double*>(smem_c);
-  __syncthreads();
+  const bool mfma_first = wave < 4;
+  f32x16 acc;  // high waves: the accumulator of the previous tile, filtered at the start of the next iteration
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    glds(t + 1, nxt);  // buffer nxt was last read one iteration ago
+    const int jn = t * 32 + 32 + (tid & 31);
+    const float nb = (jn < Nk) ? -0.5f * knb[jn] : 0.f;
+    STAMP_BEGIN();
+    if (mfma_first) {
+      acc = products(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP_END(st_prod);
+      STAMP_BEGIN();
+      select(acc, t);
+      STAMP_END(st_drain);
+    } else {
+      if (t > 0) select(acc, t - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      STAMP_END(st_drain);
+      STAMP_BEGIN();
+      acc = products(cur);
+      STAMP_END(st_prod);
+    }
+    STAMP_BEGIN();
+    if (tid < 32) bns[nxt * 32 + tid] = nb;
+    __syncthreads();
+    STAMP_END(st_bar);
+  }
+  if (!mfma_first) select(acc, ntiles - 1);
+#ifdef SAMBLE_KNN_STAMP
+  const long long st_loop = clock64() - st_t0;
+#endif
+  while (__any(tail > head)) insert_step();
+  insert_step();  // lane 1 takes in the last element handed over
+
+#ifdef SAMBLE_KNN_STAMP
+  if (d2_out && lane == 0) {  // diagnostic build: the distance output carries the stamps of (cloud, chunk, wave)
+    float* o = d2_out + ((long)b * Nq + chunk * (32 * NW) + wave * 32) * KN;
+    o[0] = (float)st_seed; o[1] = (float)st_prod; o[2] = (float)st_drain; o[3] = (float)st_bar;
+    o[4] = (float)st_loop; o[5] = (float)(clock64() - st_t0); o[6] = (float)st_steps; o[7] = (float)tail;
+    o[8] = (float)st_f; o[9] = (float)st_a; o[10] = (float)st_i; o[11] = (float)st_c;
+  }
+  if (d2_out) return;
+#endif
+  // ranks KH h .. KH h + KH - 1 of query i sit in lane (i, h): nearest first, ties by ascending index
+  if (ivalid) {
+    int* io = idx_out + ((long)b * Nq + i) * KN + KH * h;
+    float* dout = d2_out ? d2_out + ((long)b * Nq + i) * KN + KH * h : nullptr;
 #pragma unroll
-  for (int s = 0; s < KN; ++s) mg[s * NT + tid] = L[s];
-  __syncthreads();
-  if (h == 0 && ivalid) {
-    int pa = 0, pb = 0;
-    double va = mg[tid], vb = mg[tid + 32];
-    int* io = idx_out + ((long)b * Nq + i) * KN;
-    float* dout = d2_out ? d2_out + ((long)b * Nq + i) * KN : nullptr;
-    for (int k = 0; k < KN; ++k) {
-      const bool take = va <= vb;
-      const double o = take ? va : vb;
-      io[k] = (int)(__double_as_longlong(o) & 0x1FFFFFFFll);
-      if (dout) dout[k] = 2.f * (float)o;
-      if (take) {
-        ++pa;
-        va = (pa < KN) ? mg[pa * NT + tid] : __builtin_huge_val();
-      } else {
-        ++pb;
-        vb = (pb < KN) ? mg[pb * NT + tid + 32] : __builtin_huge_val();
+    for (int s2 = 0; s2 < KH; ++s2) {
+      if (KH * h + s2 < KN) {
+        io[s2] = (int)(__double_as_longlong(L[s2]) & 0x1FFFFFFFll);
+        if (dout) dout[s2] = 2.f * (float)L[s2];
       }
     }
   }
@@ -318,10 +417,8 @@ template <int KN>
 static int launch_knn_tri(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
                           const float* knorm, int* idx, float* d2, hipStream_t s) {
   constexpr int NT = 512;
-  size_t lds = (size_t)2 * kTriTile + 68 * 4 + (size_t)kCapT * NT * 4 + (size_t)kCapT * NT * 2;
-  const size_t merge = (size_t)KN * NT * 8;
-  if (merge > lds) lds = merge;
-  const bool seed = (size_t)((Nk + 31) / 32) * 32 * 4 <= (size_t)kCapT * NT * 4;
+  const size_t lds = (size_t)2 * kTriTile + 68 * 4 + (size_t)kCapT * NT * 4 + (size_t)kCapT * NT * 2;
+  const bool seed = (size_t)((Nk + 31) / 32) * 32 * 4 <= (size_t)kCapT * NT * 6;
   auto kern = seed ? knn_tri_kernel<KN, true> : knn_tri_kernel<KN, false>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);

@@ -157,10 +157,15 @@ def test_stress_size_properties():
     finally:
         D.TWO_PASS = True
     # the two paths round the logits differently (split-bf16 products vs one fp32 MFMA chain): a sampled
-    # index may flip only where two scores tie to the last bits
+    # index may flip where two scores tie to the last bits, and a cloud's per-bin counts may move by one pick
+    # where the float water-filling lands on an integer (reference utils/ops.py:403-424) -- which shifts every
+    # later position of that cloud.  So: sets nearly identical everywhere; positions compared on the clouds whose
+    # counts agree (most of them)
     assert set_agreement(idx1[:, 0].cpu(), idx[:, 0].cpu()) >= 0.999
+    same_counts = (mod1.k_point_to_choose == mod.k_point_to_choose).all(1)
+    assert int(same_counts.sum()) >= (3 * B) // 4, int(same_counts.sum())
     same = idx1[:, 0] == idx[:, 0]                     # (B, M) positions holding the same point
-    assert float(same.float().mean()) >= 0.99
+    assert float(same[same_counts].float().mean()) >= 0.99
     keep = same[:, None, :].expand_as(x_ds)
     torch.testing.assert_close(x_ds1[keep], x_ds[keep], rtol=1e-4, atol=2e-5)
     if bool(same.all()):

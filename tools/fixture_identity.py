@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-fixture, per-cloud identity of the module's sampled indices with the reference's (both matrix modes):
+the measured table that tests/test_gpu_module.py pins.  Run on the GPU box."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from samble_amd import ops
+from tests.util import Golden, golden_names
+
+out = {}
+for mode in ("tri", "f32"):
+    ops.MATRIX_MODE = mode
+    for name in golden_names():
+        g = Golden(name)
+        mod = g.module("cuda:0")
+        rows = []
+        for call in range(g.calls):
+            noise = None if g.sample_mode == "topk" else g.t("noise", call).to("cuda:0")
+            (x_ds, idx), _ = mod(g.x(call).to("cuda:0"), noise=noise)
+            same = (idx.cpu()[:, 0] == g.t("idx", call)[:, 0]).all(1)
+            cdiff = (mod.k_point_to_choose.cpu() != g.t("counts", call)).any(1)
+            rows.append({"same": same.int().tolist(), "counts_differ": cdiff.int().tolist()})
+        out[f"{mode}/{name}"] = rows
+print(json.dumps(out, indent=1))
