@@ -131,17 +131,13 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
 #define XB()
 #define XE(acc)
 #endif
+  // query operand: the h plane now (all the seed pass needs), the m and l planes after it -- 64 registers that
+  // the seed loop would otherwise push into the accumulation registers
   u32x4 q[24];
-  {
-    const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * kTriTile +
-                                                     tri_rm_off(qrow & 31, h, 0));
+  const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * kTriTile +
+                                                   tri_rm_off(qrow & 31, h, 0));
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      q[3 * ks] = qp[192 * ks];
-      q[3 * ks + 1] = qp[192 * ks + 32];
-      q[3 * ks + 2] = qp[192 * ks + 64];
-    }
-  }
+  for (int ks = 0; ks < 8; ++ks) q[3 * ks] = qp[192 * ks];
   const float an = qnorm[(long)b * Nq + qrow];
   const float half_an = 0.5f * an;
 
@@ -174,7 +170,8 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     for (int s = 0; s < KH; ++s) G[s] = -__builtin_huge_valf();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // one tile of the seed pass: leading partial product, maximum over the lane's 16 keys, sorted insertion
-    auto seed_tile = [&](int t) {
+    auto seed_tile = [&](int t, auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;  // the last tile: padding keys past Nk must not count
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -184,8 +181,14 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
       }
       const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % kSeedDepth) * kSeedTile) + 32 * h + lo;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) acc = mfma_bf(lp[64 * ks], q[3 * ks], acc);
-      if ((t + 1) * 32 > Nk) {
+#ifndef SAMBLE_KNN_SEEDABL
+#define SAMBLE_KNN_SEEDABL 0
+#endif
+      for (int ks = 0; ks < 8; ++ks) {
+        if (SAMBLE_KNN_SEEDABL & 1) acc[ks] += __uint_as_float(lp[64 * ks][0] ^ q[3 * ks][1]);
+        else acc = mfma_bf(lp[64 * ks], q[3 * ks], acc);
+      }
+      if (MASKED) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (t * 32 + crow(r, h) >= Nk) acc[r] = -__builtin_huge_valf();
@@ -196,18 +199,25 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
       gm = fmaxf(gm, acc[15]);
       // sorted insertion into the descending list: G[s] <- max(G[s], min(G[s-1], gm)) = median(G[s-1], G[s], gm)
 #pragma unroll
-      for (int s = KH - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
+      for (int s = KH - 1; s > 0 && !(SAMBLE_KNN_SEEDABL & 2); --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
       G[0] = fmaxf(G[0], gm);
     };
-    // two tiles per barrier; tiles 2i+2 .. 2i+5 are in flight or landed while 2i, 2i+1 are used
-    for (int t = 0; t < ntiles; t += 2) {
-      glds_h(t + kSeedDepth - 2);  // their slots were read one iteration ago
-      glds_h(t + kSeedDepth - 1);
-      seed_tile(t);
-      if (t + 1 < ntiles) seed_tile(t + 1);  // (uniform branch)
+    // two FULL tiles per barrier; tiles t+2 .. t+5 are in flight or landed while t, t+1 are used
+    const int nfull = Nk / 32;
+    int t = 0;
+    for (; t + 2 <= nfull; t += 2) {
+      if (!(SAMBLE_KNN_SEEDABL & 4)) {
+        glds_h(t + kSeedDepth - 2);  // their slots were read one iteration ago
+        glds_h(t + kSeedDepth - 1);
+      }
+      seed_tile(t, std::false_type{});
+      seed_tile(t + 1, std::false_type{});
       // tiles t+2, t+3 have landed for this wave once at most the two youngest DMAs remain
       asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    // the remaining one or two tiles (the last one may hold padding keys); their DMAs were issued above
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (; t < ntiles; ++t) seed_tile(t, std::true_type{});
     float bm = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
@@ -220,6 +230,11 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
 #ifdef SAMBLE_KNN_STAMP
   st_seed = clock64() - st_t0;
 #endif
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    q[3 * ks + 1] = qp[192 * ks + 32];
+    q[3 * ks + 2] = qp[192 * ks + 64];
+  }
 
   auto glds = [&](int t, int buf) {
     const char* gt = Kb + (long)min(t, ntiles - 1) * kTriTile;
