@@ -159,12 +159,58 @@ class _P2PCore(torch.autograd.Function):
         return dqkv
 
 
+def _heads_as_batches(qkv: torch.Tensor, heads: int, asm: str) -> torch.Tensor:
+    """(B,N,3C) projection rows -> (B*H, N, 3C) operands for the one-head-of-C attention kernels such that
+    batch b*H + h computes head h of `asm` scoring with depth D = C / H:
+
+      Q' = s * q restricted to head h's channels (zeros elsewhere), s = sqrt(C / D) undoes the kernel's 1/sqrt(C);
+      K' = k, V' = v (the contraction only sees head h's channels of K'; the output's head-h channels are head h).
+      l2 / l2+ (reference attention.py:345-349, energy = -+|q - k|^2): the row term |q_i|^2 cancels in the softmax,
+      the key term rides in a channel that head h does not use: Q'[c*] = s, K'[c*] = -+|k_h|^2, and the dot part
+      is scaled by +-2.  Needs a free channel, i.e. H >= 2.
+
+    Built from differentiable torch ops: autograd carries the gradients back to q, k, v."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    D = C // heads
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    head_of = torch.arange(C, device=qkv.device) // D                                  # (C,)
+    own = (head_of.unsqueeze(0) == torch.arange(heads, device=qkv.device).unsqueeze(1)).to(qkv.dtype)  # (H,C)
+    s = (C / D) ** 0.5
+    sign = {"dot": 1.0, "l2": 2.0, "l2+": -2.0}[asm]
+    qe = q.unsqueeze(1) * (own * (s * sign)).view(1, heads, 1, C)                      # (B,H,N,C)
+    ke = k.unsqueeze(1).expand(-1, heads, -1, -1)
+    if asm != "dot":
+        if heads < 2:
+            raise NotImplementedError("asm l2 / l2+ needs num_heads >= 2 here (a free channel carries the key norms)")
+        spare = ((torch.arange(heads, device=qkv.device) + 1) % heads) * D             # first channel of another head
+        k_sq = (k.unsqueeze(1) * own.view(1, heads, 1, C)).square().sum(-1)            # (B,H,N) |k_h|^2
+        onehot = torch.zeros(heads, C, dtype=qkv.dtype, device=qkv.device)
+        onehot[torch.arange(heads), spare] = 1.0
+        bias_sign = -1.0 if asm == "l2" else 1.0
+        qe = qe + (s * onehot).view(1, heads, 1, C)
+        ke = ke * (1.0 - onehot).view(1, heads, 1, C) + (bias_sign * k_sq).unsqueeze(-1) * onehot.view(1, heads, 1, C)
+    ve = v.unsqueeze(1).expand(-1, heads, -1, -1)
+    return torch.cat((qe, ke.expand(B, heads, N, C), ve), dim=-1).reshape(B * heads, N, 3 * C)
+
+
+def _own_head_channels(out: torch.Tensor, B: int, heads: int) -> torch.Tensor:
+    """(B*H, C, N) per-head outputs -> (B, C, N): channel block h taken from head h's batch entry."""
+    _, C, N = out.shape
+    D = C // heads
+    blocks = out.view(B, heads, heads, D, N)
+    return torch.diagonal(blocks, dim1=1, dim2=2).permute(0, 3, 1, 2).reshape(B, C, N)
+
+
 class Point2PointAttention(nn.Module):
-    """Drop-in for the reference's global self-attention layer (models/attention.py:253-355, asm 'dot'):
-    same constructor, state_dict keys (`q_conv/k_conv/v_conv.weight` (C,C,1), `ff.*`, `bn1/bn2.*`) and
-    forward (B,C,N) -> (B,C,N).  Built on the sampler's kernels for ONE head of 128 channels (the
-    fp32-MFMA projection and the flash attention forward / backward); the reference default of 4 heads
-    of 32 channels needs a D = 32 kernel that does not exist yet."""
+    """Drop-in for the reference's global self-attention layer (models/attention.py:253-355): same constructor,
+    state_dict keys (`q_conv/k_conv/v_conv.weight` (C,C,1), `ff.*`, `bn1/bn2.*`) and forward (B,C,N) -> (B,C,N),
+    `asm` dot / l2 / l2+, any head count dividing 128 (reference default: 4 heads of 32).
+
+    Runs on the sampler's kernels (HIP projection + single-pass flash attention forward / backward for one head
+    of 128 channels, no N x N tensor): the H heads become H batch entries whose queries are zero outside their
+    head's channels (`_heads_as_batches`), so a head of depth 32 costs what a head of 128 does -- the layer is
+    a secondary consumer (no shipped config selects it), correctness first."""
 
     def __init__(self, config_attention, layer):
         num_heads = config_attention.num_heads[layer]
@@ -173,7 +219,7 @@ class Point2PointAttention(nn.Module):
         v_in, v_out = config_attention.v_in[layer], config_attention.v_out[layer]
         super().__init__()
         self.attention_mode = config_attention.attention_mode[layer]
-        self.asm = config_attention.asm[layer]
+        self.asm = config_attention.asm[layer] if hasattr(config_attention, "asm") else "dot"
         if q_in != k_in or q_in != v_in or k_in != v_in:
             raise ValueError(f"q_in, k_in and v_in should be the same! Got q_in:{q_in}, k_in:{k_in}, v_in:{v_in}")
         if q_out != k_out:
@@ -199,12 +245,12 @@ class Point2PointAttention(nn.Module):
         )
         self.bn1 = nn.BatchNorm1d(v_out)
         self.bn2 = nn.BatchNorm1d(v_out)
-        if self.asm != "dot":
-            if self.asm in ("l2", "l2+"):
-                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (only 'dot')")
+        if self.asm not in ("dot", "l2", "l2+"):
             raise ValueError("Please check the setting of asm in feature learning layer!")
-        if num_heads != 1 or not (q_in == q_out == v_out == 128):
-            raise NotImplementedError("the HIP attention kernels are built for one head of 128 channels")
+        if not (q_in == q_out == v_out == 128):
+            raise NotImplementedError("the HIP attention kernels are built for 128 channels")
+        if self.asm != "dot" and num_heads < 2:
+            raise NotImplementedError("asm l2 / l2+ with a single head of 128 channels is not built (no free channel)")
 
     def forward(self, x):
         if not x.is_cuda:
@@ -212,7 +258,11 @@ class Point2PointAttention(nn.Module):
         from .downsample import _Projection
         no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
         qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
-        x_tmp = _P2PCore.apply(qkv)
+        if self.num_heads == 1:
+            x_tmp = _P2PCore.apply(qkv)
+        else:
+            x_tmp = _own_head_channels(_P2PCore.apply(_heads_as_batches(qkv, self.num_heads, self.asm)), x.shape[0],
+                                       self.num_heads)
         x = self.bn1(x + x_tmp)
         x_tmp = self.ff(x)
         x = self.bn2(x + x_tmp)

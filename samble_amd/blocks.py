@@ -1,10 +1,16 @@
-"""`FeatureLearningBlock` wiring of the reference's classification model (models/cls_model.py:10-145)
-for the shipped path (`ds_which: token`, `fl_which: n2p`), built from the drop-in modules of this
-package.  It reproduces the CALL PROTOCOL only -- submodule names (hence state_dict keys), the order
-EdgeConv x2 -> N2P -> [DownSampleToken -> N2P -> gather_by_idx(xyz)] x2, the res-link max-pool heads --
-so that a reference checkpoint of the block loads and the sampler can be exercised mid-network.
-The MLP head, STN and the segmentation decoder are out of scope."""
+"""Test / bench harness around the drop-in layers: the encoder (and, for segmentation, decoder) of the reference's
+feature-learning blocks, so that the sampler can be exercised mid-network and a reference checkpoint of a block
+loads (BASELINE.json configs[1] and configs[2]).
+
+Only the CONTRACT is taken from the reference (models/cls_model.py:10-145, models/seg_model.py:7-133): the
+submodule attribute names -- they are the state_dict keys -- and what each layer is fed.  The control flow is this
+package's own: the encoder produces a list of resolution levels (`_Level`), the classification block pools each
+level, the segmentation block walks the list back up.  The MLP heads, STN and trainers stay out of scope
+(SURVEY.md section 2)."""
 from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn
@@ -14,128 +20,123 @@ from .attention import Neighbor2PointAttention, Point2PointAttention
 from .downsample import DownSampleGlobal, DownSampleLocal, DownSampleToken
 from .embedding import EdgeConv
 
+_SAMPLERS = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}
 
-class FeatureLearningBlock(nn.Module):
+
+@dataclass
+class _Level:
+    """One resolution of a cloud batch on its way through the encoder."""
+    feat: torch.Tensor                      # (B, C, n) features after this level's attention layer
+    xyz: torch.Tensor                       # (B, 3, n) coordinates of the same points
+    picked: Optional[torch.Tensor] = None   # (B, 1, n) indices of these points in the previous level
+    dropped: Tuple = (None, None)           # what the sampler set aside: (features, indices) or (None, None)
+
+
+class _Encoder(nn.Module):
+    """EdgeConv embeddings, one attention layer per resolution, one sampler between two resolutions."""
+
+    def _build_encoder(self, cfg, attention_cls):
+        sampler_cls = _SAMPLERS.get(cfg.downsample.ds_which)
+        if sampler_cls is None:
+            raise NotImplementedError(f"ds_which={cfg.downsample.ds_which!r}: token, global and local are built")
+        self.embedding_list = nn.ModuleList(EdgeConv(cfg.embedding, i) for i in range(len(cfg.embedding.K)))
+        self.downsample_list = nn.ModuleList(sampler_cls(cfg.downsample, i) for i in range(len(cfg.downsample.M)))
+        self.feature_learning_layer_list = nn.ModuleList(
+            attention_cls(cfg.attention, i) for i in range(len(cfg.attention.K)))
+
+    def _run_sampler(self, i: int, feat, xyz, noise):
+        layer = self.downsample_list[i]
+        if isinstance(layer, DownSampleToken):
+            return layer(feat, xyz, noise=noise)   # the selection noise is an explicit input (parity tests)
+        return layer(feat, xyz)
+
+    def _encode(self, xyz: torch.Tensor, noise_list: Optional[Sequence], pre_select=None) -> List[_Level]:
+        stacked = []
+        feat = xyz
+        for edge_conv in self.embedding_list:      # each EdgeConv feeds the next; all of them are concatenated
+            feat = edge_conv(feat)
+            stacked.append(feat)
+        level = _Level(self.feature_learning_layer_list[0](torch.cat(stacked, dim=1)), xyz[:, :3, :])
+        levels = [level]
+        for i in range(len(self.downsample_list)):
+            noise = noise_list[i] if noise_list is not None else None
+            feat_in, xyz_in, remap = level.feat, level.xyz, None
+            if pre_select is not None:             # farthest-point pre-selection in front of the sampler
+                feat_in, xyz_in, remap = pre_select(i, level)
+            (feat, picked), dropped = self._run_sampler(i, feat_in, xyz_in, noise)
+            if remap is not None:
+                picked = torch.gather(remap.unsqueeze(1), 2, picked)
+            level = _Level(self.feature_learning_layer_list[i + 1](feat), ops.gather_by_idx(level.xyz, picked),
+                           picked, dropped)
+            levels.append(level)
+        return levels
+
+
+class FeatureLearningBlock(_Encoder):
+    """Classification trunk: every level is projected to 1024 channels and max-pooled; the pooled vectors are
+    concatenated (`res_link.enable`), or only the last level is pooled.  Returns (B, 1024 * levels) and the list
+    of pooled vectors, like the reference block."""
+
     def __init__(self, config_feature_learning_block, fps=False):
         super().__init__()
         cfg = config_feature_learning_block
-        self.fps = fps  # reference cls_model.py:100,117-131: FPS pre-selection of 2M points before each sampler
-        self.M_list = cfg.downsample.M
-        sampler = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}.get(cfg.downsample.ds_which)
-        if sampler is None:
-            raise NotImplementedError
-        fl_which = getattr(cfg.attention, "fl_which", "n2p")
-        if fl_which not in ("n2p", "p2p"):
+        which = getattr(cfg.attention, "fl_which", "n2p")
+        if which not in ("n2p", "p2p"):
             raise ValueError("Only n2p and p2p are valid for fl_which")
-        layer_cls = Neighbor2PointAttention if fl_which == "n2p" else Point2PointAttention
-        self.res_link_enable = cfg.res_link.enable
-        self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
-        self.downsample_list = nn.ModuleList([sampler(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
-        self.feature_learning_layer_list = nn.ModuleList(
-            [layer_cls(cfg.attention, l) for l in range(len(cfg.attention.K))])
-        outs = cfg.attention.ff_conv2_channels_out
-        if self.res_link_enable:
-            self.conv_list = nn.ModuleList([nn.Conv1d(c, 1024, kernel_size=1, bias=False) for c in outs])
-        else:
-            self.conv = nn.Conv1d(outs[-1], 1024, kernel_size=1, bias=False)
+        self.fps = fps
         self.M_list = cfg.downsample.M
+        self.res_link_enable = cfg.res_link.enable
+        self._build_encoder(cfg, Neighbor2PointAttention if which == "n2p" else Point2PointAttention)
+        widths = cfg.attention.ff_conv2_channels_out
+        if self.res_link_enable:
+            self.conv_list = nn.ModuleList(nn.Conv1d(c, 1024, kernel_size=1, bias=False) for c in widths)
+        else:
+            self.conv = nn.Conv1d(widths[-1], 1024, kernel_size=1, bias=False)
 
-    def _sample(self, i, x, x_xyz, noise):
-        layer = self.downsample_list[i]
-        if isinstance(layer, DownSampleToken):
-            return layer(x, x_xyz, noise=noise)[0]
-        return layer(x, x_xyz)[0]
+    def _fps_subset(self, i: int, level: _Level):
+        """2 M_i farthest points of the level (reference cls_model.py:117-131, only with fps=True)."""
+        keep = ops.farthest_point_sample(level.xyz.permute(0, 2, 1), self.M_list[i] * 2)
+        take = keep.unsqueeze(1)
+        return (torch.gather(level.feat, 2, take.expand(-1, level.feat.shape[1], -1)),
+                torch.gather(level.xyz, 2, take.expand(-1, 3, -1)), keep)
 
     def forward(self, x, noise_list=None):
-        """x (B,3,N) xyz.  noise_list: optional per-sampler-layer Exp(1) tensors (parity tests)."""
-        x_list = []
-        x_xyz = x.clone()
-        for embedding in self.embedding_list:
-            x = embedding(x)
-            x_list.append(x)
-        x = torch.cat(x_list, dim=1)
-        x = self.feature_learning_layer_list[0](x)
-        if self.res_link_enable:
-            res_link_list = [self.conv_list[0](x).max(dim=-1)[0]]
-            for i in range(len(self.downsample_list)):
-                noise = None if noise_list is None else noise_list[i]
-                if self.fps:
-                    x_idx = ops.farthest_point_sample(torch.permute(x_xyz, (0, 2, 1)), self.M_list[i] * 2)
-                    x = torch.gather(x, 2, x_idx.unsqueeze(1).expand(-1, x.shape[1], -1))
-                    x_xyz_down = torch.gather(x_xyz, 2, x_idx.unsqueeze(1).expand(-1, 3, -1))
-                    (x, idx_select) = self._sample(i, x, x_xyz_down, noise)
-                    idx_select = torch.gather(x_idx.unsqueeze(1), 2, idx_select)
-                else:
-                    (x, idx_select) = self._sample(i, x, x_xyz, noise)
-                x = self.feature_learning_layer_list[i + 1](x)
-                x_xyz = ops.gather_by_idx(x_xyz, idx_select)
-                res_link_list.append(self.conv_list[i + 1](x).max(dim=-1)[0])
-            self.res_link_list = res_link_list
-            return torch.cat(res_link_list, dim=1), res_link_list
-        for i in range(len(self.downsample_list)):
-            noise = None if noise_list is None else noise_list[i]
-            x = self._sample(i, x, None, noise)[0]
-            x = self.feature_learning_layer_list[i + 1](x)
-        return self.conv(x).max(dim=-1)[0]
+        """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors."""
+        levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None)
+        if not self.res_link_enable:
+            return self.conv(levels[-1].feat).amax(dim=-1)
+        pooled = [head(level.feat).amax(dim=-1) for head, level in zip(self.conv_list, levels)]
+        self.res_link_list = pooled
+        return torch.cat(pooled, dim=1), pooled
 
 
-class SegFeatureLearningBlock(nn.Module):
-    """The segmentation block (reference models/seg_model.py:7-133, seg.yaml): EdgeConv x2 -> N2P ->
-    [sampler -> N2P -> gather xyz] x2 -> [UpSampleInterpolation -> N2P] x2, returning per-point features
-    (B,128,N).  Wiring only; same submodule names and state_dict keys as the reference block."""
+class SegFeatureLearningBlock(_Encoder):
+    """Segmentation trunk: the encoder's levels, then one interpolation upsampling + attention layer per level
+    on the way back up; returns per-point features (B, 128, N)."""
 
     def __init__(self, config_feature_learning_block):
         super().__init__()
         cfg = config_feature_learning_block
-        sampler = {"token": DownSampleToken, "global": DownSampleGlobal, "local": DownSampleLocal}.get(cfg.downsample.ds_which)
-        if sampler is None:
-            raise ValueError("Only global_carve and local_insert are valid for ds_which!")
         if cfg.upsample.us_which != "interpolation":
             if cfg.upsample.us_which in ("crossA", "selfA"):
                 raise NotImplementedError("us_which crossA / selfA are not built (shipped seg.yaml: interpolation)")
             raise ValueError("Only crossA and selfA are valid for us_which!")
         from .upsample import UpSampleInterpolation
-        self.embedding_list = nn.ModuleList([EdgeConv(cfg.embedding, l) for l in range(len(cfg.embedding.K))])
-        self.downsample_list = nn.ModuleList([sampler(cfg.downsample, l) for l in range(len(cfg.downsample.M))])
-        self.feature_learning_layer_list = nn.ModuleList(
-            [Neighbor2PointAttention(cfg.attention, l) for l in range(len(cfg.attention.K))])
-        self.upsample_list = nn.ModuleList([UpSampleInterpolation(cfg.upsample, l) for l in range(len(cfg.upsample.q_in))])
+        self._build_encoder(cfg, Neighbor2PointAttention)
+        self.upsample_list = nn.ModuleList(UpSampleInterpolation(cfg.upsample, i) for i in range(len(cfg.upsample.q_in)))
 
     def forward(self, x, noise_list=None):
-        x_xyz = x[:, :3, :]
-        x_list = []
-        for embedding in self.embedding_list:
-            x = embedding(x)
-            x_list.append(x)
-        x = torch.cat(x_list, dim=1)
-        x = self.feature_learning_layer_list[0](x)
-        x_list = [x]
-        points_drop_list, idx_select_list, idx_drop_list = [], [], []
-        x_xyz_list = [x_xyz]
-        for i in range(len(self.downsample_list)):
-            layer = self.downsample_list[i]
-            if isinstance(layer, DownSampleToken):
-                noise = None if noise_list is None else noise_list[i]
-                (x, idx_select), (points_drop, idx_drop) = layer(x, x_xyz, noise=noise)
-            else:
-                (x, idx_select), (points_drop, idx_drop) = layer(x, x_xyz)
-            x = self.feature_learning_layer_list[i + 1](x)
-            x_xyz = ops.gather_by_idx(x_xyz, idx_select)
-            x_list.append(x)
-            x_xyz_list.append(x_xyz)
-            points_drop_list.append(points_drop)
-            idx_select_list.append(idx_select)
-            idx_drop_list.append(idx_drop)
-        split = int((len(self.feature_learning_layer_list) - 1) / 2)
-        x = ((x_list.pop(), idx_select_list.pop(), x_xyz_list.pop()), (points_drop_list.pop(), idx_drop_list.pop()))
-        for j in range(len(self.upsample_list)):
-            x_tmp = x_list.pop()
-            x_xyz_tmp = x_xyz_list[-1 - j]
-            x = self.upsample_list[j](x_tmp, x, x_xyz_tmp)
-            x = self.feature_learning_layer_list[j + 1 + split](x)
-            if j < len(self.upsample_list) - 1:
-                x = ((x, idx_select_list.pop(), x_xyz_list[-1 - j]), (points_drop_list.pop(), idx_drop_list.pop()))
-        return x
+        levels = self._encode(x, noise_list)
+        first_decoder_layer = 1 + (len(self.feature_learning_layer_list) - 1) // 2
+        coarse = levels[-1]
+        for j, upsample in enumerate(self.upsample_list):
+            fine = levels[-2 - j]
+            # the reference's upsampling layers take the coarse side as ((features, indices, xyz), (dropped features,
+            # dropped indices)) -- kept, so that the layer stays a drop-in
+            merged = upsample(fine.feat, ((coarse.feat, coarse.picked, coarse.xyz), coarse.dropped), fine.xyz)
+            coarse = _Level(self.feature_learning_layer_list[first_decoder_layer + j](merged), fine.xyz, fine.picked,
+                            fine.dropped)
+        return coarse.feat
 
 
 def seg_block_config(M=(1024, 512)):

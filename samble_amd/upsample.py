@@ -1,14 +1,41 @@
-"""Drop-in `UpSampleInterpolation` (reference models/upsample.py:136-213), the decoder layer of the
-shipped segmentation preset (`us_which: interpolation`, `distance_type: xyz`, K = 3): cross-set
-K-nearest neighbours with reference-normalised distances run on the HIP kNN kernels
-(`ops.select_neighbors_interpolate`), inverse-distance weights and the two Conv1d+BN+LeakyReLU
-blocks are stock torch."""
+"""Drop-in `UpSampleInterpolation` (reference models/upsample.py:136-213), the decoder layer of the shipped
+segmentation preset (`us_which: interpolation`, `distance_type: xyz`, K = 3).
+
+Contract kept from the reference: the constructor's config reads, the parameter names (`conv.*`, `res_conv.*`)
+and `forward(fine_features, ((coarse_features, indices, coarse_xyz), dropped), fine_xyz)`.  The work is laid out
+this package's way: one cross-set K-nearest-neighbour search on the HIP kNN kernels (exact sum (a-b)^2 path for
+xyz, reference-normalised distances), then an inverse-distance blend of the projected coarse features."""
 from __future__ import annotations
 
 import torch
 from torch import nn
 
 from . import ops
+
+
+def _unit_block(c_in: int, c_out: int) -> nn.Sequential:
+    return nn.Sequential(nn.Conv1d(c_in, c_out, 1, bias=False), nn.BatchNorm1d(c_out), nn.LeakyReLU(negative_slope=0.2))
+
+
+def inverse_distance_blend(values: torch.Tensor, dist: torch.Tensor) -> torch.Tensor:
+    """values (B,C,N,K) neighbour features, dist (B,N,K) positive distances -> (B,C,N): weights 1/(d + 1e-8)
+    normalised over the K neighbours (reference models/upsample.py:205-213)."""
+    inv = (dist + 1e-8).reciprocal()
+    share = inv / inv.sum(dim=-1, keepdim=True)
+    return (values * share.unsqueeze(1)).sum(dim=-1)
+
+
+def _normalised_pair_distances(query: torch.Tensor, keys: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Differentiable distances between every query point and its K chosen keys, in the reference's kNN
+    normalisation (utils/ops.py:23-29: both sets centred on the query mean, divided by the mean unbiased
+    per-channel std of the queries).  query (B,C,N), keys (B,C,M), idx (B,N,K) -> (B,N,K)."""
+    q = query.transpose(1, 2)
+    k = keys.transpose(1, 2)
+    centre = q.mean(dim=1, keepdim=True)
+    q, k = q - centre, k - centre
+    scale = q.std(dim=1, keepdim=True).mean(dim=2, keepdim=True)
+    q, k = q / scale, k / scale
+    return torch.linalg.vector_norm(q.unsqueeze(2) - ops.index_points(k, idx), dim=-1)
 
 
 class UpSampleInterpolation(nn.Module):
@@ -18,42 +45,27 @@ class UpSampleInterpolation(nn.Module):
         v_out = config_upsample.v_out[layer]
         self.distance_type = config_upsample.interpolation.distance_type[layer]
         self.K = config_upsample.interpolation.K[layer]
-        self.conv = nn.Sequential(nn.Conv1d(q_in, v_out, 1, bias=False), nn.BatchNorm1d(v_out),
-                                  nn.LeakyReLU(negative_slope=0.2))
-        self.res_conv = nn.Sequential(nn.Conv1d(2 * v_out, v_out, 1, bias=False), nn.BatchNorm1d(v_out),
-                                      nn.LeakyReLU(negative_slope=0.2))
+        self.conv = _unit_block(q_in, v_out)
+        self.res_conv = _unit_block(2 * v_out, v_out)
 
     def forward(self, pcd_up, pcd_down, pcd_up_xyz):
-        (points_select, idx_select, points_select_xyz), (points_drop, idx_drop) = pcd_down
-        interpolated_points = self.interpolate(pcd_up, points_select, pcd_up_xyz, points_select_xyz,
-                                               distance_type=self.distance_type, K=self.K)
-        x = torch.concat([pcd_up, interpolated_points], dim=1)
-        return self.res_conv(x)
+        (coarse, _, coarse_xyz), _ = pcd_down
+        filled = self.interpolate(pcd_up, coarse, pcd_up_xyz, coarse_xyz, self.distance_type, self.K)
+        return self.res_conv(torch.cat((pcd_up, filled), dim=1))
 
     def interpolate(self, pcd_up, points_select, pcd_up_xyz, points_select_xyz, distance_type="feature", K=3):
-        points_select_conv = self.conv(points_select)
-        if distance_type == "xyz":
-            neighbors, _, d_neighbors = ops.select_neighbors_interpolate(pcd_up_xyz, points_select_xyz,
-                                                                         points_select_conv, K=K)
-        elif distance_type == "feature":
-            # the reference back-propagates through cdist of the (normalised) features: the neighbour SEARCH
-            # runs on the HIP kNN kernels (indices carry no gradient), the K distances per point are then
-            # recomputed differentiably for the selected pairs only (utils/ops.py:17-44 normalisation)
-            _, idx, _ = ops.select_neighbors_interpolate(pcd_up.detach(), points_select.detach(),
-                                                         points_select_conv.detach(), K=K)
-            a = pcd_up.permute(0, 2, 1)
-            b = points_select.permute(0, 2, 1)
-            a_mean = torch.mean(a, dim=1, keepdim=True)
-            a, b = a - a_mean, b - a_mean
-            a_std = torch.mean(torch.std(a, dim=1, keepdim=True), dim=2, keepdim=True)
-            a, b = a / a_std, b / a_std
-            d_neighbors = torch.linalg.vector_norm(a.unsqueeze(2) - ops.index_points(b, idx), dim=-1)  # (B,N,K)
-            neighbors = ops.index_points(points_select_conv.permute(0, 2, 1), idx).permute(0, 3, 1, 2)
-        else:
+        """Features of the coarse set spread onto the fine set (same signature as the reference's method)."""
+        if distance_type not in ("xyz", "feature"):
             raise ValueError(f"upsample interpolation distance type can only be feature or xyz! Got: {distance_type}")
-        weights = 1.0 / (d_neighbors + 1e-8)
-        weights = weights / torch.sum(weights, dim=-1, keepdim=True)
-        return torch.sum(neighbors * weights.unsqueeze(dim=1), dim=-1)
+        projected = self.conv(points_select)
+        if distance_type == "xyz":
+            picked, _, dist = ops.select_neighbors_interpolate(pcd_up_xyz, points_select_xyz, projected, K=K)
+            return inverse_distance_blend(picked, dist)
+        # feature space: the reference back-propagates through its cdist; here the SEARCH runs on the HIP kNN
+        # kernels (indices carry no gradient) and only the K chosen distances per point are recomputed in torch
+        _, idx, _ = ops.select_neighbors_interpolate(pcd_up.detach(), points_select.detach(), projected.detach(), K=K)
+        picked = ops.index_points(projected.transpose(1, 2), idx).permute(0, 3, 1, 2)
+        return inverse_distance_blend(picked, _normalised_pair_distances(pcd_up, points_select, idx))
 
 
 def upsample_config(preset: str = "seg"):

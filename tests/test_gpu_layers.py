@@ -449,3 +449,32 @@ def test_modules_are_safe_under_autocast():
     # the sampler's own arithmetic stays fp32 end to end (its projection is a HIP kernel, not an autocast matmul)
     assert torch.equal(a_idx, r_idx) and torch.equal(a_ds.float(), r_ds)
     assert torch.isfinite(xin.grad).all()
+
+
+@pytest.mark.parametrize("name", ["layer_p2p_dot", "layer_p2p_l2", "layer_p2p_l2plus"])
+def test_point2point_attention_against_reference_fixture(name):
+    """Point2PointAttention as the reference configures it (4 heads of 32 channels, models/attention.py:253-355;
+    asm dot / l2 / l2+) against fixtures from the unmodified reference (tests/golden/make_golden_p2p.py):
+    output, dx and every parameter gradient."""
+    from samble_amd.attention import Point2PointAttention, attention_config
+    from samble_amd.config import to_attr
+    from tests.util import fill_parameters
+    d = layer_fixture(name)
+    B, C, N, H, seed = [int(v) for v in d["meta"]]
+    cfg = attention_config("cls")
+    cfg["asm"] = [str(d["asm"])] * 3
+    assert cfg["num_heads"][0] == H == 4
+    mod = Point2PointAttention(to_attr(cfg), 0)
+    assert sorted(n for n, _ in mod.named_parameters()) == sorted(k[len("grad__"):] for k in d.files if k.startswith("grad__"))
+    fill_parameters(mod, seed)
+    mod = mod.to(DEV).train()
+    x = (torch.from_numpy(synth.features(B, C, N, seed + 10) * 0.5)).to(DEV).requires_grad_(True)
+    y = mod(x)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=3e-4, atol=3e-4)
+    y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    ref = torch.from_numpy(d["dx"])
+    assert float((x.grad.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-6
+    for pname, p in mod.named_parameters():
+        ref = torch.from_numpy(d["grad__" + pname])
+        err = float((p.grad.cpu() - ref).abs().max())
+        assert err <= 1e-3 * float(ref.abs().max()) + 1e-6, (pname, err)

@@ -22,6 +22,19 @@ def matrix_mode(request):
     ops.MATRIX_MODE = old
 
 
+def _pinned_identity(mode, name, call):
+    """Per-cloud identity (1 = sampled indices equal the reference's) measured on MI355X and committed:
+    tests/expected_identity.json, written by tools/fixture_identity.py."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "expected_identity.json")
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    rows = table.get(f"{mode}/{name}")
+    return rows[call]["same"] if rows else None
+
+
 @pytest.mark.parametrize("name", golden_names())
 def test_module_against_reference_fixture(name, matrix_mode):
     g = Golden(name)
@@ -45,11 +58,32 @@ def test_module_against_reference_fixture(name, matrix_mode):
         # reference's count allocation is ill-conditioned by construction: when all bins but one
         # saturate, the float water-filling (ops.py:403-424) lands on an exact integer and `.int()`
         # truncates it up or down on a 1e-9 difference of a bin weight (measured: |dw| <= 7e-9 flips a
-        # cloud).  MKL/Sleef vs MFMA/ocml arithmetic differ by more than that, so a minority of clouds
-        # may differ; given the reference's own stage inputs every integer is exact
-        # (test_select_stages_exact_on_golden).  Required here: most clouds identical, every cloud's
-        # sampled SET nearly identical.
+        # cloud).  MKL/Sleef vs MFMA/ocml arithmetic differ by more than that.  Given the reference's own stage
+        # inputs every integer is exact (test_select_stages_exact_on_golden); END TO END the measured
+        # per-cloud identities are pinned in tests/expected_identity.json (tools/fixture_identity.py): a cloud
+        # that is identical there must stay identical, and a cloud that is not must be explained by one of the
+        # two measured mechanisms below.
         same = (idx.cpu()[:, 0] == g.t("idx", call)[:, 0]).all(1)
+        pinned = _pinned_identity(matrix_mode, name, call)
+        if pinned is not None:
+            lost = [b for b in range(g.B) if pinned[b] and not bool(same[b])]
+            assert not lost, f"clouds {lost} were identical to the reference when the table was pinned"
+        counts_same = (mod.k_point_to_choose.cpu() == g.t("counts", call)).all(1)
+        for b in range(g.B):
+            if bool(same[b]):
+                continue
+            got_b, ref_b = idx.cpu()[b, 0], g.t("idx", call)[b, 0]
+            if not bool(counts_same[b]):
+                # (1) one pick moved between two bins: the truncation flip of the water-filling
+                dc = (mod.k_point_to_choose.cpu()[b].long() - g.t("counts", call)[b].long())
+                assert int(dc.abs().sum()) == 2 and int(dc.sum()) == 0, dc.tolist()
+                torch.testing.assert_close(mod.bin_weights_beforerelu.cpu()[b], g.t("w_pre", call)[b], rtol=2e-6,
+                                           atol=1e-7)
+                assert len(set(got_b.tolist()) ^ set(ref_b.tolist())) <= 2
+            else:
+                # (2) same counts: a near-tie of two selection keys (or of two scores at a bin boundary) resolved
+                # the other way -- at most a couple of points change place or membership
+                assert len(set(got_b.tolist()) ^ set(ref_b.tolist())) <= 4, (name, b)
         assert int(same.sum()) >= g.B - max(1, g.B // 4), "sampled indices differ from the reference"
         assert set_agreement(idx.cpu()[:, 0], g.t("idx", call)[:, 0]) >= 0.99
         if g.has("x_ds", call):
