@@ -268,25 +268,42 @@ __global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict
 
 // dW[o][c] = sum over the per-chunk partials (fixed order) + the token rows' share
 //            sum_t gsum[t][o] * tokens[c][t]
+// 49 152 outputs x (B * chunks) partials = 50 MB at B = 32: bandwidth work, so every load must be in flight at
+// once.  Workgroup = 16 float4 columns x 16 partial groups: thread (e4, g) sums partials g, g + 16, g + 32, ...
+// (16 independent 16-byte loads in flight per round), the 16 group sums are added in index order through LDS.
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nparts,
                                                              const float* __restrict__ gsum,
                                                              const float* __restrict__ tokens, int nt,
                                                              float* __restrict__ dW) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= kO * kC) return;
-  float s = 0.f;
-  int p = 0;
-  for (; p + 8 <= nparts; p += 8) {  // 8 loads in flight, summed in index order
-    float v[8];
+  __shared__ f32x4 red[16][17];
+  const int e4l = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e4 = blockIdx.x * 16 + e4l;  // float4 column of the (384 x 128) matrix; grid covers it exactly
+  const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + e4;
+  constexpr long kStride4 = (long)kO * kC / 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int p0 = g; p0 < nparts; p0 += 16 * 16) {
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = part[(long)(p + u) * kO * kC + e];
+    for (int u = 0; u < 16; ++u) {
+      const int p = p0 + 16 * u;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      v[u] = (p < nparts) ? p4[(long)p * kStride4] : z4;
+    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 16; ++u) s += v[u];
   }
-  for (; p < nparts; ++p) s += part[(long)p * kO * kC + e];
-  const int o = e / kC, c = e % kC;
-  for (int t = 0; t < nt; ++t) s = fmaf(gsum[t * kO + o], tokens[c * nt + t], s);
-  dW[e] = s;
+  red[g][e4l] = s;
+  __syncthreads();
+  if (g == 0) {
+    f32x4 tot = red[0][e4l];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tot += red[k][e4l];
+    const int e = 4 * e4, o = e / kC, c = e % kC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      for (int t = 0; t < nt; ++t) tot[j] = fmaf(gsum[t * kO + o], tokens[(c + j) * nt + t], tot[j]);
+    reinterpret_cast<f32x4*>(dW)[e4] = tot;
+  }
 }
 
 // token rows, one workgroup per token t: gsum[t][o] = sum_b dqkv[b][N+t][o] (fixed order), then
@@ -297,7 +314,15 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
   __shared__ float gs[kO];
   const int t = blockIdx.x, o = threadIdx.x;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {  // 8 loads in flight, summed in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = dqkv[(long)(b + u) * g_bs + (long)(N + t) * g_rs + o];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
   gs[o] = s;
   gsum[t * kO + o] = s;
   __syncthreads();
@@ -315,6 +340,7 @@ using namespace samble;
 extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, int, const float*, void*, float*, long,
                                           long, hipStream_t);
 extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, float*, long, hipStream_t);
+extern "C" int samble_launch_proj_dw_tri(const float*, long, long, const float*, long, int, int, float*, hipStream_t);
 
 // wimg != null: room for the row image of W -> the split-bf16 kernel (proj_tri.hip)
 extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, const float* tokens, int nt,
@@ -364,11 +390,16 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   }
   if (dW) {
     Timed timed(kT_proj_dw, s);
-    hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
+    if (wtr) {  // split-bf16 mode
+      const int rc = samble_launch_proj_dw_tri(dqkv, g_bs, g_rs, x, x_bs, B, N, part, s);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
+    }
     if (nt > 0)
       hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, gsum, dtok);
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((kO * kC + 255) / 256), dim3(256), 0, s, part, B * chunks, gsum,
-                       tokens, nt, dW);
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO * kC / 64), dim3(256), 0, s, part, B * chunks, gsum, tokens, nt,
+                       dW);
   }
   return (int)hipGetLastError();
 }

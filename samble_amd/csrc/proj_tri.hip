@@ -1,7 +1,7 @@
 // QKV projection forward and its input gradient on the bf16 matrix cores with split fp32 operands
 // (tri_dev.h); same results contract as proj_fwd_kernel / proj_dx_kernel of proj.hip (fp32-equivalent
-// products, other rounding).  dW stays on the fp32 MFMA kernel (its contraction runs over the points: both
-// operands would have to be transposed on the fly).
+// products, other rounding).  dW: proj_dw_tri_kernel below (its contraction runs over the points: both
+// operands are transposed through LDS and split in registers).
 //
 //   forward   qkv[n][o] = sum_c W[o][c] x[c][n]      A: W row image tile (32 outputs, LDS ring), B: the point's
 //                                                    128 channels, read channel-major and split in registers
@@ -145,6 +145,113 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dW partials on the split scheme: dW[o][c] = sum_n dqkv[n][o] x[c][n].  The contraction runs over the POINTS, so
+// both operands are transposed on the fly: a 32-point tile of dqkv ([n][384 o]) and of x ([128 c][n]) goes through
+// LDS as in proj_dw_kernel (proj.hip); lane (o or c, h) then reads its 8 points of a k-step column-wise and splits
+// them into the three bf16 planes in registers.  Workgroup = (cloud, 256-point chunk), 8 waves = two per SIMD;
+// wave w owns output rows 96 (w >> 1) .. +95 and channels 64 (w & 1) .. +63: six accumulator tiles, per 32 points
+// 2 k-steps x (3 + 2 operand splits, 36 MFMAs).
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwTriPts = 256;
+constexpr int kDwTriGS = 388, kDwTriXS = 33;  // row strides: dqkv tile rows 16-byte aligned, column reads conflict-free
+constexpr int kDwTriBuf = kTile * kDwTriGS + 128 * kDwTriXS;
+constexpr int kDwTriLds = 2 * kDwTriBuf * 4;
+
+__global__ __launch_bounds__(512, 2) void proj_dw_tri_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
+                                                             const float* __restrict__ x, long x_bs, int N,
+                                                             float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  float* smem = reinterpret_cast<float*>(smem_c);
+  constexpr int GS = kDwTriGS, XS = kDwTriXS, BUF = kDwTriBuf;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int og = wave >> 1, ch = wave & 1;
+  const int b = blockIdx.y;
+  const int n0 = blockIdx.x * kDwTriPts;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = zero16();
+
+  f32x4 gst[6];  // 32 rows x 96 float4 = 3072 float4 / 512 threads
+  float xst[8];  // 128 channels x 32 points = 4096 floats / 512 threads
+  auto issue = [&](int nn0) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int e = tid + 512 * it;
+      const int r = e / 96, c4 = (e % 96) * 4;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      gst[it] = (nn0 + r < N) ? *reinterpret_cast<const f32x4*>(dqkv + (long)b * g_bs + (long)(nn0 + r) * g_rs + c4) : z4;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 512 * it;
+      const int c = e >> 5, pnt = e & 31;
+      xst[it] = (nn0 + pnt < N) ? x[(long)b * x_bs + (long)c * N + nn0 + pnt] : 0.f;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      const int e = tid + 512 * it;
+      const int r = e / 96, c4 = (e % 96) * 4;
+      *reinterpret_cast<f32x4*>(buf + r * GS + c4) = gst[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 512 * it;
+      buf[kTile * GS + (e >> 5) * XS + (e & 31)] = xst[it];
+    }
+  };
+  constexpr int ntiles = kDwTriPts / kTile;
+  issue(n0);
+  commit(smem);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    float* cur = smem + (t & 1) * BUF;
+    float* nxt = smem + ((t & 1) ^ 1) * BUF;
+    if (t + 1 < ntiles) issue(n0 + (t + 1) * kTile);
+    const float* gt = cur;
+    const float* xt = cur + kTile * GS;
+    // D[row = o][col = c] += sum_n dqkv[n][o] * x[c][n]; k-step ks covers points 16 ks .. 16 ks + 15, lane half h
+    // the 8 points 16 ks + 8 h + e
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Tri bq[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xt[(64 * ch + 32 * ct + lo) * XS + 16 * ks + 8 * h + e];
+        bq[ct] = tri_split8(v);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 3; ++ot) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * ks + 8 * h + e) * GS + 96 * og + 32 * ot + lo];
+        const Tri a = tri_split8(v);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ot][ct] = mfma_tri(a, bq[ct], acc[ot][ct]);
+      }
+    }
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  float* out = part + ((long)b * gridDim.x + blockIdx.x) * kPO * 128;
+#pragma unroll
+  for (int ot = 0; ot < 3; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = 96 * og + 32 * ot + crow(r, h);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) out[(long)o * 128 + 64 * ch + 32 * ct + lo] = acc[ot][ct][r];
+    }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -185,5 +292,16 @@ extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs
   Timed timed(kT_proj_dx, s);
   hipLaunchKernelGGL(proj_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, dqkv, g_bs, g_rs,
                      (const char*)wtr, N, dx, dx_bs);
+  return (int)hipGetLastError();
+}
+
+// per-chunk partials of dW (same layout and chunking as proj_dw_kernel: the fixed-order reduce of proj.hip follows)
+extern "C" int samble_launch_proj_dw_tri(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
+                                         float* part, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dw_tri_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kDwTriLds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(proj_dw_tri_kernel, dim3((N + kDwTriPts - 1) / kDwTriPts, B), dim3(512), kDwTriLds, s, dqkv, g_bs,
+                     g_rs, x, x_bs, N, part);
   return (int)hipGetLastError();
 }
