@@ -275,6 +275,28 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
                              float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
                              int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- the integer tail as two launches (same reference lines as the stand-alone entries above) ----------------
+ * For shapes samble_select_chain_supported(B, N, nb) accepts (one 1024-thread workgroup per cloud, all resident:
+ * B <= min(128, CUs), B * nb <= 1024, N <= 16384), over ONE caller-owned workspace of
+ * samble_select_chain_workspace_bytes(B, N):
+ *   samble_sparse_score_map_quantiles_f32  = samble_sparse_score_map_f32 (models/downsample.py:300-344, score + z,
+ *       in-degree) + samble_batch_quantiles_f32 (utils/ops.py:180-189) in two launches (accumulation; finalize +
+ *       radix select with grid barriers).  quantiles_out (nb-1) or NULL (static boundaries: no quantiles).
+ *   [the caller averages the quantiles over the ranks here, utils/ops.py:191-199]
+ *   samble_bin_plan_f32  = samble_blend_boundaries_f32 (utils/ops.py:201-233; quantiles NULL: boundaries are used as
+ *       they are) + samble_bin_assign_f32 + samble_alloc_counts_f32 (utils/ops.py:385-464) in one launch.  Must follow
+ *       the call above on the same stream and workspace (it holds the barrier counters that call zeroed).
+ * Same integers as the stand-alone entries: both run the same device functions (csrc/select_dev.h). */
+int samble_select_chain_supported(int B, int N, int nb);
+size_t samble_select_chain_workspace_bytes(int B, int N);
+int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,
+                                          int KN, int mode, int nb, float* score, float* z, int32_t* indeg_out,
+                                          float* quantiles_out, void* ws, size_t ws_bytes, void* stream);
+int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper, float* lower,
+                        int first, float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
+                        uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* ---- the same passes on the bf16 matrix cores with split fp32 operands ------------------------------
  * An fp32 operand is carried as three bf16 planes h + m + l (all 24 significand bits); a product keeps
  * the six partial products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm), each one bf16 MFMA with fp32

@@ -46,6 +46,13 @@ _SIGNATURES = {
     "samble_sparse_score_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),
+    "samble_select_chain_supported": (c_int, [c_int, c_int, c_int]),
+    "samble_select_chain_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "samble_sparse_score_map_quantiles_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_bin_plan_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
+                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
     "samble_zscore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "samble_quantiles_workspace_bytes": (c_size_t, []),
     "samble_batch_quantiles_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -71,6 +71,14 @@ int samble_launch_attn_rows(const float*, int, const float*, const float*, long,
 int samble_launch_sparse_score_map(const float*, int, const float*, const int*, int, int, int, int, float*, float*, int*,
                                    void*, hipStream_t);
 size_t samble_attn_bwd_slab_floats(int B, int N, int M);
+size_t samble_chain_ws_bytes(void);
+int samble_chain_supported(int B, int N, int nb);
+int samble_launch_sparse_score_map_acc(const float*, int, const float*, const int*, int, int, int, int, void*, size_t,
+                                       hipStream_t);
+int samble_launch_score_quantiles(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*,
+                                  float*, hipStream_t);
+int samble_launch_bin_plan(const float*, const float*, int, const float*, float*, float*, int, float, float, int, int, int,
+                           int, int, unsigned char*, int*, float*, float*, int*, void*, hipStream_t);
 }
 
 namespace {
@@ -554,6 +562,60 @@ SAMBLE_API int samble_sparse_score_map_f32(const float* smap, int ld, const floa
   return done(samble_launch_sparse_score_map(smap, ld, lse, nn, B, N, KN, mode, score, z, indeg_out, ws,
                                              (hipStream_t)stream),
               "samble_sparse_score_map_f32");
+}
+
+// ---- the fused select chain (chain.hip): score + z + batch quantiles in one launch, boundaries + bins + counts in another
+SAMBLE_API int samble_select_chain_supported(int B, int N, int nb) { return samble_chain_supported(B, N, nb); }
+
+static size_t chain_score_bytes(int B, int N) { return (samble_score_ws_bytes(B, N) + 255) & ~(size_t)255; }
+
+SAMBLE_API size_t samble_select_chain_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return chain_score_bytes(B, N) + samble_chain_ws_bytes();
+}
+
+SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B,
+                                                     int N, int KN, int mode, int nb, float* score, float* z,
+                                                     int32_t* indeg_out, float* quantiles_out, void* ws, size_t ws_bytes,
+                                                     void* stream) {
+  if (!smap || !lse || !nn || !score || !z || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: null pointer");
+  if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: unknown score mode");
+  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: N too large for LDS");
+  if (!samble_chain_supported(B, N, nb))
+    return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: shape not taken by the fused chain "
+                                  "(samble_select_chain_supported)");
+  if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_map_quantiles_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = samble_launch_sparse_score_map_acc(smap, ld, lse, nn, B, N, KN, mode, ws, samble_select_chain_workspace_bytes(B, N), s);
+  if (rc) return done(rc, "samble_sparse_score_map_quantiles_f32");
+  char* w8 = (char*)ws;
+  const void* colacc = w8;
+  const int* indeg = (const int*)(w8 + (size_t)B * N * 8);
+  const float* rowstat = (const float*)(w8 + (size_t)B * N * 12);
+  return done(samble_launch_score_quantiles(colacc, indeg, rowstat, B, N, mode, nb, score, z, indeg_out,
+                                            w8 + chain_score_bytes(B, N), quantiles_out, s),
+              "samble_sparse_score_map_quantiles_f32");
+}
+
+SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper,
+                                   float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb,
+                                   int relu_first, int M, uint8_t* member, int32_t* cap, float* w_pre, float* w,
+                                   int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+  if (!z || !tok || !upper || !lower || !member || !cap || !w_pre || !w || !counts || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: null pointer");
+  if (nb < 1 || nb > 8 || (nt != 1 && nt != nb))
+    return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: need 1 <= num_bins <= 8 and nt in {1, num_bins}");
+  if (!samble_chain_supported(B, N, nb < 2 ? 2 : nb))
+    return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: shape not taken by the fused chain (samble_select_chain_supported)");
+  if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_bin_plan_f32: workspace too small");
+  return done(samble_launch_bin_plan(z, tok, nt, quantiles, upper, lower, first, momentum, one_minus_momentum, B, N, nb,
+                                     relu_first, M, member, cap, w_pre, w, counts, (char*)ws + chain_score_bytes(B, N),
+                                     (hipStream_t)stream),
+              "samble_bin_plan_f32");
 }
 
 SAMBLE_API size_t samble_proj_workspace_bytes(int B, int N) {

@@ -1,0 +1,269 @@
+// The integer tail of the sampler as TWO launches instead of eleven (reference models/downsample.py:309-344,
+// utils/ops.py:174-236, 385-464):
+//
+//   score_quantiles   one workgroup per cloud (all co-resident): score and z-score of the cloud from the exact
+//                     column sums of sparse_score(_map) [what finalize_score_kernel does], then the nb-1 batch
+//                     quantiles of ALL B*N z-scores by the same three-level radix select as qsel_kernel<0..3> --
+//                     each workgroup histograms its own cloud's values (they never leave its registers), the
+//                     per-level global histograms are combined with integer atomics, and the workgroups meet at a
+//                     grid barrier per level.  Replaces memset + finalize + 4 qsel launches + the in-degree copy.
+//   [the reference's all-reduce of the quantiles over the ranks sits here: torch.distributed, utils/ops.py:191-199]
+//   bin_plan          one workgroup per cloud: boundary state update (first call: the quantiles; later: momentum blend,
+//                     ops.py:201-233), bin membership + bin weights of the cloud, a grid barrier, then the count
+//                     allocation of the whole batch (every workgroup runs it -- it is B x nb numbers -- and keeps its
+//                     cloud's row).  Replaces blend_boundaries + bin_assign + alloc_counts.
+//
+// Every arithmetic step is the shared device function the stand-alone kernels use (select_dev.h), thread-to-point
+// mapping and summation orders included: the two paths give the same integers.
+//
+// Grid barrier (MI355X_MICROARCH.md, "barrier-counter"): monotonic counter in the workspace (zeroed by the
+// launcher's memset), lane 0 of each workgroup: release fence, atomic add, relaxed agent-scope poll with s_sleep,
+// acquire fence; __syncthreads on both sides.  All B <= 256 workgroups are resident (1024 threads, one per CU),
+// which the launchers check against the device's CU count.
+#include "select_dev.h"
+
+namespace samble {
+
+constexpr float kUnfixC = 1.f / 17592186044416.f;  // 2^-44: the fixed-point scale of the score accumulators (score.hip)
+enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };
+
+__device__ __forceinline__ void grid_barrier(unsigned int* counter, unsigned int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+// chain workspace (uint32 words): [quantile histograms and state: kQWords][barrier counters: 16]
+constexpr int kChainBar = kQWords;
+constexpr int kChainWords = kQWords + 16;
+
+// PT = ceil(N / 1024) values per thread (point n = tid + 1024 k)
+template <int PT>
+__global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned long long* __restrict__ colacc,
+                                                               const int* __restrict__ indeg,
+                                                               const float* __restrict__ rowstat, int N, int mode,
+                                                               int nb, float* __restrict__ score,
+                                                               float* __restrict__ z, int* __restrict__ indeg_out,
+                                                               unsigned int* __restrict__ cws,
+                                                               float* __restrict__ quant_out) {
+  extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
+  __shared__ double red[256];
+  __shared__ unsigned int scanbuf[16];
+  __shared__ unsigned int prefix[kMaxBins];
+  __shared__ unsigned int rem[kMaxBins];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int B = gridDim.x;
+  const long n_all = (long)B * N;
+  const int nq = nb - 1;
+
+  // ---- score + z of this cloud: the arithmetic and summation order of finalize_score_kernel (score.hip): the
+  // first 256 threads own points n = tid, tid + 256, ... for the two double-precision reductions
+  float* sbuf = reinterpret_cast<float*>(qsm);  // N floats, free again before the histograms
+  for (int n = tid; n < N; n += 1024) {
+    float s;
+    if (mode >= kRowSumC) {
+      s = rowstat[(long)b * N + n];
+    } else {
+      const float sum = __ll2float_rn((long long)colacc[(long)b * N + n]) * kUnfixC;
+      const float num = (float)indeg[(long)b * N + n] + 1e-8f;
+      s = sum;
+      if (mode == kColAvgC) s = sum / num;
+      if (mode == kColSqrC) s = sum / num / num;
+    }
+    if (s != s) s = 0.f;
+    sbuf[n] = s;
+    score[(long)b * N + n] = s;
+    if (indeg_out) indeg_out[(long)b * N + n] = indeg[(long)b * N + n];
+  }
+  __syncthreads();
+  double part = 0.0;
+  if (tid < 256)
+    for (int n = tid; n < N; n += 256) part += (double)sbuf[n];
+  if (tid < 256) red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double mean_d = red[0] / N;
+  __syncthreads();
+  part = 0.0;
+  if (tid < 256)
+    for (int n = tid; n < N; n += 256) {
+      const double d = (double)sbuf[n] - mean_d;
+      part += d * d;
+    }
+  if (tid < 256) red[tid] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float mean_f = (float)mean_d;
+  const float std_f = (float)sqrt(red[0] / N);
+  unsigned int key[PT];
+#pragma unroll
+  for (int k = 0; k < PT; ++k) {
+    const int n = tid + 1024 * k;
+    key[k] = 0u;
+    if (n < N) {
+      const float zv = (sbuf[n] - mean_f) / std_f;
+      z[(long)b * N + n] = zv;
+      key[k] = ordered_bits(zv);
+    }
+  }
+  __syncthreads();  // sbuf is free
+  if (quant_out == nullptr) return;  // static boundaries: no quantiles wanted (uniform over the grid)
+
+  // ---- batch quantiles: three levels of digits (11 / 11 / 10 bits), all nb-1 ranks at once
+  unsigned int* bar = cws + kChainBar;
+#pragma unroll
+  for (int level = 0; level < 3; ++level) {
+    const int bits = (level == 2) ? 10 : 11, nbin = 1 << bits;
+    const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
+    const int nh = (level == 0) ? 1 : nq;
+    for (int e = tid; e < nh * nbin; e += 1024) qsm[e] = 0u;
+    unsigned int want[kMaxBins];
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) want[t] = (level > 0 && t < nq) ? (prefix[t] >> (shift + bits)) : 0xFFFFFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      if (tid + 1024 * k >= N) continue;
+      const unsigned int dig = (unsigned int)(nbin - 1) - ((key[k] >> shift) & (unsigned int)(nbin - 1));
+      if (level == 0) {
+        atomicAdd(&qsm[dig], 1u);
+      } else {
+        const unsigned int hi = key[k] >> (shift + bits);
+#pragma unroll
+        for (int t = 0; t < kMaxBins; ++t)
+          if (t < nq && hi == want[t]) atomicAdd(&qsm[t * nbin + dig], 1u);
+      }
+    }
+    __syncthreads();
+    unsigned int* gh = cws + (level == 0 ? kQH0 : level == 1 ? kQH1 : kQH2);
+    for (int e = tid; e < nh * nbin; e += 1024) {
+      const unsigned int c = qsm[e];
+      if (c) atomicAdd(&gh[(level == 2) ? (e / nbin) * 1024 + (e % nbin) : (level == 1) ? (e / nbin) * 2048 + (e % nbin) : e], c);
+    }
+    grid_barrier(bar, (unsigned int)B * (level + 1));
+    qsel_resolve(level, cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
+  }
+  if (b == 0 && tid < nq) quant_out[tid] = from_ordered_bits(prefix[tid]);
+}
+
+// boundaries in (1,1,1,nb) layout: upper[0] = +inf, upper[t] = q[t-1]; lower[t] = q[t], lower[nb-1] = -inf
+__global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict__ z, const float* __restrict__ tok,
+                                                        int nt, const float* __restrict__ quant, float* upper,
+                                                        float* lower, int first, float mu, float one_minus_mu, int N,
+                                                        int nb, int relu_first, int M,
+                                                        unsigned char* __restrict__ member, int* cap, float* w_pre,
+                                                        float* w, int* __restrict__ counts,
+                                                        unsigned int* __restrict__ cws) {
+  __shared__ double rsum[kMaxBins][16];
+  __shared__ int rcnt[kMaxBins][16];
+  __shared__ float up_s[kMaxBins], lo_s[kMaxBins];
+  const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
+  // ---- boundary state (blend_boundaries_kernel's arithmetic: two fp32 products, then the sum; no FMA in this file)
+  if (tid < nb) {
+    float u = upper[tid], l = lower[tid];
+    if (quant) {
+      if (tid >= 1) {
+        float v = quant[tid - 1];
+        if (!first) v = u * mu + one_minus_mu * v;
+        u = v;
+      } else {
+        u = first ? __builtin_huge_valf() : u;
+      }
+      if (tid < nb - 1) {
+        float v = quant[tid];
+        if (!first) v = upper[tid + 1] * mu + one_minus_mu * v;
+        l = v;
+      } else {
+        l = first ? -__builtin_huge_valf() : l;
+      }
+    }
+    up_s[tid] = u;
+    lo_s[tid] = l;
+  }
+  __syncthreads();
+  bin_assign_body(b, z, tok, nt, up_s, lo_s, N, nb, relu_first, member, cap, w_pre, w, rsum, rcnt);
+  // every workgroup has read the old state and published its cloud's (w, cap): now the state may be overwritten
+  // and the whole batch's counts allocated
+  grid_barrier(cws + kChainBar + 1, (unsigned int)B);
+  if (b == 0 && quant && tid < nb) {
+    upper[tid] = up_s[tid];
+    lower[tid] = lo_s[tid];
+  }
+  __shared__ int counts_s[1024 * kMaxBins / 8];  // B x nb <= 1024 ints (B <= 128 at nb = 8)
+  alloc_counts_body(w, cap, B, nb, M, counts_s);
+  __syncthreads();
+  if (tid < nb) counts[b * nb + tid] = counts_s[b * nb + tid];
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+static int resident_workgroups(int* out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  int cus = 0;
+  e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return (int)e;
+  *out = cus;  // one 1024-thread workgroup per CU
+  return 0;
+}
+
+extern "C" size_t samble_chain_ws_bytes(void) { return (size_t)kChainWords * sizeof(unsigned int); }
+
+// 1 if the fused chain takes this shape (else the caller uses the stand-alone kernels)
+extern "C" int samble_chain_supported(int B, int N, int nb) {
+  int cus = 0;
+  if (resident_workgroups(&cus)) return 0;
+  return B >= 1 && B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && N <= 16 * 1024 && nb >= 2 && nb <= kMaxBins;
+}
+
+// cws must have been zeroed on the stream (the score launcher's memset covers it)
+extern "C" int samble_launch_score_quantiles(const void* colacc, const int* indeg, const float* rowstat, int B, int N,
+                                             int mode, int nb, float* score, float* z, int* indeg_out, void* cws,
+                                             float* quant_out, hipStream_t s) {
+  const int pt = (N + 1023) / 1024;
+  size_t lds = (size_t)(nb - 1) * 2048 * 4;
+  if ((size_t)N * 4 > lds) lds = (size_t)N * 4;
+  if (lds < 2048 * 4) lds = 2048 * 4;
+  Timed timed(kT_quantiles, s);
+#define SAMBLE_SQ(PT)                                                                                              \
+  {                                                                                                                \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(score_quantiles_kernel<PT>),                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+    if (e != hipSuccess) return (int)e;                                                                            \
+    hipLaunchKernelGGL(score_quantiles_kernel<PT>, dim3(B), dim3(1024), lds, s, (const unsigned long long*)colacc, \
+                       indeg, rowstat, N, mode, nb, score, z, indeg_out, (unsigned int*)cws, quant_out);           \
+  }
+  if (pt <= 1) SAMBLE_SQ(1)
+  else if (pt <= 2) SAMBLE_SQ(2)
+  else if (pt <= 4) SAMBLE_SQ(4)
+  else if (pt <= 8) SAMBLE_SQ(8)
+  else SAMBLE_SQ(16)
+#undef SAMBLE_SQ
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bin_plan(const float* z, const float* tok, int nt, const float* quant, float* upper,
+                                      float* lower, int first, float mu, float one_minus_mu, int B, int N, int nb,
+                                      int relu_first, int M, unsigned char* member, int* cap, float* w_pre, float* w,
+                                      int* counts, void* cws, hipStream_t s) {
+  Timed timed(kT_bin_assign, s);
+  hipLaunchKernelGGL(bin_plan_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, quant, upper, lower, first, mu,
+                     one_minus_mu, N, nb, relu_first, M, member, cap, w_pre, w, counts, (unsigned int*)cws);
+  return (int)hipGetLastError();
+}

@@ -322,6 +322,28 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
   return (int)hipGetLastError();
 }
 
+// the accumulation pass alone, for the fused select chain (chain.hip): zeroes `zero_bytes` of ws (accumulators and
+// whatever follows them: the chain's histograms and barrier counters), then gathers the map entries
+extern "C" int samble_launch_sparse_score_map_acc(const float* smap, int ld, const float* lse, const int* nn, int B, int N,
+                                                  int KN, int mode, void* ws, size_t zero_bytes, hipStream_t stream) {
+  if (mode < 0 || mode > kRowStd) return -22;
+  unsigned long long* colacc = reinterpret_cast<unsigned long long*>(ws);
+  int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
+  float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
+  hipError_t e = hipMemsetAsync(ws, 0, zero_bytes, stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = (size_t)N * 12;
+  if (lds > 64 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_map_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  Timed timed(kT_sparse_score, stream);
+  hipLaunchKernelGGL(sparse_score_map_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN,
+                     colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
+  return (int)hipGetLastError();
+}
+
 // score = stat with NaN -> 0 (models/downsample.py:342), then the z-score
 __global__ __launch_bounds__(256) void clean_kernel(const float* __restrict__ stat, long n, float* __restrict__ score) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;

@@ -1,0 +1,209 @@
+// Device functions shared by the stand-alone select kernels (select.hip) and the fused select chain (chain.hip):
+// the batch-quantile radix select's resolve step, the bin assignment and the count allocation.  One definition,
+// so that both paths produce the same integers from the same fp32 inputs.
+#pragma once
+#include "samble_dev.h"
+#pragma clang fp contract(off)
+
+namespace samble {
+
+constexpr int kMaxBins = 8;
+
+// inclusive scan of one value per thread over the 1024-thread block: shuffles inside a wave, the 16
+// wave totals through LDS (buf: >= 16 words); two barriers
+__device__ __forceinline__ unsigned int block_scan_incl(unsigned int v, unsigned int* buf, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  unsigned int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  __syncthreads();  // previous users of buf are done
+  if (lane == 63) buf[wv] = incl;
+  __syncthreads();
+  unsigned int base = 0u;
+  for (int w2 = 0; w2 < wv; ++w2) base += buf[w2];
+  return base + incl;
+}
+
+// ---- multi-workgroup version of the same radix select (one CU sweeping B*N values is VALU-bound:
+// ~30 instructions per value on 4 SIMDs).  Three sweep kernels of G workgroups + a one-workgroup
+// finish; level L's sweep first resolves level L-1 from its global histogram (every workgroup does
+// that redundantly and writes the identical result: no tickets, no fences), then histograms its own
+// slice in LDS and adds the non-empty counters to the global histogram of level L.
+// ws (uint32): hist0[2048] | hist1[7*2048] | hist2[7*1024] | 3 x state {prefix[8], rem[8]}; zeroed by the launcher.
+constexpr int kQH0 = 0, kQH1 = 2048, kQH2 = 2048 + 7 * 2048, kQState = kQH2 + 7 * 1024, kQWords = kQState + 3 * 16;  // state: one slot per resolved level
+
+// resolve the ranks of level `level` (0,1,2) from its global histogram; all 1024 threads; result in prefix/rem (LDS)
+// keep_state: prefix / rem of the previous level are already in LDS (the fused chain resolves every level in the
+// same workgroup); otherwise they are read from the state block 0 of the previous sweep published in ws.
+__device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, long n, int nb,
+                                    unsigned int* prefix, unsigned int* rem, unsigned int* scanbuf,
+                                    bool keep_state = false) {
+  const int tid = threadIdx.x;
+  if (keep_state && level > 0) {
+  } else if (level == 0) {
+    if (tid < kMaxBins) {
+      const float frac = (float)(tid + 1) / (float)nb;  // fp32 arithmetic then truncation (utils/ops.py:182-183)
+      rem[tid] = (tid < nq) ? (unsigned int)(int)(frac * (float)n) : 0u;
+      prefix[tid] = 0u;
+    }
+  } else if (tid < kMaxBins) {
+    prefix[tid] = ws[kQState + 16 * (level - 1) + tid];  // published by block 0 of the previous sweep
+    rem[tid] = ws[kQState + 16 * (level - 1) + 8 + tid];
+  }
+  __syncthreads();
+  const int bits = (level == 2) ? 10 : 11, nbin = 1 << bits, per = nbin >> 10;
+  const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
+  unsigned int rr[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) rr[t] = rem[t];
+  for (int t = 0; t < nq; ++t) {
+    const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
+    unsigned int loc[2] = {0u, 0u}, ts = 0u;
+    for (int u = 0; u < per; ++u) {
+      loc[u] = h[per * tid + u];
+      ts += loc[u];
+    }
+    const unsigned int incl = block_scan_incl(ts, scanbuf, tid);
+    unsigned int c = incl - ts;
+    for (int u = 0; u < per; ++u) {
+      if (c <= rr[t] && rr[t] < c + loc[u]) {
+        prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
+        rem[t] = rr[t] - c;
+      }
+      c += loc[u];
+    }
+  }
+  __syncthreads();
+}
+
+// bin membership + weights of cloud b (reference utils/ops.py:454-463, models/downsample.py:264-284); the whole
+// 1024-thread workgroup takes part; rsum / rcnt: LDS scratch
+__device__ inline void bin_assign_body(int b, const float* __restrict__ z, const float* __restrict__ tok, int nt,
+                                       const float* upper, const float* lower, int N, int nb, int relu_first,
+                                       unsigned char* __restrict__ member, int* cap, float* w_pre, float* w,
+                                       double (*rsum)[16], int (*rcnt)[16]) {
+  // 1024 threads per cloud (two points each at N = 2048: the per-point token-logit loads are latency
+  // bound); per-bin sums in double: lane tree inside a wave, then the 16 wave partials in index order
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float up[kMaxBins], lo[kMaxBins];
+  double ps[kMaxBins];
+  int pc[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    up[t] = (t < nb) ? upper[t] : 0.f;
+    lo[t] = (t < nb) ? lower[t] : 0.f;
+    ps[t] = 0.0;
+    pc[t] = 0;
+  }
+  for (int n = tid; n < N; n += 1024) {
+    const float zv = z[(long)b * N + n];
+    unsigned int bits = 0;
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      if (t < nb && zv < up[t] && zv >= lo[t]) {
+        bits |= 1u << t;
+        float lg = tok[((long)b * N + n) * nt + (nt == 1 ? 0 : t)];
+        if (relu_first) lg = fmaxf(lg, 0.f);
+        ps[t] += (double)lg;
+        pc[t] += 1;
+      }
+    }
+    member[(long)b * N + n] = (unsigned char)bits;
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    double v = ps[t];
+    int c = pc[t];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      v += __shfl_xor(v, off, 64);
+      c += __shfl_xor(c, off, 64);
+    }
+    if (lane == 0) {
+      rsum[t][wv] = v;
+      rcnt[t][wv] = c;
+    }
+  }
+  __syncthreads();
+  if (tid < nb) {
+    double v = 0.0;
+    int c = 0;
+    for (int w2 = 0; w2 < 16; ++w2) {
+      v += rsum[tid][w2];
+      c += rcnt[tid][w2];
+    }
+    const float pre = (float)v / ((float)c + 1e-8f);
+    cap[b * nb + tid] = c;
+    w_pre[b * nb + tid] = pre;
+    w[b * nb + tid] = relu_first ? pre : fmaxf(pre, 0.f);
+  }
+}
+
+// Sum of n <= 8 floats in the order ATen's scalar reduction path uses for a short contiguous row
+// (4 interleaved partial sums, tail onto partial 0, partials folded left to right).
+__device__ __forceinline__ float short_row_sum(const float (&a)[kMaxBins], int n) {
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  const int q = n >> 2;
+  for (int i = 0; i < q; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[k] = __fadd_rn(part[k], a[4 * i + k]);
+  for (int i = 4 * q; i < n; ++i) part[0] = __fadd_rn(part[0], a[i]);
+  float s = part[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) s = __fadd_rn(s, part[k]);
+  return s;
+}
+
+// count allocation of the whole batch (reference utils/ops.py:385-432): thread b of the workgroup = cloud b
+// (B <= blockDim.x), every thread of the workgroup must call it (whole-batch early exit by __syncthreads_and)
+__device__ inline void alloc_counts_body(const float* w, const int* cap, int B, int nb, int M, int* counts) {
+  const int b = threadIdx.x;
+  const bool live = b < B;
+  float p[kMaxBins], chosen[kMaxBins], capf[kMaxBins];
+  int capi[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    capi[t] = (live && t < nb) ? cap[b * nb + t] : 0;
+    capf[t] = (float)capi[t];
+    const float wt = (live && t < nb) ? w[b * nb + t] : 0.f;
+    p[t] = __fadd_rn(__fmul_rn(wt, capf[t]), 1e-10f);
+    chosen[t] = 0.f;
+  }
+  for (int round = 0; round < nb; ++round) {
+    const float s = short_row_sum(p, nb);
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) p[t] = __fdiv_rn(p[t], s);
+    const float left = __fsub_rn((float)M, short_row_sum(chosen, nb));
+    const int done = (!live) || (left == 0.f);
+    if (__syncthreads_and(done)) break;  // whole-batch early exit (utils/ops.py:409)
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      float c = __fadd_rn(chosen[t], __fmul_rn(p[t], left));
+      const bool sat = c >= capf[t];
+      chosen[t] = sat ? capf[t] : c;
+      p[t] = __fmul_rn(p[t], sat ? 0.f : 1.f);
+    }
+  }
+  if (!live) return;
+  int k[kMaxBins];
+  int total = 0, best = 0;
+  long bestv = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    k[t] = (t < nb) ? (int)chosen[t] : 0;
+    total += k[t];
+  }
+  for (int t = 0; t < nb; ++t) {
+    const long room = (long)capi[t] - k[t];
+    if (t == 0 || room > bestv) {
+      bestv = room;
+      best = t;
+    }
+  }
+  for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
+}
+
+}  // namespace samble

@@ -74,6 +74,9 @@ class _SamplerCore(torch.autograd.Function):
         v = qkv[:, :, 2 * D:3 * D]
 
         smap = None
+        plan = None  # (member, cap, w_pre, w, counts) when the fused select chain ran
+        if mod.bin_boundaries is not None:
+            mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
         if mod.idx_mode in ("col_sum", "row_std"):
             # dense statistics of the attention map: no neighbour lists involved
             if mod.idx_mode == "row_std":
@@ -90,19 +93,31 @@ class _SamplerCore(torch.autograd.Function):
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
                 imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
                 smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
-                score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
+                if ops.chain_supported(B, N, nb):
+                    # score + z + batch quantiles, then boundaries + bins + counts: two launches, the rank
+                    # average of the quantiles (reference utils/ops.py:191-199) in between
+                    score, z, indeg, quant, cws = ops.stage_score_quantiles(smap, lse, nn_idx, mod.idx_mode, nb,
+                                                                            mod.dynamic_boundaries_enable)
+                    if quant is not None:
+                        quant = ops.world_average(quant)
+                    mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
+                                                                   mod.momentum_update_factor,
+                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws)
+                else:
+                    score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
                 O, lse, tok = ops.stage_attn_fwd(q, k, v, N, nt)
                 score, z, indeg = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
 
-        if mod.bin_boundaries is not None:
-            mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
-        if mod.dynamic_boundaries_enable:
-            quant = ops.world_average(ops.stage_batch_quantiles(z, nb))
-            mod.bin_boundaries = ops.blend_boundaries(mod.bin_boundaries, quant, nb, mod.momentum_update_factor)
-        member, cap, w_pre, w = ops.stage_bin_assign(z, tok, mod.bin_boundaries[0], mod.bin_boundaries[1],
-                                                     mod.relu_mean_order == "relu_mean")
-        counts = ops.stage_alloc_counts(w, cap, mod.M)
+        if plan is not None:
+            member, cap, w_pre, w, counts = plan
+        else:
+            if mod.dynamic_boundaries_enable:
+                quant = ops.world_average(ops.stage_batch_quantiles(z, nb))
+                mod.bin_boundaries = ops.blend_boundaries(mod.bin_boundaries, quant, nb, mod.momentum_update_factor)
+            member, cap, w_pre, w = ops.stage_bin_assign(z, tok, mod.bin_boundaries[0], mod.bin_boundaries[1],
+                                                         mod.relu_mean_order == "relu_mean")
+            counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
         if smap is not None:
             x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=imgs[2] if imgs else None)

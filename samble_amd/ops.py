@@ -317,7 +317,7 @@ def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzma
         if noise.shape != (B * nb, N):
             raise ValueError(f"noise must be (B*num_bins, N) = {(B * nb, N)}, got {tuple(noise.shape)}")
     with torch.cuda.device(score.device):
-        idx = torch.zeros((B, M), dtype=torch.int64, device=score.device)
+        idx = torch.empty((B, M), dtype=torch.int64, device=score.device)  # every slot is written (counts sum to M)
         _lib.call("samble_bin_select_f32", score.data_ptr(), z.data_ptr(), member.data_ptr(), counts.data_ptr(),
                   _p(noise), B, N, nb, M, SAMPLE_MODES[sample_mode], temp_mode, float(temp), idx.data_ptr(),
                   _stream())
@@ -482,6 +482,67 @@ def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
                   nn_idx.shape[2], SCORE_MODES[idx_mode], score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
                   ws.data_ptr(), nbytes, _stream())
     return score, z, indeg
+
+
+def chain_supported(B: int, N: int, num_bins: int) -> bool:
+    """True when the fused select chain (csrc/chain.hip: two launches for score/z/quantiles and
+    boundaries/bins/counts) takes this shape; otherwise the stand-alone stage kernels run."""
+    return bool(_lib.query("samble_select_chain_supported", B, N, num_bins))
+
+
+def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool):
+    """stage_sparse_score_map + stage_batch_quantiles in two launches.
+    -> score (B,N), z (B,N), in-degree (B,N) int32, quantiles (nb-1,) or None, chain workspace (hand it to
+    stage_bin_plan)."""
+    if idx_mode not in SCORE_MODES:
+        raise ValueError("Please check the setting of idx mode!")
+    _need_gpu(smap, lse, nn_idx)
+    B, N, ld = smap.shape
+    with torch.cuda.device(smap.device):
+        score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
+        z = torch.empty_like(score)
+        indeg = torch.empty((B, N), dtype=torch.int32, device=smap.device)
+        quant = torch.empty((num_bins - 1,), dtype=torch.float32, device=smap.device) if want_quantiles else None
+        nbytes = _lib.query("samble_select_chain_workspace_bytes", B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=smap.device)
+        _lib.call("samble_sparse_score_map_quantiles_f32", smap.data_ptr(), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
+                  nn_idx.shape[2], SCORE_MODES[idx_mode], num_bins, score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
+                  _p(quant), ws.data_ptr(), nbytes, _stream())
+    return score, z, indeg, quant, ws
+
+
+def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum_update_factor: float, relu_first: bool,
+                   M: int, ws):
+    """blend_boundaries + stage_bin_assign + stage_alloc_counts in one launch (`ws` from stage_score_quantiles).
+    quantiles None: `boundaries` are used as they are (static); else they are initialised (boundaries None) or
+    blended IN PLACE (reference utils/ops.py:201-233).
+    -> boundaries [upper, lower], member (B,N) uint8, cap (B,nb), w_pre (B,nb), w (B,nb), counts (B,nb) int32."""
+    _need_gpu(z, tok_logits)
+    z, tok_logits = _f32c(z), _f32c(tok_logits)
+    B, N = z.shape
+    nb = num_bins
+    dev = z.device
+    first = boundaries is None
+    if first:
+        if quantiles is None:
+            raise ValueError("static boundaries must be given")
+        boundaries = [torch.empty((1, 1, 1, nb), dtype=torch.float32, device=dev) for _ in range(2)]
+    else:
+        boundaries = [boundaries[0].detach(), boundaries[1].detach()]
+        if not all(t.is_contiguous() and t.dtype == torch.float32 and t.device == dev for t in boundaries):
+            boundaries = [t.to(device=dev, dtype=torch.float32).contiguous() for t in boundaries]
+    with torch.cuda.device(dev):
+        member = torch.empty((B, N), dtype=torch.uint8, device=dev)
+        cap = torch.empty((B, nb), dtype=torch.int32, device=dev)
+        w_pre = torch.empty((B, nb), dtype=torch.float32, device=dev)
+        w = torch.empty_like(w_pre)
+        counts = torch.empty((B, nb), dtype=torch.int32, device=dev)
+        _lib.call("samble_bin_plan_f32", z.data_ptr(), tok_logits.data_ptr(), tok_logits.shape[-1],
+                  _p(_f32c(quantiles)) if quantiles is not None else None, boundaries[0].data_ptr(),
+                  boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
+                  float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), member.data_ptr(),
+                  cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+    return boundaries, member, cap, w_pre, w, counts
 
 
 def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv,

@@ -748,3 +748,46 @@ def test_split_bf16_edge_shapes(B, N, nt, M, matrix_mode):
         assert torch.isfinite(got).all(), name
         scale = ref.abs().max().item()
         assert (got.cpu().double() - ref).abs().max().item() <= 3e-5 * scale + 1e-7, name
+
+
+@pytest.mark.parametrize("B,N,nb,nt", [(2, 256, 6, 6), (32, 2048, 6, 6), (3, 1000, 4, 4), (5, 512, 6, 1), (16, 8192, 6, 6)])
+def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
+    """csrc/chain.hip (score + z + batch quantiles in one launch, boundary update + bins + counts in another) against
+    the stand-alone stage kernels it replaces: every output BITWISE equal, over a first call (boundaries initialised
+    from the quantiles) and a second one (momentum blend in place), and with static boundaries."""
+    o_ = ops()
+    assert o_.chain_supported(B, N, nb)
+    K, M = 32, N // 2
+    q, k, v = _qkv(B, N, nt, 77 + N)
+    q, k = q * 0.3, k * 0.3
+    nn = torch.stack([torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b * N + i))[:K]
+                                   for i in range(N)]) for b in range(B)]).int().to(DEV) if N <= 1024 else \
+        o_.stage_knn(q.permute(0, 2, 1).contiguous().to(DEV), q.permute(0, 2, 1).contiguous().to(DEV), K)
+    smap, lse, tok = o_.stage_attn_stats(q.to(DEV), k.to(DEV), N, nt)
+    state_a = state_b = None
+    for call in range(2):
+        # stage kernels
+        score, z, indeg = o_.stage_sparse_score_map(smap, lse, nn, "sparse_col_sqr")
+        quant = o_.stage_batch_quantiles(z, nb)
+        state_a = o_.blend_boundaries(state_a, quant, nb, 0.99)
+        member, cap, w_pre, w = o_.stage_bin_assign(z, tok, state_a[0], state_a[1], False)
+        counts = o_.stage_alloc_counts(w, cap, M)
+        # fused chain
+        score2, z2, indeg2, quant2, cws = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", nb, True)
+        state_b, member2, cap2, w_pre2, w2, counts2 = o_.stage_bin_plan(z2, tok, quant2, state_b, nb, 0.99, False, M, cws)
+        torch.cuda.synchronize()
+        for a, b2, what in ((score, score2, "score"), (z, z2, "z"), (indeg, indeg2, "indeg"), (quant, quant2, "quantiles"),
+                            (state_a[0], state_b[0], "upper"), (state_a[1], state_b[1], "lower"),
+                            (member, member2, "member"), (cap, cap2, "cap"), (w_pre, w_pre2, "w_pre"), (w, w2, "w"),
+                            (counts, counts2, "counts")):
+            assert torch.equal(a, b2), (what, call)
+        assert bool((counts2.sum(1) == M).all())
+        lse = lse + 0.01 * (call + 1)  # other scores for the second call
+    # static boundaries: no quantiles, state untouched
+    up = state_a[0].clone()
+    score3, z3, _, quant3, cws = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", nb, False)
+    assert quant3 is None
+    st, member3, cap3, _, w3, counts3 = o_.stage_bin_plan(z3, tok, None, [state_a[0], state_a[1]], nb, 0.99, True, M, cws)
+    member4, cap4, _, w4 = o_.stage_bin_assign(z3, tok, state_a[0], state_a[1], True)
+    assert torch.equal(st[0], up) and torch.equal(member3, member4) and torch.equal(cap3, cap4) and torch.equal(w3, w4)
+    assert torch.equal(counts3, o_.stage_alloc_counts(w4, cap4, M))
