@@ -27,13 +27,20 @@ namespace samble {
 constexpr float kUnfixC = 1.f / 17592186044416.f;  // 2^-44: the fixed-point scale of the score accumulators (score.hip)
 enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };
 
+// RELEASE: the workgroups hand over plain stores (needs the L2 write-back of an agent-scope release fence: a few
+// microseconds); false when everything exchanged went through agent-scope atomics (performed at the memory side:
+// each wave only has to wait until its own have been issued and acknowledged)
+template <bool RELEASE>
 __device__ __forceinline__ void grid_barrier(unsigned int* counter, unsigned int target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (RELEASE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
                                                                float* __restrict__ quant_out) {
   extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
   __shared__ double red[256];
-  __shared__ unsigned int scanbuf[16];
+  __shared__ unsigned int scanbuf[16 * kMaxBins];
   __shared__ unsigned int prefix[kMaxBins];
   __shared__ unsigned int rem[kMaxBins];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
       const unsigned int c = qsm[e];
       if (c) atomicAdd(&gh[(level == 2) ? (e / nbin) * 1024 + (e % nbin) : (level == 1) ? (e / nbin) * 2048 + (e % nbin) : e], c);
     }
-    grid_barrier(bar, (unsigned int)B * (level + 1));
+    grid_barrier<false>(bar, (unsigned int)B * (level + 1));  // the histograms were combined by atomics
     qsel_resolve(level, cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
   }
   if (b == 0 && tid < nq) quant_out[tid] = from_ordered_bits(prefix[tid]);
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
   bin_assign_body(b, z, tok, nt, up_s, lo_s, N, nb, relu_first, member, cap, w_pre, w, rsum, rcnt);
   // every workgroup has read the old state and published its cloud's (w, cap): now the state may be overwritten
   // and the whole batch's counts allocated
-  grid_barrier(cws + kChainBar + 1, (unsigned int)B);
+  grid_barrier<true>(cws + kChainBar + 1, (unsigned int)B);
   if (b == 0 && quant && tid < nb) {
     upper[tid] = up_s[tid];
     lower[tid] = lo_s[tid];

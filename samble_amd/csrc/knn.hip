@@ -49,7 +49,15 @@ __global__ __launch_bounds__(256) void cloud_mean_kernel(const float* __restrict
   if (c >= C) return;
   const float* p = x + (long)b * bs + (long)c * N;
   float s = 0.f;
-  for (int n = lane; n < N; n += 64) s += p[n];
+  int n = lane;
+  for (; n + 7 * 64 < N; n += 8 * 64) {  // 8 loads in flight per lane, summed in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[n + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; n < N; n += 64) s += p[n];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) mean[b * C + c] = s / (float)N;

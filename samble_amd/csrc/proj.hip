@@ -30,27 +30,27 @@ constexpr int kO = 384;
 constexpr int kProjLdsFloats = 2 * kTile * kLdsPad;
 
 // token rows are the same for every cloud: tokqkv[t][o] = sum_c W[o][c] tokens[c][t], computed once.
-// One wave per 8 outputs; lanes span the channels (coalesced 512-byte reads of W rows).
-__global__ __launch_bounds__(64) void proj_tok_fwd_kernel(const float* __restrict__ tokens, int nt,
-                                                          const float* __restrict__ W, float* __restrict__ tokqkv) {
-  const int lane = threadIdx.x;
-  float tk0[8], tk1[8];
+// One wave per output row o (lanes span the channels: coalesced 512-byte reads of the W row), the 8 token sums of
+// a wave are independent shuffle trees.
+__global__ __launch_bounds__(256) void proj_tok_fwd_kernel(const float* __restrict__ tokens, int nt,
+                                                           const float* __restrict__ W, float* __restrict__ tokqkv) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const float w0 = W[(long)o * kC + lane], w1 = W[(long)o * kC + lane + 64];
+  float p[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    tk0[t] = (t < nt) ? tokens[lane * nt + t] : 0.f;
-    tk1[t] = (t < nt) ? tokens[(lane + 64) * nt + t] : 0.f;
+    const float tk0 = (t < nt) ? tokens[lane * nt + t] : 0.f;
+    const float tk1 = (t < nt) ? tokens[(lane + 64) * nt + t] : 0.f;
+    p[t] = fmaf(w0, tk0, w1 * tk1);
   }
-  for (int oo = 0; oo < 8; ++oo) {
-    const int o = blockIdx.x * 8 + oo;
-    const float w0 = W[(long)o * kC + lane], w1 = W[(long)o * kC + lane + 64];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      float p = fmaf(w0, tk0[t], w1 * tk1[t]);
+  for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-      if (lane == 0 && t < nt) tokqkv[t * kO + o] = p;
-    }
-  }
+    for (int t = 0; t < 8; ++t) p[t] += __shfl_xor(p[t], off, 64);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (lane == 0 && t < nt) tokqkv[t * kO + o] = p[t];
 }
 
 __global__ __launch_bounds__(256, 2) void proj_fwd_kernel(const float* __restrict__ x, long x_bs, int N,
@@ -348,7 +348,7 @@ extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, c
                                       hipStream_t s) {
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
-  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 8), dim3(64), 0, s, tokens, nt, W, tokqkv);
+  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 4), dim3(256), 0, s, tokens, nt, W, tokqkv);
   if (wimg) return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, s);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),

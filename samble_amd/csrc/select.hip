@@ -154,7 +154,7 @@ template <int LEVEL>
 __global__ __launch_bounds__(1024) void qsel_kernel(const float* __restrict__ z, long n, int nb,
                                                     unsigned int* __restrict__ ws, float* __restrict__ out) {
   extern __shared__ unsigned int qsm[];  // LDS histogram of this level
-  __shared__ unsigned int scanbuf[16];
+  __shared__ unsigned int scanbuf[16 * kMaxBins];
   __shared__ unsigned int prefix[kMaxBins];
   __shared__ unsigned int rem[kMaxBins];
   const int tid = threadIdx.x;

@@ -59,21 +59,70 @@ __device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, l
   unsigned int rr[kMaxBins];
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) rr[t] = rem[t];
-  for (int t = 0; t < nq; ++t) {
-    const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
-    unsigned int loc[2] = {0u, 0u}, ts = 0u;
-    for (int u = 0; u < per; ++u) {
-      loc[u] = h[per * tid + u];
-      ts += loc[u];
+  // all nq ranks resolved by ONE scan round (two barriers): every thread carries the nq per-rank partial counts
+  // side by side (level 0 has one histogram for all ranks).  scanbuf: 16 x kMaxBins words.
+  unsigned int loc[kMaxBins][2], ts[kMaxBins], incl[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    loc[t][0] = loc[t][1] = ts[t] = 0u;
+    if (t < nq && (level > 0 || t == 0)) {
+      const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
+      for (int u = 0; u < per; ++u) {
+        loc[t][u] = h[per * tid + u];
+        ts[t] += loc[t][u];
+      }
     }
-    const unsigned int incl = block_scan_incl(ts, scanbuf, tid);
-    unsigned int c = incl - ts;
+  }
+  if (level == 0) {
+#pragma unroll
+    for (int t = 1; t < kMaxBins; ++t) {
+      loc[t][0] = loc[0][0];
+      loc[t][1] = loc[0][1];
+      ts[t] = ts[0];
+    }
+  }
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) incl[t] = ts[t];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+      for (int t = 0; t < kMaxBins; ++t) {
+        if (t < nq && (level > 0 || t == 0)) {
+          const unsigned int up = __shfl_up(incl[t], o, 64);
+          if (lane >= o) incl[t] += up;
+        }
+      }
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int t = 0; t < kMaxBins; ++t) scanbuf[wv * kMaxBins + t] = incl[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      if (t < nq && (level > 0 || t == 0)) {
+        unsigned int base = 0u;
+        for (int w2 = 0; w2 < wv; ++w2) base += scanbuf[w2 * kMaxBins + t];
+        incl[t] += base;
+      }
+    }
+    if (level == 0) {
+#pragma unroll
+      for (int t = 1; t < kMaxBins; ++t) incl[t] = incl[0];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    if (t >= nq) continue;
+    unsigned int c = incl[t] - ts[t];
     for (int u = 0; u < per; ++u) {
-      if (c <= rr[t] && rr[t] < c + loc[u]) {
+      if (c <= rr[t] && rr[t] < c + loc[t][u]) {  // exactly one (thread, u) matches
         prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
         rem[t] = rr[t] - c;
       }
-      c += loc[u];
+      c += loc[t][u];
     }
   }
   __syncthreads();
