@@ -157,6 +157,8 @@ def main():
                     help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--logit-map", action="store_true",
+                    help="A/B: keep the N x (N+nt) logit map in HBM (the round-1 pipeline) instead of the map-free forward")
     ap.add_argument("--backend", default="nccl",
                     help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
     args = ap.parse_args()
@@ -187,6 +189,9 @@ def main():
 
     from samble_amd import _lib, ops, sampler_config, synth
     from samble_amd.downsample import DownSampleToken
+    if args.logit_map:
+        import samble_amd.downsample as _ds
+        _ds.MAP_FREE = False
 
     seed = 1000 * 2
     mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0)

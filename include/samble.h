@@ -251,6 +251,8 @@ int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float*
  *                               replaces q@k, /sqrt(D), the softmax normaliser and the token split
  *                               (models/downsample.py:139-153)
  *   samble_sparse_score_map_f32 = samble_sparse_score_f32 reading A_ij = exp(S_ij - lse_i) from the map
+ *                               (ld == 0: `smap` is the compact (B, N, KN) neighbour-logit array of
+ *                               samble_attn_stats_nl_tri_f32 and nn its ascending lists, see below)
  *                               (models/downsample.py:300-344)
  *   samble_attn_rows_fwd_f32    pass 2, the M sampled rows: x_ds (B,D,M) = softmax(S[idx]) V
  *                               replaces gather + @v + permute (models/downsample.py:242-252)
@@ -334,6 +336,33 @@ int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, con
                                  void* stream);
 int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, const void* v_tr_image,
                                  const int64_t* idx, int B, int N, int nt, int M, int D, float* x_ds, void* stream);
+
+/* ---- the map-free forward (split-bf16 images, asm "dot", the sparse_* score modes) ------------------------------
+ * The sparse score modes (models/downsample.py:300-344) read only the K kNN entries of each attention row, and the
+ * gathered product (downsample.py:242-252) only the M sampled rows: the N x (N+nt) logit map never has to exist.
+ *   samble_nn_prepare            neighbour lists (B, N, KN) of samble_knn_f32 -> the same lists in ascending index
+ *                                order (nn_sorted) and one 32-bit word per (cloud, tile of 32 keys, query):
+ *                                masks (B, ceil(N/32), N), bit k of word (b, t, i) set <=> 32 t + k in nn[b][i].
+ *                                KN in {16, 32}.  samble_nn_masks_bytes(B, N) = size of `masks`.
+ *   samble_attn_stats_nl_tri_f32 = samble_attn_stats_tri_f32 without the map: lse (B,N), tok (B,N,nt) and
+ *                                nl (B, N, KN), nl[b][i][k] = S[b][i][nn_sorted[b][i][k]] (bit-identical to the map's
+ *                                entries).  1 <= KN <= 32.
+ *   samble_sparse_score_map_f32 / samble_sparse_score_map_quantiles_f32 take that pair as (smap = nl, ld = 0,
+ *                                nn = nn_sorted).
+ *   samble_attn_rows_fwd_recompute_tri_f32 = samble_attn_rows_fwd_tri_f32 recomputing the logits of the M sampled
+ *                                rows from the Q / K images; pmap (optional, (B, M, ld), ld >=
+ *                                samble_attn_map_row_stride(N, nt)) receives P = softmax rows of the sampled rows,
+ *                                which samble_attn_rows_bwd_tri_f32 takes as `smap` with variant
+ *                                SAMBLE_ROWS_BWD_PMAP (no exponentials, no row indirection in the backward). */
+#define SAMBLE_ROWS_BWD_FUSED_DKDV 1 /* fused dP / dV / dK kernel instead of the dS map (logit map only) */
+#define SAMBLE_ROWS_BWD_PMAP 2       /* `smap` is the (B, M, ld) P map of samble_attn_rows_fwd_recompute_tri_f32 */
+size_t samble_nn_masks_bytes(int B, int N);
+int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks, void* stream);
+int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
+                                 const uint32_t* masks, int KN, float* nl, float* lse, float* tok, void* stream);
+int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_image, const void* v_tr_image,
+                                           const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
+                                           float* x_ds, float* pmap, int ld, void* stream);
 
 /* ---- measurement hook (bench.py; the only entry points that are not part of the path) ------------------
  * The library records HIP events around its own launches of the selected kernels, on the stream each is

@@ -62,6 +62,11 @@ int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hi
 int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, void*, void*, hipStream_t);
 int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
                                 hipStream_t);
+int samble_launch_attn_stats_nl_tri(const void*, const void*, int, int, int, float, const unsigned*, int, float*, float*,
+                                    float*, hipStream_t);
+int samble_launch_attn_rows_rc_tri(const void*, const void*, const void*, const float*, const long long*, int, int, int,
+                                   int, float, float*, float*, int, hipStream_t);
+int samble_launch_nn_prepare(const int*, int, int, int, int*, unsigned*, hipStream_t);
 int samble_launch_attn_stats_tri(const void*, const void*, int, int, int, float, float*, int, float*, float*, const float*,
                                  const float*, hipStream_t);
 int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
@@ -373,7 +378,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
     snprintf(msg, sizeof msg, "%s: null pointer", who);
     return fail(SAMBLE_E_INVALID, msg);
   }
-  if (variant < 0 || variant > 1) {
+  if (variant < 0 || variant > 2 || (variant == 2 && !(k_tr_image && v_rm_image && smap))) {
     snprintf(msg, sizeof msg, "%s: unknown variant", who);
     return fail(SAMBLE_E_INVALID, msg);
   }
@@ -547,6 +552,46 @@ SAMBLE_API int samble_attn_rows_fwd_f32(const float* smap, int ld, const float* 
   return done(samble_launch_attn_rows(smap, ld, lse, V, v_bs, v_rs, (const long long*)idx, B, N, nt, M, x_ds,
                                       (hipStream_t)stream),
               "samble_attn_rows_fwd_f32");
+}
+
+SAMBLE_API size_t samble_nn_masks_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (size_t)B * ((N + 31) / 32) * N * sizeof(uint32_t);
+}
+
+SAMBLE_API int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks,
+                                 void* stream) {
+  if (!nn || !nn_sorted || !masks) return fail(SAMBLE_E_INVALID, "samble_nn_prepare: null pointer");
+  if (B <= 0 || N <= 0 || (KN != 16 && KN != 32)) return fail(SAMBLE_E_INVALID, "samble_nn_prepare: need KN in {16, 32}");
+  return done(samble_launch_nn_prepare(nn, B, N, KN, nn_sorted, masks, (hipStream_t)stream), "samble_nn_prepare");
+}
+
+SAMBLE_API int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
+                                            const uint32_t* masks, int KN, float* nl, float* lse, float* tok,
+                                            void* stream) {
+  if (!q_image || !k_image || !masks || !nl || !lse || (nt > 0 && !tok))
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: D must be 128");
+  if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || KN < 1 || KN > 32)
+    return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: bad B/N/nt, or KN outside 1..32");
+  return done(samble_launch_attn_stats_nl_tri(q_image, k_image, B, N, nt, inv_sqrt_d(D), masks, KN, nl, lse, tok,
+                                              (hipStream_t)stream),
+              "samble_attn_stats_nl_tri_f32");
+}
+
+SAMBLE_API int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_image, const void* v_tr_image,
+                                                      const float* lse, const int64_t* idx, int B, int N, int nt, int M,
+                                                      int D, float* x_ds, float* pmap, int ld, void* stream) {
+  if (!q_image || !k_image || !v_tr_image || !lse || !idx || !x_ds)
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_recompute_tri_f32: null pointer");
+  if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_recompute_tri_f32: D must be 128");
+  if (B <= 0 || N <= 0 || M <= 0 || nt < 0 || nt > 8)
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_recompute_tri_f32: bad sizes");
+  if (pmap && ((ld & 3) || ld < samble_attn_map_ld(N, nt)))
+    return fail(SAMBLE_E_INVALID, "samble_attn_rows_fwd_recompute_tri_f32: bad P map row stride");
+  return done(samble_launch_attn_rows_rc_tri(q_image, k_image, v_tr_image, lse, (const long long*)idx, B, N, nt, M,
+                                             inv_sqrt_d(D), x_ds, pmap, ld, (hipStream_t)stream),
+              "samble_attn_rows_fwd_recompute_tri_f32");
 }
 
 SAMBLE_API int samble_sparse_score_map_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,

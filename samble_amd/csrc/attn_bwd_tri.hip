@@ -102,7 +102,9 @@ struct DqTriArgs {
   float* dsmap;  // optional (B, M, ld): dS of the sampled rows, for the key-stationary kernels
 };
 
-template <int ABL>  // timing-only ablations (wrong results): 1 = tiles staged once, 2 = no matrix products
+// PMAP: a.smap is the P map of the SAMPLED rows (B, M, ld) written by attn_rows_rc_tri_kernel -- P is read, not
+// re-exponentiated, and the row needs no index indirection
+template <int ABL, bool PMAP>  // ABL: timing-only ablations (wrong results): 1 = tiles staged once, 2 = no matrix products
 __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int NW = 4;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
   const int mc = mvalid ? mrow : M - 1;
   const long row = a.idx[(long)b * M + mc];
   const float my_lse = a.lse_s[(long)b * M + mc], my_delta = a.delta[(long)b * M + mc];
-  const float* srow = a.smap + ((long)b * N + row) * a.ld + 4 * h;
+  const float* srow = a.smap + (PMAP ? (long)b * M + mc : (long)b * N + row) * a.ld + 4 * h;
   const int ntiles = (a.NK + kTile - 1) / kTile, mtiles = (M + kTile - 1) / kTile;
   const char* Vb = a.V_rm + (long)b * ntiles * kTriTile;
   const char* Kb = a.K_tr + (long)b * ntiles * kTriTile;
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        ds[r] = __expf(v4[e] - my_lse) * (dp[r] - my_delta) * scale;  // columns past N + nt hold -inf: P = 0
+        // columns past N + nt hold -inf (P map: 0): P = 0
+        ds[r] = (PMAP ? v4[e] : __expf(v4[e] - my_lse)) * (dp[r] - my_delta) * scale;
       }
     }
     if (a.dsmap) {  // dS tile -> map rows as full 128-byte lines (8 lanes per row), through the wave's LDS tile
@@ -531,12 +534,14 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
                                      const void* dO_tr, const void* Q_tr, const void* V_rm, const void* K_tr,
                                      const long long* idx, int B, int N, int nt, int M, float scale, float* dQ, long dq_bs,
                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                     float* cs, float* dsmap, int fused_dkdv, hipStream_t stream) {
+                                     float* cs, float* dsmap, int fused_dkdv, int pmap, hipStream_t stream) {
+  // pmap != 0: smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri); needs the dS-map variant
   // fused_dkdv == 0 (default): the dQ kernel writes a dS map and dV / dK accumulate from the maps (4 products per
   // tile); != 0: fused dP / dV / dK kernel (5 products, no dS map)
   {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipSuccess;
-    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0, false>),
+                          reinterpret_cast<const void*>(bwd_dq_tri_kernel<0, true>)}) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
       if (e != hipSuccess) return (int)e;
     }
@@ -551,18 +556,23 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
     }
   }
   const bool use_map = !fused_dkdv && dsmap;
+  if (pmap && !use_map) return (int)hipErrorInvalidValue;
   const DqTriArgs dq{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)V_rm, (const char*)K_tr, idx, N, N + nt, M,
                      scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
   {
     Timed timed(kT_bwd_dq, stream);
-    hipLaunchKernelGGL(bwd_dq_tri_kernel<0>, dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+    if (pmap) hipLaunchKernelGGL((bwd_dq_tri_kernel<0, true>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+    else hipLaunchKernelGGL((bwd_dq_tri_kernel<0, false>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
   }
   if (use_map) {
     const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr};
     const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs};
     {
       Timed timed(kT_bwd_dv, stream);
-      hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+      if (pmap)  // P is there already: the dS-map mode of the kernel, on (P map, dO^T)
+        hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+      else
+        hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
     }
     Timed timed(kT_bwd_dk, stream);
     if (cs) hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, true>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);

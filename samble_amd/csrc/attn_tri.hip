@@ -287,6 +287,142 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// pass 1 WITHOUT the logit map ("nl" = neighbour logits): the sparse_* score modes only touch the K kNN entries of
+// a row, so the pass keeps the softmax statistics (lse), the token logits and -- instead of streaming all N x (N+nt)
+// logits to HBM (545 MB at B = 32, N = 2048) -- just the K logits S[i][j], j in kNN(i), in ascending-j order
+// (nl (B, N, K): 8 MB).  Which keys of a tile are neighbours of a query comes as one 32-bit mask per (query, tile)
+// (nn_prepare_kernel, score.hip); the logits sit in this lane's accumulator registers, so the extraction is a bit
+// test, a popcount for the slot and a predicated 4-byte LDS write per register (a row of K slots per query in LDS,
+// flushed once at the end: predicated GLOBAL stores would sit behind exec-zero branches, and a store that may or
+// may not issue cannot be on a hand-counted vmcnt queue).  The sampled rows' logits are recomputed by pass 2
+// (attn_rows_rc_tri_kernel).  Same products, same order as attn_stats_tri_kernel: the statistics and every
+// extracted logit are bit-identical to that kernel's.
+// ------------------------------------------------------------------------------------------------
+constexpr int kNlStride = 33;  // words per query row in LDS (K <= 32; odd: rows on distinct banks)
+constexpr int kStatsNlLds = kStatsDepth * kTriTile + kStatsDepth * 2048 + 256 * kNlStride * 4;
+
+template <bool TAIL>
+__device__ __forceinline__ void stats_nl_epilogue(int h, f32x16& s_cur, float scale, unsigned mask, int& cnt,
+                                                  float* nlrow, int j0, int N, int NK,
+                                                  float* __restrict__ tokrow, float& m, float& l) {
+  float mt = kNegInf, ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = s_cur[r] * scale;
+    const int kk = crow(r, h);
+    if (TAIL) {
+      const int j = j0 + kk;
+      if (j >= NK) v = kNegInf;
+      if (j >= N && j < NK) tokrow[j - N] = v;
+    }
+    s_cur[r] = v;
+    mt = fmaxf(mt, v);
+    if ((mask >> kk) & 1u) nlrow[cnt + (int)__popc(mask & ((1u << kk) - 1u))] = v;
+  }
+  cnt += (int)__popc(mask);
+  mt = fmaxf(mt, wave_xor32(mt));  // running max (branch-free rescale of the running sum)
+  const float mnew = fmaxf(m, mt);
+  l *= __expf(m - mnew);
+  m = mnew;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ps += __expf(s_cur[r] - m);
+  l += ps;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* __restrict__ Qimg,
+                                                                   const char* __restrict__ Kimg, int N, int NK,
+                                                                   float scale, const unsigned* __restrict__ masks,
+                                                                   int KN, float* __restrict__ nl,
+                                                                   float* __restrict__ lse, float* __restrict__ tok,
+                                                                   int nt) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 8, D = kStatsDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int qtiles = (N + kTile - 1) / kTile, ntiles = (NK + kTile - 1) / kTile;
+  const int mtiles = qtiles;  // mask words per query: one per tile of POINT keys
+  // rows past N are clamped to row N-1 (they recompute and rewrite its values bit for bit)
+  const int qrow = min(chunk * (32 * NW) + wave * 32 + lo, N - 1);
+  const char* Kb = Kimg + (long)b * ntiles * kTriTile;
+  auto tile_ptr = [&](int t) { return Kb + (long)min(t, ntiles - 1) * kTriTile; };  // past the end: the last tile again, unused
+  auto buf_ptr = [&](int t) { return smem_c + (t & (D - 1)) * kTriTile; };
+  // the mask word of (this query, tile t) rides along with tile t through the ring, by LDS-DMA as well: a
+  // register-returning load in the loop would make the compiler drain the whole queue (vmcnt(0)) every tile
+  const unsigned* mrow = masks + (long)b * mtiles * N + qrow;  // + t * N: the word of tile t
+  char* mring = smem_c + D * kTriTile;                        // D slots of 512 words
+  auto stage = [&](int t) {
+    glds_tile(tile_ptr(t), buf_ptr(t), tid, wave);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mrow + (long)min(t, mtiles - 1) * N),
+                                     (__attribute__((address_space(3))) void*)(mring + (t & (D - 1)) * 2048 + wave * 256),
+                                     4, 0, 0);
+  };
+#pragma unroll
+  for (int t = 0; t < D; ++t) stage(t);
+
+  u32x4 q[24];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * kTriTile +
+                                                     tri_rm_off(qrow & 31, h, 0));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      q[3 * ks] = qp[192 * ks];
+      q[3 * ks + 1] = qp[192 * ks + 32];
+      q[3 * ks + 2] = qp[192 * ks + 64];
+    }
+  }
+  float* tokrow = tok + ((long)b * N + qrow) * nt;
+  // neighbour logits of this wave's 32 queries: rows of kNlStride words behind the mask ring (both half-waves fill
+  // the row of their query; the slots are disjoint)
+  float* nlrow = reinterpret_cast<float*>(mring + D * 2048) + (wave * 32 + lo) * kNlStride;
+  float m = kNegInf, l = 0.f;
+  int cnt = 0;
+  auto mask_of = [&](int t) {  // tiles of token / padding keys only: no neighbours
+    const unsigned w = *reinterpret_cast<const unsigned*>(mring + (t & (D - 1)) * 2048 + tid * 4);
+    return t < mtiles ? w : 0u;
+  };
+
+  // all D prologue tiles (and this wave's Q rows) have landed; from here on the waits are counted
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  f32x16 s_cur, s_nxt;
+  stats_products<0>(buf_ptr(0), lo, h, q, s_cur);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
+
+  // iteration t: restage the slot of tile t (read one iteration ago) with tile t+D and its mask word, products of
+  // tile t+1, statistics / neighbour logits of tile t, then retire tile t+2's DMA.  VM operations issued after
+  // that DMA for certain: 3 + 1 DMA pieces per later iteration = 4 (D - 2).  (The tail tiles' predicated token
+  // stores may add to that: counting low is the safe side, vmcnt(n) = at most n pending.)
+  const bool pfirst = wave < 4;
+  auto step = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    const int j0 = t * kTile;
+    const unsigned mask_cur = mask_of(t);  // before its slot is restaged
+    stage(t + D);
+    if (pfirst) {
+      stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
+    } else {
+      stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
+      __builtin_amdgcn_sched_barrier(0);
+      stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (D - 2)) : "memory");
+    s_cur = s_nxt;
+  };
+  const int n_full = min(N / kTile, ntiles);  // tiles without token / padding columns
+  int t = 0;
+  for (; t < n_full; ++t) step(t, std::false_type{});
+  for (; t < ntiles; ++t) step(t, std::true_type{});
+  const float ltot = l + wave_xor32(l);
+  if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row was written by this wave's two halves only
+  float* nlout = nl + ((long)b * N + qrow) * KN;
+  for (int k = h; k < KN; k += 2) nlout[k] = nlrow[k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 2 (attn_rows_kernel of attn_map.hip): one workgroup = 4 waves = 128 SAMPLED rows of one cloud.
 // Lane (i, h) takes its row's 16 logits per key tile from the map, P = exp(S - lse) lands in the
 // accumulator layout, is split into three bf16 planes in registers (accumulator-as-operand: registers
@@ -388,6 +524,148 @@ __global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// pass 2 WITHOUT the logit map: the M sampled rows recompute their logits (the same 48 MFMAs per tile and the same
+// operand images as pass 1: S comes out bit-identical), P = exp(S - lse) feeds O^T += V^T P^T as in
+// attn_rows_tri_kernel, and -- when the backward will run -- the P tile goes out to a P MAP of the SAMPLED rows
+// only, pmap (B, M, ld): what bwd_dq_tri / bwd_kacc_tri read (no exp, no row indirection there).  Per tile a
+// K row-image tile and a V transposed-image tile by LDS-DMA, ring of 3, every wait counted: per iteration a thread
+// issues 12 DMA pieces and (PMAP) 4 stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRcDepth = 3;
+constexpr int kRcLds = kRcDepth * 2 * kTriTile;
+
+// This kernel runs ONE wave per SIMD (32 768 sampled rows / 32), so nothing but its own instruction stream can
+// fill the matrix pipe while it exponentiates and splits P: the logit products of tile t+1 (48 MFMAs) are issued
+// INTERLEAVED with the vector work on tile t (one slice of two logits -> two P values -> one packed word of each
+// plane per k-step), then the 48 MFMAs of P V of tile t follow back to back.  K tiles run one tile ahead of the
+// V tiles through their two rings (K three tiles ahead of the loop counter, V two).
+template <bool PMAP>
+__global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __restrict__ Qimg,
+                                                               const char* __restrict__ Kimg,
+                                                               const char* __restrict__ Vtr,
+                                                               const float* __restrict__ lse,
+                                                               const long long* __restrict__ idx, int N, int NK, int M,
+                                                               float scale, float* __restrict__ xds,
+                                                               float* __restrict__ pmap, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 4, D = kRcDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int mrow = chunk * (32 * NW) + wave * 32 + lo;
+  const bool mvalid = mrow < M;
+  const int mc = mvalid ? mrow : M - 1;  // rows past M-1 recompute and rewrite row M-1's values (same bytes)
+  const long row = idx[(long)b * M + mc];
+  const float my_lse = lse[(long)b * N + row];
+  const int qtiles = (N + kTile - 1) / kTile, ntiles = (NK + kTile - 1) / kTile;
+  const char* Kb = Kimg + (long)b * ntiles * kTriTile;
+  const char* Vb = Vtr + (long)b * ntiles * kTriTile;
+  char* kring = smem_c;
+  char* vring = smem_c + D * kTriTile;
+
+  auto stage = [&](const char* img, char* ring, int t) {  // tile t -> slot t % D: 6 DMA pieces per thread
+    const int tt = min(t, ntiles - 1);                      // past the end: the last tile again, unused
+    char* lt = ring + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(img + (long)tt * kTriTile + (tid + 256 * k) * 16),
+          (__attribute__((address_space(3))) void*)(lt + (wave * 64 + 256 * k) * 16), 16, 0, 0);
+  };
+  stage(Kb, kring, 0);
+  stage(Kb, kring, 1);
+  stage(Vb, vring, 0);
+  stage(Kb, kring, 2);
+  stage(Vb, vring, 1);
+  u32x4 q[24];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (int)(row >> 5)) * kTriTile +
+                                                     tri_rm_off((int)(row & 31), h, 0));
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      q[3 * ks] = qp[192 * ks];
+      q[3 * ks + 1] = qp[192 * ks + 32];
+      q[3 * ks + 2] = qp[192 * ks + 64];
+    }
+  }
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+  float* prow = PMAP ? pmap + ((long)b * M + mc) * ld + 4 * h : nullptr;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  f32x16 s_cur, s_nxt;
+  stats_products<0>(kring, lo, h, q, s_cur);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K slot 0 is restaged by iteration 0
+
+  for (int t = 0; t < ntiles; ++t) {
+    stage(Kb, kring, t + 3);  // slot of K tile t: its reads ended before the last barrier
+    stage(Vb, vring, t + 2);  // slot of V tile t-1: likewise
+    const char* vt = vring + (t % D) * kTriTile;
+    const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
+    Tri bp[2];  // P^T fragments of the two k-steps of P V: elements e <-> registers 8 ks + e
+    float p[16];
+    s_nxt = zero16();
+    Tri a0 = {lp[0], lp[32], lp[64]}, a1 = {lp[192], lp[192 + 32], lp[192 + 64]};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      Tri a2 = a1;
+      if (ks + 2 < 8) a2 = Tri{lp[192 * (ks + 2)], lp[192 * (ks + 2) + 32], lp[192 * (ks + 2) + 64]};
+      __builtin_amdgcn_sched_barrier(0);
+      const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+      s_nxt = mfma_tri(a0, bq, s_nxt);
+      {  // slice ks of the vector work on tile t: logits 2 ks, 2 ks + 1
+#pragma clang fp contract(off)  // the statistics pass formed lse from round(s * scale): no fma here
+        const int r0 = 2 * ks, r1 = 2 * ks + 1;
+        const float e0 = __expf(s_cur[r0] * scale - my_lse), e1 = __expf(s_cur[r1] * scale - my_lse);
+        p[r0] = (t * kTile + crow(r0, h) < NK) ? e0 : 0.f;  // padding keys of the last tile
+        p[r1] = (t * kTile + crow(r1, h) < NK) ? e1 : 0.f;
+        unsigned hh, mm, ll;
+        tri_split2(p[r0], p[r1], hh, mm, ll);
+        bp[ks >> 2].h[ks & 3] = hh;
+        bp[ks >> 2].m[ks & 3] = mm;
+        bp[ks >> 2].l[ks & 3] = ll;
+      }
+      // one MFMA, then its share of the slice's vector instructions
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+      a1 = a2;
+    }
+    if (PMAP) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(prow + t * kTile + 8 * g) = o;
+      }
+    }
+    tri_pipelined<8>(
+        [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+          const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+          return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                     *reinterpret_cast<const u32x4*>(ap + 4096)};
+        },
+        [&](int i, const Tri& a) { oacc[i & 3] = mfma_tri(a, bp[i >> 2], oacc[i & 3]); });
+    // K tile t+2 and V tile t+1 (staged one iteration ago) must have landed before anyone reads them.  Younger
+    // than their pieces: the previous iteration's stores, this iteration's 12 pieces and stores
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
+    s_cur = s_nxt;
+  }
+  if (mvalid) {
+    float* ob = xds + (long)b * 128 * M + mrow;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ob[(long)(32 * dt + crow(r, h)) * M] = oacc[dt][r];
+    }
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -444,5 +722,41 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
   Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm);
+  return (int)hipGetLastError();
+}
+
+// pass 1 without the map: lse, token logits and the K neighbour logits per row (nl (B, N, KN), ascending-index order)
+extern "C" int samble_launch_attn_stats_nl_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
+                                               const unsigned* masks, int KN, float* nl, float* lse, float* tok,
+                                               hipStream_t stream) {
+  if (KN < 1 || KN > 32) return (int)hipErrorInvalidValue;
+  const size_t lds = kStatsNlLds;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stats_nl_tri_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_attn_stats, stream);
+  hipLaunchKernelGGL(attn_stats_nl_tri_kernel, dim3((N + 255) / 256, B), dim3(512), lds, stream, (const char*)qimg,
+                     (const char*)kimg, N, N + nt, scale, masks, KN, nl, lse, tok, nt);
+  return (int)hipGetLastError();
+}
+
+// pass 2 without the map: x_ds of the M sampled rows, and (pmap != null) their P map (B, M, ld) for the backward
+extern "C" int samble_launch_attn_rows_rc_tri(const void* qimg, const void* kimg, const void* v_tr_image,
+                                              const float* lse, const long long* idx, int B, int N, int nt, int M,
+                                              float scale, float* xds, float* pmap, int ld, hipStream_t stream) {
+  for (const void* f : {reinterpret_cast<const void*>(attn_rows_rc_tri_kernel<false>),
+                        reinterpret_cast<const void*>(attn_rows_rc_tri_kernel<true>)}) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kRcLds);
+    if (e != hipSuccess) return (int)e;
+  }
+  Timed timed(kT_attn_rows, stream);
+  if (pmap)
+    hipLaunchKernelGGL(attn_rows_rc_tri_kernel<true>, dim3((M + 127) / 128, B), dim3(256), kRcLds, stream,
+                       (const char*)qimg, (const char*)kimg, (const char*)v_tr_image, lse, idx, N, N + nt, M, scale, xds,
+                       pmap, ld);
+  else
+    hipLaunchKernelGGL(attn_rows_rc_tri_kernel<false>, dim3((M + 127) / 128, B), dim3(256), kRcLds, stream,
+                       (const char*)qimg, (const char*)kimg, (const char*)v_tr_image, lse, idx, N, N + nt, M, scale, xds,
+                       pmap, ld);
   return (int)hipGetLastError();
 }

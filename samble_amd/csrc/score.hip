@@ -99,6 +99,9 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
 // recomputed: A_ij = exp(S_ij - lse_i), one lane per (row, neighbour) pair.  The reference gathers these
 // very entries from its dense map (downsample.py:300-307), so this is also the closer restatement.
 // grid (ceil(N/64), B), 256 threads: 8 half-waves, each walks rows r0+hw, r0+hw+8, ...
+// COMPACT: `smap` is the (B, N, KN) array of neighbour logits of attn_stats_nl (entry k of row i = the logit of
+// neighbour nn[i][k], nn in ascending-index order) instead of the (B, N, ld) logit map.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __restrict__ smap, int ld,
                                                                const float* __restrict__ lse,
                                                                const int* __restrict__ nn, int N, int KN,
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __re
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = min(r0 + hw + 8 * u, N - 1);
-      sv[u] = smap[((long)b * N + i) * ld + j[u]];
+      sv[u] = COMPACT ? smap[((long)b * N + i) * KN + min(k, KN - 1)] : smap[((long)b * N + i) * ld + j[u]];
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -306,14 +309,14 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
   hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)N * 12;
+  auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;  // ld == 0: compact logits
   if (lds > 64 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_map_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_sparse_score, stream);
-  hipLaunchKernelGGL(sparse_score_map_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN,
-                     colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
+  hipLaunchKernelGGL(kern, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN, colacc, indeg,
+                     mode >= kRowSum ? rowstat : nullptr, mode);
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
   if (indeg_out) {
     e = hipMemcpyAsync(indeg_out, indeg, (size_t)B * N * sizeof(int), hipMemcpyDeviceToDevice, stream);
@@ -324,6 +327,7 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
 
 // the accumulation pass alone, for the fused select chain (chain.hip): zeroes `zero_bytes` of ws (accumulators and
 // whatever follows them: the chain's histograms and barrier counters), then gathers the map entries
+// (ld == 0: `smap` holds the compact neighbour logits (B, N, KN) of attn_stats_nl, nn their ascending index lists)
 extern "C" int samble_launch_sparse_score_map_acc(const float* smap, int ld, const float* lse, const int* nn, int B, int N,
                                                   int KN, int mode, void* ws, size_t zero_bytes, hipStream_t stream) {
   if (mode < 0 || mode > kRowStd) return -22;
@@ -333,14 +337,63 @@ extern "C" int samble_launch_sparse_score_map_acc(const float* smap, int ld, con
   hipError_t e = hipMemsetAsync(ws, 0, zero_bytes, stream);
   if (e != hipSuccess) return (int)e;
   const size_t lds = (size_t)N * 12;
+  auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;
   if (lds > 64 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_map_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_sparse_score, stream);
-  hipLaunchKernelGGL(sparse_score_map_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN,
-                     colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
+  hipLaunchKernelGGL(kern, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN, colacc, indeg,
+                     mode >= kRowSum ? rowstat : nullptr, mode);
+  return (int)hipGetLastError();
+}
+
+// Neighbour lists for the map-free forward (attn_stats_nl_tri_kernel): per query the K neighbour indices in
+// ASCENDING order (rank by counting: the K indices of a row are distinct) and one 32-bit mask per (query, tile of
+// 32 point keys): bit k set <=> key 32 t + k is a neighbour.  masks (B, T, N), T = ceil(N / 32): the word of a
+// (tile, 32 consecutive queries) is one coalesced 128-byte line.  One thread per query; the mask words of 64 tiles
+// at a time are built in LDS (one private column per thread).
+template <int KN>
+__global__ __launch_bounds__(256) void nn_prepare_kernel(const int* __restrict__ nn, int N, int T,
+                                                         int* __restrict__ nn_sorted, unsigned* __restrict__ masks) {
+  __shared__ unsigned words[64][256];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const bool live = i < N;
+  int v[KN];
+  const int* row = nn + ((long)b * N + min(i, N - 1)) * KN;
+#pragma unroll
+  for (int k = 0; k < KN; ++k) v[k] = row[k];
+  if (live) {
+    int* out = nn_sorted + ((long)b * N + i) * KN;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      int rank = 0;
+#pragma unroll
+      for (int k2 = 0; k2 < KN; ++k2) rank += (v[k2] < v[k]) ? 1 : 0;
+      out[rank] = v[k];
+    }
+  }
+  for (int t0 = 0; t0 < T; t0 += 64) {
+#pragma unroll 8
+    for (int t = 0; t < 64; ++t) words[t][tid] = 0u;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int t = (v[k] >> 5) - t0;
+      if (t >= 0 && t < 64) words[t][tid] |= 1u << (v[k] & 31);
+    }
+    if (live)
+      for (int t = 0; t < 64 && t0 + t < T; ++t) masks[((long)b * T + t0 + t) * N + i] = words[t][tid];
+  }
+}
+
+extern "C" int samble_launch_nn_prepare(const int* nn, int B, int N, int KN, int* nn_sorted, unsigned* masks,
+                                        hipStream_t stream) {
+  const int T = (N + 31) / 32;
+  const dim3 grid((N + 255) / 256, B);
+  if (KN == 32) hipLaunchKernelGGL(nn_prepare_kernel<32>, grid, dim3(256), 0, stream, nn, N, T, nn_sorted, masks);
+  else if (KN == 16) hipLaunchKernelGGL(nn_prepare_kernel<16>, grid, dim3(256), 0, stream, nn, N, T, nn_sorted, masks);
+  else return -22;
   return (int)hipGetLastError();
 }
 

@@ -56,6 +56,10 @@ class _Projection(torch.autograd.Function):
 # Two-pass forward with the logit map kept in HBM (csrc/attn_map.hip) for the sparse_* score modes;
 # False selects the single-pass flash kernel (csrc/attn_fwd.hip) for A/B runs.
 TWO_PASS = True
+# With the split-bf16 kernels, asm "dot" and a sparse_* score mode the N x (N+nt) logit map is not built at all
+# (csrc/attn_tri.hip: attn_stats_nl_tri / attn_rows_rc_tri): pass 1 keeps the K neighbour logits of each row, pass 2
+# recomputes the M sampled rows and hands their P rows to the backward.  False keeps the map (A/B runs, tests).
+MAP_FREE = True
 
 
 class _SamplerCore(torch.autograd.Function):
@@ -74,6 +78,7 @@ class _SamplerCore(torch.autograd.Function):
         v = qkv[:, :, 2 * D:3 * D]
 
         smap = None
+        map_free = False
         plan = None  # (member, cap, w_pre, w, counts) when the fused select chain ran
         if mod.bin_boundaries is not None:
             mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
@@ -89,7 +94,24 @@ class _SamplerCore(torch.autograd.Function):
             indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
         else:
             nn_idx = ops.stage_knn(x, x, mod.K)
-            if TWO_PASS or mod.asm == "l2":
+            if MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and mod.asm == "dot" and mod.K in (16, 32):
+                need_bwd = ctx.needs_input_grad[0]
+                imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
+                nn_sorted, masks = ops.stage_nn_prepare(nn_idx)
+                nl, lse, tok = ops.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, mod.K, D)
+                del masks
+                if ops.chain_supported(B, N, nb):
+                    score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
+                                                                            mod.dynamic_boundaries_enable, compact=True)
+                    if quant is not None:
+                        quant = ops.world_average(quant)
+                    mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
+                                                                   mod.momentum_update_factor,
+                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws)
+                else:
+                    score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=True)
+                map_free = True
+            elif TWO_PASS or mod.asm == "l2":
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
                 imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
                 smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
@@ -119,7 +141,14 @@ class _SamplerCore(torch.autograd.Function):
                                                          mod.relu_mean_order == "relu_mean")
             counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
-        if smap is not None:
+        ctx.pmap = False
+        if map_free:
+            x_ds, pmap = ops.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, need_bwd, D)
+            if need_bwd:  # the P rows of the sampled points stand in for the logit map in the backward
+                ctx.save_for_backward(qkv, x_ds, lse, idx, pmap)
+                ctx.pmap = True
+                ctx.bwd_images = (imgs[3], imgs[4])
+        elif smap is not None:
             x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=imgs[2] if imgs else None)
             ctx.save_for_backward(qkv, x_ds, lse, idx, smap)
             ctx.bwd_images = (imgs[3], imgs[4]) if imgs is not None and len(imgs) == 5 else None
@@ -146,7 +175,8 @@ class _SamplerCore(torch.autograd.Function):
             if smap is not None:  # O is x_ds (B,D,M) here
                 ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
                                         dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm,
-                                        images=getattr(ctx, "bwd_images", None))
+                                        images=getattr(ctx, "bwd_images", None),
+                                        variant=ops.ROWS_BWD_PMAP if ctx.pmap else 0)
             else:
                 ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
                                    dqkv[:, :, 2 * D:3 * D])

@@ -466,12 +466,64 @@ def stage_attn_rows(smap: torch.Tensor, lse: torch.Tensor, v: torch.Tensor, idx:
     return out
 
 
-def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str):
-    """stage_sparse_score with A_ij read from the logit map instead of recomputed."""
+ROWS_BWD_FUSED_DKDV, ROWS_BWD_PMAP = 1, 2   # include/samble.h: variants of samble_attn_rows_bwd_tri_f32
+
+
+def stage_nn_prepare(nn_idx: torch.Tensor):
+    """Neighbour lists (B,N,K) int32 -> (the same lists in ascending index order, the per-(tile, query) membership
+    words (B, ceil(N/32), N) int32) for the map-free forward (stage_attn_stats_nl)."""
+    _need_gpu(nn_idx)
+    nn_idx = nn_idx.to(torch.int32).contiguous()
+    B, N, K = nn_idx.shape
+    with torch.cuda.device(nn_idx.device):
+        nn_sorted = torch.empty_like(nn_idx)
+        masks = torch.empty((B, (N + 31) // 32, N), dtype=torch.int32, device=nn_idx.device)
+        assert masks.numel() * 4 == _lib.query("samble_nn_masks_bytes", B, N)
+        _lib.call("samble_nn_prepare", nn_idx.data_ptr(), B, N, K, nn_sorted.data_ptr(), masks.data_ptr(), _stream())
+    return nn_sorted, masks
+
+
+def stage_attn_stats_nl(q_image, k_image, masks, B: int, n_points: int, n_tokens: int, n_neighbors: int, D: int = 128):
+    """Pass 1 without the logit map (MATRIX_MODE "tri", asm "dot"): -> neighbour logits (B,N,K) in the order of
+    stage_nn_prepare's sorted lists, lse (B,N), token logits (B,N,nt)."""
+    _need_gpu(q_image, k_image, masks)
+    dev = q_image.device
+    with torch.cuda.device(dev):
+        nl = torch.empty((B, n_points, n_neighbors), dtype=torch.float32, device=dev)
+        lse = torch.empty((B, n_points), dtype=torch.float32, device=dev)
+        tok = torch.empty((B, n_points, max(n_tokens, 1)), dtype=torch.float32, device=dev)
+        _lib.call("samble_attn_stats_nl_tri_f32", q_image.data_ptr(), k_image.data_ptr(), B, n_points, n_tokens, D,
+                  masks.data_ptr(), n_neighbors, nl.data_ptr(), lse.data_ptr(), tok.data_ptr(), _stream())
+    return nl, lse, tok[:, :, :n_tokens]
+
+
+def stage_attn_rows_recompute(q_image, k_image, v_image, lse, idx, n_points: int, n_tokens: int, want_pmap: bool,
+                              D: int = 128):
+    """Pass 2 without the logit map: the M sampled rows idx (B,M) recompute their logits from the images.
+    -> x_ds (B,D,M), P map (B,M,ld) of the sampled rows (what stage_attn_rows_bwd takes with ROWS_BWD_PMAP) or None."""
+    _need_gpu(q_image, k_image, v_image, lse, idx)
+    B, M = idx.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    dev = lse.device
+    with torch.cuda.device(dev):
+        out = torch.empty((B, D, M), dtype=torch.float32, device=dev)
+        ld = _lib.query("samble_attn_map_row_stride", n_points, n_tokens)
+        pmap = torch.empty((B, M, ld), dtype=torch.float32, device=dev) if want_pmap else None
+        _lib.call("samble_attn_rows_fwd_recompute_tri_f32", q_image.data_ptr(), k_image.data_ptr(), v_image.data_ptr(),
+                  lse.data_ptr(), idx.data_ptr(), B, n_points, n_tokens, M, D, out.data_ptr(), _p(pmap), ld, _stream())
+    return out, pmap
+
+
+def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str, compact: bool = False):
+    """stage_sparse_score with A_ij read from the logit map instead of recomputed.
+    compact: `smap` is the (B,N,K) neighbour-logit array of stage_attn_stats_nl and nn_idx the sorted lists."""
     if idx_mode not in SCORE_MODES:
         raise ValueError("Please check the setting of idx mode!")
     _need_gpu(smap, lse, nn_idx)
     B, N, ld = smap.shape
+    if compact:
+        assert smap.shape == nn_idx.shape
+        ld = 0
     with torch.cuda.device(smap.device):
         score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
         z = torch.empty_like(score)
@@ -490,14 +542,17 @@ def chain_supported(B: int, N: int, num_bins: int) -> bool:
     return bool(_lib.query("samble_select_chain_supported", B, N, num_bins))
 
 
-def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool):
-    """stage_sparse_score_map + stage_batch_quantiles in two launches.
+def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, compact: bool = False):
+    """stage_sparse_score_map + stage_batch_quantiles in two launches (compact: as in stage_sparse_score_map).
     -> score (B,N), z (B,N), in-degree (B,N) int32, quantiles (nb-1,) or None, chain workspace (hand it to
     stage_bin_plan)."""
     if idx_mode not in SCORE_MODES:
         raise ValueError("Please check the setting of idx mode!")
     _need_gpu(smap, lse, nn_idx)
     B, N, ld = smap.shape
+    if compact:
+        assert smap.shape == nn_idx.shape
+        ld = 0
     with torch.cuda.device(smap.device):
         score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
         z = torch.empty_like(score)

@@ -276,3 +276,38 @@ def test_res_block_against_reference_fixture(name, matrix_mode):
             torch.testing.assert_close(b.cpu(), refb, rtol=2e-4, atol=1e-6)
         else:
             assert torch.equal(b.cpu(), refb)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_map_free_module_equals_map_module(name):
+    """DownSampleToken with and without the logit map (downsample.MAP_FREE): same indices, same x_ds, same
+    boundaries and same input / parameter gradients, bit for bit, on the reference fixtures' inputs."""
+    import samble_amd.downsample as D
+    from samble_amd import ops
+    g = Golden(name)
+    if not g.idx_mode.startswith("sparse") or g.asm != "dot":
+        pytest.skip("the map-free forward serves the sparse_* score modes with dot-product logits")
+    outs = []
+    old_mode, old_free = ops.MATRIX_MODE, D.MAP_FREE
+    try:
+        ops.MATRIX_MODE = "tri"
+        for free in (False, True):
+            D.MAP_FREE = free
+            mod = g.module(DEV)
+            res = []
+            for call in range(g.calls):
+                x = g.x(call).to(DEV).requires_grad_(True)
+                noise = None if g.sample_mode == "topk" else g.t("noise", call).to(DEV)
+                (x_ds, idx), _ = mod(x, noise=noise)
+                w = torch.linspace(-1, 1, x_ds.numel(), device=DEV).view_as(x_ds)
+                mod.zero_grad()
+                ((x_ds * w).sum() + mod.attention_bins_beforesoftmax.square().sum()).backward()
+                res.append([x_ds.detach(), idx, mod.attention_point_score, mod.bin_boundaries[0].clone(), x.grad] +
+                           [p.grad.clone() for p in mod.parameters() if p.grad is not None])
+            outs.append(res)
+    finally:
+        ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
+    for call, (a, b) in enumerate(zip(*outs)):
+        assert len(a) == len(b) and len(a) > 6
+        for j, (t1, t2) in enumerate(zip(a, b)):
+            assert torch.equal(t1, t2), (call, j)

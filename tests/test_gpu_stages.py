@@ -791,3 +791,59 @@ def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
     member4, cap4, _, w4 = o_.stage_bin_assign(z3, tok, state_a[0], state_a[1], True)
     assert torch.equal(st[0], up) and torch.equal(member3, member4) and torch.equal(cap3, cap4) and torch.equal(w3, w4)
     assert torch.equal(counts3, o_.stage_alloc_counts(w4, cap4, M))
+
+
+@pytest.mark.parametrize("B,N,nt,M,K", [(2, 256, 6, 128, 32), (3, 1000, 4, 333, 16), (32, 2048, 6, 1024, 32),
+                                         (1, 77, 1, 40, 16), (4, 4096, 6, 2048, 32)])
+def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
+    """The forward that never builds the N x (N+nt) logit map (attn_stats_nl_tri + attn_rows_rc_tri, csrc/attn_tri.hip)
+    against the two-pass map kernels it replaces: lse, token logits, the K neighbour logits of every row, every score
+    mode's score / z / in-degree, x_ds, the P rows of the sampled points and all three gradients BITWISE equal."""
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    o_.MATRIX_MODE = "tri"
+    try:
+        q, k, v = _qkv(B, N, nt, 4000 + N)
+        qkv = torch.cat((torch.cat((q, torch.zeros(B, nt, 128)), 1) * 0.3, k * 0.3, v), dim=2).to(DEV).contiguous()
+        qd, kd, vd = qkv[:, :N, :128], qkv[:, :, 128:256], qkv[:, :, 256:]
+        g = torch.Generator().manual_seed(N)
+        nn = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]) \
+            .int().to(DEV) if N <= 1024 else o_.stage_knn(qd.permute(0, 2, 1).contiguous(), qd.permute(0, 2, 1).contiguous(), K)
+        idx = torch.stack([torch.randperm(N, generator=g)[:M] for _ in range(B)]).to(DEV)
+        imgs = o_.stage_tri_split_qkv(qkv, N, for_backward=True)
+        smap, lse, tok = o_.stage_attn_stats(qd, kd, N, nt, images=imgs[:2])
+        nn_sorted, masks = o_.stage_nn_prepare(nn)
+        assert torch.equal(nn_sorted, nn.sort(dim=-1).values)
+        bits = torch.zeros((B, N, 32 * ((N + 31) // 32)), dtype=torch.bool, device=DEV)
+        bits.scatter_(2, nn.long(), True)
+        words = (bits.view(B, N, -1, 32).long() << torch.arange(32, device=DEV)).sum(-1)   # (B, N, T) as uint32 values
+        assert torch.equal(masks.long() & 0xFFFFFFFF, words.permute(0, 2, 1))
+        nl, lse2, tok2 = o_.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, K)
+        assert torch.equal(lse2, lse) and torch.equal(tok2, tok)
+        assert torch.equal(nl, torch.gather(smap, 2, nn_sorted.long()))
+        for mode in ("sparse_col_sum", "sparse_col_avg", "sparse_col_sqr", "sparse_row_sum", "sparse_row_std"):
+            a = o_.stage_sparse_score_map(smap, lse, nn, mode)
+            b2 = o_.stage_sparse_score_map(nl, lse, nn_sorted, mode, compact=True)
+            for x1, x2, what in zip(a, b2, ("score", "z", "indeg")):
+                assert torch.equal(x1, x2), (mode, what)
+        x_ds = o_.stage_attn_rows(smap, lse, vd, idx, N, nt, v_image=imgs[2])
+        x_ds2, pmap = o_.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, True)
+        x_ds3, none = o_.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, False)
+        assert none is None and torch.equal(x_ds2, x_ds) and torch.equal(x_ds3, x_ds)
+        rows = torch.gather(smap, 1, idx[:, :, None].expand(-1, -1, smap.shape[2]))
+        p_ref = torch.exp(rows[:, :, :N + nt] - torch.gather(lse, 1, idx)[:, :, None])
+        torch.testing.assert_close(pmap[:, :, :N + nt], p_ref, rtol=2e-6, atol=1e-12)
+        assert bool((pmap[:, :, N + nt:] == 0).all())
+        gr = torch.randn(B, 128, M, generator=g).to(DEV)
+        grads = []
+        for m, variant in ((smap, 0), (pmap, o_.ROWS_BWD_PMAP)):
+            dqkv = torch.full_like(qkv, float("nan"))
+            o_.stage_attn_rows_bwd(qd, kd, vd, m, lse, x_ds, idx, gr, N, nt, dqkv[:, :N, :128], dqkv[:, :, 128:256],
+                                   dqkv[:, :, 256:], images=(imgs[3], imgs[4]), variant=variant)
+            dqkv[:, N:, :128] = 0
+            grads.append(dqkv)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(grads[1]).any())
+        assert torch.equal(grads[0], grads[1])
+    finally:
+        o_.MATRIX_MODE = old
