@@ -533,13 +533,18 @@ __global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restr
 // issues 12 DMA pieces and (PMAP) 4 stores.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRcDepth = 3;
-constexpr int kRcLds = kRcDepth * 2 * kTriTile;
+constexpr int kRcLds = kRcDepth * 2 * kTriTile + 4 * 4096;  // K ring, V ring, one 32 x 32 fp32 tile per wave
 
 // This kernel runs ONE wave per SIMD (32 768 sampled rows / 32), so nothing but its own instruction stream can
-// fill the matrix pipe while it exponentiates and splits P: the logit products of tile t+1 (48 MFMAs) are issued
-// INTERLEAVED with the vector work on tile t (one slice of two logits -> two P values -> one packed word of each
-// plane per k-step), then the 48 MFMAs of P V of tile t follow back to back.  K tiles run one tile ahead of the
-// V tiles through their two rings (K three tiles ahead of the loop counter, V two).
+// fill the matrix pipe while it exponentiates and splits P.  Measured (tools/micro/split_mfma_bench.hip): a bf16
+// MFMA holds the SIMD's issue port for 16 of its 32 cycles and up to 4 vector instructions fit under the rest, so
+// an iteration is three INDEPENDENT streams woven together, one k-step at a time:
+//     logit products of tile t+1 (48 MFMAs)  |  P V of tile t-1 (48 MFMAs)  |  vector work on tile t (exp, mask,
+//     three-plane split: one slice of two logits per k-step, ~3 vector instructions per MFMA)
+// K tiles run two tiles ahead of the V tiles through their rings; every wait is counted.
+#ifndef SAMBLE_RC_ABL
+#define SAMBLE_RC_ABL 0  // timing-only ablations (wrong results): 1 no in-loop DMA, 2 no P V MFMAs, 4 no logit MFMAs
+#endif
 template <bool PMAP>
 __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __restrict__ Qimg,
                                                                const char* __restrict__ Kimg,
@@ -578,7 +583,6 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   stage(Kb, kring, 1);
   stage(Vb, vring, 0);
   stage(Kb, kring, 2);
-  stage(Vb, vring, 1);
   u32x4 q[24];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (int)(row >> 5)) * kTriTile +
@@ -593,69 +597,105 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   f32x16 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
-  float* prow = PMAP ? pmap + ((long)b * M + mc) * ld + 4 * h : nullptr;
+  const int m0 = chunk * (32 * NW) + wave * 32;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   f32x16 s_cur, s_nxt;
   stats_products<0>(kring, lo, h, q, s_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K slot 0 is restaged by iteration 0
+  Tri bp[2];  // P^T fragments (two k-steps of 16 keys) of the tile whose P V is due: tile t-1; none yet
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) bp[ks] = Tri{u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
 
-  for (int t = 0; t < ntiles; ++t) {
-    stage(Kb, kring, t + 3);  // slot of K tile t: its reads ended before the last barrier
-    stage(Vb, vring, t + 2);  // slot of V tile t-1: likewise
-    const char* vt = vring + (t % D) * kTriTile;
+  // iteration t = 0 .. ntiles: logits of tile t+1, P of tile t, P V of tile t-1 (t = 0: zeros against tile 0;
+  // t = ntiles: P is all padding, the logits are not used)
+  auto step = [&](int t, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+    if (!LAST && !(SAMBLE_RC_ABL & 1)) {
+      stage(Kb, kring, t + 3);  // slot of K tile t: its reads ended before the last barrier
+      stage(Vb, vring, t + 1);  // slot of V tile t-2: likewise
+    }
+    const char* vt = vring + (max(t - 1, 0) % D) * kTriTile;
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
-    Tri bp[2];  // P^T fragments of the two k-steps of P V: elements e <-> registers 8 ks + e
+    auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
+    auto fetch_v = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+      const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                 *reinterpret_cast<const u32x4*>(ap + 4096)};
+    };
+    Tri bn[2];
     float p[16];
     s_nxt = zero16();
-    Tri a0 = {lp[0], lp[32], lp[64]}, a1 = {lp[192], lp[192 + 32], lp[192 + 64]};
+    Tri k0 = fetch_k(0), k1 = fetch_k(1), v0 = fetch_v(0), v1 = fetch_v(1);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      Tri a2 = a1;
-      if (ks + 2 < 8) a2 = Tri{lp[192 * (ks + 2)], lp[192 * (ks + 2) + 32], lp[192 * (ks + 2) + 64]};
+    for (int i = 0; i < 8; ++i) {
+      Tri k2 = k1, v2 = v1;
+      if (i + 2 < 8) {
+        k2 = fetch_k(i + 2);
+        v2 = fetch_v(i + 2);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-      s_nxt = mfma_tri(a0, bq, s_nxt);
-      {  // slice ks of the vector work on tile t: logits 2 ks, 2 ks + 1
+      const Tri bq = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};
+      if (!LAST) {
+        if (SAMBLE_RC_ABL & 4) s_nxt[i] += __uint_as_float(k0.h[0] ^ bq.l[1] ^ k0.m[1] ^ k0.l[2]);
+        else s_nxt = mfma_tri(k0, bq, s_nxt);
+      }
+      if (SAMBLE_RC_ABL & 2) oacc[i & 3][i] += __uint_as_float(v0.h[0] ^ bp[i >> 2].l[1] ^ v0.m[1] ^ v0.l[2] ^ bp[i >> 2].h[1] ^ bp[i >> 2].m[1]);
+      else oacc[i & 3] = mfma_tri(v0, bp[i >> 2], oacc[i & 3]);
+      {  // slice i of the vector work on tile t: logits 2 i, 2 i + 1
 #pragma clang fp contract(off)  // the statistics pass formed lse from round(s * scale): no fma here
-        const int r0 = 2 * ks, r1 = 2 * ks + 1;
-        const float e0 = __expf(s_cur[r0] * scale - my_lse), e1 = __expf(s_cur[r1] * scale - my_lse);
-        p[r0] = (t * kTile + crow(r0, h) < NK) ? e0 : 0.f;  // padding keys of the last tile
-        p[r1] = (t * kTile + crow(r1, h) < NK) ? e1 : 0.f;
+        const int r0 = 2 * i, r1 = 2 * i + 1;
+        float x0 = s_cur[r0], x1 = s_cur[r1];
+        asm volatile("" : "+v"(x0), "+v"(x1));  // pins the slice inside this k-step's scheduling region (with the one below)
+        const float e0 = __expf(x0 * scale - my_lse), e1 = __expf(x1 * scale - my_lse);
+        p[r0] = (!LAST && t * kTile + crow(r0, h) < NK) ? e0 : 0.f;  // padding keys of the last tile
+        p[r1] = (!LAST && t * kTile + crow(r1, h) < NK) ? e1 : 0.f;
         unsigned hh, mm, ll;
         tri_split2(p[r0], p[r1], hh, mm, ll);
-        bp[ks >> 2].h[ks & 3] = hh;
-        bp[ks >> 2].m[ks & 3] = mm;
-        bp[ks >> 2].l[ks & 3] = ll;
+        asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));
+        bn[i >> 2].h[i & 3] = hh;
+        bn[i >> 2].m[i & 3] = mm;
+        bn[i >> 2].l[i & 3] = ll;
       }
-      // one MFMA, then its share of the slice's vector instructions
+      // the weave: one MFMA, then its share of the slice's vector instructions
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int m = 0; m < (LAST ? 6 : 12); ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 6 : 3, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      a0 = a1;
-      a1 = a2;
+      k0 = k1;
+      k1 = k2;
+      v0 = v1;
+      v1 = v2;
     }
-    if (PMAP) {
+    if (PMAP && !LAST) {
+      // P tile -> map rows as full 128-byte lines (8 lanes per row) through the wave's own 4 KB of LDS; 16-byte
+      // block c of row r sits at block c ^ (r & 7): conflict-free both ways without padding (the rings leave
+      // exactly 4 x 4 KB of the 160 KB)
+      char* xt = smem_c + 2 * D * kTriTile + wave * 4096;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(prow + t * kTile + 8 * g) = o;
+        *reinterpret_cast<f32x4*>(xt + lo * 128 + (((2 * g + h) ^ (lo & 7)) << 4)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: no barrier
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+        const int rr = (lane >> 3) + 8 * k8;
+        const f32x4 o = *reinterpret_cast<const f32x4*>(xt + rr * 128 + (((lane & 7) ^ (rr & 7)) << 4));
+        const int mr = min(m0 + rr, M - 1);  // rows past M-1 rewrite row M-1's values of this wave (same bytes)
+        *reinterpret_cast<f32x4*>(pmap + ((long)b * M + mr) * ld + t * kTile + 4 * (lane & 7)) = o;
       }
     }
-    tri_pipelined<8>(
-        [&](int i) {  // step i: k-step i >> 2, channel block i & 3
-          const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
-          return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
-                     *reinterpret_cast<const u32x4*>(ap + 4096)};
-        },
-        [&](int i, const Tri& a) { oacc[i & 3] = mfma_tri(a, bp[i >> 2], oacc[i & 3]); });
-    // K tile t+2 and V tile t+1 (staged one iteration ago) must have landed before anyone reads them.  Younger
+    // K tile t+2 and V tile t (staged one iteration ago) must have landed before anyone reads them.  Younger
     // than their pieces: the previous iteration's stores, this iteration's 12 pieces and stores
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
+    if (!LAST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
     s_cur = s_nxt;
-  }
+    bp[0] = bn[0];
+    bp[1] = bn[1];
+  };
+  for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
+  step(ntiles, std::true_type{});  // P V of the last tile
   if (mvalid) {
     float* ob = xds + (long)b * 128 * M + mrow;
 #pragma unroll
