@@ -346,9 +346,15 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
  *                                KN in {16, 32}.  samble_nn_masks_bytes(B, N) = size of `masks`.
  *   samble_attn_stats_nl_tri_f32 = samble_attn_stats_tri_f32 without the map: lse (B,N), tok (B,N,nt) and
  *                                nl (B, N, KN), nl[b][i][k] = S[b][i][nn_sorted[b][i][k]] (bit-identical to the map's
- *                                entries).  1 <= KN <= 32.
- *   samble_sparse_score_map_f32 / samble_sparse_score_map_quantiles_f32 take that pair as (smap = nl, ld = 0,
- *                                nn = nn_sorted).
+ *                                entries).  1 <= KN <= 32.  nl may be NULL when score_ws is given:
+ *                                with score_ws (samble_score_workspace_bytes or, for the fused chain,
+ *                                samble_select_chain_workspace_bytes; ALL score_ws_bytes are zeroed first) the
+ *                                pass also accumulates the sparse_* statistics of score_mode (A_ij = exp(S_ij -
+ *                                lse_i), i over all rows, j in nn_sorted[i]) into it as samble_sparse_score_map_f32
+ *                                would (N <= 8192): follow with samble_sparse_score_map(_quantiles)_f32 passing
+ *                                smap = NULL.
+ *   samble_sparse_score_map_f32 / samble_sparse_score_map_quantiles_f32 take (smap = nl, ld = 0, nn = nn_sorted),
+ *                                or smap = NULL: the statistics are in `ws` already (see above).
  *   samble_attn_rows_fwd_recompute_tri_f32 = samble_attn_rows_fwd_tri_f32 recomputing the logits of the M sampled
  *                                rows from the Q / K images; pmap (optional, (B, M, ld), ld >=
  *                                samble_attn_map_row_stride(N, nt)) receives P = softmax rows of the sampled rows,
@@ -359,7 +365,9 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
 size_t samble_nn_masks_bytes(int B, int N);
 int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks, void* stream);
 int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
-                                 const uint32_t* masks, int KN, float* nl, float* lse, float* tok, void* stream);
+                                 const uint32_t* masks, int KN, float* nl, float* lse, float* tok,
+                                 const int32_t* nn_sorted, int score_mode, void* score_ws, size_t score_ws_bytes,
+                                 void* stream);
 int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_image, const void* v_tr_image,
                                            const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
                                            float* x_ds, float* pmap, int ld, void* stream);

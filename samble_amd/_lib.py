@@ -101,7 +101,7 @@ _SIGNATURES = {
     "samble_nn_masks_bytes": (c_size_t, [c_int, c_int]),
     "samble_nn_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_attn_stats_nl_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "samble_attn_rows_fwd_recompute_tri_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "samble_attn_stats_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,

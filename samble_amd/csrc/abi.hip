@@ -63,7 +63,7 @@ int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, 
 int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
                                 hipStream_t);
 int samble_launch_attn_stats_nl_tri(const void*, const void*, int, int, int, float, const unsigned*, int, float*, float*,
-                                    float*, hipStream_t);
+                                    float*, const int*, int, void*, size_t, hipStream_t);
 int samble_launch_attn_rows_rc_tri(const void*, const void*, const void*, const float*, const long long*, int, int, int,
                                    int, float, float*, float*, int, hipStream_t);
 int samble_launch_nn_prepare(const int*, int, int, int, int*, unsigned*, hipStream_t);
@@ -568,13 +568,25 @@ SAMBLE_API int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_
 
 SAMBLE_API int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
                                             const uint32_t* masks, int KN, float* nl, float* lse, float* tok,
-                                            void* stream) {
-  if (!q_image || !k_image || !masks || !nl || !lse || (nt > 0 && !tok))
+                                            const int32_t* nn_sorted, int score_mode, void* score_ws,
+                                            size_t score_ws_bytes, void* stream) {
+  if (!q_image || !k_image || !masks || !lse || (nt > 0 && !tok) || (!nl && !score_ws))
     return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: D must be 128");
   if (B <= 0 || N <= 0 || nt < 0 || nt > 8 || KN < 1 || KN > 32)
     return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: bad B/N/nt, or KN outside 1..32");
+  if (score_ws) {
+    if (!nn_sorted) return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: score accumulation needs nn_sorted");
+    if (score_mode < 0 || score_mode > SAMBLE_SCORE_SPARSE_ROW_STD)
+      return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: unknown score mode");
+    if (N > 8192)
+      return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: score accumulation needs N <= 8192 (LDS accumulators); "
+                                    "take nl and run samble_sparse_score_map_f32 on it");
+    if (score_ws_bytes < samble_score_ws_bytes(B, N))
+      return fail(SAMBLE_E_WORKSPACE, "samble_attn_stats_nl_tri_f32: score workspace too small");
+  }
   return done(samble_launch_attn_stats_nl_tri(q_image, k_image, B, N, nt, inv_sqrt_d(D), masks, KN, nl, lse, tok,
+                                              score_ws ? nn_sorted : nullptr, score_mode, score_ws, score_ws_bytes,
                                               (hipStream_t)stream),
               "samble_attn_stats_nl_tri_f32");
 }
@@ -597,7 +609,7 @@ SAMBLE_API int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const
 SAMBLE_API int samble_sparse_score_map_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,
                                            int KN, int mode, float* score, float* z, int32_t* indeg_out, void* ws,
                                            size_t ws_bytes, void* stream) {
-  if (!smap || !lse || !nn || !score || !z || !ws)
+  if ((smap && (!lse || !nn)) || !score || !z || !ws)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: null pointer");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: unknown score mode");
@@ -623,7 +635,7 @@ SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, 
                                                      int N, int KN, int mode, int nb, float* score, float* z,
                                                      int32_t* indeg_out, float* quantiles_out, void* ws, size_t ws_bytes,
                                                      void* stream) {
-  if (!smap || !lse || !nn || !score || !z || !ws)
+  if ((smap && (!lse || !nn)) || !score || !z || !ws)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: null pointer");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: unknown score mode");
@@ -634,8 +646,10 @@ SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, 
   if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
     return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_map_quantiles_f32: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int rc = samble_launch_sparse_score_map_acc(smap, ld, lse, nn, B, N, KN, mode, ws, samble_select_chain_workspace_bytes(B, N), s);
-  if (rc) return done(rc, "samble_sparse_score_map_quantiles_f32");
+  if (smap) {  // NULL: samble_attn_stats_nl_tri_f32 accumulated into (and zeroed all of) this workspace already
+    int rc = samble_launch_sparse_score_map_acc(smap, ld, lse, nn, B, N, KN, mode, ws, samble_select_chain_workspace_bytes(B, N), s);
+    if (rc) return done(rc, "samble_sparse_score_map_quantiles_f32");
+  }
   char* w8 = (char*)ws;
   const void* colacc = w8;
   const int* indeg = (const int*)(w8 + (size_t)B * N * 8);

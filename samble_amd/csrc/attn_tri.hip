@@ -298,6 +298,19 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
 // (attn_rows_rc_tri_kernel).  Same products, same order as attn_stats_tri_kernel: the statistics and every
 // extracted logit are bit-identical to that kernel's.
 // ------------------------------------------------------------------------------------------------
+// Score accumulators of the sparse_* modes (score.hip: sparse_score_map_kernel does the same from a logit array):
+// with nn_sorted non-null the flush of a row also forms A_ij = exp(S_ij - lse_i) of its K neighbours and adds it to
+// the fixed-point column sums / in-degrees (order-free integer atomics) and, for the row modes, writes the row
+// statistic -- the separate score pass and the neighbour-logit array are then not needed at all.
+struct NlScoreArgs {
+  const int* nn_sorted;          // (B, N, KN) ascending neighbour indices, or null: no accumulation
+  unsigned long long* colacc;    // (B, N) sums of round(A * 2^44)
+  int* indeg;                    // (B, N)
+  float* rowstat;                // (B, N) or null (column modes)
+  int row_std;                   // row modes: 0 = sum, 1 = unbiased std over the K entries
+};
+constexpr float kNlFix = 17592186044416.f;  // 2^44, as score.hip
+
 constexpr int kNlStride = 33;  // words per query row in LDS (K <= 32; odd: rows on distinct banks)
 constexpr int kStatsNlLds = kStatsDepth * kTriTile + kStatsDepth * 2048 + 256 * kNlStride * 4;
 
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
                                                                    float scale, const unsigned* __restrict__ masks,
                                                                    int KN, float* __restrict__ nl,
                                                                    float* __restrict__ lse, float* __restrict__ tok,
-                                                                   int nt) {
+                                                                   int nt, const NlScoreArgs sc) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int NW = 8, D = kStatsDepth;
   const int tid = threadIdx.x;
@@ -416,10 +429,71 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
   for (; t < n_full; ++t) step(t, std::false_type{});
   for (; t < ntiles; ++t) step(t, std::true_type{});
   const float ltot = l + wave_xor32(l);
-  if (h == 0) lse[(long)b * N + qrow] = m + __logf(ltot);
+  const float my_lse = m + __logf(ltot);
+  if (h == 0) lse[(long)b * N + qrow] = my_lse;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the row was written by this wave's two halves only
-  float* nlout = nl + ((long)b * N + qrow) * KN;
-  for (int k = h; k < KN; k += 2) nlout[k] = nlrow[k];
+  if (nl) {
+    float* nlout = nl + ((long)b * N + qrow) * KN;
+    for (int k = h; k < KN; k += 2) nlout[k] = nlrow[k];
+  }
+  const bool live = chunk * (32 * NW) + wave * 32 + lo < N;  // clamped duplicates of row N-1 must not count twice
+  if (!sc.nn_sorted) return;  // (uniform)
+  // Column sums: scattered device-scope atomics from every lane would each be a memory-side transaction (measured:
+  // +250 us); instead the workgroup's 256 rows x K entries meet in LDS accumulators laid over the tile ring (free
+  // now: N x 12 bytes, N <= 8192), and one coalesced sweep adds the non-empty columns to the cloud's totals.
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the ring's last (unused) DMA pieces have landed
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_c);
+  int* deg = reinterpret_cast<int*>(acc + N);
+  for (int n = tid; n < N; n += 512) {
+    acc[n] = 0ull;
+    deg[n] = 0;
+  }
+  __syncthreads();
+  if (live) {
+    const int* jrow = sc.nn_sorted + ((long)b * N + qrow) * KN;
+    for (int k = h; k < KN; k += 2) {
+      const float a = __expf(nlrow[k] - my_lse);
+      const int j = jrow[k];
+      atomicAdd(&acc[j], (unsigned long long)__float2ll_rn(a * kNlFix));
+      atomicAdd(&deg[j], 1);
+    }
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += 512) {
+    const int cn = deg[n];
+    if (cn) {
+      atomicAdd(&sc.colacc[(long)b * N + n], acc[n]);
+      atomicAdd(&sc.indeg[(long)b * N + n], cn);
+    }
+  }
+  if (live) {
+    if (sc.rowstat && h == 0) {
+      // the K entries in double, summed in the order of sparse_score_map_kernel's 32-lane xor butterfly (entry k on
+      // lane k, zeros past K): same partial sums, bit for bit
+#pragma clang fp contract(off)
+      double x[32], x2[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const double a = k < KN ? (double)__expf(nlrow[k] - my_lse) : 0.0;
+        x[k] = a;
+        x2[k] = a * a;
+      }
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < off; ++c) {
+          x[c] += x[c + off];
+          x2[c] += x2[c + off];
+        }
+      const double tot = x[0], tot2 = x2[0];
+      float v = (float)tot;
+      if (sc.row_std) {
+        const double mean = tot / KN;
+        v = (float)sqrt(fmax((tot2 - KN * mean * mean) / (KN - 1), 0.0));
+      }
+      sc.rowstat[(long)b * N + qrow] = v;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -766,17 +840,30 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
 }
 
 // pass 1 without the map: lse, token logits and the K neighbour logits per row (nl (B, N, KN), ascending-index order)
+// nn_sorted / acc_ws non-null: also accumulate the sparse_* score statistics of `score_mode` (score.hip's modes)
+// into acc_ws = [colacc B*N u64][indeg B*N i32][rowstat B*N f32], after zeroing zero_bytes of it
 extern "C" int samble_launch_attn_stats_nl_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
                                                const unsigned* masks, int KN, float* nl, float* lse, float* tok,
+                                               const int* nn_sorted, int score_mode, void* acc_ws, size_t zero_bytes,
                                                hipStream_t stream) {
   if (KN < 1 || KN > 32) return (int)hipErrorInvalidValue;
   const size_t lds = kStatsNlLds;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_stats_nl_tri_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
+  NlScoreArgs sc{nullptr, nullptr, nullptr, nullptr, 0};
+  if (nn_sorted && acc_ws) {
+    if (score_mode < 0 || score_mode > 4 || (size_t)N * 12 > (size_t)kStatsDepth * kTriTile) return (int)hipErrorInvalidValue;
+    e = hipMemsetAsync(acc_ws, 0, zero_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long* colacc = reinterpret_cast<unsigned long long*>(acc_ws);
+    int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
+    float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
+    sc = NlScoreArgs{nn_sorted, colacc, indeg, score_mode >= 3 ? rowstat : nullptr, score_mode == 4};
+  }
   Timed timed(kT_attn_stats, stream);
   hipLaunchKernelGGL(attn_stats_nl_tri_kernel, dim3((N + 255) / 256, B), dim3(512), lds, stream, (const char*)qimg,
-                     (const char*)kimg, N, N + nt, scale, masks, KN, nl, lse, tok, nt);
+                     (const char*)kimg, N, N + nt, scale, masks, KN, nl, lse, tok, nt, sc);
   return (int)hipGetLastError();
 }
 

@@ -306,17 +306,20 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
   unsigned long long* colacc = reinterpret_cast<unsigned long long*>(ws);
   int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
   float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
-  if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)N * 12;
-  auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;  // ld == 0: compact logits
-  if (lds > 64 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
+  hipError_t e = hipSuccess;
   Timed timed(kT_sparse_score, stream);
-  hipLaunchKernelGGL(kern, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN, colacc, indeg,
-                     mode >= kRowSum ? rowstat : nullptr, mode);
+  if (smap) {  // null: the accumulators were filled by attn_stats_nl_tri (attn_tri.hip)
+    e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t lds = (size_t)N * 12;
+    auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;  // ld == 0: compact logits
+    if (lds > 64 * 1024) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((N + 63) / 64, B), dim3(256), lds, stream, smap, ld, lse, nn, N, KN, colacc, indeg,
+                       mode >= kRowSum ? rowstat : nullptr, mode);
+  }
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
   if (indeg_out) {
     e = hipMemcpyAsync(indeg_out, indeg, (size_t)B * N * sizeof(int), hipMemcpyDeviceToDevice, stream);

@@ -98,18 +98,25 @@ class _SamplerCore(torch.autograd.Function):
                 need_bwd = ctx.needs_input_grad[0]
                 imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
                 nn_sorted, masks = ops.stage_nn_prepare(nn_idx)
-                nl, lse, tok = ops.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, mod.K, D)
+                chain = ops.chain_supported(B, N, nb)
+                # the pass also accumulates the score statistics of the K neighbour entries of every row
+                fused = N <= 8192   # LDS accumulators of the pass; longer clouds take the neighbour-logit array
+                nl, lse, tok, sws = ops.stage_attn_stats_nl(
+                    imgs[0], imgs[1], masks, B, N, nt, mod.K, D, want_nl=not fused,
+                    score=(nn_sorted, mod.idx_mode, nb if chain else None) if fused else None)
                 del masks
-                if ops.chain_supported(B, N, nb):
+                if chain:
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
-                                                                            mod.dynamic_boundaries_enable, compact=True)
+                                                                            mod.dynamic_boundaries_enable,
+                                                                            compact=not fused, ws=sws)
                     if quant is not None:
                         quant = ops.world_average(quant)
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
                                                                    mod.relu_mean_order == "relu_mean", mod.M, cws)
                 else:
-                    score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=True)
+                    score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=not fused,
+                                                                 ws=sws)
                 map_free = True
             elif TWO_PASS or mod.asm == "l2":
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it

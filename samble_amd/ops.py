@@ -483,18 +483,32 @@ def stage_nn_prepare(nn_idx: torch.Tensor):
     return nn_sorted, masks
 
 
-def stage_attn_stats_nl(q_image, k_image, masks, B: int, n_points: int, n_tokens: int, n_neighbors: int, D: int = 128):
+def stage_attn_stats_nl(q_image, k_image, masks, B: int, n_points: int, n_tokens: int, n_neighbors: int, D: int = 128,
+                        want_nl: bool = True, score=None):
     """Pass 1 without the logit map (MATRIX_MODE "tri", asm "dot"): -> neighbour logits (B,N,K) in the order of
-    stage_nn_prepare's sorted lists, lse (B,N), token logits (B,N,nt)."""
+    stage_nn_prepare's sorted lists (None unless want_nl), lse (B,N), token logits (B,N,nt).
+    score = (nn_sorted, idx_mode, num_bins or None): the pass also accumulates the sparse_* score statistics into a
+    fresh workspace (returned as 4th value; hand it to stage_sparse_score_map / stage_score_quantiles with
+    smap=None): no separate score pass, no neighbour-logit array."""
     _need_gpu(q_image, k_image, masks)
     dev = q_image.device
     with torch.cuda.device(dev):
-        nl = torch.empty((B, n_points, n_neighbors), dtype=torch.float32, device=dev)
+        nl = torch.empty((B, n_points, n_neighbors), dtype=torch.float32, device=dev) if want_nl else None
         lse = torch.empty((B, n_points), dtype=torch.float32, device=dev)
         tok = torch.empty((B, n_points, max(n_tokens, 1)), dtype=torch.float32, device=dev)
+        nn_sorted, mode, ws, nbytes = None, 0, None, 0
+        if score is not None:
+            nn_sorted, idx_mode, num_bins = score
+            if idx_mode not in SCORE_MODES:
+                raise ValueError("Please check the setting of idx mode!")
+            mode = SCORE_MODES[idx_mode]
+            nbytes = _lib.query("samble_select_chain_workspace_bytes", B, n_points) if num_bins else \
+                _lib.query("samble_score_workspace_bytes", B, n_points)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call("samble_attn_stats_nl_tri_f32", q_image.data_ptr(), k_image.data_ptr(), B, n_points, n_tokens, D,
-                  masks.data_ptr(), n_neighbors, nl.data_ptr(), lse.data_ptr(), tok.data_ptr(), _stream())
-    return nl, lse, tok[:, :, :n_tokens]
+                  masks.data_ptr(), n_neighbors, _p(nl), lse.data_ptr(), tok.data_ptr(), _p(nn_sorted), mode, _p(ws),
+                  nbytes, _stream())
+    return nl, lse, tok[:, :, :n_tokens], ws
 
 
 def stage_attn_rows_recompute(q_image, k_image, v_image, lse, idx, n_points: int, n_tokens: int, want_pmap: bool,
@@ -514,25 +528,33 @@ def stage_attn_rows_recompute(q_image, k_image, v_image, lse, idx, n_points: int
     return out, pmap
 
 
-def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str, compact: bool = False):
+def stage_sparse_score_map(smap, lse, nn_idx, idx_mode: str, compact: bool = False, ws=None):
     """stage_sparse_score with A_ij read from the logit map instead of recomputed.
-    compact: `smap` is the (B,N,K) neighbour-logit array of stage_attn_stats_nl and nn_idx the sorted lists."""
+    compact: `smap` is the (B,N,K) neighbour-logit array of stage_attn_stats_nl and nn_idx the sorted lists.
+    smap None: the statistics were accumulated into `ws` by stage_attn_stats_nl(score=...) already."""
     if idx_mode not in SCORE_MODES:
         raise ValueError("Please check the setting of idx mode!")
-    _need_gpu(smap, lse, nn_idx)
-    B, N, ld = smap.shape
-    if compact:
-        assert smap.shape == nn_idx.shape
-        ld = 0
-    with torch.cuda.device(smap.device):
-        score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
+    _need_gpu(lse, nn_idx)
+    B, N = lse.shape
+    ld = 0
+    if smap is not None:
+        _need_gpu(smap)
+        ld = smap.shape[2]
+        if compact:
+            assert smap.shape == nn_idx.shape
+            ld = 0
+    elif ws is None:
+        raise ValueError("smap=None needs the workspace stage_attn_stats_nl filled")
+    with torch.cuda.device(lse.device):
+        score = torch.empty((B, N), dtype=torch.float32, device=lse.device)
         z = torch.empty_like(score)
-        indeg = torch.empty((B, N), dtype=torch.int32, device=smap.device)
+        indeg = torch.empty((B, N), dtype=torch.int32, device=lse.device)
         nbytes = _lib.query("samble_score_workspace_bytes", B, N)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=smap.device)
-        _lib.call("samble_sparse_score_map_f32", smap.data_ptr(), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
+        if smap is not None:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=lse.device)
+        _lib.call("samble_sparse_score_map_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
                   nn_idx.shape[2], SCORE_MODES[idx_mode], score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
-                  ws.data_ptr(), nbytes, _stream())
+                  ws.data_ptr(), ws.numel(), _stream())
     return score, z, indeg
 
 
@@ -542,27 +564,37 @@ def chain_supported(B: int, N: int, num_bins: int) -> bool:
     return bool(_lib.query("samble_select_chain_supported", B, N, num_bins))
 
 
-def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, compact: bool = False):
-    """stage_sparse_score_map + stage_batch_quantiles in two launches (compact: as in stage_sparse_score_map).
+def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, compact: bool = False,
+                          ws=None):
+    """stage_sparse_score_map + stage_batch_quantiles in two launches (compact / smap None + ws: as in
+    stage_sparse_score_map; then it is ONE launch).
     -> score (B,N), z (B,N), in-degree (B,N) int32, quantiles (nb-1,) or None, chain workspace (hand it to
     stage_bin_plan)."""
     if idx_mode not in SCORE_MODES:
         raise ValueError("Please check the setting of idx mode!")
-    _need_gpu(smap, lse, nn_idx)
-    B, N, ld = smap.shape
-    if compact:
-        assert smap.shape == nn_idx.shape
-        ld = 0
-    with torch.cuda.device(smap.device):
-        score = torch.empty((B, N), dtype=torch.float32, device=smap.device)
+    _need_gpu(lse, nn_idx)
+    B, N = lse.shape
+    ld = 0
+    if smap is not None:
+        _need_gpu(smap)
+        ld = smap.shape[2]
+        if compact:
+            assert smap.shape == nn_idx.shape
+            ld = 0
+    elif ws is None:
+        raise ValueError("smap=None needs the workspace stage_attn_stats_nl filled")
+    with torch.cuda.device(lse.device):
+        score = torch.empty((B, N), dtype=torch.float32, device=lse.device)
         z = torch.empty_like(score)
-        indeg = torch.empty((B, N), dtype=torch.int32, device=smap.device)
-        quant = torch.empty((num_bins - 1,), dtype=torch.float32, device=smap.device) if want_quantiles else None
+        indeg = torch.empty((B, N), dtype=torch.int32, device=lse.device)
+        quant = torch.empty((num_bins - 1,), dtype=torch.float32, device=lse.device) if want_quantiles else None
         nbytes = _lib.query("samble_select_chain_workspace_bytes", B, N)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=smap.device)
-        _lib.call("samble_sparse_score_map_quantiles_f32", smap.data_ptr(), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
+        if smap is not None:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=lse.device)
+        assert ws.numel() >= nbytes
+        _lib.call("samble_sparse_score_map_quantiles_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
                   nn_idx.shape[2], SCORE_MODES[idx_mode], num_bins, score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
-                  _p(quant), ws.data_ptr(), nbytes, _stream())
+                  _p(quant), ws.data_ptr(), ws.numel(), _stream())
     return score, z, indeg, quant, ws
 
 

@@ -818,14 +818,27 @@ def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
         bits.scatter_(2, nn.long(), True)
         words = (bits.view(B, N, -1, 32).long() << torch.arange(32, device=DEV)).sum(-1)   # (B, N, T) as uint32 values
         assert torch.equal(masks.long() & 0xFFFFFFFF, words.permute(0, 2, 1))
-        nl, lse2, tok2 = o_.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, K)
+        nl, lse2, tok2, _ = o_.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, K)
         assert torch.equal(lse2, lse) and torch.equal(tok2, tok)
         assert torch.equal(nl, torch.gather(smap, 2, nn_sorted.long()))
         for mode in ("sparse_col_sum", "sparse_col_avg", "sparse_col_sqr", "sparse_row_sum", "sparse_row_std"):
             a = o_.stage_sparse_score_map(smap, lse, nn, mode)
             b2 = o_.stage_sparse_score_map(nl, lse, nn_sorted, mode, compact=True)
-            for x1, x2, what in zip(a, b2, ("score", "z", "indeg")):
+            # ... and with the statistics accumulated by the pass itself (no logit array at all)
+            none, lse3, tok3, sws = o_.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, K, want_nl=False,
+                                                           score=(nn_sorted, mode, None))
+            assert none is None and torch.equal(lse3, lse) and torch.equal(tok3, tok)
+            c3 = o_.stage_sparse_score_map(None, lse, nn_sorted, mode, ws=sws)
+            for x1, x2, x3, what in zip(a, b2, c3, ("score", "z", "indeg")):
                 assert torch.equal(x1, x2), (mode, what)
+                assert torch.equal(x1, x3), (mode, what, "fused")
+        if o_.chain_supported(B, N, 6):
+            ref = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", 6, True)
+            _, _, _, sws = o_.stage_attn_stats_nl(imgs[0], imgs[1], masks, B, N, nt, K, want_nl=False,
+                                                  score=(nn_sorted, "sparse_col_sqr", 6))
+            got = o_.stage_score_quantiles(None, lse, nn_sorted, "sparse_col_sqr", 6, True, ws=sws)
+            for x1, x2, what in zip(ref[:4], got[:4], ("score", "z", "indeg", "quantiles")):
+                assert torch.equal(x1, x2), ("chain", what)
         x_ds = o_.stage_attn_rows(smap, lse, vd, idx, N, nt, v_image=imgs[2])
         x_ds2, pmap = o_.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, True)
         x_ds3, none = o_.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, False)
