@@ -23,6 +23,161 @@ namespace samble {
 // ------------------------------------------------------------------------------------------------
 // prep: one workgroup = 32 sampled rows of one cloud
 // ------------------------------------------------------------------------------------------------
+// The same preparation for the split-bf16 backward (one workgroup = one tile of 32 sampled rows), laid out so that
+// nothing waits on a chain of dependent gathers or on cross-lane reductions: the dO^T and Q^T tiles sit in LDS
+// ([channel][row], 33-float rows), all 32 row gathers are in flight together, the (row, token) logits are one
+// thread each (32 x 8 = the workgroup), and every token-gradient partial is owned by one thread (fixed order).
+// Outputs as bwd_prep_kernel with dO_rm / dO_tr / Q_tr given: lse_s, delta, tok_part, (L2) cs_part, the images.
+template <bool L2>
+__global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
+                                                           const float* __restrict__ K, long k_bs, long k_rs,
+                                                           const float* __restrict__ V, long v_bs, long v_rs,
+                                                           const float* __restrict__ Oc, const float* __restrict__ lse,
+                                                           const long long* __restrict__ idx,
+                                                           const float* __restrict__ g, int N, int nt, int M,
+                                                           float scale, float* __restrict__ lse_s,
+                                                           float* __restrict__ delta, float* __restrict__ tok_part,
+                                                           float* __restrict__ cs_part, char* __restrict__ dO_rm,
+                                                           char* __restrict__ dO_tr, char* __restrict__ Q_tr) {
+  __shared__ float gt[128 * 33];  // dO^T tile
+  __shared__ float qt[128 * 33];  // Q^T tile of the gathered rows
+  __shared__ __attribute__((aligned(16))) float kts[8][128], vts[8][128];
+  __shared__ float dred[8][32];
+  __shared__ float ps[32][9], dss[32][9];  // P and dS of (row, token)
+  __shared__ float lrow_s[32], delta_s[32];
+  __shared__ long long rows[32];
+  const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
+  const float* gb = g + (long)b * 128 * M;
+  const float* ob = Oc + (long)b * 128 * M;
+  if (tid < 32) rows[tid] = idx[(long)b * M + min(m0 + tid, M - 1)];
+  for (int e = tid; e < 8 * 128; e += 256) {
+    const int t = e >> 7, c = e & 127;
+    kts[t][c] = t < nt ? K[(long)b * k_bs + (long)(N + t) * k_rs + c] : 0.f;
+    vts[t][c] = t < nt ? V[(long)b * v_bs + (long)(N + t) * v_rs + c] : 0.f;
+  }
+  // dO tile and delta = sum_c dO O: each thread 16 channels of one row, the 8 channel groups in a fixed order below
+  float dpart = 0.f;
+  {
+    const int mm = tid & 31;
+    const bool ok = m0 + mm < M;
+    float gv[16], ov[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = (tid >> 5) + 8 * i;
+      gv[i] = ok ? gb[(long)d * M + m0 + mm] : 0.f;
+      ov[i] = ok ? ob[(long)d * M + m0 + mm] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      gt[((tid >> 5) + 8 * i) * 33 + mm] = gv[i];
+      dpart = fmaf(gv[i], ov[i], dpart);
+    }
+  }
+  dred[tid >> 5][tid & 31] = dpart;
+  __syncthreads();
+  {  // the 32 row gathers: every half-wave has its 4 rows in flight at once
+    const int sub = tid >> 5, l32 = tid & 31;
+    f32x4 qv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = sub + 8 * u;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      qv[u] = (m0 + rr < M) ? *reinterpret_cast<const f32x4*>(Q + (long)b * q_bs + rows[rr] * q_rs + 4 * l32) : z4;
+    }
+    float lr = 0.f;
+    if (tid < 32) lr = lse[(long)b * N + rows[tid]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = sub + 8 * u;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) qt[(4 * l32 + c) * 33 + rr] = qv[u][c];
+    }
+    if (tid < 32) {
+      float part = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) part += dred[w8][tid];
+      lrow_s[tid] = lr;
+      delta_s[tid] = part;
+      if (m0 + tid < M) {
+        delta[(long)b * M + m0 + tid] = part;
+        lse_s[(long)b * M + m0 + tid] = lr;
+      }
+    }
+  }
+  __syncthreads();
+  const int ntiles_m = gridDim.x;
+  {  // operand images of the tile (layouts: tri_dev.h); rows past M-1 are zeros in both tiles
+    char* irm = dO_rm + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    char* itr = dO_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    char* qtr = Q_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      {
+        const int r = e & 31, gq = e >> 5;
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = gt[(8 * gq + i) * 33 + r];
+        const Tri t3 = tri_split8(x);
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 2)) = t3.l;
+      }
+      const int d = e & 127, cg = e >> 7;
+      float x[8], y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int o = d * 33 + 16 * (cg >> 1) + 8 * (i >> 2) + 4 * (cg & 1) + (i & 3);
+        x[i] = gt[o];
+        y[i] = qt[o];
+      }
+      const Tri t3 = tri_split8(x), u3 = tri_split8(y);
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = t3.h;
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = t3.m;
+      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 2)) = t3.l;
+      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = u3.h;
+      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = u3.m;
+      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 2)) = u3.l;
+    }
+  }
+  if (nt <= 0) return;  // (uniform)
+  {  // token logits: thread = (row r, token t)
+    const int r = tid & 31, t = tid >> 5;
+    float st = 0.f, dpt = 0.f, qq = 0.f, kk = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < 128; ++c) {
+      const float qc = qt[c * 33 + r], kc = kts[t][c];
+      st = fmaf(qc, kc, st);
+      dpt = fmaf(gt[c * 33 + r], vts[t][c], dpt);
+      if (L2) {
+        qq = fmaf(qc, qc, qq);
+        kk = fmaf(kc, kc, kk);
+      }
+    }
+    if (L2) st = 2.f * st - qq - kk;  // -|q - k_tok|^2
+    const bool ok = t < nt && m0 + r < M;
+    const float p = ok ? __expf(st * scale - lrow_s[r]) : 0.f;
+    ps[r][t] = p;
+    dss[r][t] = p * (dpt - delta_s[r]) * scale;
+  }
+  __syncthreads();
+  float* outp = tok_part + ((long)b * gridDim.x + blockIdx.x) * 2 * 8 * 128;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // [dK | dV][token][channel]: dK_t += dS_rt q_r, dV_t += P_rt dO_r, rows ascending
+    const int e = tid + 256 * i;
+    const int t = (e >> 7) & 7, c = e & 127;
+    const float* w = (e >> 10) ? &ps[0][t] : &dss[0][t];
+    const float* x = (e >> 10) ? &gt[c * 33] : &qt[c * 33];
+    float a = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) a = fmaf(w[9 * r], x[r], a);
+    outp[e] = a;
+  }
+  if (L2 && tid < 8) {  // column sums of dS over this workgroup's rows, per token
+    float a = 0.f;
+    for (int r = 0; r < 32; ++r) a += dss[r][tid];
+    cs_part[((long)b * gridDim.x + blockIdx.x) * 8 + tid] = a;
+  }
+}
+
 template <bool L2>  // L2: token logits are -|q-k|^2 and the dS column sums of the token keys are produced
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                        const float* __restrict__ K, long k_bs, long k_rs,
@@ -670,7 +825,12 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   char* dO_rm = tri ? (char*)img_ws : nullptr;
   char* dO_tr = tri ? dO_rm + img : nullptr;
   char* Q_tr = tri ? dO_tr + img : nullptr;
-  {
+  if (tri && Oc) {
+    Timed timed(kT_bwd_prep, stream);
+    hipLaunchKernelGGL(l2 ? bwd_prep_tri_kernel<true> : bwd_prep_tri_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q,
+                       q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, Oc, lse, idx, g, N, nt, M, scale, lse_s, delta, tok_part,
+                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr);
+  } else {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
                      O, Oc, lse, idx, g, N, nt, M, scale, Qs, dOb, lse_s, delta, tok_part, fused ? slab : nullptr,
