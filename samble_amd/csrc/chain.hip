@@ -24,6 +24,13 @@
 
 namespace samble {
 
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch): s_memtime marks of workgroup 0, read back by the harness
+__device__ unsigned long long g_chain_stamps[64];
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 constexpr float kUnfixC = 1.f / 17592186044416.f;  // 2^-44: the fixed-point scale of the score accumulators (score.hip)
 enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };
 
@@ -62,13 +69,14 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
                                                                float* __restrict__ quant_out) {
   extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
   __shared__ double red[256];
-  __shared__ unsigned int scanbuf[16 * kMaxBins];
+  __shared__ unsigned int scanbuf[2 * 16 * kMaxBins];
   __shared__ unsigned int prefix[kMaxBins];
   __shared__ unsigned int rem[kMaxBins];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int B = gridDim.x;
   const long n_all = (long)B * N;
   const int nq = nb - 1;
+  STAMP(0);
 
   // ---- score + z of this cloud: the arithmetic and summation order of finalize_score_kernel (score.hip): the
   // first 256 threads own points n = tid, tid + 256, ... for the two double-precision reductions
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
     if (indeg_out) indeg_out[(long)b * N + n] = indeg[(long)b * N + n];
   }
   __syncthreads();
+  STAMP(1);
   double part = 0.0;
   if (tid < 256)
     for (int n = tid; n < N; n += 256) part += (double)sbuf[n];
@@ -127,6 +136,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
     }
   }
   __syncthreads();  // sbuf is free
+  STAMP(2);
   if (quant_out == nullptr) return;  // static boundaries: no quantiles wanted (uniform over the grid)
 
   // ---- batch quantiles: three levels of digits (11 / 11 / 10 bits), all nb-1 ranks at once
@@ -136,6 +146,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
     const int bits = (level == 2) ? 10 : 11, nbin = 1 << bits;
     const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
     const int nh = (level == 0) ? 1 : nq;
+    STAMP(3 + 5 * level);
     for (int e = tid; e < nh * nbin; e += 1024) qsm[e] = 0u;
     unsigned int want[kMaxBins];
 #pragma unroll
@@ -155,13 +166,19 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
       }
     }
     __syncthreads();
+    STAMP(4 + 5 * level);
     unsigned int* gh = cws + (level == 0 ? kQH0 : level == 1 ? kQH1 : kQH2);
     for (int e = tid; e < nh * nbin; e += 1024) {
       const unsigned int c = qsm[e];
       if (c) atomicAdd(&gh[(level == 2) ? (e / nbin) * 1024 + (e % nbin) : (level == 1) ? (e / nbin) * 2048 + (e % nbin) : e], c);
     }
+    STAMP(5 + 5 * level);
     grid_barrier<false>(bar, (unsigned int)B * (level + 1));  // the histograms were combined by atomics
-    qsel_resolve(level, cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
+    STAMP(6 + 5 * level);
+    if (level == 0) qsel_resolve<0>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
+    else if (level == 1) qsel_resolve<1>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
+    else qsel_resolve<2>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
+    STAMP(7 + 5 * level);
   }
   if (b == 0 && tid < nq) quant_out[tid] = from_ordered_bits(prefix[tid]);
 }
@@ -178,6 +195,7 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
   __shared__ int rcnt[kMaxBins][16];
   __shared__ float up_s[kMaxBins], lo_s[kMaxBins];
   const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
+  STAMP(20);
   // ---- boundary state (blend_boundaries_kernel's arithmetic: two fp32 products, then the sum; no FMA in this file)
   if (tid < nb) {
     float u = upper[tid], l = lower[tid];
@@ -201,17 +219,22 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
     lo_s[tid] = l;
   }
   __syncthreads();
+  STAMP(21);
   bin_assign_body(b, z, tok, nt, up_s, lo_s, N, nb, relu_first, member, cap, w_pre, w, rsum, rcnt);
+  STAMP(22);
   // every workgroup has read the old state and published its cloud's (w, cap): now the state may be overwritten
   // and the whole batch's counts allocated
   grid_barrier<true>(cws + kChainBar + 1, (unsigned int)B);
+  STAMP(23);
   if (b == 0 && quant && tid < nb) {
     upper[tid] = up_s[tid];
     lower[tid] = lo_s[tid];
   }
   __shared__ int counts_s[1024 * kMaxBins / 8];  // B x nb <= 1024 ints (B <= 128 at nb = 8)
-  alloc_counts_body(w, cap, B, nb, M, counts_s);
+  if (B <= 64) alloc_counts_wave(w, cap, B, nb, M, counts_s);  // one wave, lane = cloud, no barriers
+  else alloc_counts_lanes(w, cap, B, nb, M, counts_s);          // B <= 128: eight lanes per cloud
   __syncthreads();
+  STAMP(24);
   if (tid < nb) counts[b * nb + tid] = counts_s[b * nb + tid];
 }
 
@@ -229,6 +252,12 @@ static int resident_workgroups(int* out) {
   *out = cus;  // one 1024-thread workgroup per CU
   return 0;
 }
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_chain_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 extern "C" size_t samble_chain_ws_bytes(void) { return (size_t)kChainWords * sizeof(unsigned int); }
 

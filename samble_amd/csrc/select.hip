@@ -154,13 +154,13 @@ template <int LEVEL>
 __global__ __launch_bounds__(1024) void qsel_kernel(const float* __restrict__ z, long n, int nb,
                                                     unsigned int* __restrict__ ws, float* __restrict__ out) {
   extern __shared__ unsigned int qsm[];  // LDS histogram of this level
-  __shared__ unsigned int scanbuf[16 * kMaxBins];
+  __shared__ unsigned int scanbuf[2 * 16 * kMaxBins];
   __shared__ unsigned int prefix[kMaxBins];
   __shared__ unsigned int rem[kMaxBins];
   const int tid = threadIdx.x;
   const int nq = nb - 1;
   if (LEVEL > 0) {
-    qsel_resolve(LEVEL - 1, ws, nq, n, nb, prefix, rem, scanbuf);
+    qsel_resolve<LEVEL - 1>(ws, nq, n, nb, prefix, rem, scanbuf);
     if (blockIdx.x == 0 && tid < kMaxBins) {  // identical in every workgroup; one publishes
       ws[kQState + 16 * (LEVEL - 1) + tid] = prefix[tid];
       ws[kQState + 16 * (LEVEL - 1) + 8 + tid] = rem[tid];
@@ -259,6 +259,12 @@ __global__ __launch_bounds__(1024) void alloc_counts_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // per-(cloud, bin) selection
 // ------------------------------------------------------------------------------------------------
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch)
+__device__ unsigned long long g_select_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_select_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 enum SampleMode { kTopk = 0, kUniform = 1, kRandom = 2, kTopRaw = 3, kBottomRaw = 4 };
 enum TempMode { kTempFixed = 0, kTempCount = 1 };  // count: inv_T = members / temp_div
 
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
   const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const unsigned int bit = 1u << t;
   const unsigned char* mb = member + (long)b * N;
+  STAMP(0);
 
   // Boltzmann normaliser: sum over members of exp(tanh(z) * inv_T), fixed-order double tree
   float inv_t = temp;
@@ -308,33 +315,69 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
     }
   }
   const float* nz = noise ? noise + ((long)b * nb + t) * N : nullptr;
-  for (int n = tid; n < NP; n += 1024) {
-    // non-members sort behind every member, in index order: if a count ever exceeds its bin's population (a
-    // degenerate cloud: NaN scores leave every bin empty and bin 0 is handed all M picks) the surplus slots
-    // receive valid, distinct point indices, as the reference's sort of the masked zeros does (utils/ops.py:486-503)
-    unsigned long long c = (n < N) ? (0xFFFFFFFF00000000ull | (unsigned int)n) : ~0ull;
-    if (n < N && (mb[n] & bit)) {
-      float key;
-      if (mode == kTopRaw) {
-        key = score[(long)b * N + n];  // plain topk(M) of the score (DownSampleGlobal)
-      } else if (mode == kBottomRaw) {
-        key = -score[(long)b * N + n];  // topk(.., largest=False)
-      } else if (mode == kTopk) {
-        key = score[(long)b * N + n] + 1e-8f;
-      } else if (mode == kUniform) {
-        key = 1.f / nz[n];
-      } else {
-        float p = expf(tanhf(z[(long)b * N + n]) * inv_t) / psum;
-        if (p != p) p = 1e-8f;
-        key = p / nz[n];
-      }
-      c = ((unsigned long long)(~ordered_bits(key)) << 32) | (unsigned int)n;
+  STAMP(1);
+  int off = 0;
+  for (int u = 0; u < t; ++u) off += counts[b * nb + u];
+  const int kt = counts[b * nb + t];
+  // composite of a member: (descending key, index) -- unique, so ranks are a permutation
+  auto composite = [&](int n) {
+    float key;
+    if (mode == kTopRaw) {
+      key = score[(long)b * N + n];  // plain topk(M) of the score (DownSampleGlobal)
+    } else if (mode == kBottomRaw) {
+      key = -score[(long)b * N + n];  // topk(.., largest=False)
+    } else if (mode == kTopk) {
+      key = score[(long)b * N + n] + 1e-8f;
+    } else if (mode == kUniform) {
+      key = 1.f / nz[n];
+    } else {
+      float p = expf(tanhf(z[(long)b * N + n]) * inv_t) / psum;
+      if (p != p) p = 1e-8f;
+      key = p / nz[n];
     }
+    return ((unsigned long long)(~ordered_bits(key)) << 32) | (unsigned int)n;
+  };
+  // ---- the usual case: the bin holds at least its count.  The members are compacted into LDS (any order) and
+  // every member finds its rank by counting the smaller composites (all lanes read the same words: LDS broadcast,
+  // no barrier inside): m^2 / 1024 steps per thread, m ~ N / nb -- against 66 barrier-separated passes of a bitonic
+  // network over all N points.
+  __shared__ int n_members;
+  if (tid == 0) n_members = 0;
+  __syncthreads();
+  for (int n = tid; n < N; n += 1024) {
+    if (mb[n] & bit) comp[atomicAdd(&n_members, 1)] = composite(n);
+  }
+  __syncthreads();
+  const int m = n_members;
+  if (kt <= m) {
+    if (tid == 0) comp[m] = ~0ull;  // pad to an even count (m < NP, or m == NP == N even)
+    __syncthreads();
+    STAMP(2);
+    const int m2 = (m + 1) & ~1;
+    for (int i = tid; i < m; i += 1024) {
+      const unsigned long long ci = comp[i];
+      int rank = 0;
+      for (int j = 0; j < m2; j += 2) {
+        const ulonglong2 c2 = *reinterpret_cast<const ulonglong2*>(&comp[j]);
+        rank += (c2.x < ci) ? 1 : 0;
+        rank += (c2.y < ci) ? 1 : 0;
+      }
+      if (rank < kt && off + rank < M) idx_out[(long)b * M + off + rank] = (long long)(ci & 0xFFFFFFFFull);
+    }
+    STAMP(3);
+    return;
+  }
+  // ---- degenerate cloud (NaN scores leave every bin empty and bin 0 is handed all M picks): non-members sort behind
+  // every member, in index order, so that the surplus slots receive valid, distinct point indices, as the
+  // reference's sort of the masked zeros does (utils/ops.py:486-503)
+  __syncthreads();
+  for (int n = tid; n < NP; n += 1024) {
+    unsigned long long c = (n < N) ? (0xFFFFFFFF00000000ull | (unsigned int)n) : ~0ull;
+    if (n < N && (mb[n] & bit)) c = composite(n);
     comp[n] = c;
   }
   __syncthreads();
-  // bitonic sort ascending
-  for (int k = 2; k <= NP; k <<= 1) {
+  for (int k = 2; k <= NP; k <<= 1) {  // bitonic sort ascending
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int e = tid; e < NP; e += 1024) {
         const int partner = e ^ j;
@@ -350,9 +393,6 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
       __syncthreads();
     }
   }
-  int off = 0;
-  for (int u = 0; u < t; ++u) off += counts[b * nb + u];
-  const int kt = counts[b * nb + t];
   for (int s = tid; s < kt; s += 1024) {
     if (off + s < M) idx_out[(long)b * M + off + s] = (long long)(comp[s] & 0xFFFFFFFFull);
   }
@@ -545,6 +585,12 @@ extern "C" int samble_launch_blend_boundaries(const float* quant, float* upper, 
   return (int)hipGetLastError();
 }
 
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_select_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_select_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
+
 extern "C" int samble_launch_bin_assign(const float* z, const float* tok, int nt, const float* upper,
                                         const float* lower, int B, int N, int nb, int relu_first,
                                         unsigned char* member, int* cap, float* w_pre, float* w, hipStream_t s) {
@@ -570,7 +616,7 @@ extern "C" int samble_launch_bin_select(const float* score, const float* z, cons
   if ((mode == kUniform || mode == kRandom) && noise == nullptr) return -22;
   int NP = 1;
   while (NP < N) NP <<= 1;
-  const size_t lds = (size_t)NP * 8;
+  const size_t lds = (size_t)(NP + 2) * 8;  // + the pad word of the rank-by-counting path
   if (lds > 144 * 1024) return -27;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bin_select_kernel),

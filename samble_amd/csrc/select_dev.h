@@ -38,9 +38,9 @@ constexpr int kQH0 = 0, kQH1 = 2048, kQH2 = 2048 + 7 * 2048, kQState = kQH2 + 7 
 // resolve the ranks of level `level` (0,1,2) from its global histogram; all 1024 threads; result in prefix/rem (LDS)
 // keep_state: prefix / rem of the previous level are already in LDS (the fused chain resolves every level in the
 // same workgroup); otherwise they are read from the state block 0 of the previous sweep published in ws.
-__device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, long n, int nb,
-                                    unsigned int* prefix, unsigned int* rem, unsigned int* scanbuf,
-                                    bool keep_state = false) {
+template <int level>
+__device__ inline void qsel_resolve(const unsigned int* ws, int nq, long n, int nb, unsigned int* prefix,
+                                    unsigned int* rem, unsigned int* scanbuf, bool keep_state = false) {
   const int tid = threadIdx.x;
   if (keep_state && level > 0) {
   } else if (level == 0) {
@@ -54,19 +54,20 @@ __device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, l
     rem[tid] = ws[kQState + 16 * (level - 1) + 8 + tid];
   }
   __syncthreads();
-  const int bits = (level == 2) ? 10 : 11, nbin = 1 << bits, per = nbin >> 10;
-  const int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
+  constexpr int bits = (level == 2) ? 10 : 11, nbin = 1 << bits, per = nbin >> 10;
+  constexpr int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
   unsigned int rr[kMaxBins];
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) rr[t] = rem[t];
   // all nq ranks resolved by ONE scan round (two barriers): every thread carries the nq per-rank partial counts
-  // side by side (level 0 has one histogram for all ranks).  scanbuf: 16 x kMaxBins words.
+  // side by side (level 0 has one histogram for all ranks).  scanbuf: 2 x 16 x kMaxBins words.
   unsigned int loc[kMaxBins][2], ts[kMaxBins], incl[kMaxBins];
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) {
     loc[t][0] = loc[t][1] = ts[t] = 0u;
     if (t < nq && (level > 0 || t == 0)) {
       const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
+#pragma unroll
       for (int u = 0; u < per; ++u) {
         loc[t][u] = h[per * tid + u];
         ts[t] += loc[t][u];
@@ -100,13 +101,22 @@ __device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, l
       for (int t = 0; t < kMaxBins; ++t) scanbuf[wv * kMaxBins + t] = incl[t];
     }
     __syncthreads();
+    // exclusive scan of the 16 wave totals of every rank: thread (t, w) = tid 16 t + w, 16-lane shuffle scan
+    if (tid < 16 * kMaxBins) {
+      const int w = tid & 15, t = tid >> 4;
+      const unsigned int mine = scanbuf[w * kMaxBins + t];
+      unsigned int acc = mine;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const unsigned int up = __shfl_up(acc, o, 64);
+        if (w >= o) acc += up;
+      }
+      scanbuf[16 * kMaxBins + w * kMaxBins + t] = acc - mine;
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < kMaxBins; ++t) {
-      if (t < nq && (level > 0 || t == 0)) {
-        unsigned int base = 0u;
-        for (int w2 = 0; w2 < wv; ++w2) base += scanbuf[w2 * kMaxBins + t];
-        incl[t] += base;
-      }
+      if (t < nq && (level > 0 || t == 0)) incl[t] += scanbuf[16 * kMaxBins + wv * kMaxBins + t];
     }
     if (level == 0) {
 #pragma unroll
@@ -117,6 +127,7 @@ __device__ inline void qsel_resolve(int level, const unsigned int* ws, int nq, l
   for (int t = 0; t < kMaxBins; ++t) {
     if (t >= nq) continue;
     unsigned int c = incl[t] - ts[t];
+#pragma unroll
     for (int u = 0; u < per; ++u) {
       if (c <= rr[t] && rr[t] < c + loc[t][u]) {  // exactly one (thread, u) matches
         prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
@@ -253,6 +264,103 @@ __device__ inline void alloc_counts_body(const float* w, const int* cap, int B, 
     }
   }
   for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
+}
+
+// The same allocation with EIGHT lanes per cloud (lane = 8 b + t owns bin t; B <= blockDim.x / 8): the serial
+// version is one long dependent chain per cloud (six IEEE divisions per round on one wave); here a round is one
+// division per lane and two 8-lane gathers.  Every sum is formed by short_row_sum on the gathered row, in every
+// lane alike: the same arithmetic in the same order, the same integers.  Every thread of the workgroup must call it.
+// B <= 64: ONE wave runs the serial allocation (lane = cloud) and the whole-batch exit is a wave vote -- no
+// workgroup barrier inside the rounds (each costs more than a round's arithmetic).  The other waves just return;
+// the caller synchronises afterwards.  Same arithmetic as alloc_counts_body.
+__device__ inline void alloc_counts_wave(const float* w, const int* cap, int B, int nb, int M, int* counts) {
+  if (threadIdx.x >= 64) return;
+  const int b = threadIdx.x;
+  const bool live = b < B;
+  float p[kMaxBins], chosen[kMaxBins], capf[kMaxBins];
+  int capi[kMaxBins];
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    capi[t] = (live && t < nb) ? cap[b * nb + t] : 0;
+    capf[t] = (float)capi[t];
+    const float wt = (live && t < nb) ? w[b * nb + t] : 0.f;
+    p[t] = __fadd_rn(__fmul_rn(wt, capf[t]), 1e-10f);
+    chosen[t] = 0.f;
+  }
+  for (int round = 0; round < nb; ++round) {
+    const float s = short_row_sum(p, nb);
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) p[t] = __fdiv_rn(p[t], s);
+    const float left = __fsub_rn((float)M, short_row_sum(chosen, nb));
+    const int done = (!live) || (left == 0.f);
+    if (__all(done)) break;  // whole-batch early exit (utils/ops.py:409)
+#pragma unroll
+    for (int t = 0; t < kMaxBins; ++t) {
+      float c = __fadd_rn(chosen[t], __fmul_rn(p[t], left));
+      const bool sat = c >= capf[t];
+      chosen[t] = sat ? capf[t] : c;
+      p[t] = __fmul_rn(p[t], sat ? 0.f : 1.f);
+    }
+  }
+  if (!live) return;
+  int k[kMaxBins];
+  int total = 0, best = 0;
+  long bestv = 0;
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
+    k[t] = (t < nb) ? (int)chosen[t] : 0;
+    total += k[t];
+  }
+  for (int t = 0; t < nb; ++t) {
+    const long room = (long)capi[t] - k[t];
+    if (t == 0 || room > bestv) {
+      bestv = room;
+      best = t;
+    }
+  }
+  for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
+}
+
+__device__ inline void alloc_counts_lanes(const float* w, const int* cap, int B, int nb, int M, int* counts) {
+  const int tid = threadIdx.x, b = tid >> 3, t = tid & 7, lane = tid & 63, g0 = lane & ~7;
+  const bool live = b < B;
+  const bool mine = live && t < nb;
+  const int capi = mine ? cap[b * nb + t] : 0;
+  const float capf = (float)capi;
+  float p = __fadd_rn(__fmul_rn(mine ? w[b * nb + t] : 0.f, capf), 1e-10f);
+  float chosen = 0.f;
+  auto row = [&](float v, float (&out)[kMaxBins]) {
+#pragma unroll
+    for (int u = 0; u < kMaxBins; ++u) out[u] = __shfl(v, g0 + u, 64);
+  };
+  float r[kMaxBins];
+  for (int round = 0; round < nb; ++round) {
+    row(p, r);
+    const float s = short_row_sum(r, nb);
+    p = __fdiv_rn(p, s);
+    row(chosen, r);
+    const float left = __fsub_rn((float)M, short_row_sum(r, nb));
+    const int done = (!live) || (left == 0.f);
+    if (__syncthreads_and(done)) break;  // whole-batch early exit (utils/ops.py:409)
+    const float c = __fadd_rn(chosen, __fmul_rn(p, left));
+    const bool sat = c >= capf;
+    chosen = sat ? capf : c;
+    p = __fmul_rn(p, sat ? 0.f : 1.f);
+  }
+  const int k = (t < nb) ? (int)chosen : 0;
+  int total = 0, best = 0;
+  long bestv = 0;
+#pragma unroll
+  for (int u = 0; u < kMaxBins; ++u) {
+    const int ku = __shfl(k, g0 + u, 64), cu = __shfl(capi, g0 + u, 64);
+    total += ku;
+    const long room = (long)cu - ku;
+    if (u < nb && (u == 0 || room > bestv)) {
+      bestv = room;
+      best = u;
+    }
+  }
+  if (mine) counts[b * nb + t] = k + (t == best ? (M - total) : 0);
 }
 
 }  // namespace samble
