@@ -52,7 +52,9 @@ def algorithmic_bytes_per_cloud():
         knn=4 * N * C + 4 * N * KNN,                          # points in, neighbour lists out
         select=4 * N + 4 * N * NB + 4 * NB + 8 * M,           # score, Exp(1) noise, boundaries in; idx out
         sparse_score=8 * N * KNN + 4 * N + 12 * N,            # neighbour ids + one logit each, lse in; score, z, in-degree out
+                                                              # (map-free forward: folded into attn_stats_nl_tri, no launch)
         knn_prep=4 * N * C + 6 * N * C + 4 * N,               # points in; operand image (6 B / element) + norms out
+        nn_prepare=4 * N * KNN + 4 * N * KNN + 4 * N * ((N + 31) // 32),  # lists in; sorted lists + one word per (tile, row) out
         tri_split=4 * 3 * C * (N + NB) + 5 * 6 * C * (N + NB),  # [Q|K|V] rows in; five operand images out
         bwd_prep=8 * M + 8 * M * C + 3 * 6 * M * C,           # idx, Q rows, dO in; three operand images of the sampled rows out
         fused_step=4 * N * C + 4 * M * C + 8 * M + 4 * M * C + 8 * N * C,  # ideal fused layer: x, x_ds, idx; g, dx(+x)
@@ -286,7 +288,7 @@ def main():
             # (profiles/*_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require)
             try:
                 import glob
-                path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))[-1]
+                path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc.json")))[-1]
                 pmc = json.load(open(path))["kernels"]
                 key = next(k for k in pmc if k == kernel or k.startswith(kernel + "<"))  # template arguments vary
                 return pmc[key]["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
@@ -326,6 +328,9 @@ def main():
             result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
         result["roofline"]["launches_timed"] = dom[2] if dom else 0
         result["matrix_mode"] = ops.MATRIX_MODE
+        import samble_amd.downsample as _dsm0
+        result["forward"] = ("map-free (K neighbour logits per row in pass 1, sampled rows recomputed in pass 2)"
+                             if (tri and _dsm0.MAP_FREE) else "logit map in HBM (two-pass)")
         if not args.no_breakdown:
             # every other kernel of the step, timed the same way (library-side HIP events on the launch stream)
             # over 5 further full steps: same cache state as the timed region
@@ -338,17 +343,26 @@ def main():
             _lib.timing_select([])
             result["kernel_us"] = {n: round(v[1] * 1e3, 1) for n, v in kt.items() if v}
             sfx = "_tri_kernel" if tri else "_kernel"
+            import samble_amd.downsample as _dsm
+            map_free = tri and _dsm.MAP_FREE  # no N x (N+nt) logit map: pass 1 keeps K logits per row, pass 2 recomputes
             mf = []
             if kt.get("attn_stats"):
-                mf.append(roof("attn_stats" + sfx, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::attn_stats" + sfx))
+                nm = "attn_stats_nl_tri_kernel" if map_free else "attn_stats" + sfx
+                mf.append(roof(nm, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::" + nm))
             if kt.get("attn_rows"):
-                mf.append(roof("attn_rows" + sfx, fl["av"] * B_PER_GPU, kt["attn_rows"][0], "samble::attn_rows" + sfx))
+                nm = "attn_rows_rc_tri_kernel" if map_free else "attn_rows" + sfx
+                r_ = roof(nm, fl["av"] * B_PER_GPU, kt["attn_rows"][0], "samble::" + nm)
+                if map_free:
+                    r_["note"] = ("algorithmic flops = P V only (SURVEY 8d: recomputation is not counted); the kernel also "
+                                  "recomputes the sampled rows' logits: executed matrix work = 2 x algorithmic")
+                mf.append(r_)
             if tri:
                 # backward: dQ kernel = dP + dQ (2 products over N + nt keys), then dV and dK (1 product each, N keys)
                 if kt.get("bwd_dq"):
                     mf.append(roof("bwd_dq_tri_kernel", 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::bwd_dq_tri_kernel"))
                 if kt.get("bwd_dv"):
-                    mf.append(roof("bwd_kacc_tri_kernel<0> (dV)", 2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
+                    mf.append(roof("bwd_kacc_tri_kernel (dV)", 2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
+                                   "samble::bwd_kacc_tri_kernel<1, false>" if map_free else
                                    "samble::bwd_kacc_tri_kernel<0, false>"))
                 if kt.get("bwd_dk"):
                     mf.append(roof("bwd_kacc_tri_kernel<1> (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
@@ -370,13 +384,17 @@ def main():
             if kt.get("sparse_score"):
                 hb.append(hbm("sparse_score_map + finalize_score", by["sparse_score"] * B_PER_GPU, kt["sparse_score"][0],
                               "samble::sparse_score_map_kernel"))
-            sel = [kt.get(n_) for n_ in ("quantiles", "bin_assign", "alloc_counts", "bin_select")]
-            if all(sel):
-                hb.append(hbm("select chain (quantiles + bin_assign + alloc_counts + bin_select)",
-                              by["select"] * B_PER_GPU, sum(v[0] for v in sel), "samble::bin_select_kernel"))
+            sel = {n_: kt.get(n_) for n_ in ("quantiles", "bin_assign", "alloc_counts", "bin_select")}
+            if sel["quantiles"] and sel["bin_assign"] and sel["bin_select"]:
+                # fused chain: "quantiles" = score + z + batch quantiles, "bin_assign" = boundaries + bins + counts
+                hb.append(hbm("select chain (" + " + ".join(k_ for k_, v in sel.items() if v) + ")",
+                              by["select"] * B_PER_GPU, sum(v[0] for v in sel.values() if v), "samble::bin_select_kernel"))
+            if kt.get("nn_prepare"):
+                hb.append(hbm("nn_prepare (ascending neighbour lists + membership words)", by["nn_prepare"] * B_PER_GPU,
+                              kt["nn_prepare"][0], "nn_prepare_kernel"))
             for n_, label, key in (("knn_prep", "cloud_mean + tri_split_cm (kNN operand image + norms)", "knn_prep"),
                                    ("tri_split", "tri_split_qkv (operand images of Q, K, V)", "tri_split"),
-                                   ("bwd_prep", "bwd_prep (gather of the sampled rows + their operand images)", "bwd_prep")):
+                                   ("bwd_prep", "bwd_prep_tri (gather of the sampled rows + their operand images)", "bwd_prep")):
                 if kt.get(n_):
                     hb.append(hbm(label, by[key] * B_PER_GPU, kt[n_][0], "samble::" + label.split(" ")[0]))
             if kt.get("knn"):

@@ -351,7 +351,7 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
  *                                samble_select_chain_workspace_bytes; ALL score_ws_bytes are zeroed first) the
  *                                pass also accumulates the sparse_* statistics of score_mode (A_ij = exp(S_ij -
  *                                lse_i), i over all rows, j in nn_sorted[i]) into it as samble_sparse_score_map_f32
- *                                would (N <= 8192): follow with samble_sparse_score_map(_quantiles)_f32 passing
+ *                                would (N <= 8192): follow with samble_sparse_score_map_f32 or its _quantiles variant passing
  *                                smap = NULL.
  *   samble_sparse_score_map_f32 / samble_sparse_score_map_quantiles_f32 take (smap = nl, ld = 0, nn = nn_sorted),
  *                                or smap = NULL: the statistics are in `ws` already (see above).
@@ -378,9 +378,9 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
  * samble_timing_read(id, ...) waits for that kernel's recorded launches (the last 32 at most) and returns
  * their mean / median duration in ms and how many launches were seen.  Process-wide, not thread-safe, no
  * effect on results; nothing on the data path reads it. */
-#define SAMBLE_T_ATTN_STATS 1   /* attn_stats(_tri): QK^T + softmax statistics over all rows */
-#define SAMBLE_T_ATTN_ROWS 2    /* attn_rows(_tri): P V of the sampled rows */
-#define SAMBLE_T_BWD_DV 3       /* bwd_kacc_tri<0> (dV) */
+#define SAMBLE_T_ATTN_STATS 1   /* attn_stats(_tri / _nl_tri): QK^T + softmax statistics over all rows */
+#define SAMBLE_T_ATTN_ROWS 2    /* attn_rows(_tri / _rc_tri): P V of the sampled rows */
+#define SAMBLE_T_BWD_DV 3       /* bwd_kacc_tri (dV) */
 #define SAMBLE_T_KNN 4          /* knn_tri / knn_stream: fused Gram + top-K */
 #define SAMBLE_T_ATTN_FWD 5     /* attn_fwd: single-pass flash forward */
 #define SAMBLE_T_BWD_DQ 6       /* bwd_dq_tri (dP, dS map, dQ) */
@@ -398,6 +398,7 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
 #define SAMBLE_T_BWD_PREP 18
 #define SAMBLE_T_GATHER 19
 #define SAMBLE_T_BWD_ROWS_F32 22 /* bwd_rows (fp32-MFMA backward over the key blocks) */
+#define SAMBLE_T_NN_PREPARE 23   /* nn_prepare: ascending neighbour lists + per-tile membership words */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

@@ -163,7 +163,7 @@ def query(name: str, *args) -> int:
 TIMED_KERNELS = {
     "attn_stats": 1, "attn_rows": 2, "bwd_dv": 3, "knn": 4, "attn_fwd": 5, "bwd_dq": 6, "bwd_dk": 7, "proj_fwd": 8,
     "proj_dx": 9, "proj_dw": 10, "tri_split": 11, "knn_prep": 12, "sparse_score": 13, "quantiles": 14, "bin_assign": 15,
-    "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22,
+    "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22, "nn_prepare": 23,
 }
 
 

@@ -28,7 +28,7 @@ enum TimedKernel {
   kT_attn_stats = 1, kT_attn_rows = 2, kT_bwd_dv = 3, kT_knn = 4, kT_attn_fwd = 5, kT_bwd_dq = 6, kT_bwd_dk = 7,
   kT_proj_fwd = 8, kT_proj_dx = 9, kT_proj_dw = 10, kT_tri_split = 11, kT_knn_prep = 12, kT_sparse_score = 13,
   kT_quantiles = 14, kT_bin_assign = 15, kT_alloc_counts = 16, kT_bin_select = 17, kT_bwd_prep = 18,
-  kT_gather = 19, kT_knn_seed = 20, kT_select_chain = 21, kT_bwd_rows_f32 = 22,
+  kT_gather = 19, kT_knn_seed = 20, kT_select_chain = 21, kT_bwd_rows_f32 = 22, kT_nn_prepare = 23,
 };
 struct Timed {  // brackets the launches made during its lifetime
   int id;

@@ -394,6 +394,7 @@ extern "C" int samble_launch_nn_prepare(const int* nn, int B, int N, int KN, int
                                         hipStream_t stream) {
   const int T = (N + 31) / 32;
   const dim3 grid((N + 255) / 256, B);
+  Timed timed(kT_nn_prepare, stream);
   if (KN == 32) hipLaunchKernelGGL(nn_prepare_kernel<32>, grid, dim3(256), 0, stream, nn, N, T, nn_sorted, masks);
   else if (KN == 16) hipLaunchKernelGGL(nn_prepare_kernel<16>, grid, dim3(256), 0, stream, nn, N, T, nn_sorted, masks);
   else return -22;
