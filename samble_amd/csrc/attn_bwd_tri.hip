@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
   const char* Vb = a.V_rm + (long)b * ntiles * kTriTile;
   const char* Kb = a.K_tr + (long)b * ntiles * kTriTile;
 
+  const float* prow8[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = min(chunk * (32 * NW) + wave * 32 + 8 * k + (lane >> 3), M - 1);
+    prow8[k] = a.smap + ((long)b * M + r) * a.ld + 4 * ((lane & 7) ^ (lane >> 3));
+  }
   auto stage = [&](int t) {  // 16 DMA pieces per thread
     const int tt = min(t, ntiles - 1);
     char* st = smem_c + (t & 1) * kDqStage;
@@ -131,8 +137,17 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
       glds16(Vb + (long)tt * kTriTile + (tid + 256 * k) * 16, st + (wave * 64 + 256 * k) * 16);
       glds16(Kb + (long)tt * kTriTile + (tid + 256 * k) * 16, st + kTriTile + (wave * 64 + 256 * k) * 16);
     }
+    if (PMAP) {
+      // the wave's 32 x 32 block of the P map as whole 128-byte lines: piece k = rows 8k .. 8k+7, lane (r8 = lane >> 3,
+      // c = lane & 7) fetches 16-byte block c ^ r8 of its row (swizzle on the source: the rows' blocks land on
+      // distinct banks for the row-per-lane reads below)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) glds16(srow + tt * kTile + 8 * g, st + 2 * kTriTile + wave * 4096 + g * 1024);
+      for (int k = 0; k < 4; ++k)
+        glds16(prow8[k] + tt * kTile, st + 2 * kTriTile + wave * 4096 + k * 1024);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) glds16(srow + tt * kTile + 8 * g, st + 2 * kTriTile + wave * 4096 + g * 1024);
+    }
   };
   stage(0);
   u32x4 go[24];
@@ -151,11 +166,14 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = __uint_as_float(go[r][0]);
     } else dp = mma_rm_x_regs(st, lo, h, go);  // dP^T: rows = keys crow(r, h), column = this lane's row
-    const f32x4* sp = reinterpret_cast<const f32x4*>(st + 2 * kTriTile + wave * 4096 + lane * 16);
+    const char* sw = st + 2 * kTriTile + wave * 4096;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(sw + lane * 16);
     float ds[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 v4 = sp[64 * g];
+      const f32x4 v4 = PMAP ? *reinterpret_cast<const f32x4*>(sw + (lo >> 3) * 1024 + (lo & 7) * 128 +
+                                                              (((2 * g + h) ^ (lo & 7)) << 4))
+                            : sp[64 * g];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;

@@ -351,6 +351,7 @@ extern "C" int samble_launch_sparse_score_map_acc(const float* smap, int ld, con
   return (int)hipGetLastError();
 }
 
+namespace samble {
 // Neighbour lists for the map-free forward (attn_stats_nl_tri_kernel): per query the K neighbour indices in
 // ASCENDING order (rank by counting: the K indices of a row are distinct) and one 32-bit mask per (query, tile of
 // 32 point keys): bit k set <=> key 32 t + k is a neighbour.  masks (B, T, N), T = ceil(N / 32): the word of a
@@ -389,6 +390,7 @@ __global__ __launch_bounds__(256) void nn_prepare_kernel(const int* __restrict__
       for (int t = 0; t < 64 && t0 + t < T; ++t) masks[((long)b * T + t0 + t) * N + i] = words[t][tid];
   }
 }
+}  // namespace samble
 
 extern "C" int samble_launch_nn_prepare(const int* nn, int B, int N, int KN, int* nn_sorted, unsigned* masks,
                                         hipStream_t stream) {
