@@ -8,11 +8,17 @@ side-effect attributes (`attention_point_score`, `bin_boundaries`, `bin_points_m
 reference, so `cls_model` / `seg_model` can use it unchanged and reference checkpoints load.
 
 What differs is how the work is done: two autograd nodes over hand-written HIP kernels, the QKV
-projection (one fp32-MFMA kernel producing point-major rows; backward dx / dW / dtokens) and the
-sampler core:
-kNN build -> flash attention over all rows (no N x N tensor) -> exact sparse column score ->
-batch quantiles -> [RCCL all-reduce of nb-1 floats] -> bins / counts / per-bin selection -> row
-gather; backward is a flash-attention backward over the M sampled rows only.
+projection (one kernel producing point-major rows; backward dx / dW / dtokens) and the sampler core:
+kNN build -> attention pass 1 over all rows (softmax statistics, token logits, the exact sparse column score
+of the K neighbour entries of every row) -> batch quantiles -> [RCCL all-reduce of nb-1 floats] -> bins /
+counts / per-bin selection -> attention pass 2 over the M sampled rows; backward over the M sampled rows only.
+
+Memory held between forward and backward, per layer (B=32, N=2048 -> 1024; stress B=16, N=8192 -> 4096):
+  default (split-bf16, asm dot, sparse_* score: MAP_FREE)   qkv 101 MB + P rows of the sampled points (B,M,ld) 269 MB
+      + two operand images 101 MB (stress: 202 MB + 2.2 GB + 202 MB); nothing beyond the outputs under no_grad
+  logit-map pipeline (MAP_FREE = False, fp32-MFMA mode, asm l2)   the (B,N,ld) logit map 545 MB (stress 4.3 GB)
+      exists during the forward in any case and is kept for the backward only when a gradient is wanted
+  dense idx modes (col_sum, row_std)   the single-pass flash kernels: O (B,N,D) 34 MB, no N x N tensor
 """
 from __future__ import annotations
 
@@ -148,17 +154,19 @@ class _SamplerCore(torch.autograd.Function):
                                                          mod.relu_mean_order == "relu_mean")
             counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
+        # saved for backward: (qkv, O | x_ds, lse, idx[, map[, K transposed image, V row image]]) -- everything through
+        # save_for_backward (hooks and version checks see it), nothing when no gradient is wanted
         ctx.pmap = False
         if map_free:
             x_ds, pmap = ops.stage_attn_rows_recompute(imgs[0], imgs[1], imgs[2], lse, idx, N, nt, need_bwd, D)
             if need_bwd:  # the P rows of the sampled points stand in for the logit map in the backward
-                ctx.save_for_backward(qkv, x_ds, lse, idx, pmap)
+                ctx.save_for_backward(qkv, x_ds, lse, idx, pmap, imgs[3], imgs[4])
                 ctx.pmap = True
-                ctx.bwd_images = (imgs[3], imgs[4])
         elif smap is not None:
             x_ds = ops.stage_attn_rows(smap, lse, v, idx, N, nt, v_image=imgs[2] if imgs else None)
-            ctx.save_for_backward(qkv, x_ds, lse, idx, smap)
-            ctx.bwd_images = (imgs[3], imgs[4]) if imgs is not None and len(imgs) == 5 else None
+            if ctx.needs_input_grad[0]:
+                extra = (imgs[3], imgs[4]) if imgs is not None and len(imgs) == 5 else ()
+                ctx.save_for_backward(qkv, x_ds, lse, idx, smap, *extra)
         else:
             x_ds = ops.stage_gather_rows(O, idx)
             ctx.save_for_backward(qkv, O, lse, idx)
@@ -173,6 +181,7 @@ class _SamplerCore(torch.autograd.Function):
     def backward(ctx, g_xds, g_tok, *_):
         qkv, O, lse, idx = ctx.saved_tensors[:4]
         smap = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
+        images = tuple(ctx.saved_tensors[5:7]) if len(ctx.saved_tensors) > 6 else None
         N, nt, D = ctx.dims
         q = qkv[:, :N, 0:D]
         k = qkv[:, :, D:2 * D]
@@ -182,7 +191,7 @@ class _SamplerCore(torch.autograd.Function):
             if smap is not None:  # O is x_ds (B,D,M) here
                 ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
                                         dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm,
-                                        images=getattr(ctx, "bwd_images", None),
+                                        images=images,
                                         variant=ops.ROWS_BWD_PMAP if ctx.pmap else 0)
             else:
                 ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
