@@ -619,6 +619,9 @@ constexpr int kRcLds = kRcDepth * 2 * kTriTile + 4 * 4096;  // K ring, V ring, o
 #ifndef SAMBLE_RC_ABL
 #define SAMBLE_RC_ABL 0  // timing-only ablations (wrong results): 1 no in-loop DMA, 2 no P V MFMAs, 4 no logit MFMAs
 #endif
+#ifndef SAMBLE_RC_REGSTAGE
+#define SAMBLE_RC_REGSTAGE 0  // 1: register staging instead of LDS-DMA (measured in the step: 224-228 us against 204)
+#endif
 template <bool PMAP>
 __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __restrict__ Qimg,
                                                                const char* __restrict__ Kimg,
@@ -656,7 +659,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   stage(Kb, kring, 0);
   stage(Kb, kring, 1);
   stage(Vb, vring, 0);
+#if !SAMBLE_RC_REGSTAGE
   stage(Kb, kring, 2);
+#endif
   u32x4 q[24];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (int)(row >> 5)) * kTriTile +
@@ -684,10 +689,25 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   // t = ntiles: P is all padding, the logits are not used)
   auto step = [&](int t, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
+#if SAMBLE_RC_REGSTAGE
+    // register staging instead of LDS-DMA: the tiles needed from the NEXT iteration on (K tile t+2, V tile t) are
+    // loaded into registers here and written to their ring slots at the end of the iteration
+    u32x4 kreg[6], vreg[6];
+    if (!LAST) {
+      const char* ksrc = Kb + (long)min(t + 2, ntiles - 1) * kTriTile;
+      const char* vsrc = Vb + (long)min(t, ntiles - 1) * kTriTile;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        kreg[k] = *reinterpret_cast<const u32x4*>(ksrc + (tid + 256 * k) * 16);
+        vreg[k] = *reinterpret_cast<const u32x4*>(vsrc + (tid + 256 * k) * 16);
+      }
+    }
+#else
     if (!LAST && !(SAMBLE_RC_ABL & 1)) {
       stage(Kb, kring, t + 3);  // slot of K tile t: its reads ended before the last barrier
       stage(Vb, vring, t + 1);  // slot of V tile t-2: likewise
     }
+#endif
     const char* vt = vring + (max(t - 1, 0) % D) * kTriTile;
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
     auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
@@ -763,7 +783,20 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     }
     // K tile t+2 and V tile t (staged one iteration ago) must have landed before anyone reads them.  Younger
     // than their pieces: the previous iteration's stores, this iteration's 12 pieces and stores
+#if SAMBLE_RC_REGSTAGE
+    if (!LAST) {
+      char* kdst = kring + ((t + 2) % D) * kTriTile;  // K tile t-1's slot: last read two iterations ago
+      char* vdst = vring + (t % D) * kTriTile;        // V tile t-3's slot
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        *reinterpret_cast<u32x4*>(kdst + (tid + 256 * k) * 16) = kreg[k];
+        *reinterpret_cast<u32x4*>(vdst + (tid + 256 * k) * 16) = vreg[k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#else
     if (!LAST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
+#endif
     s_cur = s_nxt;
     bp[0] = bn[0];
     bp[1] = bn[1];
