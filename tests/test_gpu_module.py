@@ -311,3 +311,30 @@ def test_map_free_module_equals_map_module(name):
         assert len(a) == len(b) and len(a) > 6
         for j, (t1, t2) in enumerate(zip(a, b)):
             assert torch.equal(t1, t2), (call, j)
+
+
+def test_map_free_long_cloud_takes_the_compact_score_route():
+    """N = 8500 > 8192: pass 1 cannot hold the score accumulators in LDS, so the module keeps the K neighbour logits per
+    row and runs the separate score pass on them -- still without the N x (N+nt) map, same outputs as with the map."""
+    import samble_amd.downsample as D
+    from samble_amd import ops, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 1, 128, 8500, 1000, 6
+    x = torch.from_numpy(synth.features(B, C, N, 31)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 32)).to(DEV)
+    outs = []
+    old_mode, old_free = ops.MATRIX_MODE, D.MAP_FREE
+    try:
+        ops.MATRIX_MODE = "tri"
+        for free in (False, True):
+            D.MAP_FREE = free
+            torch.manual_seed(3)
+            mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+            xin = x.clone().requires_grad_(True)
+            (x_ds, idx), _ = mod(xin, noise=noise)
+            x_ds.sum().backward()
+            outs.append((x_ds.detach(), idx, mod.attention_point_score, xin.grad, mod.q_conv.weight.grad))
+    finally:
+        ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
+    for j, (t1, t2) in enumerate(zip(*outs)):
+        assert torch.equal(t1, t2), j
