@@ -117,13 +117,23 @@ __device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int 
                                                f32x16& s_nxt) {
   const u32x4* lp = reinterpret_cast<const u32x4*>(Kn + tri_rm_off(lo, h, 0));  // group 2 ks + h: + ks * 192 chunks
   s_nxt = zero16();
+  if (ABL & 8) {  // the compiler's own placement of the operand reads
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
-    const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-    if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
-    else s_nxt = mfma_tri(a, bq, s_nxt);
+    for (int ks = 0; ks < 8; ++ks) {
+      const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
+      const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+      if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
+      else s_nxt = mfma_tri(a, bq, s_nxt);
+    }
+    return;
   }
+  // operand reads two k-steps ahead of their MFMAs (stamped: 44-51 cycles per MFMA with the compiler's placement)
+  tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; },
+                   [&](int ks, const Tri& a) {
+                     const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+                     if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
+                     else s_nxt = mfma_tri(a, bq, s_nxt);
+                   });
 }
 
 template <bool TAIL, bool L2, int ABL>
@@ -311,6 +321,16 @@ struct NlScoreArgs {
 };
 constexpr float kNlFix = 17592186044416.f;  // 2^44, as score.hip
 
+#ifdef SAMBLE_STAMPS  // scratch builds only: s_memtime marks of workgroup 0, tiles 20 and 21, every wave
+__device__ unsigned long long g_nl_stamps[8 * 2 * 8];
+#define NL_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t == 20 || t == 21))                           \
+      g_nl_stamps[(wave * 2 + (t - 20)) * 8 + (i)] = __builtin_amdgcn_s_memtime();                         \
+  } while (0)
+#else
+#define NL_STAMP(i) do { } while (0)
+#endif
 constexpr int kNlStride = 33;  // words per query row in LDS (K <= 32; odd: rows on distinct banks)
 constexpr int kStatsNlLds = kStatsDepth * kTriTile + kStatsDepth * 2048 + 256 * kNlStride * 4;
 
@@ -410,18 +430,31 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
   auto step = [&](int t, auto tail_c) {
     constexpr bool TAIL = decltype(tail_c)::value;
     const int j0 = t * kTile;
+    NL_STAMP(0);
     const unsigned mask_cur = mask_of(t);  // before its slot is restaged
     stage(t + D);
+    NL_STAMP(1);
     if (pfirst) {
       stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
       __builtin_amdgcn_sched_barrier(0);
+      NL_STAMP(2);
       stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
+      NL_STAMP(3);
     } else {
       stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
       __builtin_amdgcn_sched_barrier(0);
+      NL_STAMP(2);
       stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      NL_STAMP(3);
     }
+#ifdef SAMBLE_STAMPS
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (D - 2)) : "memory");
+    NL_STAMP(4);
+    asm volatile("s_barrier" ::: "memory");
+    NL_STAMP(5);
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (D - 2)) : "memory");
+#endif
     s_cur = s_nxt;
   };
   const int n_full = min(N / kTile, ntiles);  // tiles without token / padding columns
@@ -619,8 +652,15 @@ constexpr int kRcLds = kRcDepth * 2 * kTriTile + 4 * 4096;  // K ring, V ring, o
 #ifndef SAMBLE_RC_ABL
 #define SAMBLE_RC_ABL 0  // timing-only ablations (wrong results): 1 no in-loop DMA, 2 no P V MFMAs, 4 no logit MFMAs
 #endif
-#ifndef SAMBLE_RC_REGSTAGE
-#define SAMBLE_RC_REGSTAGE 0  // 1: register staging instead of LDS-DMA (measured in the step: 224-228 us against 204)
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch): s_memtime marks of workgroup 0, tiles 20 and 21
+__device__ unsigned long long g_rc_stamps[4 * 2 * 16];
+#define RC_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t == 20 || t == 21))                           \
+      g_rc_stamps[(wave * 2 + (t - 20)) * 16 + (i)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#else
+#define RC_STAMP(i) do { } while (0)
 #endif
 template <bool PMAP>
 __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __restrict__ Qimg,
@@ -659,9 +699,7 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   stage(Kb, kring, 0);
   stage(Kb, kring, 1);
   stage(Vb, vring, 0);
-#if !SAMBLE_RC_REGSTAGE
   stage(Kb, kring, 2);
-#endif
   u32x4 q[24];
   {
     const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (int)(row >> 5)) * kTriTile +
@@ -687,27 +725,18 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
 
   // iteration t = 0 .. ntiles: logits of tile t+1, P of tile t, P V of tile t-1 (t = 0: zeros against tile 0;
   // t = ntiles: P is all padding, the logits are not used)
+  float pprev[16];  // P of the previous tile: its map rows leave under the NEXT iteration's MFMAs
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
+  char* xt = smem_c + 2 * D * kTriTile + wave * 4096;  // this wave's 32 x 32 fp32 transpose tile
+
+  // Everything an iteration issues besides MFMAs is spread over its eight k-steps, so that it runs in the MFMAs'
+  // shadow (stamped, tools/rc_stamps.py: at the top / bottom of the loop body the 12 DMA pieces cost 780 cycles, the
+  // P tile's way out 640, the first operand fetch 500 -- of 6 100): operand reads first; two DMA pieces per k-step
+  // in steps 0-5; the previous tile's P goes through the wave's LDS tile in steps 0 / 2 and out in steps 6 / 7.
   auto step = [&](int t, auto last_c) {
     constexpr bool LAST = decltype(last_c)::value;
-#if SAMBLE_RC_REGSTAGE
-    // register staging instead of LDS-DMA: the tiles needed from the NEXT iteration on (K tile t+2, V tile t) are
-    // loaded into registers here and written to their ring slots at the end of the iteration
-    u32x4 kreg[6], vreg[6];
-    if (!LAST) {
-      const char* ksrc = Kb + (long)min(t + 2, ntiles - 1) * kTriTile;
-      const char* vsrc = Vb + (long)min(t, ntiles - 1) * kTriTile;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        kreg[k] = *reinterpret_cast<const u32x4*>(ksrc + (tid + 256 * k) * 16);
-        vreg[k] = *reinterpret_cast<const u32x4*>(vsrc + (tid + 256 * k) * 16);
-      }
-    }
-#else
-    if (!LAST && !(SAMBLE_RC_ABL & 1)) {
-      stage(Kb, kring, t + 3);  // slot of K tile t: its reads ended before the last barrier
-      stage(Vb, vring, t + 1);  // slot of V tile t-2: likewise
-    }
-#endif
+    RC_STAMP(0);
     const char* vt = vring + (max(t - 1, 0) % D) * kTriTile;
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
     auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
@@ -716,10 +745,25 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
       return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
                  *reinterpret_cast<const u32x4*>(ap + 4096)};
     };
+    Tri k0 = fetch_k(0), k1 = fetch_k(1), v0 = fetch_v(0), v1 = fetch_v(1);
+    // DMA piece i of K tile t+3 (slot of K tile t: its reads ended before the last barrier) and of V tile t+1
+    // (slot of V tile t-2: likewise); past the end: the last tile again, unused
+    const char* ksrc = Kb + (long)min(t + 3, ntiles - 1) * kTriTile + tid * 16;
+    const char* vsrc = Vb + (long)min(t + 1, ntiles - 1) * kTriTile + tid * 16;
+    char* kdst = kring + ((t + 3) % D) * kTriTile + wave * 1024;
+    char* vdst = vring + ((t + 1) % D) * kTriTile + wave * 1024;
+    auto piece = [&](int k) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + 4096 * k),
+                                       (__attribute__((address_space(3))) void*)(kdst + 4096 * k), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + 4096 * k),
+                                       (__attribute__((address_space(3))) void*)(vdst + 4096 * k), 16, 0, 0);
+    };
+    float* pout = PMAP ? pmap + (long)b * M * ld + max(t - 1, 0) * kTile + 4 * (lane & 7) : nullptr;
+    f32x4 po[4];
     Tri bn[2];
     float p[16];
     s_nxt = zero16();
-    Tri k0 = fetch_k(0), k1 = fetch_k(1), v0 = fetch_v(0), v1 = fetch_v(1);
+    RC_STAMP(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       Tri k2 = k1, v2 = v1;
@@ -750,56 +794,65 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
         bn[i >> 2].m[i & 3] = mm;
         bn[i >> 2].l[i & 3] = ll;
       }
-      // the weave: one MFMA, then its share of the slice's vector instructions
+      if (!LAST && !(SAMBLE_RC_ABL & 1) && i < 6) piece(i);
+      if (PMAP) {
+        // the previous tile's P -> map rows as full 128-byte lines (8 lanes per row) through the wave's own 4 KB of
+        // LDS; 16-byte block c of row r sits at block c ^ (r & 7): conflict-free both ways without padding.  LDS
+        // operations of a wave execute in order: no wait between the writes and the reads.  (Iteration 0 writes
+        // zeros over tile 0's place; iteration 1 overwrites them.)
+        if (i == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 o = {pprev[4 * g], pprev[4 * g + 1], pprev[4 * g + 2], pprev[4 * g + 3]};
+            *reinterpret_cast<f32x4*>(xt + lo * 128 + (((2 * g + h) ^ (lo & 7)) << 4)) = o;
+          }
+        }
+        if (i == 2) {
+#pragma unroll
+          for (int k8 = 0; k8 < 4; ++k8) {
+            const int rr = (lane >> 3) + 8 * k8;
+            po[k8] = *reinterpret_cast<const f32x4*>(xt + rr * 128 + (((lane & 7) ^ (rr & 7)) << 4));
+          }
+        }
+        if (i >= 6) {
+#pragma unroll
+          for (int k8 = 2 * (i - 6); k8 < 2 * (i - 6) + 2; ++k8) {
+            const int mr = min(m0 + (lane >> 3) + 8 * k8, M - 1);  // rows past M-1 rewrite row M-1's values (same bytes)
+            *reinterpret_cast<f32x4*>(pout + (long)mr * ld) = po[k8];
+          }
+        }
+      }
+      // the weave: one MFMA, then its share of the step's vector instructions; memory operations float
 #pragma unroll
       for (int m = 0; m < (LAST ? 6 : 12); ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 6 : 3, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      RC_STAMP(2 + i);
       k0 = k1;
       k1 = k2;
       v0 = v1;
       v1 = v2;
     }
-    if (PMAP && !LAST) {
-      // P tile -> map rows as full 128-byte lines (8 lanes per row) through the wave's own 4 KB of LDS; 16-byte
-      // block c of row r sits at block c ^ (r & 7): conflict-free both ways without padding (the rings leave
-      // exactly 4 x 4 KB of the 160 KB)
-      char* xt = smem_c + 2 * D * kTriTile + wave * 4096;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
-        *reinterpret_cast<f32x4*>(xt + lo * 128 + (((2 * g + h) ^ (lo & 7)) << 4)) = o;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private: no barrier
-#pragma unroll
-      for (int k8 = 0; k8 < 4; ++k8) {
-        const int rr = (lane >> 3) + 8 * k8;
-        const f32x4 o = *reinterpret_cast<const f32x4*>(xt + rr * 128 + (((lane & 7) ^ (rr & 7)) << 4));
-        const int mr = min(m0 + rr, M - 1);  // rows past M-1 rewrite row M-1's values of this wave (same bytes)
-        *reinterpret_cast<f32x4*>(pmap + ((long)b * M + mr) * ld + t * kTile + 4 * (lane & 7)) = o;
-      }
-    }
-    // K tile t+2 and V tile t (staged one iteration ago) must have landed before anyone reads them.  Younger
-    // than their pieces: the previous iteration's stores, this iteration's 12 pieces and stores
-#if SAMBLE_RC_REGSTAGE
+    // K tile t+2 and V tile t (their pieces went out in the PREVIOUS iteration's k-steps 0-5) must have landed before
+    // anyone reads them.  Younger than those pieces: that iteration's 4 stores, this iteration's 12 pieces and 4 stores
+    RC_STAMP(10);
+#ifdef SAMBLE_STAMPS
     if (!LAST) {
-      char* kdst = kring + ((t + 2) % D) * kTriTile;  // K tile t-1's slot: last read two iterations ago
-      char* vdst = vring + (t % D) * kTriTile;        // V tile t-3's slot
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        *reinterpret_cast<u32x4*>(kdst + (tid + 256 * k) * 16) = kreg[k];
-        *reinterpret_cast<u32x4*>(vdst + (tid + 256 * k) * 16) = vreg[k];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(PMAP ? 20 : 12) : "memory");
+      RC_STAMP(11);
+      asm volatile("s_barrier" ::: "memory");
     }
 #else
     if (!LAST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
 #endif
+    RC_STAMP(12);
     s_cur = s_nxt;
     bp[0] = bn[0];
     bp[1] = bn[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pprev[r] = p[r];
   };
   for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
   step(ntiles, std::true_type{});  // P V of the last tile
@@ -871,6 +924,15 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm);
   return (int)hipGetLastError();
 }
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_nl_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_nl_stamps), sizeof(unsigned long long) * 128);
+}
+extern "C" __attribute__((visibility("default"))) int samble_scratch_rc_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_rc_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 // pass 1 without the map: lse, token logits and the K neighbour logits per row (nl (B, N, KN), ascending-index order)
 // nn_sorted / acc_ws non-null: also accumulate the sparse_* score statistics of `score_mode` (score.hip's modes)
