@@ -297,12 +297,13 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
       for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
     }
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + buf * kTriTile + tri_rm_off(lo, h, 0));
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
-      const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-      acc = mfma_tri(a, bq, acc);
-    }
+    // operand reads two k-steps ahead of their MFMAs (the compiler's own placement: 44-51 cycles per MFMA, stamped
+    // in attn_stats)
+    tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; },
+                     [&](int ks, const Tri& a) {
+                       const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
+                       acc = mfma_tri(a, bq, acc);
+                     });
     return acc;
   };
   // filter of tile tt's accumulator into the ring + ONE insertion step (~0.8 candidates per row and tile arrive
