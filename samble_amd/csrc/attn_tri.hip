@@ -639,6 +639,13 @@ __global__ __launch_bounds__(256) void attn_rows_tri_kernel(const float* __restr
 // K row-image tile and a V transposed-image tile by LDS-DMA, ring of 3, every wait counted: per iteration a thread
 // issues 12 DMA pieces and (PMAP) 4 stores.
 // ------------------------------------------------------------------------------------------------
+// a pointer the compiler can keep in scalar registers (the value IS wave-uniform; this tells it so)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi32 << 32) | lo32);
+}
+
 constexpr int kRcDepth = 3;
 constexpr int kRcLds = kRcDepth * 2 * kTriTile + 4 * 4096;  // K ring, V ring, one 32 x 32 fp32 tile per wave
 
@@ -725,6 +732,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
 
   // iteration t = 0 .. ntiles: logits of tile t+1, P of tile t, P V of tile t-1 (t = 0: zeros against tile 0;
   // t = ntiles: P is all padding, the logits are not used)
+  unsigned voff[6];  // byte offset of this thread's piece k inside a tile (loop-invariant)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) voff[k] = (unsigned)(tid * 16 + 4096 * k);
   float pprev[16];  // P of the previous tile: its map rows leave under the NEXT iteration's MFMAs
 #pragma unroll
   for (int r = 0; r < 16; ++r) pprev[r] = 0.f;
@@ -734,8 +744,10 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   // shadow (stamped, tools/rc_stamps.py: at the top / bottom of the loop body the 12 DMA pieces cost 780 cycles, the
   // P tile's way out 640, the first operand fetch 500 -- of 6 100): operand reads first; two DMA pieces per k-step
   // in steps 0-5; the previous tile's P goes through the wave's LDS tile in steps 0 / 2 and out in steps 6 / 7.
-  auto step = [&](int t, auto last_c) {
+  // LAST: the extra step after the last tile (only P V of tile ntiles-1); TAILK: tile t may hold padding keys
+  auto step = [&](int t, auto last_c, auto tail_c) {
     constexpr bool LAST = decltype(last_c)::value;
+    constexpr bool TAILK = decltype(tail_c)::value;
     RC_STAMP(0);
     const char* vt = vring + (max(t - 1, 0) % D) * kTriTile;
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
@@ -748,14 +760,14 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     Tri k0 = fetch_k(0), k1 = fetch_k(1), v0 = fetch_v(0), v1 = fetch_v(1);
     // DMA piece i of K tile t+3 (slot of K tile t: its reads ended before the last barrier) and of V tile t+1
     // (slot of V tile t-2: likewise); past the end: the last tile again, unused
-    const char* ksrc = Kb + (long)min(t + 3, ntiles - 1) * kTriTile + tid * 16;
-    const char* vsrc = Vb + (long)min(t + 1, ntiles - 1) * kTriTile + tid * 16;
+    const char* ksrc = uniform_ptr(Kb + (long)min(t + 3, ntiles - 1) * kTriTile);  // scalar base + 32-bit lane offset:
+    const char* vsrc = uniform_ptr(Vb + (long)min(t + 1, ntiles - 1) * kTriTile);  // no 64-bit vector address arithmetic
     char* kdst = kring + ((t + 3) % D) * kTriTile + wave * 1024;
     char* vdst = vring + ((t + 1) % D) * kTriTile + wave * 1024;
     auto piece = [&](int k) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + 4096 * k),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + voff[k]),
                                        (__attribute__((address_space(3))) void*)(kdst + 4096 * k), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + 4096 * k),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + voff[k]),
                                        (__attribute__((address_space(3))) void*)(vdst + 4096 * k), 16, 0, 0);
     };
     float* pout = PMAP ? pmap + (long)b * M * ld + max(t - 1, 0) * kTile + 4 * (lane & 7) : nullptr;
@@ -785,8 +797,8 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
         float x0 = s_cur[r0], x1 = s_cur[r1];
         asm volatile("" : "+v"(x0), "+v"(x1));  // pins the slice inside this k-step's scheduling region (with the one below)
         const float e0 = __expf(x0 * scale - my_lse), e1 = __expf(x1 * scale - my_lse);
-        p[r0] = (!LAST && t * kTile + crow(r0, h) < NK) ? e0 : 0.f;  // padding keys of the last tile
-        p[r1] = (!LAST && t * kTile + crow(r1, h) < NK) ? e1 : 0.f;
+        p[r0] = LAST ? 0.f : (TAILK && t * kTile + crow(r0, h) >= NK) ? 0.f : e0;  // padding keys of the last tile
+        p[r1] = LAST ? 0.f : (TAILK && t * kTile + crow(r1, h) >= NK) ? 0.f : e1;
         unsigned hh, mm, ll;
         tri_split2(p[r0], p[r1], hh, mm, ll);
         asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));
@@ -854,8 +866,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) pprev[r] = p[r];
   };
-  for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
-  step(ntiles, std::true_type{});  // P V of the last tile
+  for (int t = 0; t < ntiles - 1; ++t) step(t, std::false_type{}, std::false_type{});
+  step(ntiles - 1, std::false_type{}, std::true_type{});
+  step(ntiles, std::true_type{}, std::false_type{});  // P V of the last tile
   if (mvalid) {
     float* ob = xds + (long)b * 128 * M + mrow;
 #pragma unroll

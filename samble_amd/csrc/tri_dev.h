@@ -65,15 +65,23 @@ __device__ __forceinline__ unsigned bf16_bits(float x) {  // round to nearest ev
 }
 __device__ __forceinline__ float bf16_value(unsigned bits) { return __uint_as_float(bits << 16); }
 
-// split two fp32 values into the packed (lo = x0, hi = x1) words of the three planes
+// two fp32 values -> one packed word of bf16 (lo = a, hi = b), round to nearest even: ONE v_cvt_pk_bf16_f32
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// split two fp32 values into the packed (lo = x0, hi = x1) words of the three planes: 3 packed conversions, 4 bit
+// operations to widen the halves again, 4 exact subtractions (scalar conversions + packing cost 18 instructions;
+// these are issued beside MFMAs that hold the same issue port)
 __device__ __forceinline__ void tri_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned h0 = bf16_bits(x0), h1 = bf16_bits(x1);
-  const float r0 = x0 - bf16_value(h0), r1 = x1 - bf16_value(h1);
-  const unsigned m0 = bf16_bits(r0), m1 = bf16_bits(r1);
-  const float q0 = r0 - bf16_value(m0), q1 = r1 - bf16_value(m1);
-  h = h0 | (h1 << 16);
-  m = m0 | (m1 << 16);
-  l = bf16_bits(q0) | (bf16_bits(q1) << 16);
+  h = bf16_pack2(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);
+  m = bf16_pack2(r0, r1);
+  const float q0 = r0 - __uint_as_float(m << 16), q1 = r1 - __uint_as_float(m & 0xFFFF0000u);
+  l = bf16_pack2(q0, q1);
 }
 
 __device__ __forceinline__ Tri tri_split8(const float (&x)[8]) {
