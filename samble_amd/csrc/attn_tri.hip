@@ -350,7 +350,28 @@ __device__ __forceinline__ void stats_nl_epilogue(int h, f32x16& s_cur, float sc
     }
     s_cur[r] = v;
     mt = fmaxf(mt, v);
-    if ((mask >> kk) & 1u) nlrow[cnt + (int)__popc(mask & ((1u << kk) - 1u))] = v;
+    if (TAIL && ((mask >> kk) & 1u)) nlrow[cnt + (int)__popc(mask & ((1u << kk) - 1u))] = v;
+  }
+  if (!TAIL) {
+    // neighbour logits of this tile: a lane holds 16 of the tile's 32 keys and on average a quarter of a neighbour
+    // among them, so instead of 16 predicated writes (8 instructions each, issued whether or not the bit is set:
+    // 128 of the epilogue's 208) the lanes walk their set bits -- the fullest lane of the wave sets the trip count
+    // (about 2) -- and pick the value out of the 16 registers by a select tree
+    unsigned sub = __builtin_amdgcn_ubfe(mask, 4 * h, 4) | (__builtin_amdgcn_ubfe(mask, 8 + 4 * h, 4) << 4) |
+                   (__builtin_amdgcn_ubfe(mask, 16 + 4 * h, 4) << 8) | (__builtin_amdgcn_ubfe(mask, 24 + 4 * h, 4) << 12);
+    while (__any(sub != 0)) {
+      const int r = __builtin_ctz(sub | 0x10000u) & 15;  // (lanes without a bit left pick register 0 and write nothing)
+      const bool b0 = r & 1, b1 = r & 2, b2 = r & 4;
+      const float e0 = b0 ? s_cur[1] : s_cur[0], e1 = b0 ? s_cur[3] : s_cur[2], e2 = b0 ? s_cur[5] : s_cur[4];
+      const float e3 = b0 ? s_cur[7] : s_cur[6], e4 = b0 ? s_cur[9] : s_cur[8], e5 = b0 ? s_cur[11] : s_cur[10];
+      const float e6 = b0 ? s_cur[13] : s_cur[12], e7 = b0 ? s_cur[15] : s_cur[14];
+      const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+      const float g0 = b2 ? f1 : f0, g1 = b2 ? f3 : f2;
+      const float val = (r & 8) ? g1 : g0;
+      const int kk = 8 * (r >> 2) + 4 * h + (r & 3);
+      if (sub != 0) nlrow[cnt + (int)__popc(mask & ((1u << kk) - 1u))] = val;
+      sub &= sub - 1;
+    }
   }
   cnt += (int)__popc(mask);
   mt = fmaxf(mt, wave_xor32(mt));  // running max (branch-free rescale of the running sum)
