@@ -15,6 +15,8 @@
 // 5 matrix products per (rows x keys) tile instead of 4 -- dP is formed in both orientations -- which
 // the 2.6x matrix rate pays for several times over; dQ rows are written once, in place.
 // Operand tiles arrive by LDS-DMA; all waits are counted by hand (see attn_tri.hip).
+#include <type_traits>
+
 #include "tri_dev.h"
 
 namespace samble {
@@ -491,16 +493,20 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
   float csum = 0.f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  for (int t = 0; t < mtiles; ++t) {
+  // Vector instructions share the SIMD's issue port with the MFMAs (48 per tile here), so the loop carries as few
+  // as it can: keys past N need no masking (their outputs are never stored), sampled rows past M exist only in the
+  // last tile (TAIL), and the 16 map reads use immediate offsets off one address.
+  auto step = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
     const char* st = smem_c + (t % kAccTrSlots) * kTriTile;
     stage_tr(t + 1);                     // slot of tile t-1
     if (MODE == 0) stage_meta(t + 3);    // slot of tile t-1; needed by stage_map(t + 3) in the next iteration
     stage_map(t + 2);                    // slot of tile t-1; the 4 youngest operations
-    const float* mp = reinterpret_cast<const float*>(mapring + (t % kAccMapSlots) * kAccMap) + wave * 32 + lo;
+    const float* mp = reinterpret_cast<const float*>(mapring + (t % kAccMapSlots) * kAccMap) + wave * 32 + lo + 1024 * h;
     const int i0 = t * kTile;
     float x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = mp[crow(r, h) * 256];
+    for (int r = 0; r < 16; ++r) x[r] = mp[(8 * (r >> 2) + (r & 3)) * 256];  // row crow(r, h) = 8 (r >> 2) + 4 h + (r & 3)
     if (MODE == 0) {
       const float* Lt = reinterpret_cast<const float*>(meta + (t % kAccMetaSlots) * kAccMeta);
 #pragma unroll
@@ -510,19 +516,21 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const float pv = __expf(x[r] - l4[e]);
-          x[r] = (i0 + crow(r, h) < M) ? pv : 0.f;
+          x[r] = (TAIL && i0 + crow(r, h) >= M) ? 0.f : pv;
         }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        x[r] = (jvalid && i0 + crow(r, h) < M) ? x[r] : 0.f;
+        if (TAIL) x[r] = (i0 + crow(r, h) < M) ? x[r] : 0.f;  // rows past M: the clamped copies of row M-1
         if (CS) csum += x[r];
       }
     }
     mma_tr_x_acc(st, lo, h, x, acc);
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
+  };
+  for (int t = 0; t < mtiles - 1; ++t) step(t, std::false_type{});
+  step(mtiles - 1, std::true_type{});
   if (MODE == 1 && CS) {
     const float ctot = csum + wave_xor32(csum);
     if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
