@@ -45,9 +45,20 @@ __device__ __forceinline__ Tri tri_from_acc(const float (&x)[16], int ks) {
 }
 
 // out[dt] (channels 32 dt .. 32 dt + 31 x this lane's column) += TRtile^T x frag, both k-steps
+template <int DEPTH = 2>
 __device__ __forceinline__ void mma_tr_x_acc(const char* __restrict__ tr_tile, int lo, int h, const float (&x)[16],
                                              f32x16 (&out)[4]) {
   const Tri b0 = tri_from_acc(x, 0), b1 = tri_from_acc(x, 1);
+  auto fetch = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+    const char* ap = tr_tile + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+    return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+               *reinterpret_cast<const u32x4*>(ap + 4096)};
+  };
+  auto use = [&](int i, const Tri& a) { out[i & 3] = mfma_tri(a, (i >> 2) ? b1 : b0, out[i & 3]); };
+  if (DEPTH == 3) {
+    tri_pipelined3<8>(fetch, use);
+    return;
+  }
   tri_pipelined<8>(
       [&](int i) {  // step i: k-step i >> 2, channel block i & 3
         const char* ap = tr_tile + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
@@ -419,6 +430,16 @@ constexpr int kAccMap = 32 * 256 * 4;  // 32 sampled rows x the workgroup's 256 
 constexpr int kAccMeta = 512;          // per slot: lse[32] twice (MODE 0), idx[32] (int64) at +256
 constexpr int kAccLds = kAccTrSlots * kTriTile + kAccMapSlots * kAccMap + kAccMetaSlots * kAccMeta;
 
+#ifdef SAMBLE_STAMPS  // scratch builds only: s_memtime marks of workgroup 0, tiles 10 and 11, every wave
+__device__ unsigned long long g_ka_stamps[8 * 2 * 8];
+#define KA_STAMP(i)                                                                                        \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t == 10 || t == 11))                           \
+      g_ka_stamps[(wave * 2 + (t - 10)) * 8 + (i)] = __builtin_amdgcn_s_memtime();                         \
+  } while (0)
+#else
+#define KA_STAMP(i) do { } while (0)
+#endif
 struct KaccArgs {
   const float* map;    // MODE 0: smap (B, N, ld);  MODE 1: dsmap (B, M, ld)
   int ld;
@@ -498,10 +519,12 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
   // last tile (TAIL), and the 16 map reads use immediate offsets off one address.
   auto step = [&](int t, auto tail_c) {
     constexpr bool TAIL = decltype(tail_c)::value;
+    KA_STAMP(0);
     const char* st = smem_c + (t % kAccTrSlots) * kTriTile;
     stage_tr(t + 1);                     // slot of tile t-1
     if (MODE == 0) stage_meta(t + 3);    // slot of tile t-1; needed by stage_map(t + 3) in the next iteration
     stage_map(t + 2);                    // slot of tile t-1; the 4 youngest operations
+    KA_STAMP(1);
     const float* mp = reinterpret_cast<const float*>(mapring + (t % kAccMapSlots) * kAccMap) + wave * 32 + lo + 1024 * h;
     const int i0 = t * kTile;
     float x[16];
@@ -526,8 +549,17 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
         if (CS) csum += x[r];
       }
     }
-    mma_tr_x_acc(st, lo, h, x, acc);
+    KA_STAMP(2);
+    mma_tr_x_acc<3>(st, lo, h, x, acc);
+    KA_STAMP(3);
+#ifdef SAMBLE_STAMPS
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    KA_STAMP(4);
+    asm volatile("s_barrier" ::: "memory");
+    KA_STAMP(5);
+#else
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
   };
   for (int t = 0; t < mtiles - 1; ++t) step(t, std::false_type{});
   step(mtiles - 1, std::true_type{});
@@ -551,6 +583,12 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
 }  // namespace samble
 
 using namespace samble;
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_ka_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_ka_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
 
 extern "C" size_t samble_bwd_tri_dsmap_bytes(int B, int N, int M) {
   return (size_t)B * M * (32 * ((N + 8 + 31) / 32)) * sizeof(float);

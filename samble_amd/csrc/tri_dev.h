@@ -101,6 +101,24 @@ __device__ __forceinline__ Tri tri_split8(const float (&x)[8]) {
 // issues its six MFMAs.  For kernels that run ONE wave per SIMD: nothing else hides the LDS latency
 // between a ds_read and the MFMA that consumes it, and left to itself the compiler places each read
 // right in front of its use (62 s_waitcnt per 144 MFMAs in the first build of the dK/dV kernel).
+// Same with the operand requested THREE steps ahead (+12 registers): for kernels whose two waves per SIMD hit the
+// LDS together (stamped in bwd_kacc_tri: 45 cycles per MFMA with both waves in their product phase)
+template <int NSTEP, class Fetch, class Use>
+__device__ __forceinline__ void tri_pipelined3(Fetch fetch, Use use) {
+  Tri a0 = fetch(0), a1 = fetch(NSTEP > 1 ? 1 : 0), a2 = fetch(NSTEP > 2 ? 2 : 0);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    Tri a3 = a2;
+    if (i + 3 < NSTEP) a3 = fetch(i + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    use(i, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = a1;
+    a1 = a2;
+    a2 = a3;
+  }
+}
+
 template <int NSTEP, class Fetch, class Use>
 __device__ __forceinline__ void tri_pipelined(Fetch fetch, Use use) {
   Tri a0 = fetch(0), a1 = fetch(NSTEP > 1 ? 1 : 0);

@@ -13,7 +13,8 @@ mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(dev)
 x = torch.from_numpy(synth.features(B, C, N, 2001)).to(dev).requires_grad_(True)
 noise = torch.from_numpy(synth.exp1((B * NB, N), 2002)).to(dev)
 for _ in range(3):
-    mod(x, noise=noise)
+    (x_ds, idx), _ = mod(x, noise=noise)
+    x_ds.sum().backward()
 torch.cuda.synchronize()
 lib = L.load()
 buf = (ctypes.c_ulonglong * 128)()
@@ -36,3 +37,15 @@ for wave in range(8):
     for it in range(2):
         s = v[(wave * 2 + it) * 8:(wave * 2 + it) * 8 + 6]
         print(f"wave {wave} tile {20 + it}: " + " ".join(f"{names[i]}:{s[i] - s[i - 1]}" for i in range(1, 6)) + f"  | total {s[5] - s[0]}")
+
+if hasattr(lib, "samble_scratch_ka_stamps"):
+    buf = (ctypes.c_ulonglong * 128)()
+    lib.samble_scratch_ka_stamps.argtypes = [ctypes.c_void_p]
+    assert lib.samble_scratch_ka_stamps(buf) == 0
+    v = list(buf)
+    names = ["top", "dma issued", "map values", "products", "vmcnt wait", "barrier"]
+    print("bwd_kacc_tri (last launch = dK), tiles 10 and 11")
+    for wave in range(8):
+        for it in range(2):
+            s = v[(wave * 2 + it) * 8:(wave * 2 + it) * 8 + 6]
+            print(f"wave {wave} tile {10 + it}: " + " ".join(f"{names[i]}:{s[i] - s[i - 1]}" for i in range(1, 6)) + f"  | total {s[5] - s[0]}")
