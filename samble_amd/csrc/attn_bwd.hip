@@ -793,7 +793,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                                       void* img_ws, int variant, hipStream_t stream) {
   // variant (include/samble.h): single-pass path: 1 = the two-kernel backward (bwd_dq + bwd_dkdv, 7 products)
   // instead of the fused one (5); split-bf16 map path: 1 = fused dP / dV / dK kernel instead of the dS map,
-  // 2 = smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri) instead of the logit map
+  // 2 = smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri) instead of the logit map; 2 + 4 = the same
+  // on the un-woven dQ kernel (A/B)
   // k_tr_image / v_rm_image / img_ws != null (map path only): the split-bf16 kernels of attn_bwd_tri.hip
   // l2 != 0 (map path only): token logits are -|q-k|^2 and cs (B, N+nt) receives the column sums of dS
   // O (B,N,128) rows of the single-pass forward, or Oc (B,128,M) = x_ds of attn_rows; smap (B,N,ld) =
@@ -840,7 +841,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     float* dsmap = reinterpret_cast<float*>(Q_tr + img);  // (B, M, ld) after the three images
     const int rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M,
                                          scale, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr,
-                                         dsmap, variant & 1, variant & 2, stream);
+                                         dsmap, variant & 1, variant & 6, stream);
     if (rc) return rc;
   } else if (fused) {
     if (smap) {

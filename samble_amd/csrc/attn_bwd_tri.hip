@@ -230,6 +230,193 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dQ from the P map, woven (the structure of attn_rows_rc_tri_kernel, attn_tri.hip): this kernel runs one wave per
+// SIMD, so an iteration issues three INDEPENDENT streams k-step by k-step --
+//     dP^T of tile t+1 (48 MFMAs)  |  dQ^T += K^T dS^T of tile t-1 (48 MFMAs)  |  dS of tile t = P (dP - delta) scale
+//     and its three-plane split (vector work), + the dS tile of t-1 on its way to the dS map
+// instead of running dP -> dS -> dQ of one tile back to back behind a drained queue.  V row tiles, K transposed
+// tiles and the waves' P blocks through 2-deep LDS rings (everything staged in iteration t is waited for at its
+// end: the 16 pieces go out in the first k-steps), every wait counted.  Same products in the same order as
+// bwd_dq_tri_kernel<.., true>: bit-identical dQ and dS map.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDqpLds = 4 * kTriTile + 2 * 4 * 4096 + 4 * 4096;  // V ring, K ring, P slots, transpose tiles: 144 KB
+
+__global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int NW = 4;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int M = a.M;
+  const int m0 = chunk * (32 * NW) + wave * 32;
+  const int mrow = m0 + lo;
+  const bool mvalid = mrow < M;
+  const int mc = mvalid ? mrow : M - 1;
+  const long row = a.idx[(long)b * M + mc];
+  const float my_delta = a.delta[(long)b * M + mc];
+  const float scale = a.scale;
+  const int ntiles = (a.NK + kTile - 1) / kTile, mtiles = (M + kTile - 1) / kTile;
+  const char* Vb = a.V_rm + (long)b * ntiles * kTriTile;
+  const char* Kb = a.K_tr + (long)b * ntiles * kTriTile;
+  char* vring = smem_c;
+  char* kring = smem_c + 2 * kTriTile;
+  char* pslots = smem_c + 4 * kTriTile + wave * 4096;  // + (t & 1) * 16384
+  char* xt = smem_c + 4 * kTriTile + 2 * 16384 + wave * 4096;
+  // the wave's 32 x 32 block of the P map as whole 128-byte lines: piece k = rows 8k .. 8k+7, lane (r8 = lane >> 3,
+  // c = lane & 7) fetches 16-byte block c ^ r8 of its row (swizzle on the source)
+  const float* prow8[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = min(m0 + 8 * k + (lane >> 3), M - 1);
+    prow8[k] = a.smap + ((long)b * M + r) * a.ld + 4 * ((lane & 7) ^ (lane >> 3));
+  }
+  auto stage_tile = [&](const char* img, char* ring, int t) {  // 6 pieces per thread
+    const char* src = img + (long)min(t, ntiles - 1) * kTriTile;
+    char* dst = ring + (t & 1) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) glds16(src + (tid + 256 * k) * 16, dst + (wave * 64 + 256 * k) * 16);
+  };
+  auto stage_p = [&](int t) {  // 4 pieces per thread
+    const int tt = min(t, ntiles - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) glds16(prow8[k] + tt * kTile, pslots + (t & 1) * 16384 + k * 1024);
+  };
+  stage_tile(Vb, vring, 0);
+  stage_tile(Vb, vring, 1);
+  stage_p(0);
+  u32x4 go[24];
+  load_rm_row(a.dO_rm, mtiles, b, mc, h, go);
+  f32x16 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  f32x16 dp_cur = mma_rm_x_regs(vring, lo, h, go), dp_nxt;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V slot 0 is restaged by iteration 0
+  Tri bp[2];  // dS^T fragments of the tile whose dQ product is due (tile t-1): none yet
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) bp[ks] = Tri{u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+  float dsprev[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dsprev[r] = 0.f;
+
+  // iteration t = 0 .. ntiles: dP of tile t+1, dS of tile t, dQ product and dS-map rows of tile t-1
+  auto step = [&](int t, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+    // operand reads first
+    const u32x4* lp = reinterpret_cast<const u32x4*>(vring + ((t + 1) & 1) * kTriTile + tri_rm_off(lo, h, 0));
+    // t = 0: no dS yet (zeros): any finite tile will do, K tile 0 is only arriving -- V tile 1's slot holds finite data
+    const char* kt = (t == 0) ? vring + kTriTile : kring + ((t - 1) & 1) * kTriTile;
+    auto fetch_v = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
+    auto fetch_k = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+      const char* ap = kt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                 *reinterpret_cast<const u32x4*>(ap + 4096)};
+    };
+    Tri v0 = fetch_v(0), v1 = fetch_v(1), k0 = fetch_k(0), k1 = fetch_k(1);
+    f32x4 p4[4];  // this lane's 16 P values of tile t (row lo, columns 8g + 4h .. + 3)
+    {
+      const char* sw = pslots + (t & 1) * 16384;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        p4[g] = *reinterpret_cast<const f32x4*>(sw + (lo >> 3) * 1024 + (lo & 7) * 128 + (((2 * g + h) ^ (lo & 7)) << 4));
+    }
+    float* dsout = a.dsmap + (long)b * M * a.ld + max(t - 1, 0) * kTile + 4 * (lane & 7);
+    f32x4 po[4];
+    Tri bn[2];
+    float ds[16];
+    dp_nxt = zero16();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Tri v2 = v1, k2 = k1;
+      if (i + 2 < 8) {
+        v2 = fetch_v(i + 2);
+        k2 = fetch_k(i + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LAST) {
+        const Tri bq = {go[3 * i], go[3 * i + 1], go[3 * i + 2]};
+        dp_nxt = mfma_tri(v0, bq, dp_nxt);
+      }
+      oacc[i & 3] = mfma_tri(k0, bp[i >> 2], oacc[i & 3]);
+      {  // slice i of the vector work on tile t: elements 2 i, 2 i + 1
+#pragma clang fp contract(off)  // dS is what the map holds: the split must start from the ROUNDED product, not fuse into it
+        const int r0 = 2 * i, r1 = 2 * i + 1;
+        float x0 = dp_cur[r0], x1 = dp_cur[r1];
+        asm volatile("" : "+v"(x0), "+v"(x1));  // pins the slice inside this k-step's scheduling region
+        // columns past N + nt hold P = 0
+        ds[r0] = LAST ? 0.f : p4[r0 >> 2][r0 & 3] * (x0 - my_delta) * scale;
+        ds[r1] = LAST ? 0.f : p4[r1 >> 2][r1 & 3] * (x1 - my_delta) * scale;
+        unsigned hh, mm, ll;
+        tri_split2(ds[r0], ds[r1], hh, mm, ll);
+        asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));
+        bn[i >> 2].h[i & 3] = hh;
+        bn[i >> 2].m[i & 3] = mm;
+        bn[i >> 2].l[i & 3] = ll;
+      }
+      if (!LAST) {  // this iteration's 16 DMA pieces in the first k-steps: they are waited for at its end
+        if (i == 0) stage_tile(Vb, vring, t + 2);   // slot of V tile t: read in iteration t-1
+        if (i == 1) stage_tile(Kb, kring, t);       // slot of K tile t-2: read in iteration t-1
+        if (i == 2) stage_p(t + 1);                 // slot of P block t-1: read at the top of iteration t-1
+      }
+      // the previous tile's dS -> map rows as full 128-byte lines through the wave's own 4 KB of LDS (XOR-swizzled
+      // 16-byte blocks; LDS operations of a wave execute in order).  Iteration 0 writes zeros over tile 0's place.
+      if (i == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = {dsprev[4 * g], dsprev[4 * g + 1], dsprev[4 * g + 2], dsprev[4 * g + 3]};
+          *reinterpret_cast<f32x4*>(xt + lo * 128 + (((2 * g + h) ^ (lo & 7)) << 4)) = o;
+        }
+      }
+      if (i == 3) {
+#pragma unroll
+        for (int k8 = 0; k8 < 4; ++k8) {
+          const int rr = (lane >> 3) + 8 * k8;
+          po[k8] = *reinterpret_cast<const f32x4*>(xt + rr * 128 + (((lane & 7) ^ (rr & 7)) << 4));
+        }
+      }
+      if (i >= 6) {
+#pragma unroll
+        for (int k8 = 2 * (i - 6); k8 < 2 * (i - 6) + 2; ++k8) {
+          const int mr = min(m0 + (lane >> 3) + 8 * k8, M - 1);  // rows past M-1 rewrite row M-1's values (same bytes)
+          *reinterpret_cast<f32x4*>(dsout + (long)mr * a.ld) = po[k8];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < (LAST ? 6 : 12); ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 4 : 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      v0 = v1;
+      v1 = v2;
+      k0 = k1;
+      k1 = k2;
+    }
+    // the 16 pieces of this iteration must have landed; younger than them: its 4 stores
+    if (!LAST) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    dp_cur = dp_nxt;
+    bp[0] = bn[0];
+    bp[1] = bn[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dsprev[r] = ds[r];
+  };
+  for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
+  step(ntiles, std::true_type{});
+  if (mvalid) {
+    float* orow = a.dQ + (long)b * a.dq_bs + row * a.dq_rs + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {oacc[dt][4 * g], oacc[dt][4 * g + 1], oacc[dt][4 * g + 2], oacc[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dK, dV (and the column sums of dS): one workgroup = 4 waves = 128 point keys; tiles of 32 sampled rows
 // (dO RM, dO TR, Q TR images, 72 KB) double-buffered, their lse / delta / row ids in three small slots
 // ------------------------------------------------------------------------------------------------
@@ -609,6 +796,9 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
       if (e != hipSuccess) return (int)e;
     }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_pm_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kDqpLds);
+    if (e != hipSuccess) return (int)e;
     for (const void* f : {reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<false>), reinterpret_cast<const void*>(bwd_dkdv_tri_kernel<true>)}) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
       if (e != hipSuccess) return (int)e;
@@ -625,7 +815,8 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
                      scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
   {
     Timed timed(kT_bwd_dq, stream);
-    if (pmap) hipLaunchKernelGGL((bwd_dq_tri_kernel<0, true>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+    if (pmap && (pmap & 4)) hipLaunchKernelGGL((bwd_dq_tri_kernel<0, true>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
+    else if (pmap) hipLaunchKernelGGL(bwd_dq_pm_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kDqpLds, stream, dq);
     else hipLaunchKernelGGL((bwd_dq_tri_kernel<0, false>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
   }
   if (use_map) {
