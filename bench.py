@@ -359,7 +359,8 @@ def main():
             if tri:
                 # backward: dQ kernel = dP + dQ (2 products over N + nt keys), then dV and dK (1 product each, N keys)
                 if kt.get("bwd_dq"):
-                    mf.append(roof("bwd_dq_tri_kernel", 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::bwd_dq_tri_kernel"))
+                    nm = "bwd_dq_pm_tri_kernel" if map_free else "bwd_dq_tri_kernel"
+                    mf.append(roof(nm, 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::" + nm))
                 if kt.get("bwd_dv"):
                     mf.append(roof("bwd_kacc_tri_kernel (dV)", 2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
                                    "samble::bwd_kacc_tri_kernel<1, false>" if map_free else
@@ -371,10 +372,11 @@ def main():
                 mf.append(roof("knn_stream_kernel", fl["dist"] * B_PER_GPU, kt["knn"][0], "samble::knn_stream_kernel"))
             pj = 2 * C * C * 3 * N * B_PER_GPU
             for n_, name, flops in (("proj_fwd", "proj_fwd" + sfx, pj), ("proj_dx", "proj_dx" + sfx, pj),
-                                    ("proj_dw", "proj_dw_kernel (+ reduce; fp32 MFMA)", pj)):
+                                    ("proj_dw", ("proj_dw_tri_kernel (+ reduce and token gradients)" if tri else
+                                                 "proj_dw_kernel (+ reduce; fp32 MFMA)"), pj)):
                 if kt.get(n_):
                     r_ = roof(name, flops, kt[n_][0], "samble::" + name.split(" ")[0])
-                    if n_ == "proj_dw":
+                    if n_ == "proj_dw" and not tri:
                         r_["peak"], r_["frac"] = PEAK_FP32_MFMA_TFLOPS, round(r_["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
                         r_.pop("peak_note", None)
                     mf.append(r_)
