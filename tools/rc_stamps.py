@@ -49,3 +49,14 @@ if hasattr(lib, "samble_scratch_ka_stamps"):
         for it in range(2):
             s = v[(wave * 2 + it) * 8:(wave * 2 + it) * 8 + 6]
             print(f"wave {wave} tile {10 + it}: " + " ".join(f"{names[i]}:{s[i] - s[i - 1]}" for i in range(1, 6)) + f"  | total {s[5] - s[0]}")
+
+if hasattr(lib, "samble_scratch_pc_stamps"):
+    buf = (ctypes.c_ulonglong * 128)()
+    lib.samble_scratch_pc_stamps.argtypes = [ctypes.c_void_p]
+    assert lib.samble_scratch_pc_stamps(buf) == 0
+    v = list(buf)
+    print("attn_rows_pc_tri: S waves 0-3 (P work | logit products | lgkm | barrier), O waves 4-7 (P V products | DMA issue | vmcnt | barrier)")
+    for wave in range(8):
+        for it in range(2):
+            s = v[(wave * 2 + it) * 8:(wave * 2 + it) * 8 + 5]
+            print(f"wave {wave} tile {20 + it}: " + " ".join(str(s[i] - s[i - 1]) for i in range(1, 5)) + f"  | total {s[4] - s[0]}")
