@@ -794,7 +794,9 @@ def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
 
 
 @pytest.mark.parametrize("B,N,nt,M,K", [(2, 256, 6, 128, 32), (3, 1000, 4, 333, 16), (32, 2048, 6, 1024, 32),
-                                         (1, 77, 1, 40, 16), (4, 4096, 6, 2048, 32), (1, 8500, 6, 700, 32)])
+                                         (1, 77, 1, 40, 16), (4, 4096, 6, 2048, 32), (1, 8500, 6, 700, 32),
+                                         (2, 33, 8, 7, 16), (5, 513, 3, 100, 32), (1, 2047, 6, 1023, 32),
+                                         (7, 96, 0, 96, 16)])
 def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
     """The forward that never builds the N x (N+nt) logit map (attn_stats_nl_tri + attn_rows_rc_tri, csrc/attn_tri.hip)
     against the two-pass map kernels it replaces: lse, token logits, the K neighbour logits of every row, every score
