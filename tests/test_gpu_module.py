@@ -338,3 +338,33 @@ def test_map_free_long_cloud_takes_the_compact_score_route():
         ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
     for j, (t1, t2) in enumerate(zip(*outs)):
         assert torch.equal(t1, t2), j
+
+
+def test_map_free_without_the_fused_chain():
+    """B = 130 clouds: more workgroups than the fused select chain takes (one per cloud, B <= 128), so the map-free
+    forward hands its in-pass score statistics to the stand-alone finalize / quantile / bin kernels -- same outputs as
+    the logit-map pipeline."""
+    import samble_amd.downsample as D
+    from samble_amd import ops, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 130, 128, 96, 40, 6
+    assert not ops.chain_supported(B, N, nb)
+    x = torch.from_numpy(synth.features(B, C, N, 41)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 42)).to(DEV)
+    outs = []
+    old_mode, old_free = ops.MATRIX_MODE, D.MAP_FREE
+    try:
+        ops.MATRIX_MODE = "tri"
+        for free in (False, True):
+            D.MAP_FREE = free
+            torch.manual_seed(5)
+            mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+            xin = x.clone().requires_grad_(True)
+            (x_ds, idx), _ = mod(xin, noise=noise)
+            x_ds.sum().backward()
+            outs.append((x_ds.detach(), idx, mod.attention_point_score, mod.bin_boundaries[0].clone(), xin.grad,
+                         mod.k_conv.weight.grad))
+    finally:
+        ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
+    for j, (t1, t2) in enumerate(zip(*outs)):
+        assert torch.equal(t1, t2), j
