@@ -326,6 +326,14 @@ int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, i
 
 int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, int N, int nt, int D, void* q_image,
                              void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, void* stream);
+/* samble_proj_fwd_tri_f32 and samble_tri_split_qkv_f32 in one: the projection kernel writes the operand images of
+ * every full 32-point tile from its accumulators (the fp32 rows are not read back), a split launch over the remaining
+ * tiles (token rows, ragged end) completes them.  Same bytes in qkv and in all images as the two separate calls.
+ * k_tr_image / v_rm_image: both or neither.  Workspace: samble_proj_fwd_tri_workspace_bytes(). */
+int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
+                                  const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image, void* k_image,
+                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, void* ws, size_t ws_bytes,
+                                  void* stream);
 size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D);
 int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                                  const float* V, int64_t v_bs, int64_t v_rs, const void* k_tr_image,

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void tri_split_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void tri_split_qkv_kernel(const float* __restrict__ qkv, long bs, long rs, int N,
                                                             int NK, char* __restrict__ qimg, char* __restrict__ kimg,
                                                             char* __restrict__ vimg, char* __restrict__ ktr,
-                                                            char* __restrict__ vrm) {
-  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+                                                            char* __restrict__ vrm, int tile0) {
+  const int tile = tile0 + blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int qtiles = (N + 31) / 32, ntiles = (NK + 31) / 32;
   const float* sb = qkv + (long)b * bs;
   for (int e = tid; e < 1536; e += 256) {  // RM chunks of Q (e < 512), K and (for the backward) V
@@ -1144,7 +1144,17 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
                                            void* vimg, void* ktr, void* vrm, hipStream_t stream) {
   Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
-                     (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm);
+                     (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm, 0);
+  return (int)hipGetLastError();
+}
+
+// the same for the tiles tile0 .. only (the projection kernel writes the images of the full point tiles itself)
+extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long rs, int B, int N, int nt, int tile0, void* qimg,
+                                                 void* kimg, void* vimg, void* ktr, void* vrm, hipStream_t stream) {
+  const int ntiles = (N + nt + 31) / 32;
+  if (tile0 >= ntiles) return 0;
+  hipLaunchKernelGGL(tri_split_qkv_kernel, dim3(ntiles - tile0, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
+                     (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm, tile0);
   return (int)hipGetLastError();
 }
 

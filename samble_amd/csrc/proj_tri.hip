@@ -22,10 +22,26 @@ __device__ __forceinline__ void pglds16(const void* g, void* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The operand images of the attention passes (row images of Q, K and -- for the backward -- V; transposed images of V
+// and -- for the backward -- K; layouts: tri_dev.h), written by the projection itself for every FULL tile of 32 points
+// (the tiles that hold token rows or the ragged end of the cloud go through tri_split_qkv): the split pass then
+// reads back only those, not the 101 MB of fp32 rows that were just written.
+struct ProjImages {
+  char* q_rm;   // null: no images at all
+  char* k_rm;
+  char* v_tr;
+  char* k_tr;   // null: no backward images
+  char* v_rm;
+  int ktiles;   // tiles per cloud of the K / V images (rows N + nt); the Q image has ceil(N / 32)
+};
+constexpr int kPXt = 36;  // row stride (floats) of a wave's 32 x 32 transpose tile
+
+template <bool IMG>
 __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int N,
                                                               const float* __restrict__ tokqkv, int nt,
                                                               const char* __restrict__ Wimg,  // row image of W (384 rows)
-                                                              float* __restrict__ qkv, long o_bs, long o_rs) {
+                                                              float* __restrict__ qkv, long o_bs, long o_rs,
+                                                              const ProjImages im) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kPDepth;
   const int tid = threadIdx.x;
@@ -57,10 +73,16 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
     xq[3 * ks + 2] = t3.l;
   }
   float* orow = qkv + (long)b * o_bs + (long)n * o_rs + 4 * h;
+  // images: this wave's 32 points are one image tile when all of them exist (wave-uniform)
+  const int n0 = chunk * 256 + wave * 32;
+  const bool full = IMG && n0 + 31 < N;
+  const int ptile = n0 >> 5, qtiles = (N + 31) >> 5;
+  float* xt = reinterpret_cast<float*>(smem_c + D * kTriTile) + wave * (32 * kPXt);  // [output of the tile][point]
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // iteration t: tile t+3 into the slot of tile t-1, product of tile t, its 4 row stores; VM operations
-  // younger than tile t+1's DMA at the end of the iteration: stores(t-2) 4 + 2 x (3 + 4) = 18
+  // younger than tile t+1's DMA at the end of the iteration: stores(t-2) 4 + 2 x (3 + 4) = 18 (image stores only
+  // add to that: counting low is the safe side)
   for (int t = 0; t < kPTiles; ++t) {
     stage(t + D - 1);
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
@@ -75,6 +97,54 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
     for (int g = 0; g < 4; ++g) {
       const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
+    }
+    if (full) {
+      const int which = t >> 2, tc = t & 3;  // 0 Q, 1 K, 2 V; channels 32 tc .. 32 tc + 31 of it
+      char* rm = which == 0 ? im.q_rm + ((long)b * qtiles + ptile) * kTriTile
+                            : (which == 1 ? im.k_rm : im.v_rm) + ((long)b * im.ktiles + ptile) * kTriTile;
+      char* tr = (which == 1 ? im.k_tr : im.v_tr) + ((long)b * im.ktiles + ptile) * kTriTile;
+      if (which == 0 || which == 1 || im.v_rm) {
+        // row image: a chunk = 8 consecutive channels of one point.  Lane (point, h) holds channels 8 g + 4 h .. + 3 of
+        // the groups g = 0..3; one v_permlane32_swap per register pair hands lane h = 0 the whole groups 0 and 1 and
+        // lane h = 1 the whole groups 2 and 3
+        float c8[2][8];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {  // groups (pr, pr + 2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[4 * pr + e]), __float_as_uint(acc[4 * (pr + 2) + e]),
+                                                             false, false);
+            // r2[0] = {h0's group pr, h0's group pr+2}, r2[1] = {h1's group pr, h1's group pr+2} (lower | upper half)
+            c8[pr][e] = __uint_as_float(r2[0]);      // channels 0..3 of this lane's group (own for h = 0, partner's for h = 1)
+            c8[pr][4 + e] = __uint_as_float(r2[1]);  // channels 4..7
+          }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int g = 4 * tc + pr + 2 * h;  // 8-channel group inside the 128 channels
+          const Tri t3 = tri_split8(c8[pr]);
+          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 0)) = t3.h;
+          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 1)) = t3.m;
+          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 2)) = t3.l;
+        }
+      }
+      if (which == 2 || (which == 1 && im.k_tr)) {
+        // transposed image: a chunk = 8 POINTS of one channel: through the wave's LDS tile (wave-private, in-order LDS)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xt[crow(r, h) * kPXt + lo] = acc[r];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = lane + 64 * u, c = e & 31, cg = e >> 5, s2 = cg >> 1, hh = cg & 1;
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(xt + c * kPXt + 16 * s2 + 4 * hh);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(xt + c * kPXt + 16 * s2 + 8 + 4 * hh);
+          const float v8[8] = {a4[0], a4[1], a4[2], a4[3], b4[0], b4[1], b4[2], b4[3]};
+          const Tri t3 = tri_split8(v8);
+          const int d = 32 * tc + c;
+          *reinterpret_cast<u32x4*>(tr + tri_tr_off(d, cg, 0)) = t3.h;
+          *reinterpret_cast<u32x4*>(tr + tri_tr_off(d, cg, 1)) = t3.m;
+          *reinterpret_cast<u32x4*>(tr + tri_tr_off(d, cg, 2)) = t3.l;
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
@@ -262,11 +332,21 @@ extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B
 // image bytes of W (384 x 128), either kind
 extern "C" size_t samble_proj_tri_image_bytes() { return (size_t)kPTiles * kTriTile; }
 
+extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long rs, int B, int N, int nt, int tile0, void* qimg,
+                                                 void* kimg, void* vimg, void* ktr, void* vrm, hipStream_t stream);
+
+// images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
+// 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
 extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokqkv, int nt,
-                                          const float* W, void* wimg, float* qkv, long o_bs, long o_rs, hipStream_t s) {
+                                          const float* W, void* wimg, float* qkv, long o_bs, long o_rs, void* q_rm,
+                                          void* k_rm, void* v_tr, void* k_tr, void* v_rm, hipStream_t s) {
+  const int lds_img = kProjTriLds + 8 * 32 * kPXt * 4;
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_img);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kProjTriLds);
@@ -274,9 +354,20 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
   }
   int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, wimg, nullptr, s);
   if (rc) return rc;
-  Timed timed(kT_proj_fwd, s);
-  hipLaunchKernelGGL(proj_fwd_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, x, x_bs, N, tokqkv, nt,
-                     (const char*)wimg, qkv, o_bs, o_rs);
+  const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32};
+  {
+    Timed timed(kT_proj_fwd, s);
+    if (q_rm)
+      hipLaunchKernelGGL(proj_fwd_tri_kernel<true>, dim3((N + 255) / 256, B), dim3(512), lds_img, s, x, x_bs, N, tokqkv, nt,
+                         (const char*)wimg, qkv, o_bs, o_rs, im);
+    else
+      hipLaunchKernelGGL(proj_fwd_tri_kernel<false>, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, x, x_bs, N, tokqkv,
+                         nt, (const char*)wimg, qkv, o_bs, o_rs, im);
+  }
+  if (q_rm) {  // the tiles the kernel did not cover: from the first one that is not 32 whole points
+    rc = samble_launch_tri_split_qkv_tiles(qkv, o_bs, o_rs, B, N, nt, N / 32, q_rm, k_rm, v_tr, k_tr, v_rm, s);
+    if (rc) return rc;
+  }
   return (int)hipGetLastError();
 }
 

@@ -38,25 +38,34 @@ class _Projection(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, tokens, wq, wk, wv):
+    def forward(ctx, x, tokens, wq, wk, wv, images=""):
+        """images "fwd" / "fwd+bwd": also returns the split-bf16 operand images of [Q|K|V] (non-differentiable byte
+        tensors), written by the projection kernel itself instead of a split pass over the fp32 rows."""
         w = torch.cat((wq, wk, wv), dim=0).squeeze(-1)  # (3C, C)
         tok = tokens[0]                                  # (C, nt)
         ctx.save_for_backward(x, tok, w)
         ctx.splits = (wq.shape[0], wk.shape[0], wv.shape[0])
-        return ops.stage_proj_fwd(x, tok, w)
+        if not images:
+            return ops.stage_proj_fwd(x, tok, w)
+        qkv, imgs = ops.stage_proj_fwd(x, tok, w, images=images)
+        ctx.mark_non_differentiable(*imgs)
+        ctx.set_materialize_grads(False)  # (else autograd zero-fills a 50 MB "gradient" per image on the way back)
+        return (qkv,) + tuple(imgs)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, dqkv):
+    def backward(ctx, dqkv, *_):
+        if dqkv is None:
+            return None, None, None, None, None, None
         x, tok, w = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:])
         dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw)
         if not need_dw:
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         a, b, c = ctx.splits
         dtokens = dtok.unsqueeze(0) if ctx.needs_input_grad[1] else None
-        return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1))
+        return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1), None)
 
 
 # Two-pass forward with the logit map kept in HBM (csrc/attn_map.hip) for the sparse_* score modes;
@@ -74,7 +83,7 @@ class _SamplerCore(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, qkv, x, mod, noise):
+    def forward(ctx, qkv, x, mod, noise, images=None):
         B, C, N = x.shape
         D = mod.q_depth
         nt = qkv.shape[1] - N
@@ -102,7 +111,8 @@ class _SamplerCore(torch.autograd.Function):
             nn_idx = ops.stage_knn(x, x, mod.K)
             if MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and mod.asm == "dot" and mod.K in (16, 32):
                 need_bwd = ctx.needs_input_grad[0]
-                imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
+                imgs = images if images is not None and (len(images) == 5 or not need_bwd) else \
+                    ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
                 nn_sorted, masks = ops.stage_nn_prepare(nn_idx)
                 chain = ops.chain_supported(B, N, nb)
                 # the pass also accumulates the score statistics of the K neighbour entries of every row
@@ -211,7 +221,7 @@ class _SamplerCore(torch.autograd.Function):
             else:
                 dqkv[:, :N, 0:D] += scale * torch.matmul(g_tok, k[:, N:, :])
                 dqkv[:, N:, D:2 * D] += scale * torch.matmul(g_tok.transpose(1, 2), q)
-        return dqkv, None, None, None
+        return dqkv, None, None, None, None
 
 
 class DownSampleToken(nn.Module):
@@ -298,10 +308,19 @@ class DownSampleToken(nn.Module):
         if C != 128 or self.q_depth != 128 or self.k_depth != 128 or self.v_depth != 128:
             raise NotImplementedError("the HIP kernels are built for C = q_out = k_out = v_out = 128 (shipped configs)")
         # (B, N+nt, 3D) point-major rows [Q|K|V]; rows N.. are the bin tokens
-        qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
+        # the map-free forward takes its operand images straight from the projection kernel (no split pass over qkv)
+        fused_images = (MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and self.asm == "dot" and self.K in (16, 32)
+                        and self.idx_mode not in ("col_sum", "row_std"))
+        if fused_images:
+            need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+            qkv, *images = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight,
+                                             self.v_conv.weight, "fwd+bwd" if need_bwd else "fwd")
+        else:
+            images = None
+            qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
 
         (x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx) = _SamplerCore.apply(
-            qkv, x.detach(), self, noise)
+            qkv, x.detach(), self, noise, tuple(images) if images is not None else None)
 
         index_down = idx.unsqueeze(1)
         if self.res is True:

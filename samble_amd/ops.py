@@ -69,12 +69,29 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     return (idx, dist) if want_dist else idx
 
 
-def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor) -> torch.Tensor:
-    """x (B,C,N), tokens (C,nt), w_qkv (3C,C) -> qkv (B,N+nt,3C) point-major rows [Q|K|V]."""
+def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, images: str = ""):
+    """x (B,C,N), tokens (C,nt), w_qkv (3C,C) -> qkv (B,N+nt,3C) point-major rows [Q|K|V].
+    images "fwd" / "fwd+bwd" (MATRIX_MODE "tri"): -> (qkv, operand images as stage_tri_split_qkv returns them), written by
+    the projection kernel itself (the split pass then covers only the tiles with token rows / a ragged end)."""
     _need_gpu(x, tokens, w_qkv)
     x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
     B, C, N = x.shape
     nt = tokens.shape[1]
+    if images:
+        if MATRIX_MODE != "tri" or images not in ("fwd", "fwd+bwd"):
+            raise ValueError("operand images come with MATRIX_MODE 'tri' only: images in ('fwd', 'fwd+bwd')")
+        with torch.cuda.device(x.device):
+            qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)
+            img = lambda rows, tr: torch.empty(_lib.query("samble_tri_image_bytes", B, rows, tr), dtype=torch.uint8,
+                                               device=x.device)
+            q_img, k_img, v_img = img(N, 0), img(N + nt, 0), img(N + nt, 1)
+            k_tr, v_rm = (img(N + nt, 1), img(N + nt, 0)) if images == "fwd+bwd" else (None, None)
+            nbytes = _lib.query("samble_proj_fwd_tri_workspace_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _lib.call("samble_proj_fwd_split_tri_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
+                      qkv.data_ptr(), qkv.stride(0), qkv.stride(1), q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(),
+                      _p(k_tr), _p(v_rm), ws.data_ptr(), nbytes, _stream())
+        return qkv, ((q_img, k_img, v_img, k_tr, v_rm) if images == "fwd+bwd" else (q_img, k_img, v_img))
     with torch.cuda.device(x.device):
         qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)
         tri = MATRIX_MODE == "tri"

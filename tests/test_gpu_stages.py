@@ -867,3 +867,28 @@ def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
         assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     finally:
         o_.MATRIX_MODE = old
+
+
+@pytest.mark.parametrize("B,N,nt", [(2, 256, 6), (3, 1000, 4), (1, 77, 1), (32, 2048, 6), (2, 96, 0), (1, 20, 8)])
+def test_projection_writes_the_operand_images_itself(B, N, nt):
+    """samble_proj_fwd_split_tri_f32 (images of the full point tiles from the projection kernel's accumulators + a split
+    launch over the tiles with token rows / a ragged end) against projection + tri_split_qkv: the same bytes in qkv and
+    in all five images."""
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    o_.MATRIX_MODE = "tri"
+    try:
+        x = torch.from_numpy(synth.normal((B, 128, N), 900 + N)).to(DEV)
+        tokens = torch.from_numpy(synth.normal((128, max(nt, 1)), 901))[:, :nt].contiguous().to(DEV)
+        w = (torch.from_numpy(synth.normal((384, 128), 902)) * 0.1).to(DEV)
+        qkv = o_.stage_proj_fwd(x, tokens, w)
+        imgs = o_.stage_tri_split_qkv(qkv, N, for_backward=True)
+        for want in ("fwd+bwd", "fwd"):
+            qkv2, imgs2 = o_.stage_proj_fwd(x, tokens, w, images=want)
+            torch.cuda.synchronize()
+            assert torch.equal(qkv2, qkv)
+            assert len(imgs2) == (5 if want == "fwd+bwd" else 3)
+            for j, (a, b2) in enumerate(zip(imgs, imgs2)):
+                assert torch.equal(a, b2), (want, "image", j, int((a != b2).sum()))
+    finally:
+        o_.MATRIX_MODE = old
