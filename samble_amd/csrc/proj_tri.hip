@@ -23,9 +23,9 @@ __device__ __forceinline__ void pglds16(const void* g, void* l) {
 }
 
 // The operand images of the attention passes (row images of Q, K and -- for the backward -- V; transposed images of V
-// and -- for the backward -- K; layouts: tri_dev.h), written by the projection itself for every FULL tile of 32 points
-// (the tiles that hold token rows or the ragged end of the cloud go through tri_split_qkv): the split pass then
-// reads back only those, not the 101 MB of fp32 rows that were just written.
+// and -- for the backward -- K; layouts: tri_dev.h), written by the projection itself: every FULL tile of 32 points from
+// the accumulators, the token rows' own tile (N a multiple of 32) by the workgroup that copies them; only a ragged
+// last point tile goes through tri_split_qkv.  Nothing reads the 101 MB of fp32 rows back.
 struct ProjImages {
   char* q_rm;   // null: no images at all
   char* k_rm;
@@ -60,6 +60,37 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
   for (int t = 0; t < D - 1; ++t) stage(t);
   if (chunk == 0) {  // this cloud's copy of the token rows
     for (int e = tid; e < nt * kPO; e += 512) qkv[(long)b * o_bs + (long)(N + e / kPO) * o_rs + (e % kPO)] = tokqkv[e];
+    if (IMG && nt > 0 && (N & 31) == 0) {
+      // ... and, when the token rows have an image tile of their own, that tile of the K / V images (rows nt.. zero)
+      const long toff = ((long)b * im.ktiles + (N >> 5)) * kTriTile;
+      for (int e = tid; e < 1024; e += 512) {  // row-image chunks of K and (for the backward) V
+        const int which = 1 + (e >> 9), r = e & 31, g = (e >> 5) & 15;
+        if (which == 2 && !im.v_rm) continue;
+        float v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v8[i] = (r < nt) ? tokqkv[r * kPO + 128 * which + 8 * g + i] : 0.f;
+        const Tri t3 = tri_split8(v8);
+        char* img = (which == 1 ? im.k_rm : im.v_rm) + toff;
+        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t3.l;
+      }
+      for (int e = tid; e < 1024; e += 512) {  // transposed-image chunks of V and (for the backward) K
+        const int which = e >> 9, d = e & 127, cg = (e >> 7) & 3, s2 = cg >> 1, hh = cg & 1;
+        if (which == 1 && !im.k_tr) continue;
+        float v8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = 16 * s2 + 8 * (i >> 2) + 4 * hh + (i & 3);
+          v8[i] = (row < nt) ? tokqkv[row * kPO + (which ? 128 : 256) + d] : 0.f;
+        }
+        const Tri t3 = tri_split8(v8);
+        char* img = (which ? im.k_tr : im.v_tr) + toff;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = t3.l;
+      }
+    }
   }
   u32x4 xq[24];  // this point's channels as the B operand: k-step ks, half h <-> channels 16 ks + 8 h + e
 #pragma unroll
@@ -364,7 +395,7 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
       hipLaunchKernelGGL(proj_fwd_tri_kernel<false>, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, x, x_bs, N, tokqkv,
                          nt, (const char*)wimg, qkv, o_bs, o_rs, im);
   }
-  if (q_rm) {  // the tiles the kernel did not cover: from the first one that is not 32 whole points
+  if (q_rm && (N & 31)) {  // a ragged last point tile (+ the token rows behind it): the split kernel over those tiles
     rc = samble_launch_tri_split_qkv_tiles(qkv, o_bs, o_rs, B, N, nt, N / 32, q_rm, k_rm, v_tr, k_tr, v_rm, s);
     if (rc) return rc;
   }
