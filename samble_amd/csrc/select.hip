@@ -357,7 +357,16 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
     for (int i = tid; i < m; i += 1024) {
       const unsigned long long ci = comp[i];
       int rank = 0;
-      for (int j = 0; j < m2; j += 2) {
+      int j = 0;
+      // 16 composites per trip: the eight reads go out together (one LDS latency per trip, not per pair)
+      for (; j + 16 <= m2; j += 16) {
+        ulonglong2 c2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c2[u] = *reinterpret_cast<const ulonglong2*>(&comp[j + 2 * u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += ((c2[u].x < ci) ? 1 : 0) + ((c2[u].y < ci) ? 1 : 0);
+      }
+      for (; j < m2; j += 2) {
         const ulonglong2 c2 = *reinterpret_cast<const ulonglong2*>(&comp[j]);
         rank += (c2.x < ci) ? 1 : 0;
         rank += (c2.y < ci) ? 1 : 0;
