@@ -231,7 +231,11 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
     lower[tid] = lo_s[tid];
   }
   __shared__ int counts_s[1024 * kMaxBins / 8];  // B x nb <= 1024 ints (B <= 128 at nb = 8)
-  if (B <= 64) alloc_counts_wave(w, cap, B, nb, M, counts_s);  // one wave, lane = cloud, no barriers
+  if (B <= 64) {  // one wave, lane = cloud, no barriers; the shipped bin counts fully unrolled
+    if (nb == 6) alloc_counts_wave<6>(w, cap, B, nb, M, counts_s);
+    else if (nb == 4) alloc_counts_wave<4>(w, cap, B, nb, M, counts_s);
+    else alloc_counts_wave<0>(w, cap, B, nb, M, counts_s);
+  }
   else alloc_counts_lanes(w, cap, B, nb, M, counts_s);          // B <= 128: eight lanes per cloud
   __syncthreads();
   STAMP(24);

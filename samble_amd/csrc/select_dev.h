@@ -266,15 +266,35 @@ __device__ inline void alloc_counts_body(const float* w, const int* cap, int B, 
   for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
 }
 
-// The same allocation with EIGHT lanes per cloud (lane = 8 b + t owns bin t; B <= blockDim.x / 8): the serial
-// version is one long dependent chain per cloud (six IEEE divisions per round on one wave); here a round is one
-// division per lane and two 8-lane gathers.  Every sum is formed by short_row_sum on the gathered row, in every
-// lane alike: the same arithmetic in the same order, the same integers.  Every thread of the workgroup must call it.
 // B <= 64: ONE wave runs the serial allocation (lane = cloud) and the whole-batch exit is a wave vote -- no
 // workgroup barrier inside the rounds (each costs more than a round's arithmetic).  The other waves just return;
 // the caller synchronises afterwards.  Same arithmetic as alloc_counts_body.
-__device__ inline void alloc_counts_wave(const float* w, const int* cap, int B, int nb, int M, int* counts) {
+// NB: the bin count when it is known at compile time (every loop unrolls: no dynamic indexing of the per-bin
+// registers), 0 = take `nb` at run time.  Same operations in the same order either way.
+template <int NB>
+__device__ __forceinline__ float short_row_sum_t(const float (&a)[kMaxBins], int n_rt) {
+  const int n = NB ? NB : n_rt;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  const int q = n >> 2;
+#pragma unroll
+  for (int i = 0; i < kMaxBins / 4; ++i)
+    if (i < q) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) part[k] = __fadd_rn(part[k], a[4 * i + k]);
+    }
+#pragma unroll
+  for (int i = 0; i < kMaxBins; ++i)
+    if (i >= 4 * q && i < n) part[0] = __fadd_rn(part[0], a[i]);
+  float s = part[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) s = __fadd_rn(s, part[k]);
+  return s;
+}
+
+template <int NB>
+__device__ inline void alloc_counts_wave(const float* w, const int* cap, int B, int nb_rt, int M, int* counts) {
   if (threadIdx.x >= 64) return;
+  const int nb = NB ? NB : nb_rt;
   const int b = threadIdx.x;
   const bool live = b < B;
   float p[kMaxBins], chosen[kMaxBins], capf[kMaxBins];
@@ -287,11 +307,13 @@ __device__ inline void alloc_counts_wave(const float* w, const int* cap, int B, 
     p[t] = __fadd_rn(__fmul_rn(wt, capf[t]), 1e-10f);
     chosen[t] = 0.f;
   }
-  for (int round = 0; round < nb; ++round) {
-    const float s = short_row_sum(p, nb);
+#pragma unroll
+  for (int round = 0; round < kMaxBins; ++round) {
+    if (round >= nb) break;
+    const float s = short_row_sum_t<NB>(p, nb);
 #pragma unroll
     for (int t = 0; t < kMaxBins; ++t) p[t] = __fdiv_rn(p[t], s);
-    const float left = __fsub_rn((float)M, short_row_sum(chosen, nb));
+    const float left = __fsub_rn((float)M, short_row_sum_t<NB>(chosen, nb));
     const int done = (!live) || (left == 0.f);
     if (__all(done)) break;  // whole-batch early exit (utils/ops.py:409)
 #pragma unroll
@@ -311,16 +333,23 @@ __device__ inline void alloc_counts_wave(const float* w, const int* cap, int B, 
     k[t] = (t < nb) ? (int)chosen[t] : 0;
     total += k[t];
   }
-  for (int t = 0; t < nb; ++t) {
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t) {
     const long room = (long)capi[t] - k[t];
-    if (t == 0 || room > bestv) {
+    if (t < nb && (t == 0 || room > bestv)) {
       bestv = room;
       best = t;
     }
   }
-  for (int t = 0; t < nb; ++t) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
+#pragma unroll
+  for (int t = 0; t < kMaxBins; ++t)
+    if (t < nb) counts[b * nb + t] = k[t] + (t == best ? (M - total) : 0);
 }
 
+// The same allocation with EIGHT lanes per cloud (lane = 8 b + t owns bin t; B <= blockDim.x / 8): the serial
+// version is one long dependent chain per cloud (six IEEE divisions per round on one wave); here a round is one
+// division per lane and two 8-lane gathers.  Every sum is formed by short_row_sum on the gathered row, in every
+// lane alike: the same arithmetic in the same order, the same integers.  Every thread of the workgroup must call it.
 __device__ inline void alloc_counts_lanes(const float* w, const int* cap, int B, int nb, int M, int* counts) {
   const int tid = threadIdx.x, b = tid >> 3, t = tid & 7, lane = tid & 63, g0 = lane & ~7;
   const bool live = b < B;
