@@ -20,16 +20,20 @@
 // launcher's memset), lane 0 of each workgroup: release fence, atomic add, relaxed agent-scope poll with s_sleep,
 // acquire fence; __syncthreads on both sides.  All B <= 256 workgroups are resident (1024 threads, one per CU),
 // which the launchers check against the device's CU count.
-#include "select_dev.h"
-
 namespace samble {
-
 #ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch): s_memtime marks of workgroup 0, read back by the harness
 __device__ unsigned long long g_chain_stamps[64];
 #define STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_chain_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
+}  // namespace samble
+#define BA_STAMP(i) STAMP(i)
+#include "select_dev.h"
+
+namespace samble {
+
+
 
 constexpr float kUnfixC = 1.f / 17592186044416.f;  // 2^-44: the fixed-point scale of the score accumulators (score.hip)
 enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };

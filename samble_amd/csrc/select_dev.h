@@ -5,6 +5,10 @@
 #include "samble_dev.h"
 #pragma clang fp contract(off)
 
+#ifndef BA_STAMP
+#define BA_STAMP(i) do { } while (0)
+#endif
+
 namespace samble {
 
 constexpr int kMaxBins = 8;
@@ -139,6 +143,37 @@ __device__ inline void qsel_resolve(const unsigned int* ws, int nq, long n, int 
   __syncthreads();
 }
 
+// Sum over the 64 lanes of a wave, delivered in lane 63: quad swaps, half-row and row mirrors, then the row broadcasts
+// of gfx9 DPP (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3).  A fixed tree: run-to-run identical.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_sum_i32(int x) {
+  x += dpp_i32<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x += dpp_i32<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x += dpp_i32<0x141, 0xF>(x);  // row_half_mirror
+  x += dpp_i32<0x140, 0xF>(x);  // row_mirror
+  x += dpp_i32<0x142, 0xA>(x);  // row_bcast15 -> rows 1, 3
+  x += dpp_i32<0x143, 0xC>(x);  // row_bcast31 -> rows 2, 3
+  return x;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const long long u = __double_as_longlong(x);
+  const int lo = dpp_i32<CTRL, ROW_MASK>((int)u), hi = dpp_i32<CTRL, ROW_MASK>((int)(u >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);  // (rows masked off receive +0.0)
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {
+  x += dpp_f64<0xB1, 0xF>(x);
+  x += dpp_f64<0x4E, 0xF>(x);
+  x += dpp_f64<0x141, 0xF>(x);
+  x += dpp_f64<0x140, 0xF>(x);
+  x += dpp_f64<0x142, 0xA>(x);
+  x += dpp_f64<0x143, 0xC>(x);
+  return x;
+}
+
 // bin membership + weights of cloud b (reference utils/ops.py:454-463, models/downsample.py:264-284); the whole
 // 1024-thread workgroup takes part; rsum / rcnt: LDS scratch
 __device__ inline void bin_assign_body(int b, const float* __restrict__ z, const float* __restrict__ tok, int nt,
@@ -178,21 +213,23 @@ __device__ inline void bin_assign_body(int b, const float* __restrict__ z, const
     }
     member[(long)b * N + n] = (unsigned char)bits;
   }
+  BA_STAMP(30);
+  // wave sums by DPP (vector ALU only; lane 63 ends up with the total): 16 waves x 8 bins x 6 xor-shuffle steps of a
+  // double and an int were 336 ds_bpermute per wave -- the LDS crossbar of the CU, not the arithmetic, set the pace
+  // (stamped: 7-15 k cycles of the body's 22 k)
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) {
-    double v = ps[t];
-    int c = pc[t];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      v += __shfl_xor(v, off, 64);
-      c += __shfl_xor(c, off, 64);
-    }
-    if (lane == 0) {
+    if (t >= nb) break;
+    const double v = wave_sum_f64(ps[t]);
+    const int c = wave_sum_i32(pc[t]);
+    if (lane == 63) {
       rsum[t][wv] = v;
       rcnt[t][wv] = c;
     }
   }
+  BA_STAMP(31);
   __syncthreads();
+  BA_STAMP(32);
   if (tid < nb) {
     double v = 0.0;
     int c = 0;
