@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
                                                                unsigned int* __restrict__ cws,
                                                                float* __restrict__ quant_out) {
   extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
-  __shared__ double red[256];
+  __shared__ double red[258];
   __shared__ unsigned int scanbuf[2 * 16 * kMaxBins];
   __shared__ unsigned int prefix[kMaxBins];
   __shared__ unsigned int rem[kMaxBins];
@@ -85,49 +85,93 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
   // ---- score + z of this cloud: the arithmetic and summation order of finalize_score_kernel (score.hip): the
   // first 256 threads own points n = tid, tid + 256, ... for the two double-precision reductions
   float* sbuf = reinterpret_cast<float*>(qsm);  // N floats, free again before the histograms
-  for (int n = tid; n < N; n += 1024) {
-    float s;
-    if (mode >= kRowSumC) {
-      s = rowstat[(long)b * N + n];
-    } else {
-      const float sum = __ll2float_rn((long long)colacc[(long)b * N + n]) * kUnfixC;
-      const float num = (float)indeg[(long)b * N + n] + 1e-8f;
-      s = sum;
-      if (mode == kColAvgC) s = sum / num;
-      if (mode == kColSqrC) s = sum / num / num;
+  {
+    // every input word of the thread's PT points is requested before any of them is used (a runtime-bound loop waited
+    // for each point's loads in turn: stamped 4.7 k cycles for two points)
+    unsigned long long ca[PT];
+    int dg[PT];
+    float rs[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      ca[k] = 0ull;
+      dg[k] = 0;
+      rs[k] = 0.f;
     }
-    if (s != s) s = 0.f;
-    sbuf[n] = s;
-    score[(long)b * N + n] = s;
-    if (indeg_out) indeg_out[(long)b * N + n] = indeg[(long)b * N + n];
+    if (mode >= kRowSumC) {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const long at = (long)b * N + min(tid + 1024 * k, N - 1);
+        rs[k] = rowstat[at];
+        if (indeg_out) dg[k] = indeg[at];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PT; ++k) {
+        const long at = (long)b * N + min(tid + 1024 * k, N - 1);
+        ca[k] = colacc[at];
+        dg[k] = indeg[at];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+      const int n = tid + 1024 * k;
+      float s;
+      if (mode >= kRowSumC) {
+        s = rs[k];
+      } else {
+        const float sum = __ll2float_rn((long long)ca[k]) * kUnfixC;
+        const float num = (float)dg[k] + 1e-8f;
+        s = sum;
+        if (mode == kColAvgC) s = sum / num;
+        if (mode == kColSqrC) s = sum / num / num;
+      }
+      if (s != s) s = 0.f;
+      if (n < N) {
+        sbuf[n] = s;
+        score[(long)b * N + n] = s;
+        if (indeg_out) indeg_out[(long)b * N + n] = dg[k];
+      }
+    }
   }
   __syncthreads();
   STAMP(1);
-  double part = 0.0;
-  if (tid < 256)
-    for (int n = tid; n < N; n += 256) part += (double)sbuf[n];
-  if (tid < 256) red[tid] = part;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
+  // two double-precision reductions in the summation order of finalize_score_kernel: thread t < 256 sums points
+  // t, t + 256, ... in order, then the pairwise tree o = 128, 64, ..., 1 (element i takes element i + o).  The tree's
+  // last six levels run inside wave 0 on shuffles (a + b is commutative bit for bit), so three barriers per
+  // reduction instead of nine.
+  constexpr int PQ = 4 * PT;
+  float sv[PQ];
+#pragma unroll
+  for (int k = 0; k < PQ; ++k) sv[k] = sbuf[min((tid & 255) + 256 * k, N - 1)];
+  auto tree = [&](double part, int slot) -> double {
+    if (tid < 256) red[tid] = part;
     __syncthreads();
-  }
-  const double mean_d = red[0] / N;
-  __syncthreads();
+    if (tid < 128) red[tid] = red[tid] + red[tid + 128];  // nobody else touches elements tid and tid + 128 here
+    __syncthreads();
+    if (tid < 64) {
+      part = red[tid] + red[tid + 64];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      if (tid == 0) red[256 + slot] = part;
+    }
+    __syncthreads();
+    return red[256 + slot];
+  };
+  double part = 0.0;
+#pragma unroll
+  for (int k = 0; k < PQ; ++k)
+    if ((tid & 255) + 256 * k < N) part += (double)sv[k];
+  const double mean_d = tree(part, 0) / N;
   part = 0.0;
-  if (tid < 256)
-    for (int n = tid; n < N; n += 256) {
-      const double d = (double)sbuf[n] - mean_d;
+#pragma unroll
+  for (int k = 0; k < PQ; ++k)
+    if ((tid & 255) + 256 * k < N) {
+      const double d = (double)sv[k] - mean_d;
       part += d * d;
     }
-  if (tid < 256) red[tid] = part;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
+  const double var_sum = tree(part, 1);
   const float mean_f = (float)mean_d;
-  const float std_f = (float)sqrt(red[0] / N);
+  const float std_f = (float)sqrt(var_sum / N);
   unsigned int key[PT];
 #pragma unroll
   for (int k = 0; k < PT; ++k) {

@@ -39,6 +39,23 @@ __device__ __forceinline__ unsigned int block_scan_incl(unsigned int v, unsigned
 // ws (uint32): hist0[2048] | hist1[7*2048] | hist2[7*1024] | 3 x state {prefix[8], rem[8]}; zeroed by the launcher.
 constexpr int kQH0 = 0, kQH1 = 2048, kQH2 = 2048 + 7 * 2048, kQState = kQH2 + 7 * 1024, kQWords = kQState + 3 * 16;  // state: one slot per resolved level
 
+// Inclusive prefix sum over the 64 lanes of a wave in DPP: Hillis-Steele inside each row of 16 (row_shr 1,2,4,8, lanes
+// without a source read 0), then row_bcast15 into rows 1 and 3 and row_bcast31 into rows 2 and 3.  Seven VALU
+// instructions and no LDS crossbar traffic (the __shfl_up version was 6 dependent ds_bpermute per rank).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int qsel_dpp(unsigned int x) {
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ unsigned int qsel_wave_scan(unsigned int x) {
+  x += qsel_dpp<0x111, 0xF>(x);
+  x += qsel_dpp<0x112, 0xF>(x);
+  x += qsel_dpp<0x114, 0xF>(x);
+  x += qsel_dpp<0x118, 0xF>(x);
+  x += qsel_dpp<0x142, 0xA>(x);
+  x += qsel_dpp<0x143, 0xC>(x);
+  return x;
+}
+
 // resolve the ranks of level `level` (0,1,2) from its global histogram; all 1024 threads; result in prefix/rem (LDS)
 // keep_state: prefix / rem of the previous level are already in LDS (the fused chain resolves every level in the
 // same workgroup); otherwise they are read from the state block 0 of the previous sweep published in ws.
@@ -60,20 +77,34 @@ __device__ inline void qsel_resolve(const unsigned int* ws, int nq, long n, int 
   __syncthreads();
   constexpr int bits = (level == 2) ? 10 : 11, nbin = 1 << bits, per = nbin >> 10;
   constexpr int shift = (level == 0) ? 21 : (level == 1) ? 10 : 0;
-  unsigned int rr[kMaxBins];
+  unsigned int rr[kMaxBins], pp[kMaxBins];
 #pragma unroll
-  for (int t = 0; t < kMaxBins; ++t) rr[t] = rem[t];
+  for (int t = 0; t < kMaxBins; ++t) {
+    rr[t] = rem[t];
+    pp[t] = prefix[t];
+  }
   // all nq ranks resolved by ONE scan round (two barriers): every thread carries the nq per-rank partial counts
   // side by side (level 0 has one histogram for all ranks).  scanbuf: 2 x 16 x kMaxBins words.
   unsigned int loc[kMaxBins][2], ts[kMaxBins], incl[kMaxBins];
+  // every histogram word this thread needs, loaded unconditionally (rank index clamped) before any of them is used:
+  // inside the per-rank branches each load was waited for in turn (stamped: 15 k cycles at level 1 against 5 k at
+  // level 0, which reads one histogram)
+  unsigned int raw[kMaxBins][2];
+  if (level == 1) BA_STAMP(40);
+#pragma unroll
+  for (int t = 0; t < (level == 0 ? 1 : kMaxBins); ++t) {
+    const int tt = min(t, max(nq - 1, 0));
+    const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + tt * 2048 : kQH2 + tt * 1024);
+#pragma unroll
+    for (int u = 0; u < per; ++u) raw[t][u] = h[per * tid + u];
+  }
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) {
     loc[t][0] = loc[t][1] = ts[t] = 0u;
     if (t < nq && (level > 0 || t == 0)) {
-      const unsigned int* h = ws + (level == 0 ? kQH0 : level == 1 ? kQH1 + t * 2048 : kQH2 + t * 1024);
 #pragma unroll
       for (int u = 0; u < per; ++u) {
-        loc[t][u] = h[per * tid + u];
+        loc[t][u] = raw[t][u];
         ts[t] += loc[t][u];
       }
     }
@@ -86,42 +117,33 @@ __device__ inline void qsel_resolve(const unsigned int* ws, int nq, long n, int 
       ts[t] = ts[0];
     }
   }
+  if (level == 1) BA_STAMP(41);
   {
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int t = 0; t < kMaxBins; ++t) incl[t] = ts[t];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-      for (int t = 0; t < kMaxBins; ++t) {
-        if (t < nq && (level > 0 || t == 0)) {
-          const unsigned int up = __shfl_up(incl[t], o, 64);
-          if (lane >= o) incl[t] += up;
-        }
-      }
-    }
+    for (int t = 0; t < kMaxBins; ++t) incl[t] = (level == 0 && t > 0) ? 0u : qsel_wave_scan(ts[t]);
+    if (level == 1) BA_STAMP(42);
     if (lane == 63) {
 #pragma unroll
       for (int t = 0; t < kMaxBins; ++t) scanbuf[wv * kMaxBins + t] = incl[t];
     }
     __syncthreads();
-    // exclusive scan of the 16 wave totals of every rank: thread (t, w) = tid 16 t + w, 16-lane shuffle scan
+    if (level == 1) BA_STAMP(43);
+    // exclusive scan of the 16 wave totals of every rank: thread (t, w) = tid 16 t + w, one DPP row each
     if (tid < 16 * kMaxBins) {
       const int w = tid & 15, t = tid >> 4;
       const unsigned int mine = scanbuf[w * kMaxBins + t];
-      unsigned int acc = mine;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        const unsigned int up = __shfl_up(acc, o, 64);
-        if (w >= o) acc += up;
-      }
+      unsigned int acc = mine;  // w is the lane's position in its DPP row of 16
+      acc += qsel_dpp<0x111, 0xF>(acc);
+      acc += qsel_dpp<0x112, 0xF>(acc);
+      acc += qsel_dpp<0x114, 0xF>(acc);
+      acc += qsel_dpp<0x118, 0xF>(acc);
       scanbuf[16 * kMaxBins + w * kMaxBins + t] = acc - mine;
     }
     __syncthreads();
+    if (level == 1) BA_STAMP(44);
 #pragma unroll
-    for (int t = 0; t < kMaxBins; ++t) {
-      if (t < nq && (level > 0 || t == 0)) incl[t] += scanbuf[16 * kMaxBins + wv * kMaxBins + t];
-    }
+    for (int t = 0; t < (level == 0 ? 1 : kMaxBins); ++t) incl[t] += scanbuf[16 * kMaxBins + wv * kMaxBins + t];
     if (level == 0) {
 #pragma unroll
       for (int t = 1; t < kMaxBins; ++t) incl[t] = incl[0];
@@ -129,12 +151,11 @@ __device__ inline void qsel_resolve(const unsigned int* ws, int nq, long n, int 
   }
 #pragma unroll
   for (int t = 0; t < kMaxBins; ++t) {
-    if (t >= nq) continue;
     unsigned int c = incl[t] - ts[t];
 #pragma unroll
     for (int u = 0; u < per; ++u) {
-      if (c <= rr[t] && rr[t] < c + loc[t][u]) {  // exactly one (thread, u) matches
-        prefix[t] |= ((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift;
+      if (t < nq && c <= rr[t] && rr[t] < c + loc[t][u]) {  // exactly one (thread, u) matches
+        prefix[t] = pp[t] | (((unsigned int)(nbin - 1) - (unsigned int)(per * tid + u)) << shift);
         rem[t] = rr[t] - c;
       }
       c += loc[t][u];
