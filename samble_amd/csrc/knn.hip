@@ -49,15 +49,22 @@ __global__ __launch_bounds__(256) void cloud_mean_kernel(const float* __restrict
   if (c >= C) return;
   const float* p = x + (long)b * bs + (long)c * N;
   float s = 0.f;
-  int n = lane;
-  for (; n + 7 * 64 < N; n += 8 * 64) {  // 8 loads in flight per lane, summed in index order
-    float v[8];
+  int n = 0;
+  if ((N & 3) == 0 && (bs & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+    // 16-byte loads, 8 in flight per lane (a row of 2048 floats is one trip); a lane sums its values in index order
+    for (; n + 8 * 256 <= N; n += 8 * 256) {
+      f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[n + 64 * u];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + n + 256 * u + 4 * lane);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    for (; n + 256 <= N; n += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + n + 4 * lane);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
   }
-  for (; n < N; n += 64) s += p[n];
+  for (n += lane; n < N; n += 64) s += p[n];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) mean[b * C + c] = s / (float)N;

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
                                                            int N, int nt, const float* __restrict__ W,
                                                            float* __restrict__ gsum, float* __restrict__ dtok) {
   __shared__ float gs[kO];
+  __shared__ float ps[3][kC];
   const int t = blockIdx.x, o = threadIdx.x;
   float s = 0.f;
   int b = 0;
@@ -326,11 +327,19 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
   gs[o] = s;
   gsum[t * kO + o] = s;
   __syncthreads();
-  if (o < kC) {
-    float acc = 0.f;
-    for (int oo = 0; oo < kO; ++oo) acc = fmaf(W[(long)oo * kC + o], gs[oo], acc);
-    dtok[o * nt + t] = acc;
+  // thread = (channel c, third `part` of the 384 outputs): 16 W loads in flight, partial sums combined in part order
+  const int c = o & (kC - 1), part = o >> 7;
+  float acc = 0.f;
+  for (int o0 = 128 * part; o0 < 128 * part + 128; o0 += 16) {
+    float wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wv[u] = W[(long)(o0 + u) * kC + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = fmaf(wv[u], gs[o0 + u], acc);
   }
+  ps[part][c] = acc;
+  __syncthreads();
+  if (o < kC) dtok[o * nt + t] = (ps[0][o] + ps[1][o]) + ps[2][o];
 }
 
 }  // namespace samble
