@@ -28,6 +28,13 @@ namespace samble {
 // ([channel][row], 33-float rows), all 32 row gathers are in flight together, the (row, token) logits are one
 // thread each (32 x 8 = the workgroup), and every token-gradient partial is owned by one thread (fixed order).
 // Outputs as bwd_prep_kernel with dO_rm / dO_tr / Q_tr given: lse_s, delta, tok_part, (L2) cs_part, the images.
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch, tools/prep_stamps.py): first and last workgroup of the grid
+__device__ unsigned long long g_prep_stamps[32];
+#define PSTAMP(i) do { if (threadIdx.x == 0) { if (blockIdx.x == 0 && blockIdx.y == 0) g_prep_stamps[i] = __builtin_amdgcn_s_memtime(); \
+  if (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1) g_prep_stamps[16 + i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
 template <bool L2>
 __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                            const float* __restrict__ K, long k_bs, long k_rs,
@@ -41,19 +48,29 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
                                                            char* __restrict__ dO_tr, char* __restrict__ Q_tr) {
   __shared__ float gt[128 * 33];  // dO^T tile
   __shared__ float qt[128 * 33];  // Q^T tile of the gathered rows
-  __shared__ __attribute__((aligned(16))) float kts[8][128], vts[8][128];
-  __shared__ float dred[8][32];
-  __shared__ float ps[32][9], dss[32][9];  // P and dS of (row, token)
+  // 40 704 bytes of LDS in all, so that four workgroups fit a CU and the grid's 4 x 256 workgroups are one round
+  __shared__ __attribute__((aligned(16))) float tk[8][128];  // the token keys, later the token values
+  __shared__ float ps[32][9], dss[32][9];  // P and dS of (row, token); ps doubles as the delta partials before that
+  float (*dred)[32] = reinterpret_cast<float (*)[32]>(&ps[0][0]);  // [8][32]
   __shared__ float lrow_s[32], delta_s[32];
   __shared__ long long rows[32];
   const int b = blockIdx.y, m0 = blockIdx.x * 32, tid = threadIdx.x;
   const float* gb = g + (long)b * 128 * M;
   const float* ob = Oc + (long)b * 128 * M;
+  PSTAMP(0);
   if (tid < 32) rows[tid] = idx[(long)b * M + min(m0 + tid, M - 1)];
-  for (int e = tid; e < 8 * 128; e += 256) {
-    const int t = e >> 7, c = e & 127;
-    kts[t][c] = t < nt ? K[(long)b * k_bs + (long)(N + t) * k_rs + c] : 0.f;
-    vts[t][c] = t < nt ? V[(long)b * v_bs + (long)(N + t) * v_rs + c] : 0.f;
+  f32x4 vtok = {0.f, 0.f, 0.f, 0.f};  // this thread's four token-value words: into tk once the keys are done with
+  {
+    const int t = tid >> 5, c = 4 * (tid & 31);
+    f32x4 ktok = {0.f, 0.f, 0.f, 0.f};
+    if (t < nt) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // (row strides need not be multiples of four)
+        ktok[u] = K[(long)b * k_bs + (long)(N + t) * k_rs + c + u];
+        vtok[u] = V[(long)b * v_bs + (long)(N + t) * v_rs + c + u];
+      }
+    }
+    *reinterpret_cast<f32x4*>(&tk[t][c]) = ktok;
   }
   // dO tile and delta = sum_c dO O: each thread 16 channels of one row, the 8 channel groups in a fixed order below
   float dpart = 0.f;
@@ -75,6 +92,7 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
   }
   dred[tid >> 5][tid & 31] = dpart;
   __syncthreads();
+  PSTAMP(1);
   {  // the 32 row gathers: every half-wave has its 4 rows in flight at once
     const int sub = tid >> 5, l32 = tid & 31;
     f32x4 qv[4];
@@ -105,6 +123,7 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
     }
   }
   __syncthreads();
+  PSTAMP(2);
   const int ntiles_m = gridDim.x;
   {  // operand images of the tile (layouts: tri_dev.h); rows past M-1 are zeros in both tiles
     char* irm = dO_rm + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
@@ -138,19 +157,38 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
       *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 2)) = u3.l;
     }
   }
+  PSTAMP(3);
   if (nt <= 0) return;  // (uniform)
   {  // token logits: thread = (row r, token t)
     const int r = tid & 31, t = tid >> 5;
     float st = 0.f, dpt = 0.f, qq = 0.f, kk = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < 128; ++c) {
-      const float qc = qt[c * 33 + r], kc = kts[t][c];
-      st = fmaf(qc, kc, st);
-      dpt = fmaf(gt[c * 33 + r], vts[t][c], dpt);
-      if (L2) {
-        qq = fmaf(qc, qc, qq);
-        kk = fmaf(kc, kc, kk);
+    // the token words as 16-byte broadcast reads; channels in order (one fma chain per sum, as before)
+#pragma unroll 4
+    for (int c4 = 0; c4 < 32; ++c4) {
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(&tk[t][4 * c4]);
+      float q4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q4[u] = qt[(4 * c4 + u) * 33 + r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        st = fmaf(q4[u], k4[u], st);
+        if (L2) {
+          qq = fmaf(q4[u], q4[u], qq);
+          kk = fmaf(k4[u], k4[u], kk);
+        }
       }
+    }
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&tk[tid >> 5][4 * (tid & 31)]) = vtok;
+    __syncthreads();
+#pragma unroll 4
+    for (int c4 = 0; c4 < 32; ++c4) {
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(&tk[t][4 * c4]);
+      float g4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g4[u] = gt[(4 * c4 + u) * 33 + r];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dpt = fmaf(g4[u], v4[u], dpt);
     }
     if (L2) st = 2.f * st - qq - kk;  // -|q - k_tok|^2
     const bool ok = t < nt && m0 + r < M;
@@ -159,18 +197,30 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
     dss[r][t] = p * (dpt - delta_s[r]) * scale;
   }
   __syncthreads();
+  PSTAMP(4);
   float* outp = tok_part + ((long)b * gridDim.x + blockIdx.x) * 2 * 8 * 128;
+  // [dK | dV][token][channel]: dK_t += dS_rt q_r, dV_t += P_rt dO_r, rows ascending.  Thread = channel tid & 127 and the
+  // tokens (tid >> 7) + 2 i: the channel's 32 row values are read once per tile and serve its four tokens
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {  // [dK | dV][token][channel]: dK_t += dS_rt q_r, dV_t += P_rt dO_r, rows ascending
-    const int e = tid + 256 * i;
-    const int t = (e >> 7) & 7, c = e & 127;
-    const float* w = (e >> 10) ? &ps[0][t] : &dss[0][t];
-    const float* x = (e >> 10) ? &gt[c * 33] : &qt[c * 33];
-    float a = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < 32; ++r) a = fmaf(w[9 * r], x[r], a);
-    outp[e] = a;
+  for (int which = 0; which < 2; ++which) {
+    const int c = tid & 127;
+    const float* x = which ? &gt[c * 33] : &qt[c * 33];
+    float xr[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) xr[r] = x[r];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int t = (tid >> 7) + 2 * i;
+        a[i] = fmaf((which ? ps : dss)[r][t], xr[r], a[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) outp[which * 1024 + ((tid >> 7) + 2 * i) * 128 + c] = a[i];
   }
+  PSTAMP(5);
   if (L2 && tid < 8) {  // column sums of dS over this workgroup's rows, per token
     float a = 0.f;
     for (int r = 0; r < 32; ++r) a += dss[r][tid];
@@ -868,3 +918,9 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                        dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs_part : nullptr, l2 ? cs : nullptr);
   return (int)hipGetLastError();
 }
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_prep_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_prep_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
