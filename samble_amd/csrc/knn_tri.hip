@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
                                        0);
   };
   glds(0, 0);
-  if (tid < 32) bns[tid] = (tid < Nk) ? -0.5f * knb[tid] : 0.f;
+  if (tid < 64) bns[tid] = (tid < 32 && tid < Nk) ? knb[tid] : 0.f;  // |b_j|^2 as stored; halved and negated where it is read
 
   // The K-list of a query is ONE sorted list split by rank over its two half-lanes: lane (i, 0) keeps the KH best
   // (ranks 0 .. KH-1), lane (i, 1) ranks KH .. 2 KH - 1 (32 registers per lane instead of 64).  Packed doubles
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     for (int g = 0; g < 4; ++g) {
       const f32x4 v4 = *reinterpret_cast<const f32x4*>(bns + buf * 32 + 8 * g + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * g + e] = v4[e];
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] = -0.5f * v4[e];
     }
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + buf * kTriTile + tri_rm_off(lo, h, 0));
     // operand reads two k-steps ahead of their MFMAs (the compiler's own placement: 44-51 cycles per MFMA, stamped
@@ -376,8 +376,16 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
     glds(t + 1, nxt);  // buffer nxt was last read one iteration ago
-    const int jn = t * 32 + 32 + (tid & 31);
-    const float nb = (jn < Nk) ? -0.5f * knb[jn] : 0.f;
+    // the next tile's 32 key norms go to LDS by DMA as well.  (As a register load consumed at the end of the iteration
+    // the compiler moved it into wave 0's `tid < 32` branch and waited for it there with vmcnt(0) -- behind the three
+    // tile pieces just issued: wave 0 sat out their whole latency at the top of every tile, and the other seven
+    // waves waited for it at the barrier.)  Keys past Nk keep a stale slot: their candidates are masked (last tile).
+    if (wave == 0) {
+      const int jn = t * 32 + 32 + lane;
+      if (lane < 32 && jn < Nk)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(knb + jn),
+                                         (__attribute__((address_space(3))) void*)(bns + nxt * 32), 4, 0, 0);
+    }
     STAMP_BEGIN();
     if (mfma_first) {
       acc = products(cur);
@@ -395,7 +403,6 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
       STAMP_END(st_prod);
     }
     STAMP_BEGIN();
-    if (tid < 32) bns[nxt * 32 + tid] = nb;
     __syncthreads();
     STAMP_END(st_bar);
   }

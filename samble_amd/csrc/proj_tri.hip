@@ -199,13 +199,17 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
   };
   // this lane's 16 gradient values of tile t in the transposed image's element order:
   // k-step s, element e <-> output 32 t + 16 s + 8 (e >> 2) + 4 h + (e & 3)
+  // The loads are written in assembly so that the compiler does not count them: with its own bookkeeping it put an
+  // s_waitcnt vmcnt(0) at the top of the loop (for the rows loaded one iteration earlier) -- behind the three W pieces
+  // just issued, so every tile sat out a DMA round trip (stamped: 2000-3000 of a tile's 6000 cycles; tools/isa_waits.py
+  // finds such waits).  The hand-counted wait at the end of the iteration names the registers, which orders their use.
   auto load_g = [&](int t, f32x4 (&dst)[4]) {
     const float* p = grow + min(t, kPTiles - 1) * 32;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      dst[2 * s] = *reinterpret_cast<const f32x4*>(p + 16 * s);
-      dst[2 * s + 1] = *reinterpret_cast<const f32x4*>(p + 16 * s + 8);
-    }
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])
+                 : "v"(p)
+                 : "memory");
   };
 #pragma unroll
   for (int t = 0; t < D - 1; ++t) stage(t);
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
   for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
   f32x4 gc[4], gn[4];
   load_g(0, gc);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(gc[0]), "+v"(gc[1]), "+v"(gc[2]), "+v"(gc[3])::"memory");
 
   for (int t = 0; t < kPTiles; ++t) {
     load_g(t + 1, gn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
@@ -233,9 +237,9 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
         acc[ct] = mfma_tri(a, bg, acc[ct]);
       }
     }
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gn[0]), "+v"(gn[1]), "+v"(gn[2]), "+v"(gn[3])::"memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) gc[i] = gn[i];
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   // rows past N-1 hold point N-1's column again: same values to the same address
   float* ob = dx + (long)b * dx_bs + n;
