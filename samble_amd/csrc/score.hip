@@ -355,57 +355,81 @@ namespace samble {
 // Neighbour lists for the map-free forward (attn_stats_nl_tri_kernel): per query the K neighbour indices in
 // ASCENDING order (rank by counting: the K indices of a row are distinct) and one 32-bit mask per (query, tile of
 // 32 point keys): bit k set <=> key 32 t + k is a neighbour.  masks (B, T, N), T = ceil(N / 32): the word of a
-// (tile, 32 consecutive queries) is one coalesced 128-byte line.  One thread per query; the mask words of 64 tiles
-// at a time are built in LDS (one private column per thread).
-// (one-wave workgroups with 16 KB of LDS, several resident per SIMD, measured slower: 25 against 21 us)
-constexpr int kNnpThreads = 256;
+// (tile, 32 consecutive queries) is one coalesced 128-byte line.
+// Workgroup = 64 queries x 4 waves; wave p owns a quarter of every query's list (entries KN/4 p ..) and a quarter of
+// the mask tiles: a thread ranks its KN/4 entries against the query's KN (all of them read back from an LDS tile),
+// ORs their bits into the query's column of mask words in LDS and stores its 16 tiles of the column.  (One thread per
+// query -- 1024 compares and 64 stores in a row on one wave per SIMD -- took 21 us at B = 32, N = 2048.)
+constexpr int kNnpQ = 64, kNnpThreads = 4 * kNnpQ;
 template <int KN>
 __global__ __launch_bounds__(kNnpThreads) void nn_prepare_kernel(const int* __restrict__ nn, int N, int T,
-                                                         int* __restrict__ nn_sorted, unsigned* __restrict__ masks) {
-  __shared__ unsigned words[64][kNnpThreads];
+                                                                 int* __restrict__ nn_sorted, unsigned* __restrict__ masks) {
+  constexpr int PER = KN / 4;
+  __shared__ int vals[kNnpQ][KN + 1];     // the lists as loaded, then in ascending order
+  __shared__ unsigned words[64][kNnpQ];   // 64 mask tiles x the 64 queries
   const int b = blockIdx.y, tid = threadIdx.x;
-  const int i = blockIdx.x * kNnpThreads + tid;
+  const int q = tid & 63, part = tid >> 6;
+  const int i0 = blockIdx.x * kNnpQ, i = i0 + q;
   const bool live = i < N;
-  int v[KN];
-  const int* row = nn + ((long)b * N + min(i, N - 1)) * KN;
-#pragma unroll
-  for (int k = 0; k < KN; ++k) v[k] = row[k];
+  int v[PER];
   {
-    // rank by counting into this thread's row of an LDS tile (rows of KN + 1 words: the scattered writes of the
-    // 64 lanes fall on distinct banks), then the tile leaves as whole lines: lane l of a wave writes 16 bytes of
-    // row l / (KN / 4), so KN / 4 consecutive lanes cover one query's list
-    int* tile = reinterpret_cast<int*>(&words[0][0]);  // kNnpThreads x (KN + 1) words, well inside the array
+    const int* row = nn + ((long)b * N + min(i, N - 1)) * KN + PER * part;
 #pragma unroll
-    for (int k = 0; k < KN; ++k) {
-      int rank = 0;
-#pragma unroll
-      for (int k2 = 0; k2 < KN; ++k2) rank += (v[k2] < v[k]) ? 1 : 0;
-      tile[tid * (KN + 1) + rank] = v[k];
+    for (int k4 = 0; k4 < PER / 4; ++k4) {
+      const int4 o = *reinterpret_cast<const int4*>(row + 4 * k4);
+      v[4 * k4] = o.x;
+      v[4 * k4 + 1] = o.y;
+      v[4 * k4 + 2] = o.z;
+      v[4 * k4 + 3] = o.w;
     }
-    __syncthreads();
-    constexpr int kQuads = KN / 4;  // 16-byte pieces per row
-    const int i0 = blockIdx.x * kNnpThreads;
+  }
 #pragma unroll
-    for (int e = tid; e < kNnpThreads * kQuads; e += kNnpThreads) {
+  for (int k = 0; k < PER; ++k) vals[q][PER * part + k] = v[k];
+  __syncthreads();
+  int rank[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) rank[k] = 0;
+#pragma unroll
+  for (int k2 = 0; k2 < KN; ++k2) {
+    const int o = vals[q][k2];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) rank[k] += (o < v[k]) ? 1 : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) vals[q][rank[k]] = v[k];
+  __syncthreads();
+  {  // the sorted lists leave as whole lines: KN / 4 consecutive lanes cover one query's list
+    constexpr int kQuads = KN / 4;
+#pragma unroll
+    for (int e = tid; e < kNnpQ * kQuads; e += kNnpThreads) {
       const int r = e / kQuads, c4 = e % kQuads;
       if (i0 + r < N) {
-        const int* src = tile + r * (KN + 1) + 4 * c4;
+        const int* src = &vals[r][4 * c4];
         const int4 o = {src[0], src[1], src[2], src[3]};
         *reinterpret_cast<int4*>(nn_sorted + ((long)b * N + i0 + r) * KN + 4 * c4) = o;
       }
     }
-    __syncthreads();
   }
   for (int t0 = 0; t0 < T; t0 += 64) {
-#pragma unroll 8
-    for (int t = 0; t < 64; ++t) words[t][tid] = 0u;
 #pragma unroll
-    for (int k = 0; k < KN; ++k) {
+    for (int t = 0; t < 16; ++t) words[16 * part + t][q] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
       const int t = (v[k] >> 5) - t0;
-      if (t >= 0 && t < 64) words[t][tid] |= 1u << (v[k] & 31);
+      if (t >= 0 && t < 64) atomicOr(&words[t][q], 1u << (v[k] & 31));
     }
-    if (live)
-      for (int t = 0; t < 64 && t0 + t < T; ++t) masks[((long)b * T + t0 + t) * N + i] = words[t][tid];
+    __syncthreads();
+    unsigned w[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) w[t] = words[16 * part + t][q];
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t0 + 16 * part + t < T) masks[((long)b * T + t0 + 16 * part + t) * N + i] = w[t];
+    }
+    __syncthreads();
   }
 }
 }  // namespace samble
@@ -413,7 +437,8 @@ __global__ __launch_bounds__(kNnpThreads) void nn_prepare_kernel(const int* __re
 extern "C" int samble_launch_nn_prepare(const int* nn, int B, int N, int KN, int* nn_sorted, unsigned* masks,
                                         hipStream_t stream) {
   const int T = (N + 31) / 32;
-  const dim3 grid((N + kNnpThreads - 1) / kNnpThreads, B);
+  if ((reinterpret_cast<size_t>(nn) | reinterpret_cast<size_t>(nn_sorted)) & 15) return -22;  // 16-byte row pieces
+  const dim3 grid((N + kNnpQ - 1) / kNnpQ, B);
   Timed timed(kT_nn_prepare, stream);
   if (KN == 32) hipLaunchKernelGGL(nn_prepare_kernel<32>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks);
   else if (KN == 16) hipLaunchKernelGGL(nn_prepare_kernel<16>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks);
