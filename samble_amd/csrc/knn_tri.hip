@@ -65,11 +65,24 @@ __global__ __launch_bounds__(256) void tri_split_cm_kernel(const float* __restri
   }
 }
 
+// v_max_f64 / v_min_f64 as written: fmax / fmin come with a canonicalising `v_max_f64 x, x, x` per list slot under
+// the kernel's IEEE mode (quieting signalling NaNs that cannot occur here: the packed values are finite or +inf) --
+// three double-precision instructions per slot and insertion instead of two, plus register copies.
+__device__ __forceinline__ double max_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int KN>
 __device__ __forceinline__ void insert_packed_t(double (&L)[KN], double x) {
 #pragma unroll
-  for (int s = KN - 1; s > 0; --s) L[s] = fmin(L[s], fmax(L[s - 1], x));
-  L[0] = fmin(L[0], x);
+  for (int s = KN - 1; s > 0; --s) L[s] = min_f64(L[s], max_f64(L[s - 1], x));
+  L[0] = min_f64(L[0], x);
 }
 
 __device__ __forceinline__ double pack_wj_t(float w, unsigned int j) {
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     const bool v_p = x_p < __builtin_huge_val();
     // lane 0 inserts the row's candidate (its own first), lane 1 the element that left lane 0 last step
     const double ins = h == 0 ? (v_own ? x_own : x_p) : pend;
-    const double y = fmax(L[KH - 1], ins);                 // what leaves this lane's list
+    const double y = max_f64(L[KH - 1], ins);              // what leaves this lane's list
     insert_packed_t<KH>(L, ins);
     const double y_p = partner64(y, h);
     pend = h == 1 ? y_p : __builtin_huge_val();
@@ -357,7 +370,10 @@ __global__ __launch_bounds__(512, 2) void knn_tri_kernel(const char* __restrict_
     }
     XE(st_a);
     XB();
-    insert_step();  // (a fixed step per tile beats purely adaptive drains: 262 vs 288-302 us -- every wave does the same work)
+    // (a fixed step per tile beats purely adaptive drains, 262 vs 288-302 us: every wave does the same work.  One
+    // every other tile: 246 against 236 us.  The step woven into products() behind the MFMAs: no change, 237-240 --
+    // the two waves of a SIMD share its vector issue, and the other wave is in its selection phase then.)
+    insert_step();
     while (__any(tail - head > kKeepT)) {
       insert_step();
 #ifdef SAMBLE_KNN_STAMP
