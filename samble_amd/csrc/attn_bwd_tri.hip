@@ -767,6 +767,146 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same accumulation from an M-row map (P or dS: MODE 1 above), woven.  In the kernel above the two waves of a SIMD
+// run in step -- both split their map values (vector work), then both issue their 48 MFMAs -- so the matrix pipe
+// idles through the splits and the vector ALU through the products (SQ_VALU_MFMA_COEXEC_CYCLES: 3.6 % of the busy
+// cycles; per tile 2 x 1000 + 2 x 1536 cycles, one after the other).  Here every wave brings ITS OWN 32 keys x 32 rows
+// of the map block (four pieces of eight 128-byte row segments: nobody else reads them, so no barrier stands between
+// their arrival and their use) and splits tile t+1's values k-step by k-step behind the MFMAs of tile t.
+// Same products in the same order: bit-identical dV / dK.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAccPmMapSlots = 2;
+constexpr int kAccPmLds = kAccTrSlots * kTriTile + kAccPmMapSlots * kAccMap;
+
+template <bool CS>
+__global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int N = a.N, M = a.M, ld = a.ld;
+  const int j = chunk * 256 + wave * 32 + lo;
+  const bool jvalid = j < N;
+  const int mtiles = (M + kTile - 1) / kTile;
+  const char* Tb = a.tr + (long)b * mtiles * kTriTile;
+  char* mapring = smem_c + kAccTrSlots * kTriTile;
+  // lane l of a piece: row l >> 3 of its eight rows, 16-byte chunk l & 7 of the wave's 128 bytes (past the row's end
+  // the chunk is pulled back inside it: those keys are >= N, their outputs are never stored)
+  const float* mapb = a.map + (long)b * M * ld + min(chunk * 256 + wave * 32 + 4 * (lane & 7), ld - 4);
+  const int prow = lane >> 3;
+
+  auto stage_tr = [&](int t) {  // 3 pieces per thread
+    const int tt = min(t, mtiles - 1);
+    char* st = smem_c + (t % kAccTrSlots) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) glds16(Tb + (long)tt * kTriTile + (tid + 512 * k) * 16, st + (wave * 64 + 512 * k) * 16);
+  };
+  auto stage_map = [&](int t) {  // 4 pieces per thread: rows 8 q .. 8 q + 7 of the tile, the wave's own 32 keys
+    const int tt = min(t, mtiles - 1);
+    char* ms = mapring + (t % kAccPmMapSlots) * kAccMap + wave * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
+  };
+  float csum = 0.f;
+  // the wave's block of tile t: [32 rows][32 keys]; this lane's 16 values in accumulator order (row crow(r, h), key lo)
+  auto read_x = [&](int t, float (&x)[16]) {
+    const float* xp = reinterpret_cast<const float*>(mapring + (t % kAccPmMapSlots) * kAccMap + wave * 4096) + lo + 128 * h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = xp[(8 * (r >> 2) + (r & 3)) * 32];
+  };
+  auto mask_tail = [&](int t, float (&x)[16]) {  // rows past M: the clamped copies of row M-1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (t * kTile + crow(r, h) < M) ? x[r] : 0.f;
+  };
+  stage_tr(0);
+  stage_map(0);
+  stage_map(1);
+  f32x16 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  Tri bcur[2], bnext[2];
+  {
+    float x0[16];
+    read_x(0, x0);
+    if (mtiles == 1) mask_tail(0, x0);
+    if (CS) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) csum += x0[r];
+    }
+    bcur[0] = tri_from_acc(x0, 0);
+    bcur[1] = tri_from_acc(x0, 1);
+  }
+
+  auto step = [&](int t, auto next_tail_c, auto last_c) {
+    constexpr bool NEXT_TAIL = decltype(next_tail_c)::value, LAST = decltype(last_c)::value;
+    const char* st = smem_c + (t % kAccTrSlots) * kTriTile;
+    stage_tr(t + 1);   // slot of tile t-1
+    stage_map(t + 2);  // the wave's slot of tile t: its values were split in the previous iteration
+    // tile t+1's block (this wave's own pieces, the 4 youngest of the previous iteration) has landed
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    float x[16];
+    if (!LAST) {
+      read_x(t + 1, x);
+      if (NEXT_TAIL) mask_tail(t + 1, x);
+    }
+    auto fetch = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+      const char* ap = st + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                 *reinterpret_cast<const u32x4*>(ap + 4096)};
+    };
+    Tri a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      Tri a3 = a2;
+      if (i + 3 < 8) a3 = fetch(i + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i & 3] = mfma_tri(a0, bcur[i >> 2], acc[i & 3]);
+      if (!LAST) {  // pair i of tile t+1's values -> word i & 3 of the fragment of k-step i >> 2
+        unsigned hh, mm, ll;
+        tri_split2(x[2 * i], x[2 * i + 1], hh, mm, ll);
+        bnext[i >> 2].h[i & 3] = hh;
+        bnext[i >> 2].m[i & 3] = mm;
+        bnext[i >> 2].l[i & 3] = ll;
+        if (CS) csum += x[2 * i] + x[2 * i + 1];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {  // the weave: an MFMA, then its share of the split
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+      a1 = a2;
+      a2 = a3;
+    }
+    bcur[0] = bnext[0];
+    bcur[1] = bnext[1];
+    // tile t+1's image tile must have landed for everybody; the 4 youngest (block t+2) stay in flight
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (int t = 0; t < mtiles - 2; ++t) step(t, std::false_type{}, std::false_type{});
+  if (mtiles >= 2) step(mtiles - 2, std::true_type{}, std::false_type{});
+  step(mtiles - 1, std::false_type{}, std::true_type{});
+  if (CS) {
+    const float ctot = csum + wave_xor32(csum);
+    if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
+  }
+  if (jvalid) {
+    float* orow = a.out + (long)b * a.o_bs + (long)j * a.o_rs + 4 * h;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
+      }
+    }
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -808,6 +948,10 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
       if (e != hipSuccess) return (int)e;
     }
+    for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<false>), reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<true>)}) {
+      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccPmLds);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   const bool use_map = !fused_dkdv && dsmap;
   if (pmap && !use_map) return (int)hipErrorInvalidValue;
@@ -824,14 +968,23 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
     const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs};
     {
       Timed timed(kT_bwd_dv, stream);
-      if (pmap)  // P is there already: the dS-map mode of the kernel, on (P map, dO^T)
+      if (pmap)  // P is there already: the M-row-map kernel on (P map, dO^T)
+#ifdef SAMBLE_KACC_IN_STEP
         hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+#else
+        hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, av);
+#endif
       else
         hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
     }
     Timed timed(kT_bwd_dk, stream);
+#ifdef SAMBLE_KACC_IN_STEP
     if (cs) hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, true>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
     else hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
+#else
+    if (cs) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
+    else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
+#endif
   } else {
     const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
                        idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};
