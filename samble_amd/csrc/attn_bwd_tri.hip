@@ -776,8 +776,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
 // their arrival and their use) and splits tile t+1's values k-step by k-step behind the MFMAs of tile t.
 // Same products in the same order: bit-identical dV / dK.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAccPmMapSlots = 2;
-constexpr int kAccPmLds = kAccTrSlots * kTriTile + kAccPmMapSlots * kAccMap;
+constexpr int kAccPmMapSlots = 2, kAccPmTrSlots = 3;
+constexpr int kAccPmLds = kAccPmTrSlots * kTriTile + kAccPmMapSlots * kAccMap;
 
 template <bool CS>
 __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs a) {
@@ -791,23 +791,22 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
   const bool jvalid = j < N;
   const int mtiles = (M + kTile - 1) / kTile;
   const char* Tb = a.tr + (long)b * mtiles * kTriTile;
-  char* mapring = smem_c + kAccTrSlots * kTriTile;
+  char* mapring = smem_c + kAccPmTrSlots * kTriTile;
   // lane l of a piece: row l >> 3 of its eight rows, 16-byte chunk l & 7 of the wave's 128 bytes (past the row's end
   // the chunk is pulled back inside it: those keys are >= N, their outputs are never stored)
   const float* mapb = a.map + (long)b * M * ld + min(chunk * 256 + wave * 32 + 4 * (lane & 7), ld - 4);
   const int prow = lane >> 3;
 
-  auto stage_tr = [&](int t) {  // 3 pieces per thread
+  // one piece of the image tile t (k = 0..2) / of the wave's map block of tile t (q = 0..3: rows 8 q .. 8 q + 7)
+  auto tr_piece = [&](int t, int k) {
     const int tt = min(t, mtiles - 1);
-    char* st = smem_c + (t % kAccTrSlots) * kTriTile;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) glds16(Tb + (long)tt * kTriTile + (tid + 512 * k) * 16, st + (wave * 64 + 512 * k) * 16);
+    char* st = smem_c + (t % kAccPmTrSlots) * kTriTile;
+    glds16(Tb + (long)tt * kTriTile + (tid + 512 * k) * 16, st + (wave * 64 + 512 * k) * 16);
   };
-  auto stage_map = [&](int t) {  // 4 pieces per thread: rows 8 q .. 8 q + 7 of the tile, the wave's own 32 keys
+  auto map_piece = [&](int t, int q) {
     const int tt = min(t, mtiles - 1);
     char* ms = mapring + (t % kAccPmMapSlots) * kAccMap + wave * 4096;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
+    glds16(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
   };
   float csum = 0.f;
   // the wave's block of tile t: [32 rows][32 keys]; this lane's 16 values in accumulator order (row crow(r, h), key lo)
@@ -820,13 +819,19 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = (t * kTile + crow(r, h) < M) ? x[r] : 0.f;
   };
-  stage_tr(0);
-  stage_map(0);
-  stage_map(1);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tr_piece(0, k);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) map_piece(0, q);
+  // (order as inside the loop: a tile's map block, then its image tile)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) map_piece(1, q);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tr_piece(1, k);
   f32x16 acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all but image tile 1
   Tri bcur[2], bnext[2];
   {
     float x0[16];
@@ -842,11 +847,10 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
 
   auto step = [&](int t, auto next_tail_c, auto last_c) {
     constexpr bool NEXT_TAIL = decltype(next_tail_c)::value, LAST = decltype(last_c)::value;
-    const char* st = smem_c + (t % kAccTrSlots) * kTriTile;
-    stage_tr(t + 1);   // slot of tile t-1
-    stage_map(t + 2);  // the wave's slot of tile t: its values were split in the previous iteration
-    // tile t+1's block (this wave's own pieces, the 4 youngest of the previous iteration) has landed
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    const char* st = smem_c + (t % kAccPmTrSlots) * kTriTile;
+    // Outstanding here: tile t+1's map block (4 pieces of the previous iteration's k-steps 0-3), then image tile t+1
+    // (3 pieces, k-steps 4-6).  The block -- this wave's own pieces, nobody else reads them -- must have landed.
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     float x[16];
     if (!LAST) {
       read_x(t + 1, x);
@@ -864,18 +868,28 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
       if (i + 3 < 8) a3 = fetch(i + 3);
       __builtin_amdgcn_sched_barrier(0);
       acc[i & 3] = mfma_tri(a0, bcur[i >> 2], acc[i & 3]);
-      if (!LAST) {  // pair i of tile t+1's values -> word i & 3 of the fragment of k-step i >> 2
-        unsigned hh, mm, ll;
-        tri_split2(x[2 * i], x[2 * i + 1], hh, mm, ll);
-        bnext[i >> 2].h[i & 3] = hh;
-        bnext[i >> 2].m[i & 3] = mm;
-        bnext[i >> 2].l[i & 3] = ll;
-        if (CS) csum += x[2 * i] + x[2 * i + 1];
+      if (!LAST) {  // pair c of tile t+1's values -> word c & 3 of the fragment of k-step c >> 2; one k-step behind
+                    // the reads (k-step 0 has only its MFMAs: the values are still on their way from LDS)
 #pragma unroll
-        for (int m = 0; m < 6; ++m) {  // the weave: an MFMA, then its share of the split
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        for (int c = (i == 0 ? 8 : i - 1); c < (i == 7 ? 8 : i); ++c) {
+          unsigned hh, mm, ll;
+          tri_split2(x[2 * c], x[2 * c + 1], hh, mm, ll);
+          bnext[c >> 2].h[c & 3] = hh;
+          bnext[c >> 2].m[c & 3] = mm;
+          bnext[c >> 2].l[c & 3] = ll;
+          if (CS) csum += x[2 * c] + x[2 * c + 1];
         }
+      }
+      // this iteration's 7 DMA pieces, one per k-step (issuing them in a row at the top kept both waves of the SIMD
+      // off the matrix pipe together): tile t+2's map block into the slot of tile t (split one iteration ago), then
+      // image tile t+2 into the slot of tile t-1
+      if (i < 4) map_piece(t + 2, i);
+      else if (i < 7) tr_piece(t + 2, i - 4);
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {  // the weave: an MFMA, then its share of the vector work
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (m == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       a0 = a1;
@@ -884,12 +898,13 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
     }
     bcur[0] = bnext[0];
     bcur[1] = bnext[1];
-    // tile t+1's image tile must have landed for everybody; the 4 youngest (block t+2) stay in flight
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // image tile t+1 (the previous iteration's pieces: 7 younger ones) must have landed for everybody
+    asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (int t = 0; t < mtiles - 2; ++t) step(t, std::false_type{}, std::false_type{});
   if (mtiles >= 2) step(mtiles - 2, std::true_type{}, std::false_type{});
   step(mtiles - 1, std::false_type{}, std::true_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the clamped pieces of the tiles past the end)
   if (CS) {
     const float ctot = csum + wave_xor32(csum);
     if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
