@@ -181,6 +181,13 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
   }
 }
 
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch, tools/proj_stamps.py): workgroup (0,0), every wave, tiles 5 and 6
+__device__ unsigned long long g_proj_stamps[8 * 2 * 4];
+#define XSTAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t == 5 || t == 6)) \
+  g_proj_stamps[(wave * 2 + (t - 5)) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XSTAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
                                                              const char* __restrict__ Wtr,  // transposed image of W
                                                              int N, float* __restrict__ dx, long dx_bs) {
@@ -216,30 +223,68 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
   f32x16 acc[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
-  f32x4 gc[4], gn[4];
-  load_g(0, gc);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(gc[0]), "+v"(gc[1]), "+v"(gc[2]), "+v"(gc[3])::"memory");
+  // Software pipeline: tile t's products run on operands split one iteration earlier; tile t+1's rows (loaded one
+  // iteration earlier still) are split pair by pair behind the MFMAs -- the two waves of a SIMD run this loop in step,
+  // and with the split in front of the products both sat on the vector ALU, then both on the matrix pipe.
+  f32x4 gn[4], gnn[4];
+  Tri bg[2], nb[2];
+  load_g(0, gnn);
+  load_g(1, gn);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3]), "+v"(gn[0]), "+v"(gn[1]), "+v"(gn[2]), "+v"(gn[3])::"memory");
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const float v[8] = {gnn[2 * ks][0], gnn[2 * ks][1], gnn[2 * ks][2], gnn[2 * ks][3],
+                        gnn[2 * ks + 1][0], gnn[2 * ks + 1][1], gnn[2 * ks + 1][2], gnn[2 * ks + 1][3]};
+    bg[ks] = tri_split8(v);
+  }
 
   for (int t = 0; t < kPTiles; ++t) {
-    load_g(t + 1, gn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    XSTAMP(0);
+    load_g(t + 2, gnn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
     stage(t + D - 1);
     const char* wt = smem_c + (t % D) * kTriTile;
+    auto fetch = [&](int i) {
+      const char* ap = wt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                 *reinterpret_cast<const u32x4*>(ap + 4096)};
+    };
+    Tri a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);  // W operands three groups ahead of their MFMAs
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const float v[8] = {gc[2 * ks][0], gc[2 * ks][1], gc[2 * ks][2], gc[2 * ks][3],
-                          gc[2 * ks + 1][0], gc[2 * ks + 1][1], gc[2 * ks + 1][2], gc[2 * ks + 1][3]};
-      const Tri bg = tri_split8(v);
+    for (int i = 0; i < 8; ++i) {  // k-step i >> 2, channel tile i & 3; pair i of tile t+1's values beside it
+      const int ks = i >> 2, ct = i & 3;
+      Tri a3 = a2;
+      if (i + 3 < 8) a3 = fetch(i + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[ct] = mfma_tri(a0, bg[ks], acc[ct]);
+      unsigned hh, mm, ll;
+      tri_split2(gn[2 * ks + (ct >> 1)][2 * (ct & 1)], gn[2 * ks + (ct >> 1)][2 * (ct & 1) + 1], hh, mm, ll);
+      nb[ks].h[ct] = hh;
+      nb[ks].m[ct] = mm;
+      nb[ks].l[ct] = ll;
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const char* ap = wt + tri_tr_off(32 * ct + lo, 2 * ks + h, 0);
-        const Tri a = {*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
-                       *reinterpret_cast<const u32x4*>(ap + 4096)};
-        acc[ct] = mfma_tri(a, bg, acc[ct]);
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+      a1 = a2;
+      a2 = a3;
     }
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gn[0]), "+v"(gn[1]), "+v"(gn[2]), "+v"(gn[3])::"memory");
+#ifdef SAMBLE_STAMPS
+    XSTAMP(1);
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+    XSTAMP(2);
+    asm volatile("s_barrier" ::: "memory");
+    XSTAMP(3);
+#else
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+#endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gc[i] = gn[i];
+    for (int i = 0; i < 4; ++i) gn[i] = gnn[i];
+    bg[0] = nb[0];
+    bg[1] = nb[1];
   }
   // rows past N-1 hold point N-1's column again: same values to the same address
   float* ob = dx + (long)b * dx_bs + n;
@@ -431,3 +476,9 @@ extern "C" int samble_launch_proj_dw_tri(const float* dqkv, long g_bs, long g_rs
                      g_rs, x, x_bs, N, part);
   return (int)hipGetLastError();
 }
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_proj_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_proj_stamps), sizeof(unsigned long long) * 64);
+}
+#endif

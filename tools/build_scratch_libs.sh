@@ -12,8 +12,8 @@ mkdir -p ../../tools/scratch/abl
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden"
 for f in chain select; do hipcc $F -ffp-contract=off -DSAMBLE_STAMPS -c $f.hip -o /tmp/${f}_st.o; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/lib_stamps.so $(ls build/*.o | grep -v "chain.o\|select.o") /tmp/chain_st.o /tmp/select_st.o
-for f in attn_tri attn_bwd_tri attn_bwd; do hipcc $F -DSAMBLE_STAMPS $EXTRA -c $f.hip -o /tmp/${f}_st.o; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/lib_rc_stamps.so $(ls build/*.o | grep -v "attn_tri.o\|attn_bwd_tri.o\|attn_bwd.o") /tmp/attn_tri_st.o /tmp/attn_bwd_tri_st.o /tmp/attn_bwd_st.o
+for f in attn_tri attn_bwd_tri attn_bwd proj_tri; do hipcc $F -DSAMBLE_STAMPS $EXTRA -c $f.hip -o /tmp/${f}_st.o; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/lib_rc_stamps.so $(ls build/*.o | grep -v "attn_tri.o\|attn_bwd_tri.o\|attn_bwd.o\|proj_tri.o") /tmp/attn_tri_st.o /tmp/attn_bwd_tri_st.o /tmp/attn_bwd_st.o /tmp/proj_tri_st.o
 for a in 0 1 2 4 6; do
   hipcc $F -DSAMBLE_RC_ABL=$a -c attn_tri.hip -o /tmp/attn_tri_$a.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/abl/lib_$a.so $(ls build/*.o | grep -v attn_tri.o) /tmp/attn_tri_$a.o
