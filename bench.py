@@ -362,12 +362,13 @@ def main():
                     nm = "bwd_dq_pm_tri_kernel" if map_free else "bwd_dq_tri_kernel"
                     mf.append(roof(nm, 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::" + nm))
                 if kt.get("bwd_dv"):
-                    mf.append(roof("bwd_kacc_tri_kernel (dV)", 2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
-                                   "samble::bwd_kacc_tri_kernel<1, false>" if map_free else
+                    mf.append(roof("bwd_kacc_pm_tri_kernel (dV)" if map_free else "bwd_kacc_tri_kernel<0> (dV)",
+                                   2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
+                                   "samble::bwd_kacc_pm_tri_kernel<false>" if map_free else
                                    "samble::bwd_kacc_tri_kernel<0, false>"))
                 if kt.get("bwd_dk"):
-                    mf.append(roof("bwd_kacc_tri_kernel<1> (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
-                                   "samble::bwd_kacc_tri_kernel<1, false>"))
+                    mf.append(roof("bwd_kacc_pm_tri_kernel (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
+                                   "samble::bwd_kacc_pm_tri_kernel<false>"))
             elif kt.get("knn"):
                 mf.append(roof("knn_stream_kernel", fl["dist"] * B_PER_GPU, kt["knn"][0], "samble::knn_stream_kernel"))
             pj = 2 * C * C * 3 * N * B_PER_GPU
