@@ -329,11 +329,17 @@ int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, in
 /* samble_proj_fwd_tri_f32 and samble_tri_split_qkv_f32 in one: the projection kernel writes the operand images of
  * every full 32-point tile from its accumulators (the fp32 rows are not read back), a split launch over the remaining
  * tiles (token rows, ragged end) completes them.  Same bytes in qkv and in all images as the two separate calls.
- * k_tr_image / v_rm_image: both or neither.  Workspace: samble_proj_fwd_tri_workspace_bytes(). */
+ * k_tr_image / v_rm_image: both or neither.  Workspace: samble_proj_fwd_tri_workspace_bytes().
+ * rows = SAMBLE_PROJ_ROWS_Q_ONLY: the K and V columns of the fp32 point rows are left UNWRITTEN wherever the images
+ * carry the tile (every full 32-point tile; a ragged last tile and the token rows are always written in full) -- for
+ * callers that go on with the images only, as the map-free forward and its backward do (they read the Q rows, the
+ * token rows and the images): one sixth less written by the kernel. */
+#define SAMBLE_PROJ_ROWS_ALL 0
+#define SAMBLE_PROJ_ROWS_Q_ONLY 1
 int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
                                   const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image, void* k_image,
-                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, void* ws, size_t ws_bytes,
-                                  void* stream);
+                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows, void* ws,
+                                  size_t ws_bytes, void* stream);
 size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D);
 int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                                  const float* V, int64_t v_bs, int64_t v_rs, const void* k_tr_image,

@@ -41,7 +41,7 @@ int samble_launch_fps(const float*, const long long*, int, int, int, long long*,
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 size_t samble_proj_tri_image_bytes();
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*, void*,
-                           void* const*, hipStream_t);
+                           void* const*, int, hipStream_t);
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
                            float*, long, float*, float*, float*, void*, hipStream_t);
@@ -691,7 +691,7 @@ SAMBLE_API int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, i
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: bad B/N/nt");
   if ((o_rs & 3) || (o_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: output strides must be multiples of 4");
   if (ws_bytes < 8 * 384 * sizeof(float)) return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_f32: workspace too small");
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr, 0,
                                      (hipStream_t)stream),
               "samble_proj_fwd_f32");
 }
@@ -710,18 +710,20 @@ SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int 
   if (ws_bytes < samble_proj_fwd_tri_workspace_bytes())
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_tri_f32: workspace too small");
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr, 0,
                                      (hipStream_t)stream),
               "samble_proj_fwd_tri_f32");
 }
 
 SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
                                              const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image,
-                                             void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, void* ws,
-                                             size_t ws_bytes, void* stream) {
+                                             void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows,
+                                             void* ws, size_t ws_bytes, void* stream) {
   if (!x || !W || !qkv || !ws || (nt > 0 && !tokens) || !q_image || !k_image || !v_tr_image || (!k_tr_image != !v_rm_image))
     return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: null pointer (the two backward images come as a pair)");
   if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: C = D must be 128");
+  if (rows != SAMBLE_PROJ_ROWS_ALL && rows != SAMBLE_PROJ_ROWS_Q_ONLY)
+    return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: rows is SAMBLE_PROJ_ROWS_ALL or SAMBLE_PROJ_ROWS_Q_ONLY");
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: bad B/N/nt");
   if ((o_rs & 3) || (o_bs & 3))
     return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: output strides must be multiples of 4");
@@ -730,7 +732,7 @@ SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
   void* const images[5] = {q_image, k_image, v_tr_image, k_tr_image, v_rm_image};
   return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, images,
-                                     (hipStream_t)stream),
+                                     rows == SAMBLE_PROJ_ROWS_Q_ONLY, (hipStream_t)stream),
               "samble_proj_fwd_split_tri_f32");
 }
 

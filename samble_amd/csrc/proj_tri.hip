@@ -33,6 +33,7 @@ struct ProjImages {
   char* k_tr;   // null: no backward images
   char* v_rm;
   int ktiles;   // tiles per cloud of the K / V images (rows N + nt); the Q image has ceil(N / 32)
+  int q_only;   // the fp32 K / V columns of the point rows are not written where the images cover the tile
 };
 constexpr int kPXt = 36;  // row stride (floats) of a wave's 32 x 32 transpose tile
 
@@ -124,10 +125,12 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
       const Tri bq = {xq[3 * ks], xq[3 * ks + 1], xq[3 * ks + 2]};
       acc = mfma_tri(a, bq, acc);
     }
+    if (t < 4 || !(IMG && im.q_only && full)) {  // (wave-uniform; 67 of the kernel's 392 MB at B=32, N=2048)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
+      }
     }
     if (full) {
       const int which = t >> 2, tc = t & 3;  // 0 Q, 1 K, 2 V; channels 32 tc .. 32 tc + 31 of it
@@ -419,7 +422,7 @@ extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
 extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokqkv, int nt,
                                           const float* W, void* wimg, float* qkv, long o_bs, long o_rs, void* q_rm,
-                                          void* k_rm, void* v_tr, void* k_tr, void* v_rm, hipStream_t s) {
+                                          void* k_rm, void* v_tr, void* k_tr, void* v_rm, int q_only, hipStream_t s) {
   const int lds_img = kProjTriLds + 8 * 32 * kPXt * 4;
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_tri_kernel<false>),
@@ -434,7 +437,7 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
   }
   int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, wimg, nullptr, s);
   if (rc) return rc;
-  const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32};
+  const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32, q_only};
   {
     Timed timed(kT_proj_fwd, s);
     if (q_rm)

@@ -38,16 +38,18 @@ class _Projection(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, tokens, wq, wk, wv, images=""):
+    def forward(ctx, x, tokens, wq, wk, wv, images="", q_only=False):
         """images "fwd" / "fwd+bwd": also returns the split-bf16 operand images of [Q|K|V] (non-differentiable byte
-        tensors), written by the projection kernel itself instead of a split pass over the fp32 rows."""
+        tensors), written by the projection kernel itself instead of a split pass over the fp32 rows.
+        q_only: the caller reads K and V from the images only (the map-free sampler): the kernel then leaves the K / V
+        columns of qkv's point rows unwritten (ops.stage_proj_fwd)."""
         w = torch.cat((wq, wk, wv), dim=0).squeeze(-1)  # (3C, C)
         tok = tokens[0]                                  # (C, nt)
         ctx.save_for_backward(x, tok, w)
         ctx.splits = (wq.shape[0], wk.shape[0], wv.shape[0])
         if not images:
             return ops.stage_proj_fwd(x, tok, w)
-        qkv, imgs = ops.stage_proj_fwd(x, tok, w, images=images)
+        qkv, imgs = ops.stage_proj_fwd(x, tok, w, images=images, q_only=q_only)
         ctx.mark_non_differentiable(*imgs)
         ctx.set_materialize_grads(False)  # (else autograd zero-fills a 50 MB "gradient" per image on the way back)
         return (qkv,) + tuple(imgs)
@@ -56,16 +58,16 @@ class _Projection(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dqkv, *_):
         if dqkv is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, tok, w = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:])
         dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw)
         if not need_dw:
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None
         a, b, c = ctx.splits
         dtokens = dtok.unsqueeze(0) if ctx.needs_input_grad[1] else None
-        return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1), None)
+        return (dx, dtokens, dw[:a].unsqueeze(-1), dw[a:a + b].unsqueeze(-1), dw[a + b:].unsqueeze(-1), None, None)
 
 
 # Two-pass forward with the logit map kept in HBM (csrc/attn_map.hip) for the sparse_* score modes;
@@ -111,8 +113,12 @@ class _SamplerCore(torch.autograd.Function):
             nn_idx = ops.stage_knn(x, x, mod.K)
             if MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and mod.asm == "dot" and mod.K in (16, 32):
                 need_bwd = ctx.needs_input_grad[0]
-                imgs = images if images is not None and (len(images) == 5 or not need_bwd) else \
-                    ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
+                if images is not None and (len(images) == 5 or not need_bwd):
+                    imgs = images
+                elif images is not None:  # (qkv came with its K / V point rows unwritten: nothing to split from)
+                    raise ops._lib.SambleError("the projection's images lack the backward pair although a gradient is wanted")
+                else:
+                    imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
                 nn_sorted, masks = ops.stage_nn_prepare(nn_idx)
                 chain = ops.chain_supported(B, N, nb)
                 # the pass also accumulates the score statistics of the K neighbour entries of every row
@@ -313,8 +319,9 @@ class DownSampleToken(nn.Module):
                         and self.idx_mode not in ("col_sum", "row_std"))
         if fused_images:
             need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+            # (everything downstream of the projection reads K and V from the images: their fp32 point rows stay unwritten)
             qkv, *images = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight,
-                                             self.v_conv.weight, "fwd+bwd" if need_bwd else "fwd")
+                                             self.v_conv.weight, "fwd+bwd" if need_bwd else "fwd", True)
         else:
             images = None
             qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)

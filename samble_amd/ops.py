@@ -69,10 +69,12 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     return (idx, dist) if want_dist else idx
 
 
-def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, images: str = ""):
+def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, images: str = "", q_only: bool = False):
     """x (B,C,N), tokens (C,nt), w_qkv (3C,C) -> qkv (B,N+nt,3C) point-major rows [Q|K|V].
     images "fwd" / "fwd+bwd" (MATRIX_MODE "tri"): -> (qkv, operand images as stage_tri_split_qkv returns them), written by
-    the projection kernel itself (the split pass then covers only the tiles with token rows / a ragged end)."""
+    the projection kernel itself (the split pass then covers only the tiles with token rows / a ragged end).
+    q_only (with images): the K / V columns of qkv's point rows stay unwritten where the images carry the tile
+    (include/samble.h SAMBLE_PROJ_ROWS_Q_ONLY) -- for callers that read the Q rows, the token rows and the images only."""
     _need_gpu(x, tokens, w_qkv)
     x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
     B, C, N = x.shape
@@ -90,7 +92,7 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, i
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _lib.call("samble_proj_fwd_split_tri_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
                       qkv.data_ptr(), qkv.stride(0), qkv.stride(1), q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(),
-                      _p(k_tr), _p(v_rm), ws.data_ptr(), nbytes, _stream())
+                      _p(k_tr), _p(v_rm), 1 if q_only else 0, ws.data_ptr(), nbytes, _stream())
         return qkv, ((q_img, k_img, v_img, k_tr, v_rm) if images == "fwd+bwd" else (q_img, k_img, v_img))
     with torch.cuda.device(x.device):
         qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)

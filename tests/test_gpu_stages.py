@@ -890,5 +890,22 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
             assert len(imgs2) == (5 if want == "fwd+bwd" else 3)
             for j, (a, b2) in enumerate(zip(imgs, imgs2)):
                 assert torch.equal(a, b2), (want, "image", j, int((a != b2).sum()))
+            # SAMBLE_PROJ_ROWS_Q_ONLY: the same images, the Q columns, the token rows and a ragged last tile's rows; the K / V
+            # columns of the full point tiles are not written at all (the poison planted below survives there)
+            import samble_amd.ops as _o
+            empty = torch.empty
+            try:
+                _o.torch.empty = lambda *a_, **k_: empty(*a_, **k_).fill_(-7.0) if k_.get("dtype") == torch.float32 else empty(*a_, **k_)
+                qkv3, imgs3 = o_.stage_proj_fwd(x, tokens, w, images=want, q_only=True)
+            finally:
+                _o.torch.empty = empty
+            torch.cuda.synchronize()
+            nfull = (N // 32) * 32
+            assert torch.equal(qkv3[:, :, :128][:, :N], qkv[:, :N, :128]) and torch.equal(qkv3[:, N:], qkv[:, N:])
+            assert torch.equal(qkv3[:, nfull:N], qkv[:, nfull:N])
+            if nfull > 1:  # (row N-1 may be written in full by the waves past the end: they recompute that row)
+                assert bool((qkv3[:, :nfull - 1, 128:] == -7.0).all())
+            for j, (a, b2) in enumerate(zip(imgs, imgs3)):
+                assert torch.equal(a, b2), (want, "q_only image", j, int((a != b2).sum()))
     finally:
         o_.MATRIX_MODE = old
