@@ -346,8 +346,8 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
 
 using namespace samble;
 
-extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, int, const float*, void*, float*, long,
-                                          long, void*, void*, void*, void*, void*, int, hipStream_t);
+extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, void*, float*,
+                                          long, long, void*, void*, void*, void*, void*, int, hipStream_t);
 extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, float*, long, hipStream_t);
 extern "C" int samble_launch_proj_dw_tri(const float*, long, long, const float*, long, int, int, float*, hipStream_t);
 
@@ -357,11 +357,11 @@ extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, c
                                       void* const* images, int q_only, hipStream_t s) {
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
-  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 4), dim3(256), 0, s, tokens, nt, W, tokqkv);
-  if (wimg)  // images: {q_rm, k_rm, v_tr, k_tr | null, v_rm | null} or null
-    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, images ? images[0] : nullptr,
+  if (wimg)  // images: {q_rm, k_rm, v_tr, k_tr | null, v_rm | null} or null; the token rows come with the W image
+    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokens, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, images ? images[0] : nullptr,
                                       images ? images[1] : nullptr, images ? images[2] : nullptr,
                                       images ? images[3] : nullptr, images ? images[4] : nullptr, images ? q_only : 0, s);
+  if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 4), dim3(256), 0, s, tokens, nt, W, tokqkv);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -37,6 +37,47 @@ struct ProjImages {
 };
 constexpr int kPXt = 36;  // row stride (floats) of a wave's 32 x 32 transpose tile
 
+// What the projection needs from the weights and the tokens, in ONE launch (they were two of ~5 us each, both far
+// below the cost of a launch): workgroups 0..11 write the row image of W (tile = 32 output rows; tri_split_kernel's
+// bytes), workgroups 12.. the token rows tokqkv[t][o] = sum_c W[o][c] tokens[c][t] (proj_tok_fwd_kernel's arithmetic:
+// one wave per output row, lanes across the channels, independent shuffle trees for the 8 token sums).
+__global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restrict__ W, const float* __restrict__ tokens,
+                                                            int nt, char* __restrict__ wimg, float* __restrict__ tokqkv) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x < kPTiles) {
+    char* img = wimg + (long)blockIdx.x * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int r = e & 31, g = e >> 5, row = blockIdx.x * 32 + r;
+      const f32x4* p = reinterpret_cast<const f32x4*>(W + (long)row * 128 + 8 * g);
+      const f32x4 a = p[0], bb = p[1];
+      const float x[8] = {a[0], a[1], a[2], a[3], bb[0], bb[1], bb[2], bb[3]};
+      const Tri t = tri_split8(x);
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t.h;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t.m;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t.l;
+    }
+    return;
+  }
+  if (nt <= 0) return;
+  const int lane = tid & 63;
+  const int o = (blockIdx.x - kPTiles) * 4 + (tid >> 6);
+  const float w0 = W[(long)o * 128 + lane], w1 = W[(long)o * 128 + lane + 64];
+  float p[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float tk0 = (t < nt) ? tokens[lane * nt + t] : 0.f;
+    const float tk1 = (t < nt) ? tokens[(lane + 64) * nt + t] : 0.f;
+    p[t] = fmaf(w0, tk0, w1 * tk1);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) p[t] += __shfl_xor(p[t], off, 64);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (lane == 0 && t < nt) tokqkv[t * kPO + o] = p[t];
+}
+
 template <bool IMG>
 __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int N,
                                                               const float* __restrict__ tokqkv, int nt,
@@ -420,8 +461,8 @@ extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long
 
 // images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
-extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokqkv, int nt,
-                                          const float* W, void* wimg, float* qkv, long o_bs, long o_rs, void* q_rm,
+extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokens, float* tokqkv,
+                                          int nt, const float* W, void* wimg, float* qkv, long o_bs, long o_rs, void* q_rm,
                                           void* k_rm, void* v_tr, void* k_tr, void* v_rm, int q_only, hipStream_t s) {
   const int lds_img = kProjTriLds + 8 * 32 * kPXt * 4;
   {
@@ -435,8 +476,8 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
                             kProjTriLds);
     if (e != hipSuccess) return (int)e;
   }
-  int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, wimg, nullptr, s);
-  if (rc) return rc;
+  int rc = 0;
+  hipLaunchKernelGGL(proj_prologue_kernel, dim3(kPTiles + kPO / 4), dim3(256), 0, s, W, tokens, nt, (char*)wimg, tokqkv);
   const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32, q_only};
   {
     Timed timed(kT_proj_fwd, s);
