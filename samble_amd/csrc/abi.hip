@@ -54,7 +54,8 @@ int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, i
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
-                           long, float*, long, long, int, float*, float*, const void*, const void*, void*, int, hipStream_t);
+                           long, float*, long, long, int, float*, float*, const void*, const void*, void*, int, int, hipStream_t);
+int samble_attn_bwd_prep_clears_dq(const float*, const float*, const void*, const void*, const void*);
 int samble_attn_map_ld(int N, int nt);
 size_t samble_tri_image_size(int, int, int);
 size_t samble_bwd_tri_dsmap_bytes(int, int, int);
@@ -401,8 +402,10 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
     return fail(SAMBLE_E_INVALID, msg);
   }
   hipStream_t s = (hipStream_t)stream;
-  // rows of dQ that were not sampled carry no gradient: one strided zero-fill launch
-  {
+  // rows of dQ that were not sampled carry no gradient: cleared by the split-bf16 preparation kernel on its way, else
+  // by one strided zero-fill launch
+  const int prep_clears = samble_attn_bwd_prep_clears_dq(smap, Oc, k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr);
+  if (!prep_clears) {
     const long quads = (long)B * N * (D / 4);
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, dQ, (long)dq_bs,
                        (long)dq_rs, N, D / 4, quads);
@@ -417,7 +420,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
                                      (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
                                      slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part,
-                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, variant, s),
+                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, variant, prep_clears, s),
               who);
 }
 

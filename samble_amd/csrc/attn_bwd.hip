@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
                                                            float scale, float* __restrict__ lse_s,
                                                            float* __restrict__ delta, float* __restrict__ tok_part,
                                                            float* __restrict__ cs_part, char* __restrict__ dO_rm,
-                                                           char* __restrict__ dO_tr, char* __restrict__ Q_tr) {
+                                                           char* __restrict__ dO_tr, char* __restrict__ Q_tr,
+                                                           float* __restrict__ dQ, long dq_bs, long dq_rs) {
   __shared__ float gt[128 * 33];  // dO^T tile
   __shared__ float qt[128 * 33];  // Q^T tile of the gathered rows
   // 40 704 bytes of LDS in all, so that four workgroups fit a CU and the grid's 4 x 256 workgroups are one round
@@ -58,6 +59,15 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
   const float* gb = g + (long)b * 128 * M;
   const float* ob = Oc + (long)b * 128 * M;
   PSTAMP(0);
+  if (dQ) {
+    // the rows of dQ that were not sampled carry no gradient: this workgroup clears its share of the cloud's N rows
+    // (all of them: the dQ kernel, which runs after this one, then writes the sampled rows) -- was a launch of its own
+    const int per = (N + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(N, r0 + per);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < (r1 - r0) * 32; e += 256)
+      *reinterpret_cast<f32x4*>(dQ + (long)b * dq_bs + (long)(r0 + (e >> 5)) * dq_rs + 4 * (e & 31)) = z4;
+  }
   if (tid < 32) rows[tid] = idx[(long)b * M + min(m0 + tid, M - 1)];
   f32x4 vtok = {0.f, 0.f, 0.f, 0.f};  // this thread's four token-value words: into tk once the keys are done with
   {
@@ -840,7 +850,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                                       float* lse_s, float* delta, float* tok_part, float* slab, float* dQ, long dq_bs,
                                       long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
                                       int l2, float* cs, float* cs_part, const void* k_tr_image, const void* v_rm_image,
-                                      void* img_ws, int variant, hipStream_t stream) {
+                                      void* img_ws, int variant, int zero_dq, hipStream_t stream) {
+  // zero_dq: the caller left clearing dQ's N rows to bwd_prep_tri (samble_attn_bwd_prep_clears_dq says when it may)
   // variant (include/samble.h): single-pass path: 1 = the two-kernel backward (bwd_dq + bwd_dkdv, 7 products)
   // instead of the fused one (5); split-bf16 map path: 1 = fused dP / dV / dK kernel instead of the dS map,
   // 2 = smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri) instead of the logit map; 2 + 4 = the same
@@ -880,7 +891,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_tri_kernel<true> : bwd_prep_tri_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q,
                        q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, Oc, lse, idx, g, N, nt, M, scale, lse_s, delta, tok_part,
-                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr);
+                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr, zero_dq ? dQ : nullptr, dq_bs, dq_rs);
   } else {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
@@ -924,3 +935,9 @@ extern "C" __attribute__((visibility("default"))) int samble_scratch_prep_stamps
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_prep_stamps), sizeof(unsigned long long) * 32);
 }
 #endif
+
+// true when samble_launch_attn_bwd with these arguments runs bwd_prep_tri_kernel, which can clear dQ on its way
+extern "C" int samble_attn_bwd_prep_clears_dq(const float* smap, const float* Oc, const void* k_tr_image,
+                                              const void* v_rm_image, const void* img_ws) {
+  return smap && Oc && k_tr_image && v_rm_image && img_ws;
+}
