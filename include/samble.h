@@ -92,8 +92,9 @@ int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, c
                             void* stream);
 size_t samble_proj_bwd_tri_workspace_bytes(int B, int N);
 int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
-                            int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs, float* dW,
-                            float* dtokens, void* ws, size_t ws_bytes, void* stream);
+                            int N, const float* tokens, int nt, const float* W, const void* w_tr_image /* or NULL */,
+                            float* dx, int64_t dx_bs, float* dW, float* dtokens, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
@@ -336,10 +337,13 @@ int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, in
  * token rows and the images): one sixth less written by the kernel. */
 #define SAMBLE_PROJ_ROWS_ALL 0
 #define SAMBLE_PROJ_ROWS_Q_ONLY 1
+/* w_tr_image (optional, samble_proj_w_image_bytes() bytes): receives the transposed operand image of W, which
+ * samble_proj_bwd_tri_f32 takes back as its w_tr_image (no split launch in the backward; W must be unchanged). */
+size_t samble_proj_w_image_bytes(void);
 int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
                                   const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image, void* k_image,
-                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows, void* ws,
-                                  size_t ws_bytes, void* stream);
+                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows, void* w_tr_image,
+                                  void* ws, size_t ws_bytes, void* stream);
 size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D);
 int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                                  const float* V, int64_t v_bs, int64_t v_rs, const void* k_tr_image,

@@ -33,9 +33,10 @@ _SIGNATURES = {
     "samble_proj_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                     c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "samble_proj_bwd_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
-                                    c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                    c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                     c_void_p]),
     "samble_proj_fwd_tri_workspace_bytes": (c_size_t, []),
+    "samble_proj_w_image_bytes": (c_size_t, []),
     "samble_proj_bwd_tri_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -90,7 +91,7 @@ _SIGNATURES = {
     "samble_tri_split_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_proj_fwd_split_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                              c_void_p, c_size_t, c_void_p]),
+                                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_tri_split_qkv_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     "samble_attn_rows_bwd_tri_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -41,10 +41,10 @@ int samble_launch_fps(const float*, const long long*, int, int, int, long long*,
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 size_t samble_proj_tri_image_bytes();
 int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*, void*,
-                           void* const*, int, hipStream_t);
+                           void* const*, int, void*, hipStream_t);
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
-                           float*, long, float*, float*, float*, void*, hipStream_t);
+                           float*, long, float*, float*, float*, void*, const void*, hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
@@ -694,12 +694,14 @@ SAMBLE_API int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, i
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: bad B/N/nt");
   if ((o_rs & 3) || (o_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: output strides must be multiples of 4");
   if (ws_bytes < 8 * 384 * sizeof(float)) return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_f32: workspace too small");
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr, 0,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr, 0, nullptr,
                                      (hipStream_t)stream),
               "samble_proj_fwd_f32");
 }
 
 /* the same projection on the bf16 matrix cores with split fp32 operands: the workspace also holds W's image */
+SAMBLE_API size_t samble_proj_w_image_bytes(void) { return samble_proj_tri_image_bytes(); }
+
 SAMBLE_API size_t samble_proj_fwd_tri_workspace_bytes(void) { return 8 * 384 * sizeof(float) + 256 + samble_proj_tri_image_bytes(); }
 
 SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
@@ -713,7 +715,7 @@ SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int 
   if (ws_bytes < samble_proj_fwd_tri_workspace_bytes())
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_tri_f32: workspace too small");
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr, 0,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr, 0, nullptr,
                                      (hipStream_t)stream),
               "samble_proj_fwd_tri_f32");
 }
@@ -721,7 +723,7 @@ SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int 
 SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
                                              const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image,
                                              void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows,
-                                             void* ws, size_t ws_bytes, void* stream) {
+                                             void* w_tr_image, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !W || !qkv || !ws || (nt > 0 && !tokens) || !q_image || !k_image || !v_tr_image || (!k_tr_image != !v_rm_image))
     return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: null pointer (the two backward images come as a pair)");
   if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: C = D must be 128");
@@ -735,7 +737,7 @@ SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
   void* const images[5] = {q_image, k_image, v_tr_image, k_tr_image, v_rm_image};
   return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, images,
-                                     rows == SAMBLE_PROJ_ROWS_Q_ONLY, (hipStream_t)stream),
+                                     rows == SAMBLE_PROJ_ROWS_Q_ONLY, w_tr_image, (hipStream_t)stream),
               "samble_proj_fwd_split_tri_f32");
 }
 
@@ -750,7 +752,7 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
   if (ws_bytes < samble_proj_bwd_ws_floats(B, N) * sizeof(float))
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_f32: workspace too small");
   return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, nullptr,
-                                     (hipStream_t)stream),
+                                     nullptr, (hipStream_t)stream),
               "samble_proj_bwd_f32");
 }
 
@@ -761,8 +763,9 @@ SAMBLE_API size_t samble_proj_bwd_tri_workspace_bytes(int B, int N) {
 }
 
 SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
-                                       int C, int N, const float* tokens, int nt, const float* W, float* dx, int64_t dx_bs,
-                                       float* dW, float* dtokens, void* ws, size_t ws_bytes, void* stream) {
+                                       int C, int N, const float* tokens, int nt, const float* W, const void* w_tr_image,
+                                       float* dx, int64_t dx_bs, float* dW, float* dtokens, void* ws, size_t ws_bytes,
+                                       void* stream) {
   if (!dqkv || !x || !W || !ws) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: null pointer");
   if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: C = D must be 128");
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: bad B/N/nt");
@@ -772,7 +775,7 @@ SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t 
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_tri_f32: workspace too small");
   char* wtr = (char*)ws + ((samble_proj_bwd_ws_floats(B, N) * sizeof(float) + 255) & ~(size_t)255);
   return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, wtr,
-                                     (hipStream_t)stream),
+                                     w_tr_image, (hipStream_t)stream),
               "samble_proj_bwd_tri_f32");
 }
 

@@ -346,19 +346,19 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
 
 using namespace samble;
 
-extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, void*, float*,
-                                          long, long, void*, void*, void*, void*, void*, int, hipStream_t);
-extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, float*, long, hipStream_t);
+extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, void*, void*,
+                                          float*, long, long, void*, void*, void*, void*, void*, int, hipStream_t);
+extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, int, float*, long, hipStream_t);
 extern "C" int samble_launch_proj_dw_tri(const float*, long, long, const float*, long, int, int, float*, hipStream_t);
 
 // wimg != null: room for the row image of W -> the split-bf16 kernel (proj_tri.hip)
 extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, const float* tokens, int nt,
                                       const float* W, float* qkv, long o_bs, long o_rs, float* ws, void* wimg,
-                                      void* const* images, int q_only, hipStream_t s) {
+                                      void* const* images, int q_only, void* wtr_out, hipStream_t s) {
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
   if (wimg)  // images: {q_rm, k_rm, v_tr, k_tr | null, v_rm | null} or null; the token rows come with the W image
-    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokens, tokqkv, nt, W, wimg, qkv, o_bs, o_rs, images ? images[0] : nullptr,
+    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokens, tokqkv, nt, W, wimg, wtr_out, qkv, o_bs, o_rs, images ? images[0] : nullptr,
                                       images ? images[1] : nullptr, images ? images[2] : nullptr,
                                       images ? images[3] : nullptr, images ? images[4] : nullptr, images ? q_only : 0, s);
   if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 4), dim3(256), 0, s, tokens, nt, W, tokqkv);
@@ -380,7 +380,8 @@ extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
 
 extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
                                       const float* tokens, int nt, const float* W, float* dx, long dx_bs, float* dW,
-                                      float* dtok, float* ws, void* wtr, hipStream_t s) {
+                                      float* dtok, float* ws, void* wtr, const void* wtr_ready, hipStream_t s) {
+  // wtr_ready: the transposed image of W as the forward's prologue wrote it (then wtr is not used)
   const size_t lds_dx = kDxLdsFloats * sizeof(float), lds_dw = kDwLdsFloats * sizeof(float);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dw_kernel),
@@ -394,7 +395,8 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   float* part = ws;
   float* gsum = ws + (size_t)B * chunks * kO * kC;  // 8 x 384
   if (dx && wtr) {  // room for the transposed image of W -> the split-bf16 kernel
-    const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr, B, N, dx, dx_bs, s);
+    const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr_ready ? const_cast<void*>(wtr_ready) : wtr,
+                                             wtr_ready != nullptr, B, N, dx, dx_bs, s);
     if (rc) return rc;
   } else if (dx) {
     Timed timed(kT_proj_dx, s);

@@ -42,9 +42,23 @@ constexpr int kPXt = 36;  // row stride (floats) of a wave's 32 x 32 transpose t
 // bytes), workgroups 12.. the token rows tokqkv[t][o] = sum_c W[o][c] tokens[c][t] (proj_tok_fwd_kernel's arithmetic:
 // one wave per output row, lanes across the channels, independent shuffle trees for the 8 token sums).
 __global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restrict__ W, const float* __restrict__ tokens,
-                                                            int nt, char* __restrict__ wimg, float* __restrict__ tokqkv) {
+                                                            int nt, char* __restrict__ wimg, char* __restrict__ wtr,
+                                                            float* __restrict__ tokqkv) {
   const int tid = threadIdx.x;
   if (blockIdx.x < kPTiles) {
+    if (wtr) {  // the transposed image as well (the backward's proj_dx_tri reads it: no split launch there)
+      char* img = wtr + (long)blockIdx.x * kTriTile;
+      for (int e = tid; e < 512; e += 256) {
+        const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = W[(long)(blockIdx.x * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3)) * 128 + d];
+        const Tri t = tri_split8(x);
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t.h;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = t.m;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = t.l;
+      }
+    }
     char* img = wimg + (long)blockIdx.x * kTriTile;
     for (int e = tid; e < 512; e += 256) {
       const int r = e & 31, g = e >> 5, row = blockIdx.x * 32 + r;
@@ -462,7 +476,7 @@ extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long
 // images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
 extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokens, float* tokqkv,
-                                          int nt, const float* W, void* wimg, float* qkv, long o_bs, long o_rs, void* q_rm,
+                                          int nt, const float* W, void* wimg, void* wtr_out, float* qkv, long o_bs, long o_rs, void* q_rm,
                                           void* k_rm, void* v_tr, void* k_tr, void* v_rm, int q_only, hipStream_t s) {
   const int lds_img = kProjTriLds + 8 * 32 * kPXt * 4;
   {
@@ -477,7 +491,8 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
     if (e != hipSuccess) return (int)e;
   }
   int rc = 0;
-  hipLaunchKernelGGL(proj_prologue_kernel, dim3(kPTiles + kPO / 4), dim3(256), 0, s, W, tokens, nt, (char*)wimg, tokqkv);
+  hipLaunchKernelGGL(proj_prologue_kernel, dim3(kPTiles + kPO / 4), dim3(256), 0, s, W, tokens, nt, (char*)wimg,
+                     (char*)wtr_out, tokqkv);
   const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32, q_only};
   {
     Timed timed(kT_proj_fwd, s);
@@ -495,15 +510,17 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
   return (int)hipGetLastError();
 }
 
-extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int B, int N,
-                                         float* dx, long dx_bs, hipStream_t s) {
+extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int have_wtr,
+                                         int B, int N, float* dx, long dx_bs, hipStream_t s) {
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
     if (e != hipSuccess) return (int)e;
   }
-  int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, nullptr, wtr, s);
-  if (rc) return rc;
+  if (!have_wtr) {  // (the forward's prologue wrote it otherwise)
+    const int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, nullptr, wtr, s);
+    if (rc) return rc;
+  }
   Timed timed(kT_proj_dx, s);
   hipLaunchKernelGGL(proj_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, dqkv, g_bs, g_rs,
                      (const char*)wtr, N, dx, dx_bs);

@@ -50,6 +50,9 @@ class _Projection(torch.autograd.Function):
         if not images:
             return ops.stage_proj_fwd(x, tok, w)
         qkv, imgs = ops.stage_proj_fwd(x, tok, w, images=images, q_only=q_only)
+        if len(imgs) == 6:  # the transposed image of W stays with this node: its own backward reads it
+            ctx.save_for_backward(x, tok, w, imgs[5])
+            imgs = imgs[:5]
         ctx.mark_non_differentiable(*imgs)
         ctx.set_materialize_grads(False)  # (else autograd zero-fills a 50 MB "gradient" per image on the way back)
         return (qkv,) + tuple(imgs)
@@ -59,10 +62,11 @@ class _Projection(torch.autograd.Function):
     def backward(ctx, dqkv, *_):
         if dqkv is None:
             return None, None, None, None, None, None, None
-        x, tok, w = ctx.saved_tensors
+        x, tok, w = ctx.saved_tensors[:3]
+        w_tr = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:])
-        dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw)
+        dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw, w_tr=w_tr)
         if not need_dw:
             return dx, None, None, None, None, None, None
         a, b, c = ctx.splits

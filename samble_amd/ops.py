@@ -88,12 +88,15 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, i
                                                device=x.device)
             q_img, k_img, v_img = img(N, 0), img(N + nt, 0), img(N + nt, 1)
             k_tr, v_rm = (img(N + nt, 1), img(N + nt, 0)) if images == "fwd+bwd" else (None, None)
+            # with the backward pair also the transposed image of W, for stage_proj_bwd(w_tr=...): last of the tuple
+            w_tr = torch.empty(_lib.query("samble_proj_w_image_bytes"), dtype=torch.uint8, device=x.device) \
+                if images == "fwd+bwd" else None
             nbytes = _lib.query("samble_proj_fwd_tri_workspace_bytes")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             _lib.call("samble_proj_fwd_split_tri_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
                       qkv.data_ptr(), qkv.stride(0), qkv.stride(1), q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(),
-                      _p(k_tr), _p(v_rm), 1 if q_only else 0, ws.data_ptr(), nbytes, _stream())
-        return qkv, ((q_img, k_img, v_img, k_tr, v_rm) if images == "fwd+bwd" else (q_img, k_img, v_img))
+                      _p(k_tr), _p(v_rm), 1 if q_only else 0, _p(w_tr), ws.data_ptr(), nbytes, _stream())
+        return qkv, ((q_img, k_img, v_img, k_tr, v_rm, w_tr) if images == "fwd+bwd" else (q_img, k_img, v_img))
     with torch.cuda.device(x.device):
         qkv = torch.empty((B, N + nt, 3 * C), dtype=torch.float32, device=x.device)
         tri = MATRIX_MODE == "tri"
@@ -105,8 +108,9 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, i
     return qkv
 
 
-def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
-    """-> (dx (B,C,N) | None, dW (3C,C) | None, dtokens (C,nt) | None)."""
+def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool, w_tr: Optional[torch.Tensor] = None):
+    """-> (dx (B,C,N) | None, dW (3C,C) | None, dtokens (C,nt) | None).  w_tr: the transposed operand image of w_qkv as
+    stage_proj_fwd(images="fwd+bwd") returned it (MATRIX_MODE "tri"; the weights must not have changed since)."""
     _need_gpu(dqkv, x, tokens, w_qkv)
     x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
     if dqkv.stride(2) != 1:
@@ -120,9 +124,14 @@ def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool):
         tri = MATRIX_MODE == "tri"
         nbytes = _lib.query("samble_proj_bwd_tri_workspace_bytes" if tri else "samble_proj_workspace_bytes", B, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        _lib.call("samble_proj_bwd_tri_f32" if tri else "samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
-                  tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
-                  _stream())
+        if tri:
+            _lib.call("samble_proj_bwd_tri_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
+                      tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(w_tr), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(),
+                      nbytes, _stream())
+        else:
+            _lib.call("samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
+                      tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
+                      _stream())
     return dx, dw, dtok
 
 

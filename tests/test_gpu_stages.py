@@ -887,7 +887,10 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
             qkv2, imgs2 = o_.stage_proj_fwd(x, tokens, w, images=want)
             torch.cuda.synchronize()
             assert torch.equal(qkv2, qkv)
-            assert len(imgs2) == (5 if want == "fwd+bwd" else 3)
+            assert len(imgs2) == (6 if want == "fwd+bwd" else 3)
+            if want == "fwd+bwd":  # ... + the transposed image of W for the projection's own backward
+                _, w_tr = o_.stage_tri_split(w.unsqueeze(0), want_rm=False, want_tr=True)
+                assert torch.equal(imgs2[5], w_tr)
             for j, (a, b2) in enumerate(zip(imgs, imgs2)):
                 assert torch.equal(a, b2), (want, "image", j, int((a != b2).sum()))
             # SAMBLE_PROJ_ROWS_Q_ONLY: the same images, the Q columns, the token rows and a ragged last tile's rows; the K / V
