@@ -228,6 +228,13 @@ int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
  * sources' per-point rows over a point's reverse neighbours). */
 int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K, int C,
                                 int per_edge, int64_t n_targets, float* out, void* stream);
+/* The lists themselves, on the device and without a sort (a query lists a target at most once -- the rows of nn hold
+ * distinct indices, as samble_knn_f32 writes them -- so "ascending edge id" inside a group is "ascending query": a
+ * bit matrix targets x queries, prefix popcounts, one placement pass).  nn (B,N,KN) with entries in [0, N);
+ * inv_order (B*N*KN), inv_offsets (B*N + 1), indegree (B*N) or NULL.  N < 65536. */
+size_t samble_inverse_neighbors_workspace_bytes(int B, int N);
+int samble_inverse_neighbors(const int32_t* nn, int B, int N, int KN, int32_t* inv_order, int32_t* inv_offsets,
+                             int32_t* indegree, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- autograd of downsample.py:139-147 + 242-252 ----------------------------------------------
  * g (B,D,M) = gradient w.r.t. x_ds.  Writes dQ rows idx (other rows are zeroed), dK and dV rows

@@ -37,6 +37,9 @@ _SIGNATURES = {
                                     c_void_p]),
     "samble_proj_fwd_tri_workspace_bytes": (c_size_t, []),
     "samble_proj_w_image_bytes": (c_size_t, []),
+    "samble_inverse_neighbors_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "samble_inverse_neighbors": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
     "samble_proj_bwd_tri_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -49,6 +49,8 @@ size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
 int samble_launch_seg_sum_rows64(const float*, const int*, const int*, int, int, long, float*, hipStream_t);
+size_t samble_inverse_neighbors_ws_bytes(int B, int N);
+int samble_launch_inverse_neighbors(const int*, int, int, int, int*, int*, int*, void*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
                           hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
@@ -332,6 +334,22 @@ SAMBLE_API int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const i
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: built for K = 32 neighbours, 64 channels");
   return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, kext, sdv, c0c1, B, N, du, dw2_partials, (hipStream_t)stream),
               "samble_edge_mlp_bwd_f32");
+}
+
+SAMBLE_API size_t samble_inverse_neighbors_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return samble_inverse_neighbors_ws_bytes(B, N);
+}
+
+SAMBLE_API int samble_inverse_neighbors(const int32_t* nn, int B, int N, int KN, int32_t* inv_order, int32_t* inv_offsets,
+                                        int32_t* indegree, void* ws, size_t ws_bytes, void* stream) {
+  if (!nn || !inv_order || !inv_offsets || !ws) return fail(SAMBLE_E_INVALID, "samble_inverse_neighbors: null pointer");
+  if (B <= 0 || N <= 0 || N > 65535 || KN <= 0 || (long long)B * N * KN > 2147483647LL)
+    return fail(SAMBLE_E_INVALID, "samble_inverse_neighbors: need 0 < N < 65536 and B N KN < 2^31");
+  if (ws_bytes < samble_inverse_neighbors_ws_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_inverse_neighbors: workspace too small");
+  return done(samble_launch_inverse_neighbors(nn, B, N, KN, inv_order, inv_offsets, indegree, ws, (hipStream_t)stream),
+              "samble_inverse_neighbors");
 }
 
 SAMBLE_API int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K,

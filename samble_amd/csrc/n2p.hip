@@ -423,7 +423,103 @@ __global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inverse neighbour lists without a sort.  A query lists a target at most once, so the incoming edges of target t
+// come from distinct queries and "ascending edge id" is "ascending query": the position of edge (i -> t) in t's
+// group is the number of queries i' < i that list t.  Three launches over a bit matrix (B, N targets, ceil(N/32)
+// words over the queries):
+//   mark     one thread per edge: bits[b][t][i >> 5] |= 1 << (i & 31)                        (atomic OR)
+//   count    one workgroup per cloud: per-word prefix popcounts of every target row (uint16), the row totals =
+//            in-degrees, their exclusive scan + b N K = the group boundaries
+//   place    one thread per edge: order[offset[t] + prefix[t][i >> 5] + popc(bits below i)] = e
+// Exact and run-to-run identical (the atomics only set bits).  Replaces a 2 M-key radix sort + bincount + cumsum
+// (~450 us per table at B=32, N=2048, K=32) by ~100 us.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inv_mark_kernel(const int* __restrict__ nn, int N, int K, int W, long nedges,
+                                                       unsigned* __restrict__ bits) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nedges) return;
+  const long q = e / K;           // b * N + i
+  const int i = (int)(q % N);
+  const long b = q / N;
+  const int t = nn[e];
+  if (t < 0 || t >= N) return;
+  atomicOr(&bits[(b * N + t) * W + (i >> 5)], 1u << (i & 31));
+}
+
+__global__ __launch_bounds__(1024) void inv_count_kernel(const unsigned* __restrict__ bits, int N, int K, int W,
+                                                         unsigned short* __restrict__ pre, int* __restrict__ offsets,
+                                                         int* __restrict__ indeg) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int per = (N + 1023) / 1024;
+  const int t0 = min(tid * per, N), t1 = min(t0 + per, N);
+  int mine = 0;
+  for (int t = t0; t < t1; ++t) {  // pass 1: this thread's targets' totals
+    const unsigned* row = bits + ((long)b * N + t) * W;
+    unsigned short* prow = pre + ((long)b * N + t) * W;
+    int c = 0;
+    for (int w = 0; w < W; ++w) {
+      prow[w] = (unsigned short)c;
+      c += __popc(row[w]);
+    }
+    if (indeg) indeg[(long)b * N + t] = c;
+    mine += c;
+  }
+  part[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan of the thread totals
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = (int)((long)b * N * K) + part[tid] - mine;
+  for (int t = t0; t < t1; ++t) {  // pass 2: boundaries (the totals again from the prefix of the last word)
+    const unsigned* row = bits + ((long)b * N + t) * W;
+    offsets[(long)b * N + t] = run;
+    run += (int)pre[((long)b * N + t) * W + W - 1] + __popc(row[W - 1]);
+  }
+  if (b == gridDim.x - 1 && tid == 1023) offsets[(long)gridDim.x * N] = run;
+}
+
+__global__ __launch_bounds__(256) void inv_place_kernel(const int* __restrict__ nn, int N, int K, int W, long nedges,
+                                                        const unsigned* __restrict__ bits,
+                                                        const unsigned short* __restrict__ pre,
+                                                        const int* __restrict__ offsets, int* __restrict__ order) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nedges) return;
+  const long q = e / K;
+  const int i = (int)(q % N);
+  const long b = q / N;
+  const int t = nn[e];
+  if (t < 0 || t >= N) return;
+  const long r = (b * N + t) * W + (i >> 5);
+  const int rank = (int)pre[r] + __popc(bits[r] & ((1u << (i & 31)) - 1u));
+  order[offsets[b * N + t] + rank] = (int)e;
+}
+
 }  // namespace samble
+
+extern "C" size_t samble_inverse_neighbors_ws_bytes(int B, int N) {
+  const size_t W = (size_t)(N + 31) / 32;
+  return (size_t)B * N * W * 4 + (size_t)B * N * W * 2 + 256;
+}
+
+extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int K, int* order, int* offsets, int* indeg,
+                                               void* ws, hipStream_t s) {
+  const int W = (N + 31) / 32;
+  const long nedges = (long)B * N * K;
+  unsigned* bits = reinterpret_cast<unsigned*>(ws);
+  unsigned short* pre = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + (((size_t)B * N * W * 4 + 255) & ~(size_t)255));
+  hipError_t e = hipMemsetAsync(bits, 0, (size_t)B * N * W * 4, s);
+  if (e != hipSuccess) return (int)e;
+  const unsigned blocks = (unsigned)((nedges + 255) / 256);
+  hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
+  hipLaunchKernelGGL(samble::inv_count_kernel, dim3(B), dim3(1024), 0, s, bits, N, K, W, pre, offsets, indeg);
+  hipLaunchKernelGGL(samble::inv_place_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets, order);
+  return (int)hipGetLastError();
+}
 
 extern "C" int samble_launch_seg_sum_rows64(const float* src, const int* order, const int* offs, int KN, int per_edge,
                                             long ntargets, float* out, hipStream_t s) {

@@ -152,14 +152,22 @@ def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff
 def inverse_neighbors(nn_idx: torch.Tensor):
     """Inverse neighbour lists of a kNN table nn_idx (B,N,K): (order (B*N*K) int32 = edge ids
     e = (b*N + i)*K + k grouped by target b*N + nn[e], ascending e inside a group; offsets (B*N + 1) int32).
-    A stable sort of the table: radix sort on the GPU, deterministic."""
+    = a stable sort of the table by target, built on the device without sorting (samble_inverse_neighbors); counts (B*N)
+    int32 = the in-degrees."""
+    _need_gpu(nn_idx)
     B, N, K = nn_idx.shape
-    flat = (nn_idx.long() + (torch.arange(B, device=nn_idx.device) * N).view(B, 1, 1)).reshape(-1)
-    order = torch.sort(flat, stable=True)[1].to(torch.int32)
-    counts = torch.bincount(flat, minlength=B * N)
-    offsets = torch.zeros(B * N + 1, dtype=torch.int32, device=nn_idx.device)
-    offsets[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return order.contiguous(), offsets, counts
+    nn_idx = nn_idx.contiguous()
+    if nn_idx.dtype != torch.int32:
+        nn_idx = nn_idx.to(torch.int32)
+    with torch.cuda.device(nn_idx.device):
+        order = torch.empty(B * N * K, dtype=torch.int32, device=nn_idx.device)
+        offsets = torch.empty(B * N + 1, dtype=torch.int32, device=nn_idx.device)
+        counts = torch.empty(B * N, dtype=torch.int32, device=nn_idx.device)
+        nbytes = _lib.query("samble_inverse_neighbors_workspace_bytes", B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=nn_idx.device)
+        _lib.call("samble_inverse_neighbors", nn_idx.data_ptr(), B, N, K, order.data_ptr(), offsets.data_ptr(),
+                  counts.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return order, offsets, counts
 
 
 def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torch.Tensor, K: int, per_edge: bool):

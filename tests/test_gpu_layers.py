@@ -478,3 +478,24 @@ def test_point2point_attention_against_reference_fixture(name):
         ref = torch.from_numpy(d["grad__" + pname])
         err = float((p.grad.cpu() - ref).abs().max())
         assert err <= 1e-3 * float(ref.abs().max()) + 1e-6, (pname, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,K", [(2, 300, 16), (3, 2048, 32), (1, 33, 4), (2, 1000, 3), (1, 4100, 32)])
+def test_inverse_neighbour_lists_equal_a_stable_sort(B, N, K):
+    """samble_inverse_neighbors (bit matrix + prefix popcounts, no sort) against the definition: the edge ids
+    e = (b N + i) K + k in a STABLE sort by target b N + nn[e], the group boundaries and the in-degrees."""
+    from samble_amd import ops
+    g = torch.Generator().manual_seed(40 + N)
+    # rows of distinct indices (what the kNN writes): a random permutation's first K entries per query
+    nn = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).to(torch.int32)
+    nn = nn.to(DEV)
+    order, offsets, counts = ops.inverse_neighbors(nn)
+    flat = (nn.long() + (torch.arange(B, device=DEV) * N).view(B, 1, 1)).reshape(-1)
+    ref_order = torch.sort(flat, stable=True)[1].to(torch.int32)
+    ref_counts = torch.bincount(flat, minlength=B * N)
+    ref_offsets = torch.zeros(B * N + 1, dtype=torch.int64, device=DEV)
+    ref_offsets[1:] = torch.cumsum(ref_counts, 0)
+    assert torch.equal(order, ref_order)
+    assert torch.equal(offsets.long(), ref_offsets)
+    assert torch.equal(counts.long(), ref_counts)
