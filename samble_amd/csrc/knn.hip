@@ -412,15 +412,18 @@ static bool knn_uses_fused(int C, int K, int Nk, int variant) {
 static bool knn_uses_small_fused(int C, int K, int Nk, int variant) {
   return C <= 8 && !(variant & kVarTwoKernel) && Nk <= 65536 && Nk >= K;
 }
-static bool knn_uses_tri(int C, int K, int Nk, int variant) {
-  return C == 128 && !(variant & kVarF32) && knn_uses_fused(C, K, Nk, variant);
+extern "C" int samble_knn_duo_supported(int C, int K, int Nk);
+extern "C" size_t samble_knn_duo_image_bytes(int B, int C, int N);
+extern "C" int samble_launch_knn_duo_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                                          int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
+                                          float* qnorm, float* knorm, hipStream_t s);
+extern "C" int samble_launch_knn_duo(const void* qimg, int Nq, const void* kimg, int Nk, int B, int C, int K,
+                                     const float* qnorm, const float* knorm, const float* inv_scale, int* idx, float* d2,
+                                     hipStream_t s);
+// two fp16 planes per operand on the matrix cores (knn_duo.hip): the default for C in {64, 128}, K in {16, 32}
+static bool knn_uses_duo(int C, int K, int Nk, int variant) {
+  return !(variant & (kVarF32 | kVarTwoKernel)) && samble_knn_duo_supported(C, K, Nk) && Nk >= 2 * K;
 }
-
-extern "C" size_t samble_knn_tri_image_bytes(int B, int N);
-extern "C" int samble_launch_knn_tri_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
-                                          float* mean, void* qimg, void* kimg, float* qnorm, float* knorm, hipStream_t s);
-extern "C" int samble_launch_knn_tri(const void* qimg, int Nq, const void* kimg, int Nk, int B, int K, const float* qnorm,
-                                     const float* knorm, int* idx, float* d2, hipStream_t s);
 
 extern "C" int samble_launch_cloud_mean(const float* x, long bs, int C, int N, int B, float* mean, hipStream_t s) {
   hipLaunchKernelGGL(cloud_mean_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, x, bs, C, N, mean);
@@ -429,20 +432,22 @@ extern "C" int samble_launch_cloud_mean(const float* x, long bs, int C, int N, i
 
 // the key matrix (B*Nk*Nq floats) is only needed by the two-kernel path; the MFMA paths that form the Gram in
 // fp32 (C >= 16) work on centred copies of the two sets
-static bool knn_centres_copy(int C, int K, int Nk, int variant) { return C > 8 && !knn_uses_tri(C, K, Nk, variant); }
+static bool knn_centres_copy(int C, int K, int Nk, int variant) { return C > 8 && !knn_uses_duo(C, K, Nk, variant); }
 static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K, int variant) {
   const size_t key_matrix =
       (knn_uses_fused(C, K, Nk, variant) || knn_uses_small_fused(C, K, Nk, variant)) ? 0 : (size_t)B * Nk * Nq;
   const size_t centred = knn_centres_copy(C, K, Nk, variant) ? (size_t)B * C * ((size_t)Nq + Nk) : 0;
-  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + (size_t)B * C +
+  // (mean B*C; the duo path: + the key set's scratch mean, two per-channel extents, 1/scale per cloud)
+  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + (size_t)4 * B * C + B +
                    centred + 64;
   return (n + 63) & ~(size_t)63;  // what follows (operand images) stays 256-byte aligned
 }
 
-// C = 128 fused: + the split-bf16 operand images of the two point sets (knn_tri.hip)
+// duo path: + the fp16 operand images of the two point sets (knn_duo.hip)
 extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K, int variant) {
   size_t n = knn_base_floats(B, C, Nq, Nk, K, variant);
-  if (knn_uses_tri(C, K, Nk, variant)) n += (samble_knn_tri_image_bytes(B, Nq) + samble_knn_tri_image_bytes(B, Nk)) / 4;
+  if (knn_uses_duo(C, K, Nk, variant))
+    n += (samble_knn_duo_image_bytes(B, C, Nq) + samble_knn_duo_image_bytes(B, C, Nk)) / 4;
   return n;
 }
 
@@ -477,15 +482,20 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   bool have_qnorm = false;
   if (fused) {
     int rc = 0;
-    if (knn_uses_tri(C, K, Nk, variant)) {
-      // bf16 matrix cores on split fp32 operands: centred images + norms of the point sets first (one
+    if (knn_uses_duo(C, K, Nk, variant)) {
+      // fp16 matrix cores on two-plane operands: centred, scaled images + norms of the point sets first (one
       // image if the sets coincide)
       char* kimg = reinterpret_cast<char*>(ws + knn_base_floats(B, C, Nq, Nk, K, variant));
       const bool same = xq == xk && Nq == Nk && q_bs == k_bs;
-      char* qimg = same ? kimg : kimg + samble_knn_tri_image_bytes(B, Nk);
-      rc = samble_launch_knn_tri_prep(xq, q_bs, Nq, same ? nullptr : xk, k_bs, Nk, B, mean, qimg, kimg, qnorm, knorm, stream);
+      char* qimg = same ? kimg : kimg + samble_knn_duo_image_bytes(B, C, Nk);
+      float* amax = mean + (size_t)2 * B * C;
+      float* inv_scale = mean + (size_t)4 * B * C;
+      rc = samble_launch_knn_duo_prep(xq, q_bs, Nq, same ? nullptr : xk, k_bs, Nk, B, C, mean, amax, inv_scale, qimg, kimg,
+                                      qnorm, knorm, stream);
       have_qnorm = true;
-      if (!rc) rc = samble_launch_knn_tri(qimg, Nq, kimg, Nk, B, K, same ? knorm : qnorm, knorm, idx_out, kout, stream);
+      if (!rc)
+        rc = samble_launch_knn_duo(qimg, Nq, kimg, Nk, B, C, K, same ? knorm : qnorm, knorm, inv_scale, idx_out, kout,
+                                   stream);
     } else {
       hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);
       rc = samble_launch_knn_stream(xq, q_bs, Nq, xk, k_bs, Nk, B, C, K, knorm, idx_out, kout, stream);

@@ -1,0 +1,761 @@
+// Fused Gram + top-K kNN on the fp16 matrix cores: every operand carried as TWO fp16 planes ("duo").
+//
+// Replaces torch.cdist + topk of utils/ops.py:35-43 for C in {64, 128}, K in {16, 32}.
+//
+// Why two fp16 planes and not the three bf16 planes of tri_dev.h: the neighbour ORDER is invariant under a common
+// scale of the cloud, so the centred points are first multiplied by a power of two that puts the cloud's largest
+// coordinate just under 2^13 -- no overflow, and fp16's short exponent range costs nothing.  x~ = h + m with
+// h = fp16(x), m = fp16(x - h) keeps 22 significant bits of every coordinate (absolute residual <= 2^-22 |x|, or
+// 2^-25 of a unit that is 2^-13 of the cloud's extent where m is subnormal).  The kernel then computes the distances
+// between the points x~ -- the cloud moved by <= 2^-22 per coordinate, which changes no neighbour set of any test
+// cloud (tests/test_gpu_stages.py: agreement with the fp64 order) -- with three matrix products per pair
+// (h h + h m + m h; the dropped m m is <= 2^-22 |a||b|) instead of six: half the matrix work and 2/3 of the
+// bytes per tile of the bf16 scheme, and a seed pass (leading product only) whose error bound is 8x tighter.
+//
+// Structure (workgroup = 8 waves = 256 queries, two waves per SIMD, key tiles of 32 rows by LDS-DMA):
+//   pass A (seed)   leading product h h over all key tiles (8 MFMAs per tile at C = 128): per half-lane the ceil(K/2)
+//                   largest per-tile maxima; T = the smaller of the two halves' last entries: at least K keys have
+//                   an approximate value >= T, hence an exact one >= T - e (e: fp16 rounding of both operands +
+//                   accumulation, by Cauchy-Schwarz) = the row's cut;
+//   pass B (exact)  three products per tile; an accumulator entry passes when >= cut (sign bits collected by
+//                   v_alignbit); the row's survivors (K + ~10 on unstructured data) are appended to ONE ring per
+//                   row in LDS -- no sorted list is maintained inside the loop;
+//   ranking         once, after the scan: the wave takes its rows one at a time, lane = ring entry, rank = number of
+//                   entries with a smaller (distance, index) -- written straight to the output in rank order.
+//                   The same routine is the ring's overflow handler (degenerate clouds, where every key ties): it
+//                   keeps the best K of a row in rank order and raises the row's cut to the K-th.
+#include <type_traits>
+
+#include "tri_dev.h"
+
+namespace samble {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kDuoCap = 56;    // ring slots per query row (<= 64: a lane of the ranking wave per slot)
+constexpr int kDuoRS = 257;    // entries per ring slot row: 256 queries + 1 (odd: a row's column is conflict-free too)
+// |leading product - exact| <= kDuoErrMul |a| max|b| + kDuoErrAdd max|b|^2: fp16 rounding of both operands
+// (2 x 2^-11 + 2^-22, summed over the channels by Cauchy-Schwarz) and fp32 accumulation of either product
+// (< 2^-18 of |a||b| + |b|^2/2), with 8 % of slack
+constexpr float kDuoErrMul = 0.0011f;
+constexpr float kDuoErrAdd = 3e-6f;
+
+template <int C>
+struct Duo {
+  static constexpr int kSteps = C / 16;       // MFMA k-steps of a contraction over the channels
+  static constexpr int kPlane = 32 * C * 2;   // bytes of one plane of a 32-row tile
+  static constexpr int kTile = 2 * kPlane;    // plane h, then plane m; chunk (g = channel / 8, r) at (g * 32 + r) * 16
+};
+
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// per (cloud, channel): mean over the points and largest |x| (one wave each, fixed order)
+__global__ __launch_bounds__(256) void cloud_mean_amax_kernel(const float* __restrict__ x, long bs, int C, int N,
+                                                              float* __restrict__ mean, float* __restrict__ amax) {
+  const int b = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (c >= C) return;
+  const float* p = x + (long)b * bs + (long)c * N;
+  float s = 0.f, mx = 0.f;
+  int n = 0;
+  if ((N & 3) == 0 && (bs & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) {
+    for (; n + 8 * 256 <= N; n += 8 * 256) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + n + 256 * u + 4 * lane);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+      }
+    }
+    for (; n + 256 <= N; n += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + n + 4 * lane);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  }
+  for (n += lane; n < N; n += 64) {
+    s += p[n];
+    mx = fmaxf(mx, fabsf(p[n]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if (lane == 0) {
+    mean[b * C + c] = s / (float)N;
+    amax[b * C + c] = mx;
+  }
+}
+
+// channel-major fp32 (B, C, N) -> duo image of the CENTRED, SCALED points (rows = points, contraction = channels),
+// their squared norms |x~|^2 (of the values the image holds, fixed order) and 1 / scale per cloud.
+// scale = 2^(12 - e), e = exponent of max_c (amax_c + |mean_c|) >= max |x - mean|: the scaled coordinates stay below 2^13
+template <int C>
+__global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restrict__ x, long bs, int N,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ amax, char* __restrict__ img_all,
+                                                           float* __restrict__ norm_all,
+                                                           float* __restrict__ inv_scale_out) {
+  __shared__ float part[C / 8][33];
+  __shared__ float sbound;
+  const int tile = blockIdx.x, b = blockIdx.y, ntiles = gridDim.x, tid = threadIdx.x;
+  const float* xb = x + (long)b * bs;
+  const float* mb = mean + b * C;
+  if (tid < 64) {
+    float v = 0.f;
+    for (int c = tid; c < C; c += 64) v = fmaxf(v, amax[b * C + c] + fabsf(mb[c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (tid == 0) sbound = v;
+  }
+  __syncthreads();
+  const int e = (int)((__float_as_uint(sbound) >> 23) & 0xFFu) - 127;
+  const int se = max(-100, min(100, 12 - e));
+  const float s = __uint_as_float((unsigned)(se + 127) << 23), inv = __uint_as_float((unsigned)(127 - se) << 23);
+  char* img = img_all + ((long)b * ntiles + tile) * Duo<C>::kTile;
+  for (int el = tid; el < 32 * (C / 8); el += 256) {
+    const int r = el & 31, g = el >> 5, n = tile * 32 + r;
+    unsigned hw[4], mw[4];
+    float p = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float xt[2];
+      unsigned short hb[2], mbits[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = 8 * g + 2 * i + u;
+        const float v = (n < N) ? (xb[(long)c * N + n] - mb[c]) * s : 0.f;
+        const _Float16 h = (_Float16)v;            // round to nearest even
+        const _Float16 m = (_Float16)(v - (float)h);  // the subtraction is exact
+        xt[u] = (float)h + (float)m;                // exact: the planes do not overlap
+        hb[u] = __builtin_bit_cast(unsigned short, h);
+        mbits[u] = __builtin_bit_cast(unsigned short, m);
+      }
+      hw[i] = (unsigned)hb[0] | ((unsigned)hb[1] << 16);
+      mw[i] = (unsigned)mbits[0] | ((unsigned)mbits[1] << 16);
+      p = fmaf(xt[0], xt[0], p);
+      p = fmaf(xt[1], xt[1], p);
+    }
+    *reinterpret_cast<u32x4*>(img + (g * 32 + r) * 16) = u32x4{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<u32x4*>(img + Duo<C>::kPlane + (g * 32 + r) * 16) = u32x4{mw[0], mw[1], mw[2], mw[3]};
+    part[g][r] = p;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int g = 0; g < C / 8; ++g) sacc += part[g][tid];
+    const int n = tile * 32 + tid;
+    if (n < N) norm_all[(long)b * N + n] = sacc;
+  }
+  if (tile == 0 && tid == 0 && inv_scale_out) inv_scale_out[b] = inv;
+}
+
+// amax <- max(amax, other): the key set's extent enters the common scale
+__global__ void duo_amax_merge_kernel(float* __restrict__ amax, const float* __restrict__ other, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) amax[e] = fmaxf(amax[e], other[e]);
+}
+
+__device__ __forceinline__ unsigned duo_partner32(unsigned v, int h) {  // value of lane ^ 32 (v_permlane32_swap)
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return h ? r[0] : r[1];
+}
+__device__ __forceinline__ float duo_readlane_f(float v, int l) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+// k-steps whose two LDS operand planes are requested two steps before their MFMAs (tri_pipelined for two planes)
+struct DuoOp {
+  u32x4 h, m;
+};
+template <int NSTEP, class Fetch, class Use>
+__device__ __forceinline__ void duo_pipelined(Fetch fetch, Use use) {
+  DuoOp a0 = fetch(0), a1 = fetch(NSTEP > 1 ? 1 : 0);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    DuoOp a2 = a1;
+    if (i + 2 < NSTEP) a2 = fetch(i + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    use(i, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = a1;
+    a1 = a2;
+  }
+}
+
+#ifdef SAMBLE_KNN_STAMP
+#define DUO_T0() const long long st_t0 = clock64(); long long st_seed = 0, st_prod = 0, st_sel = 0, st_bar = 0, st_tmp = 0, st_prunes = 0
+#define DUO_BEGIN() st_tmp = clock64()
+#define DUO_END(acc) acc += clock64() - st_tmp
+#else
+#define DUO_T0()
+#define DUO_BEGIN()
+#define DUO_END(acc)
+#endif
+
+template <int C>
+struct DuoLds {  // byte offsets of the workgroup's dynamic LDS
+  static constexpr int kTiles = 4 * Duo<C>::kTile;         // pass B: ring of 4 tiles; pass A: ring of 8 h planes
+  static constexpr int kBns = kTiles;                      // 4 x 32 key norms of the tiles in flight
+  static constexpr int kScratch = kBns + 4 * 32 * 4;       // ranking: 8 waves x (72 + 64 + 72) words
+  static constexpr int kQa = kScratch + 8 * 208 * 4;       // ring: accumulator values [slot][row]
+  static constexpr int kQj = kQa + kDuoCap * kDuoRS * 4;   // ring: key codes
+  static constexpr int kTotal = kQj + kDuoCap * kDuoRS * 2;
+  static_assert(kTotal <= 160 * 1024 && (kTotal & 15) == 0, "LDS budget");
+};
+
+template <int KN, int C>
+__global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict__ Qimg, int Nq,
+                                                         const char* __restrict__ Kimg, int Nk,
+                                                         const float* __restrict__ qnorm,
+                                                         const float* __restrict__ knorm,
+                                                         const float* __restrict__ inv_scale, int* __restrict__ idx_out,
+                                                         float* __restrict__ d2_out) {
+  using D = Duo<C>;
+  using L = DuoLds<C>;
+  constexpr int NT = 512, NW = 8, NS = D::kSteps;
+  constexpr int KS = (3 * KN + 3) / 4;            // per-tile maxima kept per half-lane in pass A
+  constexpr int kPieces = D::kTile / (NT * 16);   // 16-byte LDS-DMA pieces per thread and tile (2 at C = 128)
+  constexpr bool kAllSeed = D::kPlane >= NT * 16;  // every thread moves a piece of an h plane (C = 128)
+  static_assert(kPieces * NT * 16 == D::kTile, "tile must be a whole number of pieces per thread");
+  static_assert(KN + 16 <= kDuoCap && kDuoCap <= 64, "a prune must leave room for half a tile's candidates; lane = slot");
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  float* bns = reinterpret_cast<float*>(smem_c + L::kBns);
+  float* qa = reinterpret_cast<float*>(smem_c + L::kQa);
+  unsigned short* qj = reinterpret_cast<unsigned short*>(smem_c + L::kQj);
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int i = chunk * (32 * NW) + wave * 32 + lo;
+  const int qrow = min(i, Nq - 1);
+  const int qtiles = (Nq + 31) / 32, ntiles = (Nk + 31) / 32;
+  const char* Kb = Kimg + (long)b * ntiles * D::kTile;
+  const float* knb = knorm + (long)b * Nk;
+  DUO_T0();
+
+  // query operand: both planes, k-step ks of half h = channel group 2 ks + h
+  u32x4 qh[NS], qm[NS];
+  {
+    const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (qrow >> 5)) * D::kTile) + h * 32 +
+                      (qrow & 31);
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      qh[ks] = qp[64 * ks];
+      qm[ks] = qp[64 * ks + D::kPlane / 16];
+    }
+  }
+  const float an = qnorm[(long)b * Nq + qrow];
+  const float half_an = 0.5f * an;
+
+  // ---- pass A: lower bound of this query's K-th best accumulator value -------------------------------------
+  // h planes through a ring of 8 slots, two tiles per barrier, DMAs three pairs ahead; a tile's 12 operand reads are
+  // issued one tile before its MFMAs (every wave of the workgroup passes the barrier at the same time: with the reads
+  // right behind it the LDS array serves all eight waves' 24 reads before any MFMA can start)
+  float cut;
+  {
+    float* nrm = reinterpret_cast<float*>(smem_c + L::kTotal) - ntiles * 32;  // key norms as accumulator start values
+    float* red = bns;                                                         // 8 partial maxima
+    auto glds_h = [&](int t) {  // plane h of tile t, verbatim
+      if (kAllSeed || tid < D::kPlane / 16) {
+        const char* gt = Kb + (long)min(t, ntiles - 1) * D::kTile + tid * 16;
+        char* lt = smem_c + (t & 7) * D::kPlane + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gt,
+                                         (__attribute__((address_space(3))) void*)lt, 16, 0, 0);
+      }
+    };
+    auto wait3 = [&]() {  // all but this thread's three newest plane DMAs have landed
+      if (kAllSeed || wave < D::kPlane / 1024) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+    float bmax = 0.f;
+    for (int j = tid; j < ntiles * 32; j += NT) {
+      const float v = (j < Nk) ? knb[j] : 0.f;
+      nrm[j] = -0.5f * v;
+      bmax = fmaxf(bmax, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+    if (lane == 0) red[wave] = bmax;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 6; ++t) glds_h(t);
+    float G[KS];  // the KS largest per-tile maxima of this half-lane, descending
+#pragma unroll
+    for (int s = 0; s < KS; ++s) G[s] = -__builtin_huge_valf();
+    wait3();  // tiles 0..2
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    struct SeedOps {
+      u32x4 k[NS];
+      f32x4 n[4];
+    };
+    auto seed_fetch = [&](int t) {
+      SeedOps o;
+      const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t & 7) * D::kPlane) + 32 * h + lo;
+      const float* np = nrm + min(t, ntiles - 1) * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.n[g] = *reinterpret_cast<const f32x4*>(np + 8 * g);
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) o.k[ks] = lp[64 * ks];
+      return o;
+    };
+    auto seed_products = [&](const SeedOps& o) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = o.n[g][e];
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) acc = mfma_h(o.k[ks], qh[ks], acc);
+      return acc;
+    };
+    auto seed_reduce = [&](f32x16 acc, int t, auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;  // the last tile: padding keys past Nk must not count
+      if (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 32 + crow(r, h) >= Nk) acc[r] = -__builtin_huge_valf();
+      }
+      float gm = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);  // v_max3_f32
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[r]), acc[r + 1]);
+      gm = fmaxf(gm, acc[15]);
+      // sorted insertion into the descending list: G[s] <- median(G[s-1], G[s], gm)
+#pragma unroll
+      for (int s = KS - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
+      G[0] = fmaxf(G[0], gm);
+    };
+    // One tile of the steady state, WOVEN: the wave issues in order and an MFMA holds its issue for 8 of the 32 cycles
+    // it runs, so whatever is to overlap the matrix pipe has to sit between the MFMAs in program order (measured
+    // un-woven: the two waves of a SIMD run their MFMA blocks together and their vector blocks together, 1 060
+    // cycles per tile against 512 of matrix time).  Behind MFMA ks of tile t come a share of (a) the operand reads
+    // of tile tn (12 ds_read_b128 into `nxt`), (b) the reduction of the PREVIOUS tile's accumulator `pa`: maximum
+    // over the lane's 16 keys (8 v_max3), (c) its sorted insertion (KS v_med3).
+    auto seed_step = [&](const SeedOps& cur, SeedOps& nxt, const f32x16& pa, int tn) {
+      f32x16 acc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = cur.n[g][e];
+      const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (tn & 7) * D::kPlane) + 32 * h + lo;
+      const float* np = nrm + min(tn, ntiles - 1) * 32 + 4 * h;
+      constexpr int F = 4 + NS + 8 + KS, PER = (F + NS - 1) / NS;
+      float gm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NS; ++ks) {
+        acc = mfma_h(cur.k[ks], qh[ks], acc);
+#pragma unroll
+        for (int it = ks * PER; it < (ks + 1) * PER && it < F; ++it) {
+          if (it < 4) {
+            nxt.n[it] = *reinterpret_cast<const f32x4*>(np + 8 * it);
+          } else if (it < 4 + NS) {
+            nxt.k[it - 4] = lp[64 * (it - 4)];
+          } else if (it == 4 + NS) {
+            gm = __builtin_fmaxf(__builtin_fmaxf(pa[0], pa[1]), pa[2]);
+          } else if (it < 4 + NS + 7) {
+            const int r = 3 + 2 * (it - (4 + NS) - 1);
+            gm = __builtin_fmaxf(__builtin_fmaxf(gm, pa[r]), pa[r + 1]);
+          } else if (it == 4 + NS + 7) {
+            gm = fmaxf(gm, pa[15]);
+          } else {
+            const int sl = KS - 1 - (it - (4 + NS + 8));
+            if (sl > 0) G[sl] = __builtin_amdgcn_fmed3f(G[sl - 1], G[sl], gm);
+            else G[0] = fmaxf(G[0], gm);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return acc;
+    };
+    const int nfull = Nk / 32;
+    int t = 0;
+    f32x16 accp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = -__builtin_huge_valf();  // (its reduction changes nothing)
+    SeedOps oa = seed_fetch(0), ob;
+    // two FULL tiles per barrier; DMAs three pairs ahead
+    for (; t + 2 <= nfull; t += 2) {
+      DUO_BEGIN();
+      glds_h(t + 6);  // slots of tiles t-2, t-1: read two / one iteration(s) ago, before a barrier
+      glds_h(t + 7);
+      __builtin_amdgcn_sched_barrier(0);
+      DUO_END(st_sel);
+      const f32x16 acc0 = seed_step(oa, ob, accp, t + 1);
+      accp = seed_step(ob, oa, acc0, t + 2);  // (tile t + 2 has landed: the previous barrier vouches for tiles <= t + 2)
+      DUO_BEGIN();
+      wait3();  // tiles <= t + 4 have landed for this wave; after the barrier for every wave
+      DUO_END(st_prod);
+      DUO_BEGIN();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      DUO_END(st_bar);
+    }
+    if (t > 0) seed_reduce(accp, t - 1, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (t < ntiles) seed_reduce(seed_products(oa), t, std::true_type{});  // the remaining one or two tiles
+    if (t + 1 < ntiles) seed_reduce(seed_products(seed_fetch(t + 1)), t + 1, std::true_type{});
+    float bm = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) bm = fmaxf(bm, red[w]);
+    // T = the KN-th largest of the two half-lanes' lists together (2 KS >= KN distinct keys): with x_i the i-th
+    // largest of a list, max over i of min(mine_i, theirs_(KN-i)); the same value in both half-lanes
+    float T = -__builtin_huge_valf();
+#pragma unroll
+    for (int ii = KN - KS; ii <= KS; ++ii) {
+      const float theirs = __uint_as_float(duo_partner32(__float_as_uint(G[KN - ii - 1]), h));
+      T = fmaxf(T, fminf(G[ii - 1], theirs));
+    }
+    const float err = (kDuoErrMul * sqrtf(an) * sqrtf(bm) + kDuoErrAdd * bm) * 1.0001f;
+    const float c = T - err;
+    cut = c - fabsf(c) * 0x1p-21f - 0x1p-100f;  // (-inf stays -inf: too few tiles)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // seed ring, norms, red are free
+  }
+#ifdef SAMBLE_KNN_STAMP
+  st_seed = clock64() - st_t0;
+  const long long sd_wait = st_prod, sd_bar = st_bar, sd_dma = st_sel;
+  st_prod = st_bar = st_sel = 0;
+#ifndef SAMBLE_KNN_SEEDABL
+#define SAMBLE_KNN_SEEDABL 0  // 8: stop after pass A (timing of the pass alone, scratch builds)
+#endif
+  if (SAMBLE_KNN_SEEDABL & 8) {
+    if (lane == 0 && d2_out) {
+      float* o = d2_out + ((long)b * Nq + chunk * (32 * NW) + wave * 32) * KN;
+      o[0] = (float)st_seed; o[5] = (float)st_seed; o[1] = cut;
+    }
+    return;
+  }
+#endif
+
+  // ---- pass B: exact values, survivors into the row's ring ---------------------------------------------------
+  auto glds = [&](int t) {
+    const char* gt = Kb + (long)min(t, ntiles - 1) * D::kTile;
+    char* lt = smem_c + (t & 3) * D::kTile;
+#pragma unroll
+    for (int k = 0; k < kPieces; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gt + (tid + NT * k) * 16),
+                                       (__attribute__((address_space(3))) void*)(lt + (wave * 64 + NT * k) * 16), 16, 0,
+                                       0);
+    // the tile's 32 key norms by DMA as well (a register load in this loop would be waited for with vmcnt(0)).
+    // Keys past Nk get the last key's norm: their candidates are masked (last tile).
+    if (wave == 0) {
+      const int jn = min(t * 32 + lane, Nk - 1);  // (always issued: the waits below count it)
+      if (lane < 32)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(knb + jn),
+                                         (__attribute__((address_space(3))) void*)(bns + (t & 3) * 32), 4, 0, 0);
+    }
+  };
+  // wait until all but the DMAs of the newest tile have landed (wave 0 carries one more piece per tile: the norms)
+  auto wait_newest_only = [&]() {
+    if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces + 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces) : "memory");
+  };
+  glds(0);
+  glds(1);
+  glds(2);
+
+  // the two half-lanes of a row share its ring without talking to each other: half 0 fills slots 0, 1, ..., half 1
+  // slots kDuoCap-1, kDuoCap-2, ...
+  int cnt = 0;  // entries of this half-lane
+  const int ring_base = (h ? (kDuoCap - 1) * kDuoRS : 0) + wave * 32 + lo, ring_step = h ? -kDuoRS : kDuoRS;
+  const int final_base = chunk * (32 * NW) + wave * 32;
+  const float inv = inv_scale[b];
+
+  // Ranks the entries of a row: lane = entry, rank = number of the row's entries with a smaller (w, index),
+  // w = max(|a|^2/2 - acc, 0): every lane meets every entry as a broadcast LDS read.  FINAL (every row): the K best
+  // go to the output in rank order.  Otherwise (rows whose ring cannot take `incoming` more entries): they go back
+  // to slots 0..KN-1 in rank order and the row's cut rises to the K-th entry's accumulator value, exclusive --
+  // later keys have larger indices and lose ties (+inf when w_K = 0: nothing can displace it).
+  auto rank_rows = [&](auto final_c, int incoming) {
+    constexpr bool FINAL = decltype(final_c)::value;
+#ifdef SAMBLE_KNN_STAMP
+    if (!FINAL) ++st_prunes;
+#endif
+    unsigned* rkw = reinterpret_cast<unsigned*>(smem_c + L::kScratch) + wave * 208;  // 72 words: the entries' w
+    unsigned* cw = rkw + 72;                                                           // 64 words: lane of a rank
+    unsigned* rkj = cw + 64;                                                           // 72 words: the entries' index
+    for (int row = 0; row < 32; ++row) {
+      const int c0 = __builtin_amdgcn_readlane(cnt, row), c = c0 + __builtin_amdgcn_readlane(cnt, row + 32);
+      if (!FINAL) {
+        const int inc = __builtin_amdgcn_readlane(incoming, row) + __builtin_amdgcn_readlane(incoming, row + 32);
+        if (c + inc <= kDuoCap) continue;
+      }
+      const float han = duo_readlane_f(half_an, row);
+      const bool have = lane < c;
+      const int slot = (lane < c0 ? lane : kDuoCap - 1 - (lane - c0)) * kDuoRS + wave * 32 + row;
+      const float a = have ? qa[slot] : 0.f;
+      const unsigned code = have ? (unsigned)qj[slot] : 0u;
+      const float w = fmaxf(han - a, 0.f);
+      const unsigned j = (code >> 5) * 32 + (code & 3) + 8 * ((code >> 2) & 3) + 4 * ((code >> 4) & 1);
+      const unsigned wb = have ? __float_as_uint(w) : 0xFFFFFFFFu;  // w >= 0: its bits order like the value
+      rkw[lane] = wb;
+      int rank = 0;
+      for (int s = 0; s < c; s += 8) {  // (entries past c hold 0xFFFFFFFF: never smaller)
+        const u32x4 p0 = *reinterpret_cast<const u32x4*>(rkw + s), p1 = *reinterpret_cast<const u32x4*>(rkw + s + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rank += (p0[e] < wb ? 1 : 0) + (p1[e] < wb ? 1 : 0);
+      }
+      // entries of equal w share a rank: seen as two lanes claiming the same word; then the index decides
+      // (volatile: another lane's store to the same word is the point)
+      if (have) reinterpret_cast<volatile unsigned*>(cw)[rank] = lane;
+      const bool clash = have && reinterpret_cast<volatile unsigned*>(cw)[rank] != (unsigned)lane;
+      if (__any(clash)) {
+        rkj[lane] = j;
+        for (int s = 0; s < c; ++s) rank += (rkw[s] == wb && rkj[s] < j) ? 1 : 0;
+      }
+      if (FINAL) {
+        const int irow = final_base + row;
+        if (irow < Nq) {
+          const long o = ((long)b * Nq + irow) * KN;
+          if (have && rank < KN) {
+            idx_out[o + rank] = (int)j;
+            if (d2_out) d2_out[o + rank] = 2.f * w * inv * inv;
+          } else if (!have && lane < KN) {  // fewer than K survivors: only with non-finite inputs
+            idx_out[o + lane] = 0;
+            if (d2_out) d2_out[o + lane] = __builtin_huge_valf();
+          }
+        }
+      } else {
+        if (have && rank < KN) {
+          const int ns = rank * kDuoRS + wave * 32 + row;
+          qa[ns] = a;
+          qj[ns] = (unsigned short)code;
+        }
+        const unsigned long long mk = __ballot(have && rank == KN - 1);
+        const int src = __builtin_ctzll(mk | (1ull << 63));
+        const float ak = duo_readlane_f(a, src), wk = duo_readlane_f(w, src);
+        const float up = ak == 0.f ? 0x1p-149f : __uint_as_float(__float_as_uint(ak) + (ak > 0.f ? 1u : 0xFFFFFFFFu));
+        if (lo == row && c >= KN) {
+          cut = fmaxf(cut, wk > 0.f ? up : __builtin_huge_valf());
+          cnt = h ? 0 : KN;  // the K survivors sit in half 0's slots, in rank order
+        }
+      }
+    }
+  };
+
+  // the start of a tile's products -- accumulator start values and the operands of the first two k-steps -- is
+  // fetched before the other phase of the iteration, so that no LDS latency stands in front of the first MFMA
+  struct Head {
+    f32x4 n[4];
+    DuoOp a0, a1;
+  };
+  auto head = [&](int t) {
+    Head hd;
+    const int buf = t & 3;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hd.n[g] = *reinterpret_cast<const f32x4*>(bns + buf * 32 + 8 * g + 4 * h);
+    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + buf * D::kTile) + 32 * h + lo;
+    hd.a0 = DuoOp{lp[0], lp[D::kPlane / 16]};
+    hd.a1 = DuoOp{lp[NS > 1 ? 64 : 0], lp[(NS > 1 ? 64 : 0) + D::kPlane / 16]};
+    return hd;
+  };
+  auto products = [&](const Head& hd, int t) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] = -0.5f * hd.n[g][e];
+    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t & 3) * D::kTile) + 32 * h + lo;
+    DuoOp a0 = hd.a0, a1 = hd.a1;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      DuoOp a2 = a1;
+      if (ks + 2 < NS) a2 = DuoOp{lp[64 * (ks + 2)], lp[64 * (ks + 2) + D::kPlane / 16]};
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma_h(a0.m, qh[ks], acc);
+      acc = mfma_h(a0.h, qm[ks], acc);
+      acc = mfma_h(a0.h, qh[ks], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+      a1 = a2;
+    }
+    return acc;
+  };
+  const unsigned validbits_last = [&]() {  // bit (15 - r) set: key crow(r, h) of the LAST tile exists
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= ((ntiles - 1) * 32 + crow(r, h) < Nk) ? (1u << (15 - r)) : 0u;
+    return m;
+  }();
+  // filter of tile tt's accumulator (d_r = acc_r - cut: sign bit clear <=> passes) and append of the survivors
+  auto select = [&](const f32x16 accv, int tt) {
+    // sixteen scalars (each pinned by an empty asm), not a vector: the optimiser turns a select between two vector
+    // elements into a dynamically indexed extract, which the backend expands into 16 compare + select pairs
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[r] = accv[r];
+      asm volatile("" : "+v"(acc[r]));
+    }
+    auto filter = [&]() {
+      unsigned sb = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sb = __builtin_amdgcn_alignbit(sb, __float_as_uint(acc[r] - cut), 31);
+      const unsigned bits = ~sb & 0xFFFFu;  // bit (15 - r): element r passes
+      return tt == ntiles - 1 ? bits & validbits_last : bits;
+    };
+    auto no_room = [&](unsigned sel) {
+      const int mine = cnt + (int)__popc(sel);
+      return __any(mine + (int)duo_partner32((unsigned)mine, h) > kDuoCap);
+    };
+    const unsigned codebase = ((unsigned)tt << 5) | ((unsigned)h << 4);
+    auto append = [&](unsigned bits) {
+      while (__any(bits != 0)) {
+        const int pos = __builtin_ctz(bits | 0x10000u);
+        int r = 15 - pos;  // (-1 for a lane without candidates: it writes nothing)
+        // (opaque to the optimiser: knowing r's range it turns the 15-select tree below into 16 compare + select pairs)
+        asm volatile("" : "+v"(r));
+        const bool b0 = r & 1, b1 = r & 2, b2 = r & 4;
+        const float e0 = b0 ? acc[1] : acc[0], e1 = b0 ? acc[3] : acc[2], e2 = b0 ? acc[5] : acc[4];
+        const float e3 = b0 ? acc[7] : acc[6], e4 = b0 ? acc[9] : acc[8], e5 = b0 ? acc[11] : acc[10];
+        const float e6 = b0 ? acc[13] : acc[12], e7 = b0 ? acc[15] : acc[14];
+        const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+        const float g0 = b2 ? f1 : f0, g1 = b2 ? f3 : f2;
+        float val = (r & 8) ? g1 : g0;
+        asm volatile("" : "+v"(val));  // (formed here, not re-derived inside the branch)
+        if (bits != 0) {
+          const int slot = ring_base + cnt * ring_step;
+          qa[slot] = val;
+          qj[slot] = (unsigned short)(codebase | (unsigned)r);
+          ++cnt;
+        }
+        bits &= bits - 1;
+      }
+    };
+    unsigned bits = filter();
+    if (no_room(bits)) {  // rare: structured or degenerate clouds
+      rank_rows(std::false_type{}, (int)__popc(bits));
+      bits = filter();  // under the raised cuts
+      if (no_room(bits)) {
+        // a row takes more than kDuoCap - KN candidates from this one tile: half 0's first (<= 16), another prune,
+        // then half 1's
+        append(h == 0 ? bits : 0u);
+        rank_rows(std::false_type{}, h == 1 ? (int)__popc(bits) : 0);
+        bits = h == 1 ? filter() : 0u;
+      }
+    }
+    append(bits);
+  };
+  wait_newest_only();  // tiles 0 and 1 (and their norms) have landed for this wave
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  const bool mfma_first = wave < 4;
+  f32x16 acc;  // high waves: the accumulator of the previous tile, filtered at the start of the next iteration
+  Head hd = head(0);
+  for (int t = 0; t < ntiles; ++t) {
+    glds(t + 3);  // into the buffer that was read in iteration t - 1
+    DUO_BEGIN();
+    if (mfma_first) {
+      acc = products(hd, t);
+      __builtin_amdgcn_sched_barrier(0);
+      hd = head(t + 1);  // (landed: the previous barrier vouches for tiles <= t + 1)
+      DUO_END(st_prod);
+      DUO_BEGIN();
+      select(acc, t);
+      DUO_END(st_sel);
+    } else {
+      if (t > 0) select(acc, t - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      DUO_END(st_sel);
+      DUO_BEGIN();
+      acc = products(hd, t);
+      __builtin_amdgcn_sched_barrier(0);
+      hd = head(t + 1);
+      DUO_END(st_prod);
+    }
+    DUO_BEGIN();
+    wait_newest_only();  // tiles <= t + 2 have landed for this wave; after the barrier for every wave
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DUO_END(st_bar);
+  }
+  if (!mfma_first) select(acc, ntiles - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SAMBLE_KNN_STAMP
+  const long long st_loop = clock64() - st_t0;
+  if (d2_out) {  // diagnostic build: the distance output carries the stamps of (cloud, chunk, wave)
+    int mx = cnt + (int)duo_partner32((unsigned)cnt, h), sm = mx;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      mx = max(mx, __shfl_xor(mx, o, 64));
+      sm += __shfl_xor(sm, o, 64);
+    }
+    rank_rows(std::true_type{}, 0);
+    if (lane == 0 && final_base < Nq) {
+      float* o = d2_out + ((long)b * Nq + final_base) * KN;
+      o[0] = (float)st_seed; o[1] = (float)st_prod; o[2] = (float)st_sel; o[3] = (float)st_bar;
+      o[4] = (float)st_loop; o[5] = (float)(clock64() - st_t0); o[6] = (float)st_prunes; o[7] = (float)mx;
+      o[8] = (float)sm / 32.f; o[9] = (float)sd_dma; o[10] = (float)sd_wait; o[11] = (float)sd_bar;
+    }
+    return;
+  }
+#endif
+  rank_rows(std::true_type{}, 0);
+}
+
+template <int KN, int C>
+static int launch_knn_duo(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
+                          const float* knorm, const float* inv_scale, int* idx, float* d2, hipStream_t s) {
+  constexpr int NT = 512;
+  const size_t lds = DuoLds<C>::kTotal;
+  auto kern = knn_duo_kernel<KN, C>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_knn, s);
+  hipLaunchKernelGGL(kern, dim3((Nq + 255) / 256, B), dim3(NT), lds, s, qimg, Nq, kimg, Nk, qnorm, knorm, inv_scale, idx,
+                     d2);
+  return (int)hipGetLastError();
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+// pass A keeps all key norms in LDS beside its ring of h planes
+extern "C" int samble_knn_duo_supported(int C, int K, int Nk) {
+  if (!((C == 128 || C == 64) && (K == 32 || K == 16) && Nk >= K)) return 0;
+  const size_t room = C == 128 ? DuoLds<128>::kTotal - 8 * Duo<128>::kPlane : DuoLds<64>::kTotal - 8 * Duo<64>::kPlane;
+  return (size_t)((Nk + 31) / 32) * 32 * 4 <= room;
+}
+
+// image bytes for one point set of a (B, C, N) cloud batch
+extern "C" size_t samble_knn_duo_image_bytes(int B, int C, int N) { return (size_t)B * ((N + 31) / 32) * 128 * C; }
+
+// centred, scaled operand images and squared norms of the two point sets (xk == nullptr: the key set is the query
+// set); mean (B*C), amax (B*C), inv_scale (B): scratch / outputs
+extern "C" int samble_launch_knn_duo_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
+                                          int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
+                                          float* qnorm, float* knorm, hipStream_t s) {
+  Timed timed(kT_knn_prep, s);
+  hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xq, q_bs, C, Nq, mean, amax);
+  if (xk) {
+    // the key set is centred on the QUERY set's mean too (utils/ops.py:23-25): its extent enters the bound
+    float* amax_k = amax + (size_t)B * C;
+    float* mean_k = mean + (size_t)B * C;  // (scratch: the key set's own mean is not used)
+    hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xk, k_bs, C, Nk, mean_k, amax_k);
+    hipLaunchKernelGGL(duo_amax_merge_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, amax, amax_k, B * C);
+  }
+  if (C == 128) {
+    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
+    hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
+  } else {
+    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
+    hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_knn_duo(const void* qimg, int Nq, const void* kimg, int Nk, int B, int C, int K,
+                                     const float* qnorm, const float* knorm, const float* inv_scale, int* idx, float* d2,
+                                     hipStream_t s) {
+  const char* q = (const char*)qimg;
+  const char* k = (const char*)kimg;
+  if (C == 128 && K == 32) return launch_knn_duo<32, 128>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 128 && K == 16) return launch_knn_duo<16, 128>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 64 && K == 32) return launch_knn_duo<32, 64>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 64 && K == 16) return launch_knn_duo<16, 64>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  return -22;
+}

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Phase cycles of knn_tri_kernel from a -DSAMBLE_KNN_STAMP build (diagnostic: the distance output carries stamps)."""
+"""Phase cycles of knn_duo_kernel from a -DSAMBLE_KNN_STAMP scratch build (tools/knn_stamp_run.sh): the distance
+output carries the stamps of every wave.  usage: knn_stamps.py <lib.so> [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from samble_amd import _lib, synth
-B, C, N, K = 32, 128, 2048, 32
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+B, C, K = 32, 128, 32
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 x = torch.from_numpy(synth.features(B, C, N, 2001)).cuda()
 idx = torch.empty((B, N, K), dtype=torch.int32, device="cuda")
 dist = torch.zeros((B, N, K), dtype=torch.float32, device="cuda")
@@ -17,7 +20,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 # keys buffer inside the workspace: [knorm B*N][qnorm B*N][scale B][keys B*N*K]
 keys = ws.view(torch.float32)[2 * B * N + B: 2 * B * N + B + B * N * K].view(B, N // 32, 32, K)[:, :, 0, :12]
-names = ["seed", "prod+filter", "drain", "barrier", "loop_end", "total", "steps", "tail", "sel:filter", "sel:append", "sel:insert", "sel:cut"]
+names = ["seed", "products", "select", "barrier", "loop_end", "total", "prunes", "max ring", "mean ring", "seed:dma", "seed:wait", "seed:barrier"]
 m = keys.reshape(-1, 12).double()
 m = m[m[:, 5] > 0]  # rows that carry stamps (one per wave)
 for i, n in enumerate(names):
