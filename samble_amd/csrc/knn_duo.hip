@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void cloud_mean_amax_kernel(const float* __res
 }
 
 // channel-major fp32 (B, C, N) -> duo image of the CENTRED, SCALED points (rows = points, contraction = channels),
-// their squared norms |x~|^2 (of the values the image holds, fixed order) and 1 / scale per cloud.
+// -|x~|^2 / 2 of every point (of the values the image holds, fixed order) and 1 / scale per cloud.
 // scale = 2^(12 - e), e = exponent of max_c (amax_c + |mean_c|) >= max |x - mean|: the scaled coordinates stay below 2^13
 template <int C>
 __global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restrict__ x, long bs, int N,
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restri
 #pragma unroll
     for (int g = 0; g < C / 8; ++g) sacc += part[g][tid];
     const int n = tile * 32 + tid;
-    if (n < N) norm_all[(long)b * N + n] = sacc;
+    if (n < N) norm_all[(long)b * N + n] = -0.5f * sacc;  // the accumulator start value of the point as a key
   }
   if (tile == 0 && tid == 0 && inv_scale_out) inv_scale_out[b] = inv;
 }
@@ -168,6 +168,54 @@ __device__ __forceinline__ unsigned duo_partner32(unsigned v, int h) {  // value
 __device__ __forceinline__ float duo_readlane_f(float v, int l) {
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
 }
+
+// LDS reads whose wait is placed by hand.  The compiler counts lgkmcnt itself, but not across the branches of the
+// woven selection and not the way the weave needs it: it hoists a step's prefetch reads above the step's first MFMA
+// and then waits for ALL of them (lgkmcnt(0)) to get at that MFMA's operands -- an exposed LDS round trip in front of
+// every group of MFMAs (tools/micro/weave_bench.hip: +45..70 cycles per MFMA slot).  An asm read is opaque to it: the
+// destination counts as written at the asm statement, so every consumer sits behind an explicit
+// `s_waitcnt lgkmcnt(n)` (n = reads issued later that may still be in flight; LDS returns in order) and an empty asm
+// that "rewrites" the registers (uses cannot rise above it).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_ld128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// One append block of the woven selection (knn_duo_kernel, pass B): under the lane mask `m` (skipped when empty) the
+// accumulator value `val` and the key code vcode | R go to ring slot min(cnt, lim) of the lane's half of the row's
+// ring -- byte addresses ba + slot * sa (values) and bj + slot * sj (codes), one v_mad_i32_i24 each -- and cnt grows.
+// One asm statement: the compiler must neither move any of this out from under the mask nor anything else into it.
+template <int R>
+__device__ __forceinline__ void duo_append(int& cnt, unsigned long long m, int lim, int sa, int ba, int sj, int bj,
+                                           float val, unsigned vcode) {
+  int t0, t1;
+  asm volatile(
+      "s_mov_b64 exec, %[m]\n\t"
+      "s_cbranch_execz 1f\n\t"
+      "v_min_i32 %[t0], %[cnt], %[lim]\n\t"
+      "v_mad_i32_i24 %[t1], %[t0], %[sa], %[ba]\n\t"
+      "v_mad_i32_i24 %[t0], %[t0], %[sj], %[bj]\n\t"
+      "ds_write_b32 %[t1], %[val]\n\t"
+      "v_or_b32 %[t1], %[rr], %[vc]\n\t"
+      "ds_write_b16 %[t0], %[t1]\n\t"
+      "v_add_u32 %[cnt], 1, %[cnt]\n"
+      "1:\n\t"
+      "s_mov_b64 exec, -1"
+      : [cnt] "+v"(cnt), [t0] "=&v"(t0), [t1] "=&v"(t1)
+      : [m] "s"(m), [lim] "v"(lim), [sa] "v"(sa), [ba] "v"(ba), [sj] "v"(sj), [bj] "v"(bj), [val] "v"(val), [rr] "n"(R),
+        [vc] "v"(vcode)
+      : "memory");
+}
+
+#define DUO_LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 // k-steps whose two LDS operand planes are requested two steps before their MFMAs (tri_pipelined for two planes)
 struct DuoOp {
@@ -204,8 +252,9 @@ struct DuoLds {  // byte offsets of the workgroup's dynamic LDS
   static constexpr int kBns = kTiles;                      // 4 x 32 key norms of the tiles in flight
   static constexpr int kScratch = kBns + 4 * 32 * 4;       // ranking: 8 waves x (72 + 64 + 72) words
   static constexpr int kQa = kScratch + 8 * 208 * 4;       // ring: accumulator values [slot][row]
-  static constexpr int kQj = kQa + kDuoCap * kDuoRS * 4;   // ring: key codes
-  static constexpr int kTotal = kQj + kDuoCap * kDuoRS * 2;
+  static constexpr int kQj = kQa + (kDuoCap + 1) * kDuoRS * 4;   // ring: key codes (slot kDuoCap: a dummy for lanes
+                                                                 // without a candidate)
+  static constexpr int kTotal = (kQj + (kDuoCap + 1) * kDuoRS * 2 + 15) & ~15;
   static_assert(kTotal <= 160 * 1024 && (kTotal & 15) == 0, "LDS budget");
 };
 
@@ -251,8 +300,8 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
       qm[ks] = qp[64 * ks + D::kPlane / 16];
     }
   }
-  const float an = qnorm[(long)b * Nq + qrow];
-  const float half_an = 0.5f * an;
+  const float half_an = -qnorm[(long)b * Nq + qrow];  // (the norm arrays hold -|x|^2 / 2)
+  const float an = 2.f * half_an;
 
   // ---- pass A: lower bound of this query's K-th best accumulator value -------------------------------------
   // h planes through a ring of 8 slots, two tiles per barrier, DMAs three pairs ahead; a tile's 12 operand reads are
@@ -276,8 +325,8 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
     float bmax = 0.f;
     for (int j = tid; j < ntiles * 32; j += NT) {
       const float v = (j < Nk) ? knb[j] : 0.f;
-      nrm[j] = -0.5f * v;
-      bmax = fmaxf(bmax, v);
+      nrm[j] = v;
+      bmax = fmaxf(bmax, -2.f * v);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
@@ -336,40 +385,53 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
     // cycles per tile against 512 of matrix time).  Behind MFMA ks of tile t come a share of (a) the operand reads
     // of tile tn (12 ds_read_b128 into `nxt`), (b) the reduction of the PREVIOUS tile's accumulator `pa`: maximum
     // over the lane's 16 keys (8 v_max3), (c) its sorted insertion (KS v_med3).
-    auto seed_step = [&](const SeedOps& cur, SeedOps& nxt, const f32x16& pa, int tn) {
+    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_c);  // (LDS byte address of the dynamic block)
+    const unsigned nrm_a = lds0 + (unsigned)L::kTotal - (unsigned)ntiles * 128u + 16u * h;
+    const unsigned key_a = lds0 + (32u * h + lo) * 16u;
+    auto seed_step = [&](SeedOps& cur, SeedOps& nxt, const f32x16& pa, int tn) {
+      // `cur` was read one step ago and nothing has been read since
+      DUO_LGKM_WAIT(0);
+      static_assert(NS == 8 || NS == 4, "operand anchors below are written out");
+      if constexpr (NS == 8)
+        asm volatile("" : "+v"(cur.k[0]), "+v"(cur.k[1]), "+v"(cur.k[2]), "+v"(cur.k[3]), "+v"(cur.k[4]), "+v"(cur.k[5]),
+                          "+v"(cur.k[6]), "+v"(cur.k[7]), "+v"(cur.n[0]), "+v"(cur.n[1]), "+v"(cur.n[2]), "+v"(cur.n[3]));
+      else
+        asm volatile("" : "+v"(cur.k[0]), "+v"(cur.k[1]), "+v"(cur.k[2]), "+v"(cur.k[3]), "+v"(cur.n[0]), "+v"(cur.n[1]),
+                          "+v"(cur.n[2]), "+v"(cur.n[3]));
       f32x16 acc;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[4 * g + e] = cur.n[g][e];
-      const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (tn & 7) * D::kPlane) + 32 * h + lo;
-      const float* np = nrm + min(tn, ntiles - 1) * 32 + 4 * h;
+      const unsigned la = key_a + (unsigned)(tn & 7) * D::kPlane;
+      const unsigned na = nrm_a + (unsigned)min(tn, ntiles - 1) * 128u;
       constexpr int F = 4 + NS + 8 + KS, PER = (F + NS - 1) / NS;
       float gm = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < NS; ++ks) {
+      static_for<0, NS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
         acc = mfma_h(cur.k[ks], qh[ks], acc);
-#pragma unroll
-        for (int it = ks * PER; it < (ks + 1) * PER && it < F; ++it) {
-          if (it < 4) {
-            nxt.n[it] = *reinterpret_cast<const f32x4*>(np + 8 * it);
-          } else if (it < 4 + NS) {
-            nxt.k[it - 4] = lp[64 * (it - 4)];
-          } else if (it == 4 + NS) {
+        static_for<ks * PER, ((ks + 1) * PER < F ? (ks + 1) * PER : F)>([&](auto it_c) {
+          constexpr int it = decltype(it_c)::value;
+          if constexpr (it < 4) {
+            nxt.n[it] = __builtin_bit_cast(f32x4, lds_ld128<32 * it>(na));
+          } else if constexpr (it < 4 + NS) {
+            nxt.k[it - 4] = lds_ld128<1024 * (it - 4)>(la);
+          } else if constexpr (it == 4 + NS) {
             gm = __builtin_fmaxf(__builtin_fmaxf(pa[0], pa[1]), pa[2]);
-          } else if (it < 4 + NS + 7) {
-            const int r = 3 + 2 * (it - (4 + NS) - 1);
+          } else if constexpr (it < 4 + NS + 7) {
+            constexpr int r = 3 + 2 * (it - (4 + NS) - 1);
             gm = __builtin_fmaxf(__builtin_fmaxf(gm, pa[r]), pa[r + 1]);
-          } else if (it == 4 + NS + 7) {
+          } else if constexpr (it == 4 + NS + 7) {
             gm = fmaxf(gm, pa[15]);
           } else {
-            const int sl = KS - 1 - (it - (4 + NS + 8));
-            if (sl > 0) G[sl] = __builtin_amdgcn_fmed3f(G[sl - 1], G[sl], gm);
+            constexpr int sl = KS - 1 - (it - (4 + NS + 8));
+            if constexpr (sl > 0) G[sl] = __builtin_amdgcn_fmed3f(G[sl - 1], G[sl], gm);
             else G[0] = fmaxf(G[0], gm);
           }
-        }
+        });
+        asm volatile("" : "+v"(acc), "+v"(gm));
         __builtin_amdgcn_sched_barrier(0);
-      }
+      });
       return acc;
     };
     const int nfull = Nk / 32;
@@ -396,6 +458,12 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
     }
     if (t > 0) seed_reduce(accp, t - 1, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (NS == 8)  // (`oa` may come from the last step's asm reads: complete now)
+      asm volatile("" : "+v"(oa.k[0]), "+v"(oa.k[1]), "+v"(oa.k[2]), "+v"(oa.k[3]), "+v"(oa.k[4]), "+v"(oa.k[5]),
+                        "+v"(oa.k[6]), "+v"(oa.k[7]), "+v"(oa.n[0]), "+v"(oa.n[1]), "+v"(oa.n[2]), "+v"(oa.n[3]));
+    else
+      asm volatile("" : "+v"(oa.k[0]), "+v"(oa.k[1]), "+v"(oa.k[2]), "+v"(oa.k[3]), "+v"(oa.n[0]), "+v"(oa.n[1]),
+                        "+v"(oa.n[2]), "+v"(oa.n[3]));
     if (t < ntiles) seed_reduce(seed_products(oa), t, std::true_type{});  // the remaining one or two tiles
     if (t + 1 < ntiles) seed_reduce(seed_products(seed_fetch(t + 1)), t + 1, std::true_type{});
     float bm = red[0];
@@ -461,6 +529,7 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
   // slots kDuoCap-1, kDuoCap-2, ...
   int cnt = 0;  // entries of this half-lane
   const int ring_base = (h ? (kDuoCap - 1) * kDuoRS : 0) + wave * 32 + lo, ring_step = h ? -kDuoRS : kDuoRS;
+  const int ring_a = L::kQa + 4 * ring_base, ring_j = L::kQj + 2 * ring_base;  // byte offsets of the lane's slot 0
   const int final_base = chunk * (32 * NW) + wave * 32;
   const float inv = inv_scale[b];
 
@@ -552,28 +621,6 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
     hd.a1 = DuoOp{lp[NS > 1 ? 64 : 0], lp[(NS > 1 ? 64 : 0) + D::kPlane / 16]};
     return hd;
   };
-  auto products = [&](const Head& hd, int t) {
-    f32x16 acc;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * g + e] = -0.5f * hd.n[g][e];
-    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t & 3) * D::kTile) + 32 * h + lo;
-    DuoOp a0 = hd.a0, a1 = hd.a1;
-#pragma unroll
-    for (int ks = 0; ks < NS; ++ks) {
-      DuoOp a2 = a1;
-      if (ks + 2 < NS) a2 = DuoOp{lp[64 * (ks + 2)], lp[64 * (ks + 2) + D::kPlane / 16]};
-      __builtin_amdgcn_sched_barrier(0);
-      acc = mfma_h(a0.m, qh[ks], acc);
-      acc = mfma_h(a0.h, qm[ks], acc);
-      acc = mfma_h(a0.h, qh[ks], acc);
-      __builtin_amdgcn_sched_barrier(0);
-      a0 = a1;
-      a1 = a2;
-    }
-    return acc;
-  };
   const unsigned validbits_last = [&]() {  // bit (15 - r) set: key crow(r, h) of the LAST tile exists
     unsigned m = 0;
 #pragma unroll
@@ -642,36 +689,149 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
   wait_newest_only();  // tiles 0 and 1 (and their norms) have landed for this wave
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  const bool mfma_first = wave < 4;
-  f32x16 acc;  // high waves: the accumulator of the previous tile, filtered at the start of the next iteration
-  Head hd = head(0);
-  for (int t = 0; t < ntiles; ++t) {
-    glds(t + 3);  // into the buffer that was read in iteration t - 1
-    DUO_BEGIN();
-    if (mfma_first) {
-      acc = products(hd, t);
-      __builtin_amdgcn_sched_barrier(0);
-      hd = head(t + 1);  // (landed: the previous barrier vouches for tiles <= t + 1)
-      DUO_END(st_prod);
-      DUO_BEGIN();
-      select(acc, t);
-      DUO_END(st_sel);
-    } else {
-      if (t > 0) select(acc, t - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      DUO_END(st_sel);
-      DUO_BEGIN();
-      acc = products(hd, t);
-      __builtin_amdgcn_sched_barrier(0);
-      hd = head(t + 1);
-      DUO_END(st_prod);
+  // One tile of the steady state, WOVEN like pass A: the wave issues in order and an MFMA holds its issue port for 8
+  // of its 32 cycles, so only what stands between the MFMAs in program order overlaps the matrix pipe.  Behind the
+  // MFMAs of tile t (3 NS of them) come
+  //   (a) the selection of the PREVIOUS tile's accumulator `pav` (tile tp), one accumulator register r at a time:
+  //       v_cmp against the cut, and under the resulting lane mask (skipped when it is empty: 30 % of the registers)
+  //       the append to the row's ring -- value = the register as it stands, no per-lane bit masks, no select tree,
+  //       no data-dependent loop: 16 + 5 per non-empty register instead of ~150 vector instructions per tile (the
+  //       kernel is bound by vector issue: 20.5 k instructions per wave against 2 k MFMAs, profiles/r03_*);
+  //   (b) the operand reads two k-steps ahead, and at the end the head of tile t + 1.
+  // Room in the ring is not counted beforehand: the two half-lanes of a row split what is free at the start of the
+  // tile (minus a spare slot each, where entries past a half's share land); a half that would have needed more
+  // shows at the end of the tile (cnt > lim): then the tile's appends are undone (cnt back to its value at the
+  // start) and the exact unwoven path (select) takes the tile.  Rare: rows hold ~38 of 56 slots at the end of the scan.
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_c);  // (LDS byte address of the dynamic block)
+  const unsigned key_b = lds0 + (32u * h + lo) * 16u, bns_b = lds0 + (unsigned)L::kBns + 16u * h;
+  auto weave_tile = [&](auto sel_c, Head& hd, Head& hdn, const f32x16& pav, int tp, int t) {
+#ifndef SAMBLE_KNN_BABL
+#define SAMBLE_KNN_BABL 0  // timing-only ablations of pass B (scratch builds): 1 no selection, 2 no operand reads, 4 no MFMA
+#endif
+    constexpr bool SEL = decltype(sel_c)::value && !(SAMBLE_KNN_BABL & 1);
+    // the head was read at the end of the previous tile (or before the loop) and nothing has been read since
+    DUO_LGKM_WAIT(0);
+    asm volatile("" : "+v"(hd.n[0]), "+v"(hd.n[1]), "+v"(hd.n[2]), "+v"(hd.n[3]), "+v"(hd.a0.h), "+v"(hd.a0.m),
+                      "+v"(hd.a1.h), "+v"(hd.a1.m));
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[4 * g + e] = hd.n[g][e];
+    const unsigned ta = key_b + (unsigned)(t & 3) * D::kTile, tna = key_b + (unsigned)((t + 1) & 3) * D::kTile;
+    const unsigned bna = bns_b + (unsigned)((t + 1) & 3) * 128u;
+    const int cnt0 = cnt;
+    int lim = 0;
+    bool bad = false;
+    unsigned vcode = 0;
+    float cut_t = cut;
+    unsigned long long pass[16];
+    const int step_a = 4 * ring_step, step_j = 2 * ring_step;
+    if (SEL) {
+      const int fre = kDuoCap - cnt - (int)duo_partner32((unsigned)cnt, h);
+      bad = __any(fre < 2);
+      lim = cnt + ((fre - 2) >> 1);
+      cut_t = bad ? __builtin_huge_valf() : cut;  // (nothing is appended here then; NaN inputs aside)
+      vcode = ((unsigned)tp << 5) | ((unsigned)h << 4);
     }
+    constexpr int NSLOT = 3 * NS;
+    DuoOp a0 = hd.a0, a1 = hd.a1, a2 = hd.a1;
+    static_for<0, NS>([&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+      if constexpr (ks >= 2) {
+        // operands of k-step ks: read two k-steps ago; the reads issued one k-step ago may still be in flight
+        if constexpr (ks + 1 < NS) DUO_LGKM_WAIT(2);
+        else DUO_LGKM_WAIT(4);
+        asm volatile("" : "+v"(a0.h), "+v"(a0.m));
+      }
+      static_for<0, 3>([&](auto j_c) {
+        constexpr int j3 = decltype(j_c)::value, q = 3 * ks + j3;
+        if constexpr (!(SAMBLE_KNN_BABL & 4)) {
+          if constexpr (j3 == 0) acc = mfma_h(a0.m, qh[ks], acc);
+          if constexpr (j3 == 1) acc = mfma_h(a0.h, qm[ks], acc);
+          if constexpr (j3 == 2) acc = mfma_h(a0.h, qh[ks], acc);
+        } else {
+          acc[j3] += __uint_as_float(a0.h[j3] ^ qh[ks][j3]);
+        }
+        if constexpr (j3 == 0 && !(SAMBLE_KNN_BABL & 2)) {
+          if constexpr (ks + 2 < NS) {
+            a2.h = lds_ld128<1024 * (ks + 2)>(ta);
+            a2.m = lds_ld128<1024 * (ks + 2) + D::kPlane>(ta);
+          } else if constexpr (ks + 2 == NS) {
+            hdn.n[0] = __builtin_bit_cast(f32x4, lds_ld128<0>(bna));
+            hdn.n[1] = __builtin_bit_cast(f32x4, lds_ld128<32>(bna));
+            hdn.n[2] = __builtin_bit_cast(f32x4, lds_ld128<64>(bna));
+            hdn.n[3] = __builtin_bit_cast(f32x4, lds_ld128<96>(bna));
+          } else {
+            hdn.a0.h = lds_ld128<0>(tna);
+            hdn.a0.m = lds_ld128<D::kPlane>(tna);
+            hdn.a1.h = lds_ld128<(NS > 1 ? 1024 : 0)>(tna);
+            hdn.a1.m = lds_ld128<(NS > 1 ? 1024 : 0) + D::kPlane>(tna);
+          }
+        }
+        if constexpr (SEL) {
+          // masks of ALL registers first (slot 0: 16 independent v_cmp into scalar registers), so that no append block
+          // starts with a vector -> scalar round trip; then one block per register, under its mask, skipped when empty
+          if constexpr (q == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pass[r] = __ballot(pav[r] >= cut_t);
+          }
+          static_for<q * 16 / NSLOT, (q + 1) * 16 / NSLOT>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
+            // slot index min(cnt, lim) -> byte addresses by one v_mad_i32_i24 each; value = the register as it stands.
+            // One asm statement: the compiler must neither move anything of this out from under the mask nor into it.
+            duo_append<r>(cnt, pass[r], lim, step_a, ring_a, step_j, ring_j, pav[r], vcode);
+          });
+        }
+        // the slot ends in an anchor: what it computed cannot sink below it, what the next slot computes cannot rise
+        // above it (IR-level code motion does not respect sched_barrier: without anchors all MFMAs end up in front)
+        asm volatile("" : "+v"(acc), "+v"(cnt) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      a0 = a1;
+      a1 = a2;
+    });
+    if (SEL) {
+      if (bad || __any(cnt > lim)) {
+        cnt = cnt0;
+        select(pav, tp);
+      }
+    }
+    return acc;
+  };
+
+  // two tiles per trip so that the heads and the accumulators swap roles instead of being copied
+  f32x16 acc_a = {}, acc_b;
+  Head hd_a = head(0), hd_b;
+  auto tile_end = [&]() {
     DUO_BEGIN();
     wait_newest_only();  // tiles <= t + 2 have landed for this wave; after the barrier for every wave
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // this tile's operand reads are done (the 8 reads of the next tile's head, of another buffer, may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(8)\n\ts_barrier" ::: "memory");
     DUO_END(st_bar);
+  };
+  glds(3);
+  DUO_BEGIN();
+  acc_a = weave_tile(std::false_type{}, hd_a, hd_b, acc_a, -1, 0);
+  DUO_END(st_prod);
+  tile_end();
+  for (int t = 1; t < ntiles; t += 2) {
+    glds(t + 3);  // into the buffer that was read in iteration t - 1
+    DUO_BEGIN();
+    acc_b = weave_tile(std::true_type{}, hd_b, hd_a, acc_a, t - 1, t);
+    DUO_END(st_prod);
+    tile_end();
+    if (t + 1 < ntiles) {
+      glds(t + 4);
+      DUO_BEGIN();
+      acc_a = weave_tile(std::true_type{}, hd_a, hd_b, acc_b, t, t + 1);
+      DUO_END(st_prod);
+      tile_end();
+    }
   }
-  if (!mfma_first) select(acc, ntiles - 1);
+  DUO_BEGIN();
+  select((ntiles & 1) ? acc_a : acc_b, ntiles - 1);
+  DUO_END(st_sel);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SAMBLE_KNN_STAMP
   const long long st_loop = clock64() - st_t0;
