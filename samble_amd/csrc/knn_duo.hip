@@ -597,9 +597,9 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
         const int src = __builtin_ctzll(mk | (1ull << 63));
         const float ak = duo_readlane_f(a, src), wk = duo_readlane_f(w, src);
         const float up = ak == 0.f ? 0x1p-149f : __uint_as_float(__float_as_uint(ak) + (ak > 0.f ? 1u : 0xFFFFFFFFu));
-        if (lo == row && c >= KN) {
-          cut = fmaxf(cut, wk > 0.f ? up : __builtin_huge_valf());
-          cnt = h ? 0 : KN;  // the K survivors sit in half 0's slots, in rank order
+        if (lo == row) {
+          if (c >= KN) cut = fmaxf(cut, wk > 0.f ? up : __builtin_huge_valf());
+          cnt = h ? 0 : min(c, KN);  // the survivors sit in half 0's slots, in rank order
         }
       }
     }

@@ -94,6 +94,31 @@ def test_knn_degenerate_clouds():
     assert torch.equal(hi, (N // 2 + torch.arange(K, dtype=torch.int32)).expand(N // 2, K))
 
 
+def test_knn_duplicate_burst_in_one_tile():
+    """62 copies of one point: 30 scattered over the first eight 32-key tiles, 32 filling the ninth.  For a query among
+    them every copy ties at distance 0, so its candidate ring holds 30 entries when one tile delivers 32 more: the
+    ring's overflow path has to prune a row that holds FEWER than K entries (round 3: that case left the half-lane
+    counters stale and an output slot unwritten).  Ties go by ascending index."""
+    B, C, N, K = 2, 128, 512, 32
+    x = torch.from_numpy(synth.features(B, C, N, 4242)).clone()
+    g = torch.Generator().manual_seed(7)
+    scattered = torch.randperm(256, generator=g)[:30].sort()[0]
+    dup = torch.cat([scattered, torch.arange(256, 288)])
+    x[:, :, dup] = x[:, :, dup[:1]]
+    got = ops().stage_knn(x.to(DEV), x.to(DEV), K).cpu()
+    assert int(got.min()) >= 0 and int(got.max()) < N
+    assert all(len(set(r.tolist())) == K for r in got.reshape(-1, K))
+    want = dup[:K].to(torch.int32)
+    for b in range(B):
+        assert torch.equal(got[b, dup], want.expand(len(dup), K)), "copies of a point: the K lowest indices, ascending"
+    # the other rows: which of the tied copies enter a list is arbitrary in the fp64 reference, the distances are not
+    p = x.double().permute(0, 2, 1)
+    d = ((p[:, :, None, :] - p[:, None, :, :]) ** 2).sum(-1)
+    ref_d = d.topk(K, dim=-1, largest=False)[0]
+    got_d = torch.gather(d, 2, got.long()).sort(-1)[0]
+    assert float(((got_d - ref_d).abs() > 1e-3).double().mean()) <= 5e-4
+
+
 def test_knn_ragged_sizes_fused():
     B, C, K = 2, 128, 32
     for Nq, Nk in ((200, 330), (129, 97), (1000, 1000)):
