@@ -53,7 +53,7 @@ def algorithmic_bytes_per_cloud():
         select=4 * N + 4 * N * NB + 4 * NB + 8 * M,           # score, Exp(1) noise, boundaries in; idx out
         sparse_score=8 * N * KNN + 4 * N + 12 * N,            # neighbour ids + one logit each, lse in; score, z, in-degree out
                                                               # (map-free forward: folded into attn_stats_nl_tri, no launch)
-        knn_prep=4 * N * C + 6 * N * C + 4 * N,               # points in; operand image (6 B / element) + norms out
+        knn_prep=4 * N * C + 4 * N * C + 4 * N,               # points in; operand image (two fp16 planes: 4 B / element) + norms out
         nn_prepare=4 * N * KNN + 4 * N * KNN + 4 * N * ((N + 31) // 32),  # lists in; sorted lists + one word per (tile, row) out
         tri_split=4 * 3 * C * (N + NB) + 5 * 6 * C * (N + NB),  # [Q|K|V] rows in; five operand images out
         bwd_prep=8 * M + 8 * M * C + 3 * 6 * M * C,           # idx, Q rows, dO in; three operand images of the sampled rows out
@@ -226,7 +226,17 @@ def main():
     # HIP events around every launch of the dominant kernel during the timed steps, recorded by the
     # library on the stream it launches on (two event records per step: no host sync); read back after
     # the final synchronize
+    # the dominant kernel is whichever of the big matrix kernels takes longest on this box: measured over two untimed
+    # steps before the timed region (rounds 1-2: the kNN; round 3 brought it under the sampled-row kernels)
     dominant = "knn" if tri else "bwd_rows_f32"
+    if tri:
+        cand = ["knn", "attn_stats", "attn_rows", "bwd_dq"]
+        _lib.timing_select(cand)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        seen = {n: _lib.timing_read(n) for n in cand}
+        dominant = max((n for n in cand if seen.get(n)), key=lambda n: seen[n][1], default="knn")
     _lib.timing_select([dominant])
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if world > 1:
@@ -320,9 +330,33 @@ def main():
                     "us_per_launch": round(ms * 1e3, 1), "algorithmic_bytes_per_launch": alg_bytes}
 
         dominant_ms = dom[0] if dom else float("nan")
+        import samble_amd.downsample as _dsm1
+        map_free1 = tri and _dsm1.MAP_FREE
+
+        def tri_desc(n_):
+            """(kernel name, algorithmic flops per launch, rocprof kernel name, note) of a split-bf16 step kernel"""
+            if n_ == "knn":
+                return ("knn_duo_kernel", fl["dist"] * B_PER_GPU, "samble::knn_duo_kernel",
+                        "feature-space kNN on two fp16 planes per operand: executed matrix work = 4 fp16 products per "
+                        "(query, key) pair (1 seed + 3 exact) against the 6 bf16 products the ceiling is written for: "
+                        "the fraction of the ceiling of the scheme as executed (2500 / 4) is 2/3 of `frac`")
+            if n_ == "attn_stats":
+                nm = "attn_stats_nl_tri_kernel" if map_free1 else "attn_stats_tri_kernel"
+                return (nm, fl["qk"] * B_PER_GPU, "samble::" + nm, None)
+            if n_ == "attn_rows":
+                nm = "attn_rows_rc_tri_kernel" if map_free1 else "attn_rows_tri_kernel"
+                return (nm, fl["av"] * B_PER_GPU, "samble::" + nm,
+                        ("algorithmic flops = P V only (SURVEY 8d: recomputation is not counted); the kernel also "
+                         "recomputes the sampled rows' logits: executed matrix work = 2 x algorithmic") if map_free1 else None)
+            nm = "bwd_dq_pm_tri_kernel" if map_free1 else "bwd_dq_tri_kernel"
+            return (nm, 2 * fl["av"] * B_PER_GPU, "samble::" + nm, None)
+
         if tri:
-            # dominant kernel: knn_tri (fused Gram + top-K of the feature-space kNN; algorithmic flops = the Gram)
-            result["roofline"] = roof("knn_tri_kernel", fl["dist"] * B_PER_GPU, dominant_ms, "samble::knn_tri_kernel")
+            nm, flops, pmcn, note = tri_desc(dominant)
+            result["roofline"] = roof(nm, flops, dominant_ms, pmcn)
+            if note:
+                result["roofline"]["note"] = note
+            result["roofline"]["chosen_from_us"] = {n_: round(v[1] * 1e3, 1) for n_, v in seen.items() if v}
         else:
             bwd_alg = 4 * 2 * M * N * C * B_PER_GPU
             result["roofline"] = roof("bwd_rows_kernel", bwd_alg, dominant_ms, "samble::bwd_rows_kernel")
@@ -346,21 +380,15 @@ def main():
             import samble_amd.downsample as _dsm
             map_free = tri and _dsm.MAP_FREE  # no N x (N+nt) logit map: pass 1 keeps K logits per row, pass 2 recomputes
             mf = []
-            if kt.get("attn_stats"):
-                nm = "attn_stats_nl_tri_kernel" if map_free else "attn_stats" + sfx
-                mf.append(roof(nm, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::" + nm))
-            if kt.get("attn_rows"):
-                nm = "attn_rows_rc_tri_kernel" if map_free else "attn_rows" + sfx
-                r_ = roof(nm, fl["av"] * B_PER_GPU, kt["attn_rows"][0], "samble::" + nm)
-                if map_free:
-                    r_["note"] = ("algorithmic flops = P V only (SURVEY 8d: recomputation is not counted); the kernel also "
-                                  "recomputes the sampled rows' logits: executed matrix work = 2 x algorithmic")
-                mf.append(r_)
             if tri:
-                # backward: dQ kernel = dP + dQ (2 products over N + nt keys), then dV and dK (1 product each, N keys)
-                if kt.get("bwd_dq"):
-                    nm = "bwd_dq_pm_tri_kernel" if map_free else "bwd_dq_tri_kernel"
-                    mf.append(roof(nm, 2 * fl["av"] * B_PER_GPU, kt["bwd_dq"][0], "samble::" + nm))
+                for n_ in ("knn", "attn_stats", "attn_rows", "bwd_dq"):
+                    if kt.get(n_):
+                        nm, flops, pmcn, note = tri_desc(n_)
+                        r_ = roof(nm, flops, kt[n_][0], pmcn)
+                        if note:
+                            r_["note"] = note
+                        mf.append(r_)
+                # backward: dV and dK accumulated key-stationary from the two maps (1 product each, N keys)
                 if kt.get("bwd_dv"):
                     mf.append(roof("bwd_kacc_pm_tri_kernel (dV)" if map_free else "bwd_kacc_tri_kernel<0> (dV)",
                                    2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
@@ -369,8 +397,13 @@ def main():
                 if kt.get("bwd_dk"):
                     mf.append(roof("bwd_kacc_pm_tri_kernel (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
                                    "samble::bwd_kacc_pm_tri_kernel<false>"))
-            elif kt.get("knn"):
-                mf.append(roof("knn_stream_kernel", fl["dist"] * B_PER_GPU, kt["knn"][0], "samble::knn_stream_kernel"))
+            else:
+                if kt.get("attn_stats"):
+                    mf.append(roof("attn_stats" + sfx, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::attn_stats" + sfx))
+                if kt.get("attn_rows"):
+                    mf.append(roof("attn_rows" + sfx, fl["av"] * B_PER_GPU, kt["attn_rows"][0], "samble::attn_rows" + sfx))
+                if kt.get("knn"):
+                    mf.append(roof("knn_stream_kernel", fl["dist"] * B_PER_GPU, kt["knn"][0], "samble::knn_stream_kernel"))
             pj = 2 * C * C * 3 * N * B_PER_GPU
             for n_, name, flops in (("proj_fwd", "proj_fwd" + sfx, pj), ("proj_dx", "proj_dx" + sfx, pj),
                                     ("proj_dw", ("proj_dw_tri_kernel (+ reduce and token gradients)" if tri else
@@ -395,14 +428,14 @@ def main():
             if kt.get("nn_prepare"):
                 hb.append(hbm("nn_prepare (ascending neighbour lists + membership words)", by["nn_prepare"] * B_PER_GPU,
                               kt["nn_prepare"][0], "nn_prepare_kernel"))
-            for n_, label, key in (("knn_prep", "cloud_mean + tri_split_cm (kNN operand image + norms)", "knn_prep"),
+            for n_, label, key in (("knn_prep", "cloud_mean_amax + duo_split_cm (kNN operand image + norms)", "knn_prep"),
                                    ("tri_split", "tri_split_qkv (operand images of Q, K, V)", "tri_split"),
                                    ("bwd_prep", "bwd_prep_tri (gather of the sampled rows + their operand images)", "bwd_prep")):
                 if kt.get(n_):
                     hb.append(hbm(label, by[key] * B_PER_GPU, kt[n_][0], "samble::" + label.split(" ")[0]))
             if kt.get("knn"):
                 hb.append(hbm("knn (SURVEY 8d per-kernel bytes; compute-bound by construction)", by["knn"] * B_PER_GPU,
-                              kt["knn"][0], "samble::knn_tri_kernel"))
+                              kt["knn"][0], "samble::knn_duo_kernel"))
             hb.append(hbm("whole step vs the ideal fused layer's bytes (4.20 MB/cloud)", by["fused_step"] * B_PER_GPU,
                           ms_per_step, "-"))
             result["roofline_hbm_kernels"] = hb

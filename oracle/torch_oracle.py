@@ -529,7 +529,19 @@ def local_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "local_std", k:
     def heads(t):  # (B,C,N,K) -> (B,1,N,K,D)
         return t.view(B, 1, C, t.shape[2], t.shape[3]).permute(0, 1, 3, 4, 2)
     q, kk, vv = heads(q), heads(kk), heads(vv)
-    energy = q @ kk.permute(0, 1, 2, 4, 3)                         # (B,1,N,1,K)
+    kt = kk.permute(0, 1, 2, 4, 3)                                 # (B,1,N,D,K)
+    # attention_scoring, models/downsample.py:977-1000
+    if asm in ("dot", "dot-neighbor"):
+        energy = q @ kt                                            # (B,1,N,1,K)
+    elif asm == "dot-sub":
+        energy = q @ (q.transpose(-1, -2) - kt)
+    elif asm in ("l2", "l2+"):
+        energy = (q - kt.transpose(-1, -2)) @ (q.transpose(-1, -2) - kt)   # (B,1,N,K,K)
+        if asm == "l2":
+            energy = -1 * energy
+        energy = torch.mean(energy, dim=-2).unsqueeze(-2)
+    else:
+        raise ValueError("Please check the setting of asm!")
     att = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)
     a2 = att.squeeze(-2)                                           # (B,1,N,K)
     idx4 = nidx.view(B, 1, N, k)
@@ -577,14 +589,25 @@ def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -
     return centroids
 
 
-def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum"):
-    """DownSampleGlobal.forward (models/downsample.py:1281-1330, asm dot, H=1, no res block).
+def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm: str = "dot"):
+    """DownSampleGlobal.forward (models/downsample.py:1281-1330, H=1, no res block) with
+    attention_scoring (models/downsample.py:1338-1358) for asm dot / dot-sub / l2 / l2+.
     Returns ((x_ds, idx (B,1,M)), (x_dropped, idx_dropped (B,1,N-M)), score (B,1,N))."""
     B, C, N = x.shape
     q = F.conv1d(x, wq).view(B, 1, C, N).permute(0, 1, 3, 2)
     k = F.conv1d(x, wk).view(B, 1, C, N)
     v = F.conv1d(x, wv).view(B, 1, C, N)
-    A = torch.softmax((q @ k) / math.sqrt(q.shape[-1]), dim=-1)
+    if asm == "dot":
+        energy = q @ k
+    elif asm == "dot-sub":
+        energy = q @ (q.transpose(-1, -2) - k)
+    elif asm == "l2":
+        energy = -1 * l2_global(q, k)
+    elif asm == "l2+":
+        energy = l2_global(q, k)
+    else:
+        raise ValueError("Please check the setting of asm!")
+    A = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)
     if idx_mode == "col_sum":
         score = torch.sum(A, dim=-2)
     elif idx_mode == "row_std":

@@ -103,7 +103,19 @@ class _SamplerCore(torch.autograd.Function):
         plan = None  # (member, cap, w_pre, w, counts) when the fused select chain ran
         if mod.bin_boundaries is not None:
             mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
-        if mod.idx_mode in ("col_sum", "row_std"):
+        imgs = None
+        if mod.idx_mode in ("col_sum", "row_std") and mod.asm == "l2":
+            # dense statistics with l2 scoring (models/downsample.py:154-189 + 315-320): the logit map is in HBM on
+            # this path anyway; its column sums / row deviations are two torch reductions over exp(S - lse)
+            imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
+            smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, "l2", images=imgs[:2] if imgs else None)
+            A = torch.exp(smap[:, :, :N] - lse.unsqueeze(-1))
+            stat = A.sum(dim=1) if mod.idx_mode == "col_sum" else torch.std(A, dim=-1)
+            del A
+            score, z = ops.stage_stat_score(stat.contiguous())
+            nn_idx = torch.empty((B, N, 0), dtype=torch.int32, device=x.device)
+            indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
+        elif mod.idx_mode in ("col_sum", "row_std"):
             # dense statistics of the attention map: no neighbour lists involved
             if mod.idx_mode == "row_std":
                 O, lse, tok, stat = ops.stage_attn_fwd(q, k, v, N, nt, want_row_std=True)
@@ -297,8 +309,6 @@ class DownSampleToken(nn.Module):
 
         if self.asm not in ("dot", "l2"):
             raise NotImplementedError
-        if self.asm == "l2" and self.idx_mode in ("col_sum", "row_std"):
-            raise NotImplementedError("asm='l2' is built for the sparse_* idx modes (the logit-map path)")
         if self.num_heads != 1:
             raise NotImplementedError("DownSampleToken requires num_heads == 1 (reference utils/check_config.py:158)")
         self._member_bits = None
@@ -434,9 +444,60 @@ class _GlobalCore(torch.autograd.Function):
         return dqkv, None, None
 
 
+class _GlobalMapCore(torch.autograd.Function):
+    """_GlobalCore for asm l2 / l2+ (models/downsample.py:1347-1350): S = -/+ |q - k|^2 / sqrt(D) through the logit map
+    (pass 1 with the norm terms, pass 2 over ALL rows), statistics from the map, backward from the map."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, qkv, x, mod):
+        B, C, N = x.shape
+        D = mod.q_depth
+        q, k, v = qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:3 * D]
+        smap, lse, _ = ops.stage_attn_stats(q, k, N, 0, mod.asm)
+        rows = torch.arange(N, device=qkv.device, dtype=torch.int64).unsqueeze(0).expand(B, -1).contiguous()
+        o_all = ops.stage_attn_rows(smap, lse, v, rows, N, 0)                 # (B,D,N): every row's A V
+        A = torch.exp(smap[:, :, :N] - lse.unsqueeze(-1))
+        col = A.sum(dim=1).contiguous()
+        if mod.idx_mode == "col_sum":
+            stat = col
+        elif mod.idx_mode == "row_std":
+            stat = torch.std(A, dim=-1).contiguous()
+        elif mod.idx_mode in ops.SCORE_MODES:
+            stat, _, _ = ops.stage_sparse_score_map(smap, lse, ops.stage_knn(x, x, mod.K), mod.idx_mode)
+        else:
+            raise ValueError("Please check the setting of idx mode!")
+        del A
+        idx = ops.stage_topk_indices(stat, mod.M, largest=True)
+        idx_dropped = ops.stage_topk_indices(col, N - mod.M, largest=False)
+        x_ds = torch.gather(o_all, 2, idx.unsqueeze(1).expand(-1, D, -1))
+        x_dropped = torch.gather(o_all, 2, idx_dropped.unsqueeze(1).expand(-1, D, -1))
+        ctx.save_for_backward(qkv, o_all, lse, idx, idx_dropped, smap, rows)
+        ctx.dims = (N, D, mod.asm)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(idx, idx_dropped, stat)
+        return x_ds, x_dropped, idx, idx_dropped, stat
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g_ds, g_dropped, *_):
+        qkv, o_all, lse, idx, idx_dropped, smap, rows = ctx.saved_tensors
+        N, D, asm = ctx.dims
+        B = qkv.shape[0]
+        g_all = torch.zeros((B, D, N), dtype=torch.float32, device=qkv.device)
+        if g_ds is not None:
+            g_all.scatter_add_(2, idx.unsqueeze(1).expand(-1, D, -1), g_ds)
+        if g_dropped is not None:
+            g_all.scatter_add_(2, idx_dropped.unsqueeze(1).expand(-1, D, -1), g_dropped)
+        dqkv = torch.empty_like(qkv)
+        ops.stage_attn_rows_bwd(qkv[:, :, 0:D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], smap, lse, o_all, rows, g_all, N, 0,
+                                dqkv[:, :, 0:D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], asm)
+        return dqkv, None, None
+
+
 class DownSampleGlobal(nn.Module):
     """Drop-in for the reference's APES-style global sampler (models/downsample.py:1232-1405, asm
-    'dot'): softmax(QK^T/sqrt(D)) over the N points, score per `idx_mode`, top-M rows kept and the
+    'dot' / 'dot-sub' / 'l2' / 'l2+'): softmax(QK^T/sqrt(D)) over the N points, score per `idx_mode`, top-M rows kept and the
     N-M rows with the smallest column sum returned as the dropped set.
     Outputs: ((x_ds (B,C,M), idx (B,1,M)), (x_dropped (B,C,N-M), idx_dropped (B,1,N-M)))."""
 
@@ -465,9 +526,7 @@ class DownSampleGlobal(nn.Module):
         self.k_conv = nn.Conv1d(k_in, k_out, 1, bias=False)
         self.v_conv = nn.Conv1d(v_in, v_out, 1, bias=False)
         self.softmax = nn.Softmax(dim=-1)
-        if self.asm != "dot":
-            if self.asm in ("dot-sub", "l2", "l2+"):
-                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (only 'dot')")
+        if self.asm not in ("dot", "dot-sub", "l2", "l2+"):
             raise ValueError("Please check the setting of asm!")
         if self.num_heads != 1 or not (q_in == q_out == k_out == v_out == 128):
             raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
@@ -476,8 +535,13 @@ class DownSampleGlobal(nn.Module):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
         no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
-        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
-        x_ds, x_dropped, idx, idx_dropped, stat = _GlobalCore.apply(qkv, x.detach(), self)
+        # attention_scoring (models/downsample.py:1338-1358).  dot-sub: energy = Q (Q^T - K) with Q^T, K both (D, N):
+        # energy_ij = <q_i, q_j - k_j> -- dot attention with the keys Q - K, i.e. the key weights W_q - W_k (the convs
+        # are linear).  l2 / l2+: the logit-map pipeline (the norm terms enter the logits there).
+        wk = (self.q_conv.weight - self.k_conv.weight) if self.asm == "dot-sub" else self.k_conv.weight
+        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, wk, self.v_conv.weight)
+        core = _GlobalMapCore if self.asm in ("l2", "l2+") else _GlobalCore
+        x_ds, x_dropped, idx, idx_dropped, stat = core.apply(qkv, x.detach(), self)
         self.idx = idx.unsqueeze(1)
         self.attention = stat.unsqueeze(1)
         idx_dropped = idx_dropped.unsqueeze(1)
@@ -527,6 +591,26 @@ class _LocalCore(torch.autograd.Function):
                 None, None)
 
 
+class _N2PAttention(torch.autograd.Function):
+    """qkv (B,N,3C) point-major rows [Q|K|V], neighbour lists -> one-head attention of every point over its neighbours'
+    K / V rows ("neighbor" grouping): (B,C,N) [differentiable w.r.t. qkv] and the (B,N,K) probabilities."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, qkv, nn_idx):
+        qkv = qkv.contiguous()
+        out, att = ops.stage_n2p_attn_fwd(qkv, nn_idx, 1, False, want_att=True)
+        ctx.save_for_backward(qkv, nn_idx)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g, _):
+        qkv, nn_idx = ctx.saved_tensors
+        return ops.stage_n2p_attn_bwd(qkv, nn_idx, g, 1, False), None
+
+
 class DownSampleLocal(nn.Module):
     """Drop-in for the reference's local-attention sampler (models/downsample.py:818-1229): 1 x K
     attention of every point over its K = 32 nearest neighbours in feature space, a per-point score
@@ -572,9 +656,7 @@ class DownSampleLocal(nn.Module):
         self.boltzmann_enable = config_ds.boltzmann.enable[layer]
         self.boltzmann_T = config_ds.boltzmann.boltzmann_T[layer]
         self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
-        if self.asm not in ("dot", "dot-neighbor"):
-            if self.asm in ("dot-sub", "l2", "l2+"):
-                raise NotImplementedError(f"asm={self.asm!r} is not built on HIP (dot / dot-neighbor are)")
+        if self.asm not in ("dot", "dot-neighbor", "dot-sub", "l2", "l2+"):
             raise ValueError("Please check the setting of asm!")
         if self.num_heads != 1 or not (q_in == q_out == k_in == k_out == v_in == v_out == 128):
             raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
@@ -585,8 +667,14 @@ class DownSampleLocal(nn.Module):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape
-        x_all, att, nn_idx = _LocalCore.apply(x, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.K,
-                                              self.group_type == "diff")
+        if self.asm in ("l2", "l2+"):
+            x_all, att, nn_idx = self._l2_attention(x)
+        else:
+            # attention_scoring (models/downsample.py:977-1000).  dot-sub: q (q^T - k_j) = |q|^2 - <q, k_j>: the first
+            # term cancels in the softmax over the K neighbours -> the dot kernels on -K
+            wk = -self.k_conv.weight if self.asm == "dot-sub" else self.k_conv.weight
+            x_all, att, nn_idx = _LocalCore.apply(x, self.q_conv.weight, wk, self.v_conv.weight, self.K,
+                                                  self.group_type == "diff")
         self.neighbors_idx = nn_idx.long()
         self.attention_map = att.view(B, 1, N, 1, self.K)
         std = torch.std(att, dim=-1, unbiased=False)                      # (B,N)
@@ -612,6 +700,23 @@ class DownSampleLocal(nn.Module):
         if self.res == True:  # noqa: E712
             x_ds = self.res_block(x, x_ds)
         return (x_ds, self.idx), (x_dropped, idx_dropped.unsqueeze(1))
+
+    def _l2_attention(self, x):
+        """asm l2 / l2+ (models/downsample.py:984-996): the reference forms the K x K matrix (q - k_a)(q - k_b) and
+        averages it over a: energy_b = -/+ <q - kbar, q - k_b>, kbar = mean of the K neighbour keys.  The part that does
+        not depend on b cancels in the softmax over b, which leaves a dot-product attention of the query q - kbar
+        (negated for l2+) over the neighbour keys: the N2P kernels, with kbar a gather-mean of the projected keys."""
+        B, C, N = x.shape
+        no_tokens = self.q_conv.weight.new_zeros((1, C, 0))
+        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight.view(C, C, 1), self.k_conv.weight.view(C, C, 1),
+                                self.v_conv.weight.view(C, C, 1))
+        nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
+        q, k, v = qkv[:, :, 0:C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+        gather_at = nn_idx.long().reshape(B, N * self.K, 1).expand(-1, -1, C)
+        kbar = torch.gather(k, 1, gather_at).view(B, N, self.K, C).mean(dim=2)
+        qe = (q - kbar) if self.asm == "l2" else (kbar - q)
+        out, att = _N2PAttention.apply(torch.cat((qe, k, v), dim=-1), nn_idx)
+        return out, att, nn_idx
 
     def boltzmann_idx_selection(self):
         """reference models/downsample.py:1205-1229: softmax(norm_range(score) / T) -> multinomial without replacement."""

@@ -449,7 +449,8 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
                      images=None):
     """Pass 1 of the two-pass forward: q (B,N,D), k (B,N+nt,D) -> logit map (B,N,ld) kept in HBM,
     lse (B,N), token logits (B,N,nt).  Columns >= N+nt of the map are -inf.
-    asm "dot": S = <q,k>/sqrt(D); "l2": S = -|q-k|^2/sqrt(D) (reference downsample.py:154-175).
+    asm "dot": S = <q,k>/sqrt(D); "l2": S = -|q-k|^2/sqrt(D) (reference downsample.py:154-175); "l2+": S = +|q-k|^2/sqrt(D)
+    (downsample.py:1349, n_tokens = 0).
     images: optional (q_image, k_image) already split (MATRIX_MODE "tri")."""
     _need_gpu(q, k)
     B, N, D = q.shape
@@ -463,14 +464,20 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
         lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
         tok = torch.empty((B, N, max(n_tokens, 1)), dtype=torch.float32, device=q.device)
         qn = kn = None
-        if asm == "l2":
-            qn = (q * q).sum(-1).contiguous()
+        if asm in ("l2", "l2+"):
+            # the kernels form S = (2 <a, k> - qn_i - kn_j) / sqrt(D) from the three inputs as given: a = q with the
+            # squared norms gives -|q - k|^2 (l2); a = -q with NEGATED norms gives +|q - k|^2 (l2+, reference
+            # models/downsample.py:1349: attends to the farthest keys)
+            sgn = 1.0 if asm == "l2" else -1.0
+            qn = (sgn * (q * q).sum(-1)).contiguous()
             kn = torch.zeros((B, ld), dtype=torch.float32, device=q.device)
-            kn[:, :n_points + n_tokens] = (k * k).sum(-1)
+            kn[:, :n_points + n_tokens] = sgn * (k * k).sum(-1)
+            if asm == "l2+":
+                q, images = (-q).contiguous(), None
         elif asm != "dot":
             raise NotImplementedError
         # l2 scoring keeps the cloud's scaled key norms in LDS beside the tile ring: very long clouds use the fp32 kernel
-        if MATRIX_MODE == "tri" and not (asm == "l2" and ld * 4 > 24 * 1024):
+        if MATRIX_MODE == "tri" and not (asm in ("l2", "l2+") and ld * 4 > 24 * 1024):
             q_img, k_img = images if images is not None else (stage_tri_split(q)[0], stage_tri_split(k)[0])
             _lib.call("samble_attn_stats_tri_f32", q_img.data_ptr(), k_img.data_ptr(), B, N, n_tokens, D,
                       smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn), _stream())
@@ -679,8 +686,10 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
     M = idx.shape[1]
     g = _f32c(g)
     x_ds = _f32c(x_ds)
+    if asm == "l2+":  # the forward's query operand was a = -q (stage_attn_stats)
+        q = (-q).contiguous()
     with torch.cuda.device(q.device):
-        cs = torch.zeros((B, n_points + n_tokens), dtype=torch.float32, device=q.device) if asm == "l2" else None
+        cs = torch.zeros((B, n_points + n_tokens), dtype=torch.float32, device=q.device) if asm in ("l2", "l2+") else None
         if MATRIX_MODE == "tri":
             if images is None:
                 images = (stage_tri_split(k, want_rm=False, want_tr=True)[1], stage_tri_split(v)[0])
@@ -703,6 +712,10 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
         if asm == "l2":
             dq.mul_(2.0)
             dk.mul_(2.0).sub_(2.0 * cs.unsqueeze(-1) * k)
+        elif asm == "l2+":
+            # S = scale (2 <a, k> + |q|^2 + |k|^2), a = -q: dq = -(2 dA), dk_j = 2 dK_j + 2 c_j k_j (rows of dS sum to 0)
+            dq.mul_(-2.0)
+            dk.mul_(2.0).add_(2.0 * cs.unsqueeze(-1) * k)
 
 
 # ------------------------------------------------------------------------------------------------

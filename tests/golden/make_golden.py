@@ -85,6 +85,10 @@ CASES = [
     dict(name="cls_mode1_random", cfg="cls", B=2, N=256, M=128, calls=1, big=False, boltzmann_T="mode_1"),
     dict(name="seg_mode2_rowstd", cfg="seg", B=2, N=256, M=128, calls=1, big=False, boltzmann_T="mode_2",
          idx_mode="sparse_row_std"),
+    # round 3: l2 scoring with the dense score modes (models/downsample.py:154-189 + 315-320)
+    dict(name="cls_l2_colsum_topk", cfg="cls", B=2, N=256, M=128, calls=1, big=False, asm="l2", sample_mode="topk",
+         idx_mode="col_sum"),
+    dict(name="cls_l2_rowstd_random", cfg="cls", B=2, N=256, M=128, calls=1, big=False, asm="l2", idx_mode="row_std"),
 ]
 
 

@@ -226,13 +226,17 @@ def test_upsample_interpolation_against_reference_fixture():
         assert rel <= 5e-2, (key, rel)
 
 
-def test_downsample_global_against_reference_fixture():
-    """APES-style global sampler (reference models/downsample.py:1232-1405), idx_mode col_sum."""
+@pytest.mark.parametrize("name", ["layer_global_colsum", "layer_global_dotsub", "layer_global_l2", "layer_global_l2plus"])
+def test_downsample_global_against_reference_fixture(name):
+    """APES-style global sampler (reference models/downsample.py:1232-1405), idx_mode col_sum, every attention
+    scoring of attention_scoring (models/downsample.py:1338-1358): dot, dot-sub, l2, l2+."""
     from samble_amd import sampler_config
     from samble_amd.downsample import DownSampleGlobal
-    d = layer_fixture("layer_global_colsum")
+    d = layer_fixture(name)
     B, C, N, M, seed = [int(v) for v in d["meta"]]
+    asm = str(d["asm"]) if "asm" in d else "dot"
     cfg = sampler_config("cls", M=[M, M // 2], idx_mode=["col_sum", "col_sum"])
+    cfg.asm = [asm, asm]
     mod = DownSampleGlobal(cfg, 0)
     assert sorted(mod.state_dict()) == ["k_conv.weight", "q_conv.weight", "v_conv.weight"]
     with torch.no_grad():
@@ -281,7 +285,8 @@ def test_farthest_point_sample_exact():
     assert torch.equal(r.cpu(), O.farthest_point_sample(xyz.contiguous(), 16, r[:, 0].cpu()))
 
 
-@pytest.mark.parametrize("name", ["layer_local_std", "layer_local_colsqr"])
+@pytest.mark.parametrize("name", ["layer_local_std", "layer_local_colsqr", "layer_local_dotsub", "layer_local_l2",
+                                  "layer_local_l2plus"])
 def test_downsample_local_against_reference_fixture(name):
     """Local-attention sampler (reference models/downsample.py:818-1229) on the single-head N2P kernels."""
     from samble_amd import sampler_config
@@ -289,7 +294,9 @@ def test_downsample_local_against_reference_fixture(name):
     d = layer_fixture(name)
     B, C, N, M, seed = [int(v) for v in d["meta"]]
     mode = str(d["idx_mode"])
+    asm = str(d["asm"]) if "asm" in d else "dot"
     cfg = sampler_config("cls", M=[M, M // 2], idx_mode=[mode, mode])
+    cfg.asm = [asm, asm]
     mod = DownSampleLocal(cfg, 0)
     assert sorted(mod.state_dict()) == ["k_conv.weight", "q_conv.weight", "v_conv.weight"]
     assert tuple(mod.q_conv.weight.shape) == (C, C, 1, 1)

@@ -113,6 +113,16 @@ def test_state_dict_keys_and_forward_contract():
     mod.output_variable_calculatio()
     assert len(mod.idx_chunks) == 6 and len(mod.idx_chunks[0]) == g.B
     assert mod.output_variables("idx", "bin_prob")[0] is mod.idx
+    # a15 against the reference's fixture: chunk (t, b) = the points of cloud b in bin t, ascending
+    # (models/downsample.py:346-362: torch.where on the mask), bin_prob = the weights before relu
+    bin_id = g.t("bin_id").long()
+    for t in range(6):
+        for b in range(g.B):
+            want = torch.where(bin_id[b] == t)[0].reshape(1, -1)
+            assert torch.equal(mod.idx_chunks[t][b].cpu(), want), (t, b)
+    assert mod.bin_prob is mod.bin_weights_beforerelu
+    torch.testing.assert_close(mod.bin_prob.detach().cpu().reshape(g.B, 6), g.t("w_pre").reshape(g.B, 6), rtol=1e-4,
+                               atol=1e-6)
 
 
 def test_metric_size_properties_and_determinism():

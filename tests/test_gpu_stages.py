@@ -567,9 +567,11 @@ def test_bin_select_exact_vs_oracle_full_size(mode):
 
 def test_bin_select_random_mode_full_size_vs_oracle():
     """`random` (Boltzmann) selection at the metric size from the oracle's stage inputs.  Its key
-    exp(tanh(z)/T) / sum / q goes through tanh and exp: Sleef on the CPU (the oracle = torch), ocml on the GPU,
-    each within 1 ulp of the true value but not of each other, so two keys closer than a few ulp may trade
-    places.  Pinned here: every position where the two index tensors differ is such a near-tie (the two keys
+    exp(tanh(z)/T) / sum / q goes through tanh and exp: MKL's closed-source vector math library on the CPU (this
+    torch build routes contiguous float exp / tanh to vsExp / vsTanh: tools/libm_probe shows that a bit-exact
+    restatement of Sleef u10 -- the open routine torch also ships -- differs from torch.exp in 9.5 % of arguments),
+    ocml on the GPU, each within 1 ulp of the true value but not of each other, so two keys closer than a few ulp
+    may trade places.  Pinned here: every position where the two index tensors differ is such a near-tie (the two keys
     involved agree to 1e-6 relative), there are at most a handful of them, and the per-bin SETS differ only by
     such near-ties at the cut."""
     B, N, nb, M = 8, 2048, 6, 1024
@@ -599,6 +601,39 @@ def test_bin_select_random_mode_full_size_vs_oracle():
             ki = float(p[b, i] / noise[b * nb + t, i])
             kj = float(p[b, j] / noise[b * nb + t, j])
             assert abs(ki - kj) <= 1e-6 * max(ki, kj), (b, pos, ki, kj)
+
+
+def test_select_chain_with_a_constant_score_cloud():
+    """One cloud of the batch has a constant score: its z-score is 0/0 (or x/0), every comparison with the
+    boundaries is false, all its bins are empty.  The reference itself fails there (its float -> int count allocation
+    yields INT_MIN entries and torch.stack raises); ours must stay in bounds -- bin 0 of that cloud is handed all M
+    picks and the select kernel serves them from the whole cloud -- and the healthy clouds of the batch must come out
+    exactly as the oracle's (static boundaries, so the poisoned batch quantiles of the reference do not enter)."""
+    B, N, nb, M = 3, 2048, 6, 1024
+    score = torch.from_numpy(np.abs(synth.normal((B, 1, N), 77)) * 1e-4 + 1e-6)
+    score[1] = 0.25  # exactly representable: mean exact, (x - mean) / std = 0 / 0
+    state = O.static_boundary_state([1.2, 0.4, -0.1, -0.5, -0.9], nb)
+    o_ = ops()
+    z = o_.stage_zscore(score.reshape(B, N).to(DEV))
+    assert bool(torch.isnan(z[1]).all()) and bool(torch.isfinite(z[[0, 2]]).all())
+    tok = torch.from_numpy(synth.normal((B, N, nb), 78)).to(DEV)
+    member, cap, w_pre, w = o_.stage_bin_assign(z, tok, state[0].to(DEV), state[1].to(DEV), False)
+    assert int(cap[1].sum()) == 0 and int(member[1].sum()) == 0
+    counts = o_.stage_alloc_counts(w, cap, M)
+    assert counts[1].tolist() == [M, 0, 0, 0, 0, 0]
+    idx = o_.stage_bin_select(score.reshape(B, N).to(DEV), z, member, counts, M, "topk", 0.1).cpu()
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    assert all(len(set(r.tolist())) == M for r in idx)
+    # healthy clouds: the oracle on the same stage inputs
+    zc = z.cpu().reshape(B, 1, N)
+    for b in (0, 2):
+        mem = O.bin_membership(zc[b:b + 1], state)
+        capb = mem.squeeze(1).sum(1)
+        assert torch.equal(cap[b:b + 1].cpu().long(), capb)
+        cnt = O.allocate_counts(w[b:b + 1].cpu(), capb, M)
+        assert torch.equal(counts[b:b + 1].cpu(), cnt)
+        ref = O.select_indices(score[b:b + 1], mem, cnt, M, "topk", 0.1).reshape(1, M)
+        assert torch.equal(idx[b:b + 1], ref)
 
 
 def test_bin_select_ties_break_by_ascending_index():
