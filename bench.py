@@ -64,40 +64,83 @@ def algorithmic_bytes_per_cloud():
 # ------------------------------------------------------------------------------------------------
 # N > 1 without torch.distributed.run: start the ranks ourselves, BEFORE anything touches the GPU
 # ------------------------------------------------------------------------------------------------
+EADDRINUSE_EXIT = 98  # a rank that loses the race for MASTER_PORT exits with this code: the parent retries
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
+def _visible_gpus() -> int:
+    """GPUs this process may use, WITHOUT bringing up the HIP runtime (torch.cuda.device_count() goes through
+    hipGetDeviceCount on ROCm): the visibility variables, else the KFD topology."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    try:
+        for node in os.listdir("/sys/class/kfd/kfd/topology/nodes"):
+            props = open(f"/sys/class/kfd/kfd/topology/nodes/{node}/properties").read().split()
+            if "simd_count" in props and int(props[props.index("simd_count") + 1]) > 0:
+                n += 1
+    except OSError:
+        n = torch.cuda.device_count()
+    return n
+
+
 def launch_ranks(n: int, argv) -> int:
     """Parent of `python bench.py --gpus N` (N > 1, no RANK in the environment): one child process per
-    rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would.  The parent never
-    initialises the GPU (device_count() does not); rank 0's stdout is the JSON line."""
-    ndev = torch.cuda.device_count()
-    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would.  The ranks are fresh child
+    processes (never an exec of this one); the parent counts the GPUs without initialising the runtime, forwards
+    SIGINT / SIGTERM to the ranks and reaps them on every way out; rank 0's stdout is the JSON line."""
+    import signal
+    ndev = _visible_gpus()
     if "--backend" not in " ".join(argv) and ndev < n:
         # RCCL refuses two ranks on one device: on a box with fewer GPUs than ranks the ranks share GPUs over gloo
         # (a functional check of the N > 1 path, flagged in the JSON line; never a scaling number)
         argv = list(argv) + ["--backend", "gloo"]
     procs = []
-    for r in range(n):
-        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop(*_):
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+
+    old = {sig: signal.signal(sig, lambda *_: (stop(), sys.exit(130))) for sig in (signal.SIGINT, signal.SIGTERM)}
     rc = 0
-    alive = set(range(n))
-    while alive:
-        for r in list(alive):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            alive.discard(r)
-            if code != 0:
-                rc = rc or code
-                for o in alive:  # a dead rank would leave the others waiting at the rendezvous / next collective
-                    procs[o].terminate()
-        time.sleep(0.05)
+    try:
+        for attempt in range(3):  # (the port is free when probed, not necessarily when rank 0 binds it)
+            env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs[:] = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                         env=dict(env0, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+            rc = 0
+            alive = set(range(n))
+            while alive:
+                for r in list(alive):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    alive.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        for o in alive:  # a dead rank would leave the others waiting at the rendezvous / next collective
+                            procs[o].terminate()
+                time.sleep(0.05)
+            if rc != EADDRINUSE_EXIT:
+                break
+    finally:
+        stop()
+        for p_ in procs:
+            try:
+                p_.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p_.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 
@@ -184,10 +227,15 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group(args.backend)
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" in str(e) or "address already in use" in str(e).lower():
+                sys.exit(EADDRINUSE_EXIT)  # (launch_ranks picks another port)
+            raise
 
     from samble_amd import _lib, ops, sampler_config, synth
     from samble_amd.downsample import DownSampleToken

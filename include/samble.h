@@ -287,7 +287,8 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
 
 /* ---- the integer tail as two launches (same reference lines as the stand-alone entries above) ----------------
  * For shapes samble_select_chain_supported(B, N, nb) accepts (one 1024-thread workgroup per cloud, all resident:
- * B <= min(128, CUs), B * nb <= 1024, N <= 16384), over ONE caller-owned workspace of
+ * B <= min(128, CUs / 2), B * nb <= 1024, N <= 16384; the grid barrier's poll is bounded: if the workgroups turn out
+ * not to be co-resident the kernel traps after ~1 s and the next entry point reports the HIP error), over ONE caller-owned workspace of
  * samble_select_chain_workspace_bytes(B, N):
  *   samble_sparse_score_map_quantiles_f32  = samble_sparse_score_map_f32 (models/downsample.py:300-344, score + z,
  *       in-degree) + samble_batch_quantiles_f32 (utils/ops.py:180-189) in two launches (accumulation; finalize +

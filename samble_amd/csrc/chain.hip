@@ -51,7 +51,16 @@ __device__ __forceinline__ void grid_barrier(unsigned int* counter, unsigned int
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    // bounded: the barrier assumes that all B workgroups are resident at once, which the launcher can only infer (CU
+    // count, nothing else on the device).  If a co-tenant, a CU mask or a second stream keeps some of them off the
+    // chip, the poll gives up after kSpinBudget rounds (~1 s) and traps: the stream then carries a HIP error that the
+    // next entry point reports (SAMBLE_E_HIP_BASE - code) instead of the step hanging forever.
+    constexpr unsigned kSpinBudget = 1u << 20;
+    unsigned spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > kSpinBudget) __builtin_trap();
+      __builtin_amdgcn_s_sleep(1);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -317,7 +326,9 @@ extern "C" size_t samble_chain_ws_bytes(void) { return (size_t)kChainWords * siz
 extern "C" int samble_chain_supported(int B, int N, int nb) {
   int cus = 0;
   if (resident_workgroups(&cus)) return 0;
-  return B >= 1 && B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && N <= 16 * 1024 && nb >= 2 && nb <= kMaxBins;
+  // (2 B <= CUs: head-room for a second rank or another stream sharing the device -- co-residency is inferred, not
+  // guaranteed; the barrier's poll is bounded for the cases this does not catch)
+  return B >= 1 && 2 * B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && N <= 16 * 1024 && nb >= 2 && nb <= kMaxBins;
 }
 
 // cws must have been zeroed on the stream (the score launcher's memset covers it)

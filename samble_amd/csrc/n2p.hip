@@ -514,6 +514,13 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   unsigned short* pre = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + (((size_t)B * N * W * 4 + 255) & ~(size_t)255));
   hipError_t e = hipMemsetAsync(bits, 0, (size_t)B * N * W * 4, s);
   if (e != hipSuccess) return (int)e;
+  // PRECONDITION (include/samble.h): every row of nn holds K DISTINCT indices in [0, N), as samble_knn_f32 writes
+  // them.  A table that breaks it (duplicates collapse into one bit, out-of-range entries are skipped) places
+  // fewer than N*K edges per cloud, and the slots between a cloud's last placed edge and the next cloud's first
+  // offset stay unwritten: zero them, so that whatever a consumer gathers through such a slot is edge 0 -- a wrong
+  // gradient for a malformed table, never an out-of-bounds read
+  e = hipMemsetAsync(order, 0, (size_t)nedges * sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
   const unsigned blocks = (unsigned)((nedges + 255) / 256);
   hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
   hipLaunchKernelGGL(samble::inv_count_kernel, dim3(B), dim3(1024), 0, s, bits, N, K, W, pre, offsets, indeg);

@@ -104,6 +104,8 @@ class _SamplerCore(torch.autograd.Function):
         if mod.bin_boundaries is not None:
             mod.bin_boundaries = [item.to(x.device) for item in mod.bin_boundaries]
         imgs = None
+        if images is not None and mod.idx_mode in ("col_sum", "row_std"):
+            raise ops._lib.SambleError("qkv came from the image-writing projection but a dense score mode is selected")
         if mod.idx_mode in ("col_sum", "row_std") and mod.asm == "l2":
             # dense statistics with l2 scoring (models/downsample.py:154-189 + 315-320): the logit map is in HBM on
             # this path anyway; its column sums / row deviations are two torch reductions over exp(S - lse)
@@ -127,7 +129,14 @@ class _SamplerCore(torch.autograd.Function):
             indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
         else:
             nn_idx = ops.stage_knn(x, x, mod.K)
-            if MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and mod.asm == "dot" and mod.K in (16, 32):
+            map_free_ok = MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and mod.asm == "dot" and mod.K in (16, 32)
+            if images is not None and not map_free_ok:
+                # the projection left the K / V columns of qkv's point rows unwritten (q_only) because the module decided
+                # on the map-free forward; a switch flipped between the two calls must not send such a qkv down a
+                # pipeline that reads them
+                raise ops._lib.SambleError("qkv came from the image-writing projection (K / V rows unwritten) but the "
+                                           "map-free forward is no longer selected")
+            if map_free_ok:
                 need_bwd = ctx.needs_input_grad[0]
                 if images is not None and (len(images) == 5 or not need_bwd):
                     imgs = images

@@ -153,7 +153,10 @@ def inverse_neighbors(nn_idx: torch.Tensor):
     """Inverse neighbour lists of a kNN table nn_idx (B,N,K): (order (B*N*K) int32 = edge ids
     e = (b*N + i)*K + k grouped by target b*N + nn[e], ascending e inside a group; offsets (B*N + 1) int32).
     = a stable sort of the table by target, built on the device without sorting (samble_inverse_neighbors); counts (B*N)
-    int32 = the in-degrees."""
+    int32 = the in-degrees.
+    Precondition: every row of nn_idx holds K distinct indices in [0, N) (what stage_knn returns).  A table that
+    breaks it yields lists with fewer than N*K edges per cloud and zero-filled slack -- wrong sums downstream, but
+    no out-of-bounds access."""
     _need_gpu(nn_idx)
     B, N, K = nn_idx.shape
     nn_idx = nn_idx.contiguous()
