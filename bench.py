@@ -193,13 +193,111 @@ def cpu_baseline(seed):
                        f"(bit-identical restatement of the reference), {cores} threads")
 
 
+def run_block(args):
+    """BASELINE.json configs[1] (block_cls: EdgeConv x2 -> N2P -> sampler 2048->1024 -> N2P -> sampler 1024->512 -> N2P)
+    and configs[2] (block_seg: the same path down with 4 bins, interpolation + N2P back up to 2048): one step = forward +
+    backward + SGD of the whole block on B=32 clouds of N=2048 xyz points resident in HBM.  One GPU (the metric workload
+    carries the multi-GPU contract).  The JSON line has the contract's shape; `roofline` is for the kernel family that
+    takes the most time per step, timed by the library's HIP events on its launch stream over the timed steps."""
+    if args.gpus != 1:
+        raise SystemExit("the block workloads run on one GPU")
+    from samble_amd import _lib, synth
+    from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    Bb, Nb = 32, 2048
+    torch.manual_seed(1000 * (1 if args.workload == "block_cls" else 3))
+    seg = args.workload == "block_seg"
+    blk = (SegFeatureLearningBlock(seg_block_config()) if seg else FeatureLearningBlock(block_config("cls"))).to(dev).train()
+    xyz = torch.from_numpy(synth.xyz_clouds(Bb, Nb, 77)).to(dev)
+    opt = torch.optim.SGD(blk.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = blk(xyz)
+        feat = out if seg else out[0]
+        feat.square().mean().backward()
+        opt.step()
+
+    for _ in range(max(args.warmup - 2, 0)):
+        step()
+    # which kernel family dominates, from two untimed steps; then that one is timed over the timed region
+    fam = ["n2p_bwd", "edge_bwd", "knn", "edge_fwd", "n2p_fwd", "knn_small", "inv_nn", "seg_sum", "bwd_dq", "attn_rows",
+           "attn_stats"]
+    _lib.timing_select(fam)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    seen = {n: _lib.timing_read(n) for n in fam}
+    per_step = {n: v[0] * v[2] / 2 for n, v in seen.items() if v}   # mean ms x launches / 2 steps
+    dominant = max(per_step, key=per_step.get)
+    _lib.timing_select([dominant])
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dom = _lib.timing_read(dominant)
+    _lib.timing_select([])
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    ms = 1e3 * elapsed / args.steps
+    launches_per_step = dom[2] / args.steps if dom else 0
+    # algorithmic work of the dominant family per launch, averaged over its launches of a step (layers of 2048 / 1024 /
+    # 512 points): SURVEY 8(d) style, inputs read once and outputs written once, recomputation not counted
+    K, Cc = 32, 128
+    layers_n = [2048, 1024, 512] + ([1024, 2048] if seg else [])
+    if dominant in ("n2p_bwd", "n2p_fwd"):
+        # per point: its qkv row, the upstream gradient row, the K neighbour ids in; a dqkv row out
+        by = sum(Bb * n * (3 * Cc * 4 * 2 + Cc * 4 + K * 4) for n in layers_n) / len(layers_n)
+        roof = {"kernel": "n2p backward (transpose + n2p_bwd_point + n2p_bwd_gather)" if dominant == "n2p_bwd" else "n2p_attn_fwd",
+                "bound": "hbm", "achieved": round(by / (dom[0] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "note": ("gather kernel: every point reads the K / V rows of its 32 neighbours (32 KB per point) through "
+                         "L2; the algorithmic HBM bytes are the rows read once, so the fraction is small by construction")}
+    elif dominant in ("edge_bwd", "edge_fwd"):
+        # conv2 of the EdgeConv body on B*N*K edges, 64 -> 64 channels: forward 1 product, backward 2 (dh, dW2)
+        fl = Bb * Nb * K * 2 * 64 * 64 * (2 if dominant == "edge_bwd" else 1)
+        roof = {"kernel": "edge_mlp_bwd_kernel" if dominant == "edge_bwd" else "edge_mlp_fwd_kernel", "bound": "mfma",
+                "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "note": "fp32 MFMA; the backward recomputes the edge activations (a third product, not counted)"}
+    else:
+        fl = sum(2.0 * Bb * n * n * Cc for n in layers_n) / len(layers_n)
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2),
+                "peak": PEAK_TRI_TFLOPS, "unit": "TFLOP/s"}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    roof["us_per_launch"] = round(dom[0] * 1e3, 1)
+    roof["launches_per_step"] = round(launches_per_step, 1)
+    roof["traffic"] = None
+    result = {
+        "metric": ("point-clouds/sec (feature-learning block fwd+bwd), " + ("ShapeNet-part seg block" if seg else "ModelNet40 cls block")
+                   + " B=32 N=2048->1024->512" + ("->1024->2048" if seg else "")),
+        "value": round(Bb * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_median": round(statistics.median(step_ms), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (unit-sphere xyz clouds with jitter and anisotropic scale, random-init weights; no dataset files offline)",
+        "config": {"workload": ("BASELINE configs[2]: SegFeatureLearningBlock" if seg else "BASELINE configs[1]: FeatureLearningBlock")
+                               + " fwd+bwd+SGD, B=32 xyz (32,3,2048), EdgeConv x2, N2P x" + ("5" if seg else "3")
+                               + ", DownSampleToken x2 (" + ("4" if seg else "6") + " bins, random T=0.1, dynamic boundaries)"
+                               + (", UpSampleInterpolation x2" if seg else ""),
+                   "global_batch": Bb, "parallelism": "dp1"},
+        "roofline": roof,
+        "kernel_family_ms_per_step": {n: round(v, 3) for n, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+    }
+    print(json.dumps(result), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="metric", choices=["metric", "stress"],
-                    help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096")
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "block_cls", "block_seg"],
+                    help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096; "
+                         "block_cls / block_seg = configs[1] / configs[2]: the whole feature-learning block, B=32 N=2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--logit-map", action="store_true",
@@ -208,6 +306,8 @@ def main():
                     help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
     args = ap.parse_args()
 
+    if args.workload.startswith("block_"):
+        return run_block(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 

@@ -428,6 +428,14 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
 #define SAMBLE_T_GATHER 19
 #define SAMBLE_T_BWD_ROWS_F32 22 /* bwd_rows (fp32-MFMA backward over the key blocks) */
 #define SAMBLE_T_NN_PREPARE 23   /* nn_prepare: ascending neighbour lists + per-tile membership words */
+#define SAMBLE_T_EDGE_FWD 24     /* edge_mlp_fwd (EdgeConv body) */
+#define SAMBLE_T_EDGE_BWD 25     /* edge_mlp_bwd */
+#define SAMBLE_T_N2P_FWD 26      /* n2p_attn_fwd */
+#define SAMBLE_T_N2P_BWD 27      /* n2p backward: transpose + n2p_bwd_point + n2p_bwd_gather / scatter */
+#define SAMBLE_T_INV_NN 28       /* samble_inverse_neighbors: mark + count + place */
+#define SAMBLE_T_SEG_SUM 29      /* seg_sum_rows64 */
+#define SAMBLE_T_EDGE_SUMS 30    /* edge_gather_sums */
+#define SAMBLE_T_KNN_SMALL 31    /* knn_smallc_fused (xyz) */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

@@ -171,6 +171,8 @@ TIMED_KERNELS = {
     "attn_stats": 1, "attn_rows": 2, "bwd_dv": 3, "knn": 4, "attn_fwd": 5, "bwd_dq": 6, "bwd_dk": 7, "proj_fwd": 8,
     "proj_dx": 9, "proj_dw": 10, "tri_split": 11, "knn_prep": 12, "sparse_score": 13, "quantiles": 14, "bin_assign": 15,
     "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22, "nn_prepare": 23,
+    "edge_fwd": 24, "edge_bwd": 25, "n2p_fwd": 26, "n2p_bwd": 27, "inv_nn": 28, "seg_sum": 29, "edge_sums": 30,
+    "knn_small": 31,
 }
 
 

@@ -283,6 +283,7 @@ extern "C" int samble_edge_waves(void) { return 2048; }  // persistent waves per
 extern "C" int samble_launch_edge_gather_sums(const float* bp, const int* nn, int B, int N, float* S, float* Q,
                                               hipStream_t s) {
   const long np = (long)B * N;
+  Timed timed(kT_edge_sums, s);
   hipLaunchKernelGGL(edge_gather_sums_kernel, dim3(2048), dim3(256), 0, s, bp, nn, N, np, S, Q);
   return (int)hipGetLastError();
 }
@@ -291,6 +292,7 @@ extern "C" int samble_launch_edge_mlp_fwd(const float* ap, const float* bp, cons
                                           float* ymax, float* ymin, unsigned char* kmax, unsigned char* kmin,
                                           double* part, hipStream_t s) {
   const long np = (long)B * N;
+  Timed timed(kT_edge_fwd, s);
   hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), 0, s, ap, bp, nn, W2, N, np, ymax, ymin,
                      kmax, kmin, part);
   return (int)hipGetLastError();
@@ -306,6 +308,7 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  Timed timed(kT_edge_bwd, s);
   hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
                      N, np, du, dw2part);
   return (int)hipGetLastError();

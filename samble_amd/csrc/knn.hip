@@ -503,6 +503,7 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
     if (rc) return rc;
   } else {
     if (small_fused) {
+      Timed timed(kT_knn_small, stream);
       bool ok = true;
       switch (K) {
         case 1: launch_smallc_fused<1>(xq, q_bs, Nq, xk, k_bs, Nk, B, C, idx_out, kout, stream); break;

@@ -107,6 +107,7 @@ using namespace samble;
 extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const int* nn, int B, int N, int KN, int diff,
                                      float scale, float* out, int heads, float* att, hipStream_t s) {
   if ((heads != 1 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
+  Timed timed(kT_n2p_fwd, s);
   hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
                      out, heads, att);
   return (int)hipGetLastError();
@@ -522,6 +523,7 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   e = hipMemsetAsync(order, 0, (size_t)nedges * sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   const unsigned blocks = (unsigned)((nedges + 255) / 256);
+  samble::Timed timed(samble::kT_inv_nn, s);
   hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
   hipLaunchKernelGGL(samble::inv_count_kernel, dim3(B), dim3(1024), 0, s, bits, N, K, W, pre, offsets, indeg);
   hipLaunchKernelGGL(samble::inv_place_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets, order);
@@ -530,6 +532,7 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
 
 extern "C" int samble_launch_seg_sum_rows64(const float* src, const int* order, const int* offs, int KN, int per_edge,
                                             long ntargets, float* out, hipStream_t s) {
+  samble::Timed timed(samble::kT_seg_sum, s);
   hipLaunchKernelGGL(samble::seg_sum_rows64_kernel, dim3(2048), dim3(256), 0, s, src, order, offs, KN, per_edge, ntargets,
                      out);
   return (int)hipGetLastError();
@@ -553,6 +556,7 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  Timed timed(kT_n2p_bwd, s);  // (transpose + per-point kernel + gather / scatter of the neighbours' shares)
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
   hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
                      scale, dqkv, dbs, drs, A, DL, heads);

@@ -29,6 +29,8 @@ enum TimedKernel {
   kT_proj_fwd = 8, kT_proj_dx = 9, kT_proj_dw = 10, kT_tri_split = 11, kT_knn_prep = 12, kT_sparse_score = 13,
   kT_quantiles = 14, kT_bin_assign = 15, kT_alloc_counts = 16, kT_bin_select = 17, kT_bwd_prep = 18,
   kT_gather = 19, kT_knn_seed = 20, kT_select_chain = 21, kT_bwd_rows_f32 = 22, kT_nn_prepare = 23,
+  kT_edge_fwd = 24, kT_edge_bwd = 25, kT_n2p_fwd = 26, kT_n2p_bwd = 27, kT_inv_nn = 28, kT_seg_sum = 29,
+  kT_edge_sums = 30, kT_knn_small = 31,
 };
 struct Timed {  // brackets the launches made during its lifetime
   int id;
