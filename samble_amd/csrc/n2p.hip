@@ -448,25 +448,41 @@ __global__ __launch_bounds__(256) void inv_mark_kernel(const int* __restrict__ n
   atomicOr(&bits[(b * N + t) * W + (i >> 5)], 1u << (i & 31));
 }
 
-__global__ __launch_bounds__(1024) void inv_count_kernel(const unsigned* __restrict__ bits, int N, int K, int W,
-                                                         unsigned short* __restrict__ pre, int* __restrict__ offsets,
-                                                         int* __restrict__ indeg) {
+// per target row (one wave each): exclusive prefix popcounts of its W membership words (`pre`) and its in-degree.
+// Lane = word: coalesced 256-byte reads (round 2: one thread walked a row's words one by one, 32 workgroups in all:
+// 125-190 us per table against ~10 for this kernel and the scan below)
+__global__ __launch_bounds__(256) void inv_rowscan_kernel(const unsigned* __restrict__ bits, long nrows, int W,
+                                                          unsigned short* __restrict__ pre, int* __restrict__ total) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= nrows) return;
+  const unsigned* r = bits + row * W;
+  unsigned short* p = pre + row * W;
+  int carry = 0;
+  for (int w0 = 0; w0 < W; w0 += 64) {
+    const int w = w0 + lane;
+    const int c = w < W ? __popc(r[w]) : 0;
+    int inc = c;  // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (w < W) p[w] = (unsigned short)(carry + inc - c);
+    carry += __shfl(inc, 63, 64);
+  }
+  if (lane == 0) total[row] = carry;
+}
+
+// per cloud: group boundaries = exclusive scan of the targets' in-degrees, seeded with b * N * K
+__global__ __launch_bounds__(1024) void inv_offsets_kernel(const int* __restrict__ total, int N, int K,
+                                                           int* __restrict__ offsets) {
   __shared__ int part[1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int per = (N + 1023) / 1024;
   const int t0 = min(tid * per, N), t1 = min(t0 + per, N);
   int mine = 0;
-  for (int t = t0; t < t1; ++t) {  // pass 1: this thread's targets' totals
-    const unsigned* row = bits + ((long)b * N + t) * W;
-    unsigned short* prow = pre + ((long)b * N + t) * W;
-    int c = 0;
-    for (int w = 0; w < W; ++w) {
-      prow[w] = (unsigned short)c;
-      c += __popc(row[w]);
-    }
-    if (indeg) indeg[(long)b * N + t] = c;
-    mine += c;
-  }
+  for (int t = t0; t < t1; ++t) mine += total[(long)b * N + t];
   part[tid] = mine;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan of the thread totals
@@ -476,10 +492,9 @@ __global__ __launch_bounds__(1024) void inv_count_kernel(const unsigned* __restr
     __syncthreads();
   }
   int run = (int)((long)b * N * K) + part[tid] - mine;
-  for (int t = t0; t < t1; ++t) {  // pass 2: boundaries (the totals again from the prefix of the last word)
-    const unsigned* row = bits + ((long)b * N + t) * W;
+  for (int t = t0; t < t1; ++t) {
     offsets[(long)b * N + t] = run;
-    run += (int)pre[((long)b * N + t) * W + W - 1] + __popc(row[W - 1]);
+    run += total[(long)b * N + t];
   }
   if (b == gridDim.x - 1 && tid == 1023) offsets[(long)gridDim.x * N] = run;
 }
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(256) void inv_place_kernel(const int* __restrict__ 
 
 extern "C" size_t samble_inverse_neighbors_ws_bytes(int B, int N) {
   const size_t W = (size_t)(N + 31) / 32;
-  return (size_t)B * N * W * 4 + (size_t)B * N * W * 2 + 256;
+  return (size_t)B * N * W * 4 + (size_t)B * N * W * 2 + (size_t)B * N * 4 + 768;
 }
 
 extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int K, int* order, int* offsets, int* indeg,
@@ -525,7 +540,11 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   const unsigned blocks = (unsigned)((nedges + 255) / 256);
   samble::Timed timed(samble::kT_inv_nn, s);
   hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
-  hipLaunchKernelGGL(samble::inv_count_kernel, dim3(B), dim3(1024), 0, s, bits, N, K, W, pre, offsets, indeg);
+  // (in-degrees: the caller's array, or the tail of the workspace)
+  int* tot = indeg ? indeg : reinterpret_cast<int*>(reinterpret_cast<char*>(pre) + (((size_t)B * N * W * 2 + 255) & ~(size_t)255));
+  hipLaunchKernelGGL(samble::inv_rowscan_kernel, dim3((unsigned)(((long)B * N + 3) / 4)), dim3(256), 0, s, bits, (long)B * N, W,
+                     pre, tot);
+  hipLaunchKernelGGL(samble::inv_offsets_kernel, dim3(B), dim3(1024), 0, s, tot, N, K, offsets);
   hipLaunchKernelGGL(samble::inv_place_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets, order);
   return (int)hipGetLastError();
 }
