@@ -388,8 +388,6 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
  *                                SAMBLE_ROWS_BWD_PMAP (no exponentials, no row indirection in the backward). */
 #define SAMBLE_ROWS_BWD_FUSED_DKDV 1 /* fused dP / dV / dK kernel instead of the dS map (logit map only) */
 #define SAMBLE_ROWS_BWD_PMAP 2       /* `smap` is the (B, M, ld) P map of samble_attn_rows_fwd_recompute_tri_f32 */
-#define SAMBLE_ROWS_BWD_PMAP_SERIAL 6 /* the same on the round-1 structure of the dQ kernel (dP, dS, dQ of a tile back
-                                         to back); bit-identical results, kept for A/B */
 size_t samble_nn_masks_bytes(int B, int N);
 /* nn and nn_sorted 16-byte aligned (the rows move in 16-byte pieces); KN 16 or 32 */
 int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks, void* stream);

@@ -397,7 +397,7 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
     snprintf(msg, sizeof msg, "%s: null pointer", who);
     return fail(SAMBLE_E_INVALID, msg);
   }
-  if (variant < 0 || (variant > 2 && variant != 6) || (variant >= 2 && !(k_tr_image && v_rm_image && smap))) {
+  if (variant < 0 || variant > 2 || (variant >= 2 && !(k_tr_image && v_rm_image && smap))) {
     snprintf(msg, sizeof msg, "%s: unknown variant", who);
     return fail(SAMBLE_E_INVALID, msg);
   }

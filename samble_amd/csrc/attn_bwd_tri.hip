@@ -946,11 +946,9 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
   // tile); != 0: fused dP / dV / dK kernel (5 products, no dS map)
   {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
     hipError_t e = hipSuccess;
-    for (const void* f : {reinterpret_cast<const void*>(bwd_dq_tri_kernel<0, false>),
-                          reinterpret_cast<const void*>(bwd_dq_tri_kernel<0, true>)}) {
-      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
-      if (e != hipSuccess) return (int)e;
-    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_tri_kernel<0, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kDqLds);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dq_pm_tri_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kDqpLds);
     if (e != hipSuccess) return (int)e;
@@ -958,11 +956,9 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kKvLds);
       if (e != hipSuccess) return (int)e;
     }
-    for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_tri_kernel<0, false>), reinterpret_cast<const void*>(bwd_kacc_tri_kernel<1, false>),
-                          reinterpret_cast<const void*>(bwd_kacc_tri_kernel<1, true>)}) {
-      e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
-      if (e != hipSuccess) return (int)e;
-    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_kacc_tri_kernel<0, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
+    if (e != hipSuccess) return (int)e;
     for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<false>), reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<true>)}) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccPmLds);
       if (e != hipSuccess) return (int)e;
@@ -974,8 +970,7 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
                      scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
   {
     Timed timed(kT_bwd_dq, stream);
-    if (pmap && (pmap & 4)) hipLaunchKernelGGL((bwd_dq_tri_kernel<0, true>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
-    else if (pmap) hipLaunchKernelGGL(bwd_dq_pm_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kDqpLds, stream, dq);
+    if (pmap) hipLaunchKernelGGL(bwd_dq_pm_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kDqpLds, stream, dq);
     else hipLaunchKernelGGL((bwd_dq_tri_kernel<0, false>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
   }
   if (use_map) {
@@ -984,22 +979,13 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
     {
       Timed timed(kT_bwd_dv, stream);
       if (pmap)  // P is there already: the M-row-map kernel on (P map, dO^T)
-#ifdef SAMBLE_KACC_IN_STEP
-        hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
-#else
         hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, av);
-#endif
       else
         hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
     }
     Timed timed(kT_bwd_dk, stream);
-#ifdef SAMBLE_KACC_IN_STEP
-    if (cs) hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, true>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
-    else hipLaunchKernelGGL((bwd_kacc_tri_kernel<1, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, ak);
-#else
     if (cs) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
     else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
-#endif
   } else {
     const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
                        idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};

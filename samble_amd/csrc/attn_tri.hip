@@ -900,195 +900,6 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// pass 2 without the map, PRODUCER / CONSUMER form: 8 waves = 128 sampled rows, two waves per SIMD with different
-// jobs.  A wave issues in order, so in the one-wave-per-SIMD kernel above every DMA piece, vector instruction and
-// store of the wave opens a bubble in the matrix pipe (stamped: 5 700 cycles per tile for 3 072 of MFMA).  Here
-//   waves 0-3 ("S"): P = exp(S - lse) of tile t, three-plane split, planes -> LDS (lane-linear 16-byte words), P rows
-//                    -> map (through the wave's transpose tile); then the logits of tile t+1 = Q K^T (48 MFMAs,
-//                    Q rows in registers);
-//   waves 4-7 ("O"): P planes of tile t-1 from LDS, O^T += V_{t-1}^T P^T (48 MFMAs); then every DMA piece of the
-//                    workgroup (K tile t+2, V tile t); the output at the end;
-// wave w and w + 4 share a SIMD and the same 32 rows: while one exponentiates / stages, the other's MFMAs run.
-// One barrier per tile; K and V tiles in 2-deep rings (what is staged in iteration t is used in t+1), the plane
-// buffers double: 2 x 48 + 48 + 16 KB = exactly 160 KB.  Same products in the same order as the kernel above.
-// ------------------------------------------------------------------------------------------------
-#ifdef SAMBLE_STAMPS
-__device__ unsigned long long g_pc_stamps[8 * 2 * 8];
-#define PC_STAMP(i)                                                                                        \
-  do {                                                                                                     \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (t == 20 || t == 21))                           \
-      g_pc_stamps[(wave * 2 + (t - 20)) * 8 + (i)] = __builtin_amdgcn_s_memtime();                         \
-  } while (0)
-#else
-#define PC_STAMP(i) do { } while (0)
-#endif
-constexpr int kPcLds = 4 * kTriTile + 2 * 4 * 6144 + 4 * 4096;
-
-template <bool PMAP>
-__global__ __launch_bounds__(512, 2) void attn_rows_pc_tri_kernel(const char* __restrict__ Qimg,
-                                                                  const char* __restrict__ Kimg,
-                                                                  const char* __restrict__ Vtr,
-                                                                  const float* __restrict__ lse,
-                                                                  const long long* __restrict__ idx, int N, int NK, int M,
-                                                                  float scale, float* __restrict__ xds,
-                                                                  float* __restrict__ pmap, int ld) {
-  extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
-  const bool producer = wave < 4;
-  const int rb = wave & 3;  // the 32-row block of this wave (shared by waves rb and rb + 4)
-  int chunk, b;
-  xcd_assign(chunk, b);
-  const int m0 = chunk * 128 + rb * 32;
-  const int mrow = m0 + lo;
-  const bool mvalid = mrow < M;
-  const int mc = mvalid ? mrow : M - 1;  // rows past M-1 recompute and rewrite row M-1's values (same bytes)
-  const int qtiles = (N + kTile - 1) / kTile, ntiles = (NK + kTile - 1) / kTile;
-  const char* Kb = Kimg + (long)b * ntiles * kTriTile;
-  const char* Vb = Vtr + (long)b * ntiles * kTriTile;
-  char* kring = smem_c;
-  char* vring = smem_c + 2 * kTriTile;
-  char* planes = smem_c + 4 * kTriTile + rb * 6144;       // + (t & 1) * 24576: h0 m0 l0 h1 m1 l1, 1 KB each
-  char* xt = smem_c + 4 * kTriTile + 2 * 24576 + rb * 4096;
-  const int ctid = tid & 255;  // thread index inside the role
-
-  auto stage6 = [&](const char* src, char* dst) {  // one image tile by the 256 threads of the O waves
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (ctid + 256 * k) * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + (rb * 64 + 256 * k) * 16), 16, 0, 0);
-  };
-  if (!producer) {  // K tiles 0 and 1 for the producers' prologue and first iteration
-    stage6(Kb, kring);
-    stage6(Kb + (long)min(1, ntiles - 1) * kTriTile, kring + kTriTile);
-  }
-  // The two waves of a SIMD take their matrix and non-matrix phases in OPPOSITE order within an iteration:
-  //   S wave:  [exp / split / planes / map rows of tile t]   then  [logit products of tile t+1]
-  //   O wave:  [P V products of tile t-1]                     then  [DMA pieces of K tile t+2 and V tile t]
-  if (producer) {
-    // ---------------- S waves ----------------
-    const long row = idx[(long)b * M + mc];
-    const float my_lse = lse[(long)b * N + row];
-    u32x4 q[24];
-    {
-      const u32x4* qp = reinterpret_cast<const u32x4*>(Qimg + ((long)b * qtiles + (int)(row >> 5)) * kTriTile +
-                                                       tri_rm_off((int)(row & 31), h, 0));
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        q[3 * ks] = qp[192 * ks];
-        q[3 * ks + 1] = qp[192 * ks + 32];
-        q[3 * ks + 2] = qp[192 * ks + 64];
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    f32x16 sacc;
-    stats_products<0>(kring, lo, h, q, sacc);  // tile 0
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K slot 0 is restaged by the consumers' iteration 0
-    auto step = [&](int t, auto tail_c) {
-      constexpr bool TAILK = decltype(tail_c)::value;
-      PC_STAMP(0);
-      float p[16];
-      char* pl = planes + (t & 1) * 24576 + lane * 16;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma clang fp contract(off)  // the statistics pass formed lse from round(s * scale): no fma here
-        const int r0 = 2 * i, r1 = 2 * i + 1;
-        const float e0 = __expf(sacc[r0] * scale - my_lse), e1 = __expf(sacc[r1] * scale - my_lse);
-        p[r0] = (TAILK && t * kTile + crow(r0, h) >= NK) ? 0.f : e0;  // padding keys of the last tile
-        p[r1] = (TAILK && t * kTile + crow(r1, h) >= NK) ? 0.f : e1;
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        u32x4 ph, pm, pq;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          unsigned hh, mm, ll;
-          tri_split2(p[8 * ks + 2 * w], p[8 * ks + 2 * w + 1], hh, mm, ll);
-          ph[w] = hh;
-          pm[w] = mm;
-          pq[w] = ll;
-        }
-        *reinterpret_cast<u32x4*>(pl + (3 * ks + 0) * 1024) = ph;
-        *reinterpret_cast<u32x4*>(pl + (3 * ks + 1) * 1024) = pm;
-        *reinterpret_cast<u32x4*>(pl + (3 * ks + 2) * 1024) = pq;
-      }
-      if (PMAP) {  // P tile -> map rows as full 128-byte lines through the wave's transpose tile (XOR-swizzled blocks)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 o = {p[4 * g], p[4 * g + 1], p[4 * g + 2], p[4 * g + 3]};
-          *reinterpret_cast<f32x4*>(xt + lo * 128 + (((2 * g + h) ^ (lo & 7)) << 4)) = o;
-        }
-#pragma unroll
-        for (int k8 = 0; k8 < 4; ++k8) {
-          const int rr = (lane >> 3) + 8 * k8;
-          const f32x4 o = *reinterpret_cast<const f32x4*>(xt + rr * 128 + (((lane & 7) ^ (rr & 7)) << 4));
-          const int mr = min(m0 + rr, M - 1);
-          *reinterpret_cast<f32x4*>(pmap + ((long)b * M + mr) * ld + t * kTile + 4 * (lane & 7)) = o;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      PC_STAMP(1);
-      if (!TAILK) stats_products<0>(kring + ((t + 1) & 1) * kTriTile, lo, h, q, sacc);  // tile t+1 (landed an iteration ago)
-      PC_STAMP(2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PC_STAMP(3);
-      asm volatile("s_barrier" ::: "memory");
-      PC_STAMP(4);
-    };
-    for (int t = 0; t < ntiles - 1; ++t) step(t, std::false_type{});
-    step(ntiles - 1, std::true_type{});
-    asm volatile("s_barrier" ::: "memory");  // the consumers' last iteration
-    return;
-  }
-  // ---------------- O waves ----------------
-  f32x16 oacc[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  asm volatile("s_barrier" ::: "memory");  // the producers' logits of tile 0
-  for (int t = 0; t <= ntiles; ++t) {
-    PC_STAMP(0);
-    if (t > 0) {
-      const char* pl = planes + ((t - 1) & 1) * 24576 + lane * 16;
-      Tri bp[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bp[ks] = Tri{*reinterpret_cast<const u32x4*>(pl + (3 * ks + 0) * 1024),
-                     *reinterpret_cast<const u32x4*>(pl + (3 * ks + 1) * 1024),
-                     *reinterpret_cast<const u32x4*>(pl + (3 * ks + 2) * 1024)};
-      const char* vt = vring + ((t - 1) & 1) * kTriTile;
-      tri_pipelined<8>(
-          [&](int i) {  // step i: k-step i >> 2, channel block i & 3
-            const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
-            return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
-                       *reinterpret_cast<const u32x4*>(ap + 4096)};
-          },
-          [&](int i, const Tri& a) { oacc[i & 3] = mfma_tri(a, bp[i >> 2], oacc[i & 3]); });
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    PC_STAMP(1);
-    if (t < ntiles) {
-      // K tile t+2 -> slot of tile t (its products ran in iteration t-1); V tile t -> slot of tile t-2 (read in t-1)
-      stage6(Kb + (long)min(t + 2, ntiles - 1) * kTriTile, kring + (t & 1) * kTriTile);
-      stage6(Vb + (long)t * kTriTile, vring + (t & 1) * kTriTile);
-    }
-    PC_STAMP(2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    PC_STAMP(3);
-    asm volatile("s_barrier" ::: "memory");
-    PC_STAMP(4);
-  }
-  if (mvalid) {
-    float* ob = xds + (long)b * 128 * M + mrow;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ob[(long)(32 * dt + crow(r, h)) * M] = oacc[dt][r];
-    }
-  }
-}
-
 }  // namespace samble
 
 using namespace samble;
@@ -1159,9 +970,6 @@ extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long
 }
 
 #ifdef SAMBLE_STAMPS
-extern "C" __attribute__((visibility("default"))) int samble_scratch_pc_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_pc_stamps), sizeof(unsigned long long) * 128);
-}
 extern "C" __attribute__((visibility("default"))) int samble_scratch_nl_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_nl_stamps), sizeof(unsigned long long) * 128);
 }
@@ -1208,27 +1016,6 @@ extern "C" int samble_launch_attn_rows_rc_tri(const void* qimg, const void* kimg
     if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_attn_rows, stream);
-#ifdef SAMBLE_ROWS_PRODUCER_CONSUMER  // A/B build: the producer / consumer kernel instead of the woven one-wave-per-SIMD one
-  // (measured in the step: 196 us with both waves of a SIMD in the same phase order, 213 with opposite orders -- the
-  //  O waves' DMA then has to land within the iteration it is issued in: 1 500-1 850 cycles of exposed wait -- against
-  //  193-197 for the woven kernel)
-  {
-    for (const void* f : {reinterpret_cast<const void*>(attn_rows_pc_tri_kernel<false>),
-                          reinterpret_cast<const void*>(attn_rows_pc_tri_kernel<true>)}) {
-      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kPcLds);
-      if (e != hipSuccess) return (int)e;
-    }
-    if (pmap)
-      hipLaunchKernelGGL(attn_rows_pc_tri_kernel<true>, dim3((M + 127) / 128, B), dim3(512), kPcLds, stream,
-                         (const char*)qimg, (const char*)kimg, (const char*)v_tr_image, lse, idx, N, N + nt, M, scale, xds,
-                         pmap, ld);
-    else
-      hipLaunchKernelGGL(attn_rows_pc_tri_kernel<false>, dim3((M + 127) / 128, B), dim3(512), kPcLds, stream,
-                         (const char*)qimg, (const char*)kimg, (const char*)v_tr_image, lse, idx, N, N + nt, M, scale, xds,
-                         pmap, ld);
-    return (int)hipGetLastError();
-  }
-#endif
   if (pmap)
     hipLaunchKernelGGL(attn_rows_rc_tri_kernel<true>, dim3((M + 127) / 128, B), dim3(256), kRcLds, stream,
                        (const char*)qimg, (const char*)kimg, (const char*)v_tr_image, lse, idx, N, N + nt, M, scale, xds,

@@ -512,7 +512,7 @@ def stage_attn_rows(smap: torch.Tensor, lse: torch.Tensor, v: torch.Tensor, idx:
     return out
 
 
-ROWS_BWD_FUSED_DKDV, ROWS_BWD_PMAP, ROWS_BWD_PMAP_SERIAL = 1, 2, 6   # include/samble.h: variants of samble_attn_rows_bwd_tri_f32
+ROWS_BWD_FUSED_DKDV, ROWS_BWD_PMAP = 1, 2   # include/samble.h: variants of samble_attn_rows_bwd_tri_f32
 
 
 def stage_nn_prepare(nn_idx: torch.Tensor):

@@ -916,7 +916,7 @@ def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
         assert bool((pmap[:, :, N + nt:] == 0).all())
         gr = torch.randn(B, 128, M, generator=g).to(DEV)
         grads = []
-        for m, variant in ((smap, 0), (pmap, o_.ROWS_BWD_PMAP), (pmap, o_.ROWS_BWD_PMAP_SERIAL)):
+        for m, variant in ((smap, 0), (pmap, o_.ROWS_BWD_PMAP)):
             dqkv = torch.full_like(qkv, float("nan"))
             o_.stage_attn_rows_bwd(qd, kd, vd, m, lse, x_ds, idx, gr, N, nt, dqkv[:, :N, :128], dqkv[:, :, 128:256],
                                    dqkv[:, :, 256:], images=(imgs[3], imgs[4]), variant=variant)
@@ -924,7 +924,7 @@ def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
             grads.append(dqkv)
         torch.cuda.synchronize()
         assert not bool(torch.isnan(grads[1]).any())
-        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        assert torch.equal(grads[0], grads[1])
     finally:
         o_.MATRIX_MODE = old
 
