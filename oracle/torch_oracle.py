@@ -450,9 +450,11 @@ class N2PState:
     bn2_b: torch.Tensor
 
 
-def n2p_attention(x, wq, wk, wv, k: int, heads: int, group_type: str = "diff"):
+def n2p_attention(x, wq, wk, wv, k: int, heads: int, group_type: str = "diff", asm: str = "dot",
+                  attention_mode: str = "scalar_dot"):
     """The attention part of Neighbor2PointAttention.forward (models/attention.py:167-185,
-    203-250; scalar_dot / asm dot): x (B,C,N) -> (B,C,N) before the residual BatchNorm."""
+    203-250; scalar_dot / vector_sub, asm dot / dot-sub, all four groupings): x (B,C,N) -> (B,C,N) before the
+    residual BatchNorm."""
     neighbors, idx = group_neighbors(x, k, group_type)
     B, C, N = x.shape
     D = wq.shape[0] // heads
@@ -463,14 +465,28 @@ def n2p_attention(x, wq, wk, wv, k: int, heads: int, group_type: str = "diff"):
     q = split(F.conv2d(x[:, :, :, None], wq))
     kk = split(F.conv2d(neighbors, wk)).permute(0, 1, 2, 4, 3)
     v = split(F.conv2d(neighbors, wv))
-    att = torch.softmax((q @ kk) / math.sqrt(q.shape[-1]), dim=-1)
-    out = (att @ v)[:, :, :, 0, :].permute(0, 2, 1, 3)
+    if attention_mode == "scalar_dot":
+        if asm == "dot":
+            energy = q @ kk
+        elif asm == "dot-sub":
+            energy = q @ (q.transpose(-1, -2) - kk)
+        else:
+            raise ValueError("Please check the setting of asm in feature learning layer!")
+        att = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)
+        out = (att @ v)[:, :, :, 0, :].permute(0, 2, 1, 3)
+    elif attention_mode == "vector_sub":
+        energy = q.repeat(1, 1, 1, kk.shape[-1], 1) - kk.permute(0, 1, 2, 4, 3)   # (B,H,N,K,D)
+        att = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)
+        out = (att * v).permute(0, 2, 1, 3, 4).sum(dim=-2)
+    else:
+        raise ValueError(f"attention_mode can only be scalar_dot or vector_sub, but got: {attention_mode}")
     return out.reshape(out.shape[0], out.shape[1], -1).permute(0, 2, 1), idx
 
 
-def n2p_forward(st: N2PState, x, k: int, heads: int, group_type: str = "diff", training: bool = True):
+def n2p_forward(st: N2PState, x, k: int, heads: int, group_type: str = "diff", training: bool = True, asm: str = "dot",
+                attention_mode: str = "scalar_dot"):
     """Whole layer (models/attention.py:165-193): attention, bn1(x + .), FFN, bn2(x + .)."""
-    a, idx = n2p_attention(x, st.wq, st.wk, st.wv, k, heads, group_type)
+    a, idx = n2p_attention(x, st.wq, st.wk, st.wv, k, heads, group_type, asm, attention_mode)
     y = F.batch_norm(x + a, None, None, st.bn1_w, st.bn1_b, training=True if training else False)
     f = F.conv1d(F.leaky_relu(F.conv1d(y, st.ff1), negative_slope=0.2), st.ff2)
     return F.batch_norm(y + f, None, None, st.bn2_w, st.bn2_b, training=True if training else False), a, idx

@@ -105,31 +105,58 @@ class Neighbor2PointAttention(nn.Module):
         )
         self.bn1 = nn.BatchNorm1d(v_out)
         self.bn2 = nn.BatchNorm1d(v_out)
-        if self.attention_mode != "scalar_dot":
-            if self.attention_mode == "vector_sub":
-                raise NotImplementedError("attention_mode 'vector_sub' is not built on HIP (shipped configs use scalar_dot)")
+        if self.attention_mode not in ("scalar_dot", "vector_sub"):
             raise ValueError(f"attention_mode can only be scalar_dot or vector_sub, but got: {self.attention_mode}")
-        if self.asm != "dot":
-            if self.asm == "dot-sub":
-                raise NotImplementedError("asm 'dot-sub' is not built on HIP (shipped configs use dot)")
+        if self.asm not in ("dot", "dot-sub"):
             raise ValueError("Please check the setting of asm in feature learning layer!")
-        if self.group_type not in ("diff", "neighbor"):
-            if self.group_type in ("center_neighbor", "center_diff"):
-                raise NotImplementedError(f"group_type {self.group_type!r} is not built on HIP for N2P (shipped: diff)")
+        if self.group_type not in ("diff", "neighbor", "center_neighbor", "center_diff"):
             raise ValueError(
                 f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {self.group_type}")
-        if not (q_in == q_out == k_in == k_out == v_in == v_out == 128 and self.num_heads == 4):
+        grouped = 2 * q_in if self.group_type.startswith("center_") else q_in   # channels of the grouped tensor
+        if not (q_in == q_out == k_out == v_out == 128 and k_in == v_in == grouped and self.num_heads == 4):
             raise NotImplementedError("the HIP N2P kernels are built for 128 channels, 4 heads (shipped cls/seg configs)")
 
     def forward(self, x):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.Neighbor2PointAttention runs on the GPU only (no CPU fallback)")
-        x_tmp = _N2PCore.apply(x, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.K, self.num_heads,
-                               self.group_type == "diff")
+        if self.attention_mode == "vector_sub":
+            x_tmp = self._vector_sub(x)
+        else:
+            # What the gather-attention kernel computes is softmax_j(<q_i, K x_j [- K x_i]>) and the same mix of
+            # V x_j [- V x_i].  The other scalar_dot variants of the reference reduce to it (models/attention.py:
+            # 203-250): dot-sub: q (q^T - k_j) = |q|^2 - <q, k_j>, and what does not depend on j cancels in the softmax
+            # over the neighbours -> the kernel on -K.  center_*: the 2C-channel grouped tensor [x_i ; g_ij] makes
+            # k_ij = K1 x_i + K2 g_ij, v_ij = V1 x_i + V2 g_ij; K1 x_i cancels in the softmax, V1 x_i passes through it
+            # (the weights sum to one) -> the kernel on (K2, V2) plus the per-point term V1 x_i.
+            C = x.shape[1]
+            wk, wv = self.k_conv.weight, self.v_conv.weight
+            center = self.group_type.startswith("center_")
+            wk2, wv2 = (wk[:, C:], wv[:, C:]) if center else (wk, wv)
+            if self.asm == "dot-sub":
+                wk2 = -wk2
+            x_tmp = _N2PCore.apply(x, self.q_conv.weight, wk2.contiguous(), wv2.contiguous(), self.K, self.num_heads,
+                                   self.group_type in ("diff", "center_diff"))
+            if center:
+                x_tmp = x_tmp + torch.nn.functional.conv1d(x, wv[:, :C, :, 0])
         x = self.bn1(x + x_tmp)
         x_tmp = self.ff(x)
         x = self.bn2(x + x_tmp)
         return x
+
+    def _vector_sub(self, x):
+        """attention_mode vector_sub (models/attention.py:216-225): a softmax over the D channels of each head for every
+        (point, neighbour) pair -- no shipped config uses it.  The neighbour tensor comes from the HIP gather
+        (ops.group), the rest is the reference's own expression in torch on the device (the stock composition, as for
+        EdgeConv shapes the fused kernels do not take)."""
+        B, C, N = x.shape
+        H, D = self.num_heads, self.q_depth
+        neighbors, _ = ops.group(x, self.K, self.group_type)                       # (B, C | 2C, N, K)
+        q = self.q_conv(x[:, :, :, None]).view(B, H, D, N, 1).permute(0, 1, 3, 4, 2)   # (B,H,N,1,D)
+        k = self.k_conv(neighbors).view(B, H, D, N, self.K).permute(0, 1, 3, 4, 2)     # (B,H,N,K,D)
+        v = self.v_conv(neighbors).view(B, H, D, N, self.K).permute(0, 1, 3, 4, 2)
+        att = torch.softmax((q - k) / math.sqrt(D), dim=-1)
+        out = (att * v).sum(dim=-2)                                                    # (B,H,N,D)
+        return out.permute(0, 1, 3, 2).reshape(B, C, N)
 
 
 class _P2PCore(torch.autograd.Function):

@@ -63,6 +63,46 @@ def test_n2p_against_reference_fixture(name, group_type):
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["layer_n2p_dotsub", "layer_n2p_center_diff", "layer_n2p_center_neighbor",
+                                  "layer_n2p_vector_sub"])
+def test_n2p_variants_against_reference_fixture(name):
+    """The branches of Neighbor2PointAttention no shipped config selects (models/attention.py:203-250): asm dot-sub,
+    the center_* groupings (2C-channel k / v convolutions), attention_mode vector_sub -- whole layer, forward +
+    backward, against fixtures of the unmodified reference."""
+    from samble_amd.attention import Neighbor2PointAttention, attention_config
+    d = layer_fixture(name)
+    B, C, N, K, H, seed = [int(v) for v in d["meta"]]
+    group_type, asm, mode = str(d["group_type"]), str(d["asm"]), str(d["attention_mode"])
+    cfg = attention_config("cls")
+    cfg.group_type[0], cfg.asm[0], cfg.attention_mode[0] = group_type, asm, mode
+    Ck = 2 * C if group_type.startswith("center_") else C
+    cfg.k_in[0] = cfg.v_in[0] = Ck
+    mod = Neighbor2PointAttention(cfg, 0)
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, Ck, 1, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, Ck, 1, 1), seed + 3, 0.09))
+        mod.ff[0].weight.copy_(_w((4 * C, C, 1), seed + 4, 0.09))
+        mod.ff[2].weight.copy_(_w((C, 4 * C, 1), seed + 5, 0.045))
+        mod.bn1.weight.copy_(1 + _w((C,), seed + 6, 0.1)); mod.bn1.bias.copy_(_w((C,), seed + 7, 0.1))
+        mod.bn2.weight.copy_(1 + _w((C,), seed + 8, 0.1)); mod.bn2.bias.copy_(_w((C,), seed + 9, 0.1))
+    mod = mod.to(DEV).train()
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    y = mod(x)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
+    y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    for got, key in ((x.grad, "dx"), (mod.q_conv.weight.grad, "dwq"), (mod.k_conv.weight.grad, "dwk"),
+                     (mod.v_conv.weight.grad, "dwv"), (mod.ff[0].weight.grad, "dff1")):
+        ref = torch.from_numpy(d[key])
+        if key == "dwk" and group_type.startswith("center_"):
+            # the centre's half of the key weights: its term cancels in the softmax -- the reference's gradient there
+            # is rounding noise around zero, ours is exactly zero
+            assert float(ref[:, :C].abs().max()) <= 1e-5 * float(ref[:, C:].abs().max())
+            got, ref = got[:, C:], ref[:, C:]
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
+
+
 def test_n2p_backward_kernels_match_autograd_of_the_restatement():
     """HIP backward of the gather-attention vs torch autograd of the same expression, incl. an
     index-local neighbour pattern (every neighbour inside one 64-row block) that fills the hit list."""
