@@ -169,26 +169,6 @@ __device__ __forceinline__ float duo_readlane_f(float v, int l) {
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
 }
 
-// LDS reads whose wait is placed by hand.  The compiler counts lgkmcnt itself, but not across the branches of the
-// woven selection and not the way the weave needs it: it hoists a step's prefetch reads above the step's first MFMA
-// and then waits for ALL of them (lgkmcnt(0)) to get at that MFMA's operands -- an exposed LDS round trip in front of
-// every group of MFMAs (tools/micro/weave_bench.hip: +45..70 cycles per MFMA slot).  An asm read is opaque to it: the
-// destination counts as written at the asm statement, so every consumer sits behind an explicit
-// `s_waitcnt lgkmcnt(n)` (n = reads issued later that may still be in flight; LDS returns in order) and an empty asm
-// that "rewrites" the registers (uses cannot rise above it).
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_ld128(unsigned addr) {
-  u32x4 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-  return r;
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 // One append block of the woven selection (knn_duo_kernel, pass B): under the lane mask `m` (skipped when empty) the
 // accumulator value `val` and the key code vcode | R go to ring slot min(cnt, lim) of the lane's half of the row's
 // ring -- byte addresses ba + slot * sa (values) and bj + slot * sj (codes), one v_mad_i32_i24 each -- and cnt grows.
@@ -215,7 +195,6 @@ __device__ __forceinline__ void duo_append(int& cnt, unsigned long long m, int l
       : "memory");
 }
 
-#define DUO_LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 // k-steps whose two LDS operand planes are requested two steps before their MFMAs (tri_pipelined for two planes)
 struct DuoOp {

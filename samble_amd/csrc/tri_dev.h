@@ -27,6 +27,9 @@
 //     tile rows j = 16 s + 8 (e >> 2) + 4 h + (e & 3), e = 0..7 -- the order in which a 32x32
 //     accumulator presents its rows when it is used as the other operand (accumulator-as-operand).
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "samble_dev.h"
 
 namespace samble {
@@ -152,5 +155,27 @@ struct TriStage {
     for (int i = 0; i < kPer; ++i) d[tid + NT * i] = v[i];
   }
 };
+
+// LDS reads whose wait is placed by hand.  The compiler counts lgkmcnt itself, but not across the branches of the
+// woven selection and not the way the weave needs it: it hoists a step's prefetch reads above the step's first MFMA
+// and then waits for ALL of them (lgkmcnt(0)) to get at that MFMA's operands -- an exposed LDS round trip in front of
+// every group of MFMAs (tools/micro/weave_bench.hip: +45..70 cycles per MFMA slot).  An asm read is opaque to it: the
+// destination counts as written at the asm statement, so every consumer sits behind an explicit
+// `s_waitcnt lgkmcnt(n)` (n = reads issued later that may still be in flight; LDS returns in order) and an empty asm
+// that "rewrites" the registers (uses cannot rise above it).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_ld128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+#define DUO_LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
 }  // namespace samble
