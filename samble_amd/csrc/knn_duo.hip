@@ -237,7 +237,11 @@ struct DuoLds {  // byte offsets of the workgroup's dynamic LDS
   static_assert(kTotal <= 160 * 1024 && (kTotal & 15) == 0, "LDS budget");
 };
 
-template <int KN, int C>
+// FINE: candidates pass A takes per tile and half-lane -- 1: the maximum over its 16 keys, 2: the maxima of its two
+// groups of 8.  The bound T is the KN-th largest of the candidates, so with Nk / 32 tiles a half-lane needs
+// Nk / 32 * FINE >> KN of them: at Nk = 512 (16 tiles) one per tile leaves T at the SMALLEST tile maximum, ~80
+// survivors per row against a ring of 56, a dozen prunes per wave (364-400 us where 2 048 keys take 163).
+template <int KN, int C, int FINE>
 __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict__ Qimg, int Nq,
                                                          const char* __restrict__ Kimg, int Nk,
                                                          const float* __restrict__ qnorm,
@@ -349,14 +353,30 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
         for (int r = 0; r < 16; ++r)
           if (t * 32 + crow(r, h) >= Nk) acc[r] = -__builtin_huge_valf();
       }
-      float gm = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);  // v_max3_f32
+      if constexpr (FINE == 1) {
+        float gm = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), acc[2]);  // v_max3_f32
 #pragma unroll
-      for (int r = 3; r < 15; r += 2) gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[r]), acc[r + 1]);
-      gm = fmaxf(gm, acc[15]);
-      // sorted insertion into the descending list: G[s] <- median(G[s-1], G[s], gm)
+        for (int r = 3; r < 15; r += 2) gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[r]), acc[r + 1]);
+        gm = fmaxf(gm, acc[15]);
+        // sorted insertion into the descending list: G[s] <- median(G[s-1], G[s], gm)
 #pragma unroll
-      for (int s = KS - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
-      G[0] = fmaxf(G[0], gm);
+        for (int s = KS - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
+        G[0] = fmaxf(G[0], gm);
+      } else {
+        constexpr int W = 16 / FINE;  // keys per group: 8 or 4
+#pragma unroll
+        for (int f = 0; f < FINE; ++f) {
+          float gm = __builtin_fmaxf(__builtin_fmaxf(acc[W * f], acc[W * f + 1]), acc[W * f + 2]);
+          if constexpr (W == 8) {
+            gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[8 * f + 3]), acc[8 * f + 4]);
+            gm = __builtin_fmaxf(__builtin_fmaxf(gm, acc[8 * f + 5]), acc[8 * f + 6]);
+          }
+          gm = fmaxf(gm, acc[W * f + W - 1]);
+#pragma unroll
+          for (int s = KS - 1; s > 0; --s) G[s] = __builtin_amdgcn_fmed3f(G[s - 1], G[s], gm);
+          G[0] = fmaxf(G[0], gm);
+        }
+      }
     };
     // One tile of the steady state, WOVEN: the wave issues in order and an MFMA holds its issue for 8 of the 32 cycles
     // it runs, so whatever is to overlap the matrix pipe has to sit between the MFMAs in program order (measured
@@ -384,8 +404,9 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
         for (int e = 0; e < 4; ++e) acc[4 * g + e] = cur.n[g][e];
       const unsigned la = key_a + (unsigned)(tn & 7) * D::kPlane;
       const unsigned na = nrm_a + (unsigned)min(tn, ntiles - 1) * 128u;
-      constexpr int F = 4 + NS + 8 + KS, PER = (F + NS - 1) / NS;
-      float gm = 0.f;
+      constexpr int F = 4 + NS + 8 + KS * FINE, PER = (F + NS - 1) / NS;
+      float gv[4] = {0.f, 0.f, 0.f, 0.f};
+      float& gm = gv[0];
       static_for<0, NS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         acc = mfma_h(cur.k[ks], qh[ks], acc);
@@ -395,20 +416,30 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
             nxt.n[it] = __builtin_bit_cast(f32x4, lds_ld128<32 * it>(na));
           } else if constexpr (it < 4 + NS) {
             nxt.k[it - 4] = lds_ld128<1024 * (it - 4)>(la);
-          } else if constexpr (it == 4 + NS) {
-            gm = __builtin_fmaxf(__builtin_fmaxf(pa[0], pa[1]), pa[2]);
-          } else if constexpr (it < 4 + NS + 7) {
-            constexpr int r = 3 + 2 * (it - (4 + NS) - 1);
-            gm = __builtin_fmaxf(__builtin_fmaxf(gm, pa[r]), pa[r + 1]);
-          } else if constexpr (it == 4 + NS + 7) {
-            gm = fmaxf(gm, pa[15]);
+          } else if constexpr (it < 4 + NS + 8 && FINE == 1) {
+            constexpr int j = it - (4 + NS);  // 8 steps: v_max3 x 7, v_max
+            if constexpr (j == 0) gm = __builtin_fmaxf(__builtin_fmaxf(pa[0], pa[1]), pa[2]);
+            else if constexpr (j < 7) gm = __builtin_fmaxf(__builtin_fmaxf(gm, pa[1 + 2 * j]), pa[2 + 2 * j]);
+            else gm = fmaxf(gm, pa[15]);
+          } else if constexpr (it < 4 + NS + 8 && FINE == 2) {
+            constexpr int j = it - (4 + NS), f = j >> 2, q = j & 3;  // two groups of 8: v_max3 x 3, v_max each
+            float& g = gv[f];
+            if constexpr (q == 0) g = __builtin_fmaxf(__builtin_fmaxf(pa[8 * f], pa[8 * f + 1]), pa[8 * f + 2]);
+            else if constexpr (q < 3) g = __builtin_fmaxf(__builtin_fmaxf(g, pa[8 * f + 1 + 2 * q]), pa[8 * f + 2 + 2 * q]);
+            else g = fmaxf(g, pa[8 * f + 7]);
+          } else if constexpr (it < 4 + NS + 8) {
+            constexpr int j = it - (4 + NS), f = j >> 1, q = j & 1;  // four groups of 4: v_max3, v_max each
+            float& g = gv[f];
+            if constexpr (q == 0) g = __builtin_fmaxf(__builtin_fmaxf(pa[4 * f], pa[4 * f + 1]), pa[4 * f + 2]);
+            else g = fmaxf(g, pa[4 * f + 3]);
           } else {
-            constexpr int sl = KS - 1 - (it - (4 + NS + 8));
-            if constexpr (sl > 0) G[sl] = __builtin_amdgcn_fmed3f(G[sl - 1], G[sl], gm);
-            else G[0] = fmaxf(G[0], gm);
+            constexpr int u = it - (4 + NS + 8), f = u / KS, sl = KS - 1 - u % KS;
+            const float g = gv[f];
+            if constexpr (sl > 0) G[sl] = __builtin_amdgcn_fmed3f(G[sl - 1], G[sl], g);
+            else G[0] = fmaxf(G[0], g);
           }
         });
-        asm volatile("" : "+v"(acc), "+v"(gm));
+        asm volatile("" : "+v"(acc), "+v"(gv[0]), "+v"(gv[1]), "+v"(gv[2]), "+v"(gv[3]));
         __builtin_amdgcn_sched_barrier(0);
       });
       return acc;
@@ -834,12 +865,12 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
   rank_rows(std::true_type{}, 0);
 }
 
-template <int KN, int C>
+template <int KN, int C, int FINE>
 static int launch_knn_duo(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
                           const float* knorm, const float* inv_scale, int* idx, float* d2, hipStream_t s) {
   constexpr int NT = 512;
   const size_t lds = DuoLds<C>::kTotal;
-  auto kern = knn_duo_kernel<KN, C>;
+  auto kern = knn_duo_kernel<KN, C, FINE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
@@ -892,9 +923,20 @@ extern "C" int samble_launch_knn_duo(const void* qimg, int Nq, const void* kimg,
                                      hipStream_t s) {
   const char* q = (const char*)qimg;
   const char* k = (const char*)kimg;
-  if (C == 128 && K == 32) return launch_knn_duo<32, 128>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
-  if (C == 128 && K == 16) return launch_knn_duo<16, 128>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
-  if (C == 64 && K == 32) return launch_knn_duo<32, 64>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
-  if (C == 64 && K == 16) return launch_knn_duo<16, 64>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  // candidates of pass A per half-lane: tiles x fine >= 2 K (what 2 048 keys give K = 32 with one per tile)
+  const int tiles = (Nk + 31) / 32;
+  const int fine = tiles >= 2 * K ? 1 : 2 * tiles >= 2 * K ? 2 : 4;
+  if (C == 128 && K == 32) return fine == 1 ? launch_knn_duo<32, 128, 1>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+         : fine == 2 ? launch_knn_duo<32, 128, 2>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+                     : launch_knn_duo<32, 128, 4>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 128 && K == 16) return fine == 1 ? launch_knn_duo<16, 128, 1>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+         : fine == 2 ? launch_knn_duo<16, 128, 2>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+                     : launch_knn_duo<16, 128, 4>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 64 && K == 32) return fine == 1 ? launch_knn_duo<32, 64, 1>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+         : fine == 2 ? launch_knn_duo<32, 64, 2>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+                     : launch_knn_duo<32, 64, 4>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  if (C == 64 && K == 16) return fine == 1 ? launch_knn_duo<16, 64, 1>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+         : fine == 2 ? launch_knn_duo<16, 64, 2>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
+                     : launch_knn_duo<16, 64, 4>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
   return -22;
 }
