@@ -406,24 +406,31 @@ static void launch_select(const float* keyT, int B, int Nq, int Nk, int* idx, fl
 constexpr int kVarF32 = 1, kVarTwoKernel = 2;
 
 // workspace layout: [keyT B*Nk*Nq][knorm B*Nk][qnorm B*Nq][scale B][keys B*Nq*K][mean B*C][operand images]
+extern "C" int samble_knn_duo_supported(int C, int K, int Nk);
+// Channel count of the fp16 matrix-core kernel's operand images for a C-channel problem, 0 = not its shape.  Point
+// sets of fewer than 64 channels (xyz: C = 3) are padded with zero channels: the 64-channel kernel takes 135 us where
+// the exact small-C kernel takes 550 (B = 32, N = 2 048, K = 32) -- selection, not the products, is what costs.
+static int knn_duo_channels(int C, int K, int Nk, int variant) {
+  if (variant & (kVarF32 | kVarTwoKernel)) return 0;
+  const int Cd = C == 128 ? 128 : (C >= 1 && C <= 64) ? 64 : 0;
+  return (Cd && samble_knn_duo_supported(Cd, K, Nk) && Nk >= 2 * K) ? Cd : 0;
+}
 static bool knn_uses_fused(int C, int K, int Nk, int variant) {
+  if (knn_duo_channels(C, K, Nk, variant)) return true;
   return !(variant & kVarTwoKernel) && (C == 128 || C == 64) && (K == 32 || K == 16) && Nk <= 65536 && Nk >= 2 * K;
 }
 static bool knn_uses_small_fused(int C, int K, int Nk, int variant) {
-  return C <= 8 && !(variant & kVarTwoKernel) && Nk <= 65536 && Nk >= K;
+  return C <= 8 && !(variant & kVarTwoKernel) && Nk <= 65536 && Nk >= K && !knn_duo_channels(C, K, Nk, variant);
 }
-extern "C" int samble_knn_duo_supported(int C, int K, int Nk);
 extern "C" size_t samble_knn_duo_image_bytes(int B, int C, int N);
 extern "C" int samble_launch_knn_duo_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
-                                          int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
+                                          int Cin, int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
                                           float* qnorm, float* knorm, hipStream_t s);
 extern "C" int samble_launch_knn_duo(const void* qimg, int Nq, const void* kimg, int Nk, int B, int C, int K,
                                      const float* qnorm, const float* knorm, const float* inv_scale, int* idx, float* d2,
                                      hipStream_t s);
 // two fp16 planes per operand on the matrix cores (knn_duo.hip): the default for C in {64, 128}, K in {16, 32}
-static bool knn_uses_duo(int C, int K, int Nk, int variant) {
-  return !(variant & (kVarF32 | kVarTwoKernel)) && samble_knn_duo_supported(C, K, Nk) && Nk >= 2 * K;
-}
+static bool knn_uses_duo(int C, int K, int Nk, int variant) { return knn_duo_channels(C, K, Nk, variant) != 0; }
 
 extern "C" int samble_launch_cloud_mean(const float* x, long bs, int C, int N, int B, float* mean, hipStream_t s) {
   hipLaunchKernelGGL(cloud_mean_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, x, bs, C, N, mean);
@@ -438,7 +445,8 @@ static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K, int variant) 
       (knn_uses_fused(C, K, Nk, variant) || knn_uses_small_fused(C, K, Nk, variant)) ? 0 : (size_t)B * Nk * Nq;
   const size_t centred = knn_centres_copy(C, K, Nk, variant) ? (size_t)B * C * ((size_t)Nq + Nk) : 0;
   // (mean B*C; the duo path: + the key set's scratch mean, two per-channel extents, 1/scale per cloud)
-  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + (size_t)4 * B * C + B +
+  const int Cd = knn_duo_channels(C, K, Nk, variant), Cw = Cd > C ? Cd : C;
+  const size_t n = key_matrix + (size_t)B * Nk + (size_t)B * Nq + (size_t)B + (size_t)B * Nq * K + (size_t)4 * B * Cw + B +
                    centred + 64;
   return (n + 63) & ~(size_t)63;  // what follows (operand images) stays 256-byte aligned
 }
@@ -446,8 +454,8 @@ static size_t knn_base_floats(int B, int C, int Nq, int Nk, int K, int variant) 
 // duo path: + the fp16 operand images of the two point sets (knn_duo.hip)
 extern "C" size_t samble_knn_ws_floats(int B, int C, int Nq, int Nk, int K, int variant) {
   size_t n = knn_base_floats(B, C, Nq, Nk, K, variant);
-  if (knn_uses_duo(C, K, Nk, variant))
-    n += (samble_knn_duo_image_bytes(B, C, Nq) + samble_knn_duo_image_bytes(B, C, Nk)) / 4;
+  if (const int Cd = knn_duo_channels(C, K, Nk, variant))
+    n += (samble_knn_duo_image_bytes(B, Cd, Nq) + samble_knn_duo_image_bytes(B, Cd, Nk)) / 4;
   return n;
 }
 
@@ -482,19 +490,19 @@ extern "C" int samble_launch_knn(const float* xq, long q_bs, int Nq, const float
   bool have_qnorm = false;
   if (fused) {
     int rc = 0;
-    if (knn_uses_duo(C, K, Nk, variant)) {
+    if (const int Cd = knn_duo_channels(C, K, Nk, variant)) {
       // fp16 matrix cores on two-plane operands: centred, scaled images + norms of the point sets first (one
-      // image if the sets coincide)
+      // image if the sets coincide); Cd > C: zero channels behind the C real ones
       char* kimg = reinterpret_cast<char*>(ws + knn_base_floats(B, C, Nq, Nk, K, variant));
       const bool same = xq == xk && Nq == Nk && q_bs == k_bs;
-      char* qimg = same ? kimg : kimg + samble_knn_duo_image_bytes(B, C, Nk);
-      float* amax = mean + (size_t)2 * B * C;
-      float* inv_scale = mean + (size_t)4 * B * C;
-      rc = samble_launch_knn_duo_prep(xq, q_bs, Nq, same ? nullptr : xk, k_bs, Nk, B, C, mean, amax, inv_scale, qimg, kimg,
-                                      qnorm, knorm, stream);
+      char* qimg = same ? kimg : kimg + samble_knn_duo_image_bytes(B, Cd, Nk);
+      float* amax = mean + (size_t)2 * B * Cd;
+      float* inv_scale = mean + (size_t)4 * B * Cd;
+      rc = samble_launch_knn_duo_prep(xq, q_bs, Nq, same ? nullptr : xk, k_bs, Nk, B, C, Cd, mean, amax, inv_scale, qimg,
+                                      kimg, qnorm, knorm, stream);
       have_qnorm = true;
       if (!rc)
-        rc = samble_launch_knn_duo(qimg, Nq, kimg, Nk, B, C, K, same ? knorm : qnorm, knorm, inv_scale, idx_out, kout,
+        rc = samble_launch_knn_duo(qimg, Nq, kimg, Nk, B, Cd, K, same ? knorm : qnorm, knorm, inv_scale, idx_out, kout,
                                    stream);
     } else {
       hipLaunchKernelGGL(rownorm_kernel, dim3((Nk + 255) / 256, B), dim3(256), 0, stream, xk, k_bs, C, Nk, knorm);

@@ -52,10 +52,15 @@ __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 // per (cloud, channel): mean over the points and largest |x| (one wave each, fixed order)
-__global__ __launch_bounds__(256) void cloud_mean_amax_kernel(const float* __restrict__ x, long bs, int C, int N,
+// (channels Cin .. C-1 do not exist in x: the zero padding of a narrow point set, mean = amax = 0)
+__global__ __launch_bounds__(256) void cloud_mean_amax_kernel(const float* __restrict__ x, long bs, int Cin, int C, int N,
                                                               float* __restrict__ mean, float* __restrict__ amax) {
   const int b = blockIdx.y, c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (c >= C) return;
+  if (c >= Cin) {
+    if (lane == 0) mean[b * C + c] = amax[b * C + c] = 0.f;
+    return;
+  }
   const float* p = x + (long)b * bs + (long)c * N;
   float s = 0.f, mx = 0.f;
   int n = 0;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void cloud_mean_amax_kernel(const float* __res
 // -|x~|^2 / 2 of every point (of the values the image holds, fixed order) and 1 / scale per cloud.
 // scale = 2^(12 - e), e = exponent of max_c (amax_c + |mean_c|) >= max |x - mean|: the scaled coordinates stay below 2^13
 template <int C>
-__global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restrict__ x, long bs, int N,
+__global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restrict__ x, long bs, int Cin, int N,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ amax, char* __restrict__ img_all,
                                                            float* __restrict__ norm_all,
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void duo_split_cm_kernel(const float* __restri
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int c = 8 * g + 2 * i + u;
-        const float v = (n < N) ? (xb[(long)c * N + n] - mb[c]) * s : 0.f;
+        const float v = (n < N && c < Cin) ? (xb[(long)c * N + n] - mb[c]) * s : 0.f;
         const _Float16 h = (_Float16)v;            // round to nearest even
         const _Float16 m = (_Float16)(v - (float)h);  // the subtraction is exact
         xt[u] = (float)h + (float)m;                // exact: the planes do not overlap
@@ -897,23 +902,23 @@ extern "C" size_t samble_knn_duo_image_bytes(int B, int C, int N) { return (size
 // centred, scaled operand images and squared norms of the two point sets (xk == nullptr: the key set is the query
 // set); mean (B*C), amax (B*C), inv_scale (B): scratch / outputs
 extern "C" int samble_launch_knn_duo_prep(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B,
-                                          int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
+                                          int Cin, int C, float* mean, float* amax, float* inv_scale, void* qimg, void* kimg,
                                           float* qnorm, float* knorm, hipStream_t s) {
   Timed timed(kT_knn_prep, s);
-  hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xq, q_bs, C, Nq, mean, amax);
+  hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xq, q_bs, Cin, C, Nq, mean, amax);
   if (xk) {
     // the key set is centred on the QUERY set's mean too (utils/ops.py:23-25): its extent enters the bound
     float* amax_k = amax + (size_t)B * C;
     float* mean_k = mean + (size_t)B * C;  // (scratch: the key set's own mean is not used)
-    hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xk, k_bs, C, Nk, mean_k, amax_k);
+    hipLaunchKernelGGL(cloud_mean_amax_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, xk, k_bs, Cin, C, Nk, mean_k, amax_k);
     hipLaunchKernelGGL(duo_amax_merge_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, amax, amax_k, B * C);
   }
   if (C == 128) {
-    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
-    hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
+    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Cin, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
+    hipLaunchKernelGGL(duo_split_cm_kernel<128>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Cin, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
   } else {
-    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
-    hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
+    if (xk) hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nq + 31) / 32, B), dim3(256), 0, s, xq, q_bs, Cin, Nq, mean, amax, (char*)qimg, qnorm, inv_scale);
+    hipLaunchKernelGGL(duo_split_cm_kernel<64>, dim3((Nk + 31) / 32, B), dim3(256), 0, s, xk ? xk : xq, xk ? k_bs : q_bs, Cin, Nk, mean, amax, (char*)kimg, knorm, inv_scale);
   }
   return (int)hipGetLastError();
 }

@@ -54,9 +54,11 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
 
 // c += a b over one 16-deep k-step, six partial products, smallest first
 __device__ __forceinline__ f32x16 mfma_tri(const Tri& a, const Tri& b, f32x16 c) {
+#ifndef SAMBLE_TRI_HALF  // (timing-only scratch builds, tools/tri_half.sh: what three products per k-step would cost)
   c = mfma_bf(a.m, b.m, c);
   c = mfma_bf(a.h, b.l, c);
   c = mfma_bf(a.l, b.h, c);
+#endif
   c = mfma_bf(a.h, b.m, c);
   c = mfma_bf(a.m, b.h, c);
   c = mfma_bf(a.h, b.h, c);
