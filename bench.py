@@ -298,6 +298,8 @@ def main():
     ap.add_argument("--workload", default="metric", choices=["metric", "stress", "block_cls", "block_seg"],
                     help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096; "
                          "block_cls / block_seg = configs[1] / configs[2]: the whole feature-learning block, B=32 N=2048")
+    ap.add_argument("--prewarm-steps", type=int, default=250,
+                    help="untimed steps before the --warmup steps (device pre-warm, ~0.3 s; metric / stress workloads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--logit-map", action="store_true",
@@ -368,6 +370,12 @@ def main():
         x_ds.backward(g)
         opt.step()
 
+    # Device pre-warm (untimed, before the W warm-up steps): a fresh process starts on a GPU that has been idle -- the
+    # first ~0.3 s of steps run 2-3 % slower than the steady state a training job sees (clocks, caches, allocator).  The
+    # number of pre-warm steps is reported in the JSON line; --prewarm-steps 0 turns it off.
+    prewarm_steps = max(args.prewarm_steps, 0)  # (a count, not a time: every rank runs the same collectives)
+    for _ in range(prewarm_steps):
+        step()
     for _ in range(args.warmup):
         step()
     tri = ops.MATRIX_MODE == "tri"
@@ -421,6 +429,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": prewarm_steps,
             "ms_per_step": round(ms_per_step, 4),
             "ms_per_step_median": round(statistics.median(step_ms), 4),
             "higher_is_better": True,

@@ -93,7 +93,7 @@ def test_bench_starts_its_own_ranks():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                          "--no-breakdown", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+                          "--prewarm-steps", "4", "--no-breakdown", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)

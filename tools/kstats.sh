@@ -4,7 +4,7 @@ tag=${1:-k}; shift
 export TMPDIR=/tmp
 out=$PWD/gpurun_out
 mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o run -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-breakdown "$@" > "$out/${tag}_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o run -- python3 bench.py --steps 20 --warmup 5 --prewarm-steps 0 --no-cpu-baseline --no-breakdown "$@" > "$out/${tag}_stats.log" 2>&1
 python3 - "$out/${tag}_stats" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -6,7 +6,7 @@ tag=${1:-d}
 out=$PWD/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
-P=${PMC_CMD:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown"}
+P=${PMC_CMD:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-breakdown --prewarm-steps 0"}
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES \
   --output-format csv -d "$out/${tag}_deep1" -o run -- $P > "$out/${tag}_deep1.log" 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY \
