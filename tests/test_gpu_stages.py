@@ -131,6 +131,31 @@ def test_knn_ragged_sizes_fused():
         assert all(len(set(r.tolist())) == K for r in idx.reshape(-1, K)[::17])
 
 
+@pytest.mark.parametrize("C,Nq,Nk,K", [(3, 2048, 2048, 32), (3, 512, 512, 32), (3, 300, 64, 32), (6, 1000, 700, 16),
+                                        (32, 640, 640, 32), (128, 512, 512, 32), (128, 96, 64, 32), (64, 256, 1024, 16)])
+def test_knn_narrow_sets_and_short_key_sets_on_the_matrix_core_kernel(C, Nq, Nk, K):
+    """C < 64 (xyz: C = 3) runs on the fp16 matrix-core kernel with zero channels behind the real ones
+    (csrc/knn.hip knn_duo_channels), and key sets of fewer than 64 K points take 2 or 4 seed candidates per tile
+    (csrc/knn_duo.hip FINE): neighbour sets against the oracle, distances against the reference-normalised ones, no
+    duplicate and no out-of-range index, rows in ascending distance."""
+    B = 2
+    gen = (lambda n, s: synth.xyz_clouds(B, n, s)) if C == 3 else (lambda n, s: synth.features(B, C, n, s))
+    a = torch.from_numpy(gen(Nq, 400 + Nq + C))
+    b = a if Nq == Nk else torch.from_numpy(gen(Nk, 900 + Nk + C))
+    idx, dist = ops().stage_knn(a.to(DEV), b.to(DEV), K, want_dist=True)
+    idx, dist = idx.cpu(), dist.cpu()
+    ref_d, ref_i = O.knn(a.permute(0, 2, 1), b.permute(0, 2, 1), K)
+    assert int(idx.min()) >= 0 and int(idx.max()) < Nk
+    assert all(len(set(r.tolist())) == K for r in idx.reshape(-1, K)[::7])
+    assert set_agreement(idx, ref_i) >= 0.999, set_agreement(idx, ref_i)
+    # squared distances: the kernel forms |a|^2 + |b|^2 - 2 a.b from 22-bit operands, so the error is absolute in d^2
+    # (a square root would blow it up next to d = 0, the self match)
+    d2, ref2 = dist.double() ** 2, ref_d.double() ** 2
+    top = float(ref2.max())
+    assert bool((d2[:, :, 1:] >= d2[:, :, :-1] - 1e-5 * top).all())
+    torch.testing.assert_close(d2, ref2, rtol=1e-3, atol=1e-5 * top)
+
+
 def test_knn_xyz_cross_set_with_distance():
     B, Nq, Nk, K = 2, 700, 300, 3
     a = torch.from_numpy(synth.xyz_clouds(B, Nq, 11))
