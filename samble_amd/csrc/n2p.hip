@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(const float* __restri
   }
 }
 
+template <bool FULL>  // FULL: KN == 32, no slot of the 32 is masked (the shipped configs)
 __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restrict__ qkv, long bs, long rs,
                                                             const int* __restrict__ nn,
                                                             const float* __restrict__ gt,  // (B,N,128)
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
   const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
   const int hl = 32 / heads;
   const float* base = qkv + (long)b * bs;
+#pragma unroll 1
   for (int pp = 0; pp < 4; ++pp) {
     const int i = chunk * 32 + hw * 4 + pp;
     if (i >= N) continue;  // uniform per half-wave
@@ -175,66 +177,78 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
       qkc = head_sum(dot4(q, kc), hl);
     }
     const int* ni = nn + ((long)b * N + i) * KN;
+    // ONE sweep over the neighbours (their K and V rows are gathered once, as in the forward): the logits and da stay in
+    // registers (one value per neighbour: this lane's head), and dQ comes from three running sums under the
+    // online-softmax rescaling -- with p_k = exp(logit_k - m):  l = sum p_k,  D = sum p_k da_k,
+    // S2 = sum p_k K_j,  S1 = sum p_k da_k K_j  =>  delta = D / l  and
+    //     dQ = sum_k dl_k (K_j - k_c) = scale (S1 - delta S2) / l        (sum_k dl_k = 0: the k_c term drops out)
+    // (round 2 re-read every K row in a second loop over the neighbours: three row gathers per pair, 160 registers.)
     float lg[32], da[32];
+    float m = kNegInf, l = 0.f, D = 0.f;
+    f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k0 = 0; k0 < 32; k0 += 4) {
       f32x4 kv[4], vv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int j = (k0 + u < KN) ? ni[k0 + u] : ni[0];
+        const int j = (FULL || k0 + u < KN) ? ni[k0 + u] : ni[0];
         const float* jr = base + (long)j * rs + 4 * c;
         kv[u] = *reinterpret_cast<const f32x4*>(jr + 128);
         vv[u] = *reinterpret_cast<const f32x4*>(jr + 256);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        lg[k0 + u] = (k0 + u < KN) ? (head_sum(dot4(q, kv[u]), hl) - qkc) * scale : kNegInf;
-        da[k0 + u] = head_sum(dot4(g, vv[u]), hl);
+        const int k = k0 + u;
+        lg[k] = (FULL || k < KN) ? (head_sum(dot4(q, kv[u]), hl) - qkc) * scale : kNegInf;
+        da[k] = head_sum(dot4(g, vv[u]), hl);
+        if (FULL || k < KN) {
+          const float mn = fmaxf(m, lg[k]);
+          const float al = __expf(m - mn), p = __expf(lg[k] - mn), pd = p * da[k];
+          l = l * al + p;
+          D = D * al + pd;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            S2[e] = S2[e] * al + p * kv[u][e];
+            S1[e] = S1[e] * al + pd * kv[u][e];
+          }
+          m = mn;
+        }
       }
-    }
-    float m = kNegInf;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) m = fmaxf(m, lg[k]);
-    float l = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      lg[k] = __expf(lg[k] - m);  // masked slots: exp(-inf) = 0
-      l += lg[k];
+      // the running sums are DUE here (else their updates sink below the loop and all 32 K rows stay in registers)
+      asm volatile("" : "+v"(S1), "+v"(S2), "+v"(l), "+v"(D), "+v"(m));
     }
     const float inv = 1.f / l;
     float delta = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
-      lg[k] *= inv;  // a_ij
+      lg[k] = __expf(lg[k] - m) * inv;  // a_ij (masked slots: exp(-inf) = 0)
       delta = fmaf(lg[k], da[k], delta);
     }
     float sdl = 0.f;
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-    float* Ai = A + ((long)b * N + i) * KN * 4;
-    float* Di = DL + ((long)b * N + i) * KN * 4;
+    // (one lane-dependent base per array + constant offsets: the compiler otherwise keeps 64 precomputed 64-bit
+    // addresses alive across the loop over the points)
+    float* Ai = A + ((long)b * N + i) * KN * 4 + c / hl;
+    float* Di = DL + ((long)b * N + i) * KN * 4 + c / hl;
+    asm volatile("" : "+v"(Ai), "+v"(Di));
+    const bool writer = (c & (hl - 1)) == 0;
 #pragma unroll
-    for (int k0 = 0; k0 < 32; k0 += 4) {
-      f32x4 kv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = (k0 + u < KN) ? ni[k0 + u] : ni[0];
-        kv[u] = *reinterpret_cast<const f32x4*>(base + (long)j * rs + 4 * c + 128);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;
-        if (k < KN) {
-          const float dl = lg[k] * (da[k] - delta) * scale;
-          sdl += dl;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dq[e] = fmaf(dl, kv[u][e] - kc[e], dq[e]);
-          if ((c & (hl - 1)) == 0) {
-            Ai[k * 4 + c / hl] = lg[k];
-            Di[k * 4 + c / hl] = dl;
-          }
+    for (int k = 0; k < 32; ++k) {
+      if (FULL || k < KN) {
+        const float dl = lg[k] * (da[k] - delta) * scale;
+        sdl += dl;
+        if (writer) {
+          Ai[k * 4] = lg[k];
+          Di[k * 4] = dl;
         }
       }
     }
+    f32x4 dq;
+    {
+      const float dsum = D * inv;  // = delta up to rounding; the same normalisation as S1 / l, S2 / l
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dq[e] = scale * inv * (S1[e] - dsum * S2[e]);
+    }
+    (void)kc;
     float* drow = dqkv + (long)b * dbs + (long)i * drs + 4 * c;
     *reinterpret_cast<f32x4*>(drow) = dq;
     f32x4 sk = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
@@ -577,7 +591,7 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
   }
   Timed timed(kT_n2p_bwd, s);  // (transpose + per-point kernel + gather / scatter of the neighbours' shares)
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
-  hipLaunchKernelGGL(n2p_bwd_point_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
+  hipLaunchKernelGGL(KN == 32 ? n2p_bwd_point_kernel<true> : n2p_bwd_point_kernel<false>, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
                      scale, dqkv, dbs, drs, A, DL, heads);
   if (order && offs)
     hipLaunchKernelGGL(n2p_bwd_gather_kernel, dim3(2048), dim3(256), 0, s, qkv, bs, rs, gt, A, DL, order, offs, N, KN,
