@@ -739,6 +739,14 @@ def knn(a: torch.Tensor, b: torch.Tensor, k: int):
 def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """utils/ops.py:5-14: points (B,N,C), idx (B,M,K) -> (B,M,K,C)."""
     shape = idx.shape
+    B, N, C = points.shape
+    if points.is_cuda and points.requires_grad:
+        # same rows, picked as an embedding lookup over the (B*N, C) table: its backward is ATen's sorted segment
+        # reduction instead of torch.gather's element-wise atomic scatter (1.09 ms -> 0.2 ms for the seg block's
+        # interpolation: 6 144 picks of 128 channels per cloud)
+        flat = (idx.reshape(B, -1).long() + torch.arange(B, device=idx.device)[:, None] * N).reshape(-1)
+        res = torch.nn.functional.embedding(flat, points.reshape(B * N, C))
+        return res.view(*shape, C)
     flat = idx.reshape(shape[0], -1).long()
     res = torch.gather(points, 1, flat[..., None].expand(-1, -1, points.shape[-1]))
     return res.view(*shape, -1)
