@@ -60,11 +60,14 @@ const char* samble_last_error(void);
  * dist_out (B,Nq,K) or NULL: POSITIVE distance of the reference-normalised points (centred on
  * xq's mean, divided by the mean unbiased per-channel std), i.e. -1 * the reference's first
  * return value.  K in {1,3,8,16,20,32,40,64}.
- * variant (stateless kernel choice, same results contract): 0 = the default for the shape (C = 128,
- * K in {16,32}: fused Gram + top-K on the bf16 matrix cores with split fp32 operands, points centred
- * on xq's mean as the reference does; C = 64: fused fp32-MFMA kernel; C <= 8: exact sum (a-b)^2 on
- * the vector ALU); SAMBLE_KNN_FP32_MFMA = fused fp32-MFMA kernel also for C = 128;
- * SAMBLE_KNN_TWO_KERNEL = key matrix through HBM + row select (what every other shape falls back to). */
+ * variant (stateless kernel choice, same results contract): 0 = the default for the shape (K in {16,32},
+ * Nk >= 2 K, C = 128 or C <= 64: fused Gram + top-K on the fp16 matrix cores, operands = two fp16 planes
+ * of the points centred on xq's mean (as the reference centres them) under a per-cloud power-of-two
+ * scale, C < 64 zero-padded to 64 channels; other K with C <= 8: exact sum (a-b)^2 on the vector ALU);
+ * SAMBLE_KNN_FP32_MFMA = the fused fp32-MFMA kernel for C in {64,128};
+ * SAMBLE_KNN_TWO_KERNEL = key matrix through HBM + row select (what every other shape falls back to).
+ * dist_out of the matrix-core kernels is formed as |a|^2 + |b|^2 - 2 a.b: absolute error ~2^-21 |a||b| in
+ * d^2 (the self match comes out as sqrt of that, not as 0); the vector-ALU path is exact to fp32 rounding. */
 #define SAMBLE_KNN_FP32_MFMA 1
 #define SAMBLE_KNN_TWO_KERNEL 2
 size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K, int variant);
@@ -408,7 +411,7 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
 #define SAMBLE_T_ATTN_STATS 1   /* attn_stats(_tri / _nl_tri): QK^T + softmax statistics over all rows */
 #define SAMBLE_T_ATTN_ROWS 2    /* attn_rows(_tri / _rc_tri): P V of the sampled rows */
 #define SAMBLE_T_BWD_DV 3       /* bwd_kacc_tri (dV) */
-#define SAMBLE_T_KNN 4          /* knn_tri / knn_stream: fused Gram + top-K */
+#define SAMBLE_T_KNN 4          /* knn_duo / knn_stream: fused Gram + top-K */
 #define SAMBLE_T_ATTN_FWD 5     /* attn_fwd: single-pass flash forward */
 #define SAMBLE_T_BWD_DQ 6       /* bwd_dq_tri (dP, dS map, dQ) */
 #define SAMBLE_T_BWD_DK 7       /* bwd_kacc_tri<1> (dK) */
