@@ -298,8 +298,12 @@ def main():
     ap.add_argument("--workload", default="metric", choices=["metric", "stress", "block_cls", "block_seg"],
                     help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096; "
                          "block_cls / block_seg = configs[1] / configs[2]: the whole feature-learning block, B=32 N=2048")
-    ap.add_argument("--prewarm-steps", type=int, default=250,
-                    help="untimed steps before the --warmup steps (device pre-warm, ~0.3 s; metric / stress workloads)")
+    ap.add_argument("--prewarm-steps", type=int, default=0,
+                    help="untimed steps before the --warmup steps, with the parameters put back afterwards (metric / "
+                         "stress workloads; worth ~1 %% on an idle GPU, off by default)")
+    ap.add_argument("--lr", type=float, default=1e-4,
+                    help="SGD learning rate of the synthetic step (0 keeps the weights where they are: long runs for "
+                         "power / clock probes, where 1e-4 against a fixed random gradient would blow the weights up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--logit-map", action="store_true",
@@ -357,7 +361,7 @@ def main():
     model = mod
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(mod, device_ids=[local])
-    opt = torch.optim.SGD(mod.parameters(), lr=1e-4)
+    opt = torch.optim.SGD(mod.parameters(), lr=args.lr)
 
     # this rank's shard of the global batch (cloud ids rank*32 .. rank*32+31), resident in HBM
     x = torch.from_numpy(synth.features(B_PER_GPU, C, N, seed + 1, first_cloud=rank * B_PER_GPU)).to(dev)
@@ -370,12 +374,20 @@ def main():
         x_ds.backward(g)
         opt.step()
 
-    # Device pre-warm (untimed, before the W warm-up steps): a fresh process starts on a GPU that has been idle -- the
-    # first ~0.3 s of steps run 2-3 % slower than the steady state a training job sees (clocks, caches, allocator).  The
-    # number of pre-warm steps is reported in the JSON line; --prewarm-steps 0 turns it off.
+    # Optional device pre-warm (untimed, before the W warm-up steps; off by default): a fresh process starts on a GPU
+    # that has been idle, and the first tenths of a second run ~1 % slower.  Reported as prewarm_steps.
     prewarm_steps = max(args.prewarm_steps, 0)  # (a count, not a time: every rank runs the same collectives)
-    for _ in range(prewarm_steps):
-        step()
+    if prewarm_steps:
+        # the pre-warm must not change the workload: 250 SGD steps against a fixed random upstream gradient blow the
+        # projection weights up (|W_q| 6.5 -> 18 after 300 steps), the attention saturates and the bins collapse onto
+        # one.  Parameters and boundary state are put back afterwards.
+        saved = {k_: v_.detach().clone() for k_, v_ in mod.state_dict().items()}
+        saved_bounds = None if mod.bin_boundaries is None else [b_.clone() for b_ in mod.bin_boundaries]
+        for _ in range(prewarm_steps):
+            step()
+        with torch.no_grad():
+            mod.load_state_dict(saved)
+        mod.bin_boundaries = saved_bounds
     for _ in range(args.warmup):
         step()
     tri = ops.MATRIX_MODE == "tri"

@@ -3,7 +3,7 @@
 # (rocm-smi needs no privileges for reading).  Output: gpurun_out/power_probe.log
 steps=${1:-3000}
 out=gpurun_out/power_probe.log; mkdir -p gpurun_out; : > $out
-python3 bench.py --steps $steps --warmup 50 --no-cpu-baseline > gpurun_out/power_probe_bench.log 2>&1 &
+python3 bench.py --steps $steps --warmup 50 --lr 0 --no-cpu-baseline > gpurun_out/power_probe_bench.log 2>&1 &
 pid=$!
 sleep 12   # import + warm-up
 for i in $(seq 1 12); do
