@@ -95,6 +95,7 @@ _SIGNATURES = {
     "samble_proj_fwd_split_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_tri_k_logit_form": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "samble_tri_split_qkv_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     "samble_attn_rows_bwd_tri_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

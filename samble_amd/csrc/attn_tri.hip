@@ -113,27 +113,30 @@ constexpr int kStPadT = 36;
 // the loads it has just issued (measured: 2900 cycles per tile instead of the MFMA time).
 // ABL (timing-only ablations, wrong outputs): 1 = no map stores, 2 = no matrix products
 template <int ABL>
-__device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int lo, int h, const u32x4 (&q)[24],
-                                               f32x16& s_nxt) {
+__device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int lo, int h, const u32x4 (&qd)[16],
+                                               float q_unscale, f32x16& s_nxt) {
+  // Kn: a K tile converted to two fp16 planes (tri_k_to_duo_kernel): h in the first, l in the second piece slot of
+  // each channel group; qd: this lane's query row as two fp16 planes (duo_q_from_tri)
   const u32x4* lp = reinterpret_cast<const u32x4*>(Kn + tri_rm_off(lo, h, 0));  // group 2 ks + h: + ks * 192 chunks
+  const float f = q_unscale * *reinterpret_cast<const float*>(Kn + kDuoScaleSlot);  // 2^-(e_q + e_k): exact
   s_nxt = zero16();
   if (ABL & 8) {  // the compiler's own placement of the operand reads
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
-      const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-      if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
-      else s_nxt = mfma_tri(a, bq, s_nxt);
+      const u32x4 ah = lp[192 * ks], al = lp[192 * ks + 32];
+      if (ABL & 2) s_nxt[ks] += __uint_as_float(ah[0] ^ qd[2 * ks + 1][1]);
+      else s_nxt = mfma_duo(ah, al, qd[2 * ks], qd[2 * ks + 1], s_nxt);
     }
-    return;
+  } else {
+    // operand reads two k-steps ahead of their MFMAs (stamped: 44-51 cycles per MFMA with the compiler's placement)
+    tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], u32x4{0, 0, 0, 0}}; },
+                     [&](int ks, const Tri& a) {
+                       if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ qd[2 * ks + 1][1]);
+                       else s_nxt = mfma_duo(a.h, a.m, qd[2 * ks], qd[2 * ks + 1], s_nxt);
+                     });
   }
-  // operand reads two k-steps ahead of their MFMAs (stamped: 44-51 cycles per MFMA with the compiler's placement)
-  tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; },
-                   [&](int ks, const Tri& a) {
-                     const Tri bq = {q[3 * ks], q[3 * ks + 1], q[3 * ks + 2]};
-                     if (ABL & 2) s_nxt[ks] += __uint_as_float(a.h[0] ^ bq.l[1]);
-                     else s_nxt = mfma_tri(a, bq, s_nxt);
-                   });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_nxt[r] *= f;
 }
 
 template <bool TAIL, bool L2, int ABL>
@@ -260,8 +263,11 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
 
   // all D prologue tiles (and this wave's Q rows) have landed; from here on the waits are counted
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  u32x4 qd[16];  // the query row as two fp16 planes under its own scale (tri_dev.h)
+  float q_unscale;
+  duo_q_from_tri(q, qd, q_unscale);
   f32x16 s_cur, s_nxt;
-  stats_products<ABL>(buf_ptr(0), lo, h, q, s_cur);
+  stats_products<ABL>(buf_ptr(0), lo, h, qd, q_unscale, s_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
 
   // iteration t: restage the buffer of tile t (read one iteration ago) with tile t+D, products of tile
@@ -276,13 +282,13 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
     // the two waves of a SIMD (w and w + 4) take the two phases in opposite order, so one's vector work
     // and stores run under the other's MFMAs (same order: both in the MFMA phase, then both out of it)
     if (pfirst || (ABL & 4)) {
-      stats_products<ABL>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
       __builtin_amdgcn_sched_barrier(0);
       stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
     } else {
       stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
       __builtin_amdgcn_sched_barrier(0);
-      stats_products<ABL>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((ABL & 1) ? 3 * (D - 2) : 4 + 7 * (D - 2))
                  : "memory");
@@ -439,8 +445,11 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
 
   // all D prologue tiles (and this wave's Q rows) have landed; from here on the waits are counted
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  u32x4 qd[16];  // the query row as two fp16 planes under its own scale (tri_dev.h)
+  float q_unscale;
+  duo_q_from_tri(q, qd, q_unscale);
   f32x16 s_cur, s_nxt;
-  stats_products<0>(buf_ptr(0), lo, h, q, s_cur);
+  stats_products<0>(buf_ptr(0), lo, h, qd, q_unscale, s_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
 
   // iteration t: restage the slot of tile t (read one iteration ago) with tile t+D and its mask word, products of
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
     stage(t + D);
     NL_STAMP(1);
     if (pfirst) {
-      stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
       stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
       stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
-      stats_products<0>(buf_ptr(t + 1), lo, h, q, s_nxt);
+      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
       NL_STAMP(3);
     }
 #ifdef SAMBLE_STAMPS
@@ -744,8 +753,11 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
   const int m0 = chunk * (32 * NW) + wave * 32;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  u32x4 qd[16];  // the sampled row as two fp16 planes under its own scale: the SAME conversion as in pass 1, so the
+  float q_unscale;  // recomputed logits are the bits lse was formed from
+  duo_q_from_tri(q, qd, q_unscale);
   f32x16 s_cur, s_nxt;
-  stats_products<0>(kring, lo, h, q, s_cur);
+  stats_products<0>(kring, lo, h, qd, q_unscale, s_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K slot 0 is restaged by iteration 0
   Tri bp[2];  // P^T fragments (two k-steps of 16 keys) of the tile whose P V is due: tile t-1; none yet
 #pragma unroll
@@ -772,7 +784,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     RC_STAMP(0);
     const char* vt = vring + (max(t - 1, 0) % D) * kTriTile;
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
-    auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
+    auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], u32x4{0, 0, 0, 0}}; };  // fp16 planes h, l
+    // 2^-(e_q + e_k) of tile t+1 (its slot is not restaged before the next barrier)
+    const float kf = q_unscale * *reinterpret_cast<const float*>(kring + ((t + 1) % D) * kTriTile + kDuoScaleSlot);
     auto fetch_v = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
       const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
       return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
@@ -805,10 +819,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
         v2 = fetch_v(i + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
-      const Tri bq = {q[3 * i], q[3 * i + 1], q[3 * i + 2]};
       if (!LAST) {
-        if (SAMBLE_RC_ABL & 4) s_nxt[i] += __uint_as_float(k0.h[0] ^ bq.l[1] ^ k0.m[1] ^ k0.l[2]);
-        else s_nxt = mfma_tri(k0, bq, s_nxt);
+        if (SAMBLE_RC_ABL & 4) s_nxt[i] += __uint_as_float(k0.h[0] ^ qd[2 * i + 1][1] ^ k0.m[1]);
+        else s_nxt = mfma_duo(k0.h, k0.m, qd[2 * i], qd[2 * i + 1], s_nxt);
       }
       if (SAMBLE_RC_ABL & 2) oacc[i & 3][i] += __uint_as_float(v0.h[0] ^ bp[i >> 2].l[1] ^ v0.m[1] ^ v0.l[2] ^ bp[i >> 2].h[1] ^ bp[i >> 2].m[1]);
       else oacc[i & 3] = mfma_tri(v0, bp[i >> 2], oacc[i & 3]);
@@ -857,9 +870,9 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
       }
       // the weave: one MFMA, then its share of the step's vector instructions; memory operations float
 #pragma unroll
-      for (int m = 0; m < (LAST ? 6 : 12); ++m) {
+      for (int m = 0; m < (LAST ? 6 : 9); ++m) {  // 3 logit + 6 P V products per k-step
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 6 : 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 6 : 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       RC_STAMP(2 + i);
@@ -881,7 +894,8 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     if (!LAST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
 #endif
     RC_STAMP(12);
-    s_cur = s_nxt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_cur[r] = s_nxt[r] * kf;
     bp[0] = bn[0];
     bp[1] = bn[1];
 #pragma unroll
@@ -951,11 +965,64 @@ extern "C" int samble_launch_attn_rows_tri(const float* smap, int ld, const floa
   return (int)hipGetLastError();
 }
 
+namespace samble {
+// A K row-image tile -> its LOGIT form, in place (tri_dev.h, "two fp16 planes for the logit products"): the tile's
+// 32 x 128 values x 2^e as fp16 h / l planes in the h / m piece slots, 2^-e in the l slot of (group 0, row 0).
+// One workgroup per tile; a thread owns two (row, channel group) chunk triples and rewrites only those.
+__global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ img, int ntiles) {
+  __shared__ float wmax[4];
+  char* tile = img + ((long)blockIdx.y * ntiles + blockIdx.x) * kTriTile;
+  const int tid = threadIdx.x;
+  float x[2][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int p = tid + 256 * u, r = p & 31, g = p >> 5;
+    const u32x4* c = reinterpret_cast<const u32x4*>(tile + tri_rm_off(r, g, 0));
+    tri_chunk_values(c[0], c[32], c[64], x[u]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(x[u][e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  float sc, inv;
+  duo_scale_for(amax, sc, inv);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int p = tid + 256 * u, r = p & 31, g = p >> 5;
+    u32x4 hw, lw;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned a, b2;
+      duo_split2(x[u][2 * w] * sc, x[u][2 * w + 1] * sc, a, b2);
+      hw[w] = a;
+      lw[w] = b2;
+    }
+    u32x4* c = reinterpret_cast<u32x4*>(tile + tri_rm_off(r, g, 0));
+    c[0] = hw;
+    c[32] = lw;
+    if (p == 0) c[64] = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
+  }
+}
+}  // namespace samble
+
+// the K row image of (B, rows, 128) in place -> its logit form (what attn_stats_tri / attn_stats_nl_tri /
+// attn_rows_rc_tri read); samble_launch_tri_split_qkv and samble_launch_proj_fwd_tri end with it
+extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, hipStream_t stream) {
+  const int ntiles = (rows + 31) / 32;
+  hipLaunchKernelGGL(tri_k_to_duo_kernel, dim3(ntiles, B), dim3(256), 0, stream, (char*)kimg, ntiles);
+  return (int)hipGetLastError();
+}
+
 extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, int B, int N, int nt, void* qimg, void* kimg,
                                            void* vimg, void* ktr, void* vrm, hipStream_t stream) {
   Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm, 0);
+  if (kimg) return samble_launch_k_to_duo(kimg, B, N + nt, stream);
   return (int)hipGetLastError();
 }
 

@@ -472,6 +472,7 @@ extern "C" size_t samble_proj_tri_image_bytes() { return (size_t)kPTiles * kTriT
 
 extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long rs, int B, int N, int nt, int tile0, void* qimg,
                                                  void* kimg, void* vimg, void* ktr, void* vrm, hipStream_t stream);
+extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, hipStream_t stream);
 
 // images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
@@ -507,6 +508,7 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
     rc = samble_launch_tri_split_qkv_tiles(qkv, o_bs, o_rs, B, N, nt, N / 32, q_rm, k_rm, v_tr, k_tr, v_rm, s);
     if (rc) return rc;
   }
+  if (k_rm) return samble_launch_k_to_duo(k_rm, B, N + nt, s);  // the K row image leaves in its logit form (tri_dev.h)
   return (int)hipGetLastError();
 }
 

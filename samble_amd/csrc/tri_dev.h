@@ -65,6 +65,78 @@ __device__ __forceinline__ f32x16 mfma_tri(const Tri& a, const Tri& b, f32x16 c)
   return c;
 }
 
+// ---- two fp16 planes for the LOGIT products (round 3) ---------------------------------------------------------
+// S = Q K^T is the one product of the attention passes that is formed tile by tile with nothing accumulated across
+// tiles, so each operand block can carry its own power-of-two scale: a K row-image tile is rewritten IN PLACE as two
+// fp16 planes of the tile's values x 2^e (e: max |k| of the tile lands just under 2^12), h = fp16(x), l = fp16(x - h),
+// in the slots of the h and m pieces; the l slot of (group 0, row 0) holds 2^-e as a float.  A query row is converted
+// in registers, scale from its own row.  Three products (lh + hl + hh; the dropped ll <= 2^-22 |a||b|) instead of
+// six, and the accumulator x 2^-(e_q + e_k) -- exact -- is the logit's fp32 numerator as before.  22 significant
+// bits per operand: the sampled indices are as close to the oracle's as any other fp32 evaluation of the sums
+// (tools/experiments/duo_identity_probe.py); P V and the backward stay on three bf16 planes.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_hf(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_duo(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x16 c) {
+  c = mfma_hf(al, bh, c);
+  c = mfma_hf(ah, bl, c);
+  c = mfma_hf(ah, bh, c);
+  return c;
+}
+constexpr int kDuoScaleSlot = ((3 * 0 + 2) * 32 + 0) * 16;  // tri_rm_off(0, 0, 2): where a converted K tile keeps 2^-e
+// 2^e with amax x 2^e in [2^12, 2^13) (amax = 0 or denormal: 1; the exponent is clamped so that 2^e and 2^-e are normal)
+__device__ __forceinline__ void duo_scale_for(float amax, float& s, float& inv) {
+  const int ex = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+  const int se = ex == 0 ? 0 : max(-100, min(100, 12 - (ex - 127)));
+  s = __uint_as_float((unsigned)(127 + se) << 23);
+  inv = __uint_as_float((unsigned)(127 - se) << 23);
+}
+// two scaled fp32 values -> the packed words of the two fp16 planes
+__device__ __forceinline__ void duo_split2(float x0, float x1, unsigned& h, unsigned& l) {
+  const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;  // round to nearest even
+  const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);  // exact subtractions
+  h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+// the 8 fp32 values of one 16-byte chunk triple (h, m, l pieces of 8 consecutive channels): exact sums
+__device__ __forceinline__ void tri_chunk_values(u32x4 hh, u32x4 mm, u32x4 ll, float (&x)[8]) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    x[2 * w] = (__uint_as_float(hh[w] << 16) + __uint_as_float(mm[w] << 16)) + __uint_as_float(ll[w] << 16);
+    x[2 * w + 1] = (__uint_as_float(hh[w] & 0xFFFF0000u) + __uint_as_float(mm[w] & 0xFFFF0000u)) +
+                   __uint_as_float(ll[w] & 0xFFFF0000u);
+  }
+}
+// this lane's half of a query row (q[3 ks + piece], as loaded from the Q row image) -> two fp16 planes qd[2 ks + plane]
+// under the ROW's own scale (both halves of the row agree on it: lanes x and x + 32), unscale = 2^-e
+__device__ __forceinline__ void duo_q_from_tri(const u32x4 (&q)[24], u32x4 (&qd)[16], float& unscale) {
+  float x[64];
+  float amax = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    float v[8];
+    tri_chunk_values(q[3 * ks], q[3 * ks + 1], q[3 * ks + 2], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      x[8 * ks + e] = v[e];
+      amax = fmaxf(amax, fabsf(v[e]));
+    }
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  float s;
+  duo_scale_for(amax, s, unscale);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned hw, lw;
+      duo_split2(x[8 * ks + 2 * w] * s, x[8 * ks + 2 * w + 1] * s, hw, lw);
+      qd[2 * ks][w] = hw;
+      qd[2 * ks + 1][w] = lw;
+    }
+}
+
 __device__ __forceinline__ unsigned bf16_bits(float x) {  // round to nearest even
   return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
 }

@@ -409,6 +409,16 @@ def stage_attn_bwd(q, k, v, O, lse, idx, g, n_points: int, n_tokens: int, dq, dk
 MATRIX_MODE = os.environ.get("SAMBLE_MATRIX_MODE", "tri")
 
 
+def stage_k_logit_form(k_image: torch.Tensor, k_rows: torch.Tensor) -> torch.Tensor:
+    """A K row image from stage_tri_split -> its logit form, IN PLACE (include/samble.h samble_tri_k_logit_form):
+    what the `k_image` arguments of stage_attn_stats / stage_attn_stats_nl / stage_attn_rows_recompute expect.
+    stage_tri_split_qkv and stage_proj_fwd(images=...) hand their K row image over in this form already."""
+    B, rows = k_rows.shape[0], k_rows.shape[1]
+    with torch.cuda.device(k_image.device):
+        _lib.call("samble_tri_k_logit_form", k_image.data_ptr(), B, rows, _stream())
+    return k_image
+
+
 def stage_tri_split(rows: torch.Tensor, want_rm: bool = True, want_tr: bool = False):
     """fp32 rows (B,R,128) (any row / batch stride) -> operand images (uint8 tensors) for the tri
     kernels: rm (contraction over channels), tr (contraction over the rows of a 32-row tile)."""
@@ -481,7 +491,7 @@ def stage_attn_stats(q: torch.Tensor, k: torch.Tensor, n_points: int, n_tokens: 
             raise NotImplementedError
         # l2 scoring keeps the cloud's scaled key norms in LDS beside the tile ring: very long clouds use the fp32 kernel
         if MATRIX_MODE == "tri" and not (asm in ("l2", "l2+") and ld * 4 > 24 * 1024):
-            q_img, k_img = images if images is not None else (stage_tri_split(q)[0], stage_tri_split(k)[0])
+            q_img, k_img = images if images is not None else (stage_tri_split(q)[0], stage_k_logit_form(stage_tri_split(k)[0], k))
             _lib.call("samble_attn_stats_tri_f32", q_img.data_ptr(), k_img.data_ptr(), B, N, n_tokens, D,
                       smap.data_ptr(), ld, lse.data_ptr(), tok.data_ptr(), _p(qn), _p(kn), _stream())
         else:

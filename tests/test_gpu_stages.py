@@ -757,6 +757,7 @@ def test_qkv_split_matches_the_single_operand_splits():
     q_img, k_img, v_tr, k_tr, v_rm = o_.stage_tri_split_qkv(qkv, N, for_backward=True)
     assert torch.equal(q_img, o_.stage_tri_split(qkv[:, :N, :D])[0])
     k_rm_ref, k_tr_ref = o_.stage_tri_split(qkv[:, :, D:2 * D], want_rm=True, want_tr=True)
+    k_rm_ref = o_.stage_k_logit_form(k_rm_ref, qkv[:, :, D:2 * D])  # the K row image is handed over in its logit form
     v_rm_ref, v_tr_ref = o_.stage_tri_split(qkv[:, :, 2 * D:], want_rm=True, want_tr=True)
     assert torch.equal(k_img, k_rm_ref) and torch.equal(k_tr, k_tr_ref)
     assert torch.equal(v_rm, v_rm_ref) and torch.equal(v_tr, v_tr_ref)
