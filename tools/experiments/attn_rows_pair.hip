@@ -1,4 +1,7 @@
-// EXPERIMENT (round 3), not part of the library: pass 2 of the map-free forward with TWO waves per SIMD -- a pair of
+// EXPERIMENT (round 3), not part of the library.  State of commit 1f6d637: the library's K row image was three bf16
+// planes then; since the logit products moved to two fp16 planes (tri_dev.h) the one-wave kernel reads its K image
+// differently and rows_pair.py's bitwise comparison no longer applies (timings and stamps still do).
+// What it was: pass 2 of the map-free forward with TWO waves per SIMD -- a pair of
 // waves shares 32 sampled rows.  Bit-identical to attn_rows_rc_tri_kernel (x_ds and the P map), and slower:
 // 221 us against 201 us in the step (tools/experiments/run_rows_pair.sh).  Kept because the measurements explain why
 // a second wave per SIMD does not buy this kernel anything:

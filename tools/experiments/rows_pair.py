@@ -1,6 +1,8 @@
 """The rows-pair experiment (tools/experiments/attn_rows_pair.hip) against the library's one-wave kernel on the metric's
 shape: bitwise comparison of x_ds and the P map, event timing of both, and the s_memtime marks of one pair of waves.
-Libraries: tools/scratch/pair/lib_<ablation mask>.so (tools/experiments/run_rows_pair.sh)."""
+Libraries: tools/scratch/pair/lib_<ablation mask>.so (tools/experiments/run_rows_pair.sh).
+The bitwise comparison held at commit 1f6d637; the library's kernel has since moved its logit products to two fp16 planes
+(a different K image): "DIFFERENT" is expected now, the timings and stamps remain meaningful."""
 import ctypes, glob, os, torch
 B, N, nt, M = 32, 2048, 6, 1024
 NK = N + nt
