@@ -63,7 +63,7 @@ size_t samble_tri_image_size(int, int, int);
 size_t samble_bwd_tri_dsmap_bytes(int, int, int);
 int samble_launch_tri_split(const float*, long, long, int, int, void*, void*, hipStream_t);
 int samble_launch_tri_split_qkv(const float*, long, long, int, int, int, void*, void*, void*, void*, void*, hipStream_t);
-int samble_launch_k_to_duo(void*, int, int, hipStream_t);
+int samble_launch_k_to_duo(void*, int, int, int, hipStream_t);
 int samble_launch_attn_rows_tri(const float*, int, const float*, const void*, const long long*, int, int, int, int, float*,
                                 hipStream_t);
 int samble_launch_attn_stats_nl_tri(const void*, const void*, int, int, int, float, const unsigned*, int, float*, float*,
@@ -535,7 +535,7 @@ SAMBLE_API int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs
 SAMBLE_API int samble_tri_k_logit_form(void* k_image, int B, int rows, void* stream) {
   if (!k_image) return fail(SAMBLE_E_INVALID, "samble_tri_k_logit_form: null pointer");
   if (B <= 0 || rows <= 0) return fail(SAMBLE_E_INVALID, "samble_tri_k_logit_form: bad sizes");
-  return done(samble_launch_k_to_duo(k_image, B, rows, (hipStream_t)stream), "samble_tri_k_logit_form");
+  return done(samble_launch_k_to_duo(k_image, B, rows, 0, (hipStream_t)stream), "samble_tri_k_logit_form");
 }
 
 SAMBLE_API int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,

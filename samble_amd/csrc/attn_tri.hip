@@ -969,9 +969,9 @@ namespace samble {
 // A K row-image tile -> its LOGIT form, in place (tri_dev.h, "two fp16 planes for the logit products"): the tile's
 // 32 x 128 values x 2^e as fp16 h / l planes in the h / m piece slots, 2^-e in the l slot of (group 0, row 0).
 // One workgroup per tile; a thread owns two (row, channel group) chunk triples and rewrites only those.
-__global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ img, int ntiles) {
+__global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ img, int ntiles, int tile0) {
   __shared__ float wmax[4];
-  char* tile = img + ((long)blockIdx.y * ntiles + blockIdx.x) * kTriTile;
+  char* tile = img + ((long)blockIdx.y * ntiles + tile0 + blockIdx.x) * kTriTile;
   const int tid = threadIdx.x;
   float x[2][8];
   float amax = 0.f;
@@ -1011,9 +1011,10 @@ __global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ im
 
 // the K row image of (B, rows, 128) in place -> its logit form (what attn_stats_tri / attn_stats_nl_tri /
 // attn_rows_rc_tri read); samble_launch_tri_split_qkv and samble_launch_proj_fwd_tri end with it
-extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, hipStream_t stream) {
-  const int ntiles = (rows + 31) / 32;
-  hipLaunchKernelGGL(tri_k_to_duo_kernel, dim3(ntiles, B), dim3(256), 0, stream, (char*)kimg, ntiles);
+extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, int tile0, hipStream_t stream) {
+  const int ntiles = (rows + 31) / 32;  // tiles tile0 .. ntiles-1 of every cloud (the projection writes the full point
+  if (tile0 >= ntiles) return 0;        // tiles in this form itself: only the token / ragged tiles are left to it)
+  hipLaunchKernelGGL(tri_k_to_duo_kernel, dim3(ntiles - tile0, B), dim3(256), 0, stream, (char*)kimg, ntiles, tile0);
   return (int)hipGetLastError();
 }
 
@@ -1022,7 +1023,7 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
   Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm, 0);
-  if (kimg) return samble_launch_k_to_duo(kimg, B, N + nt, stream);
+  if (kimg) return samble_launch_k_to_duo(kimg, B, N + nt, 0, stream);
   return (int)hipGetLastError();
 }
 

@@ -170,7 +170,13 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
   // iteration t: tile t+3 into the slot of tile t-1, product of tile t, its 4 row stores; VM operations
   // younger than tile t+1's DMA at the end of the iteration: stores(t-2) 4 + 2 x (3 + 4) = 18 (image stores only
   // add to that: counting low is the safe side)
-  for (int t = 0; t < kPTiles; ++t) {
+  // The K row image leaves in its LOGIT form (tri_dev.h: two fp16 planes per 32-point tile under the tile's own
+  // power-of-two scale).  A wave's 32 points ARE one tile, its 128 K channels come out of iterations t = 4..7: their
+  // values wait in registers (kst, compile-time indices: those four iterations are written out below) until the last of
+  // them knows the tile's largest |k|.
+  float kst[4][2][8];
+  auto body = [&](int t, auto kc_c) {
+    constexpr int KC = decltype(kc_c)::value;  // 0..3: K channel block tc of a FULL tile with images; -1: everything else
     stage(t + D - 1);
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
     f32x16 acc = zero16();  // D[row = output 32 t + crow(r, h)][col = point]
@@ -208,13 +214,51 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
             c8[pr][4 + e] = __uint_as_float(r2[1]);  // channels 4..7
           }
         }
+        if constexpr (KC >= 0) {
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const int g = 4 * tc + pr + 2 * h;  // 8-channel group inside the 128 channels
-          const Tri t3 = tri_split8(c8[pr]);
-          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 0)) = t3.h;
-          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 1)) = t3.m;
-          *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 2)) = t3.l;
+          for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kst[KC][pr][e] = c8[pr][e];
+          if constexpr (KC == 3) {  // the tile is complete: its exponent, then the two fp16 planes of all 8 groups of this lane
+            float amax = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(kst[c][pr][e]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            float sc, inv;
+            duo_scale_for(amax, sc, inv);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                const int g = 4 * c + pr + 2 * h;
+                u32x4 hw, lw;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                  unsigned a, b2;
+                  duo_split2(kst[c][pr][2 * w] * sc, kst[c][pr][2 * w + 1] * sc, a, b2);
+                  hw[w] = a;
+                  lw[w] = b2;
+                }
+                *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 0)) = hw;
+                *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 1)) = lw;
+              }
+            // (the third piece slots stay unwritten: dead space of the image, except the tile's 2^-e)
+            if (lane == 0) *reinterpret_cast<u32x4*>(rm + kDuoScaleSlot) = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
+          }
+        } else {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int g = 4 * tc + pr + 2 * h;  // 8-channel group inside the 128 channels
+            const Tri t3 = tri_split8(c8[pr]);
+            *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 0)) = t3.h;
+            *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 1)) = t3.m;
+            *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 2)) = t3.l;
+          }
         }
       }
       if (which == 2 || (which == 1 && im.k_tr)) {
@@ -236,7 +280,18 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
       }
     }
     asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  using std::integral_constant;
+  for (int t = 0; t < 4; ++t) body(t, integral_constant<int, -1>{});
+  if (full) {  // (wave-uniform)
+    body(4, integral_constant<int, 0>{});
+    body(5, integral_constant<int, 1>{});
+    body(6, integral_constant<int, 2>{});
+    body(7, integral_constant<int, 3>{});
+  } else {
+    for (int t = 4; t < 8; ++t) body(t, integral_constant<int, -1>{});
   }
+  for (int t = 8; t < kPTiles; ++t) body(t, integral_constant<int, -1>{});
 }
 
 #ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch, tools/proj_stamps.py): workgroup (0,0), every wave, tiles 5 and 6
@@ -472,7 +527,7 @@ extern "C" size_t samble_proj_tri_image_bytes() { return (size_t)kPTiles * kTriT
 
 extern "C" int samble_launch_tri_split_qkv_tiles(const float* qkv, long bs, long rs, int B, int N, int nt, int tile0, void* qimg,
                                                  void* kimg, void* vimg, void* ktr, void* vrm, hipStream_t stream);
-extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, hipStream_t stream);
+extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, int tile0, hipStream_t stream);
 
 // images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
@@ -508,7 +563,9 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
     rc = samble_launch_tri_split_qkv_tiles(qkv, o_bs, o_rs, B, N, nt, N / 32, q_rm, k_rm, v_tr, k_tr, v_rm, s);
     if (rc) return rc;
   }
-  if (k_rm) return samble_launch_k_to_duo(k_rm, B, N + nt, s);  // the K row image leaves in its logit form (tri_dev.h)
+  // the K row image leaves in its logit form (tri_dev.h): the full point tiles from the kernel's epilogue, the token /
+  // ragged tiles (written as three planes above) by the conversion kernel
+  if (k_rm) return samble_launch_k_to_duo(k_rm, B, N + nt, N / 32, s);
   return (int)hipGetLastError();
 }
 

@@ -955,6 +955,13 @@ def test_map_free_forward_equals_the_map_pipeline(B, N, nt, M, K):
         o_.MATRIX_MODE = old
 
 
+def _k_image_live_equal(a, b2):
+    """K row images in their logit form: the two fp16 planes of every (group, row) chunk and the tile's scale word; the
+    rest of the third piece slots is dead space (the projection leaves it unwritten)."""
+    va, vb = a.view(-1, 16, 3, 32, 16), b2.view(-1, 16, 3, 32, 16)
+    return bool(torch.equal(va[:, :, :2], vb[:, :, :2]) and torch.equal(va[:, 0, 2, 0, :4], vb[:, 0, 2, 0, :4]))
+
+
 @pytest.mark.parametrize("B,N,nt", [(2, 256, 6), (3, 1000, 4), (1, 77, 1), (32, 2048, 6), (2, 96, 0), (1, 20, 8)])
 def test_projection_writes_the_operand_images_itself(B, N, nt):
     """samble_proj_fwd_split_tri_f32 (images of the full point tiles from the projection kernel's accumulators + a split
@@ -978,7 +985,7 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
                 _, w_tr = o_.stage_tri_split(w.unsqueeze(0), want_rm=False, want_tr=True)
                 assert torch.equal(imgs2[5], w_tr)
             for j, (a, b2) in enumerate(zip(imgs, imgs2)):
-                assert torch.equal(a, b2), (want, "image", j, int((a != b2).sum()))
+                assert (_k_image_live_equal(a, b2) if j == 1 else torch.equal(a, b2)), (want, "image", j, int((a != b2).sum()))
             # SAMBLE_PROJ_ROWS_Q_ONLY: the same images, the Q columns, the token rows and a ragged last tile's rows; the K / V
             # columns of the full point tiles are not written at all (the poison planted below survives there)
             import samble_amd.ops as _o
@@ -995,6 +1002,6 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
             if nfull > 1:  # (row N-1 may be written in full by the waves past the end: they recompute that row)
                 assert bool((qkv3[:, :nfull - 1, 128:] == -7.0).all())
             for j, (a, b2) in enumerate(zip(imgs, imgs3)):
-                assert torch.equal(a, b2), (want, "q_only image", j, int((a != b2).sum()))
+                assert (_k_image_live_equal(a, b2) if j == 1 else torch.equal(a, b2)), (want, "q_only image", j, int((a != b2).sum()))
     finally:
         o_.MATRIX_MODE = old
