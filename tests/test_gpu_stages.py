@@ -305,6 +305,36 @@ def test_split_products_are_fp32_equivalent():
     assert err["tri"][0] <= 1.25 * err["f32"][0] and err["tri"][1] <= 2.0 * err["f32"][1], err
 
 
+@pytest.mark.parametrize("sq,sk", [(1.0, 1.0), (1e-3, 1e-3), (1e3, 1e-2), (3e4, 3e-5)])
+def test_logit_products_are_blind_to_operand_scale(sq, sk):
+    """The logit products run on two fp16 planes under per-tile (K) and per-row (Q) power-of-two scales
+    (csrc/tri_dev.h): whatever the operands' magnitude, a key row 50x the others in a tile, a tile of zeros, a zero query
+    row -- the logits stay as close to fp64 as the fp32-MFMA kernel's, and nothing overflows fp16."""
+    B, N, nt = 2, 512, 6
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(B, N, 128, generator=g) * sq
+    k = torch.randn(B, N + nt, 128, generator=g) * sk
+    k[:, 5] *= 50.0
+    k[:, 64:96] = 0.0   # a whole key tile of zeros
+    q[:, 3] = 0.0
+    s = (q.double() @ k.double().transpose(1, 2)) / math.sqrt(128)
+    o_ = ops()
+    err = {}
+    old = o_.MATRIX_MODE
+    try:
+        for mode in ("f32", "tri"):
+            o_.MATRIX_MODE = mode
+            smap, lse, _ = o_.stage_attn_stats(q.to(DEV), k.to(DEV), N, nt)
+            got = smap[:, :, :N + nt].cpu().double()
+            assert bool(torch.isfinite(got).all()) and bool(torch.isfinite(lse).all())
+            d = got - s
+            err[mode] = (d.pow(2).mean().sqrt().item(), d.abs().max().item())
+            assert bool((got[:, :, 64:96] == 0).all()) and bool((got[:, 3] == 0).all())
+    finally:
+        o_.MATRIX_MODE = old
+    assert err["tri"][0] <= 1.25 * err["f32"][0] and err["tri"][1] <= 2.0 * err["f32"][1], err
+
+
 # ---------------------------------------------------------------------------------------------
 # two-pass forward with the logit map in HBM (attn_stats / attn_rows / sparse_score_map / rows_bwd)
 # ---------------------------------------------------------------------------------------------
