@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
                                                            float* __restrict__ delta, float* __restrict__ tok_part,
                                                            float* __restrict__ cs_part, char* __restrict__ dO_rm,
                                                            char* __restrict__ dO_tr, char* __restrict__ Q_tr,
-                                                           float* __restrict__ dQ, long dq_bs, long dq_rs) {
+                                                           float* __restrict__ dQ, long dq_bs, long dq_rs,
+                                                           unsigned* __restrict__ ds_amax) {
+  // ds_amax != null: the two TRANSPOSED images leave as two fp16 planes per tile under the tile's own power-of-two
+  // scale (tri_dev.h, "products that accumulate over tiles": what bwd_kacc_tri / bwd_kacc_pm_tri read), and the cloud's
+  // slot of ds_amax (largest |dS|, raised by the dQ kernel that runs next) is cleared here
   __shared__ float gt[128 * 33];  // dO^T tile
   __shared__ float qt[128 * 33];  // Q^T tile of the gathered rows
   // 40 704 bytes of LDS in all, so that four workgroups fit a CU and the grid's 4 x 256 workgroups are one round
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
         *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = t3.m;
         *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 2)) = t3.l;
       }
+      if (ds_amax) continue;  // (the transposed images: below, once the tile's largest values are known)
       const int d = e & 127, cg = e >> 7;
       float x[8], y[8];
 #pragma unroll
@@ -165,6 +170,61 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
       *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = u3.h;
       *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = u3.m;
       *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 2)) = u3.l;
+    }
+    if (ds_amax) {  // (uniform)
+      __shared__ float amx[2][4];
+      if (blockIdx.x == 0 && tid == 0) ds_amax[b] = 0u;
+      float x[2][8], y[2][8], ax = 0.f, ay = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, d = e & 127, cg = e >> 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int o = d * 33 + 16 * (cg >> 1) + 8 * (i >> 2) + 4 * (cg & 1) + (i & 3);
+          x[u][i] = gt[o];
+          y[u][i] = qt[o];
+          ax = fmaxf(ax, fabsf(x[u][i]));
+          ay = fmaxf(ay, fabsf(y[u][i]));
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+        ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+      }
+      if ((tid & 63) == 0) {
+        amx[0][tid >> 6] = ax;
+        amx[1][tid >> 6] = ay;
+      }
+      __syncthreads();
+      ax = fmaxf(fmaxf(amx[0][0], amx[0][1]), fmaxf(amx[0][2], amx[0][3]));
+      ay = fmaxf(fmaxf(amx[1][0], amx[1][1]), fmaxf(amx[1][2], amx[1][3]));
+      float sx, ix, sy, iy;
+      duo_scale_for(ax, sx, ix);
+      duo_scale_for(ay, sy, iy);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, d = e & 127, cg = e >> 7;
+        u32x4 xh, xl, yh, yl;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          unsigned a1, a2;
+          duo_split2(x[u][2 * w] * sx, x[u][2 * w + 1] * sx, a1, a2);
+          xh[w] = a1;
+          xl[w] = a2;
+          duo_split2(y[u][2 * w] * sy, y[u][2 * w + 1] * sy, a1, a2);
+          yh[w] = a1;
+          yl[w] = a2;
+        }
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = xh;
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = xl;
+        *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = yh;
+        *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = yl;
+        if (e == 0) {
+          *reinterpret_cast<u32x4*>(itr + kDuoTrScaleSlot) = u32x4{__float_as_uint(ix), 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(qtr + kDuoTrScaleSlot) = u32x4{__float_as_uint(iy), 0u, 0u, 0u};
+        }
+      }
     }
   }
   PSTAMP(3);
@@ -841,8 +901,10 @@ extern "C" size_t samble_attn_bwd_slab_floats(int B, int N, int M) {
 extern "C" size_t samble_tri_image_size(int, int, int);
 extern "C" int samble_launch_bwd_tri(const float*, int, const float*, const float*, const void*, const void*, const void*,
                                      const void*, const void*, const long long*, int, int, int, int, float, float*, long,
-                                     long, float*, long, long, float*, long, long, float*, float*, int, int, hipStream_t);
+                                     long, float*, long, long, float*, long, long, float*, float*, int, int, unsigned*,
+                                     hipStream_t);
 
+extern "C" size_t samble_bwd_tri_dsmap_floats(int B, int N, int M);
 extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, const float* K, long k_bs, long k_rs,
                                       const float* V, long v_bs, long v_rs, const float* O, const float* Oc,
                                       const float* smap, int ld, const float* lse, const long long* idx,
@@ -887,11 +949,16 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   char* dO_rm = tri ? (char*)img_ws : nullptr;
   char* dO_tr = tri ? dO_rm + img : nullptr;
   char* Q_tr = tri ? dO_tr + img : nullptr;
+  // the dS-map backward (variant bit 0 clear) reads its transposed images as two fp16 planes per tile; the cloud's
+  // largest |dS| lives behind the dS map (samble_bwd_tri_dsmap_bytes counts it)
+  unsigned* ds_amax = (tri && Oc && !(variant & 1))
+                          ? reinterpret_cast<unsigned*>(Q_tr + img + samble_bwd_tri_dsmap_floats(B, N, M) * sizeof(float))
+                          : nullptr;
   if (tri && Oc) {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_tri_kernel<true> : bwd_prep_tri_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q,
                        q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, Oc, lse, idx, g, N, nt, M, scale, lse_s, delta, tok_part,
-                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr, zero_dq ? dQ : nullptr, dq_bs, dq_rs);
+                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr, zero_dq ? dQ : nullptr, dq_bs, dq_rs, ds_amax);
   } else {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
@@ -902,7 +969,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     float* dsmap = reinterpret_cast<float*>(Q_tr + img);  // (B, M, ld) after the three images
     const int rc = samble_launch_bwd_tri(smap, ld, lse_s, delta, dO_rm, dO_tr, Q_tr, v_rm_image, k_tr_image, idx, B, N, nt, M,
                                          scale, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs : nullptr,
-                                         dsmap, variant & 1, variant & 6, stream);
+                                         dsmap, variant & 1, variant & 6, ds_amax, stream);
     if (rc) return rc;
   } else if (fused) {
     if (smap) {

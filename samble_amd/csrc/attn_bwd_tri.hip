@@ -68,6 +68,34 @@ __device__ __forceinline__ void mma_tr_x_acc(const char* __restrict__ tr_tile, i
       [&](int i, const Tri& a) { out[i & 3] = mfma_tri(a, (i >> 2) ? b1 : b0, out[i & 3]); });
 }
 
+// the same on a transposed image in its two-fp16-plane form (tri_dev.h, "products that accumulate over tiles"): x is
+// multiplied by f (the tile's 2^(13 - (e_t - e_min)) x xs) before its split, three products per k-step
+__device__ __forceinline__ Tri duo_from_acc(const float (&x)[16], int ks, float f) {
+  Tri t;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned hh, ll;
+    duo_split2(x[8 * ks + 2 * w] * f, x[8 * ks + 2 * w + 1] * f, hh, ll);
+    t.h[w] = hh;
+    t.m[w] = ll;
+  }
+  t.l = u32x4{0, 0, 0, 0};
+  return t;
+}
+__device__ __forceinline__ void mma_tr_x_acc_duo(const char* __restrict__ tr_tile, int lo, int h, const float (&x)[16], float f,
+                                                 f32x16 (&out)[4]) {
+  const Tri b0 = duo_from_acc(x, 0, f), b1 = duo_from_acc(x, 1, f);
+  tri_pipelined3<8>(
+      [&](int i) {  // step i: k-step i >> 2, channel block i & 3
+        const char* ap = tr_tile + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+        return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048), u32x4{0, 0, 0, 0}};
+      },
+      [&](int i, const Tri& a) {
+        const Tri& bb = (i >> 2) ? b1 : b0;
+        out[i & 3] = mfma_duo(a.h, a.m, bb.h, bb.m, out[i & 3]);
+      });
+}
+
 // acc(32x32) = RMtile(rows from LDS) x reg(24 operand registers of this lane's row)^T
 __device__ __forceinline__ f32x16 mma_rm_x_regs(const char* __restrict__ rm_tile, int lo, int h, const u32x4 (&q)[24]) {
   const u32x4* lp = reinterpret_cast<const u32x4*>(rm_tile + tri_rm_off(lo, h, 0));
@@ -113,12 +141,14 @@ struct DqTriArgs {
   float* dQ;
   long dq_bs, dq_rs;
   float* dsmap;  // optional (B, M, ld): dS of the sampled rows, for the key-stationary kernels
+  unsigned* ds_amax;  // optional (B): raised to the bits of the cloud's largest |dS| (what scales dS for two-plane dK products)
 };
 
 // PMAP: a.smap is the P map of the SAMPLED rows (B, M, ld) written by attn_rows_rc_tri_kernel -- P is read, not
 // re-exponentiated, and the row needs no index indirection
 template <int ABL, bool PMAP>  // ABL: timing-only ablations (wrong results): 1 = tiles staged once, 2 = no matrix products
 __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
+  float ds_max = 0.f;  // this lane's largest |dS| (a.ds_amax)
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int NW = 4;
   const int tid = threadIdx.x;
@@ -194,6 +224,10 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
         ds[r] = (PMAP ? v4[e] : __expf(v4[e] - my_lse)) * (dp[r] - my_delta) * scale;
       }
     }
+    if (a.ds_amax) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) ds_max = __builtin_fmaxf(__builtin_fmaxf(ds_max, fabsf(ds[r])), fabsf(ds[r + 1]));
+    }
     if (a.dsmap) {  // dS tile -> map rows as full 128-byte lines (8 lanes per row), through the wave's LDS tile
       float* xt = reinterpret_cast<float*>(smem_c + 2 * kDqStage) + wave * (32 * kDqXt);
 #pragma unroll
@@ -215,6 +249,11 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
       for (int r = 0; r < 16; ++r) oacc[r & 3][r] += ds[r];
     } else mma_tr_x_acc(st + kTriTile, lo, h, ds, oacc);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (a.ds_amax) {  // (non-negative floats order as their bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ds_max = fmaxf(ds_max, __shfl_xor(ds_max, o, 64));
+    if (lane == 0) atomicMax(a.ds_amax + b, __float_as_uint(ds_max));
   }
   if (mvalid) {
     float* orow = a.dQ + (long)b * a.dq_bs + row * a.dq_rs + 4 * h;
@@ -242,6 +281,7 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
 constexpr int kDqpLds = 4 * kTriTile + 2 * 4 * 4096 + 4 * 4096;  // V ring, K ring, P slots, transpose tiles: 144 KB
 
 __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
+  float ds_max = 0.f;  // this lane's largest |dS| (a.ds_amax)
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int NW = 4;
   const int tid = threadIdx.x;
@@ -347,6 +387,7 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
         // columns past N + nt hold P = 0
         ds[r0] = LAST ? 0.f : p4[r0 >> 2][r0 & 3] * (x0 - my_delta) * scale;
         ds[r1] = LAST ? 0.f : p4[r1 >> 2][r1 & 3] * (x1 - my_delta) * scale;
+        ds_max = __builtin_fmaxf(__builtin_fmaxf(ds_max, fabsf(ds[r0])), fabsf(ds[r1]));  // (v_max3 with |.| modifiers)
         unsigned hh, mm, ll;
         tri_split2(ds[r0], ds[r1], hh, mm, ll);
         asm volatile("" : "+v"(hh), "+v"(mm), "+v"(ll));
@@ -403,6 +444,11 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
   };
   for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
   step(ntiles, std::true_type{});
+  if (a.ds_amax) {  // (non-negative floats order as their bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ds_max = fmaxf(ds_max, __shfl_xor(ds_max, o, 64));
+    if (lane == 0) atomicMax(a.ds_amax + b, __float_as_uint(ds_max));
+  }
   if (mvalid) {
     float* orow = a.dQ + (long)b * a.dq_bs + row * a.dq_rs + 4 * h;
 #pragma unroll
@@ -637,6 +683,25 @@ struct KaccArgs {
   float* out;          // dV / dK rows
   long o_bs, o_rs;
   float* cs;           // MODE 1, optional (B, N + nt)
+  int duo;             // the transposed image is in its two-fp16-plane form (bwd_prep_tri with ds_amax)
+  const unsigned* x_amax;  // duo, map = dS: (B) bits of the cloud's largest |dS|; null: the map values are <= 1 (P)
+};
+// scales of the two-plane accumulation (tri_dev.h): the factor of tile t's map values is ts.x_scale(t) * xs, the finished
+// sum comes out x out_un
+struct KaccDuo {
+  DuoTileScales ts;
+  float xs, out_un;
+  __device__ __forceinline__ void init(const KaccArgs& a, const char* Tb, int mtiles, int b, int lane) {
+    ts.load(Tb, mtiles, lane);
+    xs = 1.f;
+    if (a.x_amax) {
+      float s2, inv2;
+      duo_scale_for(__uint_as_float(a.x_amax[b]), s2, inv2);  // |dS| s2 < 2^13
+      xs = s2 * (1.f / 8192.f);
+    }
+    out_un = ts.unscale() / xs;
+  }
+  __device__ __forceinline__ float factor(int t) const { return ts.x_scale(t) * xs; }
 };
 
 // The map block of a tile (32 rows x 256 keys = 32 pieces of 1 KB, each one contiguous kilobyte of a map
@@ -699,6 +764,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
   float csum = 0.f;
+  KaccDuo kd;
+  if (a.duo) kd.init(a, Tb, mtiles, b, lane);  // (uniform)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   // Vector instructions share the SIMD's issue port with the MFMAs (48 per tile here), so the loop carries as few
@@ -737,7 +804,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
       }
     }
     KA_STAMP(2);
-    mma_tr_x_acc<3>(st, lo, h, x, acc);
+    if (a.duo) mma_tr_x_acc_duo(st, lo, h, x, kd.factor(t), acc);
+    else mma_tr_x_acc<3>(st, lo, h, x, acc);
     KA_STAMP(3);
 #ifdef SAMBLE_STAMPS
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -755,12 +823,13 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
     if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
   }
   if (jvalid) {
+    const float un = a.duo ? kd.out_un : 1.f;  // (x 1 is exact: the three-plane results are unchanged)
     float* orow = a.out + (long)b * a.o_bs + (long)j * a.o_rs + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        const f32x4 o = {acc[dt][4 * g] * un, acc[dt][4 * g + 1] * un, acc[dt][4 * g + 2] * un, acc[dt][4 * g + 3] * un};
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
       }
     }
@@ -779,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_tri_kernel(const KaccArgs a) 
 constexpr int kAccPmMapSlots = 2, kAccPmTrSlots = 3;
 constexpr int kAccPmLds = kAccPmTrSlots * kTriTile + kAccPmMapSlots * kAccMap;
 
-template <bool CS>
+template <bool CS, bool DUO>  // DUO: the transposed image in its two-fp16-plane form, three products per k-step (a.duo)
 __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   const int tid = threadIdx.x;
@@ -831,6 +900,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
   f32x16 acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) acc[dt] = zero16();
+  KaccDuo kd;
+  if (DUO) kd.init(a, Tb, mtiles, b, lane);
   asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // all but image tile 1
   Tri bcur[2], bnext[2];
   {
@@ -841,8 +912,14 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) csum += x0[r];
     }
-    bcur[0] = tri_from_acc(x0, 0);
-    bcur[1] = tri_from_acc(x0, 1);
+    if (DUO) {
+      const float f0 = kd.factor(0);
+      bcur[0] = duo_from_acc(x0, 0, f0);
+      bcur[1] = duo_from_acc(x0, 1, f0);
+    } else {
+      bcur[0] = tri_from_acc(x0, 0);
+      bcur[1] = tri_from_acc(x0, 1);
+    }
   }
 
   auto step = [&](int t, auto next_tail_c, auto last_c) {
@@ -856,8 +933,10 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
       read_x(t + 1, x);
       if (NEXT_TAIL) mask_tail(t + 1, x);
     }
+    const float f1 = DUO ? kd.factor(min(t + 1, mtiles - 1)) : 1.f;  // tile t+1's map values: x f1 before their split
     auto fetch = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
       const char* ap = st + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      if (DUO) return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048), u32x4{0, 0, 0, 0}};
       return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
                  *reinterpret_cast<const u32x4*>(ap + 4096)};
     };
@@ -867,13 +946,15 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
       Tri a3 = a2;
       if (i + 3 < 8) a3 = fetch(i + 3);
       __builtin_amdgcn_sched_barrier(0);
-      acc[i & 3] = mfma_tri(a0, bcur[i >> 2], acc[i & 3]);
+      if (DUO) acc[i & 3] = mfma_duo(a0.h, a0.m, bcur[i >> 2].h, bcur[i >> 2].m, acc[i & 3]);
+      else acc[i & 3] = mfma_tri(a0, bcur[i >> 2], acc[i & 3]);
       if (!LAST) {  // pair c of tile t+1's values -> word c & 3 of the fragment of k-step c >> 2; one k-step behind
                     // the reads (k-step 0 has only its MFMAs: the values are still on their way from LDS)
 #pragma unroll
         for (int c = (i == 0 ? 8 : i - 1); c < (i == 7 ? 8 : i); ++c) {
-          unsigned hh, mm, ll;
-          tri_split2(x[2 * c], x[2 * c + 1], hh, mm, ll);
+          unsigned hh, mm, ll = 0;
+          if (DUO) duo_split2(x[2 * c] * f1, x[2 * c + 1] * f1, hh, mm);
+          else tri_split2(x[2 * c], x[2 * c + 1], hh, mm, ll);
           bnext[c >> 2].h[c & 3] = hh;
           bnext[c >> 2].m[c & 3] = mm;
           bnext[c >> 2].l[c & 3] = ll;
@@ -886,9 +967,9 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
       if (i < 4) map_piece(t + 2, i);
       else if (i < 7) tr_piece(t + 2, i - 4);
 #pragma unroll
-      for (int m = 0; m < 6; ++m) {  // the weave: an MFMA, then its share of the vector work
+      for (int m = 0; m < (DUO ? 3 : 6); ++m) {  // the weave: an MFMA, then its share of the vector work
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, DUO ? 7 : 3, 0);
         if (m == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -910,12 +991,13 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
     if (jvalid && h == 0) a.cs[(long)b * a.NK + j] = ctot;
   }
   if (jvalid) {
+    const float un = a.duo ? kd.out_un : 1.f;  // (x 1 is exact: the three-plane results are unchanged)
     float* orow = a.out + (long)b * a.o_bs + (long)j * a.o_rs + 4 * h;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]};
+        const f32x4 o = {acc[dt][4 * g] * un, acc[dt][4 * g + 1] * un, acc[dt][4 * g + 2] * un, acc[dt][4 * g + 3] * un};
         *reinterpret_cast<f32x4*>(orow + 32 * dt + 8 * g) = o;
       }
     }
@@ -932,15 +1014,20 @@ extern "C" __attribute__((visibility("default"))) int samble_scratch_ka_stamps(u
 }
 #endif
 
+extern "C" size_t samble_bwd_tri_dsmap_floats(int B, int N, int M) { return (size_t)B * M * (32 * ((N + 8 + 31) / 32)); }
+// the dS map (B, M, ld) + behind it one word per cloud: the largest |dS| (what scales dS for the two-plane dK products)
 extern "C" size_t samble_bwd_tri_dsmap_bytes(int B, int N, int M) {
-  return (size_t)B * M * (32 * ((N + 8 + 31) / 32)) * sizeof(float);
+  return samble_bwd_tri_dsmap_floats(B, N, M) * sizeof(float) + (((size_t)B * 4 + 255) & ~(size_t)255);
 }
 
 extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse_s, const float* delta, const void* dO_rm,
                                      const void* dO_tr, const void* Q_tr, const void* V_rm, const void* K_tr,
                                      const long long* idx, int B, int N, int nt, int M, float scale, float* dQ, long dq_bs,
                                      long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
-                                     float* cs, float* dsmap, int fused_dkdv, int pmap, hipStream_t stream) {
+                                     float* cs, float* dsmap, int fused_dkdv, int pmap, unsigned* ds_amax,
+                                     hipStream_t stream) {
+  // ds_amax != null (dS-map variants only): bwd_prep_tri wrote dO_tr / Q_tr as two fp16 planes per tile and cleared the
+  // clouds' slots; the dQ kernel raises them to the largest |dS|, the key-stationary kernels run three products
   // pmap != 0: smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri); needs the dS-map variant
   // fused_dkdv == 0 (default): the dQ kernel writes a dS map and dV / dK accumulate from the maps (4 products per
   // tile); != 0: fused dP / dV / dK kernel (5 products, no dS map)
@@ -959,7 +1046,8 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_kacc_tri_kernel<0, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kAccLds);
     if (e != hipSuccess) return (int)e;
-    for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<false>), reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<true>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<false, false>), reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<true, false>),
+                          reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<false, true>), reinterpret_cast<const void*>(bwd_kacc_pm_tri_kernel<true, true>)}) {
       e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAccPmLds);
       if (e != hipSuccess) return (int)e;
     }
@@ -967,25 +1055,34 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
   const bool use_map = !fused_dkdv && dsmap;
   if (pmap && !use_map) return (int)hipErrorInvalidValue;
   const DqTriArgs dq{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)V_rm, (const char*)K_tr, idx, N, N + nt, M,
-                     scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr};
+                     scale, dQ, dq_bs, dq_rs, use_map ? dsmap : nullptr, use_map ? ds_amax : nullptr};
+  const int duo = (use_map && ds_amax) ? 1 : 0;
   {
     Timed timed(kT_bwd_dq, stream);
     if (pmap) hipLaunchKernelGGL(bwd_dq_pm_tri_kernel, dim3((M + 127) / 128, B), dim3(256), kDqpLds, stream, dq);
     else hipLaunchKernelGGL((bwd_dq_tri_kernel<0, false>), dim3((M + 127) / 128, B), dim3(256), kDqLds, stream, dq);
   }
   if (use_map) {
-    const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr};
-    const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs};
+    const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr, duo, nullptr};
+    const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs, duo, duo ? ds_amax : nullptr};
+    const dim3 grid((N + 255) / 256, B);
     {
       Timed timed(kT_bwd_dv, stream);
-      if (pmap)  // P is there already: the M-row-map kernel on (P map, dO^T)
-        hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, av);
-      else
-        hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), dim3((N + 255) / 256, B), dim3(512), kAccLds, stream, av);
+      if (pmap) {  // P is there already: the M-row-map kernel on (P map, dO^T)
+        if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, true>), grid, dim3(512), kAccPmLds, stream, av);
+        else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, false>), grid, dim3(512), kAccPmLds, stream, av);
+      } else {
+        hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), grid, dim3(512), kAccLds, stream, av);
+      }
     }
     Timed timed(kT_bwd_dk, stream);
-    if (cs) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
-    else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false>), dim3((N + 255) / 256, B), dim3(512), kAccPmLds, stream, ak);
+    if (cs) {
+      if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, true>), grid, dim3(512), kAccPmLds, stream, ak);
+      else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, false>), grid, dim3(512), kAccPmLds, stream, ak);
+    } else {
+      if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, true>), grid, dim3(512), kAccPmLds, stream, ak);
+      else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, false>), grid, dim3(512), kAccPmLds, stream, ak);
+    }
   } else {
     const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,
                        idx, N, N + nt, M, scale, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, cs};

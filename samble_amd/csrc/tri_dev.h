@@ -85,10 +85,11 @@ __device__ __forceinline__ f32x16 mfma_duo(u32x4 ah, u32x4 al, u32x4 bh, u32x4 b
   return c;
 }
 constexpr int kDuoScaleSlot = ((3 * 0 + 2) * 32 + 0) * 16;  // tri_rm_off(0, 0, 2): where a converted K tile keeps 2^-e
-// 2^e with amax x 2^e in [2^12, 2^13) (amax = 0 or denormal: 1; the exponent is clamped so that 2^e and 2^-e are normal)
+// 2^e with amax x 2^e in [2^12, 2^13); the exponent is clamped so that 2^e and 2^-e are normal.  A tile of zeros
+// (amax = 0 or denormal) gets the LARGEST exponent: its 2^-e never is the maximum over a cloud's tiles
 __device__ __forceinline__ void duo_scale_for(float amax, float& s, float& inv) {
   const int ex = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
-  const int se = ex == 0 ? 0 : max(-100, min(100, 12 - (ex - 127)));
+  const int se = ex == 0 ? 100 : max(-100, min(100, 12 - (ex - 127)));
   s = __uint_as_float((unsigned)(127 + se) << 23);
   inv = __uint_as_float((unsigned)(127 - se) << 23);
 }
@@ -99,6 +100,47 @@ __device__ __forceinline__ void duo_split2(float x0, float x1, unsigned& h, unsi
   h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
   l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
+// ---- products that ACCUMULATE over tiles (out^T += A_tile^T X_tile: dV^T += dO^T P, dK^T += Q^T dS) ------------------
+// The A tiles (transposed images of the sampled rows) carry per-tile scales 2^e_t; their X blocks are split in the
+// kernel anyway, so X is multiplied by 2^(13 - (e_t - e_min)) x xs before ITS split (xs = 1 for probabilities, a power of
+// two that puts the cloud's largest |dS| under 1 for dS): every term of the sum carries 2^(13 + e_min) xs, taken out once
+// at the end.  A tile of small values (large e_t) gets its X scaled less: what that loses is relative to a contribution
+// that is small already.  The tiles' 2^-e_t are read once, lane l keeping those of tiles l, l + 64, ... (kDuoTsRegs
+// registers: ntiles <= 64 kDuoTsRegs), and the loop gets tile t's factor by a lane permute -- a load per tile would join
+// the hand-counted vmcnt queue of the DMA rings (and v_readlane of a register a load wrote draws a compiler-placed
+// vmcnt(0) into the loop).
+constexpr int kDuoTrScaleSlot = ((3 * 0 + 2) * 128 + 0) * 16;  // tri_tr_off(0, 0, 2): a transposed-image tile's 2^-e
+constexpr int kDuoTsRegs = 8;
+struct DuoTileScales {
+  float inv[kDuoTsRegs];
+  float rcp_max;
+  __device__ __forceinline__ void load(const char* __restrict__ img, int ntiles, int lane) {
+    float mx = 0.f;
+#pragma unroll
+    for (int j = 0; j < kDuoTsRegs; ++j) {
+      const int t = 64 * j + lane;
+      inv[j] = t < ntiles ? *reinterpret_cast<const float*>(img + (long)t * kTriTile + kDuoTrScaleSlot) : 0.f;
+      mx = fmaxf(mx, inv[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    rcp_max = 1.f / mx;  // (mx = 2^-e_min: a power of two, the reciprocal is exact)
+#pragma unroll
+    for (int j = 0; j < kDuoTsRegs; ++j) {  // (into registers a vector-ALU instruction wrote: see above)
+      float c;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(c) : "v"(inv[j]));
+      inv[j] = c;
+    }
+  }
+  __device__ __forceinline__ float x_scale(int t) const {  // 2^(13 - (e_t - e_min)); t wave-uniform
+    float v = inv[0];
+#pragma unroll
+    for (int j = 1; j < kDuoTsRegs; ++j) v = (t >> 6) == j ? inv[j] : v;
+    return 8192.f * __shfl(v, t & 63, 64) * rcp_max;
+  }
+  __device__ __forceinline__ float unscale() const { return (1.f / 8192.f) / rcp_max; }  // 2^-(13 + e_min)
+};
+
 // the 8 fp32 values of one 16-byte chunk triple (h, m, l pieces of 8 consecutive channels): exact sums
 __device__ __forceinline__ void tri_chunk_values(u32x4 hh, u32x4 mm, u32x4 ll, float (&x)[8]) {
 #pragma unroll
