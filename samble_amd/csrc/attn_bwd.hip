@@ -139,22 +139,55 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
   __syncthreads();
   PSTAMP(2);
   const int ntiles_m = gridDim.x;
-  {  // operand images of the tile (layouts: tri_dev.h); rows past M-1 are zeros in both tiles
+  {  // operand images of the tile (layouts: tri_dev.h); rows past M-1 are zeros in both tiles.
+    // The ROW image of dO (the dQ kernels' dP = dO V^T) always leaves as two fp16 planes under the tile's power-of-two
+    // scale (tri_dev.h, the logit form); the two TRANSPOSED images likewise when ds_amax is given, else as three planes.
     char* irm = dO_rm + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
     char* itr = dO_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
     char* qtr = Q_tr + ((long)b * ntiles_m + blockIdx.x) * kTriTile;
+    __shared__ float amx[2][4];
+    if (ds_amax && blockIdx.x == 0 && tid == 0) ds_amax[b] = 0u;
+    float ax = 0.f, ay = 0.f;
+    for (int e = tid; e < 128 * 32; e += 256) {
+      ax = fmaxf(ax, fabsf(gt[(e >> 5) * 33 + (e & 31)]));
+      ay = fmaxf(ay, fabsf(qt[(e >> 5) * 33 + (e & 31)]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ax = fmaxf(ax, __shfl_xor(ax, o, 64));
+      ay = fmaxf(ay, __shfl_xor(ay, o, 64));
+    }
+    if ((tid & 63) == 0) {
+      amx[0][tid >> 6] = ax;
+      amx[1][tid >> 6] = ay;
+    }
+    __syncthreads();
+    ax = fmaxf(fmaxf(amx[0][0], amx[0][1]), fmaxf(amx[0][2], amx[0][3]));
+    ay = fmaxf(fmaxf(amx[1][0], amx[1][1]), fmaxf(amx[1][2], amx[1][3]));
+    float sx, ix, sy, iy;
+    duo_scale_for(ax, sx, ix);
+    duo_scale_for(ay, sy, iy);
+    auto duo8 = [&](const float (&v)[8], float sc, u32x4& hw, u32x4& lw) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned a1, a2;
+        duo_split2(v[2 * w] * sc, v[2 * w + 1] * sc, a1, a2);
+        hw[w] = a1;
+        lw[w] = a2;
+      }
+    };
     for (int e = tid; e < 512; e += 256) {
       {
         const int r = e & 31, gq = e >> 5;
         float x[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = gt[(8 * gq + i) * 33 + r];
-        const Tri t3 = tri_split8(x);
-        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 0)) = t3.h;
-        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = t3.m;
-        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 2)) = t3.l;
+        u32x4 hw, lw;
+        duo8(x, sx, hw, lw);
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 0)) = hw;
+        *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = lw;
+        if (e == 0) *reinterpret_cast<u32x4*>(irm + kDuoScaleSlot) = u32x4{__float_as_uint(ix), 0u, 0u, 0u};
       }
-      if (ds_amax) continue;  // (the transposed images: below, once the tile's largest values are known)
       const int d = e & 127, cg = e >> 7;
       float x[8], y[8];
 #pragma unroll
@@ -163,59 +196,10 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
         x[i] = gt[o];
         y[i] = qt[o];
       }
-      const Tri t3 = tri_split8(x), u3 = tri_split8(y);
-      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = t3.h;
-      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = t3.m;
-      *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 2)) = t3.l;
-      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = u3.h;
-      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = u3.m;
-      *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 2)) = u3.l;
-    }
-    if (ds_amax) {  // (uniform)
-      __shared__ float amx[2][4];
-      if (blockIdx.x == 0 && tid == 0) ds_amax[b] = 0u;
-      float x[2][8], y[2][8], ax = 0.f, ay = 0.f;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u, d = e & 127, cg = e >> 7;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int o = d * 33 + 16 * (cg >> 1) + 8 * (i >> 2) + 4 * (cg & 1) + (i & 3);
-          x[u][i] = gt[o];
-          y[u][i] = qt[o];
-          ax = fmaxf(ax, fabsf(x[u][i]));
-          ay = fmaxf(ay, fabsf(y[u][i]));
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        ax = fmaxf(ax, __shfl_xor(ax, o, 64));
-        ay = fmaxf(ay, __shfl_xor(ay, o, 64));
-      }
-      if ((tid & 63) == 0) {
-        amx[0][tid >> 6] = ax;
-        amx[1][tid >> 6] = ay;
-      }
-      __syncthreads();
-      ax = fmaxf(fmaxf(amx[0][0], amx[0][1]), fmaxf(amx[0][2], amx[0][3]));
-      ay = fmaxf(fmaxf(amx[1][0], amx[1][1]), fmaxf(amx[1][2], amx[1][3]));
-      float sx, ix, sy, iy;
-      duo_scale_for(ax, sx, ix);
-      duo_scale_for(ay, sy, iy);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u, d = e & 127, cg = e >> 7;
+      if (ds_amax) {  // (uniform)
         u32x4 xh, xl, yh, yl;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          unsigned a1, a2;
-          duo_split2(x[u][2 * w] * sx, x[u][2 * w + 1] * sx, a1, a2);
-          xh[w] = a1;
-          xl[w] = a2;
-          duo_split2(y[u][2 * w] * sy, y[u][2 * w + 1] * sy, a1, a2);
-          yh[w] = a1;
-          yl[w] = a2;
-        }
+        duo8(x, sx, xh, xl);
+        duo8(y, sy, yh, yl);
         *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = xh;
         *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = xl;
         *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = yh;
@@ -224,6 +208,14 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
           *reinterpret_cast<u32x4*>(itr + kDuoTrScaleSlot) = u32x4{__float_as_uint(ix), 0u, 0u, 0u};
           *reinterpret_cast<u32x4*>(qtr + kDuoTrScaleSlot) = u32x4{__float_as_uint(iy), 0u, 0u, 0u};
         }
+      } else {
+        const Tri t3 = tri_split8(x), u3 = tri_split8(y);
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 0)) = t3.h;
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 1)) = t3.m;
+        *reinterpret_cast<u32x4*>(itr + tri_tr_off(d, cg, 2)) = t3.l;
+        *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = u3.h;
+        *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = u3.m;
+        *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 2)) = u3.l;
       }
     }
   }
@@ -954,6 +946,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   unsigned* ds_amax = (tri && Oc && !(variant & 1))
                           ? reinterpret_cast<unsigned*>(Q_tr + img + samble_bwd_tri_dsmap_floats(B, N, M) * sizeof(float))
                           : nullptr;
+  if (tri && !Oc) return (int)hipErrorInvalidValue;  // (the split-bf16 backward is the map pipeline's: x_ds is there)
   if (tri && Oc) {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_tri_kernel<true> : bwd_prep_tri_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q,

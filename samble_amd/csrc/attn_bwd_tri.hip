@@ -108,6 +108,25 @@ __device__ __forceinline__ f32x16 mma_rm_x_regs(const char* __restrict__ rm_tile
   return acc;
 }
 
+// the same with both operands in their two-fp16-plane form (tri_dev.h): the tile from LDS carries 2^-e in its scale
+// slot, the register operand (planes h, l in q[3 ks], q[3 ks + 1], as load_rm_row fetches them from such an image) its
+// own tile's 2^-e in q_inv; three products per k-step, the accumulator x 2^-(e_a + e_q) is exact
+__device__ __forceinline__ f32x16 mma_rm_x_regs_duo(const char* __restrict__ rm_tile, int lo, int h, const u32x4 (&q)[24],
+                                                    float q_inv) {
+  const u32x4* lp = reinterpret_cast<const u32x4*>(rm_tile + tri_rm_off(lo, h, 0));
+  const float f = q_inv * *reinterpret_cast<const float*>(rm_tile + kDuoScaleSlot);
+  f32x16 acc = zero16();
+  tri_pipelined<8>([&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], u32x4{0, 0, 0, 0}}; },
+                   [&](int ks, const Tri& a) { acc = mfma_duo(a.h, a.m, q[3 * ks], q[3 * ks + 1], acc); });
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] *= f;
+  return acc;
+}
+// 2^-e of the tile that holds `row` of a row image in that form
+__device__ __forceinline__ float rm_tile_inv(const char* __restrict__ img, long tiles_per_cloud, int b, int row) {
+  return *reinterpret_cast<const float*>(img + ((long)b * tiles_per_cloud + (row >> 5)) * kTriTile + kDuoScaleSlot);
+}
+
 __device__ __forceinline__ void load_rm_row(const char* __restrict__ img, long tiles_per_cloud, int b, int row, int h,
                                             u32x4 (&q)[24]) {
   const u32x4* qp = reinterpret_cast<const u32x4*>(img + ((long)b * tiles_per_cloud + (row >> 5)) * kTriTile +
@@ -195,6 +214,7 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
   stage(0);
   u32x4 go[24];
   load_rm_row(a.dO_rm, mtiles, b, mc, h, go);
+  const float do_inv = rm_tile_inv(a.dO_rm, mtiles, b, mc);  // (wave-uniform: the wave's 32 rows are one tile)
   f32x16 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(256) void bwd_dq_tri_kernel(const DqTriArgs a) {
     if (ABL & 2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dp[r] = __uint_as_float(go[r][0]);
-    } else dp = mma_rm_x_regs(st, lo, h, go);  // dP^T: rows = keys crow(r, h), column = this lane's row
+    } else dp = mma_rm_x_regs_duo(st, lo, h, go, do_inv);  // dP^T: rows = keys crow(r, h), column = this lane's row
     const char* sw = st + 2 * kTriTile + wave * 4096;
     const f32x4* sp = reinterpret_cast<const f32x4*>(sw + lane * 16);
     float ds[16];
@@ -327,11 +347,12 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
   stage_p(0);
   u32x4 go[24];
   load_rm_row(a.dO_rm, mtiles, b, mc, h, go);
+  const float do_inv = rm_tile_inv(a.dO_rm, mtiles, b, mc);  // (wave-uniform: the wave's 32 rows are one tile)
   f32x16 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) oacc[dt] = zero16();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  f32x16 dp_cur = mma_rm_x_regs(vring, lo, h, go), dp_nxt;
+  f32x16 dp_cur = mma_rm_x_regs_duo(vring, lo, h, go, do_inv), dp_nxt;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // V slot 0 is restaged by iteration 0
   Tri bp[2];  // dS^T fragments of the tile whose dQ product is due (tile t-1): none yet
 #pragma unroll
@@ -341,13 +362,16 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
   for (int r = 0; r < 16; ++r) dsprev[r] = 0.f;
 
   // iteration t = 0 .. ntiles: dP of tile t+1, dS of tile t, dQ product and dS-map rows of tile t-1
-  auto step = [&](int t, auto last_c) {
-    constexpr bool LAST = decltype(last_c)::value;
+  auto step = [&](int t, auto last_c, auto first_c) {
+    constexpr bool LAST = decltype(last_c)::value, FIRST = decltype(first_c)::value;
     // operand reads first
     const u32x4* lp = reinterpret_cast<const u32x4*>(vring + ((t + 1) & 1) * kTriTile + tri_rm_off(lo, h, 0));
-    // t = 0: no dS yet (zeros): any finite tile will do, K tile 0 is only arriving -- V tile 1's slot holds finite data
-    const char* kt = (t == 0) ? vring + kTriTile : kring + ((t - 1) & 1) * kTriTile;
-    auto fetch_v = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]}; };
+    // dP of tile t+1: V tile and dO row as two fp16 planes each; 2^-(e_dO + e_V) comes out of the finished sum
+    const float vf = do_inv * *reinterpret_cast<const float*>(vring + ((t + 1) & 1) * kTriTile + kDuoScaleSlot);
+    // FIRST (t = 0): no dS yet, K tile 0 is only arriving: the dQ products are left out (any stand-in operand would have
+    // to be finite in all three pieces, and the third piece slots of a two-plane image are unwritten memory)
+    const char* kt = FIRST ? vring + kTriTile : kring + ((t - 1) & 1) * kTriTile;
+    auto fetch_v = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], u32x4{0, 0, 0, 0}}; };
     auto fetch_k = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
       const char* ap = kt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
       return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
@@ -374,11 +398,8 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
         k2 = fetch_k(i + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!LAST) {
-        const Tri bq = {go[3 * i], go[3 * i + 1], go[3 * i + 2]};
-        dp_nxt = mfma_tri(v0, bq, dp_nxt);
-      }
-      oacc[i & 3] = mfma_tri(k0, bp[i >> 2], oacc[i & 3]);
+      if (!LAST) dp_nxt = mfma_duo(v0.h, v0.m, go[3 * i], go[3 * i + 1], dp_nxt);
+      if (!FIRST) oacc[i & 3] = mfma_tri(k0, bp[i >> 2], oacc[i & 3]);
       {  // slice i of the vector work on tile t: elements 2 i, 2 i + 1
 #pragma clang fp contract(off)  // dS is what the map holds: the split must start from the ROUNDED product, not fuse into it
         const int r0 = 2 * i, r1 = 2 * i + 1;
@@ -424,9 +445,9 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
         }
       }
 #pragma unroll
-      for (int m = 0; m < (LAST ? 6 : 12); ++m) {
+      for (int m = 0; m < (LAST ? 6 : FIRST ? 3 : 9); ++m) {  // 3 dP + 6 dQ products per k-step
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 4 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, LAST ? 4 : FIRST ? 8 : 3, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       v0 = v1;
@@ -436,14 +457,16 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
     }
     // the 16 pieces of this iteration must have landed; younger than them: its 4 stores
     if (!LAST) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    dp_cur = dp_nxt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp_cur[r] = dp_nxt[r] * vf;
     bp[0] = bn[0];
     bp[1] = bn[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) dsprev[r] = ds[r];
   };
-  for (int t = 0; t < ntiles; ++t) step(t, std::false_type{});
-  step(ntiles, std::true_type{});
+  step(0, std::false_type{}, std::true_type{});
+  for (int t = 1; t < ntiles; ++t) step(t, std::false_type{}, std::false_type{});
+  step(ntiles, std::true_type{}, std::false_type{});
   if (a.ds_amax) {  // (non-negative floats order as their bits)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ds_max = fmaxf(ds_max, __shfl_xor(ds_max, o, 64));
@@ -530,6 +553,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
   stage_meta(1);
   u32x4 vr[24];
   load_rm_row(a.V_rm, ktiles, b, jc, h, vr);
+  const float v_inv = rm_tile_inv(a.V_rm, ktiles, b, jc);  // (wave-uniform: the wave's 32 keys are one tile)
   f32x16 dv[4], dk[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dv[dt] = dk[dt] = zero16();
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(256) void bwd_dkdv_tri_kernel(const KvTriArgs a) {
     stage_meta(t + 2);
     rows16(Lt + 32, dl);
     rows16(Ln, lv);
-    const f32x16 dp = mma_rm_x_regs(st, lo, h, vr);  // dP: rows = sampled rows crow(r, h), column = this lane's key
+    const f32x16 dp = mma_rm_x_regs_duo(st, lo, h, vr, v_inv);  // dP: rows = sampled rows crow(r, h), column = this lane's key
     Tri df[2];
     float ds[16];
     block(st + kTriTile, pf, dv, [&](int i) {

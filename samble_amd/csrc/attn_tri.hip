@@ -1023,7 +1023,11 @@ extern "C" int samble_launch_tri_split_qkv(const float* qkv, long bs, long rs, i
   Timed timed(kT_tri_split, stream);
   hipLaunchKernelGGL(tri_split_qkv_kernel, dim3((N + nt + 31) / 32, B), dim3(256), 0, stream, qkv, bs, rs, N, N + nt,
                      (char*)qimg, (char*)kimg, (char*)vimg, (char*)ktr, (char*)vrm, 0);
-  if (kimg) return samble_launch_k_to_duo(kimg, B, N + nt, 0, stream);
+  if (kimg) {
+    const int rc = samble_launch_k_to_duo(kimg, B, N + nt, 0, stream);
+    if (rc) return rc;
+  }
+  if (vrm) return samble_launch_k_to_duo(vrm, B, N + nt, 0, stream);  // (the backward's dP = dO V^T: same form)
   return (int)hipGetLastError();
 }
 

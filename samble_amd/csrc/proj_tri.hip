@@ -170,8 +170,9 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
   // iteration t: tile t+3 into the slot of tile t-1, product of tile t, its 4 row stores; VM operations
   // younger than tile t+1's DMA at the end of the iteration: stores(t-2) 4 + 2 x (3 + 4) = 18 (image stores only
   // add to that: counting low is the safe side)
-  // The K row image leaves in its LOGIT form (tri_dev.h: two fp16 planes per 32-point tile under the tile's own
-  // power-of-two scale).  A wave's 32 points ARE one tile, its 128 K channels come out of iterations t = 4..7: their
+  // The K row image (and the V row image of the backward) leaves in its LOGIT form (tri_dev.h: two fp16 planes per
+  // 32-point tile under the tile's own power-of-two scale).  A wave's 32 points ARE one tile, its 128 K channels come out
+  // of iterations t = 4..7 (V: 8..11): their
   // values wait in registers (kst, compile-time indices: those four iterations are written out below) until the last of
   // them knows the tile's largest |k|.
   float kst[4][2][8];
@@ -291,7 +292,14 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
   } else {
     for (int t = 4; t < 8; ++t) body(t, integral_constant<int, -1>{});
   }
-  for (int t = 8; t < kPTiles; ++t) body(t, integral_constant<int, -1>{});
+  if (full && im.v_rm) {  // the V row image (the backward's dP = dO V^T) leaves the same way
+    body(8, integral_constant<int, 0>{});
+    body(9, integral_constant<int, 1>{});
+    body(10, integral_constant<int, 2>{});
+    body(11, integral_constant<int, 3>{});
+  } else {
+    for (int t = 8; t < kPTiles; ++t) body(t, integral_constant<int, -1>{});
+  }
 }
 
 #ifdef SAMBLE_STAMPS  // scratch builds only (tools/scratch, tools/proj_stamps.py): workgroup (0,0), every wave, tiles 5 and 6
@@ -565,7 +573,11 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
   }
   // the K row image leaves in its logit form (tri_dev.h): the full point tiles from the kernel's epilogue, the token /
   // ragged tiles (written as three planes above) by the conversion kernel
-  if (k_rm) return samble_launch_k_to_duo(k_rm, B, N + nt, N / 32, s);
+  if (k_rm) {
+    rc = samble_launch_k_to_duo(k_rm, B, N + nt, N / 32, s);
+    if (rc) return rc;
+    if (v_rm) return samble_launch_k_to_duo(v_rm, B, N + nt, N / 32, s);
+  }
   return (int)hipGetLastError();
 }
 

@@ -410,9 +410,10 @@ MATRIX_MODE = os.environ.get("SAMBLE_MATRIX_MODE", "tri")
 
 
 def stage_k_logit_form(k_image: torch.Tensor, k_rows: torch.Tensor) -> torch.Tensor:
-    """A K row image from stage_tri_split -> its logit form, IN PLACE (include/samble.h samble_tri_k_logit_form):
-    what the `k_image` arguments of stage_attn_stats / stage_attn_stats_nl / stage_attn_rows_recompute expect.
-    stage_tri_split_qkv and stage_proj_fwd(images=...) hand their K row image over in this form already."""
+    """A row image from stage_tri_split -> its logit form, IN PLACE (include/samble.h samble_tri_k_logit_form):
+    what the `k_image` arguments of stage_attn_stats / stage_attn_stats_nl / stage_attn_rows_recompute and the V row
+    image of stage_attn_rows_bwd (`images[1]`) expect.  stage_tri_split_qkv and stage_proj_fwd(images=...) hand their K
+    and V row images over in this form already."""
     B, rows = k_rows.shape[0], k_rows.shape[1]
     with torch.cuda.device(k_image.device):
         _lib.call("samble_tri_k_logit_form", k_image.data_ptr(), B, rows, _stream())
@@ -705,7 +706,7 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
         cs = torch.zeros((B, n_points + n_tokens), dtype=torch.float32, device=q.device) if asm in ("l2", "l2+") else None
         if MATRIX_MODE == "tri":
             if images is None:
-                images = (stage_tri_split(k, want_rm=False, want_tr=True)[1], stage_tri_split(v)[0])
+                images = (stage_tri_split(k, want_rm=False, want_tr=True)[1], stage_k_logit_form(stage_tri_split(v)[0], v))
             nbytes = _lib.query("samble_attn_rows_bwd_tri_workspace_bytes", B, n_points, M, D)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
             _lib.call("samble_attn_rows_bwd_tri_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0),
