@@ -322,15 +322,20 @@ int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* q
  *   samble_tri_split_qkv_f32 one launch for the projection output (B, N+nt, 3*128) = [Q|K|V]: row image of Q (N
  *                            rows), row image of K and transposed image of V (N+nt rows); optionally (non-NULL)
  *                            the two images the backward wants: transposed K, row V
- *                            -- the K ROW image leaves in its LOGIT FORM (below)
- *   samble_tri_k_logit_form  a K row image (as samble_tri_split_f32 writes it) -> its logit form, in place, once:
- *                            S = Q K^T is formed tile by tile, so each 32-key tile is rewritten as two fp16 planes of
- *                            its values x 2^e (e per tile; 2^-e kept in the tile) and the logit kernels run three fp16
- *                            products per k-step instead of six bf16 ones, the query row converted in registers under
- *                            its own scale: 22 significant bits per operand, exact power-of-two scaling, fp32
- *                            accumulation (samble_amd/csrc/tri_dev.h; P V and the backward stay on three bf16 planes).
- *                            samble_tri_split_qkv_f32 and samble_proj_fwd_split_tri_f32 apply it themselves; the K
- *                            image arguments of the three logit entries below expect it
+ *                            -- the two ROW images of K and V leave in their LOGIT FORM (below)
+ *   samble_tri_k_logit_form  a row image (as samble_tri_split_f32 writes it) -> its logit form, in place, once: each
+ *                            32-row tile is rewritten as two fp16 planes of its values x 2^e (e per tile; 2^-e kept in
+ *                            the tile) -- for the products that are formed tile by tile with nothing accumulated across
+ *                            tiles: S = Q K^T (row image of K; the query row is converted in registers under its own
+ *                            scale) and the backward's dP = dO V^T (row image of V; the dO rows come from the
+ *                            backward's own preparation in the same form).  Those kernels run three fp16 MFMA products
+ *                            per k-step instead of six bf16 ones and take the scales out of the finished accumulator,
+ *                            exactly: 22 significant bits per operand, power-of-two scaling, fp32 accumulation
+ *                            (samble_amd/csrc/tri_dev.h; the backward's dV / dK accumulation does the same on images it
+ *                            prepares itself; P V and dQ stay on three bf16 planes).  samble_tri_split_qkv_f32 and
+ *                            samble_proj_fwd_split_tri_f32 apply it to k_image and v_rm_image themselves; the K row
+ *                            image arguments of the three logit entries and the v_rm_image argument of
+ *                            samble_attn_rows_bwd_tri_f32 expect it
  *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows, logit form)
  *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows)
  *   samble_attn_rows_bwd_tri_f32 = samble_attn_rows_bwd_f32 (same outputs, same ds_colsum contract).  variant 0:
@@ -341,7 +346,7 @@ int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* q
 size_t samble_tri_image_bytes(int B, int rows, int transposed);
 int samble_tri_split_f32(const float* src, int64_t bs, int64_t rs, int B, int rows, int D, void* rm_image,
                          void* tr_image, void* stream);
-int samble_tri_k_logit_form(void* k_image, int B, int rows, void* stream);
+int samble_tri_k_logit_form(void* row_image, int B, int rows, void* stream);
 int samble_attn_stats_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D, float* smap,
                               int ld, float* lse, float* tok, const float* q_sqnorm, const float* k_sqnorm,
                               void* stream);
