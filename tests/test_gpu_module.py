@@ -378,3 +378,26 @@ def test_map_free_without_the_fused_chain():
         ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
     for j, (t1, t2) in enumerate(zip(*outs)):
         assert torch.equal(t1, t2), j
+
+
+@pytest.mark.parametrize("k", [-40, -12, 20, 60])
+def test_backward_is_exactly_linear_in_a_power_of_two(k):
+    """Every operand of the backward's matrix products carries power-of-two scales (tile scales of dO / Q / V, the cloud's
+    largest |dS|, csrc/tri_dev.h) or is split into planes that scale exactly: an upstream gradient x 2^k must give every
+    gradient x 2^k, bit for bit -- from 2^-40 to 2^60 (nothing underflows into fp16's denormals, nothing overflows) --
+    and a zero gradient gives zeros."""
+    g = Golden("cls_random_dyn")
+    noise = g.t("noise").to(DEV)
+    up = g.upstream().to(DEV)
+    grads = []
+    for scale in (1.0, 2.0 ** k, 0.0):
+        mod = g.module(DEV)
+        x = g.x().to(DEV).requires_grad_(True)
+        (x_ds, _), _ = mod(x, noise=noise)
+        x_ds.backward(up * scale)
+        grads.append([x.grad.clone()] + [p.grad.clone() for p in (mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight,
+                                                                   mod.bin_tokens)])
+    for a, b2, z in zip(*grads):
+        assert bool(torch.isfinite(b2).all())
+        assert torch.equal(a * 2.0 ** k, b2), float((a * 2.0 ** k - b2).abs().max())
+        assert bool((z == 0).all())
