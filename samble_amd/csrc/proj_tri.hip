@@ -119,17 +119,40 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
     if (IMG && nt > 0 && (N & 31) == 0) {
       // ... and, when the token rows have an image tile of their own, that tile of the K / V images (rows nt.. zero)
       const long toff = ((long)b * im.ktiles + (N >> 5)) * kTriTile;
-      for (int e = tid; e < 1024; e += 512) {  // row-image chunks of K and (for the backward) V
-        const int which = 1 + (e >> 9), r = e & 31, g = (e >> 5) & 15;
-        if (which == 2 && !im.v_rm) continue;
-        float v8[8];
+      // row-image tiles of K and (for the backward) V, in their logit form like the point tiles below (tri_dev.h): pass
+      // `which` has the whole workgroup on one image, one chunk triple per thread; the tile's largest value through the
+      // (still unused) transpose area of the LDS
+      float* red = reinterpret_cast<float*>(smem_c + D * kTriTile);
+      for (int which = 1; which <= 2; ++which) {
+        if (which == 2 && !im.v_rm) break;  // (uniform)
+        const int r = tid & 31, g = tid >> 5;
+        float v8[8], amax = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v8[i] = (r < nt) ? tokqkv[r * kPO + 128 * which + 8 * g + i] : 0.f;
-        const Tri t3 = tri_split8(v8);
+        for (int i = 0; i < 8; ++i) {
+          v8[i] = (r < nt) ? tokqkv[r * kPO + 128 * which + 8 * g + i] : 0.f;
+          amax = fmaxf(amax, fabsf(v8[i]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        __syncthreads();  // (the previous pass's readers of red)
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 8; ++w) amax = fmaxf(amax, red[w]);
+        float sc, inv;
+        duo_scale_for(amax, sc, inv);
+        u32x4 hw, lw;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          unsigned a1, a2;
+          duo_split2(v8[2 * w] * sc, v8[2 * w + 1] * sc, a1, a2);
+          hw[w] = a1;
+          lw[w] = a2;
+        }
         char* img = (which == 1 ? im.k_rm : im.v_rm) + toff;
-        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = t3.h;
-        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = t3.m;
-        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = t3.l;
+        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = hw;
+        *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = lw;
+        if (tid == 0) *reinterpret_cast<u32x4*>(img + kDuoScaleSlot) = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
       }
       for (int e = tid; e < 1024; e += 512) {  // transposed-image chunks of V and (for the backward) K
         const int which = e >> 9, d = e & 127, cg = (e >> 7) & 3, s2 = cg >> 1, hh = cg & 1;
@@ -571,9 +594,9 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
     rc = samble_launch_tri_split_qkv_tiles(qkv, o_bs, o_rs, B, N, nt, N / 32, q_rm, k_rm, v_tr, k_tr, v_rm, s);
     if (rc) return rc;
   }
-  // the K row image leaves in its logit form (tri_dev.h): the full point tiles from the kernel's epilogue, the token /
-  // ragged tiles (written as three planes above) by the conversion kernel
-  if (k_rm) {
+  // the K and V row images leave in their logit form (tri_dev.h): the full point tiles and a token tile of its own from
+  // the kernel, the tiles of a ragged end (written as three planes by the split launch above) by the conversion kernel
+  if (k_rm && (N & 31)) {  // (N % 32 == 0: the kernel wrote the token tile in that form as well)
     rc = samble_launch_k_to_duo(k_rm, B, N + nt, N / 32, s);
     if (rc) return rc;
     if (v_rm) return samble_launch_k_to_duo(v_rm, B, N + nt, N / 32, s);
