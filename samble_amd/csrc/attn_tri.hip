@@ -114,11 +114,14 @@ constexpr int kStPadT = 36;
 // ABL (timing-only ablations, wrong outputs): 1 = no map stores, 2 = no matrix products
 template <int ABL>
 __device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int lo, int h, const u32x4 (&qd)[16],
-                                               float q_unscale, f32x16& s_nxt) {
+                                               float q_scale, f32x16& s_nxt, float& sc_nxt) {
   // Kn: a K tile converted to two fp16 planes (tri_k_to_duo_kernel): h in the first, l in the second piece slot of
   // each channel group; qd: this lane's query row as two fp16 planes (duo_q_from_tri)
   const u32x4* lp = reinterpret_cast<const u32x4*>(Kn + tri_rm_off(lo, h, 0));  // group 2 ks + h: + ks * 192 chunks
-  const float f = q_unscale * *reinterpret_cast<const float*>(Kn + kDuoScaleSlot);  // 2^-(e_q + e_k): exact
+  // q_scale = 2^-e_q x the logit scale 1/sqrt(D); x the tile's 2^-e_k (both factors of two: exact) = the ONE factor that
+  // turns the raw accumulator into the logit -- a single rounding, the bits round(S 2^-(e_q + e_k) / sqrt(D)) in every
+  // kernel that forms logits
+  sc_nxt = q_scale * *reinterpret_cast<const float*>(Kn + kDuoScaleSlot);
   s_nxt = zero16();
   if (ABL & 8) {  // the compiler's own placement of the operand reads
 #pragma unroll
@@ -135,8 +138,6 @@ __device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int 
                        else s_nxt = mfma_duo(a.h, a.m, qd[2 * ks], qd[2 * ks + 1], s_nxt);
                      });
   }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s_nxt[r] *= f;
 }
 
 template <bool TAIL, bool L2, int ABL>
@@ -266,8 +267,10 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
   u32x4 qd[16];  // the query row as two fp16 planes under its own scale (tri_dev.h)
   float q_unscale;
   duo_q_from_tri(q, qd, q_unscale);
+  const float q_scale = q_unscale * scale;  // (exact: q_unscale is a power of two)
+  float sc_cur, sc_nxt;
   f32x16 s_cur, s_nxt;
-  stats_products<ABL>(buf_ptr(0), lo, h, qd, q_unscale, s_cur);
+  stats_products<ABL>(buf_ptr(0), lo, h, qd, q_scale, s_cur, sc_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
 
   // iteration t: restage the buffer of tile t (read one iteration ago) with tile t+D, products of tile
@@ -282,17 +285,18 @@ __global__ __launch_bounds__(512, 2) void attn_stats_tri_kernel(const char* __re
     // the two waves of a SIMD (w and w + 4) take the two phases in opposite order, so one's vector work
     // and stores run under the other's MFMAs (same order: both in the MFMA phase, then both out of it)
     if (pfirst || (ABL & 4)) {
-      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
       __builtin_amdgcn_sched_barrier(0);
-      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
+      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, sc_cur, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
     } else {
-      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, scale, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
+      stats_epilogue<TAIL, L2, ABL>(lo, h, s_cur, sc_cur, xt, gdst + j0, roff, j0, N, NK, tokrow, m, l, qb, kb);
       __builtin_amdgcn_sched_barrier(0);
-      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
+      stats_products<ABL>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((ABL & 1) ? 3 * (D - 2) : 4 + 7 * (D - 2))
                  : "memory");
     s_cur = s_nxt;
+    sc_cur = sc_nxt;
   };
   const int n_full = min(N / kTile, ntiles);  // tiles without token / padding columns
   int t = 0;
@@ -448,8 +452,10 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
   u32x4 qd[16];  // the query row as two fp16 planes under its own scale (tri_dev.h)
   float q_unscale;
   duo_q_from_tri(q, qd, q_unscale);
+  const float q_scale = q_unscale * scale;  // (exact: q_unscale is a power of two)
+  float sc_cur, sc_nxt;
   f32x16 s_cur, s_nxt;
-  stats_products<0>(buf_ptr(0), lo, h, qd, q_unscale, s_cur);
+  stats_products<0>(buf_ptr(0), lo, h, qd, q_scale, s_cur, sc_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
 
   // iteration t: restage the slot of tile t (read one iteration ago) with tile t+D and its mask word, products of
@@ -465,16 +471,16 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
     stage(t + D);
     NL_STAMP(1);
     if (pfirst) {
-      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
+      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
-      stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
+      stats_nl_epilogue<TAIL>(h, s_cur, sc_cur, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
       NL_STAMP(3);
     } else {
-      stats_nl_epilogue<TAIL>(h, s_cur, scale, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
+      stats_nl_epilogue<TAIL>(h, s_cur, sc_cur, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
-      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_unscale, s_nxt);
+      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
       NL_STAMP(3);
     }
 #ifdef SAMBLE_STAMPS
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (D - 2)) : "memory");
 #endif
     s_cur = s_nxt;
+    sc_cur = sc_nxt;
   };
   const int n_full = min(N / kTile, ntiles);  // tiles without token / padding columns
   int t = 0;
@@ -756,8 +763,10 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
   u32x4 qd[16];  // the sampled row as two fp16 planes under its own scale: the SAME conversion as in pass 1, so the
   float q_unscale;  // recomputed logits are the bits lse was formed from
   duo_q_from_tri(q, qd, q_unscale);
+  const float q_scale = q_unscale * scale;  // (exact: q_unscale is a power of two)
+  float sc_cur;
   f32x16 s_cur, s_nxt;
-  stats_products<0>(kring, lo, h, qd, q_unscale, s_cur);
+  stats_products<0>(kring, lo, h, qd, q_scale, s_cur, sc_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K slot 0 is restaged by iteration 0
   Tri bp[2];  // P^T fragments (two k-steps of 16 keys) of the tile whose P V is due: tile t-1; none yet
 #pragma unroll
@@ -786,7 +795,7 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     const u32x4* lp = reinterpret_cast<const u32x4*>(kring + ((t + 1) % D) * kTriTile + tri_rm_off(lo, h, 0));
     auto fetch_k = [&](int ks) { return Tri{lp[192 * ks], lp[192 * ks + 32], u32x4{0, 0, 0, 0}}; };  // fp16 planes h, l
     // 2^-(e_q + e_k) of tile t+1 (its slot is not restaged before the next barrier)
-    const float kf = q_unscale * *reinterpret_cast<const float*>(kring + ((t + 1) % D) * kTriTile + kDuoScaleSlot);
+    const float sc_nxt = q_scale * *reinterpret_cast<const float*>(kring + ((t + 1) % D) * kTriTile + kDuoScaleSlot);
     auto fetch_v = [&](int i) {  // step i: k-step i >> 2, channel block i & 3
       const char* ap = vt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
       return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
         const int r0 = 2 * i, r1 = 2 * i + 1;
         float x0 = s_cur[r0], x1 = s_cur[r1];
         asm volatile("" : "+v"(x0), "+v"(x1));  // pins the slice inside this k-step's scheduling region (with the one below)
-        const float e0 = __expf(x0 * scale - my_lse), e1 = __expf(x1 * scale - my_lse);
+        const float e0 = __expf(x0 * sc_cur - my_lse), e1 = __expf(x1 * sc_cur - my_lse);
         p[r0] = LAST ? 0.f : (TAILK && t * kTile + crow(r0, h) >= NK) ? 0.f : e0;  // padding keys of the last tile
         p[r1] = LAST ? 0.f : (TAILK && t * kTile + crow(r1, h) >= NK) ? 0.f : e1;
         unsigned hh, mm, ll;
@@ -894,8 +903,8 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
     if (!LAST) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PMAP ? 20 : 12) : "memory");
 #endif
     RC_STAMP(12);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_cur[r] = s_nxt[r] * kf;
+    s_cur = s_nxt;
+    sc_cur = sc_nxt;
     bp[0] = bn[0];
     bp[1] = bn[1];
 #pragma unroll
