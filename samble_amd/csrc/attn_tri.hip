@@ -176,8 +176,11 @@ __device__ __forceinline__ void stats_epilogue(int lo, int h, f32x16& s_cur, flo
   const float mnew = fmaxf(m, mt);
   l *= __expf(m - mnew);
   m = mnew;
+  // exp(v - m) as exp2(v log2e - m log2e): one fused multiply-add and the exponential instead of subtract, multiply,
+  // exponential (the sum only enters lse; both statistics kernels form it the same way)
+  const float m2 = m * 1.4426950408889634f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ps += __expf(s_cur[r] - m);
+  for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(fmaf(s_cur[r], 1.4426950408889634f, -m2));
   l += ps;
 }
 
@@ -388,8 +391,11 @@ __device__ __forceinline__ void stats_nl_epilogue(int h, f32x16& s_cur, float sc
   const float mnew = fmaxf(m, mt);
   l *= __expf(m - mnew);
   m = mnew;
+  // exp(v - m) as exp2(v log2e - m log2e): one fused multiply-add and the exponential instead of subtract, multiply,
+  // exponential (the sum only enters lse; both statistics kernels form it the same way)
+  const float m2 = m * 1.4426950408889634f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ps += __expf(s_cur[r] - m);
+  for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(fmaf(s_cur[r], 1.4426950408889634f, -m2));
   l += ps;
 }
 
