@@ -88,16 +88,20 @@ int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const flo
                         float* dtokens, void* ws, size_t ws_bytes, void* stream);
 /* The same two entries with the forward and dx on the bf16 matrix cores (fp32 operands split into three bf16
  * planes, six products each, fp32 accumulation: see the "split fp32 operands" block below); dW stays fp32 MFMA.
- * Same arguments; the workspaces also hold an operand image of W. */
+ * Same arguments; the workspaces also hold an operand image of W.
+ * Wk / Wv (samble_proj_bwd_tri_f32 here, samble_proj_fwd_split_tri_f32 below): NULL, NULL -- W is the (3C, C) block
+ * [Wq; Wk; Wv]; both non-NULL -- W is Wq and the three (C, C) weights are tensors of their own, as the reference's
+ * q_conv / k_conv / v_conv hold them (models/downsample.py:54-56): no concatenation on the caller's side.  The
+ * backward takes the three only together with w_tr_image (dx reads the image; W itself is read for the token rows). */
 size_t samble_proj_fwd_tri_workspace_bytes(void);
 int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
                             const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* ws, size_t ws_bytes,
                             void* stream);
 size_t samble_proj_bwd_tri_workspace_bytes(int B, int N);
 int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
-                            int N, const float* tokens, int nt, const float* W, const void* w_tr_image /* or NULL */,
-                            float* dx, int64_t dx_bs, float* dW, float* dtokens, void* ws, size_t ws_bytes,
-                            void* stream);
+                            int N, const float* tokens, int nt, const float* W, const float* Wk /* or NULL */,
+                            const float* Wv /* or NULL */, const void* w_tr_image /* or NULL */, float* dx, int64_t dx_bs,
+                            float* dW, float* dtokens, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
@@ -161,6 +165,15 @@ int samble_alloc_counts_f32(const float* w, const int32_t* cap, int B, int nb, i
 int samble_bin_select_f32(const float* score, const float* z, const uint8_t* member, const int32_t* counts,
                           const float* noise, int B, int N, int nb, int M, int sample_mode, int temp_mode, float temp,
                           int64_t* idx_out, void* stream);
+/* The same with the Exp(1) draw made inside the kernel (no (B*nb, N) tensor, no launch to fill it): element (row,
+ * n) of the draw is Philox4x32-10 under (seed, offset) in the counter layout of torch's device generator -- offset
+ * in 32-bit outputs, a multiple of 4; a caller that owns such a generator passes its state and advances it by 4 --
+ * first output word, 23 bits into (0, 1), -log.  samble_exp1_noise_f32 writes that (rows = B*nb, N) tensor out:
+ * samble_bin_select_f32 on it returns the same indices, bit for bit (tests/test_gpu_stages.py). */
+int samble_bin_select_seeded_f32(const float* score, const float* z, const uint8_t* member, const int32_t* counts,
+                                 uint64_t seed, uint64_t offset, int B, int N, int nb, int M, int sample_mode,
+                                 int temp_mode, float temp, int64_t* idx_out, void* stream);
+int samble_exp1_noise_f32(uint64_t seed, uint64_t offset, int rows, int N, float* noise, void* stream);
 
 /* ---- models/downsample.py:242-252  gather of the sampled rows -> x_ds (B,D,M) ---------------- */
 int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int64_t* idx, int B, int M, int D,
@@ -367,9 +380,10 @@ int samble_tri_split_qkv_f32(const float* qkv, int64_t bs, int64_t rs, int B, in
  * samble_proj_bwd_tri_f32 takes back as its w_tr_image (no split launch in the backward; W must be unchanged). */
 size_t samble_proj_w_image_bytes(void);
 int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
-                                  const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image, void* k_image,
-                                  void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows, void* w_tr_image,
-                                  void* ws, size_t ws_bytes, void* stream);
+                                  const float* W, const float* Wk /* or NULL */, const float* Wv /* or NULL */, float* qkv,
+                                  int64_t o_bs, int64_t o_rs, void* q_image, void* k_image, void* v_tr_image,
+                                  void* k_tr_image, void* v_rm_image, int rows, void* w_tr_image, void* ws, size_t ws_bytes,
+                                  void* stream);
 size_t samble_attn_rows_bwd_tri_workspace_bytes(int B, int N, int M, int D);
 int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                                  const float* V, int64_t v_bs, int64_t v_rs, const void* k_tr_image,
@@ -388,11 +402,15 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
  *                                order (nn_sorted) and one 32-bit word per (cloud, tile of 32 keys, query):
  *                                masks (B, ceil(N/32), N), bit k of word (b, t, i) set <=> 32 t + k in nn[b][i].
  *                                KN in {16, 32}.  samble_nn_masks_bytes(B, N) = size of `masks`.
+ *                                clear / clear_bytes (optional): the kernel also zeroes that range on its way -- the
+ *                                score workspace of the statistics pass that follows (then pass score_ws_cleared = 1
+ *                                there: no memset launch between the two).
  *   samble_attn_stats_nl_tri_f32 = samble_attn_stats_tri_f32 without the map: lse (B,N), tok (B,N,nt) and
  *                                nl (B, N, KN), nl[b][i][k] = S[b][i][nn_sorted[b][i][k]] (bit-identical to the map's
  *                                entries).  1 <= KN <= 32.  nl may be NULL when score_ws is given:
  *                                with score_ws (samble_score_workspace_bytes or, for the fused chain,
- *                                samble_select_chain_workspace_bytes; ALL score_ws_bytes are zeroed first) the
+ *                                samble_select_chain_workspace_bytes; ALL score_ws_bytes are zeroed first unless
+ *                                score_ws_cleared says the caller did: samble_nn_prepare's `clear`) the
  *                                pass also accumulates the sparse_* statistics of score_mode (A_ij = exp(S_ij -
  *                                lse_i), i over all rows, j in nn_sorted[i]) into it as samble_sparse_score_map_f32
  *                                would (N <= 8192): follow with samble_sparse_score_map_f32 or its _quantiles variant passing
@@ -406,13 +424,18 @@ int samble_attn_rows_fwd_tri_f32(const float* smap, int ld, const float* lse, co
  *                                SAMBLE_ROWS_BWD_PMAP (no exponentials, no row indirection in the backward). */
 #define SAMBLE_ROWS_BWD_FUSED_DKDV 1 /* fused dP / dV / dK kernel instead of the dS map (logit map only) */
 #define SAMBLE_ROWS_BWD_PMAP 2       /* `smap` is the (B, M, ld) P map of samble_attn_rows_fwd_recompute_tri_f32 */
+/* or-ed into `variant` of any backward entry: dQ has nt more rows behind its N point rows (same strides) -- the Q
+ * columns of the projection's [Q|K|V] gradient block, whose token rows are keys only -- and they receive zeros
+ * (no fill launch on the caller's side) */
+#define SAMBLE_BWD_DQ_TOKEN_ROWS 8
 size_t samble_nn_masks_bytes(int B, int N);
 /* nn and nn_sorted 16-byte aligned (the rows move in 16-byte pieces); KN 16 or 32 */
-int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks, void* stream);
+int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks, void* clear /* or NULL */,
+                      size_t clear_bytes, void* stream);
 int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
                                  const uint32_t* masks, int KN, float* nl, float* lse, float* tok,
                                  const int32_t* nn_sorted, int score_mode, void* score_ws, size_t score_ws_bytes,
-                                 void* stream);
+                                 int score_ws_cleared, void* stream);
 int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_image, const void* v_tr_image,
                                            const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
                                            float* x_ds, float* pmap, int ld, void* stream);

@@ -33,8 +33,8 @@ _SIGNATURES = {
     "samble_proj_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                     c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "samble_proj_bwd_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
-                                    c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
-                                    c_void_p]),
+                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
     "samble_proj_fwd_tri_workspace_bytes": (c_size_t, []),
     "samble_proj_w_image_bytes": (c_size_t, []),
     "samble_inverse_neighbors_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -66,6 +66,9 @@ _SIGNATURES = {
     "samble_alloc_counts_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_bin_select_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_int, c_int, c_float, c_void_p, c_void_p]),
+    "samble_bin_select_seeded_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int, c_int,
+                                             c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "samble_exp1_noise_f32": (c_int, [c_uint64, c_uint64, c_int, c_int, c_void_p, c_void_p]),
     "samble_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_gather_points_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_n2p_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -93,7 +96,7 @@ _SIGNATURES = {
     "samble_tri_image_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_tri_split_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_proj_fwd_split_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
-                                              c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                              c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_tri_k_logit_form": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "samble_tri_split_qkv_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -107,9 +110,9 @@ _SIGNATURES = {
     "samble_attn_rows_fwd_tri_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                              c_void_p, c_void_p]),
     "samble_nn_masks_bytes": (c_size_t, [c_int, c_int]),
-    "samble_nn_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "samble_nn_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_attn_stats_nl_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
-                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "samble_attn_rows_fwd_recompute_tri_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                        c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "samble_attn_stats_tri_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,

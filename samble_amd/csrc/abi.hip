@@ -26,8 +26,9 @@ size_t samble_quantiles_ws_bytes(void);
 int samble_launch_bin_assign(const float*, const float*, int, const float*, const float*, int, int, int, int,
                              unsigned char*, int*, float*, float*, hipStream_t);
 int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hipStream_t);
-int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, int, int, int,
-                             int, int, int, float, long long*, hipStream_t);
+int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, unsigned long long,
+                             unsigned long long, int, int, int, int, int, int, float, long long*, hipStream_t);
+int samble_launch_exp1_noise(unsigned long long, unsigned long long, long, float*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
 int samble_launch_blend_boundaries(const float*, float*, float*, int, float, float, int, hipStream_t);
 int samble_edge_waves(void);
@@ -40,11 +41,11 @@ int samble_launch_group_gather(const float*, const int*, int, int, int, int, int
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
 size_t samble_proj_tri_image_bytes();
-int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, float*, long, long, float*, void*,
-                           void* const*, int, void*, hipStream_t);
+int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, const float*, const float*, const float*, float*,
+                           long, long, float*, void*, void* const*, int, void*, hipStream_t);
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
-                           float*, long, float*, float*, float*, void*, const void*, hipStream_t);
+                           const float*, const float*, float*, long, float*, float*, float*, void*, const void*, hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
@@ -70,7 +71,7 @@ int samble_launch_attn_stats_nl_tri(const void*, const void*, int, int, int, flo
                                     float*, const int*, int, void*, size_t, hipStream_t);
 int samble_launch_attn_rows_rc_tri(const void*, const void*, const void*, const float*, const long long*, int, int, int,
                                    int, float, float*, float*, int, hipStream_t);
-int samble_launch_nn_prepare(const int*, int, int, int, int*, unsigned*, hipStream_t);
+int samble_launch_nn_prepare(const int*, int, int, int, int*, unsigned*, void*, size_t, hipStream_t);
 int samble_launch_attn_stats_tri(const void*, const void*, int, int, int, float, float*, int, float*, float*, const float*,
                                  const float*, hipStream_t);
 int samble_launch_attn_stats(const float*, long, long, const float*, long, long, int, int, int, float, float*, int,
@@ -285,9 +286,31 @@ SAMBLE_API int samble_bin_select_f32(const float* score, const float* z, const u
   if ((sample_mode == SAMBLE_SAMPLE_UNIFORM || sample_mode == SAMBLE_SAMPLE_RANDOM) && !noise)
     return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: uniform/random need the Exp(1) noise tensor");
   if (nb < 1 || nb > 8 || N > 16384) return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: need num_bins <= 8, N <= 16384");
-  return done(samble_launch_bin_select(score, z, member, counts, noise, B, N, nb, M, sample_mode, temp_mode, temp,
+  return done(samble_launch_bin_select(score, z, member, counts, noise, 0, 0, B, N, nb, M, sample_mode, temp_mode, temp,
                                        (long long*)idx_out, (hipStream_t)stream),
               "samble_bin_select_f32");
+}
+
+SAMBLE_API int samble_bin_select_seeded_f32(const float* score, const float* z, const uint8_t* member,
+                                            const int32_t* counts, uint64_t seed, uint64_t offset, int B, int N, int nb,
+                                            int M, int sample_mode, int temp_mode, float temp, int64_t* idx_out,
+                                            void* stream) {
+  if (!score || !z || !member || !counts || !idx_out)
+    return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: null pointer");
+  if (sample_mode < 0 || sample_mode > SAMBLE_SAMPLE_BOTTOM_RAW)
+    return fail(SAMBLE_E_INVALID, "Please check the setting of bin sample mode. It must be topk, uniform or random!");
+  if (offset & 3) return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: the Philox offset is a multiple of 4");
+  if (nb < 1 || nb > 8 || N > 16384)
+    return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: need num_bins <= 8, N <= 16384");
+  return done(samble_launch_bin_select(score, z, member, counts, nullptr, seed, offset, B, N, nb, M, sample_mode, temp_mode,
+                                       temp, (long long*)idx_out, (hipStream_t)stream),
+              "samble_bin_select_seeded_f32");
+}
+
+SAMBLE_API int samble_exp1_noise_f32(uint64_t seed, uint64_t offset, int rows, int N, float* noise, void* stream) {
+  if (!noise || rows <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_exp1_noise_f32: null pointer or empty shape");
+  if (offset & 3) return fail(SAMBLE_E_INVALID, "samble_exp1_noise_f32: the Philox offset is a multiple of 4");
+  return done(samble_launch_exp1_noise(seed, offset, (long)rows * N, noise, (hipStream_t)stream), "samble_exp1_noise_f32");
 }
 
 SAMBLE_API int samble_gather_rows_f32(const float* O, int64_t o_bs, int64_t o_rs, const int64_t* idx, int B, int M, int D,
@@ -394,6 +417,8 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
                            void* stream, int variant = 0, int l2 = 0, float* cs = nullptr,
                            const void* k_tr_image = nullptr, const void* v_rm_image = nullptr) {
   char msg[160];
+  const int dq_token_rows = (variant & SAMBLE_BWD_DQ_TOKEN_ROWS) ? 2 : 0;
+  variant &= ~SAMBLE_BWD_DQ_TOKEN_ROWS;
   if (!Q || !K || !V || (!O && !Oc) || !lse || !idx || !g || !dQ || !dK || !dV || !ws) {
     snprintf(msg, sizeof msg, "%s: null pointer", who);
     return fail(SAMBLE_E_INVALID, msg);
@@ -439,7 +464,8 @@ static int attn_bwd_common(const char* who, const float* Q, int64_t q_bs, int64_
   return done(samble_launch_attn_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, O, Oc, smap, ld, lse,
                                      (const long long*)idx, g, B, N, nt, M, inv_sqrt_d(D), Qs, dOb, lse_s, delta, tok_part,
                                      slab, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, l2, cs, cs_part,
-                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, variant, prep_clears, s),
+                                     k_tr_image, v_rm_image, tri ? (char*)ws + base_bytes : nullptr, variant,
+                                     (prep_clears ? 1 : 0) | dq_token_rows, s),
               who);
 }
 
@@ -588,16 +614,18 @@ SAMBLE_API size_t samble_nn_masks_bytes(int B, int N) {
 }
 
 SAMBLE_API int samble_nn_prepare(const int32_t* nn, int B, int N, int KN, int32_t* nn_sorted, uint32_t* masks,
-                                 void* stream) {
+                                 void* clear, size_t clear_bytes, void* stream) {
   if (!nn || !nn_sorted || !masks) return fail(SAMBLE_E_INVALID, "samble_nn_prepare: null pointer");
   if (B <= 0 || N <= 0 || (KN != 16 && KN != 32)) return fail(SAMBLE_E_INVALID, "samble_nn_prepare: need KN in {16, 32}");
-  return done(samble_launch_nn_prepare(nn, B, N, KN, nn_sorted, masks, (hipStream_t)stream), "samble_nn_prepare");
+  if (!clear) clear_bytes = 0;
+  return done(samble_launch_nn_prepare(nn, B, N, KN, nn_sorted, masks, clear, clear_bytes, (hipStream_t)stream),
+              "samble_nn_prepare");
 }
 
 SAMBLE_API int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_image, int B, int N, int nt, int D,
                                             const uint32_t* masks, int KN, float* nl, float* lse, float* tok,
                                             const int32_t* nn_sorted, int score_mode, void* score_ws,
-                                            size_t score_ws_bytes, void* stream) {
+                                            size_t score_ws_bytes, int score_ws_cleared, void* stream) {
   if (!q_image || !k_image || !masks || !lse || (nt > 0 && !tok) || (!nl && !score_ws))
     return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: null pointer");
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_attn_stats_nl_tri_f32: D must be 128");
@@ -614,8 +642,8 @@ SAMBLE_API int samble_attn_stats_nl_tri_f32(const void* q_image, const void* k_i
       return fail(SAMBLE_E_WORKSPACE, "samble_attn_stats_nl_tri_f32: score workspace too small");
   }
   return done(samble_launch_attn_stats_nl_tri(q_image, k_image, B, N, nt, inv_sqrt_d(D), masks, KN, nl, lse, tok,
-                                              score_ws ? nn_sorted : nullptr, score_mode, score_ws, score_ws_bytes,
-                                              (hipStream_t)stream),
+                                              score_ws ? nn_sorted : nullptr, score_mode, score_ws,
+                                              score_ws_cleared ? 0 : score_ws_bytes, (hipStream_t)stream),
               "samble_attn_stats_nl_tri_f32");
 }
 
@@ -719,7 +747,7 @@ SAMBLE_API int samble_proj_fwd_f32(const float* x, int64_t x_bs, int B, int C, i
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: bad B/N/nt");
   if ((o_rs & 3) || (o_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_f32: output strides must be multiples of 4");
   if (ws_bytes < 8 * 384 * sizeof(float)) return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_f32: workspace too small");
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr, 0, nullptr,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, nullptr, nullptr, qkv, o_bs, o_rs, (float*)ws, nullptr, nullptr, 0, nullptr,
                                      (hipStream_t)stream),
               "samble_proj_fwd_f32");
 }
@@ -740,17 +768,19 @@ SAMBLE_API int samble_proj_fwd_tri_f32(const float* x, int64_t x_bs, int B, int 
   if (ws_bytes < samble_proj_fwd_tri_workspace_bytes())
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_tri_f32: workspace too small");
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr, 0, nullptr,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, nullptr, nullptr, qkv, o_bs, o_rs, (float*)ws, wimg, nullptr, 0, nullptr,
                                      (hipStream_t)stream),
               "samble_proj_fwd_tri_f32");
 }
 
 SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const float* tokens, int nt,
-                                             const float* W, float* qkv, int64_t o_bs, int64_t o_rs, void* q_image,
+                                             const float* W, const float* Wk, const float* Wv, float* qkv, int64_t o_bs,
+                                             int64_t o_rs, void* q_image,
                                              void* k_image, void* v_tr_image, void* k_tr_image, void* v_rm_image, int rows,
                                              void* w_tr_image, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !W || !qkv || !ws || (nt > 0 && !tokens) || !q_image || !k_image || !v_tr_image || (!k_tr_image != !v_rm_image))
     return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: null pointer (the two backward images come as a pair)");
+  if (!Wk != !Wv) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: Wk and Wv come as a pair");
   if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: C = D must be 128");
   if (rows != SAMBLE_PROJ_ROWS_ALL && rows != SAMBLE_PROJ_ROWS_Q_ONLY)
     return fail(SAMBLE_E_INVALID, "samble_proj_fwd_split_tri_f32: rows is SAMBLE_PROJ_ROWS_ALL or SAMBLE_PROJ_ROWS_Q_ONLY");
@@ -761,7 +791,7 @@ SAMBLE_API int samble_proj_fwd_split_tri_f32(const float* x, int64_t x_bs, int B
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_fwd_split_tri_f32: workspace too small");
   char* wimg = (char*)ws + 8 * 384 * sizeof(float) + 256 - ((8 * 384 * sizeof(float)) & 255);
   void* const images[5] = {q_image, k_image, v_tr_image, k_tr_image, v_rm_image};
-  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, qkv, o_bs, o_rs, (float*)ws, wimg, images,
+  return done(samble_launch_proj_fwd(x, x_bs, B, N, tokens, nt, W, Wk, Wv, qkv, o_bs, o_rs, (float*)ws, wimg, images,
                                      rows == SAMBLE_PROJ_ROWS_Q_ONLY, w_tr_image, (hipStream_t)stream),
               "samble_proj_fwd_split_tri_f32");
 }
@@ -776,7 +806,7 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
   if ((g_rs & 3) || (g_bs & 3)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_f32: strides must be multiples of 4");
   if (ws_bytes < samble_proj_bwd_ws_floats(B, N) * sizeof(float))
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_f32: workspace too small");
-  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, nullptr,
+  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, nullptr, nullptr, dx, dx_bs, dW, dtokens, (float*)ws, nullptr,
                                      nullptr, (hipStream_t)stream),
               "samble_proj_bwd_f32");
 }
@@ -788,10 +818,12 @@ SAMBLE_API size_t samble_proj_bwd_tri_workspace_bytes(int B, int N) {
 }
 
 SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
-                                       int C, int N, const float* tokens, int nt, const float* W, const void* w_tr_image,
-                                       float* dx, int64_t dx_bs, float* dW, float* dtokens, void* ws, size_t ws_bytes,
-                                       void* stream) {
+                                       int C, int N, const float* tokens, int nt, const float* W, const float* Wk,
+                                       const float* Wv, const void* w_tr_image, float* dx, int64_t dx_bs, float* dW,
+                                       float* dtokens, void* ws, size_t ws_bytes, void* stream) {
   if (!dqkv || !x || !W || !ws) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: null pointer");
+  if (!Wk != !Wv || (Wk && !w_tr_image))
+    return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: Wk and Wv come as a pair, and only together with w_tr_image");
   if (C != 128) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: C = D must be 128");
   if (nt < 0 || nt > 8 || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: bad B/N/nt");
   if (dW && nt > 0 && (!dtokens || !tokens)) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: dtokens/tokens missing");
@@ -799,7 +831,7 @@ SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t 
   if (ws_bytes < samble_proj_bwd_tri_workspace_bytes(B, N))
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_tri_f32: workspace too small");
   char* wtr = (char*)ws + ((samble_proj_bwd_ws_floats(B, N) * sizeof(float) + 255) & ~(size_t)255);
-  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, dx, dx_bs, dW, dtokens, (float*)ws, wtr,
+  return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, Wk, Wv, dx, dx_bs, dW, dtokens, (float*)ws, wtr,
                                      w_tr_image, (hipStream_t)stream),
               "samble_proj_bwd_tri_f32");
 }

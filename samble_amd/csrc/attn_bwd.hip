@@ -494,7 +494,10 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
                                                                 int nt, float* __restrict__ dK, long dk_bs, long dk_rs,
                                                                 float* __restrict__ dV, long dv_bs, long dv_rs,
                                                                 const float* __restrict__ cs_part,
-                                                                float* __restrict__ cs) {
+                                                                float* __restrict__ cs, float* __restrict__ dq_tok,
+                                                                long dq_bs, long dq_rs) {
+  // dq_tok (optional) = dQ where it has nt rows behind its N point rows (the [Q|K|V] gradient block of the
+  // projection): token rows are keys only, their dQ is zero
   const int b = blockIdx.y, which = blockIdx.x >> 3, t = blockIdx.x & 7, d = threadIdx.x;
   if (blockIdx.x == 16) {  // l2 scoring: column sums of dS for the token keys -> cs[b][N + t]
     if (cs && d < nt) {
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(128) void bwd_tokens_reduce_kernel(const float* __r
     return;
   }
   if (t >= nt) return;
+  if (dq_tok && which == 0) dq_tok[(long)b * dq_bs + (long)(N + t) * dq_rs + d] = 0.f;
   const float* src = tok_part + (long)b * nparts * 2 * 8 * 128 + (which * 8 + t) * 128 + d;
   float sacc = 0.f;
   int p = 0;
@@ -905,7 +909,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
                                       long dq_rs, float* dK, long dk_bs, long dk_rs, float* dV, long dv_bs, long dv_rs,
                                       int l2, float* cs, float* cs_part, const void* k_tr_image, const void* v_rm_image,
                                       void* img_ws, int variant, int zero_dq, hipStream_t stream) {
-  // zero_dq: the caller left clearing dQ's N rows to bwd_prep_tri (samble_attn_bwd_prep_clears_dq says when it may)
+  // zero_dq bit 0: the caller left clearing dQ's N rows to bwd_prep_tri (samble_attn_bwd_prep_clears_dq says when it may);
+  // bit 1: dQ has nt token rows behind the N point rows, cleared by bwd_tokens_reduce
   // variant (include/samble.h): single-pass path: 1 = the two-kernel backward (bwd_dq + bwd_dkdv, 7 products)
   // instead of the fused one (5); split-bf16 map path: 1 = fused dP / dV / dK kernel instead of the dS map,
   // 2 = smap is the P map (B, M, ld) of the sampled rows (attn_rows_rc_tri) instead of the logit map; 2 + 4 = the same
@@ -951,7 +956,7 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_tri_kernel<true> : bwd_prep_tri_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q,
                        q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, Oc, lse, idx, g, N, nt, M, scale, lse_s, delta, tok_part,
-                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr, zero_dq ? dQ : nullptr, dq_bs, dq_rs, ds_amax);
+                       l2 ? cs_part : nullptr, dO_rm, dO_tr, Q_tr, (zero_dq & 1) ? dQ : nullptr, dq_bs, dq_rs, ds_amax);
   } else {
     Timed timed(kT_bwd_prep, stream);
     hipLaunchKernelGGL(l2 ? bwd_prep_kernel<true> : bwd_prep_kernel<false>, dim3(nparts, B), dim3(256), 0, stream, Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs,
@@ -986,7 +991,8 @@ extern "C" int samble_launch_attn_bwd(const float* Q, long q_bs, long q_rs, cons
   (void)tok_slab;
   if (nt > 0)
     hipLaunchKernelGGL(bwd_tokens_reduce_kernel, dim3(l2 ? 17 : 16, B), dim3(128), 0, stream, tok_part, nparts, N, nt, dK,
-                       dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs_part : nullptr, l2 ? cs : nullptr);
+                       dk_bs, dk_rs, dV, dv_bs, dv_rs, l2 ? cs_part : nullptr, l2 ? cs : nullptr, (zero_dq & 2) ? dQ : nullptr,
+                       dq_bs, dq_rs);
   return (int)hipGetLastError();
 }
 

@@ -1067,7 +1067,8 @@ extern "C" __attribute__((visibility("default"))) int samble_scratch_rc_stamps(u
 
 // pass 1 without the map: lse, token logits and the K neighbour logits per row (nl (B, N, KN), ascending-index order)
 // nn_sorted / acc_ws non-null: also accumulate the sparse_* score statistics of `score_mode` (score.hip's modes)
-// into acc_ws = [colacc B*N u64][indeg B*N i32][rowstat B*N f32], after zeroing zero_bytes of it
+// into acc_ws = [colacc B*N u64][indeg B*N i32][rowstat B*N f32], after zeroing zero_bytes of it (0: the caller
+// cleared it, samble_launch_nn_prepare does on request)
 extern "C" int samble_launch_attn_stats_nl_tri(const void* qimg, const void* kimg, int B, int N, int nt, float scale,
                                                const unsigned* masks, int KN, float* nl, float* lse, float* tok,
                                                const int* nn_sorted, int score_mode, void* acc_ws, size_t zero_bytes,
@@ -1080,8 +1081,10 @@ extern "C" int samble_launch_attn_stats_nl_tri(const void* qimg, const void* kim
   NlScoreArgs sc{nullptr, nullptr, nullptr, nullptr, 0};
   if (nn_sorted && acc_ws) {
     if (score_mode < 0 || score_mode > 4 || (size_t)N * 12 > (size_t)kStatsDepth * kTriTile) return (int)hipErrorInvalidValue;
-    e = hipMemsetAsync(acc_ws, 0, zero_bytes, stream);
-    if (e != hipSuccess) return (int)e;
+    if (zero_bytes) {
+      e = hipMemsetAsync(acc_ws, 0, zero_bytes, stream);
+      if (e != hipSuccess) return (int)e;
+    }
     unsigned long long* colacc = reinterpret_cast<unsigned long long*>(acc_ws);
     int* indeg = reinterpret_cast<int*>(colacc + (size_t)B * N);
     float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);

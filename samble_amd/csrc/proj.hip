@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
 // token rows, one workgroup per token t: gsum[t][o] = sum_b dqkv[b][N+t][o] (fixed order), then
 // dtokens[c][t] = sum_o W[o][c] gsum[t][o] (thread = channel, W read coalesced)
 __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs, int B,
-                                                           int N, int nt, const float* __restrict__ W,
+                                                           int N, int nt, const ProjW W,
                                                            float* __restrict__ gsum, float* __restrict__ dtok) {
   __shared__ float gs[kO];
   __shared__ float ps[3][kC];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
   for (int o0 = 128 * part; o0 < 128 * part + 128; o0 += 16) {
     float wv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) wv[u] = W[(long)(o0 + u) * kC + c];
+    for (int u = 0; u < 16; ++u) wv[u] = W.row(o0 + u)[c];
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc = fmaf(wv[u], gs[o0 + u], acc);
   }
@@ -346,21 +346,24 @@ __global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restri
 
 using namespace samble;
 
-extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, void*, void*,
+extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, const float*,
+                                          const float*, void*, void*,
                                           float*, long, long, void*, void*, void*, void*, void*, int, hipStream_t);
 extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, int, float*, long, hipStream_t);
 extern "C" int samble_launch_proj_dw_tri(const float*, long, long, const float*, long, int, int, float*, hipStream_t);
 
 // wimg != null: room for the row image of W -> the split-bf16 kernel (proj_tri.hip)
 extern "C" int samble_launch_proj_fwd(const float* x, long x_bs, int B, int N, const float* tokens, int nt,
-                                      const float* W, float* qkv, long o_bs, long o_rs, float* ws, void* wimg,
-                                      void* const* images, int q_only, void* wtr_out, hipStream_t s) {
+                                      const float* W, const float* Wk, const float* Wv, float* qkv, long o_bs, long o_rs,
+                                      float* ws, void* wimg, void* const* images, int q_only, void* wtr_out, hipStream_t s) {
+  // Wk / Wv non-null (split-bf16 path only): W = Wq and the three 128 x 128 weights are tensors of their own
   const size_t lds = kProjLdsFloats * sizeof(float);
   float* tokqkv = ws;  // 8 x 384 floats
   if (wimg)  // images: {q_rm, k_rm, v_tr, k_tr | null, v_rm | null} or null; the token rows come with the W image
-    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokens, tokqkv, nt, W, wimg, wtr_out, qkv, o_bs, o_rs, images ? images[0] : nullptr,
+    return samble_launch_proj_fwd_tri(x, x_bs, B, N, tokens, tokqkv, nt, W, Wk, Wv, wimg, wtr_out, qkv, o_bs, o_rs, images ? images[0] : nullptr,
                                       images ? images[1] : nullptr, images ? images[2] : nullptr,
                                       images ? images[3] : nullptr, images ? images[4] : nullptr, images ? q_only : 0, s);
+  if (Wk) return (int)hipErrorInvalidValue;
   if (nt > 0) hipLaunchKernelGGL(proj_tok_fwd_kernel, dim3(kO / 4), dim3(256), 0, s, tokens, nt, W, tokqkv);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_fwd_kernel),
@@ -379,8 +382,11 @@ extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
 }
 
 extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
-                                      const float* tokens, int nt, const float* W, float* dx, long dx_bs, float* dW,
-                                      float* dtok, float* ws, void* wtr, const void* wtr_ready, hipStream_t s) {
+                                      const float* tokens, int nt, const float* W, const float* Wk, const float* Wv,
+                                      float* dx, long dx_bs, float* dW, float* dtok, float* ws, void* wtr,
+                                      const void* wtr_ready, hipStream_t s) {
+  // Wk / Wv non-null: W = Wq, three tensors -- only with wtr_ready (nothing else reads W as one block then)
+  if (Wk && !(wtr && wtr_ready)) return (int)hipErrorInvalidValue;
   // wtr_ready: the transposed image of W as the forward's prologue wrote it (then wtr is not used)
   const size_t lds_dx = kDxLdsFloats * sizeof(float), lds_dw = kDwLdsFloats * sizeof(float);
   {
@@ -411,7 +417,8 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
       hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     }
     if (nt > 0)
-      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt, W, gsum, dtok);
+      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt,
+                         proj_w(W, Wk, Wv), gsum, dtok);
     hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO * kC / 64), dim3(256), 0, s, part, B * chunks, gsum, tokens, nt,
                        dW);
   }

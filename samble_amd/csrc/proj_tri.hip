@@ -41,7 +41,7 @@ constexpr int kPXt = 36;  // row stride (floats) of a wave's 32 x 32 transpose t
 // below the cost of a launch): workgroups 0..11 write the row image of W (tile = 32 output rows; tri_split_kernel's
 // bytes), workgroups 12.. the token rows tokqkv[t][o] = sum_c W[o][c] tokens[c][t] (proj_tok_fwd_kernel's arithmetic:
 // one wave per output row, lanes across the channels, independent shuffle trees for the 8 token sums).
-__global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restrict__ W, const float* __restrict__ tokens,
+__global__ __launch_bounds__(256) void proj_prologue_kernel(const ProjW W, const float* __restrict__ tokens,
                                                             int nt, char* __restrict__ wimg, char* __restrict__ wtr,
                                                             float* __restrict__ tokqkv) {
   const int tid = threadIdx.x;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restr
         const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
         float x[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = W[(long)(blockIdx.x * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3)) * 128 + d];
+        for (int i = 0; i < 8; ++i) x[i] = W.row(blockIdx.x * 32 + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3))[d];
         const Tri t = tri_split8(x);
         *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = t.h;
         *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = t.m;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restr
     char* img = wimg + (long)blockIdx.x * kTriTile;
     for (int e = tid; e < 512; e += 256) {
       const int r = e & 31, g = e >> 5, row = blockIdx.x * 32 + r;
-      const f32x4* p = reinterpret_cast<const f32x4*>(W + (long)row * 128 + 8 * g);
+      const f32x4* p = reinterpret_cast<const f32x4*>(W.row(row) + 8 * g);
       const f32x4 a = p[0], bb = p[1];
       const float x[8] = {a[0], a[1], a[2], a[3], bb[0], bb[1], bb[2], bb[3]};
       const Tri t = tri_split8(x);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void proj_prologue_kernel(const float* __restr
   if (nt <= 0) return;
   const int lane = tid & 63;
   const int o = (blockIdx.x - kPTiles) * 4 + (tid >> 6);
-  const float w0 = W[(long)o * 128 + lane], w1 = W[(long)o * 128 + lane + 64];
+  const float w0 = W.row(o)[lane], w1 = W.row(o)[lane + 64];
   float p[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
@@ -563,7 +563,8 @@ extern "C" int samble_launch_k_to_duo(void* kimg, int B, int rows, int tile0, hi
 // images (q_rm non-null): the five operand images of (B, N + nt, 384) = [Q | K | V] are written as well -- the full
 // 32-point tiles by the projection kernel, the rest (token rows, ragged end) by a tri_split_qkv launch over those tiles
 extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int N, const float* tokens, float* tokqkv,
-                                          int nt, const float* W, void* wimg, void* wtr_out, float* qkv, long o_bs, long o_rs, void* q_rm,
+                                          int nt, const float* W, const float* Wk, const float* Wv, void* wimg,
+                                          void* wtr_out, float* qkv, long o_bs, long o_rs, void* q_rm,
                                           void* k_rm, void* v_tr, void* k_tr, void* v_rm, int q_only, hipStream_t s) {
   const int lds_img = kProjTriLds + 8 * 32 * kPXt * 4;
   {
@@ -578,8 +579,8 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
     if (e != hipSuccess) return (int)e;
   }
   int rc = 0;
-  hipLaunchKernelGGL(proj_prologue_kernel, dim3(kPTiles + kPO / 4), dim3(256), 0, s, W, tokens, nt, (char*)wimg,
-                     (char*)wtr_out, tokqkv);
+  hipLaunchKernelGGL(proj_prologue_kernel, dim3(kPTiles + kPO / 4), dim3(256), 0, s, proj_w(W, Wk, Wv), tokens, nt,
+                     (char*)wimg, (char*)wtr_out, tokqkv);
   const ProjImages im{(char*)q_rm, (char*)k_rm, (char*)v_tr, (char*)k_tr, (char*)v_rm, (N + nt + 31) / 32, q_only};
   {
     Timed timed(kT_proj_fwd, s);

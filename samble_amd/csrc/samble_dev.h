@@ -32,6 +32,17 @@ enum TimedKernel {
   kT_edge_fwd = 24, kT_edge_bwd = 25, kT_n2p_fwd = 26, kT_n2p_bwd = 27, kT_inv_nn = 28, kT_seg_sum = 29,
   kT_edge_sums = 30, kT_knn_small = 31,
 };
+// the three 128 x 128 projection weights [Wq; Wk; Wv] where they live (one (384, 128) block, or three tensors)
+struct ProjW {
+  const float* q;
+  const float* k;
+  const float* v;
+  __host__ __device__ const float* row(int o) const { return (o < 128 ? q : o < 256 ? k : v) + (long)(o & 127) * 128; }
+};
+inline ProjW proj_w(const float* W, const float* Wk, const float* Wv) {
+  return Wk ? ProjW{W, Wk, Wv} : ProjW{W, W + 128 * 128, W + 2 * 128 * 128};
+}
+
 struct Timed {  // brackets the launches made during its lifetime
   int id;
   hipStream_t s;

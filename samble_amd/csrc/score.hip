@@ -363,8 +363,14 @@ namespace samble {
 constexpr int kNnpQ = 64, kNnpThreads = 4 * kNnpQ;
 template <int KN>
 __global__ __launch_bounds__(kNnpThreads) void nn_prepare_kernel(const int* __restrict__ nn, int N, int T,
-                                                                 int* __restrict__ nn_sorted, unsigned* __restrict__ masks) {
+                                                                 int* __restrict__ nn_sorted, unsigned* __restrict__ masks,
+                                                                 f32x4* __restrict__ clear, long clear_quads) {
   constexpr int PER = KN / 4;
+  if (clear) {  // the statistics pass that follows accumulates into a zeroed workspace: cleared here, not by a launch
+    const long total = (long)gridDim.x * gridDim.y * kNnpThreads;
+    for (long e = ((long)blockIdx.y * gridDim.x + blockIdx.x) * kNnpThreads + threadIdx.x; e < clear_quads; e += total)
+      clear[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   __shared__ int vals[kNnpQ][KN + 1];     // the lists as loaded, then in ascending order
   __shared__ unsigned words[64][kNnpQ];   // 64 mask tiles x the 64 queries
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -435,14 +441,23 @@ __global__ __launch_bounds__(kNnpThreads) void nn_prepare_kernel(const int* __re
 }  // namespace samble
 
 extern "C" int samble_launch_nn_prepare(const int* nn, int B, int N, int KN, int* nn_sorted, unsigned* masks,
-                                        hipStream_t stream) {
+                                        void* clear, size_t clear_bytes, hipStream_t stream) {
   const int T = (N + 31) / 32;
   if ((reinterpret_cast<size_t>(nn) | reinterpret_cast<size_t>(nn_sorted)) & 15) return -22;  // 16-byte row pieces
+  if (KN != 32 && KN != 16) return -22;
+  if (clear && ((reinterpret_cast<size_t>(clear) | clear_bytes) & 15)) {  // odd piece: a memset of its own
+    hipError_t e = hipMemsetAsync(clear, 0, clear_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    clear = nullptr;
+  }
+  f32x4* cl = clear_bytes ? reinterpret_cast<f32x4*>(clear) : nullptr;
+  const long quads = (long)(clear_bytes / 16);
   const dim3 grid((N + kNnpQ - 1) / kNnpQ, B);
   Timed timed(kT_nn_prepare, stream);
-  if (KN == 32) hipLaunchKernelGGL(nn_prepare_kernel<32>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks);
-  else if (KN == 16) hipLaunchKernelGGL(nn_prepare_kernel<16>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks);
-  else return -22;
+  if (KN == 32)
+    hipLaunchKernelGGL(nn_prepare_kernel<32>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks, cl, quads);
+  else
+    hipLaunchKernelGGL(nn_prepare_kernel<16>, grid, dim3(kNnpThreads), 0, stream, nn, N, T, nn_sorted, masks, cl, quads);
   return (int)hipGetLastError();
 }
 

@@ -266,14 +266,47 @@ __device__ unsigned long long g_select_stamps[16];
 #define STAMP(i) do { } while (0)
 #endif
 enum SampleMode { kTopk = 0, kUniform = 1, kRandom = 2, kTopRaw = 3, kBottomRaw = 4 };
+
+// Exp(1) draw of element `elem` under a (seed, offset) Philox state: Philox4x32-10 with the counter laid out as
+// curand / torch lay it out (offset in 128-bit blocks in the low words, the element as the subsequence in the high
+// ones), first output word, 23 random bits into the open interval (0, 1), -log.  What torch.multinomial draws inside
+// (an Exp(1) tensor the size of its input) without the tensor: models/downsample.py:346-362 via utils/ops.py:516-597.
+struct PhiloxState {
+  unsigned long long seed, offset;  // offset in 32-bit outputs (a multiple of 4), as torch's generator counts it
+};
+__device__ inline float exp1_draw(PhiloxState st, unsigned long long elem) {
+  const unsigned long long blk = st.offset >> 2;
+  unsigned c0 = (unsigned)blk, c1 = (unsigned)(blk >> 32), c2 = (unsigned)elem, c3 = (unsigned)(elem >> 32);
+  unsigned k0 = (unsigned)st.seed, k1 = (unsigned)(st.seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1;
+    c3 = (unsigned)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u = ((float)(c0 >> 9) + 0.5f) * 1.1920928955078125e-07f;  // (0, 1): 2^-23 (i + 1/2)
+  return -logf(u);
+}
+
+// the (rows, N) Exp(1) matrix a seeded bin_select draws from, written out (tests: the seeded select against the
+// select on this tensor, and the distribution itself)
+__global__ __launch_bounds__(256) void exp1_noise_kernel(PhiloxState st, long n, float* __restrict__ out) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) out[e] = exp1_draw(st, (unsigned long long)e);
+}
 enum TempMode { kTempFixed = 0, kTempCount = 1 };  // count: inv_T = members / temp_div
 
 // dynamic LDS: NP composites (u64) ; grid (nb, B), 1024 threads
 __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restrict__ score, const float* __restrict__ z,
                                                           const unsigned char* __restrict__ member,
                                                           const int* __restrict__ counts,
-                                                          const float* __restrict__ noise, int N, int NP, int nb,
-                                                          int M, int mode, int temp_mode, float temp,
+                                                          const float* __restrict__ noise, PhiloxState philox, int N,
+                                                          int NP, int nb, int M, int mode, int temp_mode, float temp,
                                                           long long* __restrict__ idx_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long comp[];
   __shared__ double red[1024];
@@ -314,7 +347,9 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
       __syncthreads();
     }
   }
-  const float* nz = noise ? noise + ((long)b * nb + t) * N : nullptr;
+  // the Exp(1) draw of (bin row b nb + t, point n): the caller's tensor, or drawn here
+  const long nrow = ((long)b * nb + t) * N;
+  auto nzv = [&](int n) { return noise ? noise[nrow + n] : exp1_draw(philox, (unsigned long long)(nrow + n)); };
   STAMP(1);
   int off = 0;
   for (int u = 0; u < t; ++u) off += counts[b * nb + u];
@@ -329,11 +364,11 @@ __global__ __launch_bounds__(1024) void bin_select_kernel(const float* __restric
     } else if (mode == kTopk) {
       key = score[(long)b * N + n] + 1e-8f;
     } else if (mode == kUniform) {
-      key = 1.f / nz[n];
+      key = 1.f / nzv(n);
     } else {
       float p = expf(tanhf(z[(long)b * N + n]) * inv_t) / psum;
       if (p != p) p = 1e-8f;
-      key = p / nz[n];
+      key = p / nzv(n);
     }
     return ((unsigned long long)(~ordered_bits(key)) << 32) | (unsigned int)n;
   };
@@ -619,10 +654,11 @@ extern "C" int samble_launch_alloc_counts(const float* w, const int* cap, int B,
 }
 
 extern "C" int samble_launch_bin_select(const float* score, const float* z, const unsigned char* member,
-                                        const int* counts, const float* noise, int B, int N, int nb, int M, int mode,
+                                        const int* counts, const float* noise, unsigned long long seed,
+                                        unsigned long long offset, int B, int N, int nb, int M, int mode,
                                         int temp_mode, float temp, long long* idx_out, hipStream_t s) {
+  // noise null (uniform / random): the kernel draws Exp(1) itself under the Philox state (seed, offset)
   if (mode < 0 || mode > kBottomRaw) return -22;
-  if ((mode == kUniform || mode == kRandom) && noise == nullptr) return -22;
   int NP = 1;
   while (NP < N) NP <<= 1;
   const size_t lds = (size_t)(NP + 2) * 8;  // + the pad word of the rank-by-counting path
@@ -633,8 +669,15 @@ extern "C" int samble_launch_bin_select(const float* score, const float* z, cons
     if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_bin_select, s);
-  hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise, N, NP, nb, M,
-                     mode, temp_mode, temp, idx_out);
+  hipLaunchKernelGGL(bin_select_kernel, dim3(nb, B), dim3(1024), lds, s, score, z, member, counts, noise,
+                     PhiloxState{seed, offset}, N, NP, nb, M, mode, temp_mode, temp, idx_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_exp1_noise(unsigned long long seed, unsigned long long offset, long n, float* out,
+                                        hipStream_t s) {
+  hipLaunchKernelGGL(exp1_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, PhiloxState{seed, offset}, n,
+                     out);
   return (int)hipGetLastError();
 }
 

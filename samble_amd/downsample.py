@@ -43,15 +43,17 @@ class _Projection(torch.autograd.Function):
         tensors), written by the projection kernel itself instead of a split pass over the fp32 rows.
         q_only: the caller reads K and V from the images only (the map-free sampler): the kernel then leaves the K / V
         columns of qkv's point rows unwritten (ops.stage_proj_fwd)."""
-        w = torch.cat((wq, wk, wv), dim=0).squeeze(-1)  # (3C, C)
         tok = tokens[0]                                  # (C, nt)
-        ctx.save_for_backward(x, tok, w)
         ctx.splits = (wq.shape[0], wk.shape[0], wv.shape[0])
+        # the kernels read the three weights where the Conv1d modules hold them (no concatenation launch); the
+        # backward reads them again for the token rows only, and dx from the transposed image saved beside them
+        w3 = (wq.squeeze(-1), wk.squeeze(-1), wv.squeeze(-1))
+        ctx.save_for_backward(x, tok, *w3)
         if not images:
-            return ops.stage_proj_fwd(x, tok, w)
-        qkv, imgs = ops.stage_proj_fwd(x, tok, w, images=images, q_only=q_only)
+            return ops.stage_proj_fwd(x, tok, w3)
+        qkv, imgs = ops.stage_proj_fwd(x, tok, w3, images=images, q_only=q_only)
         if len(imgs) == 6:  # the transposed image of W stays with this node: its own backward reads it
-            ctx.save_for_backward(x, tok, w, imgs[5])
+            ctx.save_for_backward(x, tok, *w3, imgs[5])
             imgs = imgs[:5]
         ctx.mark_non_differentiable(*imgs)
         ctx.set_materialize_grads(False)  # (else autograd zero-fills a 50 MB "gradient" per image on the way back)
@@ -62,8 +64,9 @@ class _Projection(torch.autograd.Function):
     def backward(ctx, dqkv, *_):
         if dqkv is None:
             return None, None, None, None, None, None, None
-        x, tok, w = ctx.saved_tensors[:3]
-        w_tr = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        x, tok = ctx.saved_tensors[:2]
+        w = tuple(ctx.saved_tensors[2:5])
+        w_tr = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:])
         dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw, w_tr=w_tr)
@@ -144,13 +147,14 @@ class _SamplerCore(torch.autograd.Function):
                     raise ops._lib.SambleError("the projection's images lack the backward pair although a gradient is wanted")
                 else:
                     imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
-                nn_sorted, masks = ops.stage_nn_prepare(nn_idx)
                 chain = ops.chain_supported(B, N, nb)
                 # the pass also accumulates the score statistics of the K neighbour entries of every row
                 fused = N <= 8192   # LDS accumulators of the pass; longer clouds take the neighbour-logit array
+                sws = ops.score_workspace(B, N, nb if chain else None, x.device) if fused else None
+                nn_sorted, masks = ops.stage_nn_prepare(nn_idx, clear=sws)  # (zeroes the score workspace on its way)
                 nl, lse, tok, sws = ops.stage_attn_stats_nl(
                     imgs[0], imgs[1], masks, B, N, nt, mod.K, D, want_nl=not fused,
-                    score=(nn_sorted, mod.idx_mode, nb if chain else None) if fused else None)
+                    score=(nn_sorted, mod.idx_mode, nb if chain else None) if fused else None, cleared_ws=sws)
                 del masks
                 if chain:
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
@@ -229,15 +233,16 @@ class _SamplerCore(torch.autograd.Function):
         v = qkv[:, :, 2 * D:3 * D]
         if g_xds is not None:
             dqkv = torch.empty_like(qkv)
+            tok_by_kernel = smap is not None and ops.MATRIX_MODE == "tri"  # (that backward clears dQ's token rows)
             if smap is not None:  # O is x_ds (B,D,M) here
                 ops.stage_attn_rows_bwd(q, k, v, smap, lse, O, idx, g_xds, N, nt, dqkv[:, :N, 0:D],
                                         dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:3 * D], ctx.asm,
                                         images=images,
-                                        variant=ops.ROWS_BWD_PMAP if ctx.pmap else 0)
+                                        variant=ops.ROWS_BWD_PMAP if ctx.pmap else 0, dq_token_rows=tok_by_kernel)
             else:
                 ops.stage_attn_bwd(q, k, v, O, lse, idx, g_xds, N, nt, dqkv[:, :N, 0:D], dqkv[:, :, D:2 * D],
                                    dqkv[:, :, 2 * D:3 * D])
-            if nt:
+            if nt and not tok_by_kernel:
                 dqkv[:, N:, 0:D].zero_()
         else:
             dqkv = torch.zeros_like(qkv)

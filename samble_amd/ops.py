@@ -69,14 +69,30 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     return (idx, dist) if want_dist else idx
 
 
-def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, images: str = "", q_only: bool = False):
+def _three_weights(w_qkv):
+    """w_qkv as (Wq, Wk, Wv) tensors of their own -> three contiguous fp32 (C,C) matrices; a single tensor -> None."""
+    if not isinstance(w_qkv, (tuple, list)):
+        return None
+    ws = tuple(_f32c(w.reshape(w.shape[0], w.shape[1])) for w in w_qkv)
+    if len(ws) != 3 or any(w.shape != ws[0].shape or w.shape[0] != w.shape[1] for w in ws):
+        raise ValueError("three weights: (Wq, Wk, Wv), each (C, C)")
+    return ws
+
+
+def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv, images: str = "", q_only: bool = False):
     """x (B,C,N), tokens (C,nt), w_qkv (3C,C) -> qkv (B,N+nt,3C) point-major rows [Q|K|V].
+    w_qkv may be the tuple (Wq, Wk, Wv) of (C,C) tensors: with images the kernels read the three where they are (no
+    concatenation launch); without images they are concatenated here.
     images "fwd" / "fwd+bwd" (MATRIX_MODE "tri"): -> (qkv, operand images as stage_tri_split_qkv returns them), written by
     the projection kernel itself (the split pass then covers only the tiles with token rows / a ragged end).
     q_only (with images): the K / V columns of qkv's point rows stay unwritten where the images carry the tile
     (include/samble.h SAMBLE_PROJ_ROWS_Q_ONLY) -- for callers that read the Q rows, the token rows and the images only."""
-    _need_gpu(x, tokens, w_qkv)
-    x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
+    w3 = _three_weights(w_qkv)
+    if w3 is not None and not images:
+        w_qkv, w3 = torch.cat(w3, dim=0), None
+    _need_gpu(x, tokens, *(w3 or (w_qkv,)))
+    x, tokens = _f32c(x), _f32c(tokens)
+    w_qkv = None if w3 else _f32c(w_qkv)
     B, C, N = x.shape
     nt = tokens.shape[1]
     if images:
@@ -93,7 +109,8 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, i
                 if images == "fwd+bwd" else None
             nbytes = _lib.query("samble_proj_fwd_tri_workspace_bytes")
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            _lib.call("samble_proj_fwd_split_tri_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, w_qkv.data_ptr(),
+            wp = [w.data_ptr() for w in w3] if w3 else [w_qkv.data_ptr(), None, None]
+            _lib.call("samble_proj_fwd_split_tri_f32", x.data_ptr(), C * N, B, C, N, tokens.data_ptr(), nt, *wp,
                       qkv.data_ptr(), qkv.stride(0), qkv.stride(1), q_img.data_ptr(), k_img.data_ptr(), v_img.data_ptr(),
                       _p(k_tr), _p(v_rm), 1 if q_only else 0, _p(w_tr), ws.data_ptr(), nbytes, _stream())
         return qkv, ((q_img, k_img, v_img, k_tr, v_rm, w_tr) if images == "fwd+bwd" else (q_img, k_img, v_img))
@@ -110,24 +127,29 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv: torch.Tensor, i
 
 def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool, w_tr: Optional[torch.Tensor] = None):
     """-> (dx (B,C,N) | None, dW (3C,C) | None, dtokens (C,nt) | None).  w_tr: the transposed operand image of w_qkv as
-    stage_proj_fwd(images="fwd+bwd") returned it (MATRIX_MODE "tri"; the weights must not have changed since)."""
-    _need_gpu(dqkv, x, tokens, w_qkv)
-    x, tokens, w_qkv = _f32c(x), _f32c(tokens), _f32c(w_qkv)
+    stage_proj_fwd(images="fwd+bwd") returned it (MATRIX_MODE "tri"; the weights must not have changed since).
+    w_qkv may be the tuple (Wq, Wk, Wv): read where they are when w_tr comes along, concatenated here otherwise."""
+    w3 = _three_weights(w_qkv)
+    if w3 is not None and (w_tr is None or MATRIX_MODE != "tri"):
+        w_qkv, w3 = torch.cat(w3, dim=0), None
+    _need_gpu(dqkv, x, tokens, *(w3 or (w_qkv,)))
+    x, tokens = _f32c(x), _f32c(tokens)
+    w_qkv = None if w3 else _f32c(w_qkv)
     if dqkv.stride(2) != 1:
         dqkv = dqkv.contiguous()
     B, C, N = x.shape
     nt = tokens.shape[1]
     with torch.cuda.device(x.device):
         dx = torch.empty_like(x) if need_dx else None
-        dw = torch.empty_like(w_qkv) if need_dw else None
+        dw = torch.empty((3 * C, C), dtype=torch.float32, device=x.device) if need_dw else None
         dtok = torch.empty_like(tokens) if need_dw else None
         tri = MATRIX_MODE == "tri"
         nbytes = _lib.query("samble_proj_bwd_tri_workspace_bytes" if tri else "samble_proj_workspace_bytes", B, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         if tri:
             _lib.call("samble_proj_bwd_tri_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
-                      tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(w_tr), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(),
-                      nbytes, _stream())
+                      tokens.data_ptr(), nt, *([w.data_ptr() for w in w3] if w3 else [w_qkv.data_ptr(), None, None]),
+                      _p(w_tr), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes, _stream())
         else:
             _lib.call("samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
                       tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
@@ -339,8 +361,29 @@ def boltzmann_temperature(boltzmann_t, n_points: int, num_bins: int) -> Tuple[in
     raise NotImplementedError
 
 
-def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzmann_t, noise=None):
-    """-> idx (B,M) int64: bins ascending, inside a bin by descending key."""
+def philox_state(device, advance: bool = True):
+    """(seed, offset) of the device's default torch generator, the offset advanced by one Philox block (4 outputs):
+    what the kernels that draw their own random numbers are keyed with (torch.manual_seed reproduces them)."""
+    gen = torch.cuda.default_generators[torch.device(device).index if torch.device(device).index is not None
+                                        else torch.cuda.current_device()]
+    seed, offset = gen.initial_seed(), gen.get_offset()
+    if advance:
+        gen.set_offset(offset + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, offset
+
+
+def stage_exp1_noise(seed: int, offset: int, rows: int, n_points: int, device) -> torch.Tensor:
+    """The (rows, n_points) Exp(1) tensor stage_bin_select draws from under philox=(seed, offset), written out."""
+    with torch.cuda.device(device):
+        out = torch.empty((rows, n_points), dtype=torch.float32, device=device)
+        _lib.call("samble_exp1_noise_f32", seed, offset, rows, n_points, out.data_ptr(), _stream())
+    return out
+
+
+def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzmann_t, noise=None, philox=None):
+    """-> idx (B,M) int64: bins ascending, inside a bin by descending key.
+    uniform / random: `noise` (B*num_bins, N) is the Exp(1) draw torch.multinomial makes inside; None: the kernel draws
+    it itself under philox = (seed, offset) (default: the state of torch's device generator, advanced)."""
     if sample_mode not in SAMPLE_MODES:
         raise ValueError("Please check the setting of bin sample mode. It must be topk, multinomial or random!")
     _need_gpu(score, z, member, counts, noise)
@@ -351,7 +394,13 @@ def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzma
         temp_mode, temp = boltzmann_temperature(boltzmann_t, N, nb)
     if sample_mode in ("uniform", "random"):
         if noise is None:
-            noise = torch.empty((B * nb, N), dtype=torch.float32, device=score.device).exponential_(1)
+            seed, offset = philox if philox is not None else philox_state(score.device)
+            with torch.cuda.device(score.device):
+                idx = torch.empty((B, M), dtype=torch.int64, device=score.device)
+                _lib.call("samble_bin_select_seeded_f32", score.data_ptr(), z.data_ptr(), member.data_ptr(),
+                          counts.data_ptr(), seed, offset, B, N, nb, M, SAMPLE_MODES[sample_mode], temp_mode, float(temp),
+                          idx.data_ptr(), _stream())
+            return idx
         noise = _f32c(noise)
         if noise.shape != (B * nb, N):
             raise ValueError(f"noise must be (B*num_bins, N) = {(B * nb, N)}, got {tuple(noise.shape)}")
@@ -524,29 +573,42 @@ def stage_attn_rows(smap: torch.Tensor, lse: torch.Tensor, v: torch.Tensor, idx:
 
 
 ROWS_BWD_FUSED_DKDV, ROWS_BWD_PMAP = 1, 2   # include/samble.h: variants of samble_attn_rows_bwd_tri_f32
+BWD_DQ_TOKEN_ROWS = 8                       # SAMBLE_BWD_DQ_TOKEN_ROWS
 
 
-def stage_nn_prepare(nn_idx: torch.Tensor):
+def score_workspace(B: int, n_points: int, num_bins, device):
+    """The (uninitialised) workspace stage_attn_stats_nl(score=...) accumulates into: hand it to stage_nn_prepare(clear=)
+    and on to stage_attn_stats_nl(cleared_ws=) so that no memset launch sits between the two."""
+    nbytes = _lib.query("samble_select_chain_workspace_bytes", B, n_points) if num_bins else \
+        _lib.query("samble_score_workspace_bytes", B, n_points)
+    with torch.cuda.device(device):
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def stage_nn_prepare(nn_idx: torch.Tensor, clear: Optional[torch.Tensor] = None):
     """Neighbour lists (B,N,K) int32 -> (the same lists in ascending index order, the per-(tile, query) membership
-    words (B, ceil(N/32), N) int32) for the map-free forward (stage_attn_stats_nl)."""
-    _need_gpu(nn_idx)
+    words (B, ceil(N/32), N) int32) for the map-free forward (stage_attn_stats_nl).
+    clear: a contiguous byte tensor the kernel zeroes on its way (score_workspace)."""
+    _need_gpu(nn_idx, clear)
     nn_idx = nn_idx.to(torch.int32).contiguous()
     B, N, K = nn_idx.shape
     with torch.cuda.device(nn_idx.device):
         nn_sorted = torch.empty_like(nn_idx)
         masks = torch.empty((B, (N + 31) // 32, N), dtype=torch.int32, device=nn_idx.device)
         assert masks.numel() * 4 == _lib.query("samble_nn_masks_bytes", B, N)
-        _lib.call("samble_nn_prepare", nn_idx.data_ptr(), B, N, K, nn_sorted.data_ptr(), masks.data_ptr(), _stream())
+        _lib.call("samble_nn_prepare", nn_idx.data_ptr(), B, N, K, nn_sorted.data_ptr(), masks.data_ptr(), _p(clear),
+                  clear.numel() * clear.element_size() if clear is not None else 0, _stream())
     return nn_sorted, masks
 
 
 def stage_attn_stats_nl(q_image, k_image, masks, B: int, n_points: int, n_tokens: int, n_neighbors: int, D: int = 128,
-                        want_nl: bool = True, score=None):
+                        want_nl: bool = True, score=None, cleared_ws: Optional[torch.Tensor] = None):
     """Pass 1 without the logit map (MATRIX_MODE "tri", asm "dot"): -> neighbour logits (B,N,K) in the order of
     stage_nn_prepare's sorted lists (None unless want_nl), lse (B,N), token logits (B,N,nt).
     score = (nn_sorted, idx_mode, num_bins or None): the pass also accumulates the sparse_* score statistics into a
     fresh workspace (returned as 4th value; hand it to stage_sparse_score_map / stage_score_quantiles with
-    smap=None): no separate score pass, no neighbour-logit array."""
+    smap=None): no separate score pass, no neighbour-logit array.  cleared_ws: that workspace, already zeroed
+    (score_workspace + stage_nn_prepare(clear=)); else a fresh one is allocated and zeroed by a memset launch."""
     _need_gpu(q_image, k_image, masks)
     dev = q_image.device
     with torch.cuda.device(dev):
@@ -561,10 +623,15 @@ def stage_attn_stats_nl(q_image, k_image, masks, B: int, n_points: int, n_tokens
             mode = SCORE_MODES[idx_mode]
             nbytes = _lib.query("samble_select_chain_workspace_bytes", B, n_points) if num_bins else \
                 _lib.query("samble_score_workspace_bytes", B, n_points)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if cleared_ws is not None:
+                if cleared_ws.numel() != nbytes or cleared_ws.dtype != torch.uint8 or not cleared_ws.is_contiguous():
+                    raise ValueError(f"cleared_ws must be the {nbytes} bytes of score_workspace")
+                ws = cleared_ws
+            else:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         _lib.call("samble_attn_stats_nl_tri_f32", q_image.data_ptr(), k_image.data_ptr(), B, n_points, n_tokens, D,
                   masks.data_ptr(), n_neighbors, _p(nl), lse.data_ptr(), tok.data_ptr(), _p(nn_sorted), mode, _p(ws),
-                  nbytes, _stream())
+                  nbytes, 1 if (ws is not None and ws is cleared_ws) else 0, _stream())
     return nl, lse, tok[:, :, :n_tokens], ws
 
 
@@ -690,8 +757,10 @@ def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum
 
 
 def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_tokens: int, dq, dk, dv,
-                        asm: str = "dot", images=None, variant: int = 0) -> None:
+                        asm: str = "dot", images=None, variant: int = 0, dq_token_rows: bool = False) -> None:
     """stage_attn_bwd for the two-pass forward: S comes from the map, O from x_ds (B,D,M).
+    dq_token_rows: dq is the first n_points rows of a (B, n_points + n_tokens, .) block and the token rows behind them
+    are to receive zeros (SAMBLE_BWD_DQ_TOKEN_ROWS).
     asm "l2": the kernels also return the column sums of dS and the gradients are finished here:
     dS/dq_i = scale (2 k_j - 2 q_i), dS/dk_j = scale (2 q_i - 2 k_j), rows of dS sum to zero.
     images: optional (k_tr_image, v_rm_image) of the forward's split (MATRIX_MODE "tri")."""
@@ -700,6 +769,10 @@ def stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, g, n_points: int, n_token
     M = idx.shape[1]
     g = _f32c(g)
     x_ds = _f32c(x_ds)
+    if dq_token_rows and n_tokens:
+        if MATRIX_MODE != "tri":
+            raise ValueError("dq_token_rows comes with MATRIX_MODE 'tri' (samble_attn_rows_bwd_tri_f32's variant bits)")
+        variant = int(variant) | BWD_DQ_TOKEN_ROWS
     if asm == "l2+":  # the forward's query operand was a = -q (stage_attn_stats)
         q = (-q).contiguous()
     with torch.cuda.device(q.device):

@@ -1036,3 +1036,142 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
                 assert (_k_image_live_equal(a, b2) if j in (1, 4) else torch.equal(a, b2)), (want, "q_only image", j, int((a != b2).sum()))
     finally:
         o_.MATRIX_MODE = old
+
+
+def test_projection_reads_three_weight_tensors_where_they_are():
+    """(Wq, Wk, Wv) as three tensors of their own (the reference's q_conv / k_conv / v_conv weights): the same bytes in qkv,
+    in every image and in the backward's three results as with the concatenated (3C, C) block."""
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    o_.MATRIX_MODE = "tri"
+    try:
+        B, N, nt = 3, 1000, 6
+        x = torch.from_numpy(synth.normal((B, 128, N), 1900)).to(DEV)
+        tokens = torch.from_numpy(synth.normal((128, nt), 1901)).to(DEV)
+        w = (torch.from_numpy(synth.normal((384, 128), 1902)) * 0.1).to(DEV)
+        # three allocations in another order than [q, k, v], with padding between them
+        w3 = tuple(t.clone() for t in (w[256:], w[:128], w[128:256]))
+        w3 = (w3[1], w3[2], w3[0])
+        for want in ("fwd+bwd", "fwd", ""):
+            a = o_.stage_proj_fwd(x, tokens, w, images=want)
+            b2 = o_.stage_proj_fwd(x, tokens, w3, images=want)
+            if not want:
+                assert torch.equal(a, b2)
+                continue
+            assert torch.equal(a[0], b2[0])
+            for j, (p, q2) in enumerate(zip(a[1], b2[1])):  # (the K / V row images keep unwritten bytes in their dead plane)
+                assert (_k_image_live_equal(p, q2) if j in (1, 4) else torch.equal(p, q2)), (want, j)
+        qkv, imgs = o_.stage_proj_fwd(x, tokens, w3, images="fwd+bwd")
+        dqkv = torch.from_numpy(synth.normal(tuple(qkv.shape), 1903)).to(DEV)
+        ref = o_.stage_proj_bwd(dqkv, x, tokens, w, True, True, w_tr=imgs[5])
+        for kw in ({"w_tr": imgs[5]}, {}):  # ({}: no image at hand -> concatenated on the host side)
+            got = o_.stage_proj_bwd(dqkv, x, tokens, w3, True, True, **kw)
+            assert all(torch.equal(p, q) for p, q in zip(ref, got))
+        with pytest.raises(ValueError):
+            o_.stage_proj_fwd(x, tokens, (w3[0], w3[1]))
+        lib = o_._lib
+        ws = torch.empty(lib.query("samble_proj_bwd_tri_workspace_bytes", B, N), dtype=torch.uint8, device=DEV)
+        with pytest.raises(lib.SambleError):  # three tensors without the transposed image
+            lib.call("samble_proj_bwd_tri_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), 128 * N, B, 128,
+                     N, tokens.data_ptr(), nt, w3[0].data_ptr(), w3[1].data_ptr(), w3[2].data_ptr(), None, None, 128 * N, None,
+                     None, ws.data_ptr(), ws.numel(), None)
+    finally:
+        o_.MATRIX_MODE = old
+
+
+def test_nn_prepare_clears_the_score_workspace_on_request():
+    """samble_nn_prepare's clear range (aligned: in the kernel; odd: a memset) and the statistics pass told that the
+    workspace is clean: the same workspace bytes and outputs as the pass that zeroes it itself."""
+    o_ = ops()
+    B, N, nt, K = 3, 1000, 6, 32
+    q, k, _ = (t.to(DEV) for t in _qkv(B, N, nt, 2100))
+    g = torch.Generator().manual_seed(21)
+    nn_idx = torch.stack([torch.stack([torch.randperm(N, generator=g)[:K] for _ in range(N)]) for _ in range(B)]).int().to(DEV)
+    qimg = o_.stage_tri_split(q)[0]
+    kimg = o_.stage_k_logit_form(o_.stage_tri_split(k)[0], k)
+    ref_sorted, ref_masks = o_.stage_nn_prepare(nn_idx)
+    ref = o_.stage_attn_stats_nl(qimg, kimg, ref_masks, B, N, nt, K, want_nl=False, score=(ref_sorted, "sparse_col_sqr", 6))
+    for odd in (0, 5):
+        ws = o_.score_workspace(B, N, 6, DEV)
+        ws.fill_(0xA5)
+        target = ws[odd:] if odd else ws
+        got_sorted, got_masks = o_.stage_nn_prepare(nn_idx, clear=target)
+        torch.cuda.synchronize()
+        assert torch.equal(got_sorted, ref_sorted) and torch.equal(got_masks, ref_masks)
+        assert bool((target == 0).all()) and (not odd or bool((ws[:odd] == 0xA5).all()))
+    ws = o_.score_workspace(B, N, 6, DEV).fill_(0xA5)
+    s2, m2 = o_.stage_nn_prepare(nn_idx, clear=ws)
+    got = o_.stage_attn_stats_nl(qimg, kimg, m2, B, N, nt, K, want_nl=False, score=(s2, "sparse_col_sqr", 6), cleared_ws=ws)
+    assert got[3] is ws
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    with pytest.raises(ValueError):
+        o_.stage_attn_stats_nl(qimg, kimg, m2, B, N, nt, K, want_nl=False, score=(s2, "sparse_col_sqr", 6), cleared_ws=ws[16:])
+
+
+@pytest.mark.parametrize("mode", ["uniform", "random"])
+def test_bin_select_draws_its_own_noise_like_the_injected_one(mode):
+    """The seeded select (Exp(1) drawn inside the kernel from a Philox state) returns, bit for bit, the indices of the
+    select on the tensor samble_exp1_noise_f32 writes for the same state -- so the oracle comparison of the
+    injected-noise entry covers it -- and that tensor is an Exp(1) sample: positive, finite, the right moments, a
+    Kolmogorov-Smirnov distance from 1 - exp(-x) as small as a sample of its size gives, other states other numbers."""
+    from scipy import stats
+    o_ = ops()
+    B, N, nb, M = 8, 2048, 6, 1024
+    score = torch.from_numpy(np.abs(synth.normal((B, 1, N), 41)) * 1e-4 + 1e-6)
+    z = O.zscore(score)
+    state = O.blend_boundaries(None, O.batch_quantiles(z.reshape(B, 1, N, 1), nb), nb, 0.99)
+    member = O.bin_membership(z, state)
+    counts = O.allocate_counts(torch.rand(B, nb, generator=torch.Generator().manual_seed(6)), member.squeeze(1).sum(1), M)
+    bits = (member.squeeze(1).long() * (1 << torch.arange(nb))).sum(-1).to(torch.uint8)
+    args = (score.reshape(B, N).to(DEV), z.reshape(B, N).to(DEV), bits.to(DEV), counts.to(DEV), M, mode, 0.1)
+    seed, offset = 0x1234_5678_9ABC_DEF1, 4 * 123_456_789_012
+    noise = o_.stage_exp1_noise(seed, offset, B * nb, N, DEV)
+    got = o_.stage_bin_select(*args, philox=(seed, offset))
+    assert torch.equal(got, o_.stage_bin_select(*args, noise=noise))
+    ref = O.select_indices(score, member, counts, M, mode, 0.1, noise.cpu()).reshape(B, M)
+    assert int((got.cpu() != ref).sum()) <= (8 if mode == "random" else 0)   # (random: exp / tanh near-ties, see above)
+    v = noise.double().cpu().numpy().ravel()
+    assert np.isfinite(v).all() and (v > 0).all()
+    assert abs(v.mean() - 1.0) < 0.02 and abs(v.var() - 1.0) < 0.05
+    assert stats.kstest(v, "expon").statistic < 0.01
+    assert abs(np.corrcoef(v[:-1], v[1:])[0, 1]) < 0.02
+    other = o_.stage_exp1_noise(seed, offset + 4, B * nb, N, DEV)
+    assert not bool((other == noise).any()) or float((other == noise).float().mean()) < 1e-3
+    assert torch.equal(noise, o_.stage_exp1_noise(seed, offset, B * nb, N, DEV))
+    # the module-level default: torch's device generator keys the draw, and moves on
+    torch.manual_seed(77)
+    a = o_.stage_bin_select(*args)
+    b2 = o_.stage_bin_select(*args)
+    torch.manual_seed(77)
+    assert torch.equal(a, o_.stage_bin_select(*args)) and not torch.equal(a, b2)
+    with pytest.raises(o_._lib.SambleError):
+        o_.stage_bin_select(*args, philox=(seed, 3))
+
+
+def test_rows_backward_clears_the_token_rows_of_dq_on_request():
+    """SAMBLE_BWD_DQ_TOKEN_ROWS: dQ handed over as the first N rows of the projection's (B, N + nt, .) gradient block --
+    the nt rows behind them come back as zeros (they were NaN), the N rows and dK / dV as without the flag."""
+    o_ = ops()
+    old = o_.MATRIX_MODE
+    o_.MATRIX_MODE = "tri"
+    try:
+        B, N, nt, M, D = 2, 1000, 6, 333, 128
+        q, k, v = (t.to(DEV) for t in _qkv(B, N, nt, 2300))
+        gr = torch.from_numpy(synth.normal((B, D, M), 8)).to(DEV)
+        idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:M] for b in range(B)]).to(DEV)
+        smap, lse, _ = o_.stage_attn_stats(q, k, N, nt)
+        x_ds = o_.stage_attn_rows(smap, lse, v, idx, N, nt)
+        ref = [torch.full((B, n, D), float("nan"), device=DEV) for n in (N, N + nt, N + nt)]
+        o_.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, gr, N, nt, *ref)
+        block = torch.full((B, N + nt, 3 * D), float("nan"), device=DEV)
+        o_.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, gr, N, nt, block[:, :N, :D], block[:, :, D:2 * D],
+                               block[:, :, 2 * D:], dq_token_rows=True)
+        assert torch.equal(block[:, :N, :D], ref[0]) and torch.equal(block[:, :, D:2 * D], ref[1])
+        assert torch.equal(block[:, :, 2 * D:], ref[2])
+        assert bool((block[:, N:, :D] == 0).all())
+        o_.MATRIX_MODE = "f32"
+        with pytest.raises(ValueError):
+            o_.stage_attn_rows_bwd(q, k, v, smap, lse, x_ds, idx, gr, N, nt, block[:, :N, :D], block[:, :, D:2 * D],
+                                   block[:, :, 2 * D:], dq_token_rows=True)
+    finally:
+        o_.MATRIX_MODE = old
