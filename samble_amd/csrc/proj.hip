@@ -271,12 +271,69 @@ __global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict
 // 49 152 outputs x (B * chunks) partials = 50 MB at B = 32: bandwidth work, so every load must be in flight at
 // once.  Workgroup = 16 float4 columns x 16 partial groups: thread (e4, g) sums partials g, g + 16, g + 32, ...
 // (16 independent 16-byte loads in flight per round), the 16 group sums are added in index order through LDS.
+// The token rows ride along (no launch of their own): every workgroup forms the gsum[t][o] of ITS output row o =
+// sum_b dqkv[b][N+t][o] (index order) while its partial loads are in flight, and workgroups kO * kC / 64 .. + nt - 1 are
+// the token workgroups: all of gsum[t][.] for one token t, then dtokens[c][t] = sum_o W[o][c] gsum[t][o] in three
+// parts of 128 outputs combined in part order (the arithmetic of the former proj_tok_bwd_kernel, bit for bit).
+struct TokGrad {
+  const float* dqkv;  // (B, N + nt, 384) gradient block: the token rows are read
+  long g_bs, g_rs;
+  int B, N;
+  ProjW W;
+  float* dtok;        // (128, nt)
+};
+__device__ __forceinline__ float tok_gsum(const TokGrad& tg, int t, int o) {
+  const float* src = tg.dqkv + (long)(tg.N + t) * tg.g_rs + o;
+  float s = 0.f;
+  int b = 0;
+  for (; b + 32 <= tg.B; b += 32) {  // 32 loads in flight, summed in index order
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = src[(long)(b + u) * tg.g_bs];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += v[u];
+  }
+  for (; b + 8 <= tg.B; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(long)(b + u) * tg.g_bs];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < tg.B; ++b) s += src[(long)b * tg.g_bs];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nparts,
-                                                             const float* __restrict__ gsum,
-                                                             const float* __restrict__ tokens, int nt,
+                                                             const TokGrad tg, const float* __restrict__ tokens, int nt,
                                                              float* __restrict__ dW) {
   __shared__ f32x4 red[16][17];
+  __shared__ float gs[kO];
+  __shared__ float ps[3][kC];
+  if (blockIdx.x >= kO * kC / 64) {  // a token workgroup
+    const int t = blockIdx.x - kO * kC / 64, tid = threadIdx.x;
+    for (int o = tid; o < kO; o += 256) gs[o] = tok_gsum(tg, t, o);
+    __syncthreads();
+    // thread = (channel c, half): half 0 takes parts 0 and 2 of the 384 outputs, half 1 part 1; 16 W loads in flight
+    const int c = tid & (kC - 1);
+    for (int part3 = tid >> 7; part3 < 3; part3 += 2) {
+      float acc = 0.f;
+      for (int o0 = 128 * part3; o0 < 128 * part3 + 128; o0 += 64) {  // (one weight: 64 loads in flight)
+        float wv[64];
+        const float* wp = tg.W.row(o0) + c;
+#pragma unroll
+        for (int u = 0; u < 64; ++u) wv[u] = wp[u * kC];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) acc = fmaf(wv[u], gs[o0 + u], acc);
+      }
+      ps[part3][c] = acc;
+    }
+    __syncthreads();
+    if (tid < kC) tg.dtok[tid * nt + t] = (ps[0][tid] + ps[1][tid]) + ps[2][tid];
+    return;
+  }
   const int e4l = threadIdx.x & 15, g = threadIdx.x >> 4;
+  if (threadIdx.x < nt) gs[threadIdx.x] = tok_gsum(tg, threadIdx.x, (blockIdx.x * 64) / kC);  // (one output row per WG)
   const int e4 = blockIdx.x * 16 + e4l;  // float4 column of the (384 x 128) matrix; grid covers it exactly
   const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + e4;
   constexpr long kStride4 = (long)kO * kC / 4;
@@ -298,48 +355,12 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
     f32x4 tot = red[0][e4l];
 #pragma unroll
     for (int k = 1; k < 16; ++k) tot += red[k][e4l];
-    const int e = 4 * e4, o = e / kC, c = e % kC;
+    const int c = (4 * e4) % kC;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      for (int t = 0; t < nt; ++t) tot[j] = fmaf(gsum[t * kO + o], tokens[(c + j) * nt + t], tot[j]);
+      for (int t = 0; t < nt; ++t) tot[j] = fmaf(gs[t], tokens[(c + j) * nt + t], tot[j]);
     reinterpret_cast<f32x4*>(dW)[e4] = tot;
   }
-}
-
-// token rows, one workgroup per token t: gsum[t][o] = sum_b dqkv[b][N+t][o] (fixed order), then
-// dtokens[c][t] = sum_o W[o][c] gsum[t][o] (thread = channel, W read coalesced)
-__global__ __launch_bounds__(384) void proj_tok_bwd_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs, int B,
-                                                           int N, int nt, const ProjW W,
-                                                           float* __restrict__ gsum, float* __restrict__ dtok) {
-  __shared__ float gs[kO];
-  __shared__ float ps[3][kC];
-  const int t = blockIdx.x, o = threadIdx.x;
-  float s = 0.f;
-  int b = 0;
-  for (; b + 8 <= B; b += 8) {  // 8 loads in flight, summed in index order
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = dqkv[(long)(b + u) * g_bs + (long)(N + t) * g_rs + o];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; b < B; ++b) s += dqkv[(long)b * g_bs + (long)(N + t) * g_rs + o];
-  gs[o] = s;
-  gsum[t * kO + o] = s;
-  __syncthreads();
-  // thread = (channel c, third `part` of the 384 outputs): 16 W loads in flight, partial sums combined in part order
-  const int c = o & (kC - 1), part = o >> 7;
-  float acc = 0.f;
-  for (int o0 = 128 * part; o0 < 128 * part + 128; o0 += 16) {
-    float wv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) wv[u] = W.row(o0 + u)[c];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc = fmaf(wv[u], gs[o0 + u], acc);
-  }
-  ps[part][c] = acc;
-  __syncthreads();
-  if (o < kC) dtok[o * nt + t] = (ps[0][o] + ps[1][o]) + ps[2][o];
 }
 
 }  // namespace samble
@@ -399,7 +420,6 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   }
   const int chunks = (N + kDwPts - 1) / kDwPts;
   float* part = ws;
-  float* gsum = ws + (size_t)B * chunks * kO * kC;  // 8 x 384
   if (dx && wtr) {  // room for the transposed image of W -> the split-bf16 kernel
     const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr_ready ? const_cast<void*>(wtr_ready) : wtr,
                                              wtr_ready != nullptr, B, N, dx, dx_bs, s);
@@ -416,10 +436,8 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
     } else {
       hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     }
-    if (nt > 0)
-      hipLaunchKernelGGL(proj_tok_bwd_kernel, dim3(nt), dim3(384), 0, s, dqkv, g_bs, g_rs, B, N, nt,
-                         proj_w(W, Wk, Wv), gsum, dtok);
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO * kC / 64), dim3(256), 0, s, part, B * chunks, gsum, tokens, nt,
+    const TokGrad tg{dqkv, g_bs, g_rs, B, N, proj_w(W, Wk, Wv), dtok};
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO * kC / 64 + nt), dim3(256), 0, s, part, B * chunks, tg, tokens, nt,
                        dW);
   }
   return (int)hipGetLastError();
