@@ -264,6 +264,28 @@ int samble_attn_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float*
                         int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
                         int64_t dv_bs, int64_t dv_rs, int variant, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- models/attention.py:253-355  Point2PointAttention: global self-attention over H heads of depth D ----------
+ * Q, K, V (B, N, H*D) point-major rows with explicit strides (head h = columns h*D .. h*D + D - 1; the three may be
+ * column blocks of one [Q|K|V] row); per head
+ *     O = softmax((qk_mul * Q K^T + key_bias_j) / sqrt(D)) V          (no (B, H, N, N) tensor)
+ * asm "dot" (attention.py:341): qk_mul = 1, key_bias NULL; "l2" (:343, energy -|q - k|^2): qk_mul = 2, key_bias_j =
+ * -|k_j|^2; "l2+" (:345): qk_mul = -2, key_bias_j = +|k_j|^2 -- the row term |q_i|^2 is constant along a softmax row.
+ * key_bias (B, H, N).  O (B, N, H*D), lse (B, H, N).  D in 4..128, a multiple of 4; all bases 16-byte aligned, strides
+ * multiples of 4.  True fp32 matrix products (v_mfma_f32_32x32x2_f32).
+ * Backward: dO (B, N, H*D) -> dQ, dK, dV (same layout as their operands; dK holds qk_mul * dS^T Q only) and
+ * bias_grad (B, H, N) = d loss / d key_bias (the column sums of dS; required when key_bias is given: the caller adds
+ * bias_grad_j * d key_bias_j / d k_j to dK).  Workspace: samble_attn_heads_bwd_workspace_bytes. */
+int samble_attn_heads_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                              const float* V, int64_t v_bs, int64_t v_rs, const float* key_bias /* or NULL */, float qk_mul,
+                              int B, int N, int H, int D, float* O, int64_t o_bs, int64_t o_rs, float* lse, void* stream);
+size_t samble_attn_heads_bwd_workspace_bytes(int B, int N, int H);
+int samble_attn_heads_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
+                              const float* V, int64_t v_bs, int64_t v_rs, const float* key_bias /* or NULL */, float qk_mul,
+                              int B, int N, int H, int D, const float* O, int64_t o_bs, int64_t o_rs, const float* lse,
+                              const float* dO, int64_t g_bs, int64_t g_rs, float* dQ, int64_t dq_bs, int64_t dq_rs,
+                              float* dK, int64_t dk_bs, int64_t dk_rs, float* dV, int64_t dv_bs, int64_t dv_rs,
+                              float* bias_grad /* or NULL */, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- two-pass forward with the logit map kept in HBM (same reference lines as samble_attn_fwd_f32) ---
  * In exact fp32 on MI355X reloading a logit (4 bytes) is ~3x cheaper than recomputing it (2*D flop),
  * so S = Q K^T / sqrt(D) is computed once and kept: smap (B, N, ld) row-major,

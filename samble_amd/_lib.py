@@ -69,6 +69,15 @@ _SIGNATURES = {
     "samble_bin_select_seeded_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_uint64, c_int, c_int, c_int,
                                              c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "samble_exp1_noise_f32": (c_int, [c_uint64, c_uint64, c_int, c_int, c_void_p, c_void_p]),
+    "samble_attn_heads_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_void_p]),
+    "samble_attn_heads_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "samble_attn_heads_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int64,
+                                          c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                          c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_size_t,
+                                          c_void_p]),
     "samble_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_gather_points_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_n2p_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

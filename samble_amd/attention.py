@@ -186,47 +186,39 @@ class _P2PCore(torch.autograd.Function):
         return dqkv
 
 
-def _heads_as_batches(qkv: torch.Tensor, heads: int, asm: str) -> torch.Tensor:
-    """(B,N,3C) projection rows -> (B*H, N, 3C) operands for the one-head-of-C attention kernels such that
-    batch b*H + h computes head h of `asm` scoring with depth D = C / H:
+class _P2PHeads(torch.autograd.Function):
+    """qkv (B,N,3C) point-major -> per head softmax(energy / sqrt(D)) v for every point, (B,C,N): the multi-head
+    kernels of csrc/attn_heads.hip (a wave owns 32 rows of one head of depth D = C / H; no (B,H,N,N) tensor).
+    energy (reference models/attention.py:338-349): q k^T | -|q - k|^2 | +|q - k|^2."""
 
-      Q' = s * q restricted to head h's channels (zeros elsewhere), s = sqrt(C / D) undoes the kernel's 1/sqrt(C);
-      K' = k, V' = v (the contraction only sees head h's channels of K'; the output's head-h channels are head h).
-      l2 / l2+ (reference attention.py:345-349, energy = -+|q - k|^2): the row term |q_i|^2 cancels in the softmax,
-      the key term rides in a channel that head h does not use: Q'[c*] = s, K'[c*] = -+|k_h|^2, and the dot part
-      is scaled by +-2.  Needs a free channel, i.e. H >= 2.
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, qkv, heads, asm):
+        qkv = qkv.contiguous()
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        bias = None
+        if asm != "dot":  # the key term of -+|q - k|^2 (the query term is constant along a softmax row)
+            k_sq = qkv[:, :, C:2 * C].reshape(B, N, heads, C // heads).square().sum(-1).permute(0, 2, 1)  # (B,H,N)
+            bias = (-k_sq if asm == "l2" else k_sq).contiguous()
+        out, lse = ops.stage_attn_heads_fwd(qkv, heads, asm, bias)
+        ctx.save_for_backward(qkv, out, lse, bias)
+        ctx.cfg = (heads, asm)
+        return out.permute(0, 2, 1).contiguous()
 
-    Built from differentiable torch ops: autograd carries the gradients back to q, k, v."""
-    B, N, C3 = qkv.shape
-    C = C3 // 3
-    D = C // heads
-    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    head_of = torch.arange(C, device=qkv.device) // D                                  # (C,)
-    own = (head_of.unsqueeze(0) == torch.arange(heads, device=qkv.device).unsqueeze(1)).to(qkv.dtype)  # (H,C)
-    s = (C / D) ** 0.5
-    sign = {"dot": 1.0, "l2": 2.0, "l2+": -2.0}[asm]
-    qe = q.unsqueeze(1) * (own * (s * sign)).view(1, heads, 1, C)                      # (B,H,N,C)
-    ke = k.unsqueeze(1).expand(-1, heads, -1, -1)
-    if asm != "dot":
-        if heads < 2:
-            raise NotImplementedError("asm l2 / l2+ needs num_heads >= 2 here (a free channel carries the key norms)")
-        spare = ((torch.arange(heads, device=qkv.device) + 1) % heads) * D             # first channel of another head
-        k_sq = (k.unsqueeze(1) * own.view(1, heads, 1, C)).square().sum(-1)            # (B,H,N) |k_h|^2
-        onehot = torch.zeros(heads, C, dtype=qkv.dtype, device=qkv.device)
-        onehot[torch.arange(heads), spare] = 1.0
-        bias_sign = -1.0 if asm == "l2" else 1.0
-        qe = qe + (s * onehot).view(1, heads, 1, C)
-        ke = ke * (1.0 - onehot).view(1, heads, 1, C) + (bias_sign * k_sq).unsqueeze(-1) * onehot.view(1, heads, 1, C)
-    ve = v.unsqueeze(1).expand(-1, heads, -1, -1)
-    return torch.cat((qe, ke.expand(B, heads, N, C), ve), dim=-1).reshape(B * heads, N, 3 * C)
-
-
-def _own_head_channels(out: torch.Tensor, B: int, heads: int) -> torch.Tensor:
-    """(B*H, C, N) per-head outputs -> (B, C, N): channel block h taken from head h's batch entry."""
-    _, C, N = out.shape
-    D = C // heads
-    blocks = out.view(B, heads, heads, D, N)
-    return torch.diagonal(blocks, dim1=1, dim2=2).permute(0, 3, 1, 2).reshape(B, C, N)
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        qkv, out, lse, bias = ctx.saved_tensors
+        heads, asm = ctx.cfg
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        dqkv, bias_grad = ops.stage_attn_heads_bwd(qkv, heads, out, lse, g.permute(0, 2, 1).contiguous(), asm, bias)
+        if bias is not None:  # bias_j = -+|k_j|^2: d bias_j / d k_j = -+2 k_j
+            k = qkv[:, :, C:2 * C].reshape(B, N, heads, C // heads)
+            sign = -2.0 if asm == "l2" else 2.0
+            dqkv[:, :, C:2 * C] += (sign * bias_grad.permute(0, 2, 1).unsqueeze(-1) * k).reshape(B, N, C)
+        return dqkv, None, None
 
 
 class Point2PointAttention(nn.Module):
@@ -234,10 +226,9 @@ class Point2PointAttention(nn.Module):
     state_dict keys (`q_conv/k_conv/v_conv.weight` (C,C,1), `ff.*`, `bn1/bn2.*`) and forward (B,C,N) -> (B,C,N),
     `asm` dot / l2 / l2+, any head count dividing 128 (reference default: 4 heads of 32).
 
-    Runs on the sampler's kernels (HIP projection + single-pass flash attention forward / backward for one head
-    of 128 channels, no N x N tensor): the H heads become H batch entries whose queries are zero outside their
-    head's channels (`_heads_as_batches`), so a head of depth 32 costs what a head of 128 does -- the layer is
-    a secondary consumer (no shipped config selects it), correctness first."""
+    Runs on the HIP projection and, per head of depth D = 128 / H, the multi-head attention kernels of
+    csrc/attn_heads.hip (forward, dQ, dK / dV; true fp32 MFMA products, no N x N tensor); a single head with asm dot
+    takes the sampler's single-pass flash kernels.  A secondary consumer: no shipped config selects the layer."""
 
     def __init__(self, config_attention, layer):
         num_heads = config_attention.num_heads[layer]
@@ -276,8 +267,8 @@ class Point2PointAttention(nn.Module):
             raise ValueError("Please check the setting of asm in feature learning layer!")
         if not (q_in == q_out == v_out == 128):
             raise NotImplementedError("the HIP attention kernels are built for 128 channels")
-        if self.asm != "dot" and num_heads < 2:
-            raise NotImplementedError("asm l2 / l2+ with a single head of 128 channels is not built (no free channel)")
+        if self.q_depth % 4:
+            raise NotImplementedError("the multi-head kernels move rows in 16-byte pieces: head depth a multiple of 4")
 
     def forward(self, x):
         if not x.is_cuda:
@@ -285,11 +276,10 @@ class Point2PointAttention(nn.Module):
         from .downsample import _Projection
         no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
         qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
-        if self.num_heads == 1:
+        if self.num_heads == 1 and self.asm == "dot":
             x_tmp = _P2PCore.apply(qkv)
         else:
-            x_tmp = _own_head_channels(_P2PCore.apply(_heads_as_batches(qkv, self.num_heads, self.asm)), x.shape[0],
-                                       self.num_heads)
+            x_tmp = _P2PHeads.apply(qkv, self.num_heads, self.asm)
         x = self.bn1(x + x_tmp)
         x_tmp = self.ff(x)
         x = self.bn2(x + x_tmp)

@@ -29,6 +29,11 @@ int samble_launch_alloc_counts(const float*, const int*, int, int, int, int*, hi
 int samble_launch_bin_select(const float*, const float*, const unsigned char*, const int*, const float*, unsigned long long,
                              unsigned long long, int, int, int, int, int, int, float, long long*, hipStream_t);
 int samble_launch_exp1_noise(unsigned long long, unsigned long long, long, float*, hipStream_t);
+int samble_launch_attn_heads_fwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
+                                 float, float, int, int, int, int, float*, long, long, float*, hipStream_t);
+int samble_launch_attn_heads_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
+                                 float, float, int, int, int, int, const float*, long, long, const float*, const float*, long,
+                                 long, float*, float*, long, long, float*, long, long, float*, long, long, float*, hipStream_t);
 int samble_launch_gather_rows(const float*, long, long, const long long*, int, int, float*, hipStream_t);
 int samble_launch_blend_boundaries(const float*, float*, float*, int, float, float, int, hipStream_t);
 int samble_edge_waves(void);
@@ -509,6 +514,65 @@ SAMBLE_API int samble_attn_rows_bwd_tri_f32(const float* Q, int64_t q_bs, int64_
   return attn_bwd_common("samble_attn_rows_bwd_tri_f32", Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, nullptr, x_ds, smap,
                          ld, lse, idx, g, B, N, nt, M, D, dQ, dq_bs, dq_rs, dK, dk_bs, dk_rs, dV, dv_bs, dv_rs, ws,
                          ws_bytes, stream, variant, ds_colsum ? 1 : 0, ds_colsum, k_tr_image, v_rm_image);
+}
+
+/* ---- multi-head global attention (Point2PointAttention) ---- */
+static int heads_args_ok(const char* who, const void* Q, const void* K, const void* V, int B, int N, int H, int D,
+                         int64_t s0, int64_t s1, int64_t s2, int64_t s3, int64_t s4, int64_t s5) {
+  char msg[160];
+  if (!Q || !K || !V) {
+    snprintf(msg, sizeof msg, "%s: null pointer", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (B <= 0 || N <= 0 || H <= 0 || D < 4 || D > 128 || (D & 3)) {
+    snprintf(msg, sizeof msg, "%s: need positive B/N/H and a head depth D in 4..128, a multiple of 4", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  if (((s0 | s1 | s2 | s3 | s4 | s5) & 3) || ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(K) |
+                                               reinterpret_cast<uintptr_t>(V)) & 15)) {
+    snprintf(msg, sizeof msg, "%s: rows move in 16-byte pieces: strides multiples of 4 elements, 16-byte aligned bases", who);
+    return fail(SAMBLE_E_INVALID, msg);
+  }
+  return 0;
+}
+
+SAMBLE_API int samble_attn_heads_fwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                         int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* key_bias,
+                                         float qk_mul, int B, int N, int H, int D, float* O, int64_t o_bs, int64_t o_rs,
+                                         float* lse, void* stream) {
+  if (int rc = heads_args_ok("samble_attn_heads_fwd_f32", Q, K, V, B, N, H, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs)) return rc;
+  if (!O || !lse || ((o_bs | o_rs) & 3) || (reinterpret_cast<uintptr_t>(O) & 15))
+    return fail(SAMBLE_E_INVALID, "samble_attn_heads_fwd_f32: O / lse missing, or O not in 16-byte pieces");
+  return done(samble_launch_attn_heads_fwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, key_bias, qk_mul, inv_sqrt_d(D), B, N,
+                                           H, D, O, o_bs, o_rs, lse, (hipStream_t)stream),
+              "samble_attn_heads_fwd_f32");
+}
+
+SAMBLE_API size_t samble_attn_heads_bwd_workspace_bytes(int B, int N, int H) {
+  if (B <= 0 || N <= 0 || H <= 0) return 0;
+  return (size_t)B * H * N * sizeof(float);
+}
+
+SAMBLE_API int samble_attn_heads_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs,
+                                         int64_t k_rs, const float* V, int64_t v_bs, int64_t v_rs, const float* key_bias,
+                                         float qk_mul, int B, int N, int H, int D, const float* O, int64_t o_bs,
+                                         int64_t o_rs, const float* lse, const float* dO, int64_t g_bs, int64_t g_rs,
+                                         float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs,
+                                         float* dV, int64_t dv_bs, int64_t dv_rs, float* bias_grad, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  if (int rc = heads_args_ok("samble_attn_heads_bwd_f32", Q, K, V, B, N, H, D, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs)) return rc;
+  if (!O || !lse || !dO || !dQ || !dK || !dV || !ws) return fail(SAMBLE_E_INVALID, "samble_attn_heads_bwd_f32: null pointer");
+  if (((o_bs | o_rs | g_bs | g_rs | dq_bs | dq_rs | dk_bs | dk_rs | dv_bs | dv_rs) & 3) ||
+      ((reinterpret_cast<uintptr_t>(O) | reinterpret_cast<uintptr_t>(dO) | reinterpret_cast<uintptr_t>(dQ) |
+        reinterpret_cast<uintptr_t>(dK) | reinterpret_cast<uintptr_t>(dV)) & 15))
+    return fail(SAMBLE_E_INVALID, "samble_attn_heads_bwd_f32: rows move in 16-byte pieces (strides, bases)");
+  if (key_bias && !bias_grad) return fail(SAMBLE_E_INVALID, "samble_attn_heads_bwd_f32: key_bias without bias_grad");
+  if (ws_bytes < samble_attn_heads_bwd_workspace_bytes(B, N, H))
+    return fail(SAMBLE_E_WORKSPACE, "samble_attn_heads_bwd_f32: workspace too small");
+  return done(samble_launch_attn_heads_bwd(Q, q_bs, q_rs, K, k_bs, k_rs, V, v_bs, v_rs, key_bias, qk_mul, inv_sqrt_d(D), B, N,
+                                           H, D, O, o_bs, o_rs, lse, dO, g_bs, g_rs, (float*)ws, dQ, dq_bs, dq_rs, dK, dk_bs,
+                                           dk_rs, dV, dv_bs, dv_rs, bias_grad, (hipStream_t)stream),
+              "samble_attn_heads_bwd_f32");
 }
 
 SAMBLE_API int samble_attn_map_row_stride(int N, int nt) { return samble_attn_map_ld(N, nt); }

@@ -228,6 +228,61 @@ def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor,
     return dqkv
 
 
+HEADS_ASM = {"dot": 1.0, "l2": 2.0, "l2+": -2.0}   # qk_mul of samble_attn_heads_*_f32 (include/samble.h)
+
+
+def _heads_operands(qkv: torch.Tensor, heads: int):
+    if qkv.dim() != 3 or qkv.shape[2] % (3 * heads) or qkv.dtype != torch.float32 or not qkv.is_contiguous():
+        raise ValueError("qkv must be contiguous fp32 (B, N, 3 * H * D) rows [Q|K|V]")
+    C = qkv.shape[2] // 3
+    return qkv[:, :, 0:C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], C // heads
+
+
+def stage_attn_heads_fwd(qkv: torch.Tensor, heads: int, asm: str = "dot", key_bias: Optional[torch.Tensor] = None):
+    """qkv (B,N,3C) rows [Q|K|V], C = heads * D -> (O (B,N,C), lse (B,heads,N)): per head
+    softmax((qk_mul q k^T + key_bias_j) / sqrt(D)) v over all N points (reference models/attention.py:317-355).
+    key_bias (B,heads,N): -|k_j|^2 for asm "l2", +|k_j|^2 for "l2+" (the caller forms it), None for "dot"."""
+    _need_gpu(qkv, key_bias)
+    q, k, v, D = _heads_operands(qkv, heads)
+    B, N, _ = qkv.shape
+    if key_bias is not None:
+        key_bias = _f32c(key_bias)
+        if key_bias.shape != (B, heads, N):
+            raise ValueError(f"key_bias must be (B, heads, N) = {(B, heads, N)}")
+    with torch.cuda.device(qkv.device):
+        out = torch.empty((B, N, heads * D), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        _lib.call("samble_attn_heads_fwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                  v.data_ptr(), v.stride(0), v.stride(1), _p(key_bias), HEADS_ASM[asm], B, N, heads, D, out.data_ptr(),
+                  out.stride(0), out.stride(1), lse.data_ptr(), _stream())
+    return out, lse
+
+
+def stage_attn_heads_bwd(qkv: torch.Tensor, heads: int, out: torch.Tensor, lse: torch.Tensor, g: torch.Tensor,
+                         asm: str = "dot", key_bias: Optional[torch.Tensor] = None):
+    """g (B,N,C) = gradient of stage_attn_heads_fwd's O -> (dqkv (B,N,3C), bias_grad (B,heads,N) | None).
+    dK in dqkv is the part through q k^T only; bias_grad = d loss / d key_bias."""
+    _need_gpu(qkv, out, lse, g, key_bias)
+    q, k, v, D = _heads_operands(qkv, heads)
+    B, N, _ = qkv.shape
+    g, out, lse = _f32c(g), _f32c(out), _f32c(lse)
+    if key_bias is not None:
+        key_bias = _f32c(key_bias)
+    with torch.cuda.device(qkv.device):
+        dqkv = torch.empty_like(qkv)
+        C = heads * D
+        dq, dk, dv = dqkv[:, :, 0:C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:]
+        bias_grad = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device) if key_bias is not None else None
+        nbytes = _lib.query("samble_attn_heads_bwd_workspace_bytes", B, N, heads)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=qkv.device)
+        _lib.call("samble_attn_heads_bwd_f32", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                  v.data_ptr(), v.stride(0), v.stride(1), _p(key_bias), HEADS_ASM[asm], B, N, heads, D, out.data_ptr(),
+                  out.stride(0), out.stride(1), lse.data_ptr(), g.data_ptr(), g.stride(0), g.stride(1), dq.data_ptr(),
+                  dq.stride(0), dq.stride(1), dk.data_ptr(), dk.stride(0), dk.stride(1), dv.data_ptr(), dv.stride(0),
+                  dv.stride(1), _p(bias_grad), ws.data_ptr(), nbytes, _stream())
+    return dqkv, bias_grad
+
+
 def stage_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_points: int, n_tokens: int,
                    want_row_std: bool = False):
     """q (B,N,D), k/v (B,N+nt,D) (any row/batch stride, unit channel stride) ->
