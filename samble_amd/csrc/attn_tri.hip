@@ -123,7 +123,14 @@ __device__ __forceinline__ void stats_products(const char* __restrict__ Kn, int 
   // kernel that forms logits
   sc_nxt = q_scale * *reinterpret_cast<const float*>(Kn + kDuoScaleSlot);
   s_nxt = zero16();
-  if (ABL & 8) {  // the compiler's own placement of the operand reads
+  if (ABL & 16) {  // timing only (wrong logits): half the operand reads, every pair of k-steps shares one
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+      const u32x4 ah = lp[192 * 2 * kp], al = lp[192 * 2 * kp + 32];
+      s_nxt = mfma_duo(ah, al, qd[4 * kp], qd[4 * kp + 1], s_nxt);
+      s_nxt = mfma_duo(ah, al, qd[4 * kp + 2], qd[4 * kp + 3], s_nxt);
+    }
+  } else if (ABL & 8) {  // the compiler's own placement of the operand reads
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const u32x4 ah = lp[192 * ks], al = lp[192 * ks + 32];
@@ -351,6 +358,9 @@ __device__ unsigned long long g_nl_stamps[8 * 2 * 8];
 #else
 #define NL_STAMP(i) do { } while (0)
 #endif
+#ifndef SAMBLE_NL_ABL
+#define SAMBLE_NL_ABL 0  // scratch builds: stats_products' timing-only ablations inside attn_stats_nl_tri_kernel
+#endif
 constexpr int kNlStride = 33;  // words per query row in LDS (K <= 32; odd: rows on distinct banks)
 constexpr int kStatsNlLds = kStatsDepth * kTriTile + kStatsDepth * 2048 + 256 * kNlStride * 4;
 
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
   const float q_scale = q_unscale * scale;  // (exact: q_unscale is a power of two)
   float sc_cur, sc_nxt;
   f32x16 s_cur, s_nxt;
-  stats_products<0>(buf_ptr(0), lo, h, qd, q_scale, s_cur, sc_cur);
+  stats_products<SAMBLE_NL_ABL>(buf_ptr(0), lo, h, qd, q_scale, s_cur, sc_cur);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // buffer 0 is restaged by iteration 0
 
   // iteration t: restage the slot of tile t (read one iteration ago) with tile t+D and its mask word, products of
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
     stage(t + D);
     NL_STAMP(1);
     if (pfirst) {
-      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
+      stats_products<SAMBLE_NL_ABL>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
       stats_nl_epilogue<TAIL>(h, s_cur, sc_cur, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
       stats_nl_epilogue<TAIL>(h, s_cur, sc_cur, mask_cur, cnt, nlrow, j0, N, NK, tokrow, m, l);
       __builtin_amdgcn_sched_barrier(0);
       NL_STAMP(2);
-      stats_products<0>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
+      stats_products<SAMBLE_NL_ABL>(buf_ptr(t + 1), lo, h, qd, q_scale, s_nxt, sc_nxt);
       NL_STAMP(3);
     }
 #ifdef SAMBLE_STAMPS
@@ -502,7 +512,11 @@ __global__ __launch_bounds__(512, 2) void attn_stats_nl_tri_kernel(const char* _
     asm volatile("s_barrier" ::: "memory");
     NL_STAMP(5);
 #else
+#if defined(SAMBLE_NL_NOBAR)  // scratch builds, timing only (races on the ring): what the per-tile barrier costs
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(4 * (D - 2)) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * (D - 2)) : "memory");
+#endif
 #endif
     s_cur = s_nxt;
     sc_cur = sc_nxt;

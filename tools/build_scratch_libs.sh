@@ -18,3 +18,14 @@ for a in 0 1 2 4 6; do
   hipcc $F -DSAMBLE_RC_ABL=$a -c attn_tri.hip -o /tmp/attn_tri_$a.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/abl/lib_$a.so $(ls build/*.o | grep -v attn_tri.o) /tmp/attn_tri_$a.o
 done
+# tools/scratch/nlabl/lib_<name>.so: attn_stats_nl_tri timing-only ablations (tools/abl_stats_nl.py)
+mkdir -p ../../tools/scratch/nlabl
+nl() {  # name, flags...
+  local name=$1; shift
+  hipcc $F "$@" -c attn_tri.hip -o /tmp/attn_tri_nl_$name.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/scratch/nlabl/lib_$name.so $(ls build/*.o | grep -v attn_tri.o) /tmp/attn_tri_nl_$name.o
+}
+nl nomfma -DSAMBLE_NL_ABL=2
+nl halfreads -DSAMBLE_NL_ABL=16
+nl nobar -DSAMBLE_NL_NOBAR
+nl nobar_nomfma -DSAMBLE_NL_NOBAR -DSAMBLE_NL_ABL=2
