@@ -550,7 +550,7 @@ def test_inverse_neighbour_lists_equal_a_stable_sort(B, N, K):
     assert torch.equal(counts.long(), ref_counts)
 
 
-@pytest.mark.parametrize("B,N", [(2, 300), (1, 1024), (3, 33)])
+@pytest.mark.parametrize("B,N", [(2, 300), (1, 1024), (3, 33), (2, 5), (1, 1)])
 @pytest.mark.parametrize("H,asm", [(4, "dot"), (4, "l2"), (4, "l2+"), (1, "l2"), (1, "l2+"), (2, "dot"), (8, "l2+"), (32, "dot")])
 def test_multi_head_attention_kernels_against_float64(B, N, H, asm):
     """csrc/attn_heads.hip (a wave = 32 rows of ONE head of depth D = 128 / H) against the definition in float64
@@ -595,7 +595,8 @@ def test_multi_head_attention_kernels_against_float64(B, N, H, asm):
     for j, name in enumerate(("dq", "dk", "dv")):
         got, ref = dqkv[:, :, j * C:(j + 1) * C].double(), ref_in.grad[:, :, j * C:(j + 1) * C]
         err = float((got - ref).abs().max())
-        assert err <= 5e-5 * float(ref.abs().max()) + 1e-7, (name, err, float(ref.abs().max()))
+        # (a single key: P = 1 and dS = dP - delta is zero up to the rounding of two dot products of |g| |v| ~ 1)
+        assert err <= 5e-5 * float(ref.abs().max()) + 1e-6, (name, err, float(ref.abs().max()))
     out2, lse2, dqkv2 = run()
     assert torch.equal(out, out2) and torch.equal(lse, lse2) and torch.equal(dqkv, dqkv2)
 

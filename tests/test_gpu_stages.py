@@ -1106,6 +1106,12 @@ def test_nn_prepare_clears_the_score_workspace_on_request():
     assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
     with pytest.raises(ValueError):
         o_.stage_attn_stats_nl(qimg, kimg, m2, B, N, nt, K, want_nl=False, score=(s2, "sparse_col_sqr", 6), cleared_ws=ws[16:])
+    # K = 16 lists as well
+    nn16 = nn_idx[:, :, :16].contiguous()
+    ref16 = o_.stage_nn_prepare(nn16)
+    ws16 = o_.score_workspace(B, N, None, DEV).fill_(0x5A)
+    got16 = o_.stage_nn_prepare(nn16, clear=ws16)
+    assert torch.equal(got16[0], ref16[0]) and torch.equal(got16[1], ref16[1]) and bool((ws16 == 0).all())
 
 
 @pytest.mark.parametrize("mode", ["uniform", "random"])
