@@ -27,11 +27,26 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
-# split-bf16 kernels (samble_amd/csrc/tri_dev.h): every fp32 product is 6 bf16 MFMA products, so the
-# ceiling for ALGORITHMIC (fp32) flops is the dense bf16 peak / 6
+# split-plane kernels (samble_amd/csrc/tri_dev.h): an fp32 product is formed from 16-bit MFMA products of operand planes
+# -- six with three bf16 planes per operand, three with two fp16 planes -- so the ceiling for ALGORITHMIC (fp32) flops of
+# a kernel is the dense 16-bit peak (bf16 = fp16 = 2500 TFLOP/s) / the 16-bit products it EXECUTES per algorithmic product
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_TRI_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
 PEAK_HBM_GBS = 8000.0
+# 16-bit MFMA products executed per ALGORITHMIC fp32 product, per kernel of the default (split-plane, map-free) step
+EXECUTED_PRODUCTS = {
+    "knn": (4.0, "two fp16 planes: 1 seed product (h h) over all key tiles + 3 exact products (hh + hm + mh)"),
+    "attn_stats": (3.0, "logits on two fp16 planes under per-tile / per-row power-of-two scales: 3 products"),
+    "attn_rows": (9.0, "algorithmic work = P V (SURVEY 8d: recomputation is not counted); executed = the sampled rows' "
+                       "logits again (3 fp16 products) + P V on three bf16 planes (6)"),
+    "bwd_dq": (4.5, "two algorithmic products (dP, dQ): dP on two fp16 planes (3) + dQ += dS K on three bf16 planes (6) "
+                    "= 9 executed per 2"),
+    "bwd_dv": (3.0, "dV += dO^T P on two fp16 planes: 3 products"),
+    "bwd_dk": (3.0, "dK += Q^T dS on two fp16 planes: 3 products"),
+    "proj_fwd": (6.0, "three bf16 planes per operand: 6 products"),
+    "proj_dx": (6.0, "three bf16 planes per operand: 6 products"),
+    "proj_dw": (6.0, "three bf16 planes per operand: 6 products"),
+}
 
 B_PER_GPU, C, N, M, NB, KNN = 32, 128, 2048, 1024, 6, 32
 
@@ -144,6 +159,43 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
+def measure_collectives(dev, world):
+    """After the timed region, every rank: which library carried the collectives, how many ranks it formed, and the
+    latency of the two messages on the data path -- C1, the all-reduce of the nb-1 boundary quantiles that sits between
+    score_quantiles and bin_plan in every forward (reference utils/ops.py:191-199), and C2, one DDP bucket with the
+    sampler layer's 99 840 parameters (reference train_modelnet.py:245-250) -- so that a scaling curve explains itself."""
+    backend = dist.get_backend()
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    torch.cuda.synchronize()
+    out = {"backend": backend, "ranks_formed": int(round(float(one.item()))), "world_size": dist.get_world_size()}
+    try:
+        v = torch.cuda.nccl.version()
+        out["rccl_version"] = ".".join(str(i) for i in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:  # noqa: BLE001
+        out["rccl_version"] = f"unavailable ({e!r})"
+    for label, n in (("c1_boundary_allreduce_5_floats_us", NB - 1), ("c2_ddp_bucket_399KB_allreduce_us", 3 * C * C + C * NB)):
+        buf = torch.zeros(n, device=dev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 20
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
+            dist.all_reduce(buf)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        out[label] = round(1e3 * statistics.median(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)), 1)
+    worst = torch.tensor([out["c1_boundary_allreduce_5_floats_us"], out["c2_ddp_bucket_399KB_allreduce_us"]], device=dev)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    out["c1_boundary_allreduce_5_floats_us"], out["c2_ddp_bucket_399KB_allreduce_us"] = [round(float(v), 1) for v in worst]
+    out["note"] = ("median of 20 back-to-back all-reduces timed by HIP events on the compute stream, max over ranks; C1 is "
+                   "on the forward's critical path once per layer, C2 overlaps the backward under DDP")
+    return out
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -182,25 +234,134 @@ def cpu_baseline(seed):
     reps = 3
     O.sampler_grads(spec, st, x, g, noise)  # warm-up at the full batch (first-touch of the 2 x 538 MB maps)
     times = []
+    ref = None
     for _ in range(reps):
         t0 = time.perf_counter()
-        O.sampler_grads(spec, st, x, g, noise)
+        ref = O.sampler_grads(spec, st, x, g, noise)
         times.append(time.perf_counter() - t0)
     dt = statistics.median(times)
-    return dict(value=round(sample_b / dt, 3), unit="clouds/s", cores=cores, kind="port", cpu=cpu_model(),
+    line = dict(value=round(sample_b / dt, 3), unit="clouds/s", cores=cores, kind="port", cpu=cpu_model(),
                 host_cpus=ncpu,
                 sample=f"median of {reps} x fwd+bwd of {sample_b} clouds (N={N}->{M}) after 1 warm-up, torch CPU oracle "
                        f"(bit-identical restatement of the reference), {cores} threads")
+    return line, dict(idx=ref["idx"], x_ds=ref["x_ds"], dx=ref["dx"], noise=noise, g=g)
+
+
+def parity_vs_oracle(seed, dev, ref):
+    """One UNTIMED step of a fresh layer (the initial weights, the same 32 clouds, the oracle's Exp(1) noise injected)
+    against what the oracle produced in cpu_baseline(): the end-to-end sampled-index match at the headline
+    configuration (reference utils/ops.py:467-619; SURVEY section 7: stage-wise exactness is what the tests assert,
+    this is the reported end-to-end rate)."""
+    from samble_amd import sampler_config, synth
+    from samble_amd.downsample import DownSampleToken
+    mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0)
+    wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(torch.from_numpy(wq))
+        mod.k_conv.weight.copy_(torch.from_numpy(wk))
+        mod.v_conv.weight.copy_(torch.from_numpy(wv))
+        mod.bin_tokens.copy_(torch.from_numpy(tok))
+    mod = mod.to(dev)
+    x = torch.from_numpy(synth.features(B_PER_GPU, C, N, seed + 1)).to(dev).requires_grad_(True)
+    (x_ds, idx), _ = mod(x, noise=ref["noise"].to(dev))
+    x_ds.backward(ref["g"].to(dev))
+    torch.cuda.synchronize()
+    a, b = idx.cpu()[:, 0], ref["idx"][:, 0]
+    same = (a == b).all(1)
+    inter = sum(len(set(a[i].tolist()) & set(b[i].tolist())) for i in range(a.shape[0]))
+    out = {"clouds_identical": int(same.sum()), "of": int(a.shape[0]),
+           "positions_identical": round(float((a == b).float().mean()), 6),
+           "set_agreement": round(inter / a.numel(), 6),
+           "max_points_differing_in_a_cloud": max(len(set(a[i].tolist()) ^ set(b[i].tolist())) // 2 for i in range(a.shape[0])),
+           "against": "the CPU oracle's fwd+bwd of the same 32 clouds in cpu_baseline (same weights, same Exp(1) noise)"}
+    if bool(same.any()):
+        xr, dr = ref["x_ds"][same], ref["dx"][same]
+        out["x_ds_max_err_on_identical_clouds"] = float((x_ds.detach().cpu()[same] - xr).abs().max())
+        out["dx_max_rel_err_on_identical_clouds"] = float((x.grad.cpu()[same] - dr).abs().max() / dr.abs().max())
+    return out
+
+
+def quick_sampler(Bq, Nq, Mq, steps, warmup):
+    """ms/step and the longest kernel of one DownSampleToken layer fwd+bwd+SGD at another geometry (the stress workload
+    behind the headline line; `--workload stress` prints its full line)."""
+    from samble_amd import _lib, sampler_config, synth
+    from samble_amd.downsample import DownSampleToken
+    dev = torch.device("cuda", torch.cuda.current_device())
+    seed = 1000 * 5
+    mod = DownSampleToken(sampler_config("cls", M=[Mq, Mq // 2]), 0)
+    wq, wk, wv, tok = synth.sampler_weights(C, NB, seed)
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(torch.from_numpy(wq))
+        mod.k_conv.weight.copy_(torch.from_numpy(wk))
+        mod.v_conv.weight.copy_(torch.from_numpy(wv))
+        mod.bin_tokens.copy_(torch.from_numpy(tok))
+    mod = mod.to(dev)
+    opt = torch.optim.SGD(mod.parameters(), lr=1e-4)
+    x = torch.from_numpy(synth.features(Bq, C, Nq, seed + 1)).to(dev)
+    g = torch.from_numpy(synth.normal((Bq, C, Mq), seed + 2)).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        (x_ds, _), _ = mod(x.detach().requires_grad_(True))
+        x_ds.backward(g)
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    cand = ["knn", "attn_stats", "attn_rows", "bwd_dq", "bwd_dv", "bwd_dk"]
+    _lib.timing_select(cand)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    seen = {n: _lib.timing_read(n) for n in cand}
+    _lib.timing_select([])
+    dom = max((n for n in cand if seen.get(n)), key=lambda n: seen[n][1], default=None)
+    fl = (2 * C * C * (3 * Nq + 2 * NB) * 3 + 2 * Nq * Nq * C + 2 * Nq * (Nq + NB) * C + 5 * 2 * Mq * (Nq + NB) * C) * Bq
+    return {"config": f"BASELINE configs[4]: one DownSampleToken layer fwd+bwd+SGD, B={Bq} C=128 N={Nq}->{Mq}",
+            "ms_per_step": round(ms, 4), "clouds_per_s": round(Bq / (ms * 1e-3), 1), "steps": steps, "warmup": warmup,
+            "dominant_kernel": dom, "dominant_kernel_us": round(seen[dom][1] * 1e3, 1) if dom else None,
+            "kernel_us": {n: round(v[1] * 1e3, 1) for n, v in seen.items() if v},
+            "step_fraction_of_fp32_mfma_roofline": round(fl / (ms * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4)}
+
+
+def extra_workloads(args):
+    out = {}
+    for name, fn in (("stress", lambda: quick_sampler(16, 8192, 4096, steps=8, warmup=3)),
+                     ("block_cls", lambda: measure_block("block_cls", steps=8, warmup=4)),
+                     ("block_seg", lambda: measure_block("block_seg", steps=8, warmup=4))):
+        try:
+            r = fn()
+            if name != "stress":
+                r = {"config": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "clouds_per_s": r["value"],
+                     "steps": r["steps"], "warmup": r["warmup"], "dominant_kernel": r["roofline"]["kernel"],
+                     "dominant_kernel_us": r["roofline"]["us_per_launch"],
+                     "dominant_launches_per_step": r["roofline"]["launches_per_step"],
+                     "kernel_family_ms_per_step": r["kernel_family_ms_per_step"]}
+            out[name] = r
+        except Exception as e:  # noqa: BLE001  (the headline line must survive)
+            out[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    return out
 
 
 def run_block(args):
+    if args.gpus != 1:
+        raise SystemExit("the block workloads run on one GPU")
+    print(json.dumps(measure_block(args.workload, args.steps, args.warmup)), flush=True)
+    return 0
+
+
+def measure_block(workload, steps, warmup):
     """BASELINE.json configs[1] (block_cls: EdgeConv x2 -> N2P -> sampler 2048->1024 -> N2P -> sampler 1024->512 -> N2P)
     and configs[2] (block_seg: the same path down with 4 bins, interpolation + N2P back up to 2048): one step = forward +
     backward + SGD of the whole block on B=32 clouds of N=2048 xyz points resident in HBM.  One GPU (the metric workload
     carries the multi-GPU contract).  The JSON line has the contract's shape; `roofline` is for the kernel family that
     takes the most time per step, timed by the library's HIP events on its launch stream over the timed steps."""
-    if args.gpus != 1:
-        raise SystemExit("the block workloads run on one GPU")
+    from types import SimpleNamespace
+    args = SimpleNamespace(workload=workload, steps=steps, warmup=warmup)
     from samble_amd import _lib, synth
     from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
     torch.cuda.set_device(0)
@@ -286,8 +447,7 @@ def run_block(args):
         "roofline": roof,
         "kernel_family_ms_per_step": {n: round(v, 3) for n, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
-    print(json.dumps(result), flush=True)
-    return 0
+    return result
 
 
 def main():
@@ -306,6 +466,8 @@ def main():
                          "power / clock probes, where 1e-4 against a fixed random gradient would blow the weights up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
     ap.add_argument("--logit-map", action="store_true",
                     help="A/B: keep the N x (N+nt) logit map in HBM (the round-1 pipeline) instead of the map-free forward")
     ap.add_argument("--backend", default="nccl",
@@ -422,10 +584,12 @@ def main():
     dom = _lib.timing_read(dominant)
     _lib.timing_select([])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    comm = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        comm = measure_collectives(dev, world)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -458,35 +622,52 @@ def main():
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
+        if comm is not None:
+            result["comm"] = comm
         if shared_gpus:
             result["note"] = (f"{world} ranks share {ndev} GPU(s) over {args.backend}: functional check of the N>1 path "
                               "(DDP + boundary all-reduce), not a scaling measurement")
 
-        def pmc_traffic(kernel):
-            # fabric-side bytes per launch from the newest committed rocprofv3 --pmc summary
-            # (profiles/*_pmc.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require)
+        def pmc_entry(kernel):
+            # per-launch counters from the newest committed rocprofv3 --pmc summary (profiles/*_pmc.json: fabric bytes
+            # = (2*FETCH_SIZE + WRITE_SIZE)*1024, separate passes as the counters require; matrix-pipe busy =
+            # SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x 1024 SIMDs x 2.4 GHz))
             try:
                 import glob
                 path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc.json")))[-1]
                 pmc = json.load(open(path))["kernels"]
                 key = next(k for k in pmc if k == kernel or k.startswith(kernel + "<"))  # template arguments vary
-                return pmc[key]["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
+                return pmc[key], "profiles/" + os.path.basename(path)
             except Exception:
                 return None, None
 
-        peak = PEAK_TRI_TFLOPS if tri else PEAK_FP32_MFMA_TFLOPS
+        def pmc_traffic(kernel):
+            e, src = pmc_entry(kernel)
+            return (e.get("traffic_bytes_per_launch"), src) if e else (None, None)
 
-        def roof(kernel, alg_flops, ms, pmc_name):
+        def roof(kernel, alg_flops, ms, pmc_name, timed_as=None):
+            """MFMA roofline of one kernel: achieved = ALGORITHMIC fp32 flops / launch time; peak = what the matrix pipe
+            could deliver of such flops given the 16-bit products this kernel executes per algorithmic product."""
             ach = alg_flops / (ms * 1e-3) / 1e12
-            traffic, src = pmc_traffic(pmc_name)
+            e, src = pmc_entry(pmc_name)
+            if tri:
+                products, why = EXECUTED_PRODUCTS.get(timed_as, (6.0, "three bf16 planes per operand: 6 products"))
+                peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
+            else:
+                products, why, peak = 1.0, "v_mfma_f32_32x32x2_f32 (true fp32 products)", PEAK_FP32_MFMA_TFLOPS
             out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
-                   "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                   "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                   "traffic": e.get("traffic_bytes_per_launch") if e else None,
                    "traffic_source": (f"{src} (rocprofv3 --pmc of an earlier run of this command, not measured in this run)"
                                       if src else None),
-                   "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops}
+                   "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops,
+                   "executed_products": products,
+                   "executed_tflops": round(ach * products, 1),
+                   "mfma_busy": e.get("mfma_busy_frac_at_2.4GHz") if e else None}
             if tri:
-                out["peak_note"] = ("fp32 products as 6 bf16 MFMA products (3 bf16 planes per operand, fp32 accumulate): "
-                                    "peak = dense bf16 2500 TFLOP/s / 6; executed bf16 flop = 6 x algorithmic")
+                out["peak_note"] = (f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products:g} products executed per "
+                                    f"algorithmic fp32 product ({why}); frac = executed 16-bit TFLOP/s / 2500; mfma_busy = "
+                                    "SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC run / (kernel time x 1024 SIMDs x 2.4 GHz)")
                 out["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
             return out
 
@@ -505,24 +686,19 @@ def main():
         def tri_desc(n_):
             """(kernel name, algorithmic flops per launch, rocprof kernel name, note) of a split-bf16 step kernel"""
             if n_ == "knn":
-                return ("knn_duo_kernel", fl["dist"] * B_PER_GPU, "samble::knn_duo_kernel",
-                        "feature-space kNN on two fp16 planes per operand: executed matrix work = 4 fp16 products per "
-                        "(query, key) pair (1 seed + 3 exact) against the 6 bf16 products the ceiling is written for: "
-                        "the fraction of the ceiling of the scheme as executed (2500 / 4) is 2/3 of `frac`")
+                return ("knn_duo_kernel", fl["dist"] * B_PER_GPU, "samble::knn_duo_kernel", None)
             if n_ == "attn_stats":
                 nm = "attn_stats_nl_tri_kernel" if map_free1 else "attn_stats_tri_kernel"
                 return (nm, fl["qk"] * B_PER_GPU, "samble::" + nm, None)
             if n_ == "attn_rows":
                 nm = "attn_rows_rc_tri_kernel" if map_free1 else "attn_rows_tri_kernel"
-                return (nm, fl["av"] * B_PER_GPU, "samble::" + nm,
-                        ("algorithmic flops = P V only (SURVEY 8d: recomputation is not counted); the kernel also "
-                         "recomputes the sampled rows' logits: executed matrix work = 2 x algorithmic") if map_free1 else None)
+                return (nm, fl["av"] * B_PER_GPU, "samble::" + nm, None)
             nm = "bwd_dq_pm_tri_kernel" if map_free1 else "bwd_dq_tri_kernel"
             return (nm, 2 * fl["av"] * B_PER_GPU, "samble::" + nm, None)
 
         if tri:
             nm, flops, pmcn, note = tri_desc(dominant)
-            result["roofline"] = roof(nm, flops, dominant_ms, pmcn)
+            result["roofline"] = roof(nm, flops, dominant_ms, pmcn, timed_as=dominant)
             if note:
                 result["roofline"]["note"] = note
             result["roofline"]["chosen_from_us"] = {n_: round(v[1] * 1e3, 1) for n_, v in seen.items() if v}
@@ -553,7 +729,7 @@ def main():
                 for n_ in ("knn", "attn_stats", "attn_rows", "bwd_dq"):
                     if kt.get(n_):
                         nm, flops, pmcn, note = tri_desc(n_)
-                        r_ = roof(nm, flops, kt[n_][0], pmcn)
+                        r_ = roof(nm, flops, kt[n_][0], pmcn, timed_as=n_)
                         if note:
                             r_["note"] = note
                         mf.append(r_)
@@ -562,10 +738,10 @@ def main():
                     mf.append(roof("bwd_kacc_pm_tri_kernel (dV)" if map_free else "bwd_kacc_tri_kernel<0> (dV)",
                                    2 * M * N * C * B_PER_GPU, kt["bwd_dv"][0],
                                    "samble::bwd_kacc_pm_tri_kernel<false>" if map_free else
-                                   "samble::bwd_kacc_tri_kernel<0, false>"))
+                                   "samble::bwd_kacc_tri_kernel<0, false>", timed_as="bwd_dv"))
                 if kt.get("bwd_dk"):
                     mf.append(roof("bwd_kacc_pm_tri_kernel (dK)", 2 * M * N * C * B_PER_GPU, kt["bwd_dk"][0],
-                                   "samble::bwd_kacc_pm_tri_kernel<false>"))
+                                   "samble::bwd_kacc_pm_tri_kernel<false>", timed_as="bwd_dk"))
             else:
                 if kt.get("attn_stats"):
                     mf.append(roof("attn_stats" + sfx, fl["qk"] * B_PER_GPU, kt["attn_stats"][0], "samble::attn_stats" + sfx))
@@ -578,7 +754,7 @@ def main():
                                     ("proj_dw", ("proj_dw_tri_kernel (+ reduce and token gradients)" if tri else
                                                  "proj_dw_kernel (+ reduce; fp32 MFMA)"), pj)):
                 if kt.get(n_):
-                    r_ = roof(name, flops, kt[n_][0], "samble::" + name.split(" ")[0])
+                    r_ = roof(name, flops, kt[n_][0], "samble::" + name.split(" ")[0], timed_as=n_)
                     if n_ == "proj_dw" and not tri:
                         r_["peak"], r_["frac"] = PEAK_FP32_MFMA_TFLOPS, round(r_["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
                         r_.pop("peak_note", None)
@@ -609,8 +785,16 @@ def main():
                           ms_per_step, "-"))
             result["roofline_hbm_kernels"] = hb
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(seed)
+            result["cpu_baseline"], oracle_out = cpu_baseline(seed)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)
+            try:
+                result["parity"] = parity_vs_oracle(seed, dev, oracle_out)
+            except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra check)
+                result["parity"] = {"error": repr(e)}
+        if world == 1 and args.workload == "metric" and not args.no_extra_workloads:
+            # BASELINE configs[4], [1], [2] with a clock of this run on them: ms/step + the kernel (family) that takes the
+            # most time, a few steps each after the headline's timed region (their own full lines: --workload <name>)
+            result["workloads"] = extra_workloads(args)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

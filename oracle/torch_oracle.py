@@ -530,6 +530,21 @@ def norm_range(x, dim=-1, n_min=0.0, n_max=1.0, mode="minmax"):
     return xn * (n_max - n_min) + n_min
 
 
+def sort_chunk(score, num_bins: int, dim: int = -1, descending: bool = False):
+    """reference utils/ops.py:239-259: sorted scores and their indices, each cut into num_bins chunks."""
+    x_sorted, idx_sorted = torch.sort(score, dim=dim, descending=descending)
+    return torch.chunk(x_sorted, num_bins, dim=dim), torch.chunk(idx_sorted, num_bins, dim=dim)
+
+
+def fps(x, xyz, npoint: int, start: torch.Tensor):
+    """reference utils/ops.py:646-692 (index_points_for_fps + fps) with the first centroid given:
+    x (B,C,N), xyz (B,3,N) -> ((x at the farthest points (B,C,npoint), idx (B,1,npoint)), (None, None))."""
+    idx = farthest_point_sample(xyz.permute(0, 2, 1), npoint, start)
+    pts = x.permute(0, 2, 1)
+    batch = torch.arange(x.shape[0], dtype=torch.long).view(-1, 1).repeat(1, npoint)
+    return (pts[batch, idx, :].permute(0, 2, 1), idx.unsqueeze(1)), (None, None)
+
+
 def local_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "local_std", k: int = 32, asm: str = "dot"):
     """DownSampleLocal (reference models/downsample.py:818-1229) for one head, no boltzmann draw:
     local 1 x K attention of every point over its K nearest neighbours (in feature space), a per-point
@@ -605,7 +620,7 @@ def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -
     return centroids
 
 
-def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm: str = "dot"):
+def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm: str = "dot", knn_k: int = 32):
     """DownSampleGlobal.forward (models/downsample.py:1281-1330, H=1, no res block) with
     attention_scoring (models/downsample.py:1338-1358) for asm dot / dot-sub / l2 / l2+.
     Returns ((x_ds, idx (B,1,M)), (x_dropped, idx_dropped (B,1,N-M)), score (B,1,N))."""
@@ -629,7 +644,28 @@ def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm
     elif idx_mode == "row_std":
         score = torch.std(A, dim=-1)
     else:
-        raise NotImplementedError
+        # idx_selection's sparse branch (models/downsample.py:1383-1401).  NOT DownSampleToken's formulas: the row
+        # deviation runs over all N entries of the masked row (zeros included), the in-degree is used as it is (no
+        # 1e-8, no NaN -> 0: a column nobody lists gives 0/0 = NaN, which topk ranks first)
+        mask, _ = knn_mask(x, knn_k)
+        mask4 = mask.unsqueeze(1).expand(-1, A.shape[1], -1, -1)
+        sam = A * mask4
+        num = torch.sum(mask4, dim=-2)
+        if idx_mode == "sparse_row_sum":
+            score = torch.sum(sam, dim=-1)
+        elif idx_mode == "sparse_row_std":
+            score = torch.std(sam, dim=-1)
+        elif idx_mode == "sparse_col_sum":
+            score = torch.sum(sam, dim=-2)
+        elif idx_mode == "sparse_col_avg":
+            score = torch.sum(sam, dim=-2) / num
+        elif idx_mode == "sparse_col_sqr":
+            score = torch.sum(sam, dim=-2) / num / num
+        elif idx_mode == "sparse_col_sum_sqr":
+            cs = torch.sum(sam, dim=-2)
+            score = 0.5 * (cs / num / num) + 0.5 * cs
+        else:
+            raise ValueError("Please check the setting of idx mode!")
     idx = score.topk(M, dim=-1)[1]
     idx_dropped = torch.sum(A, dim=-2).topk(N - M, dim=-1, largest=False)[1]
     def rows(ix):

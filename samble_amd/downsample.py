@@ -92,7 +92,7 @@ class _SamplerCore(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, qkv, x, mod, noise, images=None):
+    def forward(ctx, qkv, x, mod, noise, images=None, forced_idx=None):
         B, C, N = x.shape
         D = mod.q_depth
         nt = qkv.shape[1] - N
@@ -199,6 +199,10 @@ class _SamplerCore(torch.autograd.Function):
                                                          mod.relu_mean_order == "relu_mean")
             counts = ops.stage_alloc_counts(w, cap, mod.M)
         idx = ops.stage_bin_select(score, z, member, counts, mod.M, mod.bin_sample_mode, mod.boltzmann_T, noise)
+        if forced_idx is not None:
+            # parity-test hook: the rows to gather are given (the reference's own sampled indices), everything before
+            # this line still ran and is returned as measured
+            idx = forced_idx.reshape(B, mod.M).to(device=x.device, dtype=torch.int64).contiguous()
         # saved for backward: (qkv, O | x_ds, lse, idx[, map[, K transposed image, V row image]]) -- everything through
         # save_for_backward (hooks and version checks see it), nothing when no gradient is wanted
         ctx.pmap = False
@@ -257,7 +261,7 @@ class _SamplerCore(torch.autograd.Function):
             else:
                 dqkv[:, :N, 0:D] += scale * torch.matmul(g_tok, k[:, N:, :])
                 dqkv[:, N:, D:2 * D] += scale * torch.matmul(g_tok.transpose(1, 2), q)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class DownSampleToken(nn.Module):
@@ -335,7 +339,10 @@ class DownSampleToken(nn.Module):
             return None
         return ops._member_to_mask(self._member_bits, self.num_bins)
 
-    def forward(self, x, x_xyz=None, noise: Optional[torch.Tensor] = None):
+    def forward(self, x, x_xyz=None, noise: Optional[torch.Tensor] = None, forced_idx: Optional[torch.Tensor] = None):
+        """noise: the (B*nb, N) Exp(1) draw torch.multinomial makes inside (None: drawn on the device).
+        forced_idx (B,1,M) | (B,M): parity-test hook -- gather these rows instead of the ones the selection produced
+        (scores, bins, counts and boundaries are still computed and published as usual)."""
         B, C, N = x.shape
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
@@ -355,7 +362,7 @@ class DownSampleToken(nn.Module):
             qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
 
         (x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx) = _SamplerCore.apply(
-            qkv, x.detach(), self, noise, tuple(images) if images is not None else None)
+            qkv, x.detach(), self, noise, tuple(images) if images is not None else None, forced_idx)
 
         index_down = idx.unsqueeze(1)
         if self.res is True:
@@ -406,6 +413,38 @@ class DownSampleToken(nn.Module):
         return variables
 
 
+GLOBAL_SPARSE_MODES = ("sparse_row_sum", "sparse_row_std", "sparse_col_sum", "sparse_col_avg", "sparse_col_sqr",
+                       "sparse_col_sum_sqr")
+
+
+def _global_sparse_statistic(mode, N, K, stat_of):
+    """DownSampleGlobal.idx_selection's sparse branch (reference models/downsample.py:1383-1401) from the kernels'
+    DownSampleToken statistics.  stat_of(token_mode) -> (statistic (B,N), in-degree (B,N) int32).  The reference's Global
+    formulas differ from DownSampleToken's: the row deviation is torch.std over ALL N entries of the masked row (zeros
+    included), the column averages divide by the raw in-degree (>= 1: every point lists itself), and
+    sparse_col_sum_sqr exists."""
+    if mode == "sparse_row_sum":
+        return stat_of("sparse_row_sum")[0]
+    if mode == "sparse_row_std":
+        # the kernel gives s1 = sum and the unbiased deviation over the K picked entries; the other N-K entries are 0
+        s1 = stat_of("sparse_row_sum")[0].double()
+        sk = stat_of("sparse_row_std")[0].double()
+        s2 = sk * sk * (K - 1) + s1 * s1 / K
+        return torch.sqrt(torch.clamp((s2 - s1 * s1 / N) / (N - 1), min=0.0)).float()
+    cs, indeg = stat_of("sparse_col_sum")
+    num = indeg.float()
+    if mode == "sparse_col_sum":
+        return cs
+    if mode == "sparse_col_avg":
+        return cs / num
+    if mode == "sparse_col_sqr":
+        return cs / num / num
+    if mode == "sparse_col_sum_sqr":
+        return 0.5 * (cs / num / num) + 0.5 * cs
+    raise ValueError("Please check the setting of idx mode!")
+
+
+
 class _GlobalCore(torch.autograd.Function):
     """qkv (B,N,3D) -> x_ds (B,D,M), x_dropped (B,D,N-M) + indices, for DownSampleGlobal."""
 
@@ -423,13 +462,17 @@ class _GlobalCore(torch.autograd.Function):
             col = ops.stage_attn_colsum(q, k, lse)
             if mod.idx_mode == "col_sum":
                 stat = col
-            elif mod.idx_mode in ops.SCORE_MODES:
+            elif mod.idx_mode in GLOBAL_SPARSE_MODES:
                 nn_idx = ops.stage_knn(x, x, mod.K)
-                stat, _, _ = ops.stage_sparse_score(q, k, lse, nn_idx, mod.idx_mode)
+                stat = _global_sparse_statistic(
+                    mod.idx_mode, N, mod.K,
+                    lambda m: (lambda r: (r[0], r[2]))(ops.stage_sparse_score(q, k, lse, nn_idx, m))).contiguous()
             else:
                 raise ValueError("Please check the setting of idx mode!")
         idx = ops.stage_topk_indices(stat, mod.M, largest=True)
         idx_dropped = ops.stage_topk_indices(col, N - mod.M, largest=False)
+        if mod._forced_idx is not None:
+            idx, idx_dropped = mod._forced_idx
         x_ds = ops.stage_gather_rows(O, idx)
         x_dropped = ops.stage_gather_rows(O, idx_dropped)
         ctx.save_for_backward(qkv, O, lse, idx, idx_dropped)
@@ -477,13 +520,18 @@ class _GlobalMapCore(torch.autograd.Function):
             stat = col
         elif mod.idx_mode == "row_std":
             stat = torch.std(A, dim=-1).contiguous()
-        elif mod.idx_mode in ops.SCORE_MODES:
-            stat, _, _ = ops.stage_sparse_score_map(smap, lse, ops.stage_knn(x, x, mod.K), mod.idx_mode)
+        elif mod.idx_mode in GLOBAL_SPARSE_MODES:
+            nn_idx = ops.stage_knn(x, x, mod.K)
+            stat = _global_sparse_statistic(
+                mod.idx_mode, N, mod.K,
+                lambda m: (lambda r: (r[0], r[2]))(ops.stage_sparse_score_map(smap, lse, nn_idx, m))).contiguous()
         else:
             raise ValueError("Please check the setting of idx mode!")
         del A
         idx = ops.stage_topk_indices(stat, mod.M, largest=True)
         idx_dropped = ops.stage_topk_indices(col, N - mod.M, largest=False)
+        if mod._forced_idx is not None:
+            idx, idx_dropped = mod._forced_idx
         x_ds = torch.gather(o_all, 2, idx.unsqueeze(1).expand(-1, D, -1))
         x_dropped = torch.gather(o_all, 2, idx_dropped.unsqueeze(1).expand(-1, D, -1))
         ctx.save_for_backward(qkv, o_all, lse, idx, idx_dropped, smap, rows)
@@ -544,10 +592,17 @@ class DownSampleGlobal(nn.Module):
             raise ValueError("Please check the setting of asm!")
         if self.num_heads != 1 or not (q_in == q_out == k_out == v_out == 128):
             raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
+        self._forced_idx = None
 
-    def forward(self, x, x_xyz=None):
+    def forward(self, x, x_xyz=None, forced_idx=None):
+        """forced_idx = (idx (B,1,M), idx_dropped (B,1,N-M)): parity-test hook -- gather these rows instead of the
+        selected ones (the statistic is still computed and published as `attention`)."""
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
+        B, N = x.shape[0], x.shape[2]
+        self._forced_idx = None if forced_idx is None else (
+            forced_idx[0].reshape(B, self.M).to(device=x.device, dtype=torch.int64).contiguous(),
+            forced_idx[1].reshape(B, N - self.M).to(device=x.device, dtype=torch.int64).contiguous())
         no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
         # attention_scoring (models/downsample.py:1338-1358).  dot-sub: energy = Q (Q^T - K) with Q^T, K both (D, N):
         # energy_ij = <q_i, q_j - k_j> -- dot attention with the keys Q - K, i.e. the key weights W_q - W_k (the convs
@@ -677,7 +732,9 @@ class DownSampleLocal(nn.Module):
         if self.idx_mode not in ("local_std", "sparse_row_std", "sparse_col_sum", "sparse_col_avg", "sparse_col_sqr"):
             raise ValueError("Please check the setting of idx mode!")
 
-    def forward(self, x, x_xyz=None):
+    def forward(self, x, x_xyz=None, forced_idx=None):
+        """forced_idx = (idx (B,1,M), idx_dropped (B,1,N-M)): parity-test hook -- gather these columns instead of the
+        selected ones (score and attention map are still computed and published)."""
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape
@@ -708,6 +765,9 @@ class DownSampleLocal(nn.Module):
         if self.boltzmann_enable:
             idx = self.boltzmann_idx_selection()[:, 0]
         idx_dropped = ops.stage_topk_indices(std, N - self.M, largest=False)
+        if forced_idx is not None:
+            idx = forced_idx[0].reshape(B, self.M).to(device=x.device, dtype=torch.int64)
+            idx_dropped = forced_idx[1].reshape(B, N - self.M).to(device=x.device, dtype=torch.int64)
         self.idx = idx.unsqueeze(1)
         x_ds = torch.gather(x_all, 2, self.idx.expand(-1, C, -1))
         x_dropped = torch.gather(x_all, 2, idx_dropped.unsqueeze(1).expand(-1, C, -1))
@@ -726,8 +786,10 @@ class DownSampleLocal(nn.Module):
                                 self.v_conv.weight.view(C, C, 1))
         nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
         q, k, v = qkv[:, :, 0:C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
-        gather_at = nn_idx.long().reshape(B, N * self.K, 1).expand(-1, -1, C)
-        kbar = torch.gather(k, 1, gather_at).view(B, N, self.K, C).mean(dim=2)
+        # kbar = mean of the K neighbour keys, as an embedding-bag lookup over the (B*N, C) table of projected keys: no
+        # (B, N, K, C) intermediate (1.07 GB at B=32, N=2048) in the forward, a segment reduction in the backward
+        flat = (nn_idx.long() + torch.arange(B, device=x.device).view(B, 1, 1) * N).reshape(B * N, self.K)
+        kbar = F.embedding_bag(flat, k.reshape(B * N, C), mode="mean").view(B, N, C)
         qe = (q - kbar) if self.asm == "l2" else (kbar - q)
         out, att = _N2PAttention.apply(torch.cat((qe, k, v), dim=-1), nn_idx)
         return out, att, nn_idx

@@ -448,6 +448,10 @@ def stage_bin_select(score, z, member, counts, M: int, sample_mode: str, boltzma
     if sample_mode == "random":
         temp_mode, temp = boltzmann_temperature(boltzmann_t, N, nb)
     if sample_mode in ("uniform", "random"):
+        if noise is None and philox is None and torch.cuda.is_current_stream_capturing():
+            # under stream capture a host-side bump of the generator offset is not replayed (every replay would draw
+            # the same numbers): draw the Exp(1) tensor with torch's graph-safe generator path instead
+            noise = torch.empty((B * nb, N), dtype=torch.float32, device=score.device).exponential_()
         if noise is None:
             seed, offset = philox if philox is not None else philox_state(score.device)
             with torch.cuda.device(score.device):
@@ -1010,6 +1014,64 @@ def gather_by_idx(pcd, idx):
         out = torch.empty((B, C, M), dtype=torch.float32, device=pcd.device)
         _lib.call("samble_gather_points_f32", pcd.data_ptr(), B, C, N, idx2.data_ptr(), M, out.data_ptr(), _stream())
     return out
+
+
+def index_points_for_fps(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """utils/ops.py:646-667: points (B,N,C), idx (B,S) -> (B,S,C)."""
+    return torch.gather(points, 1, idx.long().unsqueeze(-1).expand(-1, -1, points.shape[-1]))
+
+
+def fps(x: torch.Tensor, xyz: torch.Tensor, npoint: int):
+    """utils/ops.py:670-692: x (B,C,N), xyz (B,3,N) -> ((x at the npoint farthest points (B,C,npoint), idx (B,1,npoint)),
+    (None, None)) -- the sampler-shaped return of the reference, on the HIP farthest-point kernel + the HIP column gather."""
+    fps_idx = farthest_point_sample(xyz.permute(0, 2, 1), npoint)
+    return (gather_by_idx(x, fps_idx.unsqueeze(1)), fps_idx.unsqueeze(1)), (None, None)
+
+
+def l2_global(q: torch.Tensor, k: torch.Tensor) -> torch.Tensor:
+    """utils/ops.py:115-122: q (B,H,N,D), k (B,H,D,N) -> |q_i - k_j|^2 as the dense (B,H,N,N) tensor, the reference's own
+    three-term expression.  API parity only: the samplers and Point2PointAttention never build this tensor (the norm
+    terms enter the logits inside attn_stats / attn_heads)."""
+    _need_gpu(q, k)
+    inner = -2 * torch.matmul(q, k)
+    qq = torch.sum(q ** 2, dim=-1, keepdim=True)
+    kk = torch.sum(k.transpose(-2, -1) ** 2, dim=-1, keepdim=True)
+    return qq + inner + kk.transpose(-2, -1)
+
+
+def norm_range(x: torch.Tensor, dim: int = -1, n_min=0, n_max=1, mode: str = "minmax") -> torch.Tensor:
+    """utils/ops.py:148-171 (minmax / sigmoid / tanh rescaled to [n_min, n_max]; z-score shifted by n_min)."""
+    _need_gpu(x)
+    if mode == "minmax":
+        lo = torch.min(x, dim=dim, keepdim=True)[0]
+        x_norm = (x - lo) / (torch.max(x, dim=dim, keepdim=True)[0] - lo + 1e-8)
+    elif mode == "sigmoid":
+        x_norm = torch.sigmoid(x)
+    elif mode == "tanh":
+        x_norm = (torch.tanh(x) + 1.0) / 2
+    elif mode == "z-score":
+        if x.dtype == torch.float32 and dim in (-1, x.dim() - 1) and x.is_contiguous():
+            return stage_zscore(x.reshape(-1, x.shape[-1])).view_as(x) + n_min     # the sampler's own z-score kernel
+        return (x - torch.mean(x, dim=dim, keepdim=True)) / torch.std(x, dim=dim, unbiased=False, keepdim=True) + n_min
+    else:
+        raise ValueError(f"norm_range mode should be minmax, sigmoid or tanh, but got {mode}")
+    return x_norm * (n_max - n_min) + n_min
+
+
+def sort_chunk(attention_point_score: torch.Tensor, num_bins: int, dim: int = -1, descending: bool = False):
+    """utils/ops.py:239-259: score (B,H,N) -> (num_bins value chunks, num_bins index chunks) of the sorted scores
+    (torch.chunk's sizes: ceil(N / num_bins) each, the last one shorter).  fp32 along the last dimension, N <= 8192: the
+    HIP select kernel's full ordering (exact ties by ascending index, where torch.sort leaves them unspecified)."""
+    _need_gpu(attention_point_score)
+    x = attention_point_score
+    if x.dtype == torch.float32 and dim in (-1, x.dim() - 1) and x.shape[-1] <= 8192:
+        flat = _f32c(x.reshape(-1, x.shape[-1]))
+        order = stage_topk_indices(flat, flat.shape[1], largest=descending)
+        idx_sorted = order.view(*x.shape[:-1], x.shape[-1])
+        x_sorted = torch.gather(x, -1, idx_sorted)
+    else:
+        x_sorted, idx_sorted = torch.sort(x, dim=dim, descending=descending)
+    return torch.chunk(x_sorted, num_bins, dim=dim), torch.chunk(idx_sorted, num_bins, dim=dim)
 
 
 def world_average(t: torch.Tensor) -> torch.Tensor:

@@ -210,6 +210,10 @@ def run_case(case, case_id):
             x_ds_r.backward(torch.from_numpy(g_np))
             # oracle grads from a fresh copy of the pre-call boundary state
             out[p + "dx_sum"] = np.array([xr.grad.double().sum().item(), (xr.grad.double() ** 2).sum().item()])
+            # per cloud as well (dx is separable per cloud): lets a test compare the clouds whose sampled indices
+            # agree even where the full dx is not stored
+            out[p + "dx_cloud_sums"] = np.stack([xr.grad.double().sum((1, 2)).numpy(),
+                                                 (xr.grad.double() ** 2).sum((1, 2)).numpy()], axis=1)
             grads = dict(dx=xr.grad, dwq=mod.q_conv.weight.grad, dwk=mod.k_conv.weight.grad,
                          dwv=mod.v_conv.weight.grad, dtokens=mod.bin_tokens.grad)
             leaves = [t.detach().clone().requires_grad_(True) for t in (x, st.wq, st.wk, st.wv, st.tokens)]

@@ -74,11 +74,22 @@ def test_module_against_reference_fixture(name, matrix_mode):
                 continue
             got_b, ref_b = idx.cpu()[b, 0], g.t("idx", call)[b, 0]
             if not bool(counts_same[b]):
-                # (1) one pick moved between two bins: the truncation flip of the water-filling
+                # (1) one pick moved between two bins: the truncation flip of the water-filling.  Evidence per cloud:
+                # the integer stage is exact on both sides -- the reference's water-filling (oracle) run on OUR bin
+                # weights gives OUR counts, run on the fixture's weights it gives the fixture's -- and the weights
+                # themselves agree to 2e-6
                 dc = (mod.k_point_to_choose.cpu()[b].long() - g.t("counts", call)[b].long())
                 assert int(dc.abs().sum()) == 2 and int(dc.sum()) == 0, dc.tolist()
                 torch.testing.assert_close(mod.bin_weights_beforerelu.cpu()[b], g.t("w_pre", call)[b], rtol=2e-6,
                                            atol=1e-7)
+                cap = g.t("cap", call).long()
+                assert torch.equal(mod.max_num_points.cpu().long(), cap), "bin populations"
+                w_ours = torch.relu(mod.bin_weights_beforerelu.cpu()) if g.relu_mean_order == "mean_relu" else \
+                    mod.bin_weights_beforerelu.cpu()
+                w_ref = torch.relu(g.t("w_pre", call)) if g.relu_mean_order == "mean_relu" else g.t("w_pre", call)
+                if g.relu_mean_order == "mean_relu":
+                    assert torch.equal(O.allocate_counts(w_ours.clone(), cap, g.M)[b], mod.k_point_to_choose.cpu()[b])
+                    assert torch.equal(O.allocate_counts(w_ref.clone(), cap, g.M)[b], g.t("counts", call)[b].int())
                 assert len(set(got_b.tolist()) ^ set(ref_b.tolist())) <= 2
             else:
                 # (2) same counts: a near-tie of two selection keys (or of two scores at a bin boundary) resolved
@@ -88,15 +99,50 @@ def test_module_against_reference_fixture(name, matrix_mode):
         assert set_agreement(idx.cpu()[:, 0], g.t("idx", call)[:, 0]) >= 0.99
         if g.has("x_ds", call):
             torch.testing.assert_close(x_ds.detach().cpu()[same], g.t("x_ds", call)[same], rtol=1e-4, atol=2e-5)
-        if last and bool(same.all()):
-            x_ds.backward(g.upstream().to(DEV))
+        if not last:
+            continue
+        # gradients.  dx is separable per cloud: always compared on the clouds whose indices are the reference's; the
+        # parameter gradients sum over the batch, so they are compared when every cloud is identical AND, on every
+        # fixture, in a second pass that gathers the reference's own indices (forced_idx: tests/golden/make_golden.py
+        # forms the reference gradients the same way, through its idx)
+        up = g.upstream().to(DEV)
+        x_ds.backward(up)
+
+        def check_params(tag):
             for got, key in ((mod.q_conv.weight.grad, "dwq"), (mod.k_conv.weight.grad, "dwk"),
-                             (mod.v_conv.weight.grad, "dwv"), (mod.bin_tokens.grad, "dtokens"), (x.grad, "dx")):
+                             (mod.v_conv.weight.grad, "dwv"), (mod.bin_tokens.grad, "dtokens")):
                 if not g.has(key, call):
                     continue
                 ref = g.t(key, call)
                 err = (got.cpu() - ref).abs().max().item()
-                assert err <= 2e-4 * ref.abs().max().item() + 1e-6, (key, err)
+                assert err <= 2e-4 * ref.abs().max().item() + 1e-6, (tag, key, err)
+
+        def check_dx(grad, rows, tag):
+            gd = grad.cpu().double()
+            if g.has("dx", call) and bool(rows.any()):
+                ref = g.t("dx", call)
+                err = (grad.cpu()[rows] - ref[rows]).abs().max().item()
+                assert err <= 2e-4 * ref.abs().max().item() + 1e-6, (tag, "dx", err)
+            if g.has("dx_cloud_sums", call) and bool(rows.any()):
+                # every fixture: per-cloud (sum, sum of squares) of dx in float64 -- the big fixture stores no full dx
+                ref = g.t("dx_cloud_sums", call)[rows]
+                got = torch.stack([gd.sum((1, 2)), gd.square().sum((1, 2))], dim=1)[rows]
+                n = gd[0].numel()
+                assert bool(((got[:, 1] - ref[:, 1]).abs() <= 1e-3 * ref[:, 1]).all()), (tag, "dx sum of squares")
+                assert bool(((got[:, 0] - ref[:, 0]).abs() <= 2e-4 * (n * ref[:, 1]).sqrt() + 1e-6).all()), (tag, "dx sum")
+
+        check_dx(x.grad, same, "own idx")
+        if bool(same.all()):
+            check_params("own idx")
+        mod.zero_grad()
+        x2 = g.x(call).to(DEV).requires_grad_(True)
+        (x_ds2, idx2), _ = mod(x2, noise=noise, forced_idx=g.t("idx", call).to(DEV))
+        assert torch.equal(idx2.cpu(), g.t("idx", call))
+        if g.has("x_ds", call):
+            torch.testing.assert_close(x_ds2.detach().cpu(), g.t("x_ds", call), rtol=1e-4, atol=2e-5)
+        x_ds2.backward(up)
+        check_dx(x2.grad, torch.ones(g.B, dtype=torch.bool), "reference idx")
+        check_params("reference idx")
 
 
 def test_state_dict_keys_and_forward_contract():
@@ -153,19 +199,24 @@ def test_metric_size_properties_and_determinism():
     mod2.load_state_dict(mod.state_dict())
     (x_ds2, idx2), _ = mod2(x, noise=noise)
     assert torch.equal(idx2, idx) and torch.equal(x_ds2, x_ds)
-    # oracle on 4 of the clouds (dense N x N on CPU) with the GPU's boundaries: sampled sets agree
-    sub = slice(0, 4)
+    # the oracle on ALL 32 clouds (dense N x N on the CPU, a few seconds) under the GPU's boundaries: the end-to-end index
+    # match rate at the headline configuration, asserted and printed ("stage-wise bit-exactness plus a
+    # reported end-to-end index match rate"; reference utils/ops.py:467-619)
     spec = O.SamplerSpec(M=M, K=32, C=C, num_bins=nb, dynamic_boundaries=False)
     st = O.SamplerState(mod.q_conv.weight.detach().cpu(), mod.k_conv.weight.detach().cpu(),
                         mod.v_conv.weight.detach().cpu(), mod.bin_tokens.detach().cpu(),
                         [t.cpu().clone() for t in mod.bin_boundaries])
-    nz = noise.cpu().reshape(B, nb, N)[sub].reshape(-1, N)
-    x_ref, idx_ref = O.sampler_forward(spec, st, x.cpu()[sub], nz)
-    agree = set_agreement(idx[sub, 0].cpu(), idx_ref[:, 0])
+    x_ref, idx_ref = O.sampler_forward(spec, st, x.cpu(), noise.cpu())
+    agree = set_agreement(idx[:, 0].cpu(), idx_ref[:, 0])
+    same_rows = (idx[:, 0].cpu() == idx_ref[:, 0]).all(1)
+    pos = float((idx[:, 0].cpu() == idx_ref[:, 0]).float().mean())
+    print(f"\nmetric size B={B} N={N}->{M}: clouds with the oracle's exact index tensor {int(same_rows.sum())} of {B}; "
+          f"positions identical {pos:.5f}; sampled-set agreement {agree:.5f}")
     assert agree >= 0.995, agree
-    same_rows = (idx[sub, 0].cpu() == idx_ref[:, 0]).all(1)
-    if bool(same_rows.any()):
-        torch.testing.assert_close(x_ds[sub].cpu()[same_rows], x_ref[same_rows], rtol=1e-4, atol=2e-5)
+    assert int(same_rows.sum()) >= B // 2, int(same_rows.sum())
+    for b in range(B):   # a cloud that differs does so by a handful of points (near-ties of keys / one count flip)
+        assert len(set(idx[b, 0].tolist()) ^ set(idx_ref[b, 0].tolist())) <= 8, b
+    torch.testing.assert_close(x_ds.cpu()[same_rows], x_ref[same_rows], rtol=1e-4, atol=2e-5)
 
 
 def test_stress_size_properties():
@@ -212,11 +263,25 @@ def test_stress_size_properties():
     assert float(same[same_counts].float().mean()) >= 0.99
     keep = same[:, None, :].expand_as(x_ds)
     torch.testing.assert_close(x_ds1[keep], x_ds[keep], rtol=1e-4, atol=2e-5)
-    if bool(same.all()):
-        scale = float(dx2.abs().max())
-        assert float((x1.grad - dx2).abs().max()) <= 2e-4 * scale
-        for a, b2 in zip(grads2, [p.grad for p in mod1.parameters()]):
-            assert float((a - b2).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7
+    # dx is separable per cloud: compared on every cloud whose index tensor agrees; the parameter gradients (sums over
+    # the batch) through a second backward of the single-pass path on the two-pass path's indices
+    rows = same.all(1)
+    assert int(rows.sum()) >= B // 2
+    scale = float(dx2.abs().max())
+    assert float((x1.grad[rows] - dx2[rows]).abs().max()) <= 2e-4 * scale
+    mod1.zero_grad()
+    x3 = x.detach().clone().requires_grad_(True)
+    D.TWO_PASS = False
+    try:
+        (x_ds3, idx3), _ = mod1(x3, noise=noise, forced_idx=idx)
+        x_ds3.backward(g)
+    finally:
+        D.TWO_PASS = True
+    assert torch.equal(idx3, idx)
+    torch.testing.assert_close(x_ds3, x_ds, rtol=1e-4, atol=2e-5)
+    assert float((x3.grad - dx2).abs().max()) <= 2e-4 * scale
+    for a, b2 in zip(grads2, [p.grad for p in mod1.parameters()]):
+        assert float((a - b2).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7
 
 
 def test_seg_preset_and_second_layer_shape():
@@ -288,15 +353,23 @@ def test_res_block_against_reference_fixture(name, matrix_mode):
             assert torch.equal(b.cpu(), refb)
 
 
-@pytest.mark.parametrize("name", golden_names())
+def _map_free_fixtures():
+    """the fixtures the map-free forward serves: a sparse_* score mode with dot-product logits"""
+    out = []
+    for n in golden_names():
+        g = Golden(n)
+        if g.idx_mode.startswith("sparse") and g.asm == "dot":
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("name", _map_free_fixtures())
 def test_map_free_module_equals_map_module(name):
     """DownSampleToken with and without the logit map (downsample.MAP_FREE): same indices, same x_ds, same
     boundaries and same input / parameter gradients, bit for bit, on the reference fixtures' inputs."""
     import samble_amd.downsample as D
     from samble_amd import ops
     g = Golden(name)
-    if not g.idx_mode.startswith("sparse") or g.asm != "dot":
-        pytest.skip("the map-free forward serves the sparse_* score modes with dot-product logits")
     outs = []
     old_mode, old_free = ops.MATRIX_MODE, D.MAP_FREE
     try:

@@ -1181,3 +1181,42 @@ def test_rows_backward_clears_the_token_rows_of_dq_on_request():
                                    block[:, :, 2 * D:], dq_token_rows=True)
     finally:
         o_.MATRIX_MODE = old
+
+
+def test_small_ops_against_reference_vectors():
+    """norm_range, sort_chunk, l2_global, fps (reference utils/ops.py:148-171, 239-259, 115-122, 646-692) against vectors
+    from the unmodified reference (tests/golden/make_golden_ops.py)."""
+    import os
+    from tests.util import GOLDEN_DIR
+    d = np.load(os.path.join(GOLDEN_DIR, "layer_ops_small.npz"))
+    B, H, N, D, nb, seed = [int(v) for v in d["meta"]]
+    o_ = ops()
+    score = torch.from_numpy(synth.normal((B, H, N), seed)) * 0.7 + 0.1
+    score[0, 0, 17] = score[0, 0, 400]
+    sg = score.to(DEV)
+    for mode in ("minmax", "sigmoid", "tanh", "z-score"):
+        got = o_.norm_range(sg, dim=-1, n_min=0.25, n_max=2.0, mode=mode)
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(d["norm_" + mode.replace("-", "")]), rtol=2e-6, atol=2e-6)
+    with pytest.raises(ValueError):
+        o_.norm_range(sg, mode="bogus")
+    for tag, desc in (("asc", False), ("desc", True)):
+        xs, ids = o_.sort_chunk(sg, nb, dim=-1, descending=desc)
+        assert [t.shape[-1] for t in xs] == d[f"chunk_sizes_{tag}"].tolist() and len(ids) == nb
+        # values are exact (a sort moves values, it does not compute); indices agree except inside the exact tie
+        assert torch.equal(torch.cat(xs, dim=-1).cpu(), torch.from_numpy(d[f"sorted_{tag}"]))
+        order = torch.cat(ids, dim=-1).cpu()
+        ref = torch.from_numpy(d[f"order_{tag}"])
+        assert order.dtype == torch.int64 and int((order != ref).sum()) <= 2
+        assert torch.equal(torch.gather(score, -1, order), torch.from_numpy(d[f"sorted_{tag}"]))
+    q = torch.from_numpy(synth.normal((B, H, 40, D), seed + 1)).to(DEV)
+    k = torch.from_numpy(synth.normal((B, H, D, 40), seed + 2)).to(DEV)
+    torch.testing.assert_close(o_.l2_global(q, k).cpu(), torch.from_numpy(d["l2_global"]), rtol=1e-5, atol=1e-5)
+    Bf, Nf, Cf, npnt, sd = [int(v) for v in d["fps_meta"]]
+    xyz = torch.from_numpy(synth.xyz_clouds(Bf, Nf, sd + 3)).to(DEV)
+    x = torch.from_numpy(synth.normal((Bf, Cf, Nf), sd + 4)).to(DEV)
+    idx = o_.farthest_point_sample(xyz.permute(0, 2, 1), npnt, torch.from_numpy(d["fps_start"]).to(DEV))
+    assert torch.equal(idx.cpu(), torch.from_numpy(d["fps_idx"])[:, 0])
+    assert torch.equal(o_.index_points_for_fps(x.permute(0, 2, 1), idx).permute(0, 2, 1).cpu(), torch.from_numpy(d["fps_x"]))
+    (xf, idf), rest = o_.fps(x, xyz, npnt)      # (its own torch.randint start: shapes and the gather relation)
+    assert rest == (None, None) and idf.shape == (Bf, 1, npnt) and xf.shape == (Bf, Cf, npnt)
+    assert torch.equal(xf, torch.gather(x, 2, idf.expand(-1, Cf, -1)))

@@ -116,3 +116,29 @@ def test_oracle_local_sampler_reproduces_reference_fixtures():
         torch.testing.assert_close(score, torch.from_numpy(d["score"]), rtol=1e-4, atol=1e-7)
         assert torch.equal(idx, torch.from_numpy(d["idx"])) and torch.equal(idx_dr, torch.from_numpy(d["idx_dropped"]))
         torch.testing.assert_close(x_ds, torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_small_ops_reproduce_reference_vectors():
+    """norm_range / sort_chunk / l2_global / fps of the oracle against the reference's vectors (make_golden_ops.py)."""
+    import os
+    from samble_amd import synth
+    from tests.util import GOLDEN_DIR
+    d = np.load(os.path.join(GOLDEN_DIR, "layer_ops_small.npz"))
+    B, H, N, D, nb, seed = [int(v) for v in d["meta"]]
+    score = torch.from_numpy(synth.normal((B, H, N), seed)) * 0.7 + 0.1
+    score[0, 0, 17] = score[0, 0, 400]
+    for mode in ("minmax", "sigmoid", "tanh", "z-score"):
+        torch.testing.assert_close(O.norm_range(score, dim=-1, n_min=0.25, n_max=2.0, mode=mode),
+                                   torch.from_numpy(d["norm_" + mode.replace("-", "")]), rtol=1e-6, atol=1e-6)
+    for tag, desc in (("asc", False), ("desc", True)):
+        xs, ids = O.sort_chunk(score, nb, dim=-1, descending=desc)
+        assert torch.equal(torch.cat(xs, dim=-1), torch.from_numpy(d[f"sorted_{tag}"]))
+        assert int((torch.cat(ids, dim=-1) != torch.from_numpy(d[f"order_{tag}"])).sum()) <= 2
+    q = torch.from_numpy(synth.normal((B, H, 40, D), seed + 1))
+    k = torch.from_numpy(synth.normal((B, H, D, 40), seed + 2))
+    torch.testing.assert_close(O.l2_global(q, k), torch.from_numpy(d["l2_global"]), rtol=1e-6, atol=1e-6)
+    Bf, Nf, Cf, npnt, sd = [int(v) for v in d["fps_meta"]]
+    xyz = torch.from_numpy(synth.xyz_clouds(Bf, Nf, sd + 3))
+    x = torch.from_numpy(synth.normal((Bf, Cf, Nf), sd + 4))
+    (xf, idf), _ = O.fps(x, xyz, npnt, torch.from_numpy(d["fps_start"]))
+    assert torch.equal(idf, torch.from_numpy(d["fps_idx"])) and torch.equal(xf, torch.from_numpy(d["fps_x"]))
