@@ -31,6 +31,8 @@ extern "C" {
 #define SAMBLE_E_INVALID (-22)     /* bad argument / unsupported shape */
 #define SAMBLE_E_WORKSPACE (-12)   /* workspace too small */
 #define SAMBLE_E_HIP_BASE (-1000)  /* -1000 - hipError_t */
+#define SAMBLE_E_TIMEOUT (-110)    /* a grid barrier of the fused select chain gave up (reported through the chain's status
+                                      word, samble_select_chain_status_async: no entry point synchronises to return it) */
 
 /* score modes (reference models/downsample.py:315-340) */
 #define SAMBLE_SCORE_SPARSE_COL_SUM 0
@@ -323,11 +325,16 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
                              float* dQ, int64_t dq_bs, int64_t dq_rs, float* dK, int64_t dk_bs, int64_t dk_rs, float* dV,
                              int64_t dv_bs, int64_t dv_rs, float* ds_colsum, void* ws, size_t ws_bytes, void* stream);
 
-/* ---- the integer tail as two launches (same reference lines as the stand-alone entries above) ----------------
+/* ---- the integer tail as two launches, or one (same reference lines as the stand-alone entries above) ----------------
  * For shapes samble_select_chain_supported(B, N, nb) accepts (one 1024-thread workgroup per cloud, all resident:
- * B <= min(128, CUs / 2), B * nb <= 1024, N <= 16384; the grid barrier's poll is bounded: if the workgroups turn out
- * not to be co-resident the kernel traps after ~1 s and the next entry point reports the HIP error), over ONE caller-owned workspace of
- * samble_select_chain_workspace_bytes(B, N):
+ * B <= min(128, CUs / 2), B * nb <= 1024, N <= 16384), over ONE caller-owned workspace of
+ * samble_select_chain_workspace_bytes(B, N).
+ * The grid barrier's poll is BOUNDED and its give-up is CLEAN: if the workgroups turn out not to be co-resident (a
+ * co-tenant, a CU mask), the poll stops after ~1 s, raises the workspace's status word and every workgroup leaves the
+ * kernel with valid placeholder integers for its cloud (all points in bin 0, all M picks from it) -- nothing traps, the
+ * HIP context lives on and the kernels downstream run on memory they own.  The step's results are then meaningless:
+ * the caller reads the word with samble_select_chain_status_async (an async copy into its pinned memory: 1 = SAMBLE_E_TIMEOUT)
+ * whenever it next synchronises, and switches to the stand-alone stage entries above:
  *   samble_sparse_score_map_quantiles_f32  = samble_sparse_score_map_f32 (models/downsample.py:300-344, score + z,
  *       in-degree) + samble_batch_quantiles_f32 (utils/ops.py:180-189) in two launches (accumulation; finalize +
  *       radix select with grid barriers).  quantiles_out (nb-1) or NULL (static boundaries: no quantiles).
@@ -335,16 +342,30 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  *   samble_bin_plan_f32  = samble_blend_boundaries_f32 (utils/ops.py:201-233; quantiles NULL: boundaries are used as
  *       they are) + samble_bin_assign_f32 + samble_alloc_counts_f32 (utils/ops.py:385-464) in one launch.  Must follow
  *       the call above on the same stream and workspace (it holds the barrier counters that call zeroed).
+ *   samble_select_chain_f32  = the two entries above in ONE launch, for a caller with nothing to exchange between them (a
+ *       single rank): arguments as theirs (smap / lse / nn NULL when samble_attn_stats_nl_tri_f32 filled the workspace;
+ *       want_quantiles 0: static boundaries).
+ *   samble_select_chain_status_async  copies the workspace's status word to host_flag (pinned host memory) on the stream.
+ * spin_budget (all three launching entries): poll rounds a grid barrier waits before it gives up; 0 = the default
+ * (2^20, about a second).  A caller that knows its kernels share the device may shorten it; 0xFFFFFFFF injects the fault:
+ * every barrier gives up without polling (tests of the give-up path).
  * Same integers as the stand-alone entries: both run the same device functions (csrc/select_dev.h). */
 int samble_select_chain_supported(int B, int N, int nb);
 size_t samble_select_chain_workspace_bytes(int B, int N);
+int samble_select_chain_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int KN, int mode, const float* tok,
+                            int nt, int want_quantiles, float* quantiles_out, float* upper, float* lower, int first,
+                            float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
+                            float* score, float* z, int32_t* indeg_out, uint8_t* member, int32_t* cap, float* w_pre, float* w,
+                            int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, void* stream);
+int samble_select_chain_status_async(const void* ws, int B, int N, int32_t* host_flag, void* stream);
 int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,
                                           int KN, int mode, int nb, float* score, float* z, int32_t* indeg_out,
-                                          float* quantiles_out, void* ws, size_t ws_bytes, void* stream);
+                                          float* quantiles_out, void* ws, size_t ws_bytes, unsigned int spin_budget,
+                                          void* stream);
 int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper, float* lower,
                         int first, float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
                         uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws, size_t ws_bytes,
-                        void* stream);
+                        unsigned int spin_budget, void* stream);
 
 /* ---- the same passes on the bf16 matrix cores with split fp32 operands ------------------------------
  * An fp32 operand is carried as three bf16 planes h + m + l (all 24 significand bits); a product keeps

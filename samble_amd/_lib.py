@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsamble_hip.so")
@@ -53,10 +53,16 @@ _SIGNATURES = {
     "samble_select_chain_supported": (c_int, [c_int, c_int, c_int]),
     "samble_select_chain_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_sparse_score_map_quantiles_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint,
+                                                      c_void_p]),
     "samble_bin_plan_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_size_t, c_void_p]),
+                                    c_size_t, c_uint, c_void_p]),
+    "samble_select_chain_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_uint, c_void_p]),
+    "samble_select_chain_status_async": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "samble_zscore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "samble_quantiles_workspace_bytes": (c_size_t, []),
     "samble_batch_quantiles_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -91,9 +91,13 @@ int samble_chain_supported(int B, int N, int nb);
 int samble_launch_sparse_score_map_acc(const float*, int, const float*, const int*, int, int, int, int, void*, size_t,
                                        hipStream_t);
 int samble_launch_score_quantiles(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*,
-                                  float*, hipStream_t);
+                                  float*, unsigned int, hipStream_t);
 int samble_launch_bin_plan(const float*, const float*, int, const float*, float*, float*, int, float, float, int, int, int,
-                           int, int, unsigned char*, int*, float*, float*, int*, void*, hipStream_t);
+                           int, int, unsigned char*, int*, float*, float*, int*, void*, unsigned int, hipStream_t);
+int samble_launch_select_chain(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*, float*,
+                               const float*, int, float*, float*, int, float, float, int, int, unsigned char*, int*, float*,
+                               float*, int*, unsigned int, hipStream_t);
+size_t samble_chain_flag_offset(void);
 }
 
 namespace {
@@ -179,7 +183,7 @@ SAMBLE_API int samble_timing_read(int id, float* mean_ms, float* median_ms, int*
   return SAMBLE_OK;
 }
 
-SAMBLE_API const char* samble_version(void) { return "samble-hip 0.1 (gfx950)"; }
+SAMBLE_API const char* samble_version(void) { return "samble-hip 0.2 (gfx950)"; }
 SAMBLE_API const char* samble_last_error(void) { return g_err; }
 
 SAMBLE_API size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K, int variant) {
@@ -754,7 +758,7 @@ SAMBLE_API size_t samble_select_chain_workspace_bytes(int B, int N) {
 SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B,
                                                      int N, int KN, int mode, int nb, float* score, float* z,
                                                      int32_t* indeg_out, float* quantiles_out, void* ws, size_t ws_bytes,
-                                                     void* stream) {
+                                                     unsigned int spin_budget, void* stream) {
   if ((smap && (!lse || !nn)) || !score || !z || !ws)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: null pointer");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
@@ -775,14 +779,14 @@ SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, 
   const int* indeg = (const int*)(w8 + (size_t)B * N * 8);
   const float* rowstat = (const float*)(w8 + (size_t)B * N * 12);
   return done(samble_launch_score_quantiles(colacc, indeg, rowstat, B, N, mode, nb, score, z, indeg_out,
-                                            w8 + chain_score_bytes(B, N), quantiles_out, s),
+                                            w8 + chain_score_bytes(B, N), quantiles_out, spin_budget, s),
               "samble_sparse_score_map_quantiles_f32");
 }
 
 SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper,
                                    float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb,
                                    int relu_first, int M, uint8_t* member, int32_t* cap, float* w_pre, float* w,
-                                   int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+                                   int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, void* stream) {
   if (!z || !tok || !upper || !lower || !member || !cap || !w_pre || !w || !counts || !ws)
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: null pointer");
   if (nb < 1 || nb > 8 || (nt != 1 && nt != nb))
@@ -793,8 +797,45 @@ SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, con
     return fail(SAMBLE_E_WORKSPACE, "samble_bin_plan_f32: workspace too small");
   return done(samble_launch_bin_plan(z, tok, nt, quantiles, upper, lower, first, momentum, one_minus_momentum, B, N, nb,
                                      relu_first, M, member, cap, w_pre, w, counts, (char*)ws + chain_score_bytes(B, N),
-                                     (hipStream_t)stream),
+                                     spin_budget, (hipStream_t)stream),
               "samble_bin_plan_f32");
+}
+
+SAMBLE_API int samble_select_chain_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int KN, int mode,
+                                       const float* tok, int nt, int want_quantiles, float* quantiles_out, float* upper,
+                                       float* lower, int first, float momentum, float one_minus_momentum, int B, int N,
+                                       int nb, int relu_first, int M, float* score, float* z, int32_t* indeg_out,
+                                       uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws,
+                                       size_t ws_bytes, unsigned int spin_budget, void* stream) {
+  if ((smap && (!lse || !nn)) || !score || !z || !ws || !tok || !upper || !lower || !member || !cap || !w_pre || !w ||
+      !counts || (want_quantiles && !quantiles_out))
+    return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: null pointer");
+  if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD) return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: unknown score mode");
+  if (nb < 2 || nb > 8 || (nt != 1 && nt != nb))
+    return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: need 2 <= num_bins <= 8 and nt in {1, num_bins}");
+  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: N too large for LDS");
+  if (!samble_chain_supported(B, N, nb))
+    return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: shape not taken by the fused chain (samble_select_chain_supported)");
+  if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
+    return fail(SAMBLE_E_WORKSPACE, "samble_select_chain_f32: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  if (smap) {
+    int rc = samble_launch_sparse_score_map_acc(smap, ld, lse, nn, B, N, KN, mode, ws, samble_select_chain_workspace_bytes(B, N), s);
+    if (rc) return done(rc, "samble_select_chain_f32");
+  }
+  char* w8 = (char*)ws;
+  return done(samble_launch_select_chain(w8, (const int*)(w8 + (size_t)B * N * 8), (const float*)(w8 + (size_t)B * N * 12), B,
+                                         N, mode, nb, score, z, indeg_out, w8 + chain_score_bytes(B, N),
+                                         want_quantiles ? quantiles_out : nullptr, tok, nt, upper, lower, first, momentum,
+                                         one_minus_momentum, relu_first, M, member, cap, w_pre, w, counts, spin_budget, s),
+              "samble_select_chain_f32");
+}
+
+SAMBLE_API int samble_select_chain_status_async(const void* ws, int B, int N, int32_t* host_flag, void* stream) {
+  if (!ws || !host_flag || B <= 0 || N <= 0) return fail(SAMBLE_E_INVALID, "samble_select_chain_status_async: bad argument");
+  const char* word = (const char*)ws + chain_score_bytes(B, N) + samble_chain_flag_offset();
+  return done((int)hipMemcpyAsync(host_flag, word, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
+              "samble_select_chain_status_async");
 }
 
 SAMBLE_API size_t samble_proj_workspace_bytes(int B, int N) {

@@ -40,9 +40,18 @@ enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };
 
 // RELEASE: the workgroups hand over plain stores (needs the L2 write-back of an agent-scope release fence: a few
 // microseconds); false when everything exchanged went through agent-scope atomics (performed at the memory side:
-// each wave only has to wait until its own have been issued and acknowledged)
+// each wave only has to wait until its own have been issued and acknowledged).
+//
+// Bounded and clean: the barrier assumes that all B workgroups are resident at once, which the launcher can only infer
+// (CU count, nothing else on the device).  If a co-tenant, a CU mask or a second stream keeps some of them off the chip,
+// the poll gives up after `budget` rounds (default ~1 s), raises the chain's TIMEOUT word and the workgroup LEAVES the
+// kernel through chain_bail (valid, harmless outputs for its cloud); every other workgroup sees the word in its own poll
+// and leaves the same way, workgroups that start later leave at their first barrier.  Nothing traps: the context stays
+// alive, the host reads the word (samble_select_chain_status_async) and falls back to the stage kernels.
+// Returns true when the barrier completed (uniform over the workgroup).
 template <bool RELEASE>
-__device__ __forceinline__ void grid_barrier(unsigned int* counter, unsigned int target) {
+__device__ __forceinline__ bool grid_barrier(unsigned int* counter, unsigned int target, unsigned int* flag,
+                                             unsigned int budget, int* ok_lds) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -51,42 +60,75 @@ __device__ __forceinline__ void grid_barrier(unsigned int* counter, unsigned int
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // bounded: the barrier assumes that all B workgroups are resident at once, which the launcher can only infer (CU
-    // count, nothing else on the device).  If a co-tenant, a CU mask or a second stream keeps some of them off the
-    // chip, the poll gives up after kSpinBudget rounds (~1 s) and traps: the stream then carries a HIP error that the
-    // next entry point reports (SAMBLE_E_HIP_BASE - code) instead of the step hanging forever.
-    constexpr unsigned kSpinBudget = 1u << 20;
+    // (budget 0xFFFFFFFF: fault injection -- the barrier gives up without polling; include/samble.h `spin_budget`)
+    bool ok = budget != 0xFFFFFFFFu && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
     unsigned spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > kSpinBudget) __builtin_trap();
-      __builtin_amdgcn_s_sleep(1);
+    while (ok && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      ++spins;
+      if (spins > budget || ((spins & 63u) == 0u && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        ok = false;
+      else
+        __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ok) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    *ok_lds = ok ? 1 : 0;
   }
   __syncthreads();
+  return *ok_lds != 0;
 }
 
-// chain workspace (uint32 words): [quantile histograms and state: kQWords][barrier counters: 16]
+// What a workgroup leaves behind when the chain gave up (TIMEOUT word raised): every point of its cloud in bin 0 and
+// all M picks from that bin -- integers that the kernels downstream (bin_select, the row gather) can run on without
+// touching memory they do not own.  The step's results are meaningless; the host learns from the word.
+__device__ inline void chain_bail(int b, int N, int nb, int M, unsigned char* __restrict__ member, int* cap, float* w_pre,
+                                  float* w, int* counts) {
+  for (int n = threadIdx.x; n < N; n += blockDim.x) member[(long)b * N + n] = 1;
+  if ((int)threadIdx.x < nb) {
+    const int t = threadIdx.x;
+    cap[b * nb + t] = t == 0 ? N : 0;
+    w_pre[b * nb + t] = 0.f;
+    w[b * nb + t] = 0.f;
+    counts[b * nb + t] = t == 0 ? M : 0;
+  }
+}
+
+// chain workspace (uint32 words): [quantile histograms and state: kQWords][barrier counters: 8][TIMEOUT word][pad: 7]
 constexpr int kChainBar = kQWords;
+constexpr int kChainFlag = kQWords + 8;
 constexpr int kChainWords = kQWords + 16;
 
-// PT = ceil(N / 1024) values per thread (point n = tid + 1024 k)
+// LDS of the chain's two bodies (static part; the histograms / score buffer are dynamic)
+struct ChainLds {
+  double red[258];
+  unsigned int scanbuf[2 * 16 * kMaxBins];
+  unsigned int prefix[kMaxBins];
+  unsigned int rem[kMaxBins];
+  double rsum[kMaxBins][16];
+  int rcnt[kMaxBins][16];
+  float up_s[kMaxBins], lo_s[kMaxBins];
+  int counts_s[1024 * kMaxBins / 8];  // B x nb <= 1024 ints (B <= 128 at nb = 8)
+  int ok;
+};
+
+// score + z of cloud b, then (want_q) the nb-1 batch quantiles: their ordered bits end up in L.prefix[0..nb-2] of EVERY
+// workgroup.  PT = ceil(N / 1024) values per thread (point n = tid + 1024 k).  false: the grid barrier gave up.
 template <int PT>
-__global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned long long* __restrict__ colacc,
-                                                               const int* __restrict__ indeg,
-                                                               const float* __restrict__ rowstat, int N, int mode,
-                                                               int nb, float* __restrict__ score,
-                                                               float* __restrict__ z, int* __restrict__ indeg_out,
-                                                               unsigned int* __restrict__ cws,
-                                                               float* __restrict__ quant_out) {
-  extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
-  __shared__ double red[258];
-  __shared__ unsigned int scanbuf[2 * 16 * kMaxBins];
-  __shared__ unsigned int prefix[kMaxBins];
-  __shared__ unsigned int rem[kMaxBins];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int B = gridDim.x;
+__device__ __forceinline__ bool score_quantiles_body(ChainLds& L, unsigned int* qsm, int b, int B,
+                                                     const unsigned long long* __restrict__ colacc,
+                                                     const int* __restrict__ indeg, const float* __restrict__ rowstat,
+                                                     int N, int mode, int nb, float* __restrict__ score,
+                                                     float* __restrict__ z, int* __restrict__ indeg_out,
+                                                     unsigned int* __restrict__ cws, bool want_q, unsigned int budget) {
+  double* red = L.red;
+  unsigned int* scanbuf = L.scanbuf;
+  unsigned int* prefix = L.prefix;
+  unsigned int* rem = L.rem;
+  const int tid = threadIdx.x;
   const long n_all = (long)B * N;
   const int nq = nb - 1;
   STAMP(0);
@@ -194,7 +236,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
   }
   __syncthreads();  // sbuf is free
   STAMP(2);
-  if (quant_out == nullptr) return;  // static boundaries: no quantiles wanted (uniform over the grid)
+  if (!want_q) return true;  // static boundaries: no quantiles wanted (uniform over the grid)
 
   // ---- batch quantiles: three levels of digits (11 / 11 / 10 bits), all nb-1 ranks at once
   unsigned int* bar = cws + kChainBar;
@@ -230,42 +272,47 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
       if (c) atomicAdd(&gh[(level == 2) ? (e / nbin) * 1024 + (e % nbin) : (level == 1) ? (e / nbin) * 2048 + (e % nbin) : e], c);
     }
     STAMP(5 + 5 * level);
-    grid_barrier<false>(bar, (unsigned int)B * (level + 1));  // the histograms were combined by atomics
+    // the histograms were combined by atomics: no release needed
+    if (!grid_barrier<false>(bar, (unsigned int)B * (level + 1), cws + kChainFlag, budget, &L.ok)) return false;
     STAMP(6 + 5 * level);
     if (level == 0) qsel_resolve<0>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
     else if (level == 1) qsel_resolve<1>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
     else qsel_resolve<2>(cws, nq, n_all, nb, prefix, rem, scanbuf, /*keep_state=*/true);
     STAMP(7 + 5 * level);
   }
-  if (b == 0 && tid < nq) quant_out[tid] = from_ordered_bits(prefix[tid]);
+  return true;
 }
 
-// boundaries in (1,1,1,nb) layout: upper[0] = +inf, upper[t] = q[t-1]; lower[t] = q[t], lower[nb-1] = -inf
-__global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict__ z, const float* __restrict__ tok,
-                                                        int nt, const float* __restrict__ quant, float* upper,
-                                                        float* lower, int first, float mu, float one_minus_mu, int N,
-                                                        int nb, int relu_first, int M,
-                                                        unsigned char* __restrict__ member, int* cap, float* w_pre,
-                                                        float* w, int* __restrict__ counts,
-                                                        unsigned int* __restrict__ cws) {
-  __shared__ double rsum[kMaxBins][16];
-  __shared__ int rcnt[kMaxBins][16];
-  __shared__ float up_s[kMaxBins], lo_s[kMaxBins];
-  const int b = blockIdx.x, tid = threadIdx.x, B = gridDim.x;
+// boundary state update (first call: the quantiles; later: momentum blend, ops.py:201-233), bin membership + bin
+// weights of the cloud, a grid barrier, then the count allocation of the whole batch.
+// Boundaries in (1,1,1,nb) layout: upper[0] = +inf, upper[t] = q[t-1]; lower[t] = q[t], lower[nb-1] = -inf.
+// The nb-1 quantiles: quant (global; null with qbits null = static boundaries) or qbits (their ordered bits in LDS).
+__device__ __forceinline__ bool bin_plan_body(ChainLds& L, int b, int B, const float* __restrict__ z,
+                                              const float* __restrict__ tok, int nt, const float* __restrict__ quant,
+                                              const unsigned int* qbits, float* upper, float* lower, int first,
+                                              float mu, float one_minus_mu, int N, int nb, int relu_first, int M,
+                                              unsigned char* __restrict__ member, int* cap, float* w_pre, float* w,
+                                              int* __restrict__ counts, unsigned int* __restrict__ cws,
+                                              unsigned int budget) {
+  const int tid = threadIdx.x;
+  float* up_s = L.up_s;
+  float* lo_s = L.lo_s;
+  const bool have_q = quant != nullptr || qbits != nullptr;
+  auto q_at = [&](int t) { return quant ? quant[t] : from_ordered_bits(qbits[t]); };
   STAMP(20);
   // ---- boundary state (blend_boundaries_kernel's arithmetic: two fp32 products, then the sum; no FMA in this file)
   if (tid < nb) {
     float u = upper[tid], l = lower[tid];
-    if (quant) {
+    if (have_q) {
       if (tid >= 1) {
-        float v = quant[tid - 1];
+        float v = q_at(tid - 1);
         if (!first) v = u * mu + one_minus_mu * v;
         u = v;
       } else {
         u = first ? __builtin_huge_valf() : u;
       }
       if (tid < nb - 1) {
-        float v = quant[tid];
+        float v = q_at(tid);
         if (!first) v = upper[tid + 1] * mu + one_minus_mu * v;
         l = v;
       } else {
@@ -277,17 +324,17 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
   }
   __syncthreads();
   STAMP(21);
-  bin_assign_body(b, z, tok, nt, up_s, lo_s, N, nb, relu_first, member, cap, w_pre, w, rsum, rcnt);
+  bin_assign_body(b, z, tok, nt, up_s, lo_s, N, nb, relu_first, member, cap, w_pre, w, L.rsum, L.rcnt);
   STAMP(22);
   // every workgroup has read the old state and published its cloud's (w, cap): now the state may be overwritten
   // and the whole batch's counts allocated
-  grid_barrier<true>(cws + kChainBar + 1, (unsigned int)B);
+  if (!grid_barrier<true>(cws + kChainBar + 1, (unsigned int)B, cws + kChainFlag, budget, &L.ok)) return false;
   STAMP(23);
-  if (b == 0 && quant && tid < nb) {
+  if (b == 0 && have_q && tid < nb) {
     upper[tid] = up_s[tid];
     lower[tid] = lo_s[tid];
   }
-  __shared__ int counts_s[1024 * kMaxBins / 8];  // B x nb <= 1024 ints (B <= 128 at nb = 8)
+  int* counts_s = L.counts_s;
   if (B <= 64) {  // one wave, lane = cloud, no barriers; the shipped bin counts fully unrolled
     if (nb == 6) alloc_counts_wave<6>(w, cap, B, nb, M, counts_s);
     else if (nb == 4) alloc_counts_wave<4>(w, cap, B, nb, M, counts_s);
@@ -297,6 +344,69 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
   __syncthreads();
   STAMP(24);
   if (tid < nb) counts[b * nb + tid] = counts_s[b * nb + tid];
+  return true;
+}
+
+template <int PT>
+__global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned long long* __restrict__ colacc,
+                                                               const int* __restrict__ indeg,
+                                                               const float* __restrict__ rowstat, int N, int mode,
+                                                               int nb, float* __restrict__ score,
+                                                               float* __restrict__ z, int* __restrict__ indeg_out,
+                                                               unsigned int* __restrict__ cws,
+                                                               float* __restrict__ quant_out, unsigned int budget) {
+  extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
+  __shared__ ChainLds L;
+  const int b = blockIdx.x, B = gridDim.x;
+  // (a give-up leaves the TIMEOUT word raised: bin_plan_kernel, which follows on the stream, bails on it)
+  if (!score_quantiles_body<PT>(L, qsm, b, B, colacc, indeg, rowstat, N, mode, nb, score, z, indeg_out, cws,
+                                quant_out != nullptr, budget))
+    return;
+  if (quant_out && b == 0 && (int)threadIdx.x < nb - 1) quant_out[threadIdx.x] = from_ordered_bits(L.prefix[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict__ z, const float* __restrict__ tok,
+                                                        int nt, const float* __restrict__ quant, float* upper,
+                                                        float* lower, int first, float mu, float one_minus_mu, int N,
+                                                        int nb, int relu_first, int M,
+                                                        unsigned char* __restrict__ member, int* cap, float* w_pre,
+                                                        float* w, int* __restrict__ counts,
+                                                        unsigned int* __restrict__ cws, unsigned int budget) {
+  __shared__ ChainLds L;
+  const int b = blockIdx.x, B = gridDim.x;
+  const bool dead = __hip_atomic_load(cws + kChainFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // uniform
+  if (dead || !bin_plan_body(L, b, B, z, tok, nt, quant, nullptr, upper, lower, first, mu, one_minus_mu, N, nb, relu_first,
+                             M, member, cap, w_pre, w, counts, cws, budget))
+    chain_bail(b, N, nb, M, member, cap, w_pre, w, counts);
+}
+
+// Both bodies in ONE launch, for a single rank (no all-reduce of the quantiles stands between them): every workgroup
+// holds the quantiles in LDS after the third level, so nothing is re-read and no launch boundary is paid.
+template <int PT>
+__global__ __launch_bounds__(1024) void select_chain_kernel(const unsigned long long* __restrict__ colacc,
+                                                            const int* __restrict__ indeg,
+                                                            const float* __restrict__ rowstat, int N, int mode, int nb,
+                                                            float* __restrict__ score, float* __restrict__ z,
+                                                            int* __restrict__ indeg_out, unsigned int* __restrict__ cws,
+                                                            float* __restrict__ quant_out, const float* __restrict__ tok,
+                                                            int nt, float* upper, float* lower, int first, float mu,
+                                                            float one_minus_mu, int relu_first, int M,
+                                                            unsigned char* __restrict__ member, int* cap, float* w_pre,
+                                                            float* w, int* __restrict__ counts, unsigned int budget) {
+  extern __shared__ unsigned int qsm[];
+  __shared__ ChainLds L;
+  const int b = blockIdx.x, B = gridDim.x;
+  const bool want_q = quant_out != nullptr;
+  bool ok = score_quantiles_body<PT>(L, qsm, b, B, colacc, indeg, rowstat, N, mode, nb, score, z, indeg_out, cws, want_q,
+                                     budget);
+  if (ok) {
+    if (want_q && b == 0 && (int)threadIdx.x < nb - 1) quant_out[threadIdx.x] = from_ordered_bits(L.prefix[threadIdx.x]);
+    // (this workgroup wrote its cloud's z itself: the barrier inside the body orders those stores before its loads)
+    __syncthreads();
+    ok = bin_plan_body(L, b, B, z, tok, nt, nullptr, want_q ? L.prefix : nullptr, upper, lower, first, mu, one_minus_mu, N,
+                       nb, relu_first, M, member, cap, w_pre, w, counts, cws, budget);
+  }
+  if (!ok) chain_bail(b, N, nb, M, member, cap, w_pre, w, counts);
 }
 
 }  // namespace samble
@@ -331,14 +441,25 @@ extern "C" int samble_chain_supported(int B, int N, int nb) {
   return B >= 1 && 2 * B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && N <= 16 * 1024 && nb >= 2 && nb <= kMaxBins;
 }
 
-// cws must have been zeroed on the stream (the score launcher's memset covers it)
-extern "C" int samble_launch_score_quantiles(const void* colacc, const int* indeg, const float* rowstat, int B, int N,
-                                             int mode, int nb, float* score, float* z, int* indeg_out, void* cws,
-                                             float* quant_out, hipStream_t s) {
-  const int pt = (N + 1023) / 1024;
+// poll rounds a grid barrier waits before it gives up: the caller's `spin_budget`, 0 = the default (~1 s)
+static inline unsigned int chain_budget(unsigned int spin_budget) { return spin_budget ? spin_budget : (1u << 20); }
+
+extern "C" size_t samble_chain_flag_offset(void) { return (size_t)kChainFlag * sizeof(unsigned int); }
+
+static size_t chain_dyn_lds(int N, int nb) {
   size_t lds = (size_t)(nb - 1) * 2048 * 4;
   if ((size_t)N * 4 > lds) lds = (size_t)N * 4;
   if (lds < 2048 * 4) lds = 2048 * 4;
+  return lds;
+}
+
+// cws must have been zeroed on the stream (the score launcher's memset covers it)
+extern "C" int samble_launch_score_quantiles(const void* colacc, const int* indeg, const float* rowstat, int B, int N,
+                                             int mode, int nb, float* score, float* z, int* indeg_out, void* cws,
+                                             float* quant_out, unsigned int spin_budget, hipStream_t s) {
+  const unsigned int g_chain_budget = chain_budget(spin_budget);
+  const int pt = (N + 1023) / 1024;
+  const size_t lds = chain_dyn_lds(N, nb);
   Timed timed(kT_quantiles, s);
 #define SAMBLE_SQ(PT)                                                                                              \
   {                                                                                                                \
@@ -346,7 +467,8 @@ extern "C" int samble_launch_score_quantiles(const void* colacc, const int* inde
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
     if (e != hipSuccess) return (int)e;                                                                            \
     hipLaunchKernelGGL(score_quantiles_kernel<PT>, dim3(B), dim3(1024), lds, s, (const unsigned long long*)colacc, \
-                       indeg, rowstat, N, mode, nb, score, z, indeg_out, (unsigned int*)cws, quant_out);           \
+                       indeg, rowstat, N, mode, nb, score, z, indeg_out, (unsigned int*)cws, quant_out,            \
+                       g_chain_budget);                                                                            \
   }
   if (pt <= 1) SAMBLE_SQ(1)
   else if (pt <= 2) SAMBLE_SQ(2)
@@ -360,9 +482,41 @@ extern "C" int samble_launch_score_quantiles(const void* colacc, const int* inde
 extern "C" int samble_launch_bin_plan(const float* z, const float* tok, int nt, const float* quant, float* upper,
                                       float* lower, int first, float mu, float one_minus_mu, int B, int N, int nb,
                                       int relu_first, int M, unsigned char* member, int* cap, float* w_pre, float* w,
-                                      int* counts, void* cws, hipStream_t s) {
+                                      int* counts, void* cws, unsigned int spin_budget, hipStream_t s) {
+  const unsigned int g_chain_budget = chain_budget(spin_budget);
   Timed timed(kT_bin_assign, s);
   hipLaunchKernelGGL(bin_plan_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, quant, upper, lower, first, mu,
-                     one_minus_mu, N, nb, relu_first, M, member, cap, w_pre, w, counts, (unsigned int*)cws);
+                     one_minus_mu, N, nb, relu_first, M, member, cap, w_pre, w, counts, (unsigned int*)cws,
+                     g_chain_budget);
+  return (int)hipGetLastError();
+}
+
+// score_quantiles + bin_plan as one launch (single rank: nothing is exchanged between them)
+extern "C" int samble_launch_select_chain(const void* colacc, const int* indeg, const float* rowstat, int B, int N,
+                                          int mode, int nb, float* score, float* z, int* indeg_out, void* cws,
+                                          float* quant_out, const float* tok, int nt, float* upper, float* lower,
+                                          int first, float mu, float one_minus_mu, int relu_first, int M,
+                                          unsigned char* member, int* cap, float* w_pre, float* w, int* counts,
+                                          unsigned int spin_budget, hipStream_t s) {
+  const unsigned int g_chain_budget = chain_budget(spin_budget);
+  const int pt = (N + 1023) / 1024;
+  const size_t lds = chain_dyn_lds(N, nb);
+  Timed timed(kT_quantiles, s);
+#define SAMBLE_SC(PT)                                                                                              \
+  {                                                                                                                \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(select_chain_kernel<PT>),                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                     \
+    if (e != hipSuccess) return (int)e;                                                                            \
+    hipLaunchKernelGGL(select_chain_kernel<PT>, dim3(B), dim3(1024), lds, s, (const unsigned long long*)colacc,    \
+                       indeg, rowstat, N, mode, nb, score, z, indeg_out, (unsigned int*)cws, quant_out, tok, nt,   \
+                       upper, lower, first, mu, one_minus_mu, relu_first, M, member, cap, w_pre, w, counts,        \
+                       g_chain_budget);                                                                            \
+  }
+  if (pt <= 1) SAMBLE_SC(1)
+  else if (pt <= 2) SAMBLE_SC(2)
+  else if (pt <= 4) SAMBLE_SC(4)
+  else if (pt <= 8) SAMBLE_SC(8)
+  else SAMBLE_SC(16)
+#undef SAMBLE_SC
   return (int)hipGetLastError();
 }

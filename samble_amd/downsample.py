@@ -84,6 +84,9 @@ TWO_PASS = True
 # (csrc/attn_tri.hip: attn_stats_nl_tri / attn_rows_rc_tri): pass 1 keeps the K neighbour logits of each row, pass 2
 # recomputes the M sampled rows and hands their P rows to the backward.  False keeps the map (A/B runs, tests).
 MAP_FREE = True
+# A single rank runs the integer tail (score + z + batch quantiles + boundaries + bins + counts) as ONE launch
+# (csrc/chain.hip select_chain_kernel); False keeps the two launches a process group needs (A/B runs, tests).
+FUSED_CHAIN = True
 
 
 class _SamplerCore(torch.autograd.Function):
@@ -147,7 +150,7 @@ class _SamplerCore(torch.autograd.Function):
                     raise ops._lib.SambleError("the projection's images lack the backward pair although a gradient is wanted")
                 else:
                     imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
-                chain = ops.chain_supported(B, N, nb)
+                chain = ops.chain_supported(B, N, nb) and not mod._chain_watch.timed_out()
                 # the pass also accumulates the score statistics of the K neighbour entries of every row
                 fused = N <= 8192   # LDS accumulators of the pass; longer clouds take the neighbour-logit array
                 sws = ops.score_workspace(B, N, nb if chain else None, x.device) if fused else None
@@ -156,7 +159,14 @@ class _SamplerCore(torch.autograd.Function):
                     imgs[0], imgs[1], masks, B, N, nt, mod.K, D, want_nl=not fused,
                     score=(nn_sorted, mod.idx_mode, nb if chain else None) if fused else None, cleared_ws=sws)
                 del masks
-                if chain:
+                if chain and ops.single_rank() and FUSED_CHAIN:
+                    # one launch: score + z + batch quantiles + boundaries + bins + counts
+                    (score, z, indeg, quant, mod.bin_boundaries, *plan, cws) = ops.stage_select_chain(
+                        lse, tok, nn_sorted, mod.idx_mode, nb, mod.dynamic_boundaries_enable, mod.bin_boundaries,
+                        mod.momentum_update_factor, mod.relu_mean_order == "relu_mean", mod.M, smap=nl,
+                        compact=not fused, ws=sws)
+                    mod._chain_watch.arm(cws, B, N)
+                elif chain:
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
                                                                             mod.dynamic_boundaries_enable,
                                                                             compact=not fused, ws=sws)
@@ -165,6 +175,7 @@ class _SamplerCore(torch.autograd.Function):
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
                                                                    mod.relu_mean_order == "relu_mean", mod.M, cws)
+                    mod._chain_watch.arm(cws, B, N)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=not fused,
                                                                  ws=sws)
@@ -173,7 +184,7 @@ class _SamplerCore(torch.autograd.Function):
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
                 imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
                 smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
-                if ops.chain_supported(B, N, nb):
+                if ops.chain_supported(B, N, nb) and not mod._chain_watch.timed_out():
                     # score + z + batch quantiles, then boundaries + bins + counts: two launches, the rank
                     # average of the quantiles (reference utils/ops.py:191-199) in between
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(smap, lse, nn_idx, mod.idx_mode, nb,
@@ -183,6 +194,7 @@ class _SamplerCore(torch.autograd.Function):
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
                                                                    mod.relu_mean_order == "relu_mean", mod.M, cws)
+                    mod._chain_watch.arm(cws, B, N)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
@@ -330,6 +342,7 @@ class DownSampleToken(nn.Module):
         if self.num_heads != 1:
             raise NotImplementedError("DownSampleToken requires num_heads == 1 (reference utils/check_config.py:158)")
         self._member_bits = None
+        self._chain_watch = ops.ChainWatch()
 
     # -- reference-visible state ---------------------------------------------------------------
     @property
@@ -346,6 +359,13 @@ class DownSampleToken(nn.Module):
         B, C, N = x.shape
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
+        if not self._chain_watch.tripped and self._chain_watch.timed_out():
+            # raised ONCE, at the first call after the status word arrived; from here on the layer runs the stand-alone
+            # stage kernels (no grid barrier), so a caller that catches this and carries on gets valid results
+            raise ops._lib.SambleError(
+                "SAMBLE_E_TIMEOUT: a grid barrier of the fused select chain gave up in an earlier forward of this layer "
+                "(its workgroups were not all resident); that forward's selection was a placeholder. The layer has "
+                "switched to the stand-alone stage kernels.")
         if C != 128 or self.q_depth != 128 or self.k_depth != 128 or self.v_depth != 128:
             raise NotImplementedError("the HIP kernels are built for C = q_out = k_out = v_out = 128 (shipped configs)")
         # (B, N+nt, 3D) point-major rows [Q|K|V]; rows N.. are the bin tokens

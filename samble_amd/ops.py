@@ -777,8 +777,94 @@ def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_
         assert ws.numel() >= nbytes
         _lib.call("samble_sparse_score_map_quantiles_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
                   nn_idx.shape[2], SCORE_MODES[idx_mode], num_bins, score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
-                  _p(quant), ws.data_ptr(), ws.numel(), _stream())
+                  _p(quant), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _stream())
     return score, z, indeg, quant, ws
+
+
+# poll rounds a grid barrier of the fused select chain waits before it gives up (include/samble.h `spin_budget`):
+# 0 = the library's default (2^20, about a second); 0xFFFFFFFF injects the give-up (tests)
+CHAIN_SPIN_BUDGET = 0
+
+
+class ChainWatch:
+    """The fused select chain's status word, watched without a synchronisation: after each chain launch the word is
+    copied (asynchronously, on the stream) into one pinned int32; the host looks at that int before the NEXT chain launch,
+    or any time through `timed_out()`.  1 = SAMBLE_E_TIMEOUT: a grid barrier gave up (its workgroups were not all
+    resident) and the step that ran it produced placeholder selections -- the watch then stays tripped and the caller
+    uses the stand-alone stage kernels (stage_sparse_score_map, stage_batch_quantiles, ...)."""
+
+    def __init__(self):
+        self.flag = None
+        self.tripped = False
+
+    def arm(self, ws: torch.Tensor, B: int, N: int) -> None:
+        if self.flag is None:
+            self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _lib.call("samble_select_chain_status_async", ws.data_ptr(), B, N, self.flag.data_ptr(), _stream())
+
+    def timed_out(self, sync: bool = False) -> bool:
+        if sync:
+            torch.cuda.synchronize()
+        if self.flag is not None and int(self.flag[0]) != 0:
+            self.tripped = True
+            self.flag[0] = 0
+        return self.tripped
+
+
+def stage_select_chain(lse, tok_logits, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, boundaries,
+                       momentum_update_factor: float, relu_first: bool, M: int, smap=None, compact: bool = False, ws=None):
+    """stage_score_quantiles + stage_bin_plan as ONE launch (a single rank: no all-reduce of the quantiles stands between
+    them; csrc/chain.hip select_chain_kernel).  smap / compact / ws as in stage_score_quantiles.
+    -> score, z, in-degree, quantiles | None, boundaries [upper, lower], member, cap, w_pre, w, counts, workspace."""
+    if idx_mode not in SCORE_MODES:
+        raise ValueError("Please check the setting of idx mode!")
+    _need_gpu(lse, nn_idx, tok_logits)
+    B, N = lse.shape
+    nb = num_bins
+    dev = lse.device
+    tok_logits = _f32c(tok_logits)
+    ld = 0
+    if smap is not None:
+        _need_gpu(smap)
+        ld = 0 if compact else smap.shape[2]
+    elif ws is None:
+        raise ValueError("smap=None needs the workspace stage_attn_stats_nl filled")
+    first = boundaries is None
+    if first:
+        if not want_quantiles:
+            raise ValueError("static boundaries must be given")
+        boundaries = [torch.empty((1, 1, 1, nb), dtype=torch.float32, device=dev) for _ in range(2)]
+    else:
+        boundaries = [boundaries[0].detach(), boundaries[1].detach()]
+        if not all(t.is_contiguous() and t.dtype == torch.float32 and t.device == dev for t in boundaries):
+            boundaries = [t.to(device=dev, dtype=torch.float32).contiguous() for t in boundaries]
+    with torch.cuda.device(dev):
+        score = torch.empty((B, N), dtype=torch.float32, device=dev)
+        z = torch.empty_like(score)
+        indeg = torch.empty((B, N), dtype=torch.int32, device=dev)
+        quant = torch.empty((nb - 1,), dtype=torch.float32, device=dev) if want_quantiles else None
+        member = torch.empty((B, N), dtype=torch.uint8, device=dev)
+        cap = torch.empty((B, nb), dtype=torch.int32, device=dev)
+        w_pre = torch.empty((B, nb), dtype=torch.float32, device=dev)
+        w = torch.empty_like(w_pre)
+        counts = torch.empty((B, nb), dtype=torch.int32, device=dev)
+        nbytes = _lib.query("samble_select_chain_workspace_bytes", B, N)
+        if smap is not None:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        assert ws.numel() >= nbytes
+        _lib.call("samble_select_chain_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), nn_idx.shape[2],
+                  SCORE_MODES[idx_mode], tok_logits.data_ptr(), tok_logits.shape[-1], int(bool(want_quantiles)), _p(quant),
+                  boundaries[0].data_ptr(), boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
+                  float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), score.data_ptr(),
+                  z.data_ptr(), indeg.data_ptr(), member.data_ptr(), cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(),
+                  counts.data_ptr(), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _stream())
+    return score, z, indeg, quant, boundaries, member, cap, w_pre, w, counts, ws
+
+
+def single_rank() -> bool:
+    """No process group, or a group of one: nothing is exchanged between the quantiles and the bin plan."""
+    return not (torch.distributed.is_available() and torch.distributed.is_initialized()
+                and torch.distributed.get_world_size() > 1)
 
 
 def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum_update_factor: float, relu_first: bool,
@@ -811,7 +897,8 @@ def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum
                   _p(_f32c(quantiles)) if quantiles is not None else None, boundaries[0].data_ptr(),
                   boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
                   float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), member.data_ptr(),
-                  cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(), _stream())
+                  cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                  CHAIN_SPIN_BUDGET, _stream())
     return boundaries, member, cap, w_pre, w, counts
 
 

@@ -396,6 +396,35 @@ def test_map_free_module_equals_map_module(name):
             assert torch.equal(t1, t2), (call, j)
 
 
+@pytest.mark.parametrize("name", ["cls_random_dyn", "seg_random_dyn", "cls_random_static", "cls_random_cfg1"])
+def test_one_launch_chain_module_equals_two_launch_module(name):
+    """downsample.FUSED_CHAIN: the integer tail as one launch (single rank) against the two launches a process group
+    needs -- same indices, outputs, boundaries and gradients, bit for bit, over the fixtures' calls."""
+    import samble_amd.downsample as D
+    g = Golden(name)
+    outs = []
+    old = D.FUSED_CHAIN
+    try:
+        for fused in (False, True):
+            D.FUSED_CHAIN = fused
+            mod = g.module(DEV)
+            res = []
+            for call in range(g.calls):
+                x = g.x(call).to(DEV).requires_grad_(True)
+                (x_ds, idx), _ = mod(x, noise=g.t("noise", call).to(DEV))
+                x_ds.square().sum().backward()
+                res.append([x_ds.detach(), idx, mod.attention_point_score, mod.normalized_score, mod.bin_boundaries[0].clone(),
+                            mod.bin_boundaries[1].clone(), mod.k_point_to_choose, mod._member_bits, x.grad,
+                            mod.bin_tokens.grad.clone()])
+                mod.zero_grad()
+            outs.append(res)
+    finally:
+        D.FUSED_CHAIN = old
+    for call, (a, b) in enumerate(zip(*outs)):
+        for j, (t1, t2) in enumerate(zip(a, b)):
+            assert torch.equal(t1, t2), (call, j)
+
+
 def test_map_free_long_cloud_takes_the_compact_score_route():
     """N = 8500 > 8192: pass 1 cannot hold the score accumulators in LDS, so the module keeps the K neighbour logits per
     row and runs the separate score pass on them -- still without the N x (N+nt) map, same outputs as with the map."""

@@ -881,7 +881,7 @@ def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
                                    for i in range(N)]) for b in range(B)]).int().to(DEV) if N <= 1024 else \
         o_.stage_knn(q.permute(0, 2, 1).contiguous().to(DEV), q.permute(0, 2, 1).contiguous().to(DEV), K)
     smap, lse, tok = o_.stage_attn_stats(q.to(DEV), k.to(DEV), N, nt)
-    state_a = state_b = None
+    state_a = state_b = state_c = None
     for call in range(2):
         # stage kernels
         score, z, indeg = o_.stage_sparse_score_map(smap, lse, nn, "sparse_col_sqr")
@@ -899,6 +899,14 @@ def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
                             (counts, counts2, "counts")):
             assert torch.equal(a, b2), (what, call)
         assert bool((counts2.sum(1) == M).all())
+        # the same chain as ONE launch (a single rank has nothing to exchange between the quantiles and the bin plan)
+        (score5, z5, indeg5, quant5, state_c, member5, cap5, w_pre5, w5, counts5, _) = o_.stage_select_chain(
+            lse, tok, nn, "sparse_col_sqr", nb, True, state_c, 0.99, False, M, smap=smap)
+        for a, b2, what in ((score, score5, "score"), (z, z5, "z"), (indeg, indeg5, "indeg"), (quant, quant5, "quantiles"),
+                            (state_a[0], state_c[0], "upper"), (state_a[1], state_c[1], "lower"),
+                            (member, member5, "member"), (cap, cap5, "cap"), (w_pre, w_pre5, "w_pre"), (w, w5, "w"),
+                            (counts, counts5, "counts")):
+            assert torch.equal(a, b2), ("one launch", what, call)
         lse = lse + 0.01 * (call + 1)  # other scores for the second call
     # static boundaries: no quantiles, state untouched
     up = state_a[0].clone()
@@ -908,6 +916,49 @@ def test_fused_select_chain_equals_the_stage_kernels(B, N, nb, nt):
     member4, cap4, _, w4 = o_.stage_bin_assign(z3, tok, state_a[0], state_a[1], True)
     assert torch.equal(st[0], up) and torch.equal(member3, member4) and torch.equal(cap3, cap4) and torch.equal(w3, w4)
     assert torch.equal(counts3, o_.stage_alloc_counts(w4, cap4, M))
+    (_, z6, _, quant6, st6, member6, cap6, _, w6, counts6, _) = o_.stage_select_chain(
+        lse, tok, nn, "sparse_col_sqr", nb, False, [state_a[0], state_a[1]], 0.99, True, M, smap=smap)
+    assert quant6 is None and torch.equal(st6[0], up) and torch.equal(z6, z3) and torch.equal(member6, member4)
+    assert torch.equal(cap6, cap4) and torch.equal(w6, w4) and torch.equal(counts6, counts3)
+
+
+def test_select_chain_gives_up_cleanly_and_the_layer_falls_back():
+    """The grid barrier of the fused chain is bounded, and its give-up is clean (csrc/chain.hip grid_barrier / chain_bail):
+    with the give-up injected (the entries' spin_budget argument = 0xFFFFFFFF) the barrier gives up at once -- the kernel ends
+    (no trap: the context lives on), leaves valid placeholder integers and raises the workspace's status word; the layer
+    sees the word at its next call, raises SAMBLE_E_TIMEOUT once, and from then on runs the stand-alone stage kernels,
+    whose results equal those of a layer that never used the chain."""
+    from samble_amd import _lib, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 4, 128, 512, 256, 6
+    x = torch.from_numpy(synth.features(B, C, N, 611)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 612)).to(DEV)
+    torch.manual_seed(9)
+    mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+    assert ops().chain_supported(B, N, nb)
+    try:
+        ops().CHAIN_SPIN_BUDGET = 0xFFFFFFFF
+        (x_ds, idx), _ = mod(x, noise=noise)               # the chain gives up inside this call
+        torch.cuda.synchronize()                           # ... and the process is still alive
+    finally:
+        ops().CHAIN_SPIN_BUDGET = 0
+    i = idx[:, 0].cpu()
+    assert int(i.min()) >= 0 and int(i.max()) < N and all(len(set(r.tolist())) == M for r in i)   # placeholders, but valid
+    assert bool((mod.k_point_to_choose.cpu()[:, 0] == M).all()) and torch.isfinite(x_ds).all()
+    with pytest.raises(_lib.SambleError, match="SAMBLE_E_TIMEOUT"):
+        mod(x, noise=noise)
+    assert mod._chain_watch.tripped
+    mod.bin_boundaries = None                              # (the timed-out call left the state untouched or half-made)
+    (x_ds2, idx2), _ = mod(x, noise=noise)                 # stage kernels now
+    ref = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+    ref.load_state_dict(mod.state_dict())
+    ref._chain_watch.tripped = True                        # a layer that never takes the chain
+    (x_ds3, idx3), _ = ref(x, noise=noise)
+    assert torch.equal(idx2, idx3) and torch.equal(x_ds2, x_ds3)
+    good = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)   # and the chain itself, with its real budget
+    good.load_state_dict(mod.state_dict())
+    (x_ds4, idx4), _ = good(x, noise=noise)
+    assert torch.equal(idx4, idx3) and torch.equal(x_ds4, x_ds3) and not good._chain_watch.timed_out(sync=True)
 
 
 @pytest.mark.parametrize("B,N,nt,M,K", [(2, 256, 6, 128, 32), (3, 1000, 4, 333, 16), (32, 2048, 6, 1024, 32),
