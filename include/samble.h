@@ -483,6 +483,50 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
                                            const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
                                            float* x_ds, float* pmap, int ld, void* stream);
 
+/* ---- 1x1 convolutions over C = 128 input channels next to the neighbour / sampler kernels (csrc/linear.hip) --------
+ * Replace, in the layers that sandwich the sampler:
+ *   models/attention.py:187-192 (Neighbor2PointAttention / Point2PointAttention): ff = Conv1d(128 -> 512, bias=False),
+ *       LeakyReLU(0.2), Conv1d(512 -> 128, bias=False) and its autograd;
+ *   models/cls_model.py:136 (FeatureLearningBlock): conv_list[i](x).max(dim=-1)[0] -- Conv1d(128 -> 1024, bias=False)
+ *       followed by the maximum over the points -- and its autograd.
+ * fp32 in, fp32 out; products on the bf16 matrix cores with each fp32 operand split into three bf16 planes (six partial
+ * products, fp32 accumulation: fp32-equivalent, csrc/tri_dev.h).  Layouts: x and dx channel-major (B, 128, N) as the
+ * modules hold them (x_bs = elements between clouds); the wide side point-major rows (B, N, O) (o_bs / o_rs = elements
+ * between clouds / rows; rows 16-byte aligned); W (O, 128) row-major, O a multiple of 32, handed over as OPERAND IMAGES
+ * of samble_linear_image_bytes(O) bytes each, written by samble_linear_weight_images_f32 (either pointer may be NULL):
+ *   rm_image  contraction over the 128 channels   (samble_linear_fwd_tri_f32, samble_linear_amax_fwd_tri_f32)
+ *   tr_image  contraction over the O outputs      (samble_linear_dx_tri_f32)
+ *   samble_linear_fwd_tri_f32       out[b][n][o] = epilogue(sum_c W[o][c] x[b][c][n]); epilogue SAMBLE_LIN_PLAIN,
+ *                                   SAMBLE_LIN_LEAKY (LeakyReLU 0.2), SAMBLE_LIN_LEAKY_MASK (times 1 where ref > 0, else
+ *                                   0.2; ref: a (B, N, O) tensor laid out like out -- the backward of the activation)
+ *   samble_linear_amax_fwd_tri_f32  y[b][o] = max_n sum_c W[o][c] x[b][c][n], arg[b][o] = the first point that reaches
+ *                                   it; the (B, O, N) tensor is never written
+ *   samble_linear_dx_tri_f32        dx[b][c][n] = sum_o W[o][c] g[b][n][o]
+ *   samble_linear_dw_tri_f32        dW[o][c] = sum_{b,n} g[b][n][o] x[b][c][n]; O a multiple of 256; per-workgroup
+ *                                   partials in ws, summed in a fixed order (deterministic, no float atomics)
+ *   samble_amax_bwd_f32             backward of samble_linear_amax_fwd_tri_f32 for upstream gy (B, O): the arg-max columns
+ *                                   of dx (which must be ZERO on entry) and dW (O, 128); outputs grouped by point with a
+ *                                   counting sort, sums in ascending output / cloud order (deterministic).  An exact tie of
+ *                                   the maximum goes to the lowest point index (torch.amax's backward splits it evenly). */
+#define SAMBLE_LIN_PLAIN 0
+#define SAMBLE_LIN_LEAKY 1
+#define SAMBLE_LIN_LEAKY_MASK 2
+size_t samble_linear_image_bytes(int O);
+int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream);
+int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int epilogue,
+                              const float* ref, float* out, int64_t o_bs, int64_t o_rs, void* stream);
+size_t samble_linear_amax_workspace_bytes(int B, int N, int O);
+int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, float* y,
+                                   int32_t* arg, void* ws, size_t ws_bytes, void* stream);
+int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const void* w_tr_image, int O, int B, int C, int N,
+                             float* dx, int64_t dx_bs, void* stream);
+size_t samble_linear_dw_workspace_bytes(int B, int N, int O);
+int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
+                             int O, float* dW, void* ws, size_t ws_bytes, void* stream);
+size_t samble_amax_bwd_workspace_bytes(int B, int O);
+int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
+                        int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement hook (bench.py; the only entry points that are not part of the path) ------------------
  * The library records HIP events around its own launches of the selected kernels, on the stream each is
  * launched on.  samble_timing_select(mask): bit SAMBLE_T_x set = time kernel x (0 = off; resets the samples);
@@ -518,6 +562,11 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
 #define SAMBLE_T_SEG_SUM 29      /* seg_sum_rows64 */
 #define SAMBLE_T_EDGE_SUMS 30    /* edge_gather_sums */
 #define SAMBLE_T_KNN_SMALL 31    /* knn_smallc_fused (xyz) */
+#define SAMBLE_T_LIN_FWD 32      /* lin_fwd_tri (1x1 convolution, point-major output, leaky / mask epilogues) */
+#define SAMBLE_T_LIN_DX 33       /* lin_dx_tri */
+#define SAMBLE_T_LIN_DW 34       /* lin_dw_tri + its partial sum */
+#define SAMBLE_T_LIN_AMAX 35     /* lin_fwd_tri<amax> + reduce: 1x1 convolution and max over the points */
+#define SAMBLE_T_LIN_AMAX_BWD 36 /* amax_bwd + the sum over the clouds */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

@@ -17,7 +17,7 @@ import math
 import torch
 from torch import nn
 
-from . import ops
+from . import linear, ops
 
 
 def _attention_from_projection(qkv, nn_idx, heads: int, diff: bool):
@@ -37,6 +37,20 @@ def _attention_from_projection(qkv, nn_idx, heads: int, diff: bool):
     att = torch.softmax(logits, dim=2)
     out = (att.unsqueeze(-1) * vg.view(b, N, K, heads, D)).sum(2).reshape(b, N, C)
     return out.permute(0, 2, 1)
+
+
+FUSED_FFN = True  # False: the stock Conv1d modules (A/B runs)
+
+
+def _feed_forward(ff: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """`self.ff(x)` of the reference's attention layers (models/attention.py:187-192: Conv1d 128->512, LeakyReLU(0.2),
+    Conv1d 512->128, no biases) on the HIP 1x1-convolution kernels (csrc/linear.hip) when the shape is theirs; any other
+    configuration runs the stock modules."""
+    w1, w2 = ff[0].weight, ff[2].weight
+    if (FUSED_FFN and ff[0].bias is None and ff[2].bias is None and abs(ff[1].negative_slope - 0.2) < 1e-12
+            and linear.ffn_supported(x, w1, w2)):
+        return linear.ffn(x, w1, w2)
+    return ff(x)
 
 
 class _N2PCore(torch.autograd.Function):
@@ -139,7 +153,7 @@ class Neighbor2PointAttention(nn.Module):
             if center:
                 x_tmp = x_tmp + torch.nn.functional.conv1d(x, wv[:, :C, :, 0])
         x = self.bn1(x + x_tmp)
-        x_tmp = self.ff(x)
+        x_tmp = _feed_forward(self.ff, x)
         x = self.bn2(x + x_tmp)
         return x
 
@@ -281,7 +295,7 @@ class Point2PointAttention(nn.Module):
         else:
             x_tmp = _P2PHeads.apply(qkv, self.num_heads, self.asm)
         x = self.bn1(x + x_tmp)
-        x_tmp = self.ff(x)
+        x_tmp = _feed_forward(self.ff, x)
         x = self.bn2(x + x_tmp)
         return x
 

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import nn
 
-from . import ops
+from . import linear, ops
 from .attention import Neighbor2PointAttention, Point2PointAttention
 from .downsample import DownSampleGlobal, DownSampleLocal, DownSampleToken
 from .embedding import EdgeConv
@@ -72,6 +72,17 @@ class _Encoder(nn.Module):
         return levels
 
 
+FUSED_HEADS = True  # False: the stock Conv1d + max (A/B runs)
+
+
+def _pooled_head(head: nn.Conv1d, feat: torch.Tensor) -> torch.Tensor:
+    """`conv(x).max(dim=-1)[0]` of the classification trunk (models/cls_model.py:113, 136, 144) as one HIP pass: the
+    (B, 1024, N) tensor is never written, the backward touches the arg-max columns only (csrc/linear.hip)."""
+    if FUSED_HEADS and head.bias is None and linear.linear_max_supported(feat, head.weight):
+        return linear.linear_max(feat, head.weight)
+    return head(feat).max(dim=-1)[0]
+
+
 class FeatureLearningBlock(_Encoder):
     """Classification trunk: every level is projected to 1024 channels and max-pooled; the pooled vectors are
     concatenated (`res_link.enable`), or only the last level is pooled.  Returns (B, 1024 * levels) and the list
@@ -104,8 +115,8 @@ class FeatureLearningBlock(_Encoder):
         """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors."""
         levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None)
         if not self.res_link_enable:
-            return self.conv(levels[-1].feat).amax(dim=-1)
-        pooled = [head(level.feat).amax(dim=-1) for head, level in zip(self.conv_list, levels)]
+            return _pooled_head(self.conv, levels[-1].feat)
+        pooled = [_pooled_head(head, level.feat) for head, level in zip(self.conv_list, levels)]
         self.res_link_list = pooled
         return torch.cat(pooled, dim=1), pooled
 

@@ -98,6 +98,17 @@ int samble_launch_select_chain(const void*, const int*, const float*, int, int, 
                                const float*, int, float*, float*, int, float, float, int, int, unsigned char*, int*, float*,
                                float*, int*, unsigned int, hipStream_t);
 size_t samble_chain_flag_offset(void);
+size_t samble_linear_image_bytes_impl(int O);
+int samble_launch_linear_images(const float*, int, void*, void*, hipStream_t);
+int samble_launch_linear_fwd(const float*, long, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
+size_t samble_linear_amax_ws_bytes(int, int, int);
+int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
+int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, float*, long, hipStream_t);
+size_t samble_linear_dw_ws_bytes(int, int, int);
+int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, float*, void*, hipStream_t);
+size_t samble_amax_bwd_ws_bytes(int, int);
+int samble_launch_amax_bwd(const float*, long, int, int, const int*, const float*, const float*, int, float*, long, float*,
+                           void*, hipStream_t);
 }
 
 namespace {
@@ -836,6 +847,78 @@ SAMBLE_API int samble_select_chain_status_async(const void* ws, int B, int N, in
   const char* word = (const char*)ws + chain_score_bytes(B, N) + samble_chain_flag_offset();
   return done((int)hipMemcpyAsync(host_flag, word, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
               "samble_select_chain_status_async");
+}
+
+/* ---- 1x1 convolutions over 128 input channels (csrc/linear.hip) ------------------------------------------------- */
+static int lin_shape_ok(int B, int N, int O) { return B > 0 && N > 0 && O >= 32 && O <= 4096 && (O & 31) == 0; }
+
+SAMBLE_API size_t samble_linear_image_bytes(int O) { return O > 0 ? samble_linear_image_bytes_impl(O) : 0; }
+
+SAMBLE_API int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream) {
+  if (!W || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: C must be 128, O a multiple of 32");
+  return done(samble_launch_linear_images(W, O, rm_image, tr_image, (hipStream_t)stream), "samble_linear_weight_images_f32");
+}
+
+SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O,
+                                         int epilogue, const float* ref, float* out, int64_t o_bs, int64_t o_rs,
+                                         void* stream) {
+  if (!x || !w_rm_image || !out) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: C must be 128, O a multiple of 32");
+  if (epilogue < SAMBLE_LIN_PLAIN || epilogue > SAMBLE_LIN_LEAKY_MASK || (epilogue == SAMBLE_LIN_LEAKY_MASK && !ref))
+    return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: unknown epilogue, or the mask epilogue without ref");
+  if ((o_rs & 3) || (o_bs & 3) || o_rs < O) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: output strides must be multiples of 4");
+  return done(samble_launch_linear_fwd(x, x_bs, B, N, w_rm_image, O, epilogue, ref, out, o_bs, o_rs, (hipStream_t)stream),
+              "samble_linear_fwd_tri_f32");
+}
+
+SAMBLE_API size_t samble_linear_amax_workspace_bytes(int B, int N, int O) {
+  return lin_shape_ok(B, N, O) ? samble_linear_amax_ws_bytes(B, N, O) : 0;
+}
+
+SAMBLE_API int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O,
+                                              float* y, int32_t* arg, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !w_rm_image || !y || !arg || !ws) return fail(SAMBLE_E_INVALID, "samble_linear_amax_fwd_tri_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_amax_fwd_tri_f32: C must be 128, O a multiple of 32");
+  if (ws_bytes < samble_linear_amax_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_amax_fwd_tri_f32: workspace too small");
+  return done(samble_launch_linear_amax(x, x_bs, B, N, w_rm_image, O, y, arg, ws, (hipStream_t)stream),
+              "samble_linear_amax_fwd_tri_f32");
+}
+
+SAMBLE_API int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const void* w_tr_image, int O, int B, int C,
+                                        int N, float* dx, int64_t dx_bs, void* stream) {
+  if (!g || !w_tr_image || !dx) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: C must be 128, O a multiple of 32");
+  if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: g rows must be 16-byte aligned");
+  return done(samble_launch_linear_dx(g, g_bs, g_rs, w_tr_image, O, B, N, dx, dx_bs, (hipStream_t)stream), "samble_linear_dx_tri_f32");
+}
+
+SAMBLE_API size_t samble_linear_dw_workspace_bytes(int B, int N, int O) {
+  return lin_shape_ok(B, N, O) ? samble_linear_dw_ws_bytes(B, N, O) : 0;
+}
+
+SAMBLE_API int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
+                                        int N, int O, float* dW, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !x || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(B, N, O) || (O & 255))
+    return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: C must be 128, O a multiple of 256");
+  if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: g rows must be 16-byte aligned");
+  if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_tri_f32: workspace too small");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, N, O, dW, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
+}
+
+SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int O) { return (B > 0 && O > 0) ? samble_amax_bwd_ws_bytes(B, O) : 0; }
+
+SAMBLE_API int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy,
+                                   const float* W, int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  if (!x || !arg || !gy || !W || !dx_zeroed || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: null pointer");
+  if (C != 128 || B <= 0 || N <= 0 || O <= 0 || (O & 3) || N > 32767 || O > 8192)
+    return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: C must be 128, N <= 32767, O <= 8192 and a multiple of 4");
+  if (((size_t)N + 1 + 3 * (size_t)O) * 4 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: N + 3 O too large for LDS");
+  if (ws_bytes < samble_amax_bwd_ws_bytes(B, O)) return fail(SAMBLE_E_WORKSPACE, "samble_amax_bwd_f32: workspace too small");
+  return done(samble_launch_amax_bwd(x, x_bs, B, N, arg, gy, W, O, dx_zeroed, dx_bs, dW, ws, (hipStream_t)stream),
+              "samble_amax_bwd_f32");
 }
 
 SAMBLE_API size_t samble_proj_workspace_bytes(int B, int N) {

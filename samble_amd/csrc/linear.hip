@@ -1,0 +1,595 @@
+// 1x1 convolutions over 128 input channels around the neighbour / sampler kernels, on the bf16 matrix cores with split
+// fp32 operands (tri_dev.h: six partial products per fp32 product, fp32 accumulation):
+//
+//   reference                                                       here
+//   models/attention.py:187-192  ff = Conv1d 128->512, LeakyReLU(0.2), Conv1d 512->128   lin_fwd (+ leaky), lin_dx;
+//                                (and its autograd)                                      backward: lin_fwd (+ mask), lin_dx, lin_dw x 2
+//   models/cls_model.py:136      conv_list[i](x).max(dim=-1): Conv1d 128->1024 + max    lin_fwd<AMAX>: the (B, 1024, N) tensor
+//                                over the points                                         (268 MB at N=2048) is never written;
+//                                (and its autograd: only the arg-max column counts)      backward: amax_bwd (sparse, ordered)
+//
+// Same tile machinery as the QKV projection (proj_tri.hip), for any output width O that is a multiple of 32:
+//   lin_fwd   out[n][o] = sum_c W[o][c] x[c][n]      x channel-major (B,128,N) -> point-major rows (B,N,O); A: W row-image
+//             tiles through a ring of 4 LDS slots by LDS-DMA, B: the point's channels split in registers
+//   lin_dx    dx[c][n]  = sum_o W[o][c] g[n][o]      point-major (B,N,O) -> channel-major (B,128,N); A: W transposed-image
+//             tiles, B: 16 outputs of the point's row per k-step
+//   lin_dw    dW[o][c]  = sum_n g[n][o] x[c][n]      per-workgroup partials (256 outputs x 128 channels over 512 points),
+//             summed in a fixed order by lin_sum_parts: deterministic, no float atomics
+#include "tri_dev.h"
+
+namespace samble {
+
+constexpr int kLinDepth = 4;
+constexpr int kLinLds = kLinDepth * kTriTile;
+enum { kLinPlain = 0, kLinLeaky = 1, kLinMask = 2, kLinAmax = 3 };
+constexpr float kLeakySlope = 0.2f;
+
+__device__ __forceinline__ void lin_glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// max over the 32 lanes of each half of the wave (DPP: quad swaps, half-row and row mirrors, row broadcast), delivered in
+// lanes 31 and 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float lin_dpp_f(float x, float old) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(x), CTRL,
+                                                               ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_max(float x) {
+  x = fmaxf(x, lin_dpp_f<0xB1, 0xF>(x, x));   // quad_perm [1,0,3,2]
+  x = fmaxf(x, lin_dpp_f<0x4E, 0xF>(x, x));   // quad_perm [2,3,0,1]
+  x = fmaxf(x, lin_dpp_f<0x141, 0xF>(x, x));  // row_half_mirror
+  x = fmaxf(x, lin_dpp_f<0x140, 0xF>(x, x));  // row_mirror: every lane of a row of 16 holds the row's max
+  x = fmaxf(x, lin_dpp_f<0x142, 0xA>(x, x));  // row_bcast15 -> rows 1, 3 (lanes of rows 0, 2 keep their value: old = x)
+  return x;                                    // lanes 16..31 / 48..63 hold the half's max
+}
+
+// EPI  kLinPlain: out = W x            kLinLeaky: out = leaky(W x)
+//      kLinMask:  out = (W x) * (ref > 0 ? 1 : 0.2)   (ref: same layout as out -- the activation the forward kept)
+//      kLinAmax:  no out: per 32-point tile the maximum of every output row over the tile's points and the first point
+//                 that reaches it -> pmax / parg [(b, tile, o)]
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int N,
+                                                             const char* __restrict__ Wimg, int otiles, int O,
+                                                             float* __restrict__ out, long o_bs, long o_rs,
+                                                             const float* __restrict__ ref, float* __restrict__ pmax,
+                                                             int* __restrict__ parg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kLinDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  // points past N-1 are clamped: those lanes recompute and rewrite point N-1's row bit for bit (no predicated store)
+  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  auto stage = [&](int t) {
+    const char* gt = Wimg + (long)min(t, otiles - 1) * kTriTile;
+    char* lt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lin_glds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) stage(t);
+  u32x4 xq[24];  // this point's channels as the B operand: k-step ks, half h <-> channels 16 ks + 8 h + e
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[(long)b * x_bs + (long)(16 * ks + 8 * h + e) * N + n];
+    const Tri t3 = tri_split8(v);
+    xq[3 * ks] = t3.h;
+    xq[3 * ks + 1] = t3.m;
+    xq[3 * ks + 2] = t3.l;
+  }
+  float* orow = (EPI == kLinAmax) ? nullptr : out + (long)b * o_bs + (long)n * o_rs + 4 * h;
+  const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h : nullptr;
+  const long ptile = (long)b * (gridDim.x * 8) + chunk * 8 + wave;   // (b, 32-point tile) of this wave
+  const int n_first = chunk * 256 + wave * 32;
+  f32x4 rf[4];
+  if (EPI == kLinMask) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rf[g] = *reinterpret_cast<const f32x4*>(rrow + 8 * g);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // iteration t: [mask: the activation words of tile t+1], tile t+3 into the slot of tile t-1, the product of tile t, its
+  // stores.  VM operations younger than tile t+1's DMA at the end of iteration t (in-order retirement): plain / leaky
+  // 4 + 2 x (3 + 4) = 18; mask 4 + 2 x (4 + 3 + 4) = 26; amax 2 + 2 x (3 + 2) = 12.  Counting LOW is the safe side.
+  float res_m = 0.f;
+  int res_a = 0;
+  for (int t = 0; t < otiles; ++t) {
+    f32x4 rn[4];
+    if (EPI == kLinMask) {
+      const float* rp = rrow + min(t + 1, otiles - 1) * 32;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(rp + 8 * g);
+    }
+    stage(t + D - 1);
+    const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
+    f32x16 acc = zero16();  // D[row = output 32 t + crow(r, h)][col = point]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
+      const Tri bq = {xq[3 * ks], xq[3 * ks + 1], xq[3 * ks + 2]};
+      acc = mfma_tri(a, bq, acc);
+    }
+    if (EPI == kLinAmax) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float hm = half_wave_max(acc[r]);
+        const float m0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(hm), 31));
+        const float m1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(hm), 63));
+        const float m = h ? m1 : m0;
+        const unsigned long long hit = __ballot(acc[r] == m);   // (a NaN row: no lane hits, index 0 of the tile)
+        const int a0 = __builtin_ctz((unsigned)hit | 0x80000000u) & 31;
+        const int a1 = __builtin_ctz((unsigned)(hit >> 32) | 0x80000000u) & 31;
+        const bool mine = (lo & 15) == r;
+        res_m = mine ? m : res_m;
+        res_a = mine ? (h ? a1 : a0) : res_a;
+      }
+      // lanes (lo, h) and (lo + 16, h) hold row crow(lo & 15, h) of the tile: the same value to the same address
+      const long at = ptile * O + t * 32 + crow(lo & 15, h);
+      pmax[at] = res_m;
+      parg[at] = min(n_first + res_a, N - 1);
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (EPI == kLinLeaky) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : kLeakySlope * o[e];
+        }
+        if (EPI == kLinMask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rf[g][e] > 0.f ? o[e] : kLeakySlope * o[e];
+        }
+        *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
+      }
+      if (EPI == kLinMask) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rf[g] = rn[g];
+        asm volatile("s_waitcnt vmcnt(26) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+  }
+}
+
+// (b, tile, o) partial maxima -> y[b][o] = max over the tiles, arg[b][o] = the first point that reaches it (tiles in
+// ascending point order: the first tile with the maximum wins)
+__global__ __launch_bounds__(256) void lin_amax_reduce_kernel(const float* __restrict__ pmax, const int* __restrict__ parg,
+                                                              int ntiles, int O, float* __restrict__ y,
+                                                              int* __restrict__ arg) {
+  const int b = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= O) return;
+  const float* pm = pmax + (long)b * ntiles * O + o;
+  const int* pa = parg + (long)b * ntiles * O + o;
+  float m = pm[0];
+  int a = pa[0];
+  for (int t = 1; t < ntiles; ++t) {
+    const float v = pm[(long)t * O];
+    const int av = pa[(long)t * O];
+    if (v > m || (v == m && av < a)) {
+      m = v;
+      a = av;
+    }
+  }
+  y[(long)b * O + o] = m;
+  arg[(long)b * O + o] = a;
+}
+
+// dx[c][n] = sum_o W[o][c] g[n][o] (proj_dx_tri_kernel with a run-time tile count)
+__global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
+                                                            const char* __restrict__ Wtr, int otiles, int N,
+                                                            float* __restrict__ dx, long dx_bs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kLinDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  const float* grow = g + (long)b * g_bs + (long)n * g_rs + 4 * h;
+  auto stage = [&](int t) {
+    const char* gt = Wtr + (long)min(t, otiles - 1) * kTriTile;
+    char* lt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lin_glds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+  };
+  // this lane's 16 gradient values of tile t in the transposed image's element order (k-step s, element e <-> output
+  // 32 t + 16 s + 8 (e >> 2) + 4 h + (e & 3)); loads in assembly so that the compiler does not count them (it would wait
+  // for them with vmcnt(0) behind the DMA pieces just issued): the hand-counted wait below names the registers
+  auto load_g = [&](int t, f32x4 (&dst)[4]) {
+    const float* p = grow + min(t, otiles - 1) * 32;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])
+                 : "v"(p)
+                 : "memory");
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) stage(t);
+  f32x16 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = zero16();
+  f32x4 gn[4], gnn[4];
+  Tri bg[2], nb[2];
+  load_g(0, gnn);
+  load_g(1, gn);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3]), "+v"(gn[0]), "+v"(gn[1]), "+v"(gn[2]), "+v"(gn[3])::"memory");
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const float v[8] = {gnn[2 * ks][0], gnn[2 * ks][1], gnn[2 * ks][2], gnn[2 * ks][3],
+                        gnn[2 * ks + 1][0], gnn[2 * ks + 1][1], gnn[2 * ks + 1][2], gnn[2 * ks + 1][3]};
+    bg[ks] = tri_split8(v);
+  }
+  for (int t = 0; t < otiles; ++t) {
+    load_g(t + 2, gnn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    stage(t + D - 1);
+    const char* wt = smem_c + (t % D) * kTriTile;
+    auto fetch = [&](int i) {
+      const char* ap = wt + tri_tr_off(32 * (i & 3) + lo, 2 * (i >> 2) + h, 0);
+      return Tri{*reinterpret_cast<const u32x4*>(ap), *reinterpret_cast<const u32x4*>(ap + 2048),
+                 *reinterpret_cast<const u32x4*>(ap + 4096)};
+    };
+    Tri a0 = fetch(0), a1 = fetch(1), a2 = fetch(2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // k-step i >> 2, channel tile i & 3; pair i of tile t+1's values split beside it
+      const int ks = i >> 2, ct = i & 3;
+      Tri a3 = a2;
+      if (i + 3 < 8) a3 = fetch(i + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[ct] = mfma_tri(a0, bg[ks], acc[ct]);
+      unsigned hh, mm, ll;
+      tri_split2(gn[2 * ks + (ct >> 1)][2 * (ct & 1)], gn[2 * ks + (ct >> 1)][2 * (ct & 1) + 1], hh, mm, ll);
+      nb[ks].h[ct] = hh;
+      nb[ks].m[ct] = mm;
+      nb[ks].l[ct] = ll;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = a1;
+      a1 = a2;
+      a2 = a3;
+    }
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gn[i] = gnn[i];
+    bg[0] = nb[0];
+    bg[1] = nb[1];
+  }
+  float* ob = dx + (long)b * dx_bs + n;  // rows past N-1 hold point N-1's column again: same values, same address
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
+  }
+}
+
+// dW partials: workgroup = (512-point chunk, cloud, block of 256 outputs); wave w owns output rows 64 (w >> 1) .. +63 of
+// the block and channels 64 (w & 1) .. +63: four accumulator tiles.  Both operands are transposed through LDS (the
+// contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
+constexpr int kLdwPts = 512, kLdwOB = 256;
+constexpr int kLdwGS = kLdwOB + 4, kLdwXS = 33;  // row strides: g tile rows 16-byte aligned, column reads conflict-free
+constexpr int kLdwBuf = kTile * kLdwGS + 128 * kLdwXS;
+constexpr int kLdwLds = 2 * kLdwBuf * 4;
+
+__global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
+                                                            const float* __restrict__ x, long x_bs, int N, int O,
+                                                            float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  float* smem = reinterpret_cast<float*>(smem_c);
+  constexpr int GS = kLdwGS, XS = kLdwXS, BUF = kLdwBuf;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const int og = wave >> 1, ch = wave & 1;
+  const int b = blockIdx.y, o0 = blockIdx.z * kLdwOB;
+  const int n0 = blockIdx.x * kLdwPts;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = zero16();
+  f32x4 gst[4];  // 32 rows x 64 float4 = 2048 float4 / 512 threads
+  float xst[8];  // 128 channels x 32 points = 4096 floats / 512 threads
+  auto issue = [&](int nn0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 512 * it;
+      const int r = e >> 6, c4 = (e & 63) * 4;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      gst[it] = (nn0 + r < N) ? *reinterpret_cast<const f32x4*>(g + (long)b * g_bs + (long)(nn0 + r) * g_rs + o0 + c4) : z4;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 512 * it;
+      const int c = e >> 5, pnt = e & 31;
+      xst[it] = (nn0 + pnt < N) ? x[(long)b * x_bs + (long)c * N + nn0 + pnt] : 0.f;
+    }
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = tid + 512 * it;
+      const int r = e >> 6, c4 = (e & 63) * 4;
+      *reinterpret_cast<f32x4*>(buf + r * GS + c4) = gst[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + 512 * it;
+      buf[kTile * GS + (e >> 5) * XS + (e & 31)] = xst[it];
+    }
+  };
+  constexpr int ntiles = kLdwPts / kTile;
+  issue(n0);
+  commit(smem);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    float* cur = smem + (t & 1) * BUF;
+    float* nxt = smem + ((t & 1) ^ 1) * BUF;
+    if (t + 1 < ntiles) issue(n0 + (t + 1) * kTile);
+    const float* gt = cur;
+    const float* xt = cur + kTile * GS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // points 16 ks .. 16 ks + 15; lane half h: the 8 points 16 ks + 8 h + e
+      Tri bq[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xt[(64 * ch + 32 * ct + lo) * XS + 16 * ks + 8 * h + e];
+        bq[ct] = tri_split8(v);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * ks + 8 * h + e) * GS + 64 * og + 32 * ot + lo];
+        const Tri a = tri_split8(v);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[ot][ct] = mfma_tri(a, bq[ct], acc[ot][ct]);
+      }
+    }
+    if (t + 1 < ntiles) commit(nxt);
+    __syncthreads();
+  }
+  float* outp = part + ((long)b * gridDim.x + blockIdx.x) * O * 128;
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + 64 * og + 32 * ot + crow(r, h);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) outp[(long)o * 128 + 64 * ch + 32 * ct + lo] = acc[ot][ct][r];
+    }
+}
+
+// out[e] = sum over the nparts partial blocks (each n4 float4) in a fixed order: 16 groups of threads take the parts
+// p = g, g + 16, ... (16 loads in flight each), then the 16 group sums are added in index order
+__global__ __launch_bounds__(256) void lin_sum_parts_kernel(const float* __restrict__ part, int nparts, long n4,
+                                                            float* __restrict__ out) {
+  __shared__ f32x4 red[16][17];
+  const int e4l = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long e4 = (long)blockIdx.x * 16 + e4l;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (e4 < n4) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + e4;
+    for (int p0 = g; p0 < nparts; p0 += 16 * 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int p = p0 + 16 * u;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        v[u] = (p < nparts) ? p4[(long)p * n4] : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+  }
+  red[g][e4l] = s;
+  __syncthreads();
+  if (g == 0 && e4 < n4) {
+    f32x4 tot = red[0][e4l];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tot += red[k][e4l];
+    reinterpret_cast<f32x4*>(out)[e4] = tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of y[b][o] = max_n (W x)[o][n] (models/cls_model.py:136 and its autograd): only the arg-max column of each
+// (cloud, output) carries gradient --
+//   dx[b][:, n] = sum over the outputs o with arg[b][o] = n of gy[b][o] W[o][:]     (every other column: 0)
+//   dW[o][:]    = sum over the clouds b of gy[b][o] x[b][:, arg[b][o]]
+// One workgroup per cloud: the O outputs are grouped by their arg-max point with a counting sort in LDS (order inside a
+// group: ascending output), a wave per group sums its W rows in that order (deterministic) and writes the point's 128
+// gradient values; the per-cloud dW rows go to dwp[b][o][:] and are summed over the clouds by lin_sum_parts.
+// (Exact ties of the maximum go to the lowest point index; torch.amax's backward splits them evenly.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void amax_bwd_kernel(const float* __restrict__ x, long x_bs, int N,
+                                                        const int* __restrict__ arg, const float* __restrict__ gy,
+                                                        const float* __restrict__ W, int O, float* __restrict__ dx,
+                                                        long dx_bs, float* __restrict__ dwp) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  int* cnt = reinterpret_cast<int*>(smem_c);        // N + 1 words: points' group sizes, then their start offsets
+  int* ord = cnt + N + 1;                           // O words: outputs grouped by point
+  int* pts = ord + O;                               // O words: the distinct points in ascending order
+  int* abl = pts + O;                               // O words: this cloud's arg-max points
+  __shared__ int wtot[16];
+  __shared__ int ngroups_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int* ab = arg + (long)b * O;
+  for (int n = tid; n <= N; n += 1024) cnt[n] = 0;
+  for (int o = tid; o < O; o += 1024) abl[o] = min(max(ab[o], 0), N - 1);
+  __syncthreads();
+  for (int o = tid; o < O; o += 1024) atomicAdd(&cnt[abl[o]], 1);
+  __syncthreads();
+  // exclusive scan of cnt[0..N) in place; each thread owns a contiguous run of per = ceil(N / 1024) points
+  const int per = (N + 1023) / 1024, lo_n = tid * per, hi_n = min(lo_n + per, N);
+  int run = 0, distinct = 0;
+  for (int n = lo_n; n < hi_n; ++n) {
+    run += cnt[n];
+    distinct += cnt[n] > 0;
+  }
+  int incl = run, dincl = distinct;
+#pragma unroll
+  for (int ofs = 1; ofs < 64; ofs <<= 1) {
+    const int u = __shfl_up(incl, ofs, 64), du = __shfl_up(dincl, ofs, 64);
+    if (lane >= ofs) {
+      incl += u;
+      dincl += du;
+    }
+  }
+  if (lane == 63) wtot[wave] = incl | (dincl << 16);   // (O, N <= 32767 each)
+  __syncthreads();
+  int base = 0, dbase = 0;
+  for (int w = 0; w < wave; ++w) {
+    base += wtot[w] & 0xFFFF;
+    dbase += wtot[w] >> 16;
+  }
+  int start = base + incl - run, dpos = dbase + dincl - distinct;
+  for (int n = lo_n; n < hi_n; ++n) {
+    const int c = cnt[n];
+    cnt[n] = start;
+    if (c > 0) pts[dpos++] = n;
+    start += c;
+  }
+  if (tid == 1023) {
+    cnt[N] = O;
+    ngroups_s = dbase + dincl;
+  }
+  __syncthreads();
+  // placement, ascending output inside a group: output o goes to start[n] + #{o' < o : arg[o'] = n}
+  for (int o = tid; o < O; o += 1024) {
+    const int n = abl[o];
+    int before = 0;
+    for (int o2 = 0; o2 < o; ++o2) before += (abl[o2] == n);   // (wave-uniform o2: broadcast LDS reads)
+    ord[cnt[n] + before] = o;
+  }
+  __syncthreads();
+  const int ngroups = ngroups_s;
+  for (int gi = wave; gi < ngroups; gi += 16) {
+    const int n = pts[gi];
+    const int s0 = cnt[n], s1 = (gi + 1 < ngroups) ? cnt[pts[gi + 1]] : O;
+    const float x0 = x[(long)b * x_bs + (long)lane * N + n], x1 = x[(long)b * x_bs + (long)(lane + 64) * N + n];
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = s0; k < s1; ++k) {
+      const int o = ord[k];
+      const float gv = gy[(long)b * O + o];
+      a0 = fmaf(gv, W[(long)o * 128 + lane], a0);
+      a1 = fmaf(gv, W[(long)o * 128 + lane + 64], a1);
+      dwp[((long)b * O + o) * 128 + lane] = gv * x0;
+      dwp[((long)b * O + o) * 128 + lane + 64] = gv * x1;
+    }
+    dx[(long)b * dx_bs + (long)lane * N + n] = a0;
+    dx[(long)b * dx_bs + (long)(lane + 64) * N + n] = a1;
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B, int rows, void* rm, void* tr,
+                                       hipStream_t stream);
+
+extern "C" size_t samble_linear_image_bytes_impl(int O) { return (size_t)((O + 31) / 32) * kTriTile; }
+
+// row image and / or transposed image of W (O x 128, row-major)
+extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, hipStream_t s) {
+  return samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
+}
+
+extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int N, const void* w_rm, int O, int epi,
+                                        const float* ref, float* out, long o_bs, long o_rs, hipStream_t s) {
+  const void* fns[3] = {reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain>),
+                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinLeaky>),
+                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinMask>)};
+  hipError_t e = hipFuncSetAttribute(fns[epi], hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid((N + 255) / 256, B);
+  Timed timed(kT_lin_fwd, s);
+  if (epi == kLinPlain)
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr);
+  else if (epi == kLinLeaky)
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr);
+  else
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+                       out, o_bs, o_rs, ref, nullptr, nullptr);
+  return (int)hipGetLastError();
+}
+
+// workspace: partial maxima + indices of the ceil(N / 256) * 8 point tiles of every cloud
+extern "C" size_t samble_linear_amax_ws_bytes(int B, int N, int O) {
+  return (size_t)B * ((N + 255) / 256) * 8 * O * 8;
+}
+
+extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N, const void* w_rm, int O, float* y,
+                                         int* arg, void* ws, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinAmax>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  if (e != hipSuccess) return (int)e;
+  const int chunks = (N + 255) / 256, ntiles = chunks * 8;
+  float* pmax = (float*)ws;
+  int* parg = (int*)(pmax + (size_t)B * ntiles * O);
+  Timed timed(kT_lin_amax, s);
+  hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B), dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm,
+                     O / 32, O, nullptr, 0, 0, nullptr, pmax, parg);
+  hipLaunchKernelGGL(lin_amax_reduce_kernel, dim3((O + 255) / 256, B), dim3(256), 0, s, pmax, parg, ntiles, O, y, arg);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int N,
+                                       float* dx, long dx_bs, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dx_tri_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_lin_dx, s);
+  hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
+                     O / 32, N, dx, dx_bs);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t samble_linear_dw_ws_bytes(int B, int N, int O) {
+  return (size_t)B * ((N + kLdwPts - 1) / kLdwPts) * O * 128 * sizeof(float);
+}
+
+extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int N, int O,
+                                       float* dW, void* ws, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdwLds);
+  if (e != hipSuccess) return (int)e;
+  const int chunks = (N + kLdwPts - 1) / kLdwPts;
+  Timed timed(kT_lin_dw, s);
+  hipLaunchKernelGGL(lin_dw_tri_kernel, dim3(chunks, B, O / kLdwOB), dim3(512), kLdwLds, s, g, g_bs, g_rs, x, x_bs, N, O,
+                     (float*)ws);
+  const long n4 = (long)O * 128 / 4;
+  hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B * chunks,
+                     n4, dW);
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t samble_amax_bwd_ws_bytes(int B, int O) { return (size_t)B * O * 128 * sizeof(float); }
+
+// dx must be ZERO on entry (the kernel writes the arg-max columns only)
+extern "C" int samble_launch_amax_bwd(const float* x, long x_bs, int B, int N, const int* arg, const float* gy,
+                                      const float* W, int O, float* dx, long dx_bs, float* dW, void* ws, hipStream_t s) {
+  const size_t lds = ((size_t)N + 1 + 3 * (size_t)O) * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(amax_bwd_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_lin_amax_bwd, s);
+  hipLaunchKernelGGL(amax_bwd_kernel, dim3(B), dim3(1024), lds, s, x, x_bs, N, arg, gy, W, O, dx, dx_bs, (float*)ws);
+  const long n4 = (long)O * 128 / 4;
+  hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B, n4, dW);
+  return (int)hipGetLastError();
+}

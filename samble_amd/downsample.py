@@ -32,6 +32,16 @@ from torch import nn
 from . import ops
 
 
+def _res_ffn(ffn: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """the residual link's Conv1d 128->512, LeakyReLU(0.2), Conv1d 512->128 (models/downsample.py:75-83) on the HIP
+    1x1-convolution kernels when the shape is theirs"""
+    from . import linear
+    w1, w2 = ffn[0].weight, ffn[2].weight
+    if ffn[0].bias is None and ffn[2].bias is None and linear.ffn_supported(x, w1, w2):
+        return linear.ffn(x, w1, w2)
+    return ffn(x)
+
+
 class _Projection(torch.autograd.Function):
     """q_conv / k_conv / v_conv of the reference (bias-free 1x1 Conv1d, models/downsample.py:54-56,
     124-137) as ONE fp32-MFMA kernel producing point-major [Q|K|V] rows for x and the bin tokens."""
@@ -405,7 +415,7 @@ class DownSampleToken(nn.Module):
         x_tmp = torch.gather(x, dim=-1, index=idx)
         x_res = self.bn1(x_ds + x_tmp)
         if self.ff == True:  # noqa: E712  (reference semantics)
-            x_tmp = self.ffn(x_res)
+            x_tmp = _res_ffn(self.ffn, x_res)
             x_res = self.bn2(x_ds + x_tmp)
         return x_res
 
@@ -642,7 +652,7 @@ class DownSampleGlobal(nn.Module):
         x_tmp = torch.gather(x, dim=-1, index=self.idx)
         x_res = self.bn1(x_ds + x_tmp)
         if self.ff == True:  # noqa: E712
-            x_tmp = self.ffn(x_res)
+            x_tmp = _res_ffn(self.ffn, x_res)
             x_res = self.bn2(x_ds + x_tmp)
         return x_res
 
@@ -837,6 +847,6 @@ class DownSampleLocal(nn.Module):
         x_tmp = torch.gather(x, dim=-1, index=self.idx)
         x_res = self.bn1(x_ds + x_tmp)
         if self.ff == True:  # noqa: E712
-            x_tmp = self.ffn(x_res)
+            x_tmp = _res_ffn(self.ffn, x_res)
             x_res = self.bn2(x_ds + x_tmp)
         return x_res

@@ -1,0 +1,183 @@
+"""1x1 convolutions over 128 input channels on the HIP kernels of csrc/linear.hip, behind two autograd nodes:
+
+* `ffn(x, w1, w2)`       = Conv1d(128->H) -> LeakyReLU(0.2) -> Conv1d(H->128), the feed-forward part of the reference's
+                           attention layers (models/attention.py:187-192, `self.ff`), H a multiple of 256;
+* `linear_max(x, w)`     = Conv1d(128->O)(x).max(dim=-1)[0], the pooled heads of the classification trunk
+                           (models/cls_model.py:113, 136, 144), O a multiple of 32 -- the (B, O, N) tensor is never built.
+
+x is channel-major (B, 128, N) as the modules hold it; weights are the Conv1d weights (out, in, 1).  fp32 in and out;
+products on the bf16 matrix cores with split fp32 operands (fp32-equivalent, csrc/tri_dev.h).  No CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _f32c, _need_gpu, _p, _stream
+
+LIN_PLAIN, LIN_LEAKY, LIN_LEAKY_MASK = 0, 1, 2   # include/samble.h SAMBLE_LIN_*
+
+
+def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True):
+    """W (O, 128) -> (row image | None, transposed image | None) as uint8 tensors (include/samble.h: operand images)."""
+    _need_gpu(W)
+    W = _f32c(W)
+    O, C = W.shape
+    with torch.cuda.device(W.device):
+        nbytes = _lib.query("samble_linear_image_bytes", O)
+        rm = torch.empty(nbytes, dtype=torch.uint8, device=W.device) if want_rm else None
+        tr = torch.empty(nbytes, dtype=torch.uint8, device=W.device) if want_tr else None
+        _lib.call("samble_linear_weight_images_f32", W.data_ptr(), O, C, _p(rm), _p(tr), _stream())
+    return rm, tr
+
+
+def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int = LIN_PLAIN, ref=None) -> torch.Tensor:
+    """x (B,128,N) -> (B,N,O) point-major rows: epilogue(W x)."""
+    _need_gpu(x, w_rm, ref)
+    x = _f32c(x)
+    B, C, N = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((B, N, O), dtype=torch.float32, device=x.device)
+        if ref is not None and (ref.shape != out.shape or not ref.is_contiguous() or ref.dtype != torch.float32):
+            raise ValueError("ref must be a contiguous fp32 (B, N, O) tensor")
+        _lib.call("samble_linear_fwd_tri_f32", x.data_ptr(), C * N, B, C, N, w_rm.data_ptr(), O, int(epilogue), _p(ref),
+                  out.data_ptr(), out.stride(0), out.stride(1), _stream())
+    return out
+
+
+def stage_linear_amax(x: torch.Tensor, w_rm: torch.Tensor, O: int):
+    """x (B,128,N) -> (y (B,O) = max over the points of W x, arg (B,O) int32 = the first point that reaches it)."""
+    _need_gpu(x, w_rm)
+    x = _f32c(x)
+    B, C, N = x.shape
+    with torch.cuda.device(x.device):
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        arg = torch.empty((B, O), dtype=torch.int32, device=x.device)
+        nbytes = _lib.query("samble_linear_amax_workspace_bytes", B, N, O)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call("samble_linear_amax_fwd_tri_f32", x.data_ptr(), C * N, B, C, N, w_rm.data_ptr(), O, y.data_ptr(),
+                  arg.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return y, arg
+
+
+def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int) -> torch.Tensor:
+    """g (B,N,O) point-major -> (B,128,N): W^T g."""
+    _need_gpu(g, w_tr)
+    g = _f32c(g)
+    B, N, Og = g.shape
+    assert Og == O
+    with torch.cuda.device(g.device):
+        dx = torch.empty((B, 128, N), dtype=torch.float32, device=g.device)
+        _lib.call("samble_linear_dx_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), w_tr.data_ptr(), O, B, 128, N,
+                  dx.data_ptr(), 128 * N, _stream())
+    return dx
+
+
+def stage_linear_dw(g: torch.Tensor, x: torch.Tensor, O: int) -> torch.Tensor:
+    """g (B,N,O), x (B,128,N) -> dW (O,128) = sum over clouds and points of g^T x^T (deterministic)."""
+    _need_gpu(g, x)
+    g, x = _f32c(g), _f32c(x)
+    B, N, Og = g.shape
+    assert Og == O and x.shape == (B, 128, N)
+    with torch.cuda.device(g.device):
+        dW = torch.empty((O, 128), dtype=torch.float32, device=g.device)
+        nbytes = _lib.query("samble_linear_dw_workspace_bytes", B, N, O)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        _lib.call("samble_linear_dw_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), x.data_ptr(), 128 * N, B, 128, N, O,
+                  dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return dW
+
+
+def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor):
+    """Backward of stage_linear_amax: -> (dx (B,128,N), zero outside the arg-max columns; dW (O,128))."""
+    _need_gpu(x, arg, gy, W)
+    x, gy, W = _f32c(x), _f32c(gy), _f32c(W)
+    B, C, N = x.shape
+    O = W.shape[0]
+    with torch.cuda.device(x.device):
+        dx = torch.zeros_like(x)
+        dW = torch.empty((O, 128), dtype=torch.float32, device=x.device)
+        nbytes = _lib.query("samble_amax_bwd_workspace_bytes", B, O)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call("samble_amax_bwd_f32", x.data_ptr(), C * N, B, C, N, arg.data_ptr(), gy.data_ptr(), W.data_ptr(), O,
+                  dx.data_ptr(), C * N, dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return dx, dW
+
+
+class _FFN(torch.autograd.Function):
+    """Conv1d(128->H, no bias) -> LeakyReLU(0.2) -> Conv1d(H->128, no bias) on (B,128,N); the hidden activation lives
+    point-major (B,N,H) and is the only tensor kept for the backward besides the input."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w1, w2):
+        H = w1.shape[0]
+        W1 = w1.reshape(H, 128)
+        W2t = w2.reshape(128, H).t().contiguous()                     # (H, 128): row j = column j of W2
+        w1_rm, w1_tr = weight_images(W1)
+        w2t_rm, w2t_tr = weight_images(W2t)
+        hr = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY)                 # leaky(W1 x), (B,N,H)
+        y = stage_linear_dx(hr, w2t_tr, H)                            # y[c][n] = sum_j W2[c][j] hr[n][j]
+        ctx.save_for_backward(x, hr, w1_tr, w2t_rm)
+        ctx.H = H
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        x, hr, w1_tr, w2t_rm = ctx.saved_tensors
+        H = ctx.H
+        dy = _f32c(dy)
+        dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK, ref=hr)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
+        dx = stage_linear_dx(dh, w1_tr, H) if ctx.needs_input_grad[0] else None
+        dw1 = stage_linear_dw(dh, x, H).reshape(H, 128, 1) if ctx.needs_input_grad[1] else None
+        dw2 = stage_linear_dw(hr, dy, H).t().reshape(128, H, 1) if ctx.needs_input_grad[2] else None
+        return dx, dw1, dw2
+
+
+class _LinearMax(torch.autograd.Function):
+    """Conv1d(128->O, no bias)(x).max(dim=-1)[0]: values only; the gradient goes to the arg-max column (torch.max(dim)
+    routes it to the one index it returned: the first maximum on the CPU reference)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w):
+        O = w.shape[0]
+        W = _f32c(w.reshape(O, 128))
+        w_rm, _ = weight_images(W, want_tr=False)
+        y, arg = stage_linear_amax(x, w_rm, O)
+        ctx.save_for_backward(x, arg, W)
+        ctx.mark_non_differentiable(arg)
+        return y, arg
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy, _):
+        x, arg, W = ctx.saved_tensors
+        dx, dW = stage_amax_bwd(x, arg, gy, W)
+        return dx, dW.reshape(W.shape[0], 128, 1)
+
+
+def ffn_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] == 128 and w1.dim() == 3 and w2.dim() == 3 and w1.shape[1] == 128
+            and w1.shape[2] == 1 and w2.shape[2] == 1 and w2.shape[0] == 128 and w2.shape[1] == w1.shape[0]
+            and w1.shape[0] % 256 == 0 and x.dtype == torch.float32)
+
+
+def ffn(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """models/attention.py:187-192 `self.ff(x)` with the two Conv1d weights."""
+    if not x.is_cuda:
+        raise _lib.SambleError("samble_amd.linear.ffn runs on the GPU only (no CPU fallback)")
+    return _FFN.apply(x, w1, w2)
+
+
+def linear_max_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 3 and x.shape[1] == 128 and w.dim() == 3 and w.shape[1] == 128 and w.shape[2] == 1
+            and w.shape[0] % 32 == 0 and x.shape[2] + 3 * w.shape[0] < 36000 and x.dtype == torch.float32)
+
+
+def linear_max(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """models/cls_model.py:113 `conv(x).max(dim=-1)[0]` -> (B, O)."""
+    if not x.is_cuda:
+        raise _lib.SambleError("samble_amd.linear.linear_max runs on the GPU only (no CPU fallback)")
+    return _LinearMax.apply(x, w)[0]

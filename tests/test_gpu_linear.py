@@ -1,0 +1,129 @@
+"""csrc/linear.hip: the 1x1 convolutions around the neighbour / sampler kernels (reference models/attention.py:187-192:
+the attention layers' feed-forward part; models/cls_model.py:113,136,144: Conv1d + max over the points) against the same
+expressions in float64 torch, forward and backward, at ragged and full sizes."""
+import numpy as np
+import pytest
+import torch
+
+from samble_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _w(shape, seed, scale):
+    return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
+
+
+@pytest.mark.parametrize("B,N,O", [(2, 300, 512), (1, 33, 256), (3, 1024, 512), (2, 77, 1024), (32, 2048, 512)])
+def test_linear_stages_against_float64(B, N, O):
+    from samble_amd import linear as L
+    x = torch.from_numpy(synth.features(B, 128, N, 50 + N)).to(DEV)
+    W = _w((O, 128), 51 + N, 0.09).to(DEV)
+    rm, tr = L.weight_images(W)
+    ref = torch.einsum("oc,bcn->bno", W.double(), x.double())
+    out = L.stage_linear_fwd(x, rm, O)
+    assert out.shape == (B, N, O) and _rel(out, ref) <= 2e-6
+    lk = L.stage_linear_fwd(x, rm, O, L.LIN_LEAKY)
+    assert _rel(lk, torch.nn.functional.leaky_relu(ref, 0.2)) <= 2e-6
+    assert torch.equal(lk, torch.where(out > 0, out, 0.2 * out))                     # the epilogue is elementwise on the same sums
+    mk = L.stage_linear_fwd(x, rm, O, L.LIN_LEAKY_MASK, ref=lk)
+    assert torch.equal(mk, torch.where(lk > 0, out, 0.2 * out))
+    assert torch.equal(L.stage_linear_fwd(x, rm, O), out), "run-to-run identical"
+    # dx: point-major rows back to the channel-major side
+    g = torch.from_numpy(synth.normal((B, N, O), 52 + N)).to(DEV)
+    dx = L.stage_linear_dx(g, tr, O)
+    assert dx.shape == (B, 128, N) and _rel(dx, torch.einsum("oc,bno->bcn", W.double(), g.double())) <= 2e-6
+    # dW: contraction over clouds and points, deterministic
+    if O % 256 == 0:
+        dW = L.stage_linear_dw(g, x, O)
+        assert _rel(dW, torch.einsum("bno,bcn->oc", g.double(), x.double())) <= 3e-6
+        assert torch.equal(L.stage_linear_dw(g, x, O), dW)
+    # max over the points
+    y, arg = L.stage_linear_amax(x, rm, O)
+    ref_y, ref_arg = ref.max(dim=1)
+    assert _rel(y, ref_y) <= 2e-6
+    same = arg.long().cpu() == ref_arg.cpu()
+    # a near-tie of two points may resolve the other way in fp32: the point picked must then hold the maximum to rounding
+    picked = torch.gather(ref, 1, arg.long().unsqueeze(1)).squeeze(1)
+    assert float(same.float().mean()) >= 0.999 and float(((ref_y - picked) / ref_y.abs().clamp_min(1e-3)).max()) <= 1e-5
+    assert torch.equal(y, torch.gather(out, 1, arg.long().unsqueeze(1)).squeeze(1)), "the maximum is one of the kernel's own sums"
+    assert bool((out <= y.unsqueeze(1)).all())
+
+
+@pytest.mark.parametrize("B,N", [(2, 300), (4, 2048), (1, 40)])
+def test_ffn_against_the_torch_modules(B, N):
+    """ffn = Conv1d(128->512) -> LeakyReLU(0.2) -> Conv1d(512->128) with the Conv1d weights (models/attention.py:187-192):
+    output, input gradient and both weight gradients against the stock modules in float64."""
+    from samble_amd import linear as L
+    ff = torch.nn.Sequential(torch.nn.Conv1d(128, 512, 1, bias=False), torch.nn.LeakyReLU(0.2), torch.nn.Conv1d(512, 128, 1, bias=False))
+    with torch.no_grad():
+        ff[0].weight.copy_(_w((512, 128, 1), 61, 0.09))
+        ff[2].weight.copy_(_w((128, 512, 1), 62, 0.045))
+    x = torch.from_numpy(synth.features(B, 128, N, 63 + N))
+    g = torch.from_numpy(synth.normal((B, 128, N), 64 + N))
+    ref = ff.double()
+    xd = x.double().requires_grad_(True)
+    yr = ref(xd)
+    yr.backward(g.double())
+    w1 = ff[0].weight.detach().float().to(DEV).requires_grad_(True)
+    w2 = ff[2].weight.detach().float().to(DEV).requires_grad_(True)
+    xg = x.to(DEV).requires_grad_(True)
+    assert L.ffn_supported(xg, w1, w2)
+    y = L.ffn(xg, w1, w2)
+    y.backward(g.to(DEV))
+    assert _rel(y, yr) <= 3e-6
+    assert _rel(xg.grad, xd.grad) <= 3e-6
+    assert _rel(w1.grad, ref[0].weight.grad) <= 5e-6 and _rel(w2.grad, ref[2].weight.grad) <= 5e-6
+    # deterministic
+    xg2 = x.to(DEV).requires_grad_(True)
+    w1b, w2b = w1.detach().clone().requires_grad_(True), w2.detach().clone().requires_grad_(True)
+    y2 = L.ffn(xg2, w1b, w2b)
+    y2.backward(g.to(DEV))
+    assert torch.equal(y2, y) and torch.equal(xg2.grad, xg.grad) and torch.equal(w1b.grad, w1.grad) and torch.equal(w2b.grad, w2.grad)
+
+
+@pytest.mark.parametrize("B,N,O", [(2, 300, 1024), (32, 2048, 1024), (3, 64, 128)])
+def test_linear_max_against_conv_max(B, N, O):
+    """linear_max = Conv1d(128->O)(x).max(dim=-1)[0] (models/cls_model.py:113,136): values, dx and dW against float64
+    torch (whose max(dim) backward also sends the gradient to the ONE index it returned); a point that is the arg-max of
+    several outputs collects all of them."""
+    from samble_amd import linear as L
+    conv = torch.nn.Conv1d(128, O, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(_w((O, 128, 1), 71, 0.09))
+    x = torch.from_numpy(synth.features(B, 128, N, 72 + N))
+    g = torch.from_numpy(synth.normal((B, O), 73 + N))
+    xd = x.double().requires_grad_(True)
+    cd = conv.double()
+    yr, ar = cd(xd).max(dim=-1)
+    yr.backward(g.double())
+    w = conv.weight.detach().float().to(DEV).requires_grad_(True)
+    xg = x.to(DEV).requires_grad_(True)
+    assert L.linear_max_supported(xg, w)
+    y, arg = L._LinearMax.apply(xg, w)
+    y.backward(g.to(DEV))
+    assert _rel(y, yr) <= 2e-6
+    same = (arg.long().cpu() == ar)
+    assert float(same.float().mean()) >= 0.999
+    if bool(same.all()):
+        assert _rel(xg.grad, xd.grad) <= 3e-6 and _rel(w.grad, cd.weight.grad) <= 3e-6
+    else:  # a near-tie picked another point for a few outputs: the float64 gradient through OUR indices
+        x2 = x.double().requires_grad_(True)
+        cd.zero_grad()
+        torch.gather(cd(x2), 2, arg.long().cpu().unsqueeze(-1)).squeeze(-1).backward(g.double())
+        assert _rel(xg.grad, x2.grad) <= 3e-6 and _rel(w.grad, cd.weight.grad) <= 3e-6
+    # columns that are nobody's arg-max get exactly zero
+    hit = torch.zeros((B, N), dtype=torch.bool)
+    hit.scatter_(1, arg.long().cpu(), True)
+    assert bool((xg.grad.cpu().abs().sum(1)[~hit] == 0).all())
+    # deterministic
+    xg2 = x.to(DEV).requires_grad_(True)
+    wb = w.detach().clone().requires_grad_(True)
+    y2, arg2 = L._LinearMax.apply(xg2, wb)
+    y2.backward(g.to(DEV))
+    assert torch.equal(y2, y) and torch.equal(arg2, arg) and torch.equal(xg2.grad, xg.grad) and torch.equal(wb.grad, w.grad)
