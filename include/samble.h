@@ -483,15 +483,58 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
                                            const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
                                            float* x_ds, float* pmap, int ld, void* stream);
 
+/* ---- the closed forms around the fused EdgeConv's two MLP sweeps (csrc/edge_glue.hip) ------------------------------
+ * EdgeConv (models/embedding.py:7-39) here = per-point projections a, b (B, N, 64) of conv1, samble_edge_mlp_fwd_f32 /
+ * samble_edge_mlp_bwd_f32 over the B N K edges (above), and between them the two BatchNorm2d layers in TRAINING mode,
+ * the LeakyReLU and the max over the K neighbours in closed form on (points, 64) rows.  These entries are that closed
+ * form: per-channel sums in double, workgroup partials added in index order (deterministic, no atomics, no host round
+ * trip).  One caller-owned block each of samble_edge_glue_constants_bytes() (floats the sweeps read: BN scales / shifts,
+ * the backward's correction terms), samble_edge_glue_statistics_bytes() (doubles: mu / sigma of both layers; keep both
+ * from forward to backward) and samble_edge_glue_partials_bytes() (scratch).
+ *   samble_edge_bn1_f32       S_i = sum_k b_j, Q_i = sum_k b_j^2; BN1 batch statistics over the edges; the folded
+ *                             projections ap = a sc1 + sh1, bp = b sc1 the sweeps read; running statistics updated in
+ *                             place when given (momentum as nn.BatchNorm2d: unbiased running variance)
+ *   samble_edge_bn2_out_f32   BN2 statistics from samble_edge_mlp_fwd_f32's partials; ext / kext = the max (gamma2 >= 0)
+ *                             or min of conv2's output over a point's edges and the edge that attains it; out (B, 64, N)
+ *                             = LeakyReLU(BN2(ext)), channel-major
+ *   samble_edge_bwd_pre_f32   g (B, 64, N) -> sdv = sc2 g LeakyReLU'(v) rows for samble_edge_mlp_bwd_f32, whose `c0c1`
+ *                             argument is constants + 256 after this call; d gamma2, d beta2
+ *   samble_edge_du_rowsum_f32 dusum_i = sum_k du_ik
+ *   samble_edge_bwd_post_f32  from dusum, D_i = sum of du over the INCOMING edges of i and R_i = sum of a over them
+ *                             (samble_segment_sum_rows_f32 over samble_inverse_neighbors' lists; indeg = their counts):
+ *                             d gamma1, d beta1, the per-point gradients da, db and dW2 (64, 64) = the ordered sum of
+ *                             samble_edge_mlp_bwd_f32's per-wave partials */
+size_t samble_edge_glue_partials_bytes(void);
+size_t samble_edge_glue_constants_bytes(void);
+size_t samble_edge_glue_statistics_bytes(void);
+int samble_edge_bn1_f32(const float* a, const float* b, const int32_t* nn, int B, int N, int K, int C, const float* gamma1,
+                        const float* beta1, float eps, float* running_mean, float* running_var, float momentum, float* S,
+                        float* Q, float* ap, float* bp, float* constants, double* statistics, double* partials, void* stream);
+int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
+                            const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
+                            const float* beta2, float eps, float* running_mean, float* running_var, float momentum,
+                            float* constants, double* statistics, float* ext, uint8_t* kext, float* out, void* stream);
+int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2, float* constants,
+                            const double* statistics, float* sdv, float* dgamma2, float* dbeta2, double* partials,
+                            void* stream);
+int samble_edge_du_rowsum_f32(const float* du, int B, int N, int K, int C, float* dusum, void* stream);
+int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum, const float* D,
+                             const int32_t* indeg, int B, int N, int K, int C, float* constants, const double* statistics,
+                             const float* dw2_partials, int n_partials, float* da, float* db, float* dgamma1, float* dbeta1,
+                             float* dW2, double* partials, void* stream);
+
 /* ---- 1x1 convolutions over C = 128 input channels next to the neighbour / sampler kernels (csrc/linear.hip) --------
  * Replace, in the layers that sandwich the sampler:
  *   models/attention.py:187-192 (Neighbor2PointAttention / Point2PointAttention): ff = Conv1d(128 -> 512, bias=False),
  *       LeakyReLU(0.2), Conv1d(512 -> 128, bias=False) and its autograd;
  *   models/cls_model.py:136 (FeatureLearningBlock): conv_list[i](x).max(dim=-1)[0] -- Conv1d(128 -> 1024, bias=False)
  *       followed by the maximum over the points -- and its autograd.
+ *   models/embedding.py:20-28 (EdgeConv): conv1 over [x_i ; x_j - x_i] = two per-point projections of x (C = 3 / 64
+ *       input channels -> 64 + 64 outputs) and their autograd.
  * fp32 in, fp32 out; products on the bf16 matrix cores with each fp32 operand split into three bf16 planes (six partial
- * products, fp32 accumulation: fp32-equivalent, csrc/tri_dev.h).  Layouts: x and dx channel-major (B, 128, N) as the
- * modules hold them (x_bs = elements between clouds); the wide side point-major rows (B, N, O) (o_bs / o_rs = elements
+ * products, fp32 accumulation: fp32-equivalent, csrc/tri_dev.h).  Layouts: x and dx channel-major (B, C, N) as the
+ * modules hold them (x_bs = elements between clouds), 1 <= C <= 128 (the kernels contract over 128 channels: the missing
+ * ones are zeros, and so are W's columns C .. 127); the wide side point-major rows (B, N, O) (o_bs / o_rs = elements
  * between clouds / rows; rows 16-byte aligned); W (O, 128) row-major, O a multiple of 32, handed over as OPERAND IMAGES
  * of samble_linear_image_bytes(O) bytes each, written by samble_linear_weight_images_f32 (either pointer may be NULL):
  *   rm_image  contraction over the 128 channels   (samble_linear_fwd_tri_f32, samble_linear_amax_fwd_tri_f32)
@@ -502,7 +545,7 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
  *   samble_linear_amax_fwd_tri_f32  y[b][o] = max_n sum_c W[o][c] x[b][c][n], arg[b][o] = the first point that reaches
  *                                   it; the (B, O, N) tensor is never written
  *   samble_linear_dx_tri_f32        dx[b][c][n] = sum_o W[o][c] g[b][n][o]
- *   samble_linear_dw_tri_f32        dW[o][c] = sum_{b,n} g[b][n][o] x[b][c][n]; O a multiple of 256; per-workgroup
+ *   samble_linear_dw_tri_f32        dW[o][c] = sum_{b,n} g[b][n][o] x[b][c][n] as (O, 128); O a multiple of 128; per-workgroup
  *                                   partials in ws, summed in a fixed order (deterministic, no float atomics)
  *   samble_amax_bwd_f32             backward of samble_linear_amax_fwd_tri_f32 for upstream gy (B, O): the arg-max columns
  *                                   of dx (which must be ZERO on entry) and dW (O, 128); outputs grouped by point with a
@@ -523,7 +566,7 @@ int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const v
 size_t samble_linear_dw_workspace_bytes(int B, int N, int O);
 int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
                              int O, float* dW, void* ws, size_t ws_bytes, void* stream);
-size_t samble_amax_bwd_workspace_bytes(int B, int O);
+size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
 

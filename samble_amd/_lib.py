@@ -63,6 +63,21 @@ _SIGNATURES = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_size_t, c_uint, c_void_p]),
     "samble_select_chain_status_async": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "samble_edge_glue_partials_bytes": (c_size_t, []),
+    "samble_edge_glue_constants_bytes": (c_size_t, []),
+    "samble_edge_glue_statistics_bytes": (c_size_t, []),
+    "samble_edge_bn1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+                                    c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "samble_edge_bn2_out_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "samble_edge_bwd_pre_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_edge_du_rowsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_linear_image_bytes": (c_size_t, [c_int]),
     "samble_linear_weight_images_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -75,7 +90,7 @@ _SIGNATURES = {
     "samble_linear_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_dw_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
-    "samble_amax_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "samble_amax_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_amax_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_zscore_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -98,15 +98,29 @@ int samble_launch_select_chain(const void*, const int*, const float*, int, int, 
                                const float*, int, float*, float*, int, float, float, int, int, unsigned char*, int*, float*,
                                float*, int*, unsigned int, hipStream_t);
 size_t samble_chain_flag_offset(void);
+size_t samble_edge_glue_part_bytes(void);
+size_t samble_edge_glue_cst_bytes(void);
+size_t samble_edge_glue_st_bytes(void);
+int samble_launch_edge_pre(const float*, const float*, const int*, int, int, const float*, const float*, float, float*, float*,
+                           float, float*, float*, float*, float*, float*, double*, double*, hipStream_t);
+int samble_launch_edge_post(const float*, const float*, const unsigned char*, const unsigned char*, const double*, int, int, int,
+                            const float*, const float*, float, float*, float*, float, float*, double*, float*, unsigned char*,
+                            float*, hipStream_t);
+int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float*, float*, const double*, float*, float*, float*,
+                               double*, hipStream_t);
+int samble_launch_edge_du_rowsum(const float*, int, int, float*, hipStream_t);
+int samble_launch_edge_bwd_post(const float*, const float*, const float*, const float*, const float*, const float*, const int*,
+                                int, int, float*, const double*, const float*, int, float*, float*, float*, float*, float*,
+                                double*, hipStream_t);
 size_t samble_linear_image_bytes_impl(int O);
 int samble_launch_linear_images(const float*, int, void*, void*, hipStream_t);
-int samble_launch_linear_fwd(const float*, long, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
+int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
 size_t samble_linear_amax_ws_bytes(int, int, int);
 int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
-int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, float*, long, hipStream_t);
+int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, int, float*, long, hipStream_t);
 size_t samble_linear_dw_ws_bytes(int, int, int);
-int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, float*, void*, hipStream_t);
-size_t samble_amax_bwd_ws_bytes(int, int);
+int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, void*, hipStream_t);
+size_t samble_amax_bwd_ws_bytes(int, int, int);
 int samble_launch_amax_bwd(const float*, long, int, int, const int*, const float*, const float*, int, float*, long, float*,
                            void*, hipStream_t);
 }
@@ -849,6 +863,71 @@ SAMBLE_API int samble_select_chain_status_async(const void* ws, int B, int N, in
               "samble_select_chain_status_async");
 }
 
+/* ---- the closed forms around the fused EdgeConv's two MLP sweeps (csrc/edge_glue.hip) ------------------------------ */
+SAMBLE_API size_t samble_edge_glue_partials_bytes(void) { return samble_edge_glue_part_bytes(); }
+SAMBLE_API size_t samble_edge_glue_constants_bytes(void) { return samble_edge_glue_cst_bytes(); }
+SAMBLE_API size_t samble_edge_glue_statistics_bytes(void) { return samble_edge_glue_st_bytes(); }
+
+static int edge_shape_ok(int B, int N, int K, int C) { return B > 0 && N > 0 && K == 32 && C == 64; }
+
+SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, const int32_t* nn, int B, int N, int K, int C,
+                                   const float* gamma1, const float* beta1, float eps, float* running_mean,
+                                   float* running_var, float momentum, float* S, float* Q, float* ap, float* bp,
+                                   float* constants, double* statistics, double* partials, void* stream) {
+  if (!a || !b || !nn || !gamma1 || !beta1 || !S || !Q || !ap || !bp || !constants || !statistics || !partials)
+    return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: null pointer");
+  if (!edge_shape_ok(B, N, K, C)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: built for K = 32 neighbours, 64 channels");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: running statistics come as a pair");
+  return done(samble_launch_edge_pre(a, b, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum, S, Q, ap, bp,
+                                     constants, statistics, partials, (hipStream_t)stream),
+              "samble_edge_bn1_f32");
+}
+
+SAMBLE_API int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
+                                       const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
+                                       const float* beta2, float eps, float* running_mean, float* running_var,
+                                       float momentum, float* constants, double* statistics, float* ext, uint8_t* kext,
+                                       float* out, void* stream) {
+  if (!ymax || !ymin || !kmax || !kmin || !mlp_partials || !gamma2 || !beta2 || !constants || !statistics || !ext || !kext || !out)
+    return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: null pointer");
+  if (!edge_shape_ok(B, N, 32, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: built for 64 channels");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: running statistics come as a pair");
+  return done(samble_launch_edge_post(ymax, ymin, kmax, kmin, mlp_partials, n_partials, B, N, gamma2, beta2, eps, running_mean,
+                                      running_var, momentum, constants, statistics, ext, kext, out, (hipStream_t)stream),
+              "samble_edge_bn2_out_f32");
+}
+
+SAMBLE_API int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2,
+                                       float* constants, const double* statistics, float* sdv, float* dgamma2, float* dbeta2,
+                                       double* partials, void* stream) {
+  if (!g || !ext || !gamma2 || !constants || !statistics || !sdv || !dgamma2 || !dbeta2 || !partials)
+    return fail(SAMBLE_E_INVALID, "samble_edge_bwd_pre_f32: null pointer");
+  if (!edge_shape_ok(B, N, 32, C)) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_pre_f32: built for 64 channels");
+  return done(samble_launch_edge_bwd_pre(g, ext, B, N, gamma2, constants, statistics, sdv, dgamma2, dbeta2, partials,
+                                         (hipStream_t)stream),
+              "samble_edge_bwd_pre_f32");
+}
+
+SAMBLE_API int samble_edge_du_rowsum_f32(const float* du, int B, int N, int K, int C, float* dusum, void* stream) {
+  if (!du || !dusum) return fail(SAMBLE_E_INVALID, "samble_edge_du_rowsum_f32: null pointer");
+  if (!edge_shape_ok(B, N, K, C)) return fail(SAMBLE_E_INVALID, "samble_edge_du_rowsum_f32: built for K = 32 neighbours, 64 channels");
+  return done(samble_launch_edge_du_rowsum(du, B, N, dusum, (hipStream_t)stream), "samble_edge_du_rowsum_f32");
+}
+
+SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum,
+                                        const float* D, const int32_t* indeg, int B, int N, int K, int C, float* constants,
+                                        const double* statistics, const float* dw2_partials, int n_partials, float* da,
+                                        float* db, float* dgamma1, float* dbeta1, float* dW2, double* partials,
+                                        void* stream) {
+  if (!a || !b || !S || !R || !dusum || !D || !indeg || !constants || !statistics || !dw2_partials || !da || !db || !dgamma1 ||
+      !dbeta1 || !dW2 || !partials)
+    return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: null pointer");
+  if (!edge_shape_ok(B, N, K, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: built for K = 32 neighbours, 64 channels");
+  return done(samble_launch_edge_bwd_post(a, b, S, R, dusum, D, indeg, B, N, constants, statistics, dw2_partials, n_partials,
+                                          da, db, dgamma1, dbeta1, dW2, partials, (hipStream_t)stream),
+              "samble_edge_bwd_post_f32");
+}
+
 /* ---- 1x1 convolutions over 128 input channels (csrc/linear.hip) ------------------------------------------------- */
 static int lin_shape_ok(int B, int N, int O) { return B > 0 && N > 0 && O >= 32 && O <= 4096 && (O & 31) == 0; }
 
@@ -856,7 +935,7 @@ SAMBLE_API size_t samble_linear_image_bytes(int O) { return O > 0 ? samble_linea
 
 SAMBLE_API int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream) {
   if (!W || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: null pointer");
-  if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: C must be 128, O a multiple of 32");
+  if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: W must be (O, 128) (narrower layers: zero columns), O a multiple of 32");
   return done(samble_launch_linear_images(W, O, rm_image, tr_image, (hipStream_t)stream), "samble_linear_weight_images_f32");
 }
 
@@ -864,11 +943,11 @@ SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, in
                                          int epilogue, const float* ref, float* out, int64_t o_bs, int64_t o_rs,
                                          void* stream) {
   if (!x || !w_rm_image || !out) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: null pointer");
-  if (C != 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: C must be 128, O a multiple of 32");
+  if (C < 1 || C > 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: 1 <= C <= 128, O a multiple of 32");
   if (epilogue < SAMBLE_LIN_PLAIN || epilogue > SAMBLE_LIN_LEAKY_MASK || (epilogue == SAMBLE_LIN_LEAKY_MASK && !ref))
     return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: unknown epilogue, or the mask epilogue without ref");
   if ((o_rs & 3) || (o_bs & 3) || o_rs < O) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: output strides must be multiples of 4");
-  return done(samble_launch_linear_fwd(x, x_bs, B, N, w_rm_image, O, epilogue, ref, out, o_bs, o_rs, (hipStream_t)stream),
+  return done(samble_launch_linear_fwd(x, x_bs, B, C, N, w_rm_image, O, epilogue, ref, out, o_bs, o_rs, (hipStream_t)stream),
               "samble_linear_fwd_tri_f32");
 }
 
@@ -888,9 +967,9 @@ SAMBLE_API int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int 
 SAMBLE_API int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const void* w_tr_image, int O, int B, int C,
                                         int N, float* dx, int64_t dx_bs, void* stream) {
   if (!g || !w_tr_image || !dx) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: null pointer");
-  if (C != 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: C must be 128, O a multiple of 32");
+  if (C < 1 || C > 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: 1 <= C <= 128, O a multiple of 32");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: g rows must be 16-byte aligned");
-  return done(samble_launch_linear_dx(g, g_bs, g_rs, w_tr_image, O, B, N, dx, dx_bs, (hipStream_t)stream), "samble_linear_dx_tri_f32");
+  return done(samble_launch_linear_dx(g, g_bs, g_rs, w_tr_image, O, B, C, N, dx, dx_bs, (hipStream_t)stream), "samble_linear_dx_tri_f32");
 }
 
 SAMBLE_API size_t samble_linear_dw_workspace_bytes(int B, int N, int O) {
@@ -900,14 +979,16 @@ SAMBLE_API size_t samble_linear_dw_workspace_bytes(int B, int N, int O) {
 SAMBLE_API int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
                                         int N, int O, float* dW, void* ws, size_t ws_bytes, void* stream) {
   if (!g || !x || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: null pointer");
-  if (C != 128 || !lin_shape_ok(B, N, O) || (O & 255))
-    return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: C must be 128, O a multiple of 256");
+  if (C < 1 || C > 128 || !lin_shape_ok(B, N, O) || (O & 127))
+    return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: 1 <= C <= 128, O a multiple of 128");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: g rows must be 16-byte aligned");
   if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_tri_f32: workspace too small");
-  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, N, O, dW, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dW, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
 }
 
-SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int O) { return (B > 0 && O > 0) ? samble_amax_bwd_ws_bytes(B, O) : 0; }
+SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int N, int O) {
+  return (B > 0 && N > 0 && O > 0) ? samble_amax_bwd_ws_bytes(B, N, O) : 0;
+}
 
 SAMBLE_API int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy,
                                    const float* W, int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws,
@@ -915,8 +996,8 @@ SAMBLE_API int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, i
   if (!x || !arg || !gy || !W || !dx_zeroed || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: null pointer");
   if (C != 128 || B <= 0 || N <= 0 || O <= 0 || (O & 3) || N > 32767 || O > 8192)
     return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: C must be 128, N <= 32767, O <= 8192 and a multiple of 4");
-  if (((size_t)N + 1 + 3 * (size_t)O) * 4 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: N + 3 O too large for LDS");
-  if (ws_bytes < samble_amax_bwd_ws_bytes(B, O)) return fail(SAMBLE_E_WORKSPACE, "samble_amax_bwd_f32: workspace too small");
+  if (((size_t)N + 4 + (size_t)O) * 4 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: N + O too large for LDS");
+  if (ws_bytes < samble_amax_bwd_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_amax_bwd_f32: workspace too small");
   return done(samble_launch_amax_bwd(x, x_bs, B, N, arg, gy, W, O, dx_zeroed, dx_bs, dW, ws, (hipStream_t)stream),
               "samble_amax_bwd_f32");
 }

@@ -1,0 +1,436 @@
+// Everything of the fused EdgeConv (csrc/edgeconv.hip, reference models/embedding.py:7-39) that is not its two MLP
+// sweeps: the closed forms of the two BatchNorms (batch statistics over the B N K edges from per-point sums, their
+// backward corrections), the activation, and the per-point gradients -- as a handful of HIP kernels over (points, 64)
+// rows instead of ~250 torch launches per layer and step (profiles/r04a: 5 of the block's 14.8 ms were this glue and the
+// host-bound gaps between its tiny kernels).
+//
+// Per-channel sums over all points are formed in DOUBLE, deterministically: every workgroup owns a contiguous run of
+// points and writes one partial row per statistic, a one-workgroup kernel adds the partials in index order and derives
+// the constants the next sweep needs (no host round trip, no atomics).
+//
+// Notation (embedding.py of this package): a_i, b_i the two per-point projections of conv1; an edge (i, k) with
+// j = nn[i][k] has u = a_i + b_j; S_i = sum_k b_j, Q_i = sum_k b_j^2; BN1: z = gamma1 (u - mu1) / sig1 + beta1;
+// conv2 output y; BN2: v = gamma2 (ext - mu2) / sig2 + beta2 on the per-point extremum ext of y (max or min by the
+// sign of gamma2: LeakyReLU o BN2 is monotone), out = LeakyReLU(v).
+#include "samble_dev.h"
+
+namespace samble {
+
+constexpr int kGC = 64;    // channels
+constexpr int kGK = 32;    // neighbours per point
+constexpr int kGParts = 1024;
+
+// layout of the per-layer constants block `cst` (floats) and statistics block `st` (doubles)
+enum { kCstSc1 = 0, kCstSh1 = 64, kCstSc2 = 128, kCstSh2 = 192, kCstC0 = 256, kCstC1 = 320, kCstM1p = 384, kCstM2p = 448,
+       kCstWords = 512 };
+enum { kStMu1 = 0, kStSig1 = 64, kStMu2 = 128, kStSig2 = 192, kStWords = 256 };
+
+// per-workgroup partial of NS statistics: thread (rl = tid >> 5, c2 = tid & 31) holds channels 2 c2, 2 c2 + 1
+template <int NS>
+__device__ __forceinline__ void chan_partial_store(const double (&acc)[NS][2], double* __restrict__ part) {
+  __shared__ double red[8][NS][kGC];
+  const int rl = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    red[rl][s][2 * c2] = acc[s][0];
+    red[rl][s][2 * c2 + 1] = acc[s][1];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NS * kGC; e += 256) {
+    const int s = e / kGC, c = e % kGC;
+    double v = red[0][s][c];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v += red[r][s][c];
+    part[((long)blockIdx.x * NS + s) * kGC + c] = v;
+  }
+}
+
+// sums of the workgroup partials of two statistics for channel c = tid & 63, by a 1024-thread workgroup: 16 groups take
+// the partials p = g, g + 16, ... (loads in flight eight deep), the 16 group sums are added in index order.  Valid in
+// the threads tid < 64 (the callers' channel threads); fixed order: deterministic.
+__device__ __forceinline__ void chan_totals2(const double* __restrict__ part, int nparts, double& t0, double& t1) {
+  __shared__ double red[16][2][kGC];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  double v0 = 0.0, v1 = 0.0;
+#pragma unroll 8
+  for (int p = g; p < nparts; p += 16) {
+    v0 += part[((long)p * 2 + 0) * kGC + c];
+    v1 += part[((long)p * 2 + 1) * kGC + c];
+  }
+  red[g][0][c] = v0;
+  red[g][1][c] = v1;
+  __syncthreads();
+  t0 = red[0][0][c];
+  t1 = red[0][1][c];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    t0 += red[k][0][c];
+    t1 += red[k][1][c];
+  }
+}
+
+// ---- forward 1: S, Q of every point (edge_gather_sums) and the BN1 edge sums  sum u = K a + S,  sum u^2 = K a^2 + 2 a S + Q
+__global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+                                                              const int* __restrict__ nn, int N, long npoints,
+                                                              float* __restrict__ S, float* __restrict__ Q,
+                                                              double* __restrict__ part) {
+  const int hw = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  const long per = (npoints + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(p0 + per, npoints);
+  for (long p = p0 + hw; p < p1; p += 8) {
+    const long cloud = p / N;
+    const int* ni = nn + p * kGK;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < kGK; ++k) {
+      const int j = ni[k];
+      const float2 v = *reinterpret_cast<const float2*>(bp + (cloud * N + j) * kGC + 2 * c2);
+      s0 += v.x;
+      s1 += v.y;
+      q0 = fmaf(v.x, v.x, q0);
+      q1 = fmaf(v.y, v.y, q1);
+    }
+    *reinterpret_cast<float2*>(S + p * kGC + 2 * c2) = make_float2(s0, s1);
+    *reinterpret_cast<float2*>(Q + p * kGC + 2 * c2) = make_float2(q0, q1);
+    const float2 av = *reinterpret_cast<const float2*>(a + p * kGC + 2 * c2);
+    const double a0 = av.x, a1 = av.y;
+    acc[0][0] += kGK * a0 + (double)s0;
+    acc[0][1] += kGK * a1 + (double)s1;
+    acc[1][0] += kGK * a0 * a0 + 2.0 * a0 * (double)s0 + (double)q0;
+    acc[1][1] += kGK * a1 * a1 + 2.0 * a1 * (double)s1 + (double)q1;
+  }
+  chan_partial_store<2>(acc, part);
+}
+
+// running statistics of nn.BatchNorm2d in training mode (biased batch variance -> unbiased running variance)
+__device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int c, double mu, double var, double E,
+                                                  float momentum) {
+  if (!rmean) return;
+  rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+  rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * (var * E / (E - 1.0)));
+}
+
+// ---- forward 2: BN1 constants from the partials: mu1, sig1; sc1 = gamma1 / sig1, sh1 = beta1 - mu1 sc1
+__global__ __launch_bounds__(1024) void edge_bn1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float* __restrict__ cst, double* __restrict__ st,
+                                                               float* rmean, float* rvar, float momentum) {
+  const int c = threadIdx.x;
+  double t0, t1;
+  chan_totals2(part, nparts, t0, t1);
+  if (c >= kGC) return;
+  const double mu = t0 / E;
+  double var = t1 / E - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  const double sig = sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] / sig;
+  st[kStMu1 + c] = mu;
+  st[kStSig1 + c] = sig;
+  cst[kCstSc1 + c] = (float)sc;
+  cst[kCstSh1 + c] = (float)((double)beta[c] - mu * sc);
+  bn_running_update(rmean, rvar, c, mu, var, E, momentum);
+}
+
+// ---- forward 2b: the BN1-folded projections the MLP sweeps read: a' = a sc1 + sh1, b' = b sc1 (two roundings each,
+// like the elementwise expressions they replace)
+__global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+                                                        const float* __restrict__ cst, long n4, float* __restrict__ ap,
+                                                        float* __restrict__ bpo) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of a row (16 per row)
+  if (e >= n4) return;
+  const int c = 4 * (int)(e & 15);
+  const f32x4 av = reinterpret_cast<const f32x4*>(a)[e], bv = reinterpret_cast<const f32x4*>(bp)[e];
+  f32x4 oa, ob;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    oa[u] = __fadd_rn(__fmul_rn(av[u], cst[kCstSc1 + c + u]), cst[kCstSh1 + c + u]);
+    ob[u] = __fmul_rn(bv[u], cst[kCstSc1 + c + u]);
+  }
+  reinterpret_cast<f32x4*>(ap)[e] = oa;
+  reinterpret_cast<f32x4*>(bpo)[e] = ob;
+}
+
+// ---- forward 3: BN2 constants from edge_mlp_fwd's per-wave sums of y and y^2: mu2, sig2; sc2 = gamma2 / sig2, sh2 = beta2 - mu2 sc2
+__global__ __launch_bounds__(1024) void edge_bn2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float* __restrict__ cst, double* __restrict__ st,
+                                                               float* rmean, float* rvar, float momentum) {
+  const int c = threadIdx.x;
+  double t0, t1;
+  chan_totals2(part, nparts, t0, t1);
+  if (c >= kGC) return;
+  const double mu = t0 / E;
+  double var = t1 / E - mu * mu;
+  var = var < 0.0 ? 0.0 : var;
+  const double sig = sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] / sig;
+  st[kStMu2 + c] = mu;
+  st[kStSig2 + c] = sig;
+  cst[kCstSc2 + c] = (float)sc;
+  cst[kCstSh2 + c] = (float)((double)beta[c] - mu * sc);
+  bn_running_update(rmean, rvar, c, mu, var, E, momentum);
+}
+
+// ---- forward 4: ext = the extremum the sign of gamma2 selects, its edge, out = LeakyReLU(sc2 ext + sh2) written
+// CHANNEL-MAJOR (B, 64, N) through a 64 x 64 LDS tile (the layers downstream hold features that way)
+__global__ __launch_bounds__(256) void edge_out_kernel(const float* __restrict__ ymax, const float* __restrict__ ymin,
+                                                       const unsigned char* __restrict__ kmax,
+                                                       const unsigned char* __restrict__ kmin,
+                                                       const float* __restrict__ gamma2, const float* __restrict__ cst, int N,
+                                                       float* __restrict__ ext, unsigned char* __restrict__ kext,
+                                                       float* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y, n0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63, n = n0 + r;
+    float v = 0.f;
+    if (n < N) {
+      const long at = ((long)b * N + n) * kGC + c;
+      const bool up = gamma2[c] >= 0.f;
+      const float x = up ? ymax[at] : ymin[at];
+      ext[at] = x;
+      kext[at] = up ? kmax[at] : kmin[at];
+      v = fmaf(x, cst[kCstSc2 + c], cst[kCstSh2 + c]);
+      v = fmaxf(v, 0.2f * v);
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int c = e >> 6, r = e & 63, n = n0 + r;
+    if (n < N) out[((long)b * kGC + c) * N + n] = tile[r][c];
+  }
+}
+
+// ---- backward 1: g (B, 64, N) channel-major -> dv = g LeakyReLU'(v); sc2 dv as (points, 64) rows, the sums of dv and dv yhat
+__global__ __launch_bounds__(256) void edge_bwd_pre_kernel(const float* __restrict__ g, const float* __restrict__ ext,
+                                                           const float* __restrict__ cst, const double* __restrict__ st,
+                                                           int N, int tiles_per_cloud, int ntiles, float* __restrict__ dv,
+                                                           double* __restrict__ part) {
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x, rl = tid >> 5, c2 = tid & 31;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  const double mu0 = st[kStMu2 + 2 * c2], mu1 = st[kStMu2 + 2 * c2 + 1];
+  const double is0 = 1.0 / st[kStSig2 + 2 * c2], is1 = 1.0 / st[kStSig2 + 2 * c2 + 1];
+  const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = min(t0 + per, ntiles);
+  for (int t = t0; t < t1; ++t) {
+    const int b = t / tiles_per_cloud, n0 = (t % tiles_per_cloud) * 64;
+    __syncthreads();
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int c = e >> 6, r = e & 63, n = n0 + r;
+      tile[r][c] = n < N ? g[((long)b * kGC + c) * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = rl; r < 64; r += 8) {
+      const int n = n0 + r;
+      if (n >= N) break;
+      const long at = ((long)b * N + n) * kGC + 2 * c2;
+      const float2 x = *reinterpret_cast<const float2*>(ext + at);
+      const float v0 = fmaf(x.x, cst[kCstSc2 + 2 * c2], cst[kCstSh2 + 2 * c2]);
+      const float v1 = fmaf(x.y, cst[kCstSc2 + 2 * c2 + 1], cst[kCstSh2 + 2 * c2 + 1]);
+      const float d0 = tile[r][2 * c2] * (v0 > 0.f ? 1.f : 0.2f), d1 = tile[r][2 * c2 + 1] * (v1 > 0.f ? 1.f : 0.2f);
+      // what the MLP sweep consumes is sc2 dv (the gradient that arrives at the extremal edge, BN2's scale applied)
+      *reinterpret_cast<float2*>(dv + at) = make_float2(d0 * cst[kCstSc2 + 2 * c2], d1 * cst[kCstSc2 + 2 * c2 + 1]);
+      acc[0][0] += (double)d0;
+      acc[0][1] += (double)d1;
+      acc[1][0] += (double)d0 * (((double)x.x - mu0) * is0);
+      acc[1][1] += (double)d1 * (((double)x.y - mu1) * is1);
+    }
+  }
+  chan_partial_store<2>(acc, part);
+}
+
+// ---- backward 2: BN2's dense correction dy += c0 + c1 y per edge (c1 = -sc2 m2 / sig2, c0 = -sc2 m1 - c1 mu2 with
+// m1 = mean dv, m2 = mean dv yhat over the EDGES), d gamma2 = sum dv yhat, d beta2 = sum dv
+__global__ __launch_bounds__(1024) void edge_bwd2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+                                                                const float* __restrict__ gamma, float* __restrict__ cst,
+                                                                const double* __restrict__ st, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  double sdv, sdvy;
+  chan_totals2(part, nparts, sdv, sdvy);
+  if (c >= kGC) return;
+  const double m1 = sdv / E, m2 = sdvy / E;
+  const double sig = st[kStSig2 + c], mu = st[kStMu2 + c], sc = (double)gamma[c] / sig;
+  const double c1 = -sc * m2 / sig;
+  cst[kCstC1 + c] = (float)c1;
+  cst[kCstC0 + c] = (float)(-sc * m1 - c1 * mu);
+  dgamma[c] = (float)sdvy;
+  dbeta[c] = (float)sdv;
+}
+
+// ---- backward 3: sums over the points of du_i (= sum_k du_ik) and of a_i du_i + b_i D_i (D_i = sum over the incoming
+// edges of du): the edge sums of du and du u that BN1's backward needs
+__global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+                                                             const float* __restrict__ dusum, const float* __restrict__ D,
+                                                             long npoints, double* __restrict__ part) {
+  const int rl = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+  double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  const long per = (npoints + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(p0 + per, npoints);
+  for (long p = p0 + rl; p < p1; p += 8) {
+    const long at = p * kGC + 2 * c2;
+    const float2 av = *reinterpret_cast<const float2*>(a + at), bv = *reinterpret_cast<const float2*>(bp + at);
+    const float2 uv = *reinterpret_cast<const float2*>(dusum + at), dvv = *reinterpret_cast<const float2*>(D + at);
+    acc[0][0] += (double)uv.x;
+    acc[0][1] += (double)uv.y;
+    acc[1][0] += (double)av.x * (double)uv.x + (double)bv.x * (double)dvv.x;
+    acc[1][1] += (double)av.y * (double)uv.y + (double)bv.y * (double)dvv.y;
+  }
+  chan_partial_store<2>(acc, part);
+}
+
+// ---- backward 4: m1' = mean du, m2' = mean du zhat over the edges; d gamma1 = sum du zhat, d beta1 = sum du
+__global__ __launch_bounds__(1024) void edge_bwd1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+                                                                float* __restrict__ cst, const double* __restrict__ st,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  double sdu, raw;
+  chan_totals2(part, nparts, sdu, raw);
+  if (c >= kGC) return;
+  const double sduz = (raw - st[kStMu1 + c] * sdu) / st[kStSig1 + c];
+  cst[kCstM1p + c] = (float)(sdu / E);
+  cst[kCstM2p + c] = (float)(sduz / E);
+  dgamma[c] = (float)sduz;
+  dbeta[c] = (float)sdu;
+}
+
+// ---- backward 5: the per-point gradients of the two projections
+//   da = sc1 (du_i - K m1' - m2' Zs),  Zs = (K a + S - K mu1) / sig1       (the K outgoing edges of point i)
+//   db = sc1 (D_i - deg m1' - m2' Zr), Zr = (R + deg (b - mu1)) / sig1     (its deg incoming edges; R = sum of their a)
+__global__ __launch_bounds__(256) void edge_bwd_final_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+                                                             const float* __restrict__ S, const float* __restrict__ R,
+                                                             const float* __restrict__ dusum, const float* __restrict__ D,
+                                                             const int* __restrict__ indeg, const float* __restrict__ cst,
+                                                             const double* __restrict__ st, long npoints,
+                                                             float* __restrict__ da, float* __restrict__ db) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;  // one float2 of a row
+  if (e >= npoints * 32) return;
+  const long p = e >> 5;
+  const int c = 2 * (int)(e & 31);
+  const long at = p * kGC + c;
+  const float deg = (float)indeg[p];
+  const float2 av = *reinterpret_cast<const float2*>(a + at), bv = *reinterpret_cast<const float2*>(bp + at);
+  const float2 sv = *reinterpret_cast<const float2*>(S + at), rv = *reinterpret_cast<const float2*>(R + at);
+  const float2 uv = *reinterpret_cast<const float2*>(dusum + at), dvv = *reinterpret_cast<const float2*>(D + at);
+  float oa[2], ob[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float mu = (float)st[kStMu1 + c + u], sig = (float)st[kStSig1 + c + u];
+    const float sc = cst[kCstSc1 + c + u], m1 = cst[kCstM1p + c + u], m2 = cst[kCstM2p + c + u];
+    const float aa = u ? av.y : av.x, bb = u ? bv.y : bv.x, ss = u ? sv.y : sv.x, rr = u ? rv.y : rv.x;
+    const float du = u ? uv.y : uv.x, dd = u ? dvv.y : dvv.x;
+    const float zs = (kGK * aa + ss - kGK * mu) / sig;
+    const float zr = (rr + deg * (bb - mu)) / sig;
+    oa[u] = sc * (du - kGK * m1 - m2 * zs);
+    ob[u] = sc * (dd - deg * m1 - m2 * zr);
+  }
+  *reinterpret_cast<float2*>(da + at) = make_float2(oa[0], oa[1]);
+  *reinterpret_cast<float2*>(db + at) = make_float2(ob[0], ob[1]);
+}
+
+// dusum[p][c] = sum_k du[p][k][c]   (one wave per point: lanes = channels, 32 rows of 256 B)
+__global__ __launch_bounds__(256) void edge_du_rowsum_kernel(const float* __restrict__ du, long npoints,
+                                                             float* __restrict__ dusum) {
+  const int lane = threadIdx.x & 63;
+  for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npoints; p += (long)gridDim.x * 4) {
+    const float* base = du + p * kGK * kGC + lane;
+    float v[kGK];
+#pragma unroll
+    for (int k = 0; k < kGK; ++k) v[k] = base[k * kGC];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kGK; ++k) s += v[k];
+    dusum[p * kGC + lane] = s;
+  }
+}
+
+// out[e] = sum over the nparts blocks (each n floats) in ascending order: 64 x 64 dW2 from the per-wave partials
+__global__ __launch_bounds__(256) void edge_sum_parts_kernel(const float* __restrict__ part, int nparts, int n,
+                                                             float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s = 0.f;
+  if (e < n)
+    for (int p = g; p < nparts; p += 8) s += part[(long)p * n + e];
+  red[g][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (g == 0 && e < n) {
+    float t = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    out[e] = t;
+  }
+}
+
+}  // namespace samble
+
+using namespace samble;
+
+extern "C" size_t samble_edge_glue_part_bytes(void) { return (size_t)kGParts * 2 * kGC * sizeof(double); }
+extern "C" size_t samble_edge_glue_cst_bytes(void) { return (size_t)kCstWords * sizeof(float); }
+extern "C" size_t samble_edge_glue_st_bytes(void) { return (size_t)kStWords * sizeof(double); }
+
+// forward, before the MLP sweep: S, Q, BN1 constants (cst: sc1, sh1; st: mu1, sig1), running statistics (optional)
+extern "C" int samble_launch_edge_pre(const float* a, const float* b, const int* nn, int B, int N, const float* gamma1,
+                                      const float* beta1, float eps, float* rmean, float* rvar, float momentum, float* S,
+                                      float* Q, float* ap, float* bp, float* cst, double* st, double* part, hipStream_t s) {
+  const long np = (long)B * N;
+  Timed timed(kT_edge_sums, s);
+  hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, nn, N, np, S, Q, part);
+  hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
+                     cst, st, rmean, rvar, momentum);
+  hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, cst, np * 16, ap, bp);
+  return (int)hipGetLastError();
+}
+
+// forward, after the MLP sweep (its per-wave sums in `mlp_part`, nwaves of them): BN2 constants, the selected extremum and
+// its edge, the activated output channel-major
+extern "C" int samble_launch_edge_post(const float* ymax, const float* ymin, const unsigned char* kmax,
+                                       const unsigned char* kmin, const double* mlp_part, int nwaves, int B, int N,
+                                       const float* gamma2, const float* beta2, float eps, float* rmean, float* rvar,
+                                       float momentum, float* cst, double* st, float* ext, unsigned char* kext, float* out,
+                                       hipStream_t s) {
+  const long np = (long)B * N;
+  hipLaunchKernelGGL(edge_bn2_finalize_kernel, dim3(1), dim3(1024), 0, s, mlp_part, nwaves, (double)np * kGK, gamma2, beta2,
+                     eps, cst, st, rmean, rvar, momentum);
+  hipLaunchKernelGGL(edge_out_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, ymax, ymin, kmax, kmin, gamma2, cst, N, ext,
+                     kext, out);
+  return (int)hipGetLastError();
+}
+
+// backward, before the MLP sweep: dv rows, c0 / c1 of BN2's dense correction, d gamma2, d beta2
+extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int B, int N, const float* gamma2, float* cst,
+                                          const double* st, float* dv, float* dgamma2, float* dbeta2, double* part,
+                                          hipStream_t s) {
+  const long np = (long)B * N;
+  const int tpc = (N + 63) / 64, ntiles = tpc * B;
+  const int grid = ntiles < kGParts ? ntiles : kGParts;
+  hipLaunchKernelGGL(edge_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, g, ext, cst, st, N, tpc, ntiles, dv, part);
+  hipLaunchKernelGGL(edge_bwd2_finalize_kernel, dim3(1), dim3(1024), 0, s, part, grid, (double)np * kGK, gamma2, cst, st,
+                     dgamma2, dbeta2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_edge_du_rowsum(const float* du, int B, int N, float* dusum, hipStream_t s) {
+  hipLaunchKernelGGL(edge_du_rowsum_kernel, dim3(2048), dim3(256), 0, s, du, (long)B * N, dusum);
+  return (int)hipGetLastError();
+}
+
+// backward, after the MLP sweep and the reverse-neighbour sums D (of du) and R (of a): d gamma1, d beta1, da, db; dW2
+extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, const float* S, const float* R,
+                                           const float* dusum, const float* D, const int* indeg, int B, int N, float* cst,
+                                           const double* st, const float* dw2part, int nwaves, float* da, float* db,
+                                           float* dgamma1, float* dbeta1, float* dW2, double* part, hipStream_t s) {
+  const long np = (long)B * N;
+  hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, dusum, D, np, part);
+  hipLaunchKernelGGL(edge_bwd1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, cst, st, dgamma1,
+                     dbeta1);
+  hipLaunchKernelGGL(edge_bwd_final_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, a, b, S, R, dusum, D,
+                     indeg, cst, st, np, da, db);
+  hipLaunchKernelGGL(edge_sum_parts_kernel, dim3(kGC * kGC / 32), dim3(256), 0, s, dw2part, nwaves, kGC * kGC, dW2);
+  return (int)hipGetLastError();
+}

@@ -50,7 +50,7 @@ __device__ __forceinline__ float half_wave_max(float x) {
 //      kLinAmax:  no out: per 32-point tile the maximum of every output row over the tile's points and the first point
 //                 that reaches it -> pmax / parg [(b, tile, o)]
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int N,
+__global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int Cin, int N,
                                                              const char* __restrict__ Wimg, int otiles, int O,
                                                              float* __restrict__ out, long o_bs, long o_rs,
                                                              const float* __restrict__ ref, float* __restrict__ pmax,
@@ -76,7 +76,10 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
   for (int ks = 0; ks < 8; ++ks) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = x[(long)b * x_bs + (long)(16 * ks + 8 * h + e) * N + n];
+    for (int e = 0; e < 8; ++e) {
+      const int c = 16 * ks + 8 * h + e;   // (channels Cin .. 127 do not exist: zeros, as in W's image)
+      v[e] = c < Cin ? x[(long)b * x_bs + (long)c * N + n] : 0.f;
+    }
     const Tri t3 = tri_split8(v);
     xq[3 * ks] = t3.h;
     xq[3 * ks + 1] = t3.m;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void lin_amax_reduce_kernel(const float* __res
 
 // dx[c][n] = sum_o W[o][c] g[n][o] (proj_dx_tri_kernel with a run-time tile count)
 __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
-                                                            const char* __restrict__ Wtr, int otiles, int N,
+                                                            const char* __restrict__ Wtr, int otiles, int Cin, int N,
                                                             float* __restrict__ dx, long dx_bs) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
@@ -268,42 +271,52 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
   float* ob = dx + (long)b * dx_bs + n;  // rows past N-1 hold point N-1's column again: same values, same address
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
+    if (32 * ct >= Cin) break;   // (uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ob[(long)(32 * ct + crow(r, h)) * N] = acc[ct][r];
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * ct + crow(r, h);
+      if (c < Cin) ob[(long)c * N] = acc[ct][r];
+    }
   }
 }
 
-// dW partials: workgroup = (512-point chunk, cloud, block of 256 outputs); wave w owns output rows 64 (w >> 1) .. +63 of
-// the block and channels 64 (w & 1) .. +63: four accumulator tiles.  Both operands are transposed through LDS (the
+// dW partials: workgroup = (512-point chunk, cloud, block of 128 OT outputs); wave w owns output rows 32 OT (w >> 1) .. of
+// the block and channels 64 (w & 1) .. +63: 2 OT accumulator tiles.  Both operands are transposed through LDS (the
 // contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
-constexpr int kLdwPts = 512, kLdwOB = 256;
-constexpr int kLdwGS = kLdwOB + 4, kLdwXS = 33;  // row strides: g tile rows 16-byte aligned, column reads conflict-free
-constexpr int kLdwBuf = kTile * kLdwGS + 128 * kLdwXS;
-constexpr int kLdwLds = 2 * kLdwBuf * 4;
+// OT = output tiles per wave: 2 (blocks of 256 outputs) or 1 (blocks of 128: narrow layers)
+constexpr int kLdwPts = 512, kLdwXS = 33;
+template <int OT>
+struct Ldw {
+  static constexpr int kOB = 128 * OT;
+  static constexpr int kGS = kOB + 4;  // row stride: g tile rows 16-byte aligned, column reads conflict-free
+  static constexpr int kBuf = kTile * kGS + 128 * kLdwXS;
+  static constexpr int kLds = 2 * kBuf * 4;
+};
 
+template <int OT>
 __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
-                                                            const float* __restrict__ x, long x_bs, int N, int O,
+                                                            const float* __restrict__ x, long x_bs, int Cin, int N, int O,
                                                             float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   float* smem = reinterpret_cast<float*>(smem_c);
-  constexpr int GS = kLdwGS, XS = kLdwXS, BUF = kLdwBuf;
+  constexpr int GS = Ldw<OT>::kGS, XS = kLdwXS, BUF = Ldw<OT>::kBuf, kLdwOB = Ldw<OT>::kOB;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const int og = wave >> 1, ch = wave & 1;
   const int b = blockIdx.y, o0 = blockIdx.z * kLdwOB;
   const int n0 = blockIdx.x * kLdwPts;
-  f32x16 acc[2][2];
+  f32x16 acc[OT][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < OT; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = zero16();
-  f32x4 gst[4];  // 32 rows x 64 float4 = 2048 float4 / 512 threads
+  f32x4 gst[2 * OT];  // 32 rows x (32 OT) float4 / 512 threads
   float xst[8];  // 128 channels x 32 points = 4096 floats / 512 threads
   auto issue = [&](int nn0) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2 * OT; ++it) {
       const int e = tid + 512 * it;
-      const int r = e >> 6, c4 = (e & 63) * 4;
+      const int r = e / (32 * OT), c4 = (e % (32 * OT)) * 4;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       gst[it] = (nn0 + r < N) ? *reinterpret_cast<const f32x4*>(g + (long)b * g_bs + (long)(nn0 + r) * g_rs + o0 + c4) : z4;
     }
@@ -311,14 +324,14 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
     for (int it = 0; it < 8; ++it) {
       const int e = tid + 512 * it;
       const int c = e >> 5, pnt = e & 31;
-      xst[it] = (nn0 + pnt < N) ? x[(long)b * x_bs + (long)c * N + nn0 + pnt] : 0.f;
+      xst[it] = (nn0 + pnt < N && c < Cin) ? x[(long)b * x_bs + (long)c * N + nn0 + pnt] : 0.f;
     }
   };
   auto commit = [&](float* buf) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2 * OT; ++it) {
       const int e = tid + 512 * it;
-      const int r = e >> 6, c4 = (e & 63) * 4;
+      const int r = e / (32 * OT), c4 = (e % (32 * OT)) * 4;
       *reinterpret_cast<f32x4*>(buf + r * GS + c4) = gst[it];
     }
 #pragma unroll
@@ -348,10 +361,10 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
         bq[ct] = tri_split8(v);
       }
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) {
+      for (int ot = 0; ot < OT; ++ot) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * ks + 8 * h + e) * GS + 64 * og + 32 * ot + lo];
+        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * ks + 8 * h + e) * GS + 32 * OT * og + 32 * ot + lo];
         const Tri a = tri_split8(v);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[ot][ct] = mfma_tri(a, bq[ct], acc[ot][ct]);
@@ -362,10 +375,10 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
   }
   float* outp = part + ((long)b * gridDim.x + blockIdx.x) * O * 128;
 #pragma unroll
-  for (int ot = 0; ot < 2; ++ot)
+  for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int o = o0 + 64 * og + 32 * ot + crow(r, h);
+      const int o = o0 + 32 * OT * og + 32 * ot + crow(r, h);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) outp[(long)o * 128 + 64 * ch + 32 * ct + lo] = acc[ot][ct][r];
     }
@@ -408,31 +421,31 @@ __global__ __launch_bounds__(256) void lin_sum_parts_kernel(const float* __restr
 // (cloud, output) carries gradient --
 //   dx[b][:, n] = sum over the outputs o with arg[b][o] = n of gy[b][o] W[o][:]     (every other column: 0)
 //   dW[o][:]    = sum over the clouds b of gy[b][o] x[b][:, arg[b][o]]
-// One workgroup per cloud: the O outputs are grouped by their arg-max point with a counting sort in LDS (order inside a
-// group: ascending output), a wave per group sums its W rows in that order (deterministic) and writes the point's 128
-// gradient values; the per-cloud dW rows go to dwp[b][o][:] and are summed over the clouds by lin_sum_parts.
+// amax_sort: one workgroup per cloud groups the O outputs by their arg-max point (counting sort in LDS; order inside a
+// group: ascending output); amax_dx: a wave per group sums its W rows in that order and writes the point's 128 gradient
+// values; amax_dw: a wave per output sums the clouds' arg-max columns in ascending cloud order.  No atomics: run-to-run
+// identical.
 // (Exact ties of the maximum go to the lowest point index; torch.amax's backward splits them evenly.)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void amax_bwd_kernel(const float* __restrict__ x, long x_bs, int N,
-                                                        const int* __restrict__ arg, const float* __restrict__ gy,
-                                                        const float* __restrict__ W, int O, float* __restrict__ dx,
-                                                        long dx_bs, float* __restrict__ dwp) {
+// workspace of the backward, per cloud: [start offsets of the points' groups: N + 1][outputs grouped by point: O]
+// [distinct points, ascending: O][number of groups: 1] (ints)
+__global__ __launch_bounds__(1024) void amax_sort_kernel(int N, const int* __restrict__ arg, int O, int* __restrict__ wsi) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   int* cnt = reinterpret_cast<int*>(smem_c);        // N + 1 words: points' group sizes, then their start offsets
-  int* ord = cnt + N + 1;                           // O words: outputs grouped by point
-  int* pts = ord + O;                               // O words: the distinct points in ascending order
-  int* abl = pts + O;                               // O words: this cloud's arg-max points
+  int* abl = cnt + ((N + 4) & ~3);                  // O words (16-byte aligned): this cloud's arg-max points
   __shared__ int wtot[16];
-  __shared__ int ngroups_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int* ab = arg + (long)b * O;
+  int* start_g = wsi + (long)b * (N + 2 + 2 * O);
+  int* ord_g = start_g + N + 1;
+  int* pts_g = ord_g + O;
   for (int n = tid; n <= N; n += 1024) cnt[n] = 0;
   for (int o = tid; o < O; o += 1024) abl[o] = min(max(ab[o], 0), N - 1);
   __syncthreads();
   for (int o = tid; o < O; o += 1024) atomicAdd(&cnt[abl[o]], 1);
   __syncthreads();
   // exclusive scan of cnt[0..N) in place; each thread owns a contiguous run of per = ceil(N / 1024) points
-  const int per = (N + 1023) / 1024, lo_n = tid * per, hi_n = min(lo_n + per, N);
+  const int per = (N + 1023) / 1024, lo_n = min(tid * per, N), hi_n = min(lo_n + per, N);
   int run = 0, distinct = 0;
   for (int n = lo_n; n < hi_n; ++n) {
     run += cnt[n];
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(1024) void amax_bwd_kernel(const float* __restrict_
       dincl += du;
     }
   }
-  if (lane == 63) wtot[wave] = incl | (dincl << 16);   // (O, N <= 32767 each)
+  if (lane == 63) wtot[wave] = incl | (dincl << 16);   // (O <= 8192, N <= 32767)
   __syncthreads();
   int base = 0, dbase = 0;
   for (int w = 0; w < wave; ++w) {
@@ -458,39 +471,110 @@ __global__ __launch_bounds__(1024) void amax_bwd_kernel(const float* __restrict_
   for (int n = lo_n; n < hi_n; ++n) {
     const int c = cnt[n];
     cnt[n] = start;
-    if (c > 0) pts[dpos++] = n;
+    start_g[n] = start;
+    if (c > 0) pts_g[dpos++] = n;
     start += c;
   }
   if (tid == 1023) {
-    cnt[N] = O;
-    ngroups_s = dbase + dincl;
+    start_g[N] = O;
+    pts_g[O] = dbase + dincl;   // number of groups
   }
   __syncthreads();
-  // placement, ascending output inside a group: output o goes to start[n] + #{o' < o : arg[o'] = n}
+  // placement, ascending output inside a group: output o goes to start[n] + #{o' < o : arg[o'] = n}; the earlier
+  // outputs four at a time from LDS (wave-uniform addresses: broadcast reads)
   for (int o = tid; o < O; o += 1024) {
     const int n = abl[o];
     int before = 0;
-    for (int o2 = 0; o2 < o; ++o2) before += (abl[o2] == n);   // (wave-uniform o2: broadcast LDS reads)
-    ord[cnt[n] + before] = o;
+    const int o4 = o & ~3;
+    for (int q = 0; q < o4; q += 16) {
+      int4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const int4*>(abl + min(q + 4 * u, O - 4));
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q + 4 * u < o4) before += (v[u].x == n) + (v[u].y == n) + (v[u].z == n) + (v[u].w == n);
+    }
+    for (int o2 = o4; o2 < o; ++o2) before += (abl[o2] == n);
+    ord_g[cnt[n] + before] = o;
   }
-  __syncthreads();
-  const int ngroups = ngroups_s;
-  for (int gi = wave; gi < ngroups; gi += 16) {
-    const int n = pts[gi];
-    const int s0 = cnt[n], s1 = (gi + 1 < ngroups) ? cnt[pts[gi + 1]] : O;
-    const float x0 = x[(long)b * x_bs + (long)lane * N + n], x1 = x[(long)b * x_bs + (long)(lane + 64) * N + n];
+}
+
+// dx: one wave per group (= one arg-max point of one cloud), lane = two channels; the group's members in ascending
+// output order, four W rows in flight
+__global__ __launch_bounds__(256) void amax_dx_kernel(int N, const float* __restrict__ gy, const float* __restrict__ W,
+                                                      int O, const int* __restrict__ wsi, float* __restrict__ dx,
+                                                      long dx_bs) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int* start_g = wsi + (long)b * (N + 2 + 2 * O);
+  const int* ord_g = start_g + N + 1;
+  const int* pts_g = ord_g + O;
+  const int ngroups = pts_g[O];
+  const float* gb = gy + (long)b * O;
+  for (int gi = blockIdx.x * 4 + (threadIdx.x >> 6); gi < ngroups; gi += gridDim.x * 4) {
+    const int n = pts_g[gi];
+    const int s0 = start_g[n], s1 = start_g[n + 1];
     float a0 = 0.f, a1 = 0.f;
-    for (int k = s0; k < s1; ++k) {
-      const int o = ord[k];
-      const float gv = gy[(long)b * O + o];
+    int k = s0;
+    for (; k + 4 <= s1; k += 4) {
+      int o[4];
+      float gv[4], w0[4], w1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[u] = ord_g[k + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gv[u] = gb[o[u]];
+        w0[u] = W[(long)o[u] * 128 + lane];
+        w1[u] = W[(long)o[u] * 128 + lane + 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 = fmaf(gv[u], w0[u], a0);
+        a1 = fmaf(gv[u], w1[u], a1);
+      }
+    }
+    for (; k < s1; ++k) {
+      const int o = ord_g[k];
+      const float gv = gb[o];
       a0 = fmaf(gv, W[(long)o * 128 + lane], a0);
       a1 = fmaf(gv, W[(long)o * 128 + lane + 64], a1);
-      dwp[((long)b * O + o) * 128 + lane] = gv * x0;
-      dwp[((long)b * O + o) * 128 + lane + 64] = gv * x1;
     }
     dx[(long)b * dx_bs + (long)lane * N + n] = a0;
     dx[(long)b * dx_bs + (long)(lane + 64) * N + n] = a1;
   }
+}
+
+// dW[o][c] = sum over the clouds (ascending) of gy[b][o] x[b][c][arg[b][o]]: one wave per output, lane = two channels,
+// eight clouds' columns in flight
+__global__ __launch_bounds__(256) void amax_dw_kernel(const float* __restrict__ x, long x_bs, int B, int N,
+                                                      const int* __restrict__ arg, const float* __restrict__ gy, int O,
+                                                      float* __restrict__ dW) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= O) return;
+  float a0 = 0.f, a1 = 0.f;
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float gv[8], x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int n = min(max(arg[(long)(b + u) * O + o], 0), N - 1);
+      gv[u] = gy[(long)(b + u) * O + o];
+      x0[u] = x[(long)(b + u) * x_bs + (long)lane * N + n];
+      x1[u] = x[(long)(b + u) * x_bs + (long)(lane + 64) * N + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = fmaf(gv[u], x0[u], a0);
+      a1 = fmaf(gv[u], x1[u], a1);
+    }
+  }
+  for (; b < B; ++b) {
+    const int n = min(max(arg[(long)b * O + o], 0), N - 1);
+    const float gv = gy[(long)b * O + o];
+    a0 = fmaf(gv, x[(long)b * x_bs + (long)lane * N + n], a0);
+    a1 = fmaf(gv, x[(long)b * x_bs + (long)(lane + 64) * N + n], a1);
+  }
+  dW[(long)o * 128 + lane] = a0;
+  dW[(long)o * 128 + lane + 64] = a1;
 }
 
 }  // namespace samble
@@ -507,7 +591,7 @@ extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void
   return samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
 }
 
-extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int N, const void* w_rm, int O, int epi,
+extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O, int epi,
                                         const float* ref, float* out, long o_bs, long o_rs, hipStream_t s) {
   const void* fns[3] = {reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain>),
                         reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinLeaky>),
@@ -517,13 +601,13 @@ extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int N,
   const dim3 grid((N + 255) / 256, B);
   Timed timed(kT_lin_fwd, s);
   if (epi == kLinPlain)
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
                        out, o_bs, o_rs, nullptr, nullptr, nullptr);
   else if (epi == kLinLeaky)
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
                        out, o_bs, o_rs, nullptr, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
                        out, o_bs, o_rs, ref, nullptr, nullptr);
   return (int)hipGetLastError();
 }
@@ -542,20 +626,20 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
   float* pmax = (float*)ws;
   int* parg = (int*)(pmax + (size_t)B * ntiles * O);
   Timed timed(kT_lin_amax, s);
-  hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B), dim3(512), kLinLds, s, x, x_bs, N, (const char*)w_rm,
+  hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B), dim3(512), kLinLds, s, x, x_bs, 128, N, (const char*)w_rm,
                      O / 32, O, nullptr, 0, 0, nullptr, pmax, parg);
   hipLaunchKernelGGL(lin_amax_reduce_kernel, dim3((O + 255) / 256, B), dim3(256), 0, s, pmax, parg, ntiles, O, y, arg);
   return (int)hipGetLastError();
 }
 
-extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int N,
+extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
                                        float* dx, long dx_bs, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dx_tri_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_dx, s);
   hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                     O / 32, N, dx, dx_bs);
+                     O / 32, Cin, N, dx, dx_bs);
   return (int)hipGetLastError();
 }
 
@@ -563,33 +647,41 @@ extern "C" size_t samble_linear_dw_ws_bytes(int B, int N, int O) {
   return (size_t)B * ((N + kLdwPts - 1) / kLdwPts) * O * 128 * sizeof(float);
 }
 
-extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int N, int O,
-                                       float* dW, void* ws, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdwLds);
-  if (e != hipSuccess) return (int)e;
+extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int Cin, int N,
+                                       int O, float* dW, void* ws, hipStream_t s) {
   const int chunks = (N + kLdwPts - 1) / kLdwPts;
   Timed timed(kT_lin_dw, s);
-  hipLaunchKernelGGL(lin_dw_tri_kernel, dim3(chunks, B, O / kLdwOB), dim3(512), kLdwLds, s, g, g_bs, g_rs, x, x_bs, N, O,
-                     (float*)ws);
+  if (O % 256 == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Ldw<2>::kLds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lin_dw_tri_kernel<2>, dim3(chunks, B, O / 256), dim3(512), Ldw<2>::kLds, s, g, g_bs, g_rs, x, x_bs,
+                       Cin, N, O, (float*)ws);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Ldw<1>::kLds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lin_dw_tri_kernel<1>, dim3(chunks, B, O / 128), dim3(512), Ldw<1>::kLds, s, g, g_bs, g_rs, x, x_bs,
+                       Cin, N, O, (float*)ws);
+  }
   const long n4 = (long)O * 128 / 4;
   hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B * chunks,
                      n4, dW);
   return (int)hipGetLastError();
 }
 
-extern "C" size_t samble_amax_bwd_ws_bytes(int B, int O) { return (size_t)B * O * 128 * sizeof(float); }
+extern "C" size_t samble_amax_bwd_ws_bytes(int B, int N, int O) { return (size_t)B * ((size_t)N + 2 + 2 * (size_t)O) * sizeof(int); }
 
-// dx must be ZERO on entry (the kernel writes the arg-max columns only)
+// dx must be ZERO on entry (the kernels write the arg-max columns only)
 extern "C" int samble_launch_amax_bwd(const float* x, long x_bs, int B, int N, const int* arg, const float* gy,
                                       const float* W, int O, float* dx, long dx_bs, float* dW, void* ws, hipStream_t s) {
-  const size_t lds = ((size_t)N + 1 + 3 * (size_t)O) * sizeof(int);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(amax_bwd_kernel),
+  const size_t lds = (((size_t)N + 4) & ~(size_t)3) * sizeof(int) + (size_t)O * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(amax_sort_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_amax_bwd, s);
-  hipLaunchKernelGGL(amax_bwd_kernel, dim3(B), dim3(1024), lds, s, x, x_bs, N, arg, gy, W, O, dx, dx_bs, (float*)ws);
-  const long n4 = (long)O * 128 / 4;
-  hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B, n4, dW);
+  hipLaunchKernelGGL(amax_sort_kernel, dim3(B), dim3(1024), lds, s, N, arg, O, (int*)ws);
+  hipLaunchKernelGGL(amax_dx_kernel, dim3(16, B), dim3(256), 0, s, N, gy, W, O, (const int*)ws, dx, dx_bs);
+  hipLaunchKernelGGL(amax_dw_kernel, dim3((O + 3) / 4), dim3(256), 0, s, x, x_bs, B, N, arg, gy, O, dW);
   return (int)hipGetLastError();
 }

@@ -21,8 +21,10 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from . import ops
+from . import linear, ops
 from . import _lib
+
+FUSED_PROJECTIONS = True  # False: torch.matmul for the two per-point projections of conv1 (A/B runs)
 
 
 def _sync_group(bn):
@@ -193,6 +195,95 @@ class _EdgeMLP(torch.autograd.Function):
                 dbeta2.to(g2.dtype), None, None, None)
 
 
+class _EdgeMLPFused(torch.autograd.Function):
+    """_EdgeMLP with its closed forms on HIP (csrc/edge_glue.hip): BatchNorm batch statistics, their backward
+    corrections, the activation and the per-point gradients as a dozen launches instead of ~250 torch ones.  Training
+    mode on one rank (SyncBatchNorm pooling and evaluation take _EdgeMLP).  a, b (B,N,64), nn (B,N,32) -> (B,64,N)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, a, b, nn_idx, g1, b1, w2, g2, b2, bn1, bn2):
+        B, N, C = a.shape
+        K = nn_idx.shape[2]
+        dev = a.device
+        a, b = a.contiguous(), b.contiguous()
+        g1, b1, g2, b2 = (t.detach().float().contiguous() for t in (g1, b1, g2, b2))
+        w2m = w2.detach()[:, :, 0, 0].float().contiguous()
+        run = lambda bn: (bn.running_mean, bn.running_var) if (bn.track_running_stats and bn.running_mean is not None) \
+            else (None, None)
+        with torch.cuda.device(dev):
+            f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            S, Q, ap, bp = f32(B, N, C), f32(B, N, C), f32(B, N, C), f32(B, N, C)
+            cst = torch.empty(_lib.query("samble_edge_glue_constants_bytes") // 4, dtype=torch.float32, device=dev)
+            st = torch.empty(_lib.query("samble_edge_glue_statistics_bytes") // 8, dtype=torch.float64, device=dev)
+            part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
+            rm1, rv1 = run(bn1)
+            _lib.call("samble_edge_bn1_f32", a.data_ptr(), b.data_ptr(), nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
+                      b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), S.data_ptr(),
+                      Q.data_ptr(), ap.data_ptr(), bp.data_ptr(), cst.data_ptr(), st.data_ptr(), part.data_ptr(),
+                      ops._stream())
+            nparts = _lib.query("samble_edge_partial_count")
+            ymax, ymin = f32(B, N, C), f32(B, N, C)
+            kmax = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
+            kmin = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
+            mpart = torch.empty((nparts, 2, C), dtype=torch.float64, device=dev)
+            _lib.call("samble_edge_mlp_fwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(), B, N, K,
+                      C, ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(), mpart.data_ptr(),
+                      ops._stream())
+            ext = f32(B, N, C)
+            kext = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
+            out = f32(B, C, N)
+            rm2, rv2 = run(bn2)
+            _lib.call("samble_edge_bn2_out_f32", ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(),
+                      mpart.data_ptr(), nparts, B, N, C, g2.data_ptr(), b2.data_ptr(), float(bn2.eps), ops._p(rm2),
+                      ops._p(rv2), float(bn2.momentum), cst.data_ptr(), st.data_ptr(), ext.data_ptr(), kext.data_ptr(),
+                      out.data_ptr(), ops._stream())
+            with torch.no_grad():
+                for bn in (bn1, bn2):
+                    if bn.track_running_stats and bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked += 1
+        ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        a, b, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2 = ctx.saved_tensors
+        B, N, C = a.shape
+        K = nn_idx.shape[2]
+        dev = a.device
+        g = g.float().contiguous()
+        with torch.cuda.device(dev):
+            f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            cst = cst.clone()   # (the backward adds its correction terms: the saved block stays as the forward left it)
+            part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
+            sdv, dg2, db2 = f32(B, N, C), f32(C), f32(C)
+            _lib.call("samble_edge_bwd_pre_f32", g.data_ptr(), ext.data_ptr(), B, N, C, g2.data_ptr(), cst.data_ptr(),
+                      st.data_ptr(), sdv.data_ptr(), dg2.data_ptr(), db2.data_ptr(), part.data_ptr(), ops._stream())
+            nparts = _lib.query("samble_edge_partial_count")
+            du = f32(B, N, K, C)
+            dwp = f32(nparts, C, C)
+            _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
+                      kext.data_ptr(), sdv.data_ptr(), cst.data_ptr() + 256 * 4, B, N, K, C, du.data_ptr(), dwp.data_ptr(),
+                      ops._stream())
+            dusum = f32(B, N, C)
+            _lib.call("samble_edge_du_rowsum_f32", du.data_ptr(), B, N, K, C, dusum.data_ptr(), ops._stream())
+            # reverse-neighbour sums in a fixed order (inverse lists), not index_add_'s atomics
+            order, offsets, counts = ops.inverse_neighbors(nn_idx)
+            D = ops.stage_segment_sum_rows(du.view(-1, C), order, offsets, K, per_edge=True)
+            R = ops.stage_segment_sum_rows(a.view(-1, C), order, offsets, K, per_edge=False)
+            da, db = f32(B, N, C), f32(B, N, C)
+            dg1, db1, dw2 = f32(C), f32(C), f32(C, C)
+            _lib.call("samble_edge_bwd_post_f32", a.data_ptr(), b.data_ptr(), S.data_ptr(), R.data_ptr(), dusum.data_ptr(),
+                      D.data_ptr(), counts.data_ptr(), B, N, K, C, cst.data_ptr(), st.data_ptr(), dwp.data_ptr(), nparts,
+                      da.data_ptr(), db.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), part.data_ptr(),
+                      ops._stream())
+        return da, db, None, dg1, db1, dw2.view(C, C, 1, 1), dg2, db2, None, None
+
+
+FUSED_GLUE = True  # False: the closed forms as torch expressions (_EdgeMLP; A/B runs)
+
+
 class EdgeConv(nn.Module):
     def __init__(self, config_embedding, layer):
         super().__init__()
@@ -222,11 +313,20 @@ class EdgeConv(nn.Module):
             return x.max(dim=-1, keepdim=False)[0]
         nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
         wa, wb = _edge_weights(self.conv1[0].weight, self.group_type)
-        xt = x.permute(0, 2, 1)
-        a = torch.matmul(xt, wa.t())
-        b = torch.matmul(xt, wb.t())
+        wab = torch.cat((wa, wb), dim=0)                              # (128, C): both per-point projections at once
+        if FUSED_PROJECTIONS and linear.linear_supported(x, wab):
+            ab = linear.linear_rows(x, wab)                           # HIP 1x1 convolution (csrc/linear.hip): (B,N,128)
+            a, b = ab[..., :64], ab[..., 64:]
+        else:
+            xt = x.permute(0, 2, 1)
+            a = torch.matmul(xt, wa.t())
+            b = torch.matmul(xt, wb.t())
         bn1, bn2 = self.conv1[1], self.conv2[1]
         use_batch_stats = self.training or not bn1.track_running_stats
+        if (FUSED_GLUE and use_batch_stats and _sync_group(bn1) is None and _sync_group(bn2) is None
+                and bn1.momentum is not None and bn2.momentum is not None):
+            return _EdgeMLPFused.apply(a, b, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias,
+                                       bn1, bn2)
         return _EdgeMLP.apply(a, b, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias, bn1, bn2,
                               use_batch_stats)
 

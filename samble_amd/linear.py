@@ -19,9 +19,12 @@ LIN_PLAIN, LIN_LEAKY, LIN_LEAKY_MASK = 0, 1, 2   # include/samble.h SAMBLE_LIN_*
 
 
 def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True):
-    """W (O, 128) -> (row image | None, transposed image | None) as uint8 tensors (include/samble.h: operand images)."""
+    """W (O, C <= 128) -> (row image | None, transposed image | None) as uint8 tensors (include/samble.h: operand images;
+    a narrower W is padded with zero columns)."""
     _need_gpu(W)
     W = _f32c(W)
+    if W.shape[1] < 128:
+        W = torch.nn.functional.pad(W, (0, 128 - W.shape[1]))
     O, C = W.shape
     with torch.cuda.device(W.device):
         nbytes = _lib.query("samble_linear_image_bytes", O)
@@ -60,32 +63,33 @@ def stage_linear_amax(x: torch.Tensor, w_rm: torch.Tensor, O: int):
     return y, arg
 
 
-def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int) -> torch.Tensor:
-    """g (B,N,O) point-major -> (B,128,N): W^T g."""
+def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int, C: int = 128) -> torch.Tensor:
+    """g (B,N,O) point-major -> (B,C,N): W^T g."""
     _need_gpu(g, w_tr)
     g = _f32c(g)
     B, N, Og = g.shape
     assert Og == O
     with torch.cuda.device(g.device):
-        dx = torch.empty((B, 128, N), dtype=torch.float32, device=g.device)
-        _lib.call("samble_linear_dx_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), w_tr.data_ptr(), O, B, 128, N,
-                  dx.data_ptr(), 128 * N, _stream())
+        dx = torch.empty((B, C, N), dtype=torch.float32, device=g.device)
+        _lib.call("samble_linear_dx_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), w_tr.data_ptr(), O, B, C, N,
+                  dx.data_ptr(), C * N, _stream())
     return dx
 
 
 def stage_linear_dw(g: torch.Tensor, x: torch.Tensor, O: int) -> torch.Tensor:
-    """g (B,N,O), x (B,128,N) -> dW (O,128) = sum over clouds and points of g^T x^T (deterministic)."""
+    """g (B,N,O), x (B,C,N) -> dW (O,C) = sum over clouds and points of g^T x^T (deterministic)."""
     _need_gpu(g, x)
     g, x = _f32c(g), _f32c(x)
     B, N, Og = g.shape
-    assert Og == O and x.shape == (B, 128, N)
+    C = x.shape[1]
+    assert Og == O and x.shape == (B, C, N)
     with torch.cuda.device(g.device):
         dW = torch.empty((O, 128), dtype=torch.float32, device=g.device)
         nbytes = _lib.query("samble_linear_dw_workspace_bytes", B, N, O)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-        _lib.call("samble_linear_dw_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), x.data_ptr(), 128 * N, B, 128, N, O,
+        _lib.call("samble_linear_dw_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), x.data_ptr(), C * N, B, C, N, O,
                   dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
-    return dW
+    return dW if C == 128 else dW[:, :C]
 
 
 def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor):
@@ -97,7 +101,7 @@ def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torc
     with torch.cuda.device(x.device):
         dx = torch.zeros_like(x)
         dW = torch.empty((O, 128), dtype=torch.float32, device=x.device)
-        nbytes = _lib.query("samble_amax_bwd_workspace_bytes", B, O)
+        nbytes = _lib.query("samble_amax_bwd_workspace_bytes", B, N, O)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _lib.call("samble_amax_bwd_f32", x.data_ptr(), C * N, B, C, N, arg.data_ptr(), gy.data_ptr(), W.data_ptr(), O,
                   dx.data_ptr(), C * N, dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
@@ -133,6 +137,42 @@ class _FFN(torch.autograd.Function):
         dw1 = stage_linear_dw(dh, x, H).reshape(H, 128, 1) if ctx.needs_input_grad[1] else None
         dw2 = stage_linear_dw(hr, dy, H).t().reshape(128, H, 1) if ctx.needs_input_grad[2] else None
         return dx, dw1, dw2
+
+
+class _Linear(torch.autograd.Function):
+    """out[b][n][o] = sum_c W[o][c] x[b][c][n]: x channel-major (B, C <= 128, N) -> point-major (B, N, O), O a multiple of
+    128 (the per-point projections of EdgeConv, models/embedding.py:20-28)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, W):
+        O, C = W.shape
+        w_rm, w_tr = weight_images(W)
+        ctx.save_for_backward(x, w_tr)
+        ctx.dims = (O, C)
+        return stage_linear_fwd(x, w_rm, O)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, w_tr = ctx.saved_tensors
+        O, C = ctx.dims
+        g = _f32c(g)
+        dx = stage_linear_dx(g, w_tr, O, C) if ctx.needs_input_grad[0] else None
+        dW = stage_linear_dw(g, x, O) if ctx.needs_input_grad[1] else None
+        return dx, dW
+
+
+def linear_supported(x: torch.Tensor, W: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and W.dim() == 2 and W.shape[1] == x.shape[1]
+            and 1 <= x.shape[1] <= 128 and W.shape[0] % 128 == 0)
+
+
+def linear_rows(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """x (B,C,N), W (O,C) -> (B,N,O) = (W x)^T per cloud."""
+    if not x.is_cuda:
+        raise _lib.SambleError("samble_amd.linear.linear_rows runs on the GPU only (no CPU fallback)")
+    return _Linear.apply(x, W)
 
 
 class _LinearMax(torch.autograd.Function):

@@ -127,3 +127,22 @@ def test_linear_max_against_conv_max(B, N, O):
     y2, arg2 = L._LinearMax.apply(xg2, wb)
     y2.backward(g.to(DEV))
     assert torch.equal(y2, y) and torch.equal(arg2, arg) and torch.equal(xg2.grad, xg.grad) and torch.equal(wb.grad, w.grad)
+
+
+@pytest.mark.parametrize("B,C,N,O", [(2, 64, 300, 128), (3, 3, 2048, 128), (1, 6, 77, 256), (2, 100, 513, 128)])
+def test_linear_rows_with_fewer_input_channels(B, C, N, O):
+    """linear_rows: x (B, C <= 128, N) -> (B, N, O) = (W x)^T, the per-point projections of EdgeConv's conv1
+    (models/embedding.py:20-28; C = 3 or 64 there), against float64 torch: output, dx and dW."""
+    from samble_amd import linear as L
+    x = torch.from_numpy(synth.normal((B, C, N), 80 + N)).to(DEV).requires_grad_(True)
+    W = _w((O, C), 81 + N, 0.2).to(DEV).requires_grad_(True)
+    g = torch.from_numpy(synth.normal((B, N, O), 82 + N)).to(DEV)
+    assert L.linear_supported(x, W)
+    y = L.linear_rows(x, W)
+    y.backward(g)
+    xd, Wd = x.detach().double().requires_grad_(True), W.detach().double().requires_grad_(True)
+    yr = torch.einsum("oc,bcn->bno", Wd, xd)
+    yr.backward(g.double())
+    assert y.shape == (B, N, O) and _rel(y.detach(), yr.detach()) <= 2e-6
+    assert x.grad.shape == (B, C, N) and _rel(x.grad, xd.grad) <= 3e-6
+    assert W.grad.shape == (O, C) and _rel(W.grad, Wd.grad) <= 3e-6
