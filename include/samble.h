@@ -196,7 +196,8 @@ int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_
  *                                 samble_edge_partial_count() x (2,64) double partial sums of y, y^2
  *   samble_edge_mlp_bwd_f32       recomputes the edge tensors; dy = c0 + c1 y + [edge == kext] sdv;
  *                                 writes du (B*N, 32, 64) = gradient of the pre-activation ap_i + bp_j per
- *                                 edge and samble_edge_partial_count() x (64,64) partials of dW2 */
+ *                                 edge, dusum (B*N, 64) = its sum over a point's edges (NULL: not wanted) and
+ *                                 samble_edge_partial_count() x (64,64) partials of dW2 */
 int samble_edge_partial_count(void);
 int samble_edge_gather_sums_f32(const float* bp, const int32_t* nn, int B, int N, int K, int C, float* S, float* Q,
                                 void* stream);
@@ -204,7 +205,7 @@ int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const int32_t* nn,
                             int C, float* ymax, float* ymin, uint8_t* kmax, uint8_t* kmin, double* partials,
                             void* stream);
 int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2, const uint8_t* kext,
-                            const float* sdv, const float* c0c1, int B, int N, int K, int C, float* du,
+                            const float* sdv, const float* c0c1, int B, int N, int K, int C, float* du, float* dusum,
                             float* dw2_partials, void* stream);
 
 /* ---- utils/ops.py:47-65, 83-112  select_neighbors / group: gather of the neighbour tensor -----
@@ -499,8 +500,7 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
  *                             = LeakyReLU(BN2(ext)), channel-major
  *   samble_edge_bwd_pre_f32   g (B, 64, N) -> sdv = sc2 g LeakyReLU'(v) rows for samble_edge_mlp_bwd_f32, whose `c0c1`
  *                             argument is constants + 256 after this call; d gamma2, d beta2
- *   samble_edge_du_rowsum_f32 dusum_i = sum_k du_ik
- *   samble_edge_bwd_post_f32  from dusum, D_i = sum of du over the INCOMING edges of i and R_i = sum of a over them
+ *   samble_edge_bwd_post_f32  from dusum (samble_edge_mlp_bwd_f32), D_i = sum of du over the INCOMING edges of i and R_i = sum of a over them
  *                             (samble_segment_sum_rows_f32 over samble_inverse_neighbors' lists; indeg = their counts):
  *                             d gamma1, d beta1, the per-point gradients da, db and dW2 (64, 64) = the ordered sum of
  *                             samble_edge_mlp_bwd_f32's per-wave partials */
@@ -517,7 +517,6 @@ int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t*
 int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2, float* constants,
                             const double* statistics, float* sdv, float* dgamma2, float* dbeta2, double* partials,
                             void* stream);
-int samble_edge_du_rowsum_f32(const float* du, int B, int N, int K, int C, float* dusum, void* stream);
 int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum, const float* D,
                              const int32_t* indeg, int B, int N, int K, int C, float* constants, const double* statistics,
                              const float* dw2_partials, int n_partials, float* da, float* db, float* dgamma1, float* dbeta1,

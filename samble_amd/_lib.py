@@ -74,7 +74,6 @@ _SIGNATURES = {
                                         c_void_p, c_void_p]),
     "samble_edge_bwd_pre_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
-    "samble_edge_du_rowsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -132,7 +131,7 @@ _SIGNATURES = {
     "samble_edge_mlp_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_edge_mlp_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                        c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_group_gather_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_fps_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_timing_select": (c_int, [c_uint64]),

@@ -41,7 +41,7 @@ int samble_launch_edge_gather_sums(const float*, const int*, int, int, float*, f
 int samble_launch_edge_mlp_fwd(const float*, const float*, const int*, const float*, int, int, float*, float*,
                                unsigned char*, unsigned char*, double*, hipStream_t);
 int samble_launch_edge_mlp_bwd(const float*, const float*, const int*, const float*, const unsigned char*, const float*,
-                               const float*, int, int, float*, float*, hipStream_t);
+                               const float*, int, int, float*, float*, float*, hipStream_t);
 int samble_launch_group_gather(const float*, const int*, int, int, int, int, int, float*, hipStream_t);
 int samble_launch_fps(const float*, const long long*, int, int, int, long long*, hipStream_t);
 int samble_launch_gather_points(const float*, int, int, int, const long long*, int, float*, hipStream_t);
@@ -108,7 +108,6 @@ int samble_launch_edge_post(const float*, const float*, const unsigned char*, co
                             float*, hipStream_t);
 int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float*, float*, const double*, float*, float*, float*,
                                double*, hipStream_t);
-int samble_launch_edge_du_rowsum(const float*, int, int, float*, hipStream_t);
 int samble_launch_edge_bwd_post(const float*, const float*, const float*, const float*, const float*, const float*, const int*,
                                 int, int, float*, const double*, const float*, int, float*, float*, float*, float*, float*,
                                 double*, hipStream_t);
@@ -385,12 +384,12 @@ SAMBLE_API int samble_edge_mlp_fwd_f32(const float* ap, const float* bp, const i
 
 SAMBLE_API int samble_edge_mlp_bwd_f32(const float* ap, const float* bp, const int32_t* nn, const float* W2,
                                        const uint8_t* kext, const float* sdv, const float* c0c1, int B, int N, int K, int C,
-                                       float* du, float* dw2_partials, void* stream) {
+                                       float* du, float* dusum, float* dw2_partials, void* stream) {
   if (!ap || !bp || !nn || !W2 || !kext || !sdv || !c0c1 || !du || !dw2_partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: null pointer");
   if (K != 32 || C != 64 || B <= 0 || N <= 0)
     return fail(SAMBLE_E_INVALID, "samble_edge_mlp_bwd_f32: built for K = 32 neighbours, 64 channels");
-  return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, kext, sdv, c0c1, B, N, du, dw2_partials, (hipStream_t)stream),
+  return done(samble_launch_edge_mlp_bwd(ap, bp, nn, W2, kext, sdv, c0c1, B, N, du, dusum, dw2_partials, (hipStream_t)stream),
               "samble_edge_mlp_bwd_f32");
 }
 
@@ -906,12 +905,6 @@ SAMBLE_API int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, 
   return done(samble_launch_edge_bwd_pre(g, ext, B, N, gamma2, constants, statistics, sdv, dgamma2, dbeta2, partials,
                                          (hipStream_t)stream),
               "samble_edge_bwd_pre_f32");
-}
-
-SAMBLE_API int samble_edge_du_rowsum_f32(const float* du, int B, int N, int K, int C, float* dusum, void* stream) {
-  if (!du || !dusum) return fail(SAMBLE_E_INVALID, "samble_edge_du_rowsum_f32: null pointer");
-  if (!edge_shape_ok(B, N, K, C)) return fail(SAMBLE_E_INVALID, "samble_edge_du_rowsum_f32: built for K = 32 neighbours, 64 channels");
-  return done(samble_launch_edge_du_rowsum(du, B, N, dusum, (hipStream_t)stream), "samble_edge_du_rowsum_f32");
 }
 
 SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum,

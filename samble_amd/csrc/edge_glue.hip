@@ -332,36 +332,25 @@ __global__ __launch_bounds__(256) void edge_bwd_final_kernel(const float* __rest
   *reinterpret_cast<float2*>(db + at) = make_float2(ob[0], ob[1]);
 }
 
-// dusum[p][c] = sum_k du[p][k][c]   (one wave per point: lanes = channels, 32 rows of 256 B)
-__global__ __launch_bounds__(256) void edge_du_rowsum_kernel(const float* __restrict__ du, long npoints,
-                                                             float* __restrict__ dusum) {
-  const int lane = threadIdx.x & 63;
-  for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npoints; p += (long)gridDim.x * 4) {
-    const float* base = du + p * kGK * kGC + lane;
-    float v[kGK];
-#pragma unroll
-    for (int k = 0; k < kGK; ++k) v[k] = base[k * kGC];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < kGK; ++k) s += v[k];
-    dusum[p * kGC + lane] = s;
-  }
-}
-
-// out[e] = sum over the nparts blocks (each n floats) in ascending order: 64 x 64 dW2 from the per-wave partials
+// out[e] = sum over the nparts blocks (each n floats): 64 x 64 dW2 from the per-wave partials.  Workgroup = 16 elements
+// x 16 groups of partials (p = g, g + 16, ...: eight loads in flight), the 16 group sums added in index order:
+// deterministic.  (One thread per element walking all 2048 partials took 100 us: a dependent chain of strided loads.)
 __global__ __launch_bounds__(256) void edge_sum_parts_kernel(const float* __restrict__ part, int nparts, int n,
                                                              float* __restrict__ out) {
-  __shared__ float red[8][32];
-  const int e = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float s = 0.f;
-  if (e < n)
-    for (int p = g; p < nparts; p += 8) s += part[(long)p * n + e];
-  red[g][threadIdx.x & 31] = s;
+  if (e < n) {
+#pragma unroll 8
+    for (int p = g; p < nparts; p += 16) s += part[(long)p * n + e];
+  }
+  red[g][el] = s;
   __syncthreads();
   if (g == 0 && e < n) {
-    float t = red[0][threadIdx.x];
+    float t = red[0][el];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][threadIdx.x];
+    for (int k = 1; k < 16; ++k) t += red[k][el];
     out[e] = t;
   }
 }
@@ -415,11 +404,6 @@ extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int 
   return (int)hipGetLastError();
 }
 
-extern "C" int samble_launch_edge_du_rowsum(const float* du, int B, int N, float* dusum, hipStream_t s) {
-  hipLaunchKernelGGL(edge_du_rowsum_kernel, dim3(2048), dim3(256), 0, s, du, (long)B * N, dusum);
-  return (int)hipGetLastError();
-}
-
 // backward, after the MLP sweep and the reverse-neighbour sums D (of du) and R (of a): d gamma1, d beta1, da, db; dW2
 extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, const float* S, const float* R,
                                            const float* dusum, const float* D, const int* indeg, int B, int N, float* cst,
@@ -431,6 +415,6 @@ extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, const
                      dbeta1);
   hipLaunchKernelGGL(edge_bwd_final_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, a, b, S, R, dusum, D,
                      indeg, cst, st, np, da, db);
-  hipLaunchKernelGGL(edge_sum_parts_kernel, dim3(kGC * kGC / 32), dim3(256), 0, s, dw2part, nwaves, kGC * kGC, dW2);
+  hipLaunchKernelGGL(edge_sum_parts_kernel, dim3(kGC * kGC / 16), dim3(256), 0, s, dw2part, nwaves, kGC * kGC, dW2);
   return (int)hipGetLastError();
 }

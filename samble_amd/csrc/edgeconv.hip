@@ -23,6 +23,21 @@ constexpr int kEK = 32;   // neighbours per point = edges per wave
 
 __device__ __forceinline__ float lrelu(float v) { return fmaxf(v, 0.2f * v); }
 
+// sum over the 32 lanes of each half of the wave, in every lane of rows 1 and 3 (lanes 16..31, 48..63): quad swaps, half-row
+// and row mirrors (every lane of a row of 16 then holds the row's sum, formed in the same order), row broadcast 15
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float edge_dpp_f(float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, ROW_MASK, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float x) {
+  x += edge_dpp_f<0xB1, 0xF>(x);   // quad_perm [1,0,3,2]
+  x += edge_dpp_f<0x4E, 0xF>(x);   // quad_perm [2,3,0,1]
+  x += edge_dpp_f<0x141, 0xF>(x);  // row_half_mirror
+  x += edge_dpp_f<0x140, 0xF>(x);  // row_mirror
+  x += edge_dpp_f<0x142, 0xA>(x);  // row_bcast15 -> rows 1, 3 (rows 0, 2 receive 0: their value is not used)
+  return x;
+}
+
 // S[p][c] = sum_k bp[j(p,k)][c],  Q[p][c] = sum_k bp[j(p,k)][c]^2     (p = b*N + i)
 // half-wave per point, lane = 2 channels; grid-stride over points
 __global__ __launch_bounds__(256) void edge_gather_sums_kernel(const float* __restrict__ bp, const int* __restrict__ nn,
@@ -151,6 +166,7 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __res
                                                               const float* __restrict__ sdv,    // (npoints,64)
                                                               const float* __restrict__ c0c1,   // (2,64)
                                                               int N, long npoints, float* __restrict__ du,
+                                                              float* __restrict__ dusum,  // (npoints,64) sum_k du, or null
                                                               float* __restrict__ dw2part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* w2s = smem;                         // [64 o][kEwPad]   W2, read as rows (A operand) and as columns
@@ -239,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __res
     float* durow = du + (p * kEK + lo) * kEC;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
+      float rs = 0.f;  // lanes 16..31 of each half: the point's sum over its 32 edges for channel 32 ct + crow(lo - 16, h)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 32 * ct + 8 * g + 4 * h);
@@ -247,7 +264,15 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = dht[ct][4 * g + e] * ((a4[e] + b4[e]) > 0.f ? 1.f : 0.2f);
         *reinterpret_cast<f32x4*>(durow + 32 * ct + 8 * g + 4 * h) = o4;
+        if (dusum) {  // (uniform) the edges are the lanes: a fixed DPP butterfly over the 32 lanes of the half
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = half_wave_sum(o4[e]);
+            rs = (lo == 16 + 4 * g + e) ? t : rs;
+          }
+        }
       }
+      if (dusum && lo >= 16) dusum[p * kEC + 32 * ct + crow(lo - 16, h)] = rs;
     }
     // dW2[o][c] += sum_edge dy[edge][o] h[edge][c]: both operands read from the wave's LDS tiles by rows
     // (edge pair of MFMA step t = rows crow(t,0), crow(t,1)); same-wave LDS traffic needs no barrier
@@ -300,7 +325,7 @@ extern "C" int samble_launch_edge_mlp_fwd(const float* ap, const float* bp, cons
 
 extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, const int* nn, const float* W2,
                                           const unsigned char* yext, const float* sdv, const float* c0c1, int B, int N, float* du,
-                                          float* dw2part, hipStream_t s) {
+                                          float* dusum, float* dw2part, hipStream_t s) {
   const long np = (long)B * N;
   const size_t lds = (size_t)(kEC * kEwPad + 2 * kEC + 8 * 2 * kEK * kEwPad) * sizeof(float);  // 157 KB: one workgroup per CU
   {  // per call: cheap, and correct for every device / thread (no process-wide 'done' flag)
@@ -310,6 +335,6 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
   }
   Timed timed(kT_edge_bwd, s);
   hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
-                     N, np, du, dw2part);
+                     N, np, du, dusum, dw2part);
   return (int)hipGetLastError();
 }

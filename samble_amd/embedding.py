@@ -165,7 +165,7 @@ class _EdgeMLP(torch.autograd.Function):
             du = torch.empty((B, N, K, C), dtype=torch.float32, device=dev)
             dwp = torch.empty((nparts, C, C), dtype=torch.float32, device=dev)
             _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
-                      kext.data_ptr(), sdv.data_ptr(), c0c1.data_ptr(), B, N, K, C, du.data_ptr(), dwp.data_ptr(),
+                      kext.data_ptr(), sdv.data_ptr(), c0c1.data_ptr(), B, N, K, C, du.data_ptr(), None, dwp.data_ptr(),
                       ops._stream())
         dw2 = dwp.sum(0)
         dusum = du.sum(2)                                                # sum_k du_ik
@@ -263,11 +263,10 @@ class _EdgeMLPFused(torch.autograd.Function):
             nparts = _lib.query("samble_edge_partial_count")
             du = f32(B, N, K, C)
             dwp = f32(nparts, C, C)
-            _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
-                      kext.data_ptr(), sdv.data_ptr(), cst.data_ptr() + 256 * 4, B, N, K, C, du.data_ptr(), dwp.data_ptr(),
-                      ops._stream())
             dusum = f32(B, N, C)
-            _lib.call("samble_edge_du_rowsum_f32", du.data_ptr(), B, N, K, C, dusum.data_ptr(), ops._stream())
+            _lib.call("samble_edge_mlp_bwd_f32", ap.data_ptr(), bp.data_ptr(), nn_idx.data_ptr(), w2m.data_ptr(),
+                      kext.data_ptr(), sdv.data_ptr(), cst.data_ptr() + 256 * 4, B, N, K, C, du.data_ptr(),
+                      dusum.data_ptr(), dwp.data_ptr(), ops._stream())
             # reverse-neighbour sums in a fixed order (inverse lists), not index_add_'s atomics
             order, offsets, counts = ops.inverse_neighbors(nn_idx)
             D = ops.stage_segment_sum_rows(du.view(-1, C), order, offsets, K, per_edge=True)
