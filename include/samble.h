@@ -392,7 +392,10 @@ int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* q
  *                            prepares itself; P V and dQ stay on three bf16 planes).  samble_tri_split_qkv_f32 and
  *                            samble_proj_fwd_split_tri_f32 apply it to k_image and v_rm_image themselves; the K row
  *                            image arguments of the three logit entries and the v_rm_image argument of
- *                            samble_attn_rows_bwd_tri_f32 expect it
+ *                            samble_attn_rows_bwd_tri_f32 expect it.  IDEMPOTENT since ABI 0.2: a converted tile carries a
+ *                            tag (a bit pattern no three-plane tile can hold) beside its 2^-e and is left alone by a
+ *                            second call; a RAW samble_tri_split_f32 image handed to those entries is still the caller's
+ *                            error (they cannot check it without reading the image: wrong logits, no fault)
  *   samble_attn_stats_tri_f32  = samble_attn_stats_f32 on a Q image (N rows) and a K image (N+nt rows, logit form)
  *   samble_attn_rows_fwd_tri_f32 = samble_attn_rows_fwd_f32 on the transposed image of V (N+nt rows)
  *   samble_attn_rows_bwd_tri_f32 = samble_attn_rows_bwd_f32 (same outputs, same ds_colsum contract).  variant 0:

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
         duo8(x, sx, hw, lw);
         *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 0)) = hw;
         *reinterpret_cast<u32x4*>(irm + tri_rm_off(r, gq, 1)) = lw;
-        if (e == 0) *reinterpret_cast<u32x4*>(irm + kDuoScaleSlot) = u32x4{__float_as_uint(ix), 0u, 0u, 0u};
+        if (e == 0) *reinterpret_cast<u32x4*>(irm + kDuoScaleSlot) = u32x4{__float_as_uint(ix), kDuoTag, 0u, 0u};
       }
       const int d = e & 127, cg = e >> 7;
       float x[8], y[8];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
         *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 0)) = yh;
         *reinterpret_cast<u32x4*>(qtr + tri_tr_off(d, cg, 1)) = yl;
         if (e == 0) {
-          *reinterpret_cast<u32x4*>(itr + kDuoTrScaleSlot) = u32x4{__float_as_uint(ix), 0u, 0u, 0u};
+          *reinterpret_cast<u32x4*>(itr + kDuoTrScaleSlot) = u32x4{__float_as_uint(ix), kDuoTag, 0u, 0u};
           *reinterpret_cast<u32x4*>(qtr + kDuoTrScaleSlot) = u32x4{__float_as_uint(iy), 0u, 0u, 0u};
         }
       } else {

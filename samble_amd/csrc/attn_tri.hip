@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ im
   __shared__ float wmax[4];
   char* tile = img + ((long)blockIdx.y * ntiles + tile0 + blockIdx.x) * kTriTile;
   const int tid = threadIdx.x;
+  if (*reinterpret_cast<const unsigned*>(tile + kDuoScaleSlot + 4) == kDuoTag) return;  // converted already (uniform)
   float x[2][8];
   float amax = 0.f;
 #pragma unroll
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ im
     u32x4* c = reinterpret_cast<u32x4*>(tile + tri_rm_off(r, g, 0));
     c[0] = hw;
     c[32] = lw;
-    if (p == 0) c[64] = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
+    if (p == 0) c[64] = u32x4{__float_as_uint(inv), kDuoTag, 0u, 0u};
   }
 }
 }  // namespace samble

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
         char* img = (which == 1 ? im.k_rm : im.v_rm) + toff;
         *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = hw;
         *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = lw;
-        if (tid == 0) *reinterpret_cast<u32x4*>(img + kDuoScaleSlot) = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
+        if (tid == 0) *reinterpret_cast<u32x4*>(img + kDuoScaleSlot) = u32x4{__float_as_uint(inv), kDuoTag, 0u, 0u};
       }
       for (int e = tid; e < 1024; e += 512) {  // transposed-image chunks of V and (for the backward) K
         const int which = e >> 9, d = e & 127, cg = (e >> 7) & 3, s2 = cg >> 1, hh = cg & 1;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
                 *reinterpret_cast<u32x4*>(rm + tri_rm_off(lo, g, 1)) = lw;
               }
             // (the third piece slots stay unwritten: dead space of the image, except the tile's 2^-e)
-            if (lane == 0) *reinterpret_cast<u32x4*>(rm + kDuoScaleSlot) = u32x4{__float_as_uint(inv), 0u, 0u, 0u};
+            if (lane == 0) *reinterpret_cast<u32x4*>(rm + kDuoScaleSlot) = u32x4{__float_as_uint(inv), kDuoTag, 0u, 0u};
           }
         } else {
 #pragma unroll

@@ -85,6 +85,10 @@ __device__ __forceinline__ f32x16 mfma_duo(u32x4 ah, u32x4 al, u32x4 bh, u32x4 b
   return c;
 }
 constexpr int kDuoScaleSlot = ((3 * 0 + 2) * 32 + 0) * 16;  // tri_rm_off(0, 0, 2): where a converted K tile keeps 2^-e
+// ... and, in the word behind it, this tag: two bf16 NaNs, which the l plane of a three-plane image (the residual of a
+// finite value) cannot hold -- how samble_tri_k_logit_form tells a converted tile from a raw one (the conversion is
+// idempotent: a tile that carries the tag is left alone)
+constexpr unsigned kDuoTag = 0xFFC07FC0u;
 // 2^e with amax x 2^e in [2^12, 2^13); the exponent is clamped so that 2^e and 2^-e are normal.  A tile of zeros
 // (amax = 0 or denormal) gets the LARGEST exponent: its 2^-e never is the maximum over a cloud's tiles
 __device__ __forceinline__ void duo_scale_for(float amax, float& s, float& inv) {

@@ -107,7 +107,7 @@ class _SamplerCore(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, qkv, x, mod, noise, images=None, forced_idx=None):
         B, C, N = x.shape
-        D = mod.q_depth
+        D = qkv.shape[2] // 3          # (128: a narrower layer arrives zero-padded, DownSampleToken.forward)
         nt = qkv.shape[1] - N
         nb = mod.num_bins
         q = qkv[:, :N, 0:D]
@@ -376,8 +376,19 @@ class DownSampleToken(nn.Module):
                 "SAMBLE_E_TIMEOUT: a grid barrier of the fused select chain gave up in an earlier forward of this layer "
                 "(its workgroups were not all resident); that forward's selection was a placeholder. The layer has "
                 "switched to the stand-alone stage kernels.")
-        if C != 128 or self.q_depth != 128 or self.k_depth != 128 or self.v_depth != 128:
-            raise NotImplementedError("the HIP kernels are built for C = q_out = k_out = v_out = 128 (shipped configs)")
+        if not (self.q_depth == self.k_depth == self.v_depth == C and C <= 128):
+            raise NotImplementedError("the HIP kernels take C = q_out = k_out = v_out <= 128 (the shipped configs: 128); "
+                                      "wider layers (256 channels) have no attention kernel here")
+        wq, wk, wv, tokens = self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.bin_tokens
+        x_in = x
+        if C < 128:
+            # a narrower layer runs on the 128-channel kernels with zero channels behind its own: distances, logits and
+            # products are unchanged by them; the logits' 1 / sqrt(C) enters through W_q (the kernels divide by sqrt(128))
+            pad = 128 - C
+            grow = lambda w: F.pad(w, (0, 0, 0, pad, 0, pad))            # (C,C,1) -> (128,128,1)
+            wq, wk, wv = grow(wq * math.sqrt(128.0 / C)), grow(wk), grow(wv)
+            tokens = F.pad(tokens, (0, 0, 0, pad))                      # (1,C,nt) -> (1,128,nt)
+            x = F.pad(x, (0, 0, 0, pad))                                # (B,C,N) -> (B,128,N)
         # (B, N+nt, 3D) point-major rows [Q|K|V]; rows N.. are the bin tokens
         # the map-free forward takes its operand images straight from the projection kernel (no split pass over qkv)
         fused_images = (MAP_FREE and TWO_PASS and ops.MATRIX_MODE == "tri" and self.asm == "dot" and self.K in (16, 32)
@@ -385,18 +396,19 @@ class DownSampleToken(nn.Module):
         if fused_images:
             need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
             # (everything downstream of the projection reads K and V from the images: their fp32 point rows stay unwritten)
-            qkv, *images = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight,
-                                             self.v_conv.weight, "fwd+bwd" if need_bwd else "fwd", True)
+            qkv, *images = _Projection.apply(x, tokens, wq, wk, wv, "fwd+bwd" if need_bwd else "fwd", True)
         else:
             images = None
-            qkv = _Projection.apply(x, self.bin_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
+            qkv = _Projection.apply(x, tokens, wq, wk, wv)
 
         (x_ds, tok, idx, score, z, member, cap, w_pre, counts, indeg, nn_idx) = _SamplerCore.apply(
             qkv, x.detach(), self, noise, tuple(images) if images is not None else None, forced_idx)
 
         index_down = idx.unsqueeze(1)
+        if C < 128:
+            x_ds = x_ds[:, :C, :].contiguous()
         if self.res is True:
-            x_ds = self.res_block(x, x_ds, index_down)
+            x_ds = self.res_block(x_in, x_ds, index_down)
 
         self.attention_point_score = score.unsqueeze(1)
         self._member_bits = member

@@ -89,6 +89,8 @@ CASES = [
     dict(name="cls_l2_colsum_topk", cfg="cls", B=2, N=256, M=128, calls=1, big=False, asm="l2", sample_mode="topk",
          idx_mode="col_sum"),
     dict(name="cls_l2_rowstd_random", cfg="cls", B=2, N=256, M=128, calls=1, big=False, asm="l2", idx_mode="row_std"),
+    # round 4: a 64-channel layer (q_in = q_out = ... = 64)
+    dict(name="cls_c64_random", cfg="cls", B=2, N=256, M=128, calls=2, big=True, C=64),
 ]
 
 
@@ -107,6 +109,9 @@ def build_reference(case, seed):
         cfg.bin.relu_mean_order[layer] = case["relu_mean_order"]
     if "boltzmann_T" in case:
         cfg.bin.boltzmann_T[layer] = case["boltzmann_T"]
+    if "C" in case:  # a narrower layer (the reference constructor takes any q_in / q_out ...: models/downsample.py:33-56)
+        for key in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out"):
+            cfg[key][layer] = case["C"]
     if "static" in case:
         cfg.bin.dynamic_boundaries_enable = False
         cfg.bin.bin_boundaries[layer] = list(case["static"])

@@ -1271,3 +1271,18 @@ def test_small_ops_against_reference_vectors():
     (xf, idf), rest = o_.fps(x, xyz, npnt)      # (its own torch.randint start: shapes and the gather relation)
     assert rest == (None, None) and idf.shape == (Bf, 1, npnt) and xf.shape == (Bf, Cf, npnt)
     assert torch.equal(xf, torch.gather(x, 2, idf.expand(-1, Cf, -1)))
+
+
+def test_k_logit_form_is_idempotent():
+    """samble_tri_k_logit_form twice = once (include/samble.h: converted tiles carry a tag), on full, ragged and
+    token-bearing row counts."""
+    o_ = ops()
+    for (B, R) in ((2, 256), (1, 70), (3, 262)):
+        rows = torch.from_numpy(synth.normal((B, R, 128), 900 + R)).to(DEV)
+        img = o_.stage_tri_split(rows)[0]
+        raw = img.clone()
+        o_.stage_k_logit_form(img, rows)
+        once = img.clone()
+        assert not torch.equal(once, raw)
+        o_.stage_k_logit_form(img, rows)
+        assert torch.equal(img, once)

@@ -78,6 +78,8 @@ class Golden:
         cfg.bin.relu_mean_order = [self.relu_mean_order] * 2
         cfg.bin.boltzmann_T = [self.boltzmann_T] * 2
         cfg.bin.momentum_update_factor = [self.momentum] * 2
+        for key in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out"):
+            cfg[key] = [self.C] * 2
         if not self.dynamic:
             cfg.bin.dynamic_boundaries_enable = False
             cfg.bin.bin_boundaries = [list(self.static), list(self.static)]
