@@ -590,6 +590,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         comm = measure_collectives(dev, world)
+    # every other kernel of the step, timed the same way (library-side HIP events on the launch stream) over 5 further
+    # full steps: same cache state as the timed region.  EVERY rank runs them -- a step holds collectives (the boundary
+    # all-reduce, DDP's buckets): rank 0 alone would wait for the others forever
+    kt = None
+    if not args.no_breakdown:
+        names = [n for n in _lib.TIMED_KERNELS if n != "attn_fwd"]
+        _lib.timing_select(names)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        kt = {n: _lib.timing_read(n) for n in names}
+        _lib.timing_select([])
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -710,16 +722,7 @@ def main():
         import samble_amd.downsample as _dsm0
         result["forward"] = ("map-free (K neighbour logits per row in pass 1, sampled rows recomputed in pass 2)"
                              if (tri and _dsm0.MAP_FREE) else "logit map in HBM (two-pass)")
-        if not args.no_breakdown:
-            # every other kernel of the step, timed the same way (library-side HIP events on the launch stream)
-            # over 5 further full steps: same cache state as the timed region
-            names = [n for n in _lib.TIMED_KERNELS if n != "attn_fwd"]
-            _lib.timing_select(names)
-            for _ in range(5):
-                step()
-            torch.cuda.synchronize()
-            kt = {n: _lib.timing_read(n) for n in names}
-            _lib.timing_select([])
+        if kt is not None:
             result["kernel_us"] = {n: round(v[1] * 1e3, 1) for n, v in kt.items() if v}
             sfx = "_tri_kernel" if tri else "_kernel"
             import samble_amd.downsample as _dsm

@@ -123,3 +123,22 @@ def test_fused_edgeconv_pools_syncbatchnorm_statistics(tmp_path):
     # pooled statistics: both ranks hold the same running buffers
     for n in res[0]["fused"]["bufs"]:
         assert torch.equal(res[0]["fused"]["bufs"][n], res[1]["fused"]["bufs"][n]), n
+
+
+def test_bench_two_ranks_finishes_and_reports_the_collectives():
+    """`python bench.py --gpus 2` (the driver's N > 1 contract) on this box: two ranks share the GPU over gloo.  The run
+    must FINISH -- every phase that holds collectives (timed steps, the per-kernel breakdown steps) runs on every rank --
+    and the line carries the communication report (library, ranks formed, latencies of the two data-path messages)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=420, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2 and line["config"]["global_batch"] == 64
+    assert line["scaling"] == "weak" and line["value"] > 0 and "kernel_us" in line
+    comm = line["comm"]
+    assert comm["ranks_formed"] == 2 and comm["c1_boundary_allreduce_5_floats_us"] > 0 and comm["c2_ddp_bucket_399KB_allreduce_us"] > 0
