@@ -269,7 +269,7 @@ template <int KN>
 __global__ __launch_bounds__(256) void knn_smallc_fused_kernel(const float* __restrict__ xq, long q_bs, int Nq,
                                                                const float* __restrict__ xk, long k_bs, int Nk, int C,
                                                                int* __restrict__ idx_out, float* __restrict__ key_out) {
-  __shared__ float kx[8 * kSmallChunk];
+  __shared__ __attribute__((aligned(16))) float kx[8 * kSmallChunk];
   __shared__ float qw[kSmallQueue * 256];
   __shared__ unsigned short qj[kSmallQueue * 256];
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -298,7 +298,42 @@ __global__ __launch_bounds__(256) void knn_smallc_fused_kernel(const float* __re
     for (int c = 0; c < C; ++c)
       for (int e = tid; e < nj; e += 256) kx[c * kSmallChunk + e] = xk[(long)b * k_bs + (long)c * Nk + j0 + e];
     __syncthreads();
-    for (int jj = 0; jj < nj; ++jj) {
+    // eight keys per trip: their distances first (broadcast 16-byte LDS reads, no branch), then ONE vote on the
+    // smallest of them -- once the lists hold K entries almost every group of eight fails it as a whole and the per-key
+    // path below (same arithmetic, keys in ascending order: same lists) is skipped.  (One key per trip with a branch and
+    // a vote each took 187 us for the interpolation's two searches: a dependent LDS round trip per key.)
+    const int nj8 = nj & ~7;
+    for (int jj = 0; jj < nj8; jj += 8) {
+      float acc8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(kx + c * kSmallChunk + jj);
+          const f32x4 k1 = *reinterpret_cast<const f32x4*>(kx + c * kSmallChunk + jj + 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d0 = q[c] - k0[u], d1 = q[c] - k1[u];
+            acc8[u] = fmaf(d0, d0, acc8[u]);
+            acc8[4 + u] = fmaf(d1, d1, acc8[4 + u]);
+          }
+        }
+      }
+      const float m8 = fminf(fminf(fminf(acc8[0], acc8[1]), fminf(acc8[2], acc8[3])),
+                             fminf(fminf(acc8[4], acc8[5]), fminf(acc8[6], acc8[7])));
+      if (!__any(valid && m8 <= thr)) continue;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (valid && acc8[u] <= thr) {
+          qw[cnt * 256 + tid] = acc8[u];
+          qj[cnt * 256 + tid] = (unsigned short)(j0 + jj + u);
+          ++cnt;
+        }
+        if (__any(cnt == kSmallQueue)) drain();
+      }
+    }
+    for (int jj = nj8; jj < nj; ++jj) {
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
