@@ -487,6 +487,22 @@ int samble_attn_rows_fwd_recompute_tri_f32(const void* q_image, const void* k_im
                                            const float* lse, const int64_t* idx, int B, int N, int nt, int M, int D,
                                            float* x_ds, float* pmap, int ld, void* stream);
 
+/* ---- models/upsample.py:181-213  UpSampleInterpolation.interpolate: the inverse-distance blend (csrc/interp.hip) ----
+ * After the cross-set search (samble_knn_f32 with distances: idx (B,N,K) int32 into the M coarse points, dist (B,N,K)):
+ *   samble_interp_blend_fwd_f32  out[b][c][n] = sum_k w_k feat[b][c][idx_k], w_k = (1/(d_k + 1e-8)) / sum (…) as the
+ *                                reference forms it; feat (B,C,M) and out (B,C,N) channel-major; the weights (B,N,K) are
+ *                                kept for the backward.  The (B,C,N,K) neighbour tensor is never built.
+ *   samble_interp_blend_bwd_f32  dfeat[b][c][j] = sum over the edges (n,k) -> j of w g[b][c][n], in the order of the inverse
+ *                                lists that samble_inverse_neighbors builds from idx (targets b N + j, M <= N):
+ *                                deterministic, no atomics; works on point-major copies of g and dfeat in the workspace
+ *                                (samble_interp_blend_bwd_workspace_bytes).  1 <= K <= 8. */
+int samble_interp_blend_fwd_f32(const float* feat, int B, int C, int M, const int32_t* idx, const float* dist, int N, int K,
+                                float* weights, float* out, void* stream);
+size_t samble_interp_blend_bwd_workspace_bytes(int B, int C, int N, int M);
+int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, const float* weights, const int32_t* inv_order,
+                                const int32_t* inv_offsets, int K, int M, float* dfeat, void* ws, size_t ws_bytes,
+                                void* stream);
+
 /* ---- the closed forms around the fused EdgeConv's two MLP sweeps (csrc/edge_glue.hip) ------------------------------
  * EdgeConv (models/embedding.py:7-39) here = per-point projections a, b (B, N, 64) of conv1, samble_edge_mlp_fwd_f32 /
  * samble_edge_mlp_bwd_f32 over the B N K edges (above), and between them the two BatchNorm2d layers in TRAINING mode,

@@ -77,6 +77,11 @@ _SIGNATURES = {
     "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_interp_blend_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                            c_void_p]),
+    "samble_interp_blend_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "samble_interp_blend_bwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
     "samble_linear_image_bytes": (c_size_t, [c_int]),
     "samble_linear_weight_images_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

@@ -111,6 +111,9 @@ int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float
 int samble_launch_edge_bwd_post(const float*, const float*, const float*, const float*, const float*, const float*, const int*,
                                 int, int, float*, const double*, const float*, int, float*, float*, float*, float*, float*,
                                 double*, hipStream_t);
+int samble_launch_interp_fwd(const float*, int, int, int, const int*, const float*, int, int, float*, float*, hipStream_t);
+int samble_launch_interp_bwd(const float*, int, int, int, const float*, const int*, const int*, int, int, float*, void*, hipStream_t);
+size_t samble_interp_bwd_ws_bytes(int, int, int, int);
 size_t samble_linear_image_bytes_impl(int O);
 int samble_launch_linear_images(const float*, int, void*, void*, hipStream_t);
 int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
@@ -919,6 +922,29 @@ SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, const fl
   return done(samble_launch_edge_bwd_post(a, b, S, R, dusum, D, indeg, B, N, constants, statistics, dw2_partials, n_partials,
                                           da, db, dgamma1, dbeta1, dW2, partials, (hipStream_t)stream),
               "samble_edge_bwd_post_f32");
+}
+
+/* ---- inverse-distance interpolation (csrc/interp.hip) --------------------------------------------------------------- */
+SAMBLE_API int samble_interp_blend_fwd_f32(const float* feat, int B, int C, int M, const int32_t* idx, const float* dist,
+                                           int N, int K, float* weights, float* out, void* stream) {
+  if (!feat || !idx || !dist || !weights || !out) return fail(SAMBLE_E_INVALID, "samble_interp_blend_fwd_f32: null pointer");
+  if (B <= 0 || C <= 0 || M <= 0 || N <= 0 || K < 1 || K > 8) return fail(SAMBLE_E_INVALID, "samble_interp_blend_fwd_f32: need 1 <= K <= 8");
+  return done(samble_launch_interp_fwd(feat, B, C, M, idx, dist, N, K, weights, out, (hipStream_t)stream), "samble_interp_blend_fwd_f32");
+}
+
+SAMBLE_API size_t samble_interp_blend_bwd_workspace_bytes(int B, int C, int N, int M) {
+  return (B > 0 && C > 0 && N > 0 && M > 0) ? samble_interp_bwd_ws_bytes(B, C, N, M) : 0;
+}
+
+SAMBLE_API int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, const float* weights, const int32_t* inv_order,
+                                           const int32_t* inv_offsets, int K, int M, float* dfeat, void* ws, size_t ws_bytes,
+                                           void* stream) {
+  if (!g || !weights || !inv_order || !inv_offsets || !dfeat || !ws) return fail(SAMBLE_E_INVALID, "samble_interp_blend_bwd_f32: null pointer");
+  if (B <= 0 || C <= 0 || M <= 0 || N <= 0 || M > N || K < 1 || K > 8)
+    return fail(SAMBLE_E_INVALID, "samble_interp_blend_bwd_f32: need 1 <= K <= 8 and M <= N");
+  if (ws_bytes < samble_interp_bwd_ws_bytes(B, C, N, M)) return fail(SAMBLE_E_WORKSPACE, "samble_interp_blend_bwd_f32: workspace too small");
+  return done(samble_launch_interp_bwd(g, B, C, N, weights, inv_order, inv_offsets, K, M, dfeat, ws, (hipStream_t)stream),
+              "samble_interp_blend_bwd_f32");
 }
 
 /* ---- 1x1 convolutions over 128 input channels (csrc/linear.hip) ------------------------------------------------- */

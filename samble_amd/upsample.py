@@ -38,6 +38,47 @@ def _normalised_pair_distances(query: torch.Tensor, keys: torch.Tensor, idx: tor
     return torch.linalg.vector_norm(q.unsqueeze(2) - ops.index_points(k, idx), dim=-1)
 
 
+class _InterpBlend(torch.autograd.Function):
+    """feat (B,C,M) coarse features, idx (B,N,K) int32 nearest coarse points, dist (B,N,K) -> (B,C,N): the reference's
+    inverse-distance blend (models/upsample.py:205-213) on two HIP gather kernels (csrc/interp.hip); the distances carry
+    no gradient (xyz search)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, feat, idx, dist):
+        feat, dist = feat.contiguous(), dist.contiguous()
+        idx = idx.to(torch.int32).contiguous()
+        B, C, M = feat.shape
+        N, K = idx.shape[1], idx.shape[2]
+        with torch.cuda.device(feat.device):
+            out = torch.empty((B, C, N), dtype=torch.float32, device=feat.device)
+            w = torch.empty((B, N, K), dtype=torch.float32, device=feat.device)
+            ops._lib.call("samble_interp_blend_fwd_f32", feat.data_ptr(), B, C, M, idx.data_ptr(), dist.data_ptr(), N, K,
+                          w.data_ptr(), out.data_ptr(), ops._stream())
+        ctx.save_for_backward(idx, w)
+        ctx.M = M
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        idx, w = ctx.saved_tensors
+        g = g.float().contiguous()
+        B, C, N = g.shape
+        K, M = idx.shape[2], ctx.M
+        order, offsets, _ = ops.inverse_neighbors(idx)      # edges grouped by coarse point, ascending edge id
+        with torch.cuda.device(g.device):
+            dfeat = torch.empty((B, C, M), dtype=torch.float32, device=g.device)
+            nbytes = ops._lib.query("samble_interp_blend_bwd_workspace_bytes", B, C, N, M)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            ops._lib.call("samble_interp_blend_bwd_f32", g.data_ptr(), B, C, N, w.data_ptr(), order.data_ptr(),
+                          offsets.data_ptr(), K, M, dfeat.data_ptr(), ws.data_ptr(), nbytes, ops._stream())
+        return dfeat, None, None
+
+
+FUSED_BLEND = True  # False: the (B,C,N,K) neighbour tensor and torch expressions (A/B runs)
+
+
 class UpSampleInterpolation(nn.Module):
     def __init__(self, config_upsample, layer):
         super().__init__()
@@ -59,6 +100,9 @@ class UpSampleInterpolation(nn.Module):
             raise ValueError(f"upsample interpolation distance type can only be feature or xyz! Got: {distance_type}")
         projected = self.conv(points_select)
         if distance_type == "xyz":
+            if FUSED_BLEND and projected.is_cuda and K <= 8 and points_select_xyz.shape[2] <= pcd_up_xyz.shape[2]:
+                idx, dist = ops.stage_knn(pcd_up_xyz, points_select_xyz, K, want_dist=True)
+                return _InterpBlend.apply(projected, idx, dist)
             picked, _, dist = ops.select_neighbors_interpolate(pcd_up_xyz, points_select_xyz, projected, K=K)
             return inverse_distance_blend(picked, dist)
         # feature space: the reference back-propagates through its cdist; here the SEARCH runs on the HIP kNN

@@ -675,3 +675,29 @@ def test_point2point_attention_head_counts_train(heads, asm):
     assert float((y.detach().double() - yd.detach()).abs().max()) <= 2e-4 * float(yd.detach().abs().max()) + 1e-6
     err = float((x.grad.double() - xd.grad).abs().max())
     assert err <= 1e-3 * float(xd.grad.abs().max()) + 1e-6, err
+
+
+def test_interpolation_blend_kernels_equal_the_torch_expression():
+    """csrc/interp.hip (the inverse-distance blend of models/upsample.py:205-213 without the (B,C,N,K) neighbour tensor)
+    against the torch expression on the gathered tensor: output and the gradient of the coarse features, float64 as the
+    judge; run-to-run identical."""
+    from samble_amd import ops
+    from samble_amd.upsample import _InterpBlend, inverse_distance_blend
+    B, C, N, M, K = 3, 128, 700, 300, 3
+    feat = torch.from_numpy(synth.normal((B, C, M), 9301)).to(DEV).requires_grad_(True)
+    up = torch.from_numpy(synth.xyz_clouds(B, N, 9302)).to(DEV)
+    down = up[:, :, torch.randperm(N, generator=torch.Generator().manual_seed(5))[:M].to(DEV)].contiguous()
+    idx, dist = ops.stage_knn(up, down, K, want_dist=True)
+    g = torch.from_numpy(synth.normal((B, C, N), 9303)).to(DEV)
+    out = _InterpBlend.apply(feat, idx, dist)
+    out.backward(g)
+    fd = feat.detach().double().requires_grad_(True)
+    picked = ops.index_points(fd.permute(0, 2, 1), idx.long()).permute(0, 3, 1, 2)
+    ref = inverse_distance_blend(picked, dist.double())
+    ref.backward(g.double())
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((feat.grad.double() - fd.grad).abs().max()) <= 1e-5 * float(fd.grad.abs().max())
+    feat2 = feat.detach().clone().requires_grad_(True)
+    out2 = _InterpBlend.apply(feat2, idx, dist)
+    out2.backward(g)
+    assert torch.equal(out2, out) and torch.equal(feat2.grad, feat.grad)
