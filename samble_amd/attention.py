@@ -127,8 +127,9 @@ class Neighbor2PointAttention(nn.Module):
             raise ValueError(
                 f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {self.group_type}")
         grouped = 2 * q_in if self.group_type.startswith("center_") else q_in   # channels of the grouped tensor
-        if not (q_in == q_out == k_out == v_out == 128 and k_in == v_in == grouped and self.num_heads == 4):
-            raise NotImplementedError("the HIP N2P kernels are built for 128 channels, 4 heads (shipped cls/seg configs)")
+        if not (q_in == q_out == k_out == v_out == 128 and k_in == v_in == grouped and self.num_heads in (1, 2, 4)):
+            raise NotImplementedError("the HIP N2P kernels are built for 128 channels and 4, 2 or 1 head(s) "
+                                      "(shipped cls/seg configs: 4)")
 
     def forward(self, x):
         if not x.is_cuda:

@@ -1127,8 +1127,8 @@ SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t 
 SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN,
                                        int C, int heads, int diff, float* out, float* att, void* stream) {
   if (!qkv || !nn || !out) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: null pointer");
-  if (C != 128 || (heads != 4 && heads != 1))
-    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128 with 4 heads of 32 or 1 head of 128");
+  if (C != 128 || (heads != 4 && heads != 2 && heads != 1))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128 with 4, 2 or 1 head(s)");
   if (att && (heads != 1 || KN > 64))
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: the probability output needs heads == 1 and K <= 64");
   if ((rs & 3) || (bs & 3) || rs < 3 * C) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad strides");
@@ -1165,8 +1165,8 @@ SAMBLE_API int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs,
   if ((inv_order == nullptr) != (inv_offsets == nullptr))
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: inverse lists need both arrays");
   if (!qkv || !nn || !g || !dqkv || !ws) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: null pointer");
-  if (C != 128 || (heads != 4 && heads != 1))
-    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128 with 4 heads of 32 or 1 head of 128");
+  if (C != 128 || (heads != 4 && heads != 2 && heads != 1))
+    return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: built for C = 128 with 4, 2 or 1 head(s)");
   if (KN < 1 || KN > 32) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: need 1 <= K <= 32");
   if ((rs & 3) || (bs & 3) || (drs & 3) || (dbs & 3) || rs < 3 * C || drs < 3 * C)
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_bwd_f32: bad strides");

@@ -12,16 +12,14 @@
 
 namespace samble {
 
-// sum over the lanes of one head: hl = lanes per head = 32 / heads (8 for the 4 heads of N2P, 32 for
+// sum over the lanes of one head: hl = lanes per head = 32 / heads (8 for the 4 heads of N2P, 16 for two heads, 32 for
 // the single head of DownSampleLocal); wave-uniform
 __device__ __forceinline__ float head_sum(float v, int hl) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 4, 64);
-  if (hl > 8) {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-  }
+  if (hl > 8) v += __shfl_xor(v, 8, 64);    // 2 heads: 16 lanes each
+  if (hl > 16) v += __shfl_xor(v, 16, 64);  // 1 head: all 32 lanes of the half-wave
   return v;
 }
 
@@ -106,7 +104,7 @@ using namespace samble;
 
 extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const int* nn, int B, int N, int KN, int diff,
                                      float scale, float* out, int heads, float* att, hipStream_t s) {
-  if ((heads != 1 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
+  if ((heads != 1 && heads != 2 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
   Timed timed(kT_n2p_fwd, s);
   hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
                      out, heads, att);
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void n2p_bwd_scatter_kernel(const float* __
   int blk, b;
   xcd_assign(blk, b);
   const int tid = threadIdx.x;
-  const int c = tid & 127, which = tid >> 7, head = (heads == 4) ? c >> 5 : 0;
+  const int c = tid & 127, which = tid >> 7, head = c / (128 / heads);
   const int j0 = blk * kScatRows;
   for (int e = tid; e < 2 * kScatRows * 128; e += 256) acc[e] = 0.f;
   const float* coef = which ? A : DL;
@@ -377,7 +375,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float* __rest
                                                              const int* __restrict__ offs, int N, int KN, long ntargets,
                                                              float* __restrict__ dqkv, long dbs, long drs, int heads) {
   const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;  // lane = channels 4c .. 4c+3
-  const int head = (heads == 4) ? (c >> 3) : 0;
+  const int head = c / (32 / heads);
   for (long t = (long)blockIdx.x * 8 + hw; t < ntargets; t += (long)gridDim.x * 8) {
     const long cloud = t / N;
     const int j = (int)(t - cloud * N);
@@ -579,7 +577,7 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
                                      int KN, int diff, float scale, float* dqkv, long dbs, long drs, float* ws,
                                      int heads, const int* order, const int* offs, hipStream_t s) {
   using namespace samble;
-  if (heads != 1 && heads != 4) return -22;
+  if (heads != 1 && heads != 2 && heads != 4) return -22;
   float* gt = ws;
   float* A = gt + (size_t)B * N * 128;
   float* DL = A + (size_t)B * N * KN * 4;

@@ -19,10 +19,11 @@ def _w(shape, seed, scale):
     return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
 
 
-def _n2p_module(seed, group_type):
+def _n2p_module(seed, group_type, heads=4):
     from samble_amd.attention import Neighbor2PointAttention, attention_config
     cfg = attention_config("cls")
     cfg.group_type[0] = group_type
+    cfg.num_heads[0] = heads
     mod = Neighbor2PointAttention(cfg, 0)
     C = 128
     with torch.no_grad():
@@ -36,12 +37,13 @@ def _n2p_module(seed, group_type):
     return mod.to(DEV).train()
 
 
-@pytest.mark.parametrize("name,group_type", [("layer_n2p_diff", "diff"), ("layer_n2p_neighbor", "neighbor")])
+@pytest.mark.parametrize("name,group_type", [("layer_n2p_diff", "diff"), ("layer_n2p_neighbor", "neighbor"),
+                                             ("layer_n2p_heads2", "diff"), ("layer_n2p_heads1", "neighbor")])
 def test_n2p_against_reference_fixture(name, group_type):
     from samble_amd import ops
     d = layer_fixture(name)
     B, C, N, K, H, seed = [int(v) for v in d["meta"]]
-    mod = _n2p_module(seed, group_type)
+    mod = _n2p_module(seed, group_type, H)
     assert sorted(mod.state_dict()) == sorted(
         ["q_conv.weight", "k_conv.weight", "v_conv.weight", "ff.0.weight", "ff.2.weight", "bn1.weight", "bn1.bias",
          "bn1.running_mean", "bn1.running_var", "bn1.num_batches_tracked", "bn2.weight", "bn2.bias",
@@ -105,12 +107,13 @@ def test_n2p_variants_against_reference_fixture(name):
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
 
 
-def test_n2p_backward_kernels_match_autograd_of_the_restatement():
+@pytest.mark.parametrize("H", [4, 2, 1])
+def test_n2p_backward_kernels_match_autograd_of_the_restatement(H):
     """HIP backward of the gather-attention vs torch autograd of the same expression, incl. an
     index-local neighbour pattern (every neighbour inside one 64-row block) that fills the hit list."""
     from samble_amd import ops
     from samble_amd.attention import _attention_from_projection
-    B, C, N, K, H = 3, 128, 1000, 32, 4
+    B, C, N, K = 3, 128, 1000, 32
     qkv = torch.from_numpy(synth.normal((B, N, 3 * C), 31) * 0.5).to(DEV)
     g = torch.from_numpy(synth.normal((B, C, N), 32)).to(DEV)
     rnd = torch.stack([torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b * N + i))[:K]
@@ -130,11 +133,12 @@ def test_n2p_backward_kernels_match_autograd_of_the_restatement():
             assert torch.equal(got, ops.stage_n2p_attn_bwd(qkv, nn_idx, g, H, diff, use_inverse_lists=False))
 
 
-def test_n2p_metric_size_runs_and_matches_torch_restatement():
+@pytest.mark.parametrize("H", [4, 2, 1])
+def test_n2p_metric_size_runs_and_matches_torch_restatement(H):
     """B=8, N=2048: the HIP gather-attention against the differentiable torch restatement on the GPU."""
     from samble_amd import ops
     from samble_amd.attention import _attention_from_projection
-    B, C, N, K, H = 8, 128, 2048, 32, 4
+    B, C, N, K = 8, 128, 2048, 32
     x = torch.from_numpy(synth.features(B, C, N, 5)).to(DEV)
     w = _w((3 * C, C), 6, 0.09).to(DEV)
     qkv = ops.stage_proj_fwd(x, x.new_zeros((C, 0)), w)
