@@ -25,6 +25,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// the same with the non-temporal hint (aux bit 1): bytes that are read once (the M-row maps)
+__device__ __forceinline__ void glds16_nt(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 2);
+}
 __device__ __forceinline__ void glds4(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 4, 0, 0);
@@ -340,7 +345,10 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
   auto stage_p = [&](int t) {  // 4 pieces per thread
     const int tt = min(t, ntiles - 1);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) glds16(prow8[k] + tt * kTile, pslots + (t & 1) * 16384 + k * 1024);
+    for (int k = 0; k < 4; ++k) {
+      if (SAMBLE_MAP_NT & 2) glds16_nt(prow8[k] + tt * kTile, pslots + (t & 1) * 16384 + k * 1024);
+      else glds16(prow8[k] + tt * kTile, pslots + (t & 1) * 16384 + k * 1024);
+    }
   };
   stage_tile(Vb, vring, 0);
   stage_tile(Vb, vring, 1);
@@ -441,7 +449,8 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
 #pragma unroll
         for (int k8 = 2 * (i - 6); k8 < 2 * (i - 6) + 2; ++k8) {
           const int mr = min(m0 + (lane >> 3) + 8 * k8, M - 1);  // rows past M-1 rewrite row M-1's values (same bytes)
-          *reinterpret_cast<f32x4*>(dsout + (long)mr * a.ld) = po[k8];
+          if (SAMBLE_MAP_NT & 4) __builtin_nontemporal_store(po[k8], reinterpret_cast<f32x4*>(dsout + (long)mr * a.ld));
+          else *reinterpret_cast<f32x4*>(dsout + (long)mr * a.ld) = po[k8];
         }
       }
 #pragma unroll
@@ -899,7 +908,8 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
   auto map_piece = [&](int t, int q) {
     const int tt = min(t, mtiles - 1);
     char* ms = mapring + (t % kAccPmMapSlots) * kAccMap + wave * 4096;
-    glds16(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
+    if (SAMBLE_MAP_NT & 8) glds16_nt(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
+    else glds16(mapb + (long)min(tt * 32 + 8 * q + prow, M - 1) * ld, ms + q * 1024);
   };
   float csum = 0.f;
   // the wave's block of tile t: [32 rows][32 keys]; this lane's 16 values in accumulator order (row crow(r, h), key lo)
@@ -1090,7 +1100,7 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
     const KaccArgs av{smap, ld, lse_s, (const char*)dO_tr, idx, N, N + nt, M, dV, dv_bs, dv_rs, nullptr, duo, nullptr};
     const KaccArgs ak{dsmap, ld, nullptr, (const char*)Q_tr, idx, N, N + nt, M, dK, dk_bs, dk_rs, cs, duo, duo ? ds_amax : nullptr};
     const dim3 grid((N + 255) / 256, B);
-    {
+    auto launch_dv = [&] {
       Timed timed(kT_bwd_dv, stream);
       if (pmap) {  // P is there already: the M-row-map kernel on (P map, dO^T)
         if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, true>), grid, dim3(512), kAccPmLds, stream, av);
@@ -1098,14 +1108,24 @@ extern "C" int samble_launch_bwd_tri(const float* smap, int ld, const float* lse
       } else {
         hipLaunchKernelGGL((bwd_kacc_tri_kernel<0, false>), grid, dim3(512), kAccLds, stream, av);
       }
-    }
-    Timed timed(kT_bwd_dk, stream);
-    if (cs) {
-      if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, true>), grid, dim3(512), kAccPmLds, stream, ak);
-      else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, false>), grid, dim3(512), kAccPmLds, stream, ak);
+    };
+    auto launch_dk = [&] {
+      Timed timed(kT_bwd_dk, stream);
+      if (cs) {
+        if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, true>), grid, dim3(512), kAccPmLds, stream, ak);
+        else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<true, false>), grid, dim3(512), kAccPmLds, stream, ak);
+      } else {
+        if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, true>), grid, dim3(512), kAccPmLds, stream, ak);
+        else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, false>), grid, dim3(512), kAccPmLds, stream, ak);
+      }
+    };
+    // dK first: the dS map is what the dQ kernel wrote last
+    if (SAMBLE_KACC_DK_FIRST) {
+      launch_dk();
+      launch_dv();
     } else {
-      if (duo) hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, true>), grid, dim3(512), kAccPmLds, stream, ak);
-      else hipLaunchKernelGGL((bwd_kacc_pm_tri_kernel<false, false>), grid, dim3(512), kAccPmLds, stream, ak);
+      launch_dv();
+      launch_dk();
     }
   } else {
     const KvTriArgs kv{smap, ld, lse_s, delta, (const char*)dO_rm, (const char*)dO_tr, (const char*)Q_tr, (const char*)V_rm,

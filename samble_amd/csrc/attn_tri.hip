@@ -900,7 +900,8 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
 #pragma unroll
           for (int k8 = 2 * (i - 6); k8 < 2 * (i - 6) + 2; ++k8) {
             const int mr = min(m0 + (lane >> 3) + 8 * k8, M - 1);  // rows past M-1 rewrite row M-1's values (same bytes)
-            *reinterpret_cast<f32x4*>(pout + (long)mr * ld) = po[k8];
+            if (SAMBLE_MAP_NT & 1) __builtin_nontemporal_store(po[k8], reinterpret_cast<f32x4*>(pout + (long)mr * ld));
+            else *reinterpret_cast<f32x4*>(pout + (long)mr * ld) = po[k8];
           }
         }
       }

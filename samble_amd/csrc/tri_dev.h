@@ -32,6 +32,17 @@
 
 #include "samble_dev.h"
 
+// Non-temporal hints on the M-row maps of the backward (P written by attn_rows_rc_tri, read by bwd_dq_pm_tri and the dV
+// kernel; dS written by bwd_dq_pm_tri, read by the dK kernel): bit 0 the P stores, 1 the dQ kernel's P loads, 2 its dS
+// stores, 3 the key-stationary kernels' map loads.  The value shipped is the one the same-box A/B picked.
+#ifndef SAMBLE_MAP_NT
+#define SAMBLE_MAP_NT 9
+#endif
+
+#ifndef SAMBLE_KACC_DK_FIRST
+#define SAMBLE_KACC_DK_FIRST 1
+#endif
+
 namespace samble {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
