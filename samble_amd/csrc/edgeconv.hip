@@ -14,7 +14,17 @@
 // Backward (edge_mlp_bwd) recomputes the edge tensors tile by tile and emits the gradient of the
 // pre-activation (a'_i + b'_j) per edge plus the dW2 partials; everything else is closed form on
 // per-point tensors (samble_amd/embedding.py).
-#include "samble_dev.h"
+#include "tri_dev.h"
+
+// 1: the two sweeps on v_mfma_f32_32x32x2_f32 (the round-2 kernels; scratch builds for A/B runs)
+// timing-only ablations of edge_mlp_bwd_tri (wrong results; tools/bench_edge_mlp.py): 1 no du stores, 2 no dW2 product,
+// 4 no dh product, 8 no dusum butterflies
+#ifndef SAMBLE_EDGE_ABL
+#define SAMBLE_EDGE_ABL 0
+#endif
+#ifndef SAMBLE_EDGE_F32
+#define SAMBLE_EDGE_F32 0
+#endif
 
 namespace samble {
 
@@ -299,6 +309,287 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same two sweeps on the bf16 matrix cores with split fp32 operands (tri_dev.h: three bf16 planes per operand, six
+// products per k-step: fp32-equivalent sums at 32 cycles per instruction where v_mfma_f32_32x32x2_f32 takes 64 for an
+// eighth of the depth).  W2 waits in LDS as operand images:
+//   image 1, fragment (ot, ks): lane (o = lo, half h) holds W2[32 ot + lo][32 h + 8 ks + e], e = 0..7 -- the channels a
+//            lane of the edge tile holds in hv[8 ks + e] (the contraction order is free as long as both operands
+//            agree, so the hidden vector never moves between lanes);
+//   image 2, fragment (ct, 2 ot + gp): lane (c = lo, half h) holds W2[o(i)][32 ct + lo], o(i) = 32 ot + 16 gp +
+//            8 (i >> 2) + 4 h + (i & 3): the output channels that registers 8 gp .. 8 gp + 7 of an accumulator tile
+//            stand for (accumulator-as-operand: dy^T goes into the next product without leaving its lanes).
+// The backward forms y in BOTH orientations (the operands swapped: 48 more instructions on a pipe that is not the
+// bound): y^T[o][edge] feeds dh^T = W2^T dy^T as before, y[edge][o] puts the edges of dy on the register axis -- the
+// A operand of dW2 += dy^T h as it stands.  Only the h tile still crosses LDS (column reads for dW2's B operand).
+// ------------------------------------------------------------------------------------------------
+constexpr int kEImg = 8 * 3 * 1024;  // bytes of one W2 image: 8 fragments x 3 planes x 64 lanes x 16 B
+
+__device__ __forceinline__ Tri edge_frag(const char* img, int frag, int lane) {
+  const u32x4* pp = reinterpret_cast<const u32x4*>(img + frag * 3072) + lane;
+  return Tri{pp[0], pp[64], pp[128]};
+}
+
+// 512 threads: thread = (fragment, lane) of each image
+__device__ __forceinline__ void edge_build_images(const float* __restrict__ W2, char* img1, char* img2, int tid, bool want2) {
+  const int frag = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  {
+    const int ot = frag >> 2, ks = frag & 3;
+    const float* src = W2 + (32 * ot + lo) * kEC + 32 * h + 8 * ks;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    const Tri t = tri_split8(v);
+    u32x4* d = reinterpret_cast<u32x4*>(img1 + frag * 3072) + lane;
+    d[0] = t.h;
+    d[64] = t.m;
+    d[128] = t.l;
+  }
+  if (want2) {
+    const int ct = frag >> 2, ot = (frag >> 1) & 1, gp = frag & 1;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = W2[(32 * ot + 16 * gp + 8 * (i >> 2) + 4 * h + (i & 3)) * kEC + 32 * ct + lo];
+    const Tri t = tri_split8(v);
+    u32x4* d = reinterpret_cast<u32x4*>(img2 + frag * 3072) + lane;
+    d[0] = t.h;
+    d[64] = t.m;
+    d[128] = t.l;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
+                                                                  const int* __restrict__ nn,
+                                                                  const float* __restrict__ W2, int N, long npoints,
+                                                                  float* __restrict__ ymax, float* __restrict__ ymin,
+                                                                  unsigned char* __restrict__ kmax,
+                                                                  unsigned char* __restrict__ kmin,
+                                                                  double* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) char img1[kEImg];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  const long gw = (long)blockIdx.x * 8 + wave, nw = (long)gridDim.x * 8;
+  edge_build_images(W2, img1, nullptr, tid, false);
+  __syncthreads();
+  double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+  for (long p = gw; p < npoints; p += nw) {
+    const long cloud = p / N;
+    const int j = nn[p * kEK + lo];
+    const f32x4* av = reinterpret_cast<const f32x4*>(ap + p * kEC + 32 * h);
+    const f32x4* bv = reinterpret_cast<const f32x4*>(bp + (cloud * N + j) * kEC + 32 * h);
+    // D[row = edge][col = out channel] = sum_c h[edge][c] W2[o][c]
+    f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a0 = av[2 * ks], a1 = av[2 * ks + 1], b0 = bv[2 * ks], b1 = bv[2 * ks + 1];
+      const float v[8] = {lrelu(a0[0] + b0[0]), lrelu(a0[1] + b0[1]), lrelu(a0[2] + b0[2]), lrelu(a0[3] + b0[3]),
+                          lrelu(a1[0] + b1[0]), lrelu(a1[1] + b1[1]), lrelu(a1[2] + b1[2]), lrelu(a1[3] + b1[3])};
+      const Tri ht = tri_split8(v);
+      acc[0] = mfma_tri(ht, edge_frag(img1, ks, lane), acc[0]);
+      acc[1] = mfma_tri(ht, edge_frag(img1, 4 + ks, lane), acc[1]);
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      float mx = acc[ot][0], mn = acc[ot][0], s = 0.f, q = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        mx = fmaxf(mx, acc[ot][r]);
+        mn = fminf(mn, acc[ot][r]);
+        s += acc[ot][r];
+        q = fmaf(acc[ot][r], acc[ot][r], q);
+      }
+      mx = fmaxf(mx, wave_xor32(mx));
+      mn = fminf(mn, wave_xor32(mn));
+      s += wave_xor32(s);
+      q += wave_xor32(q);
+      // the edge that attains the extremum (first one on ties): the backward routes the gradient by index
+      int kx = 99, kn = 99;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        kx = min(kx, acc[ot][r] == mx ? crow(r, h) : 99);
+        kn = min(kn, acc[ot][r] == mn ? crow(r, h) : 99);
+      }
+      kx = min(kx, __shfl_xor(kx, 32, 64));
+      kn = min(kn, __shfl_xor(kn, 32, 64));
+      if (h == 0) {
+        ymax[p * kEC + 32 * ot + lo] = mx;
+        ymin[p * kEC + 32 * ot + lo] = mn;
+        kmax[p * kEC + 32 * ot + lo] = (unsigned char)kx;
+        kmin[p * kEC + 32 * ot + lo] = (unsigned char)kn;
+      }
+      s1[ot] += (double)s;
+      s2[ot] += (double)q;
+    }
+  }
+  if (h == 0 && gw < nw) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      part[(gw * 2 + 0) * kEC + 32 * ot + lo] = s1[ot];
+      part[(gw * 2 + 1) * kEC + 32 * ot + lo] = s2[ot];
+    }
+  }
+}
+
+constexpr int kETriBwdLds = 2 * kEImg + 2 * kEC * 4 + 8 * kEK * kEwPad * 4;  // 119 KB: one workgroup of 8 waves per CU
+
+__global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
+                                                               const int* __restrict__ nn,
+                                                               const float* __restrict__ W2,
+                                                               const unsigned char* __restrict__ kext,
+                                                               const float* __restrict__ sdv,
+                                                               const float* __restrict__ c0c1, int N, long npoints,
+                                                               float* __restrict__ du, float* __restrict__ dusum,
+                                                               float* __restrict__ dw2part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  char* img1 = smem_c;
+  char* img2 = smem_c + kEImg;
+  float* cst = reinterpret_cast<float*>(smem_c + 2 * kEImg);  // c0[64], c1[64]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  float* hts = cst + 2 * kEC + wave * (kEK * kEwPad);  // this wave's [32 edges][68] h tile
+  edge_build_images(W2, img1, img2, tid, true);
+  if (tid < 2 * kEC) cst[tid] = c0c1[tid];
+  __syncthreads();
+  const long gw = (long)blockIdx.x * 8 + wave, nw = (long)gridDim.x * 8;  // 8 waves: two per SIMD
+  f32x16 dw[2][2];  // dW2 tile [ot][ct]: rows = o, cols = c
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) dw[a][c] = zero16();
+
+  for (long p = gw; p < npoints; p += nw) {
+    const long cloud = p / N;
+    const int j = nn[p * kEK + lo];
+    const float* arow = ap + p * kEC;
+    const float* brow = bp + (cloud * N + j) * kEC;
+    // y in both orientations: yt1 = D[row = o][col = edge], yt2 = D[row = edge][col = o]
+    f32x16 yt1[2] = {zero16(), zero16()}, yt2[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + 32 * h + 8 * ks), a1 = *reinterpret_cast<const f32x4*>(arow + 32 * h + 8 * ks + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * h + 8 * ks), b1 = *reinterpret_cast<const f32x4*>(brow + 32 * h + 8 * ks + 4);
+      const f32x4 h0 = {lrelu(a0[0] + b0[0]), lrelu(a0[1] + b0[1]), lrelu(a0[2] + b0[2]), lrelu(a0[3] + b0[3])};
+      const f32x4 h1 = {lrelu(a1[0] + b1[0]), lrelu(a1[1] + b1[1]), lrelu(a1[2] + b1[2]), lrelu(a1[3] + b1[3])};
+      *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks) = h0;
+      *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks + 4) = h1;
+      const float v[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const Tri ht = tri_split8(v);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const Tri w = edge_frag(img1, 4 * ot + ks, lane);
+        yt1[ot] = mfma_tri(w, ht, yt1[ot]);
+        yt2[ot] = mfma_tri(ht, w, yt2[ot]);
+      }
+    }
+    // dy = c0 + c1 y + [edge == kext] sdv, in place, in both layouts
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // yt1: register r <-> channel o = 32 ot + crow(r, h), lane <-> edge
+        const uchar4 k4 = *reinterpret_cast<const uchar4*>(kext + p * kEC + 32 * ot + 8 * g + 4 * h);
+        const int kk4[4] = {k4.x, k4.y, k4.z, k4.w};
+        const f32x4 sdv4 = *reinterpret_cast<const f32x4*>(sdv + p * kEC + 32 * ot + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int o = 32 * ot + 8 * g + 4 * h + e;
+          yt1[ot][r] = fmaf(cst[kEC + o], yt1[ot][r], cst[o]) + (lo == kk4[e] ? sdv4[e] : 0.f);
+        }
+      }
+      {  // yt2: register r <-> edge crow(r, h), lane <-> channel o = 32 ot + lo
+        const int o = 32 * ot + lo;
+        const int ke = kext[p * kEC + o];
+        const float sv = sdv[p * kEC + o], c0 = cst[o], c1 = cst[kEC + o];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yt2[ot][r] = fmaf(c1, yt2[ot][r], c0) + (crow(r, h) == ke ? sv : 0.f);
+      }
+    }
+    // dh^T tile ct: D[row = c][col = edge] = sum_o W2[o][c] dy[edge][o]; k-step (ot, gp) = registers 8 gp .. + 7 of yt1[ot]
+    f32x16 dht[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = yt1[ot][8 * gp + i];
+        const Tri bq = tri_split8(v);
+        if (SAMBLE_EDGE_ABL & 4) {
+          dht[0][gp] += __uint_as_float(bq.h[0] ^ bq.m[1] ^ bq.l[2]);
+          continue;
+        }
+        dht[0] = mfma_tri(edge_frag(img2, 2 * ot + gp, lane), bq, dht[0]);
+        dht[1] = mfma_tri(edge_frag(img2, 4 + 2 * ot + gp, lane), bq, dht[1]);
+      }
+    }
+    // dW2[o][c] += sum_edge dy[edge][o] h[edge][c]: A = registers 8 kp .. + 7 of yt2[ot] (edges 16 kp + 8 (i >> 2) + 4 h +
+    // (i & 3)), B = the same edges of the h tile's column c (same-wave LDS traffic needs no barrier)
+#pragma unroll
+    for (int kp = 0; kp < ((SAMBLE_EDGE_ABL & 2) ? 0 : 2); ++kp) {
+      Tri bq[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = hts[(16 * kp + 8 * (i >> 2) + 4 * h + (i & 3)) * kEwPad + 32 * ct + lo];
+        bq[ct] = tri_split8(v);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = yt2[ot][8 * kp + i];
+        const Tri a = tri_split8(v);
+        dw[ot][0] = mfma_tri(a, bq[0], dw[ot][0]);
+        dw[ot][1] = mfma_tri(a, bq[1], dw[ot][1]);
+      }
+    }
+    // du = dh * LReLU'(u), u = a' + b' at channel c = 32 ct + crow(r, h); written per edge.  The point's sum over its 32
+    // edges (dusum): the tile goes through the wave's LDS tile (the h tile has been read by now) and lane = channel adds
+    // its column in edge order -- 72 instructions where the DPP butterflies over the lanes took 400
+    float* durow0 = du + p * (kEK * kEC);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // LReLU'(u) from the sign of h = LReLU(u), this edge's row of the h tile (then overwritten by du: same lane, same
+        // address, LDS operations of a wave execute in order)
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * ct + 8 * g + 4 * h);
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = dht[ct][4 * g + e] * (h4[e] > 0.f ? 1.f : 0.2f);
+        *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * ct + 8 * g + 4 * h) = o4;
+      }
+    }
+    // the point's 32 x 64 block of du is 8 KB of consecutive addresses: out of the tile as whole lines, 1 KB per
+    // instruction (16-byte pieces straight from the accumulator lanes would touch 32 lines per instruction, a quarter
+    // of each)
+    if (!(SAMBLE_EDGE_ABL & 1)) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(hts + (4 * it + (lane >> 4)) * kEwPad + 4 * (lane & 15));
+        *reinterpret_cast<f32x4*>(durow0 + 256 * it + 4 * lane) = v;
+      }
+    }
+    if (dusum && !(SAMBLE_EDGE_ABL & 8)) {  // (uniform)
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < kEK; ++e) rs += hts[e * kEwPad + lane];
+      dusum[p * kEC + lane] = rs;
+    }
+  }
+  // per-wave dW2 partial (64 x 64): tile [ot][ct] register r, lane (c = lo, h) <-> o = 32 ot + crow(r,h)
+  if (gw < nw) {
+    float* outp = dw2part + gw * kEC * kEC;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outp[(32 * ot + crow(r, h)) * kEC + 32 * ct + lo] = dw[ot][ct][r];
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -318,8 +609,12 @@ extern "C" int samble_launch_edge_mlp_fwd(const float* ap, const float* bp, cons
                                           double* part, hipStream_t s) {
   const long np = (long)B * N;
   Timed timed(kT_edge_fwd, s);
-  hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), 0, s, ap, bp, nn, W2, N, np, ymax, ymin,
-                     kmax, kmin, part);
+  if (SAMBLE_EDGE_F32)
+    hipLaunchKernelGGL(edge_mlp_fwd_kernel, dim3(samble_edge_waves() / 4), dim3(256), 0, s, ap, bp, nn, W2, N, np, ymax, ymin,
+                       kmax, kmin, part);
+  else
+    hipLaunchKernelGGL(edge_mlp_fwd_tri_kernel, dim3(samble_edge_waves() / 8), dim3(512), 0, s, ap, bp, nn, W2, N, np, ymax,
+                       ymin, kmax, kmin, part);
   return (int)hipGetLastError();
 }
 
@@ -332,9 +627,16 @@ extern "C" int samble_launch_edge_mlp_bwd(const float* ap, const float* bp, cons
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_mlp_bwd_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_mlp_bwd_tri_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kETriBwdLds);
+    if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_edge_bwd, s);
-  hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
-                     N, np, du, dusum, dw2part);
+  if (SAMBLE_EDGE_F32)
+    hipLaunchKernelGGL(edge_mlp_bwd_kernel, dim3(samble_edge_waves() / 8), dim3(512), lds, s, ap, bp, nn, W2, yext, sdv, c0c1,
+                       N, np, du, dusum, dw2part);
+  else
+    hipLaunchKernelGGL(edge_mlp_bwd_tri_kernel, dim3(samble_edge_waves() / 8), dim3(512), kETriBwdLds, s, ap, bp, nn, W2, yext,
+                       sdv, c0c1, N, np, du, dusum, dw2part);
   return (int)hipGetLastError();
 }

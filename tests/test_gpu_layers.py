@@ -166,10 +166,28 @@ def test_edgeconv_against_reference_fixture(name):
     y = mod(x)
     torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
     y.backward(torch.from_numpy(synth.normal(tuple(y.shape), seed + 20)).to(DEV))
+    # Where two edges of a point tie for a channel's maximum within fp32 rounding, which of them receives the pooled
+    # gradient is a coin toss between any two fp32 evaluations (layer_edgeconv_xyz has one such pair, 4e-7 apart): the
+    # fp64 stock composition names those (point, edge) pairs and their three points are left out of the dx comparison
+    md = EdgeConv(embedding_config("cls"), layer).to(DEV).double().train()
+    md.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in mod.state_dict().items()})
+    from samble_amd import ops
+    with torch.no_grad():
+        nb, nn_idx = ops.group(x.detach().double(), K, md.group_type)
+        pre = md.conv2(md.conv1(nb))                                     # (B, c2, N, K)
+        top = pre.topk(2, dim=-1)
+        tie = (top.values[..., 0] - top.values[..., 1]) < 1e-6 * top.values[..., 0].abs().clamp_min(1.0)
+    skip = torch.zeros((B, N), dtype=torch.bool, device=DEV)
+    for b, c, i in tie.nonzero().tolist():
+        skip[b, i] = True
+        skip[b, nn_idx[b, i, top.indices[b, c, i]]] = True
+    assert int(tie.sum()) <= 2, "the fixture should be all but free of pooling ties"
     for got, key in ((x.grad, "dx"), (mod.conv1[0].weight.grad, "dw1")):
         ref = torch.from_numpy(d[key])
-        err = (got.cpu() - ref).abs().max().item()
-        assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err)
+        err = (got.cpu() - ref).abs()
+        if key == "dx":
+            err = err.masked_fill(skip.cpu()[:, None, :], 0.0)
+        assert err.max().item() <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err.max().item())
 
 
 @pytest.mark.parametrize("layer,B,N", [(0, 2, 256), (1, 2, 256), (1, 3, 1000), (0, 1, 2048)])
