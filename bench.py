@@ -421,9 +421,16 @@ def measure_block(workload, steps, warmup):
     elif dominant in ("edge_bwd", "edge_fwd"):
         # conv2 of the EdgeConv body on B*N*K edges, 64 -> 64 channels: forward 1 product, backward 2 (dh, dW2)
         fl = Bb * Nb * K * 2 * 64 * 64 * (2 if dominant == "edge_bwd" else 1)
-        roof = {"kernel": "edge_mlp_bwd_kernel" if dominant == "edge_bwd" else "edge_mlp_fwd_kernel", "bound": "mfma",
-                "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "note": "fp32 MFMA; the backward recomputes the edge activations (a third product, not counted)"}
+        # split-bf16 kernels (csrc/edgeconv.hip): six bf16 products per product executed; the backward executes four
+        # (y in both orientations, dh, dW2) for its two algorithmic ones, the forward one for one
+        executed = 12.0 if dominant == "edge_bwd" else 6.0
+        roof = {"kernel": "edge_mlp_bwd_tri_kernel" if dominant == "edge_bwd" else "edge_mlp_fwd_tri_kernel", "bound": "mfma",
+                "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / executed, 1),
+                "unit": "TFLOP/s", "executed_products": executed,
+                "note": ("three bf16 planes per operand: 6 MFMA products per fp32 product; the backward recomputes the edge "
+                         "activations in both orientations (2 products, not counted) beside dh and dW2; the kernel is bound "
+                         "by vector issue (operand splits of tensors that are used once) and its waits, not by the matrix "
+                         "pipe (30 % busy, DESIGN 7)")}
     else:
         fl = sum(2.0 * Bb * n * n * Cc for n in layers_n) / len(layers_n)
         roof = {"kernel": dominant, "bound": "mfma", "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2),
