@@ -127,9 +127,14 @@ class Neighbor2PointAttention(nn.Module):
             raise ValueError(
                 f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {self.group_type}")
         grouped = 2 * q_in if self.group_type.startswith("center_") else q_in   # channels of the grouped tensor
-        if not (q_in == q_out == k_out == v_out == 128 and k_in == v_in == grouped and self.num_heads in (1, 2, 4)):
-            raise NotImplementedError("the HIP N2P kernels are built for 128 channels and 4, 2 or 1 head(s) "
-                                      "(shipped cls/seg configs: 4)")
+        if k_in != grouped or v_in != grouped:
+            raise ValueError(f"group_type {self.group_type} gives the key / value convolutions {grouped} input channels")
+        if q_out % self.num_heads or k_out % self.num_heads or v_out % self.num_heads or q_out != k_out:
+            raise ValueError("q_out = k_out and v_out must be multiples of num_heads")
+        # the gather-attention kernels (csrc/n2p.hip): 128 channels, 4, 2 or 1 head(s) (the shipped configs: 4).  Any other
+        # width or head count (the reference's constructor takes them, models/attention.py:131-163; no shipped config
+        # has one) runs the same expression in torch on the device, on neighbour lists from the HIP kNN
+        self.hip_attention = q_in == q_out == k_out == v_out == 128 and self.num_heads in (1, 2, 4)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -149,8 +154,20 @@ class Neighbor2PointAttention(nn.Module):
             wk2, wv2 = (wk[:, C:], wv[:, C:]) if center else (wk, wv)
             if self.asm == "dot-sub":
                 wk2 = -wk2
-            x_tmp = _N2PCore.apply(x, self.q_conv.weight, wk2.contiguous(), wv2.contiguous(), self.K, self.num_heads,
-                                   self.group_type in ("diff", "center_diff"))
+            diff = self.group_type in ("diff", "center_diff")
+            if self.hip_attention:
+                x_tmp = _N2PCore.apply(x, self.q_conv.weight, wk2.contiguous(), wv2.contiguous(), self.K, self.num_heads,
+                                       diff)
+            else:
+                Cq = self.q_conv.weight.shape[0]
+                if self.v_conv.weight.shape[0] != Cq:
+                    raise NotImplementedError("v_out != q_out outside the 128-channel kernels")
+                w = torch.cat((self.q_conv.weight, wk2, wv2), dim=0).reshape(3 * Cq, C)
+                qkv = torch.matmul(x.transpose(1, 2), w.t())                       # (B,N,3Cq) rows [Q|K|V]
+                nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
+                step = max(1, (1 << 28) // (x.shape[2] * self.K * Cq * 4))         # <= 256 MB per gathered tensor
+                x_tmp = torch.cat([_attention_from_projection(qkv[s:s + step], nn_idx[s:s + step], self.num_heads, diff)
+                                   for s in range(0, x.shape[0], step)])
             if center:
                 x_tmp = x_tmp + torch.nn.functional.conv1d(x, wv[:, :C, :, 0])
         x = self.bn1(x + x_tmp)

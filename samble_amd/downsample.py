@@ -377,8 +377,10 @@ class DownSampleToken(nn.Module):
                 "(its workgroups were not all resident); that forward's selection was a placeholder. The layer has "
                 "switched to the stand-alone stage kernels.")
         if not (self.q_depth == self.k_depth == self.v_depth == C and C <= 128):
-            raise NotImplementedError("the HIP kernels take C = q_out = k_out = v_out <= 128 (the shipped configs: 128); "
-                                      "wider layers (256 channels) have no attention kernel here")
+            # any other width (the reference's constructor takes any q_in / q_out, models/downsample.py:33-56; no shipped
+            # config has one): the matrix part as the reference's expression in torch on the device, the neighbour search,
+            # the scores and the whole selection on the HIP stage kernels
+            return self._forward_wide(x, noise, forced_idx)
         wq, wk, wv, tokens = self.q_conv.weight, self.k_conv.weight, self.v_conv.weight, self.bin_tokens
         x_in = x
         if C < 128:
@@ -416,6 +418,67 @@ class DownSampleToken(nn.Module):
         self.k_point_to_choose = counts
         self.idx = index_down
         self.attention_bins_beforesoftmax = tok.unsqueeze(1)
+        self.knn_idx = nn_idx
+        self.knn_indegree = indeg
+        self.normalized_score = z
+        self.max_num_points = cap
+        return (x_ds, index_down), (None, None)
+
+    def _forward_wide(self, x, noise, forced_idx):
+        """Channel widths the attention kernels are not built for (> 128, or q_out != k_out ...): models/downsample.py:
+        112-290 with Q K^T, the softmax of the sampled rows and P V as torch expressions (torch's autograd carries their
+        gradients; the (B, N, N + nt) logits live in HBM as in the reference), and everything that decides WHICH rows --
+        kNN, the seven score modes, z-scores, batch quantiles, boundaries, bins, counts, the draw -- on the same HIP stage
+        kernels as the 128-channel path."""
+        B, C, N = x.shape
+        nt, nb, D = self.bin_tokens.shape[2], self.num_bins, self.q_depth
+        if not (self.q_depth == self.k_depth):
+            raise ValueError("q_out and k_out must agree (the logits contract over them)")
+        xt = torch.cat((x, self.bin_tokens.expand(B, -1, -1)), dim=2)
+        q, k, v = self.q_conv(x), self.k_conv(xt), self.v_conv(xt)               # (B,D,N), (B,D,N+nt), (B,Dv,N+nt)
+        qk = torch.matmul(q.transpose(1, 2), k)                                  # (B,N,N+nt)
+        if self.asm == "l2":
+            qk = -(q.square().sum(1).unsqueeze(2) + k.square().sum(1).unsqueeze(1) - 2.0 * qk)
+        logits = qk / math.sqrt(D)
+        with torch.no_grad():
+            lse = torch.logsumexp(logits, dim=-1).contiguous()
+            tok = logits[:, :, N:].contiguous()
+            if self.idx_mode in ("col_sum", "row_std"):
+                A = torch.exp(logits[:, :, :N] - lse.unsqueeze(-1))
+                stat = A.sum(dim=1) if self.idx_mode == "col_sum" else torch.std(A, dim=-1)
+                del A
+                score, z = ops.stage_stat_score(stat.contiguous())
+                nn_idx = torch.empty((B, N, 0), dtype=torch.int32, device=x.device)
+                indeg = torch.empty((B, 0), dtype=torch.int32, device=x.device)
+            else:
+                nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
+                ld = ops.attn_map_row_stride(N, nt)
+                smap = logits.new_zeros((B, N, ld))
+                smap[:, :, :N + nt] = logits
+                score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, self.idx_mode)
+                del smap
+            if self.bin_boundaries is not None:
+                self.bin_boundaries = [item.to(x.device) for item in self.bin_boundaries]
+            if self.dynamic_boundaries_enable:
+                quant = ops.world_average(ops.stage_batch_quantiles(z, nb))
+                self.bin_boundaries = ops.blend_boundaries(self.bin_boundaries, quant, nb, self.momentum_update_factor)
+            member, cap, w_pre, w = ops.stage_bin_assign(z, tok, self.bin_boundaries[0], self.bin_boundaries[1],
+                                                         self.relu_mean_order == "relu_mean")
+            counts = ops.stage_alloc_counts(w, cap, self.M)
+            idx = ops.stage_bin_select(score, z, member, counts, self.M, self.bin_sample_mode, self.boltzmann_T, noise)
+            if forced_idx is not None:
+                idx = forced_idx.reshape(B, self.M).to(device=x.device, dtype=torch.int64).contiguous()
+        rows = torch.gather(logits, 1, idx.unsqueeze(-1).expand(-1, -1, N + nt))    # (B,M,N+nt)
+        x_ds = torch.matmul(torch.softmax(rows, dim=-1), v.transpose(1, 2)).transpose(1, 2).contiguous()   # (B,Dv,M)
+        index_down = idx.unsqueeze(1)
+        if self.res is True:
+            x_ds = self.res_block(x, x_ds, index_down)
+        self.attention_point_score = score.unsqueeze(1)
+        self._member_bits = member
+        self.bin_weights_beforerelu = w_pre
+        self.k_point_to_choose = counts
+        self.idx = index_down
+        self.attention_bins_beforesoftmax = logits[:, :, N:].unsqueeze(1)
         self.knn_idx = nn_idx
         self.knn_indegree = indeg
         self.normalized_score = z

@@ -317,6 +317,11 @@ def stage_attn_colsum(q: torch.Tensor, k: torch.Tensor, lse: torch.Tensor) -> to
     return out
 
 
+def attn_map_row_stride(n_points: int, n_tokens: int) -> int:
+    """Row stride (floats) of a logit map over n_points + n_tokens keys (samble_attn_map_row_stride)."""
+    return int(_lib.query("samble_attn_map_row_stride", n_points, n_tokens))
+
+
 def stage_stat_score(stat: torch.Tensor):
     """Dense-mode statistic (B,N) -> (score with NaN -> 0, z-score)."""
     _need_gpu(stat)

@@ -91,6 +91,8 @@ CASES = [
     dict(name="cls_l2_rowstd_random", cfg="cls", B=2, N=256, M=128, calls=1, big=False, asm="l2", idx_mode="row_std"),
     # round 4: a 64-channel layer (q_in = q_out = ... = 64)
     dict(name="cls_c64_random", cfg="cls", B=2, N=256, M=128, calls=2, big=True, C=64),
+    # ... and a 256-channel one (no 256-channel attention kernels: DownSampleToken._forward_wide)
+    dict(name="cls_c256_random", cfg="cls", B=2, N=256, M=128, calls=1, big=True, C=256),
 ]
 
 

@@ -107,6 +107,40 @@ def test_n2p_variants_against_reference_fixture(name):
         assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
 
 
+def test_n2p_other_width_and_head_count_against_reference_fixture():
+    """64 channels, 8 heads: not a shape of the gather-attention kernels (attention.py runs the expression in torch on the
+    device, on the HIP kNN's lists) -- whole layer, forward + backward, against the unmodified reference."""
+    from samble_amd.attention import Neighbor2PointAttention, attention_config
+    d = layer_fixture("layer_n2p_c64_heads8")
+    B, C, N, K, H, seed = [int(v) for v in d["meta"]]
+    assert (C, H) == (64, 8)
+    cfg = attention_config("cls")
+    cfg.num_heads[0] = H
+    for key in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out", "ff_conv1_channels_in", "ff_conv2_channels_out"):
+        cfg[key][0] = C
+    cfg.ff_conv1_channels_out[0] = cfg.ff_conv2_channels_in[0] = 4 * C
+    mod = Neighbor2PointAttention(cfg, 0)
+    assert not mod.hip_attention
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, C, 1, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, C, 1, 1), seed + 3, 0.09))
+        mod.ff[0].weight.copy_(_w((4 * C, C, 1), seed + 4, 0.09))
+        mod.ff[2].weight.copy_(_w((C, 4 * C, 1), seed + 5, 0.045))
+        mod.bn1.weight.copy_(1 + _w((C,), seed + 6, 0.1)); mod.bn1.bias.copy_(_w((C,), seed + 7, 0.1))
+        mod.bn2.weight.copy_(1 + _w((C,), seed + 8, 0.1)); mod.bn2.bias.copy_(_w((C,), seed + 9, 0.1))
+    mod = mod.to(DEV).train()
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    y = mod(x)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(d["y"]), rtol=2e-4, atol=2e-4)
+    y.backward(torch.from_numpy(synth.normal((B, C, N), seed + 20)).to(DEV))
+    for got, key in ((x.grad, "dx"), (mod.q_conv.weight.grad, "dwq"), (mod.k_conv.weight.grad, "dwk"),
+                     (mod.v_conv.weight.grad, "dwv"), (mod.ff[0].weight.grad, "dff1")):
+        ref = torch.from_numpy(d[key])
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * ref.abs().max().item() + 1e-6, (key, err, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("H", [4, 2, 1])
 def test_n2p_backward_kernels_match_autograd_of_the_restatement(H):
     """HIP backward of the gather-attention vs torch autograd of the same expression, incl. an
