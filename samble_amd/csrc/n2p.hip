@@ -460,6 +460,72 @@ __global__ __launch_bounds__(256) void inv_mark_kernel(const int* __restrict__ n
   atomicOr(&bits[(b * N + t) * W + (i >> 5)], 1u << (i & 31));
 }
 
+// mark + count in one launch for clouds of up to 4 096 points: a workgroup owns a block of R target rows of one cloud, keeps
+// their membership words in LDS (R W words <= 128 KB), reads the cloud's whole neighbour table once (coalesced, out of
+// L2 for the cloud's other blocks) and sets the bits of the edges that point into its block with LDS atomics; the rows
+// then leave as whole lines together with their prefix popcounts and in-degrees.  2 M global atomic ORs into a 16 MB
+// matrix (memory-side transactions: 62 us per table at B=32, N=2048) + the memset + the row scan become ~10 us.
+__global__ __launch_bounds__(1024) void inv_mark_scan_kernel(const int* __restrict__ nn, int N, int K, int W, int R,
+                                                             unsigned* __restrict__ bits, unsigned short* __restrict__ pre,
+                                                             int* __restrict__ total) {
+  extern __shared__ unsigned lbits[];
+  const int b = blockIdx.y, t0 = blockIdx.x * R, rows = min(R, N - t0), tid = threadIdx.x;
+  for (int w = tid; w < rows * W; w += 1024) lbits[w] = 0u;
+  __syncthreads();
+  const int* tab = nn + (long)b * N * K;
+  const int nedges = N * K;
+  auto mark = [&](int e, int tgt) {
+    const int t = tgt - t0;
+    if (t >= 0 && t < rows) {
+      const int i = e / K;
+      atomicOr(&lbits[t * W + (i >> 5)], 1u << (i & 31));
+    }
+  };
+  if ((nedges & 3) == 0) {  // (then every cloud's table starts on a 16-byte boundary) eight 16-byte loads in flight per thread
+    const int4* tab4 = reinterpret_cast<const int4*>(tab);
+    const int n4 = nedges >> 2;
+    for (int base = tid; base < n4; base += 8 * 1024) {
+      int4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base + 1024 * u < n4 ? tab4[base + 1024 * u] : int4{-1, -1, -1, -1};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e0 = 4 * (base + 1024 * u);
+        mark(e0, v[u].x);
+        mark(e0 + 1, v[u].y);
+        mark(e0 + 2, v[u].z);
+        mark(e0 + 3, v[u].w);
+      }
+    }
+  } else {
+    for (int e = tid; e < nedges; e += 1024) mark(e, tab[e]);
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int row = wave; row < rows; row += 16) {
+    const unsigned* r = lbits + row * W;
+    const long grow = (long)b * N + t0 + row;
+    int carry = 0;
+    for (int w0 = 0; w0 < W; w0 += 64) {
+      const int w = w0 + lane;
+      const unsigned word = w < W ? r[w] : 0u;
+      const int c = __popc(word);
+      int inc = c;  // inclusive scan over the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      if (w < W) {
+        bits[grow * W + w] = word;
+        pre[grow * W + w] = (unsigned short)(carry + inc - c);
+      }
+      carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) total[grow] = carry;
+  }
+}
+
 // per target row (one wave each): exclusive prefix popcounts of its W membership words (`pre`) and its in-degree.
 // Lane = word: coalesced 256-byte reads (round 2: one thread walked a row's words one by one, 32 workgroups in all:
 // 125-190 us per table against ~10 for this kernel and the scan below)
@@ -540,8 +606,8 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   const long nedges = (long)B * N * K;
   unsigned* bits = reinterpret_cast<unsigned*>(ws);
   unsigned short* pre = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ws) + (((size_t)B * N * W * 4 + 255) & ~(size_t)255));
-  hipError_t e = hipMemsetAsync(bits, 0, (size_t)B * N * W * 4, s);
-  if (e != hipSuccess) return (int)e;
+  // (the bit matrix is cleared below, where the global-atomic marking still runs)
+  hipError_t e = hipSuccess;
   // PRECONDITION (include/samble.h): every row of nn holds K DISTINCT indices in [0, N), as samble_knn_f32 writes
   // them.  A table that breaks it (duplicates collapse into one bit, out-of-range entries are skipped) places
   // fewer than N*K edges per cloud, and the slots between a cloud's last placed edge and the next cloud's first
@@ -550,12 +616,27 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   e = hipMemsetAsync(order, 0, (size_t)nedges * sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   const unsigned blocks = (unsigned)((nedges + 255) / 256);
-  samble::Timed timed(samble::kT_inv_nn, s);
-  hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
   // (in-degrees: the caller's array, or the tail of the workspace)
   int* tot = indeg ? indeg : reinterpret_cast<int*>(reinterpret_cast<char*>(pre) + (((size_t)B * N * W * 2 + 255) & ~(size_t)255));
-  hipLaunchKernelGGL(samble::inv_rowscan_kernel, dim3((unsigned)(((long)B * N + 3) / 4)), dim3(256), 0, s, bits, (long)B * N, W,
-                     pre, tot);
+  // target rows per workgroup of the LDS marking: what 128 KB hold, at least four workgroups per cloud
+  const int R = N <= 4096 ? min(((N + 3) / 4 + 15) & ~15, (128 * 1024 / 4) / W) : 0;
+  if (R == 0) {
+    e = hipMemsetAsync(bits, 0, (size_t)B * N * W * 4, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  samble::Timed timed(samble::kT_inv_nn, s);
+  if (R > 0) {
+    const int lds = R * W * 4;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(samble::inv_mark_scan_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(samble::inv_mark_scan_kernel, dim3((N + R - 1) / R, B), dim3(1024), lds, s, nn, N, K, W, R, bits, pre,
+                       tot);
+  } else {
+    hipLaunchKernelGGL(samble::inv_mark_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits);
+    hipLaunchKernelGGL(samble::inv_rowscan_kernel, dim3((unsigned)(((long)B * N + 3) / 4)), dim3(256), 0, s, bits, (long)B * N,
+                       W, pre, tot);
+  }
   hipLaunchKernelGGL(samble::inv_offsets_kernel, dim3(B), dim3(1024), 0, s, tot, N, K, offsets);
   hipLaunchKernelGGL(samble::inv_place_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets, order);
   return (int)hipGetLastError();
