@@ -358,7 +358,9 @@ def _map_free_fixtures():
     out = []
     for n in golden_names():
         g = Golden(n)
-        if g.idx_mode.startswith("sparse") and g.asm == "dot":
+        # (a wider layer runs torch's matmuls and convolutions, DownSampleToken._forward_wide: the switch does not reach
+        # it, and those libraries do not promise run-to-run identical bits)
+        if g.idx_mode.startswith("sparse") and g.asm == "dot" and g.C <= 128:
             out.append(n)
     return out
 
