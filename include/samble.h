@@ -346,7 +346,10 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  *   samble_select_chain_f32  = the two entries above in ONE launch, for a caller with nothing to exchange between them (a
  *       single rank): arguments as theirs (smap / lse / nn NULL when samble_attn_stats_nl_tri_f32 filled the workspace;
  *       want_quantiles 0: static boundaries).
- *   samble_select_chain_status_async  copies the workspace's status word to host_flag (pinned host memory) on the stream.
+ *   samble_select_chain_status_async  copies the workspace's status word to host_flag (pinned host memory) on the stream
+ *       (for callers that pass no host_status).
+ * host_status (all three launching entries, may be NULL): an int32 in pinned host memory (hipHostMalloc) that a barrier
+ * which gives up sets to 1 with a system-scope store -- the status without a copy behind every launch; the caller clears it.
  * spin_budget (all three launching entries): poll rounds a grid barrier waits before it gives up; 0 = the default
  * (2^20, about a second).  A caller that knows its kernels share the device may shorten it; 0xFFFFFFFF injects the fault:
  * every barrier gives up without polling (tests of the give-up path).
@@ -357,16 +360,17 @@ int samble_select_chain_f32(const float* smap, int ld, const float* lse, const i
                             int nt, int want_quantiles, float* quantiles_out, float* upper, float* lower, int first,
                             float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
                             float* score, float* z, int32_t* indeg_out, uint8_t* member, int32_t* cap, float* w_pre, float* w,
-                            int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, void* stream);
+                            int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, int32_t* host_status,
+                            void* stream);
 int samble_select_chain_status_async(const void* ws, int B, int N, int32_t* host_flag, void* stream);
 int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B, int N,
                                           int KN, int mode, int nb, float* score, float* z, int32_t* indeg_out,
                                           float* quantiles_out, void* ws, size_t ws_bytes, unsigned int spin_budget,
-                                          void* stream);
+                                          int32_t* host_status, void* stream);
 int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper, float* lower,
                         int first, float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
                         uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws, size_t ws_bytes,
-                        unsigned int spin_budget, void* stream);
+                        unsigned int spin_budget, int32_t* host_status, void* stream);
 
 /* ---- the same passes on the bf16 matrix cores with split fp32 operands ------------------------------
  * An fp32 operand is carried as three bf16 planes h + m + l (all 24 significand bits); a product keeps

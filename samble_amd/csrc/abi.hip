@@ -91,12 +91,12 @@ int samble_chain_supported(int B, int N, int nb);
 int samble_launch_sparse_score_map_acc(const float*, int, const float*, const int*, int, int, int, int, void*, size_t,
                                        hipStream_t);
 int samble_launch_score_quantiles(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*,
-                                  float*, unsigned int, hipStream_t);
+                                  float*, unsigned int, int*, hipStream_t);
 int samble_launch_bin_plan(const float*, const float*, int, const float*, float*, float*, int, float, float, int, int, int,
-                           int, int, unsigned char*, int*, float*, float*, int*, void*, unsigned int, hipStream_t);
+                           int, int, unsigned char*, int*, float*, float*, int*, void*, unsigned int, int*, hipStream_t);
 int samble_launch_select_chain(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*, float*,
                                const float*, int, float*, float*, int, float, float, int, int, unsigned char*, int*, float*,
-                               float*, int*, unsigned int, hipStream_t);
+                               float*, int*, unsigned int, int*, hipStream_t);
 size_t samble_chain_flag_offset(void);
 size_t samble_edge_glue_part_bytes(void);
 size_t samble_edge_glue_cst_bytes(void);
@@ -785,7 +785,7 @@ SAMBLE_API size_t samble_select_chain_workspace_bytes(int B, int N) {
 SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float* lse, const int32_t* nn, int B,
                                                      int N, int KN, int mode, int nb, float* score, float* z,
                                                      int32_t* indeg_out, float* quantiles_out, void* ws, size_t ws_bytes,
-                                                     unsigned int spin_budget, void* stream) {
+                                                     unsigned int spin_budget, int32_t* host_status, void* stream) {
   if ((smap && (!lse || !nn)) || !score || !z || !ws)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_quantiles_f32: null pointer");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
@@ -806,14 +806,14 @@ SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, 
   const int* indeg = (const int*)(w8 + (size_t)B * N * 8);
   const float* rowstat = (const float*)(w8 + (size_t)B * N * 12);
   return done(samble_launch_score_quantiles(colacc, indeg, rowstat, B, N, mode, nb, score, z, indeg_out,
-                                            w8 + chain_score_bytes(B, N), quantiles_out, spin_budget, s),
+                                            w8 + chain_score_bytes(B, N), quantiles_out, spin_budget, host_status, s),
               "samble_sparse_score_map_quantiles_f32");
 }
 
 SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper,
                                    float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb,
                                    int relu_first, int M, uint8_t* member, int32_t* cap, float* w_pre, float* w,
-                                   int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, void* stream) {
+                                   int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, int32_t* host_status, void* stream) {
   if (!z || !tok || !upper || !lower || !member || !cap || !w_pre || !w || !counts || !ws)
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: null pointer");
   if (nb < 1 || nb > 8 || (nt != 1 && nt != nb))
@@ -824,7 +824,7 @@ SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, con
     return fail(SAMBLE_E_WORKSPACE, "samble_bin_plan_f32: workspace too small");
   return done(samble_launch_bin_plan(z, tok, nt, quantiles, upper, lower, first, momentum, one_minus_momentum, B, N, nb,
                                      relu_first, M, member, cap, w_pre, w, counts, (char*)ws + chain_score_bytes(B, N),
-                                     spin_budget, (hipStream_t)stream),
+                                     spin_budget, host_status, (hipStream_t)stream),
               "samble_bin_plan_f32");
 }
 
@@ -833,7 +833,7 @@ SAMBLE_API int samble_select_chain_f32(const float* smap, int ld, const float* l
                                        float* lower, int first, float momentum, float one_minus_momentum, int B, int N,
                                        int nb, int relu_first, int M, float* score, float* z, int32_t* indeg_out,
                                        uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws,
-                                       size_t ws_bytes, unsigned int spin_budget, void* stream) {
+                                       size_t ws_bytes, unsigned int spin_budget, int32_t* host_status, void* stream) {
   if ((smap && (!lse || !nn)) || !score || !z || !ws || !tok || !upper || !lower || !member || !cap || !w_pre || !w ||
       !counts || (want_quantiles && !quantiles_out))
     return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: null pointer");
@@ -854,7 +854,7 @@ SAMBLE_API int samble_select_chain_f32(const float* smap, int ld, const float* l
   return done(samble_launch_select_chain(w8, (const int*)(w8 + (size_t)B * N * 8), (const float*)(w8 + (size_t)B * N * 12), B,
                                          N, mode, nb, score, z, indeg_out, w8 + chain_score_bytes(B, N),
                                          want_quantiles ? quantiles_out : nullptr, tok, nt, upper, lower, first, momentum,
-                                         one_minus_momentum, relu_first, M, member, cap, w_pre, w, counts, spin_budget, s),
+                                         one_minus_momentum, relu_first, M, member, cap, w_pre, w, counts, spin_budget, host_status, s),
               "samble_select_chain_f32");
 }
 

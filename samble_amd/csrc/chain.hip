@@ -49,9 +49,17 @@ enum { kColSumC = 0, kColAvgC = 1, kColSqrC = 2, kRowSumC = 3 };
 // and leaves the same way, workgroups that start later leave at their first barrier.  Nothing traps: the context stays
 // alive, the host reads the word (samble_select_chain_status_async) and falls back to the stage kernels.
 // Returns true when the barrier completed (uniform over the workgroup).
+// how a barrier gives up: after `budget` poll rounds, telling the caller's mailbox (pinned host memory, may be null)
+struct ChainCtl {
+  unsigned int budget;
+  int* host_status;
+};
+
 template <bool RELEASE>
 __device__ __forceinline__ bool grid_barrier(unsigned int* counter, unsigned int target, unsigned int* flag,
-                                             unsigned int budget, int* ok_lds) {
+                                             const ChainCtl ctl, int* ok_lds) {
+  const unsigned int budget = ctl.budget;
+  int* const host_status = ctl.host_status;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -75,6 +83,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned int* counter, unsigned int
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the caller's mailbox in pinned host memory (include/samble.h `host_status`): raised here, in the one path that
+      // needs it, instead of a device-to-host copy of the word behind every launch
+      if (host_status) __hip_atomic_store(host_status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     *ok_lds = ok ? 1 : 0;
   }
@@ -123,7 +134,7 @@ __device__ __forceinline__ bool score_quantiles_body(ChainLds& L, unsigned int* 
                                                      const int* __restrict__ indeg, const float* __restrict__ rowstat,
                                                      int N, int mode, int nb, float* __restrict__ score,
                                                      float* __restrict__ z, int* __restrict__ indeg_out,
-                                                     unsigned int* __restrict__ cws, bool want_q, unsigned int budget) {
+                                                     unsigned int* __restrict__ cws, bool want_q, const ChainCtl budget) {
   double* red = L.red;
   unsigned int* scanbuf = L.scanbuf;
   unsigned int* prefix = L.prefix;
@@ -293,7 +304,7 @@ __device__ __forceinline__ bool bin_plan_body(ChainLds& L, int b, int B, const f
                                               float mu, float one_minus_mu, int N, int nb, int relu_first, int M,
                                               unsigned char* __restrict__ member, int* cap, float* w_pre, float* w,
                                               int* __restrict__ counts, unsigned int* __restrict__ cws,
-                                              unsigned int budget) {
+                                              const ChainCtl budget) {
   const int tid = threadIdx.x;
   float* up_s = L.up_s;
   float* lo_s = L.lo_s;
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
                                                                int nb, float* __restrict__ score,
                                                                float* __restrict__ z, int* __restrict__ indeg_out,
                                                                unsigned int* __restrict__ cws,
-                                                               float* __restrict__ quant_out, unsigned int budget) {
+                                                               float* __restrict__ quant_out, const ChainCtl budget) {
   extern __shared__ unsigned int qsm[];  // per-level histogram of this cloud (up to (nb-1) x 2048 words)
   __shared__ ChainLds L;
   const int b = blockIdx.x, B = gridDim.x;
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
                                                         int nb, int relu_first, int M,
                                                         unsigned char* __restrict__ member, int* cap, float* w_pre,
                                                         float* w, int* __restrict__ counts,
-                                                        unsigned int* __restrict__ cws, unsigned int budget) {
+                                                        unsigned int* __restrict__ cws, const ChainCtl budget) {
   __shared__ ChainLds L;
   const int b = blockIdx.x, B = gridDim.x;
   const bool dead = __hip_atomic_load(cws + kChainFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // uniform
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(1024) void select_chain_kernel(const unsigned long 
                                                             int nt, float* upper, float* lower, int first, float mu,
                                                             float one_minus_mu, int relu_first, int M,
                                                             unsigned char* __restrict__ member, int* cap, float* w_pre,
-                                                            float* w, int* __restrict__ counts, unsigned int budget) {
+                                                            float* w, int* __restrict__ counts, const ChainCtl budget) {
   extern __shared__ unsigned int qsm[];
   __shared__ ChainLds L;
   const int b = blockIdx.x, B = gridDim.x;
@@ -442,7 +453,9 @@ extern "C" int samble_chain_supported(int B, int N, int nb) {
 }
 
 // poll rounds a grid barrier waits before it gives up: the caller's `spin_budget`, 0 = the default (~1 s)
-static inline unsigned int chain_budget(unsigned int spin_budget) { return spin_budget ? spin_budget : (1u << 20); }
+static inline ChainCtl chain_budget(unsigned int spin_budget, int* host_status) {
+  return ChainCtl{spin_budget ? spin_budget : (1u << 20), host_status};
+}
 
 extern "C" size_t samble_chain_flag_offset(void) { return (size_t)kChainFlag * sizeof(unsigned int); }
 
@@ -456,8 +469,8 @@ static size_t chain_dyn_lds(int N, int nb) {
 // cws must have been zeroed on the stream (the score launcher's memset covers it)
 extern "C" int samble_launch_score_quantiles(const void* colacc, const int* indeg, const float* rowstat, int B, int N,
                                              int mode, int nb, float* score, float* z, int* indeg_out, void* cws,
-                                             float* quant_out, unsigned int spin_budget, hipStream_t s) {
-  const unsigned int g_chain_budget = chain_budget(spin_budget);
+                                             float* quant_out, unsigned int spin_budget, int* host_status, hipStream_t s) {
+  const ChainCtl g_chain_budget = chain_budget(spin_budget, host_status);
   const int pt = (N + 1023) / 1024;
   const size_t lds = chain_dyn_lds(N, nb);
   Timed timed(kT_quantiles, s);
@@ -482,8 +495,8 @@ extern "C" int samble_launch_score_quantiles(const void* colacc, const int* inde
 extern "C" int samble_launch_bin_plan(const float* z, const float* tok, int nt, const float* quant, float* upper,
                                       float* lower, int first, float mu, float one_minus_mu, int B, int N, int nb,
                                       int relu_first, int M, unsigned char* member, int* cap, float* w_pre, float* w,
-                                      int* counts, void* cws, unsigned int spin_budget, hipStream_t s) {
-  const unsigned int g_chain_budget = chain_budget(spin_budget);
+                                      int* counts, void* cws, unsigned int spin_budget, int* host_status, hipStream_t s) {
+  const ChainCtl g_chain_budget = chain_budget(spin_budget, host_status);
   Timed timed(kT_bin_assign, s);
   hipLaunchKernelGGL(bin_plan_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, quant, upper, lower, first, mu,
                      one_minus_mu, N, nb, relu_first, M, member, cap, w_pre, w, counts, (unsigned int*)cws,
@@ -497,8 +510,8 @@ extern "C" int samble_launch_select_chain(const void* colacc, const int* indeg, 
                                           float* quant_out, const float* tok, int nt, float* upper, float* lower,
                                           int first, float mu, float one_minus_mu, int relu_first, int M,
                                           unsigned char* member, int* cap, float* w_pre, float* w, int* counts,
-                                          unsigned int spin_budget, hipStream_t s) {
-  const unsigned int g_chain_budget = chain_budget(spin_budget);
+                                          unsigned int spin_budget, int* host_status, hipStream_t s) {
+  const ChainCtl g_chain_budget = chain_budget(spin_budget, host_status);
   const int pt = (N + 1023) / 1024;
   const size_t lds = chain_dyn_lds(N, nb);
   Timed timed(kT_quantiles, s);

@@ -174,18 +174,18 @@ class _SamplerCore(torch.autograd.Function):
                     (score, z, indeg, quant, mod.bin_boundaries, *plan, cws) = ops.stage_select_chain(
                         lse, tok, nn_sorted, mod.idx_mode, nb, mod.dynamic_boundaries_enable, mod.bin_boundaries,
                         mod.momentum_update_factor, mod.relu_mean_order == "relu_mean", mod.M, smap=nl,
-                        compact=not fused, ws=sws)
-                    mod._chain_watch.arm(cws, B, N)
+                        compact=not fused, ws=sws, watch=mod._chain_watch)
                 elif chain:
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
                                                                             mod.dynamic_boundaries_enable,
-                                                                            compact=not fused, ws=sws)
+                                                                            compact=not fused, ws=sws,
+                                                                            watch=mod._chain_watch)
                     if quant is not None:
                         quant = ops.world_average(quant)
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
-                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws)
-                    mod._chain_watch.arm(cws, B, N)
+                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws,
+                                                                   watch=mod._chain_watch)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=not fused,
                                                                  ws=sws)
@@ -198,13 +198,14 @@ class _SamplerCore(torch.autograd.Function):
                     # score + z + batch quantiles, then boundaries + bins + counts: two launches, the rank
                     # average of the quantiles (reference utils/ops.py:191-199) in between
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(smap, lse, nn_idx, mod.idx_mode, nb,
-                                                                            mod.dynamic_boundaries_enable)
+                                                                            mod.dynamic_boundaries_enable,
+                                                                            watch=mod._chain_watch)
                     if quant is not None:
                         quant = ops.world_average(quant)
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
-                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws)
-                    mod._chain_watch.arm(cws, B, N)
+                                                                   mod.relu_mean_order == "relu_mean", mod.M, cws,
+                                                                   watch=mod._chain_watch)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:

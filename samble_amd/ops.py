@@ -753,7 +753,7 @@ def chain_supported(B: int, N: int, num_bins: int) -> bool:
 
 
 def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, compact: bool = False,
-                          ws=None):
+                          ws=None, watch=None):
     """stage_sparse_score_map + stage_batch_quantiles in two launches (compact / smap None + ws: as in
     stage_sparse_score_map; then it is ONE launch).
     -> score (B,N), z (B,N), in-degree (B,N) int32, quantiles (nb-1,) or None, chain workspace (hand it to
@@ -782,7 +782,7 @@ def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_
         assert ws.numel() >= nbytes
         _lib.call("samble_sparse_score_map_quantiles_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
                   nn_idx.shape[2], SCORE_MODES[idx_mode], num_bins, score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
-                  _p(quant), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _stream())
+                  _p(quant), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _mailbox(watch), _stream())
     return score, z, indeg, quant, ws
 
 
@@ -792,20 +792,20 @@ CHAIN_SPIN_BUDGET = 0
 
 
 class ChainWatch:
-    """The fused select chain's status word, watched without a synchronisation: after each chain launch the word is
-    copied (asynchronously, on the stream) into one pinned int32; the host looks at that int before the NEXT chain launch,
-    or any time through `timed_out()`.  1 = SAMBLE_E_TIMEOUT: a grid barrier gave up (its workgroups were not all
-    resident) and the step that ran it produced placeholder selections -- the watch then stays tripped and the caller
-    uses the stand-alone stage kernels (stage_sparse_score_map, stage_batch_quantiles, ...)."""
+    """The fused select chain's status, watched without a synchronisation and without a copy: one int32 in pinned host
+    memory that a grid barrier which gives up sets to 1 with a system-scope store (include/samble.h `host_status`); the
+    host looks at it before the NEXT chain launch, or any time through `timed_out()`.  1 = SAMBLE_E_TIMEOUT: the barrier's
+    workgroups were not all resident and the step that ran it produced placeholder selections -- the watch then stays
+    tripped and the caller uses the stand-alone stage kernels (stage_sparse_score_map, stage_batch_quantiles, ...)."""
 
     def __init__(self):
         self.flag = None
         self.tripped = False
 
-    def arm(self, ws: torch.Tensor, B: int, N: int) -> None:
+    def host_ptr(self) -> int:
         if self.flag is None:
             self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-        _lib.call("samble_select_chain_status_async", ws.data_ptr(), B, N, self.flag.data_ptr(), _stream())
+        return self.flag.data_ptr()
 
     def timed_out(self, sync: bool = False) -> bool:
         if sync:
@@ -816,8 +816,13 @@ class ChainWatch:
         return self.tripped
 
 
+def _mailbox(watch: Optional["ChainWatch"]):
+    return None if watch is None else watch.host_ptr()
+
+
 def stage_select_chain(lse, tok_logits, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, boundaries,
-                       momentum_update_factor: float, relu_first: bool, M: int, smap=None, compact: bool = False, ws=None):
+                       momentum_update_factor: float, relu_first: bool, M: int, smap=None, compact: bool = False, ws=None,
+                       watch=None):
     """stage_score_quantiles + stage_bin_plan as ONE launch (a single rank: no all-reduce of the quantiles stands between
     them; csrc/chain.hip select_chain_kernel).  smap / compact / ws as in stage_score_quantiles.
     -> score, z, in-degree, quantiles | None, boundaries [upper, lower], member, cap, w_pre, w, counts, workspace."""
@@ -862,7 +867,7 @@ def stage_select_chain(lse, tok_logits, nn_idx, idx_mode: str, num_bins: int, wa
                   boundaries[0].data_ptr(), boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
                   float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), score.data_ptr(),
                   z.data_ptr(), indeg.data_ptr(), member.data_ptr(), cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(),
-                  counts.data_ptr(), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _stream())
+                  counts.data_ptr(), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _mailbox(watch), _stream())
     return score, z, indeg, quant, boundaries, member, cap, w_pre, w, counts, ws
 
 
@@ -873,7 +878,7 @@ def single_rank() -> bool:
 
 
 def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum_update_factor: float, relu_first: bool,
-                   M: int, ws):
+                   M: int, ws, watch=None):
     """blend_boundaries + stage_bin_assign + stage_alloc_counts in one launch (`ws` from stage_score_quantiles).
     quantiles None: `boundaries` are used as they are (static); else they are initialised (boundaries None) or
     blended IN PLACE (reference utils/ops.py:201-233).
@@ -903,7 +908,7 @@ def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum
                   boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
                   float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), member.data_ptr(),
                   cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
-                  CHAIN_SPIN_BUDGET, _stream())
+                  CHAIN_SPIN_BUDGET, _mailbox(watch), _stream())
     return boundaries, member, cap, w_pre, w, counts
 
 
