@@ -297,25 +297,48 @@ class Point2PointAttention(nn.Module):
         self.bn2 = nn.BatchNorm1d(v_out)
         if self.asm not in ("dot", "l2", "l2+"):
             raise ValueError("Please check the setting of asm in feature learning layer!")
-        if not (q_in == q_out == v_out == 128):
-            raise NotImplementedError("the HIP attention kernels are built for 128 channels")
-        if self.q_depth % 4:
-            raise NotImplementedError("the multi-head kernels move rows in 16-byte pieces: head depth a multiple of 4")
+        # the multi-head kernels: 128 channels, head depth a multiple of 4 (rows move in 16-byte pieces); any other shape
+        # (the reference's constructor takes it; no shipped config has one) runs the expression in torch on the device
+        self.hip_attention = q_in == q_out == v_out == 128 and self.q_depth % 4 == 0
 
     def forward(self, x):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.Point2PointAttention runs on the GPU only (no CPU fallback)")
-        from .downsample import _Projection
-        no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
-        qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
-        if self.num_heads == 1 and self.asm == "dot":
-            x_tmp = _P2PCore.apply(qkv)
+        if not self.hip_attention:
+            x_tmp = self._attention_in_torch(x)
         else:
-            x_tmp = _P2PHeads.apply(qkv, self.num_heads, self.asm)
+            from .downsample import _Projection
+            no_tokens = self.q_conv.weight.new_zeros((1, x.shape[1], 0))
+            qkv = _Projection.apply(x, no_tokens, self.q_conv.weight, self.k_conv.weight, self.v_conv.weight)
+            if self.num_heads == 1 and self.asm == "dot":
+                x_tmp = _P2PCore.apply(qkv)
+            else:
+                x_tmp = _P2PHeads.apply(qkv, self.num_heads, self.asm)
         x = self.bn1(x + x_tmp)
         x_tmp = _feed_forward(self.ff, x)
         x = self.bn2(x + x_tmp)
         return x
+
+
+def _p2p_attention_in_torch(self, x):
+    """models/attention.py:317-355 for shapes outside the kernels: per head softmax_j(logit_ij / sqrt(D)) V_j with logit =
+    <q_i, k_j> (dot), -|q_i - k_j|^2 (l2) or +|q_i - k_j|^2 (l2+); the |q_i|^2 term is constant along a row and drops out
+    of the softmax."""
+    B, _, N = x.shape
+    H, D = self.num_heads, self.q_depth
+    q = self.q_conv(x).view(B, H, D, N)
+    k = self.k_conv(x).view(B, H, D, N)
+    v = self.v_conv(x).view(B, H, self.v_depth, N)
+    qk = torch.matmul(q.transpose(2, 3), k)                                       # (B,H,N,N)
+    if self.asm == "l2":
+        qk = 2.0 * qk - k.square().sum(2).unsqueeze(2)
+    elif self.asm == "l2+":
+        qk = k.square().sum(2).unsqueeze(2) - 2.0 * qk
+    att = torch.softmax(qk / math.sqrt(D), dim=-1)
+    return torch.matmul(v, att.transpose(2, 3)).reshape(B, H * self.v_depth, N)
+
+
+Point2PointAttention._attention_in_torch = _p2p_attention_in_torch
 
 
 def attention_config(preset: str = "cls"):

@@ -590,11 +590,12 @@ def test_modules_are_safe_under_autocast():
     assert torch.isfinite(xin.grad).all()
 
 
-@pytest.mark.parametrize("name", ["layer_p2p_dot", "layer_p2p_l2", "layer_p2p_l2plus"])
+@pytest.mark.parametrize("name", ["layer_p2p_dot", "layer_p2p_l2", "layer_p2p_l2plus", "layer_p2p_c64_heads8_l2"])
 def test_point2point_attention_against_reference_fixture(name):
     """Point2PointAttention as the reference configures it (4 heads of 32 channels, models/attention.py:253-355;
     asm dot / l2 / l2+) against fixtures from the unmodified reference (tests/golden/make_golden_p2p.py):
-    output, dx and every parameter gradient."""
+    output, dx and every parameter gradient.  The last fixture (64 channels, 8 heads) is a shape outside the kernels: the
+    layer runs the expression in torch on the device."""
     from samble_amd.attention import Point2PointAttention, attention_config
     from samble_amd.config import to_attr
     from tests.util import fill_parameters
@@ -602,8 +603,12 @@ def test_point2point_attention_against_reference_fixture(name):
     B, C, N, H, seed = [int(v) for v in d["meta"]]
     cfg = attention_config("cls")
     cfg["asm"] = [str(d["asm"])] * 3
-    assert cfg["num_heads"][0] == H == 4
+    cfg["num_heads"][0] = H
+    for key in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out", "ff_conv1_channels_in", "ff_conv2_channels_out"):
+        cfg[key][0] = C
+    cfg["ff_conv1_channels_out"][0] = cfg["ff_conv2_channels_in"][0] = 4 * C
     mod = Point2PointAttention(to_attr(cfg), 0)
+    assert mod.hip_attention == (C == 128)
     assert sorted(n for n, _ in mod.named_parameters()) == sorted(k[len("grad__"):] for k in d.files if k.startswith("grad__"))
     fill_parameters(mod, seed)
     mod = mod.to(DEV).train()
