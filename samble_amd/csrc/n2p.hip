@@ -31,13 +31,17 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restrict__ qkv, long bs, long rs,
                                                            const int* __restrict__ nn, int N, int KN, int diff,
                                                            float scale, float* __restrict__ out, int heads,
-                                                           float* __restrict__ att) {
+                                                           float* __restrict__ att, int B) {
   __shared__ float tile[128 * 33];
   __shared__ float lgs[8][64];  // att output: the logits of a half-wave's point (this lane's head), K <= 64
   const int hl = 32 / heads;
-  int chunk, b;
-  xcd_assign(chunk, b);
   const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
+  // persistent: XCD x (workgroups x, x + 8, ...) walks the 32-point chunks of the clouds x, x + 8, ... cloud after
+  // cloud, so that its L2 holds the [Q|K|V] rows of as few clouds as the grid size allows (placement only)
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, cpc = (N + 31) / 32;
+  for (int v = blockIdx.x >> 3;; v += per_xcd) {
+  const int b = (v / cpc) * 8 + xcd, chunk = v % cpc;
+  if (b >= B) break;  // uniform over the workgroup
   const float* base = qkv + (long)b * bs;
   for (int pp = 0; pp < 4; ++pp) {
     const int lp = hw * 4 + pp;
@@ -96,18 +100,24 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
     const int d = e >> 5, p = e & 31;
     if (chunk * 32 + p < N) ob[(long)d * N + chunk * 32 + p] = tile[d * 33 + p];
   }
+  __syncthreads();  // the tile is rewritten by the next chunk
+  }
 }
 
 }  // namespace samble
 
 using namespace samble;
 
+#ifndef SAMBLE_N2P_FWD_GRID
+#define SAMBLE_N2P_FWD_GRID 2048  // workgroups of the persistent forward (a multiple of 8)
+#endif
+
 extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const int* nn, int B, int N, int KN, int diff,
                                      float scale, float* out, int heads, float* att, hipStream_t s) {
   if ((heads != 1 && heads != 2 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
   Timed timed(kT_n2p_fwd, s);
-  hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
-                     out, heads, att);
+  hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3(SAMBLE_N2P_FWD_GRID), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
+                     out, heads, att, B);
   return (int)hipGetLastError();
 }
 
@@ -155,16 +165,20 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
                                                             const float* __restrict__ gt,  // (B,N,128)
                                                             int N, int KN, int diff, float scale,
                                                             float* __restrict__ dqkv, long dbs, long drs,
-                                                            float* __restrict__ A, float* __restrict__ DL, int heads) {
-  int chunk, b;
-  xcd_assign(chunk, b);
+                                                            float* __restrict__ A, float* __restrict__ DL, int heads,
+                                                            int B) {
   const int tid = threadIdx.x, hw = tid >> 5, c = tid & 31;
   const int hl = 32 / heads;
-  const float* base = qkv + (long)b * bs;
+  // a half-wave per point; XCD x (workgroups x, x + 8, ...) walks the clouds x, x + 8, ... one after the other: its L2
+  // then holds ONE cloud's [Q|K|V] rows (3 MB at N = 2048) while every point gathers 32 of them, instead of a slice of
+  // every cloud in flight (the same placement as n2p_bwd_gather_kernel below)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
 #pragma unroll 1
-  for (int pp = 0; pp < 4; ++pp) {
-    const int i = chunk * 32 + hw * 4 + pp;
-    if (i >= N) continue;  // uniform per half-wave
+  for (long u = (long)slot * 8 + hw;; u += (long)per_xcd * 8) {
+    const int b = (int)(u / N) * 8 + xcd;
+    if (b >= B) break;  // uniform per half-wave
+    const int i = (int)(u % N);
+    const float* base = qkv + (long)b * bs;
     const float* row = base + (long)i * rs + 4 * c;
     const f32x4 q = *reinterpret_cast<const f32x4*>(row);
     const f32x4 g = *reinterpret_cast<const f32x4*>(gt + ((long)b * N + i) * 128 + 4 * c);
@@ -376,9 +390,16 @@ __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float* __rest
                                                              float* __restrict__ dqkv, long dbs, long drs, int heads) {
   const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;  // lane = channels 4c .. 4c+3
   const int head = c / (32 / heads);
-  for (long t = (long)blockIdx.x * 8 + hw; t < ntargets; t += (long)gridDim.x * 8) {
-    const long cloud = t / N;
-    const int j = (int)(t - cloud * N);
+  // Workgroups are dealt round-robin over the 8 XCDs (a private 4 MB L2 each): XCD x walks the clouds x, x + 8, ... one
+  // after the other, so that what its L2 holds at any time is ONE cloud's q / g rows and coefficients (about 4 MB at
+  // N = 2048) instead of a slice of every cloud in flight.  Placement only: every target is visited exactly once.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const long nclouds = ntargets / N;
+  for (long u = (long)slot * 8 + hw;; u += (long)per_xcd * 8) {
+    const long cloud = (u / N) * 8 + xcd;
+    if (cloud >= nclouds) break;
+    const int j = (int)(u % N);
+    const long t = cloud * N + j;
     f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
     const int e0 = offs[t], e1 = offs[t + 1];
     for (int s = e0; s < e1; ++s) {
@@ -670,8 +691,8 @@ extern "C" int samble_launch_n2p_bwd(const float* qkv, long bs, long rs, const i
   }
   Timed timed(kT_n2p_bwd, s);  // (transpose + per-point kernel + gather / scatter of the neighbours' shares)
   hipLaunchKernelGGL(transpose_cn_kernel, dim3((N + 31) / 32, B), dim3(256), 0, s, g, N, gt);
-  hipLaunchKernelGGL(KN == 32 ? n2p_bwd_point_kernel<true> : n2p_bwd_point_kernel<false>, dim3((N + 31) / 32, B), dim3(256), 0, s, qkv, bs, rs, nn, gt, N, KN, diff,
-                     scale, dqkv, dbs, drs, A, DL, heads);
+  hipLaunchKernelGGL(KN == 32 ? n2p_bwd_point_kernel<true> : n2p_bwd_point_kernel<false>, dim3(2048), dim3(256), 0, s, qkv, bs,
+                     rs, nn, gt, N, KN, diff, scale, dqkv, dbs, drs, A, DL, heads, B);
   if (order && offs)
     hipLaunchKernelGGL(n2p_bwd_gather_kernel, dim3(2048), dim3(256), 0, s, qkv, bs, rs, gt, A, DL, order, offs, N, KN,
                        (long)B * N, dqkv, dbs, drs, heads);
