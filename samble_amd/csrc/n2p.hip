@@ -602,16 +602,21 @@ __global__ __launch_bounds__(256) void inv_place_kernel(const int* __restrict__ 
                                                         const unsigned* __restrict__ bits,
                                                         const unsigned short* __restrict__ pre,
                                                         const int* __restrict__ offsets, int* __restrict__ order) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= nedges) return;
-  const long q = e / K;
-  const int i = (int)(q % N);
-  const long b = q / N;
-  const int t = nn[e];
-  if (t < 0 || t >= N) return;
-  const long r = (b * N + t) * W + (i >> 5);
-  const int rank = (int)pre[r] + __popc(bits[r] & ((1u << (i & 31)) - 1u));
-  order[offsets[b * N + t] + rank] = (int)e;
+  // XCD x (workgroups x, x + 8, ...) takes the clouds x, x + 8, ... one after the other: the bit rows and prefix counts
+  // an edge looks up are its cloud's (0.75 MB at N = 2048) and stay in that XCD's L2
+  const long epc = (long)N * K, nclouds = nedges / epc;
+  const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  for (long u = (long)(blockIdx.x >> 3) * 256 + threadIdx.x;; u += (long)per_xcd * 256) {
+    const long b = (u / epc) * 8 + xcd;
+    if (b >= nclouds) break;
+    const long e = b * epc + u % epc;
+    const int i = (int)((e / K) % N);
+    const int t = nn[e];
+    if (t < 0 || t >= N) continue;
+    const long r = (b * N + t) * W + (i >> 5);
+    const int rank = (int)pre[r] + __popc(bits[r] & ((1u << (i & 31)) - 1u));
+    order[offsets[b * N + t] + rank] = (int)e;
+  }
 }
 
 }  // namespace samble
@@ -659,7 +664,12 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
                        W, pre, tot);
   }
   hipLaunchKernelGGL(samble::inv_offsets_kernel, dim3(B), dim3(1024), 0, s, tot, N, K, offsets);
-  hipLaunchKernelGGL(samble::inv_place_kernel, dim3(blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets, order);
+  {  // one cloud per XCD and pass: 8 x ceil(N K / 256) workgroups (at most 4096)
+    const long per = ((long)N * K + 255) / 256;
+    const unsigned place_blocks = (unsigned)(8 * (per < 512 ? per : 512));
+    hipLaunchKernelGGL(samble::inv_place_kernel, dim3(place_blocks), dim3(256), 0, s, nn, N, K, W, nedges, bits, pre, offsets,
+                       order);
+  }
   return (int)hipGetLastError();
 }
 
