@@ -18,6 +18,10 @@
 //                   which keeps them a whole number of rounds: N/32 key waves per cloud, not N/32 + 1)
 #include "tri_dev.h"
 
+#ifndef SAMBLE_PREP_NT
+#define SAMBLE_PREP_NT 1  // the dQ clear of bwd_prep_tri: read again only by the projection backward, three map kernels later (A/B -0.7 %)
+#endif
+
 namespace samble {
 
 // ------------------------------------------------------------------------------------------------
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(256) void bwd_prep_tri_kernel(const float* __restri
     const int r0 = blockIdx.x * per, r1 = min(N, r0 + per);
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     for (int e = tid; e < (r1 - r0) * 32; e += 256)
-      *reinterpret_cast<f32x4*>(dQ + (long)b * dq_bs + (long)(r0 + (e >> 5)) * dq_rs + 4 * (e & 31)) = z4;
+      if (SAMBLE_PREP_NT) __builtin_nontemporal_store(z4, reinterpret_cast<f32x4*>(dQ + (long)b * dq_bs + (long)(r0 + (e >> 5)) * dq_rs + 4 * (e & 31)));
+      else *reinterpret_cast<f32x4*>(dQ + (long)b * dq_bs + (long)(r0 + (e >> 5)) * dq_rs + 4 * (e & 31)) = z4;
   }
   if (tid < 32) rows[tid] = idx[(long)b * M + min(m0 + tid, M - 1)];
   f32x4 vtok = {0.f, 0.f, 0.f, 0.f};  // this thread's four token-value words: into tk once the keys are done with
