@@ -33,6 +33,27 @@ def test_header_symbols_are_exported(lib):
     assert not [n for n in exported if re.search(r"debug|force|config|ablate", n)]
 
 
+def test_ctypes_signatures_have_the_arity_of_the_header(lib):
+    """Every prototype of include/samble.h against samble_amd/_lib.py's argument table: same number of parameters,
+    pointers bound as pointers (a drifted binding would push garbage through the C ABI without an error)."""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "samble.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|size_t|const char\s*\*)\s+(samble_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header)
+    assert len(protos) >= 60
+    seen = set()
+    for name, params in protos:
+        seen.add(name)
+        plist = [q.strip() for q in params.split(",")] if params.strip() not in ("", "void") else []
+        res, args = lib._SIGNATURES[name]
+        assert len(args) == len(plist), (name, len(args), plist)
+        for ctype, text in zip(args, plist):
+            is_ptr = "*" in text
+            bound_ptr = ctype in (ctypes.c_void_p, ctypes.c_char_p) or issubclass(ctype, ctypes._Pointer)
+            assert bound_ptr == is_ptr, (name, text, ctype)
+    assert seen == set(lib.EXPORTS)
+
+
 def test_library_loads_and_reports_version(lib):
     handle = lib.load()
     assert b"gfx950" in handle.samble_version()
