@@ -269,10 +269,11 @@ __global__ __launch_bounds__(256, 1) void proj_dw_kernel(const float* __restrict
 // dW[o][c] = sum over the per-chunk partials (fixed order) + the token rows' share
 //            sum_t gsum[t][o] * tokens[c][t]
 // 49 152 outputs x (B * chunks) partials = 50 MB at B = 32: bandwidth work, so every load must be in flight at
-// once.  Workgroup = 16 float4 columns x 16 partial groups: thread (e4, g) sums partials g, g + 16, g + 32, ...
-// (16 independent 16-byte loads in flight per round), the 16 group sums are added in index order through LDS.
+// once.  Workgroup = one output row (32 float4 columns = 512 contiguous bytes of every partial) x 8 partial groups: thread
+// (e4, g) sums partials g, g + 8, g + 16, ... (16 independent 16-byte loads in flight per round), the 8 group sums are
+// added in index order through LDS.  (Round 4: 16 columns x 16 groups read 256-byte pieces: 17.1 us against the row form.)
 // The token rows ride along (no launch of their own): every workgroup forms the gsum[t][o] of ITS output row o =
-// sum_b dqkv[b][N+t][o] (index order) while its partial loads are in flight, and workgroups kO * kC / 64 .. + nt - 1 are
+// sum_b dqkv[b][N+t][o] (index order) while its partial loads are in flight, and workgroups kO .. kO + nt - 1 are
 // the token workgroups: all of gsum[t][.] for one token t, then dtokens[c][t] = sum_o W[o][c] gsum[t][o] in three
 // parts of 128 outputs combined in part order (the arithmetic of the former proj_tok_bwd_kernel, bit for bit).
 struct TokGrad {
@@ -307,11 +308,11 @@ __device__ __forceinline__ float tok_gsum(const TokGrad& tg, int t, int o) {
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ part, int nparts,
                                                              const TokGrad tg, const float* __restrict__ tokens, int nt,
                                                              float* __restrict__ dW) {
-  __shared__ f32x4 red[16][17];
+  __shared__ f32x4 red[8][33];
   __shared__ float gs[kO];
   __shared__ float ps[3][kC];
-  if (blockIdx.x >= kO * kC / 64) {  // a token workgroup
-    const int t = blockIdx.x - kO * kC / 64, tid = threadIdx.x;
+  if (blockIdx.x >= kO) {  // a token workgroup
+    const int t = blockIdx.x - kO, tid = threadIdx.x;
     for (int o = tid; o < kO; o += 256) gs[o] = tok_gsum(tg, t, o);
     __syncthreads();
     // thread = (channel c, half): half 0 takes parts 0 and 2 of the 384 outputs, half 1 part 1; 16 W loads in flight
@@ -332,17 +333,19 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
     if (tid < kC) tg.dtok[tid * nt + t] = (ps[0][tid] + ps[1][tid]) + ps[2][tid];
     return;
   }
-  const int e4l = threadIdx.x & 15, g = threadIdx.x >> 4;
-  if (threadIdx.x < nt) gs[threadIdx.x] = tok_gsum(tg, threadIdx.x, (blockIdx.x * 64) / kC);  // (one output row per WG)
-  const int e4 = blockIdx.x * 16 + e4l;  // float4 column of the (384 x 128) matrix; grid covers it exactly
+  // one output ROW (128 floats = 512 contiguous bytes of every partial) per workgroup: thread (e4, g) = float4 column e4 of
+  // the row, partials g, g + 8, g + 16, ... with 16 loads in flight; the 8 group sums are added in index order through LDS
+  const int e4l = threadIdx.x & 31, g = threadIdx.x >> 5;
+  if (threadIdx.x < nt) gs[threadIdx.x] = tok_gsum(tg, threadIdx.x, blockIdx.x);
+  const int e4 = blockIdx.x * 32 + e4l;  // float4 column of the (384 x 128) matrix; grid covers it exactly
   const f32x4* p4 = reinterpret_cast<const f32x4*>(part) + e4;
   constexpr long kStride4 = (long)kO * kC / 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int p0 = g; p0 < nparts; p0 += 16 * 16) {
+  for (int p0 = g; p0 < nparts; p0 += 8 * 16) {
     f32x4 v[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      const int p = p0 + 16 * u;
+      const int p = p0 + 8 * u;
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
       v[u] = (p < nparts) ? p4[(long)p * kStride4] : z4;
     }
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
   if (g == 0) {
     f32x4 tot = red[0][e4l];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) tot += red[k][e4l];
-    const int c = (4 * e4) % kC;
+    for (int k = 1; k < 8; ++k) tot += red[k][e4l];
+    const int c = 4 * e4l;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       for (int t = 0; t < nt; ++t) tot[j] = fmaf(gs[t], tokens[(c + j) * nt + t], tot[j]);
@@ -437,7 +440,7 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
       hipLaunchKernelGGL(proj_dw_kernel, dim3(chunks, B), dim3(256), lds_dw, s, dqkv, g_bs, g_rs, x, x_bs, N, part);
     }
     const TokGrad tg{dqkv, g_bs, g_rs, B, N, proj_w(W, Wk, Wv), dtok};
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO * kC / 64 + nt), dim3(256), 0, s, part, B * chunks, tg, tokens, nt,
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3(kO + nt), dim3(256), 0, s, part, B * chunks, tg, tokens, nt,
                        dW);
   }
   return (int)hipGetLastError();
