@@ -190,7 +190,8 @@ int samble_gather_points_f32(const float* pcd, int B, int C, int N, const int64_
  * BatchNorm-1 into them (ap, bp: (B*N, 64) point-major).  nn (B,N,32) neighbour lists.  64 channels, K = 32.
  *   samble_edge_gather_sums_f32   S[p] = sum_k bp[j(p,k)], Q[p] = sum_k bp[j(p,k)]^2  (BN1 batch statistics and
  *                                 the backward's closed forms are built from these per-point sums)
- *   samble_edge_mlp_fwd_f32       y = W2 LReLU(ap_i + bp_j) per edge on the MFMA units; returns per (point,
+ *   samble_edge_mlp_fwd_f32       y = W2 LReLU(ap_i + bp_j) per edge on the matrix cores (fp32 operands as three bf16
+ *                                 planes, six products: fp32-equivalent sums; round 2-3: v_mfma_f32_32x32x2_f32); returns per (point,
  *                                 channel) max_k y and min_k y (LReLU o BN2 is monotone, so max_k commutes with
  *                                 it), the edge index that attains each (kmax, kmin; first one on ties) and
  *                                 samble_edge_partial_count() x (2,64) double partial sums of y, y^2
