@@ -389,6 +389,7 @@ __device__ __forceinline__ void stats_nl_epilogue(int h, f32x16& s_cur, float sc
     // (about 2) -- and pick the value out of the 16 registers by a select tree
     unsigned sub = __builtin_amdgcn_ubfe(mask, 4 * h, 4) | (__builtin_amdgcn_ubfe(mask, 8 + 4 * h, 4) << 4) |
                    (__builtin_amdgcn_ubfe(mask, 16 + 4 * h, 4) << 8) | (__builtin_amdgcn_ubfe(mask, 24 + 4 * h, 4) << 12);
+    if (SAMBLE_NL_ABL & 32) sub = 0;  // (timing only: no neighbour extraction)
     while (__any(sub != 0)) {
       const int r = __builtin_ctz(sub | 0x10000u) & 15;  // (lanes without a bit left pick register 0 and write nothing)
       const bool b0 = r & 1, b1 = r & 2, b2 = r & 4;
@@ -412,7 +413,8 @@ __device__ __forceinline__ void stats_nl_epilogue(int h, f32x16& s_cur, float sc
   // exponential (the sum only enters lse; both statistics kernels form it the same way)
   const float m2 = m * 1.4426950408889634f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) ps += __builtin_amdgcn_exp2f(fmaf(s_cur[r], 1.4426950408889634f, -m2));
+  for (int r = 0; r < 16; ++r)
+    ps += (SAMBLE_NL_ABL & 64) ? fmaf(s_cur[r], 1.4426950408889634f, -m2) : __builtin_amdgcn_exp2f(fmaf(s_cur[r], 1.4426950408889634f, -m2));
   l += ps;
 }
 

@@ -1,8 +1,10 @@
 """Timing-only ablations of attn_stats_nl_tri (tools/scratch/nlabl/lib_<mask>.so = the library built with
 -DSAMBLE_NL_ABL=<mask>: 8 the compiler's own operand-read placement, 16 half the K operand reads (every pair of k-steps
-shares one read: wrong logits), 2 no matrix products) against the shipped library, on the metric shapes with real
+shares one read: wrong logits), 2 no matrix products, 32 no neighbour-logit extraction, 64 no exponentials) against the
+shipped library, on the metric shapes with real
 images.  Build: see the loop at the end of tools/build_scratch_libs.sh; run on the GPU box."""
-import ctypes, glob, os
+import ctypes, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from samble_amd import ops, synth, _lib
 B, N, nt, K = 32, 2048, 6, 32

@@ -29,3 +29,5 @@ nl nomfma -DSAMBLE_NL_ABL=2
 nl halfreads -DSAMBLE_NL_ABL=16
 nl nobar -DSAMBLE_NL_NOBAR
 nl nobar_nomfma -DSAMBLE_NL_NOBAR -DSAMBLE_NL_ABL=2
+nl noextract -DSAMBLE_NL_ABL=32
+nl noexp -DSAMBLE_NL_ABL=64
