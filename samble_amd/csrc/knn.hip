@@ -262,6 +262,9 @@ __device__ __forceinline__ double pack_wj(float w, unsigned int j) {
 // queue and are inserted into the packed-double sorted list (w bits | index: ties by ascending index)
 // when any lane's queue is full.  No (B, Nk, Nq) key matrix (537 MB at B = 32, N = 2048).
 // ------------------------------------------------------------------------------------------------
+#ifndef SAMBLE_SMALLC_SPLIT
+#define SAMBLE_SMALLC_SPLIT 1  // K <= 8: the keys of a chunk dealt to the four waves of a workgroup (0: A/B builds)
+#endif
 constexpr int kSmallChunk = 512;  // keys per LDS chunk
 constexpr int kSmallQueue = 16;
 
@@ -363,9 +366,129 @@ __global__ __launch_bounds__(256) void knn_smallc_fused_kernel(const float* __re
   }
 }
 
+// The same search with the KEYS of every chunk dealt to the four waves of a workgroup (K <= 8: the interpolation's
+// K = 3).  A lane per query gives a batch of 32 x 2048 queries 1 024 waves -- one per SIMD, each walking all keys behind
+// its own LDS round trips (89 us for a search whose arithmetic is microseconds).  Here a workgroup is 64 queries x 4
+// waves, wave w scans keys 128 w .. 128 w + 127 of each 512-key chunk into its own sorted list, and wave 0 merges the
+// four lists of a query (packed (w, index) doubles: the same K entries in the same order as one list over all keys).
+template <int KN>
+__global__ __launch_bounds__(256) void knn_smallc_split_kernel(const float* __restrict__ xq, long q_bs, int Nq,
+                                                               const float* __restrict__ xk, long k_bs, int Nk, int C,
+                                                               int* __restrict__ idx_out, float* __restrict__ key_out) {
+  constexpr int Q = 8;  // queue slots per thread
+  __shared__ __attribute__((aligned(16))) float kx[8 * kSmallChunk];  // later: the four lists of every query (doubles)
+  __shared__ float qw[Q * 256];
+  __shared__ unsigned short qj[Q * 256];
+  static_assert(4 * 64 * KN * 8 <= 8 * kSmallChunk * 4, "merge buffer must fit the key chunk");
+  const int tid = threadIdx.x, b = blockIdx.y, wave = tid >> 6, lane = tid & 63;
+  const int i = blockIdx.x * 64 + lane;
+  const bool valid = i < Nq;
+  float q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) q[c] = (c < C && valid) ? xq[(long)b * q_bs + (long)c * Nq + i] : 0.f;
+  double L[KN];
+#pragma unroll
+  for (int s = 0; s < KN; ++s) L[s] = __builtin_huge_val();
+  float thr = __builtin_huge_valf();
+  int cnt = 0;
+  auto drain = [&]() {
+    for (int s = 0; s < Q; ++s) {
+      if (!__any(s < cnt)) break;
+      const double xd = (s < cnt) ? pack_wj(qw[s * 256 + tid], qj[s * 256 + tid]) : __builtin_huge_val();
+      insert_packed<KN>(L, xd);
+    }
+    cnt = 0;
+    thr = (float)L[KN - 1];
+  };
+  for (int j0 = 0; j0 < Nk; j0 += kSmallChunk) {
+    const int nj = min(kSmallChunk, Nk - j0);
+    __syncthreads();  // previous chunk fully consumed
+    for (int c = 0; c < C; ++c)
+      for (int e = tid; e < nj; e += 256) kx[c * kSmallChunk + e] = xk[(long)b * k_bs + (long)c * Nk + j0 + e];
+    __syncthreads();
+    const int w0 = min(wave * (kSmallChunk / 4), nj), w1 = min(w0 + kSmallChunk / 4, nj);  // this wave's keys of the chunk
+    const int n8 = w0 + ((w1 - w0) & ~7);
+    for (int jj = w0; jj < n8; jj += 8) {
+      float acc8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc8[u] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+          const f32x4 k0 = *reinterpret_cast<const f32x4*>(kx + c * kSmallChunk + jj);
+          const f32x4 k1 = *reinterpret_cast<const f32x4*>(kx + c * kSmallChunk + jj + 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d0 = q[c] - k0[u], d1 = q[c] - k1[u];
+            acc8[u] = fmaf(d0, d0, acc8[u]);
+            acc8[4 + u] = fmaf(d1, d1, acc8[4 + u]);
+          }
+        }
+      }
+      const float m8 = fminf(fminf(fminf(acc8[0], acc8[1]), fminf(acc8[2], acc8[3])),
+                             fminf(fminf(acc8[4], acc8[5]), fminf(acc8[6], acc8[7])));
+      if (!__any(valid && m8 <= thr)) continue;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (valid && acc8[u] <= thr) {
+          qw[cnt * 256 + tid] = acc8[u];
+          qj[cnt * 256 + tid] = (unsigned short)(j0 + jj + u);
+          ++cnt;
+        }
+        if (__any(cnt == Q)) drain();
+      }
+    }
+    for (int jj = n8; jj < w1; ++jj) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < C) {
+          const float d = q[c] - kx[c * kSmallChunk + jj];
+          acc = fmaf(d, d, acc);
+        }
+      }
+      if (valid && acc <= thr) {
+        qw[cnt * 256 + tid] = acc;
+        qj[cnt * 256 + tid] = (unsigned short)(j0 + jj);
+        ++cnt;
+      }
+      if (__any(cnt == Q)) drain();
+    }
+  }
+  drain();
+  __syncthreads();  // the last chunk is consumed: its LDS carries the lists now
+  double* mg = reinterpret_cast<double*>(kx);  // [wave][KN][64 lanes]
+#pragma unroll
+  for (int s = 0; s < KN; ++s) mg[(wave * KN + s) * 64 + lane] = L[s];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+#pragma unroll
+      for (int s = 0; s < KN; ++s) insert_packed<KN>(L, mg[(w * KN + s) * 64 + lane]);
+    if (valid) {
+      int* io = idx_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+      for (int s = 0; s < KN; ++s) io[s] = (int)(__double_as_longlong(L[s]) & 0x1FFFFFFFll);
+      if (key_out) {
+        float* ko = key_out + ((long)b * Nq + i) * KN;
+#pragma unroll
+        for (int s = 0; s < KN; ++s) ko[s] = (float)L[s];
+      }
+    }
+  }
+}
+
 template <int KN>
 static void launch_smallc_fused(const float* xq, long q_bs, int Nq, const float* xk, long k_bs, int Nk, int B, int C,
                                 int* idx, float* keys, hipStream_t s) {
+  if constexpr (KN <= 8) {
+    if (SAMBLE_SMALLC_SPLIT) {
+      hipLaunchKernelGGL(knn_smallc_split_kernel<KN>, dim3((Nq + 63) / 64, B), dim3(256), 0, s, xq, q_bs, Nq, xk, k_bs, Nk, C,
+                         idx, keys);
+      return;
+    }
+  }
   hipLaunchKernelGGL(knn_smallc_fused_kernel<KN>, dim3((Nq + 255) / 256, B), dim3(256), 0, s, xq, q_bs, Nq, xk, k_bs, Nk,
                      C, idx, keys);
 }
