@@ -432,6 +432,17 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* _
 
 constexpr int kETriBwdLds = 2 * kEImg + 2 * kEC * 4 + 8 * kEK * kEwPad * 4;  // 119 KB: one workgroup of 8 waves per CU
 
+#ifdef SAMBLE_STAMPS  // scratch builds only (tools/bench_edge_mlp.py --stamps): workgroup 0, every wave, its 3rd and 4th point
+__device__ unsigned long long g_edge_stamps[8 * 2 * 10];
+#define EDGE_STAMP(i)                                                                                           \
+  do {                                                                                                          \
+    if (blockIdx.x == 0 && lane == 0 && (pcount == 2 || pcount == 3))                                           \
+      g_edge_stamps[(wave * 2 + (pcount - 2)) * 10 + (i)] = __builtin_amdgcn_s_memtime();                       \
+  } while (0)
+#else
+#define EDGE_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __restrict__ ap, const float* __restrict__ bp,
                                                                const int* __restrict__ nn,
                                                                const float* __restrict__ W2,
@@ -457,7 +468,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < 2; ++c) dw[a][c] = zero16();
 
+  int pcount = -1;
   for (long p = gw; p < npoints; p += nw) {
+    ++pcount;
+    EDGE_STAMP(0);
     const long cloud = p / N;
     const int j = nn[p * kEK + lo];
     const float* arow = ap + p * kEC;
@@ -481,6 +495,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
         yt2[ot] = mfma_tri(ht, w, yt2[ot]);
       }
     }
+    EDGE_STAMP(1);
     // dy = c0 + c1 y + [edge == kext] sdv, in place, in both layouts
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
@@ -504,24 +519,8 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
         for (int r = 0; r < 16; ++r) yt2[ot][r] = fmaf(c1, yt2[ot][r], c0) + (crow(r, h) == ke ? sv : 0.f);
       }
     }
-    // dh^T tile ct: D[row = c][col = edge] = sum_o W2[o][c] dy[edge][o]; k-step (ot, gp) = registers 8 gp .. + 7 of yt1[ot]
-    f32x16 dht[2] = {zero16(), zero16()};
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = yt1[ot][8 * gp + i];
-        const Tri bq = tri_split8(v);
-        if (SAMBLE_EDGE_ABL & 4) {
-          dht[0][gp] += __uint_as_float(bq.h[0] ^ bq.m[1] ^ bq.l[2]);
-          continue;
-        }
-        dht[0] = mfma_tri(edge_frag(img2, 2 * ot + gp, lane), bq, dht[0]);
-        dht[1] = mfma_tri(edge_frag(img2, 4 + 2 * ot + gp, lane), bq, dht[1]);
-      }
-    }
+    EDGE_STAMP(2);
+    // (dW2 BEFORE dh: y[edge][o] dies here instead of living through the dh product -- 548 -> 468 us alone, round 4)
     // dW2[o][c] += sum_edge dy[edge][o] h[edge][c]: A = registers 8 kp .. + 7 of yt2[ot] (edges 16 kp + 8 (i >> 2) + 4 h +
     // (i & 3)), B = the same edges of the h tile's column c (same-wave LDS traffic needs no barrier)
 #pragma unroll
@@ -544,6 +543,26 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
         dw[ot][1] = mfma_tri(a, bq[1], dw[ot][1]);
       }
     }
+    EDGE_STAMP(3);
+    // dh^T tile ct: D[row = c][col = edge] = sum_o W2[o][c] dy[edge][o]; k-step (ot, gp) = registers 8 gp .. + 7 of yt1[ot]
+    f32x16 dht[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = yt1[ot][8 * gp + i];
+        const Tri bq = tri_split8(v);
+        if (SAMBLE_EDGE_ABL & 4) {
+          dht[0][gp] += __uint_as_float(bq.h[0] ^ bq.m[1] ^ bq.l[2]);
+          continue;
+        }
+        dht[0] = mfma_tri(edge_frag(img2, 2 * ot + gp, lane), bq, dht[0]);
+        dht[1] = mfma_tri(edge_frag(img2, 4 + 2 * ot + gp, lane), bq, dht[1]);
+      }
+    }
+    EDGE_STAMP(4);
     // du = dh * LReLU'(u), u = a' + b' at channel c = 32 ct + crow(r, h); written per edge.  The point's sum over its 32
     // edges (dusum): the tile goes through the wave's LDS tile (the h tile has been read by now) and lane = channel adds
     // its column in edge order -- 72 instructions where the DPP butterflies over the lanes took 400
@@ -561,6 +580,7 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
         *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * ct + 8 * g + 4 * h) = o4;
       }
     }
+    EDGE_STAMP(5);
     // the point's 32 x 64 block of du is 8 KB of consecutive addresses: out of the tile as whole lines, 1 KB per
     // instruction (16-byte pieces straight from the accumulator lanes would touch 32 lines per instruction, a quarter
     // of each)
@@ -571,12 +591,14 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
         *reinterpret_cast<f32x4*>(durow0 + 256 * it + 4 * lane) = v;
       }
     }
+    EDGE_STAMP(6);
     if (dusum && !(SAMBLE_EDGE_ABL & 8)) {  // (uniform)
       float rs = 0.f;
 #pragma unroll
       for (int e = 0; e < kEK; ++e) rs += hts[e * kEwPad + lane];
       dusum[p * kEC + lane] = rs;
     }
+    EDGE_STAMP(7);
   }
   // per-wave dW2 partial (64 x 64): tile [ot][ct] register r, lane (c = lo, h) <-> o = 32 ot + crow(r,h)
   if (gw < nw) {
@@ -593,6 +615,12 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
 }  // namespace samble
 
 using namespace samble;
+
+#ifdef SAMBLE_STAMPS
+extern "C" __attribute__((visibility("default"))) int samble_scratch_edge_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(samble::g_edge_stamps), sizeof(unsigned long long) * 160);
+}
+#endif
 
 extern "C" int samble_edge_waves(void) { return 2048; }  // persistent waves per sweep (512 workgroups x 4)
 

@@ -43,3 +43,13 @@ for path in sys.argv[1:]:
             e1.record(); torch.cuda.synchronize()
             out.append(e0.elapsed_time(e1) / 10 * 1e3)
     print(f"{os.path.basename(path):28s} kNN lists: fwd {out[0]:6.1f} bwd {out[1]:6.1f} us | local lists: fwd {out[2]:6.1f} bwd {out[3]:6.1f} us")
+    if hasattr(lib, "samble_scratch_edge_stamps"):  # a -DSAMBLE_STAMPS build: cycles between the marks of edge_mlp_bwd_tri
+        buf = (ctypes.c_ulonglong * 160)()
+        lib.samble_scratch_edge_stamps.argtypes = [vp]
+        assert lib.samble_scratch_edge_stamps(buf) == 0
+        v = list(buf)
+        names = ["gather + y (both)", "dy", "dW2", "dh", "du tile", "du stores", "dusum"]
+        for wv in range(8):
+            for it in range(2):
+                st_ = v[(wv * 2 + it) * 10:(wv * 2 + it) * 10 + 8]
+                print(f"  wave {wv} point {2 + it}: " + "  ".join(f"{names[i]} {st_[i + 1] - st_[i]}" for i in range(7)) + f"  | total {st_[7] - st_[0]}")
