@@ -115,26 +115,40 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
     for (int ks = 0; ks < 8; ++ks) {
       const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
       const Tri bq = {xq[3 * ks], xq[3 * ks + 1], xq[3 * ks + 2]};
-      acc = mfma_tri(a, bq, acc);
+      // amax: the operands swapped -- D[row = point crow(r, h)][col = output 32 t + lo] -- so that the maximum over the
+      // tile's points runs over a lane's REGISTERS (with the points on the lanes it took a DPP butterfly, two readlanes
+      // and a ballot per output row: 400 instructions per tile beside 48 MFMAs)
+      if (EPI == kLinAmax) {  // mfma_tri(a, bq)'s six products in its order, each with its operands swapped: the same sums
+        acc = mfma_bf(bq.m, a.m, acc);
+        acc = mfma_bf(bq.l, a.h, acc);
+        acc = mfma_bf(bq.h, a.l, acc);
+        acc = mfma_bf(bq.m, a.h, acc);
+        acc = mfma_bf(bq.h, a.m, acc);
+        acc = mfma_bf(bq.h, a.h, acc);
+      } else {
+        acc = mfma_tri(a, bq, acc);
+      }
     }
     if (EPI == kLinAmax) {
+      float m = acc[0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float hm = half_wave_max(acc[r]);
-        const float m0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(hm), 31));
-        const float m1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(hm), 63));
-        const float m = h ? m1 : m0;
-        const unsigned long long hit = __ballot(acc[r] == m);   // (a NaN row: no lane hits, index 0 of the tile)
-        const int a0 = __builtin_ctz((unsigned)hit | 0x80000000u) & 31;
-        const int a1 = __builtin_ctz((unsigned)(hit >> 32) | 0x80000000u) & 31;
-        const bool mine = (lo & 15) == r;
-        res_m = mine ? m : res_m;
-        res_a = mine ? (h ? a1 : a0) : res_a;
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+      int am = 99;  // the first of this half's 16 points that reaches m (crow(r, h) ascends with r); none (NaN): 99
+#pragma unroll
+      for (int r = 15; r >= 0; --r) am = (acc[r] == m) ? crow(r, h) : am;
+      const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      const auto pa = __builtin_amdgcn_permlane32_swap((unsigned)am, (unsigned)am, false, false);
+      const float mo = __uint_as_float(h ? pm[0] : pm[1]);  // the other half's maximum and argument
+      const int ao = (int)(h ? pa[0] : pa[1]);
+      res_m = fmaxf(m, mo);
+      const int a_me = (m == res_m) ? am : 99, a_ot = (mo == res_m) ? ao : 99;
+      res_a = min(a_me, a_ot);
+      res_a = res_a == 99 ? 0 : res_a;  // (a NaN column: index 0 of the tile)
+      if (h == 0) {  // one coalesced line per array
+        const long at = ptile * O + t * 32 + lo;
+        pmax[at] = res_m;
+        parg[at] = min(n_first + res_a, N - 1);
       }
-      // lanes (lo, h) and (lo + 16, h) hold row crow(lo & 15, h) of the tile: the same value to the same address
-      const long at = ptile * O + t * 32 + crow(lo & 15, h);
-      pmax[at] = res_m;
-      parg[at] = min(n_first + res_a, N - 1);
       asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
 #pragma unroll
