@@ -76,9 +76,16 @@ __global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __res
                                                               double* __restrict__ part) {
   const int hw = threadIdx.x >> 5, c2 = threadIdx.x & 31;
   double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  const long per = (npoints + gridDim.x - 1) / gridDim.x;
-  const long p0 = (long)blockIdx.x * per, p1 = min(p0 + per, npoints);
-  for (long p = p0 + hw; p < p1; p += 8) {
+  // XCD x (workgroups x, x + 8, ...) takes the clouds x, x + 8, ...: the 32 rows a point gathers are its cloud's, and an
+  // XCD's L2 then holds its own clouds' b rows (0.5 MB each) instead of a slice of every cloud of the batch
+  const long nclouds = npoints / N;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+  const bool by_xcd = (gridDim.x & 7) == 0 && nclouds * N == npoints;
+  const long mine = by_xcd ? ((nclouds - xcd + 7) / 8) * N : npoints;          // points of this XCD's clouds
+  const long per = (mine + (by_xcd ? per_xcd : (int)gridDim.x) - 1) / (by_xcd ? per_xcd : (int)gridDim.x);
+  const long u0 = (long)(by_xcd ? slot : (int)blockIdx.x) * per, u1 = min(u0 + per, mine);
+  for (long u = u0 + hw; u < u1; u += 8) {
+    const long p = by_xcd ? ((u / N) * 8 + xcd) * N + u % N : u;
     const long cloud = p / N;
     const int* ni = nn + p * kGK;
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
