@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict
                                                          const int* __restrict__ idx, const float* __restrict__ dist,
                                                          int N, int K, float* __restrict__ w_out,
                                                          float* __restrict__ out) {
-  const int b = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
+  int chunk, b;
+  xcd_assign(chunk, b);  // a cloud's workgroups on one XCD: the coarse rows they gather are that cloud's
+  const int n = chunk * 64 + (threadIdx.x & 63), cg = threadIdx.x >> 6;
   if (n >= N) return;
   int j[kIK];
   float w[kIK];
@@ -83,7 +85,9 @@ __global__ __launch_bounds__(256) void interp_bwd_rows_kernel(const float* __res
                                                               const float* __restrict__ w, const int* __restrict__ order,
                                                               const int* __restrict__ offsets, int K, int M,
                                                               float* __restrict__ dft) {
-  const int b = blockIdx.y, j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int j = chunk * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= M) return;
   const long t = (long)b * N + j;
   const int e0 = offsets[t], e1 = offsets[t + 1];
