@@ -339,11 +339,20 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
  * whenever it next synchronises, and switches to the stand-alone stage entries above:
  *   samble_sparse_score_map_quantiles_f32  = samble_sparse_score_map_f32 (models/downsample.py:300-344, score + z,
  *       in-degree) + samble_batch_quantiles_f32 (utils/ops.py:180-189) in two launches (accumulation; finalize +
- *       radix select with grid barriers).  quantiles_out (nb-1) or NULL (static boundaries: no quantiles).
- *   [the caller averages the quantiles over the ranks here, utils/ops.py:191-199]
+ *       radix select with grid barriers).  quantiles_out: NB floats -- the nb-1 quantiles and a validity count of 1.0 --
+ *       or NULL (static boundaries: no quantiles).  A give-up (below) leaves all nb floats at ZERO.
+ *   [the caller all-reduces (SUM) the nb floats over the ranks here, utils/ops.py:191-197: element nb-1 then holds the
+ *    number of ranks whose quantiles are valid -- the world size, unless a rank's chain gave up, whose zeros then
+ *    neither enter the mean nor count towards it]
  *   samble_bin_plan_f32  = samble_blend_boundaries_f32 (utils/ops.py:201-233; quantiles NULL: boundaries are used as
  *       they are) + samble_bin_assign_f32 + samble_alloc_counts_f32 (utils/ops.py:385-464) in one launch.  Must follow
  *       the call above on the same stream and workspace (it holds the barrier counters that call zeroed).
+ *       quantile_divisor (device pointer, may be NULL = 1): every quantile is DIVIDED by *quantile_divisor on its way
+ *       in -- utils/ops.py:199 `bin_boundaries / world_size` as the reference's true division, without a launch of its
+ *       own: pass quantiles + (nb - 1) after the all-reduce above.
+ *   Boundary state whose interior is NaN counts as "no state" in every entry that blends (this one, the one-launch chain,
+ *   samble_blend_boundaries_f32): the quantiles initialise it as on a first call.  A caller that allocates a first call's
+ *   state fills it with NaN, so that a chain which gave up before writing it leaves something the next call repairs.
  *   samble_select_chain_f32  = the two entries above in ONE launch, for a caller with nothing to exchange between them (a
  *       single rank): arguments as theirs (smap / lse / nn NULL when samble_attn_stats_nl_tri_f32 filled the workspace;
  *       want_quantiles 0: static boundaries).
@@ -368,8 +377,8 @@ int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, const float
                                           int KN, int mode, int nb, float* score, float* z, int32_t* indeg_out,
                                           float* quantiles_out, void* ws, size_t ws_bytes, unsigned int spin_budget,
                                           int32_t* host_status, void* stream);
-int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper, float* lower,
-                        int first, float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
+int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, const float* quantile_divisor,
+                        float* upper, float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb, int relu_first, int M,
                         uint8_t* member, int32_t* cap, float* w_pre, float* w, int32_t* counts, void* ws, size_t ws_bytes,
                         unsigned int spin_budget, int32_t* host_status, void* stream);
 

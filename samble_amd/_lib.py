@@ -55,7 +55,7 @@ _SIGNATURES = {
     "samble_sparse_score_map_quantiles_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_uint,
                                                       c_void_p, c_void_p]),
-    "samble_bin_plan_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
+    "samble_bin_plan_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_int,
                                     c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_uint, c_void_p, c_void_p]),
     "samble_select_chain_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,

@@ -44,13 +44,15 @@ class _Encoder(nn.Module):
         self.feature_learning_layer_list = nn.ModuleList(
             attention_cls(cfg.attention, i) for i in range(len(cfg.attention.K)))
 
-    def _run_sampler(self, i: int, feat, xyz, noise):
+    def _run_sampler(self, i: int, feat, xyz, noise, forced_idx=None):
         layer = self.downsample_list[i]
         if isinstance(layer, DownSampleToken):
-            return layer(feat, xyz, noise=noise)   # the selection noise is an explicit input (parity tests)
-        return layer(feat, xyz)
+            # the selection noise and (parity tests) the indices to gather are explicit inputs
+            return layer(feat, xyz, noise=noise, forced_idx=forced_idx)
+        return layer(feat, xyz, forced_idx=forced_idx)
 
-    def _encode(self, xyz: torch.Tensor, noise_list: Optional[Sequence], pre_select=None) -> List[_Level]:
+    def _encode(self, xyz: torch.Tensor, noise_list: Optional[Sequence], pre_select=None,
+                forced_idx_list: Optional[Sequence] = None) -> List[_Level]:
         stacked = []
         feat = xyz
         for edge_conv in self.embedding_list:      # each EdgeConv feeds the next; all of them are concatenated
@@ -63,7 +65,8 @@ class _Encoder(nn.Module):
             feat_in, xyz_in, remap = level.feat, level.xyz, None
             if pre_select is not None:             # farthest-point pre-selection in front of the sampler
                 feat_in, xyz_in, remap = pre_select(i, level)
-            (feat, picked), dropped = self._run_sampler(i, feat_in, xyz_in, noise)
+            forced = forced_idx_list[i] if forced_idx_list is not None else None
+            (feat, picked), dropped = self._run_sampler(i, feat_in, xyz_in, noise, forced)
             if remap is not None:
                 picked = torch.gather(remap.unsqueeze(1), 2, picked)
             level = _Level(self.feature_learning_layer_list[i + 1](feat), ops.gather_by_idx(level.xyz, picked),
@@ -111,9 +114,12 @@ class FeatureLearningBlock(_Encoder):
         return (torch.gather(level.feat, 2, take.expand(-1, level.feat.shape[1], -1)),
                 torch.gather(level.xyz, 2, take.expand(-1, 3, -1)), keep)
 
-    def forward(self, x, noise_list=None):
-        """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors."""
-        levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None)
+    def forward(self, x, noise_list=None, forced_idx_list=None):
+        """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors.  forced_idx_list: parity-test hook,
+        per sampler the indices to gather instead of its own selection (the samplers' `forced_idx`): everything
+        behind a sampler is then compared on the reference's own point set, whatever a near-tie did to the selection."""
+        levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None,
+                              forced_idx_list)
         if not self.res_link_enable:
             return _pooled_head(self.conv, levels[-1].feat)
         pooled = [_pooled_head(head, level.feat) for head, level in zip(self.conv_list, levels)]
@@ -136,8 +142,8 @@ class SegFeatureLearningBlock(_Encoder):
         self._build_encoder(cfg, Neighbor2PointAttention)
         self.upsample_list = nn.ModuleList(UpSampleInterpolation(cfg.upsample, i) for i in range(len(cfg.upsample.q_in)))
 
-    def forward(self, x, noise_list=None):
-        levels = self._encode(x, noise_list)
+    def forward(self, x, noise_list=None, forced_idx_list=None):
+        levels = self._encode(x, noise_list, forced_idx_list=forced_idx_list)
         first_decoder_layer = 1 + (len(self.feature_learning_layer_list) - 1) // 2
         coarse = levels[-1]
         for j, upsample in enumerate(self.upsample_list):

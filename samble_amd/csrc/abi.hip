@@ -92,7 +92,7 @@ int samble_launch_sparse_score_map_acc(const float*, int, const float*, const in
                                        hipStream_t);
 int samble_launch_score_quantiles(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*,
                                   float*, unsigned int, int*, hipStream_t);
-int samble_launch_bin_plan(const float*, const float*, int, const float*, float*, float*, int, float, float, int, int, int,
+int samble_launch_bin_plan(const float*, const float*, int, const float*, const float*, float*, float*, int, float, float, int, int, int,
                            int, int, unsigned char*, int*, float*, float*, int*, void*, unsigned int, int*, hipStream_t);
 int samble_launch_select_chain(const void*, const int*, const float*, int, int, int, int, float*, float*, int*, void*, float*,
                                const float*, int, float*, float*, int, float, float, int, int, unsigned char*, int*, float*,
@@ -810,8 +810,8 @@ SAMBLE_API int samble_sparse_score_map_quantiles_f32(const float* smap, int ld, 
               "samble_sparse_score_map_quantiles_f32");
 }
 
-SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles, float* upper,
-                                   float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb,
+SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, const float* quantiles,
+                                   const float* quantile_divisor, float* upper, float* lower, int first, float momentum, float one_minus_momentum, int B, int N, int nb,
                                    int relu_first, int M, uint8_t* member, int32_t* cap, float* w_pre, float* w,
                                    int32_t* counts, void* ws, size_t ws_bytes, unsigned int spin_budget, int32_t* host_status, void* stream) {
   if (!z || !tok || !upper || !lower || !member || !cap || !w_pre || !w || !counts || !ws)
@@ -822,7 +822,7 @@ SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, con
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: shape not taken by the fused chain (samble_select_chain_supported)");
   if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
     return fail(SAMBLE_E_WORKSPACE, "samble_bin_plan_f32: workspace too small");
-  return done(samble_launch_bin_plan(z, tok, nt, quantiles, upper, lower, first, momentum, one_minus_momentum, B, N, nb,
+  return done(samble_launch_bin_plan(z, tok, nt, quantiles, quantiles ? quantile_divisor : nullptr, upper, lower, first, momentum, one_minus_momentum, B, N, nb,
                                      relu_first, M, member, cap, w_pre, w, counts, (char*)ws + chain_score_bytes(B, N),
                                      spin_budget, host_status, (hipStream_t)stream),
               "samble_bin_plan_f32");

@@ -300,7 +300,8 @@ __device__ __forceinline__ bool score_quantiles_body(ChainLds& L, unsigned int* 
 // The nb-1 quantiles: quant (global; null with qbits null = static boundaries) or qbits (their ordered bits in LDS).
 __device__ __forceinline__ bool bin_plan_body(ChainLds& L, int b, int B, const float* __restrict__ z,
                                               const float* __restrict__ tok, int nt, const float* __restrict__ quant,
-                                              const unsigned int* qbits, float* upper, float* lower, int first,
+                                              const float* __restrict__ quant_div, const unsigned int* qbits,
+                                              float* upper, float* lower, int first,
                                               float mu, float one_minus_mu, int N, int nb, int relu_first, int M,
                                               unsigned char* __restrict__ member, int* cap, float* w_pre, float* w,
                                               int* __restrict__ counts, unsigned int* __restrict__ cws,
@@ -309,8 +310,14 @@ __device__ __forceinline__ bool bin_plan_body(ChainLds& L, int b, int B, const f
   float* up_s = L.up_s;
   float* lo_s = L.lo_s;
   const bool have_q = quant != nullptr || qbits != nullptr;
-  auto q_at = [&](int t) { return quant ? quant[t] : from_ordered_bits(qbits[t]); };
+  // quant_div: the rank average's divisor (reference utils/ops.py:199 `bin_boundaries / world_size`, a true division) --
+  // the all-reduced count of ranks whose quantiles are valid, i.e. the world size unless a rank's chain gave up
+  const float qd = (quant && quant_div) ? *quant_div : 1.f;
+  auto q_at = [&](int t) { return quant ? (quant_div ? quant[t] / qd : quant[t]) : from_ordered_bits(qbits[t]); };
   STAMP(20);
+  // a state that was allocated but never written (the first call's chain gave up: the host fills new state with NaN)
+  // counts as no state: the quantiles initialise it, as on a first call
+  if (have_q && nb >= 2 && upper[1] != upper[1]) first = 1;
   // ---- boundary state (blend_boundaries_kernel's arithmetic: two fp32 products, then the sum; no FMA in this file)
   if (tid < nb) {
     float u = upper[tid], l = lower[tid];
@@ -370,14 +377,21 @@ __global__ __launch_bounds__(1024) void score_quantiles_kernel(const unsigned lo
   __shared__ ChainLds L;
   const int b = blockIdx.x, B = gridDim.x;
   // (a give-up leaves the TIMEOUT word raised: bin_plan_kernel, which follows on the stream, bails on it)
+  // quant_out: nb floats -- the nb-1 quantiles and a validity count (1) that rides through the ranks' all-reduce with
+  // them; a give-up leaves all nb at zero: the sum over the ranks then carries only the healthy ranks' quantiles and
+  // their number, which bin_plan_kernel divides by
   if (!score_quantiles_body<PT>(L, qsm, b, B, colacc, indeg, rowstat, N, mode, nb, score, z, indeg_out, cws,
-                                quant_out != nullptr, budget))
+                                quant_out != nullptr, budget)) {
+    if (quant_out && b == 0 && (int)threadIdx.x < nb) quant_out[threadIdx.x] = 0.f;
     return;
-  if (quant_out && b == 0 && (int)threadIdx.x < nb - 1) quant_out[threadIdx.x] = from_ordered_bits(L.prefix[threadIdx.x]);
+  }
+  if (quant_out && b == 0 && (int)threadIdx.x < nb)
+    quant_out[threadIdx.x] = (int)threadIdx.x < nb - 1 ? from_ordered_bits(L.prefix[threadIdx.x]) : 1.f;
 }
 
 __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict__ z, const float* __restrict__ tok,
-                                                        int nt, const float* __restrict__ quant, float* upper,
+                                                        int nt, const float* __restrict__ quant,
+                                                        const float* __restrict__ quant_div, float* upper,
                                                         float* lower, int first, float mu, float one_minus_mu, int N,
                                                         int nb, int relu_first, int M,
                                                         unsigned char* __restrict__ member, int* cap, float* w_pre,
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(1024) void bin_plan_kernel(const float* __restrict_
   __shared__ ChainLds L;
   const int b = blockIdx.x, B = gridDim.x;
   const bool dead = __hip_atomic_load(cws + kChainFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // uniform
-  if (dead || !bin_plan_body(L, b, B, z, tok, nt, quant, nullptr, upper, lower, first, mu, one_minus_mu, N, nb, relu_first,
+  if (dead || !bin_plan_body(L, b, B, z, tok, nt, quant, quant_div, nullptr, upper, lower, first, mu, one_minus_mu, N, nb, relu_first,
                              M, member, cap, w_pre, w, counts, cws, budget))
     chain_bail(b, N, nb, M, member, cap, w_pre, w, counts);
 }
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(1024) void select_chain_kernel(const unsigned long 
     if (want_q && b == 0 && (int)threadIdx.x < nb - 1) quant_out[threadIdx.x] = from_ordered_bits(L.prefix[threadIdx.x]);
     // (this workgroup wrote its cloud's z itself: the barrier inside the body orders those stores before its loads)
     __syncthreads();
-    ok = bin_plan_body(L, b, B, z, tok, nt, nullptr, want_q ? L.prefix : nullptr, upper, lower, first, mu, one_minus_mu, N,
+    ok = bin_plan_body(L, b, B, z, tok, nt, nullptr, nullptr, want_q ? L.prefix : nullptr, upper, lower, first, mu, one_minus_mu, N,
                        nb, relu_first, M, member, cap, w_pre, w, counts, cws, budget);
   }
   if (!ok) chain_bail(b, N, nb, M, member, cap, w_pre, w, counts);
@@ -492,13 +506,14 @@ extern "C" int samble_launch_score_quantiles(const void* colacc, const int* inde
   return (int)hipGetLastError();
 }
 
-extern "C" int samble_launch_bin_plan(const float* z, const float* tok, int nt, const float* quant, float* upper,
+extern "C" int samble_launch_bin_plan(const float* z, const float* tok, int nt, const float* quant,
+                                      const float* quant_div, float* upper,
                                       float* lower, int first, float mu, float one_minus_mu, int B, int N, int nb,
                                       int relu_first, int M, unsigned char* member, int* cap, float* w_pre, float* w,
                                       int* counts, void* cws, unsigned int spin_budget, int* host_status, hipStream_t s) {
   const ChainCtl g_chain_budget = chain_budget(spin_budget, host_status);
   Timed timed(kT_bin_assign, s);
-  hipLaunchKernelGGL(bin_plan_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, quant, upper, lower, first, mu,
+  hipLaunchKernelGGL(bin_plan_kernel, dim3(B), dim3(1024), 0, s, z, tok, nt, quant, quant_div, upper, lower, first, mu,
                      one_minus_mu, N, nb, relu_first, M, member, cap, w_pre, w, counts, (unsigned int*)cws,
                      g_chain_budget);
   return (int)hipGetLastError();

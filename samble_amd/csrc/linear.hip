@@ -136,14 +136,23 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
       int am = 99;  // the first of this half's 16 points that reaches m (crow(r, h) ascends with r); none (NaN): 99
 #pragma unroll
       for (int r = 15; r >= 0; --r) am = (acc[r] == m) ? crow(r, h) : am;
+      // NaN propagates like torch's conv(x).max(dim=-1) (and the stock fallback): value NaN, argument = the first NaN
+      int an = 99;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) an = (acc[r] != acc[r]) ? crow(r, h) : an;
+      if (an != 99) {
+        m = __builtin_nanf("");
+        am = an;
+      }
       const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
       const auto pa = __builtin_amdgcn_permlane32_swap((unsigned)am, (unsigned)am, false, false);
       const float mo = __uint_as_float(h ? pm[0] : pm[1]);  // the other half's maximum and argument
       const int ao = (int)(h ? pa[0] : pa[1]);
-      res_m = fmaxf(m, mo);
-      const int a_me = (m == res_m) ? am : 99, a_ot = (mo == res_m) ? ao : 99;
+      const bool n_me = m != m, n_ot = mo != mo;
+      res_m = (n_me || n_ot) ? __builtin_nanf("") : fmaxf(m, mo);
+      const int a_me = (n_me || (!n_ot && m == res_m)) ? am : 99, a_ot = (n_ot || (!n_me && mo == res_m)) ? ao : 99;
       res_a = min(a_me, a_ot);
-      res_a = res_a == 99 ? 0 : res_a;  // (a NaN column: index 0 of the tile)
+      res_a = res_a == 99 ? 0 : res_a;
       if (h == 0) {  // one coalesced line per array
         const long at = ptile * O + t * 32 + lo;
         pmax[at] = res_m;
@@ -189,7 +198,8 @@ __global__ __launch_bounds__(256) void lin_amax_reduce_kernel(const float* __res
   for (int t = 1; t < ntiles; ++t) {
     const float v = pm[(long)t * O];
     const int av = pa[(long)t * O];
-    if (v > m || (v == m && av < a)) {
+    // (a NaN partial wins over every number and keeps the first tile that has one: torch's max)
+    if (m == m && (v != v || v > m || (v == m && av < a))) {
       m = v;
       a = av;
     }

@@ -221,6 +221,8 @@ __global__ void blend_boundaries_kernel(const float* __restrict__ quant, float* 
   const int t = threadIdx.x;
   if (t >= nb - 1) return;
   float v = quant[t];
+  // (a state of NaN was allocated and never written -- a first call whose fused chain gave up: no state)
+  if (!first && upper[1] != upper[1]) first = 1;
   if (!first) {
     const float a = upper[t + 1] * mu;
     const float b = one_minus_mu * v;

@@ -160,7 +160,7 @@ class _SamplerCore(torch.autograd.Function):
                     raise ops._lib.SambleError("the projection's images lack the backward pair although a gradient is wanted")
                 else:
                     imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=need_bwd)
-                chain = ops.chain_supported(B, N, nb) and not mod._chain_watch.timed_out()
+                chain = mod._chain_usable(B, N, nb)
                 # the pass also accumulates the score statistics of the K neighbour entries of every row
                 fused = N <= 8192   # LDS accumulators of the pass; longer clouds take the neighbour-logit array
                 sws = ops.score_workspace(B, N, nb if chain else None, x.device) if fused else None
@@ -176,16 +176,18 @@ class _SamplerCore(torch.autograd.Function):
                         mod.momentum_update_factor, mod.relu_mean_order == "relu_mean", mod.M, smap=nl,
                         compact=not fused, ws=sws, watch=mod._chain_watch)
                 elif chain:
+                    # two launches with the ranks' exchange between them (reference utils/ops.py:191-199): the nb-1
+                    # quantile sums travel with a validity count, bin_plan divides by it -- no launch for the `/ world`
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(nl, lse, nn_sorted, mod.idx_mode, nb,
                                                                             mod.dynamic_boundaries_enable,
                                                                             compact=not fused, ws=sws,
-                                                                            watch=mod._chain_watch)
+                                                                            watch=mod._chain_watch, counted=True)
                     if quant is not None:
-                        quant = ops.world_average(quant)
+                        quant = ops.world_sum(quant)
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
                                                                    mod.relu_mean_order == "relu_mean", mod.M, cws,
-                                                                   watch=mod._chain_watch)
+                                                                   watch=mod._chain_watch, counted=True)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(nl, lse, nn_sorted, mod.idx_mode, compact=not fused,
                                                                  ws=sws)
@@ -194,18 +196,18 @@ class _SamplerCore(torch.autograd.Function):
                 # S once into HBM; the sampled rows' P V (pass 2) and the backward re-read it
                 imgs = ops.stage_tri_split_qkv(qkv, N, for_backward=ctx.needs_input_grad[0]) if ops.MATRIX_MODE == "tri" else None
                 smap, lse, tok = ops.stage_attn_stats(q, k, N, nt, mod.asm, images=imgs[:2] if imgs else None)
-                if ops.chain_supported(B, N, nb) and not mod._chain_watch.timed_out():
+                if mod._chain_usable(B, N, nb):
                     # score + z + batch quantiles, then boundaries + bins + counts: two launches, the rank
                     # average of the quantiles (reference utils/ops.py:191-199) in between
                     score, z, indeg, quant, cws = ops.stage_score_quantiles(smap, lse, nn_idx, mod.idx_mode, nb,
                                                                             mod.dynamic_boundaries_enable,
-                                                                            watch=mod._chain_watch)
+                                                                            watch=mod._chain_watch, counted=True)
                     if quant is not None:
-                        quant = ops.world_average(quant)
+                        quant = ops.world_sum(quant)
                     mod.bin_boundaries, *plan = ops.stage_bin_plan(z, tok, quant, mod.bin_boundaries, nb,
                                                                    mod.momentum_update_factor,
                                                                    mod.relu_mean_order == "relu_mean", mod.M, cws,
-                                                                   watch=mod._chain_watch)
+                                                                   watch=mod._chain_watch, counted=True)
                 else:
                     score, z, indeg = ops.stage_sparse_score_map(smap, lse, nn_idx, mod.idx_mode)
             else:
@@ -363,6 +365,17 @@ class DownSampleToken(nn.Module):
             return None
         return ops._member_to_mask(self._member_bits, self.num_bins)
 
+    def _chain_usable(self, B: int, N: int, nb: int) -> bool:
+        """The fused select chain takes this shape and has not given up on this layer.  The call that first finds the
+        give-up word also repairs the state the give-up may have left: a chain that bails never writes the boundaries
+        (csrc/chain.hip), so after a later call they are the last valid ones; after a FIRST call they are still the NaN
+        they were allocated with -- back to "no boundaries yet" (one synchronising read, on this path only)."""
+        watch = self._chain_watch
+        if watch.poll() and self.dynamic_boundaries_enable and self.bin_boundaries is not None:
+            if bool(torch.isnan(self.bin_boundaries[0]).any()):
+                self.bin_boundaries = None
+        return ops.chain_supported(B, N, nb) and not watch.observed
+
     def forward(self, x, x_xyz=None, noise: Optional[torch.Tensor] = None, forced_idx: Optional[torch.Tensor] = None):
         """noise: the (B*nb, N) Exp(1) draw torch.multinomial makes inside (None: drawn on the device).
         forced_idx (B,1,M) | (B,M): parity-test hook -- gather these rows instead of the ones the selection produced
@@ -370,9 +383,12 @@ class DownSampleToken(nn.Module):
         B, C, N = x.shape
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
-        if not self._chain_watch.tripped and self._chain_watch.timed_out():
-            # raised ONCE, at the first call after the status word arrived; from here on the layer runs the stand-alone
-            # stage kernels (no grid barrier), so a caller that catches this and carries on gets valid results
+        self._chain_usable(B, N, self.num_bins)   # (looks at the mailbox; repairs the boundary state if it finds the word)
+        if self._chain_watch.observed and not self._chain_watch.reported:
+            # raised ONCE, at the first call after the status word arrived -- whichever call site saw it first; from
+            # here on the layer runs the stand-alone stage kernels (no grid barrier) on a boundary state that is either
+            # the last valid one or none (first call again), so a caller that catches this and carries on gets valid results
+            self._chain_watch.reported = True
             raise ops._lib.SambleError(
                 "SAMBLE_E_TIMEOUT: a grid barrier of the fused select chain gave up in an earlier forward of this layer "
                 "(its workgroups were not all resident); that forward's selection was a placeholder. The layer has "
@@ -386,10 +402,16 @@ class DownSampleToken(nn.Module):
         x_in = x
         if C < 128:
             # a narrower layer runs on the 128-channel kernels with zero channels behind its own: distances, logits and
-            # products are unchanged by them; the logits' 1 / sqrt(C) enters through W_q (the kernels divide by sqrt(128))
+            # products are unchanged by them; the logits' 1 / sqrt(C) enters through the weights (the kernels divide by
+            # sqrt(128)): dot: q.k is linear in W_q, which takes all of sqrt(128 / C); l2: -|q - k|^2 is quadratic in
+            # (q, k) TOGETHER, so W_q and W_k (token rows included: they go through W_k) take (128 / C)^(1/4) each
             pad = 128 - C
             grow = lambda w: F.pad(w, (0, 0, 0, pad, 0, pad))            # (C,C,1) -> (128,128,1)
-            wq, wk, wv = grow(wq * math.sqrt(128.0 / C)), grow(wk), grow(wv)
+            if self.asm == "l2":
+                s4 = (128.0 / C) ** 0.25
+                wq, wk, wv = grow(wq * s4), grow(wk * s4), grow(wv)
+            else:
+                wq, wk, wv = grow(wq * math.sqrt(128.0 / C)), grow(wk), grow(wv)
             tokens = F.pad(tokens, (0, 0, 0, pad))                      # (1,C,nt) -> (1,128,nt)
             x = F.pad(x, (0, 0, 0, pad))                                # (B,C,N) -> (B,128,N)
         # (B, N+nt, 3D) point-major rows [Q|K|V]; rows N.. are the bin tokens

@@ -198,10 +198,13 @@ class _LinearMax(torch.autograd.Function):
         return dx, dW.reshape(W.shape[0], 128, 1)
 
 
+MAX_OUT_CHANNELS = 4096   # csrc/abi.hip lin_shape_ok: wider layers take the stock Conv1d path, as documented
+
+
 def ffn_supported(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> bool:
     return (x.is_cuda and x.dim() == 3 and x.shape[1] == 128 and w1.dim() == 3 and w2.dim() == 3 and w1.shape[1] == 128
             and w1.shape[2] == 1 and w2.shape[2] == 1 and w2.shape[0] == 128 and w2.shape[1] == w1.shape[0]
-            and w1.shape[0] % 256 == 0 and x.dtype == torch.float32)
+            and w1.shape[0] % 256 == 0 and w1.shape[0] <= MAX_OUT_CHANNELS and x.dtype == torch.float32)
 
 
 def ffn(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
@@ -213,7 +216,8 @@ def ffn(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
 
 def linear_max_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
     return (x.is_cuda and x.dim() == 3 and x.shape[1] == 128 and w.dim() == 3 and w.shape[1] == 128 and w.shape[2] == 1
-            and w.shape[0] % 32 == 0 and x.shape[2] + 3 * w.shape[0] < 36000 and x.dtype == torch.float32)
+            and w.shape[0] % 32 == 0 and w.shape[0] <= MAX_OUT_CHANNELS and x.shape[2] + 3 * w.shape[0] < 36000
+            and x.dtype == torch.float32)
 
 
 def linear_max(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:

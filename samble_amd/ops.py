@@ -753,11 +753,12 @@ def chain_supported(B: int, N: int, num_bins: int) -> bool:
 
 
 def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, compact: bool = False,
-                          ws=None, watch=None):
+                          ws=None, watch=None, counted: bool = False):
     """stage_sparse_score_map + stage_batch_quantiles in two launches (compact / smap None + ws: as in
     stage_sparse_score_map; then it is ONE launch).
     -> score (B,N), z (B,N), in-degree (B,N) int32, quantiles (nb-1,) or None, chain workspace (hand it to
-    stage_bin_plan)."""
+    stage_bin_plan).  counted: the quantiles come as the kernel writes them, (nb,) = the nb-1 quantiles and a validity
+    count of 1.0 (all zeros if the chain gave up) -- what `world_sum` exchanges and stage_bin_plan(counted=True) takes."""
     if idx_mode not in SCORE_MODES:
         raise ValueError("Please check the setting of idx mode!")
     _need_gpu(lse, nn_idx)
@@ -775,7 +776,7 @@ def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_
         score = torch.empty((B, N), dtype=torch.float32, device=lse.device)
         z = torch.empty_like(score)
         indeg = torch.empty((B, N), dtype=torch.int32, device=lse.device)
-        quant = torch.empty((num_bins - 1,), dtype=torch.float32, device=lse.device) if want_quantiles else None
+        quant = torch.empty((num_bins,), dtype=torch.float32, device=lse.device) if want_quantiles else None
         nbytes = _lib.query("samble_select_chain_workspace_bytes", B, N)
         if smap is not None:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=lse.device)
@@ -783,6 +784,8 @@ def stage_score_quantiles(smap, lse, nn_idx, idx_mode: str, num_bins: int, want_
         _lib.call("samble_sparse_score_map_quantiles_f32", _p(smap), ld, lse.data_ptr(), nn_idx.data_ptr(), B, N,
                   nn_idx.shape[2], SCORE_MODES[idx_mode], num_bins, score.data_ptr(), z.data_ptr(), indeg.data_ptr(),
                   _p(quant), ws.data_ptr(), ws.numel(), CHAIN_SPIN_BUDGET, _mailbox(watch), _stream())
+    if quant is not None and not counted:
+        quant = quant[:num_bins - 1]
     return score, z, indeg, quant, ws
 
 
@@ -794,30 +797,72 @@ CHAIN_SPIN_BUDGET = 0
 class ChainWatch:
     """The fused select chain's status, watched without a synchronisation and without a copy: one int32 in pinned host
     memory that a grid barrier which gives up sets to 1 with a system-scope store (include/samble.h `host_status`); the
-    host looks at it before the NEXT chain launch, or any time through `timed_out()`.  1 = SAMBLE_E_TIMEOUT: the barrier's
-    workgroups were not all resident and the step that ran it produced placeholder selections -- the watch then stays
-    tripped and the caller uses the stand-alone stage kernels (stage_sparse_score_map, stage_batch_quantiles, ...)."""
+    host looks at it before the NEXT chain launch (`poll`), or any time through `timed_out()`.  1 = SAMBLE_E_TIMEOUT: the
+    barrier's workgroups were not all resident and the step that ran it produced placeholder selections -- the watch then
+    stays `observed` and the caller uses the stand-alone stage kernels (stage_sparse_score_map, stage_batch_quantiles,
+    ...).  `observed` (the word was seen; switches the chain off) and `reported` (the layer has raised for it; owned by
+    DownSampleToken.forward) are separate, so that whichever call site sees the word first, the error is raised once."""
 
     def __init__(self):
         self.flag = None
-        self.tripped = False
+        self.observed = False
+        self.reported = False
+
+    # the mailbox is pinned host memory the kernels store to: a copy of the module (copy.deepcopy for an EMA / SWA
+    # model, pickling) must not carry a pageable clone of it -- the copy starts without one and pins its own lazily
+    def __getstate__(self):
+        return {"observed": self.observed, "reported": self.reported}
+
+    def __setstate__(self, state):
+        self.flag = None
+        self.observed = bool(state.get("observed", False))
+        self.reported = bool(state.get("reported", False))
+
+    def __deepcopy__(self, memo):
+        twin = ChainWatch()
+        twin.observed, twin.reported = self.observed, self.reported
+        return twin
+
+    @property
+    def tripped(self) -> bool:
+        return self.observed
+
+    @tripped.setter
+    def tripped(self, value: bool) -> None:
+        self.observed = bool(value)
 
     def host_ptr(self) -> int:
-        if self.flag is None:
+        if self.flag is None or not self.flag.is_pinned():
             self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
         return self.flag.data_ptr()
 
-    def timed_out(self, sync: bool = False) -> bool:
+    def poll(self, sync: bool = False) -> bool:
+        """True exactly once: at the call that finds the word raised."""
         if sync:
             torch.cuda.synchronize()
         if self.flag is not None and int(self.flag[0]) != 0:
-            self.tripped = True
             self.flag[0] = 0
-        return self.tripped
+            fresh = not self.observed
+            self.observed = True
+            return fresh
+        return False
+
+    def timed_out(self, sync: bool = False) -> bool:
+        self.poll(sync)
+        return self.observed
 
 
 def _mailbox(watch: Optional["ChainWatch"]):
     return None if watch is None else watch.host_ptr()
+
+
+def _fresh_boundary_state(nb: int, dev) -> List[torch.Tensor]:
+    """The two (1,1,1,nb) tensors of a first dynamic call, for a kernel to fill.  NaN, not uninitialised: a fused chain
+    that gives up (csrc/chain.hip chain_bail) leaves the state unwritten, and every blending kernel takes a NaN state
+    for "no state yet" (include/samble.h) -- so the next call initialises it from its quantiles, like the reference's
+    first call (utils/ops.py:214-233), instead of blending garbage for ever.  One (2, nb) fill, first call only."""
+    both = torch.full((2, 1, 1, 1, nb), float("nan"), dtype=torch.float32, device=dev)
+    return [both[0], both[1]]
 
 
 def stage_select_chain(lse, tok_logits, nn_idx, idx_mode: str, num_bins: int, want_quantiles: bool, boundaries,
@@ -843,7 +888,7 @@ def stage_select_chain(lse, tok_logits, nn_idx, idx_mode: str, num_bins: int, wa
     if first:
         if not want_quantiles:
             raise ValueError("static boundaries must be given")
-        boundaries = [torch.empty((1, 1, 1, nb), dtype=torch.float32, device=dev) for _ in range(2)]
+        boundaries = _fresh_boundary_state(nb, dev)
     else:
         boundaries = [boundaries[0].detach(), boundaries[1].detach()]
         if not all(t.is_contiguous() and t.dtype == torch.float32 and t.device == dev for t in boundaries):
@@ -878,10 +923,12 @@ def single_rank() -> bool:
 
 
 def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum_update_factor: float, relu_first: bool,
-                   M: int, ws, watch=None):
+                   M: int, ws, watch=None, counted: bool = False):
     """blend_boundaries + stage_bin_assign + stage_alloc_counts in one launch (`ws` from stage_score_quantiles).
     quantiles None: `boundaries` are used as they are (static); else they are initialised (boundaries None) or
-    blended IN PLACE (reference utils/ops.py:201-233).
+    blended IN PLACE (reference utils/ops.py:201-233).  counted: `quantiles` is the (nb,) tensor of
+    stage_score_quantiles(counted=True) after `world_sum`: the kernel divides the nb-1 sums by element nb-1, the
+    number of ranks that contributed (utils/ops.py:199's `/ world_size` without a launch of its own).
     -> boundaries [upper, lower], member (B,N) uint8, cap (B,nb), w_pre (B,nb), w (B,nb), counts (B,nb) int32."""
     _need_gpu(z, tok_logits)
     z, tok_logits = _f32c(z), _f32c(tok_logits)
@@ -892,11 +939,17 @@ def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum
     if first:
         if quantiles is None:
             raise ValueError("static boundaries must be given")
-        boundaries = [torch.empty((1, 1, 1, nb), dtype=torch.float32, device=dev) for _ in range(2)]
+        boundaries = _fresh_boundary_state(nb, dev)
     else:
         boundaries = [boundaries[0].detach(), boundaries[1].detach()]
         if not all(t.is_contiguous() and t.dtype == torch.float32 and t.device == dev for t in boundaries):
             boundaries = [t.to(device=dev, dtype=torch.float32).contiguous() for t in boundaries]
+    qd = None
+    if quantiles is not None:
+        quantiles = _f32c(quantiles)
+        if counted:
+            assert quantiles.numel() == nb
+            qd = quantiles.data_ptr() + 4 * (nb - 1)
     with torch.cuda.device(dev):
         member = torch.empty((B, N), dtype=torch.uint8, device=dev)
         cap = torch.empty((B, nb), dtype=torch.int32, device=dev)
@@ -904,8 +957,7 @@ def stage_bin_plan(z, tok_logits, quantiles, boundaries, num_bins: int, momentum
         w = torch.empty_like(w_pre)
         counts = torch.empty((B, nb), dtype=torch.int32, device=dev)
         _lib.call("samble_bin_plan_f32", z.data_ptr(), tok_logits.data_ptr(), tok_logits.shape[-1],
-                  _p(_f32c(quantiles)) if quantiles is not None else None, boundaries[0].data_ptr(),
-                  boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
+                  _p(quantiles), qd, boundaries[0].data_ptr(), boundaries[1].data_ptr(), int(first), float(momentum_update_factor),
                   float(1 - momentum_update_factor), B, N, nb, int(bool(relu_first)), int(M), member.data_ptr(),
                   cap.data_ptr(), w_pre.data_ptr(), w.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
                   CHAIN_SPIN_BUDGET, _mailbox(watch), _stream())
@@ -1180,6 +1232,15 @@ def world_average(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def world_sum(t: torch.Tensor) -> torch.Tensor:
+    """The exchange step of utils/ops.py:191-197 alone: all_reduce(SUM), in place, when a process group exists.  The
+    division by the world size is the consumer's (stage_bin_plan(counted=True) divides by the all-reduced validity
+    count inside its kernel)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(t)
+    return t
+
+
 def blend_boundaries(old: Optional[List[torch.Tensor]], quantiles: torch.Tensor, num_bins: int,
                      momentum_update_factor: float) -> List[torch.Tensor]:
     """utils/ops.py:201-233 on the (already rank-averaged) nb-1 quantiles: first call stores them,
@@ -1187,7 +1248,7 @@ def blend_boundaries(old: Optional[List[torch.Tensor]], quantiles: torch.Tensor,
     if quantiles.is_cuda:  # one HIP launch instead of five tiny tensor ops
         first = old is None
         if first:
-            new = [torch.empty((1, 1, 1, num_bins), dtype=torch.float32, device=quantiles.device) for _ in range(2)]
+            new = _fresh_boundary_state(num_bins, quantiles.device)
         else:
             new = [old[0].detach(), old[1].detach()]
             if not (new[0].is_contiguous() and new[1].is_contiguous() and new[0].dtype == torch.float32):

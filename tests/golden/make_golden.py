@@ -93,6 +93,9 @@ CASES = [
     dict(name="cls_c64_random", cfg="cls", B=2, N=256, M=128, calls=2, big=True, C=64),
     # ... and a 256-channel one (no 256-channel attention kernels: DownSampleToken._forward_wide)
     dict(name="cls_c256_random", cfg="cls", B=2, N=256, M=128, calls=1, big=True, C=256),
+    # round 5: the narrow layer with l2 logits: -|q - k|^2 / sqrt(C) is quadratic in (q, k), the 1 / sqrt(C) cannot ride
+    # on W_q alone the way it does for dot logits
+    dict(name="cls_c64_l2_random", cfg="cls", B=2, N=256, M=128, calls=1, big=True, C=64, asm="l2"),
 ]
 
 

@@ -12,16 +12,48 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_cls_block_protocol_against_reference():
-    from samble_amd.blocks import FeatureLearningBlock, block_config
-    d = layer_fixture("block_cls_small")
+def _reference_block(kind: str):
+    """(fixture, a fresh block with the fixture's parameters on the device, xyz, noise_list)."""
+    from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
+    d = layer_fixture(f"block_{kind}_small")
     B, N, M0, M1, nb, seed = [int(v) for v in d["meta"]]
-    blk = FeatureLearningBlock(block_config("cls", M=(M0, M1)))
+    blk = (FeatureLearningBlock(block_config("cls", M=(M0, M1))) if kind == "cls"
+           else SegFeatureLearningBlock(seg_block_config(M=(M0, M1))))
     assert [n for n, _ in blk.named_parameters()] == [str(n) for n in d["names"]], "state_dict layout differs"
     fill_parameters(blk, seed)
     blk = blk.to(DEV).train()
     xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500)).to(DEV)
     noise = [torch.from_numpy(d["noise0"]).to(DEV), torch.from_numpy(d["noise1"]).to(DEV)]
+    return d, blk, xyz, noise
+
+
+def _stored_rows(grad: torch.Tensor, stored: np.ndarray) -> torch.Tensor:
+    """make_golden_block.py keeps every 8th output row of the wide matrices."""
+    g = grad.detach().cpu()
+    return g[::8] if g.shape != stored.shape else g
+
+
+def _compare_gradients(blk, d, rel_max, label):
+    params = dict(blk.named_parameters())
+    keys = [k for k in d.files if k.startswith("grad/")]
+    assert len(keys) >= 12
+    worst = {}
+    for k in keys:
+        ref = torch.from_numpy(d[k])
+        got = _stored_rows(params[k[5:]].grad, d[k])
+        assert got.shape == ref.shape, k
+        worst[k[5:]] = float((got - ref).abs().max() / ref.abs().max())
+    print(f"{label}: gradient max|err| / max|ref| per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if not v <= rel_max}
+    assert not bad, bad
+
+
+def test_cls_block_protocol_against_reference():
+    """Own selection: the sampled sets against the reference's (a near-tie may flip single indices: reported).
+    Then UNCONDITIONALLY, through the reference's indices (`forced_idx_list`): the block's output and the gradients
+    of 13 parameters spread over the block, against the unmodified reference block's."""
+    d, blk, xyz, noise = _reference_block("cls")
+    B, N, M0, M1, nb, seed = [int(v) for v in d["meta"]]
     feat, res = blk(xyz, noise_list=noise)
     assert feat.shape == (B, 3 * 1024) and len(res) == 3
     ds0, ds1 = blk.downsample_list
@@ -29,18 +61,20 @@ def test_cls_block_protocol_against_reference():
     idx0, idx1 = ds0.idx.cpu()[:, 0], ds1.idx.cpu()[:, 0]
     ref0, ref1 = torch.from_numpy(d["idx0"])[:, 0], torch.from_numpy(d["idx1"])[:, 0]
     assert idx0.shape == (B, M0) and idx1.shape == (B, M1)
+    same0, same1 = int((idx0 == ref0).all(1).sum()), int((idx1 == ref1).all(1).sum())
+    print(f"cls block, own selection: clouds with the reference's exact index tensor: layer 0 {same0}/{B}, "
+          f"layer 1 {same1}/{B}; set agreement {set_agreement(idx0, ref0):.4f} / {set_agreement(idx1, ref1):.4f}")
     # three layers of fp32 arithmetic feed the first sampler, five the second: sets agree, order mostly
     assert set_agreement(idx0, ref0) >= 0.97, set_agreement(idx0, ref0)
-    if bool((idx0 == ref0).all()):
-        assert set_agreement(idx1, ref1) >= 0.9
-        if bool((idx1 == ref1).all()):
-            torch.testing.assert_close(feat.detach().cpu(), torch.from_numpy(d["feat"]), rtol=2e-3, atol=2e-3)
-    # the block trains: gradients reach the first EdgeConv through both samplers
-    feat.sum().backward()
-    g = blk.embedding_list[0].conv1[0].weight.grad
-    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
-    for ds in (ds0, ds1):
-        assert ds.bin_tokens.grad is not None and torch.isfinite(ds.bin_tokens.grad).all()
+
+    d, blk, xyz, noise = _reference_block("cls")
+    forced = [torch.from_numpy(d["idx0"]).to(DEV), torch.from_numpy(d["idx1"]).to(DEV)]
+    feat, res = blk(xyz, noise_list=noise, forced_idx_list=forced)
+    assert torch.equal(blk.downsample_list[0].idx.cpu(), torch.from_numpy(d["idx0"]))
+    assert torch.equal(blk.downsample_list[1].idx.cpu(), torch.from_numpy(d["idx1"]))
+    torch.testing.assert_close(feat.detach().cpu(), torch.from_numpy(d["feat"]), rtol=2e-3, atol=2e-3)
+    feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)).to(DEV))
+    _compare_gradients(blk, d, 5e-3, "cls block")
 
 
 def test_cls_block_metric_size_forward_backward():
@@ -58,29 +92,32 @@ def test_cls_block_metric_size_forward_backward():
 
 def test_seg_block_protocol_against_reference():
     """BASELINE.json configs[2] geometry at a small size: the segmentation block (down 256 -> 128 -> 64 with
-    4 bins, interpolation upsampling back to 256) against the unmodified reference block's fixture."""
-    from samble_amd.blocks import SegFeatureLearningBlock, seg_block_config
-    d = layer_fixture("block_seg_small")
+    4 bins, interpolation upsampling back to 256) against the unmodified reference block's fixture: own selection
+    reported, output and 13 gradients compared unconditionally through the reference's indices."""
+    d, blk, xyz, noise = _reference_block("seg")
     B, N, M0, M1, nb, seed = [int(v) for v in d["meta"]]
-    blk = SegFeatureLearningBlock(seg_block_config(M=(M0, M1)))
-    assert [n for n, _ in blk.named_parameters()] == [str(n) for n in d["names"]], "state_dict layout differs"
-    fill_parameters(blk, seed)
-    blk = blk.to(DEV).train()
-    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500)).to(DEV)
-    noise = [torch.from_numpy(d["noise0"]).to(DEV), torch.from_numpy(d["noise1"]).to(DEV)]
     feat = blk(xyz, noise_list=noise)
     assert feat.shape == (B, 128, N) and torch.isfinite(feat).all()
     idx0, idx1 = blk.downsample_list[0].idx.cpu()[:, 0], blk.downsample_list[1].idx.cpu()[:, 0]
     ref0, ref1 = torch.from_numpy(d["idx0"])[:, 0], torch.from_numpy(d["idx1"])[:, 0]
+    same0, same1 = int((idx0 == ref0).all(1).sum()), int((idx1 == ref1).all(1).sum())
+    print(f"seg block, own selection: clouds with the reference's exact index tensor: layer 0 {same0}/{B}, "
+          f"layer 1 {same1}/{B}; set agreement {set_agreement(idx0, ref0):.4f} / {set_agreement(idx1, ref1):.4f}")
     assert set_agreement(idx0, ref0) >= 0.97, set_agreement(idx0, ref0)
-    if bool((idx0 == ref0).all()) and bool((idx1 == ref1).all()):
-        # interpolation weights 1/(d+1e-8) are huge at coinciding points, where the reference's cdist
-        # (mm path) returns rounding noise instead of 0: compare away from the sampled points
-        ref_feat = torch.from_numpy(d["feat"])
-        err = (feat.detach().cpu() - ref_feat).abs()
-        assert float(err.median()) <= 5e-3 and float((err > 0.1).float().mean()) <= 0.05
-    feat.square().mean().backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+
+    d, blk, xyz, noise = _reference_block("seg")
+    forced = [torch.from_numpy(d["idx0"]).to(DEV), torch.from_numpy(d["idx1"]).to(DEV)]
+    feat = blk(xyz, noise_list=noise, forced_idx_list=forced)
+    # interpolation weights 1/(d+1e-8) are huge at coinciding points (every coarse point IS a fine point), where the
+    # reference's cdist (mm path) returns rounding noise of ~1e-4 instead of 0 and the kernel returns 0: the blend at
+    # such a point differs by the other two neighbours' share, ~1e-3 of the feature scale, and BatchNorm spreads it
+    ref_feat = torch.from_numpy(d["feat"])
+    err = (feat.detach().cpu() - ref_feat).abs()
+    print(f"seg block: feat max|err| {float(err.max()):.3e}, median {float(err.median()):.3e} "
+          f"(max|ref| {float(ref_feat.abs().max()):.3e})")
+    assert float(err.median()) <= 5e-3 and float((err > 0.1).float().mean()) <= 0.05
+    feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)).to(DEV))
+    _compare_gradients(blk, d, 5e-2, "seg block")
 
 
 def test_seg_block_metric_size_forward_backward():

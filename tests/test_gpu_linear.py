@@ -129,6 +129,27 @@ def test_linear_max_against_conv_max(B, N, O):
     assert torch.equal(y2, y) and torch.equal(arg2, arg) and torch.equal(xg2.grad, xg.grad) and torch.equal(wb.grad, w.grad)
 
 
+def test_linear_max_propagates_nan_like_torch():
+    """A NaN activation must not be masked by the pooled head: conv(x).max(dim=-1) (models/cls_model.py:113) returns NaN
+    for every output of a cloud that has a NaN point, with the FIRST NaN point as the argument -- the fused pass does
+    the same; the other clouds are untouched.  A wider head than the kernels take reports unsupported (stock path)."""
+    from samble_amd import linear as L
+    B, N, O = 3, 300, 256
+    w = _w((O, 128, 1), 81, 0.09).to(DEV)
+    x = torch.from_numpy(synth.features(B, 128, N, 82)).to(DEV)
+    y0, a0 = L._LinearMax.apply(x, w)
+    x_bad = x.clone()
+    x_bad[1, 5, 170] = float("nan")     # poisons every output channel of cloud 1 at point 170 ...
+    x_bad[1, 9, 233] = float("nan")     # ... and at point 233, in another tile and wave half
+    y, arg = L._LinearMax.apply(x_bad, w)
+    yr, ar = torch.nn.functional.conv1d(x_bad, w).max(dim=-1)
+    assert bool(torch.isnan(yr[1]).all()) and bool((ar[1] == 170).all())
+    assert bool(torch.isnan(y[1]).all()) and bool((arg[1].long() == 170).all())
+    assert torch.equal(y[0], y0[0]) and torch.equal(y[2], y0[2]) and torch.equal(arg[0], a0[0]) and torch.equal(arg[2], a0[2])
+    assert not L.linear_max_supported(x, torch.zeros((8192, 128, 1), device=DEV))
+    assert not L.ffn_supported(x, torch.zeros((8192, 128, 1), device=DEV), torch.zeros((128, 8192, 1), device=DEV))
+
+
 @pytest.mark.parametrize("B,C,N,O", [(2, 64, 300, 128), (3, 3, 2048, 128), (1, 6, 77, 256), (2, 100, 513, 128)])
 def test_linear_rows_with_fewer_input_channels(B, C, N, O):
     """linear_rows: x (B, C <= 128, N) -> (B, N, O) = (W x)^T, the per-point projections of EdgeConv's conv1

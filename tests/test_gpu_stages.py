@@ -945,11 +945,12 @@ def test_select_chain_gives_up_cleanly_and_the_layer_falls_back():
     i = idx[:, 0].cpu()
     assert int(i.min()) >= 0 and int(i.max()) < N and all(len(set(r.tolist())) == M for r in i)   # placeholders, but valid
     assert bool((mod.k_point_to_choose.cpu()[:, 0] == M).all()) and torch.isfinite(x_ds).all()
+    assert mod.bin_boundaries is not None and bool(torch.isnan(mod.bin_boundaries[0][0, 0, 0, 1:]).all())  # never written
     with pytest.raises(_lib.SambleError, match="SAMBLE_E_TIMEOUT"):
         mod(x, noise=noise)
-    assert mod._chain_watch.tripped
-    mod.bin_boundaries = None                              # (the timed-out call left the state untouched or half-made)
-    (x_ds2, idx2), _ = mod(x, noise=noise)                 # stage kernels now
+    assert mod._chain_watch.tripped and mod._chain_watch.reported
+    assert mod.bin_boundaries is None                      # the give-up of a FIRST call leaves no state: first call again
+    (x_ds2, idx2), _ = mod(x, noise=noise)                 # stage kernels now; no second raise
     ref = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
     ref.load_state_dict(mod.state_dict())
     ref._chain_watch.tripped = True                        # a layer that never takes the chain
@@ -959,6 +960,68 @@ def test_select_chain_gives_up_cleanly_and_the_layer_falls_back():
     good.load_state_dict(mod.state_dict())
     (x_ds4, idx4), _ = good(x, noise=noise)
     assert torch.equal(idx4, idx3) and torch.equal(x_ds4, x_ds3) and not good._chain_watch.timed_out(sync=True)
+    # a give-up in a LATER call leaves the boundaries of the last good call, bit for bit; and the word is reported once even
+    # when the sampler core's own look at the mailbox (before its chain launch) is the call site that finds it
+    before = [t.clone() for t in good.bin_boundaries]
+    try:
+        ops().CHAIN_SPIN_BUDGET = 0xFFFFFFFF
+        good(x, noise=noise)
+        torch.cuda.synchronize()
+    finally:
+        ops().CHAIN_SPIN_BUDGET = 0
+    assert torch.equal(good.bin_boundaries[0], before[0]) and torch.equal(good.bin_boundaries[1], before[1])
+    assert good._chain_usable(B, N, nb) is False and good._chain_watch.observed and not good._chain_watch.reported
+    with pytest.raises(_lib.SambleError, match="SAMBLE_E_TIMEOUT"):
+        good(x, noise=noise)
+    (x_ds5, idx5), _ = good(x, noise=noise)
+    assert torch.equal(good.bin_boundaries[0][0, 0, 0, 0:1].cpu(), torch.tensor([float("inf")]))
+    assert bool(torch.isfinite(good.bin_boundaries[0][0, 0, 0, 1:]).all())
+    # a copy of the module (EMA / SWA) does not share or clone the pinned mailbox
+    import copy
+    twin = copy.deepcopy(mod)
+    assert twin._chain_watch.flag is None and twin._chain_watch.observed
+    fresh = copy.deepcopy(ref)
+    fresh._chain_watch.tripped = False
+    (x_ds6, idx6), _ = fresh(x, noise=noise)               # pins its own mailbox and runs the chain
+    torch.cuda.synchronize()
+    assert fresh._chain_watch.flag is not None and fresh._chain_watch.flag.is_pinned()
+
+
+def test_give_up_on_one_rank_does_not_reach_the_others_quantiles():
+    """Two-launch form (the multi-rank path): score_quantiles writes (nb,) = quantiles + a validity count of 1; a give-up
+    writes zeros.  bin_plan divides the all-reduced sums by the all-reduced count: with one of two "ranks" dead the
+    healthy rank's boundaries are exactly its own quantiles (sum / 1), with both alive the mean (sum / 2) as the
+    reference's `all_reduce; / world_size` (utils/ops.py:191-199)."""
+    o_ = ops()
+    B, N, nb, M, K = 4, 512, 6, 256, 32
+    gen = torch.Generator().manual_seed(4)
+    lse = torch.randn(B, N, generator=gen).to(DEV)
+    tok = torch.randn(B, N, nb, generator=gen).to(DEV)
+    nn = torch.stack([torch.stack([torch.randperm(N, generator=gen)[:K] for _ in range(N)]) for _ in range(B)]).int().to(DEV)
+    smap = torch.randn(B, N, N + nb, generator=gen).to(DEV)
+    score, z, indeg, q_ok, cws = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", nb, True, counted=True)
+    assert q_ok.shape == (nb,) and float(q_ok[-1]) == 1.0
+    try:
+        o_.CHAIN_SPIN_BUDGET = 0xFFFFFFFF
+        _, _, _, q_dead, cws_dead = o_.stage_score_quantiles(smap, lse + 1.0, nn, "sparse_col_sqr", nb, True, counted=True)
+        torch.cuda.synchronize()
+    finally:
+        o_.CHAIN_SPIN_BUDGET = 0
+    assert torch.equal(q_dead.cpu(), torch.zeros(nb))
+    # "all-reduce" of a healthy and a dead rank, seen from the healthy one
+    summed = q_ok + q_dead
+    st, *_ = o_.stage_bin_plan(z, tok, summed, None, nb, 0.99, False, M, cws, counted=True)
+    assert torch.equal(st[0][0, 0, 0, 1:], q_ok[:-1]) and torch.equal(st[1][0, 0, 0, :-1], q_ok[:-1])
+    # two healthy ranks with different quantiles: the reference's expression, bit for bit (also for a divisor of 3)
+    for world in (2, 3):
+        other = q_ok.clone()
+        other[:-1] += 0.125
+        summed = q_ok.clone()
+        for _ in range(world - 1):
+            summed = summed + other
+        _, _, _, _, cws2 = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", nb, True, counted=True)
+        st2, *_ = o_.stage_bin_plan(z, tok, summed, None, nb, 0.99, False, M, cws2, counted=True)
+        assert torch.equal(st2[0][0, 0, 0, 1:], summed[:-1] / world)
 
 
 @pytest.mark.parametrize("B,N,nt,M,K", [(2, 256, 6, 128, 32), (3, 1000, 4, 333, 16), (32, 2048, 6, 1024, 32),
