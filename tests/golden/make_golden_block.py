@@ -38,6 +38,8 @@ GRAD_KEYS_SEG = ("embedding_list.0.conv1.0.weight", "downsample_list.0.bin_token
                  "downsample_list.1.bin_tokens", "downsample_list.1.q_conv.weight",
                  "feature_learning_layer_list.1.q_conv.weight", "feature_learning_layer_list.2.ff.2.weight",
                  "feature_learning_layer_list.3.k_conv.weight", "feature_learning_layer_list.4.bn2.bias",
+                 # (layers 2 and 3's bn2.bias are left out: the BatchNorm of the upsampling layer behind them removes
+                 # a constant, their true gradient is zero and what the reference returns is rounding noise)
                  "feature_learning_layer_list.4.ff.2.weight", "upsample_list.0.conv.0.weight",
                  "upsample_list.1.res_conv.0.weight", "upsample_list.1.res_conv.1.weight")
 ROW_STRIDE = 8   # wide matrices are stored every 8th output row (the fixture stays small)
@@ -52,61 +54,87 @@ def grads_of(blk, keys):
     return {"grad/" + k: thin(params[k].grad.detach().numpy()) for k in keys}
 
 
-def main():
-    torch.set_num_threads(8)
-    B, N, M, seed = 2, 256, [128, 64], 9100
-    cfg = block_config("cls")
+def reference_block(kind, seed, B, N, M, threads=8, mkldnn=True, exact_cdist=False):
+    """The unmodified reference block, forward + backward, under one of two equally valid fp32 evaluations of the same
+    code (8 threads with oneDNN, or 1 thread without: other summation orders inside the same ATen ops).
+    exact_cdist: torch.cdist in its compute_mode "donot_use_mm_for_euclid_dist" for the duration of the call -- the
+    reference source is untouched, ATen evaluates sqrt(sum((a - b)^2)) instead of sqrt(|a|^2 + |b|^2 - 2 a.b)."""
+    from models import seg_model as ref_seg
+    torch.set_num_threads(threads)
+    torch.backends.mkldnn.enabled = mkldnn
+    aten_cdist = torch.cdist
+    if exact_cdist:
+        torch.cdist = lambda a, b, *args, **kw: aten_cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist")
+    try:
+        return _reference_block(kind, seed, B, N, M, ref_seg)
+    finally:
+        torch.cdist = aten_cdist
+        torch.set_num_threads(8)
+        torch.backends.mkldnn.enabled = True
+
+
+def _reference_block(kind, seed, B, N, M, ref_seg):
+    cfg = block_config(kind)
     cfg.downsample.M = list(M)
-    blk = ref_cls.FeatureLearningBlock(cfg)
+    blk = (ref_cls if kind == "cls" else ref_seg).FeatureLearningBlock(cfg)
     fill_parameters(blk, seed)
     blk.train()
     xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500))
-    nb = cfg.downsample.bin.num_bins[0]
     torch.manual_seed(seed)
-    feat, res = blk(xyz)
+    out = blk(xyz)
+    feat = out[0] if kind == "cls" else out
     feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)))   # the test's upstream gradient
+    return cfg, blk, feat
+
+
+def self_noise(blk, other, keys):
+    """max |g - g'| / max |g| per stored gradient between the two evaluations: what "the reference's gradient" means to
+    no better than this.  Where a hidden unit sits within rounding of a LeakyReLU kink, or two edges tie for a pooled
+    maximum, the gradient is a coin toss between ANY two fp32 evaluations (seed 9100: 2e-3 on
+    feature_learning_layer_list.0.ff.0.weight and 3e-4 upstream of it; some seeds flip a sampled index): the fixture's
+    seed is one where the reference agrees with itself to 5e-5 everywhere and samples the same indices."""
+    a, b = dict(blk.named_parameters()), dict(other.named_parameters())
+    return np.array([float((a[k].grad - b[k].grad).abs().max() / a[k].grad.abs().max()) for k in keys], dtype=np.float64)
+
+
+def make(kind, seed, keys):
+    B, N, M = 2, 256, [128, 64]
+    cfg, blk, feat = reference_block(kind, seed, B, N, M)
+    _, twin, feat2 = reference_block(kind, seed, B, N, M, threads=1, mkldnn=False)
+    for a, b in zip(blk.downsample_list, twin.downsample_list):
+        assert torch.equal(a.idx, b.idx), "the reference's own two evaluations sample different points: choose another seed"
+    noise_floor = self_noise(blk, twin, keys)
+    assert noise_floor.max() < 5e-5, ("choose another seed", dict(zip(keys, noise_floor)))
+    nb = cfg.downsample.bin.num_bins[0]
     torch.manual_seed(seed)
     noise0 = O.draw_noise(B * nb, N)
     noise1 = O.draw_noise(B * nb, M[0])
     out = dict(meta=np.array([B, N, M[0], M[1], nb, seed], dtype=np.int64), feat=feat.detach().numpy(),
-               **grads_of(blk, GRAD_KEYS_CLS),
+               **grads_of(blk, keys), grad_keys=np.array(list(keys)), grad_self_noise=noise_floor,
+               feat_self_noise=np.array(float((feat - feat2).abs().max())),
                noise0=noise0.numpy(), noise1=noise1.numpy(),
                idx0=blk.downsample_list[0].idx.numpy(), idx1=blk.downsample_list[1].idx.numpy(),
                score0=blk.downsample_list[0].attention_point_score.detach().numpy(),
                names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__))
-    path = os.path.join(HERE, "block_cls_small.npz")
+    if kind == "seg":
+        # The interpolation layers weigh neighbours by 1 / (d + 1e-8) (models/upsample.py:205-213) and every coarse point
+        # IS a fine point: d = 0 there.  ATen's default cdist (|a|^2 + |b|^2 - 2 a.b) returns ~1e-3 of rounding noise
+        # instead, so the reference blends ~1 % of the two other neighbours in at those points, an amount no other
+        # evaluation of the same expression reproduces.  Second set of outputs with cdist in its exact mode (d = 0 at
+        # coinciding points, as the HIP search computes it): what the reference computes when that noise is out.
+        _, blk_x, feat_x = reference_block(kind, seed, B, N, M, exact_cdist=True)
+        out.update({k.replace("grad/", "exact/grad/"): v for k, v in grads_of(blk_x, keys).items()})
+        out.update({"exact/feat": feat_x.detach().numpy(), "exact/idx0": blk_x.downsample_list[0].idx.numpy(),
+                    "exact/idx1": blk_x.downsample_list[1].idx.numpy()})
+        print("   exact-cdist run: indices equal to the default run:",
+              [bool(torch.equal(a.idx, b.idx)) for a, b in zip(blk.downsample_list, blk_x.downsample_list)],
+              "feat max|diff| %.3e" % float((feat - feat_x).abs().max()))
+    path = os.path.join(HERE, f"block_{kind}_small.npz")
     np.savez_compressed(path, **out)
-    print("block_cls_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()))
-
-
-def seg_main():
-    """The segmentation block (models/seg_model.py:7-133, seg.yaml: down 256 -> 128 -> 64, interpolation up)."""
-    from models import seg_model as ref_seg
-    torch.set_num_threads(8)
-    B, N, M, seed = 2, 256, [128, 64], 9300
-    cfg = block_config("seg")
-    cfg.downsample.M = list(M)
-    blk = ref_seg.FeatureLearningBlock(cfg)
-    fill_parameters(blk, seed)
-    blk.train()
-    xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500))
-    nb = cfg.downsample.bin.num_bins[0]
-    torch.manual_seed(seed)
-    feat = blk(xyz)
-    feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)))
-    torch.manual_seed(seed)
-    noise0 = O.draw_noise(B * nb, N)
-    noise1 = O.draw_noise(B * nb, M[0])
-    out = dict(meta=np.array([B, N, M[0], M[1], nb, seed], dtype=np.int64), feat=feat.detach().numpy(),
-               **grads_of(blk, GRAD_KEYS_SEG),
-               noise0=noise0.numpy(), noise1=noise1.numpy(),
-               idx0=blk.downsample_list[0].idx.numpy(), idx1=blk.downsample_list[1].idx.numpy(),
-               names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__))
-    path = os.path.join(HERE, "block_seg_small.npz")
-    np.savez_compressed(path, **out)
-    print("block_seg_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()))
+    print(f"block_{kind}_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()),
+          "; gradient self-noise max %.1e" % noise_floor.max())
 
 
 if __name__ == "__main__":
-    main()
-    seg_main()
+    make("cls", 9114, GRAD_KEYS_CLS)   # (9100, the seed of rounds 2-4, sits on a LeakyReLU kink: see self_noise)
+    make("seg", 9300, GRAD_KEYS_SEG)

@@ -33,17 +33,21 @@ def _stored_rows(grad: torch.Tensor, stored: np.ndarray) -> torch.Tensor:
     return g[::8] if g.shape != stored.shape else g
 
 
-def _compare_gradients(blk, d, rel_max, label):
+def _compare_gradients(blk, d, rel_max, label, norm="max", prefix="grad/"):
+    """norm "max": max|err| / max|ref| per tensor; "l2": |err|_2 / |ref|_2."""
     params = dict(blk.named_parameters())
-    keys = [k for k in d.files if k.startswith("grad/")]
+    keys = [k for k in d.files if k.startswith(prefix)]
     assert len(keys) >= 12
     worst = {}
     for k in keys:
         ref = torch.from_numpy(d[k])
-        got = _stored_rows(params[k[5:]].grad, d[k])
+        name = k[len(prefix):]
+        got = _stored_rows(params[name].grad, d[k])
         assert got.shape == ref.shape, k
-        worst[k[5:]] = float((got - ref).abs().max() / ref.abs().max())
-    print(f"{label}: gradient max|err| / max|ref| per tensor:", {k: f"{v:.1e}" for k, v in worst.items()})
+        worst[name] = float((got - ref).abs().max() / ref.abs().max()) if norm == "max" else \
+            float((got - ref).norm() / ref.norm())
+    print(f"[{norm}]", f"{label}: gradient error per tensor:", {k: f"{v:.1e}" for k, v in worst.items()},
+          f"(the reference against itself under another summation order: <= {float(d['grad_self_noise'].max()):.1e})")
     bad = {k: v for k, v in worst.items() if not v <= rel_max}
     assert not bad, bad
 
@@ -74,7 +78,7 @@ def test_cls_block_protocol_against_reference():
     assert torch.equal(blk.downsample_list[1].idx.cpu(), torch.from_numpy(d["idx1"]))
     torch.testing.assert_close(feat.detach().cpu(), torch.from_numpy(d["feat"]), rtol=2e-3, atol=2e-3)
     feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)).to(DEV))
-    _compare_gradients(blk, d, 5e-3, "cls block")
+    _compare_gradients(blk, d, 2e-4, "cls block")
 
 
 def test_cls_block_metric_size_forward_backward():
@@ -117,7 +121,20 @@ def test_seg_block_protocol_against_reference():
           f"(max|ref| {float(ref_feat.abs().max()):.3e})")
     assert float(err.median()) <= 5e-3 and float((err > 0.1).float().mean()) <= 0.05
     feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)).to(DEV))
-    _compare_gradients(blk, d, 5e-2, "seg block")
+    # gradients: the same noise at the coinciding points perturbs LeakyReLU kinks and BatchNorm statistics of the decoder,
+    # and through them every gradient (the interpolation layer's own fixture has the same bound,
+    # test_upsample_interpolation_against_reference_fixture): relative L2 per tensor
+    _compare_gradients(blk, d, 6e-2, "seg block", norm="l2")
+    # ... and STRICTLY against the same unmodified reference block with ATen's cdist in its exact mode (d = 0 at coinciding
+    # points, which is what csrc/knn.hip computes): with that one source of noise out, output and gradients agree like
+    # the classification block's (tests/golden/make_golden_block.py: the default and the exact run sample the same points)
+    assert torch.equal(torch.from_numpy(d["exact/idx0"]), torch.from_numpy(d["idx0"]))
+    assert torch.equal(torch.from_numpy(d["exact/idx1"]), torch.from_numpy(d["idx1"]))
+    exact_feat = torch.from_numpy(d["exact/feat"])
+    print(f"seg block vs the exact-cdist reference: feat max|err| {float((feat.detach().cpu() - exact_feat).abs().max()):.3e}"
+          f" (the two reference runs differ by {float((ref_feat - exact_feat).abs().max()):.3e})")
+    torch.testing.assert_close(feat.detach().cpu(), exact_feat, rtol=2e-3, atol=2e-3)
+    _compare_gradients(blk, d, 5e-4, "seg block vs the exact-cdist reference", prefix="exact/grad/")
 
 
 def test_seg_block_metric_size_forward_backward():

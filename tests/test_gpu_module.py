@@ -65,9 +65,10 @@ def test_module_against_reference_fixture(name, matrix_mode):
         # two measured mechanisms below.
         same = (idx.cpu()[:, 0] == g.t("idx", call)[:, 0]).all(1)
         pinned = _pinned_identity(matrix_mode, name, call)
-        if pinned is not None:
-            lost = [b for b in range(g.B) if pinned[b] and not bool(same[b])]
-            assert not lost, f"clouds {lost} were identical to the reference when the table was pinned"
+        assert pinned is not None, (f"{matrix_mode}/{name} has no row in tests/expected_identity.json: run "
+                                    "tools/fixture_identity.py on the GPU box and commit its output")
+        lost = [b for b in range(g.B) if pinned[b] and not bool(same[b])]
+        assert not lost, f"clouds {lost} were identical to the reference when the table was pinned"
         counts_same = (mod.k_point_to_choose.cpu() == g.t("counts", call)).all(1)
         for b in range(g.B):
             if bool(same[b]):
@@ -213,7 +214,9 @@ def test_metric_size_properties_and_determinism():
     print(f"\nmetric size B={B} N={N}->{M}: clouds with the oracle's exact index tensor {int(same_rows.sum())} of {B}; "
           f"positions identical {pos:.5f}; sampled-set agreement {agree:.5f}")
     assert agree >= 0.995, agree
-    assert int(same_rows.sum()) >= B // 2, int(same_rows.sum())
+    # measured: 28-29 of 32 on every box of rounds 3-5 (the three that differ: one truncation flip of the float
+    # water-filling or one near-tie of two selection keys each, asserted below); floor = measured - 2
+    assert int(same_rows.sum()) >= 26, int(same_rows.sum())
     for b in range(B):   # a cloud that differs does so by a handful of points (near-ties of keys / one count flip)
         assert len(set(idx[b, 0].tolist()) ^ set(idx_ref[b, 0].tolist())) <= 8, b
     torch.testing.assert_close(x_ds.cpu()[same_rows], x_ref[same_rows], rtol=1e-4, atol=2e-5)

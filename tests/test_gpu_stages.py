@@ -953,7 +953,7 @@ def test_select_chain_gives_up_cleanly_and_the_layer_falls_back():
     (x_ds2, idx2), _ = mod(x, noise=noise)                 # stage kernels now; no second raise
     ref = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
     ref.load_state_dict(mod.state_dict())
-    ref._chain_watch.tripped = True                        # a layer that never takes the chain
+    ref._chain_watch.observed = ref._chain_watch.reported = True   # a layer that never takes the chain
     (x_ds3, idx3), _ = ref(x, noise=noise)
     assert torch.equal(idx2, idx3) and torch.equal(x_ds2, x_ds3)
     good = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)   # and the chain itself, with its real budget
@@ -978,13 +978,23 @@ def test_select_chain_gives_up_cleanly_and_the_layer_falls_back():
     assert bool(torch.isfinite(good.bin_boundaries[0][0, 0, 0, 1:]).all())
     # a copy of the module (EMA / SWA) does not share or clone the pinned mailbox
     import copy
-    twin = copy.deepcopy(mod)
-    assert twin._chain_watch.flag is None and twin._chain_watch.observed
-    fresh = copy.deepcopy(ref)
-    fresh._chain_watch.tripped = False
-    (x_ds6, idx6), _ = fresh(x, noise=noise)               # pins its own mailbox and runs the chain
+    import pickle
+    twin = copy.deepcopy(mod._chain_watch)
+    assert twin.flag is None and twin.observed and twin.reported
+    assert pickle.loads(pickle.dumps(mod._chain_watch)).flag is None
+    donor = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+    donor.load_state_dict(mod.state_dict())
+    with torch.no_grad():
+        donor(x, noise=noise)                              # its mailbox is pinned now
+    assert donor._chain_watch.flag is not None and donor._chain_watch.flag.is_pinned()
+    donor.attention_bins_beforesoftmax = None              # (plain tensor attributes deep-copy; nothing else is in the way)
+    fresh = copy.deepcopy(donor)
+    assert fresh._chain_watch.flag is None
+    with torch.no_grad():
+        (x_ds6, idx6), _ = fresh(x, noise=noise)           # pins its own mailbox and runs the chain
     torch.cuda.synchronize()
     assert fresh._chain_watch.flag is not None and fresh._chain_watch.flag.is_pinned()
+    assert fresh._chain_watch.flag.data_ptr() != donor._chain_watch.flag.data_ptr()
 
 
 def test_give_up_on_one_rank_does_not_reach_the_others_quantiles():
@@ -1021,7 +1031,9 @@ def test_give_up_on_one_rank_does_not_reach_the_others_quantiles():
             summed = summed + other
         _, _, _, _, cws2 = o_.stage_score_quantiles(smap, lse, nn, "sparse_col_sqr", nb, True, counted=True)
         st2, *_ = o_.stage_bin_plan(z, tok, summed, None, nb, 0.99, False, M, cws2, counted=True)
-        assert torch.equal(st2[0][0, 0, 0, 1:], summed[:-1] / world)
+        # (true division, as ATen's CPU kernel -- the oracle's -- does it; ATen's CUDA kernel multiplies by 1 / world: the
+        # same bits for the power-of-two world sizes a node has)
+        assert torch.equal(st2[0][0, 0, 0, 1:].cpu(), summed[:-1].cpu() / world)
 
 
 @pytest.mark.parametrize("B,N,nt,M,K", [(2, 256, 6, 128, 32), (3, 1000, 4, 333, 16), (32, 2048, 6, 1024, 32),
