@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = min(m0 + 8 * k + (lane >> 3), M - 1);
-    prow8[k] = a.smap + ((long)b * M + r) * a.ld + 4 * ((lane & 7) ^ (lane >> 3));
+    prow8[k] = a.smap + (map_cloud(b, 0) * M + r) * a.ld + 4 * ((lane & 7) ^ (lane >> 3));
   }
   auto stage_tile = [&](const char* img, char* ring, int t) {  // 6 pieces per thread
     const char* src = img + (long)min(t, ntiles - 1) * kTriTile;
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void bwd_dq_pm_tri_kernel(const DqTriArgs a) {
       for (int g = 0; g < 4; ++g)
         p4[g] = *reinterpret_cast<const f32x4*>(sw + (lo >> 3) * 1024 + (lo & 7) * 128 + (((2 * g + h) ^ (lo & 7)) << 4));
     }
-    float* dsout = a.dsmap + (long)b * M * a.ld + max(t - 1, 0) * kTile + 4 * (lane & 7);
+    float* dsout = a.dsmap + map_cloud(b, 1) * M * a.ld + max(t - 1, 0) * kTile + 4 * (lane & 7);
     f32x4 po[4];
     Tri bn[2];
     float ds[16];
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void bwd_kacc_pm_tri_kernel(const KaccArgs 
   char* mapring = smem_c + kAccPmTrSlots * kTriTile;
   // lane l of a piece: row l >> 3 of its eight rows, 16-byte chunk l & 7 of the wave's 128 bytes (past the row's end
   // the chunk is pulled back inside it: those keys are >= N, their outputs are never stored)
-  const float* mapb = a.map + (long)b * M * ld + min(chunk * 256 + wave * 32 + 4 * (lane & 7), ld - 4);
+  const float* mapb = a.map + map_cloud(b) * M * ld + min(chunk * 256 + wave * 32 + 4 * (lane & 7), ld - 4);
   const int prow = lane >> 3;
 
   // one piece of the image tile t (k = 0..2) / of the wave's map block of tile t (q = 0..3: rows 8 q .. 8 q + 7)

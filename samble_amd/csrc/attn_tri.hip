@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void attn_rows_rc_tri_kernel(const char* __res
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + voff[k]),
                                        (__attribute__((address_space(3))) void*)(vdst + 4096 * k), 16, 0, 0);
     };
-    float* pout = PMAP ? pmap + (long)b * M * ld + max(t - 1, 0) * kTile + 4 * (lane & 7) : nullptr;
+    float* pout = PMAP ? pmap + map_cloud(b, 0) * M * ld + max(t - 1, 0) * kTile + 4 * (lane & 7) : nullptr;
     f32x4 po[4];
     Tri bn[2];
     float p[16];

@@ -192,6 +192,23 @@ __device__ __forceinline__ void xcd_assign(int& chunk, int& cloud) {
   }
 }
 
+// Which cloud's slice of the two M-row maps (P, dS) cloud b uses: its own.  -DSAMBLE_MAP_ALIAS (timing-only scratch
+// builds, tools/experiments/map_alias.md; results are WRONG): B = 32 clouds share 8 slices, each one by four clouds that
+// xcd_assign puts on four different XCDs -- the maps' working set (2 x 67 MB) then lives in the memory-side cache, an
+// upper bound of what a backward that keeps the maps on-die could gain.
+// (modes 3 / 4: as 2, but only the P map's / only the dS map's accesses of the two query-stationary kernels: `which` = 0 P, 1 dS)
+__device__ __forceinline__ long map_cloud(int b, int which = -1) {
+#if defined(SAMBLE_MAP_ALIAS) && SAMBLE_MAP_ALIAS == 2
+  return 0;  // every cloud on ONE slice: 2 x 8.4 MB, the strongest form of the bound
+#elif defined(SAMBLE_MAP_ALIAS) && (SAMBLE_MAP_ALIAS == 3 || SAMBLE_MAP_ALIAS == 4)
+  return which == SAMBLE_MAP_ALIAS - 3 ? 0 : (long)b;
+#elif defined(SAMBLE_MAP_ALIAS)
+  return (long)(((b & 3) << 1) | ((b >> 4) & 1));
+#else
+  return (long)b;
+#endif
+}
+
 __device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // order-preserving float -> uint32 (larger float -> larger uint); NaN sorts above +inf

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the sampler.  Clouds shard over ranks; the only
+"""CPU, world_size 2 and 8 over gloo: the N>1 path of the sampler.  Clouds shard over ranks; the only
 exchange on the data path is the all-reduce/world_size of the nb-1 boundary quantiles
 (reference utils/ops.py:191-199) followed by the in-place momentum blend (201-233)."""
 import os
@@ -55,6 +55,68 @@ def test_boundary_exchange_two_ranks():
         state = O.blend_boundaries(state, expect.clone(), 6, 0.99)
         for up, lo in ((up0, lo0), (up1, lo1)):
             assert torch.equal(up, state[0]) and torch.equal(lo, state[1]), "ranks hold identical boundaries"
+
+
+def _worker8(rank, world, port, out):
+    """BASELINE.json configs[3] geometry on the host: 8 ranks x 32 clouds = the global batch of 256.  Every rank forms its
+    shard's quantiles, the exchange is (a) the reference's `all_reduce; / world_size` (ops.world_average) and (b) the
+    form the GPU path uses -- the nb-1 quantiles with a validity count behind them through ONE all-reduce (ops.world_sum),
+    divided by the all-reduced count (what csrc/chain.hip bin_plan_kernel does with quantile_divisor)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from samble_amd import ops, synth
+    nb, B, N = 6, 32, 128
+    state = None
+    log = []
+    for call in range(2):
+        feats = synth.features(B, 1, N, 70 + call, first_cloud=rank * B)
+        z = O.zscore(torch.from_numpy(np.abs(feats)))
+        local_q = O.batch_quantiles(z.reshape(B, 1, N, 1), nb)
+        q = ops.world_average(local_q.clone())
+        counted = torch.cat([local_q, torch.ones(1)])
+        if rank == 5 and call == 1:            # this rank's chain "gave up" in the second call: zeros, count 0
+            counted = torch.zeros(nb)
+        summed = ops.world_sum(counted.clone())
+        state = ops.blend_boundaries(state, q, nb, 0.99)
+        log.append((local_q.clone(), q.clone(), summed.clone(), state[0].clone(), float(feats.astype(np.float64).sum())))
+    out[rank] = log
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boundary_exchange_eight_ranks_tile_the_batch_of_256():
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), out), nprocs=world, join=True)
+    from samble_amd import synth
+    state = None
+    for call in range(2):
+        local = [out[r][call][0] for r in range(world)]
+        total = local[0].clone()
+        for t in local[1:]:
+            total = total + t                     # gloo's ring sums in rank order too for 5 floats; compared below
+        for r in range(world):
+            lq, q, summed, upper, shard_sum = out[r][call]
+            # the reference's exchange: SUM all-reduce, then / world_size (utils/ops.py:191-199): every rank the same mean
+            assert torch.equal(q, out[0][call][1])
+            torch.testing.assert_close(q, total / world, rtol=1e-6, atol=1e-7)
+            if call == 0:   # the counted form: same sums, count = world -> the same mean, bit for bit
+                assert float(summed[-1]) == world and torch.equal(summed[:-1] / summed[-1], q)
+            else:           # rank 5 contributed zeros: the mean of the seven healthy ranks, on every rank
+                assert float(summed[-1]) == world - 1
+                healthy = sum(local[k] for k in range(world) if k != 5) / (world - 1)
+                torch.testing.assert_close(summed[:-1] / summed[-1], healthy, rtol=1e-6, atol=1e-7)
+        state = O.blend_boundaries(state, out[0][call][1].clone(), 6, 0.99)
+        for r in range(world):
+            assert torch.equal(out[r][call][3], state[0]), "ranks hold identical boundaries: the blend of the 8-rank mean"
+        # the shards are the global batch: 8 x 32 clouds generated per rank == 256 clouds generated at once
+        full = synth.features(256, 1, 128, 70 + call)
+        assert abs(sum(out[r][call][4] for r in range(world)) - float(full.astype(np.float64).sum())) < 1e-6
+        for r in (0, 3, 7):
+            assert np.array_equal(synth.features(32, 1, 128, 70 + call, first_cloud=32 * r), full[32 * r:32 * r + 32])
 
 
 def test_shards_tile_the_global_batch():

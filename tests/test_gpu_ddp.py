@@ -142,3 +142,27 @@ def test_bench_two_ranks_finishes_and_reports_the_collectives():
     assert line["scaling"] == "weak" and line["value"] > 0 and "kernel_us" in line
     comm = line["comm"]
     assert comm["ranks_formed"] == 2 and comm["c1_boundary_allreduce_5_floats_us"] > 0 and comm["c2_ddp_bucket_399KB_allreduce_us"] > 0
+
+
+def test_bench_eight_ranks_over_gloo_on_one_gpu():
+    """BASELINE.json configs[3]'s rank count on the one GPU this box has: `bench.py --gpus 8 --backend gloo --steps 2`.
+    Eight child processes (spawned before the parent touches the GPU), eight DDP replicas of the layer, eight shards of the
+    global batch of 256, the boundary exchange and DDP's buckets over an 8-rank group.  A functional check of the N = 8
+    path -- the line says so itself -- never a scaling number."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--no-breakdown"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["ranks"] == 8 and line["config"]["global_batch"] == 256
+    assert line["config"]["parallelism"] == "dp8" and line["scaling"] == "weak" and line["value"] > 0
+    assert "not a scaling measurement" in line["note"]
+    comm = line["comm"]
+    assert comm["ranks_formed"] == 8 and comm["world_size"] == 8 and comm["backend"] == "gloo"
