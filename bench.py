@@ -492,6 +492,7 @@ def main():
                          "power / clock probes, where 1e-4 against a fixed random gradient would blow the weights up)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the step behind the timed region")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
     ap.add_argument("--logit-map", action="store_true",
@@ -627,6 +628,37 @@ def main():
         kt = {n: _lib.timing_read(n) for n in names}
         _lib.timing_select([])
 
+    # the same step as ONE hipGraph (torch.cuda.graph around forward + backward + SGD; the selection noise then comes from
+    # torch's graph-safe generator path, one extra launch): replayed K times behind the headline's eager region, reported
+    # beside it.  Eager stays the headline at every N: DDP's reducer is not captured, and a scaling curve must not mix the two.
+    graph_report = None
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                graph.replay()
+            torch.cuda.synchronize()
+            graph_ms = 1e3 * (time.perf_counter() - tg) / args.steps
+            graph_report = {"ms_per_step": round(graph_ms, 4), "clouds_per_s": round(B_PER_GPU / (graph_ms * 1e-3), 1),
+                            "steps": args.steps,
+                            "note": "forward + backward + SGD of the headline step captured once (hipStreamBeginCapture via "
+                                    "torch.cuda.graph) and replayed; not the headline value"}
+            del graph
+        except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra measurement)
+            graph_report = {"error": repr(e)[:300]}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         total_clouds = B_PER_GPU * world * args.steps
@@ -658,6 +690,8 @@ def main():
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
+        if graph_report is not None:
+            result["graph_replay"] = graph_report
         if comm is not None:
             result["comm"] = comm
         if shared_gpus:

@@ -508,3 +508,61 @@ def test_backward_is_exactly_linear_in_a_power_of_two(k):
         assert bool(torch.isfinite(b2).all())
         assert torch.equal(a * 2.0 ** k, b2), float((a * 2.0 ** k - b2).abs().max())
         assert bool((z == 0).all())
+
+
+def test_step_is_graph_capturable_and_replays_bit_identically():
+    """forward + backward of the metric layer (B=32, N=2048 -> 1024, injected noise) captured as ONE
+    hipGraph (torch.cuda.graph), replayed twice: idx, x_ds, dx and the four parameter gradients are bit-identical between
+    the replays AND to the eager run of the same step from the same boundary state.  (Round 3's segfault in
+    hipStreamEndCapture does not reproduce on this tree: tools/experiments/graph_capture_probe.py runs six configurations,
+    with and without the fused chain and its pinned-memory mailbox.)"""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 32, 128, 2048, 1024, 6
+    torch.manual_seed(3)
+    mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, 7101)).to(DEV).requires_grad_(True)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 7102)).to(DEV)
+    g = torch.from_numpy(synth.normal((B, C, M), 7103)).to(DEV)
+    params = [mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight, mod.bin_tokens]
+
+    def step():
+        for p in params + [x]:
+            if p.grad is not None:
+                p.grad.zero_()
+        (x_ds, idx), _ = mod(x, noise=noise)
+        x_ds.backward(g)
+        return x_ds, idx
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()                                      # allocator pools, first-call boundary state, grads allocated
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    state = [t.clone() for t in mod.bin_boundaries]
+
+    def snapshot(out):
+        return [out[0].detach().clone(), out[1].clone(), x.grad.clone()] + [p.grad.clone() for p in params] + \
+               [t.clone() for t in mod.bin_boundaries]
+
+    eager = snapshot(step())
+    torch.cuda.synchronize()
+    for t, t0 in zip(mod.bin_boundaries, state):
+        t.copy_(t0)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    replays = []
+    for _ in range(2):
+        for t, t0 in zip(mod.bin_boundaries, state):   # (the captured step blends into these very tensors)
+            t.copy_(t0)
+        graph.replay()
+        torch.cuda.synchronize()
+        replays.append(snapshot(out))
+    names = ["x_ds", "idx", "dx", "dWq", "dWk", "dWv", "dtokens", "upper", "lower"]
+    for n, a, b2, e in zip(names, replays[0], replays[1], eager):
+        assert torch.equal(a, b2), f"{n}: the two replays differ"
+        assert torch.equal(a, e), f"{n}: replay differs from the eager step"
+    assert not mod._chain_watch.timed_out(sync=True)
