@@ -419,9 +419,7 @@ def measure_block(workload, steps, warmup):
         marks[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    seen = {n: _lib.timing_read(n) for n in cand}
-    dominant = max((n for n in cand if seen.get(n)), key=lambda n: seen[n][0], default=dominant)
-    dom = seen.get(dominant)
+    dom = _lib.timing_read(dominant)
     _lib.timing_select([])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     ms = 1e3 * elapsed / args.steps
@@ -458,6 +456,21 @@ def measure_block(workload, steps, warmup):
     roof["us_per_launch"] = round(dom[0] * 1e3, 1)
     roof["launches_per_step"] = round(launches_per_step, 1)
     roof["traffic"] = None
+    try:  # fabric bytes per launch of the dominant family's kernels from the newest committed rocprofv3 --pmc summary
+        import glob
+        pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc.json")))[-1]
+        pmc = json.load(open(pmc_path))
+        keys = {"n2p_bwd": ("n2p_bwd",), "n2p_fwd": ("n2p_attn_fwd",), "edge_bwd": ("edge_mlp_bwd",), "edge_fwd": ("edge_mlp_fwd",),
+                "knn": ("knn_duo",)}.get(dominant, (dominant,))
+        hit = [e for k_, e in pmc["kernels"].items() if any(s_ in k_ for s_ in keys) and "traffic_bytes_per_launch" in e]
+        if hit:
+            roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e.get("launches_per_step", 1) for e in hit)
+                                  / max(sum(e.get("launches_per_step", 1) for e in hit), 1))
+            roof["traffic_source"] = f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc of an earlier run of this command)"
+        if pmc.get("step_traffic_bytes"):
+            roof["step_traffic"] = int(pmc["step_traffic_bytes"])
+    except Exception:  # noqa: BLE001
+        pass
     result = {
         "metric": ("point-clouds/sec (feature-learning block fwd+bwd), " + ("ShapeNet-part seg block" if seg else "ModelNet40 cls block")
                    + " B=32 N=2048->1024->512" + ("->1024->2048" if seg else "")),

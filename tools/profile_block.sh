@@ -11,4 +11,9 @@ for w in cls seg; do
   f=$(find "$out/${tag}_block_${w}_stats" -name "*kernel_stats.csv" | head -1)
   cp "$f" "$out/${tag}_block_${w}_kernel_stats.csv"
   head -12 "$f" | cut -c1-150
+  # HBM / fabric bytes and the matrix-pipe counter, separate passes as the counters require (no trace flags beside --pmc)
+  P="python3 bench.py --workload block_$w --steps 2 --warmup 2 --no-cpu-baseline"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_block_${w}_pmc_fetch" -o run -- $P > "$out/${tag}_block_${w}_pmc_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_block_${w}_pmc_write" -o run -- $P > "$out/${tag}_block_${w}_pmc_write.log" 2>&1
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d "$out/${tag}_block_${w}_pmc_sq" -o run -- $P > "$out/${tag}_block_${w}_pmc_sq.log" 2>&1
 done

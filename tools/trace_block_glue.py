@@ -23,12 +23,27 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-rows = []
-for ev in prof.key_averages(group_by_stack_n=6):
-    dt = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0)
-    if dt <= 0: continue
-    stack = [s for s in ev.stack if "samble_amd" in s or "bench" in s]
-    rows.append((dt, ev.count, ev.key, stack[:2]))
-rows.sort(key=lambda r: -r[0])
-for dt, n, key, stack in rows[:45]:
-    print(f"{dt:9.1f} us  x{n:<3d} {key[:48]:48s} {' | '.join(s.split('/')[-1][:70] for s in stack)}")
+# every aten op that launched a stock kernel, grouped by (op, the innermost frame of this package on its stack)
+from collections import defaultdict
+groups = defaultdict(lambda: [0.0, 0])
+bwd = defaultdict(lambda: [0.0, 0])
+for ev in prof.events():
+    if ev.device_type != torch.autograd.DeviceType.CPU:
+        continue
+    dt = getattr(ev, "self_device_time_total", 0)
+    if dt <= 0 or not ev.name.startswith("aten::"):
+        continue
+    frames = [f for f in (ev.stack or []) if "samble_amd/" in f or "trace_block_glue" in f]
+    where = frames[0].split("samble_amd/")[-1][:90] if frames else "(autograd engine thread: no Python frame)"
+    g = groups[(ev.name, where)]
+    g[0] += dt
+    g[1] += 1
+tot = sum(v[0] for v in groups.values())
+print(f"stock kernels launched by aten ops: {tot:.0f} us in {sum(v[1] for v in groups.values())} launches per step")
+for (name, where), (dt, n) in sorted(groups.items(), key=lambda kv: -kv[1][0])[:70]:
+    print(f"{dt:8.1f} us  x{n:<3d} {name:28s} {where}")
+# backward nodes of the autograd graph that own stock kernels (the engine thread has no Python stack)
+for ev in prof.key_averages():
+    dt = getattr(ev, "device_time_total", 0)
+    if dt > 0 and ("Backward" in ev.key or "AccumulateGrad" in ev.key) and "evaluate_function" not in ev.key:
+        print(f"   node {ev.key[:50]:50s} x{ev.count:<3d} {dt:8.1f} us (kernels of any kind under it)")
