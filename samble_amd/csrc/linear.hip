@@ -19,6 +19,21 @@
 
 namespace samble {
 
+// Round 5: the products run on TWO fp16 planes per operand (tri_dev.h "duo": 3 matrix instructions per k-step instead of
+// 6) under power-of-two scales that are exact to take out again:
+//   weights      per 32-row image tile (the tile's largest |w| lands just under 2^13; 2^-e rides in the tile's spare slot);
+//   lin_fwd      the point's 128 channels under the point's own scale (contraction complete inside one tile: one scale pair);
+//   lin_dx       the point's 32 gradient values of output tile t under their own scale; every tile's product starts from
+//                a ZERO accumulator and is added to the fp32 totals by the vector ALU, times 2^-(e_w + e_g) -- the sum
+//                over the tiles is an fp32 sum, as in the reference;
+//   lin_dw       the same per 32-point tile: g and x blocks under wave-uniform scales, fp32 totals.
+// 22 significant bits per operand, products of the planes exact in fp32: measured against float64 like the three-plane
+// kernels (tests/test_gpu_linear.py, same tolerances).  -DSAMBLE_LIN_DUO=0 builds the three-bf16-plane kernels (A/B).
+#ifndef SAMBLE_LIN_DUO
+#define SAMBLE_LIN_DUO 1
+#endif
+constexpr bool kLinDuo = SAMBLE_LIN_DUO != 0;
+
 constexpr int kLinDepth = 4;
 constexpr int kLinLds = kLinDepth * kTriTile;
 enum { kLinPlain = 0, kLinLeaky = 1, kLinMask = 2, kLinAmax = 3 };
@@ -43,6 +58,28 @@ __device__ __forceinline__ float half_wave_max(float x) {
   x = fmaxf(x, lin_dpp_f<0x140, 0xF>(x, x));  // row_mirror: every lane of a row of 16 holds the row's max
   x = fmaxf(x, lin_dpp_f<0x142, 0xA>(x, x));  // row_bcast15 -> rows 1, 3 (lanes of rows 0, 2 keep their value: old = x)
   return x;                                    // lanes 16..31 / 48..63 hold the half's max
+}
+
+// max over all 64 lanes, in every lane (four DPP steps inside the rows of 16, two shuffles across them)
+__device__ __forceinline__ float wave_max_all(float x) {
+  x = fmaxf(x, lin_dpp_f<0xB1, 0xF>(x, x));
+  x = fmaxf(x, lin_dpp_f<0x4E, 0xF>(x, x));
+  x = fmaxf(x, lin_dpp_f<0x141, 0xF>(x, x));
+  x = fmaxf(x, lin_dpp_f<0x140, 0xF>(x, x));
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  x = fmaxf(x, __shfl_xor(x, 32, 64));
+  return x;
+}
+
+// eight fp32 values x s -> the two fp16 planes of one 16-byte operand chunk
+__device__ __forceinline__ void duo_split8(const float (&v)[8], float s, u32x4& hp, u32x4& lp) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned hw, lw;
+    duo_split2(v[2 * w] * s, v[2 * w + 1] * s, hw, lw);
+    hp[w] = hw;
+    lp[w] = lw;
+  }
 }
 
 // EPI  kLinPlain: out = W x            kLinLeaky: out = leaky(W x)
@@ -71,19 +108,50 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
   };
 #pragma unroll
   for (int t = 0; t < D - 1; ++t) stage(t);
-  u32x4 xq[24];  // this point's channels as the B operand: k-step ks, half h <-> channels 16 ks + 8 h + e
+  // this point's channels as the B operand: k-step ks, half h <-> channels 16 ks + 8 h + e; three bf16 planes
+  // (xq[3 ks + piece]) or two fp16 planes under the point's scale (xq[2 ks + plane], x_inv = 2^-e)
+  u32x4 xq[kLinDuo ? 16 : 24];
+  float x_inv = 1.f;
+  if (kLinDuo) {
+    float xv[64];
+    float amax = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    float v[8];
+    for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = 16 * ks + 8 * h + e;   // (channels Cin .. 127 do not exist: zeros, as in W's image)
-      v[e] = c < Cin ? x[(long)b * x_bs + (long)c * N + n] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int c = 16 * ks + 8 * h + e;   // (channels Cin .. 127 do not exist: zeros, as in W's image)
+        xv[8 * ks + e] = c < Cin ? x[(long)b * x_bs + (long)c * N + n] : 0.f;
+        amax = fmaxf(amax, fabsf(xv[8 * ks + e]));
+      }
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));   // lanes lo and lo + 32 hold the two halves of one point
+    float sx;
+    duo_scale_for(amax, sx, x_inv);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float v[8] = {xv[8 * ks], xv[8 * ks + 1], xv[8 * ks + 2], xv[8 * ks + 3],
+                          xv[8 * ks + 4], xv[8 * ks + 5], xv[8 * ks + 6], xv[8 * ks + 7]};
+      duo_split8(v, sx, xq[2 * ks], xq[2 * ks + 1]);
     }
-    const Tri t3 = tri_split8(v);
-    xq[3 * ks] = t3.h;
-    xq[3 * ks + 1] = t3.m;
-    xq[3 * ks + 2] = t3.l;
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 16 * ks + 8 * h + e;
+        v[e] = c < Cin ? x[(long)b * x_bs + (long)c * N + n] : 0.f;
+      }
+      const Tri t3 = tri_split8(v);
+      xq[3 * ks] = t3.h;
+      xq[3 * ks + 1] = t3.m;
+      xq[3 * ks + 2] = t3.l;
+    }
+  }
+  // amax (operands swapped: the points are the accumulator's ROWS): the scales of the points crow(r, h) of this wave's tile
+  float xinv_r[16];
+  if (kLinDuo && EPI == kLinAmax) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xinv_r[r] = __shfl(x_inv, crow(r, h), 64);
   }
   float* orow = (EPI == kLinAmax) ? nullptr : out + (long)b * o_bs + (long)n * o_rs + 4 * h;
   const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h : nullptr;
@@ -111,10 +179,23 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
     stage(t + D - 1);
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
     f32x16 acc = zero16();  // D[row = output 32 t + crow(r, h)][col = point]
+    float w_inv = 1.f;      // duo: 2^-e of this weight tile
+    if (kLinDuo) w_inv = *reinterpret_cast<const float*>(smem_c + (t % D) * kTriTile + kDuoScaleSlot);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
+      if (kLinDuo) {
+        const u32x4 ah = lp[192 * ks], al = lp[192 * ks + 32];
+        if (EPI == kLinAmax) {  // mfma_duo(a, x)'s three products in its order, each with its operands swapped (see below)
+          acc = mfma_hf(xq[2 * ks], al, acc);
+          acc = mfma_hf(xq[2 * ks + 1], ah, acc);
+          acc = mfma_hf(xq[2 * ks], ah, acc);
+        } else {
+          acc = mfma_duo(ah, al, xq[2 * ks], xq[2 * ks + 1], acc);
+        }
+        continue;
+      }
       const Tri a = {lp[192 * ks], lp[192 * ks + 32], lp[192 * ks + 64]};
-      const Tri bq = {xq[3 * ks], xq[3 * ks + 1], xq[3 * ks + 2]};
+      const Tri bq = {xq[kLinDuo ? 0 : 3 * ks], xq[kLinDuo ? 0 : 3 * ks + 1], xq[kLinDuo ? 0 : 3 * ks + 2]};
       // amax: the operands swapped -- D[row = point crow(r, h)][col = output 32 t + lo] -- so that the maximum over the
       // tile's points runs over a lane's REGISTERS (with the points on the lanes it took a DPP butterfly, two readlanes
       // and a ballot per output row: 400 instructions per tile beside 48 MFMAs)
@@ -128,6 +209,11 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
       } else {
         acc = mfma_tri(a, bq, acc);
       }
+    }
+    if (kLinDuo) {  // take the scales out: exact (powers of two)
+      const float sc = w_inv * x_inv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= (EPI == kLinAmax) ? w_inv * xinv_r[r] : sc;
     }
     if (EPI == kLinAmax) {
       float m = acc[0];
@@ -304,6 +390,130 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
   }
 }
 
+// lin_dx on two fp16 planes.  Per output tile t: the point's 32 gradient values (16 per lane half) under their own
+// power-of-two scale, the W^T tile under the image tile's; the tile's product (two k-steps) starts from a ZERO accumulator
+// per channel tile and is added to the fp32 totals x 2^-(e_w + e_g) by the vector ALU one step later, beside the next
+// channel tile's MFMAs.  Channel tile outer, k-step inner, so that only two temporaries are alive at a time.
+__global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restrict__ g, long g_bs, long g_rs,
+                                                            const char* __restrict__ Wtr, int otiles, int Cin, int N,
+                                                            float* __restrict__ dx, long dx_bs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kLinDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  const float* grow = g + (long)b * g_bs + (long)n * g_rs + 4 * h;
+  auto stage = [&](int t) {
+    const char* gt = Wtr + (long)min(t, otiles - 1) * kTriTile;
+    char* lt = smem_c + (t % D) * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lin_glds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+  };
+  auto load_g = [&](int t, f32x4 (&dst)[4]) {  // (assembly loads: lin_dx_tri_kernel explains why)
+    const float* p = grow + min(t, otiles - 1) * 32;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                 : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3])
+                 : "v"(p)
+                 : "memory");
+  };
+  // scale of a lane pair's 32 values (this lane's 16, the other half's 16): s = 2^e with amax s in [2^12, 2^13)
+  auto scale_of = [&](const f32x4 (&v)[4], float& sc, float& inv) {
+    float amax = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[q][e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    duo_scale_for(amax, sc, inv);
+  };
+#pragma unroll
+  for (int t = 0; t < D - 1; ++t) stage(t);
+  f32x16 tot[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) tot[ct] = zero16();
+  f32x4 gn[4], gnn[4];
+  u32x4 bh[2], bl[2], nh[2], nl[2];  // planes of tile t / tile t + 1, k-steps 0 and 1
+  load_g(0, gnn);
+  load_g(1, gn);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+               : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3]), "+v"(gn[0]), "+v"(gn[1]), "+v"(gn[2]), "+v"(gn[3])::"memory");
+  float g_inv;
+  {
+    float s0;
+    scale_of(gnn, s0, g_inv);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float v[8] = {gnn[2 * ks][0], gnn[2 * ks][1], gnn[2 * ks][2], gnn[2 * ks][3],
+                          gnn[2 * ks + 1][0], gnn[2 * ks + 1][1], gnn[2 * ks + 1][2], gnn[2 * ks + 1][3]};
+      duo_split8(v, s0, bh[ks], bl[ks]);
+    }
+  }
+  for (int t = 0; t < otiles; ++t) {
+    load_g(t + 2, gnn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    stage(t + D - 1);
+    const char* wt = smem_c + (t % D) * kTriTile;
+    const float sc = *reinterpret_cast<const float*>(wt + kDuoTrScaleSlot) * g_inv;  // 2^-(e_w + e_g), this lane's point
+    float s_next, g_inv_next;
+    scale_of(gn, s_next, g_inv_next);  // tile t + 1's values (past the last tile: a repeat, never used)
+    auto fetch_h = [&](int i) { return *reinterpret_cast<const u32x4*>(wt + tri_tr_off(32 * (i >> 1) + lo, 2 * (i & 1) + h, 0)); };
+    auto fetch_l = [&](int i) { return *reinterpret_cast<const u32x4*>(wt + tri_tr_off(32 * (i >> 1) + lo, 2 * (i & 1) + h, 1)); };
+    u32x4 a0h = fetch_h(0), a0l = fetch_l(0), a1h = fetch_h(1), a1l = fetch_l(1), a2h = fetch_h(2), a2l = fetch_l(2);
+    f32x16 tmp[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // channel tile i >> 1, k-step i & 1
+      const int ct = i >> 1, ks = i & 1;
+      u32x4 a3h = a2h, a3l = a2l;
+      if (i + 3 < 8) {
+        a3h = fetch_h(i + 3);
+        a3l = fetch_l(i + 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      tmp[ct] = mfma_duo(a0h, a0l, bh[ks], bl[ks], ks ? tmp[ct] : zero16());
+      {  // pair i of tile t + 1's values -> its plane words
+        const int k2 = i >> 2, w = i & 3;
+        unsigned hw, lw;
+        duo_split2(gn[2 * k2 + (w >> 1)][2 * (w & 1)] * s_next, gn[2 * k2 + (w >> 1)][2 * (w & 1) + 1] * s_next, hw, lw);
+        nh[k2][w] = hw;
+        nl[k2][w] = lw;
+      }
+      if (ks == 0 && ct >= 1) {  // the channel tile finished one step ago joins the totals
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[ct - 1][r] = fmaf(tmp[ct - 1][r], sc, tot[ct - 1][r]);
+      }
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      a0h = a1h; a0l = a1l;
+      a1h = a2h; a1l = a2l;
+      a2h = a3h; a2l = a3l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[3][r] = fmaf(tmp[3][r], sc, tot[3][r]);
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gn[i] = gnn[i];
+    bh[0] = nh[0]; bh[1] = nh[1];
+    bl[0] = nl[0]; bl[1] = nl[1];
+    g_inv = g_inv_next;
+  }
+  float* ob = dx + (long)b * dx_bs + n;  // rows past N-1 hold point N-1's column again: same values, same address
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    if (32 * ct >= Cin) break;   // (uniform)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = 32 * ct + crow(r, h);
+      if (c < Cin) ob[(long)c * N] = tot[ct][r];
+    }
+  }
+}
+
 // dW partials: workgroup = (512-point chunk, cloud, block of 128 OT outputs); wave w owns output rows 32 OT (w >> 1) .. of
 // the block and channels 64 (w & 1) .. +63: 2 OT accumulator tiles.  Both operands are transposed through LDS (the
 // contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
@@ -374,6 +584,60 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
     if (t + 1 < ntiles) issue(n0 + (t + 1) * kTile);
     const float* gt = cur;
     const float* xt = cur + kTile * GS;
+    if (kLinDuo) {
+      // both k-steps' operands of the tile under two wave-uniform scales (the block of g this wave multiplies, its block
+      // of x), every (output tile, channel tile) product from a zero accumulator, fp32 totals by the vector ALU
+      u32x4 ah[2][OT], al[2][OT], bh[2][2], bl[2][2];
+      float inv_a, inv_b;
+      {
+        float v[2][OT][8];
+        float amax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[ks][ot][e] = gt[(16 * ks + 8 * h + e) * GS + 32 * OT * og + 32 * ot + lo];
+              amax = fmaxf(amax, fabsf(v[ks][ot][e]));
+            }
+        float sa;
+        duo_scale_for(wave_max_all(amax), sa, inv_a);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) duo_split8(v[ks][ot], sa, ah[ks][ot], al[ks][ot]);
+      }
+      {
+        float v[2][2][8];
+        float amax = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[ks][ct][e] = xt[(64 * ch + 32 * ct + lo) * XS + 16 * ks + 8 * h + e];
+              amax = fmaxf(amax, fabsf(v[ks][ct][e]));
+            }
+        float sb;
+        duo_scale_for(wave_max_all(amax), sb, inv_b);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) duo_split8(v[ks][ct], sb, bh[ks][ct], bl[ks][ct]);
+      }
+      const float sc = inv_a * inv_b;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          f32x16 tmp = mfma_duo(ah[0][ot], al[0][ot], bh[0][ct], bl[0][ct], zero16());
+          tmp = mfma_duo(ah[1][ot], al[1][ot], bh[1][ct], bl[1][ct], tmp);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ot][ct][r] = fmaf(tmp[r], sc, acc[ot][ct][r]);
+        }
+    } else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {  // points 16 ks .. 16 ks + 15; lane half h: the 8 points 16 ks + 8 h + e
       Tri bq[2];
@@ -601,6 +865,55 @@ __global__ __launch_bounds__(256) void amax_dw_kernel(const float* __restrict__ 
   dW[(long)o * 128 + lane + 64] = a1;
 }
 
+// duo images of one 32-row tile of W (O x 128 row-major) per workgroup
+__global__ __launch_bounds__(256) void lin_images_duo_kernel(const float* __restrict__ W, char* __restrict__ rm,
+                                                             char* __restrict__ tr) {
+  __shared__ float wt[32][129];
+  __shared__ float red[4];
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  float mx = 0.f;
+  for (int e = tid; e < 32 * 128; e += 256) {
+    const float v = W[((long)tile * 32 + (e >> 7)) * 128 + (e & 127)];
+    wt[e >> 7][e & 127] = v;
+    mx = fmaxf(mx, fabsf(v));
+  }
+  mx = wave_max_all(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  float sc, inv;
+  duo_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), sc, inv);
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const u32x4 tag4 = {__float_as_uint(inv), 0u, 0u, 0u};
+  if (rm) {
+    char* img = rm + (long)tile * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int r = e & 31, g = e >> 5;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wt[r][8 * g + i];
+      u32x4 hp, lp;
+      duo_split8(v, sc, hp, lp);
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 0)) = hp;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 1)) = lp;
+      *reinterpret_cast<u32x4*>(img + tri_rm_off(r, g, 2)) = (r == 0 && g == 0) ? tag4 : zero4;
+    }
+  }
+  if (tr) {
+    char* img = tr + (long)tile * kTriTile;
+    for (int e = tid; e < 512; e += 256) {
+      const int d = e & 127, cg = e >> 7, s2 = cg >> 1, hh = cg & 1;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wt[16 * s2 + 8 * (i >> 2) + 4 * hh + (i & 3)][d];
+      u32x4 hp, lp;
+      duo_split8(v, sc, hp, lp);
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = hp;
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = lp;
+      *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = (d == 0 && cg == 0) ? tag4 : zero4;
+    }
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -610,9 +923,12 @@ extern "C" int samble_launch_tri_split(const float* src, long bs, long rs, int B
 
 extern "C" size_t samble_linear_image_bytes_impl(int O) { return (size_t)((O + 31) / 32) * kTriTile; }
 
-// row image and / or transposed image of W (O x 128, row-major)
+// row image and / or transposed image of W (O x 128, row-major): three bf16 planes, or (duo) two fp16 planes of the
+// tile x 2^e in the slots of the first two pieces, 2^-e in the tile's spare slot (kDuoScaleSlot / kDuoTrScaleSlot)
 extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, hipStream_t s) {
-  return samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
+  if (!kLinDuo) return samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
+  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O / 32), dim3(256), 0, s, W, (char*)rm, (char*)tr);
+  return (int)hipGetLastError();
 }
 
 extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O, int epi,
@@ -658,12 +974,16 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
 
 extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
                                        float* dx, long dx_bs, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dx_tri_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  const void* fn = kLinDuo ? reinterpret_cast<const void*>(lin_dx_duo_kernel) : reinterpret_cast<const void*>(lin_dx_tri_kernel);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_dx, s);
-  hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                     O / 32, Cin, N, dx, dx_bs);
+  if (kLinDuo)
+    hipLaunchKernelGGL(lin_dx_duo_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
+                       O / 32, Cin, N, dx, dx_bs);
+  else
+    hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
+                       O / 32, Cin, N, dx, dx_bs);
   return (int)hipGetLastError();
 }
 
