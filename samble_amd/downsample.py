@@ -855,14 +855,21 @@ class DownSampleLocal(nn.Module):
         self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
         if self.asm not in ("dot", "dot-neighbor", "dot-sub", "l2", "l2+"):
             raise ValueError("Please check the setting of asm!")
-        if self.num_heads != 1 or not (q_in == q_out == k_in == k_out == v_in == v_out == 128):
-            raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
+        if not (q_in == q_out == k_in == k_out == v_in == v_out == 128):
+            raise NotImplementedError("the HIP kernels are built for 128 channels")
         if self.idx_mode not in ("local_std", "sparse_row_std", "sparse_col_sum", "sparse_col_avg", "sparse_col_sqr"):
             raise ValueError("Please check the setting of idx mode!")
 
     def forward(self, x, x_xyz=None, forced_idx=None):
         """forced_idx = (idx (B,1,M), idx_dropped (B,1,N-M)): parity-test hook -- gather these columns instead of the
         selected ones (score and attention map are still computed and published)."""
+        if self.num_heads != 1:
+            # The reference constructs with any head count and then fails in its first forward, every idx_mode: its
+            # get_sparse_attention_map views the (B, N, K) neighbour indices as (B, H, N, K) (models/downsample.py:1041-1044;
+            # verified on the unmodified reference: RuntimeError).  A drop-in fails the same way, with the same message.
+            B, _, N = x.shape
+            raise RuntimeError(f"shape '[{B}, {self.num_heads}, {N}, {self.K}]' is invalid for input of size "
+                               f"{B * N * self.K}")
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape

@@ -150,3 +150,20 @@ def test_checkpoint_round_trip_keeps_reference_format():
         assert torch.equal(a.q_conv.weight, b.q_conv.weight)
     vals = checkpoint.static_boundary_values(state)
     assert len(vals) == 2 and len(vals[0]) == 5 and abs(vals[1][0] - 0.51) < 1e-6
+
+
+def test_local_sampler_with_several_heads_fails_like_the_reference():
+    """reference models/downsample.py:818-1229: DownSampleLocal constructs with any head count and then raises in its
+    first forward -- get_sparse_attention_map views the (B, N, K) neighbour indices as (B, H, N, K) (lines 1041-1044; run on
+    the unmodified reference when this test was written: RuntimeError "shape '[2, 4, 256, 32]' is invalid for input of size
+    16384").  The drop-in keeps both halves of that behaviour; `bin_idx_selection` / `bin2_idx_selection` of that class are
+    never called anywhere in the reference (and read attributes its constructor does not create): not built."""
+    import pytest
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleLocal
+    cfg = sampler_config("cls", M=[64, 32], idx_mode=["local_std", "local_std"])
+    cfg.num_heads = [4, 4]
+    mod = DownSampleLocal(cfg, 0)                                      # constructs, like the reference
+    assert mod.num_heads == 4 and mod.q_depth == 32
+    with pytest.raises(RuntimeError, match=r"shape '\[2, 4, 256, 32\]' is invalid for input of size 16384"):
+        mod(torch.zeros(2, 128, 256))
