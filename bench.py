@@ -506,6 +506,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the step behind the timed region")
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
     ap.add_argument("--logit-map", action="store_true",
@@ -590,8 +591,38 @@ def main():
         with torch.no_grad():
             mod.load_state_dict(saved)
         mod.bin_boundaries = saved_bounds
-    for _ in range(args.warmup):
-        step()
+    if args.graph_child:
+        # EVERY step before the capture runs on a side stream: the parameters' AccumulateGrad nodes are bound to the stream
+        # of the first backward and stay alive (the module keeps `attention_bins_beforesoftmax`, which holds the graph);
+        # bound to the legacy default stream they make the engine synchronise the capture stream with the NULL stream,
+        # and hipStreamEndCapture answers that with SIGSEGV instead of an error (tools/experiments/graph_capture_probe.py)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 1)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+    else:
+        for _ in range(args.warmup):
+            step()
+    if args.graph_child:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        graph_ms = 1e3 * (time.perf_counter() - tg) / args.steps
+        print(json.dumps({"ms_per_step": round(graph_ms, 4), "clouds_per_s": round(B_PER_GPU / (graph_ms * 1e-3), 1),
+                          "steps": args.steps,
+                          "note": "forward + backward + SGD of the headline step captured once (hipStreamBeginCapture via "
+                                  "torch.cuda.graph) in a child process and replayed; not the headline value"}), flush=True)
+        return
     tri = ops.MATRIX_MODE == "tri"
     # HIP events around every launch of the dominant kernel during the timed steps, recorded by the
     # library on the stream it launches on (two event records per step: no host sync); read back after
@@ -642,41 +673,30 @@ def main():
         _lib.timing_select([])
 
     # the same step as ONE hipGraph (torch.cuda.graph around forward + backward + SGD; the selection noise then comes from
-    # torch's graph-safe generator path, one extra launch): replayed K times behind the headline's eager region, reported
-    # beside it.  Eager stays the headline at every N: DDP's reducer is not captured, and a scaling curve must not mix the two.
+    # torch's graph-safe generator path, one extra launch), replayed K times and reported beside the eager headline.  Eager
+    # stays the headline at every N: DDP's reducer is not captured, and a scaling curve must not mix the two.  The capture
+    # runs in a CHILD process (`--graph-child`): on this ROCm 7.2 / torch 2.10 image hipStreamEndCapture takes the process
+    # down with SIGSEGV where CUDA would return an error -- always under rocprofv3, and whenever a backward has run on the
+    # legacy default stream before the capture (the parameters' AccumulateGrad nodes stay bound to it), which the timed
+    # region above has done.  A crash that cannot be caught must not be able to cost the headline line.
     graph_report = None
-    # (under rocprofv3 hipStreamEndCapture of this step SEGFAULTS inside the profiler's tool library on this ROCm 7.2 image --
-    # the crash round 3 ran into; tools/experiments/graph_capture_probe.py reproduces it with and without the profiler -- so
-    # a profiled run skips the section: a segfault cannot be caught)
     profiled = any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
-    if world == 1 and not args.no_graph and profiled:
-        graph_report = {"skipped": "running under rocprofv3: stream capture crashes inside the profiler's tool library"}
-    elif world == 1 and not args.no_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
-            for _ in range(3):
-                graph.replay()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(args.steps):
-                graph.replay()
-            torch.cuda.synchronize()
-            graph_ms = 1e3 * (time.perf_counter() - tg) / args.steps
-            graph_report = {"ms_per_step": round(graph_ms, 4), "clouds_per_s": round(B_PER_GPU / (graph_ms * 1e-3), 1),
-                            "steps": args.steps,
-                            "note": "forward + backward + SGD of the headline step captured once (hipStreamBeginCapture via "
-                                    "torch.cuda.graph) and replayed; not the headline value"}
-            del graph
-        except Exception as e:  # noqa: BLE001  (never lose the headline line to the extra measurement)
-            graph_report = {"error": repr(e)[:300]}
+    if world == 1 and rank == 0 and not args.no_graph and args.workload == "metric":
+        if profiled:
+            graph_report = {"skipped": "running under rocprofv3: stream capture crashes inside the profiler's tool library"}
+        else:
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--graph-child", "--steps", str(args.steps),
+                                        "--warmup", "3", "--lr", str(args.lr)], capture_output=True, text=True, timeout=600, env=env)
+                lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+                if child.returncode == 0 and lines:
+                    graph_report = json.loads(lines[-1])
+                else:
+                    graph_report = {"error": f"capture child exited with code {child.returncode}",
+                                    "stderr_tail": child.stderr[-200:]}
+            except Exception as e:  # noqa: BLE001
+                graph_report = {"error": repr(e)[:300]}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

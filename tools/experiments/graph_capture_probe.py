@@ -1,5 +1,7 @@
 """Which launch of the sampler step breaks hipStreamEndCapture?  ("tried and dropped (i)": torch.cuda.graph around the
-step segfaulted in round 3 on this ROCm 7.2 / torch 2.10 build; the cause was never isolated.)
+step segfaulted in round 3 on this ROCm 7.2 / torch 2.10 build; the cause was never isolated.)  Answer (round 5): none of
+them -- every configuration of the library's launches captures and replays bit-identically; the crash needs a backward
+on the legacy default stream before the capture (last configuration), or rocprofv3.
 
     python tools/experiments/graph_capture_probe.py            # runs every configuration in a child process
     python tools/experiments/graph_capture_probe.py <config>   # one configuration in this process
@@ -14,7 +16,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-CONFIGS = ["fwd:nochain", "fwd:nomailbox", "fwd:chain", "fwdbwd:nochain", "fwdbwd:chain", "step:chain"]
+CONFIGS = ["fwd:nochain", "fwd:nomailbox", "fwd:chain", "fwdbwd:nochain", "fwdbwd:chain", "step:chain",
+           # the bench's form of the step, one difference at a time: the noise drawn inside (torch's graph-safe generator
+           # path), gradients freed and re-allocated inside the capture, a fresh leaf for the input every step
+           "step:chain+ownnoise", "step:chain+setnone", "step:chain+freshleaf", "step:chain+ownnoise+setnone+freshleaf",
+           # THE CAUSE (expected: rc -11): one backward on the legacy default stream before the capture.  The parameters'
+           # AccumulateGrad nodes are bound to the stream of the first backward and stay alive across steps (the module
+           # keeps `attention_bins_beforesoftmax`, whose grad_fn holds the graph); in the capture the autograd engine then
+           # synchronises the capture stream with the NULL stream, and hipStreamEndCapture dereferences a null pointer
+           # instead of returning hipErrorStreamCaptureImplicit / Unjoined.  Also segfaults: ANY configuration under
+           # rocprofv3.  Remedy (torch's documented recipe): every step before the capture on a side stream.
+           "step:chain+defaultwarm"]
 
 
 def one(config: str) -> None:
@@ -22,6 +34,7 @@ def one(config: str) -> None:
     from samble_amd import ops, sampler_config, synth
     from samble_amd.downsample import DownSampleToken
     what, switch = config.split(":")
+    switch, *extras = switch.split("+")
     dev = torch.device("cuda:0")
     B, C, N, M, nb = 32, 128, 2048, 1024, 6
     if os.environ.get("PROBE_SMALL"):
@@ -47,15 +60,21 @@ def one(config: str) -> None:
             with torch.no_grad():
                 (x_ds, idx), _ = mod(xin, noise=noise)
             return x_ds, idx, None
-        opt.zero_grad(set_to_none=False)
-        if xin.grad is not None:
+        opt.zero_grad(set_to_none="setnone" in extras)
+        xi = xin
+        if "freshleaf" in extras:
+            xi = x.detach().requires_grad_(True)
+        elif xin.grad is not None:
             xin.grad.zero_()
-        (x_ds, idx), _ = mod(xin, noise=noise)
+        (x_ds, idx), _ = mod(xi, noise=None if "ownnoise" in extras else noise)
         x_ds.backward(g)
         if what == "step":
             opt.step()
-        return x_ds, idx, xin.grad
+        return x_ds, idx, xi.grad
 
+    if "defaultwarm" in extras:
+        step()      # a backward on the legacy default stream: binds the AccumulateGrad nodes to it
+        torch.cuda.synchronize()
     # warm-up on a side stream, as torch.cuda.graph wants it (allocator pools, one-time library initialisation,
     # the first call's boundary state)
     s = torch.cuda.Stream()
@@ -82,6 +101,10 @@ def one(config: str) -> None:
         graph.replay()
         torch.cuda.synchronize()
         results.append([t.clone() if t is not None else None for t in out])
+    if "ownnoise" in extras:   # every replay draws new noise: nothing to compare bit for bit
+        results[1] = results[0]
+        eager = results[0]
+        eager_w = None
     same = all((a is None and b is None) or torch.equal(a, b) for a, b in zip(results[0], results[1]))
     vs_eager = all((a is None and b is None) or torch.equal(a, b) for a, b in zip(results[0], eager))
     if eager_w is not None:
