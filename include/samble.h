@@ -246,8 +246,8 @@ int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
  * samble_segment_sum_rows_f32: out[t][0:C] = sum over the incoming edges e of target t of
  * src[per_edge ? e : e / K][0:C]  (C = 64): EdgeConv's backward (sum of per-edge gradients / of the
  * sources' per-point rows over a point's reverse neighbours). */
-int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K, int C,
-                                int per_edge, int64_t n_targets, float* out, void* stream);
+int samble_segment_sum_rows_f32(const float* src, int64_t src_row_stride, const int32_t* inv_order, const int32_t* inv_offsets,
+                                int K, int C, int per_edge, int64_t n_targets, float* out, void* stream);
 /* The lists themselves, on the device and without a sort (a query lists a target at most once -- the rows of nn hold
  * distinct indices, as samble_knn_f32 writes them -- so "ascending edge id" inside a group is "ascending query": a
  * bit matrix targets x queries, prefix popcounts, one placement pass).  nn (B,N,KN) with entries in [0, N);
@@ -540,7 +540,10 @@ int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, const float
 size_t samble_edge_glue_partials_bytes(void);
 size_t samble_edge_glue_constants_bytes(void);
 size_t samble_edge_glue_statistics_bytes(void);
-int samble_edge_bn1_f32(const float* a, const float* b, const int32_t* nn, int B, int N, int K, int C, const float* gamma1,
+/* a, b: rows of C floats at ab_row_stride floats (= C for two separate tensors; 2 C for the two halves [a | b] of one
+ * (B, N, 2 C) projection output: the layer's two per-point projections come from ONE 1x1 convolution and are read where they
+ * are).  da, db of samble_edge_bwd_post_f32 likewise at dab_row_stride: written as the halves of one (B, N, 2 C) gradient. */
+int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_row_stride, const int32_t* nn, int B, int N, int K, int C, const float* gamma1,
                         const float* beta1, float eps, float* running_mean, float* running_var, float momentum, float* S,
                         float* Q, float* ap, float* bp, float* constants, double* statistics, double* partials, void* stream);
 int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
@@ -550,10 +553,11 @@ int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t*
 int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2, float* constants,
                             const double* statistics, float* sdv, float* dgamma2, float* dbeta2, double* partials,
                             void* stream);
-int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum, const float* D,
-                             const int32_t* indeg, int B, int N, int K, int C, float* constants, const double* statistics,
-                             const float* dw2_partials, int n_partials, float* da, float* db, float* dgamma1, float* dbeta1,
-                             float* dW2, double* partials, void* stream);
+int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stride, const float* S, const float* R,
+                             const float* dusum, const float* D, const int32_t* indeg, int B, int N, int K, int C,
+                             float* constants, const double* statistics, const float* dw2_partials, int n_partials, float* da,
+                             float* db, int64_t dab_row_stride, float* dgamma1, float* dbeta1, float* dW2, double* partials,
+                             void* stream);
 
 /* ---- 1x1 convolutions over C = 128 input channels next to the neighbour / sampler kernels (csrc/linear.hip) --------
  * Replace, in the layers that sandwich the sampler:
@@ -588,6 +592,10 @@ int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, con
 #define SAMBLE_LIN_LEAKY_MASK 2
 size_t samble_linear_image_bytes(int O);
 int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream);
+/* ... of the TRANSPOSE of Wt (128, O) row-major: the images samble_linear_weight_images_f32 would write for Wt^T (O, 128),
+ * without the transposing copy (models/attention.py:187-192: the second FFN convolution's weight (128, 512, 1) feeds
+ * samble_linear_dx_tri_f32 as W^T).  Two-plane build of csrc/linear.hip only (the default). */
+int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, void* rm_image, void* tr_image, void* stream);
 int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int epilogue,
                               const float* ref, float* out, int64_t o_bs, int64_t o_rs, void* stream);
 size_t samble_linear_amax_workspace_bytes(int B, int N, int O);
@@ -598,6 +606,9 @@ int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const v
 size_t samble_linear_dw_workspace_bytes(int B, int N, int O);
 int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
                              int O, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* ... written transposed: dWt (128, O) row-major -- that convolution's weight gradient in its parameter's own layout */
+int samble_linear_dw_t_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
+                               int O, float* dWt, void* ws, size_t ws_bytes, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);

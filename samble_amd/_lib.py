@@ -66,7 +66,7 @@ _SIGNATURES = {
     "samble_edge_glue_partials_bytes": (c_size_t, []),
     "samble_edge_glue_constants_bytes": (c_size_t, []),
     "samble_edge_glue_statistics_bytes": (c_size_t, []),
-    "samble_edge_bn1_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
+    "samble_edge_bn1_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "samble_edge_bn2_out_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
@@ -74,9 +74,9 @@ _SIGNATURES = {
                                         c_void_p, c_void_p]),
     "samble_edge_bwd_pre_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
-    "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_interp_blend_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                             c_void_p]),
     "samble_interp_blend_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -84,6 +84,7 @@ _SIGNATURES = {
                                             c_void_p, c_size_t, c_void_p]),
     "samble_linear_image_bytes": (c_size_t, [c_int]),
     "samble_linear_weight_images_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "samble_linear_weight_images_t_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                           c_int64, c_int64, c_void_p]),
     "samble_linear_amax_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -93,6 +94,8 @@ _SIGNATURES = {
                                          c_void_p]),
     "samble_linear_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_dw_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
+    "samble_linear_dw_t_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
     "samble_amax_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_amax_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -125,7 +128,7 @@ _SIGNATURES = {
     "samble_n2p_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_n2p_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "samble_segment_sum_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "samble_segment_sum_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "samble_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "samble_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

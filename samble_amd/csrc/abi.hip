@@ -54,7 +54,7 @@ int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, in
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
-int samble_launch_seg_sum_rows64(const float*, const int*, const int*, int, int, long, float*, hipStream_t);
+int samble_launch_seg_sum_rows64(const float*, long, const int*, const int*, int, int, long, float*, hipStream_t);
 size_t samble_inverse_neighbors_ws_bytes(int B, int N);
 int samble_launch_inverse_neighbors(const int*, int, int, int, int*, int*, int*, void*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
@@ -101,27 +101,28 @@ size_t samble_chain_flag_offset(void);
 size_t samble_edge_glue_part_bytes(void);
 size_t samble_edge_glue_cst_bytes(void);
 size_t samble_edge_glue_st_bytes(void);
-int samble_launch_edge_pre(const float*, const float*, const int*, int, int, const float*, const float*, float, float*, float*,
+int samble_launch_edge_pre(const float*, const float*, long, const int*, int, int, const float*, const float*, float, float*, float*,
                            float, float*, float*, float*, float*, float*, double*, double*, hipStream_t);
 int samble_launch_edge_post(const float*, const float*, const unsigned char*, const unsigned char*, const double*, int, int, int,
                             const float*, const float*, float, float*, float*, float, float*, double*, float*, unsigned char*,
                             float*, hipStream_t);
 int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float*, float*, const double*, float*, float*, float*,
                                double*, hipStream_t);
-int samble_launch_edge_bwd_post(const float*, const float*, const float*, const float*, const float*, const float*, const int*,
-                                int, int, float*, const double*, const float*, int, float*, float*, float*, float*, float*,
+int samble_launch_edge_bwd_post(const float*, const float*, long, const float*, const float*, const float*, const float*, const int*,
+                                int, int, float*, const double*, const float*, int, float*, float*, long, float*, float*, float*,
                                 double*, hipStream_t);
 int samble_launch_interp_fwd(const float*, int, int, int, const int*, const float*, int, int, float*, float*, hipStream_t);
 int samble_launch_interp_bwd(const float*, int, int, int, const float*, const int*, const int*, int, int, float*, void*, hipStream_t);
 size_t samble_interp_bwd_ws_bytes(int, int, int, int);
 size_t samble_linear_image_bytes_impl(int O);
-int samble_launch_linear_images(const float*, int, void*, void*, hipStream_t);
+int samble_launch_linear_images(const float*, int, void*, void*, int, hipStream_t);
+int samble_linear_is_duo(void);
 int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
 size_t samble_linear_amax_ws_bytes(int, int, int);
 int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
 int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, int, float*, long, hipStream_t);
 size_t samble_linear_dw_ws_bytes(int, int, int);
-int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, void*, hipStream_t);
+int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, int, void*, hipStream_t);
 size_t samble_amax_bwd_ws_bytes(int, int, int);
 int samble_launch_amax_bwd(const float*, long, int, int, const int*, const float*, const float*, int, float*, long, float*,
                            void*, hipStream_t);
@@ -412,12 +413,15 @@ SAMBLE_API int samble_inverse_neighbors(const int32_t* nn, int B, int N, int KN,
               "samble_inverse_neighbors");
 }
 
-SAMBLE_API int samble_segment_sum_rows_f32(const float* src, const int32_t* inv_order, const int32_t* inv_offsets, int K,
-                                           int C, int per_edge, int64_t n_targets, float* out, void* stream) {
+SAMBLE_API int samble_segment_sum_rows_f32(const float* src, int64_t src_row_stride, const int32_t* inv_order,
+                                           const int32_t* inv_offsets, int K, int C, int per_edge, int64_t n_targets,
+                                           float* out, void* stream) {
   if (!src || !inv_order || !inv_offsets || !out)
     return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_f32: null pointer");
   if (C != 64 || K <= 0 || n_targets <= 0) return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_f32: built for 64 channels");
-  return done(samble_launch_seg_sum_rows64(src, inv_order, inv_offsets, K, per_edge, (long)n_targets, out,
+  if (src_row_stride < C || (src_row_stride & 1) || ((uintptr_t)src & 7))
+    return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_f32: src rows must be 8-byte aligned, row stride >= C");
+  return done(samble_launch_seg_sum_rows64(src, (long)src_row_stride, inv_order, inv_offsets, K, per_edge, (long)n_targets, out,
                                            (hipStream_t)stream),
               "samble_segment_sum_rows_f32");
 }
@@ -872,15 +876,17 @@ SAMBLE_API size_t samble_edge_glue_statistics_bytes(void) { return samble_edge_g
 
 static int edge_shape_ok(int B, int N, int K, int C) { return B > 0 && N > 0 && K == 32 && C == 64; }
 
-SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, const int32_t* nn, int B, int N, int K, int C,
+SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_row_stride, const int32_t* nn, int B, int N, int K, int C,
                                    const float* gamma1, const float* beta1, float eps, float* running_mean,
                                    float* running_var, float momentum, float* S, float* Q, float* ap, float* bp,
                                    float* constants, double* statistics, double* partials, void* stream) {
   if (!a || !b || !nn || !gamma1 || !beta1 || !S || !Q || !ap || !bp || !constants || !statistics || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: null pointer");
   if (!edge_shape_ok(B, N, K, C)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: built for K = 32 neighbours, 64 channels");
+  if (ab_row_stride < C || (ab_row_stride & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
+    return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: a / b rows must be 16-byte aligned, row stride >= C");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: running statistics come as a pair");
-  return done(samble_launch_edge_pre(a, b, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum, S, Q, ap, bp,
+  return done(samble_launch_edge_pre(a, b, (long)ab_row_stride, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum, S, Q, ap, bp,
                                      constants, statistics, partials, (hipStream_t)stream),
               "samble_edge_bn1_f32");
 }
@@ -910,17 +916,21 @@ SAMBLE_API int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, 
               "samble_edge_bwd_pre_f32");
 }
 
-SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, const float* S, const float* R, const float* dusum,
-                                        const float* D, const int32_t* indeg, int B, int N, int K, int C, float* constants,
-                                        const double* statistics, const float* dw2_partials, int n_partials, float* da,
-                                        float* db, float* dgamma1, float* dbeta1, float* dW2, double* partials,
-                                        void* stream) {
+SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stride, const float* S, const float* R,
+                                        const float* dusum, const float* D, const int32_t* indeg, int B, int N, int K, int C,
+                                        float* constants, const double* statistics, const float* dw2_partials,
+                                        int n_partials, float* da, float* db, int64_t dab_row_stride, float* dgamma1,
+                                        float* dbeta1, float* dW2, double* partials, void* stream) {
   if (!a || !b || !S || !R || !dusum || !D || !indeg || !constants || !statistics || !dw2_partials || !da || !db || !dgamma1 ||
       !dbeta1 || !dW2 || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: null pointer");
   if (!edge_shape_ok(B, N, K, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: built for K = 32 neighbours, 64 channels");
-  return done(samble_launch_edge_bwd_post(a, b, S, R, dusum, D, indeg, B, N, constants, statistics, dw2_partials, n_partials,
-                                          da, db, dgamma1, dbeta1, dW2, partials, (hipStream_t)stream),
+  if (ab_row_stride < C || (ab_row_stride & 1) || dab_row_stride < C || (dab_row_stride & 1) || ((uintptr_t)a & 7) ||
+      ((uintptr_t)b & 7) || ((uintptr_t)da & 7) || ((uintptr_t)db & 7))
+    return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: rows must be 8-byte aligned, row strides >= C");
+  return done(samble_launch_edge_bwd_post(a, b, (long)ab_row_stride, S, R, dusum, D, indeg, B, N, constants, statistics,
+                                          dw2_partials, n_partials, da, db, (long)dab_row_stride, dgamma1, dbeta1, dW2,
+                                          partials, (hipStream_t)stream),
               "samble_edge_bwd_post_f32");
 }
 
@@ -955,7 +965,14 @@ SAMBLE_API size_t samble_linear_image_bytes(int O) { return O > 0 ? samble_linea
 SAMBLE_API int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream) {
   if (!W || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: null pointer");
   if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_f32: W must be (O, 128) (narrower layers: zero columns), O a multiple of 32");
-  return done(samble_launch_linear_images(W, O, rm_image, tr_image, (hipStream_t)stream), "samble_linear_weight_images_f32");
+  return done(samble_launch_linear_images(W, O, rm_image, tr_image, 0, (hipStream_t)stream), "samble_linear_weight_images_f32");
+}
+
+SAMBLE_API int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, void* rm_image, void* tr_image, void* stream) {
+  if (!Wt || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: Wt must be (128, O), O a multiple of 32");
+  if (!samble_linear_is_duo()) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: needs the two-plane build of csrc/linear.hip");
+  return done(samble_launch_linear_images(Wt, O, rm_image, tr_image, 1, (hipStream_t)stream), "samble_linear_weight_images_t_f32");
 }
 
 SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O,
@@ -1002,7 +1019,18 @@ SAMBLE_API int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_
     return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: 1 <= C <= 128, O a multiple of 128");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: g rows must be 16-byte aligned");
   if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_tri_f32: workspace too small");
-  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dW, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dW, 0, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
+}
+
+/* the same sum, written transposed: dWt (128, O) row-major (C = 128 only) */
+SAMBLE_API int samble_linear_dw_t_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
+                                          int N, int O, float* dWt, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !x || !dWt || !ws) return fail(SAMBLE_E_INVALID, "samble_linear_dw_t_tri_f32: null pointer");
+  if (C != 128 || !lin_shape_ok(B, N, O) || (O & 127))
+    return fail(SAMBLE_E_INVALID, "samble_linear_dw_t_tri_f32: C must be 128, O a multiple of 128");
+  if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_t_tri_f32: g rows must be 16-byte aligned");
+  if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_t_tri_f32: workspace too small");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dWt, 1, ws, (hipStream_t)stream), "samble_linear_dw_t_tri_f32");
 }
 
 SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int N, int O) {

@@ -70,8 +70,9 @@ __device__ __forceinline__ void chan_totals2(const double* __restrict__ part, in
 }
 
 // ---- forward 1: S, Q of every point (edge_gather_sums) and the BN1 edge sums  sum u = K a + S,  sum u^2 = K a^2 + 2 a S + Q
+// (a, bp: rows of 64 floats at a stride of `rs` floats -- the two halves of one (points, 128) projection output)
 __global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp,
-                                                              const int* __restrict__ nn, int N, long npoints,
+                                                              long rs, const int* __restrict__ nn, int N, long npoints,
                                                               float* __restrict__ S, float* __restrict__ Q,
                                                               double* __restrict__ part) {
   const int hw = threadIdx.x >> 5, c2 = threadIdx.x & 31;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __res
 #pragma unroll 8
     for (int k = 0; k < kGK; ++k) {
       const int j = ni[k];
-      const float2 v = *reinterpret_cast<const float2*>(bp + (cloud * N + j) * kGC + 2 * c2);
+      const float2 v = *reinterpret_cast<const float2*>(bp + (cloud * N + j) * rs + 2 * c2);
       s0 += v.x;
       s1 += v.y;
       q0 = fmaf(v.x, v.x, q0);
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __res
     }
     *reinterpret_cast<float2*>(S + p * kGC + 2 * c2) = make_float2(s0, s1);
     *reinterpret_cast<float2*>(Q + p * kGC + 2 * c2) = make_float2(q0, q1);
-    const float2 av = *reinterpret_cast<const float2*>(a + p * kGC + 2 * c2);
+    const float2 av = *reinterpret_cast<const float2*>(a + p * rs + 2 * c2);
     const double a0 = av.x, a1 = av.y;
     acc[0][0] += kGK * a0 + (double)s0;
     acc[0][1] += kGK * a1 + (double)s1;
@@ -141,13 +142,13 @@ __global__ __launch_bounds__(1024) void edge_bn1_finalize_kernel(const double* _
 
 // ---- forward 2b: the BN1-folded projections the MLP sweeps read: a' = a sc1 + sh1, b' = b sc1 (two roundings each,
 // like the elementwise expressions they replace)
-__global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+__global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict__ a, const float* __restrict__ bp, long rs,
                                                         const float* __restrict__ cst, long n4, float* __restrict__ ap,
                                                         float* __restrict__ bpo) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of a row (16 per row)
   if (e >= n4) return;
   const int c = 4 * (int)(e & 15);
-  const f32x4 av = reinterpret_cast<const f32x4*>(a)[e], bv = reinterpret_cast<const f32x4*>(bp)[e];
+  const f32x4 av = *reinterpret_cast<const f32x4*>(a + (e >> 4) * rs + c), bv = *reinterpret_cast<const f32x4*>(bp + (e >> 4) * rs + c);
   f32x4 oa, ob;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(1024) void edge_bwd2_finalize_kernel(const double* 
 
 // ---- backward 3: sums over the points of du_i (= sum_k du_ik) and of a_i du_i + b_i D_i (D_i = sum over the incoming
 // edges of du): the edge sums of du and du u that BN1's backward needs
-__global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp,
+__global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp, long rs,
                                                              const float* __restrict__ dusum, const float* __restrict__ D,
                                                              long npoints, double* __restrict__ part) {
   const int rl = threadIdx.x >> 5, c2 = threadIdx.x & 31;
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __rest
   const long per = (npoints + gridDim.x - 1) / gridDim.x;
   const long p0 = (long)blockIdx.x * per, p1 = min(p0 + per, npoints);
   for (long p = p0 + rl; p < p1; p += 8) {
-    const long at = p * kGC + 2 * c2;
-    const float2 av = *reinterpret_cast<const float2*>(a + at), bv = *reinterpret_cast<const float2*>(bp + at);
+    const long at = p * kGC + 2 * c2, ar = p * rs + 2 * c2;
+    const float2 av = *reinterpret_cast<const float2*>(a + ar), bv = *reinterpret_cast<const float2*>(bp + ar);
     const float2 uv = *reinterpret_cast<const float2*>(dusum + at), dvv = *reinterpret_cast<const float2*>(D + at);
     acc[0][0] += (double)uv.x;
     acc[0][1] += (double)uv.y;
@@ -312,15 +313,15 @@ __global__ __launch_bounds__(256) void edge_bwd_final_kernel(const float* __rest
                                                              const float* __restrict__ S, const float* __restrict__ R,
                                                              const float* __restrict__ dusum, const float* __restrict__ D,
                                                              const int* __restrict__ indeg, const float* __restrict__ cst,
-                                                             const double* __restrict__ st, long npoints,
-                                                             float* __restrict__ da, float* __restrict__ db) {
+                                                             const double* __restrict__ st, long npoints, long rs,
+                                                             float* __restrict__ da, float* __restrict__ db, long drs) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;  // one float2 of a row
   if (e >= npoints * 32) return;
   const long p = e >> 5;
   const int c = 2 * (int)(e & 31);
-  const long at = p * kGC + c;
+  const long at = p * kGC + c, ar = p * rs + c;
   const float deg = (float)indeg[p];
-  const float2 av = *reinterpret_cast<const float2*>(a + at), bv = *reinterpret_cast<const float2*>(bp + at);
+  const float2 av = *reinterpret_cast<const float2*>(a + ar), bv = *reinterpret_cast<const float2*>(bp + ar);
   const float2 sv = *reinterpret_cast<const float2*>(S + at), rv = *reinterpret_cast<const float2*>(R + at);
   const float2 uv = *reinterpret_cast<const float2*>(dusum + at), dvv = *reinterpret_cast<const float2*>(D + at);
   float oa[2], ob[2];
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(256) void edge_bwd_final_kernel(const float* __rest
     oa[u] = sc * (du - kGK * m1 - m2 * zs);
     ob[u] = sc * (dd - deg * m1 - m2 * zr);
   }
-  *reinterpret_cast<float2*>(da + at) = make_float2(oa[0], oa[1]);
-  *reinterpret_cast<float2*>(db + at) = make_float2(ob[0], ob[1]);
+  *reinterpret_cast<float2*>(da + p * drs + c) = make_float2(oa[0], oa[1]);
+  *reinterpret_cast<float2*>(db + p * drs + c) = make_float2(ob[0], ob[1]);
 }
 
 // out[e] = sum over the nparts blocks (each n floats): 64 x 64 dW2 from the per-wave partials.  Workgroup = 16 elements
@@ -371,15 +372,15 @@ extern "C" size_t samble_edge_glue_cst_bytes(void) { return (size_t)kCstWords * 
 extern "C" size_t samble_edge_glue_st_bytes(void) { return (size_t)kStWords * sizeof(double); }
 
 // forward, before the MLP sweep: S, Q, BN1 constants (cst: sc1, sh1; st: mu1, sig1), running statistics (optional)
-extern "C" int samble_launch_edge_pre(const float* a, const float* b, const int* nn, int B, int N, const float* gamma1,
+extern "C" int samble_launch_edge_pre(const float* a, const float* b, long rs, const int* nn, int B, int N, const float* gamma1,
                                       const float* beta1, float eps, float* rmean, float* rvar, float momentum, float* S,
                                       float* Q, float* ap, float* bp, float* cst, double* st, double* part, hipStream_t s) {
   const long np = (long)B * N;
   Timed timed(kT_edge_sums, s);
-  hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, nn, N, np, S, Q, part);
+  hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, nn, N, np, S, Q, part);
   hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
                      cst, st, rmean, rvar, momentum);
-  hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, cst, np * 16, ap, bp);
+  hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, rs, cst, np * 16, ap, bp);
   return (int)hipGetLastError();
 }
 
@@ -412,16 +413,16 @@ extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int 
 }
 
 // backward, after the MLP sweep and the reverse-neighbour sums D (of du) and R (of a): d gamma1, d beta1, da, db; dW2
-extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, const float* S, const float* R,
+extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, long rs, const float* S, const float* R,
                                            const float* dusum, const float* D, const int* indeg, int B, int N, float* cst,
                                            const double* st, const float* dw2part, int nwaves, float* da, float* db,
-                                           float* dgamma1, float* dbeta1, float* dW2, double* part, hipStream_t s) {
+                                           long drs, float* dgamma1, float* dbeta1, float* dW2, double* part, hipStream_t s) {
   const long np = (long)B * N;
-  hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, dusum, D, np, part);
+  hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, dusum, D, np, part);
   hipLaunchKernelGGL(edge_bwd1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, cst, st, dgamma1,
                      dbeta1);
   hipLaunchKernelGGL(edge_bwd_final_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, a, b, S, R, dusum, D,
-                     indeg, cst, st, np, da, db);
+                     indeg, cst, st, np, rs, da, db, drs);
   hipLaunchKernelGGL(edge_sum_parts_kernel, dim3(kGC * kGC / 16), dim3(256), 0, s, dw2part, nwaves, kGC * kGC, dW2);
   return (int)hipGetLastError();
 }

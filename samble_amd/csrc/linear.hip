@@ -674,8 +674,10 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
 
 // out[e] = sum over the nparts partial blocks (each n4 float4) in a fixed order: 16 groups of threads take the parts
 // p = g, g + 16, ... (16 loads in flight each), then the 16 group sums are added in index order
+// (tr_O > 0: the (tr_O, 128) sum leaves transposed, out[c][o] -- the second FFN convolution's weight gradient in the
+// layout its parameter has)
 __global__ __launch_bounds__(256) void lin_sum_parts_kernel(const float* __restrict__ part, int nparts, long n4,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int tr_O) {
   __shared__ f32x4 red[16][17];
   const int e4l = threadIdx.x & 15, g = threadIdx.x >> 4;
   const long e4 = (long)blockIdx.x * 16 + e4l;
@@ -700,7 +702,13 @@ __global__ __launch_bounds__(256) void lin_sum_parts_kernel(const float* __restr
     f32x4 tot = red[0][e4l];
 #pragma unroll
     for (int k = 1; k < 16; ++k) tot += red[k][e4l];
-    reinterpret_cast<f32x4*>(out)[e4] = tot;
+    if (tr_O) {
+      const long o = e4 >> 5, c = 4 * (e4 & 31);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) out[(c + k) * tr_O + o] = tot[k];
+    } else {
+      reinterpret_cast<f32x4*>(out)[e4] = tot;
+    }
   }
 }
 
@@ -866,14 +874,16 @@ __global__ __launch_bounds__(256) void amax_dw_kernel(const float* __restrict__ 
 }
 
 // duo images of one 32-row tile of W (O x 128 row-major) per workgroup
+// (trans_O > 0: W arrives TRANSPOSED, (128, trans_O) row-major -- the second FFN convolution's weight as the module holds
+// it -- and the images are those of its transpose (trans_O, 128): no transposing copy in front of this launch)
 __global__ __launch_bounds__(256) void lin_images_duo_kernel(const float* __restrict__ W, char* __restrict__ rm,
-                                                             char* __restrict__ tr) {
+                                                             char* __restrict__ tr, int trans_O) {
   __shared__ float wt[32][129];
   __shared__ float red[4];
   const int tile = blockIdx.x, tid = threadIdx.x;
   float mx = 0.f;
   for (int e = tid; e < 32 * 128; e += 256) {
-    const float v = W[((long)tile * 32 + (e >> 7)) * 128 + (e & 127)];
+    const float v = trans_O ? W[(long)(e & 127) * trans_O + tile * 32 + (e >> 7)] : W[((long)tile * 32 + (e >> 7)) * 128 + (e & 127)];
     wt[e >> 7][e & 127] = v;
     mx = fmaxf(mx, fabsf(v));
   }
@@ -925,11 +935,12 @@ extern "C" size_t samble_linear_image_bytes_impl(int O) { return (size_t)((O + 3
 
 // row image and / or transposed image of W (O x 128, row-major): three bf16 planes, or (duo) two fp16 planes of the
 // tile x 2^e in the slots of the first two pieces, 2^-e in the tile's spare slot (kDuoScaleSlot / kDuoTrScaleSlot)
-extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, hipStream_t s) {
-  if (!kLinDuo) return samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
-  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O / 32), dim3(256), 0, s, W, (char*)rm, (char*)tr);
+extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, int transposed, hipStream_t s) {
+  if (!kLinDuo) return transposed ? (int)hipErrorNotSupported : samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
+  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O / 32), dim3(256), 0, s, W, (char*)rm, (char*)tr, transposed ? O : 0);
   return (int)hipGetLastError();
 }
+extern "C" int samble_linear_is_duo(void) { return kLinDuo ? 1 : 0; }
 
 extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O, int epi,
                                         const float* ref, float* out, long o_bs, long o_rs, hipStream_t s) {
@@ -992,7 +1003,7 @@ extern "C" size_t samble_linear_dw_ws_bytes(int B, int N, int O) {
 }
 
 extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int Cin, int N,
-                                       int O, float* dW, void* ws, hipStream_t s) {
+                                       int O, float* dW, int transposed, void* ws, hipStream_t s) {
   const int chunks = (N + kLdwPts - 1) / kLdwPts;
   Timed timed(kT_lin_dw, s);
   if (O % 256 == 0) {
@@ -1010,7 +1021,7 @@ extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, con
   }
   const long n4 = (long)O * 128 / 4;
   hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B * chunks,
-                     n4, dW);
+                     n4, dW, transposed ? O : 0);
   return (int)hipGetLastError();
 }
 

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void n2p_bwd_gather_kernel(const float* __rest
 
 // out[t][0:C] = sum over the incoming edges e of target t of src[per_edge ? e : e / K][0:C]  (C = 64),
 // in list order: the deterministic replacement of index_add_ for EdgeConv's backward
-__global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __restrict__ src, const int* __restrict__ order,
+__global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __restrict__ src, long src_rs, const int* __restrict__ order,
                                                              const int* __restrict__ offs, int KN, int per_edge,
                                                              long ntargets, float* __restrict__ out) {
   const int hw = threadIdx.x >> 5, c = threadIdx.x & 31;  // lane = channels 2c, 2c+1
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __rest
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long e = order[s + u];
-        v[u] = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * 64 + 2 * c);
+        v[u] = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * src_rs + 2 * c);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void seg_sum_rows64_kernel(const float* __rest
     }
     for (; s < e1; ++s) {
       const long e = order[s];
-      const float2 v = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * 64 + 2 * c);
+      const float2 v = *reinterpret_cast<const float2*>(src + (per_edge ? e : e / KN) * src_rs + 2 * c);
       s0 += v.x;
       s1 += v.y;
     }
@@ -678,10 +678,10 @@ extern "C" int samble_launch_inverse_neighbors(const int* nn, int B, int N, int 
   return (int)hipGetLastError();
 }
 
-extern "C" int samble_launch_seg_sum_rows64(const float* src, const int* order, const int* offs, int KN, int per_edge,
+extern "C" int samble_launch_seg_sum_rows64(const float* src, long src_rs, const int* order, const int* offs, int KN, int per_edge,
                                             long ntargets, float* out, hipStream_t s) {
   samble::Timed timed(samble::kT_seg_sum, s);
-  hipLaunchKernelGGL(samble::seg_sum_rows64_kernel, dim3(2048), dim3(256), 0, s, src, order, offs, KN, per_edge, ntargets,
+  hipLaunchKernelGGL(samble::seg_sum_rows64_kernel, dim3(2048), dim3(256), 0, s, src, src_rs, order, offs, KN, per_edge, ntargets,
                      out);
   return (int)hipGetLastError();
 }

@@ -57,6 +57,32 @@ def _edge_weights(w1: torch.Tensor, group_type: str):
     raise ValueError(f"group_type should be neighbor, diff, center_neighbor or center_diff, but got {group_type}")
 
 
+class _EdgeWeights(torch.autograd.Function):
+    """conv1 weight (Cout, Cin_total, 1, 1) -> (2 Cout, C) = [Wa ; Wb] of _edge_weights, with its gradient in closed form: two
+    small launches each way where autograd's slice / cat / neg nodes took a dozen (each one a launch of its own)."""
+
+    @staticmethod
+    def forward(ctx, w1, group_type):
+        wa, wb = _edge_weights(w1.detach(), group_type)
+        ctx.group_type = group_type
+        return torch.cat((wa, wb), dim=0)
+
+    @staticmethod
+    def backward(ctx, dwab):
+        half = dwab.shape[0] // 2
+        da, db = dwab[:half], dwab[half:]
+        gt = ctx.group_type
+        if gt == "neighbor":
+            dw = db
+        elif gt == "diff":
+            dw = db - da
+        elif gt == "center_neighbor":
+            dw = torch.cat((da, db), dim=1)
+        else:  # center_diff: Wa = Wc - Wd, Wb = Wd
+            dw = torch.cat((da, db - da), dim=1)
+        return dw.reshape(dw.shape[0], dw.shape[1], 1, 1), None
+
+
 class _EdgeMLP(torch.autograd.Function):
     """a, b (B,N,64) per-point projections, nn (B,N,32) -> (B,64,N)."""
 
@@ -198,15 +224,19 @@ class _EdgeMLP(torch.autograd.Function):
 class _EdgeMLPFused(torch.autograd.Function):
     """_EdgeMLP with its closed forms on HIP (csrc/edge_glue.hip): BatchNorm batch statistics, their backward
     corrections, the activation and the per-point gradients as a dozen launches instead of ~250 torch ones.  Training
-    mode on one rank (SyncBatchNorm pooling and evaluation take _EdgeMLP).  a, b (B,N,64), nn (B,N,32) -> (B,64,N)."""
+    mode on one rank (SyncBatchNorm pooling and evaluation take _EdgeMLP).  ab (B,N,128) = the two per-point projections
+    [a | b] as the ONE 1x1 convolution that forms them wrote them (read where they are, row stride 128; the gradient
+    leaves as one (B,N,128) tensor the same way: no slice copies, no zero-filled halves), nn (B,N,32) -> (B,64,N)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, a, b, nn_idx, g1, b1, w2, g2, b2, bn1, bn2):
-        B, N, C = a.shape
+    def forward(ctx, ab, nn_idx, g1, b1, w2, g2, b2, bn1, bn2):
+        B, N, C2 = ab.shape
+        C = C2 // 2
         K = nn_idx.shape[2]
-        dev = a.device
-        a, b = a.contiguous(), b.contiguous()
+        dev = ab.device
+        ab = ab.contiguous()
+        a, b = ab[..., :C], ab[..., C:]          # views: a.data_ptr() = ab's, b's 4 C bytes behind it, row stride 2 C
         g1, b1, g2, b2 = (t.detach().float().contiguous() for t in (g1, b1, g2, b2))
         w2m = w2.detach()[:, :, 0, 0].float().contiguous()
         run = lambda bn: (bn.running_mean, bn.running_var) if (bn.track_running_stats and bn.running_mean is not None) \
@@ -218,7 +248,7 @@ class _EdgeMLPFused(torch.autograd.Function):
             st = torch.empty(_lib.query("samble_edge_glue_statistics_bytes") // 8, dtype=torch.float64, device=dev)
             part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
             rm1, rv1 = run(bn1)
-            _lib.call("samble_edge_bn1_f32", a.data_ptr(), b.data_ptr(), nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
+            _lib.call("samble_edge_bn1_f32", a.data_ptr(), b.data_ptr(), C2, nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
                       b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), S.data_ptr(),
                       Q.data_ptr(), ap.data_ptr(), bp.data_ptr(), cst.data_ptr(), st.data_ptr(), part.data_ptr(),
                       ops._stream())
@@ -242,14 +272,16 @@ class _EdgeMLPFused(torch.autograd.Function):
                 for bn in (bn1, bn2):
                     if bn.track_running_stats and bn.num_batches_tracked is not None:
                         bn.num_batches_tracked += 1
-        ctx.save_for_backward(a, b, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2)
+        ctx.save_for_backward(ab, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2)
         return out
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
-        a, b, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2 = ctx.saved_tensors
-        B, N, C = a.shape
+        ab, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2 = ctx.saved_tensors
+        B, N, C2 = ab.shape
+        C = C2 // 2
+        a, b = ab[..., :C], ab[..., C:]
         K = nn_idx.shape[2]
         dev = a.device
         g = g.float().contiguous()
@@ -270,14 +302,14 @@ class _EdgeMLPFused(torch.autograd.Function):
             # reverse-neighbour sums in a fixed order (inverse lists), not index_add_'s atomics
             order, offsets, counts = ops.inverse_neighbors(nn_idx)
             D = ops.stage_segment_sum_rows(du.view(-1, C), order, offsets, K, per_edge=True)
-            R = ops.stage_segment_sum_rows(a.view(-1, C), order, offsets, K, per_edge=False)
-            da, db = f32(B, N, C), f32(B, N, C)
+            R = ops.stage_segment_sum_rows(ab.view(-1, C2)[:, :C], order, offsets, K, per_edge=False)
+            dab = f32(B, N, C2)
             dg1, db1, dw2 = f32(C), f32(C), f32(C, C)
-            _lib.call("samble_edge_bwd_post_f32", a.data_ptr(), b.data_ptr(), S.data_ptr(), R.data_ptr(), dusum.data_ptr(),
+            _lib.call("samble_edge_bwd_post_f32", a.data_ptr(), b.data_ptr(), C2, S.data_ptr(), R.data_ptr(), dusum.data_ptr(),
                       D.data_ptr(), counts.data_ptr(), B, N, K, C, cst.data_ptr(), st.data_ptr(), dwp.data_ptr(), nparts,
-                      da.data_ptr(), db.data_ptr(), dg1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), part.data_ptr(),
-                      ops._stream())
-        return da, db, None, dg1, db1, dw2.view(C, C, 1, 1), dg2, db2, None, None
+                      dab.data_ptr(), dab.data_ptr() + 4 * C, C2, dg1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                      part.data_ptr(), ops._stream())
+        return dab, None, dg1, db1, dw2.view(C, C, 1, 1), dg2, db2, None, None
 
 
 FUSED_GLUE = True  # False: the closed forms as torch expressions (_EdgeMLP; A/B runs)
@@ -311,23 +343,20 @@ class EdgeConv(nn.Module):
             x = self.conv2(x)
             return x.max(dim=-1, keepdim=False)[0]
         nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K)
-        wa, wb = _edge_weights(self.conv1[0].weight, self.group_type)
-        wab = torch.cat((wa, wb), dim=0)                              # (128, C): both per-point projections at once
+        wab = _EdgeWeights.apply(self.conv1[0].weight, self.group_type)   # (128, C): both per-point projections at once
         if FUSED_PROJECTIONS and linear.linear_supported(x, wab):
             ab = linear.linear_rows(x, wab)                           # HIP 1x1 convolution (csrc/linear.hip): (B,N,128)
-            a, b = ab[..., :64], ab[..., 64:]
         else:
-            xt = x.permute(0, 2, 1)
-            a = torch.matmul(xt, wa.t())
-            b = torch.matmul(xt, wb.t())
+            ab = torch.matmul(x.permute(0, 2, 1), wab.t())
         bn1, bn2 = self.conv1[1], self.conv2[1]
         use_batch_stats = self.training or not bn1.track_running_stats
         if (FUSED_GLUE and use_batch_stats and _sync_group(bn1) is None and _sync_group(bn2) is None
                 and bn1.momentum is not None and bn2.momentum is not None):
-            return _EdgeMLPFused.apply(a, b, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias,
+            return _EdgeMLPFused.apply(ab, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias,
                                        bn1, bn2)
-        return _EdgeMLP.apply(a, b, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias, bn1, bn2,
-                              use_batch_stats)
+        half = ab.shape[-1] // 2
+        return _EdgeMLP.apply(ab[..., :half], ab[..., half:], nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight,
+                              bn2.bias, bn1, bn2, use_batch_stats)
 
 
 def embedding_config(preset: str = "cls"):

@@ -18,19 +18,25 @@ from .ops import _f32c, _need_gpu, _p, _stream
 LIN_PLAIN, LIN_LEAKY, LIN_LEAKY_MASK = 0, 1, 2   # include/samble.h SAMBLE_LIN_*
 
 
-def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True):
+def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True, transposed: bool = False):
     """W (O, C <= 128) -> (row image | None, transposed image | None) as uint8 tensors (include/samble.h: operand images;
-    a narrower W is padded with zero columns)."""
+    a narrower W is padded with zero columns).  transposed: W is given as (128, O) and the images are those of W^T (O, 128)
+    -- no transposing copy in front of the launch."""
     _need_gpu(W)
     W = _f32c(W)
-    if W.shape[1] < 128:
-        W = torch.nn.functional.pad(W, (0, 128 - W.shape[1]))
-    O, C = W.shape
+    if transposed:
+        C, O = W.shape
+        assert C == 128
+    else:
+        if W.shape[1] < 128:
+            W = torch.nn.functional.pad(W, (0, 128 - W.shape[1]))
+        O, C = W.shape
     with torch.cuda.device(W.device):
         nbytes = _lib.query("samble_linear_image_bytes", O)
         rm = torch.empty(nbytes, dtype=torch.uint8, device=W.device) if want_rm else None
         tr = torch.empty(nbytes, dtype=torch.uint8, device=W.device) if want_tr else None
-        _lib.call("samble_linear_weight_images_f32", W.data_ptr(), O, C, _p(rm), _p(tr), _stream())
+        _lib.call("samble_linear_weight_images_t_f32" if transposed else "samble_linear_weight_images_f32", W.data_ptr(), O,
+                  C, _p(rm), _p(tr), _stream())
     return rm, tr
 
 
@@ -76,20 +82,21 @@ def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int, C: int = 128) -
     return dx
 
 
-def stage_linear_dw(g: torch.Tensor, x: torch.Tensor, O: int) -> torch.Tensor:
-    """g (B,N,O), x (B,C,N) -> dW (O,C) = sum over clouds and points of g^T x^T (deterministic)."""
+def stage_linear_dw(g: torch.Tensor, x: torch.Tensor, O: int, transposed: bool = False) -> torch.Tensor:
+    """g (B,N,O), x (B,C,N) -> dW (O,C) = sum over clouds and points of g^T x^T (deterministic); transposed (C = 128):
+    the same sum as (128, O)."""
     _need_gpu(g, x)
     g, x = _f32c(g), _f32c(x)
     B, N, Og = g.shape
     C = x.shape[1]
-    assert Og == O and x.shape == (B, C, N)
+    assert Og == O and x.shape == (B, C, N) and (C == 128 or not transposed)
     with torch.cuda.device(g.device):
-        dW = torch.empty((O, 128), dtype=torch.float32, device=g.device)
+        dW = torch.empty((128, O) if transposed else (O, 128), dtype=torch.float32, device=g.device)
         nbytes = _lib.query("samble_linear_dw_workspace_bytes", B, N, O)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
-        _lib.call("samble_linear_dw_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), x.data_ptr(), C * N, B, C, N, O,
-                  dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
-    return dW if C == 128 else dW[:, :C]
+        _lib.call("samble_linear_dw_t_tri_f32" if transposed else "samble_linear_dw_tri_f32", g.data_ptr(), g.stride(0),
+                  g.stride(1), x.data_ptr(), C * N, B, C, N, O, dW.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return dW if (C == 128 or transposed) else dW[:, :C]
 
 
 def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor):
@@ -117,9 +124,8 @@ class _FFN(torch.autograd.Function):
     def forward(ctx, x, w1, w2):
         H = w1.shape[0]
         W1 = w1.reshape(H, 128)
-        W2t = w2.reshape(128, H).t().contiguous()                     # (H, 128): row j = column j of W2
         w1_rm, w1_tr = weight_images(W1)
-        w2t_rm, w2t_tr = weight_images(W2t)
+        w2t_rm, w2t_tr = weight_images(w2.reshape(128, H), transposed=True)   # images of W2^T (H, 128), read from W2 as it is
         hr = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY)                 # leaky(W1 x), (B,N,H)
         y = stage_linear_dx(hr, w2t_tr, H)                            # y[c][n] = sum_j W2[c][j] hr[n][j]
         ctx.save_for_backward(x, hr, w1_tr, w2t_rm)
@@ -135,7 +141,7 @@ class _FFN(torch.autograd.Function):
         dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK, ref=hr)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
         dx = stage_linear_dx(dh, w1_tr, H) if ctx.needs_input_grad[0] else None
         dw1 = stage_linear_dw(dh, x, H).reshape(H, 128, 1) if ctx.needs_input_grad[1] else None
-        dw2 = stage_linear_dw(hr, dy, H).t().reshape(128, H, 1) if ctx.needs_input_grad[2] else None
+        dw2 = stage_linear_dw(hr, dy, H, transposed=True).reshape(128, H, 1) if ctx.needs_input_grad[2] else None
         return dx, dw1, dw2
 
 

@@ -199,11 +199,14 @@ def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torc
     """out[t] = sum over the incoming edges e of target t of src[e] (per_edge) or src[e // K]; src (*, 64),
     list order: deterministic replacement of index_add_."""
     _need_gpu(src, order, offsets)
-    src = _f32c(src)
+    # (rows may be a column block of a wider matrix -- the a half of EdgeConv's [a | b] projection: read where they are)
+    if not (src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1 and src.stride(0) % 2 == 0
+            and src.data_ptr() % 8 == 0):
+        src = _f32c(src)
     T = offsets.numel() - 1
     with torch.cuda.device(src.device):
         out = torch.empty((T, 64), dtype=torch.float32, device=src.device)
-        _lib.call("samble_segment_sum_rows_f32", src.data_ptr(), order.data_ptr(), offsets.data_ptr(), K, 64,
+        _lib.call("samble_segment_sum_rows_f32", src.data_ptr(), src.stride(0), order.data_ptr(), offsets.data_ptr(), K, 64,
                   int(bool(per_edge)), T, out.data_ptr(), _stream())
     return out
 

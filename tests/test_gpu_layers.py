@@ -762,3 +762,21 @@ def test_interpolation_blend_kernels_equal_the_torch_expression():
     out2 = _InterpBlend.apply(feat2, idx, dist)
     out2.backward(g)
     assert torch.equal(out2, out) and torch.equal(feat2.grad, feat.grad)
+
+
+@pytest.mark.gpu
+def test_segment_sums_read_rows_where_they_are():
+    """samble_segment_sum_rows_f32 with a row stride (round 5): the 64-channel half of a (rows, 128) matrix gives the sums of
+    its contiguous copy, bit for bit (EdgeConv's [a | b] projection output is no longer sliced into copies)."""
+    from samble_amd import ops
+    B, N, K = 2, 300, 32
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 64, N, generator=gen).to("cuda:0")
+    nn_idx = ops.stage_knn(x, x, K)
+    order, offsets, counts = ops.inverse_neighbors(nn_idx)
+    wide = torch.randn(B * N, 128, generator=gen).to("cuda:0")
+    for half in (wide[:, :64], wide[:, 64:]):
+        assert not half.is_contiguous()
+        got = ops.stage_segment_sum_rows(half, order, offsets, K, per_edge=False)
+        want = ops.stage_segment_sum_rows(half.contiguous(), order, offsets, K, per_edge=False)
+        assert torch.equal(got, want)

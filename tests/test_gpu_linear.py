@@ -129,6 +129,21 @@ def test_linear_max_against_conv_max(B, N, O):
     assert torch.equal(y2, y) and torch.equal(arg2, arg) and torch.equal(xg2.grad, xg.grad) and torch.equal(wb.grad, w.grad)
 
 
+def test_transposed_weight_entries_equal_the_transposing_copies():
+    """samble_linear_weight_images_t_f32 / samble_linear_dw_t_tri_f32 (round 5): the second FFN convolution's weight is
+    (128, H); its W^T images and its gradient in (128, H) layout come straight from / go straight to that layout -- bit
+    for bit what the copies `.t().contiguous()` around the plain entries produced."""
+    from samble_amd import linear as L
+    H, B, N = 512, 3, 700
+    W2 = _w((128, H), 91, 0.045).to(DEV)
+    rm_t, tr_t = L.weight_images(W2, transposed=True)
+    rm, tr = L.weight_images(W2.t().contiguous())
+    assert torch.equal(rm_t, rm) and torch.equal(tr_t, tr)
+    g = torch.from_numpy(synth.normal((B, N, H), 92)).to(DEV)
+    x = torch.from_numpy(synth.features(B, 128, N, 93)).to(DEV)
+    assert torch.equal(L.stage_linear_dw(g, x, H, transposed=True), L.stage_linear_dw(g, x, H).t().contiguous())
+
+
 def test_linear_max_propagates_nan_like_torch():
     """A NaN activation must not be masked by the pooled head: conv(x).max(dim=-1) (models/cls_model.py:113) returns NaN
     for every output of a cloud that has a NaN point, with the FIRST NaN point as the argument -- the fused pass does
