@@ -103,7 +103,11 @@ size_t samble_proj_bwd_tri_workspace_bytes(int B, int N);
 int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C,
                             int N, const float* tokens, int nt, const float* W, const float* Wk /* or NULL */,
                             const float* Wv /* or NULL */, const void* w_tr_image /* or NULL */, float* dx, int64_t dx_bs,
-                            float* dW, float* dtokens, void* ws, size_t ws_bytes, void* stream);
+                            float* dW, float* dtokens, const float* dx_residual, void* ws, size_t ws_bytes, void* stream);
+/* residual (samble_n2p_attn_fwd_f32, samble_linear_dx_tri_f32) / dx_residual (samble_proj_bwd_tri_f32): optional tensor of
+ * the OUTPUT's layout that the kernel adds on its way out -- the `x + f(x)` of the layers around the sampler
+ * (models/attention.py:187-192) and, backward, the gradient that reaches the same tensor along the residual branch --
+ * instead of an elementwise pass of its own.  May alias the output (in-place accumulation); NULL: plain result. */
 
 /* ---- models/downsample.py:139-153 + 242-252  energy / softmax / (all rows of) A @ V^T --------
  * Q (B,N,D), K and V (B,N+nt,D) point-major with explicit strides (the nt bin-token rows follow
@@ -229,7 +233,7 @@ int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npo
  * attention of DownSampleLocal, models/downsample.py:885-963).  att: optional (B,N,KN) softmax
  * probabilities of the single head (the reference's attention_map), heads == 1 and KN <= 64 only. */
 int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN, int C,
-                            int heads, int diff, float* out, float* att, void* stream);
+                            int heads, int diff, float* out, float* att, const float* residual, void* stream);
 
 /* Backward of samble_n2p_attn_fwd_f32: g (B,C,N) = gradient of its output -> dqkv (B,N,3C) point-major
  * rows [dQ|dK|dV] (feed it to samble_proj_bwd_f32).  Deterministic (no atomics).  K <= 32. */
@@ -544,12 +548,15 @@ size_t samble_edge_glue_statistics_bytes(void);
  * (B, N, 2 C) projection output: the layer's two per-point projections come from ONE 1x1 convolution and are read where they
  * are).  da, db of samble_edge_bwd_post_f32 likewise at dab_row_stride: written as the halves of one (B, N, 2 C) gradient. */
 int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_row_stride, const int32_t* nn, int B, int N, int K, int C, const float* gamma1,
-                        const float* beta1, float eps, float* running_mean, float* running_var, float momentum, float* S,
-                        float* Q, float* ap, float* bp, float* constants, double* statistics, double* partials, void* stream);
+                        const float* beta1, float eps, float* running_mean, float* running_var, float momentum,
+                        int64_t* num_batches_tracked, float* S, float* Q, float* ap, float* bp, float* constants,
+                        double* statistics, double* partials, void* stream);
 int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
                             const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
                             const float* beta2, float eps, float* running_mean, float* running_var, float momentum,
-                            float* constants, double* statistics, float* ext, uint8_t* kext, float* out, void* stream);
+                            int64_t* num_batches_tracked, float* constants, double* statistics, float* ext, uint8_t* kext,
+                            float* out, void* stream);
+/* (num_batches_tracked, both entries: nn.BatchNorm2d's int64 counter on the device, incremented by the kernel; may be NULL) */
 int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2, float* constants,
                             const double* statistics, float* sdv, float* dgamma2, float* dbeta2, double* partials,
                             void* stream);
@@ -602,7 +609,7 @@ size_t samble_linear_amax_workspace_bytes(int B, int N, int O);
 int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, float* y,
                                    int32_t* arg, void* ws, size_t ws_bytes, void* stream);
 int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const void* w_tr_image, int O, int B, int C, int N,
-                             float* dx, int64_t dx_bs, void* stream);
+                             float* dx, int64_t dx_bs, const float* residual, void* stream);
 size_t samble_linear_dw_workspace_bytes(int B, int N, int O);
 int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
                              int O, float* dW, void* ws, size_t ws_bytes, void* stream);

@@ -34,7 +34,7 @@ _SIGNATURES = {
                                     c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "samble_proj_bwd_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_void_p,
                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                    c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_proj_fwd_tri_workspace_bytes": (c_size_t, []),
     "samble_proj_w_image_bytes": (c_size_t, []),
     "samble_inverse_neighbors_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -68,10 +68,10 @@ _SIGNATURES = {
     "samble_edge_glue_statistics_bytes": (c_size_t, []),
     "samble_edge_bn1_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p]),
     "samble_edge_bn2_out_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p]),
     "samble_edge_bwd_pre_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -91,7 +91,7 @@ _SIGNATURES = {
     "samble_linear_amax_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),
     "samble_linear_dx_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64,
-                                         c_void_p]),
+                                         c_void_p, c_void_p]),
     "samble_linear_dw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_dw_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
@@ -124,7 +124,7 @@ _SIGNATURES = {
     "samble_gather_rows_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "samble_gather_points_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_n2p_attn_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                        c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "samble_n2p_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_n2p_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -13,6 +13,7 @@ Backward of the attention part is two HIP kernels (per-point pass, then an order
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -92,6 +93,86 @@ class _N2PCore(torch.autograd.Function):
                 None, None, None)
 
 
+# False: the layer as separate autograd nodes (attention core, adds, BatchNorm1d, FFN): the A/B reference
+FUSED_LAYER = os.environ.get("SAMBLE_FUSED_LAYER", "1") != "0"
+
+
+class _N2PLayer(torch.autograd.Function):
+    """The whole Neighbor2PointAttention layer (reference models/attention.py:165-192) as ONE autograd node, training mode:
+        s1 = x + attention(x);  y1 = bn1(s1);  s2 = y1 + ff(y1);  y2 = bn2(s2)
+    The four elementwise passes of that expression and of its gradient (two residual adds forward, two gradient
+    accumulations backward: 4 x 33 MB in and out at N = 2048, a launch each) ride on the epilogues of the kernels that
+    produce the other summand -- the gather attention, the FFN's second product, the FFN's input gradient, the
+    projection's input gradient (`residual` of include/samble.h) -- and the weights' `cat`, the autograd bookkeeping
+    between eight nodes and their saved intermediates go with them.  Same kernels, same BatchNorm (MIOpen through the
+    aten entries nn.BatchNorm1d itself dispatches to), same sums in the same order: outputs, all gradients and the running
+    statistics are bit-identical to the node-by-node composition (tests/test_gpu_layers.py)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, wq, wk, wv, w1, w2, g1, b1, g2, b2, bn1, bn2, K, heads, diff):
+        B, C, N = x.shape
+        x = x.contiguous()
+        H = w1.shape[0]
+        w = torch.cat((wq, wk, wv), dim=0).reshape(3 * C, C)
+        qkv = ops.stage_proj_fwd(x, x.new_zeros((C, 0)), w)
+        nn_idx = ops.stage_knn(x, x, K)
+        s1 = ops.stage_n2p_attn_fwd(qkv, nn_idx, heads, diff, residual=x)                 # x + attention(x)
+        y1, m1, v1 = _bn_train(bn1, s1, g1, b1)
+        w1_rm, w1_tr = linear.weight_images(w1.reshape(H, C))
+        w2t_rm, w2t_tr = linear.weight_images(w2.reshape(C, H), transposed=True)
+        hr = linear.stage_linear_fwd(y1, w1_rm, H, linear.LIN_LEAKY)                      # leaky(W1 y1), (B,N,H)
+        s2 = linear.stage_linear_dx(hr, w2t_tr, H, residual=y1)                           # y1 + W2 h
+        y2, m2, v2 = _bn_train(bn2, s2, g2, b2)
+        ctx.save_for_backward(x, w, qkv, nn_idx, s1, m1, v1, y1, hr, s2, m2, v2, g1, g2, w1_tr, w2t_rm)
+        ctx.cfg = (heads, diff, wq.shape[0], wk.shape[0], H, float(bn1.eps), float(bn2.eps))
+        ctx.bns = (bn1, bn2)
+        return y2
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy2):
+        x, w, qkv, nn_idx, s1, m1, v1, y1, hr, s2, m2, v2, g1, g2, w1_tr, w2t_rm = ctx.saved_tensors
+        heads, diff, a, b, H, eps1, eps2 = ctx.cfg
+        bn1, bn2 = ctx.bns
+        C = x.shape[1]
+        dy2 = dy2.float().contiguous()
+        ds2, dg2, db2 = torch.ops.aten.miopen_batch_norm_backward(s2, dy2, g2, bn2.running_mean, bn2.running_var, m2, v2, eps2)
+        ds2 = ds2.contiguous()
+        dh = linear.stage_linear_fwd(ds2, w2t_rm, H, linear.LIN_LEAKY_MASK, ref=hr)        # (W2^T ds2) * leaky'(h)
+        dw2 = linear.stage_linear_dw(hr, ds2, H, transposed=True).reshape(C, H, 1)
+        dw1 = linear.stage_linear_dw(dh, y1, H).reshape(H, C, 1)
+        dy1 = linear.stage_linear_dx(dh, w1_tr, H, residual=ds2, out=ds2)                  # ds2 + W1^T dh, in place
+        ds1, dg1, db1 = torch.ops.aten.miopen_batch_norm_backward(s1, dy1, g1, bn1.running_mean, bn1.running_var, m1, v1, eps1)
+        ds1 = ds1.contiguous()
+        dqkv = ops.stage_n2p_attn_bwd(qkv, nn_idx, ds1, heads, diff)
+        dx, dw, _ = ops.stage_proj_bwd(dqkv, x, x.new_zeros((C, 0)), w, True, True, dx_residual=ds1)   # ds1 + W^T dqkv
+        return (dx, dw[:a].reshape(a, C, 1, 1), dw[a:a + b].reshape(b, C, 1, 1), dw[a + b:].reshape(-1, C, 1, 1), dw1, dw2,
+                dg1, db1, dg2, db2, None, None, None, None, None)
+
+
+def _bn_train(bn: nn.BatchNorm1d, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """nn.BatchNorm1d.forward in training mode on (B,C,N): the aten entry the module dispatches to on this build (MIOpen),
+    with the module's own bookkeeping (momentum, running statistics, num_batches_tracked)."""
+    factor = 0.0
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        factor = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+    elif bn.momentum is not None:
+        factor = bn.momentum
+    return torch.miopen_batch_norm(s, gamma, beta, bn.running_mean, bn.running_var, True, factor, bn.eps)
+
+
+def _layer_fusable(mod, x) -> bool:
+    bn1, bn2 = mod.bn1, mod.bn2
+    plain = lambda bn: type(bn) is nn.BatchNorm1d and bn.affine and (bn.momentum is not None or not bn.track_running_stats)
+    return (FUSED_LAYER and FUSED_FFN and mod.training and x.is_cuda and x.dtype == torch.float32 and ops.MATRIX_MODE == "tri"
+            and mod.hip_attention and mod.attention_mode == "scalar_dot" and not mod.group_type.startswith("center_")
+            and plain(bn1) and plain(bn2) and mod.ff[0].bias is None and mod.ff[2].bias is None
+            and abs(mod.ff[1].negative_slope - 0.2) < 1e-12 and linear.ffn_supported(x, mod.ff[0].weight, mod.ff[2].weight)
+            and torch.backends.cudnn.enabled)
+
+
 class Neighbor2PointAttention(nn.Module):
     def __init__(self, config_attention, layer):
         super().__init__()
@@ -139,6 +220,11 @@ class Neighbor2PointAttention(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.Neighbor2PointAttention runs on the GPU only (no CPU fallback)")
+        if _layer_fusable(self, x):
+            wk = -self.k_conv.weight if self.asm == "dot-sub" else self.k_conv.weight      # (see below)
+            return _N2PLayer.apply(x, self.q_conv.weight, wk, self.v_conv.weight, self.ff[0].weight, self.ff[2].weight,
+                                   self.bn1.weight, self.bn1.bias, self.bn2.weight, self.bn2.bias, self.bn1, self.bn2,
+                                   self.K, self.num_heads, self.group_type == "diff")
         if self.attention_mode == "vector_sub":
             x_tmp = self._vector_sub(x)
         else:

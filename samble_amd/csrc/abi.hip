@@ -50,7 +50,8 @@ int samble_launch_proj_fwd(const float*, long, int, int, const float*, int, cons
                            long, long, float*, void*, void* const*, int, void*, hipStream_t);
 size_t samble_proj_bwd_ws_floats(int B, int N);
 int samble_launch_proj_bwd(const float*, long, long, const float*, long, int, int, const float*, int, const float*,
-                           const float*, const float*, float*, long, float*, float*, float*, void*, const void*, hipStream_t);
+                           const float*, const float*, float*, long, float*, float*, float*, void*, const void*, const float*,
+                           hipStream_t);
 size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
@@ -58,7 +59,7 @@ int samble_launch_seg_sum_rows64(const float*, long, const int*, const int*, int
 size_t samble_inverse_neighbors_ws_bytes(int B, int N);
 int samble_launch_inverse_neighbors(const int*, int, int, int, int*, int*, int*, void*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
-                          hipStream_t);
+                          const float*, hipStream_t);
 int samble_launch_attn_bwd(const float*, long, long, const float*, long, long, const float*, long, long, const float*,
                            const float*, const float*, int, const float*, const long long*, const float*, int, int, int,
                            int, float, float*, float*, float*, float*, float*, float*, float*, long, long, float*, long,
@@ -102,9 +103,9 @@ size_t samble_edge_glue_part_bytes(void);
 size_t samble_edge_glue_cst_bytes(void);
 size_t samble_edge_glue_st_bytes(void);
 int samble_launch_edge_pre(const float*, const float*, long, const int*, int, int, const float*, const float*, float, float*, float*,
-                           float, float*, float*, float*, float*, float*, double*, double*, hipStream_t);
+                           float, long long*, float*, float*, float*, float*, float*, double*, double*, hipStream_t);
 int samble_launch_edge_post(const float*, const float*, const unsigned char*, const unsigned char*, const double*, int, int, int,
-                            const float*, const float*, float, float*, float*, float, float*, double*, float*, unsigned char*,
+                            const float*, const float*, float, float*, float*, float, long long*, float*, double*, float*, unsigned char*,
                             float*, hipStream_t);
 int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float*, float*, const double*, float*, float*, float*,
                                double*, hipStream_t);
@@ -120,7 +121,7 @@ int samble_linear_is_duo(void);
 int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
 size_t samble_linear_amax_ws_bytes(int, int, int);
 int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
-int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, int, float*, long, hipStream_t);
+int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, int, float*, long, const float*, hipStream_t);
 size_t samble_linear_dw_ws_bytes(int, int, int);
 int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, int, void*, hipStream_t);
 size_t samble_amax_bwd_ws_bytes(int, int, int);
@@ -878,7 +879,8 @@ static int edge_shape_ok(int B, int N, int K, int C) { return B > 0 && N > 0 && 
 
 SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_row_stride, const int32_t* nn, int B, int N, int K, int C,
                                    const float* gamma1, const float* beta1, float eps, float* running_mean,
-                                   float* running_var, float momentum, float* S, float* Q, float* ap, float* bp,
+                                   float* running_var, float momentum, int64_t* num_batches_tracked, float* S, float* Q,
+                                   float* ap, float* bp,
                                    float* constants, double* statistics, double* partials, void* stream) {
   if (!a || !b || !nn || !gamma1 || !beta1 || !S || !Q || !ap || !bp || !constants || !statistics || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: null pointer");
@@ -886,7 +888,8 @@ SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_ro
   if (ab_row_stride < C || (ab_row_stride & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
     return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: a / b rows must be 16-byte aligned, row stride >= C");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: running statistics come as a pair");
-  return done(samble_launch_edge_pre(a, b, (long)ab_row_stride, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum, S, Q, ap, bp,
+  return done(samble_launch_edge_pre(a, b, (long)ab_row_stride, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum,
+                                     (long long*)num_batches_tracked, S, Q, ap, bp,
                                      constants, statistics, partials, (hipStream_t)stream),
               "samble_edge_bn1_f32");
 }
@@ -894,14 +897,15 @@ SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_ro
 SAMBLE_API int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
                                        const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
                                        const float* beta2, float eps, float* running_mean, float* running_var,
-                                       float momentum, float* constants, double* statistics, float* ext, uint8_t* kext,
-                                       float* out, void* stream) {
+                                       float momentum, int64_t* num_batches_tracked, float* constants, double* statistics,
+                                       float* ext, uint8_t* kext, float* out, void* stream) {
   if (!ymax || !ymin || !kmax || !kmin || !mlp_partials || !gamma2 || !beta2 || !constants || !statistics || !ext || !kext || !out)
     return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: null pointer");
   if (!edge_shape_ok(B, N, 32, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: built for 64 channels");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: running statistics come as a pair");
   return done(samble_launch_edge_post(ymax, ymin, kmax, kmin, mlp_partials, n_partials, B, N, gamma2, beta2, eps, running_mean,
-                                      running_var, momentum, constants, statistics, ext, kext, out, (hipStream_t)stream),
+                                      running_var, momentum, (long long*)num_batches_tracked, constants, statistics, ext, kext,
+                                      out, (hipStream_t)stream),
               "samble_edge_bn2_out_f32");
 }
 
@@ -1001,11 +1005,11 @@ SAMBLE_API int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int 
 }
 
 SAMBLE_API int samble_linear_dx_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const void* w_tr_image, int O, int B, int C,
-                                        int N, float* dx, int64_t dx_bs, void* stream) {
+                                        int N, float* dx, int64_t dx_bs, const float* residual, void* stream) {
   if (!g || !w_tr_image || !dx) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: null pointer");
   if (C < 1 || C > 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: 1 <= C <= 128, O a multiple of 32");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dx_tri_f32: g rows must be 16-byte aligned");
-  return done(samble_launch_linear_dx(g, g_bs, g_rs, w_tr_image, O, B, C, N, dx, dx_bs, (hipStream_t)stream), "samble_linear_dx_tri_f32");
+  return done(samble_launch_linear_dx(g, g_bs, g_rs, w_tr_image, O, B, C, N, dx, dx_bs, residual, (hipStream_t)stream), "samble_linear_dx_tri_f32");
 }
 
 SAMBLE_API size_t samble_linear_dw_workspace_bytes(int B, int N, int O) {
@@ -1123,7 +1127,7 @@ SAMBLE_API int samble_proj_bwd_f32(const float* dqkv, int64_t g_bs, int64_t g_rs
   if (ws_bytes < samble_proj_bwd_ws_floats(B, N) * sizeof(float))
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_f32: workspace too small");
   return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, nullptr, nullptr, dx, dx_bs, dW, dtokens, (float*)ws, nullptr,
-                                     nullptr, (hipStream_t)stream),
+                                     nullptr, nullptr, (hipStream_t)stream),
               "samble_proj_bwd_f32");
 }
 
@@ -1136,7 +1140,7 @@ SAMBLE_API size_t samble_proj_bwd_tri_workspace_bytes(int B, int N) {
 SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B,
                                        int C, int N, const float* tokens, int nt, const float* W, const float* Wk,
                                        const float* Wv, const void* w_tr_image, float* dx, int64_t dx_bs, float* dW,
-                                       float* dtokens, void* ws, size_t ws_bytes, void* stream) {
+                                       float* dtokens, const float* dx_residual, void* ws, size_t ws_bytes, void* stream) {
   if (!dqkv || !x || !W || !ws) return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: null pointer");
   if (!Wk != !Wv || (Wk && !w_tr_image))
     return fail(SAMBLE_E_INVALID, "samble_proj_bwd_tri_f32: Wk and Wv come as a pair, and only together with w_tr_image");
@@ -1148,12 +1152,13 @@ SAMBLE_API int samble_proj_bwd_tri_f32(const float* dqkv, int64_t g_bs, int64_t 
     return fail(SAMBLE_E_WORKSPACE, "samble_proj_bwd_tri_f32: workspace too small");
   char* wtr = (char*)ws + ((samble_proj_bwd_ws_floats(B, N) * sizeof(float) + 255) & ~(size_t)255);
   return done(samble_launch_proj_bwd(dqkv, g_bs, g_rs, x, x_bs, B, N, tokens, nt, W, Wk, Wv, dx, dx_bs, dW, dtokens, (float*)ws, wtr,
-                                     w_tr_image, (hipStream_t)stream),
+                                     w_tr_image, dx ? dx_residual : nullptr, (hipStream_t)stream),
               "samble_proj_bwd_tri_f32");
 }
 
 SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs, const int32_t* nn, int B, int N, int KN,
-                                       int C, int heads, int diff, float* out, float* att, void* stream) {
+                                       int C, int heads, int diff, float* out, float* att, const float* residual,
+                                       void* stream) {
   if (!qkv || !nn || !out) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: null pointer");
   if (C != 128 || (heads != 4 && heads != 2 && heads != 1))
     return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: built for C = 128 with 4, 2 or 1 head(s)");
@@ -1162,7 +1167,7 @@ SAMBLE_API int samble_n2p_attn_fwd_f32(const float* qkv, int64_t bs, int64_t rs,
   if ((rs & 3) || (bs & 3) || rs < 3 * C) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad strides");
   if (B <= 0 || N <= 0 || KN <= 0) return fail(SAMBLE_E_INVALID, "samble_n2p_attn_fwd_f32: bad sizes");
   return done(samble_launch_n2p_fwd(qkv, bs, rs, nn, B, N, KN, diff, (float)(1.0 / sqrt((double)(C / heads))), out,
-                                    heads, att, (hipStream_t)stream),
+                                    heads, att, residual, (hipStream_t)stream),
               "samble_n2p_attn_fwd_f32");
 }
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int
 __global__ __launch_bounds__(1024) void edge_bn1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
-                                                               float* rmean, float* rvar, float momentum) {
+                                                               float* rmean, float* rvar, float momentum, long long* nbt) {
   const int c = threadIdx.x;
   double t0, t1;
   chan_totals2(part, nparts, t0, t1);
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(1024) void edge_bn1_finalize_kernel(const double* _
   cst[kCstSc1 + c] = (float)sc;
   cst[kCstSh1 + c] = (float)((double)beta[c] - mu * sc);
   bn_running_update(rmean, rvar, c, mu, var, E, momentum);
+  if (c == 0 && nbt) *nbt += 1;   // nn.BatchNorm2d.num_batches_tracked (int64), without a launch of its own
 }
 
 // ---- forward 2b: the BN1-folded projections the MLP sweeps read: a' = a sc1 + sh1, b' = b sc1 (two roundings each,
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void edge_bn2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
-                                                               float* rmean, float* rvar, float momentum) {
+                                                               float* rmean, float* rvar, float momentum, long long* nbt) {
   const int c = threadIdx.x;
   double t0, t1;
   chan_totals2(part, nparts, t0, t1);
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(1024) void edge_bn2_finalize_kernel(const double* _
   cst[kCstSc2 + c] = (float)sc;
   cst[kCstSh2 + c] = (float)((double)beta[c] - mu * sc);
   bn_running_update(rmean, rvar, c, mu, var, E, momentum);
+  if (c == 0 && nbt) *nbt += 1;   // nn.BatchNorm2d.num_batches_tracked (int64), without a launch of its own
 }
 
 // ---- forward 4: ext = the extremum the sign of gamma2 selects, its edge, out = LeakyReLU(sc2 ext + sh2) written
@@ -373,13 +375,13 @@ extern "C" size_t samble_edge_glue_st_bytes(void) { return (size_t)kStWords * si
 
 // forward, before the MLP sweep: S, Q, BN1 constants (cst: sc1, sh1; st: mu1, sig1), running statistics (optional)
 extern "C" int samble_launch_edge_pre(const float* a, const float* b, long rs, const int* nn, int B, int N, const float* gamma1,
-                                      const float* beta1, float eps, float* rmean, float* rvar, float momentum, float* S,
+                                      const float* beta1, float eps, float* rmean, float* rvar, float momentum, long long* nbt, float* S,
                                       float* Q, float* ap, float* bp, float* cst, double* st, double* part, hipStream_t s) {
   const long np = (long)B * N;
   Timed timed(kT_edge_sums, s);
   hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, nn, N, np, S, Q, part);
   hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
-                     cst, st, rmean, rvar, momentum);
+                     cst, st, rmean, rvar, momentum, nbt);
   hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, rs, cst, np * 16, ap, bp);
   return (int)hipGetLastError();
 }
@@ -389,11 +391,11 @@ extern "C" int samble_launch_edge_pre(const float* a, const float* b, long rs, c
 extern "C" int samble_launch_edge_post(const float* ymax, const float* ymin, const unsigned char* kmax,
                                        const unsigned char* kmin, const double* mlp_part, int nwaves, int B, int N,
                                        const float* gamma2, const float* beta2, float eps, float* rmean, float* rvar,
-                                       float momentum, float* cst, double* st, float* ext, unsigned char* kext, float* out,
-                                       hipStream_t s) {
+                                       float momentum, long long* nbt, float* cst, double* st, float* ext, unsigned char* kext,
+                                       float* out, hipStream_t s) {
   const long np = (long)B * N;
   hipLaunchKernelGGL(edge_bn2_finalize_kernel, dim3(1), dim3(1024), 0, s, mlp_part, nwaves, (double)np * kGK, gamma2, beta2,
-                     eps, cst, st, rmean, rvar, momentum);
+                     eps, cst, st, rmean, rvar, momentum, nbt);
   hipLaunchKernelGGL(edge_out_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, ymax, ymin, kmax, kmin, gamma2, cst, N, ext,
                      kext, out);
   return (int)hipGetLastError();

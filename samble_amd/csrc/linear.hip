@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void lin_amax_reduce_kernel(const float* __res
 // dx[c][n] = sum_o W[o][c] g[n][o] (proj_dx_tri_kernel with a run-time tile count)
 __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                             const char* __restrict__ Wtr, int otiles, int Cin, int N,
-                                                            float* __restrict__ dx, long dx_bs) {
+                                                            float* __restrict__ dx, long dx_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
   const int tid = threadIdx.x;
@@ -305,6 +305,9 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
   int chunk, b;
   xcd_assign(chunk, b);
   const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  // (lanes past N-1 repeat point N-1: harmless for a plain store of the same value, NOT for an in-place accumulation --
+  // with `res` only the point's own lane stores)
+  const bool own = chunk * 256 + wave * 32 + lo < N;
   const float* grow = g + (long)b * g_bs + (long)n * g_rs + 4 * h;
   auto stage = [&](int t) {
     const char* gt = Wtr + (long)min(t, otiles - 1) * kTriTile;
@@ -379,6 +382,27 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
     bg[1] = nb[1];
   }
   float* ob = dx + (long)b * dx_bs + n;  // rows past N-1 hold point N-1's column again: same values, same address
+  if (res) {
+    // every residual value first, then the stores: `res` may be `dx` itself, so the compiler must keep each load in front
+    // of the stores before it -- interleaved, that is 64 dependent round trips at the end of every wave
+    const float* rb = res + (long)b * dx_bs + n;
+    float rv[4][16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * ct + crow(r, h);
+        rv[ct][r] = c < Cin ? rb[(long)c * N] : 0.f;
+      }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * ct + crow(r, h);
+        if (c < Cin && own) ob[(long)c * N] = rv[ct][r] + acc[ct][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     if (32 * ct >= Cin) break;   // (uniform)
@@ -394,9 +418,11 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
 // power-of-two scale, the W^T tile under the image tile's; the tile's product (two k-steps) starts from a ZERO accumulator
 // per channel tile and is added to the fp32 totals x 2^-(e_w + e_g) by the vector ALU one step later, beside the next
 // channel tile's MFMAs.  Channel tile outer, k-step inner, so that only two temporaries are alive at a time.
+// res (may be null, may be dx itself): a tensor of dx's layout added on the way out -- the residual of the layer this
+// product closes (forward: y + W2 h), or the gradient that arrives beside it (backward: in place)
 __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                             const char* __restrict__ Wtr, int otiles, int Cin, int N,
-                                                            float* __restrict__ dx, long dx_bs) {
+                                                            float* __restrict__ dx, long dx_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
   const int tid = threadIdx.x;
@@ -404,6 +430,9 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
   int chunk, b;
   xcd_assign(chunk, b);
   const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  // (lanes past N-1 repeat point N-1: harmless for a plain store of the same value, NOT for an in-place accumulation --
+  // with `res` only the point's own lane stores)
+  const bool own = chunk * 256 + wave * 32 + lo < N;
   const float* grow = g + (long)b * g_bs + (long)n * g_rs + 4 * h;
   auto stage = [&](int t) {
     const char* gt = Wtr + (long)min(t, otiles - 1) * kTriTile;
@@ -503,6 +532,27 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
     g_inv = g_inv_next;
   }
   float* ob = dx + (long)b * dx_bs + n;  // rows past N-1 hold point N-1's column again: same values, same address
+  if (res) {
+    // every residual value first, then the stores: `res` may be `dx` itself, so the compiler must keep each load in front
+    // of the stores before it -- interleaved, that is 64 dependent round trips at the end of every wave
+    const float* rb = res + (long)b * dx_bs + n;
+    float rv[4][16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * ct + crow(r, h);
+        rv[ct][r] = c < Cin ? rb[(long)c * N] : 0.f;
+      }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = 32 * ct + crow(r, h);
+        if (c < Cin && own) ob[(long)c * N] = rv[ct][r] + tot[ct][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
     if (32 * ct >= Cin) break;   // (uniform)
@@ -984,17 +1034,17 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
 }
 
 extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
-                                       float* dx, long dx_bs, hipStream_t s) {
+                                       float* dx, long dx_bs, const float* residual, hipStream_t s) {
   const void* fn = kLinDuo ? reinterpret_cast<const void*>(lin_dx_duo_kernel) : reinterpret_cast<const void*>(lin_dx_tri_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_dx, s);
   if (kLinDuo)
     hipLaunchKernelGGL(lin_dx_duo_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                       O / 32, Cin, N, dx, dx_bs);
+                       O / 32, Cin, N, dx, dx_bs, residual);
   else
     hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                       O / 32, Cin, N, dx, dx_bs);
+                       O / 32, Cin, N, dx, dx_bs, residual);
   return (int)hipGetLastError();
 }
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restrict__ qkv, long bs, long rs,
                                                            const int* __restrict__ nn, int N, int KN, int diff,
                                                            float scale, float* __restrict__ out, int heads,
-                                                           float* __restrict__ att, int B) {
+                                                           float* __restrict__ att, int B, const float* __restrict__ res) {
   __shared__ float tile[128 * 33];
   __shared__ float lgs[8][64];  // att output: the logits of a half-wave's point (this lane's head), K <= 64
   const int hl = 32 / heads;
@@ -96,9 +96,13 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
   }
   __syncthreads();
   float* ob = out + (long)b * 128 * N;
+  const float* rb = res ? res + (long)b * 128 * N : nullptr;   // the layer's residual x + attention(x), added on the way out
   for (int e = tid; e < 128 * 32; e += 256) {
     const int d = e >> 5, p = e & 31;
-    if (chunk * 32 + p < N) ob[(long)d * N + chunk * 32 + p] = tile[d * 33 + p];
+    if (chunk * 32 + p < N) {
+      const long at = (long)d * N + chunk * 32 + p;
+      ob[at] = rb ? rb[at] + tile[d * 33 + p] : tile[d * 33 + p];
+    }
   }
   __syncthreads();  // the tile is rewritten by the next chunk
   }
@@ -116,11 +120,11 @@ using namespace samble;
 #endif
 
 extern "C" int samble_launch_n2p_fwd(const float* qkv, long bs, long rs, const int* nn, int B, int N, int KN, int diff,
-                                     float scale, float* out, int heads, float* att, hipStream_t s) {
+                                     float scale, float* out, int heads, float* att, const float* residual, hipStream_t s) {
   if ((heads != 1 && heads != 2 && heads != 4) || (att && (heads != 1 || KN > 64))) return -22;
   Timed timed(kT_n2p_fwd, s);
   hipLaunchKernelGGL(n2p_attn_fwd_kernel, dim3(SAMBLE_N2P_FWD_GRID), dim3(256), 0, s, qkv, bs, rs, nn, N, KN, diff, scale,
-                     out, heads, att, B);
+                     out, heads, att, B, residual);
   return (int)hipGetLastError();
 }
 

@@ -373,7 +373,7 @@ using namespace samble;
 extern "C" int samble_launch_proj_fwd_tri(const float*, long, int, int, const float*, float*, int, const float*, const float*,
                                           const float*, void*, void*,
                                           float*, long, long, void*, void*, void*, void*, void*, int, hipStream_t);
-extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, int, float*, long, hipStream_t);
+extern "C" int samble_launch_proj_dx_tri(const float*, long, long, const float*, void*, int, int, int, float*, long, const float*, hipStream_t);
 extern "C" int samble_launch_proj_dw_tri(const float*, long, long, const float*, long, int, int, float*, hipStream_t);
 
 // wimg != null: room for the row image of W -> the split-bf16 kernel (proj_tri.hip)
@@ -408,7 +408,8 @@ extern "C" size_t samble_proj_bwd_ws_floats(int B, int N) {
 extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, const float* x, long x_bs, int B, int N,
                                       const float* tokens, int nt, const float* W, const float* Wk, const float* Wv,
                                       float* dx, long dx_bs, float* dW, float* dtok, float* ws, void* wtr,
-                                      const void* wtr_ready, hipStream_t s) {
+                                      const void* wtr_ready, const float* dx_residual, hipStream_t s) {
+  if (dx_residual && !(dx && wtr)) return (int)hipErrorInvalidValue;  // (the split-bf16 kernel carries the epilogue)
   // Wk / Wv non-null: W = Wq, three tensors -- only with wtr_ready (nothing else reads W as one block then)
   if (Wk && !(wtr && wtr_ready)) return (int)hipErrorInvalidValue;
   // wtr_ready: the transposed image of W as the forward's prologue wrote it (then wtr is not used)
@@ -425,7 +426,7 @@ extern "C" int samble_launch_proj_bwd(const float* dqkv, long g_bs, long g_rs, c
   float* part = ws;
   if (dx && wtr) {  // room for the transposed image of W -> the split-bf16 kernel
     const int rc = samble_launch_proj_dx_tri(dqkv, g_bs, g_rs, W, wtr_ready ? const_cast<void*>(wtr_ready) : wtr,
-                                             wtr_ready != nullptr, B, N, dx, dx_bs, s);
+                                             wtr_ready != nullptr, B, N, dx, dx_bs, dx_residual, s);
     if (rc) return rc;
   } else if (dx) {
     Timed timed(kT_proj_dx, s);

@@ -334,13 +334,14 @@ __device__ unsigned long long g_proj_stamps[8 * 2 * 4];
 #endif
 __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __restrict__ dqkv, long g_bs, long g_rs,
                                                              const char* __restrict__ Wtr,  // transposed image of W
-                                                             int N, float* __restrict__ dx, long dx_bs) {
+                                                             int N, float* __restrict__ dx, long dx_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kPDepth;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   const int n = min(blockIdx.x * 256 + wave * 32 + lo, N - 1);
+  const bool own = blockIdx.x * 256 + wave * 32 + lo < N;   // (with `res`, which may alias dx: the clamped lanes do not store)
   const float* grow = dqkv + (long)b * g_bs + (long)n * g_rs + 4 * h;
   auto stage = [&](int t) {
     const char* gt = Wtr + (long)min(t, kPTiles - 1) * kTriTile;
@@ -432,6 +433,20 @@ __global__ __launch_bounds__(512, 2) void proj_dx_tri_kernel(const float* __rest
   }
   // rows past N-1 hold point N-1's column again: same values to the same address
   float* ob = dx + (long)b * dx_bs + n;
+  if (res) {  // (may be dx itself) the gradient that reaches x beside this product: all loads first, then the stores
+    const float* rb = res + (long)b * dx_bs + n;
+    float rv[4][16];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[ct][r] = rb[(long)(32 * ct + crow(r, h)) * N];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (own) ob[(long)(32 * ct + crow(r, h)) * N] = rv[ct][r] + acc[ct][r];
+    return;
+  }
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
@@ -606,7 +621,7 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
 }
 
 extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int have_wtr,
-                                         int B, int N, float* dx, long dx_bs, hipStream_t s) {
+                                         int B, int N, float* dx, long dx_bs, const float* residual, hipStream_t s) {
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
@@ -618,7 +633,7 @@ extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs
   }
   Timed timed(kT_proj_dx, s);
   hipLaunchKernelGGL(proj_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kProjTriLds, s, dqkv, g_bs, g_rs,
-                     (const char*)wtr, N, dx, dx_bs);
+                     (const char*)wtr, N, dx, dx_bs, residual);
   return (int)hipGetLastError();
 }
 

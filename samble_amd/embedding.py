@@ -241,6 +241,9 @@ class _EdgeMLPFused(torch.autograd.Function):
         w2m = w2.detach()[:, :, 0, 0].float().contiguous()
         run = lambda bn: (bn.running_mean, bn.running_var) if (bn.track_running_stats and bn.running_mean is not None) \
             else (None, None)
+        # nn.BatchNorm2d.num_batches_tracked (int64 on the device): the statistics kernels count the batch themselves
+        count = lambda bn: bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None
+                                                       and bn.num_batches_tracked.is_cuda) else None
         with torch.cuda.device(dev):
             f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             S, Q, ap, bp = f32(B, N, C), f32(B, N, C), f32(B, N, C), f32(B, N, C)
@@ -249,7 +252,7 @@ class _EdgeMLPFused(torch.autograd.Function):
             part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
             rm1, rv1 = run(bn1)
             _lib.call("samble_edge_bn1_f32", a.data_ptr(), b.data_ptr(), C2, nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
-                      b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), S.data_ptr(),
+                      b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), ops._p(count(bn1)), S.data_ptr(),
                       Q.data_ptr(), ap.data_ptr(), bp.data_ptr(), cst.data_ptr(), st.data_ptr(), part.data_ptr(),
                       ops._stream())
             nparts = _lib.query("samble_edge_partial_count")
@@ -266,11 +269,11 @@ class _EdgeMLPFused(torch.autograd.Function):
             rm2, rv2 = run(bn2)
             _lib.call("samble_edge_bn2_out_f32", ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(),
                       mpart.data_ptr(), nparts, B, N, C, g2.data_ptr(), b2.data_ptr(), float(bn2.eps), ops._p(rm2),
-                      ops._p(rv2), float(bn2.momentum), cst.data_ptr(), st.data_ptr(), ext.data_ptr(), kext.data_ptr(),
-                      out.data_ptr(), ops._stream())
+                      ops._p(rv2), float(bn2.momentum), ops._p(count(bn2)), cst.data_ptr(), st.data_ptr(), ext.data_ptr(),
+                      kext.data_ptr(), out.data_ptr(), ops._stream())
             with torch.no_grad():
-                for bn in (bn1, bn2):
-                    if bn.track_running_stats and bn.num_batches_tracked is not None:
+                for bn in (bn1, bn2):   # (a counter that does not live on this device: the launch the kernels save otherwise)
+                    if bn.track_running_stats and bn.num_batches_tracked is not None and count(bn) is None:
                         bn.num_batches_tracked += 1
         ctx.save_for_backward(ab, nn_idx, S, ap, bp, w2m, ext, kext, cst, st, g2)
         return out

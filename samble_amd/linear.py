@@ -69,16 +69,20 @@ def stage_linear_amax(x: torch.Tensor, w_rm: torch.Tensor, O: int):
     return y, arg
 
 
-def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int, C: int = 128) -> torch.Tensor:
-    """g (B,N,O) point-major -> (B,C,N): W^T g."""
-    _need_gpu(g, w_tr)
+def stage_linear_dx(g: torch.Tensor, w_tr: torch.Tensor, O: int, C: int = 128, residual=None, out=None) -> torch.Tensor:
+    """g (B,N,O) point-major -> (B,C,N): W^T g [+ residual (B,C,N), added by the kernel's epilogue; out: the tensor to
+    write, which may be `residual` itself (in-place accumulation)]."""
+    _need_gpu(g, w_tr, residual, out)
     g = _f32c(g)
     B, N, Og = g.shape
     assert Og == O
+    if residual is not None:
+        assert residual.shape == (B, C, N) and residual.is_contiguous() and residual.dtype == torch.float32
     with torch.cuda.device(g.device):
-        dx = torch.empty((B, C, N), dtype=torch.float32, device=g.device)
+        dx = out if out is not None else torch.empty((B, C, N), dtype=torch.float32, device=g.device)
+        assert dx.shape == (B, C, N) and dx.is_contiguous() and dx.dtype == torch.float32
         _lib.call("samble_linear_dx_tri_f32", g.data_ptr(), g.stride(0), g.stride(1), w_tr.data_ptr(), O, B, C, N,
-                  dx.data_ptr(), C * N, _stream())
+                  dx.data_ptr(), C * N, _p(residual), _stream())
     return dx
 
 

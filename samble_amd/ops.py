@@ -125,10 +125,13 @@ def stage_proj_fwd(x: torch.Tensor, tokens: torch.Tensor, w_qkv, images: str = "
     return qkv
 
 
-def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool, w_tr: Optional[torch.Tensor] = None):
+def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool, w_tr: Optional[torch.Tensor] = None,
+                   dx_residual: Optional[torch.Tensor] = None):
     """-> (dx (B,C,N) | None, dW (3C,C) | None, dtokens (C,nt) | None).  w_tr: the transposed operand image of w_qkv as
     stage_proj_fwd(images="fwd+bwd") returned it (MATRIX_MODE "tri"; the weights must not have changed since).
-    w_qkv may be the tuple (Wq, Wk, Wv): read where they are when w_tr comes along, concatenated here otherwise."""
+    w_qkv may be the tuple (Wq, Wk, Wv): read where they are when w_tr comes along, concatenated here otherwise.
+    dx_residual (B,C,N) (MATRIX_MODE "tri"): added to dx by the kernel's epilogue -- the gradient that reaches x along a
+    residual branch beside the projection."""
     w3 = _three_weights(w_qkv)
     if w3 is not None and (w_tr is None or MATRIX_MODE != "tri"):
         w_qkv, w3 = torch.cat(w3, dim=0), None
@@ -149,25 +152,31 @@ def stage_proj_bwd(dqkv, x, tokens, w_qkv, need_dx: bool, need_dw: bool, w_tr: O
         if tri:
             _lib.call("samble_proj_bwd_tri_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
                       tokens.data_ptr(), nt, *([w.data_ptr() for w in w3] if w3 else [w_qkv.data_ptr(), None, None]),
-                      _p(w_tr), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes, _stream())
+                      _p(w_tr), _p(dx), C * N, _p(dw), _p(dtok), _p(_f32c(dx_residual)) if dx_residual is not None else None,
+                      ws.data_ptr(), nbytes, _stream())
         else:
+            if dx_residual is not None:
+                raise ValueError("dx_residual comes with MATRIX_MODE 'tri' only")
             _lib.call("samble_proj_bwd_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), C * N, B, C, N,
                       tokens.data_ptr(), nt, w_qkv.data_ptr(), _p(dx), C * N, _p(dw), _p(dtok), ws.data_ptr(), nbytes,
                       _stream())
     return dx, dw, dtok
 
 
-def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff: bool, want_att: bool = False):
+def stage_n2p_attn_fwd(qkv: torch.Tensor, nn_idx: torch.Tensor, heads: int, diff: bool, want_att: bool = False,
+                       residual: Optional[torch.Tensor] = None):
     """qkv (B,N,3C) point-major [Q|K|V], nn_idx (B,N,K) int32 -> (B,C,N) attention output
-    [, (B,N,K) softmax probabilities when want_att (single head only)]."""
-    _need_gpu(qkv, nn_idx)
+    [, (B,N,K) softmax probabilities when want_att (single head only)].  residual (B,C,N): added on the way out."""
+    _need_gpu(qkv, nn_idx, residual)
+    if residual is not None:
+        residual = _f32c(residual)
     B, N, C3 = qkv.shape
     C = C3 // 3
     with torch.cuda.device(qkv.device):
         out = torch.empty((B, C, N), dtype=torch.float32, device=qkv.device)
         att = torch.empty((B, N, nn_idx.shape[2]), dtype=torch.float32, device=qkv.device) if want_att else None
         _lib.call("samble_n2p_attn_fwd_f32", qkv.data_ptr(), qkv.stride(0), qkv.stride(1), nn_idx.data_ptr(), B, N,
-                  nn_idx.shape[2], C, heads, int(bool(diff)), out.data_ptr(), _p(att), _stream())
+                  nn_idx.shape[2], C, heads, int(bool(diff)), out.data_ptr(), _p(att), _p(residual), _stream())
     return (out, att) if want_att else out
 
 

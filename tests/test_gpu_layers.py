@@ -780,3 +780,48 @@ def test_segment_sums_read_rows_where_they_are():
         got = ops.stage_segment_sum_rows(half, order, offsets, K, per_edge=False)
         want = ops.stage_segment_sum_rows(half.contiguous(), order, offsets, K, per_edge=False)
         assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,group_type,asm", [(2, 300, "diff", "dot"), (3, 1024, "neighbor", "dot-sub"), (32, 2048, "diff", "dot"),
+                                                 (2, 128, "diff", "dot"), (2, 77, "diff", "dot")])
+def test_n2p_layer_as_one_node_equals_the_node_by_node_composition(B, N, group_type, asm):
+    """attention._N2PLayer (round 5): the whole layer as one autograd node whose residual adds and gradient accumulations
+    ride on kernel epilogues -- output, input gradient, all nine parameter gradients and the BatchNorm buffers are
+    BIT-IDENTICAL to the composition of separate nodes (attention core, torch adds, nn.BatchNorm1d, FFN), which is what
+    the reference fixtures of this file pin."""
+    import copy
+    from samble_amd import attention as A
+    cfg = A.attention_config("cls")
+    cfg.group_type[0] = group_type
+    cfg.asm[0] = asm
+    torch.manual_seed(5)
+    one = A.Neighbor2PointAttention(cfg, 0).to("cuda:0").train()
+    with torch.no_grad():
+        for p in one.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    parts = copy.deepcopy(one)
+    x = torch.from_numpy(synth.features(B, 128, N, 3100 + N)).to("cuda:0")
+    g = torch.from_numpy(synth.normal((B, 128, N), 3200 + N)).to("cuda:0")
+    outs = []
+    for mod, fused in ((one, True), (parts, False)):
+        old = A.FUSED_LAYER
+        A.FUSED_LAYER = fused
+        try:
+            for step in range(2):               # two steps: the running statistics and the counters move twice
+                xin = x.clone().requires_grad_(True)
+                mod.zero_grad()
+                y = mod(xin)
+                y.backward(g)
+        finally:
+            A.FUSED_LAYER = old
+        outs.append((y.detach(), xin.grad, {n: p.grad for n, p in mod.named_parameters()},
+                     {n: b.clone() for n, b in mod.named_buffers()}))
+    (y1, dx1, gr1, bf1), (y2, dx2, gr2, bf2) = outs
+    assert A._layer_fusable(one, x)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for n in gr2:
+        assert torch.equal(gr1[n], gr2[n]), n
+    for n in bf2:
+        assert torch.equal(bf1[n], bf2[n]), n
