@@ -38,6 +38,11 @@ def test_linear_stages_against_float64(B, N, O):
     g = torch.from_numpy(synth.normal((B, N, O), 52 + N)).to(DEV)
     dx = L.stage_linear_dx(g, tr, O)
     assert dx.shape == (B, 128, N) and _rel(dx, torch.einsum("oc,bno->bcn", W.double(), g.double())) <= 2e-6
+    # ... with a residual on the kernel's epilogue: bitwise the separate add, also in place (ragged N: the clamped lanes)
+    r = torch.from_numpy(synth.normal((B, 128, N), 53 + N)).to(DEV)
+    assert torch.equal(L.stage_linear_dx(g, tr, O, residual=r), r + dx)
+    r2 = r.clone()
+    assert L.stage_linear_dx(g, tr, O, residual=r2, out=r2) is r2 and torch.equal(r2, r + dx)
     # dW: contraction over clouds and points, deterministic
     if O % 256 == 0:
         dW = L.stage_linear_dw(g, x, O)

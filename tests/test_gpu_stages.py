@@ -1200,7 +1200,11 @@ def test_projection_reads_three_weight_tensors_where_they_are():
         with pytest.raises(lib.SambleError):  # three tensors without the transposed image
             lib.call("samble_proj_bwd_tri_f32", dqkv.data_ptr(), dqkv.stride(0), dqkv.stride(1), x.data_ptr(), 128 * N, B, 128,
                      N, tokens.data_ptr(), nt, w3[0].data_ptr(), w3[1].data_ptr(), w3[2].data_ptr(), None, None, 128 * N, None,
-                     None, ws.data_ptr(), ws.numel(), None)
+                     None, None, ws.data_ptr(), ws.numel(), None)
+        # dx_residual (round 5): the kernel's epilogue adds a tensor of dx's layout -- bitwise the separate torch add
+        res = torch.from_numpy(synth.normal((B, 128, N), 1904)).to(DEV)
+        plus = o_.stage_proj_bwd(dqkv, x, tokens, w, True, True, dx_residual=res)
+        assert torch.equal(plus[0], res + ref[0]) and torch.equal(plus[1], ref[1]) and torch.equal(plus[2], ref[2])
     finally:
         o_.MATRIX_MODE = old
 
