@@ -1,6 +1,6 @@
 """Fold the rocprofv3 outputs of tools/profile_round.sh into the committed summaries under profiles/.
 
-  python tools/pmc_summary.py <tag>
+  python tools/pmc_summary.py <tag> [steps the traced command ran: warm-up + timed]
 
 reads  gpurun_out/<tag>_stats/**/*kernel_stats.csv and gpurun_out/<tag>_pmc_*/**/*counter_collection.csv
 writes profiles/<tag>_kernel_stats.csv (samble kernels + the largest others, verbatim rows),
@@ -26,7 +26,7 @@ def short(name):
     return n[5:] if n.startswith("void ") else n
 
 
-def main(tag):
+def main(tag, steps=0):
     gout = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
@@ -42,6 +42,8 @@ def main(tag):
     from collections import Counter
     counts = Counter(c for k, c in calls.items() if k.startswith("samble::"))
     steps_traced = counts.most_common(1)[0][0] if counts else 0
+    if steps:   # given on the command line (the block steps launch most of their kernels twice or more)
+        steps_traced = steps
     per = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(gout, f"{tag}_pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -85,4 +87,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
