@@ -25,6 +25,13 @@
 #ifndef SAMBLE_EDGE_F32
 #define SAMBLE_EDGE_F32 0
 #endif
+// 1 (default since round 5): the two sweeps' products on TWO fp16 planes per operand (tri_dev.h "duo", 3 matrix
+// instructions per k-step instead of 6) under power-of-two scales -- one per W2 image, one per point for its 32 x 64 tile
+// of hidden vectors, one per point for its tile of dy; dW2, which accumulates over the points, takes every point's product
+// from a zero accumulator and adds it to the fp32 totals.  0: the three-bf16-plane kernels of round 4 (A/B)
+#ifndef SAMBLE_EDGE_DUO
+#define SAMBLE_EDGE_DUO 1
+#endif
 
 namespace samble {
 
@@ -326,6 +333,64 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_bwd_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 constexpr int kEImg = 8 * 3 * 1024;  // bytes of one W2 image: 8 fragments x 3 planes x 64 lanes x 16 B
 
+constexpr bool kEdgeDuo = SAMBLE_EDGE_DUO != 0;
+// a wave-uniform float into a scalar register (the backward sweep sits at the 256-register limit of two waves per SIMD)
+__device__ __forceinline__ float uniform_f(float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x)));
+}
+struct EdgeDuoFrag {
+  u32x4 h, l;
+};
+__device__ __forceinline__ EdgeDuoFrag edge_frag_duo(const char* img, int frag, int lane) {
+  const u32x4* pp = reinterpret_cast<const u32x4*>(img + frag * 3072) + lane;
+  return EdgeDuoFrag{pp[0], pp[64]};
+}
+// both images as two fp16 planes of W2 x 2^e (in the slots of the first two planes); returns 2^-e (uniform over the
+// workgroup; `red`: 8 words of LDS scratch).  512 threads, thread = (fragment, lane) as edge_build_images
+__device__ __forceinline__ float edge_build_images_duo(const float* __restrict__ W2, char* img1, char* img2, int tid,
+                                                       bool want2, float* red) {
+  const int frag = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  float v1[8], v2[8];
+  {
+    const int ot = frag >> 2, ks = frag & 3;
+    const float* src = W2 + (32 * ot + lo) * kEC + 32 * h + 8 * ks;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v1[e] = a0[e];
+      v1[4 + e] = a1[e];
+    }
+  }
+  float amax = 0.f;  // image 1's fragments cover every element of W2 exactly once
+#pragma unroll
+  for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v1[e]));
+  amax = wave_amax64(amax);
+  if (lane == 0) red[frag] = amax;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) amax = fmaxf(amax, red[k]);
+  float sw, inv_w;
+  duo_scale_for(amax, sw, inv_w);
+  {
+    u32x4 hp, lp;
+    duo_split8s(v1, sw, hp, lp);
+    u32x4* d = reinterpret_cast<u32x4*>(img1 + frag * 3072) + lane;
+    d[0] = hp;
+    d[64] = lp;
+  }
+  if (want2) {
+    const int ct = frag >> 2, ot = (frag >> 1) & 1, gp = frag & 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v2[i] = W2[(32 * ot + 16 * gp + 8 * (i >> 2) + 4 * h + (i & 3)) * kEC + 32 * ct + lo];
+    u32x4 hp, lp;
+    duo_split8s(v2, sw, hp, lp);
+    u32x4* d = reinterpret_cast<u32x4*>(img2 + frag * 3072) + lane;
+    d[0] = hp;
+    d[64] = lp;
+  }
+  return inv_w;
+}
+
 __device__ __forceinline__ Tri edge_frag(const char* img, int frag, int lane) {
   const u32x4* pp = reinterpret_cast<const u32x4*>(img + frag * 3072) + lane;
   return Tri{pp[0], pp[64], pp[128]};
@@ -366,10 +431,13 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* _
                                                                   unsigned char* __restrict__ kmin,
                                                                   double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) char img1[kEImg];
+  __shared__ float red8[8];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const long gw = (long)blockIdx.x * 8 + wave, nw = (long)gridDim.x * 8;
-  edge_build_images(W2, img1, nullptr, tid, false);
+  float inv_w = 1.f;
+  if (kEdgeDuo) inv_w = edge_build_images_duo(W2, img1, nullptr, tid, false, red8);
+  else edge_build_images(W2, img1, nullptr, tid, false);
   __syncthreads();
   double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
   for (long p = gw; p < npoints; p += nw) {
@@ -379,6 +447,36 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* _
     const f32x4* bv = reinterpret_cast<const f32x4*>(bp + (cloud * N + j) * kEC + 32 * h);
     // D[row = edge][col = out channel] = sum_c h[edge][c] W2[o][c]
     f32x16 acc[2] = {zero16(), zero16()};
+    if (kEdgeDuo) {
+      float hv[32];
+      float amax = 0.f;
+#pragma unroll
+      for (int q4 = 0; q4 < 8; ++q4) {
+        const f32x4 a4 = av[q4], b4 = bv[q4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hv[4 * q4 + e] = lrelu(a4[e] + b4[e]);
+          amax = fmaxf(amax, fabsf(hv[4 * q4 + e]));
+        }
+      }
+      float sh, inv_h;
+      duo_scale_for(wave_amax64(amax), sh, inv_h);   // one scale for the point's 32 x 64 tile of hidden vectors
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float v[8] = {hv[8 * ks], hv[8 * ks + 1], hv[8 * ks + 2], hv[8 * ks + 3],
+                            hv[8 * ks + 4], hv[8 * ks + 5], hv[8 * ks + 6], hv[8 * ks + 7]};
+        u32x4 hh, hl;
+        duo_split8s(v, sh, hh, hl);
+        const EdgeDuoFrag w0 = edge_frag_duo(img1, ks, lane), w1 = edge_frag_duo(img1, 4 + ks, lane);
+        acc[0] = mfma_duo(hh, hl, w0.h, w0.l, acc[0]);
+        acc[1] = mfma_duo(hh, hl, w1.h, w1.l, acc[1]);
+      }
+      const float sc = inv_h * inv_w;   // exact: powers of two
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ot][r] *= sc;
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const f32x4 a0 = av[2 * ks], a1 = av[2 * ks + 1], b0 = bv[2 * ks], b1 = bv[2 * ks + 1];
@@ -387,6 +485,7 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* _
       const Tri ht = tri_split8(v);
       acc[0] = mfma_tri(ht, edge_frag(img1, ks, lane), acc[0]);
       acc[1] = mfma_tri(ht, edge_frag(img1, 4 + ks, lane), acc[1]);
+    }
     }
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot) {
@@ -458,7 +557,10 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   float* hts = cst + 2 * kEC + wave * (kEK * kEwPad);  // this wave's [32 edges][68] h tile
-  edge_build_images(W2, img1, img2, tid, true);
+  float inv_w = 1.f;
+  if (kEdgeDuo) inv_w = uniform_f(edge_build_images_duo(W2, img1, img2, tid, true, cst));  // (cst as scratch: rewritten below)
+  else edge_build_images(W2, img1, img2, tid, true);
+  __syncthreads();
   if (tid < 2 * kEC) cst[tid] = c0c1[tid];
   __syncthreads();
   const long gw = (long)blockIdx.x * 8 + wave, nw = (long)gridDim.x * 8;  // 8 waves: two per SIMD
@@ -469,6 +571,193 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
     for (int c = 0; c < 2; ++c) dw[a][c] = zero16();
 
   int pcount = -1;
+  float sh_run = 1.2676506e30f, sdy_run = 1.2676506e30f;   // 2^100: duo_scale_for's largest
+  if (kEdgeDuo) {
+  // ---- the same sweep on two fp16 planes: one scale for the point's tile of hidden vectors (s_h), one for its tile of dy
+  // (s_dy: y^T and y hold the same 32 x 64 values, one maximum serves both layouts), W2's from the image build
+  for (long p = gw; p < npoints; p += nw) {
+    ++pcount;
+    // (the W2 fragments are loop-invariant LDS reads: 16 x 8 registers that the compiler would otherwise hoist out of the
+    // loop and then spill -- 119 spills; they are to be read where they are used)
+    asm volatile("" ::: "memory");
+    EDGE_STAMP(0);
+    const long cloud = p / N;
+    const int j = nn[p * kEK + lo];
+    const float* arow = ap + p * kEC;
+    const float* brow = bp + (cloud * N + j) * kEC;
+    float amax = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // the tile goes to LDS as it is formed; its split waits for the tile's maximum
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + 32 * h + 8 * ks), a1 = *reinterpret_cast<const f32x4*>(arow + 32 * h + 8 * ks + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 32 * h + 8 * ks), b1 = *reinterpret_cast<const f32x4*>(brow + 32 * h + 8 * ks + 4);
+      const f32x4 h0 = {lrelu(a0[0] + b0[0]), lrelu(a0[1] + b0[1]), lrelu(a0[2] + b0[2]), lrelu(a0[3] + b0[3])};
+      const f32x4 h1 = {lrelu(a1[0] + b1[0]), lrelu(a1[1] + b1[1]), lrelu(a1[2] + b1[2]), lrelu(a1[3] + b1[3])};
+      *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks) = h0;
+      *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks + 4) = h1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(h0[e]), fabsf(h1[e])));
+    }
+    float s_h, inv_h;
+    duo_scale_for(wave_amax64(amax), s_h, inv_h);
+    s_h = uniform_f(s_h);
+    inv_h = uniform_f(inv_h);
+    // y in both orientations, ONE AT A TIME (together with the dW2 accumulators they do not fit 256 registers beside
+    // the operands: 111 spills; the price is the hidden tile split twice): first y[edge][o] = D[row = edge][col = o]
+    f32x16 yt2[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks);       // this lane's own row
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks + 4);
+      const float v[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      u32x4 hh, hl;
+      duo_split8s(v, s_h, hh, hl);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const EdgeDuoFrag w = edge_frag_duo(img1, 4 * ot + ks, lane);
+        yt2[ot] = mfma_duo(hh, hl, w.h, w.l, yt2[ot]);
+      }
+    }
+    EDGE_STAMP(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // dy = c0 + c1 y + [edge == kext] sdv in place; y = accumulator x 2^-(e_h + e_w)
+    const float sc_y = uniform_f(inv_h * inv_w);
+    float dmax = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {  // yt2: register r <-> edge crow(r, h), lane <-> channel o = 32 ot + lo
+      const int o = 32 * ot + lo;
+      const int ke = kext[p * kEC + o];
+      const float sv = sdv[p * kEC + o], c0 = cst[o], c1 = cst[kEC + o];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        yt2[ot][r] = fmaf(c1, yt2[ot][r] * sc_y, c0) + (crow(r, h) == ke ? sv : 0.f);
+        dmax = fmaxf(dmax, fabsf(yt2[ot][r]));
+      }
+    }
+    float s_dy, inv_dy;
+    duo_scale_for(wave_amax64(dmax), s_dy, inv_dy);   // (y^T below holds the same 32 x 64 values: one maximum serves both)
+    s_dy = uniform_f(s_dy);
+    inv_dy = uniform_f(inv_dy);
+    EDGE_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    // dW2[o][c] += sum_edge dy[edge][o] h[edge][c] ACCUMULATES over the wave's points, so its two operands run under
+    // scales that only ever shrink: the smallest (= for the largest tile so far) of the points' scales.  When a point
+    // brings a larger tile the accumulators are rescaled by the exact power of two (uniform over the wave, rare after
+    // the first few points); a point with a smaller tile is split under a scale larger tiles chose -- what that loses is
+    // relative to a sum those tiles dominate
+    if (s_h < sh_run || s_dy < sdy_run) {
+      const float ratio = uniform_f((fminf(s_h, sh_run) / sh_run) * (fminf(s_dy, sdy_run) / sdy_run));
+      sh_run = uniform_f(fminf(s_h, sh_run));
+      sdy_run = uniform_f(fminf(s_dy, sdy_run));
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dw[ot][ct][r] *= ratio;
+    }
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      u32x4 bqh[2], bql[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = hts[(16 * kp + 8 * (i >> 2) + 4 * h + (i & 3)) * kEwPad + 32 * ct + lo];
+        duo_split8s(v, sh_run, bqh[ct], bql[ct]);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = yt2[ot][8 * kp + i];
+        u32x4 ah, al;
+        duo_split8s(v, sdy_run, ah, al);
+        dw[ot][0] = mfma_duo(ah, al, bqh[0], bql[0], dw[ot][0]);
+        dw[ot][1] = mfma_duo(ah, al, bqh[1], bql[1], dw[ot][1]);
+      }
+    }
+    EDGE_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then y^T[o][edge] = D[row = o][col = edge] and its dy
+    f32x16 yt1[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks);
+      const f32x4 h1 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * h + 8 * ks + 4);
+      const float v[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      u32x4 hh, hl;
+      duo_split8s(v, s_h, hh, hl);
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const EdgeDuoFrag w = edge_frag_duo(img1, 4 * ot + ks, lane);
+        yt1[ot] = mfma_duo(w.h, w.l, hh, hl, yt1[ot]);
+      }
+    }
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // yt1: register r <-> channel o = 32 ot + crow(r, h), lane <-> edge
+        const uchar4 k4 = *reinterpret_cast<const uchar4*>(kext + p * kEC + 32 * ot + 8 * g + 4 * h);
+        const int kk4[4] = {k4.x, k4.y, k4.z, k4.w};
+        const f32x4 sdv4 = *reinterpret_cast<const f32x4*>(sdv + p * kEC + 32 * ot + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int o = 32 * ot + 8 * g + 4 * h + e;
+          yt1[ot][r] = fmaf(cst[kEC + o], yt1[ot][r] * sc_y, cst[o]) + (lo == kk4[e] ? sdv4[e] : 0.f);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // dh^T tile ct: D[row = c][col = edge] = sum_o W2[o][c] dy[edge][o]; k-step (ot, gp) = registers 8 gp .. + 7 of yt1[ot]
+    f32x16 dht[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = yt1[ot][8 * gp + i];
+        u32x4 bh, bl;
+        duo_split8s(v, s_dy, bh, bl);
+        const EdgeDuoFrag w0 = edge_frag_duo(img2, 2 * ot + gp, lane), w1 = edge_frag_duo(img2, 4 + 2 * ot + gp, lane);
+        dht[0] = mfma_duo(w0.h, w0.l, bh, bl, dht[0]);
+        dht[1] = mfma_duo(w1.h, w1.l, bh, bl, dht[1]);
+      }
+    }
+    EDGE_STAMP(4);
+    __builtin_amdgcn_sched_barrier(0);   // (phases stay apart: hoisted across them, the next phase's operands spill)
+    // du = dh * LReLU'(u) (the scales of dh ride on the two slopes), written per edge; see the three-plane sweep below
+    const float slope1 = uniform_f(inv_w * inv_dy), slope02 = uniform_f(0.2f * inv_w * inv_dy);
+    float* durow0 = du + p * (kEK * kEC);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 h4 = *reinterpret_cast<const f32x4*>(hts + lo * kEwPad + 32 * ct + 8 * g + 4 * h);
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = dht[ct][4 * g + e] * (h4[e] > 0.f ? slope1 : slope02);
+        *reinterpret_cast<f32x4*>(hts + lo * kEwPad + 32 * ct + 8 * g + 4 * h) = o4;
+      }
+    }
+    EDGE_STAMP(5);
+    __builtin_amdgcn_sched_barrier(0);   // (phases stay apart: hoisted across them, the next phase's operands spill)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(hts + (4 * it + (lane >> 4)) * kEwPad + 4 * (lane & 15));
+      *reinterpret_cast<f32x4*>(durow0 + 256 * it + 4 * lane) = v;
+    }
+    EDGE_STAMP(6);
+    if (dusum) {  // (uniform)
+      float rs = 0.f;
+#pragma unroll
+      for (int e = 0; e < kEK; ++e) rs += hts[e * kEwPad + lane];
+      dusum[p * kEC + lane] = rs;
+    }
+    EDGE_STAMP(7);
+  }
+  } else
   for (long p = gw; p < npoints; p += nw) {
     ++pcount;
     EDGE_STAMP(0);
@@ -602,13 +891,14 @@ __global__ __launch_bounds__(512) void edge_mlp_bwd_tri_kernel(const float* __re
   }
   // per-wave dW2 partial (64 x 64): tile [ot][ct] register r, lane (c = lo, h) <-> o = 32 ot + crow(r,h)
   if (gw < nw) {
+    const float un = kEdgeDuo ? (1.f / sh_run) * (1.f / sdy_run) : 1.f;   // (two steps: the product of the scales may not be a float)
     float* outp = dw2part + gw * kEC * kEC;
 #pragma unroll
     for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) outp[(32 * ot + crow(r, h)) * kEC + 32 * ct + lo] = dw[ot][ct][r];
+        for (int r = 0; r < 16; ++r) outp[(32 * ot + crow(r, h)) * kEC + 32 * ct + lo] = dw[ot][ct][r] * un;
   }
 }
 

@@ -115,6 +115,22 @@ __device__ __forceinline__ void duo_split2(float x0, float x1, unsigned& h, unsi
   h = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
   l = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
 }
+// eight fp32 values x s -> the two fp16 planes of one 16-byte operand chunk
+__device__ __forceinline__ void duo_split8s(const float (&v)[8], float s, u32x4& hp, u32x4& lp) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    unsigned hw, lw;
+    duo_split2(v[2 * w] * s, v[2 * w + 1] * s, hw, lw);
+    hp[w] = hw;
+    lp[w] = lw;
+  }
+}
+// largest value over the 64 lanes, in every lane
+__device__ __forceinline__ float wave_amax64(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+  return x;
+}
 // ---- products that ACCUMULATE over tiles (out^T += A_tile^T X_tile: dV^T += dO^T P, dK^T += Q^T dS) ------------------
 // The A tiles (transposed images of the sampled rows) carry per-tile scales 2^e_t; their X blocks are split in the
 // kernel anyway, so X is multiplied by 2^(13 - (e_t - e_min)) x xs before ITS split (xs = 1 for probabilities, a power of
