@@ -603,6 +603,7 @@ int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image
  * without the transposing copy (models/attention.py:187-192: the second FFN convolution's weight (128, 512, 1) feeds
  * samble_linear_dx_tri_f32 as W^T).  Two-plane build of csrc/linear.hip only (the default). */
 int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, void* rm_image, void* tr_image, void* stream);
+int samble_linear_two_plane_build(void); /* 1 in the default build; 0 in a -DSAMBLE_LIN_DUO=0 (three bf16 planes) A/B build */
 int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int epilogue,
                               const float* ref, float* out, int64_t o_bs, int64_t o_rs, void* stream);
 size_t samble_linear_amax_workspace_bytes(int B, int N, int O);

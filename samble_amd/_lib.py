@@ -85,6 +85,7 @@ _SIGNATURES = {
     "samble_linear_image_bytes": (c_size_t, [c_int]),
     "samble_linear_weight_images_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "samble_linear_weight_images_t_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "samble_linear_two_plane_build": (c_int, []),
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                           c_int64, c_int64, c_void_p]),
     "samble_linear_amax_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

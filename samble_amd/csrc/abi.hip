@@ -972,6 +972,9 @@ SAMBLE_API int samble_linear_weight_images_f32(const float* W, int O, int C, voi
   return done(samble_launch_linear_images(W, O, rm_image, tr_image, 0, (hipStream_t)stream), "samble_linear_weight_images_f32");
 }
 
+/* 1: csrc/linear.hip was built on two fp16 planes (the default) -- the transposed-weight entry below exists in that build */
+SAMBLE_API int samble_linear_two_plane_build(void) { return samble_linear_is_duo(); }
+
 SAMBLE_API int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, void* rm_image, void* tr_image, void* stream) {
   if (!Wt || (!rm_image && !tr_image)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: null pointer");
   if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: Wt must be (128, O), O a multiple of 32");

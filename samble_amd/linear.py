@@ -24,6 +24,9 @@ def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True, t
     -- no transposing copy in front of the launch."""
     _need_gpu(W)
     W = _f32c(W)
+    if transposed and not _lib.query("samble_linear_two_plane_build"):
+        # a three-bf16-plane A/B build of csrc/linear.hip has no transposed-weight entry: the copy it saves, then the plain one
+        W, transposed = W.t().contiguous(), False
     if transposed:
         C, O = W.shape
         assert C == 128
