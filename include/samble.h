@@ -617,6 +617,17 @@ int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const f
 /* ... written transposed: dWt (128, O) row-major -- that convolution's weight gradient in its parameter's own layout */
 int samble_linear_dw_t_tri_f32(const float* g, int64_t g_bs, int64_t g_rs, const float* x, int64_t x_bs, int B, int C, int N,
                                int O, float* dWt, void* ws, size_t ws_bytes, void* stream);
+/* Channel-major in, channel-major out (a 1x1 Conv1d as the reference's modules hold their tensors: the interpolation
+   layers' `conv` and `res_conv`, models/upsample.py:142-150 -- F.conv1d there):
+     samble_linear_fwd_cm_f32   out (B, O, N) [cloud stride o_bs] = W x, or out += W x when accumulate != 0 (the second
+                                128 channels of a 256-channel input, without a concatenated copy of the two inputs)
+     samble_linear_dw_cm_f32    dW (O, 128) = sum over clouds and points of g x^T, g (B, O, N) [cloud stride g_bs]
+                                channel-major; workspace: samble_linear_dw_workspace_bytes(B, N, O); O a multiple of 128
+   (the input gradient is the forward entry again with the image of W^T: samble_linear_weight_images_t_f32) */
+int samble_linear_fwd_cm_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int accumulate,
+                             float* out, int64_t o_bs, void* stream);
+int samble_linear_dw_cm_f32(const float* g, int64_t g_bs, const float* x, int64_t x_bs, int B, int C, int N, int O, float* dW,
+                            void* ws, size_t ws_bytes, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);

@@ -123,7 +123,8 @@ size_t samble_linear_amax_ws_bytes(int, int, int);
 int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
 int samble_launch_linear_dx(const float*, long, long, const void*, int, int, int, int, float*, long, const float*, hipStream_t);
 size_t samble_linear_dw_ws_bytes(int, int, int);
-int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, int, void*, hipStream_t);
+int samble_launch_linear_dw(const float*, long, long, const float*, long, int, int, int, int, float*, int, void*, hipStream_t, int);
+int samble_launch_linear_fwd_cm(const float*, long, int, int, int, const void*, int, int, float*, long, hipStream_t);
 size_t samble_amax_bwd_ws_bytes(int, int, int);
 int samble_launch_amax_bwd(const float*, long, int, int, const int*, const float*, const float*, int, float*, long, float*,
                            void*, hipStream_t);
@@ -1026,7 +1027,7 @@ SAMBLE_API int samble_linear_dw_tri_f32(const float* g, int64_t g_bs, int64_t g_
     return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: 1 <= C <= 128, O a multiple of 128");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_tri_f32: g rows must be 16-byte aligned");
   if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_tri_f32: workspace too small");
-  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dW, 0, ws, (hipStream_t)stream), "samble_linear_dw_tri_f32");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dW, 0, ws, (hipStream_t)stream, 0), "samble_linear_dw_tri_f32");
 }
 
 /* the same sum, written transposed: dWt (128, O) row-major (C = 128 only) */
@@ -1037,7 +1038,27 @@ SAMBLE_API int samble_linear_dw_t_tri_f32(const float* g, int64_t g_bs, int64_t 
     return fail(SAMBLE_E_INVALID, "samble_linear_dw_t_tri_f32: C must be 128, O a multiple of 128");
   if ((g_rs & 3) || (g_bs & 3) || ((uintptr_t)g & 15)) return fail(SAMBLE_E_INVALID, "samble_linear_dw_t_tri_f32: g rows must be 16-byte aligned");
   if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_t_tri_f32: workspace too small");
-  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dWt, 1, ws, (hipStream_t)stream), "samble_linear_dw_t_tri_f32");
+  return done(samble_launch_linear_dw(g, g_bs, g_rs, x, x_bs, B, C, N, O, dWt, 1, ws, (hipStream_t)stream, 0), "samble_linear_dw_t_tri_f32");
+}
+
+/* channel-major in, channel-major out: out (B, O, N) = W x [+ out when accumulate != 0], and the weight gradient of that
+   layer from a channel-major output gradient g (B, O, N): dW (O, 128) = sum over clouds and points of g x^T */
+SAMBLE_API int samble_linear_fwd_cm_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O,
+                                        int accumulate, float* out, int64_t o_bs, void* stream) {
+  if (!x || !w_rm_image || !out) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_cm_f32: null pointer");
+  if (C < 1 || C > 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_cm_f32: 1 <= C <= 128, O a multiple of 32");
+  if (o_bs < (int64_t)O * N) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_cm_f32: output clouds overlap");
+  return done(samble_launch_linear_fwd_cm(x, x_bs, B, C, N, w_rm_image, O, accumulate, out, o_bs, (hipStream_t)stream),
+              "samble_linear_fwd_cm_f32");
+}
+
+SAMBLE_API int samble_linear_dw_cm_f32(const float* g, int64_t g_bs, const float* x, int64_t x_bs, int B, int C, int N, int O,
+                                       float* dW, void* ws, size_t ws_bytes, void* stream) {
+  if (!g || !x || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_linear_dw_cm_f32: null pointer");
+  if (C < 1 || C > 128 || !lin_shape_ok(B, N, O) || (O & 127))
+    return fail(SAMBLE_E_INVALID, "samble_linear_dw_cm_f32: 1 <= C <= 128, O a multiple of 128");
+  if (ws_bytes < samble_linear_dw_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_linear_dw_cm_f32: workspace too small");
+  return done(samble_launch_linear_dw(g, g_bs, N, x, x_bs, B, C, N, O, dW, 0, ws, (hipStream_t)stream, 1), "samble_linear_dw_cm_f32");
 }
 
 SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int N, int O) {

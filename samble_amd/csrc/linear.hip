@@ -86,12 +86,16 @@ __device__ __forceinline__ void duo_split8(const float (&v)[8], float s, u32x4& 
 //      kLinMask:  out = (W x) * (ref > 0 ? 1 : 0.2)   (ref: same layout as out -- the activation the forward kept)
 //      kLinAmax:  no out: per 32-point tile the maximum of every output row over the tile's points and the first point
 //                 that reaches it -> pmax / parg [(b, tile, o)]
-template <int EPI>
+//
+// CM (plain epilogue only): the output leaves CHANNEL-major, out[b][o][n] (o_rs = the stride between output channels) --
+// the accumulator's columns are the points, so a register's 32 lanes write one 128-byte line; accum: out += W x (the second
+// half of a 256-channel input: models/upsample.py:150 `res_conv(cat(up, interpolated))` without the concatenation)
+template <int EPI, bool CM = false>
 __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __restrict__ x, long x_bs, int Cin, int N,
                                                              const char* __restrict__ Wimg, int otiles, int O,
                                                              float* __restrict__ out, long o_bs, long o_rs,
                                                              const float* __restrict__ ref, float* __restrict__ pmax,
-                                                             int* __restrict__ parg) {
+                                                             int* __restrict__ parg, int accum) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
   const int tid = threadIdx.x;
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
   xcd_assign(chunk, b);
   // points past N-1 are clamped: those lanes recompute and rewrite point N-1's row bit for bit (no predicated store)
   const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  const bool own = chunk * 256 + wave * 32 + lo < N;   // (CM: clamped lanes do not store -- accum is a read-modify-write)
   auto stage = [&](int t) {
     const char* gt = Wimg + (long)min(t, otiles - 1) * kTriTile;
     char* lt = smem_c + (t % D) * kTriTile;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) xinv_r[r] = __shfl(x_inv, crow(r, h), 64);
   }
-  float* orow = (EPI == kLinAmax) ? nullptr : out + (long)b * o_bs + (long)n * o_rs + 4 * h;
+  float* orow = (EPI == kLinAmax) ? nullptr : CM ? out + (long)b * o_bs + n : out + (long)b * o_bs + (long)n * o_rs + 4 * h;
   const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h : nullptr;
   const long ptile = (long)b * (gridDim.x * 8) + chunk * 8 + wave;   // (b, 32-point tile) of this wave
   const int n_first = chunk * 256 + wave * 32;
@@ -166,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 
   // iteration t: [mask: the activation words of tile t+1], tile t+3 into the slot of tile t-1, the product of tile t, its
   // stores.  VM operations younger than tile t+1's DMA at the end of iteration t (in-order retirement): plain / leaky
-  // 4 + 2 x (3 + 4) = 18; mask 4 + 2 x (4 + 3 + 4) = 26; amax 2 + 2 x (3 + 2) = 12.  Counting LOW is the safe side.
+  // 4 + 2 x (3 + 4) = 18; mask 4 + 2 x (4 + 3 + 4) = 26; amax 2 + 2 x (3 + 2) = 12; CM 16 + 2 x (3 + 16) = 54 (accum: more).
+  // Counting LOW is the safe side.
   float res_m = 0.f;
   int res_a = 0;
   for (int t = 0; t < otiles; ++t) {
@@ -245,6 +251,20 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
         parg[at] = min(n_first + res_a, N - 1);
       }
       asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (CM) {
+      float* oc = orow + (long)(t * 32 + 4 * h) * o_rs;   // acc[4 g + e]: output 32 t + 8 g + 4 h + e
+      if (accum) {
+        float prev[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r] = oc[(long)(8 * (r >> 2) + (r & 3)) * o_rs];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += prev[r];
+      }
+      if (own) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oc[(long)(8 * (r >> 2) + (r & 3)) * o_rs] = acc[r];
+      }
+      asm volatile("s_waitcnt vmcnt(54) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -569,21 +589,24 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
 // contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
 // OT = output tiles per wave: 2 (blocks of 256 outputs) or 1 (blocks of 128: narrow layers)
 constexpr int kLdwPts = 512, kLdwXS = 33;
-template <int OT>
+// GCM: g arrives channel-major, (B, O, N) with g_rs = the stride between output channels (the weight gradient of a
+// channel-major -> channel-major convolution): its tile is staged like x's, [output][point] with row stride 33
+template <int OT, bool GCM = false>
 struct Ldw {
   static constexpr int kOB = 128 * OT;
   static constexpr int kGS = kOB + 4;  // row stride: g tile rows 16-byte aligned, column reads conflict-free
-  static constexpr int kBuf = kTile * kGS + 128 * kLdwXS;
+  static constexpr int kG = GCM ? kOB * kLdwXS : kTile * kGS;
+  static constexpr int kBuf = kG + 128 * kLdwXS;
   static constexpr int kLds = 2 * kBuf * 4;
 };
 
-template <int OT>
+template <int OT, bool GCM = false>
 __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                             const float* __restrict__ x, long x_bs, int Cin, int N, int O,
                                                             float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   float* smem = reinterpret_cast<float*>(smem_c);
-  constexpr int GS = Ldw<OT>::kGS, XS = kLdwXS, BUF = Ldw<OT>::kBuf, kLdwOB = Ldw<OT>::kOB;
+  constexpr int GS = Ldw<OT, GCM>::kGS, XS = kLdwXS, BUF = Ldw<OT, GCM>::kBuf, kLdwOB = Ldw<OT, GCM>::kOB, GOFF = Ldw<OT, GCM>::kG;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const int og = wave >> 1, ch = wave & 1;
@@ -595,8 +618,16 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = zero16();
   f32x4 gst[2 * OT];  // 32 rows x (32 OT) float4 / 512 threads
+  float gsc[GCM ? 8 * OT : 1];  // GCM: (128 OT) outputs x 32 points / 512 threads
   float xst[8];  // 128 channels x 32 points = 4096 floats / 512 threads
   auto issue = [&](int nn0) {
+    if (GCM) {
+#pragma unroll
+      for (int it = 0; it < 8 * OT; ++it) {
+        const int e = tid + 512 * it;
+        gsc[GCM ? it : 0] = (nn0 + (e & 31) < N) ? g[(long)b * g_bs + (long)(o0 + (e >> 5)) * g_rs + nn0 + (e & 31)] : 0.f;
+      }
+    } else
 #pragma unroll
     for (int it = 0; it < 2 * OT; ++it) {
       const int e = tid + 512 * it;
@@ -612,6 +643,13 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
     }
   };
   auto commit = [&](float* buf) {
+    if (GCM) {
+#pragma unroll
+      for (int it = 0; it < 8 * OT; ++it) {
+        const int e = tid + 512 * it;
+        buf[(e >> 5) * XS + (e & 31)] = gsc[GCM ? it : 0];
+      }
+    } else
 #pragma unroll
     for (int it = 0; it < 2 * OT; ++it) {
       const int e = tid + 512 * it;
@@ -621,9 +659,11 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int e = tid + 512 * it;
-      buf[kTile * GS + (e >> 5) * XS + (e & 31)] = xst[it];
+      buf[GOFF + (e >> 5) * XS + (e & 31)] = xst[it];
     }
   };
+  // g's tile element (point p of the tile, output j of the block)
+  auto gat = [&](const float* gt, int p, int j) -> float { return GCM ? gt[j * XS + p] : gt[p * GS + j]; };
   constexpr int ntiles = kLdwPts / kTile;
   issue(n0);
   commit(smem);
@@ -633,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
     float* nxt = smem + ((t & 1) ^ 1) * BUF;
     if (t + 1 < ntiles) issue(n0 + (t + 1) * kTile);
     const float* gt = cur;
-    const float* xt = cur + kTile * GS;
+    const float* xt = cur + GOFF;
     if (kLinDuo) {
       // both k-steps' operands of the tile under two wave-uniform scales (the block of g this wave multiplies, its block
       // of x), every (output tile, channel tile) product from a zero accumulator, fp32 totals by the vector ALU
@@ -648,7 +688,7 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
           for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              v[ks][ot][e] = gt[(16 * ks + 8 * h + e) * GS + 32 * OT * og + 32 * ot + lo];
+              v[ks][ot][e] = gat(gt, 16 * ks + 8 * h + e, 32 * OT * og + 32 * ot + lo);
               amax = fmaxf(amax, fabsf(v[ks][ot][e]));
             }
         float sa;
@@ -702,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
       for (int ot = 0; ot < OT; ++ot) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * ks + 8 * h + e) * GS + 32 * OT * og + 32 * ot + lo];
+        for (int e = 0; e < 8; ++e) v[e] = gat(gt, 16 * ks + 8 * h + e, 32 * OT * og + 32 * ot + lo);
         const Tri a = tri_split8(v);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) acc[ot][ct] = mfma_tri(a, bq[ct], acc[ot][ct]);
@@ -1003,13 +1043,25 @@ extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Ci
   Timed timed(kT_lin_fwd, s);
   if (epi == kLinPlain)
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
-                       out, o_bs, o_rs, nullptr, nullptr, nullptr);
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
   else if (epi == kLinLeaky)
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
-                       out, o_bs, o_rs, nullptr, nullptr, nullptr);
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
   else
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
-                       out, o_bs, o_rs, ref, nullptr, nullptr);
+                       out, o_bs, o_rs, ref, nullptr, nullptr, 0);
+  return (int)hipGetLastError();
+}
+
+// out (B, O, N) channel-major = W x [+ out]
+extern "C" int samble_launch_linear_fwd_cm(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O,
+                                           int accumulate, float* out, long o_bs, hipStream_t s) {
+  const void* fn = reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain, true>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_lin_fwd, s);
+  hipLaunchKernelGGL((lin_fwd_tri_kernel<kLinPlain, true>), dim3((N + 255) / 256, B), dim3(512), kLinLds, s, x, x_bs, Cin, N,
+                     (const char*)w_rm, O / 32, O, out, o_bs, (long)N, nullptr, nullptr, nullptr, accumulate);
   return (int)hipGetLastError();
 }
 
@@ -1028,7 +1080,7 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
   int* parg = (int*)(pmax + (size_t)B * ntiles * O);
   Timed timed(kT_lin_amax, s);
   hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B), dim3(512), kLinLds, s, x, x_bs, 128, N, (const char*)w_rm,
-                     O / 32, O, nullptr, 0, 0, nullptr, pmax, parg);
+                     O / 32, O, nullptr, 0, 0, nullptr, pmax, parg, 0);
   hipLaunchKernelGGL(lin_amax_reduce_kernel, dim3((O + 255) / 256, B), dim3(256), 0, s, pmax, parg, ntiles, O, y, arg);
   return (int)hipGetLastError();
 }
@@ -1053,10 +1105,17 @@ extern "C" size_t samble_linear_dw_ws_bytes(int B, int N, int O) {
 }
 
 extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int Cin, int N,
-                                       int O, float* dW, int transposed, void* ws, hipStream_t s) {
+                                       int O, float* dW, int transposed, void* ws, hipStream_t s, int g_cm) {
   const int chunks = (N + kLdwPts - 1) / kLdwPts;
   Timed timed(kT_lin_dw, s);
-  if (O % 256 == 0) {
+  if (g_cm) {   // g (B, O, N): blocks of 128 outputs (two workgroups per CU)
+    constexpr int lds = Ldw<1, true>::kLds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((lin_dw_tri_kernel<1, true>), dim3(chunks, B, O / 128), dim3(512), lds, s, g, g_bs, g_rs, x, x_bs, Cin,
+                       N, O, (float*)ws);
+  } else if (O % 256 == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Ldw<2>::kLds);
     if (e != hipSuccess) return (int)e;

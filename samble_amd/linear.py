@@ -106,6 +106,37 @@ def stage_linear_dw(g: torch.Tensor, x: torch.Tensor, O: int, transposed: bool =
     return dW if (C == 128 or transposed) else dW[:, :C]
 
 
+def stage_linear_fwd_cm(x: torch.Tensor, w_rm: torch.Tensor, O: int, out=None, accumulate: bool = False) -> torch.Tensor:
+    """x (B,C<=128,N) channel-major -> (B,O,N) channel-major: W x [added to `out` when accumulate]."""
+    _need_gpu(x, w_rm, out)
+    x = _f32c(x)
+    B, C, N = x.shape
+    with torch.cuda.device(x.device):
+        if out is None:
+            assert not accumulate
+            out = torch.empty((B, O, N), dtype=torch.float32, device=x.device)
+        assert out.shape == (B, O, N) and out.is_contiguous() and out.dtype == torch.float32
+        _lib.call("samble_linear_fwd_cm_f32", x.data_ptr(), C * N, B, C, N, w_rm.data_ptr(), O, int(accumulate),
+                  out.data_ptr(), O * N, _stream())
+    return out
+
+
+def stage_linear_dw_cm(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g (B,O,N), x (B,C<=128,N), both channel-major -> dW (O,C) = sum over clouds and points of g x^T (deterministic)."""
+    _need_gpu(g, x)
+    g, x = _f32c(g), _f32c(x)
+    B, O, N = g.shape
+    C = x.shape[1]
+    assert x.shape == (B, C, N)
+    with torch.cuda.device(g.device):
+        dW = torch.empty((O, 128), dtype=torch.float32, device=g.device)
+        nbytes = _lib.query("samble_linear_dw_workspace_bytes", B, N, O)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        _lib.call("samble_linear_dw_cm_f32", g.data_ptr(), O * N, x.data_ptr(), C * N, B, C, N, O, dW.data_ptr(),
+                  ws.data_ptr(), nbytes, _stream())
+    return dW if C == 128 else dW[:, :C]
+
+
 def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor):
     """Backward of stage_linear_amax: -> (dx (B,128,N), zero outside the arg-max columns; dW (O,128))."""
     _need_gpu(x, arg, gy, W)
@@ -209,6 +240,59 @@ class _LinearMax(torch.autograd.Function):
         x, arg, W = ctx.saved_tensors
         dx, dW = stage_amax_bwd(x, arg, gy, W)
         return dx, dW.reshape(W.shape[0], 128, 1)
+
+
+class _PointwiseCM(torch.autograd.Function):
+    """y (B,128,N) = sum_i W[:, 128 i : 128 i + 128] x_i: a bias-free Conv1d(128 k -> 128, kernel 1) on the channel-wise
+    concatenation of k tensors (B,128,N) that is never formed (reference models/upsample.py:142-150: `conv` k = 1,
+    `res_conv(torch.cat((pcd_up, interpolated), dim=1))` k = 2).  Channel-major in and out: forward and input gradients
+    on lin_fwd's channel-major store, weight gradients on lin_dw's channel-major staging."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, w, *xs):
+        W = w.reshape(w.shape[0], -1)
+        parts = [_f32c(W[:, 128 * i:128 * i + 128]) for i in range(len(xs))]
+        y = None
+        for i, (x, Wi) in enumerate(zip(xs, parts)):
+            rm, _ = weight_images(Wi, want_tr=False)
+            y = stage_linear_fwd_cm(x, rm, W.shape[0], out=y, accumulate=i > 0)
+        ctx.save_for_backward(*xs, *parts)
+        ctx.k = len(xs)
+        ctx.wshape = w.shape
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy):
+        k = ctx.k
+        xs, parts = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        gy = _f32c(gy)
+        dxs = []
+        for i in range(k):
+            if ctx.needs_input_grad[1 + i]:
+                rm_t, _ = weight_images(parts[i], want_tr=False, transposed=True)     # the image of W_i^T, from W_i as it is
+                dxs.append(stage_linear_fwd_cm(gy, rm_t, 128))
+            else:
+                dxs.append(None)
+        dw = None
+        if ctx.needs_input_grad[0]:
+            dws = [stage_linear_dw_cm(gy, x) for x in xs]
+            dw = (dws[0] if k == 1 else torch.cat(dws, dim=1)).reshape(ctx.wshape)
+        return (dw, *dxs)
+
+
+def pointwise_cm_supported(w: torch.Tensor, *xs: torch.Tensor) -> bool:
+    return (len(xs) in (1, 2) and w.dim() == 3 and w.shape[0] == 128 and w.shape[2] == 1 and w.shape[1] == 128 * len(xs)
+            and all(x.is_cuda and x.dim() == 3 and x.shape[1] == 128 and x.dtype == torch.float32 and x.shape == xs[0].shape
+                    for x in xs) and w.is_cuda and bool(_lib.query("samble_linear_two_plane_build")))
+
+
+def pointwise_cm(w: torch.Tensor, *xs: torch.Tensor) -> torch.Tensor:
+    """Conv1d(128 k -> 128, no bias)(cat(xs, dim=1)) with the Conv1d weight w (128, 128 k, 1)."""
+    if not w.is_cuda:
+        raise _lib.SambleError("samble_amd.linear.pointwise_cm runs on the GPU only (no CPU fallback)")
+    return _PointwiseCM.apply(w, *xs)
 
 
 MAX_OUT_CHANNELS = 4096   # csrc/abi.hip lin_shape_ok: wider layers take the stock Conv1d path, as documented

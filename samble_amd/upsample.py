@@ -7,14 +7,38 @@ this package's way: one cross-set K-nearest-neighbour search on the HIP kNN kern
 xyz, reference-normalised distances), then an inverse-distance blend of the projected coarse features."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from . import ops
 
 
+# how the layers' two 1x1 convolutions run on the GPU (plain fp32 GEMMs, 128 outputs: library work).  "bmm" (default) =
+# rocBLAS through torch.bmm, weight gradient = batched GEMM + sum over the clouds; "conv" = the stock Conv1d (MIOpen: an
+# implicit-GEMM weight gradient between two batched transposes, +0.18 ms per seg-block step); "lin" = csrc/linear.hip's
+# channel-major entries, the concatenation never formed (deterministic split-operand sums; +0.12 ms over bmm: at 128
+# outputs the weight-gradient kernel fills half the chip).  Same-box A/B in DESIGN 7.
+POINTWISE = os.environ.get("SAMBLE_INTERP_CONV", "bmm")
+
+
+class _PointwiseConv(nn.Conv1d):
+    """nn.Conv1d(kernel 1, no bias): same parameter, same state_dict entry; forward(*xs) takes the channel-wise pieces
+    of the input (128 channels each) so that their concatenation is not built on the linear.hip path."""
+
+    def forward(self, *xs):
+        from . import linear
+        if POINTWISE == "lin" and xs[0].is_cuda and linear.pointwise_cm_supported(self.weight, *xs):
+            return linear.pointwise_cm(self.weight, *xs)
+        x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+        if POINTWISE == "bmm" and x.is_cuda and x.dim() == 3:
+            return torch.bmm(self.weight[:, :, 0].unsqueeze(0).expand(x.shape[0], -1, -1), x)
+        return super().forward(x)
+
+
 def _unit_block(c_in: int, c_out: int) -> nn.Sequential:
-    return nn.Sequential(nn.Conv1d(c_in, c_out, 1, bias=False), nn.BatchNorm1d(c_out), nn.LeakyReLU(negative_slope=0.2))
+    return nn.Sequential(_PointwiseConv(c_in, c_out, 1, bias=False), nn.BatchNorm1d(c_out), nn.LeakyReLU(negative_slope=0.2))
 
 
 def inverse_distance_blend(values: torch.Tensor, dist: torch.Tensor) -> torch.Tensor:
@@ -92,7 +116,8 @@ class UpSampleInterpolation(nn.Module):
     def forward(self, pcd_up, pcd_down, pcd_up_xyz):
         (coarse, _, coarse_xyz), _ = pcd_down
         filled = self.interpolate(pcd_up, coarse, pcd_up_xyz, coarse_xyz, self.distance_type, self.K)
-        return self.res_conv(torch.cat((pcd_up, filled), dim=1))
+        conv, norm, act = self.res_conv
+        return act(norm(conv(pcd_up, filled)))
 
     def interpolate(self, pcd_up, points_select, pcd_up_xyz, points_select_xyz, distance_type="feature", K=3):
         """Features of the coarse set spread onto the fine set (same signature as the reference's method)."""

@@ -187,3 +187,37 @@ def test_linear_rows_with_fewer_input_channels(B, C, N, O):
     assert y.shape == (B, N, O) and _rel(y.detach(), yr.detach()) <= 2e-6
     assert x.grad.shape == (B, C, N) and _rel(x.grad, xd.grad) <= 3e-6
     assert W.grad.shape == (O, C) and _rel(W.grad, Wd.grad) <= 3e-6
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 300, 1), (3, 77, 2), (32, 2048, 2), (4, 1024, 1), (1, 513, 2)])
+def test_channel_major_pointwise_conv_against_float64(B, N, k):
+    """The interpolation layers' two 1x1 convolutions (reference models/upsample.py:142-150: `conv` on the coarse set,
+    `res_conv(torch.cat((pcd_up, interpolated), dim=1))`), channel-major in and out, the concatenation never formed."""
+    from samble_amd import linear as L
+    xs = [torch.from_numpy(synth.features(B, 128, N, 300 + N + i)).to(DEV).requires_grad_(True) for i in range(k)]
+    w = _w((128, 128 * k, 1), 310 + N, 0.09).to(DEV).requires_grad_(True)
+    assert L.pointwise_cm_supported(w, *xs)
+    y = L.pointwise_cm(w, *xs)
+    cat = torch.cat([x.detach().double() for x in xs], dim=1).requires_grad_(True)
+    wd = w.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.conv1d(cat, wd)
+    assert y.shape == (B, 128, N) and y.is_contiguous() and _rel(y, ref) <= 2e-6
+    g = torch.from_numpy(synth.normal((B, 128, N), 320 + N)).to(DEV)
+    y.backward(g)
+    ref.backward(g.double())
+    for i, x in enumerate(xs):
+        assert _rel(x.grad, cat.grad[:, 128 * i:128 * i + 128]) <= 2e-6
+    assert w.grad.shape == w.shape and _rel(w.grad, wd.grad) <= 3e-6
+    # the stages behind it: the second half accumulates onto the first bit for bit like a separate add; run-to-run identical
+    W = w.detach().reshape(128, -1)
+    rm0, _ = L.weight_images(W[:, :128].contiguous(), want_tr=False)
+    a = L.stage_linear_fwd_cm(xs[0].detach(), rm0, 128)
+    assert torch.equal(a, L.stage_linear_fwd(xs[0].detach(), rm0, 128).transpose(1, 2)), "the point-major kernel's sums, stored the other way"
+    if k == 2:
+        rm1, _ = L.weight_images(W[:, 128:].contiguous(), want_tr=False)
+        b = L.stage_linear_fwd_cm(xs[1].detach(), rm1, 128)
+        assert torch.equal(L.stage_linear_fwd_cm(xs[1].detach(), rm1, 128, out=a.clone(), accumulate=True), b + a)
+        assert torch.equal(L.pointwise_cm(w.detach(), *[x.detach() for x in xs]), b + a)
+    dw = L.stage_linear_dw_cm(g, xs[0].detach())
+    assert torch.equal(dw, L.stage_linear_dw_cm(g, xs[0].detach()))
+    assert torch.equal(dw, L.stage_linear_dw(g.transpose(1, 2).contiguous(), xs[0].detach(), 128)), "the same sums as from point-major g"
