@@ -589,6 +589,14 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
 // contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
 // OT = output tiles per wave: 2 (blocks of 256 outputs) or 1 (blocks of 128: narrow layers)
 constexpr int kLdwPts = 512, kLdwXS = 33;
+// points per workgroup: 512, halved (down to 128) while the launch would leave CUs without a workgroup -- the coarse levels
+// of the blocks (N = 1024, 512) ran 128 / 64 workgroups of the same length as N = 2048's 256.  A function of the shape only:
+// the partial sums' grouping, hence the result's bits, are fixed per shape.
+static int ldw_points(int B, int N, int O, int ob) {
+  int pts = kLdwPts;
+  while (pts > 128 && (long)B * ((N + pts - 1) / pts) * (O / ob) < 256) pts >>= 1;
+  return pts;
+}
 // GCM: g arrives channel-major, (B, O, N) with g_rs = the stride between output channels (the weight gradient of a
 // channel-major -> channel-major convolution): its tile is staged like x's, [output][point] with row stride 33
 template <int OT, bool GCM = false>
@@ -603,7 +611,7 @@ struct Ldw {
 template <int OT, bool GCM = false>
 __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                             const float* __restrict__ x, long x_bs, int Cin, int N, int O,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   float* smem = reinterpret_cast<float*>(smem_c);
   constexpr int GS = Ldw<OT, GCM>::kGS, XS = kLdwXS, BUF = Ldw<OT, GCM>::kBuf, kLdwOB = Ldw<OT, GCM>::kOB, GOFF = Ldw<OT, GCM>::kG;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
   const int wave = tid >> 6, lane = tid & 63, lo = lane & 31, h = lane >> 5;
   const int og = wave >> 1, ch = wave & 1;
   const int b = blockIdx.y, o0 = blockIdx.z * kLdwOB;
-  const int n0 = blockIdx.x * kLdwPts;
+  const int n0 = blockIdx.x * ntiles * kTile;
   f32x16 acc[OT][2];
 #pragma unroll
   for (int a = 0; a < OT; ++a)
@@ -664,7 +672,6 @@ __global__ __launch_bounds__(512, 2) void lin_dw_tri_kernel(const float* __restr
   };
   // g's tile element (point p of the tile, output j of the block)
   auto gat = [&](const float* gt, int p, int j) -> float { return GCM ? gt[j * XS + p] : gt[p * GS + j]; };
-  constexpr int ntiles = kLdwPts / kTile;
   issue(n0);
   commit(smem);
   __syncthreads();
@@ -1101,12 +1108,14 @@ extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, con
 }
 
 extern "C" size_t samble_linear_dw_ws_bytes(int B, int N, int O) {
-  return (size_t)B * ((N + kLdwPts - 1) / kLdwPts) * O * 128 * sizeof(float);
+  const int pts = ldw_points(B, N, O, O % 256 == 0 ? 256 : 128);
+  return (size_t)B * ((N + pts - 1) / pts) * O * 128 * sizeof(float);
 }
 
 extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, const float* x, long x_bs, int B, int Cin, int N,
                                        int O, float* dW, int transposed, void* ws, hipStream_t s, int g_cm) {
-  const int chunks = (N + kLdwPts - 1) / kLdwPts;
+  // (the workspace query assumes blocks of 256 outputs where O allows: at least as many chunks as the g_cm launch makes)
+  const int pts = ldw_points(B, N, O, (O % 256 == 0 && !g_cm) ? 256 : 128), chunks = (N + pts - 1) / pts, nt = pts / kTile;
   Timed timed(kT_lin_dw, s);
   if (g_cm) {   // g (B, O, N): blocks of 128 outputs (two workgroups per CU)
     constexpr int lds = Ldw<1, true>::kLds;
@@ -1114,19 +1123,19 @@ extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, con
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((lin_dw_tri_kernel<1, true>), dim3(chunks, B, O / 128), dim3(512), lds, s, g, g_bs, g_rs, x, x_bs, Cin,
-                       N, O, (float*)ws);
+                       N, O, (float*)ws, nt);
   } else if (O % 256 == 0) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Ldw<2>::kLds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(lin_dw_tri_kernel<2>, dim3(chunks, B, O / 256), dim3(512), Ldw<2>::kLds, s, g, g_bs, g_rs, x, x_bs,
-                       Cin, N, O, (float*)ws);
+                       Cin, N, O, (float*)ws, nt);
   } else {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_dw_tri_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Ldw<1>::kLds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(lin_dw_tri_kernel<1>, dim3(chunks, B, O / 128), dim3(512), Ldw<1>::kLds, s, g, g_bs, g_rs, x, x_bs,
-                       Cin, N, O, (float*)ws);
+                       Cin, N, O, (float*)ws, nt);
   }
   const long n4 = (long)O * 128 / 4;
   hipLaunchKernelGGL(lin_sum_parts_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, (const float*)ws, B * chunks,
