@@ -34,6 +34,10 @@ namespace samble {
 #endif
 constexpr bool kLinDuo = SAMBLE_LIN_DUO != 0;
 
+#ifndef SAMBLE_LIN_FILL
+#define SAMBLE_LIN_FILL 256
+#endif
+constexpr int kLinFillWgs = SAMBLE_LIN_FILL;   // workgroups a launch should reach before it stops slicing its outputs
 constexpr int kLinDepth = 4;
 constexpr int kLinLds = kLinDepth * kTriTile;
 enum { kLinPlain = 0, kLinLeaky = 1, kLinMask = 2, kLinAmax = 3 };
@@ -105,6 +109,9 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
   // points past N-1 are clamped: those lanes recompute and rewrite point N-1's row bit for bit (no predicated store)
   const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
   const bool own = chunk * 256 + wave * 32 + lo < N;   // (CM: clamped lanes do not store -- accum is a read-modify-write)
+  // grid.z slices the output tiles (otiles = tiles per slice): small launches (the blocks' coarse levels) fill the chip
+  const int t0 = blockIdx.z * otiles;
+  Wimg += (long)t0 * kTriTile;
   auto stage = [&](int t) {
     const char* gt = Wimg + (long)min(t, otiles - 1) * kTriTile;
     char* lt = smem_c + (t % D) * kTriTile;
@@ -158,8 +165,10 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) xinv_r[r] = __shfl(x_inv, crow(r, h), 64);
   }
-  float* orow = (EPI == kLinAmax) ? nullptr : CM ? out + (long)b * o_bs + n : out + (long)b * o_bs + (long)n * o_rs + 4 * h;
-  const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h : nullptr;
+  float* orow = (EPI == kLinAmax) ? nullptr
+                : CM              ? out + (long)b * o_bs + n + (long)t0 * 32 * o_rs
+                                  : out + (long)b * o_bs + (long)n * o_rs + 4 * h + t0 * 32;
+  const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h + t0 * 32 : nullptr;
   const long ptile = (long)b * (gridDim.x * 8) + chunk * 8 + wave;   // (b, 32-point tile) of this wave
   const int n_first = chunk * 256 + wave * 32;
   f32x4 rf[4];
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
       res_a = min(a_me, a_ot);
       res_a = res_a == 99 ? 0 : res_a;
       if (h == 0) {  // one coalesced line per array
-        const long at = ptile * O + t * 32 + lo;
+        const long at = ptile * O + (t0 + t) * 32 + lo;
         pmax[at] = res_m;
         parg[at] = min(n_first + res_a, N - 1);
       }
@@ -1039,6 +1048,13 @@ extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void
 }
 extern "C" int samble_linear_is_duo(void) { return kLinDuo ? 1 : 0; }
 
+// output-tile slices of a forward launch: doubled while the launch leaves CUs without a workgroup
+static int lin_fwd_slices(int wgs, int otiles) {
+  int z = 1;
+  while (wgs * z < kLinFillWgs && otiles % (2 * z) == 0) z *= 2;
+  return z;
+}
+
 extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O, int epi,
                                         const float* ref, float* out, long o_bs, long o_rs, hipStream_t s) {
   const void* fns[3] = {reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain>),
@@ -1046,16 +1062,17 @@ extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Ci
                         reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinMask>)};
   hipError_t e = hipFuncSetAttribute(fns[epi], hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
-  const dim3 grid((N + 255) / 256, B);
+  const int Z = lin_fwd_slices((N + 255) / 256 * B, O / 32);
+  const dim3 grid((N + 255) / 256, B, Z);
   Timed timed(kT_lin_fwd, s);
   if (epi == kLinPlain)
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
                        out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
   else if (epi == kLinLeaky)
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
                        out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
   else
-    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32, O,
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
                        out, o_bs, o_rs, ref, nullptr, nullptr, 0);
   return (int)hipGetLastError();
 }
@@ -1067,8 +1084,9 @@ extern "C" int samble_launch_linear_fwd_cm(const float* x, long x_bs, int B, int
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_fwd, s);
-  hipLaunchKernelGGL((lin_fwd_tri_kernel<kLinPlain, true>), dim3((N + 255) / 256, B), dim3(512), kLinLds, s, x, x_bs, Cin, N,
-                     (const char*)w_rm, O / 32, O, out, o_bs, (long)N, nullptr, nullptr, nullptr, accumulate);
+  const int Z = lin_fwd_slices((N + 255) / 256 * B, O / 32);
+  hipLaunchKernelGGL((lin_fwd_tri_kernel<kLinPlain, true>), dim3((N + 255) / 256, B, Z), dim3(512), kLinLds, s, x, x_bs, Cin, N,
+                     (const char*)w_rm, O / 32 / Z, O, out, o_bs, (long)N, nullptr, nullptr, nullptr, accumulate);
   return (int)hipGetLastError();
 }
 
@@ -1086,8 +1104,9 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
   float* pmax = (float*)ws;
   int* parg = (int*)(pmax + (size_t)B * ntiles * O);
   Timed timed(kT_lin_amax, s);
-  hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B), dim3(512), kLinLds, s, x, x_bs, 128, N, (const char*)w_rm,
-                     O / 32, O, nullptr, 0, 0, nullptr, pmax, parg, 0);
+  const int Z = lin_fwd_slices(chunks * B, O / 32);
+  hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B, Z), dim3(512), kLinLds, s, x, x_bs, 128, N, (const char*)w_rm,
+                     O / 32 / Z, O, nullptr, 0, 0, nullptr, pmax, parg, 0);
   hipLaunchKernelGGL(lin_amax_reduce_kernel, dim3((O + 255) / 256, B), dim3(256), 0, s, pmax, parg, ntiles, O, y, arg);
   return (int)hipGetLastError();
 }
