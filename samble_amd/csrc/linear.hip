@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
     bg[ks] = tri_split8(v);
   }
   for (int t = 0; t < otiles; ++t) {
-    load_g(t + 2, gnn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    load_g(t + 2, gnn);  // 4 loads, then the P DMA pieces: the wait below leaves exactly those P in flight
     stage(t + D - 1);
     const char* wt = smem_c + (t % D) * kTriTile;
     auto fetch = [&](int i) {
@@ -449,25 +449,29 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
 // channel tile's MFMAs.  Channel tile outer, k-step inner, so that only two temporaries are alive at a time.
 // res (may be null, may be dx itself): a tensor of dx's layout added on the way out -- the residual of the layer this
 // product closes (forward: y + W2 h), or the gradient that arrives beside it (backward: in place)
-__global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restrict__ g, long g_bs, long g_rs,
-                                                            const char* __restrict__ Wtr, int otiles, int Cin, int N,
-                                                            float* __restrict__ dx, long dx_bs, const float* res) {
+// NW waves per workgroup (32 points each): 8, or 4 / 2 when 8 would leave CUs without a workgroup (the blocks' coarse
+// levels: a wave's work does not shrink with N, the waves per CU do)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void lin_dx_duo_kernel(const float* __restrict__ g, long g_bs, long g_rs,
+                                                               const char* __restrict__ Wtr, int otiles, int Cin, int N,
+                                                               float* __restrict__ dx, long dx_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  constexpr int D = kLinDepth;
+  constexpr int D = kLinDepth, NT = 64 * NW, P = kTriTile / 16 / NT;   // P: 16-byte DMA pieces per thread and tile
+  static_assert(P == 3 || P == 6 || P == 12, "8, 4 or 2 waves");
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  const int n = min(chunk * (32 * NW) + wave * 32 + lo, N - 1);
   // (lanes past N-1 repeat point N-1: harmless for a plain store of the same value, NOT for an in-place accumulation --
   // with `res` only the point's own lane stores)
-  const bool own = chunk * 256 + wave * 32 + lo < N;
+  const bool own = chunk * (32 * NW) + wave * 32 + lo < N;
   const float* grow = g + (long)b * g_bs + (long)n * g_rs + 4 * h;
   auto stage = [&](int t) {
     const char* gt = Wtr + (long)min(t, otiles - 1) * kTriTile;
     char* lt = smem_c + (t % D) * kTriTile;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) lin_glds16(gt + (tid + 512 * k) * 16, lt + (wave * 64 + 512 * k) * 16);
+    for (int k = 0; k < P; ++k) lin_glds16(gt + (tid + NT * k) * 16, lt + (wave * 64 + NT * k) * 16);
   };
   auto load_g = [&](int t, f32x4 (&dst)[4]) {  // (assembly loads: lin_dx_tri_kernel explains why)
     const float* p = grow + min(t, otiles - 1) * 32;
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
     }
   }
   for (int t = 0; t < otiles; ++t) {
-    load_g(t + 2, gnn);  // 4 loads, then the 3 DMA pieces: the wait below leaves exactly those 3 in flight
+    load_g(t + 2, gnn);  // 4 loads, then the P DMA pieces: the wait below leaves exactly those P in flight
     stage(t + D - 1);
     const char* wt = smem_c + (t % D) * kTriTile;
     const float sc = *reinterpret_cast<const float*>(wt + kDuoTrScaleSlot) * g_inv;  // 2^-(e_w + e_g), this lane's point
@@ -553,7 +557,12 @@ __global__ __launch_bounds__(512, 2) void lin_dx_duo_kernel(const float* __restr
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tot[3][r] = fmaf(tmp[3][r], sc, tot[3][r]);
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+    if (P == 3)
+      asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+    else if (P == 6)
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" : "+v"(gnn[0]), "+v"(gnn[1]), "+v"(gnn[2]), "+v"(gnn[3])::"memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) gn[i] = gnn[i];
     bh[0] = nh[0]; bh[1] = nh[1];
@@ -1113,13 +1122,33 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
 
 extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
                                        float* dx, long dx_bs, const float* residual, hipStream_t s) {
-  const void* fn = kLinDuo ? reinterpret_cast<const void*>(lin_dx_duo_kernel) : reinterpret_cast<const void*>(lin_dx_tri_kernel);
+  if (kLinDuo) {
+    int nw = 8;
+    while (nw > 2 && (long)((N + 32 * nw - 1) / (32 * nw)) * B < kLinFillWgs) nw >>= 1;
+    const void* fn = nw == 8   ? reinterpret_cast<const void*>(lin_dx_duo_kernel<8>)
+                     : nw == 4 ? reinterpret_cast<const void*>(lin_dx_duo_kernel<4>)
+                               : reinterpret_cast<const void*>(lin_dx_duo_kernel<2>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+    if (e != hipSuccess) return (int)e;
+    Timed timed(kT_lin_dx, s);
+    const dim3 grid((N + 32 * nw - 1) / (32 * nw), B);
+    if (nw == 8)
+      hipLaunchKernelGGL(lin_dx_duo_kernel<8>, grid, dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr, O / 32, Cin, N, dx,
+                         dx_bs, residual);
+    else if (nw == 4)
+      hipLaunchKernelGGL(lin_dx_duo_kernel<4>, grid, dim3(256), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr, O / 32, Cin, N, dx,
+                         dx_bs, residual);
+    else
+      hipLaunchKernelGGL(lin_dx_duo_kernel<2>, grid, dim3(128), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr, O / 32, Cin, N, dx,
+                         dx_bs, residual);
+    return (int)hipGetLastError();
+  }
+  const void* fn = reinterpret_cast<const void*>(lin_dx_tri_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_lin_dx, s);
-  if (kLinDuo)
-    hipLaunchKernelGGL(lin_dx_duo_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                       O / 32, Cin, N, dx, dx_bs, residual);
+  if (false)
+    ;
   else
     hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
                        O / 32, Cin, N, dx, dx_bs, residual);

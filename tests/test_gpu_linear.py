@@ -19,7 +19,8 @@ def _rel(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max())
 
 
-@pytest.mark.parametrize("B,N,O", [(2, 300, 512), (1, 33, 256), (3, 1024, 512), (2, 77, 1024), (32, 2048, 512)])
+@pytest.mark.parametrize("B,N,O", [(2, 300, 512), (1, 33, 256), (3, 1024, 512), (2, 77, 1024), (32, 2048, 512),
+                                   (32, 1024, 512), (32, 500, 256)])   # (the last two: the launch shapes of the coarse levels)
 def test_linear_stages_against_float64(B, N, O):
     from samble_amd import linear as L
     x = torch.from_numpy(synth.features(B, 128, N, 50 + N)).to(DEV)
