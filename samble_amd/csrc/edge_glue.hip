@@ -45,28 +45,32 @@ __device__ __forceinline__ void chan_partial_store(const double (&acc)[NS][2], d
   }
 }
 
-// sums of the workgroup partials of two statistics for channel c = tid & 63, by a 1024-thread workgroup: 16 groups take
-// the partials p = g, g + 16, ... (loads in flight eight deep), the 16 group sums are added in index order.  Valid in
-// the threads tid < 64 (the callers' channel threads); fixed order: deterministic.
-__device__ __forceinline__ void chan_totals2(const double* __restrict__ part, int nparts, double& t0, double& t1) {
-  __shared__ double red[16][2][kGC];
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+// sums of the workgroup partials of two statistics, for the finalize kernels: 8 workgroups of 256 threads, workgroup w
+// owns the channels 8 w .. 8 w + 7 (a single workgroup pulled the whole 1-2 MB of partials through one CU: 16-31 us per
+// launch, eight launches per block step).  Thread (channel tid & 7, group tid >> 3): the group's partials p = g, g + 32, ...
+// (loads in flight eight deep), then the 32 group sums in index order.  Returns the channel; the totals are valid in the
+// threads tid < 8.  Fixed order: deterministic.
+constexpr int kFinWgs = 8, kFinThreads = 256;
+__device__ __forceinline__ int chan_totals2(const double* __restrict__ part, int nparts, double& t0, double& t1) {
+  __shared__ double red[32][2][8];
+  const int cl = threadIdx.x & 7, g = threadIdx.x >> 3, c = blockIdx.x * 8 + cl;
   double v0 = 0.0, v1 = 0.0;
 #pragma unroll 8
-  for (int p = g; p < nparts; p += 16) {
+  for (int p = g; p < nparts; p += 32) {
     v0 += part[((long)p * 2 + 0) * kGC + c];
     v1 += part[((long)p * 2 + 1) * kGC + c];
   }
-  red[g][0][c] = v0;
-  red[g][1][c] = v1;
+  red[g][0][cl] = v0;
+  red[g][1][cl] = v1;
   __syncthreads();
-  t0 = red[0][0][c];
-  t1 = red[0][1][c];
+  t0 = red[0][0][cl];
+  t1 = red[0][1][cl];
 #pragma unroll
-  for (int k = 1; k < 16; ++k) {
-    t0 += red[k][0][c];
-    t1 += red[k][1][c];
+  for (int k = 1; k < 32; ++k) {
+    t0 += red[k][0][cl];
+    t1 += red[k][1][cl];
   }
+  return c;
 }
 
 // ---- forward 1: S, Q of every point (edge_gather_sums) and the BN1 edge sums  sum u = K a + S,  sum u^2 = K a^2 + 2 a S + Q
@@ -120,14 +124,13 @@ __device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int
 }
 
 // ---- forward 2: BN1 constants from the partials: mu1, sig1; sc1 = gamma1 / sig1, sh1 = beta1 - mu1 sc1
-__global__ __launch_bounds__(1024) void edge_bn1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+__global__ __launch_bounds__(kFinThreads) void edge_bn1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
                                                                float* rmean, float* rvar, float momentum, long long* nbt) {
-  const int c = threadIdx.x;
   double t0, t1;
-  chan_totals2(part, nparts, t0, t1);
-  if (c >= kGC) return;
+  const int c = chan_totals2(part, nparts, t0, t1);
+  if (threadIdx.x >= 8) return;
   const double mu = t0 / E;
   double var = t1 / E - mu * mu;
   var = var < 0.0 ? 0.0 : var;
@@ -161,14 +164,13 @@ __global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict_
 }
 
 // ---- forward 3: BN2 constants from edge_mlp_fwd's per-wave sums of y and y^2: mu2, sig2; sc2 = gamma2 / sig2, sh2 = beta2 - mu2 sc2
-__global__ __launch_bounds__(1024) void edge_bn2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+__global__ __launch_bounds__(kFinThreads) void edge_bn2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
                                                                float* rmean, float* rvar, float momentum, long long* nbt) {
-  const int c = threadIdx.x;
   double t0, t1;
-  chan_totals2(part, nparts, t0, t1);
-  if (c >= kGC) return;
+  const int c = chan_totals2(part, nparts, t0, t1);
+  if (threadIdx.x >= 8) return;
   const double mu = t0 / E;
   double var = t1 / E - mu * mu;
   var = var < 0.0 ? 0.0 : var;
@@ -255,14 +257,13 @@ __global__ __launch_bounds__(256) void edge_bwd_pre_kernel(const float* __restri
 
 // ---- backward 2: BN2's dense correction dy += c0 + c1 y per edge (c1 = -sc2 m2 / sig2, c0 = -sc2 m1 - c1 mu2 with
 // m1 = mean dv, m2 = mean dv yhat over the EDGES), d gamma2 = sum dv yhat, d beta2 = sum dv
-__global__ __launch_bounds__(1024) void edge_bwd2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+__global__ __launch_bounds__(kFinThreads) void edge_bwd2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                 const float* __restrict__ gamma, float* __restrict__ cst,
                                                                 const double* __restrict__ st, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta) {
-  const int c = threadIdx.x;
   double sdv, sdvy;
-  chan_totals2(part, nparts, sdv, sdvy);
-  if (c >= kGC) return;
+  const int c = chan_totals2(part, nparts, sdv, sdvy);
+  if (threadIdx.x >= 8) return;
   const double m1 = sdv / E, m2 = sdvy / E;
   const double sig = st[kStSig2 + c], mu = st[kStMu2 + c], sc = (double)gamma[c] / sig;
   const double c1 = -sc * m2 / sig;
@@ -294,13 +295,12 @@ __global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __rest
 }
 
 // ---- backward 4: m1' = mean du, m2' = mean du zhat over the edges; d gamma1 = sum du zhat, d beta1 = sum du
-__global__ __launch_bounds__(1024) void edge_bwd1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
+__global__ __launch_bounds__(kFinThreads) void edge_bwd1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                 float* __restrict__ cst, const double* __restrict__ st,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = threadIdx.x;
   double sdu, raw;
-  chan_totals2(part, nparts, sdu, raw);
-  if (c >= kGC) return;
+  const int c = chan_totals2(part, nparts, sdu, raw);
+  if (threadIdx.x >= 8) return;
   const double sduz = (raw - st[kStMu1 + c] * sdu) / st[kStSig1 + c];
   cst[kCstM1p + c] = (float)(sdu / E);
   cst[kCstM2p + c] = (float)(sduz / E);
@@ -380,7 +380,7 @@ extern "C" int samble_launch_edge_pre(const float* a, const float* b, long rs, c
   const long np = (long)B * N;
   Timed timed(kT_edge_sums, s);
   hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, nn, N, np, S, Q, part);
-  hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
+  hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
                      cst, st, rmean, rvar, momentum, nbt);
   hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, rs, cst, np * 16, ap, bp);
   return (int)hipGetLastError();
@@ -394,7 +394,7 @@ extern "C" int samble_launch_edge_post(const float* ymax, const float* ymin, con
                                        float momentum, long long* nbt, float* cst, double* st, float* ext, unsigned char* kext,
                                        float* out, hipStream_t s) {
   const long np = (long)B * N;
-  hipLaunchKernelGGL(edge_bn2_finalize_kernel, dim3(1), dim3(1024), 0, s, mlp_part, nwaves, (double)np * kGK, gamma2, beta2,
+  hipLaunchKernelGGL(edge_bn2_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, mlp_part, nwaves, (double)np * kGK, gamma2, beta2,
                      eps, cst, st, rmean, rvar, momentum, nbt);
   hipLaunchKernelGGL(edge_out_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, ymax, ymin, kmax, kmin, gamma2, cst, N, ext,
                      kext, out);
@@ -409,7 +409,7 @@ extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int 
   const int tpc = (N + 63) / 64, ntiles = tpc * B;
   const int grid = ntiles < kGParts ? ntiles : kGParts;
   hipLaunchKernelGGL(edge_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, g, ext, cst, st, N, tpc, ntiles, dv, part);
-  hipLaunchKernelGGL(edge_bwd2_finalize_kernel, dim3(1), dim3(1024), 0, s, part, grid, (double)np * kGK, gamma2, cst, st,
+  hipLaunchKernelGGL(edge_bwd2_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, grid, (double)np * kGK, gamma2, cst, st,
                      dgamma2, dbeta2);
   return (int)hipGetLastError();
 }
@@ -421,7 +421,7 @@ extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, long 
                                            long drs, float* dgamma1, float* dbeta1, float* dW2, double* part, hipStream_t s) {
   const long np = (long)B * N;
   hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, dusum, D, np, part);
-  hipLaunchKernelGGL(edge_bwd1_finalize_kernel, dim3(1), dim3(1024), 0, s, part, kGParts, (double)np * kGK, cst, st, dgamma1,
+  hipLaunchKernelGGL(edge_bwd1_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, kGParts, (double)np * kGK, cst, st, dgamma1,
                      dbeta1);
   hipLaunchKernelGGL(edge_bwd_final_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, a, b, S, R, dusum, D,
                      indeg, cst, st, np, rs, da, db, drs);
