@@ -151,12 +151,39 @@ class _N2PLayer(torch.autograd.Function):
                 dg1, db1, dg2, db2, None, None, None, None, None)
 
 
+class deferred_batch_counts:
+    """Inside this context the fused layers' `num_batches_tracked += 1` (one single-thread launch per BatchNorm and
+    call: ten per step of the segmentation block) are collected and applied as ONE multi-tensor add on the way out.  The
+    blocks wrap their forward in it; a layer called on its own counts at once, as before."""
+    pending = None
+
+    def __enter__(self):
+        self.outer = deferred_batch_counts.pending
+        deferred_batch_counts.pending = {}
+        return self
+
+    def __exit__(self, *exc):
+        mine, deferred_batch_counts.pending = deferred_batch_counts.pending, self.outer
+        once = [t for t, k in mine.values() if k == 1]
+        if once:
+            torch._foreach_add_(once, 1)
+        for t, k in mine.values():
+            if k > 1:       # (the same module called twice inside one forward)
+                t.add_(k)
+        return False
+
+
 def _bn_train(bn: nn.BatchNorm1d, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
     """nn.BatchNorm1d.forward in training mode on (B,C,N): the aten entry the module dispatches to on this build (MIOpen),
     with the module's own bookkeeping (momentum, running statistics, num_batches_tracked)."""
     factor = 0.0
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        pending = deferred_batch_counts.pending
+        if pending is not None and bn.momentum is not None:      # (the count is only bookkeeping then)
+            t, k = pending.get(id(bn.num_batches_tracked), (bn.num_batches_tracked, 0))
+            pending[id(bn.num_batches_tracked)] = (t, k + 1)
+        else:
+            bn.num_batches_tracked.add_(1)
         factor = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
     elif bn.momentum is not None:
         factor = bn.momentum

@@ -118,8 +118,10 @@ class FeatureLearningBlock(_Encoder):
         """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors.  forced_idx_list: parity-test hook,
         per sampler the indices to gather instead of its own selection (the samplers' `forced_idx`): everything
         behind a sampler is then compared on the reference's own point set, whatever a near-tie did to the selection."""
-        levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None,
-                              forced_idx_list)
+        from .attention import deferred_batch_counts
+        with deferred_batch_counts():
+            levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None,
+                                  forced_idx_list)
         if not self.res_link_enable:
             return _pooled_head(self.conv, levels[-1].feat)
         pooled = [_pooled_head(head, level.feat) for head, level in zip(self.conv_list, levels)]
@@ -143,6 +145,11 @@ class SegFeatureLearningBlock(_Encoder):
         self.upsample_list = nn.ModuleList(UpSampleInterpolation(cfg.upsample, i) for i in range(len(cfg.upsample.q_in)))
 
     def forward(self, x, noise_list=None, forced_idx_list=None):
+        from .attention import deferred_batch_counts
+        with deferred_batch_counts():
+            return self._forward(x, noise_list, forced_idx_list)
+
+    def _forward(self, x, noise_list, forced_idx_list):
         levels = self._encode(x, noise_list, forced_idx_list=forced_idx_list)
         first_decoder_layer = 1 + (len(self.feature_learning_layer_list) - 1) // 2
         coarse = levels[-1]

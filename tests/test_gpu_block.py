@@ -52,6 +52,13 @@ def _compare_gradients(blk, d, rel_max, label, norm="max", prefix="grad/"):
     assert not bad, bad
 
 
+def _every_batchnorm_counted(blk, calls, at_least):
+    """Every BatchNorm of the block counted each training call (the fused attention layers' counters are applied as one
+    multi-tensor add when the block's forward returns, EdgeConv's inside its statistics kernels)."""
+    counts = {k: int(v) for k, v in blk.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert len(counts) >= at_least and set(counts.values()) == {calls}, counts
+
+
 def test_cls_block_protocol_against_reference():
     """Own selection: the sampled sets against the reference's (a near-tie may flip single indices: reported).
     Then UNCONDITIONALLY, through the reference's indices (`forced_idx_list`): the block's output and the gradients
@@ -92,6 +99,7 @@ def test_cls_block_metric_size_forward_backward():
     assert blk.downsample_list[0].idx.shape == (32, 1, 1024) and blk.downsample_list[1].idx.shape == (32, 1, 512)
     feat.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+    _every_batchnorm_counted(blk, 1, at_least=8)
 
 
 def test_seg_block_protocol_against_reference():
@@ -147,3 +155,7 @@ def test_seg_block_metric_size_forward_backward():
     assert feat.shape == (32, 128, 2048) and torch.isfinite(feat).all()
     feat.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in blk.parameters())
+    _every_batchnorm_counted(blk, 1, at_least=14)
+    with torch.no_grad():
+        blk(xyz)
+    _every_batchnorm_counted(blk, 2, at_least=14)
