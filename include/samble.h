@@ -252,6 +252,11 @@ int samble_n2p_attn_bwd_f32(const float* qkv, int64_t bs, int64_t rs, const int3
  * sources' per-point rows over a point's reverse neighbours). */
 int samble_segment_sum_rows_f32(const float* src, int64_t src_row_stride, const int32_t* inv_order, const int32_t* inv_offsets,
                                 int K, int C, int per_edge, int64_t n_targets, float* out, void* stream);
+/* both forms in one pass over the lists (EdgeConv's backward needs D = the per-edge sum and R = the per-point sum over the
+ * same reverse neighbours): out_edge / out_point are bit for bit what two calls of the entry above give */
+int samble_segment_sum_rows_pair_f32(const float* src_edge, int64_t edge_row_stride, const float* src_point,
+                                     int64_t point_row_stride, const int32_t* inv_order, const int32_t* inv_offsets, int K, int C,
+                                     int64_t n_targets, float* out_edge, float* out_point, void* stream);
 /* The lists themselves, on the device and without a sort (a query lists a target at most once -- the rows of nn hold
  * distinct indices, as samble_knn_f32 writes them -- so "ascending edge id" inside a group is "ascending query": a
  * bit matrix targets x queries, prefix popcounts, one placement pass).  nn (B,N,KN) with entries in [0, N);

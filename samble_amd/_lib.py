@@ -134,6 +134,8 @@ _SIGNATURES = {
     "samble_n2p_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_segment_sum_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "samble_segment_sum_rows_pair_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                                 c_void_p, c_void_p, c_void_p]),
     "samble_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "samble_attn_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -56,6 +56,8 @@ size_t samble_n2p_bwd_ws_floats(int B, int N, int KN);
 int samble_launch_n2p_bwd(const float*, long, long, const int*, const float*, int, int, int, int, float, float*, long,
                           long, float*, int, const int*, const int*, hipStream_t);
 int samble_launch_seg_sum_rows64(const float*, long, const int*, const int*, int, int, long, float*, hipStream_t);
+int samble_launch_seg_sum_rows64_pair(const float*, long, const float*, long, const int*, const int*, int, long, float*, float*,
+                                      hipStream_t);
 size_t samble_inverse_neighbors_ws_bytes(int B, int N);
 int samble_launch_inverse_neighbors(const int*, int, int, int, int*, int*, int*, void*, hipStream_t);
 int samble_launch_n2p_fwd(const float*, long, long, const int*, int, int, int, int, float, float*, int, float*,
@@ -426,6 +428,20 @@ SAMBLE_API int samble_segment_sum_rows_f32(const float* src, int64_t src_row_str
   return done(samble_launch_seg_sum_rows64(src, (long)src_row_stride, inv_order, inv_offsets, K, per_edge, (long)n_targets, out,
                                            (hipStream_t)stream),
               "samble_segment_sum_rows_f32");
+}
+
+SAMBLE_API int samble_segment_sum_rows_pair_f32(const float* src_edge, int64_t edge_row_stride, const float* src_point,
+                                                int64_t point_row_stride, const int32_t* inv_order, const int32_t* inv_offsets,
+                                                int K, int C, int64_t n_targets, float* out_edge, float* out_point, void* stream) {
+  if (!src_edge || !src_point || !inv_order || !inv_offsets || !out_edge || !out_point)
+    return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_pair_f32: null pointer");
+  if (C != 64 || K <= 0 || n_targets <= 0) return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_pair_f32: built for 64 channels");
+  if (edge_row_stride < C || (edge_row_stride & 1) || ((uintptr_t)src_edge & 7) || point_row_stride < C || (point_row_stride & 1) ||
+      ((uintptr_t)src_point & 7))
+    return fail(SAMBLE_E_INVALID, "samble_segment_sum_rows_pair_f32: src rows must be 8-byte aligned, row stride >= C");
+  return done(samble_launch_seg_sum_rows64_pair(src_edge, (long)edge_row_stride, src_point, (long)point_row_stride, inv_order,
+                                                inv_offsets, K, (long)n_targets, out_edge, out_point, (hipStream_t)stream),
+              "samble_segment_sum_rows_pair_f32");
 }
 
 SAMBLE_API int samble_group_gather_f32(const float* x, const int32_t* nn, int B, int C, int N, int K, int mode, float* out,

@@ -304,8 +304,7 @@ class _EdgeMLPFused(torch.autograd.Function):
                       dusum.data_ptr(), dwp.data_ptr(), ops._stream())
             # reverse-neighbour sums in a fixed order (inverse lists), not index_add_'s atomics
             order, offsets, counts = ops.inverse_neighbors(nn_idx)
-            D = ops.stage_segment_sum_rows(du.view(-1, C), order, offsets, K, per_edge=True)
-            R = ops.stage_segment_sum_rows(ab.view(-1, C2)[:, :C], order, offsets, K, per_edge=False)
+            D, R = ops.stage_segment_sum_rows_pair(du.view(-1, C), ab.view(-1, C2)[:, :C], order, offsets, K)   # one pass
             dab = f32(B, N, C2)
             dg1, db1, dw2 = f32(C), f32(C), f32(C, C)
             _lib.call("samble_edge_bwd_post_f32", a.data_ptr(), b.data_ptr(), C2, S.data_ptr(), R.data_ptr(), dusum.data_ptr(),

@@ -220,6 +220,24 @@ def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torc
     return out
 
 
+def stage_segment_sum_rows_pair(src_edge: torch.Tensor, src_point: torch.Tensor, order: torch.Tensor, offsets: torch.Tensor,
+                                K: int):
+    """(sum over the incoming edges e of src_edge[e], of src_point[e // K]) per target, in ONE pass over the lists: the two
+    reverse-neighbour sums of EdgeConv's backward, bit for bit `stage_segment_sum_rows` twice."""
+    _need_gpu(src_edge, src_point, order, offsets)
+    ok = lambda t: (t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) % 2 == 0
+                    and t.data_ptr() % 8 == 0)
+    src_edge = src_edge if ok(src_edge) else _f32c(src_edge)
+    src_point = src_point if ok(src_point) else _f32c(src_point)
+    T = offsets.numel() - 1
+    with torch.cuda.device(src_edge.device):
+        out_e = torch.empty((T, 64), dtype=torch.float32, device=src_edge.device)
+        out_p = torch.empty((T, 64), dtype=torch.float32, device=src_edge.device)
+        _lib.call("samble_segment_sum_rows_pair_f32", src_edge.data_ptr(), src_edge.stride(0), src_point.data_ptr(),
+                  src_point.stride(0), order.data_ptr(), offsets.data_ptr(), K, 64, T, out_e.data_ptr(), out_p.data_ptr(), _stream())
+    return out_e, out_p
+
+
 def stage_n2p_attn_bwd(qkv: torch.Tensor, nn_idx: torch.Tensor, g: torch.Tensor, heads: int, diff: bool,
                        use_inverse_lists: bool = True) -> torch.Tensor:
     """g (B,C,N) -> dqkv (B,N,3C) of the gather-attention (deterministic)."""

@@ -780,6 +780,15 @@ def test_segment_sums_read_rows_where_they_are():
         got = ops.stage_segment_sum_rows(half, order, offsets, K, per_edge=False)
         want = ops.stage_segment_sum_rows(half.contiguous(), order, offsets, K, per_edge=False)
         assert torch.equal(got, want)
+    # both sums of EdgeConv's backward in one pass over the lists: bit for bit the two single sums
+    per_edge_rows = torch.randn(B * N * K, 64, generator=gen).to("cuda:0")
+    D, R = ops.stage_segment_sum_rows_pair(per_edge_rows, wide[:, :64], order, offsets, K)
+    assert torch.equal(D, ops.stage_segment_sum_rows(per_edge_rows, order, offsets, K, per_edge=True))
+    assert torch.equal(R, ops.stage_segment_sum_rows(wide[:, :64], order, offsets, K, per_edge=False))
+    ref = torch.zeros(B * N, 64, dtype=torch.float64, device="cuda:0")
+    tgt = (nn_idx.long() + (torch.arange(B, device="cuda:0") * N).view(B, 1, 1)).reshape(-1)
+    ref.index_add_(0, tgt, per_edge_rows.double())
+    assert float((D.double() - ref).abs().max()) <= 1e-4
 
 
 @pytest.mark.gpu
