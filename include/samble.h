@@ -608,6 +608,10 @@ int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image
  * without the transposing copy (models/attention.py:187-192: the second FFN convolution's weight (128, 512, 1) feeds
  * samble_linear_dx_tri_f32 as W^T).  Two-plane build of csrc/linear.hip only (the default). */
 int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, void* rm_image, void* tr_image, void* stream);
+/* ... and both weights of a feed-forward layer (models/attention.py:187-192: Conv1d 128->H, Conv1d H->128) in one launch:
+   W1 (O1, 128) as it is, W2t (128, O2) transposed, each image pointer may be null */
+int samble_linear_weight_images_pair_f32(const float* W1, int O1, void* rm1_image, void* tr1_image, const float* W2t, int O2,
+                                         void* rm2_image, void* tr2_image, void* stream);
 int samble_linear_two_plane_build(void); /* 1 in the default build; 0 in a -DSAMBLE_LIN_DUO=0 (three bf16 planes) A/B build */
 int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int epilogue,
                               const float* ref, float* out, int64_t o_bs, int64_t o_rs, void* stream);

@@ -98,6 +98,8 @@ _SIGNATURES = {
                                          c_void_p, c_size_t, c_void_p]),
     "samble_linear_dw_t_tri_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "samble_linear_weight_images_pair_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                     c_void_p]),
     "samble_linear_fwd_cm_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int64,
                                          c_void_p]),
     "samble_linear_dw_cm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

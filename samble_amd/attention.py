@@ -119,8 +119,7 @@ class _N2PLayer(torch.autograd.Function):
         nn_idx = ops.stage_knn(x, x, K)
         s1 = ops.stage_n2p_attn_fwd(qkv, nn_idx, heads, diff, residual=x)                 # x + attention(x)
         y1, m1, v1 = _bn_train(bn1, s1, g1, b1)
-        w1_rm, w1_tr = linear.weight_images(w1.reshape(H, C))
-        w2t_rm, w2t_tr = linear.weight_images(w2.reshape(C, H), transposed=True)
+        w1_rm, w1_tr, w2t_rm, w2t_tr = linear.ffn_weight_images(w1.reshape(H, C), w2.reshape(C, H))
         hr = linear.stage_linear_fwd(y1, w1_rm, H, linear.LIN_LEAKY)                      # leaky(W1 y1), (B,N,H)
         s2 = linear.stage_linear_dx(hr, w2t_tr, H, residual=y1)                           # y1 + W2 h
         y2, m2, v2 = _bn_train(bn2, s2, g2, b2)

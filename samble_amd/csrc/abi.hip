@@ -120,6 +120,7 @@ size_t samble_interp_bwd_ws_bytes(int, int, int, int);
 size_t samble_linear_image_bytes_impl(int O);
 int samble_launch_linear_images(const float*, int, void*, void*, int, hipStream_t);
 int samble_linear_is_duo(void);
+int samble_launch_linear_images_pair(const float*, int, void*, void*, const float*, int, void*, void*, hipStream_t);
 int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
 size_t samble_linear_amax_ws_bytes(int, int, int);
 int samble_launch_linear_amax(const float*, long, int, int, const void*, int, float*, int*, void*, hipStream_t);
@@ -997,6 +998,17 @@ SAMBLE_API int samble_linear_weight_images_t_f32(const float* Wt, int O, int C, 
   if (C != 128 || !lin_shape_ok(1, 1, O)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: Wt must be (128, O), O a multiple of 32");
   if (!samble_linear_is_duo()) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_t_f32: needs the two-plane build of csrc/linear.hip");
   return done(samble_launch_linear_images(Wt, O, rm_image, tr_image, 1, (hipStream_t)stream), "samble_linear_weight_images_t_f32");
+}
+
+/* the two weights of a feed-forward layer in one launch: W1 (O1, 128) row-major, W2t (128, O2) row-major (images of its
+   transpose), each with its row image and / or transposed image */
+SAMBLE_API int samble_linear_weight_images_pair_f32(const float* W1, int O1, void* rm1, void* tr1, const float* W2t, int O2,
+                                                    void* rm2, void* tr2, void* stream) {
+  if (!W1 || !W2t || (!rm1 && !tr1) || (!rm2 && !tr2)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_pair_f32: null pointer");
+  if (!lin_shape_ok(1, 1, O1) || !lin_shape_ok(1, 1, O2)) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_pair_f32: O1, O2 multiples of 32");
+  if (!samble_linear_is_duo()) return fail(SAMBLE_E_INVALID, "samble_linear_weight_images_pair_f32: needs the two-plane build of csrc/linear.hip");
+  return done(samble_launch_linear_images_pair(W1, O1, rm1, tr1, W2t, O2, rm2, tr2, (hipStream_t)stream),
+              "samble_linear_weight_images_pair_f32");
 }
 
 SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O,

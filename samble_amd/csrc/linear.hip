@@ -991,11 +991,23 @@ __global__ __launch_bounds__(256) void amax_dw_kernel(const float* __restrict__ 
 // duo images of one 32-row tile of W (O x 128 row-major) per workgroup
 // (trans_O > 0: W arrives TRANSPOSED, (128, trans_O) row-major -- the second FFN convolution's weight as the module holds
 // it -- and the images are those of its transpose (trans_O, 128): no transposing copy in front of this launch)
+// (W2 != null: a second matrix in the same launch -- workgroups tiles1 .. take its tiles: the two weights of a feed-forward
+// layer, 2 x 16 workgroups of latency instead of two launches of it)
 __global__ __launch_bounds__(256) void lin_images_duo_kernel(const float* __restrict__ W, char* __restrict__ rm,
-                                                             char* __restrict__ tr, int trans_O) {
+                                                             char* __restrict__ tr, int trans_O, int tiles1,
+                                                             const float* __restrict__ W2, char* __restrict__ rm2,
+                                                             char* __restrict__ tr2, int trans_O2) {
   __shared__ float wt[32][129];
   __shared__ float red[4];
-  const int tile = blockIdx.x, tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tile >= tiles1) {  // (uniform)
+    tile -= tiles1;
+    W = W2;
+    rm = rm2;
+    tr = tr2;
+    trans_O = trans_O2;
+  }
   float mx = 0.f;
   for (int e = tid; e < 32 * 128; e += 256) {
     const float v = trans_O ? W[(long)(e & 127) * trans_O + tile * 32 + (e >> 7)] : W[((long)tile * 32 + (e >> 7)) * 128 + (e & 127)];
@@ -1052,7 +1064,16 @@ extern "C" size_t samble_linear_image_bytes_impl(int O) { return (size_t)((O + 3
 // tile x 2^e in the slots of the first two pieces, 2^-e in the tile's spare slot (kDuoScaleSlot / kDuoTrScaleSlot)
 extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, int transposed, hipStream_t s) {
   if (!kLinDuo) return transposed ? (int)hipErrorNotSupported : samble_launch_tri_split(W, 0, 128, 1, O, rm, tr, s);
-  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O / 32), dim3(256), 0, s, W, (char*)rm, (char*)tr, transposed ? O : 0);
+  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O / 32), dim3(256), 0, s, W, (char*)rm, (char*)tr, transposed ? O : 0, O / 32,
+                     nullptr, nullptr, nullptr, 0);
+  return (int)hipGetLastError();
+}
+// two matrices in one launch (two-plane build only): W1 (O1, 128) as it is, W2t (128, O2) transposed
+extern "C" int samble_launch_linear_images_pair(const float* W1, int O1, void* rm1, void* tr1, const float* W2t, int O2,
+                                                void* rm2, void* tr2, hipStream_t s) {
+  if (!kLinDuo) return (int)hipErrorNotSupported;
+  hipLaunchKernelGGL(lin_images_duo_kernel, dim3(O1 / 32 + O2 / 32), dim3(256), 0, s, W1, (char*)rm1, (char*)tr1, 0, O1 / 32, W2t,
+                     (char*)rm2, (char*)tr2, O2);
   return (int)hipGetLastError();
 }
 extern "C" int samble_linear_is_duo(void) { return kLinDuo ? 1 : 0; }

@@ -43,6 +43,23 @@ def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True, t
     return rm, tr
 
 
+def ffn_weight_images(W1: torch.Tensor, W2: torch.Tensor):
+    """The four images a feed-forward layer needs, in one launch: W1 (H, 128) -> (row, transposed); W2 (128, H) -> the (row,
+    transposed) images of W2^T, read from W2 as the module holds it."""
+    if not _lib.query("samble_linear_two_plane_build"):
+        return (*weight_images(W1), *weight_images(W2, transposed=True))
+    _need_gpu(W1, W2)
+    W1, W2 = _f32c(W1), _f32c(W2)
+    H = W1.shape[0]
+    assert W1.shape == (H, 128) and W2.shape == (128, H)
+    with torch.cuda.device(W1.device):
+        nbytes = _lib.query("samble_linear_image_bytes", H)
+        imgs = [torch.empty(nbytes, dtype=torch.uint8, device=W1.device) for _ in range(4)]
+        _lib.call("samble_linear_weight_images_pair_f32", W1.data_ptr(), H, imgs[0].data_ptr(), imgs[1].data_ptr(), W2.data_ptr(),
+                  H, imgs[2].data_ptr(), imgs[3].data_ptr(), _stream())
+    return tuple(imgs)
+
+
 def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int = LIN_PLAIN, ref=None) -> torch.Tensor:
     """x (B,128,N) -> (B,N,O) point-major rows: epilogue(W x)."""
     _need_gpu(x, w_rm, ref)
@@ -162,8 +179,7 @@ class _FFN(torch.autograd.Function):
     def forward(ctx, x, w1, w2):
         H = w1.shape[0]
         W1 = w1.reshape(H, 128)
-        w1_rm, w1_tr = weight_images(W1)
-        w2t_rm, w2t_tr = weight_images(w2.reshape(128, H), transposed=True)   # images of W2^T (H, 128), read from W2 as it is
+        w1_rm, w1_tr, w2t_rm, w2t_tr = ffn_weight_images(W1, w2.reshape(128, H))   # (W2^T's images, read from W2 as it is)
         hr = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY)                 # leaky(W1 x), (B,N,H)
         y = stage_linear_dx(hr, w2t_tr, H)                            # y[c][n] = sum_j W2[c][j] hr[n][j]
         ctx.save_for_backward(x, hr, w1_tr, w2t_rm)

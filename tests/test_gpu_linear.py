@@ -148,6 +148,11 @@ def test_transposed_weight_entries_equal_the_transposing_copies():
     g = torch.from_numpy(synth.normal((B, N, H), 92)).to(DEV)
     x = torch.from_numpy(synth.features(B, 128, N, 93)).to(DEV)
     assert torch.equal(L.stage_linear_dw(g, x, H, transposed=True), L.stage_linear_dw(g, x, H).t().contiguous())
+    # both weights of a feed-forward layer in one launch: the four images of the two single calls
+    W1 = _w((H, 128), 94, 0.09).to(DEV)
+    r1, t1 = L.weight_images(W1)
+    for got, want in zip(L.ffn_weight_images(W1, W2), (r1, t1, rm_t, tr_t)):
+        assert torch.equal(got, want)
 
 
 def test_linear_max_propagates_nan_like_torch():
