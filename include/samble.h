@@ -637,6 +637,15 @@ int samble_linear_fwd_cm_f32(const float* x, int64_t x_bs, int B, int C, int N, 
                              float* out, int64_t o_bs, void* stream);
 int samble_linear_dw_cm_f32(const float* g, int64_t g_bs, const float* x, int64_t x_bs, int B, int C, int N, int O, float* dW,
                             void* ws, size_t ws_bytes, void* stream);
+/* nn.BatchNorm1d.forward in training mode on x (B, C, N) channel-major (the attention layers' bn1 / bn2,
+   models/attention.py:187-192): out = (x - mean) / sqrt(var + eps) * gamma + beta with the batch statistics over (B, N);
+   save_mean / save_invstd (C) are what aten's miopen_batch_norm_backward takes; running_mean / running_var (may be null)
+   get torch's momentum update (unbiased variance).  Statistics in float64, summed in a fixed order.
+   workspace: samble_bn_train_workspace_bytes(B, C). */
+size_t samble_bn_train_workspace_bytes(int B, int C);
+int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd, void* ws,
+                            size_t ws_bytes, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
@@ -681,6 +690,7 @@ int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const
 #define SAMBLE_T_LIN_DW 34       /* lin_dw_tri + its partial sum */
 #define SAMBLE_T_LIN_AMAX 35     /* lin_fwd_tri<amax> + reduce: 1x1 convolution and max over the points */
 #define SAMBLE_T_LIN_AMAX_BWD 36 /* amax_bwd + the sum over the clouds */
+#define SAMBLE_T_BN_FWD 37       /* bn_stats + bn_apply: BatchNorm1d training forward */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

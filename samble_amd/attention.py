@@ -186,7 +186,46 @@ def _bn_train(bn: nn.BatchNorm1d, s: torch.Tensor, gamma: torch.Tensor, beta: to
         factor = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
     elif bn.momentum is not None:
         factor = bn.momentum
+    if OWN_BATCHNORM and s.dtype == torch.float32 and s.dim() == 3 and all(
+            t is None or (t.dtype == torch.float32 and t.is_contiguous()) for t in (gamma, beta, bn.running_mean, bn.running_var)):
+        return ops.stage_bn_train(s, gamma, beta, bn.running_mean, bn.running_var, factor, bn.eps)
     return torch.miopen_batch_norm(s, gamma, beta, bn.running_mean, bn.running_var, True, factor, bn.eps)
+
+
+# csrc/batchnorm.hip for the training forward of bn1 / bn2 (the backward stays aten's); "0": MIOpen's forward (A/B runs)
+OWN_BATCHNORM = os.environ.get("SAMBLE_OWN_BATCHNORM", "1") != "0"
+
+
+class _BNTrain(torch.autograd.Function):
+    """nn.BatchNorm1d in training mode as the fused layer runs it (`_bn_train` forward, aten's MIOpen backward): what the
+    node-by-node form of the layer calls, so that both forms stay bit-identical."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, s, gamma, beta, bn):
+        s = s.contiguous()
+        y, m, v = _bn_train(bn, s, gamma, beta)
+        ctx.save_for_backward(s, gamma, m, v)
+        ctx.bn = bn
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, dy):
+        s, gamma, m, v = ctx.saved_tensors
+        bn = ctx.bn
+        ds, dg, db = torch.ops.aten.miopen_batch_norm_backward(s, dy.float().contiguous(), gamma, bn.running_mean, bn.running_var,
+                                                               m, v, float(bn.eps))
+        return ds, dg, db, None
+
+
+def batch_norm(bn: nn.BatchNorm1d, s: torch.Tensor) -> torch.Tensor:
+    """`bn(s)` -- through `_BNTrain` where the fused layer would take the same route, the module itself otherwise."""
+    plain = type(bn) is nn.BatchNorm1d and bn.affine and (bn.momentum is not None or not bn.track_running_stats)
+    if (OWN_BATCHNORM and bn.training and plain and s.is_cuda and s.dtype == torch.float32 and s.dim() == 3
+            and torch.backends.cudnn.enabled):
+        return _BNTrain.apply(s, bn.weight, bn.bias, bn)
+    return bn(s)
 
 
 def _layer_fusable(mod, x) -> bool:
@@ -282,9 +321,9 @@ class Neighbor2PointAttention(nn.Module):
                                    for s in range(0, x.shape[0], step)])
             if center:
                 x_tmp = x_tmp + torch.nn.functional.conv1d(x, wv[:, :C, :, 0])
-        x = self.bn1(x + x_tmp)
+        x = batch_norm(self.bn1, x + x_tmp)
         x_tmp = _feed_forward(self.ff, x)
-        x = self.bn2(x + x_tmp)
+        x = batch_norm(self.bn2, x + x_tmp)
         return x
 
     def _vector_sub(self, x):
@@ -426,9 +465,9 @@ class Point2PointAttention(nn.Module):
                 x_tmp = _P2PCore.apply(qkv)
             else:
                 x_tmp = _P2PHeads.apply(qkv, self.num_heads, self.asm)
-        x = self.bn1(x + x_tmp)
+        x = batch_norm(self.bn1, x + x_tmp)
         x_tmp = _feed_forward(self.ff, x)
-        x = self.bn2(x + x_tmp)
+        x = batch_norm(self.bn2, x + x_tmp)
         return x
 
 

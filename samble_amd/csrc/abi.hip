@@ -979,6 +979,26 @@ SAMBLE_API int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, 
               "samble_interp_blend_bwd_f32");
 }
 
+/* ---- BatchNorm1d training forward (csrc/batchnorm.hip) ------------------------------------------------------------- */
+extern "C" {
+size_t samble_bn_train_ws_bytes(int, int);
+int samble_launch_bn_train_fwd(const float*, int, int, int, const float*, const float*, float, float, float*, float*, float*,
+                               float*, float*, void*, hipStream_t);
+}
+SAMBLE_API size_t samble_bn_train_workspace_bytes(int B, int C) { return (B > 0 && C > 0) ? samble_bn_train_ws_bytes(B, C) : 0; }
+
+SAMBLE_API int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
+                                       float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out || !save_mean || !save_invstd || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: null pointer");
+  if (B <= 0 || B > 65535 || C <= 0 || N <= 0 || (long)B * N < 2)
+    return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: needs more than one value per channel, B <= 65535");
+  if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_fwd_f32: workspace too small");
+  return done(samble_launch_bn_train_fwd(x, B, C, N, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean,
+                                         save_invstd, ws, (hipStream_t)stream),
+              "samble_bn_train_fwd_f32");
+}
+
 /* ---- 1x1 convolutions over 128 input channels (csrc/linear.hip) ------------------------------------------------- */
 static int lin_shape_ok(int B, int N, int O) { return B > 0 && N > 0 && O >= 32 && O <= 4096 && (O & 31) == 0; }
 

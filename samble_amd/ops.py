@@ -220,6 +220,24 @@ def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torc
     return out
 
 
+def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float):
+    """nn.BatchNorm1d.forward in training mode on x (B,C,N): -> (y, batch mean (C), 1 / sqrt(batch var + eps) (C)); the
+    running estimates (may be None) get torch's momentum update in place.  csrc/batchnorm.hip."""
+    _need_gpu(x, gamma, beta, running_mean, running_var)
+    x = _f32c(x)
+    B, C, N = x.shape
+    with torch.cuda.device(x.device):
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.query("samble_bn_train_workspace_bytes", B, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        _lib.call("samble_bn_train_fwd_f32", x.data_ptr(), B, C, N, _p(gamma), _p(beta), float(eps), float(momentum),
+                  _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
+                  _stream())
+    return y, mean, invstd
+
+
 def stage_segment_sum_rows_pair(src_edge: torch.Tensor, src_point: torch.Tensor, order: torch.Tensor, offsets: torch.Tensor,
                                 K: int):
     """(sum over the incoming edges e of src_edge[e], of src_point[e // K]) per target, in ONE pass over the lists: the two

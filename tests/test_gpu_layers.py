@@ -834,3 +834,46 @@ def test_n2p_layer_as_one_node_equals_the_node_by_node_composition(B, N, group_t
         assert torch.equal(gr1[n], gr2[n]), n
     for n in bf2:
         assert torch.equal(bf1[n], bf2[n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N", [(32, 128, 2048), (3, 128, 77), (1, 64, 513), (5, 128, 1024), (2, 7, 30)])
+def test_batchnorm_training_forward_against_float64(B, C, N):
+    """csrc/batchnorm.hip (round 5): nn.BatchNorm1d.forward in training mode (reference models/attention.py:187-192, bn1 /
+    bn2) -- output, saved statistics and the running estimates against torch's BatchNorm1d in float64; the gradient through
+    `attention.batch_norm` (own forward, aten's MIOpen backward) against autograd through the float64 module."""
+    from samble_amd import attention as A, ops
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    x = (torch.randn(B, C, N, generator=gen) * 1.7 + 0.3).to("cuda:0")
+    bn = torch.nn.BatchNorm1d(C).to("cuda:0").train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=gen))
+        bn.running_mean.copy_(torch.randn(C, generator=gen))
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    ref = torch.nn.BatchNorm1d(C).to("cuda:0").double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    want = ref(xd)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    y, mean, invstd = ops.stage_bn_train(x, bn.weight.detach(), bn.bias.detach(), rm, rv, bn.momentum, bn.eps)
+    assert float((y.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    assert torch.allclose(mean.double(), xd.detach().mean((0, 2)), rtol=0, atol=1e-6)
+    assert torch.allclose(invstd.double(), (xd.detach().var((0, 2), unbiased=False) + bn.eps).rsqrt(), rtol=2e-6, atol=0)
+    assert torch.allclose(rm.double(), ref.running_mean, rtol=0, atol=1e-6) and torch.allclose(rv.double(), ref.running_var, rtol=2e-6, atol=1e-7)
+    assert torch.equal(ops.stage_bn_train(x, bn.weight.detach(), bn.bias.detach(), None, None, 0.1, bn.eps)[0], y), "run-to-run identical"
+    # the module-level route: same forward, gradients against float64 autograd
+    xg = x.clone().requires_grad_(True)
+    out = A.batch_norm(bn, xg)
+    assert torch.equal(out, y) and int(bn.num_batches_tracked) == 1
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=0, atol=1e-6)
+    g = torch.randn(B, C, N, generator=gen).to("cuda:0")
+    out.backward(g)
+    want.backward(g.double())
+    scale = float(xd.grad.abs().max())
+    assert float((xg.grad.double() - xd.grad).abs().max()) <= 2e-5 * scale
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=1e-4, atol=1e-4 * float(ref.weight.grad.abs().max()))
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=1e-4, atol=1e-4 * float(ref.bias.grad.abs().max()))
+    # eval mode: the module itself
+    bn.eval()
+    assert torch.equal(A.batch_norm(bn, x), bn(x))
