@@ -29,10 +29,7 @@ namespace samble {
 //   lin_dw       the same per 32-point tile: g and x blocks under wave-uniform scales, fp32 totals.
 // 22 significant bits per operand, products of the planes exact in fp32: measured against float64 like the three-plane
 // kernels (tests/test_gpu_linear.py, same tolerances).  -DSAMBLE_LIN_DUO=0 builds the three-bf16-plane kernels (A/B).
-#ifndef SAMBLE_LIN_DUO
-#define SAMBLE_LIN_DUO 1
-#endif
-constexpr bool kLinDuo = SAMBLE_LIN_DUO != 0;
+// (SAMBLE_LIN_DUO / kLinDuo: tri_dev.h)
 
 #ifndef SAMBLE_LIN_FILL
 #define SAMBLE_LIN_FILL 256
@@ -1141,8 +1138,15 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
   return (int)hipGetLastError();
 }
 
+extern "C" int samble_launch_linear_dx_as(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
+                                          float* dx, long dx_bs, const float* residual, hipStream_t s, int timing_id);
 extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
                                        float* dx, long dx_bs, const float* residual, hipStream_t s) {
+  return samble_launch_linear_dx_as(g, g_bs, g_rs, w_tr, O, B, Cin, N, dx, dx_bs, residual, s, kT_lin_dx);
+}
+// (timing_id: the projection's input gradient runs on this kernel too, under its own measurement id)
+extern "C" int samble_launch_linear_dx_as(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
+                                          float* dx, long dx_bs, const float* residual, hipStream_t s, int timing_id) {
   if (kLinDuo) {
     int nw = 8;
     while (nw > 2 && (long)((N + 32 * nw - 1) / (32 * nw)) * B < kLinFillWgs) nw >>= 1;
@@ -1151,7 +1155,7 @@ extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, con
                                : reinterpret_cast<const void*>(lin_dx_duo_kernel<2>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
     if (e != hipSuccess) return (int)e;
-    Timed timed(kT_lin_dx, s);
+    Timed timed(timing_id, s);
     const dim3 grid((N + 32 * nw - 1) / (32 * nw), B);
     if (nw == 8)
       hipLaunchKernelGGL(lin_dx_duo_kernel<8>, grid, dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr, O / 32, Cin, N, dx,
@@ -1167,7 +1171,7 @@ extern "C" int samble_launch_linear_dx(const float* g, long g_bs, long g_rs, con
   const void* fn = reinterpret_cast<const void*>(lin_dx_tri_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
-  Timed timed(kT_lin_dx, s);
+  Timed timed(timing_id, s);
   if (false)
     ;
   else

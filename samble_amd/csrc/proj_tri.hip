@@ -46,7 +46,45 @@ __global__ __launch_bounds__(256) void proj_prologue_kernel(const ProjW W, const
                                                             float* __restrict__ tokqkv) {
   const int tid = threadIdx.x;
   if (blockIdx.x < kPTiles) {
-    if (wtr) {  // the transposed image as well (the backward's proj_dx_tri reads it: no split launch there)
+    if (wtr && kLinDuo) {
+      // the transposed image as well, for the backward's input gradient (no image launch there) -- in the form
+      // lin_dx_duo_kernel reads: two fp16 planes under the tile's power-of-two scale, 2^-e in the spare slot; byte for byte
+      // what lin_images_duo_kernel (linear.hip) writes for this tile
+      __shared__ float red[4];
+      char* img = wtr + (long)blockIdx.x * kTriTile;
+      float v[2][8], amax = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k, d = e & 127, cg = e >> 7, s2 = cg >> 1, hh = cg & 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[k][i] = W.row(blockIdx.x * 32 + 16 * s2 + 8 * (i >> 2) + 4 * hh + (i & 3))[d];
+          amax = fmaxf(amax, fabsf(v[k][i]));
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      if ((tid & 63) == 0) red[tid >> 6] = amax;
+      __syncthreads();
+      float sc, inv;
+      duo_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), sc, inv);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k, d = e & 127, cg = e >> 7;
+        u32x4 hp, lp;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          unsigned hw, lw;
+          duo_split2(v[k][2 * w] * sc, v[k][2 * w + 1] * sc, hw, lw);
+          hp[w] = hw;
+          lp[w] = lw;
+        }
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 0)) = hp;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 1)) = lp;
+        *reinterpret_cast<u32x4*>(img + tri_tr_off(d, cg, 2)) = (d == 0 && cg == 0) ? u32x4{__float_as_uint(inv), 0u, 0u, 0u}
+                                                                                    : u32x4{0u, 0u, 0u, 0u};
+      }
+    } else if (wtr) {  // (three-plane build: proj_dx_tri_kernel's image)
       char* img = wtr + (long)blockIdx.x * kTriTile;
       for (int e = tid; e < 512; e += 256) {
         const int d = e & 127, cg = e >> 7, s = cg >> 1, hh = cg & 1;
@@ -620,12 +658,24 @@ extern "C" int samble_launch_proj_fwd_tri(const float* x, long x_bs, int B, int 
   return (int)hipGetLastError();
 }
 
+extern "C" int samble_launch_linear_images(const float* W, int O, void* rm, void* tr, int transposed, hipStream_t s);
+extern "C" int samble_launch_linear_dx_as(const float* g, long g_bs, long g_rs, const void* w_tr, int O, int B, int Cin, int N,
+                                          float* dx, long dx_bs, const float* residual, hipStream_t s, int timing_id);
 extern "C" int samble_launch_proj_dx_tri(const float* dqkv, long g_bs, long g_rs, const float* W, void* wtr, int have_wtr,
                                          int B, int N, float* dx, long dx_bs, const float* residual, hipStream_t s) {
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_dx_tri_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kProjTriLds);
     if (e != hipSuccess) return (int)e;
+  }
+  if (kLinDuo) {
+    // two fp16 planes: csrc/linear.hip's lin_dx kernel with 12 output tiles (3 matrix instructions per product instead of
+    // 6, and its launch geometry for short clouds); the image: the forward's prologue, or linear.hip's image kernel here
+    if (!have_wtr) {
+      const int rc = samble_launch_linear_images(W, kPO, nullptr, wtr, 0, s);
+      if (rc) return rc;
+    }
+    return samble_launch_linear_dx_as(dqkv, g_bs, g_rs, wtr, kPO, B, 128, N, dx, dx_bs, residual, s, kT_proj_dx);
   }
   if (!have_wtr) {  // (the forward's prologue wrote it otherwise)
     const int rc = samble_launch_tri_split(W, 0, 128, 1, kPO, nullptr, wtr, s);

@@ -100,6 +100,13 @@ constexpr int kDuoScaleSlot = ((3 * 0 + 2) * 32 + 0) * 16;  // tri_rm_off(0, 0, 
 // finite value) cannot hold -- how samble_tri_k_logit_form tells a converted tile from a raw one (the conversion is
 // idempotent: a tile that carries the tag is left alone)
 constexpr unsigned kDuoTag = 0xFFC07FC0u;
+// csrc/linear.hip's 1x1-convolution kernels (and, through lin_dx, the projection's input gradient) run on two fp16 planes;
+// -DSAMBLE_LIN_DUO=0 builds the three-bf16-plane kernels instead (A/B runs).  Both files that write those weight images
+// (linear.hip, proj_tri.hip's prologue) follow this switch.
+#ifndef SAMBLE_LIN_DUO
+#define SAMBLE_LIN_DUO 1
+#endif
+constexpr bool kLinDuo = SAMBLE_LIN_DUO != 0;
 // 2^e with amax x 2^e in [2^12, 2^13); the exponent is clamped so that 2^e and 2^-e are normal.  A tile of zeros
 // (amax = 0 or denormal) gets the LARGEST exponent: its 2^-e never is the maximum over a cloud's tiles
 __device__ __forceinline__ void duo_scale_for(float amax, float& s, float& inv) {

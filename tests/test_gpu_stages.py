@@ -1139,7 +1139,13 @@ def test_projection_writes_the_operand_images_itself(B, N, nt):
             assert torch.equal(qkv2, qkv)
             assert len(imgs2) == (6 if want == "fwd+bwd" else 3)
             if want == "fwd+bwd":  # ... + the transposed image of W for the projection's own backward
-                _, w_tr = o_.stage_tri_split(w.unsqueeze(0), want_rm=False, want_tr=True)
+                # (two fp16 planes under per-tile scales, the form csrc/linear.hip's lin_dx reads -- the projection's input
+                # gradient runs on that kernel: round 5; a three-plane build of linear.hip keeps the three-plane image)
+                from samble_amd import _lib as lib_, linear as L_
+                if lib_.query("samble_linear_two_plane_build"):
+                    w_tr = L_.weight_images(w, want_rm=False)[1]
+                else:
+                    _, w_tr = o_.stage_tri_split(w.unsqueeze(0), want_rm=False, want_tr=True)
                 assert torch.equal(imgs2[5], w_tr)
             for j, (a, b2) in enumerate(zip(imgs, imgs2)):
                 assert (_k_image_live_equal(a, b2) if j in (1, 4) else torch.equal(a, b2)), (want, "image", j, int((a != b2).sum()))
