@@ -34,7 +34,9 @@ class _PointwiseConv(nn.Conv1d):
             return linear.pointwise_cm(self.weight, *xs)
         x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
         if POINTWISE == "bmm" and x.is_cuda and x.dim() == 3:
-            return torch.bmm(self.weight[:, :, 0].unsqueeze(0).expand(x.shape[0], -1, -1), x)
+            # (weight.view: its backward is free; weight[:, :, 0]'s was a fill + copy.  W0 x0 + W1 x1 through bmm + baddbmm
+            # instead of the concatenation: measured, no faster)
+            return torch.bmm(self.weight.view(self.weight.shape[0], -1).unsqueeze(0).expand(x.shape[0], -1, -1), x)
         return super().forward(x)
 
 
