@@ -1171,12 +1171,9 @@ extern "C" int samble_launch_linear_dx_as(const float* g, long g_bs, long g_rs, 
   const void* fn = reinterpret_cast<const void*>(lin_dx_tri_kernel);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
-  Timed timed(timing_id, s);
-  if (false)
-    ;
-  else
-    hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
-                       O / 32, Cin, N, dx, dx_bs, residual);
+  Timed timed(timing_id, s);   // (three-plane build)
+  hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
+                     O / 32, Cin, N, dx, dx_bs, residual);
   return (int)hipGetLastError();
 }
 
