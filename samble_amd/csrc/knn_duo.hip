@@ -928,9 +928,13 @@ extern "C" int samble_launch_knn_duo(const void* qimg, int Nq, const void* kimg,
                                      hipStream_t s) {
   const char* q = (const char*)qimg;
   const char* k = (const char*)kimg;
-  // candidates of pass A per half-lane: tiles x fine >= 2 K (what 2 048 keys give K = 32 with one per tile)
+  // candidates of pass A per half-lane: one per tile where that gives >= 2 K of them (2 048 keys at K = 32), four per tile
+  // below.  Round 5, same box, block steps: two per tile at 1 024 keys (the round-3 rule: tiles x fine >= 2 K) left the cut
+  // loose enough that the exact pass's ring pruned -- with four the kNN family of the seg block went 1.295 -> 1.14 ms, cls
+  // 0.92 -> 0.90; the other direction (ONE per tile at 1 024 keys) costs +0.2 ms, and two per tile at 2 048 keys gains
+  // nothing (162.8 -> 166 us in the metric step): the rule is a step, not tiles x fine = const.
   const int tiles = (Nk + 31) / 32;
-  const int fine = tiles >= 2 * K ? 1 : 2 * tiles >= 2 * K ? 2 : 4;
+  const int fine = tiles >= 2 * K ? 1 : 4;
   if (C == 128 && K == 32) return fine == 1 ? launch_knn_duo<32, 128, 1>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
          : fine == 2 ? launch_knn_duo<32, 128, 2>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s)
                      : launch_knn_duo<32, 128, 4>(q, Nq, k, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
