@@ -589,7 +589,12 @@ int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stri
  *   tr_image  contraction over the O outputs      (samble_linear_dx_tri_f32)
  *   samble_linear_fwd_tri_f32       out[b][n][o] = epilogue(sum_c W[o][c] x[b][c][n]); epilogue SAMBLE_LIN_PLAIN,
  *                                   SAMBLE_LIN_LEAKY (LeakyReLU 0.2), SAMBLE_LIN_LEAKY_MASK (times 1 where ref > 0, else
- *                                   0.2; ref: a (B, N, O) tensor laid out like out -- the backward of the activation)
+ *                                   0.2; ref: a (B, N, O) tensor laid out like out -- the backward of the activation);
+ *                                   SAMBLE_LIN_LEAKY_BITS / SAMBLE_LIN_LEAKY_MASK_BITS: the same pair with the activation's
+ *                                   sign as ONE BIT per value -- `ref` then points to samble_linear_sign_bytes(B, N, O)
+ *                                   bytes of sign words, WRITTEN by LEAKY_BITS (beside out) and read by LEAKY_MASK_BITS
+ *                                   in place of the activation itself (4 MB instead of 134 MB at B = 32, N = 2048, O = 512);
+ *                                   results bit for bit those of LEAKY / LEAKY_MASK
  *   samble_linear_amax_fwd_tri_f32  y[b][o] = max_n sum_c W[o][c] x[b][c][n], arg[b][o] = the first point that reaches
  *                                   it; the (B, O, N) tensor is never written
  *   samble_linear_dx_tri_f32        dx[b][c][n] = sum_o W[o][c] g[b][n][o]
@@ -602,6 +607,9 @@ int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stri
 #define SAMBLE_LIN_PLAIN 0
 #define SAMBLE_LIN_LEAKY 1
 #define SAMBLE_LIN_LEAKY_MASK 2
+#define SAMBLE_LIN_LEAKY_BITS 4
+#define SAMBLE_LIN_LEAKY_MASK_BITS 5
+size_t samble_linear_sign_bytes(int B, int N, int O);
 size_t samble_linear_image_bytes(int O);
 int samble_linear_weight_images_f32(const float* W, int O, int C, void* rm_image, void* tr_image, void* stream);
 /* ... of the TRANSPOSE of Wt (128, O) row-major: the images samble_linear_weight_images_f32 would write for Wt^T (O, 128),

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "samble_linear_two_plane_build": (c_int, []),
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                           c_int64, c_int64, c_void_p]),
+    "samble_linear_sign_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_amax_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_amax_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),

@@ -1036,11 +1036,19 @@ SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, in
                                          void* stream) {
   if (!x || !w_rm_image || !out) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: null pointer");
   if (C < 1 || C > 128 || !lin_shape_ok(B, N, O)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: 1 <= C <= 128, O a multiple of 32");
-  if (epilogue < SAMBLE_LIN_PLAIN || epilogue > SAMBLE_LIN_LEAKY_MASK || (epilogue == SAMBLE_LIN_LEAKY_MASK && !ref))
-    return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: unknown epilogue, or the mask epilogue without ref");
+  const bool bits = epilogue == SAMBLE_LIN_LEAKY_BITS || epilogue == SAMBLE_LIN_LEAKY_MASK_BITS;
+  if (!bits && (epilogue < SAMBLE_LIN_PLAIN || epilogue > SAMBLE_LIN_LEAKY_MASK))
+    return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: unknown epilogue");
+  if ((bits || epilogue == SAMBLE_LIN_LEAKY_MASK) && !ref)
+    return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: the mask / sign-bit epilogues need ref");
+  if (bits && ((uintptr_t)ref & 1)) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: sign words must be 2-byte aligned");
   if ((o_rs & 3) || (o_bs & 3) || o_rs < O) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: output strides must be multiples of 4");
   return done(samble_launch_linear_fwd(x, x_bs, B, C, N, w_rm_image, O, epilogue, ref, out, o_bs, o_rs, (hipStream_t)stream),
               "samble_linear_fwd_tri_f32");
+}
+
+SAMBLE_API size_t samble_linear_sign_bytes(int B, int N, int O) {
+  return lin_shape_ok(B, N, O) ? (size_t)B * (O / 32) * 2 * (size_t)N * sizeof(uint16_t) : 0;
 }
 
 SAMBLE_API size_t samble_linear_amax_workspace_bytes(int B, int N, int O) {

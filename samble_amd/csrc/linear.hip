@@ -37,7 +37,7 @@ namespace samble {
 constexpr int kLinFillWgs = SAMBLE_LIN_FILL;   // workgroups a launch should reach before it stops slicing its outputs
 constexpr int kLinDepth = 4;
 constexpr int kLinLds = kLinDepth * kTriTile;
-enum { kLinPlain = 0, kLinLeaky = 1, kLinMask = 2, kLinAmax = 3 };
+enum { kLinPlain = 0, kLinLeaky = 1, kLinMask = 2, kLinAmax = 3, kLinLeakyBits = 4, kLinMaskBits = 5 };
 constexpr float kLeakySlope = 0.2f;
 
 __device__ __forceinline__ void lin_glds16(const void* g, void* l) {
@@ -87,6 +87,11 @@ __device__ __forceinline__ void duo_split8(const float (&v)[8], float s, u32x4& 
 //      kLinMask:  out = (W x) * (ref > 0 ? 1 : 0.2)   (ref: same layout as out -- the activation the forward kept)
 //      kLinAmax:  no out: per 32-point tile the maximum of every output row over the tile's points and the first point
 //                 that reaches it -> pmax / parg [(b, tile, o)]
+//      kLinLeakyBits / kLinMaskBits: the leaky / mask pair with the activation's SIGN carried as one bit per value instead of
+//                 re-reading the activation (the backward's mask pass moved 134 MB of `ref` at N = 2048, O = 512 to learn
+//                 4 MB of signs): `bits` = uint16 words [(b, output tile, lane half h)][point], bit 4 g + e <-> output
+//                 8 g + 4 h + e of the tile (the accumulator's register order), written by LeakyBits (out > 0), read by
+//                 MaskBits -- the same products, the same selects: bit for bit the kLinLeaky / kLinMask results
 //
 // CM (plain epilogue only): the output leaves CHANNEL-major, out[b][o][n] (o_rs = the stride between output channels) --
 // the accumulator's columns are the points, so a register's 32 lanes write one 128-byte line; accum: out += W x (the second
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
                                                              const char* __restrict__ Wimg, int otiles, int O,
                                                              float* __restrict__ out, long o_bs, long o_rs,
                                                              const float* __restrict__ ref, float* __restrict__ pmax,
-                                                             int* __restrict__ parg, int accum) {
+                                                             int* __restrict__ parg, int accum,
+                                                             unsigned short* __restrict__ bits) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
   const int tid = threadIdx.x;
@@ -166,6 +172,10 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
                 : CM              ? out + (long)b * o_bs + n + (long)t0 * 32 * o_rs
                                   : out + (long)b * o_bs + (long)n * o_rs + 4 * h + t0 * 32;
   const float* rrow = (EPI == kLinMask) ? ref + (long)b * o_bs + (long)n * o_rs + 4 * h + t0 * 32 : nullptr;
+  // sign words of this lane: [(b, tile, h)][point]
+  unsigned short* brow = (EPI == kLinLeakyBits || EPI == kLinMaskBits) ? bits + (((long)b * (O / 32) + t0) * 2 + h) * N + n : nullptr;
+  unsigned bf = 0, bnx = 0;
+  if (EPI == kLinMaskBits) bf = brow[0];
   const long ptile = (long)b * (gridDim.x * 8) + chunk * 8 + wave;   // (b, 32-point tile) of this wave
   const int n_first = chunk * 256 + wave * 32;
   f32x4 rf[4];
@@ -188,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 #pragma unroll
       for (int g = 0; g < 4; ++g) rn[g] = *reinterpret_cast<const f32x4*>(rp + 8 * g);
     }
+    if (EPI == kLinMaskBits) bnx = brow[(long)min(t + 1, otiles - 1) * 2 * N];
     stage(t + D - 1);
     const u32x4* lp = reinterpret_cast<const u32x4*>(smem_c + (t % D) * kTriTile + tri_rm_off(lo, h, 0));
     f32x16 acc = zero16();  // D[row = output 32 t + crow(r, h)][col = point]
@@ -275,16 +286,28 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (EPI == kLinLeaky) {
+        if (EPI == kLinLeaky || EPI == kLinLeakyBits) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : kLeakySlope * o[e];
+          for (int e = 0; e < 4; ++e) {
+            if (EPI == kLinLeakyBits) bf |= (o[e] > 0.f ? 1u : 0u) << (4 * g + e);
+            o[e] = o[e] > 0.f ? o[e] : kLeakySlope * o[e];
+          }
         }
         if (EPI == kLinMask) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rf[g][e] > 0.f ? o[e] : kLeakySlope * o[e];
         }
+        if (EPI == kLinMaskBits) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = ((bf >> (4 * g + e)) & 1u) ? o[e] : kLeakySlope * o[e];
+        }
         *reinterpret_cast<f32x4*>(orow + t * 32 + 8 * g) = o;
       }
+      if (EPI == kLinLeakyBits) {
+        if (own) brow[(long)t * 2 * N] = (unsigned short)bf;
+        bf = 0;
+      }
+      if (EPI == kLinMaskBits) bf = bnx;
       if (EPI == kLinMask) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) rf[g] = rn[g];
@@ -1084,9 +1107,12 @@ static int lin_fwd_slices(int wgs, int otiles) {
 
 extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Cin, int N, const void* w_rm, int O, int epi,
                                         const float* ref, float* out, long o_bs, long o_rs, hipStream_t s) {
-  const void* fns[3] = {reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain>),
+  const void* fns[6] = {reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinPlain>),
                         reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinLeaky>),
-                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinMask>)};
+                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinMask>),
+                        nullptr,
+                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinLeakyBits>),
+                        reinterpret_cast<const void*>(lin_fwd_tri_kernel<kLinMaskBits>)};
   hipError_t e = hipFuncSetAttribute(fns[epi], hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
   if (e != hipSuccess) return (int)e;
   const int Z = lin_fwd_slices((N + 255) / 256 * B, O / 32);
@@ -1094,13 +1120,21 @@ extern "C" int samble_launch_linear_fwd(const float* x, long x_bs, int B, int Ci
   Timed timed(kT_lin_fwd, s);
   if (epi == kLinPlain)
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinPlain>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
-                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0, nullptr);
   else if (epi == kLinLeaky)
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeaky>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
-                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0);
-  else
+                       out, o_bs, o_rs, nullptr, nullptr, nullptr, 0, nullptr);
+  else if (epi == kLinMask)
     hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMask>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm, O / 32 / Z, O,
-                       out, o_bs, o_rs, ref, nullptr, nullptr, 0);
+                       out, o_bs, o_rs, ref, nullptr, nullptr, 0, nullptr);
+  else if (epi == kLinLeakyBits)   // (`ref` carries the sign words: written here, read by kLinMaskBits)
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinLeakyBits>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm,
+                       O / 32 / Z, O, out, o_bs, o_rs, nullptr, nullptr, nullptr, 0,
+                       reinterpret_cast<unsigned short*>(const_cast<float*>(ref)));
+  else
+    hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinMaskBits>, grid, dim3(512), kLinLds, s, x, x_bs, Cin, N, (const char*)w_rm,
+                       O / 32 / Z, O, out, o_bs, o_rs, nullptr, nullptr, nullptr, 0,
+                       reinterpret_cast<unsigned short*>(const_cast<float*>(ref)));
   return (int)hipGetLastError();
 }
 
@@ -1113,7 +1147,7 @@ extern "C" int samble_launch_linear_fwd_cm(const float* x, long x_bs, int B, int
   Timed timed(kT_lin_fwd, s);
   const int Z = lin_fwd_slices((N + 255) / 256 * B, O / 32);
   hipLaunchKernelGGL((lin_fwd_tri_kernel<kLinPlain, true>), dim3((N + 255) / 256, B, Z), dim3(512), kLinLds, s, x, x_bs, Cin, N,
-                     (const char*)w_rm, O / 32 / Z, O, out, o_bs, (long)N, nullptr, nullptr, nullptr, accumulate);
+                     (const char*)w_rm, O / 32 / Z, O, out, o_bs, (long)N, nullptr, nullptr, nullptr, accumulate, nullptr);
   return (int)hipGetLastError();
 }
 
@@ -1133,7 +1167,7 @@ extern "C" int samble_launch_linear_amax(const float* x, long x_bs, int B, int N
   Timed timed(kT_lin_amax, s);
   const int Z = lin_fwd_slices(chunks * B, O / 32);
   hipLaunchKernelGGL(lin_fwd_tri_kernel<kLinAmax>, dim3(chunks, B, Z), dim3(512), kLinLds, s, x, x_bs, 128, N, (const char*)w_rm,
-                     O / 32 / Z, O, nullptr, 0, 0, nullptr, pmax, parg, 0);
+                     O / 32 / Z, O, nullptr, 0, 0, nullptr, pmax, parg, 0, nullptr);
   hipLaunchKernelGGL(lin_amax_reduce_kernel, dim3((O + 255) / 256, B), dim3(256), 0, s, pmax, parg, ntiles, O, y, arg);
   return (int)hipGetLastError();
 }

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from .ops import _f32c, _need_gpu, _p, _stream
 
-LIN_PLAIN, LIN_LEAKY, LIN_LEAKY_MASK = 0, 1, 2   # include/samble.h SAMBLE_LIN_*
+LIN_PLAIN, LIN_LEAKY, LIN_LEAKY_MASK, LIN_LEAKY_BITS, LIN_LEAKY_MASK_BITS = 0, 1, 2, 4, 5   # include/samble.h SAMBLE_LIN_*
 
 
 def weight_images(W: torch.Tensor, want_rm: bool = True, want_tr: bool = True, transposed: bool = False):
@@ -60,18 +60,27 @@ def ffn_weight_images(W1: torch.Tensor, W2: torch.Tensor):
     return tuple(imgs)
 
 
-def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int = LIN_PLAIN, ref=None) -> torch.Tensor:
-    """x (B,128,N) -> (B,N,O) point-major rows: epilogue(W x)."""
-    _need_gpu(x, w_rm, ref)
+def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int = LIN_PLAIN, ref=None, bits=None):
+    """x (B,128,N) -> (B,N,O) point-major rows: epilogue(W x).  LIN_LEAKY_BITS returns (out, sign words): one bit per value
+    of the activation's sign; LIN_LEAKY_MASK_BITS takes them as `bits` where LIN_LEAKY_MASK takes the activation as `ref`
+    (bit-identical results, 1/32 of the bytes)."""
+    _need_gpu(x, w_rm, ref, bits)
     x = _f32c(x)
     B, C, N = x.shape
     with torch.cuda.device(x.device):
         out = torch.empty((B, N, O), dtype=torch.float32, device=x.device)
         if ref is not None and (ref.shape != out.shape or not ref.is_contiguous() or ref.dtype != torch.float32):
             raise ValueError("ref must be a contiguous fp32 (B, N, O) tensor")
-        _lib.call("samble_linear_fwd_tri_f32", x.data_ptr(), C * N, B, C, N, w_rm.data_ptr(), O, int(epilogue), _p(ref),
+        side = ref
+        if epilogue == LIN_LEAKY_BITS:
+            bits = torch.empty(_lib.query("samble_linear_sign_bytes", B, N, O), dtype=torch.uint8, device=x.device)
+        if epilogue in (LIN_LEAKY_BITS, LIN_LEAKY_MASK_BITS):
+            if bits is None or bits.dtype != torch.uint8 or bits.numel() != _lib.query("samble_linear_sign_bytes", B, N, O):
+                raise ValueError("bits must be the sign words LIN_LEAKY_BITS returned for this shape")
+            side = bits
+        _lib.call("samble_linear_fwd_tri_f32", x.data_ptr(), C * N, B, C, N, w_rm.data_ptr(), O, int(epilogue), _p(side),
                   out.data_ptr(), out.stride(0), out.stride(1), _stream())
-    return out
+    return (out, bits) if epilogue == LIN_LEAKY_BITS else out
 
 
 def stage_linear_amax(x: torch.Tensor, w_rm: torch.Tensor, O: int):
@@ -180,19 +189,19 @@ class _FFN(torch.autograd.Function):
         H = w1.shape[0]
         W1 = w1.reshape(H, 128)
         w1_rm, w1_tr, w2t_rm, w2t_tr = ffn_weight_images(W1, w2.reshape(128, H))   # (W2^T's images, read from W2 as it is)
-        hr = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY)                 # leaky(W1 x), (B,N,H)
+        hr, bits = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY_BITS)      # leaky(W1 x), (B,N,H), and its signs as bits
         y = stage_linear_dx(hr, w2t_tr, H)                            # y[c][n] = sum_j W2[c][j] hr[n][j]
-        ctx.save_for_backward(x, hr, w1_tr, w2t_rm)
+        ctx.save_for_backward(x, hr, w1_tr, w2t_rm, bits)
         ctx.H = H
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        x, hr, w1_tr, w2t_rm = ctx.saved_tensors
+        x, hr, w1_tr, w2t_rm, bits = ctx.saved_tensors
         H = ctx.H
         dy = _f32c(dy)
-        dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK, ref=hr)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
+        dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK_BITS, bits=bits)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
         dx = stage_linear_dx(dh, w1_tr, H) if ctx.needs_input_grad[0] else None
         dw1 = stage_linear_dw(dh, x, H).reshape(H, 128, 1) if ctx.needs_input_grad[1] else None
         dw2 = stage_linear_dw(hr, dy, H, transposed=True).reshape(128, H, 1) if ctx.needs_input_grad[2] else None

@@ -35,6 +35,10 @@ def test_linear_stages_against_float64(B, N, O):
     mk = L.stage_linear_fwd(x, rm, O, L.LIN_LEAKY_MASK, ref=lk)
     assert torch.equal(mk, torch.where(lk > 0, out, 0.2 * out))
     assert torch.equal(L.stage_linear_fwd(x, rm, O), out), "run-to-run identical"
+    # the same pair with the activation's sign as one bit per value (what the layers use: 1/32 of the mask pass's reads)
+    lkb, bits = L.stage_linear_fwd(x, rm, O, L.LIN_LEAKY_BITS)
+    assert torch.equal(lkb, lk) and bits.numel() * 8 == B * N * O
+    assert torch.equal(L.stage_linear_fwd(x, rm, O, L.LIN_LEAKY_MASK_BITS, bits=bits), mk)
     # dx: point-major rows back to the channel-major side
     g = torch.from_numpy(synth.normal((B, N, O), 52 + N)).to(DEV)
     dx = L.stage_linear_dx(g, tr, O)
