@@ -401,7 +401,7 @@ def measure_block(workload, steps, warmup):
         step()
     # which kernel family dominates, from two untimed steps; then that one is timed over the timed region
     fam = ["n2p_bwd", "edge_bwd", "knn", "edge_fwd", "n2p_fwd", "knn_small", "inv_nn", "seg_sum", "bwd_dq", "attn_rows",
-           "attn_stats", "lin_fwd", "lin_dx", "lin_dw", "lin_amax", "lin_amax_bwd", "bn_fwd"]
+           "attn_stats", "lin_fwd", "lin_dx", "lin_dw", "lin_amax", "lin_amax_bwd", "bn_fwd", "lin_chain"]
     _lib.timing_select(fam)
     for _ in range(2):
         step()

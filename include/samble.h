@@ -623,6 +623,15 @@ int samble_linear_weight_images_pair_f32(const float* W1, int O1, void* rm1_imag
 int samble_linear_two_plane_build(void); /* 1 in the default build; 0 in a -DSAMBLE_LIN_DUO=0 (three bf16 planes) A/B build */
 int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, int epilogue,
                               const float* ref, float* out, int64_t o_bs, int64_t o_rs, void* stream);
+/* A feed-forward layer's two convolutions in ONE sweep over the points (models/attention.py:187-192 `ff` and its input
+ * gradient): mid (B, N, H) = epilogue(Wa x) as samble_linear_fwd_tri_f32 writes it (may be NULL: not kept), then
+ * out (B, 128, N) = Wb^T-contraction of mid over H as samble_linear_dx_tri_f32 forms it (+ residual, which may alias out) --
+ * without reading mid back (it is what the first product's accumulators hold).  wa_rm_image: row image of Wa (H, 128);
+ * wb_tr_image: transposed image of Wb (H, 128).  epilogue SAMBLE_LIN_LEAKY_BITS (forward: Wa = W1, Wb = W2^T; writes the
+ * sign words) or SAMBLE_LIN_LEAKY_MASK_BITS (backward: Wa = W2^T, Wb = W1; reads them).  x 128 channels.  Two-plane build. */
+int samble_linear_chain_f32(const float* x, int64_t x_bs, int B, int N, const void* wa_rm_image, const void* wb_tr_image, int H,
+                            int epilogue, float* mid, int64_t mid_bs, int64_t mid_rs, void* sign_words, float* out,
+                            int64_t out_bs, const float* residual, void* stream);
 size_t samble_linear_amax_workspace_bytes(int B, int N, int O);
 int samble_linear_amax_fwd_tri_f32(const float* x, int64_t x_bs, int B, int C, int N, const void* w_rm_image, int O, float* y,
                                    int32_t* arg, void* ws, size_t ws_bytes, void* stream);
@@ -699,6 +708,7 @@ int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const
 #define SAMBLE_T_LIN_AMAX 35     /* lin_fwd_tri<amax> + reduce: 1x1 convolution and max over the points */
 #define SAMBLE_T_LIN_AMAX_BWD 36 /* amax_bwd + the sum over the clouds */
 #define SAMBLE_T_BN_FWD 37       /* bn_stats + bn_apply: BatchNorm1d training forward */
+#define SAMBLE_T_LIN_CHAIN 38    /* lin_chain: a feed-forward layer's two convolutions in one sweep */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

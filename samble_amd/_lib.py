@@ -89,6 +89,8 @@ _SIGNATURES = {
     "samble_linear_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                           c_int64, c_int64, c_void_p]),
     "samble_linear_sign_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "samble_linear_chain_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64,
+                                        c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "samble_linear_amax_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_linear_amax_fwd_tri_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),
@@ -241,7 +243,7 @@ TIMED_KERNELS = {
     "proj_dx": 9, "proj_dw": 10, "tri_split": 11, "knn_prep": 12, "sparse_score": 13, "quantiles": 14, "bin_assign": 15,
     "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22, "nn_prepare": 23,
     "edge_fwd": 24, "edge_bwd": 25, "n2p_fwd": 26, "n2p_bwd": 27, "inv_nn": 28, "seg_sum": 29, "edge_sums": 30,
-    "knn_small": 31, "lin_fwd": 32, "lin_dx": 33, "lin_dw": 34, "lin_amax": 35, "lin_amax_bwd": 36, "bn_fwd": 37,
+    "knn_small": 31, "lin_fwd": 32, "lin_dx": 33, "lin_dw": 34, "lin_amax": 35, "lin_amax_bwd": 36, "bn_fwd": 37, "lin_chain": 38,
 }
 
 

@@ -120,8 +120,11 @@ class _N2PLayer(torch.autograd.Function):
         s1 = ops.stage_n2p_attn_fwd(qkv, nn_idx, heads, diff, residual=x)                 # x + attention(x)
         y1, m1, v1 = _bn_train(bn1, s1, g1, b1)
         w1_rm, w1_tr, w2t_rm, w2t_tr = linear.ffn_weight_images(w1.reshape(H, C), w2.reshape(C, H))
-        hr, hbits = linear.stage_linear_fwd(y1, w1_rm, H, linear.LIN_LEAKY_BITS)          # leaky(W1 y1), (B,N,H) + its sign bits
-        s2 = linear.stage_linear_dx(hr, w2t_tr, H, residual=y1)                           # y1 + W2 h
+        if linear.chain_supported(y1, H):                                                  # both products in one sweep
+            s2, hr, hbits = linear.stage_linear_chain(y1, w1_rm, w2t_tr, H, linear.LIN_LEAKY_BITS, residual=y1)
+        else:
+            hr, hbits = linear.stage_linear_fwd(y1, w1_rm, H, linear.LIN_LEAKY_BITS)      # leaky(W1 y1), (B,N,H) + its sign bits
+            s2 = linear.stage_linear_dx(hr, w2t_tr, H, residual=y1)                       # y1 + W2 h
         y2, m2, v2 = _bn_train(bn2, s2, g2, b2)
         ctx.save_for_backward(x, w, qkv, nn_idx, s1, m1, v1, y1, hr, s2, m2, v2, g1, g2, w1_tr, w2t_rm, hbits)
         ctx.cfg = (heads, diff, wq.shape[0], wk.shape[0], H, float(bn1.eps), float(bn2.eps))
@@ -138,10 +141,14 @@ class _N2PLayer(torch.autograd.Function):
         dy2 = dy2.float().contiguous()
         ds2, dg2, db2 = torch.ops.aten.miopen_batch_norm_backward(s2, dy2, g2, bn2.running_mean, bn2.running_var, m2, v2, eps2)
         ds2 = ds2.contiguous()
-        dh = linear.stage_linear_fwd(ds2, w2t_rm, H, linear.LIN_LEAKY_MASK_BITS, bits=hbits)   # (W2^T ds2) * leaky'(h)
+        if linear.chain_supported(ds2, H):
+            dy1, dh, _ = linear.stage_linear_chain(ds2, w2t_rm, w1_tr, H, linear.LIN_LEAKY_MASK_BITS, bits=hbits, residual=ds2)
+        else:
+            dh = linear.stage_linear_fwd(ds2, w2t_rm, H, linear.LIN_LEAKY_MASK_BITS, bits=hbits)   # (W2^T ds2) * leaky'(h)
         dw2 = linear.stage_linear_dw(hr, ds2, H, transposed=True).reshape(C, H, 1)
         dw1 = linear.stage_linear_dw(dh, y1, H).reshape(H, C, 1)
-        dy1 = linear.stage_linear_dx(dh, w1_tr, H, residual=ds2, out=ds2)                  # ds2 + W1^T dh, in place
+        if not linear.chain_supported(ds2, H):
+            dy1 = linear.stage_linear_dx(dh, w1_tr, H, residual=ds2, out=ds2)              # ds2 + W1^T dh, in place
         ds1, dg1, db1 = torch.ops.aten.miopen_batch_norm_backward(s1, dy1, g1, bn1.running_mean, bn1.running_var, m1, v1, eps1)
         ds1 = ds1.contiguous()
         dqkv = ops.stage_n2p_attn_bwd(qkv, nn_idx, ds1, heads, diff)

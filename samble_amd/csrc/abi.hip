@@ -120,6 +120,8 @@ size_t samble_interp_bwd_ws_bytes(int, int, int, int);
 size_t samble_linear_image_bytes_impl(int O);
 int samble_launch_linear_images(const float*, int, void*, void*, int, hipStream_t);
 int samble_linear_is_duo(void);
+int samble_launch_linear_chain(const float*, long, int, int, const void*, const void*, int, int, float*, long, long, void*, float*,
+                               long, const float*, hipStream_t);
 int samble_launch_linear_images_pair(const float*, int, void*, void*, const float*, int, void*, void*, hipStream_t);
 int samble_launch_linear_fwd(const float*, long, int, int, int, const void*, int, int, const float*, float*, long, long, hipStream_t);
 size_t samble_linear_amax_ws_bytes(int, int, int);
@@ -1045,6 +1047,23 @@ SAMBLE_API int samble_linear_fwd_tri_f32(const float* x, int64_t x_bs, int B, in
   if ((o_rs & 3) || (o_bs & 3) || o_rs < O) return fail(SAMBLE_E_INVALID, "samble_linear_fwd_tri_f32: output strides must be multiples of 4");
   return done(samble_launch_linear_fwd(x, x_bs, B, C, N, w_rm_image, O, epilogue, ref, out, o_bs, o_rs, (hipStream_t)stream),
               "samble_linear_fwd_tri_f32");
+}
+
+/* the feed-forward layer's two convolutions in one sweep (csrc/linear.hip lin_chain): see include/samble.h */
+SAMBLE_API int samble_linear_chain_f32(const float* x, int64_t x_bs, int B, int N, const void* wa_rm_image, const void* wb_tr_image,
+                                       int H, int epilogue, float* mid, int64_t mid_bs, int64_t mid_rs, void* sign_words,
+                                       float* out, int64_t out_bs, const float* residual, void* stream) {
+  if (!x || !wa_rm_image || !wb_tr_image || !sign_words || !out) return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: null pointer");
+  if (!lin_shape_ok(B, N, H)) return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: H a multiple of 32, at most 4096");
+  if (epilogue != SAMBLE_LIN_LEAKY_BITS && epilogue != SAMBLE_LIN_LEAKY_MASK_BITS)
+    return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: epilogue must be SAMBLE_LIN_LEAKY_BITS or SAMBLE_LIN_LEAKY_MASK_BITS");
+  if (mid && ((mid_rs & 3) || (mid_bs & 3) || mid_rs < H || ((uintptr_t)mid & 15)))
+    return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: mid rows must be 16-byte aligned");
+  if ((uintptr_t)sign_words & 1) return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: sign words must be 2-byte aligned");
+  if (!samble_linear_is_duo()) return fail(SAMBLE_E_INVALID, "samble_linear_chain_f32: needs the two-plane build of csrc/linear.hip");
+  return done(samble_launch_linear_chain(x, x_bs, B, N, wa_rm_image, wb_tr_image, H, epilogue, mid, mid_bs, mid_rs, sign_words, out,
+                                         out_bs, residual, (hipStream_t)stream),
+              "samble_linear_chain_f32");
 }
 
 SAMBLE_API size_t samble_linear_sign_bytes(int B, int N, int O) {

@@ -622,6 +622,161 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_dx_duo_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// lin_chain: the two 1x1 convolutions of a feed-forward layer in ONE sweep over the points --
+//     mid[n][o]  = epi(sum_c Wa[o][c] x[c][n])          (lin_fwd; written out for the weight gradients that need it)
+//     out[c][n]  = sum_o Wb[o][c] mid[n][o]  (+ res)     (lin_dx)
+// forward (models/attention.py:187-192 `ff`): Wa = W1, epi = LeakyReLU + sign words, Wb = W2^T;  backward: Wa = W2^T,
+// epi = the sign words' mask, Wb = W1 (the input gradient).  The separate kernels are memory-bound (~4 TB/s), and the
+// second one's only input is what the first just wrote: 134 MB at B = 32, N = 2048, H = 512 that this kernel does not
+// read back.  It can do so because the transposed weight image already IS in the accumulator's order (tri_tr_off's chunk
+// (k-step s, half h) holds the outputs crow(8 s + i, h): lin_dx's B operand was laid out that way on purpose), so product 1's
+// accumulator -- lane (point, h): outputs crow(r, h), r = 0..15 -- is product 2's B operand as it stands: scale (lane
+// pair's largest value), split into two fp16 planes, multiply.  Per hidden tile: 24 + 24 matrix instructions; W tiles of
+// both matrices through one ring of three slot pairs (144 KB); the point's output accumulates in fp32 as in lin_dx_duo.
+// ------------------------------------------------------------------------------------------------
+constexpr int kChainDepth = 3;
+constexpr int kChainLds = kChainDepth * 2 * kTriTile;
+static_assert(kChainLds <= 160 * 1024, "LDS budget");
+
+template <int EPI>  // kLinLeakyBits | kLinMaskBits
+__global__ __launch_bounds__(512, 2) void lin_chain_kernel(const float* __restrict__ x, long x_bs, int N,
+                                                           const char* __restrict__ Wa_rm, const char* __restrict__ Wb_tr,
+                                                           int otiles, float* __restrict__ mid, long m_bs, long m_rs,
+                                                           unsigned short* __restrict__ bits, float* __restrict__ out,
+                                                           long o_bs, const float* res) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int D = kChainDepth;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
+  int chunk, b;
+  xcd_assign(chunk, b);
+  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
+  const bool own = chunk * 256 + wave * 32 + lo < N;
+  auto stage = [&](int t) {
+    const long tt = min(t, otiles - 1);
+    char* slot = smem_c + (t % D) * 2 * kTriTile;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lin_glds16(Wa_rm + tt * kTriTile + (tid + 512 * k) * 16, slot + (wave * 64 + 512 * k) * 16);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      lin_glds16(Wb_tr + tt * kTriTile + (tid + 512 * k) * 16, slot + kTriTile + (wave * 64 + 512 * k) * 16);
+  };
+  stage(0);
+  stage(1);
+  // the point's 128 channels: two fp16 planes under the point's own scale (lin_fwd's B operand)
+  u32x4 xq[16];
+  float x_inv;
+  {
+    float xv[64];
+    float amax = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xv[8 * ks + e] = x[(long)b * x_bs + (long)(16 * ks + 8 * h + e) * N + n];
+        amax = fmaxf(amax, fabsf(xv[8 * ks + e]));
+      }
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    float sx;
+    duo_scale_for(amax, sx, x_inv);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float v[8] = {xv[8 * ks], xv[8 * ks + 1], xv[8 * ks + 2], xv[8 * ks + 3],
+                          xv[8 * ks + 4], xv[8 * ks + 5], xv[8 * ks + 6], xv[8 * ks + 7]};
+      duo_split8(v, sx, xq[2 * ks], xq[2 * ks + 1]);
+    }
+  }
+  float* mrow = mid ? mid + (long)b * m_bs + (long)n * m_rs + 4 * h : nullptr;
+  unsigned short* brow = bits + (((long)b * otiles) * 2 + h) * N + n;   // sign words [(b, tile, h)][point]
+  unsigned bf = 0, bnx = 0;
+  if (EPI == kLinMaskBits) bf = brow[0];
+  f32x16 tot[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) tot[ct] = zero16();
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // iteration t: [mask: tile t+1's sign word], tiles t+2 into the slot pair of tile t-1, product 1, its epilogue and
+  // stores, product 2.  VM operations younger than tile t+1's DMA at the end of iteration t: stores(t-1) 4 + DMA 6 +
+  // stores(t) 4 = 14 (sign-word traffic only adds to that: counting low is the safe side)
+  for (int t = 0; t < otiles; ++t) {
+    if (EPI == kLinMaskBits) bnx = brow[(long)min(t + 1, otiles - 1) * 2 * N];
+    stage(t + 2);
+    const char* slot = smem_c + (t % D) * 2 * kTriTile;
+    const u32x4* lp = reinterpret_cast<const u32x4*>(slot + tri_rm_off(lo, h, 0));
+    f32x16 acc = zero16();  // D[row = hidden unit 32 t + crow(r, h)][col = point]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) acc = mfma_duo(lp[192 * ks], lp[192 * ks + 32], xq[2 * ks], xq[2 * ks + 1], acc);
+    const float sc1 = *reinterpret_cast<const float*>(slot + kDuoScaleSlot) * x_inv;
+    unsigned word = 0;
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r] * sc1;
+      if (EPI == kLinLeakyBits) {
+        word |= (v > 0.f ? 1u : 0u) << r;
+        v = v > 0.f ? v : kLeakySlope * v;
+      } else {
+        v = ((bf >> r) & 1u) ? v : kLeakySlope * v;
+      }
+      acc[r] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+    if (mrow) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(mrow + t * 32 + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    }
+    if (EPI == kLinLeakyBits && own) brow[(long)t * 2 * N] = (unsigned short)word;
+    if (EPI == kLinMaskBits) bf = bnx;
+    // product 2: the accumulator as the B operand (k-step s: registers 8 s .. 8 s + 7), under the lane pair's scale
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    float s2, g_inv;
+    duo_scale_for(amax, s2, g_inv);
+    u32x4 bh[2], bl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float v[8] = {acc[8 * ks], acc[8 * ks + 1], acc[8 * ks + 2], acc[8 * ks + 3],
+                          acc[8 * ks + 4], acc[8 * ks + 5], acc[8 * ks + 6], acc[8 * ks + 7]};
+      duo_split8(v, s2, bh[ks], bl[ks]);
+    }
+    const char* wt = slot + kTriTile;
+    const float sc2 = *reinterpret_cast<const float*>(wt + kDuoTrScaleSlot) * g_inv;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x16 tmp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(wt + tri_tr_off(32 * ct + lo, 2 * ks + h, 0));
+        const u32x4 al = *reinterpret_cast<const u32x4*>(wt + tri_tr_off(32 * ct + lo, 2 * ks + h, 1));
+        tmp = mfma_duo(ah, al, bh[ks], bl[ks], tmp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[ct][r] = fmaf(tmp[r], sc2, tot[ct][r]);
+    }
+    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  float* ob = out + (long)b * o_bs + n;
+  if (res) {  // (may be `out` itself; a channel tile's 16 loads, then its 16 stores: 16 registers, not 64)
+    const float* rb = res + (long)b * o_bs + n;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float rv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = rb[(long)(32 * ct + crow(r, h)) * N];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (own) ob[(long)(32 * ct + crow(r, h)) * N] = rv[r] + tot[ct][r];
+    }
+    return;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (own) ob[(long)(32 * ct + crow(r, h)) * N] = tot[ct][r];
+}
+
 // dW partials: workgroup = (512-point chunk, cloud, block of 128 OT outputs); wave w owns output rows 32 OT (w >> 1) .. of
 // the block and channels 64 (w & 1) .. +63: 2 OT accumulator tiles.  Both operands are transposed through LDS (the
 // contraction runs over the points) and split in registers, as in proj_dw_tri_kernel.
@@ -1208,6 +1363,27 @@ extern "C" int samble_launch_linear_dx_as(const float* g, long g_bs, long g_rs, 
   Timed timed(timing_id, s);   // (three-plane build)
   hipLaunchKernelGGL(lin_dx_tri_kernel, dim3((N + 255) / 256, B), dim3(512), kLinLds, s, g, g_bs, g_rs, (const char*)w_tr,
                      O / 32, Cin, N, dx, dx_bs, residual);
+  return (int)hipGetLastError();
+}
+
+// mid (B, N, H) point-major rows (may be null), bits: samble_linear_sign_bytes(B, N, H) of sign words (written by the leaky
+// form, read by the mask form), out / res (B, 128, N) channel-major
+extern "C" int samble_launch_linear_chain(const float* x, long x_bs, int B, int N, const void* wa_rm, const void* wb_tr, int H,
+                                          int epi, float* mid, long m_bs, long m_rs, void* bits, float* out, long o_bs,
+                                          const float* res, hipStream_t s) {
+  if (!kLinDuo) return (int)hipErrorNotSupported;
+  const void* fn = epi == kLinLeakyBits ? reinterpret_cast<const void*>(lin_chain_kernel<kLinLeakyBits>)
+                                        : reinterpret_cast<const void*>(lin_chain_kernel<kLinMaskBits>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds);
+  if (e != hipSuccess) return (int)e;
+  Timed timed(kT_lin_chain, s);
+  const dim3 grid((N + 255) / 256, B);
+  if (epi == kLinLeakyBits)
+    hipLaunchKernelGGL(lin_chain_kernel<kLinLeakyBits>, grid, dim3(512), kChainLds, s, x, x_bs, N, (const char*)wa_rm,
+                       (const char*)wb_tr, H / 32, mid, m_bs, m_rs, (unsigned short*)bits, out, o_bs, res);
+  else
+    hipLaunchKernelGGL(lin_chain_kernel<kLinMaskBits>, grid, dim3(512), kChainLds, s, x, x_bs, N, (const char*)wa_rm,
+                       (const char*)wb_tr, H / 32, mid, m_bs, m_rs, (unsigned short*)bits, out, o_bs, res);
   return (int)hipGetLastError();
 }
 

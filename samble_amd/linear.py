@@ -83,6 +83,40 @@ def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int 
     return (out, bits) if epilogue == LIN_LEAKY_BITS else out
 
 
+def chain_supported(x: torch.Tensor, H: int) -> bool:
+    """The one-sweep kernel takes 256-point chunks of 8 waves: it pays where that fills the chip (the separate kernels carry
+    the launch geometry for short clouds), and needs the two-plane build."""
+    B, C, N = x.shape
+    return CHAIN and C == 128 and ((N + 255) // 256) * B >= 256 and bool(_lib.query("samble_linear_two_plane_build"))
+
+
+CHAIN = __import__("os").environ.get("SAMBLE_LIN_CHAIN", "1") != "0"   # "0": lin_fwd + lin_dx as two launches (A/B runs)
+
+
+def stage_linear_chain(x: torch.Tensor, wa_rm: torch.Tensor, wb_tr: torch.Tensor, H: int, epilogue: int, bits=None,
+                       residual=None, want_mid: bool = True):
+    """x (B,128,N) -> (out (B,128,N) = Wb-contraction of mid [+ residual], mid (B,N,H) = epilogue(Wa x) | None, sign words):
+    lin_fwd and lin_dx in one sweep (csrc/linear.hip lin_chain); epilogue LIN_LEAKY_BITS writes the sign words,
+    LIN_LEAKY_MASK_BITS reads `bits`."""
+    _need_gpu(x, wa_rm, wb_tr, bits, residual)
+    x = _f32c(x)
+    B, C, N = x.shape
+    assert C == 128
+    with torch.cuda.device(x.device):
+        nb = _lib.query("samble_linear_sign_bytes", B, N, H)
+        if epilogue == LIN_LEAKY_BITS:
+            bits = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        if bits is None or bits.dtype != torch.uint8 or bits.numel() != nb:
+            raise ValueError("bits must be the sign words of this shape")
+        if residual is not None:
+            assert residual.shape == x.shape and residual.is_contiguous() and residual.dtype == torch.float32
+        mid = torch.empty((B, N, H), dtype=torch.float32, device=x.device) if want_mid else None
+        out = torch.empty((B, 128, N), dtype=torch.float32, device=x.device)
+        _lib.call("samble_linear_chain_f32", x.data_ptr(), C * N, B, N, wa_rm.data_ptr(), wb_tr.data_ptr(), H, int(epilogue),
+                  _p(mid), N * H, H, bits.data_ptr(), out.data_ptr(), 128 * N, _p(residual), _stream())
+    return out, mid, bits
+
+
 def stage_linear_amax(x: torch.Tensor, w_rm: torch.Tensor, O: int):
     """x (B,128,N) -> (y (B,O) = max over the points of W x, arg (B,O) int32 = the first point that reaches it)."""
     _need_gpu(x, w_rm)
@@ -189,8 +223,11 @@ class _FFN(torch.autograd.Function):
         H = w1.shape[0]
         W1 = w1.reshape(H, 128)
         w1_rm, w1_tr, w2t_rm, w2t_tr = ffn_weight_images(W1, w2.reshape(128, H))   # (W2^T's images, read from W2 as it is)
-        hr, bits = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY_BITS)      # leaky(W1 x), (B,N,H), and its signs as bits
-        y = stage_linear_dx(hr, w2t_tr, H)                            # y[c][n] = sum_j W2[c][j] hr[n][j]
+        if chain_supported(x, H):                                     # both products in one sweep
+            y, hr, bits = stage_linear_chain(x, w1_rm, w2t_tr, H, LIN_LEAKY_BITS)
+        else:
+            hr, bits = stage_linear_fwd(x, w1_rm, H, LIN_LEAKY_BITS)  # leaky(W1 x), (B,N,H), and its signs as bits
+            y = stage_linear_dx(hr, w2t_tr, H)                        # y[c][n] = sum_j W2[c][j] hr[n][j]
         ctx.save_for_backward(x, hr, w1_tr, w2t_rm, bits)
         ctx.H = H
         return y
@@ -201,8 +238,11 @@ class _FFN(torch.autograd.Function):
         x, hr, w1_tr, w2t_rm, bits = ctx.saved_tensors
         H = ctx.H
         dy = _f32c(dy)
-        dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK_BITS, bits=bits)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
-        dx = stage_linear_dx(dh, w1_tr, H) if ctx.needs_input_grad[0] else None
+        if chain_supported(dy, H) and ctx.needs_input_grad[0]:
+            dx, dh, _ = stage_linear_chain(dy, w2t_rm, w1_tr, H, LIN_LEAKY_MASK_BITS, bits=bits)
+        else:
+            dh = stage_linear_fwd(dy, w2t_rm, H, LIN_LEAKY_MASK_BITS, bits=bits)  # (W2^T dy) * leaky'(h): sign(hr) = sign(h)
+            dx = stage_linear_dx(dh, w1_tr, H) if ctx.needs_input_grad[0] else None
         dw1 = stage_linear_dw(dh, x, H).reshape(H, 128, 1) if ctx.needs_input_grad[1] else None
         dw2 = stage_linear_dw(hr, dy, H, transposed=True).reshape(128, H, 1) if ctx.needs_input_grad[2] else None
         return dx, dw1, dw2

@@ -231,3 +231,34 @@ def test_channel_major_pointwise_conv_against_float64(B, N, k):
     dw = L.stage_linear_dw_cm(g, xs[0].detach())
     assert torch.equal(dw, L.stage_linear_dw_cm(g, xs[0].detach()))
     assert torch.equal(dw, L.stage_linear_dw(g.transpose(1, 2).contiguous(), xs[0].detach(), 128)), "the same sums as from point-major g"
+
+
+@pytest.mark.parametrize("B,N,H", [(32, 2048, 512), (2, 300, 512), (3, 77, 256), (1, 33, 1024), (5, 1024, 512)])
+def test_chain_equals_the_two_kernels(B, N, H):
+    """samble_linear_chain_f32 (round 5): a feed-forward layer's two convolutions in one sweep -- the intermediate, its sign
+    words and the output are BIT FOR BIT those of lin_fwd (leaky / mask from sign words) followed by lin_dx, with and without
+    the residual, forward form and backward form (reference models/attention.py:187-192 `ff` and its input gradient)."""
+    from samble_amd import linear as L
+    x = torch.from_numpy(synth.features(B, 128, N, 700 + N)).to(DEV)
+    W1 = _w((H, 128), 701 + N, 0.09).to(DEV)
+    W2 = _w((128, H), 702 + N, 0.045).to(DEV)
+    w1_rm, w1_tr, w2t_rm, w2t_tr = L.ffn_weight_images(W1, W2)
+    r = torch.from_numpy(synth.normal((B, 128, N), 703 + N)).to(DEV)
+    # forward: y = W2 leaky(W1 x) [+ r]
+    hr, bits = L.stage_linear_fwd(x, w1_rm, H, L.LIN_LEAKY_BITS)
+    for res in (None, r):
+        want = L.stage_linear_dx(hr, w2t_tr, H, residual=res)
+        out, mid, b2 = L.stage_linear_chain(x, w1_rm, w2t_tr, H, L.LIN_LEAKY_BITS, residual=res)
+        assert torch.equal(mid, hr) and torch.equal(b2, bits) and torch.equal(out, want)
+    out, mid, _ = L.stage_linear_chain(x, w1_rm, w2t_tr, H, L.LIN_LEAKY_BITS, want_mid=False)
+    assert mid is None and torch.equal(out, L.stage_linear_dx(hr, w2t_tr, H))
+    ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(x.double(), W1.double().unsqueeze(-1)), 0.2),
+                                     W2.double().unsqueeze(-1))
+    assert _rel(out, ref) <= 3e-6
+    # backward: dx = W1^T (mask (W2^T dy)) [+ r]
+    dy = torch.from_numpy(synth.normal((B, 128, N), 704 + N)).to(DEV)
+    dh = L.stage_linear_fwd(dy, w2t_rm, H, L.LIN_LEAKY_MASK_BITS, bits=bits)
+    for res in (None, r):
+        want = L.stage_linear_dx(dh, w1_tr, H, residual=res)
+        dx, mid, _ = L.stage_linear_chain(dy, w2t_rm, w1_tr, H, L.LIN_LEAKY_MASK_BITS, bits=bits, residual=res)
+        assert torch.equal(mid, dh) and torch.equal(dx, want)
