@@ -324,6 +324,30 @@ def test_upsample_interpolation_against_reference_fixture():
         assert rel <= 5e-2, (key, rel)
 
 
+def test_upsample_convolution_routes_agree(monkeypatch):
+    """The interpolation layer's two 1x1 convolutions run on rocBLAS (`bmm`, the default), on csrc/linear.hip's channel-major
+    entries (`lin`: the concatenation never formed) or on the stock Conv1d (`conv`): the same layer, forward and gradients,
+    to fp32 rounding (reference models/upsample.py:142-150)."""
+    from samble_amd import upsample as U
+    B, C, N, M = 3, 128, 512, 256
+    outs = {}
+    for route in ("bmm", "lin", "conv"):
+        monkeypatch.setattr(U, "POINTWISE", route)
+        torch.manual_seed(11)
+        mod = U.UpSampleInterpolation(U.upsample_config("seg"), 0).to(DEV).train()
+        up_xyz = torch.from_numpy(synth.xyz_clouds(B, N, 31)).to(DEV)
+        sel = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(40 + b))[:M] for b in range(B)]).to(DEV)
+        down_xyz = torch.gather(up_xyz, 2, sel[:, None, :].expand(-1, 3, -1))
+        up = torch.from_numpy(synth.features(B, C, N, 32)).to(DEV).requires_grad_(True)
+        down = torch.from_numpy(synth.features(B, C, M, 33)).to(DEV).requires_grad_(True)
+        y = mod(up, ((down, sel.unsqueeze(1), down_xyz), (None, None)), up_xyz)
+        y.backward(torch.from_numpy(synth.normal((B, C, N), 34)).to(DEV))
+        outs[route] = [y.detach(), up.grad, down.grad, mod.conv[0].weight.grad, mod.res_conv[0].weight.grad, mod.res_conv[1].weight.grad]
+    for route in ("lin", "conv"):
+        for a, b in zip(outs["bmm"], outs[route]):
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), route
+
+
 @pytest.mark.parametrize("name", ["layer_global_colsum", "layer_global_dotsub", "layer_global_l2", "layer_global_l2plus",
                                   "layer_global_sparse_rowstd", "layer_global_sparse_colsqr",
                                   "layer_global_sparse_colsumsqr", "layer_global_sparse_colavg_l2"])
