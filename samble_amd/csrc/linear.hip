@@ -639,28 +639,31 @@ constexpr int kChainDepth = 3;
 constexpr int kChainLds = kChainDepth * 2 * kTriTile;
 static_assert(kChainLds <= 160 * 1024, "LDS budget");
 
-template <int EPI>  // kLinLeakyBits | kLinMaskBits
-__global__ __launch_bounds__(512, 2) void lin_chain_kernel(const float* __restrict__ x, long x_bs, int N,
+// NW waves per workgroup: 8, or 4 / 2 for short clouds (the two waves of a SIMD run their phases one after the other: a
+// wave alone on its SIMD is twice as fast, and at N <= 1024 there are idle CUs to spread them over)
+template <int EPI, int NW>  // kLinLeakyBits | kLinMaskBits
+__global__ __launch_bounds__(64 * NW, 2) void lin_chain_kernel(const float* __restrict__ x, long x_bs, int N,
                                                            const char* __restrict__ Wa_rm, const char* __restrict__ Wb_tr,
                                                            int otiles, float* __restrict__ mid, long m_bs, long m_rs,
                                                            unsigned short* __restrict__ bits, float* __restrict__ out,
                                                            long o_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  constexpr int D = kChainDepth;
+  constexpr int D = kChainDepth, NT = 64 * NW, P = kTriTile / 16 / NT;   // P: 16-byte DMA pieces per thread, tile and matrix
+  static_assert(P == 3 || P == 6 || P == 12, "8, 4 or 2 waves");
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lo = lane & 31, h = lane >> 5;
   int chunk, b;
   xcd_assign(chunk, b);
-  const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
-  const bool own = chunk * 256 + wave * 32 + lo < N;
+  const int n = min(chunk * (32 * NW) + wave * 32 + lo, N - 1);
+  const bool own = chunk * (32 * NW) + wave * 32 + lo < N;
   auto stage = [&](int t) {
     const long tt = min(t, otiles - 1);
     char* slot = smem_c + (t % D) * 2 * kTriTile;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) lin_glds16(Wa_rm + tt * kTriTile + (tid + 512 * k) * 16, slot + (wave * 64 + 512 * k) * 16);
+    for (int k = 0; k < P; ++k) lin_glds16(Wa_rm + tt * kTriTile + (tid + NT * k) * 16, slot + (wave * 64 + NT * k) * 16);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      lin_glds16(Wb_tr + tt * kTriTile + (tid + 512 * k) * 16, slot + kTriTile + (wave * 64 + 512 * k) * 16);
+    for (int k = 0; k < P; ++k)
+      lin_glds16(Wb_tr + tt * kTriTile + (tid + NT * k) * 16, slot + kTriTile + (wave * 64 + NT * k) * 16);
   };
   stage(0);
   stage(1);
@@ -754,7 +757,13 @@ __global__ __launch_bounds__(512, 2) void lin_chain_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[ct][r] = fmaf(tmp[r], sc2, tot[ct][r]);
     }
-    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (4 + 2 P + 4 younger operations: 14 / 20 / 32)
+    if (P == 3)
+      asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (P == 6)
+      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
   float* ob = out + (long)b * o_bs + n;
   if (res) {  // (may be `out` itself; a channel tile's 16 loads, then its 16 stores: 16 registers, not 64)
@@ -1372,18 +1381,28 @@ extern "C" int samble_launch_linear_chain(const float* x, long x_bs, int B, int 
                                           int epi, float* mid, long m_bs, long m_rs, void* bits, float* out, long o_bs,
                                           const float* res, hipStream_t s) {
   if (!kLinDuo) return (int)hipErrorNotSupported;
-  const void* fn = epi == kLinLeakyBits ? reinterpret_cast<const void*>(lin_chain_kernel<kLinLeakyBits>)
-                                        : reinterpret_cast<const void*>(lin_chain_kernel<kLinMaskBits>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds);
-  if (e != hipSuccess) return (int)e;
+  int nw = 8;
+  while (nw > 2 && (long)((N + 32 * nw - 1) / (32 * nw)) * B < kLinFillWgs) nw >>= 1;
+  const dim3 grid((N + 32 * nw - 1) / (32 * nw), B);
   Timed timed(kT_lin_chain, s);
-  const dim3 grid((N + 255) / 256, B);
-  if (epi == kLinLeakyBits)
-    hipLaunchKernelGGL(lin_chain_kernel<kLinLeakyBits>, grid, dim3(512), kChainLds, s, x, x_bs, N, (const char*)wa_rm,
-                       (const char*)wb_tr, H / 32, mid, m_bs, m_rs, (unsigned short*)bits, out, o_bs, res);
-  else
-    hipLaunchKernelGGL(lin_chain_kernel<kLinMaskBits>, grid, dim3(512), kChainLds, s, x, x_bs, N, (const char*)wa_rm,
-                       (const char*)wb_tr, H / 32, mid, m_bs, m_rs, (unsigned short*)bits, out, o_bs, res);
+#define SAMBLE_CHAIN_LAUNCH(E, W)                                                                                              \
+  do {                                                                                                                         \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lin_chain_kernel<E, W>),                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds);                                \
+    if (e != hipSuccess) return (int)e;                                                                                        \
+    hipLaunchKernelGGL((lin_chain_kernel<E, W>), grid, dim3(64 * W), kChainLds, s, x, x_bs, N, (const char*)wa_rm,             \
+                       (const char*)wb_tr, H / 32, mid, m_bs, m_rs, (unsigned short*)bits, out, o_bs, res);                    \
+  } while (0)
+  if (epi == kLinLeakyBits) {
+    if (nw == 8) SAMBLE_CHAIN_LAUNCH(kLinLeakyBits, 8);
+    else if (nw == 4) SAMBLE_CHAIN_LAUNCH(kLinLeakyBits, 4);
+    else SAMBLE_CHAIN_LAUNCH(kLinLeakyBits, 2);
+  } else {
+    if (nw == 8) SAMBLE_CHAIN_LAUNCH(kLinMaskBits, 8);
+    else if (nw == 4) SAMBLE_CHAIN_LAUNCH(kLinMaskBits, 4);
+    else SAMBLE_CHAIN_LAUNCH(kLinMaskBits, 2);
+  }
+#undef SAMBLE_CHAIN_LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -84,10 +84,8 @@ def stage_linear_fwd(x: torch.Tensor, w_rm: torch.Tensor, O: int, epilogue: int 
 
 
 def chain_supported(x: torch.Tensor, H: int) -> bool:
-    """The one-sweep kernel takes 256-point chunks of 8 waves: it pays where that fills the chip (the separate kernels carry
-    the launch geometry for short clouds), and needs the two-plane build."""
-    B, C, N = x.shape
-    return CHAIN and C == 128 and ((N + 255) // 256) * B >= 256 and bool(_lib.query("samble_linear_two_plane_build"))
+    """The one-sweep kernel (8, 4 or 2 waves per workgroup by launch size) needs 128 channels and the two-plane build."""
+    return CHAIN and x.shape[1] == 128 and bool(_lib.query("samble_linear_two_plane_build"))
 
 
 CHAIN = __import__("os").environ.get("SAMBLE_LIN_CHAIN", "1") != "0"   # "0": lin_fwd + lin_dx as two launches (A/B runs)
