@@ -246,8 +246,10 @@ struct DuoLds {  // byte offsets of the workgroup's dynamic LDS
 // groups of 8.  The bound T is the KN-th largest of the candidates, so with Nk / 32 tiles a half-lane needs
 // Nk / 32 * FINE >> KN of them: at Nk = 512 (16 tiles) one per tile leaves T at the SMALLEST tile maximum, ~80
 // survivors per row against a ring of 56, a dozen prunes per wave (364-400 us where 2 048 keys take 163).
-template <int KN, int C, int FINE>
-__global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict__ Qimg, int Nq,
+// NW waves per workgroup (32 queries each): 8, or 4 / 2 for short clouds, where 8 leave CUs without a workgroup -- the two
+// waves of a SIMD run their phases one after the other, so a wave alone on its SIMD is up to twice as fast (round 5)
+template <int KN, int C, int FINE, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void knn_duo_kernel(const char* __restrict__ Qimg, int Nq,
                                                          const char* __restrict__ Kimg, int Nk,
                                                          const float* __restrict__ qnorm,
                                                          const float* __restrict__ knorm,
@@ -255,10 +257,11 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
                                                          float* __restrict__ d2_out) {
   using D = Duo<C>;
   using L = DuoLds<C>;
-  constexpr int NT = 512, NW = 8, NS = D::kSteps;
+  constexpr int NT = 64 * NW, NS = D::kSteps;
   constexpr int KS = (3 * KN + 3) / 4;            // per-tile maxima kept per half-lane in pass A
   constexpr int kPieces = D::kTile / (NT * 16);   // 16-byte LDS-DMA pieces per thread and tile (2 at C = 128)
   constexpr bool kAllSeed = D::kPlane >= NT * 16;  // every thread moves a piece of an h plane (C = 128)
+  constexpr int kPiecesH = kAllSeed ? D::kPlane / (NT * 16) : 1;   // ... or several (fewer than 8 waves)
   static_assert(kPieces * NT * 16 == D::kTile, "tile must be a whole number of pieces per thread");
   static_assert(KN + 16 <= kDuoCap && kDuoCap <= 64, "a prune must leave room for half a tile's candidates; lane = slot");
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -301,14 +304,17 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
     float* red = bns;                                                         // 8 partial maxima
     auto glds_h = [&](int t) {  // plane h of tile t, verbatim
       if (kAllSeed || tid < D::kPlane / 16) {
-        const char* gt = Kb + (long)min(t, ntiles - 1) * D::kTile + tid * 16;
-        char* lt = smem_c + (t & 7) * D::kPlane + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gt,
-                                         (__attribute__((address_space(3))) void*)lt, 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < kPiecesH; ++k) {
+          const char* gt = Kb + (long)min(t, ntiles - 1) * D::kTile + (tid + NT * k) * 16;
+          char* lt = smem_c + (t & 7) * D::kPlane + (wave * 64 + NT * k) * 16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gt,
+                                           (__attribute__((address_space(3))) void*)lt, 16, 0, 0);
+        }
       }
     };
     auto wait3 = [&]() {  // all but this thread's three newest plane DMAs have landed
-      if (kAllSeed || wave < D::kPlane / 1024) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (kAllSeed || wave < D::kPlane / 1024) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kPiecesH) : "memory");
     };
     float bmax = 0.f;
     for (int j = tid; j < ntiles * 32; j += NT) {
@@ -870,19 +876,33 @@ __global__ __launch_bounds__(512, 2) void knn_duo_kernel(const char* __restrict_
   rank_rows(std::true_type{}, 0);
 }
 
-template <int KN, int C, int FINE>
-static int launch_knn_duo(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
-                          const float* knorm, const float* inv_scale, int* idx, float* d2, hipStream_t s) {
-  constexpr int NT = 512;
+template <int KN, int C, int FINE, int NW>
+static int launch_knn_duo_nw(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
+                             const float* knorm, const float* inv_scale, int* idx, float* d2, hipStream_t s) {
+  constexpr int NT = 64 * NW;
   const size_t lds = DuoLds<C>::kTotal;
-  auto kern = knn_duo_kernel<KN, C, FINE>;
+  auto kern = knn_duo_kernel<KN, C, FINE, NW>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds);
   if (e != hipSuccess) return (int)e;
   Timed timed(kT_knn, s);
-  hipLaunchKernelGGL(kern, dim3((Nq + 255) / 256, B), dim3(NT), lds, s, qimg, Nq, kimg, Nk, qnorm, knorm, inv_scale, idx,
-                     d2);
+  hipLaunchKernelGGL(kern, dim3((Nq + 32 * NW - 1) / (32 * NW), B), dim3(NT), lds, s, qimg, Nq, kimg, Nk, qnorm, knorm,
+                     inv_scale, idx, d2);
   return (int)hipGetLastError();
+}
+
+#ifndef SAMBLE_KNN_SHORT_WAVES
+#define SAMBLE_KNN_SHORT_WAVES 1
+#endif
+template <int KN, int C, int FINE>
+static int launch_knn_duo(const char* qimg, int Nq, const char* kimg, int Nk, int B, const float* qnorm,
+                          const float* knorm, const float* inv_scale, int* idx, float* d2, hipStream_t s) {
+  // fewer waves per workgroup while 8 would leave CUs without one (only the seeded forms of short clouds: FINE > 1)
+  if (SAMBLE_KNN_SHORT_WAVES && FINE > 1) {
+    if ((long)((Nq + 127) / 128) * B < 256) return launch_knn_duo_nw<KN, C, FINE, 2>(qimg, Nq, kimg, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+    if ((long)((Nq + 255) / 256) * B < 256) return launch_knn_duo_nw<KN, C, FINE, 4>(qimg, Nq, kimg, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
+  }
+  return launch_knn_duo_nw<KN, C, FINE, 8>(qimg, Nq, kimg, Nk, B, qnorm, knorm, inv_scale, idx, d2, s);
 }
 
 }  // namespace samble
