@@ -31,7 +31,6 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 # -- six with three bf16 planes per operand, three with two fp16 planes -- so the ceiling for ALGORITHMIC (fp32) flops of
 # a kernel is the dense 16-bit peak (bf16 = fp16 = 2500 TFLOP/s) / the 16-bit products it EXECUTES per algorithmic product
 PEAK_BF16_MFMA_TFLOPS = 2500.0
-PEAK_TRI_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
 PEAK_HBM_GBS = 8000.0
 # 16-bit MFMA products executed per ALGORITHMIC fp32 product, per kernel of the default (split-plane, map-free) step
 EXECUTED_PRODUCTS = {
@@ -159,7 +158,7 @@ def launch_ranks(n: int, argv) -> int:
     return rc
 
 
-def measure_collectives(dev, world):
+def measure_collectives(dev, world, c2_floats=None, c2_label="c2_ddp_bucket_399KB_allreduce_us"):
     """After the timed region, every rank: which library carried the collectives, how many ranks it formed, and the
     latency of the two messages on the data path -- C1, the all-reduce of the nb-1 boundary quantiles that sits between
     score_quantiles and bin_plan in every forward (reference utils/ops.py:191-199), and C2, one DDP bucket with the
@@ -175,7 +174,8 @@ def measure_collectives(dev, world):
     except Exception as e:  # noqa: BLE001
         out["rccl_version"] = f"unavailable ({e!r})"
     # (C1 carries nb floats since round 5: the nb-1 quantiles and the validity count bin_plan divides by)
-    for label, n in (("c1_boundary_allreduce_5_floats_us", NB), ("c2_ddp_bucket_399KB_allreduce_us", 3 * C * C + C * NB)):
+    c2_floats = c2_floats or 3 * C * C + C * NB
+    for label, n in (("c1_boundary_allreduce_5_floats_us", NB), (c2_label, c2_floats)):
         buf = torch.zeros(n, device=dev)
         for _ in range(5):
             dist.all_reduce(buf)
@@ -189,9 +189,9 @@ def measure_collectives(dev, world):
             ev[i + 1].record()
         torch.cuda.synchronize()
         out[label] = round(1e3 * statistics.median(ev[i].elapsed_time(ev[i + 1]) for i in range(reps)), 1)
-    worst = torch.tensor([out["c1_boundary_allreduce_5_floats_us"], out["c2_ddp_bucket_399KB_allreduce_us"]], device=dev)
+    worst = torch.tensor([out["c1_boundary_allreduce_5_floats_us"], out[c2_label]], device=dev)
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-    out["c1_boundary_allreduce_5_floats_us"], out["c2_ddp_bucket_399KB_allreduce_us"] = [round(float(v), 1) for v in worst]
+    out["c1_boundary_allreduce_5_floats_us"], out[c2_label] = [round(float(v), 1) for v in worst]
     out["note"] = ("median of 20 back-to-back all-reduces timed by HIP events on the compute stream, max over ranks; C1 is "
                    "on the forward's critical path once per layer, C2 overlaps the backward under DDP")
     return out
@@ -282,7 +282,7 @@ def parity_vs_oracle(seed, dev, ref):
     return out
 
 
-def quick_sampler(Bq, Nq, Mq, steps, warmup):
+def quick_sampler(Bq, Nq, Mq, steps, warmup, label="BASELINE configs[4]"):
     """ms/step and the longest kernel of one DownSampleToken layer fwd+bwd+SGD at another geometry (the stress workload
     behind the headline line; `--workload stress` prints its full line)."""
     from samble_amd import _lib, sampler_config, synth
@@ -321,7 +321,7 @@ def quick_sampler(Bq, Nq, Mq, steps, warmup):
     _lib.timing_select([])
     dom = max((n for n in cand if seen.get(n)), key=lambda n: seen[n][1], default=None)
     fl = (2 * C * C * (3 * Nq + 2 * NB) * 3 + 2 * Nq * Nq * C + 2 * Nq * (Nq + NB) * C + 5 * 2 * Mq * (Nq + NB) * C) * Bq
-    return {"config": f"BASELINE configs[4]: one DownSampleToken layer fwd+bwd+SGD, B={Bq} C=128 N={Nq}->{Mq}",
+    return {"config": f"{label}: one DownSampleToken layer fwd+bwd+SGD, B={Bq} C=128 N={Nq}->{Mq}",
             "ms_per_step": round(ms, 4), "clouds_per_s": round(Bq / (ms * 1e-3), 1), "steps": steps, "warmup": warmup,
             "dominant_kernel": dom, "dominant_kernel_us": round(seen[dom][1] * 1e3, 1) if dom else None,
             "kernel_us": {n: round(v[1] * 1e3, 1) for n, v in seen.items() if v},
@@ -343,9 +343,38 @@ def metric_f32_mfma(steps, warmup):
     return r
 
 
+def config0(steps, warmup, with_cpu=True):
+    """BASELINE configs[0] -- ModelNet40 cls, B=8 N=1024->512, a single downsample layer, the reference's own CPU-runnable
+    case -- on the GPU, with the CPU oracle (the bit-identical restatement of the reference) timed beside it on the host's
+    cores in the same run."""
+    Bq, Nq, Mq = 8, 1024, 512
+    r = quick_sampler(Bq, Nq, Mq, steps, warmup, label="BASELINE configs[0]")
+    if with_cpu:
+        from oracle import torch_oracle as O
+        from samble_amd import synth
+        seed = 1000 * 0 + 1
+        spec = O.SamplerSpec(M=Mq, K=KNN, C=C, num_bins=NB)
+        st = O.SamplerState(*(torch.from_numpy(a) for a in synth.sampler_weights(C, NB, seed)))
+        x = torch.from_numpy(synth.features(Bq, C, Nq, seed + 1))
+        g = torch.from_numpy(synth.normal((Bq, C, Mq), seed + 2))
+        noise = torch.from_numpy(synth.exp1((Bq * NB, Nq), seed + 3))
+        O.sampler_grads(spec, st, x, g, noise)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.sampler_grads(spec, st, x, g, noise)
+            times.append(time.perf_counter() - t0)
+        dt = statistics.median(times)
+        r["cpu_baseline"] = dict(value=round(Bq / dt, 3), unit="clouds/s", cores=torch.get_num_threads(), kind="port",
+                                 sample=f"median of 3 x fwd+bwd of {Bq} clouds (N={Nq}->{Mq}) after 1 warm-up, torch CPU oracle")
+        r["gpu_over_cpu"] = round(r["clouds_per_s"] / r["cpu_baseline"]["value"], 1)
+    return r
+
+
 def extra_workloads(args):
     out = {}
-    for name, fn in (("metric_f32_mfma", lambda: metric_f32_mfma(steps=8, warmup=3)),
+    for name, fn in (("config0", lambda: config0(steps=20, warmup=5, with_cpu=not args.no_cpu_baseline)),
+                     ("metric_f32_mfma", lambda: metric_f32_mfma(steps=8, warmup=3)),
                      ("stress", lambda: quick_sampler(16, 8192, 4096, steps=8, warmup=3)),
                      ("block_cls", lambda: measure_block("block_cls", steps=8, warmup=4)),
                      ("block_seg", lambda: measure_block("block_seg", steps=8, warmup=4))):
@@ -364,187 +393,11 @@ def extra_workloads(args):
     return out
 
 
-def run_block(args):
-    if args.gpus != 1:
-        raise SystemExit("the block workloads run on one GPU")
-    print(json.dumps(measure_block(args.workload, args.steps, args.warmup)), flush=True)
-    return 0
-
-
-def measure_block(workload, steps, warmup):
-    """BASELINE.json configs[1] (block_cls: EdgeConv x2 -> N2P -> sampler 2048->1024 -> N2P -> sampler 1024->512 -> N2P)
-    and configs[2] (block_seg: the same path down with 4 bins, interpolation + N2P back up to 2048): one step = forward +
-    backward + SGD of the whole block on B=32 clouds of N=2048 xyz points resident in HBM.  One GPU (the metric workload
-    carries the multi-GPU contract).  The JSON line has the contract's shape; `roofline` is for the kernel family that
-    takes the most time per step, timed by the library's HIP events on its launch stream over the timed steps."""
-    from types import SimpleNamespace
-    args = SimpleNamespace(workload=workload, steps=steps, warmup=warmup)
-    from samble_amd import _lib, synth
-    from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    Bb, Nb = 32, 2048
-    torch.manual_seed(1000 * (1 if args.workload == "block_cls" else 3))
-    seg = args.workload == "block_seg"
-    blk = (SegFeatureLearningBlock(seg_block_config()) if seg else FeatureLearningBlock(block_config("cls"))).to(dev).train()
-    xyz = torch.from_numpy(synth.xyz_clouds(Bb, Nb, 77)).to(dev)
-    opt = torch.optim.SGD(blk.parameters(), lr=1e-4)
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        out = blk(xyz)
-        feat = out if seg else out[0]
-        feat.square().mean().backward()
-        opt.step()
-
-    for _ in range(max(args.warmup - 2, 0)):
-        step()
-    # which kernel family dominates, from two untimed steps; then that one is timed over the timed region
-    fam = ["n2p_bwd", "edge_bwd", "knn", "edge_fwd", "n2p_fwd", "knn_small", "inv_nn", "seg_sum", "bwd_dq", "attn_rows",
-           "attn_stats", "lin_fwd", "lin_dx", "lin_dw", "lin_amax", "lin_amax_bwd", "bn_fwd", "lin_chain"]
-    _lib.timing_select(fam)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    seen = {n: _lib.timing_read(n) for n in fam}
-    per_step = {n: v[0] * v[2] / 2 for n, v in seen.items() if v}   # mean ms x launches / 2 steps
-    dominant = max(per_step, key=per_step.get)
-    _lib.timing_select([dominant])
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    dom = _lib.timing_read(dominant)
-    _lib.timing_select([])
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    ms = 1e3 * elapsed / args.steps
-    launches_per_step = dom[2] / args.steps if dom else 0
-    # algorithmic work of the dominant family per launch, averaged over its launches of a step (layers of 2048 / 1024 /
-    # 512 points): SURVEY 8(d) style, inputs read once and outputs written once, recomputation not counted
-    K, Cc = 32, 128
-    layers_n = [2048, 1024, 512] + ([1024, 2048] if seg else [])
-    if dominant in ("n2p_bwd", "n2p_fwd"):
-        # per point: its qkv row, the upstream gradient row, the K neighbour ids in; a dqkv row out
-        by = sum(Bb * n * (3 * Cc * 4 * 2 + Cc * 4 + K * 4) for n in layers_n) / len(layers_n)
-        roof = {"kernel": "n2p backward (transpose + n2p_bwd_point + n2p_bwd_gather)" if dominant == "n2p_bwd" else "n2p_attn_fwd",
-                "bound": "hbm", "achieved": round(by / (dom[0] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "note": ("gather kernel: every point reads the K / V rows of its 32 neighbours (32 KB per point) through "
-                         "L2; the algorithmic HBM bytes are the rows read once, so the fraction is small by construction")}
-    elif dominant in ("edge_bwd", "edge_fwd"):
-        # conv2 of the EdgeConv body on B*N*K edges, 64 -> 64 channels: forward 1 product, backward 2 (dh, dW2)
-        fl = Bb * Nb * K * 2 * 64 * 64 * (2 if dominant == "edge_bwd" else 1)
-        # split-bf16 kernels (csrc/edgeconv.hip): six bf16 products per product executed; the backward executes four
-        # (y in both orientations, dh, dW2) for its two algorithmic ones, the forward one for one
-        executed = 12.0 if dominant == "edge_bwd" else 6.0
-        roof = {"kernel": "edge_mlp_bwd_tri_kernel" if dominant == "edge_bwd" else "edge_mlp_fwd_tri_kernel", "bound": "mfma",
-                "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2), "peak": round(PEAK_BF16_MFMA_TFLOPS / executed, 1),
-                "unit": "TFLOP/s", "executed_products": executed,
-                "note": ("three bf16 planes per operand: 6 MFMA products per fp32 product; the backward recomputes the edge "
-                         "activations in both orientations (2 products, not counted) beside dh and dW2; the kernel is bound "
-                         "by vector issue (operand splits of tensors that are used once) and its waits, not by the matrix "
-                         "pipe (30 % busy, DESIGN 7)")}
-    else:
-        fl = sum(2.0 * Bb * n * n * Cc for n in layers_n) / len(layers_n)
-        roof = {"kernel": dominant, "bound": "mfma", "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2),
-                "peak": PEAK_TRI_TFLOPS, "unit": "TFLOP/s"}
-    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
-    roof["us_per_launch"] = round(dom[0] * 1e3, 1)
-    roof["launches_per_step"] = round(launches_per_step, 1)
-    roof["traffic"] = None
-    try:  # fabric bytes per launch of the dominant family's kernels from the newest committed rocprofv3 --pmc summary
-        import glob
-        pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc.json")))[-1]
-        pmc = json.load(open(pmc_path))
-        keys = {"n2p_bwd": ("n2p_bwd",), "n2p_fwd": ("n2p_attn_fwd",), "edge_bwd": ("edge_mlp_bwd",), "edge_fwd": ("edge_mlp_fwd",),
-                "knn": ("knn_duo",)}.get(dominant, (dominant,))
-        hit = [e for k_, e in pmc["kernels"].items() if any(s_ in k_ for s_ in keys) and "traffic_bytes_per_launch" in e]
-        if hit:
-            roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e.get("launches_per_step", 1) for e in hit)
-                                  / max(sum(e.get("launches_per_step", 1) for e in hit), 1))
-            roof["traffic_source"] = f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc of an earlier run of this command)"
-        if pmc.get("step_traffic_bytes"):
-            roof["step_traffic"] = int(pmc["step_traffic_bytes"])
-    except Exception:  # noqa: BLE001
-        pass
-    result = {
-        "metric": ("point-clouds/sec (feature-learning block fwd+bwd), " + ("ShapeNet-part seg block" if seg else "ModelNet40 cls block")
-                   + " B=32 N=2048->1024->512" + ("->1024->2048" if seg else "")),
-        "value": round(Bb * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_median": round(statistics.median(step_ms), 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (unit-sphere xyz clouds with jitter and anisotropic scale, random-init weights; no dataset files offline)",
-        "config": {"workload": ("BASELINE configs[2]: SegFeatureLearningBlock" if seg else "BASELINE configs[1]: FeatureLearningBlock")
-                               + " fwd+bwd+SGD, B=32 xyz (32,3,2048), EdgeConv x2, N2P x" + ("5" if seg else "3")
-                               + ", DownSampleToken x2 (" + ("4" if seg else "6") + " bins, random T=0.1, dynamic boundaries)"
-                               + (", UpSampleInterpolation x2" if seg else ""),
-                   "global_batch": Bb, "parallelism": "dp1"},
-        "roofline": roof,
-        "kernel_family_ms_per_step": {n: round(v, 3) for n, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-    }
-    return result
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "block_cls", "block_seg"],
-                    help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096; "
-                         "block_cls / block_seg = configs[1] / configs[2]: the whole feature-learning block, B=32 N=2048")
-    ap.add_argument("--prewarm-steps", type=int, default=0,
-                    help="untimed steps before the --warmup steps, with the parameters put back afterwards (metric / "
-                         "stress workloads; worth ~1 %% on an idle GPU, off by default)")
-    ap.add_argument("--lr", type=float, default=1e-4,
-                    help="SGD learning rate of the synthetic step (0 keeps the weights where they are: long runs for "
-                         "power / clock probes, where 1e-4 against a fixed random gradient would blow the weights up)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the step behind the timed region")
-    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--no-extra-workloads", action="store_true",
-                    help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
-    ap.add_argument("--logit-map", action="store_true",
-                    help="A/B: keep the N x (N+nt) logit map in HBM (the round-1 pipeline) instead of the map-free forward")
-    ap.add_argument("--backend", default="nccl",
-                    help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
-    args = ap.parse_args()
-
-    if args.workload.startswith("block_"):
-        return run_block(args)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
-
-    global B_PER_GPU, N, M
-    if args.workload == "stress":
-        B_PER_GPU, N, M = 16, 8192, 4096
-        args.no_cpu_baseline = True  # the CPU oracle needs minutes per cloud at this size
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    ndev = max(torch.cuda.device_count(), 1)
-    shared_gpus = world > ndev
-    local = local % ndev
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-            else:
-                dist.init_process_group(args.backend)
-        except Exception as e:  # noqa: BLE001
-            if "EADDRINUSE" in str(e) or "address already in use" in str(e).lower():
-                sys.exit(EADDRINUSE_EXIT)  # (launch_ranks picks another port)
-            raise
+def init_ranks(args):
+    """(rank, world, device, shared_gpus): this process's place in the job, the process group formed when WORLD_SIZE > 1
+    (RCCL = backend "nccl", as the reference's trainer forms it, train_modelnet.py:162-166; gloo when the ranks share GPUs)."""
+    rank, world, dev, shared_gpus, ndev = init_ranks(args)
+    local = dev.index
 
     from samble_amd import _lib, ops, sampler_config, synth
     from samble_amd.downsample import DownSampleToken
@@ -755,13 +608,14 @@ def main():
             return (e.get("traffic_bytes_per_launch"), src) if e else (None, None)
 
         def roof(kernel, alg_flops, ms, pmc_name, timed_as=None):
-            """MFMA roofline of one kernel: achieved = ALGORITHMIC fp32 flops / launch time; peak = what the matrix pipe
-            could deliver of such flops given the 16-bit products this kernel executes per algorithmic product."""
+            """MFMA roofline of one kernel: achieved = ALGORITHMIC fp32 flops / launch time; peak = the dense
+            MFMA peak of the instruction the kernel issues (16-bit: 2500 TFLOP/s; matrix mode f32: 157.3); frac = achieved /
+            peak.  frac_executed = the 16-bit products actually issued / 2500 (what the matrix pipe is busy with)."""
             ach = alg_flops / (ms * 1e-3) / 1e12
             e, src = pmc_entry(pmc_name)
             if tri:
                 products, why = EXECUTED_PRODUCTS.get(timed_as, (6.0, "three bf16 planes per operand: 6 products"))
-                peak = round(PEAK_BF16_MFMA_TFLOPS / products, 1)
+                peak = PEAK_BF16_MFMA_TFLOPS
             else:
                 products, why, peak = 1.0, "v_mfma_f32_32x32x2_f32 (true fp32 products)", PEAK_FP32_MFMA_TFLOPS
             out = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
@@ -772,17 +626,15 @@ def main():
                    "us_per_launch": round(ms * 1e3, 1), "algorithmic_flops_per_launch": alg_flops,
                    "executed_products": products,
                    "executed_tflops": round(ach * products, 1),
+                   "frac_executed": round(ach * products / peak, 4),
                    "mfma_busy": e.get("mfma_busy_frac_at_2.4GHz") if e else None}
             if tri:
-                out["peak_note"] = (f"peak = dense 16-bit MFMA 2500 TFLOP/s / {products:g} products executed per "
-                                    f"algorithmic fp32 product ({why}); frac = EXECUTED 16-bit TFLOP/s / 2500 (what the "
-                                    "matrix pipe is busy with); frac_algorithmic = ALGORITHMIC TFLOP/s / 2500 (SURVEY 8d's "
-                                    "flops, no credit for the split products); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES of the "
-                                    "committed PMC run / (kernel time x 1024 SIMDs x 2.4 GHz)")
-                out["frac_algorithmic"] = round(ach / PEAK_BF16_MFMA_TFLOPS, 4)
+                out["peak_note"] = (f"frac = ALGORITHMIC fp32 TFLOP/s (SURVEY 8d's flops, no credit for split products or "
+                                    f"recomputation) / the dense 16-bit MFMA peak 2500; the kernel issues {products:g} 16-bit "
+                                    f"products per algorithmic fp32 product ({why}): frac_executed = executed 16-bit TFLOP/s / "
+                                    "2500; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC run / (kernel time x 1024 "
+                                    "SIMDs x 2.4 GHz)")
                 out["frac_of_fp32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)
-            else:
-                out["frac_algorithmic"] = out["frac"]
             return out
 
         def hbm(kernel, alg_bytes, ms, pmc_name):
@@ -879,9 +731,6 @@ def main():
                                                  "proj_dw_kernel (+ reduce; fp32 MFMA)"), pj)):
                 if kt.get(n_):
                     r_ = roof(name, flops, kt[n_][0], "samble::" + name.split(" ")[0], timed_as=n_)
-                    if n_ == "proj_dw" and not tri:
-                        r_["peak"], r_["frac"] = PEAK_FP32_MFMA_TFLOPS, round(r_["achieved"] / PEAK_FP32_MFMA_TFLOPS, 4)
-                        r_.pop("peak_note", None)
                     mf.append(r_)
             result["roofline_other_kernels"] = mf
             # HBM-bound kernels: algorithmic bytes / launch duration against 8 TB/s

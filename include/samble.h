@@ -55,6 +55,11 @@ extern "C" {
 
 const char* samble_version(void);
 const char* samble_last_error(void);
+/* Bumped whenever an exported prototype changes its argument list (entry points are otherwise only added): a consumer
+ * compares samble_abi_version() with the SAMBLE_ABI_VERSION it was built against BEFORE the first call -- a stale library
+ * or binding then fails at load time instead of passing shifted pointers (samble_amd/_lib.py does exactly that). */
+#define SAMBLE_ABI_VERSION 6
+int samble_abi_version(void);
 
 /* ---- utils/ops.py:17-44  knn(a, b, k) -------------------------------------------------------
  * xq (B,C,Nq), xk (B,C,Nk) channel-major (the layout the reference's callers hold before
@@ -654,15 +659,39 @@ int samble_linear_fwd_cm_f32(const float* x, int64_t x_bs, int B, int C, int N, 
                              float* out, int64_t o_bs, void* stream);
 int samble_linear_dw_cm_f32(const float* g, int64_t g_bs, const float* x, int64_t x_bs, int B, int C, int N, int O, float* dW,
                             void* ws, size_t ws_bytes, void* stream);
-/* nn.BatchNorm1d.forward in training mode on x (B, C, N) channel-major (the attention layers' bn1 / bn2,
+/* nn.BatchNorm1d in training mode on x (B, C, N) channel-major (the attention layers' bn1 / bn2,
    models/attention.py:187-192): out = (x - mean) / sqrt(var + eps) * gamma + beta with the batch statistics over (B, N);
-   save_mean / save_invstd (C) are what aten's miopen_batch_norm_backward takes; running_mean / running_var (may be null)
-   get torch's momentum update (unbiased variance).  Statistics in float64, summed in a fixed order.
-   workspace: samble_bn_train_workspace_bytes(B, C). */
+   save_mean / save_invstd (C) go to the backward; running_mean / running_var (may be null) get torch's momentum update
+   (unbiased variance).  Statistics in float64, summed in a fixed order.  workspace (every entry that takes one):
+   samble_bn_train_workspace_bytes(B, C).
+     samble_bn_train_fwd_f32        one rank: statistics + normalisation (two launches)
+     samble_bn_train_bwd_f32        one rank: dx = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)), dgamma = sum dy xhat,
+                                    dbeta = sum dy (may be null); dx may be dy
+   nn.SyncBatchNorm (the reference trainer converts every BatchNorm, train_modelnet.py:245-246): the same kernels in two
+   halves, between which the CALLER all-reduces (SUM) `pooled` over its process group --
+     samble_bn_train_stats_f32      pooled (2 C + 1 float64) = [sum x | sum x^2 | B N] of this rank
+     samble_bn_train_apply_f32      the normalisation from the all-reduced block (count = pooled[2 C])
+     samble_bn_train_bwd_sums_f32   pooled (2 C float64) = [sum dy | sum dy xhat] of this rank; dgamma / dbeta (may be null)
+                                    = the same sums as float32: they stay per rank (DistributedDataParallel averages
+                                    parameter gradients itself, as torch's SyncBatchNorm leaves them)
+     samble_bn_train_bwd_apply_f32  dx from the all-reduced sums; count = device pointer to the pooled element count
+                                    (the forward's pooled + 2 C) */
 size_t samble_bn_train_workspace_bytes(int B, int C);
 int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd, void* ws,
                             size_t ws_bytes, void* stream);
+int samble_bn_train_bwd_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean, const float* save_invstd,
+                            const float* gamma, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+int samble_bn_train_stats_f32(const float* x, int B, int C, int N, double* pooled, void* ws, size_t ws_bytes, void* stream);
+int samble_bn_train_apply_f32(const float* x, int B, int C, int N, const double* pooled, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
+                              float* save_invstd, void* stream);
+int samble_bn_train_bwd_sums_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                 const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 void* stream);
+int samble_bn_train_bwd_apply_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                  const float* save_invstd, const float* gamma, const double* pooled, const double* count,
+                                  float* dx, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
@@ -671,8 +700,11 @@ int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const
  * The library records HIP events around its own launches of the selected kernels, on the stream each is
  * launched on.  samble_timing_select(mask): bit SAMBLE_T_x set = time kernel x (0 = off; resets the samples);
  * samble_timing_read(id, ...) waits for that kernel's recorded launches (the last 32 at most) and returns
- * their mean / median duration in ms and how many launches were seen.  Process-wide, not thread-safe, no
- * effect on results; nothing on the data path reads it. */
+ * their mean / median duration in ms and how many launches were seen.  No effect on results; nothing on the data path
+ * reads it.  THE ONE EXCEPTION to "re-entrant, no mutable global state" above: the selection mask and the event tables
+ * are process-wide (csrc/abi.hip g_time_*), so select / read must not run while another thread is inside the library
+ * (a benchmark selects, runs its steps, synchronises, reads).  With the mask at 0 -- the default, and what every test and
+ * the product path run under -- the hook is two predictable branches per launch and touches nothing shared. */
 #define SAMBLE_T_ATTN_STATS 1   /* attn_stats(_tri / _nl_tri): QK^T + softmax statistics over all rows */
 #define SAMBLE_T_ATTN_ROWS 2    /* attn_rows(_tri / _rc_tri): P V of the sampled rows */
 #define SAMBLE_T_BWD_DV 3       /* bwd_kacc_tri (dV) */
@@ -709,6 +741,7 @@ int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const
 #define SAMBLE_T_LIN_AMAX_BWD 36 /* amax_bwd + the sum over the clouds */
 #define SAMBLE_T_BN_FWD 37       /* bn_stats + bn_apply: BatchNorm1d training forward */
 #define SAMBLE_T_LIN_CHAIN 38    /* lin_chain: a feed-forward layer's two convolutions in one sweep */
+#define SAMBLE_T_BN_BWD 39       /* bn_bwd_reduce + bn_bwd_apply: BatchNorm1d training backward */
 int samble_timing_select(uint64_t kernel_mask);
 int samble_timing_read(int kernel_id, float* mean_ms, float* median_ms, int* launches);
 

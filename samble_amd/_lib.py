@@ -21,6 +21,7 @@ class SambleError(RuntimeError):
 _SIGNATURES = {
     "samble_version": (c_char_p, []),
     "samble_last_error": (c_char_p, []),
+    "samble_abi_version": (c_int, []),
     "samble_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "samble_knn_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -110,6 +111,15 @@ _SIGNATURES = {
     "samble_bn_train_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_bn_train_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_bn_train_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_bn_train_stats_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_bn_train_apply_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "samble_bn_train_bwd_sums_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_size_t, c_void_p]),
+    "samble_bn_train_bwd_apply_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
     "samble_amax_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_amax_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -197,6 +207,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 6  # include/samble.h SAMBLE_ABI_VERSION this binding's argument table was written against
 
 _lib = None
 
@@ -216,8 +227,20 @@ def load() -> ctypes.CDLL:
             "`python -c \"import __graft_entry__ as g; g.build()\"` or `make -C samble_amd/csrc`. "
             "samble_amd has no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    # a library built from another revision of include/samble.h would take shifted arguments: refuse it before any call
+    try:
+        lib.samble_abi_version.restype = c_int
+        built = int(lib.samble_abi_version())
+    except AttributeError:
+        built = None
+    if built != ABI_VERSION:
+        raise SambleError(f"{LIB_PATH} implements ABI version {built}, this binding is written against {ABI_VERSION}: "
+                          "rebuild it (`make -C samble_amd/csrc`)")
     for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here means the .so is stale
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise SambleError(f"{LIB_PATH} does not export {name}: the library is stale, rebuild it") from None
         fn.restype = res
         fn.argtypes = args
     _lib = lib
@@ -243,7 +266,7 @@ TIMED_KERNELS = {
     "proj_dx": 9, "proj_dw": 10, "tri_split": 11, "knn_prep": 12, "sparse_score": 13, "quantiles": 14, "bin_assign": 15,
     "alloc_counts": 16, "bin_select": 17, "bwd_prep": 18, "gather": 19, "bwd_rows_f32": 22, "nn_prepare": 23,
     "edge_fwd": 24, "edge_bwd": 25, "n2p_fwd": 26, "n2p_bwd": 27, "inv_nn": 28, "seg_sum": 29, "edge_sums": 30,
-    "knn_small": 31, "lin_fwd": 32, "lin_dx": 33, "lin_dw": 34, "lin_amax": 35, "lin_amax_bwd": 36, "bn_fwd": 37, "lin_chain": 38,
+    "knn_small": 31, "lin_fwd": 32, "lin_dx": 33, "lin_dw": 34, "lin_amax": 35, "lin_amax_bwd": 36, "bn_fwd": 37, "lin_chain": 38, "bn_bwd": 39,
 }
 
 

@@ -5,7 +5,7 @@ keys (`q_conv/k_conv/v_conv.weight` (C,C,1,1), `ff.0/ff.2.weight`, `bn1.*`, `bn2
 reference.  The neighbour build is the fused Gram + top-K HIP kernel, the three 1x1 Conv2d collapse
 (by linearity) into one per-point fp32-MFMA projection, and the K-neighbour softmax attention is
 one HIP gather kernel: the (B,C,N,K) tensors of the reference are never built in forward.
-BatchNorm / FFN around it are stock torch modules (they are not neighbour ops).
+The BatchNorms (training mode, nn.SyncBatchNorm included) and the FFN around it run on csrc/batchnorm.hip / csrc/linear.hip.
 
 Backward of the attention part is two HIP kernels (per-point pass, then an ordered gather over
 64-row target blocks: no atomics, run-to-run identical) followed by the HIP projection backward.
@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import math
 import os
+import threading
 
 import torch
 from torch import nn
@@ -104,9 +105,10 @@ class _N2PLayer(torch.autograd.Function):
     accumulations backward: 4 x 33 MB in and out at N = 2048, a launch each) ride on the epilogues of the kernels that
     produce the other summand -- the gather attention, the FFN's second product, the FFN's input gradient, the
     projection's input gradient (`residual` of include/samble.h) -- and the weights' `cat`, the autograd bookkeeping
-    between eight nodes and their saved intermediates go with them.  Same kernels, same BatchNorm (MIOpen through the
-    aten entries nn.BatchNorm1d itself dispatches to), same sums in the same order: outputs, all gradients and the running
-    statistics are bit-identical to the node-by-node composition (tests/test_gpu_layers.py)."""
+    between eight nodes and their saved intermediates go with them.  Same kernels, same BatchNorm (csrc/batchnorm.hip, both
+    directions; under nn.SyncBatchNorm its per-channel sums are all-reduced over the module's process group), same sums in
+    the same order: outputs, all gradients and the running statistics are bit-identical to the node-by-node composition
+    (tests/test_gpu_layers.py)."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
@@ -118,29 +120,29 @@ class _N2PLayer(torch.autograd.Function):
         qkv = ops.stage_proj_fwd(x, x.new_zeros((C, 0)), w)
         nn_idx = ops.stage_knn(x, x, K)
         s1 = ops.stage_n2p_attn_fwd(qkv, nn_idx, heads, diff, residual=x)                 # x + attention(x)
-        y1, m1, v1 = _bn_train(bn1, s1, g1, b1)
+        grp1, grp2 = _sync_group(bn1), _sync_group(bn2)     # nn.SyncBatchNorm: the statistics are pooled over the ranks
+        y1, m1, v1, n1 = _bn_train(bn1, s1, g1, b1, grp1)
         w1_rm, w1_tr, w2t_rm, w2t_tr = linear.ffn_weight_images(w1.reshape(H, C), w2.reshape(C, H))
         if linear.chain_supported(y1, H):                                                  # both products in one sweep
             s2, hr, hbits = linear.stage_linear_chain(y1, w1_rm, w2t_tr, H, linear.LIN_LEAKY_BITS, residual=y1)
         else:
             hr, hbits = linear.stage_linear_fwd(y1, w1_rm, H, linear.LIN_LEAKY_BITS)      # leaky(W1 y1), (B,N,H) + its sign bits
             s2 = linear.stage_linear_dx(hr, w2t_tr, H, residual=y1)                       # y1 + W2 h
-        y2, m2, v2 = _bn_train(bn2, s2, g2, b2)
+        y2, m2, v2, n2 = _bn_train(bn2, s2, g2, b2, grp2)
         ctx.save_for_backward(x, w, qkv, nn_idx, s1, m1, v1, y1, hr, s2, m2, v2, g1, g2, w1_tr, w2t_rm, hbits)
-        ctx.cfg = (heads, diff, wq.shape[0], wk.shape[0], H, float(bn1.eps), float(bn2.eps))
-        ctx.bns = (bn1, bn2)
+        ctx.cfg = (heads, diff, wq.shape[0], wk.shape[0], H)
+        ctx.pool = (grp1, n1, grp2, n2)
         return y2
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy2):
         x, w, qkv, nn_idx, s1, m1, v1, y1, hr, s2, m2, v2, g1, g2, w1_tr, w2t_rm, hbits = ctx.saved_tensors
-        heads, diff, a, b, H, eps1, eps2 = ctx.cfg
-        bn1, bn2 = ctx.bns
+        heads, diff, a, b, H = ctx.cfg
+        grp1, n1, grp2, n2 = ctx.pool
         C = x.shape[1]
         dy2 = dy2.float().contiguous()
-        ds2, dg2, db2 = torch.ops.aten.miopen_batch_norm_backward(s2, dy2, g2, bn2.running_mean, bn2.running_var, m2, v2, eps2)
-        ds2 = ds2.contiguous()
+        ds2, dg2, db2 = ops.stage_bn_train_bwd(s2, dy2, g2, m2, v2, n2, grp2)
         if linear.chain_supported(ds2, H):
             dy1, dh, _ = linear.stage_linear_chain(ds2, w2t_rm, w1_tr, H, linear.LIN_LEAKY_MASK_BITS, bits=hbits, residual=ds2)
         else:
@@ -149,27 +151,32 @@ class _N2PLayer(torch.autograd.Function):
         dw1 = linear.stage_linear_dw(dh, y1, H).reshape(H, C, 1)
         if not linear.chain_supported(ds2, H):
             dy1 = linear.stage_linear_dx(dh, w1_tr, H, residual=ds2, out=ds2)              # ds2 + W1^T dh, in place
-        ds1, dg1, db1 = torch.ops.aten.miopen_batch_norm_backward(s1, dy1, g1, bn1.running_mean, bn1.running_var, m1, v1, eps1)
-        ds1 = ds1.contiguous()
+        ds1, dg1, db1 = ops.stage_bn_train_bwd(s1, dy1, g1, m1, v1, n1, grp1, out=dy1)   # (dy1 is this node's own buffer)
         dqkv = ops.stage_n2p_attn_bwd(qkv, nn_idx, ds1, heads, diff)
         dx, dw, _ = ops.stage_proj_bwd(dqkv, x, x.new_zeros((C, 0)), w, True, True, dx_residual=ds1)   # ds1 + W^T dqkv
         return (dx, dw[:a].reshape(a, C, 1, 1), dw[a:a + b].reshape(b, C, 1, 1), dw[a + b:].reshape(-1, C, 1, 1), dw1, dw2,
                 dg1, db1, dg2, db2, None, None, None, None, None)
 
 
+_counts = threading.local()   # .pending: this thread's open deferred_batch_counts map (None outside the context)
+
+
 class deferred_batch_counts:
     """Inside this context the fused layers' `num_batches_tracked += 1` (one single-thread launch per BatchNorm and
     call: ten per step of the segmentation block) are collected and applied as ONE multi-tensor add on the way out.  The
-    blocks wrap their forward in it; a layer called on its own counts at once, as before."""
-    pending = None
+    blocks wrap their forward in it; a layer called on its own counts at once, as before.  The map is per THREAD (two
+    replicas under nn.DataParallel, an evaluation thread beside the training one: each sees its own), and a forward that
+    raised leaves the counters where they were."""
 
     def __enter__(self):
-        self.outer = deferred_batch_counts.pending
-        deferred_batch_counts.pending = {}
+        self.outer = getattr(_counts, "pending", None)
+        _counts.pending = {}
         return self
 
     def __exit__(self, *exc):
-        mine, deferred_batch_counts.pending = deferred_batch_counts.pending, self.outer
+        mine, _counts.pending = _counts.pending, self.outer
+        if exc[0] is not None:
+            return False
         once = [t for t, k in mine.values() if k == 1]
         if once:
             torch._foreach_add_(once, 1)
@@ -179,12 +186,16 @@ class deferred_batch_counts:
         return False
 
 
-def _bn_train(bn: nn.BatchNorm1d, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
-    """nn.BatchNorm1d.forward in training mode on (B,C,N): the aten entry the module dispatches to on this build (MIOpen),
-    with the module's own bookkeeping (momentum, running statistics, num_batches_tracked)."""
+_sync_group = ops.sync_group
+
+
+def _bn_train(bn, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group=None):
+    """nn.BatchNorm1d.forward in training mode on (B,C,N) -> (y, saved mean, saved invstd, pooled count | None), with the
+    module's own bookkeeping (momentum, running statistics, num_batches_tracked).  csrc/batchnorm.hip; `group`: the ranks an
+    nn.SyncBatchNorm pools its statistics over."""
     factor = 0.0
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        pending = deferred_batch_counts.pending
+        pending = getattr(_counts, "pending", None)
         if pending is not None and bn.momentum is not None:      # (the count is only bookkeeping then)
             t, k = pending.get(id(bn.num_batches_tracked), (bn.num_batches_tracked, 0))
             pending[id(bn.num_batches_tracked)] = (t, k + 1)
@@ -193,56 +204,67 @@ def _bn_train(bn: nn.BatchNorm1d, s: torch.Tensor, gamma: torch.Tensor, beta: to
         factor = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
     elif bn.momentum is not None:
         factor = bn.momentum
-    if OWN_BATCHNORM and s.dtype == torch.float32 and s.dim() == 3 and all(
-            t is None or (t.dtype == torch.float32 and t.is_contiguous()) for t in (gamma, beta, bn.running_mean, bn.running_var)):
-        return ops.stage_bn_train(s, gamma, beta, bn.running_mean, bn.running_var, factor, bn.eps)
-    return torch.miopen_batch_norm(s, gamma, beta, bn.running_mean, bn.running_var, True, factor, bn.eps)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return ops.stage_bn_train(s, gamma, beta, rm, rv, factor, bn.eps, group)
 
 
-# csrc/batchnorm.hip for the training forward of bn1 / bn2 (the backward stays aten's); "0": MIOpen's forward (A/B runs)
+# csrc/batchnorm.hip for bn1 / bn2 in training mode, forward and backward; "0": the stock modules (A/B runs)
 OWN_BATCHNORM = os.environ.get("SAMBLE_OWN_BATCHNORM", "1") != "0"
 
 
 class _BNTrain(torch.autograd.Function):
-    """nn.BatchNorm1d in training mode as the fused layer runs it (`_bn_train` forward, aten's MIOpen backward): what the
-    node-by-node form of the layer calls, so that both forms stay bit-identical."""
+    """nn.BatchNorm1d / nn.SyncBatchNorm in training mode as the fused layer runs it (`_bn_train` forward,
+    `ops.stage_bn_train_bwd` backward): what the node-by-node form of the layer calls, so that both forms stay
+    bit-identical."""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, s, gamma, beta, bn):
         s = s.contiguous()
-        y, m, v = _bn_train(bn, s, gamma, beta)
+        group = _sync_group(bn)
+        y, m, v, n = _bn_train(bn, s, gamma, beta, group)
         ctx.save_for_backward(s, gamma, m, v)
-        ctx.bn = bn
+        ctx.pool = (group, n)
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
         s, gamma, m, v = ctx.saved_tensors
-        bn = ctx.bn
-        ds, dg, db = torch.ops.aten.miopen_batch_norm_backward(s, dy.float().contiguous(), gamma, bn.running_mean, bn.running_var,
-                                                               m, v, float(bn.eps))
+        group, n = ctx.pool
+        ds, dg, db = ops.stage_bn_train_bwd(s, dy.float().contiguous(), gamma, m, v, n, group)
         return ds, dg, db, None
 
 
-def batch_norm(bn: nn.BatchNorm1d, s: torch.Tensor) -> torch.Tensor:
-    """`bn(s)` -- through `_BNTrain` where the fused layer would take the same route, the module itself otherwise."""
-    plain = type(bn) is nn.BatchNorm1d and bn.affine and (bn.momentum is not None or not bn.track_running_stats)
-    if (OWN_BATCHNORM and bn.training and plain and s.is_cuda and s.dtype == torch.float32 and s.dim() == 3
-            and torch.backends.cudnn.enabled):
+def _plain_bn(bn) -> bool:
+    """A BatchNorm the own kernels take: nn.BatchNorm1d or nn.SyncBatchNorm (what convert_sync_batchnorm makes of it), affine,
+    float32 parameters and buffers, and either a momentum or no running statistics (the cumulative average needs the host's
+    copy of the counter)."""
+    if type(bn) not in (nn.BatchNorm1d, nn.SyncBatchNorm) or not bn.affine:
+        return False
+    if bn.track_running_stats and bn.momentum is None:
+        return False
+    tensors = [bn.weight, bn.bias] + ([bn.running_mean, bn.running_var] if bn.track_running_stats else [])
+    return all(t is not None and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+
+
+def batch_norm(bn, s: torch.Tensor) -> torch.Tensor:
+    """`bn(s)` -- through `_BNTrain` where the fused layer would take the same route, the module itself otherwise (evaluation,
+    a BatchNorm frozen with bn.eval() inside a training layer, other dtypes)."""
+    if OWN_BATCHNORM and bn.training and _plain_bn(bn) and s.is_cuda and s.dtype == torch.float32 and s.dim() == 3:
         return _BNTrain.apply(s, bn.weight, bn.bias, bn)
     return bn(s)
 
 
 def _layer_fusable(mod, x) -> bool:
     bn1, bn2 = mod.bn1, mod.bn2
-    plain = lambda bn: type(bn) is nn.BatchNorm1d and bn.affine and (bn.momentum is not None or not bn.track_running_stats)
-    return (FUSED_LAYER and FUSED_FFN and mod.training and x.is_cuda and x.dtype == torch.float32 and ops.MATRIX_MODE == "tri"
+    # bn.training, not only mod.training: a BatchNorm frozen with bn.eval() inside a layer in train() normalises with its
+    # running estimates and leaves them alone (the reference's behaviour, and `batch_norm`'s) -- the fused node would not
+    return (FUSED_LAYER and FUSED_FFN and OWN_BATCHNORM and mod.training and bn1.training and bn2.training and x.is_cuda
+            and x.dtype == torch.float32 and ops.MATRIX_MODE == "tri"
             and mod.hip_attention and mod.attention_mode == "scalar_dot" and not mod.group_type.startswith("center_")
-            and plain(bn1) and plain(bn2) and mod.ff[0].bias is None and mod.ff[2].bias is None
-            and abs(mod.ff[1].negative_slope - 0.2) < 1e-12 and linear.ffn_supported(x, mod.ff[0].weight, mod.ff[2].weight)
-            and torch.backends.cudnn.enabled)
+            and _plain_bn(bn1) and _plain_bn(bn2) and mod.ff[0].bias is None and mod.ff[2].bias is None
+            and abs(mod.ff[1].negative_slope - 0.2) < 1e-12 and linear.ffn_supported(x, mod.ff[0].weight, mod.ff[2].weight))
 
 
 class Neighbor2PointAttention(nn.Module):

@@ -218,7 +218,8 @@ SAMBLE_API int samble_timing_read(int id, float* mean_ms, float* median_ms, int*
   return SAMBLE_OK;
 }
 
-SAMBLE_API const char* samble_version(void) { return "samble-hip 0.2 (gfx950)"; }
+SAMBLE_API const char* samble_version(void) { return "samble-hip 0.3 (gfx950)"; }
+SAMBLE_API int samble_abi_version(void) { return SAMBLE_ABI_VERSION; }
 SAMBLE_API const char* samble_last_error(void) { return g_err; }
 
 SAMBLE_API size_t samble_knn_workspace_bytes(int B, int C, int Nq, int Nk, int K, int variant) {
@@ -981,24 +982,84 @@ SAMBLE_API int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, 
               "samble_interp_blend_bwd_f32");
 }
 
-/* ---- BatchNorm1d training forward (csrc/batchnorm.hip) ------------------------------------------------------------- */
+/* ---- BatchNorm1d in training mode, forward and backward (csrc/batchnorm.hip) ------------------------------------------ */
 extern "C" {
 size_t samble_bn_train_ws_bytes(int, int);
 int samble_launch_bn_train_fwd(const float*, int, int, int, const float*, const float*, float, float, float*, float*, float*,
                                float*, float*, void*, hipStream_t);
+int samble_launch_bn_train_stats(const float*, int, int, int, double*, void*, hipStream_t);
+int samble_launch_bn_train_apply(const float*, int, int, int, const double*, const float*, const float*, float, float, float*,
+                                 float*, float*, float*, float*, hipStream_t);
+int samble_launch_bn_train_bwd(const float*, const float*, int, int, int, const float*, const float*, const float*, float*,
+                               float*, float*, void*, hipStream_t);
+int samble_launch_bn_train_bwd_sums(const float*, const float*, int, int, int, const float*, const float*, double*, float*,
+                                    float*, void*, hipStream_t);
+int samble_launch_bn_train_bwd_apply(const float*, const float*, int, int, int, const float*, const float*, const float*,
+                                     const double*, const double*, float*, hipStream_t);
 }
 SAMBLE_API size_t samble_bn_train_workspace_bytes(int B, int C) { return (B > 0 && C > 0) ? samble_bn_train_ws_bytes(B, C) : 0; }
+
+static int bn_shape_ok(int B, int C, int N) { return B > 0 && B <= 65535 && C > 0 && C <= 65535 && N > 0; }
 
 SAMBLE_API int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps,
                                        float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
                                        float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !out || !save_mean || !save_invstd || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: null pointer");
-  if (B <= 0 || B > 65535 || C <= 0 || N <= 0 || (long)B * N < 2)
+  if (!bn_shape_ok(B, C, N) || (long)B * N < 2)
     return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: needs more than one value per channel, B <= 65535");
   if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_fwd_f32: workspace too small");
   return done(samble_launch_bn_train_fwd(x, B, C, N, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean,
                                          save_invstd, ws, (hipStream_t)stream),
               "samble_bn_train_fwd_f32");
+}
+
+SAMBLE_API int samble_bn_train_stats_f32(const float* x, int B, int C, int N, double* pooled, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  if (!x || !pooled || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_stats_f32: null pointer");
+  if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_stats_f32: bad shape (B, C <= 65535)");
+  if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_stats_f32: workspace too small");
+  return done(samble_launch_bn_train_stats(x, B, C, N, pooled, ws, (hipStream_t)stream), "samble_bn_train_stats_f32");
+}
+
+SAMBLE_API int samble_bn_train_apply_f32(const float* x, int B, int C, int N, const double* pooled, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                         float* out, float* save_mean, float* save_invstd, void* stream) {
+  if (!x || !pooled || !out || !save_mean || !save_invstd) return fail(SAMBLE_E_INVALID, "samble_bn_train_apply_f32: null pointer");
+  if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_apply_f32: bad shape (B, C <= 65535)");
+  return done(samble_launch_bn_train_apply(x, B, C, N, pooled, gamma, beta, eps, momentum, running_mean, running_var, out,
+                                           save_mean, save_invstd, (hipStream_t)stream),
+              "samble_bn_train_apply_f32");
+}
+
+SAMBLE_API int samble_bn_train_bwd_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                       const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                       void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !dy || !save_mean || !save_invstd || !dx || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_f32: null pointer");
+  if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_f32: bad shape (B, C <= 65535)");
+  if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_bwd_f32: workspace too small");
+  return done(samble_launch_bn_train_bwd(x, dy, B, C, N, save_mean, save_invstd, gamma, dx, dgamma, dbeta, ws, (hipStream_t)stream),
+              "samble_bn_train_bwd_f32");
+}
+
+SAMBLE_API int samble_bn_train_bwd_sums_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                            const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws,
+                                            size_t ws_bytes, void* stream) {
+  if (!x || !dy || !save_mean || !save_invstd || !pooled || !ws)
+    return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_sums_f32: null pointer");
+  if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_sums_f32: bad shape (B, C <= 65535)");
+  if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_bwd_sums_f32: workspace too small");
+  return done(samble_launch_bn_train_bwd_sums(x, dy, B, C, N, save_mean, save_invstd, pooled, dgamma, dbeta, ws, (hipStream_t)stream),
+              "samble_bn_train_bwd_sums_f32");
+}
+
+SAMBLE_API int samble_bn_train_bwd_apply_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                             const float* save_invstd, const float* gamma, const double* pooled,
+                                             const double* count, float* dx, void* stream) {
+  if (!x || !dy || !save_mean || !save_invstd || !pooled || !count || !dx)
+    return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_apply_f32: null pointer");
+  if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_apply_f32: bad shape (B, C <= 65535)");
+  return done(samble_launch_bn_train_bwd_apply(x, dy, B, C, N, save_mean, save_invstd, gamma, pooled, count, dx, (hipStream_t)stream),
+              "samble_bn_train_bwd_apply_f32");
 }
 
 /* ---- 1x1 convolutions over 128 input channels (csrc/linear.hip) ------------------------------------------------- */

@@ -1,7 +1,9 @@
-// nn.BatchNorm1d.forward in training mode on a channel-major (B, C, N) tensor -- the two BatchNorms of an attention layer
-// (reference models/attention.py:187-192: x = bn1(x + attention(x)); x = bn2(x + ff(x))), forward only: the backward stays
-// the aten entry the module dispatches to (miopen_batch_norm_backward), which takes the mean and 1 / sqrt(var + eps) this
-// forward saves.
+// nn.BatchNorm1d in training mode on a channel-major (B, C, N) tensor -- the two BatchNorms of an attention layer
+// (reference models/attention.py:187-192: x = bn1(x + attention(x)); x = bn2(x + ff(x))), forward and backward (round 6:
+// the backward was aten's miopen_batch_norm_backward).  Both directions are a per-channel REDUCTION followed by an
+// elementwise pass, and the reduction's result is a handful of float64 sums per channel: under nn.SyncBatchNorm (the
+// reference trainer converts every BatchNorm, train_modelnet.py:245-246) those sums are what the ranks all-reduce between
+// the two launches -- `pooled` below -- so one rank and eight run the same kernels.
 //
 // Why: at (32, 128, 2048) the library's training forward is one workgroup per channel (128 workgroups for 256 CUs, each
 // walking its channel's 32 rows twice): 44 us where the tensor's three passes (read, read, write: 100 MB) take ~20 at the
@@ -69,19 +71,47 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
   }
 }
 
+// (C, S) partial pairs -> pooled[0 .. C) = sum a, pooled[C .. 2C) = sum b, [pooled[2C] = count]: the block the ranks
+// all-reduce under nn.SyncBatchNorm.  dA / dB (may be null): the same sums as floats (the backward's d beta / d gamma, which
+// stay per rank -- DistributedDataParallel averages parameter gradients itself).
+__global__ __launch_bounds__(kBnThreads) void bn_fold_kernel(const double* __restrict__ part, int C, int S, double count,
+                                                             int with_count, double* __restrict__ pooled,
+                                                             float* __restrict__ dA, float* __restrict__ dB) {
+  const int c = blockIdx.x * kBnThreads + threadIdx.x;
+  if (c == 0 && with_count) pooled[2 * C] = count;
+  if (c >= C) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int s = 0; s < S; ++s) {
+    t0 += part[((long)c * S + s) * 2];
+    t1 += part[((long)c * S + s) * 2 + 1];
+  }
+  pooled[c] = t0;
+  pooled[C + c] = t1;
+  if (dA) dA[c] = (float)t0;
+  if (dB) dB[c] = (float)t1;
+}
+
+// pooled (may be null): [sum x (C) | sum x^2 (C) | count] over every rank -- then the partials are not read
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __restrict__ x, int B, int C, int N,
                                                               const double* __restrict__ part, int S,
+                                                              const double* __restrict__ pooled,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float eps, float momentum, float* running_mean,
                                                               float* running_var, float* __restrict__ out,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   double t0 = 0.0, t1 = 0.0;
-  for (int s = 0; s < S; ++s) {  // (uniform addresses: broadcast loads; the same order in every workgroup)
-    t0 += part[((long)c * S + s) * 2];
-    t1 += part[((long)c * S + s) * 2 + 1];
+  double E = (double)B * (double)N;
+  if (pooled) {
+    t0 = pooled[c];
+    t1 = pooled[C + c];
+    E = pooled[2 * C];
+  } else {
+    for (int s = 0; s < S; ++s) {  // (uniform addresses: broadcast loads; the same order in every workgroup)
+      t0 += part[((long)c * S + s) * 2];
+      t1 += part[((long)c * S + s) * 2 + 1];
+    }
   }
-  const double E = (double)B * (double)N;
   const double mean = t0 / E;
   double var = t1 / E - mean * mean;
   var = var < 0.0 ? 0.0 : var;
@@ -113,6 +143,108 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
   }
 }
 
+// ---- backward: dx = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)), d gamma = sum dy xhat, d beta = sum dy ----
+// bn_bwd_reduce  grid (C, S): sum dy and sum dy xhat over the clouds b = s, s + S, ... of channel c in float64
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   int B, int C, int N, const float* __restrict__ save_mean,
+                                                                   const float* __restrict__ save_invstd,
+                                                                   double* __restrict__ part) {
+  __shared__ double red[2][kBnThreads / 64];
+  const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
+  const float mean = save_mean[c];
+  const double invstd = (double)save_invstd[c];
+  double a0 = 0.0, a1 = 0.0;
+  const bool vec = (N & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
+  for (int b = s; b < B; b += S) {
+    const float* row = x + ((long)b * C + c) * N;
+    const float* grow = dy + ((long)b * C + c) * N;
+    if (vec) {
+      const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+      const f32x4* g4 = reinterpret_cast<const f32x4*>(grow);
+      for (int i = tid; i < (N >> 2); i += kBnThreads) {
+        const f32x4 v = r4[i], g = g4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 += (double)g[e];
+          a1 += (double)g[e] * (double)(v[e] - mean);
+        }
+      }
+    } else {
+      for (int i = tid; i < N; i += kBnThreads) {
+        a0 += (double)grow[i];
+        a1 += (double)grow[i] * (double)(row[i] - mean);
+      }
+    }
+  }
+  a0 = bn_wave_sum(a0);
+  a1 = bn_wave_sum(a1);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = a0;
+    red[1][tid >> 6] = a1;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t0 = red[0][0], t1 = red[1][0];
+#pragma unroll
+    for (int w = 1; w < kBnThreads / 64; ++w) {
+      t0 += red[0][w];
+      t1 += red[1][w];
+    }
+    part[((long)c * S + s) * 2] = t0;
+    part[((long)c * S + s) * 2 + 1] = t1 * invstd;
+  }
+}
+
+// bn_bwd_apply  grid (C, B).  pooled (may be null): [sum dy (C) | sum dy xhat (C)] over every rank and count = the pooled
+// element count of the forward; then d gamma / d beta were written by bn_fold from this rank's sums.
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* dy,   // (dx may be dy)
+                                                                  int B, int C, int N, const float* __restrict__ save_mean,
+                                                                  const float* __restrict__ save_invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const double* __restrict__ part, int S,
+                                                                  const double* __restrict__ pooled,
+                                                                  const double* __restrict__ count, float* dx,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  double t0 = 0.0, t1 = 0.0;
+  double E = (double)B * (double)N;
+  if (pooled) {
+    t0 = pooled[c];
+    t1 = pooled[C + c];
+    E = *count;
+  } else {
+    for (int s = 0; s < S; ++s) {
+      t0 += part[((long)c * S + s) * 2];
+      t1 += part[((long)c * S + s) * 2 + 1];
+    }
+    if (b == 0 && tid == 0) {
+      if (dbeta) dbeta[c] = (float)t0;
+      if (dgamma) dgamma[c] = (float)t1;
+    }
+  }
+  const float mean = save_mean[c];
+  const double invstd = (double)save_invstd[c];
+  const double k = (gamma ? (double)gamma[c] : 1.0) * invstd;
+  const float kA = (float)k, kB = (float)(-k * invstd * (t1 / E)), kC = (float)(-k * (t0 / E));
+  const float* row = x + ((long)b * C + c) * N;
+  const float* grow = dy + ((long)b * C + c) * N;
+  float* orow = dx + ((long)b * C + c) * N;
+  if ((N & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(grow);
+    f32x4* o4 = reinterpret_cast<f32x4*>(orow);
+    for (int i = tid; i < (N >> 2); i += kBnThreads) {
+      const f32x4 v = r4[i], g = g4[i];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaf(g[e], kA, fmaf(v[e] - mean, kB, kC));
+      o4[i] = o;
+    }
+  } else {
+    for (int i = tid; i < N; i += kBnThreads) orow[i] = fmaf(grow[i], kA, fmaf(row[i] - mean, kB, kC));
+  }
+}
+
 }  // namespace samble
 
 using namespace samble;
@@ -132,7 +264,58 @@ extern "C" int samble_launch_bn_train_fwd(const float* x, int B, int C, int N, c
   const int S = bn_slices(B, C);
   Timed timed(kT_bn_fwd, s);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, B, C, N, (double*)ws);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, B, C, N, (const double*)ws, S, gamma, beta, eps,
-                     momentum, running_mean, running_var, out, save_mean, save_invstd);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, B, C, N, (const double*)ws, S,
+                     (const double*)nullptr, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd);
+  return (int)hipGetLastError();
+}
+
+// the forward in two halves around the ranks' all-reduce: statistics -> pooled (2 C + 1 doubles), pooled -> output
+extern "C" int samble_launch_bn_train_stats(const float* x, int B, int C, int N, double* pooled, void* ws, hipStream_t s) {
+  const int S = bn_slices(B, C);
+  Timed timed(kT_bn_fwd, s);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, B, C, N, (double*)ws);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + kBnThreads - 1) / kBnThreads), dim3(kBnThreads), 0, s, (const double*)ws, C, S,
+                     (double)B * (double)N, 1, pooled, (float*)nullptr, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bn_train_apply(const float* x, int B, int C, int N, const double* pooled, const float* gamma,
+                                            const float* beta, float eps, float momentum, float* running_mean,
+                                            float* running_var, float* out, float* save_mean, float* save_invstd, hipStream_t s) {
+  Timed timed(kT_bn_fwd, s);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, B, C, N, (const double*)nullptr, 0, pooled, gamma,
+                     beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bn_train_bwd(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                          const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
+                                          void* ws, hipStream_t s) {
+  const int S = bn_slices(B, C);
+  Timed timed(kT_bn_bwd, s);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, gamma,
+                     (const double*)ws, S, (const double*)nullptr, (const double*)nullptr, dx, dgamma, dbeta);
+  return (int)hipGetLastError();
+}
+
+// the backward in two halves around the ranks' all-reduce: this rank's sums -> pooled (2 C doubles) + d gamma / d beta
+extern "C" int samble_launch_bn_train_bwd_sums(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                               const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws,
+                                               hipStream_t s) {
+  const int S = bn_slices(B, C);
+  Timed timed(kT_bn_bwd, s);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + kBnThreads - 1) / kBnThreads), dim3(kBnThreads), 0, s, (const double*)ws, C, S, 0.0,
+                     0, pooled, dbeta, dgamma);
+  return (int)hipGetLastError();
+}
+
+extern "C" int samble_launch_bn_train_bwd_apply(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
+                                                const float* save_invstd, const float* gamma, const double* pooled,
+                                                const double* count, float* dx, hipStream_t s) {
+  Timed timed(kT_bn_bwd, s);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, gamma,
+                     (const double*)nullptr, 0, pooled, count, dx, (float*)nullptr, (float*)nullptr);
   return (int)hipGetLastError();
 }

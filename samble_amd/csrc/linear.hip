@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
   xcd_assign(chunk, b);
   // points past N-1 are clamped: those lanes recompute and rewrite point N-1's row bit for bit (no predicated store)
   const int n = min(chunk * 256 + wave * 32 + lo, N - 1);
-  const bool own = chunk * 256 + wave * 32 + lo < N;   // (CM: clamped lanes do not store -- accum is a read-modify-write)
+  const bool own = chunk * 256 + wave * 32 + lo < N;   // (CM with accum: clamped lanes do not store -- a read-modify-write)
   // grid.z slices the output tiles (otiles = tiles per slice): small launches (the blocks' coarse levels) fill the chip
   const int t0 = blockIdx.z * otiles;
   Wimg += (long)t0 * kTriTile;
@@ -277,7 +277,10 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += prev[r];
       }
-      if (own) {
+      // without `accum` the clamped lanes store too (point N-1's value again, as the point-major path does): a wave wholly
+      // past N in a tail chunk must ISSUE its 16 stores, or vmcnt(54) below is satisfied before tile t+1's DMA has landed
+      // (only 2 x 3 DMA pieces would be younger).  With `accum` such a wave has issued the 16 `prev` loads instead.
+      if (own || !accum) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oc[(long)(8 * (r >> 2) + (r & 3)) * o_rs] = acc[r];
       }
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void lin_amax_reduce_kernel(const float* __res
 // dx[c][n] = sum_o W[o][c] g[n][o] (proj_dx_tri_kernel with a run-time tile count)
 __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                             const char* __restrict__ Wtr, int otiles, int Cin, int N,
-                                                            float* __restrict__ dx, long dx_bs, const float* res) {
+                                                            float* dx, long dx_bs, const float* res) {  // (`res` may be `dx`: no __restrict__)
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth;
   const int tid = threadIdx.x;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void lin_dx_tri_kernel(const float* __restr
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void lin_dx_duo_kernel(const float* __restrict__ g, long g_bs, long g_rs,
                                                                const char* __restrict__ Wtr, int otiles, int Cin, int N,
-                                                               float* __restrict__ dx, long dx_bs, const float* res) {
+                                                               float* dx, long dx_bs, const float* res) {  // (`res` may be `dx`: no __restrict__)
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kLinDepth, NT = 64 * NW, P = kTriTile / 16 / NT;   // P: 16-byte DMA pieces per thread and tile
   static_assert(P == 3 || P == 6 || P == 12, "8, 4 or 2 waves");
@@ -645,7 +648,7 @@ template <int EPI, int NW>  // kLinLeakyBits | kLinMaskBits
 __global__ __launch_bounds__(64 * NW, 2) void lin_chain_kernel(const float* __restrict__ x, long x_bs, int N,
                                                            const char* __restrict__ Wa_rm, const char* __restrict__ Wb_tr,
                                                            int otiles, float* __restrict__ mid, long m_bs, long m_rs,
-                                                           unsigned short* __restrict__ bits, float* __restrict__ out,
+                                                           unsigned short* __restrict__ bits, float* out,   // (`res` may be `out`)
                                                            long o_bs, const float* res) {
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   constexpr int D = kChainDepth, NT = 64 * NW, P = kTriTile / 16 / NT;   // P: 16-byte DMA pieces per thread, tile and matrix
@@ -757,13 +760,24 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_chain_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[ct][r] = fmaf(tmp[r], sc2, tot[ct][r]);
     }
-    // (4 + 2 P + 4 younger operations: 14 / 20 / 32)
-    if (P == 3)
-      asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (P == 6)
-      asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // with `mid`: 4 + 2 P + 4 younger operations (14 / 20 / 32).  Without it (mid == NULL: no stores are issued) only this
+    // iteration's 2 P DMA pieces are younger than tile t+1's -- 6 / 12 / 24 -- and the larger count would let the barrier
+    // release the waves onto a slot whose DMA has not landed.  `mrow` is a kernel argument: a wave-uniform branch.
+    if (mrow) {
+      if (P == 3)
+        asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (P == 6)
+        asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      if (P == 3)
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (P == 6)
+        asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
   }
   float* ob = out + (long)b * o_bs + n;
   if (res) {  // (may be `out` itself; a channel tile's 16 loads, then its 16 stores: 16 registers, not 64)

@@ -31,7 +31,7 @@ enum TimedKernel {
   kT_gather = 19, kT_knn_seed = 20, kT_select_chain = 21, kT_bwd_rows_f32 = 22, kT_nn_prepare = 23,
   kT_edge_fwd = 24, kT_edge_bwd = 25, kT_n2p_fwd = 26, kT_n2p_bwd = 27, kT_inv_nn = 28, kT_seg_sum = 29,
   kT_edge_sums = 30, kT_knn_small = 31, kT_lin_fwd = 32, kT_lin_dx = 33, kT_lin_dw = 34, kT_lin_amax = 35,
-  kT_lin_amax_bwd = 36, kT_bn_fwd = 37, kT_lin_chain = 38,
+  kT_lin_amax_bwd = 36, kT_bn_fwd = 37, kT_lin_chain = 38, kT_bn_bwd = 39,
 };
 // the three 128 x 128 projection weights [Wq; Wk; Wv] where they live (one (384, 128) block, or three tensors)
 struct ProjW {

@@ -27,13 +27,7 @@ from . import _lib
 FUSED_PROJECTIONS = True  # False: torch.matmul for the two per-point projections of conv1 (A/B runs)
 
 
-def _sync_group(bn):
-    """The process group over which `bn` pools its statistics, or None: nn.SyncBatchNorm in training with an
-    initialised group of more than one rank (the reference trainer converts every BatchNorm, train_modelnet.py:245-246)."""
-    if not isinstance(bn, nn.SyncBatchNorm) or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
-        return None
-    group = bn.process_group if bn.process_group is not None else torch.distributed.group.WORLD
-    return group if torch.distributed.get_world_size(group) > 1 else None
+_sync_group = ops.sync_group
 
 
 def _all_sum(t: torch.Tensor, group) -> torch.Tensor:

@@ -220,9 +220,12 @@ def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torc
     return out
 
 
-def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float):
-    """nn.BatchNorm1d.forward in training mode on x (B,C,N): -> (y, batch mean (C), 1 / sqrt(batch var + eps) (C)); the
-    running estimates (may be None) get torch's momentum update in place.  csrc/batchnorm.hip."""
+def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, group=None):
+    """nn.BatchNorm1d.forward in training mode on x (B,C,N): -> (y, batch mean (C), 1 / sqrt(batch var + eps) (C), count);
+    the running estimates (may be None) get torch's momentum update in place.  csrc/batchnorm.hip.
+    group (nn.SyncBatchNorm, reference train_modelnet.py:245-246): the process group whose ranks pool the statistics --
+    the per-channel float64 sums and the element count are all-reduced between the two launches; `count` is then the
+    device scalar holding the pooled element count (the backward divides by it), None on one rank."""
     _need_gpu(x, gamma, beta, running_mean, running_var)
     x = _f32c(x)
     B, C, N = x.shape
@@ -232,10 +235,45 @@ def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, mome
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         nbytes = _lib.query("samble_bn_train_workspace_bytes", B, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        _lib.call("samble_bn_train_fwd_f32", x.data_ptr(), B, C, N, _p(gamma), _p(beta), float(eps), float(momentum),
-                  _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
-                  _stream())
-    return y, mean, invstd
+        if group is None:
+            _lib.call("samble_bn_train_fwd_f32", x.data_ptr(), B, C, N, _p(gamma), _p(beta), float(eps), float(momentum),
+                      _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
+                      _stream())
+            return y, mean, invstd, None
+        pooled = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        _lib.call("samble_bn_train_stats_f32", x.data_ptr(), B, C, N, pooled.data_ptr(), ws.data_ptr(), nbytes, _stream())
+        torch.distributed.all_reduce(pooled, group=group)
+        _lib.call("samble_bn_train_apply_f32", x.data_ptr(), B, C, N, pooled.data_ptr(), _p(gamma), _p(beta), float(eps),
+                  float(momentum), _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _stream())
+    return y, mean, invstd, pooled[2 * C:]
+
+
+def stage_bn_train_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, mean: torch.Tensor, invstd: torch.Tensor, count=None, group=None,
+                       out: Optional[torch.Tensor] = None):
+    """Backward of stage_bn_train: -> (dx, dgamma, dbeta).  x is the forward's INPUT, mean / invstd what it saved.  With
+    `group` the two per-channel sums are all-reduced between the launches and divided by `count` (the forward's pooled
+    element count); dgamma / dbeta stay this rank's sums, as torch's SyncBatchNorm leaves them for DDP to average.
+    out: where dx goes (may be dy itself)."""
+    _need_gpu(x, dy, gamma, mean, invstd)
+    x, dy = _f32c(x), _f32c(dy)
+    B, C, N = x.shape
+    with torch.cuda.device(x.device):
+        dx = out if out is not None else torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        nbytes = _lib.query("samble_bn_train_workspace_bytes", B, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        if group is None:
+            _lib.call("samble_bn_train_bwd_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
+                      _p(gamma), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, _stream())
+            return dx, dgamma, dbeta
+        pooled = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        _lib.call("samble_bn_train_bwd_sums_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
+                  pooled.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, _stream())
+        torch.distributed.all_reduce(pooled, group=group)
+        _lib.call("samble_bn_train_bwd_apply_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
+                  _p(gamma), pooled.data_ptr(), count.data_ptr(), dx.data_ptr(), _stream())
+    return dx, dgamma, dbeta
 
 
 def stage_segment_sum_rows_pair(src_edge: torch.Tensor, src_point: torch.Tensor, order: torch.Tensor, offsets: torch.Tensor,
@@ -1269,6 +1307,21 @@ def sort_chunk(attention_point_score: torch.Tensor, num_bins: int, dim: int = -1
     else:
         x_sorted, idx_sorted = torch.sort(x, dim=dim, descending=descending)
     return torch.chunk(x_sorted, num_bins, dim=dim), torch.chunk(idx_sorted, num_bins, dim=dim)
+
+
+# True (tests: SAMBLE_POOL_SINGLE_RANK=1): a SyncBatchNorm pools its statistics through the process group even when the
+# group has ONE rank -- the all-reduce is then the identity, and the pooled kernels + the collective library (RCCL on the
+# one GPU of a test box) run where otherwise only an 8-GPU node would reach them
+POOL_SINGLE_RANK = os.environ.get("SAMBLE_POOL_SINGLE_RANK", "0") == "1"
+
+
+def sync_group(bn):
+    """The process group over which `bn` pools its statistics, or None: nn.SyncBatchNorm in training mode with an
+    initialised group of more than one rank (the reference trainer converts every BatchNorm, train_modelnet.py:245-246)."""
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else torch.distributed.group.WORLD
+    return group if (torch.distributed.get_world_size(group) > 1 or POOL_SINGLE_RANK) else None
 
 
 def world_average(t: torch.Tensor) -> torch.Tensor:

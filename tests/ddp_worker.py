@@ -4,7 +4,11 @@ gloo -- the code path is the one RCCL takes on an 8-GPU node: DDP's bucketed gra
 module's own all-reduce of the nb-1 boundary quantiles inside forward (reference utils/ops.py:191-199,
 train_modelnet.py:162-166, 245-250).
 
-    RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT in the environment;  argv: OUT_DIR [BACKEND]
+    RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT in the environment;  argv: OUT_DIR [BACKEND [sampler | edgeconv | block | block_seg]]
+
+`block`: DistributedDataParallel(SyncBatchNorm.convert_sync_batchnorm(FeatureLearningBlock)) -- the reference trainer's
+recipe around the whole block (train_modelnet.py:245-250 with configs/default.yaml `syn_bn: true`).  With WORLD_SIZE=1 and
+BACKEND=nccl the same code runs over RCCL on the one GPU of the test box (RCCL refuses two ranks on one device).
 """
 import os
 import sys
@@ -73,6 +77,60 @@ def edgeconv_syncbn(rank, dev, out_dir):
     torch.save(res, os.path.join(out_dir, f"edge{rank}.pt"))
 
 
+BLK_B, BLK_N, BLK_M, BLK_SEED = 2, 256, (128, 64), 6100
+
+
+def build_block(kind="cls"):
+    """The classification (or segmentation) feature-learning block at a small size with seeded parameters (CPU)."""
+    from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
+    from tests.util import fill_parameters
+    blk = (FeatureLearningBlock(block_config("cls", M=BLK_M)) if kind == "cls"
+           else SegFeatureLearningBlock(seg_block_config(M=BLK_M)))
+    fill_parameters(blk, BLK_SEED)
+    return blk
+
+
+def block_shard(rank, device, kind="cls"):
+    """xyz clouds, the two samplers' Exp(1) noise and the upstream gradient of this rank's shard."""
+    from samble_amd import synth
+    nb = 6 if kind == "cls" else 4
+    xyz = torch.from_numpy(synth.xyz_clouds(BLK_B, BLK_N, BLK_SEED + 1, first_cloud=rank * BLK_B)).to(device)
+    noise = [torch.from_numpy(synth.exp1((BLK_B * nb, n), BLK_SEED + 2 + 10 * rank + i)).to(device)
+             for i, n in enumerate((BLK_N, BLK_M[0]))]
+    shape = (BLK_B, 3 * 1024) if kind == "cls" else (BLK_B, 128, BLK_N)
+    g = torch.from_numpy(synth.normal(shape, BLK_SEED + 20 + rank)).to(device)
+    return xyz, noise, g
+
+
+def block_step(model, blk, xyz, noise, g, kind="cls", forced=None):
+    """One forward + backward of the block; what a comparison needs, on the CPU."""
+    blk.zero_grad(set_to_none=True)
+    xin = xyz.detach().requires_grad_(True)
+    out = model(xin, noise_list=noise, forced_idx_list=forced)
+    y = out[0] if kind == "cls" else out
+    y.backward(g)
+    torch.cuda.synchronize()
+    return {
+        "y": y.detach().cpu(), "dx": xin.grad.cpu(),
+        "grads": {n: p.grad.detach().cpu().clone() for n, p in blk.named_parameters()},
+        "bufs": {n: b.detach().cpu().clone() for n, b in blk.named_buffers()},
+        "idx": [layer.idx.cpu().clone() for layer in blk.downsample_list],
+        "bounds": [[t.detach().cpu().clone() for t in layer.bin_boundaries] for layer in blk.downsample_list],
+    }
+
+
+def block_syncbn(rank, dev, out_dir, kind="cls"):
+    """BASELINE configs[3]'s recipe around the block (reference train_modelnet.py:245-250):
+    DistributedDataParallel(SyncBatchNorm.convert_sync_batchnorm(block)) on this rank's shard, two steps."""
+    blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(build_block(kind)).to(dev).train()
+    ddp = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[dev.index])
+    xyz, noise, g = block_shard(rank, dev, kind)
+    log = [block_step(ddp, blk, xyz, noise, g, kind) for _ in range(2)]
+    kinds = sorted({type(m).__name__ for m in blk.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)})
+    torch.save({"log": log, "backend": dist.get_backend(), "world": dist.get_world_size(), "bn_types": kinds},
+               os.path.join(out_dir, f"block{rank}.pt"))
+
+
 def main():
     out_dir = sys.argv[1]
     backend = sys.argv[2] if len(sys.argv) > 2 else "gloo"
@@ -86,6 +144,11 @@ def main():
         dist.init_process_group(backend)
     if what == "edgeconv":
         edgeconv_syncbn(rank, dev, out_dir)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if what in ("block", "block_seg"):
+        block_syncbn(rank, dev, out_dir, "seg" if what == "block_seg" else "cls")
         dist.barrier()
         dist.destroy_process_group()
         return

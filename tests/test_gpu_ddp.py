@@ -26,9 +26,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(tmp_path, world=2, backend="gloo", what="sampler"):
+def _run_ranks(tmp_path, world=2, backend="gloo", what="sampler", extra_env=None):
     env0 = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
-                HSA_ENABLE_IPC_MODE_LEGACY="0")
+                HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path), backend, what],
                               env=dict(env0, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -43,7 +43,7 @@ def _run_ranks(tmp_path, world=2, backend="gloo", what="sampler"):
         outs.append(out)
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
-    prefix = "rank" if what == "sampler" else "edge"
+    prefix = {"sampler": "rank", "edgeconv": "edge"}.get(what, "block")
     return [torch.load(os.path.join(tmp_path, f"{prefix}{r}.pt")) for r in range(world)]
 
 
@@ -166,3 +166,125 @@ def test_bench_eight_ranks_over_gloo_on_one_gpu():
     assert "not a scaling measurement" in line["note"]
     comm = line["comm"]
     assert comm["ranks_formed"] == 8 and comm["world_size"] == 8 and comm["backend"] == "gloo"
+
+
+def _block_single_process(W, kind, ranks, res, fused_glue):
+    """The same block in ONE process (plain BatchNorm, no process group) on the concatenation of the ranks' shards, under
+    the boundaries and the sampled indices the ranks ended each call with: per call what `ddp_worker.block_step` returns."""
+    from samble_amd import embedding
+    blk = W.build_block(kind).to(DEV).train()
+    shards = [W.block_shard(r, DEV, kind) for r in ranks]
+    xyz = torch.cat([s_[0] for s_ in shards])
+    noise = [torch.cat([s_[1][i] for s_ in shards]) for i in range(2)]
+    g = torch.cat([s_[2] for s_ in shards])
+    old = embedding.FUSED_GLUE
+    embedding.FUSED_GLUE = fused_glue
+    out = []
+    try:
+        for call in range(2):
+            for i, layer in enumerate(blk.downsample_list):
+                layer.dynamic_boundaries_enable = False
+                layer.bin_boundaries = [t.to(DEV).clone() for t in res[ranks[0]]["log"][call]["bounds"][i]]
+            forced = [torch.cat([res[r]["log"][call]["idx"][i] for r in ranks]).to(DEV) for i in range(2)]
+            out.append(W.block_step(blk, blk, xyz, noise, g, kind, forced=forced))
+    finally:
+        embedding.FUSED_GLUE = old
+    return out
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("kind", ["cls", "seg"])
+def test_block_under_ddp_and_syncbatchnorm_two_ranks(tmp_path, kind):
+    """BASELINE configs[3]'s recipe at block level (reference train_modelnet.py:245-250, configs/default.yaml:94
+    `syn_bn: true`): DistributedDataParallel(SyncBatchNorm.convert_sync_batchnorm(block)) on two ranks against ONE process
+    on the concatenated batch -- the output rows, dx, every parameter gradient (DDP leaves the MEAN over the ranks: half
+    the single-process gradient of the summed loss), every BatchNorm buffer, and both samplers' boundaries.
+
+    Under SyncBatchNorm the attention layers stay on the fused node and the own BatchNorm kernels (their per-channel
+    float64 sums all-reduced between the two launches); the single process runs plain BatchNorm over the whole batch.  The
+    samplers' boundaries are rank-averaged quantiles by the reference's design (utils/ops.py:191-199), not the whole
+    batch's: the single process takes the ranks' boundaries and sampled indices as given (as the sampler test above does)
+    and must then reproduce everything else."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_worker as W
+    what = "block" if kind == "cls" else "block_seg"
+    res = _run_ranks(tmp_path, what=what)
+    assert res[0]["world"] == 2 and res[0]["bn_types"] == ["SyncBatchNorm"], res[0]["bn_types"]
+    # EdgeConv under a 2-rank SyncBatchNorm pools through the closed forms of _EdgeMLP: the single process takes them too
+    single = _block_single_process(W, kind, (0, 1), res, fused_glue=False)
+    Bs = W.BLK_B
+    for call in range(2):
+        r0, r1 = res[0]["log"][call], res[1]["log"][call]
+        for i in range(2):   # both samplers: identical state on both ranks after the in-forward all-reduce
+            assert torch.equal(r0["bounds"][i][0], r1["bounds"][i][0]) and torch.equal(r0["bounds"][i][1], r1["bounds"][i][1])
+            assert not torch.equal(r0["idx"][i], r1["idx"][i])
+        one = single[call]
+        for r, rr in enumerate((r0, r1)):
+            rows = slice(r * Bs, (r + 1) * Bs)
+            assert _rel(rr["y"], one["y"][rows]) <= 2e-5, (call, r, "y", _rel(rr["y"], one["y"][rows]))
+            assert _rel(rr["dx"], one["dx"][rows]) <= 2e-4, (call, r, "dx", _rel(rr["dx"], one["dx"][rows]))
+        worst = {}
+        for name, want in one["grads"].items():
+            assert torch.equal(r0["grads"][name], r1["grads"][name]), f"DDP leaves the same gradient on every rank: {name}"
+            worst[name] = _rel(r0["grads"][name] * 2, want)
+        bad = {k: v for k, v in worst.items() if not v <= 5e-4}
+        assert not bad, (call, bad)
+        for name, want in one["bufs"].items():
+            for rr in (r0, r1):
+                got = rr["bufs"][name]
+                if got.dtype.is_floating_point:
+                    torch.testing.assert_close(got, want, rtol=2e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+                else:
+                    assert torch.equal(got, want), name
+        print(f"call {call}: worst gradient rel-L2 {max(worst.values()):.2e} ({max(worst, key=worst.get)})")
+
+
+def test_rccl_world_size_one_sampler_step_is_the_single_process_step(tmp_path):
+    """RCCL on the one GPU of this box (it refuses two ranks on a device, so the group has ONE rank): init_process_group
+    ("nccl", device_id=...) as bench.py and the reference (train_modelnet.py:162-166) form it, the in-forward all-reduce of
+    the boundary quantiles on device memory (utils/ops.py:191-199) and DistributedDataParallel's reducer all execute over
+    RCCL.  With one rank every collective is the identity: boundaries, indices, output and gradients must be bit for bit
+    those of the same two steps without a process group."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_worker as W
+    res = _run_ranks(tmp_path, world=1, backend="nccl")
+    assert res[0]["world"] == 1 and res[0]["backend"] == "nccl"
+    mod = W.build_module(DEV)
+    x, noise, g = W.shard(0, DEV)
+    for call in range(2):
+        mod.zero_grad(set_to_none=True)
+        xin = x.detach().requires_grad_(True)
+        (x_ds, idx), _ = mod(xin, noise=noise)
+        x_ds.backward(g)
+        rr = res[0]["log"][call]
+        assert torch.equal(mod.bin_boundaries[0].cpu(), rr["upper"]) and torch.equal(mod.bin_boundaries[1].cpu(), rr["lower"])
+        assert torch.equal(idx.cpu(), rr["idx"])
+        assert torch.equal(x_ds.detach().cpu(), rr["x_ds"]) and torch.equal(xin.grad.cpu(), rr["dx"])
+        for n, p in mod.named_parameters():
+            assert torch.equal(p.grad.cpu(), rr["grads"][n]), n
+
+
+def test_rccl_world_size_one_block_with_pooled_syncbatchnorm(tmp_path):
+    """DDP(SyncBatchNorm(block)) over a one-rank RCCL group with SAMBLE_POOL_SINGLE_RANK=1: every SyncBatchNorm takes the
+    POOLED route (statistics kernel -> all-reduce of the float64 sums over RCCL -> normalisation kernel, and the same in
+    the backward; EdgeConv's pooled closed forms) although one rank is all there is.  An all-reduce over one rank is the
+    identity, so the result must equal the un-pooled single process: the attention layers bit for bit (the pooled kernels
+    add the same partials in the same order), the whole block to rounding."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_worker as W
+    res = _run_ranks(tmp_path, world=1, backend="nccl", what="block", extra_env={"SAMBLE_POOL_SINGLE_RANK": "1"})
+    assert res[0]["world"] == 1 and res[0]["backend"] == "nccl" and res[0]["bn_types"] == ["SyncBatchNorm"]
+    single = _block_single_process(W, "cls", (0,), res, fused_glue=False)
+    for call in range(2):
+        rr, one = res[0]["log"][call], single[call]
+        assert _rel(rr["y"], one["y"]) <= 1e-6 and _rel(rr["dx"], one["dx"]) <= 1e-5, (_rel(rr["y"], one["y"]), _rel(rr["dx"], one["dx"]))
+        for name, want in one["grads"].items():
+            assert _rel(rr["grads"][name], want) <= 1e-5, (name, _rel(rr["grads"][name], want))
+        for name, want in one["bufs"].items():
+            if want.dtype.is_floating_point:
+                torch.testing.assert_close(rr["bufs"][name], want, rtol=1e-6, atol=1e-7)
+            else:
+                assert torch.equal(rr["bufs"][name], want), name

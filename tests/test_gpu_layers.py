@@ -865,7 +865,7 @@ def test_n2p_layer_as_one_node_equals_the_node_by_node_composition(B, N, group_t
 def test_batchnorm_training_forward_against_float64(B, C, N):
     """csrc/batchnorm.hip (round 5): nn.BatchNorm1d.forward in training mode (reference models/attention.py:187-192, bn1 /
     bn2) -- output, saved statistics and the running estimates against torch's BatchNorm1d in float64; the gradient through
-    `attention.batch_norm` (own forward, aten's MIOpen backward) against autograd through the float64 module."""
+    `attention.batch_norm` (own forward and, round 6, own backward) against autograd through the float64 module."""
     from samble_amd import attention as A, ops
     gen = torch.Generator().manual_seed(B * 1000 + N)
     x = (torch.randn(B, C, N, generator=gen) * 1.7 + 0.3).to("cuda:0")
@@ -880,7 +880,7 @@ def test_batchnorm_training_forward_against_float64(B, C, N):
     xd = x.double().requires_grad_(True)
     want = ref(xd)
     rm, rv = bn.running_mean.clone(), bn.running_var.clone()
-    y, mean, invstd = ops.stage_bn_train(x, bn.weight.detach(), bn.bias.detach(), rm, rv, bn.momentum, bn.eps)
+    y, mean, invstd, _ = ops.stage_bn_train(x, bn.weight.detach(), bn.bias.detach(), rm, rv, bn.momentum, bn.eps)
     assert float((y.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
     assert torch.allclose(mean.double(), xd.detach().mean((0, 2)), rtol=0, atol=1e-6)
     assert torch.allclose(invstd.double(), (xd.detach().var((0, 2), unbiased=False) + bn.eps).rsqrt(), rtol=2e-6, atol=0)
@@ -901,3 +901,42 @@ def test_batchnorm_training_forward_against_float64(B, C, N):
     # eval mode: the module itself
     bn.eval()
     assert torch.equal(A.batch_norm(bn, x), bn(x))
+
+
+@pytest.mark.gpu
+def test_frozen_batchnorm_inside_a_training_layer_uses_its_running_estimates():
+    """a layer in train() whose bn1 / bn2 were frozen with bn.eval() (fine-tuning) must normalise with the
+    running estimates and leave them, and the counters, untouched -- what nn.BatchNorm1d and the reference do
+    (models/attention.py:187-192).  The fused node always uses batch statistics, so such a layer must not take it."""
+    import copy
+    from samble_amd import attention as A
+    torch.manual_seed(9)
+    layer = A.Neighbor2PointAttention(A.attention_config("cls"), 0).to("cuda:0").train()
+    with torch.no_grad():
+        for bn in (layer.bn1, layer.bn2):
+            bn.running_mean.copy_(0.3 * torch.randn(128))
+            bn.running_var.copy_(torch.rand(128) + 0.5)
+    x = torch.from_numpy(synth.features(2, 128, 300, 3300)).to("cuda:0")
+    assert A._layer_fusable(layer, x)
+    layer.bn1.eval()
+    layer.bn2.eval()
+    assert layer.training and not A._layer_fusable(layer, x)
+    before = {n: b.clone() for n, b in layer.named_buffers()}
+    y = layer(x)
+    for n, b in layer.named_buffers():
+        assert torch.equal(b, before[n]), f"{n} changed under a frozen BatchNorm"
+    # the same layer with the fused node and the own BatchNorm switched off altogether: the stock modules' answer
+    stock = copy.deepcopy(layer)
+    old = (A.FUSED_LAYER, A.OWN_BATCHNORM)
+    A.FUSED_LAYER, A.OWN_BATCHNORM = False, False
+    try:
+        want = stock(x)
+    finally:
+        A.FUSED_LAYER, A.OWN_BATCHNORM = old
+    assert torch.equal(y, want)
+    # only bn2 frozen: bn1 still normalises with batch statistics and moves its estimates, bn2 does not
+    layer.bn1.train()
+    assert not A._layer_fusable(layer, x)
+    layer(x)
+    assert not torch.equal(layer.bn1.running_mean, before["bn1.running_mean"]) and int(layer.bn1.num_batches_tracked) == 1
+    assert torch.equal(layer.bn2.running_mean, before["bn2.running_mean"]) and int(layer.bn2.num_batches_tracked) == 0

@@ -262,3 +262,43 @@ def test_chain_equals_the_two_kernels(B, N, H):
         want = L.stage_linear_dx(dh, w1_tr, H, residual=res)
         dx, mid, _ = L.stage_linear_chain(dy, w2t_rm, w1_tr, H, L.LIN_LEAKY_MASK_BITS, bits=bits, residual=res)
         assert torch.equal(mid, dh) and torch.equal(dx, want)
+
+
+@pytest.mark.parametrize("B,N,H", [(32, 2048, 4096), (6, 1024, 2048), (9, 512, 4096), (3, 300, 1024)])
+def test_chain_without_the_intermediate_waits_for_its_weight_tiles(B, N, H):
+    """with mid == NULL no stores are issued, and the hand-counted `s_waitcnt vmcnt` of lin_chain must
+    not count them -- or the barrier releases the waves onto an LDS slot whose weight tile has not landed.  Long hidden
+    layers (128 tiles: 128 chances per wave), all three workgroup sizes (8 / 4 / 2 waves), many repetitions: the output must
+    be bit for bit the one computed WITH the intermediate, every time."""
+    from samble_amd import linear as L
+    x = torch.from_numpy(synth.features(B, 128, N, 900 + N)).to(DEV)
+    W1 = _w((H, 128), 901 + N, 0.09).to(DEV)
+    W2 = _w((128, H), 902 + N, 0.02).to(DEV)
+    w1_rm, w1_tr, w2t_rm, w2t_tr = L.ffn_weight_images(W1, W2)
+    want, mid, bits = L.stage_linear_chain(x, w1_rm, w2t_tr, H, L.LIN_LEAKY_BITS)
+    assert torch.equal(want, L.stage_linear_dx(mid, w2t_tr, H))
+    for _ in range(8):
+        out, none, b2 = L.stage_linear_chain(x, w1_rm, w2t_tr, H, L.LIN_LEAKY_BITS, want_mid=False)
+        assert none is None and torch.equal(b2, bits) and torch.equal(out, want)
+    dy = torch.from_numpy(synth.normal((B, 128, N), 903 + N)).to(DEV)
+    want_dx, _, _ = L.stage_linear_chain(dy, w2t_rm, w1_tr, H, L.LIN_LEAKY_MASK_BITS, bits=bits)
+    for _ in range(4):
+        dx, _, _ = L.stage_linear_chain(dy, w2t_rm, w1_tr, H, L.LIN_LEAKY_MASK_BITS, bits=bits, want_mid=False)
+        assert torch.equal(dx, want_dx)
+
+
+@pytest.mark.parametrize("B,N,O", [(32, 257, 2048), (16, 2048 + 5, 1024), (40, 256 + 32, 4096), (7, 512 + 17, 2048)])
+def test_channel_major_conv_tail_chunk_with_idle_waves(B, N, O):
+    """ADVICE r5 (medium): in a tail chunk with N % 256 <= 224 some waves of the channel-major lin_fwd lie wholly past N;
+    they used to issue no stores, so their `vmcnt(54)` did not wait for their share of the next weight tile's DMA -- which
+    the OTHER waves then read.  Many output tiles, repeated: bit for bit the point-major kernel's sums, and float64."""
+    from samble_amd import linear as L
+    x = torch.from_numpy(synth.features(B, 128, N, 950 + N)).to(DEV)
+    W = _w((O, 128), 951 + N, 0.09).to(DEV)
+    rm, _ = L.weight_images(W, want_tr=False)
+    want = L.stage_linear_fwd(x, rm, O).transpose(1, 2).contiguous()
+    ref = torch.einsum("oc,bcn->bon", W.double(), x.double())
+    assert _rel(want, ref) <= 2e-6
+    for _ in range(8):
+        got = L.stage_linear_fwd_cm(x, rm, O)
+        assert torch.equal(got, want)
