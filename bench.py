@@ -396,6 +396,255 @@ def extra_workloads(args):
 def init_ranks(args):
     """(rank, world, device, shared_gpus): this process's place in the job, the process group formed when WORLD_SIZE > 1
     (RCCL = backend "nccl", as the reference's trainer forms it, train_modelnet.py:162-166; gloo when the ranks share GPUs)."""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = max(torch.cuda.device_count(), 1)
+    shared_gpus = world > ndev
+    local = local % ndev
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+            else:
+                dist.init_process_group(args.backend)
+        except Exception as e:  # noqa: BLE001
+            if "EADDRINUSE" in str(e) or "address already in use" in str(e).lower():
+                sys.exit(EADDRINUSE_EXIT)  # (launch_ranks picks another port)
+            raise
+    return rank, world, dev, shared_gpus, ndev
+
+
+def run_block(args):
+    """`--workload block_cls | block_seg [--gpus N]`: with N > 1 every rank wraps the block as the reference's trainer does
+    -- DistributedDataParallel(SyncBatchNorm.convert_sync_batchnorm(block)), train_modelnet.py:245-250 -- on its own 32
+    clouds (BASELINE configs[3]: global batch 32 N)."""
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank, world, dev, shared_gpus, ndev = init_ranks(args)
+    result = measure_block(args.workload, args.steps, args.warmup, rank=rank, world=world, dev=dev,
+                           breakdown=not args.no_breakdown)
+    if rank == 0:
+        result["config"]["backend"] = dist.get_backend() if world > 1 else None
+        result["config"]["visible_gpus"] = ndev
+        if shared_gpus:
+            result["note"] = (f"{world} ranks share {ndev} GPU(s) over {args.backend}: functional check of the N>1 path "
+                              "(DDP + SyncBatchNorm + boundary all-reduce), not a scaling measurement")
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+BLOCK_FAMILIES = ["n2p_bwd", "edge_bwd", "knn", "edge_fwd", "n2p_fwd", "knn_small", "inv_nn", "seg_sum", "bwd_dq", "attn_rows",
+                  "attn_stats", "lin_fwd", "lin_dx", "lin_dw", "lin_amax", "lin_amax_bwd", "bn_fwd", "bn_bwd", "lin_chain"]
+# the families that have ever led a block step: these carry their events through the TIMED region (two event records per
+# library call, ~20 calls per step), and the one with the most time per step in that region is the dominant one
+BLOCK_CANDIDATES = ["n2p_bwd", "edge_bwd", "knn", "seg_sum", "lin_dw"]
+
+
+def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=True):
+    """BASELINE.json configs[1] (block_cls: EdgeConv x2 -> N2P -> sampler 2048->1024 -> N2P -> sampler 1024->512 -> N2P)
+    and configs[2] (block_seg: the same path down with 4 bins, interpolation + N2P back up to 2048): one step = forward +
+    backward + SGD of the whole block on B=32 clouds per rank of N=2048 xyz points resident in HBM.  world > 1 =
+    configs[3]'s recipe: DDP(SyncBatchNorm(block)), one shard of the global batch per rank, timing bracketed by barriers,
+    max over ranks.  The JSON line has the contract's shape; `roofline` is for the kernel family that takes the most time
+    per step, timed by the library's HIP events on its launch stream over the timed steps themselves."""
+    from types import SimpleNamespace
+    args = SimpleNamespace(workload=workload, steps=steps, warmup=warmup)
+    from samble_amd import _lib, synth
+    from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
+    if dev is None:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+    Bb, Nb = 32, 2048
+    torch.manual_seed(1000 * (1 if args.workload == "block_cls" else 3))
+    seg = args.workload == "block_seg"
+    blk = SegFeatureLearningBlock(seg_block_config()) if seg else FeatureLearningBlock(block_config("cls"))
+    if world > 1:
+        blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
+    blk = blk.to(dev).train()
+    model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[dev.index]) if world > 1 else blk
+    xyz = torch.from_numpy(synth.xyz_clouds(Bb, Nb, 77, first_cloud=rank * Bb)).to(dev)
+    opt = torch.optim.SGD(blk.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(xyz)
+        feat = out if seg else out[0]
+        feat.square().mean().backward()
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    _lib.timing_select(BLOCK_CANDIDATES)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = {n: _lib.timing_read(n) for n in BLOCK_CANDIDATES}
+    _lib.timing_select([])
+    timed_per_step = {n: v[0] * v[2] / args.steps for n, v in seen.items() if v}   # mean ms x launches / steps
+    dominant = max(timed_per_step, key=timed_per_step.get)
+    dom = seen[dominant]
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    comm = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        nparam = sum(p.numel() for p in blk.parameters())
+        comm = measure_collectives(dev, world, c2_floats=nparam, c2_label="c2_ddp_all_parameters_allreduce_us")
+        comm["c2_floats"] = nparam
+        comm["syncbatchnorm_layers"] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in blk.modules())
+        comm["note"] += ("; every SyncBatchNorm adds one all-reduce of 2C+1 float64 per forward and one of 2C per backward "
+                         "(csrc/batchnorm.hip between its two launches; EdgeConv: the pooled closed forms)")
+    # every family of the step over further untimed steps (EVERY rank: a step holds collectives)
+    per_step = dict(timed_per_step)
+    if breakdown:
+        _lib.timing_select(BLOCK_FAMILIES)
+        extra = 3
+        for _ in range(extra):
+            step()
+        torch.cuda.synchronize()
+        allseen = {n: _lib.timing_read(n) for n in BLOCK_FAMILIES}
+        _lib.timing_select([])
+        per_step = {n: v[0] * v[2] / extra for n, v in allseen.items() if v}
+        per_step.update(timed_per_step)   # (the candidates: the timed region's own figures)
+    ms = 1e3 * elapsed / args.steps
+    launches_per_step = dom[2] / args.steps if dom else 0
+    # algorithmic work of the dominant family per launch, averaged over its launches of a step (layers of 2048 / 1024 /
+    # 512 points): SURVEY 8(d) style, inputs read once and outputs written once, recomputation not counted
+    K, Cc = 32, 128
+    layers_n = [2048, 1024, 512] + ([1024, 2048] if seg else [])
+    if dominant in ("n2p_bwd", "n2p_fwd"):
+        # per point: its qkv row, the upstream gradient row, the K neighbour ids in; a dqkv row out
+        by = sum(Bb * n * (3 * Cc * 4 * 2 + Cc * 4 + K * 4) for n in layers_n) / len(layers_n)
+        roof = {"kernel": "n2p backward (transpose + n2p_bwd_point + n2p_bwd_gather)" if dominant == "n2p_bwd" else "n2p_attn_fwd",
+                "bound": "hbm", "achieved": round(by / (dom[0] * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "note": ("gather kernel: every point reads the K / V rows of its 32 neighbours (32 KB per point) through "
+                         "L2; the algorithmic HBM bytes are the rows read once, so the fraction is small by construction")}
+    elif dominant in ("edge_bwd", "edge_fwd"):
+        # conv2 of the EdgeConv body on B*N*K edges, 64 -> 64 channels: forward 1 product, backward 2 (dh, dW2)
+        fl = Bb * Nb * K * 2 * 64 * 64 * (2 if dominant == "edge_bwd" else 1)
+        # split-bf16 kernels (csrc/edgeconv.hip): six bf16 products per product executed; the backward executes four
+        # (y in both orientations, dh, dW2) for its two algorithmic ones, the forward one for one
+        executed = 12.0 if dominant == "edge_bwd" else 6.0
+        roof = {"kernel": "edge_mlp_bwd_tri_kernel" if dominant == "edge_bwd" else "edge_mlp_fwd_tri_kernel", "bound": "mfma",
+                "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "executed_products": executed,
+                "note": ("three bf16 planes per operand: 6 MFMA products per fp32 product; the backward recomputes the edge "
+                         "activations in both orientations (2 products, not counted) beside dh and dW2; the kernel is bound "
+                         "by vector issue (operand splits of tensors that are used once) and its waits, not by the matrix "
+                         "pipe (DESIGN 7)")}
+    elif dominant == "seg_sum":
+        by = Bb * Nb * K * 64 * 4 + 2 * Bb * Nb * 64 * 4 + Bb * Nb * K * 4
+        roof = {"kernel": "seg_sum_rows64_pair_kernel", "bound": "hbm", "achieved": round(by / (dom[0] * 1e-3) / 1e9, 1),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s"}
+    elif dominant == "lin_dw":
+        fl = sum(2.0 * Bb * n * Cc * 512 for n in layers_n) / len(layers_n)
+        roof = {"kernel": "lin_dw_tri_kernel", "bound": "mfma", "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2),
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "executed_products": 3.0}
+    else:
+        fl = sum(2.0 * Bb * n * n * Cc for n in layers_n) / len(layers_n)
+        roof = {"kernel": dominant, "bound": "mfma", "achieved": round(fl / (dom[0] * 1e-3) / 1e12, 2),
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "executed_products": 4.0}
+    roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+    if roof["bound"] == "mfma":
+        roof["frac_executed"] = round(roof["achieved"] * roof["executed_products"] / PEAK_BF16_MFMA_TFLOPS, 4)
+        roof["frac_note"] = ("frac = ALGORITHMIC fp32 flops / launch time / the dense 16-bit MFMA peak (2500 TFLOP/s); "
+                             "frac_executed counts the 16-bit products the split-plane kernel issues per fp32 product")
+    roof["us_per_launch"] = round(dom[0] * 1e3, 1)
+    roof["launches_per_step"] = round(launches_per_step, 1)
+    roof["chosen_from_ms_per_step"] = {n: round(v, 3) for n, v in timed_per_step.items()}
+    roof["chosen_how"] = f"most time per step over the {args.steps} timed steps (HIP events on the launch stream)"
+    roof["traffic"] = None
+    try:  # fabric bytes per launch of the dominant family's kernels from the newest committed rocprofv3 --pmc summary
+        import glob
+        pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc.json")))[-1]
+        pmc = json.load(open(pmc_path))
+        keys = {"n2p_bwd": ("n2p_bwd",), "n2p_fwd": ("n2p_attn_fwd",), "edge_bwd": ("edge_mlp_bwd",), "edge_fwd": ("edge_mlp_fwd",),
+                "knn": ("knn_duo",), "seg_sum": ("seg_sum_rows64",), "lin_dw": ("lin_dw_tri",)}.get(dominant, (dominant,))
+        hit = [e for k_, e in pmc["kernels"].items() if any(s_ in k_ for s_ in keys) and "traffic_bytes_per_launch" in e]
+        if hit:
+            roof["traffic"] = int(sum(e["traffic_bytes_per_launch"] * e.get("launches_per_step", 1) for e in hit)
+                                  / max(sum(e.get("launches_per_step", 1) for e in hit), 1))
+            roof["traffic_source"] = f"profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc of an earlier run of this command)"
+        if pmc.get("step_traffic_bytes"):
+            roof["step_traffic"] = int(pmc["step_traffic_bytes"])
+    except Exception:  # noqa: BLE001
+        pass
+    result = {
+        "metric": ("point-clouds/sec (feature-learning block fwd+bwd), " + ("ShapeNet-part seg block" if seg else "ModelNet40 cls block")
+                   + " B=32 N=2048->1024->512" + ("->1024->2048" if seg else "")),
+        "value": round(Bb * world * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_median": round(statistics.median(step_ms), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (unit-sphere xyz clouds with jitter and anisotropic scale, random-init weights; no dataset files offline)",
+        "config": {"workload": ("BASELINE configs[2]: SegFeatureLearningBlock" if seg else
+                                ("BASELINE configs[1]: FeatureLearningBlock" if world == 1 else
+                                 "BASELINE configs[3]: DDP(SyncBatchNorm(FeatureLearningBlock))"))
+                               + " fwd+bwd+SGD, B=32/GPU xyz (32,3,2048), EdgeConv x2, N2P x" + ("5" if seg else "3")
+                               + ", DownSampleToken x2 (" + ("4" if seg else "6") + " bins, random T=0.1, dynamic boundaries)"
+                               + (", UpSampleInterpolation x2" if seg else ""),
+                   "global_batch": Bb * world, "parallelism": f"dp{world}", "ranks": world},
+        "roofline": roof,
+        "kernel_family_ms_per_step": {n: round(v, 3) for n, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+    }
+    if comm is not None:
+        result["comm"] = comm
+    return result
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric", choices=["metric", "stress", "block_cls", "block_seg"],
+                    help="metric = BASELINE.json's B=32 N=2048->1024 (default); stress = configs[4]: B=16 N=8192->4096; "
+                         "block_cls / block_seg = configs[1] / configs[2]: the whole feature-learning block, B=32 N=2048")
+    ap.add_argument("--prewarm-steps", type=int, default=0,
+                    help="untimed steps before the --warmup steps, with the parameters put back afterwards (metric / "
+                         "stress workloads; worth ~1 %% on an idle GPU, off by default)")
+    ap.add_argument("--lr", type=float, default=1e-4,
+                    help="SGD learning rate of the synthetic step (0 keeps the weights where they are: long runs for "
+                         "power / clock probes, where 1e-4 against a fixed random gradient would blow the weights up)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the step behind the timed region")
+    ap.add_argument("--graph-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
+    ap.add_argument("--logit-map", action="store_true",
+                    help="A/B: keep the N x (N+nt) logit map in HBM (the round-1 pipeline) instead of the map-free forward")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
+    args = ap.parse_args()
+
+    if args.workload.startswith("block_"):
+        return run_block(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    global B_PER_GPU, N, M
+    if args.workload == "stress":
+        B_PER_GPU, N, M = 16, 8192, 4096
+        args.no_cpu_baseline = True  # the CPU oracle needs minutes per cloud at this size
     rank, world, dev, shared_gpus, ndev = init_ranks(args)
     local = dev.index
 

@@ -167,3 +167,27 @@ def test_local_sampler_with_several_heads_fails_like_the_reference():
     assert mod.num_heads == 4 and mod.q_depth == 32
     with pytest.raises(RuntimeError, match=r"shape '\[2, 4, 256, 32\]' is invalid for input of size 16384"):
         mod(torch.zeros(2, 128, 256))
+
+
+def test_bench_and_entry_scripts_load_without_a_gpu():
+    """bench.py must at least parse its arguments on a box without a GPU (a broken edit of the driver's contract file shows
+    up here, not at round end), and declare every workload the docs name."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for word in ("--gpus", "--steps", "--warmup", "block_cls", "block_seg", "stress"):
+        assert word in out.stdout
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for fn in ("def main(", "def measure_block(", "def run_block(", "def init_ranks(", "def cpu_baseline(", "def config0("):
+        assert fn in src, fn
+
+
+def test_a_stale_library_is_refused_by_its_abi_version(lib, monkeypatch):
+    """exported prototypes changed in place between rounds.  include/samble.h now carries SAMBLE_ABI_VERSION, the
+    library reports the one it was built from and the binding refuses any other before the first call."""
+    header = open(os.path.join(ROOT, "include", "samble.h")).read()
+    declared = int(re.search(r"#define\s+SAMBLE_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.load().samble_abi_version() == declared == lib.ABI_VERSION
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "ABI_VERSION", declared + 1)
+    with pytest.raises(lib.SambleError, match="ABI version"):
+        lib.load()
