@@ -550,7 +550,18 @@ int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, const float
  *   samble_edge_bwd_post_f32  from dusum (samble_edge_mlp_bwd_f32), D_i = sum of du over the INCOMING edges of i and R_i = sum of a over them
  *                             (samble_segment_sum_rows_f32 over samble_inverse_neighbors' lists; indeg = their counts):
  *                             d gamma1, d beta1, the per-point gradients da, db and dW2 (64, 64) = the ordered sum of
- *                             samble_edge_mlp_bwd_f32's per-wave partials */
+ *                             samble_edge_mlp_bwd_f32's per-wave partials
+ * nn.SyncBatchNorm (the reference trainer converts every BatchNorm, train_modelnet.py:245-246): each of the four entries
+ * runs in two halves around the CALLER's all-reduce (SUM) of `pooled` -- samble_edge_glue_pooled_bytes() of float64:
+ * [total 0 (64) | total 1 (64) | edge count] -- over its process group:
+ *   phase SAMBLE_EDGE_ALL    one rank: everything (pooled unused, may be NULL)
+ *   phase SAMBLE_EDGE_SUMS   the statistics kernel and this rank's totals into pooled (backward entries: d gamma / d beta
+ *                            as well -- they stay per rank, DistributedDataParallel averages parameter gradients itself)
+ *   phase SAMBLE_EDGE_APPLY  from the constants on, with the all-reduced pooled in place of the partials */
+#define SAMBLE_EDGE_ALL 0
+#define SAMBLE_EDGE_SUMS 1
+#define SAMBLE_EDGE_APPLY 2
+size_t samble_edge_glue_pooled_bytes(void);
 size_t samble_edge_glue_partials_bytes(void);
 size_t samble_edge_glue_constants_bytes(void);
 size_t samble_edge_glue_statistics_bytes(void);
@@ -560,21 +571,21 @@ size_t samble_edge_glue_statistics_bytes(void);
 int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_row_stride, const int32_t* nn, int B, int N, int K, int C, const float* gamma1,
                         const float* beta1, float eps, float* running_mean, float* running_var, float momentum,
                         int64_t* num_batches_tracked, float* S, float* Q, float* ap, float* bp, float* constants,
-                        double* statistics, double* partials, void* stream);
+                        double* statistics, double* partials, int phase, double* pooled, void* stream);
 int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, const uint8_t* kmax, const uint8_t* kmin,
                             const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
                             const float* beta2, float eps, float* running_mean, float* running_var, float momentum,
                             int64_t* num_batches_tracked, float* constants, double* statistics, float* ext, uint8_t* kext,
-                            float* out, void* stream);
+                            float* out, int phase, double* pooled, void* stream);
 /* (num_batches_tracked, both entries: nn.BatchNorm2d's int64 counter on the device, incremented by the kernel; may be NULL) */
 int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2, float* constants,
                             const double* statistics, float* sdv, float* dgamma2, float* dbeta2, double* partials,
-                            void* stream);
+                            int phase, double* pooled, void* stream);
 int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stride, const float* S, const float* R,
                              const float* dusum, const float* D, const int32_t* indeg, int B, int N, int K, int C,
                              float* constants, const double* statistics, const float* dw2_partials, int n_partials, float* da,
                              float* db, int64_t dab_row_stride, float* dgamma1, float* dbeta1, float* dW2, double* partials,
-                             void* stream);
+                             int phase, double* pooled, void* stream);
 
 /* ---- 1x1 convolutions over C = 128 input channels next to the neighbour / sampler kernels (csrc/linear.hip) --------
  * Replace, in the layers that sandwich the sampler:

@@ -67,17 +67,18 @@ _SIGNATURES = {
     "samble_edge_glue_partials_bytes": (c_size_t, []),
     "samble_edge_glue_constants_bytes": (c_size_t, []),
     "samble_edge_glue_statistics_bytes": (c_size_t, []),
+    "samble_edge_glue_pooled_bytes": (c_size_t, []),
     "samble_edge_bn1_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_edge_bn2_out_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_edge_bwd_pre_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_edge_bwd_post_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
-                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "samble_interp_blend_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                             c_void_p]),
     "samble_interp_blend_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -104,16 +104,17 @@ size_t samble_chain_flag_offset(void);
 size_t samble_edge_glue_part_bytes(void);
 size_t samble_edge_glue_cst_bytes(void);
 size_t samble_edge_glue_st_bytes(void);
+size_t samble_edge_glue_pool_bytes(void);
 int samble_launch_edge_pre(const float*, const float*, long, const int*, int, int, const float*, const float*, float, float*, float*,
-                           float, long long*, float*, float*, float*, float*, float*, double*, double*, hipStream_t);
+                           float, long long*, float*, float*, float*, float*, float*, double*, double*, int, double*, hipStream_t);
 int samble_launch_edge_post(const float*, const float*, const unsigned char*, const unsigned char*, const double*, int, int, int,
                             const float*, const float*, float, float*, float*, float, long long*, float*, double*, float*, unsigned char*,
-                            float*, hipStream_t);
+                            float*, int, double*, hipStream_t);
 int samble_launch_edge_bwd_pre(const float*, const float*, int, int, const float*, float*, const double*, float*, float*, float*,
-                               double*, hipStream_t);
+                               double*, int, double*, hipStream_t);
 int samble_launch_edge_bwd_post(const float*, const float*, long, const float*, const float*, const float*, const float*, const int*,
                                 int, int, float*, const double*, const float*, int, float*, float*, long, float*, float*, float*,
-                                double*, hipStream_t);
+                                double*, int, double*, hipStream_t);
 int samble_launch_interp_fwd(const float*, int, int, int, const int*, const float*, int, int, float*, float*, hipStream_t);
 int samble_launch_interp_bwd(const float*, int, int, int, const float*, const int*, const int*, int, int, float*, void*, hipStream_t);
 size_t samble_interp_bwd_ws_bytes(int, int, int, int);
@@ -895,6 +896,8 @@ SAMBLE_API int samble_select_chain_status_async(const void* ws, int B, int N, in
 SAMBLE_API size_t samble_edge_glue_partials_bytes(void) { return samble_edge_glue_part_bytes(); }
 SAMBLE_API size_t samble_edge_glue_constants_bytes(void) { return samble_edge_glue_cst_bytes(); }
 SAMBLE_API size_t samble_edge_glue_statistics_bytes(void) { return samble_edge_glue_st_bytes(); }
+SAMBLE_API size_t samble_edge_glue_pooled_bytes(void) { return samble_edge_glue_pool_bytes(); }
+static int edge_phase_ok(int phase, const double* pooled) { return phase == 0 || ((phase == 1 || phase == 2) && pooled); }
 
 static int edge_shape_ok(int B, int N, int K, int C) { return B > 0 && N > 0 && K == 32 && C == 64; }
 
@@ -902,16 +905,18 @@ SAMBLE_API int samble_edge_bn1_f32(const float* a, const float* b, int64_t ab_ro
                                    const float* gamma1, const float* beta1, float eps, float* running_mean,
                                    float* running_var, float momentum, int64_t* num_batches_tracked, float* S, float* Q,
                                    float* ap, float* bp,
-                                   float* constants, double* statistics, double* partials, void* stream) {
+                                   float* constants, double* statistics, double* partials, int phase, double* pooled,
+                                   void* stream) {
   if (!a || !b || !nn || !gamma1 || !beta1 || !S || !Q || !ap || !bp || !constants || !statistics || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: null pointer");
+  if (!edge_phase_ok(phase, pooled)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: phase 0, or 1 / 2 with a pooled block");
   if (!edge_shape_ok(B, N, K, C)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: built for K = 32 neighbours, 64 channels");
   if (ab_row_stride < C || (ab_row_stride & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15))
     return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: a / b rows must be 16-byte aligned, row stride >= C");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn1_f32: running statistics come as a pair");
   return done(samble_launch_edge_pre(a, b, (long)ab_row_stride, nn, B, N, gamma1, beta1, eps, running_mean, running_var, momentum,
                                      (long long*)num_batches_tracked, S, Q, ap, bp,
-                                     constants, statistics, partials, (hipStream_t)stream),
+                                     constants, statistics, partials, phase, pooled, (hipStream_t)stream),
               "samble_edge_bn1_f32");
 }
 
@@ -919,25 +924,27 @@ SAMBLE_API int samble_edge_bn2_out_f32(const float* ymax, const float* ymin, con
                                        const double* mlp_partials, int n_partials, int B, int N, int C, const float* gamma2,
                                        const float* beta2, float eps, float* running_mean, float* running_var,
                                        float momentum, int64_t* num_batches_tracked, float* constants, double* statistics,
-                                       float* ext, uint8_t* kext, float* out, void* stream) {
+                                       float* ext, uint8_t* kext, float* out, int phase, double* pooled, void* stream) {
   if (!ymax || !ymin || !kmax || !kmin || !mlp_partials || !gamma2 || !beta2 || !constants || !statistics || !ext || !kext || !out)
     return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: null pointer");
+  if (!edge_phase_ok(phase, pooled)) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: phase 0, or 1 / 2 with a pooled block");
   if (!edge_shape_ok(B, N, 32, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: built for 64 channels");
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(SAMBLE_E_INVALID, "samble_edge_bn2_out_f32: running statistics come as a pair");
   return done(samble_launch_edge_post(ymax, ymin, kmax, kmin, mlp_partials, n_partials, B, N, gamma2, beta2, eps, running_mean,
                                       running_var, momentum, (long long*)num_batches_tracked, constants, statistics, ext, kext,
-                                      out, (hipStream_t)stream),
+                                      out, phase, pooled, (hipStream_t)stream),
               "samble_edge_bn2_out_f32");
 }
 
 SAMBLE_API int samble_edge_bwd_pre_f32(const float* g, const float* ext, int B, int N, int C, const float* gamma2,
                                        float* constants, const double* statistics, float* sdv, float* dgamma2, float* dbeta2,
-                                       double* partials, void* stream) {
+                                       double* partials, int phase, double* pooled, void* stream) {
   if (!g || !ext || !gamma2 || !constants || !statistics || !sdv || !dgamma2 || !dbeta2 || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bwd_pre_f32: null pointer");
+  if (!edge_phase_ok(phase, pooled)) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_pre_f32: phase 0, or 1 / 2 with a pooled block");
   if (!edge_shape_ok(B, N, 32, C)) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_pre_f32: built for 64 channels");
   return done(samble_launch_edge_bwd_pre(g, ext, B, N, gamma2, constants, statistics, sdv, dgamma2, dbeta2, partials,
-                                         (hipStream_t)stream),
+                                         phase, pooled, (hipStream_t)stream),
               "samble_edge_bwd_pre_f32");
 }
 
@@ -945,17 +952,18 @@ SAMBLE_API int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t 
                                         const float* dusum, const float* D, const int32_t* indeg, int B, int N, int K, int C,
                                         float* constants, const double* statistics, const float* dw2_partials,
                                         int n_partials, float* da, float* db, int64_t dab_row_stride, float* dgamma1,
-                                        float* dbeta1, float* dW2, double* partials, void* stream) {
+                                        float* dbeta1, float* dW2, double* partials, int phase, double* pooled, void* stream) {
   if (!a || !b || !S || !R || !dusum || !D || !indeg || !constants || !statistics || !dw2_partials || !da || !db || !dgamma1 ||
       !dbeta1 || !dW2 || !partials)
     return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: null pointer");
+  if (!edge_phase_ok(phase, pooled)) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: phase 0, or 1 / 2 with a pooled block");
   if (!edge_shape_ok(B, N, K, C) || n_partials <= 0) return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: built for K = 32 neighbours, 64 channels");
   if (ab_row_stride < C || (ab_row_stride & 1) || dab_row_stride < C || (dab_row_stride & 1) || ((uintptr_t)a & 7) ||
       ((uintptr_t)b & 7) || ((uintptr_t)da & 7) || ((uintptr_t)db & 7))
     return fail(SAMBLE_E_INVALID, "samble_edge_bwd_post_f32: rows must be 8-byte aligned, row strides >= C");
   return done(samble_launch_edge_bwd_post(a, b, (long)ab_row_stride, S, R, dusum, D, indeg, B, N, constants, statistics,
                                           dw2_partials, n_partials, da, db, (long)dab_row_stride, dgamma1, dbeta1, dW2,
-                                          partials, (hipStream_t)stream),
+                                          partials, phase, pooled, (hipStream_t)stream),
               "samble_edge_bwd_post_f32");
 }
 

@@ -73,6 +73,43 @@ __device__ __forceinline__ int chan_totals2(const double* __restrict__ part, int
   return c;
 }
 
+// nn.SyncBatchNorm (the reference trainer converts every BatchNorm, train_modelnet.py:245-246): the two totals of a
+// finalize kernel and the edge count as ONE block of 2 * 64 + 1 doubles -- [t0 | t1 | E] -- that the caller all-reduces
+// over its process group between a launcher's "sums" phase (statistics kernel + this fold) and its "apply" phase (the
+// finalize kernel reading the block instead of the partials, then the elementwise kernels).  Gradients of gamma / beta
+// stay this rank's sums (DistributedDataParallel averages parameter gradients itself): mode 1 / 2 write them here.
+constexpr int kPoolWords = 2 * kGC + 1;
+__global__ __launch_bounds__(kFinThreads) void edge_fold_totals_kernel(const double* __restrict__ part, int nparts, double E,
+                                                                      double* __restrict__ pooled, int mode,
+                                                                      const double* __restrict__ st,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  double t0, t1;
+  const int c = chan_totals2(part, nparts, t0, t1);
+  if (threadIdx.x >= 8) return;
+  pooled[c] = t0;
+  pooled[kGC + c] = t1;
+  if (c == 0) pooled[2 * kGC] = E;
+  if (mode == 2) {          // BN2's backward: d gamma2 = sum dv yhat, d beta2 = sum dv
+    dgamma[c] = (float)t1;
+    dbeta[c] = (float)t0;
+  } else if (mode == 1) {   // BN1's backward: d gamma1 = sum du zhat = (sum du u - mu1 sum du) / sig1, d beta1 = sum du
+    dgamma[c] = (float)((t1 - st[kStMu1 + c] * t0) / st[kStSig1 + c]);
+    dbeta[c] = (float)t0;
+  }
+}
+// the totals a finalize kernel works from: the all-reduced block when there is one, the partials otherwise
+__device__ __forceinline__ int chan_totals_or_pooled(const double* __restrict__ part, int nparts, const double* __restrict__ pooled,
+                                                     double& t0, double& t1, double& E) {
+  if (pooled) {
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    t0 = pooled[c];
+    t1 = pooled[kGC + c];
+    E = pooled[2 * kGC];
+    return c;
+  }
+  return chan_totals2(part, nparts, t0, t1);
+}
+
 // ---- forward 1: S, Q of every point (edge_gather_sums) and the BN1 edge sums  sum u = K a + S,  sum u^2 = K a^2 + 2 a S + Q
 // (a, bp: rows of 64 floats at a stride of `rs` floats -- the two halves of one (points, 128) projection output)
 __global__ __launch_bounds__(256) void edge_sums_stats_kernel(const float* __restrict__ a, const float* __restrict__ bp,
@@ -127,9 +164,10 @@ __device__ __forceinline__ void bn_running_update(float* rmean, float* rvar, int
 __global__ __launch_bounds__(kFinThreads) void edge_bn1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
-                                                               float* rmean, float* rvar, float momentum, long long* nbt) {
+                                                               float* rmean, float* rvar, float momentum, long long* nbt,
+                                                               const double* __restrict__ pooled) {
   double t0, t1;
-  const int c = chan_totals2(part, nparts, t0, t1);
+  const int c = chan_totals_or_pooled(part, nparts, pooled, t0, t1, E);
   if (threadIdx.x >= 8) return;
   const double mu = t0 / E;
   double var = t1 / E - mu * mu;
@@ -167,9 +205,10 @@ __global__ __launch_bounds__(256) void edge_fold_kernel(const float* __restrict_
 __global__ __launch_bounds__(kFinThreads) void edge_bn2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, float* __restrict__ cst, double* __restrict__ st,
-                                                               float* rmean, float* rvar, float momentum, long long* nbt) {
+                                                               float* rmean, float* rvar, float momentum, long long* nbt,
+                                                               const double* __restrict__ pooled) {
   double t0, t1;
-  const int c = chan_totals2(part, nparts, t0, t1);
+  const int c = chan_totals_or_pooled(part, nparts, pooled, t0, t1, E);
   if (threadIdx.x >= 8) return;
   const double mu = t0 / E;
   double var = t1 / E - mu * mu;
@@ -260,17 +299,19 @@ __global__ __launch_bounds__(256) void edge_bwd_pre_kernel(const float* __restri
 __global__ __launch_bounds__(kFinThreads) void edge_bwd2_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                 const float* __restrict__ gamma, float* __restrict__ cst,
                                                                 const double* __restrict__ st, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta) {
+                                                                float* __restrict__ dbeta, const double* __restrict__ pooled) {
   double sdv, sdvy;
-  const int c = chan_totals2(part, nparts, sdv, sdvy);
+  const int c = chan_totals_or_pooled(part, nparts, pooled, sdv, sdvy, E);
   if (threadIdx.x >= 8) return;
   const double m1 = sdv / E, m2 = sdvy / E;
   const double sig = st[kStSig2 + c], mu = st[kStMu2 + c], sc = (double)gamma[c] / sig;
   const double c1 = -sc * m2 / sig;
   cst[kCstC1 + c] = (float)c1;
   cst[kCstC0 + c] = (float)(-sc * m1 - c1 * mu);
-  dgamma[c] = (float)sdvy;
-  dbeta[c] = (float)sdv;
+  if (!pooled) {   // (pooled: this rank's sums went out with the fold)
+    dgamma[c] = (float)sdvy;
+    dbeta[c] = (float)sdv;
+  }
 }
 
 // ---- backward 3: sums over the points of du_i (= sum_k du_ik) and of a_i du_i + b_i D_i (D_i = sum over the incoming
@@ -297,15 +338,18 @@ __global__ __launch_bounds__(256) void edge_bwd_stats_kernel(const float* __rest
 // ---- backward 4: m1' = mean du, m2' = mean du zhat over the edges; d gamma1 = sum du zhat, d beta1 = sum du
 __global__ __launch_bounds__(kFinThreads) void edge_bwd1_finalize_kernel(const double* __restrict__ part, int nparts, double E,
                                                                 float* __restrict__ cst, const double* __restrict__ st,
-                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                const double* __restrict__ pooled) {
   double sdu, raw;
-  const int c = chan_totals2(part, nparts, sdu, raw);
+  const int c = chan_totals_or_pooled(part, nparts, pooled, sdu, raw, E);
   if (threadIdx.x >= 8) return;
   const double sduz = (raw - st[kStMu1 + c] * sdu) / st[kStSig1 + c];
   cst[kCstM1p + c] = (float)(sdu / E);
   cst[kCstM2p + c] = (float)(sduz / E);
-  dgamma[c] = (float)sduz;
-  dbeta[c] = (float)sdu;
+  if (!pooled) {
+    dgamma[c] = (float)sduz;
+    dbeta[c] = (float)sdu;
+  }
 }
 
 // ---- backward 5: the per-point gradients of the two projections
@@ -373,15 +417,27 @@ extern "C" size_t samble_edge_glue_part_bytes(void) { return (size_t)kGParts * 2
 extern "C" size_t samble_edge_glue_cst_bytes(void) { return (size_t)kCstWords * sizeof(float); }
 extern "C" size_t samble_edge_glue_st_bytes(void) { return (size_t)kStWords * sizeof(double); }
 
+extern "C" size_t samble_edge_glue_pool_bytes(void) { return (size_t)kPoolWords * sizeof(double); }
+
+// phase 0: one rank, everything.  phase 1 ("sums"): up to the fold of this rank's totals into `pooled`.  phase 2 ("apply"):
+// from the finalize kernel on, the totals read from `pooled` (all-reduced by the caller in between).
+#define FOLD(partials, nparts, E, mode, st, dg, db) \
+  hipLaunchKernelGGL(edge_fold_totals_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, partials, nparts, E, pooled, mode, st, dg, db)
+
 // forward, before the MLP sweep: S, Q, BN1 constants (cst: sc1, sh1; st: mu1, sig1), running statistics (optional)
 extern "C" int samble_launch_edge_pre(const float* a, const float* b, long rs, const int* nn, int B, int N, const float* gamma1,
                                       const float* beta1, float eps, float* rmean, float* rvar, float momentum, long long* nbt, float* S,
-                                      float* Q, float* ap, float* bp, float* cst, double* st, double* part, hipStream_t s) {
+                                      float* Q, float* ap, float* bp, float* cst, double* st, double* part, int phase, double* pooled,
+                                      hipStream_t s) {
   const long np = (long)B * N;
   Timed timed(kT_edge_sums, s);
-  hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, nn, N, np, S, Q, part);
+  if (phase != 2) hipLaunchKernelGGL(edge_sums_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, nn, N, np, S, Q, part);
+  if (phase == 1) {
+    FOLD(part, kGParts, (double)np * kGK, 0, (const double*)nullptr, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(edge_bn1_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, kGParts, (double)np * kGK, gamma1, beta1, eps,
-                     cst, st, rmean, rvar, momentum, nbt);
+                     cst, st, rmean, rvar, momentum, nbt, phase == 2 ? (const double*)pooled : (const double*)nullptr);
   hipLaunchKernelGGL(edge_fold_kernel, dim3((unsigned)((np * 16 + 255) / 256)), dim3(256), 0, s, a, b, rs, cst, np * 16, ap, bp);
   return (int)hipGetLastError();
 }
@@ -392,10 +448,14 @@ extern "C" int samble_launch_edge_post(const float* ymax, const float* ymin, con
                                        const unsigned char* kmin, const double* mlp_part, int nwaves, int B, int N,
                                        const float* gamma2, const float* beta2, float eps, float* rmean, float* rvar,
                                        float momentum, long long* nbt, float* cst, double* st, float* ext, unsigned char* kext,
-                                       float* out, hipStream_t s) {
+                                       float* out, int phase, double* pooled, hipStream_t s) {
   const long np = (long)B * N;
+  if (phase == 1) {
+    FOLD(mlp_part, nwaves, (double)np * kGK, 0, (const double*)nullptr, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(edge_bn2_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, mlp_part, nwaves, (double)np * kGK, gamma2, beta2,
-                     eps, cst, st, rmean, rvar, momentum, nbt);
+                     eps, cst, st, rmean, rvar, momentum, nbt, phase == 2 ? (const double*)pooled : (const double*)nullptr);
   hipLaunchKernelGGL(edge_out_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, ymax, ymin, kmax, kmin, gamma2, cst, N, ext,
                      kext, out);
   return (int)hipGetLastError();
@@ -404,13 +464,17 @@ extern "C" int samble_launch_edge_post(const float* ymax, const float* ymin, con
 // backward, before the MLP sweep: dv rows, c0 / c1 of BN2's dense correction, d gamma2, d beta2
 extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int B, int N, const float* gamma2, float* cst,
                                           const double* st, float* dv, float* dgamma2, float* dbeta2, double* part,
-                                          hipStream_t s) {
+                                          int phase, double* pooled, hipStream_t s) {
   const long np = (long)B * N;
   const int tpc = (N + 63) / 64, ntiles = tpc * B;
   const int grid = ntiles < kGParts ? ntiles : kGParts;
-  hipLaunchKernelGGL(edge_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, g, ext, cst, st, N, tpc, ntiles, dv, part);
+  if (phase != 2) hipLaunchKernelGGL(edge_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, g, ext, cst, st, N, tpc, ntiles, dv, part);
+  if (phase == 1) {
+    FOLD(part, grid, (double)np * kGK, 2, st, dgamma2, dbeta2);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(edge_bwd2_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, grid, (double)np * kGK, gamma2, cst, st,
-                     dgamma2, dbeta2);
+                     dgamma2, dbeta2, phase == 2 ? (const double*)pooled : (const double*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -418,13 +482,19 @@ extern "C" int samble_launch_edge_bwd_pre(const float* g, const float* ext, int 
 extern "C" int samble_launch_edge_bwd_post(const float* a, const float* b, long rs, const float* S, const float* R,
                                            const float* dusum, const float* D, const int* indeg, int B, int N, float* cst,
                                            const double* st, const float* dw2part, int nwaves, float* da, float* db,
-                                           long drs, float* dgamma1, float* dbeta1, float* dW2, double* part, hipStream_t s) {
+                                           long drs, float* dgamma1, float* dbeta1, float* dW2, double* part, int phase,
+                                           double* pooled, hipStream_t s) {
   const long np = (long)B * N;
-  hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, dusum, D, np, part);
+  if (phase != 2) hipLaunchKernelGGL(edge_bwd_stats_kernel, dim3(kGParts), dim3(256), 0, s, a, b, rs, dusum, D, np, part);
+  if (phase == 1) {
+    FOLD(part, kGParts, (double)np * kGK, 1, st, dgamma1, dbeta1);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(edge_bwd1_finalize_kernel, dim3(kFinWgs), dim3(kFinThreads), 0, s, part, kGParts, (double)np * kGK, cst, st, dgamma1,
-                     dbeta1);
+                     dbeta1, phase == 2 ? (const double*)pooled : (const double*)nullptr);
   hipLaunchKernelGGL(edge_bwd_final_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, a, b, S, R, dusum, D,
                      indeg, cst, st, np, rs, da, db, drs);
   hipLaunchKernelGGL(edge_sum_parts_kernel, dim3(kGC * kGC / 16), dim3(256), 0, s, dw2part, nwaves, kGC * kGC, dW2);
   return (int)hipGetLastError();
 }
+#undef FOLD

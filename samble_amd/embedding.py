@@ -218,7 +218,9 @@ class _EdgeMLP(torch.autograd.Function):
 class _EdgeMLPFused(torch.autograd.Function):
     """_EdgeMLP with its closed forms on HIP (csrc/edge_glue.hip): BatchNorm batch statistics, their backward
     corrections, the activation and the per-point gradients as a dozen launches instead of ~250 torch ones.  Training
-    mode on one rank (SyncBatchNorm pooling and evaluation take _EdgeMLP).  ab (B,N,128) = the two per-point projections
+    mode (evaluation takes _EdgeMLP).  Under nn.SyncBatchNorm with more than one rank each glue entry runs in two halves
+    around an all-reduce of its 2 x 64 + 1 float64 totals (include/samble.h SAMBLE_EDGE_SUMS / _APPLY): the same kernels
+    on one rank and on eight.  ab (B,N,128) = the two per-point projections
     [a | b] as the ONE 1x1 convolution that forms them wrote them (read where they are, row stride 128; the gradient
     leaves as one (B,N,128) tensor the same way: no slice copies, no zero-filled halves), nn (B,N,32) -> (B,64,N)."""
 
@@ -238,6 +240,20 @@ class _EdgeMLPFused(torch.autograd.Function):
         # nn.BatchNorm2d.num_batches_tracked (int64 on the device): the statistics kernels count the batch themselves
         count = lambda bn: bn.num_batches_tracked if (bn.track_running_stats and bn.num_batches_tracked is not None
                                                        and bn.num_batches_tracked.is_cuda) else None
+        grp1, grp2 = _sync_group(bn1), _sync_group(bn2)
+
+        def glue(name, group, *args):
+            """one glue entry: whole on one rank; statistics -> all-reduce of the pooled totals -> the rest over a group"""
+            if group is None:
+                _lib.call(name, *args, 0, None, ops._stream())
+                return
+            pooled = torch.empty(_lib.query("samble_edge_glue_pooled_bytes") // 8, dtype=torch.float64, device=dev)
+            _lib.call(name, *args, 1, pooled.data_ptr(), ops._stream())
+            torch.distributed.all_reduce(pooled, group=group)
+            _lib.call(name, *args, 2, pooled.data_ptr(), ops._stream())
+
+        ctx.glue = glue
+        ctx.groups = (grp1, grp2)
         with torch.cuda.device(dev):
             f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             S, Q, ap, bp = f32(B, N, C), f32(B, N, C), f32(B, N, C), f32(B, N, C)
@@ -245,10 +261,9 @@ class _EdgeMLPFused(torch.autograd.Function):
             st = torch.empty(_lib.query("samble_edge_glue_statistics_bytes") // 8, dtype=torch.float64, device=dev)
             part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
             rm1, rv1 = run(bn1)
-            _lib.call("samble_edge_bn1_f32", a.data_ptr(), b.data_ptr(), C2, nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
-                      b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), ops._p(count(bn1)), S.data_ptr(),
-                      Q.data_ptr(), ap.data_ptr(), bp.data_ptr(), cst.data_ptr(), st.data_ptr(), part.data_ptr(),
-                      ops._stream())
+            glue("samble_edge_bn1_f32", grp1, a.data_ptr(), b.data_ptr(), C2, nn_idx.data_ptr(), B, N, K, C, g1.data_ptr(),
+                 b1.data_ptr(), float(bn1.eps), ops._p(rm1), ops._p(rv1), float(bn1.momentum), ops._p(count(bn1)), S.data_ptr(),
+                 Q.data_ptr(), ap.data_ptr(), bp.data_ptr(), cst.data_ptr(), st.data_ptr(), part.data_ptr())
             nparts = _lib.query("samble_edge_partial_count")
             ymax, ymin = f32(B, N, C), f32(B, N, C)
             kmax = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
@@ -261,10 +276,10 @@ class _EdgeMLPFused(torch.autograd.Function):
             kext = torch.empty((B, N, C), dtype=torch.uint8, device=dev)
             out = f32(B, C, N)
             rm2, rv2 = run(bn2)
-            _lib.call("samble_edge_bn2_out_f32", ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(),
-                      mpart.data_ptr(), nparts, B, N, C, g2.data_ptr(), b2.data_ptr(), float(bn2.eps), ops._p(rm2),
-                      ops._p(rv2), float(bn2.momentum), ops._p(count(bn2)), cst.data_ptr(), st.data_ptr(), ext.data_ptr(),
-                      kext.data_ptr(), out.data_ptr(), ops._stream())
+            glue("samble_edge_bn2_out_f32", grp2, ymax.data_ptr(), ymin.data_ptr(), kmax.data_ptr(), kmin.data_ptr(),
+                 mpart.data_ptr(), nparts, B, N, C, g2.data_ptr(), b2.data_ptr(), float(bn2.eps), ops._p(rm2),
+                 ops._p(rv2), float(bn2.momentum), ops._p(count(bn2)), cst.data_ptr(), st.data_ptr(), ext.data_ptr(),
+                 kext.data_ptr(), out.data_ptr())
             with torch.no_grad():
                 for bn in (bn1, bn2):   # (a counter that does not live on this device: the launch the kernels save otherwise)
                     if bn.track_running_stats and bn.num_batches_tracked is not None and count(bn) is None:
@@ -282,13 +297,15 @@ class _EdgeMLPFused(torch.autograd.Function):
         K = nn_idx.shape[2]
         dev = a.device
         g = g.float().contiguous()
+        glue = ctx.glue
+        grp1, grp2 = ctx.groups
         with torch.cuda.device(dev):
             f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             cst = cst.clone()   # (the backward adds its correction terms: the saved block stays as the forward left it)
             part = torch.empty(_lib.query("samble_edge_glue_partials_bytes") // 8, dtype=torch.float64, device=dev)
             sdv, dg2, db2 = f32(B, N, C), f32(C), f32(C)
-            _lib.call("samble_edge_bwd_pre_f32", g.data_ptr(), ext.data_ptr(), B, N, C, g2.data_ptr(), cst.data_ptr(),
-                      st.data_ptr(), sdv.data_ptr(), dg2.data_ptr(), db2.data_ptr(), part.data_ptr(), ops._stream())
+            glue("samble_edge_bwd_pre_f32", grp2, g.data_ptr(), ext.data_ptr(), B, N, C, g2.data_ptr(), cst.data_ptr(),
+                 st.data_ptr(), sdv.data_ptr(), dg2.data_ptr(), db2.data_ptr(), part.data_ptr())
             nparts = _lib.query("samble_edge_partial_count")
             du = f32(B, N, K, C)
             dwp = f32(nparts, C, C)
@@ -301,10 +318,10 @@ class _EdgeMLPFused(torch.autograd.Function):
             D, R = ops.stage_segment_sum_rows_pair(du.view(-1, C), ab.view(-1, C2)[:, :C], order, offsets, K)   # one pass
             dab = f32(B, N, C2)
             dg1, db1, dw2 = f32(C), f32(C), f32(C, C)
-            _lib.call("samble_edge_bwd_post_f32", a.data_ptr(), b.data_ptr(), C2, S.data_ptr(), R.data_ptr(), dusum.data_ptr(),
-                      D.data_ptr(), counts.data_ptr(), B, N, K, C, cst.data_ptr(), st.data_ptr(), dwp.data_ptr(), nparts,
-                      dab.data_ptr(), dab.data_ptr() + 4 * C, C2, dg1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
-                      part.data_ptr(), ops._stream())
+            glue("samble_edge_bwd_post_f32", grp1, a.data_ptr(), b.data_ptr(), C2, S.data_ptr(), R.data_ptr(), dusum.data_ptr(),
+                 D.data_ptr(), counts.data_ptr(), B, N, K, C, cst.data_ptr(), st.data_ptr(), dwp.data_ptr(), nparts,
+                 dab.data_ptr(), dab.data_ptr() + 4 * C, C2, dg1.data_ptr(), db1.data_ptr(), dw2.data_ptr(),
+                 part.data_ptr())
         return dab, None, dg1, db1, dw2.view(C, C, 1, 1), dg2, db2, None, None
 
 
@@ -346,8 +363,7 @@ class EdgeConv(nn.Module):
             ab = torch.matmul(x.permute(0, 2, 1), wab.t())
         bn1, bn2 = self.conv1[1], self.conv2[1]
         use_batch_stats = self.training or not bn1.track_running_stats
-        if (FUSED_GLUE and use_batch_stats and _sync_group(bn1) is None and _sync_group(bn2) is None
-                and bn1.momentum is not None and bn2.momentum is not None):
+        if FUSED_GLUE and use_batch_stats and bn1.momentum is not None and bn2.momentum is not None:
             return _EdgeMLPFused.apply(ab, nn_idx, bn1.weight, bn1.bias, self.conv2[0].weight, bn2.weight, bn2.bias,
                                        bn1, bn2)
         half = ab.shape[-1] // 2

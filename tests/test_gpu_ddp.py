@@ -213,8 +213,9 @@ def test_block_under_ddp_and_syncbatchnorm_two_ranks(tmp_path, kind):
     what = "block" if kind == "cls" else "block_seg"
     res = _run_ranks(tmp_path, what=what)
     assert res[0]["world"] == 2 and res[0]["bn_types"] == ["SyncBatchNorm"], res[0]["bn_types"]
-    # EdgeConv under a 2-rank SyncBatchNorm pools through the closed forms of _EdgeMLP: the single process takes them too
-    single = _block_single_process(W, kind, (0, 1), res, fused_glue=False)
+    # (EdgeConv: the same fused kernels on the ranks -- their totals all-reduced between the two halves of every glue entry --
+    # and in the single process)
+    single = _block_single_process(W, kind, (0, 1), res, fused_glue=True)
     Bs = W.BLK_B
     for call in range(2):
         r0, r1 = res[0]["log"][call], res[1]["log"][call]
@@ -274,14 +275,14 @@ def test_rccl_world_size_one_sampler_step_is_the_single_process_step(tmp_path):
 def test_rccl_world_size_one_block_with_pooled_syncbatchnorm(tmp_path):
     """DDP(SyncBatchNorm(block)) over a one-rank RCCL group with SAMBLE_POOL_SINGLE_RANK=1: every SyncBatchNorm takes the
     POOLED route (statistics kernel -> all-reduce of the float64 sums over RCCL -> normalisation kernel, and the same in
-    the backward; EdgeConv's pooled closed forms) although one rank is all there is.  An all-reduce over one rank is the
-    identity, so the result must equal the un-pooled single process: the attention layers bit for bit (the pooled kernels
-    add the same partials in the same order), the whole block to rounding."""
+    the backward; EdgeConv's glue entries in their SUMS / APPLY halves) although one rank is all there is.  An all-reduce
+    over one rank is the identity and the pooled kernels add the same partials in the same order, so the result must equal
+    the un-pooled single process."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ddp_worker as W
     res = _run_ranks(tmp_path, world=1, backend="nccl", what="block", extra_env={"SAMBLE_POOL_SINGLE_RANK": "1"})
     assert res[0]["world"] == 1 and res[0]["backend"] == "nccl" and res[0]["bn_types"] == ["SyncBatchNorm"]
-    single = _block_single_process(W, "cls", (0,), res, fused_glue=False)
+    single = _block_single_process(W, "cls", (0,), res, fused_glue=True)
     for call in range(2):
         rr, one = res[0]["log"][call], single[call]
         assert _rel(rr["y"], one["y"]) <= 1e-6 and _rel(rr["dx"], one["dx"]) <= 1e-5, (_rel(rr["y"], one["y"]), _rel(rr["dx"], one["dx"]))
