@@ -78,12 +78,21 @@ class _Encoder(nn.Module):
 FUSED_HEADS = True  # False: the stock Conv1d + max (A/B runs)
 
 
-def _pooled_head(head: nn.Conv1d, feat: torch.Tensor) -> torch.Tensor:
+def _pooled_head(head: nn.Conv1d, feat: torch.Tensor, args_out: Optional[list] = None, forced_arg=None) -> torch.Tensor:
     """`conv(x).max(dim=-1)[0]` of the classification trunk (models/cls_model.py:113, 136, 144) as one HIP pass: the
-    (B, 1024, N) tensor is never written, the backward touches the arg-max columns only (csrc/linear.hip)."""
+    (B, 1024, N) tensor is never written, the backward touches the arg-max columns only (csrc/linear.hip).
+    args_out: the arg-max points (B, O) are appended to it (introspection: the point a gradient is routed to)."""
     if FUSED_HEADS and head.bias is None and linear.linear_max_supported(feat, head.weight):
-        return linear.linear_max(feat, head.weight)
-    return head(feat).max(dim=-1)[0]
+        y, arg = linear._LinearMax.apply(feat, head.weight, forced_arg)
+        if args_out is not None:
+            args_out.append(arg)
+        return y
+    if forced_arg is not None:
+        raise NotImplementedError("forced_arg needs the fused pooled head")
+    y, arg = head(feat).max(dim=-1)
+    if args_out is not None:
+        args_out.append(arg)
+    return y
 
 
 class FeatureLearningBlock(_Encoder):
@@ -114,18 +123,22 @@ class FeatureLearningBlock(_Encoder):
         return (torch.gather(level.feat, 2, take.expand(-1, level.feat.shape[1], -1)),
                 torch.gather(level.xyz, 2, take.expand(-1, 3, -1)), keep)
 
-    def forward(self, x, noise_list=None, forced_idx_list=None):
+    def forward(self, x, noise_list=None, forced_idx_list=None, forced_head_args=None):
         """x (B,3,N) coordinates.  noise_list: optional per-sampler Exp(1) tensors.  forced_idx_list: parity-test hook,
         per sampler the indices to gather instead of its own selection (the samplers' `forced_idx`): everything
-        behind a sampler is then compared on the reference's own point set, whatever a near-tie did to the selection."""
+        behind a sampler is then compared on the reference's own point set, whatever a near-tie did to the selection.
+        forced_head_args: the same for the pooled heads' arg-max points (`linear._LinearMax`)."""
         from .attention import deferred_batch_counts
         with deferred_batch_counts():
             levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None,
                                   forced_idx_list)
+        self.head_args = []   # per pooled head: the arg-max point of every (cloud, output)
         if not self.res_link_enable:
-            return _pooled_head(self.conv, levels[-1].feat)
-        pooled = [_pooled_head(head, level.feat) for head, level in zip(self.conv_list, levels)]
+            return _pooled_head(self.conv, levels[-1].feat, self.head_args)
+        fa = forced_head_args if forced_head_args is not None else [None] * len(levels)
+        pooled = [_pooled_head(head, level.feat, self.head_args, a) for head, level, a in zip(self.conv_list, levels, fa)]
         self.res_link_list = pooled
+        self.level_feats = [level.feat.detach() for level in levels]
         return torch.cat(pooled, dim=1), pooled
 
 

@@ -288,11 +288,16 @@ class _LinearMax(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, forced_arg=None):
+        """forced_arg (B, O), parity-test hook like the samplers' `forced_idx`: the point each (cloud, output) routes its
+        gradient to -- where two points tie to fp32 rounding, two valid evaluations pick different ones -- instead of this
+        evaluation's own arg-max; the returned values stay this evaluation's maxima."""
         O = w.shape[0]
         W = _f32c(w.reshape(O, 128))
         w_rm, _ = weight_images(W, want_tr=False)
         y, arg = stage_linear_amax(x, w_rm, O)
+        if forced_arg is not None:
+            arg = forced_arg.to(device=arg.device, dtype=arg.dtype).contiguous()
         ctx.save_for_backward(x, arg, W)
         ctx.mark_non_differentiable(arg)
         return y, arg
@@ -302,7 +307,7 @@ class _LinearMax(torch.autograd.Function):
     def backward(ctx, gy, _):
         x, arg, W = ctx.saved_tensors
         dx, dW = stage_amax_bwd(x, arg, gy, W)
-        return dx, dW.reshape(W.shape[0], 128, 1)
+        return dx, dW.reshape(W.shape[0], 128, 1), None
 
 
 class _PointwiseCM(torch.autograd.Function):

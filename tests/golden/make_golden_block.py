@@ -54,7 +54,7 @@ def grads_of(blk, keys):
     return {"grad/" + k: thin(params[k].grad.detach().numpy()) for k in keys}
 
 
-def reference_block(kind, seed, B, N, M, threads=8, mkldnn=True, exact_cdist=False):
+def reference_block(kind, seed, B, N, M, threads=8, mkldnn=True, exact_cdist=False, forced_idx=None):
     """The unmodified reference block, forward + backward, under one of two equally valid fp32 evaluations of the same
     code (8 threads with oneDNN, or 1 thread without: other summation orders inside the same ATen ops).
     exact_cdist: torch.cdist in its compute_mode "donot_use_mm_for_euclid_dist" for the duration of the call -- the
@@ -65,9 +65,18 @@ def reference_block(kind, seed, B, N, M, threads=8, mkldnn=True, exact_cdist=Fal
     aten_cdist = torch.cdist
     if exact_cdist:
         torch.cdist = lambda a, b, *args, **kw: aten_cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist")
+    # forced_idx (one (B,1,M) tensor per sampler, in call order): the sampler's index generator hands back THESE indices
+    # -- the name `models.downsample` imported is rebound for the duration of the call, the reference source is untouched --
+    # so that a second evaluation can be compared on the first one's point sets
+    from models import downsample as ref_ds_mod
+    own_generator = ref_ds_mod.generating_downsampled_index
+    if forced_idx is not None:
+        queue = [t.clone() for t in forced_idx]
+        ref_ds_mod.generating_downsampled_index = lambda *a, **k: queue.pop(0)
     try:
         return _reference_block(kind, seed, B, N, M, ref_seg)
     finally:
+        ref_ds_mod.generating_downsampled_index = own_generator
         torch.cdist = aten_cdist
         torch.set_num_threads(8)
         torch.backends.mkldnn.enabled = True
@@ -80,8 +89,15 @@ def _reference_block(kind, seed, B, N, M, ref_seg):
     fill_parameters(blk, seed)
     blk.train()
     xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed + 500))
+    # the pooled heads' arg-max points (`conv(x).max(dim=-1)`, cls_model.py:113,136,144: autograd routes the gradient to
+    # that one point): recorded by forward hooks, so that a test can tell a near-tie resolved the other way from an error
+    blk.head_args = []
+    hooks = [m.register_forward_hook(lambda mod, inp, outp: blk.head_args.append(outp.detach().max(dim=-1)[1]))
+             for m in getattr(blk, "conv_list", [])]
     torch.manual_seed(seed)
     out = blk(xyz)
+    for h in hooks:
+        h.remove()
     feat = out[0] if kind == "cls" else out
     feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), seed + 900)))   # the test's upstream gradient
     return cfg, blk, feat
@@ -97,14 +113,27 @@ def self_noise(blk, other, keys):
     return np.array([float((a[k].grad - b[k].grad).abs().max() / a[k].grad.abs().max()) for k in keys], dtype=np.float64)
 
 
-def make(kind, seed, keys):
-    B, N, M = 2, 256, [128, 64]
+def make(kind, seed, keys, B=2, N=256, M=(128, 64), name=None, pick=True):
+    """pick=True (the small fixtures): the seed must be one where the reference agrees with itself (asserted).
+    pick=False (round 6, `block_cls_mid`): the seed is fixed BEFORE looking and nothing is rejected -- the reference's
+    self-noise per gradient and whether its two evaluations sample the same points are recorded, and the test's
+    tolerances are written in terms of them."""
+    M = list(M)
+    name = name or f"block_{kind}_small"
     cfg, blk, feat = reference_block(kind, seed, B, N, M)
     _, twin, feat2 = reference_block(kind, seed, B, N, M, threads=1, mkldnn=False)
-    for a, b in zip(blk.downsample_list, twin.downsample_list):
-        assert torch.equal(a.idx, b.idx), "the reference's own two evaluations sample different points: choose another seed"
+    twin_same_idx = [bool(torch.equal(a.idx, b.idx)) for a, b in zip(blk.downsample_list, twin.downsample_list)]
+    twin_clouds_same = [int((a.idx[:, 0] == b.idx[:, 0]).all(1).sum()) for a, b in zip(blk.downsample_list, twin.downsample_list)]
+    if not pick and not all(twin_same_idx):
+        # the reference's second evaluation samples other points: its gradients are those of another computation.  The
+        # noise floor that means something for a comparison THROUGH the first evaluation's indices is the second
+        # evaluation on those same indices
+        _, twin, feat2 = reference_block(kind, seed, B, N, M, threads=1, mkldnn=False,
+                                         forced_idx=[l.idx for l in blk.downsample_list])
     noise_floor = self_noise(blk, twin, keys)
-    assert noise_floor.max() < 5e-5, ("choose another seed", dict(zip(keys, noise_floor)))
+    if pick:
+        assert all(twin_same_idx), "the reference's own two evaluations sample different points: choose another seed"
+        assert noise_floor.max() < 5e-5, ("choose another seed", dict(zip(keys, noise_floor)))
     nb = cfg.downsample.bin.num_bins[0]
     torch.manual_seed(seed)
     noise0 = O.draw_noise(B * nb, N)
@@ -115,7 +144,10 @@ def make(kind, seed, keys):
                noise0=noise0.numpy(), noise1=noise1.numpy(),
                idx0=blk.downsample_list[0].idx.numpy(), idx1=blk.downsample_list[1].idx.numpy(),
                score0=blk.downsample_list[0].attention_point_score.detach().numpy(),
-               names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__))
+               names=np.array([n for n, _ in blk.named_parameters()]), torch_version=np.array(torch.__version__),
+               twin_same_idx=np.array(twin_same_idx), twin_clouds_same=np.array(twin_clouds_same),
+               seed_picked=np.array(bool(pick)),
+               **{f"head_arg{i}": a.numpy().astype(np.int16) for i, a in enumerate(getattr(blk, "head_args", []))})
     if kind == "seg":
         # The interpolation layers weigh neighbours by 1 / (d + 1e-8) (models/upsample.py:205-213) and every coarse point
         # IS a fine point: d = 0 there.  ATen's default cdist (|a|^2 + |b|^2 - 2 a.b) returns ~1e-3 of rounding noise
@@ -129,12 +161,32 @@ def make(kind, seed, keys):
         print("   exact-cdist run: indices equal to the default run:",
               [bool(torch.equal(a.idx, b.idx)) for a, b in zip(blk.downsample_list, blk_x.downsample_list)],
               "feat max|diff| %.3e" % float((feat - feat_x).abs().max()))
-    path = os.path.join(HERE, f"block_{kind}_small.npz")
+    if not pick:   # the mid-size fixture keeps the score of two clouds only (the full tensor is of no use to its test)
+        out["score0"] = out["score0"][:2]
+        if kind == "cls":
+            # ATen's default cdist (|a|^2 + |b|^2 - 2 a.b, ~1e-3 of rounding noise on 64- / 128-channel features) decides
+            # near-ties of the K-th neighbour by that noise; at 4 x 1024 rows per search a few neighbour sets differ from
+            # the exact distance order, which the HIP search reproduces.  Second run of the same unmodified reference
+            # block with cdist in its exact mode, on the first run's sampled indices: the strict comparison
+            _, blk_x, feat_x = reference_block(kind, seed, B, N, M, exact_cdist=True, forced_idx=[l.idx for l in blk.downsample_list])
+            out.update({k.replace("grad/", "exact/grad/"): v for k, v in grads_of(blk_x, keys).items()})
+            out["exact/feat"] = feat_x.detach().numpy()
+            print("   exact-cdist run on the same indices: feat max|diff| to the default run %.3e; gradient difference per key:"
+                  % float((feat - feat_x).abs().max()),
+                  {k: "%.1e" % v for k, v in zip(keys, self_noise(blk, blk_x, keys))})
+    path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"block_{kind}_small: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()),
-          "; gradient self-noise max %.1e" % noise_floor.max())
+    print(f"{name}: ok,", os.path.getsize(path) // 1024, "KiB; params", sum(p.numel() for p in blk.parameters()),
+          "; gradient self-noise max %.1e" % noise_floor.max(), "; twin samples the same points:", twin_same_idx,
+          "clouds identical per layer:", twin_clouds_same, "of", B)
 
 
 if __name__ == "__main__":
-    make("cls", 9114, GRAD_KEYS_CLS)   # (9100, the seed of rounds 2-4, sits on a LeakyReLU kink: see self_noise)
-    make("seg", 9300, GRAD_KEYS_SEG)
+    which = set(sys.argv[1:])
+    if not which or "small" in which:
+        make("cls", 9114, GRAD_KEYS_CLS)   # (9100, the seed of rounds 2-4, sits on a LeakyReLU kink: see self_noise)
+        make("seg", 9300, GRAD_KEYS_SEG)
+    if not which or "mid" in which:
+        # round 6 (verdict r5: "block fixtures are tiny and seed-picked"): four clouds of 1024 points through
+        # 1024 -> 512 -> 256, the seed written down before the first run, nothing rejected
+        make("cls", 9500, GRAD_KEYS_CLS, B=4, N=1024, M=(512, 256), name="block_cls_mid", pick=False)
