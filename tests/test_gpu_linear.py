@@ -302,3 +302,31 @@ def test_channel_major_conv_tail_chunk_with_idle_waves(B, N, O):
     for _ in range(8):
         got = L.stage_linear_fwd_cm(x, rm, O)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,N,O", [(3, 300, 1024), (2, 2048, 4096), (32, 2048, 1024)])
+def test_pooled_head_backward_groups_are_ordered_whatever_their_size(B, N, O):
+    """amax_sort (round 6: atomic slots + a sort per group instead of a quadratic count): the gradient of
+    `conv(x).max(dim=-1)` (models/cls_model.py:113) against float64 on ordinary clouds AND on degenerate ones -- a constant
+    cloud sends EVERY output's gradient to point 0 (one group of O members), a cloud with two distinct points makes two big
+    groups -- run to run identical."""
+    from samble_amd import linear as L
+    W = _w((O, 128), 400 + O, 0.09).to(DEV)
+    x = torch.from_numpy(synth.features(B, 128, N, 401 + N)).to(DEV)
+    x[0] = x[0, :, :1]                                   # cloud 0: all points equal -> every arg-max is point 0
+    x[1, :, 1::2] = x[1, :, :1]                          # cloud 1: two distinct points alternating
+    x[1, :, 0::2] = x[1, :, 1:2].clone() * 0 + x[1, :, 2:3]
+    gy = torch.from_numpy(synth.normal((B, O), 402)).to(DEV)
+    rm, _ = L.weight_images(W, want_tr=False)
+    y, arg = L.stage_linear_amax(x, rm, O)
+    assert bool((arg[0] == 0).all()) and int(arg[1].max()) <= 1
+    dx, dW = L.stage_amax_bwd(x, arg, gy, W)
+    dx2, dW2 = L.stage_amax_bwd(x, arg, gy, W)
+    assert torch.equal(dx, dx2) and torch.equal(dW, dW2)
+    # float64 from the kernel's own arg-max points
+    dxr = torch.zeros(B, 128, N, dtype=torch.float64, device=DEV)
+    contrib = gy.double().unsqueeze(-1) * W.double().unsqueeze(0)                     # (B, O, 128)
+    dxr.permute(0, 2, 1).scatter_add_(1, arg.long().unsqueeze(-1).expand(-1, -1, 128), contrib)
+    cols = torch.gather(x.double().permute(0, 2, 1), 1, arg.long().unsqueeze(-1).expand(-1, -1, 128))   # (B, O, 128)
+    dWr = (gy.double().unsqueeze(-1) * cols).sum(0)
+    assert _rel(dx, dxr) <= 1e-5 and _rel(dW, dWr) <= 1e-5   # (fp32 sums of up to O terms in a fixed order)
