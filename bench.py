@@ -406,8 +406,13 @@ def init_ranks(args):
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or getattr(args, "force_process_group", False):
+        # (--force-process-group: a ONE-rank group -- the N > 1 code path end to end, DDP's reducer, the in-forward
+        # all-reduce and the collectives' report, over RCCL on a single GPU; tests/test_gpu_ddp.py)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         try:
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
@@ -427,16 +432,17 @@ def run_block(args):
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank, world, dev, shared_gpus, ndev = init_ranks(args)
+    grouped = dist.is_initialized()
     result = measure_block(args.workload, args.steps, args.warmup, rank=rank, world=world, dev=dev,
                            breakdown=not args.no_breakdown)
     if rank == 0:
-        result["config"]["backend"] = dist.get_backend() if world > 1 else None
+        result["config"]["backend"] = dist.get_backend() if grouped else None
         result["config"]["visible_gpus"] = ndev
         if shared_gpus:
             result["note"] = (f"{world} ranks share {ndev} GPU(s) over {args.backend}: functional check of the N>1 path "
                               "(DDP + SyncBatchNorm + boundary all-reduce), not a scaling measurement")
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -452,12 +458,13 @@ BLOCK_CANDIDATES = ["n2p_bwd", "edge_bwd", "knn", "seg_sum", "lin_dw"]
 def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=True):
     """BASELINE.json configs[1] (block_cls: EdgeConv x2 -> N2P -> sampler 2048->1024 -> N2P -> sampler 1024->512 -> N2P)
     and configs[2] (block_seg: the same path down with 4 bins, interpolation + N2P back up to 2048): one step = forward +
-    backward + SGD of the whole block on B=32 clouds per rank of N=2048 xyz points resident in HBM.  world > 1 =
+    backward + SGD of the whole block on B=32 clouds per rank of N=2048 xyz points resident in HBM.  grouped =
     configs[3]'s recipe: DDP(SyncBatchNorm(block)), one shard of the global batch per rank, timing bracketed by barriers,
     max over ranks.  The JSON line has the contract's shape; `roofline` is for the kernel family that takes the most time
     per step, timed by the library's HIP events on its launch stream over the timed steps themselves."""
     from types import SimpleNamespace
     args = SimpleNamespace(workload=workload, steps=steps, warmup=warmup)
+    grouped = dist.is_available() and dist.is_initialized()   # (world > 1, or a forced one-rank group)
     from samble_amd import _lib, synth
     from samble_amd.blocks import FeatureLearningBlock, SegFeatureLearningBlock, block_config, seg_block_config
     if dev is None:
@@ -467,10 +474,10 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
     torch.manual_seed(1000 * (1 if args.workload == "block_cls" else 3))
     seg = args.workload == "block_seg"
     blk = SegFeatureLearningBlock(seg_block_config()) if seg else FeatureLearningBlock(block_config("cls"))
-    if world > 1:
+    if grouped:
         blk = torch.nn.SyncBatchNorm.convert_sync_batchnorm(blk)
     blk = blk.to(dev).train()
-    model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[dev.index]) if world > 1 else blk
+    model = torch.nn.parallel.DistributedDataParallel(blk, device_ids=[dev.index]) if grouped else blk
     xyz = torch.from_numpy(synth.xyz_clouds(Bb, Nb, 77, first_cloud=rank * Bb)).to(dev)
     opt = torch.optim.SGD(blk.parameters(), lr=1e-4)
     # a fixed upstream gradient of the block's output, as the metric workload drives its layer (rounds 3-5 put a
@@ -490,7 +497,7 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
         step()
     _lib.timing_select(BLOCK_CANDIDATES)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -499,7 +506,7 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
         step()
         marks[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     seen = {n: _lib.timing_read(n) for n in BLOCK_CANDIDATES}
@@ -509,7 +516,7 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
     dom = seen[dominant]
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     comm = None
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -637,6 +644,8 @@ def main():
                     help="skip the short stress / block_cls / block_seg runs behind the headline line's `workloads`")
     ap.add_argument("--logit-map", action="store_true",
                     help="A/B: keep the N x (N+nt) logit map in HBM (the round-1 pipeline) instead of the map-free forward")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="form a process group even for --gpus 1 (a one-rank group: the N > 1 code path over RCCL on one GPU)")
     ap.add_argument("--backend", default="nccl",
                     help="nccl (= RCCL, default) or gloo (ranks sharing a GPU: functional check of the N>1 path)")
     args = ap.parse_args()
@@ -651,6 +660,7 @@ def main():
         B_PER_GPU, N, M = 16, 8192, 4096
         args.no_cpu_baseline = True  # the CPU oracle needs minutes per cloud at this size
     rank, world, dev, shared_gpus, ndev = init_ranks(args)
+    grouped = dist.is_initialized()
     local = dev.index
 
     from samble_amd import _lib, ops, sampler_config, synth
@@ -669,7 +679,7 @@ def main():
         mod.bin_tokens.copy_(torch.from_numpy(tok))
     mod = mod.to(dev)
     model = mod
-    if world > 1:
+    if grouped:
         model = torch.nn.parallel.DistributedDataParallel(mod, device_ids=[local])
     opt = torch.optim.SGD(mod.parameters(), lr=args.lr)
 
@@ -743,7 +753,7 @@ def main():
     cand = ["knn", "attn_stats", "attn_rows", "bwd_dq"] if tri else [dominant]
     _lib.timing_select(cand)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -752,7 +762,7 @@ def main():
         step()
         marks[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     seen = {n: _lib.timing_read(n) for n in cand}
@@ -761,7 +771,7 @@ def main():
     _lib.timing_select([])
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     comm = None
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -830,8 +840,8 @@ def main():
             "config": {"workload": f"one DownSampleToken layer fwd+bwd+SGD, cls layer 0: B={B_PER_GPU}/GPU C=128 N={N}->M={M} "
                                    "nb=6 K=32 sparse_col_sqr random T=0.1 dynamic boundaries",
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}",
-                       "backend": (dist.get_backend() if world > 1 else None),
-                       "ranks": (dist.get_world_size() if world > 1 else 1),
+                       "backend": (dist.get_backend() if grouped else None),
+                       "ranks": (dist.get_world_size() if grouped else 1),
                        "visible_gpus": ndev},
             "step_fraction_of_mfma_roofline": round(
                 (fl["fwd"] + fl["bwd"]) * B_PER_GPU / (ms_per_step * 1e-3) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
@@ -1023,7 +1033,7 @@ def main():
             # most time, a few steps each after the headline's timed region (their own full lines: --workload <name>)
             result["workloads"] = extra_workloads(args)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

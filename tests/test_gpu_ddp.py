@@ -293,3 +293,25 @@ def test_rccl_world_size_one_block_with_pooled_syncbatchnorm(tmp_path):
                 torch.testing.assert_close(rr["bufs"][name], want, rtol=1e-6, atol=1e-7)
             else:
                 assert torch.equal(rr["bufs"][name], want), name
+
+
+@pytest.mark.parametrize("workload", ["metric", "block_cls"])
+def test_bench_multi_rank_path_over_rccl_with_one_rank(workload):
+    """`bench.py --force-process-group`: the N > 1 code path of the benchmark -- init_process_group("nccl", device_id=...),
+    DistributedDataParallel (around SyncBatchNorm(block) for the block workload), the barriers, the max-over-ranks
+    all-reduce, the collectives' report -- on a ONE-rank RCCL group, which is all a one-GPU box can form (RCCL refuses two
+    ranks on a device).  What the driver's 8-GPU launch will run, minus the other seven ranks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-process-group", "--steps", "3", "--warmup", "2",
+           "--no-extra-workloads", "--no-cpu-baseline", "--no-graph", "--workload", workload]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    comm = line["comm"]
+    assert comm["backend"] == "nccl" and comm["ranks_formed"] == 1 and comm["world_size"] == 1
+    assert comm["c1_boundary_allreduce_5_floats_us"] > 0
+    if workload == "block_cls":
+        assert comm["syncbatchnorm_layers"] == 10 and line["config"]["backend"] == "nccl"
