@@ -617,7 +617,8 @@ int samble_edge_bwd_post_f32(const float* a, const float* b, int64_t ab_row_stri
  *   samble_linear_dw_tri_f32        dW[o][c] = sum_{b,n} g[b][n][o] x[b][c][n] as (O, 128); O a multiple of 128; per-workgroup
  *                                   partials in ws, summed in a fixed order (deterministic, no float atomics)
  *   samble_amax_bwd_f32             backward of samble_linear_amax_fwd_tri_f32 for upstream gy (B, O): the arg-max columns
- *                                   of dx (which must be ZERO on entry) and dW (O, 128); outputs grouped by point with a
+ *                                   are ADDED to dx_inout (zeros, or another gradient of the same tensor: one wave owns a
+ *                                   column) and dW (O, 128) is written; outputs grouped by point with a
  *                                   counting sort, sums in ascending output / cloud order (deterministic).  An exact tie of
  *                                   the maximum goes to the lowest point index (torch.amax's backward splits it evenly). */
 #define SAMBLE_LIN_PLAIN 0
@@ -705,7 +706,7 @@ int samble_bn_train_bwd_apply_f32(const float* x, const float* dy, int B, int C,
                                   float* dx, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
-                        int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
+                        int O, float* dx_inout, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- measurement hook (bench.py; the only entry points that are not part of the path) ------------------
  * The library records HIP events around its own launches of the selected kernels, on the stream each is

@@ -9,6 +9,7 @@ level, the segmentation block walks the list back up.  The MLP heads, STN and tr
 (SURVEY.md section 2)."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -52,13 +53,16 @@ class _Encoder(nn.Module):
         return layer(feat, xyz, forced_idx=forced_idx)
 
     def _encode(self, xyz: torch.Tensor, noise_list: Optional[Sequence], pre_select=None,
-                forced_idx_list: Optional[Sequence] = None) -> List[_Level]:
+                forced_idx_list: Optional[Sequence] = None, on_level=None) -> List[_Level]:
+        """on_level(i, feat) -> feat: called with every level's features before anything else consumes them (the
+        classification trunk pools a level there, so that the head and the sampler share one backward node)."""
         stacked = []
         feat = xyz
         for edge_conv in self.embedding_list:      # each EdgeConv feeds the next; all of them are concatenated
             feat = edge_conv(feat)
             stacked.append(feat)
-        level = _Level(self.feature_learning_layer_list[0](torch.cat(stacked, dim=1)), xyz[:, :3, :])
+        tap = on_level if on_level is not None else (lambda i, f: f)
+        level = _Level(tap(0, self.feature_learning_layer_list[0](torch.cat(stacked, dim=1))), xyz[:, :3, :])
         levels = [level]
         for i in range(len(self.downsample_list)):
             noise = noise_list[i] if noise_list is not None else None
@@ -69,13 +73,14 @@ class _Encoder(nn.Module):
             (feat, picked), dropped = self._run_sampler(i, feat_in, xyz_in, noise, forced)
             if remap is not None:
                 picked = torch.gather(remap.unsqueeze(1), 2, picked)
-            level = _Level(self.feature_learning_layer_list[i + 1](feat), ops.gather_by_idx(level.xyz, picked),
+            level = _Level(tap(i + 1, self.feature_learning_layer_list[i + 1](feat)), ops.gather_by_idx(level.xyz, picked),
                            picked, dropped)
             levels.append(level)
         return levels
 
 
 FUSED_HEADS = True  # False: the stock Conv1d + max (A/B runs)
+SPLIT_HEADS = os.environ.get("SAMBLE_SPLIT_HEADS", "1") != "0"  # False: the pooled heads as consumers of their own (a zero fill + a dense add per level in the backward)
 
 
 def _pooled_head(head: nn.Conv1d, feat: torch.Tensor, args_out: Optional[list] = None, forced_arg=None) -> torch.Tensor:
@@ -129,14 +134,37 @@ class FeatureLearningBlock(_Encoder):
         behind a sampler is then compared on the reference's own point set, whatever a near-tie did to the selection.
         forced_head_args: the same for the pooled heads' arg-max points (`linear._LinearMax`)."""
         from .attention import deferred_batch_counts
+        n_heads = len(self.conv_list) if self.res_link_enable else 1
+        self.head_args = [None] * n_heads   # per pooled head: the arg-max point of every (cloud, output)
+        fa = forced_head_args
+        fused = self.res_link_enable and FUSED_HEADS and SPLIT_HEADS
+        pooled_early = []
+
+        def pool_level(i, feat):
+            """the level's pooled head where the level is produced: head and onward path as ONE autograd node"""
+            head = self.conv_list[i]
+            if not (head.bias is None and linear.linear_max_supported(feat, head.weight)):
+                pooled_early.append(None)
+                return feat
+            y, arg, onward = linear._LinearMaxSplit.apply(feat, head.weight, fa[i] if fa is not None else None)
+            pooled_early.append(y)
+            self.head_args[i] = arg
+            return onward
+
+        def pool_late(i, head, feat):
+            got = []
+            y = _pooled_head(head, feat, got, fa[i] if fa is not None else None)
+            self.head_args[i] = got[-1]
+            return y
+
         with deferred_batch_counts():
             levels = self._encode(x, noise_list, self._fps_subset if (self.fps and self.res_link_enable) else None,
-                                  forced_idx_list)
-        self.head_args = []   # per pooled head: the arg-max point of every (cloud, output)
+                                  forced_idx_list, pool_level if fused else None)
         if not self.res_link_enable:
-            return _pooled_head(self.conv, levels[-1].feat, self.head_args)
-        fa = forced_head_args if forced_head_args is not None else [None] * len(levels)
-        pooled = [_pooled_head(head, level.feat, self.head_args, a) for head, level, a in zip(self.conv_list, levels, fa)]
+            return pool_late(0, self.conv, levels[-1].feat)
+        early = pooled_early if fused else [None] * len(levels)
+        pooled = [y if y is not None else pool_late(i, head, level.feat)
+                  for i, (y, head, level) in enumerate(zip(early, self.conv_list, levels))]
         self.res_link_list = pooled
         self.level_feats = [level.feat.detach() for level in levels]
         return torch.cat(pooled, dim=1), pooled

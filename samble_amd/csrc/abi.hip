@@ -1210,14 +1210,14 @@ SAMBLE_API size_t samble_amax_bwd_workspace_bytes(int B, int N, int O) {
 }
 
 SAMBLE_API int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy,
-                                   const float* W, int O, float* dx_zeroed, int64_t dx_bs, float* dW, void* ws,
+                                   const float* W, int O, float* dx_inout, int64_t dx_bs, float* dW, void* ws,
                                    size_t ws_bytes, void* stream) {
-  if (!x || !arg || !gy || !W || !dx_zeroed || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: null pointer");
+  if (!x || !arg || !gy || !W || !dx_inout || !dW || !ws) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: null pointer");
   if (C != 128 || B <= 0 || N <= 0 || O <= 0 || (O & 3) || N > 32767 || O > 8192)
     return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: C must be 128, N <= 32767, O <= 8192 and a multiple of 4");
   if (((size_t)N + 4 + (size_t)O) * 4 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_amax_bwd_f32: N + O too large for LDS");
   if (ws_bytes < samble_amax_bwd_ws_bytes(B, N, O)) return fail(SAMBLE_E_WORKSPACE, "samble_amax_bwd_f32: workspace too small");
-  return done(samble_launch_amax_bwd(x, x_bs, B, N, arg, gy, W, O, dx_zeroed, dx_bs, dW, ws, (hipStream_t)stream),
+  return done(samble_launch_amax_bwd(x, x_bs, B, N, arg, gy, W, O, dx_inout, dx_bs, dW, ws, (hipStream_t)stream),
               "samble_amax_bwd_f32");
 }
 

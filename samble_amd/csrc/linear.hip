@@ -1151,8 +1151,13 @@ __global__ __launch_bounds__(256) void amax_dx_kernel(int N, const float* __rest
       a0 = fmaf(gv, W[(long)o * 128 + lane], a0);
       a1 = fmaf(gv, W[(long)o * 128 + lane + 64], a1);
     }
-    dx[(long)b * dx_bs + (long)lane * N + n] = a0;
-    dx[(long)b * dx_bs + (long)(lane + 64) * N + n] = a1;
+    // += : the column of a point is this wave's alone, so the caller may hand over a buffer that already holds ANOTHER
+    // gradient of the same tensor (the sampler's dx behind a pooled head: no zero fill, no add launch); on zeros it is a store
+    float* d0 = dx + (long)b * dx_bs + (long)lane * N + n;
+    float* d1 = dx + (long)b * dx_bs + (long)(lane + 64) * N + n;
+    const float p0 = *d0, p1 = *d1;
+    *d0 = p0 + a0;
+    *d1 = p1 + a1;
   }
 }
 
@@ -1462,7 +1467,7 @@ extern "C" int samble_launch_linear_dw(const float* g, long g_bs, long g_rs, con
 
 extern "C" size_t samble_amax_bwd_ws_bytes(int B, int N, int O) { return (size_t)B * ((size_t)N + 2 + 2 * (size_t)O) * sizeof(int); }
 
-// dx must be ZERO on entry (the kernels write the arg-max columns only)
+// dx: zeros, or another gradient of the same tensor, on entry -- the arg-max columns are ADDED to (one wave per column)
 extern "C" int samble_launch_amax_bwd(const float* x, long x_bs, int B, int N, const int* arg, const float* gy,
                                       const float* W, int O, float* dx, long dx_bs, float* dW, void* ws, hipStream_t s) {
   const size_t lds = (((size_t)N + 4) & ~(size_t)3) * sizeof(int) + (size_t)O * sizeof(int);

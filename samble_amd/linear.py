@@ -10,6 +10,8 @@ products on the bf16 matrix cores with split fp32 operands (fp32-equivalent, csr
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -195,14 +197,18 @@ def stage_linear_dw_cm(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return dW if C == 128 else dW[:, :C]
 
 
-def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor):
-    """Backward of stage_linear_amax: -> (dx (B,128,N), zero outside the arg-max columns; dW (O,128))."""
-    _need_gpu(x, arg, gy, W)
+def stage_amax_bwd(x: torch.Tensor, arg: torch.Tensor, gy: torch.Tensor, W: torch.Tensor, into: Optional[torch.Tensor] = None):
+    """Backward of stage_linear_amax: -> (dx (B,128,N), zero outside the arg-max columns; dW (O,128)).
+    into: a contiguous float32 (B,128,N) tensor holding ANOTHER gradient of x -- the arg-max columns are added to it in
+    place and it is returned as dx (no zero fill, no separate add)."""
+    _need_gpu(x, arg, gy, W, into)
     x, gy, W = _f32c(x), _f32c(gy), _f32c(W)
     B, C, N = x.shape
     O = W.shape[0]
     with torch.cuda.device(x.device):
-        dx = torch.zeros_like(x)
+        if into is not None:
+            assert into.shape == x.shape and into.dtype == torch.float32 and into.is_contiguous()
+        dx = into if into is not None else torch.zeros_like(x)
         dW = torch.empty((O, 128), dtype=torch.float32, device=x.device)
         nbytes = _lib.query("samble_amax_bwd_workspace_bytes", B, N, O)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -307,6 +313,42 @@ class _LinearMax(torch.autograd.Function):
     def backward(ctx, gy, _):
         x, arg, W = ctx.saved_tensors
         dx, dW = stage_amax_bwd(x, arg, gy, W)
+        return dx, dW.reshape(W.shape[0], 128, 1), None
+
+
+class _LinearMaxSplit(torch.autograd.Function):
+    """(x, w) -> (Conv1d(128->O, no bias)(x).max(dim=-1)[0], arg, x): the pooled head of a level TOGETHER with the tensor
+    that goes on to the sampler (models/cls_model.py:113, 132-136: the level's features feed both).  Forward is _LinearMax
+    plus a view; the point is the backward: autograd hands over both gradients at once, so the head's sparse gradient --
+    O columns per cloud -- is added INTO the gradient that came back from the sampler, where two separate consumers cost a
+    zero-filled (B,128,N) tensor and a dense add per level (stock fill + add kernels, 0.05 ms per block step).  Same sums:
+    column = other gradient + the head's column sum."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, x, w, forced_arg=None):
+        O = w.shape[0]
+        W = _f32c(w.reshape(O, 128))
+        w_rm, _ = weight_images(W, want_tr=False)
+        y, arg = stage_linear_amax(x, w_rm, O)
+        if forced_arg is not None:
+            arg = forced_arg.to(device=arg.device, dtype=arg.dtype).contiguous()
+        ctx.save_for_backward(x, arg, W)
+        ctx.mark_non_differentiable(arg)
+        return y, arg, x.view_as(x)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, gy, _, gx):
+        x, arg, W = ctx.saved_tensors
+        into = None
+        if gx is not None:
+            # the sampler's gradient is this node's to keep (a fresh tensor from the node behind): accumulate in place unless
+            # it is not a plain dense float32 tensor
+            into = gx if (gx.dtype == torch.float32 and gx.is_contiguous() and not gx.requires_grad) else gx.float().contiguous()
+        if gy is None:
+            return into, None, None
+        dx, dW = stage_amax_bwd(x, arg, gy, W, into=into)
         return dx, dW.reshape(W.shape[0], 128, 1), None
 
 
