@@ -687,23 +687,28 @@ int samble_linear_dw_cm_f32(const float* g, int64_t g_bs, const float* x, int64_
                                     = the same sums as float32: they stay per rank (DistributedDataParallel averages
                                     parameter gradients itself, as torch's SyncBatchNorm leaves them)
      samble_bn_train_bwd_apply_f32  dx from the all-reduced sums; count = device pointer to the pooled element count
-                                    (the forward's pooled + 2 C) */
+                                    (the forward's pooled + 2 C)
+   act_slope: the LeakyReLU behind the normalisation (models/upsample.py:142-150: Conv1d, BatchNorm1d, LeakyReLU(0.2)) in the
+   same passes -- forward out = v > 0 ? v : act_slope v in the normalisation's epilogue; backward: dy is the gradient of the
+   ACTIVATED output and is masked by the sign of the normalised value, re-formed from x, save_mean, save_invstd, gamma and
+   beta by the same float expression (the activation's output is never read).  1.0f = no activation (beta unused). */
 size_t samble_bn_train_workspace_bytes(int B, int C);
 int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps, float momentum,
-                            float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd, void* ws,
-                            size_t ws_bytes, void* stream);
+                            float* running_mean, float* running_var, float* out, float* save_mean, float* save_invstd,
+                            float act_slope, void* ws, size_t ws_bytes, void* stream);
 int samble_bn_train_bwd_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean, const float* save_invstd,
-                            const float* gamma, float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+                            const float* gamma, float* dx, float* dgamma, float* dbeta, const float* beta, float act_slope,
+                            void* ws, size_t ws_bytes, void* stream);
 int samble_bn_train_stats_f32(const float* x, int B, int C, int N, double* pooled, void* ws, size_t ws_bytes, void* stream);
 int samble_bn_train_apply_f32(const float* x, int B, int C, int N, const double* pooled, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
-                              float* save_invstd, void* stream);
+                              float* save_invstd, float act_slope, void* stream);
 int samble_bn_train_bwd_sums_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
-                                 const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
-                                 void* stream);
+                                 const float* save_invstd, double* pooled, float* dgamma, float* dbeta, const float* gamma,
+                                 const float* beta, float act_slope, void* ws, size_t ws_bytes, void* stream);
 int samble_bn_train_bwd_apply_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
                                   const float* save_invstd, const float* gamma, const double* pooled, const double* count,
-                                  float* dx, void* stream);
+                                  float* dx, const float* beta, float act_slope, void* stream);
 size_t samble_amax_bwd_workspace_bytes(int B, int N, int O);
 int samble_amax_bwd_f32(const float* x, int64_t x_bs, int B, int C, int N, const int32_t* arg, const float* gy, const float* W,
                         int O, float* dx_inout, int64_t dx_bs, float* dW, void* ws, size_t ws_bytes, void* stream);

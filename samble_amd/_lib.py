@@ -111,16 +111,16 @@ _SIGNATURES = {
                                         c_size_t, c_void_p]),
     "samble_bn_train_workspace_bytes": (c_size_t, [c_int, c_int]),
     "samble_bn_train_fwd_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "samble_bn_train_bwd_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "samble_bn_train_stats_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "samble_bn_train_apply_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "samble_bn_train_bwd_sums_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                             c_void_p, c_void_p, c_size_t, c_void_p]),
+                                             c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "samble_bn_train_bwd_apply_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                              c_void_p, c_void_p, c_void_p]),
+                                              c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "samble_amax_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "samble_amax_bwd_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

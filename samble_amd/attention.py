@@ -189,7 +189,7 @@ class deferred_batch_counts:
 _sync_group = ops.sync_group
 
 
-def _bn_train(bn, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group=None):
+def _bn_train(bn, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, group=None, act_slope: float = 1.0):
     """nn.BatchNorm1d.forward in training mode on (B,C,N) -> (y, saved mean, saved invstd, pooled count | None), with the
     module's own bookkeeping (momentum, running statistics, num_batches_tracked).  csrc/batchnorm.hip; `group`: the ranks an
     nn.SyncBatchNorm pools its statistics over."""
@@ -205,7 +205,7 @@ def _bn_train(bn, s: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, grou
     elif bn.momentum is not None:
         factor = bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return ops.stage_bn_train(s, gamma, beta, rm, rv, factor, bn.eps, group)
+    return ops.stage_bn_train(s, gamma, beta, rm, rv, factor, bn.eps, group, act_slope)
 
 
 # csrc/batchnorm.hip for bn1 / bn2 in training mode, forward and backward; "0": the stock modules (A/B runs)
@@ -219,21 +219,21 @@ class _BNTrain(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, s, gamma, beta, bn):
+    def forward(ctx, s, gamma, beta, bn, act_slope=1.0):
         s = s.contiguous()
         group = _sync_group(bn)
-        y, m, v, n = _bn_train(bn, s, gamma, beta, group)
-        ctx.save_for_backward(s, gamma, m, v)
-        ctx.pool = (group, n)
+        y, m, v, n = _bn_train(bn, s, gamma, beta, group, act_slope)
+        ctx.save_for_backward(s, gamma, m, v, beta)
+        ctx.pool = (group, n, float(act_slope))
         return y
 
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, dy):
-        s, gamma, m, v = ctx.saved_tensors
-        group, n = ctx.pool
-        ds, dg, db = ops.stage_bn_train_bwd(s, dy.float().contiguous(), gamma, m, v, n, group)
-        return ds, dg, db, None
+        s, gamma, m, v, beta = ctx.saved_tensors
+        group, n, slope = ctx.pool
+        ds, dg, db = ops.stage_bn_train_bwd(s, dy.float().contiguous(), gamma, m, v, n, group, beta=beta, act_slope=slope)
+        return ds, dg, db, None, None
 
 
 def _plain_bn(bn) -> bool:
@@ -248,12 +248,22 @@ def _plain_bn(bn) -> bool:
     return all(t is not None and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
 
 
-def batch_norm(bn, s: torch.Tensor) -> torch.Tensor:
-    """`bn(s)` -- through `_BNTrain` where the fused layer would take the same route, the module itself otherwise (evaluation,
-    a BatchNorm frozen with bn.eval() inside a training layer, other dtypes)."""
+FUSED_BN_ACT = os.environ.get("SAMBLE_FUSED_BN_ACT", "1") != "0"   # "0": the LeakyReLU behind a BatchNorm as a stock op (A/B)
+
+
+def batch_norm(bn, s: torch.Tensor, act=None) -> torch.Tensor:
+    """`bn(s)` [`act(bn(s))`] -- through `_BNTrain` where the fused layer would take the same route, the module itself
+    otherwise (evaluation, a BatchNorm frozen with bn.eval() inside a training layer, other dtypes).  act: an
+    nn.LeakyReLU behind the normalisation (models/upsample.py:142-150) rides in the BatchNorm kernels' passes: no
+    elementwise launch of its own, forward or backward."""
     if OWN_BATCHNORM and bn.training and _plain_bn(bn) and s.is_cuda and s.dtype == torch.float32 and s.dim() == 3:
-        return _BNTrain.apply(s, bn.weight, bn.bias, bn)
-    return bn(s)
+        if act is None:
+            return _BNTrain.apply(s, bn.weight, bn.bias, bn)
+        if FUSED_BN_ACT and type(act) is nn.LeakyReLU and not act.inplace and 0.0 < act.negative_slope < 1.0:
+            return _BNTrain.apply(s, bn.weight, bn.bias, bn, float(act.negative_slope))
+        return act(_BNTrain.apply(s, bn.weight, bn.bias, bn))
+    y = bn(s)
+    return y if act is None else act(y)
 
 
 def _layer_fusable(mod, x) -> bool:

@@ -994,16 +994,16 @@ SAMBLE_API int samble_interp_blend_bwd_f32(const float* g, int B, int C, int N, 
 extern "C" {
 size_t samble_bn_train_ws_bytes(int, int);
 int samble_launch_bn_train_fwd(const float*, int, int, int, const float*, const float*, float, float, float*, float*, float*,
-                               float*, float*, void*, hipStream_t);
+                               float*, float*, float, void*, hipStream_t);
 int samble_launch_bn_train_stats(const float*, int, int, int, double*, void*, hipStream_t);
 int samble_launch_bn_train_apply(const float*, int, int, int, const double*, const float*, const float*, float, float, float*,
-                                 float*, float*, float*, float*, hipStream_t);
+                                 float*, float*, float*, float*, float, hipStream_t);
 int samble_launch_bn_train_bwd(const float*, const float*, int, int, int, const float*, const float*, const float*, float*,
-                               float*, float*, void*, hipStream_t);
+                               float*, float*, const float*, float, void*, hipStream_t);
 int samble_launch_bn_train_bwd_sums(const float*, const float*, int, int, int, const float*, const float*, double*, float*,
-                                    float*, void*, hipStream_t);
+                                    float*, const float*, const float*, float, void*, hipStream_t);
 int samble_launch_bn_train_bwd_apply(const float*, const float*, int, int, int, const float*, const float*, const float*,
-                                     const double*, const double*, float*, hipStream_t);
+                                     const double*, const double*, float*, const float*, float, hipStream_t);
 }
 SAMBLE_API size_t samble_bn_train_workspace_bytes(int B, int C) { return (B > 0 && C > 0) ? samble_bn_train_ws_bytes(B, C) : 0; }
 
@@ -1011,13 +1011,13 @@ static int bn_shape_ok(int B, int C, int N) { return B > 0 && B <= 65535 && C > 
 
 SAMBLE_API int samble_bn_train_fwd_f32(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps,
                                        float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
-                                       float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+                                       float* save_invstd, float act_slope, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !out || !save_mean || !save_invstd || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: null pointer");
   if (!bn_shape_ok(B, C, N) || (long)B * N < 2)
     return fail(SAMBLE_E_INVALID, "samble_bn_train_fwd_f32: needs more than one value per channel, B <= 65535");
   if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_fwd_f32: workspace too small");
   return done(samble_launch_bn_train_fwd(x, B, C, N, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean,
-                                         save_invstd, ws, (hipStream_t)stream),
+                                         save_invstd, act_slope, ws, (hipStream_t)stream),
               "samble_bn_train_fwd_f32");
 }
 
@@ -1031,42 +1031,46 @@ SAMBLE_API int samble_bn_train_stats_f32(const float* x, int B, int C, int N, do
 
 SAMBLE_API int samble_bn_train_apply_f32(const float* x, int B, int C, int N, const double* pooled, const float* gamma,
                                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                                         float* out, float* save_mean, float* save_invstd, void* stream) {
+                                         float* out, float* save_mean, float* save_invstd, float act_slope, void* stream) {
   if (!x || !pooled || !out || !save_mean || !save_invstd) return fail(SAMBLE_E_INVALID, "samble_bn_train_apply_f32: null pointer");
   if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_apply_f32: bad shape (B, C <= 65535)");
   return done(samble_launch_bn_train_apply(x, B, C, N, pooled, gamma, beta, eps, momentum, running_mean, running_var, out,
-                                           save_mean, save_invstd, (hipStream_t)stream),
+                                           save_mean, save_invstd, act_slope, (hipStream_t)stream),
               "samble_bn_train_apply_f32");
 }
 
 SAMBLE_API int samble_bn_train_bwd_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
                                        const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                                       void* ws, size_t ws_bytes, void* stream) {
+                                       const float* beta, float act_slope, void* ws, size_t ws_bytes, void* stream) {
   if (!x || !dy || !save_mean || !save_invstd || !dx || !ws) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_f32: null pointer");
   if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_f32: bad shape (B, C <= 65535)");
   if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_bwd_f32: workspace too small");
-  return done(samble_launch_bn_train_bwd(x, dy, B, C, N, save_mean, save_invstd, gamma, dx, dgamma, dbeta, ws, (hipStream_t)stream),
+  return done(samble_launch_bn_train_bwd(x, dy, B, C, N, save_mean, save_invstd, gamma, dx, dgamma, dbeta, beta, act_slope, ws,
+                                         (hipStream_t)stream),
               "samble_bn_train_bwd_f32");
 }
 
 SAMBLE_API int samble_bn_train_bwd_sums_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
-                                            const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws,
+                                            const float* save_invstd, double* pooled, float* dgamma, float* dbeta,
+                                            const float* gamma, const float* beta, float act_slope, void* ws,
                                             size_t ws_bytes, void* stream) {
   if (!x || !dy || !save_mean || !save_invstd || !pooled || !ws)
     return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_sums_f32: null pointer");
   if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_sums_f32: bad shape (B, C <= 65535)");
   if (ws_bytes < samble_bn_train_ws_bytes(B, C)) return fail(SAMBLE_E_WORKSPACE, "samble_bn_train_bwd_sums_f32: workspace too small");
-  return done(samble_launch_bn_train_bwd_sums(x, dy, B, C, N, save_mean, save_invstd, pooled, dgamma, dbeta, ws, (hipStream_t)stream),
+  return done(samble_launch_bn_train_bwd_sums(x, dy, B, C, N, save_mean, save_invstd, pooled, dgamma, dbeta, gamma, beta, act_slope,
+                                              ws, (hipStream_t)stream),
               "samble_bn_train_bwd_sums_f32");
 }
 
 SAMBLE_API int samble_bn_train_bwd_apply_f32(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
                                              const float* save_invstd, const float* gamma, const double* pooled,
-                                             const double* count, float* dx, void* stream) {
+                                             const double* count, float* dx, const float* beta, float act_slope, void* stream) {
   if (!x || !dy || !save_mean || !save_invstd || !pooled || !count || !dx)
     return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_apply_f32: null pointer");
   if (!bn_shape_ok(B, C, N)) return fail(SAMBLE_E_INVALID, "samble_bn_train_bwd_apply_f32: bad shape (B, C <= 65535)");
-  return done(samble_launch_bn_train_bwd_apply(x, dy, B, C, N, save_mean, save_invstd, gamma, pooled, count, dx, (hipStream_t)stream),
+  return done(samble_launch_bn_train_bwd_apply(x, dy, B, C, N, save_mean, save_invstd, gamma, pooled, count, dx, beta, act_slope,
+                                               (hipStream_t)stream),
               "samble_bn_train_bwd_apply_f32");
 }
 

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float eps, float momentum, float* running_mean,
                                                               float* running_var, float* __restrict__ out,
-                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              float slope) {
+  // slope: the LeakyReLU behind the normalisation (models/upsample.py:142-150: Conv1d, BatchNorm1d, LeakyReLU(0.2)) in
+  // this pass's epilogue -- out = v > 0 ? v : slope v; 1 = none
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   double t0 = 0.0, t1 = 0.0;
   double E = (double)B * (double)N;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
   const double invstd = 1.0 / sqrt(var + (double)eps);
   const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
   const float sc = (float)(g * invstd), sh = (float)(bt - mean * g * invstd);
+  const float mean_f = (float)mean, kn_f = (gamma ? gamma[c] : 1.f) * (float)invstd, bt_f = beta ? beta[c] : 0.f;
   if (b == 0 && tid == 0) {
     save_mean[c] = (float)mean;
     save_invstd[c] = (float)invstd;
@@ -135,24 +139,42 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float* __res
     for (int i = tid; i < (N >> 2); i += kBnThreads) {
       f32x4 v = r4[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc, sh);
+      for (int e = 0; e < 4; ++e) {
+        // (with an activation the value is formed the way the backward re-forms it for its mask: the same float
+        // expression from the same saved floats, so forward and backward agree on the sign of every element)
+        const float t = slope != 1.f ? fmaf(v[e] - mean_f, kn_f, bt_f) : fmaf(v[e], sc, sh);
+        v[e] = t > 0.f ? t : slope * t;
+      }
       o4[i] = v;
     }
   } else {
-    for (int i = tid; i < N; i += kBnThreads) orow[i] = fmaf(row[i], sc, sh);
+    for (int i = tid; i < N; i += kBnThreads) {
+      const float t = slope != 1.f ? fmaf(row[i] - mean_f, kn_f, bt_f) : fmaf(row[i], sc, sh);
+      orow[i] = t > 0.f ? t : slope * t;
+    }
   }
 }
 
 // ---- backward: dx = gamma invstd (dy - mean(dy) - xhat mean(dy xhat)), d gamma = sum dy xhat, d beta = sum dy ----
 // bn_bwd_reduce  grid (C, S): sum dy and sum dy xhat over the clouds b = s, s + S, ... of channel c in float64
+// slope != 1: the upstream gradient is that of LeakyReLU(bn(x)): dy is masked by the sign of the normalised value, which is
+// recomputed from x and the channel's constants (the activation's output is not read) -- the SAME float expression as
+// bn_act_factor below in the forward's epilogue and both backward kernels
+__device__ __forceinline__ float bn_act_factor(float x, float mean, float kn, float beta, float slope) {
+  return fmaf(x - mean, kn, beta) > 0.f ? 1.f : slope;   // kn = gamma invstd
+}
+
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    int B, int C, int N, const float* __restrict__ save_mean,
                                                                    const float* __restrict__ save_invstd,
-                                                                   double* __restrict__ part) {
+                                                                   double* __restrict__ part, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float slope) {
   __shared__ double red[2][kBnThreads / 64];
   const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y, tid = threadIdx.x;
   const float mean = save_mean[c];
   const double invstd = (double)save_invstd[c];
+  const bool act = slope != 1.f;
+  const float kn = (gamma ? gamma[c] : 1.f) * save_invstd[c], bt = beta ? beta[c] : 0.f;
   double a0 = 0.0, a1 = 0.0;
   const bool vec = (N & 3) == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
   for (int b = s; b < B; b += S) {
@@ -162,17 +184,20 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float* 
       const f32x4* r4 = reinterpret_cast<const f32x4*>(row);
       const f32x4* g4 = reinterpret_cast<const f32x4*>(grow);
       for (int i = tid; i < (N >> 2); i += kBnThreads) {
-        const f32x4 v = r4[i], g = g4[i];
+        const f32x4 v = r4[i];
+        f32x4 g = g4[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+          if (act) g[e] *= bn_act_factor(v[e], mean, kn, bt, slope);
           a0 += (double)g[e];
           a1 += (double)g[e] * (double)(v[e] - mean);
         }
       }
     } else {
       for (int i = tid; i < N; i += kBnThreads) {
-        a0 += (double)grow[i];
-        a1 += (double)grow[i] * (double)(row[i] - mean);
+        const float g = act ? grow[i] * bn_act_factor(row[i], mean, kn, bt, slope) : grow[i];
+        a0 += (double)g;
+        a1 += (double)g * (double)(row[i] - mean);
       }
     }
   }
@@ -204,7 +229,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const float* _
                                                                   const double* __restrict__ part, int S,
                                                                   const double* __restrict__ pooled,
                                                                   const double* __restrict__ count, float* dx,
-                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  const float* __restrict__ beta, float slope) {
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   double t0 = 0.0, t1 = 0.0;
   double E = (double)B * (double)N;
@@ -226,6 +252,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const float* _
   const double invstd = (double)save_invstd[c];
   const double k = (gamma ? (double)gamma[c] : 1.0) * invstd;
   const float kA = (float)k, kB = (float)(-k * invstd * (t1 / E)), kC = (float)(-k * (t0 / E));
+  const bool act = slope != 1.f;
+  const float kn = (gamma ? gamma[c] : 1.f) * save_invstd[c], bt = beta ? beta[c] : 0.f;
   const float* row = x + ((long)b * C + c) * N;
   const float* grow = dy + ((long)b * C + c) * N;
   float* orow = dx + ((long)b * C + c) * N;
@@ -234,14 +262,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(const float* _
     const f32x4* g4 = reinterpret_cast<const f32x4*>(grow);
     f32x4* o4 = reinterpret_cast<f32x4*>(orow);
     for (int i = tid; i < (N >> 2); i += kBnThreads) {
-      const f32x4 v = r4[i], g = g4[i];
+      const f32x4 v = r4[i];
+      f32x4 g = g4[i];
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fmaf(g[e], kA, fmaf(v[e] - mean, kB, kC));
+      for (int e = 0; e < 4; ++e) {
+        if (act) g[e] *= bn_act_factor(v[e], mean, kn, bt, slope);
+        o[e] = fmaf(g[e], kA, fmaf(v[e] - mean, kB, kC));
+      }
       o4[i] = o;
     }
   } else {
-    for (int i = tid; i < N; i += kBnThreads) orow[i] = fmaf(grow[i], kA, fmaf(row[i] - mean, kB, kC));
+    for (int i = tid; i < N; i += kBnThreads) {
+      const float g = act ? grow[i] * bn_act_factor(row[i], mean, kn, bt, slope) : grow[i];
+      orow[i] = fmaf(g, kA, fmaf(row[i] - mean, kB, kC));
+    }
   }
 }
 
@@ -260,12 +295,13 @@ extern "C" size_t samble_bn_train_ws_bytes(int B, int C) { return (size_t)C * bn
 
 extern "C" int samble_launch_bn_train_fwd(const float* x, int B, int C, int N, const float* gamma, const float* beta, float eps,
                                           float momentum, float* running_mean, float* running_var, float* out, float* save_mean,
-                                          float* save_invstd, void* ws, hipStream_t s) {
+                                          float* save_invstd, float slope, void* ws, hipStream_t s) {
   const int S = bn_slices(B, C);
   Timed timed(kT_bn_fwd, s);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, B, C, N, (double*)ws);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, B, C, N, (const double*)ws, S,
-                     (const double*)nullptr, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd);
+                     (const double*)nullptr, gamma, beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd,
+                     slope);
   return (int)hipGetLastError();
 }
 
@@ -281,31 +317,34 @@ extern "C" int samble_launch_bn_train_stats(const float* x, int B, int C, int N,
 
 extern "C" int samble_launch_bn_train_apply(const float* x, int B, int C, int N, const double* pooled, const float* gamma,
                                             const float* beta, float eps, float momentum, float* running_mean,
-                                            float* running_var, float* out, float* save_mean, float* save_invstd, hipStream_t s) {
+                                            float* running_var, float* out, float* save_mean, float* save_invstd, float slope,
+                                            hipStream_t s) {
   Timed timed(kT_bn_fwd, s);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, B, C, N, (const double*)nullptr, 0, pooled, gamma,
-                     beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd);
+                     beta, eps, momentum, running_mean, running_var, out, save_mean, save_invstd, slope);
   return (int)hipGetLastError();
 }
 
 extern "C" int samble_launch_bn_train_bwd(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
                                           const float* save_invstd, const float* gamma, float* dx, float* dgamma, float* dbeta,
-                                          void* ws, hipStream_t s) {
+                                          const float* beta, float slope, void* ws, hipStream_t s) {
   const int S = bn_slices(B, C);
   Timed timed(kT_bn_bwd, s);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws,
+                     gamma, beta, slope);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, gamma,
-                     (const double*)ws, S, (const double*)nullptr, (const double*)nullptr, dx, dgamma, dbeta);
+                     (const double*)ws, S, (const double*)nullptr, (const double*)nullptr, dx, dgamma, dbeta, beta, slope);
   return (int)hipGetLastError();
 }
 
 // the backward in two halves around the ranks' all-reduce: this rank's sums -> pooled (2 C doubles) + d gamma / d beta
 extern "C" int samble_launch_bn_train_bwd_sums(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
-                                               const float* save_invstd, double* pooled, float* dgamma, float* dbeta, void* ws,
-                                               hipStream_t s) {
+                                               const float* save_invstd, double* pooled, float* dgamma, float* dbeta,
+                                               const float* gamma, const float* beta, float slope, void* ws, hipStream_t s) {
   const int S = bn_slices(B, C);
   Timed timed(kT_bn_bwd, s);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, S), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, (double*)ws,
+                     gamma, beta, slope);
   hipLaunchKernelGGL(bn_fold_kernel, dim3((C + kBnThreads - 1) / kBnThreads), dim3(kBnThreads), 0, s, (const double*)ws, C, S, 0.0,
                      0, pooled, dbeta, dgamma);
   return (int)hipGetLastError();
@@ -313,9 +352,9 @@ extern "C" int samble_launch_bn_train_bwd_sums(const float* x, const float* dy, 
 
 extern "C" int samble_launch_bn_train_bwd_apply(const float* x, const float* dy, int B, int C, int N, const float* save_mean,
                                                 const float* save_invstd, const float* gamma, const double* pooled,
-                                                const double* count, float* dx, hipStream_t s) {
+                                                const double* count, float* dx, const float* beta, float slope, hipStream_t s) {
   Timed timed(kT_bn_bwd, s);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(C, B), dim3(kBnThreads), 0, s, x, dy, B, C, N, save_mean, save_invstd, gamma,
-                     (const double*)nullptr, 0, pooled, count, dx, (float*)nullptr, (float*)nullptr);
+                     (const double*)nullptr, 0, pooled, count, dx, (float*)nullptr, (float*)nullptr, beta, slope);
   return (int)hipGetLastError();
 }

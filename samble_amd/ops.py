@@ -220,12 +220,14 @@ def stage_segment_sum_rows(src: torch.Tensor, order: torch.Tensor, offsets: torc
     return out
 
 
-def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, group=None):
+def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, group=None,
+                   act_slope: float = 1.0):
     """nn.BatchNorm1d.forward in training mode on x (B,C,N): -> (y, batch mean (C), 1 / sqrt(batch var + eps) (C), count);
     the running estimates (may be None) get torch's momentum update in place.  csrc/batchnorm.hip.
     group (nn.SyncBatchNorm, reference train_modelnet.py:245-246): the process group whose ranks pool the statistics --
     the per-channel float64 sums and the element count are all-reduced between the two launches; `count` is then the
-    device scalar holding the pooled element count (the backward divides by it), None on one rank."""
+    device scalar holding the pooled element count (the backward divides by it), None on one rank.
+    act_slope: LeakyReLU(act_slope) of the result in the same pass (1.0 = none)."""
     _need_gpu(x, gamma, beta, running_mean, running_var)
     x = _f32c(x)
     B, C, N = x.shape
@@ -237,24 +239,25 @@ def stage_bn_train(x: torch.Tensor, gamma, beta, running_mean, running_var, mome
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         if group is None:
             _lib.call("samble_bn_train_fwd_f32", x.data_ptr(), B, C, N, _p(gamma), _p(beta), float(eps), float(momentum),
-                      _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), nbytes,
-                      _stream())
+                      _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), float(act_slope),
+                      ws.data_ptr(), nbytes, _stream())
             return y, mean, invstd, None
         pooled = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
         _lib.call("samble_bn_train_stats_f32", x.data_ptr(), B, C, N, pooled.data_ptr(), ws.data_ptr(), nbytes, _stream())
         torch.distributed.all_reduce(pooled, group=group)
         _lib.call("samble_bn_train_apply_f32", x.data_ptr(), B, C, N, pooled.data_ptr(), _p(gamma), _p(beta), float(eps),
-                  float(momentum), _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _stream())
+                  float(momentum), _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                  float(act_slope), _stream())
     return y, mean, invstd, pooled[2 * C:]
 
 
 def stage_bn_train_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, mean: torch.Tensor, invstd: torch.Tensor, count=None, group=None,
-                       out: Optional[torch.Tensor] = None):
+                       out: Optional[torch.Tensor] = None, beta=None, act_slope: float = 1.0):
     """Backward of stage_bn_train: -> (dx, dgamma, dbeta).  x is the forward's INPUT, mean / invstd what it saved.  With
     `group` the two per-channel sums are all-reduced between the launches and divided by `count` (the forward's pooled
     element count); dgamma / dbeta stay this rank's sums, as torch's SyncBatchNorm leaves them for DDP to average.
-    out: where dx goes (may be dy itself)."""
-    _need_gpu(x, dy, gamma, mean, invstd)
+    out: where dx goes (may be dy itself).  act_slope != 1 (with beta): dy is the gradient of LeakyReLU(bn(x))."""
+    _need_gpu(x, dy, gamma, mean, invstd, beta)
     x, dy = _f32c(x), _f32c(dy)
     B, C, N = x.shape
     with torch.cuda.device(x.device):
@@ -265,14 +268,16 @@ def stage_bn_train_bwd(x: torch.Tensor, dy: torch.Tensor, gamma, mean: torch.Ten
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         if group is None:
             _lib.call("samble_bn_train_bwd_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
-                      _p(gamma), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, _stream())
+                      _p(gamma), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _p(beta), float(act_slope), ws.data_ptr(),
+                      nbytes, _stream())
             return dx, dgamma, dbeta
         pooled = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         _lib.call("samble_bn_train_bwd_sums_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
-                  pooled.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), nbytes, _stream())
+                  pooled.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _p(gamma), _p(beta), float(act_slope), ws.data_ptr(),
+                  nbytes, _stream())
         torch.distributed.all_reduce(pooled, group=group)
         _lib.call("samble_bn_train_bwd_apply_f32", x.data_ptr(), dy.data_ptr(), B, C, N, mean.data_ptr(), invstd.data_ptr(),
-                  _p(gamma), pooled.data_ptr(), count.data_ptr(), dx.data_ptr(), _stream())
+                  _p(gamma), pooled.data_ptr(), count.data_ptr(), dx.data_ptr(), _p(beta), float(act_slope), _stream())
     return dx, dgamma, dbeta
 
 

@@ -120,14 +120,14 @@ class UpSampleInterpolation(nn.Module):
         (coarse, _, coarse_xyz), _ = pcd_down
         filled = self.interpolate(pcd_up, coarse, pcd_up_xyz, coarse_xyz, self.distance_type, self.K)
         conv, norm, act = self.res_conv
-        return act(batch_norm(norm, conv(pcd_up, filled)))
+        return batch_norm(norm, conv(pcd_up, filled), act)
 
     def interpolate(self, pcd_up, points_select, pcd_up_xyz, points_select_xyz, distance_type="feature", K=3):
         """Features of the coarse set spread onto the fine set (same signature as the reference's method)."""
         if distance_type not in ("xyz", "feature"):
             raise ValueError(f"upsample interpolation distance type can only be feature or xyz! Got: {distance_type}")
         conv, norm, act = self.conv
-        projected = act(batch_norm(norm, conv(points_select)))
+        projected = batch_norm(norm, conv(points_select), act)
         if distance_type == "xyz":
             if FUSED_BLEND and projected.is_cuda and K <= 8 and points_select_xyz.shape[2] <= pcd_up_xyz.shape[2]:
                 idx, dist = ops.stage_knn(pcd_up_xyz, points_select_xyz, K, want_dist=True)

@@ -940,3 +940,48 @@ def test_frozen_batchnorm_inside_a_training_layer_uses_its_running_estimates():
     layer(x)
     assert not torch.equal(layer.bn1.running_mean, before["bn1.running_mean"]) and int(layer.bn1.num_batches_tracked) == 1
     assert torch.equal(layer.bn2.running_mean, before["bn2.running_mean"]) and int(layer.bn2.num_batches_tracked) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N", [(32, 128, 1024), (3, 128, 77), (2, 64, 513)])
+def test_batchnorm_with_the_leaky_relu_in_its_passes_against_float64(B, C, N):
+    """Round 6: the LeakyReLU(0.2) behind a BatchNorm1d (the interpolation layers' `conv`, `res_conv` blocks,
+    models/upsample.py:142-150) rides in csrc/batchnorm.hip's passes -- the forward's epilogue, and the backward masks
+    the upstream gradient by the sign of the normalised value re-formed from x (the activation's output is not read).
+    Output, dx, dgamma, dbeta against float64 autograd through the stock modules; negative gammas included."""
+    from samble_amd import attention as A
+    gen = torch.Generator().manual_seed(B * 77 + N)
+    x = (torch.randn(B, C, N, generator=gen) * 1.3 + 0.2).to("cuda:0")
+    bn = torch.nn.BatchNorm1d(C).to("cuda:0").train()
+    act = torch.nn.LeakyReLU(negative_slope=0.2)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=gen))          # both signs
+        bn.bias.copy_(0.5 * torch.randn(C, generator=gen))
+    ref = torch.nn.BatchNorm1d(C).to("cuda:0").double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    want = act(ref(xd))
+    xg = x.clone().requires_grad_(True)
+    out = A.batch_norm(bn, xg, act)
+    assert float((out.double() - want).abs().max()) <= 3e-6 * max(1.0, float(want.abs().max()))
+    g = torch.randn(B, C, N, generator=gen).to("cuda:0")
+    out.backward(g)
+    want.backward(g.double())
+    # an element whose normalised value is within rounding of 0 may take the other branch: compare in relative L2
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert rel(xg.grad, xd.grad) <= 2e-4, rel(xg.grad, xd.grad)
+    assert rel(bn.weight.grad, ref.weight.grad) <= 2e-4 and rel(bn.bias.grad, ref.bias.grad) <= 2e-4
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=0, atol=1e-6)
+    # and the un-fused composition of the same kernels gives the same output bit for bit
+    old = A.FUSED_BN_ACT
+    A.FUSED_BN_ACT = False
+    try:
+        bn2 = torch.nn.BatchNorm1d(C).to("cuda:0").train()
+        bn2.load_state_dict({k: v.clone() for k, v in ref.state_dict().items() if not k.startswith("running") and k != "num_batches_tracked"}, strict=False)
+        with torch.no_grad():
+            bn2.weight.copy_(bn.weight)
+            bn2.bias.copy_(bn.bias)
+        plain = A.batch_norm(bn2, x, act)
+    finally:
+        A.FUSED_BN_ACT = old
+    assert float((plain - out).abs().max()) <= 2e-6 * max(1.0, float(out.abs().max()))
