@@ -25,9 +25,14 @@ from make_golden import O, same, synth
 NAME = "headline_cls_B32_N2048"
 CASE = dict(name=NAME, cfg="cls", B=32, N=2048, M=1024, calls=1, big=False)
 SEED = 1000 * 77
+# BASELINE.json configs[4]'s geometry (N = 8192 -> 4096: multi-tile selection chain, 257 key tiles per row) on two clouds --
+# the reference materialises ~10 (B, N, N + 6) float32 tensors, 537 MB each at B = 2
+STRESS = ("stress_cls_B2_N8192", dict(name="stress_cls_B2_N8192", cfg="cls", B=2, N=8192, M=4096, calls=1, big=False), 1000 * 78)
 
 
-def main():
+def main(name=NAME, case=CASE, seed=SEED):
+    global NAME, CASE, SEED
+    NAME, CASE, SEED = name, case, seed
     torch.set_num_threads(8)
     mod, spec, (wq, wk, wv, tok) = G.build_reference(CASE, SEED)
     B, N, M, nb, C = CASE["B"], CASE["N"], CASE["M"], spec.num_bins, spec.C
@@ -74,4 +79,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    which = set(sys.argv[1:])
+    if not which or "headline" in which:
+        main()
+    if not which or "stress" in which:
+        main(*STRESS)

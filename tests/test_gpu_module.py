@@ -570,18 +570,21 @@ def test_step_is_graph_capturable_and_replays_bit_identically():
     assert not mod._chain_watch.timed_out(sync=True)
 
 
-def _headline_fixture():
-    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "headline_cls_B32_N2048.npz"))
+SLIM_FIXTURES = ("headline_cls_B32_N2048", "stress_cls_B2_N8192")
+
+
+def _headline_fixture(name="headline_cls_B32_N2048"):
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
     B, C, N, M, nb, K, _, seed = [int(v) for v in d["meta"]]
     noise = torch.from_numpy(d["noise"])   # the Exp(1) draws the reference's torch.multinomial consumed (utils/ops.py:595)
     return d, (B, C, N, M, nb, K, seed), noise
 
 
-def headline_module_and_step(dev=DEV):
-    """The layer on the headline fixture's inputs: (fixture, module after forward + backward, idx, x_ds, x)."""
+def headline_module_and_step(dev=DEV, name="headline_cls_B32_N2048"):
+    """The layer on a slim full-size fixture's inputs: (fixture, module after forward + backward, idx, x_ds, x)."""
     from samble_amd import sampler_config
     from samble_amd.downsample import DownSampleToken
-    d, (B, C, N, M, nb, K, seed), noise = _headline_fixture()
+    d, (B, C, N, M, nb, K, seed), noise = _headline_fixture(name)
     mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0)
     wq, wk, wv, tok = synth.sampler_weights(C, nb, seed)
     with torch.no_grad():
@@ -596,14 +599,16 @@ def headline_module_and_step(dev=DEV):
     return d, mod, idx, x_ds, x
 
 
-def test_headline_configuration_against_the_reference_fixture(matrix_mode):
-    """BASELINE.json's metric configuration -- B=32, C=128, N=2048 -> 1024, 6 bins, K=32, sparse_col_sqr, DYNAMIC boundaries
+@pytest.mark.parametrize("fixture_name", SLIM_FIXTURES)
+def test_headline_configuration_against_the_reference_fixture(matrix_mode, fixture_name):
+    """(`stress_cls_B2_N8192`: the same test on BASELINE configs[4]'s geometry, N = 8192 -> 4096 on two clouds.)
+    BASELINE.json's metric configuration -- B=32, C=128, N=2048 -> 1024, 6 bins, K=32, sparse_col_sqr, DYNAMIC boundaries
     from a fresh state, random T=0.1 -- against a fixture the UNMODIFIED reference wrote in the build container
     (tests/golden/make_golden_headline.py; reference utils/ops.py:385-432, 467-619): the whole-batch quantile boundaries,
     bin populations, bin weights and counts, and the sampled indices per cloud.  The per-cloud identity is pinned in
     tests/expected_identity.json (tools/fixture_identity.py): a cloud identical there stays identical; one that is not is
     explained by one of the two measured mechanisms (a truncation flip of the float water-filling, a near-tie of two keys)."""
-    d, mod, idx, x_ds, x = headline_module_and_step()
+    d, mod, idx, x_ds, x = headline_module_and_step(name=fixture_name)
     B, M = idx.shape[0], idx.shape[2]
     torch.testing.assert_close(mod.bin_boundaries[0].cpu(), torch.from_numpy(d["upper"]), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(mod.bin_boundaries[1].cpu(), torch.from_numpy(d["lower"]), rtol=1e-4, atol=1e-5)
@@ -618,14 +623,14 @@ def test_headline_configuration_against_the_reference_fixture(matrix_mode):
     torch.testing.assert_close(score.double().sum((1, 2)), torch.from_numpy(d["score_cloud_sums"])[:, 0], rtol=2e-4, atol=0)
     cap = torch.from_numpy(d["cap"]).long()
     cap_same = (mod.max_num_points.cpu().long() == cap).all(1)
-    assert int(cap_same.sum()) >= B - 2, "bin populations (a point whose z sits on a boundary may change bin)"
+    assert int(cap_same.sum()) >= max(B - 2, 0), "bin populations (a point whose z sits on a boundary may change bin)"
     torch.testing.assert_close(mod.bin_weights_beforerelu.cpu()[cap_same], torch.from_numpy(d["w_pre"])[cap_same], rtol=2e-5, atol=1e-6)
     got, ref = idx.cpu()[:, 0], torch.from_numpy(d["idx"].astype(np.int64))
     same = (got == ref).all(1)
     counts_same = (mod.k_point_to_choose.cpu() == torch.from_numpy(d["counts"])).all(1)
     print(f"\nheadline fixture ({matrix_mode}): clouds with the reference's exact index tensor {int(same.sum())} of {B}: "
           f"{same.int().tolist()}; counts identical {int(counts_same.sum())} of {B}; set agreement {set_agreement(got, ref):.5f}")
-    pinned = _pinned_identity(matrix_mode, "headline_cls_B32_N2048", 0)
+    pinned = _pinned_identity(matrix_mode, fixture_name, 0)
     assert pinned is not None, "no row for the headline fixture in tests/expected_identity.json (tools/fixture_identity.py)"
     lost = [b for b in range(B) if pinned[b] and not bool(same[b])]
     assert not lost, f"clouds {lost} carried the reference's exact indices when the table was pinned"

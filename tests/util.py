@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(HERE, "golden")
 def golden_names():
     """Sampler fixtures (make_golden.py); the layer_* fixtures come from make_golden_layers.py."""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("layer_", "block_", "ckpt_", "headline_"))]
+    return [n for n in names if not n.startswith(("layer_", "block_", "ckpt_", "headline_", "stress_"))]
 
 
 def layer_fixture(name):

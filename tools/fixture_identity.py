@@ -25,11 +25,13 @@ for mode in ("tri", "f32"):
             cdiff = (mod.k_point_to_choose.cpu() != g.t("counts", call)).any(1)
             rows.append({"same": same.int().tolist(), "counts_differ": cdiff.int().tolist()})
         out[f"{mode}/{name}"] = rows
-    # the headline configuration (tests/golden/headline_cls_B32_N2048.npz: B=32, N=2048 -> 1024, written by the reference)
+    # the slim full-size fixtures the reference wrote (tests/golden/make_golden_headline.py): the headline configuration
+    # B=32, N=2048 -> 1024 and the stress geometry B=2, N=8192 -> 4096
     import numpy as np
-    from tests.test_gpu_module import headline_module_and_step
-    d, mod, idx, _, _ = headline_module_and_step("cuda:0")
-    same = (idx.cpu()[:, 0] == torch.from_numpy(d["idx"].astype(np.int64))).all(1)
-    cdiff = (mod.k_point_to_choose.cpu() != torch.from_numpy(d["counts"])).any(1)
-    out[f"{mode}/headline_cls_B32_N2048"] = [{"same": same.int().tolist(), "counts_differ": cdiff.int().tolist()}]
+    from tests.test_gpu_module import SLIM_FIXTURES, headline_module_and_step
+    for name in SLIM_FIXTURES:
+        d, mod, idx, _, _ = headline_module_and_step("cuda:0", name)
+        same = (idx.cpu()[:, 0] == torch.from_numpy(d["idx"].astype(np.int64))).all(1)
+        cdiff = (mod.k_point_to_choose.cpu() != torch.from_numpy(d["counts"])).any(1)
+        out[f"{mode}/{name}"] = [{"same": same.int().tolist(), "counts_differ": cdiff.int().tolist()}]
 print(json.dumps(out, indent=1))
