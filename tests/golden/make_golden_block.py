@@ -154,7 +154,8 @@ def make(kind, seed, keys, B=2, N=256, M=(128, 64), name=None, pick=True):
         # instead, so the reference blends ~1 % of the two other neighbours in at those points, an amount no other
         # evaluation of the same expression reproduces.  Second set of outputs with cdist in its exact mode (d = 0 at
         # coinciding points, as the HIP search computes it): what the reference computes when that noise is out.
-        _, blk_x, feat_x = reference_block(kind, seed, B, N, M, exact_cdist=True)
+        _, blk_x, feat_x = reference_block(kind, seed, B, N, M, exact_cdist=True,
+                                           forced_idx=None if pick else [l.idx for l in blk.downsample_list])
         out.update({k.replace("grad/", "exact/grad/"): v for k, v in grads_of(blk_x, keys).items()})
         out.update({"exact/feat": feat_x.detach().numpy(), "exact/idx0": blk_x.downsample_list[0].idx.numpy(),
                     "exact/idx1": blk_x.downsample_list[1].idx.numpy()})
@@ -163,6 +164,11 @@ def make(kind, seed, keys, B=2, N=256, M=(128, 64), name=None, pick=True):
               "feat max|diff| %.3e" % float((feat - feat_x).abs().max()))
     if not pick:   # the mid-size fixture keeps the score of two clouds only (the full tensor is of no use to its test)
         out["score0"] = out["score0"][:2]
+        if kind == "seg":   # per-point features of ONE cloud in full, of every cloud as float64 (sum, sum of squares)
+            for key in ("feat", "exact/feat"):
+                full = torch.from_numpy(out[key]).double()
+                out[key + "_cloud_sums"] = torch.stack([full.sum((1, 2)), full.square().sum((1, 2))], 1).numpy()
+                out[key] = out[key][:1]
         if kind == "cls":
             # ATen's default cdist (|a|^2 + |b|^2 - 2 a.b, ~1e-3 of rounding noise on 64- / 128-channel features) decides
             # near-ties of the K-th neighbour by that noise; at 4 x 1024 rows per search a few neighbour sets differ from
@@ -190,3 +196,5 @@ if __name__ == "__main__":
         # round 6 (verdict r5: "block fixtures are tiny and seed-picked"): four clouds of 1024 points through
         # 1024 -> 512 -> 256, the seed written down before the first run, nothing rejected
         make("cls", 9500, GRAD_KEYS_CLS, B=4, N=1024, M=(512, 256), name="block_cls_mid", pick=False)
+    if not which or "segmid" in which:
+        make("seg", 9600, GRAD_KEYS_SEG, B=4, N=1024, M=(512, 256), name="block_seg_mid", pick=False)
