@@ -525,7 +525,7 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
         comm["c2_floats"] = nparam
         comm["syncbatchnorm_layers"] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in blk.modules())
         comm["note"] += ("; every SyncBatchNorm adds one all-reduce of 2C+1 float64 per forward and one of 2C per backward "
-                         "(csrc/batchnorm.hip between its two launches; EdgeConv: the pooled closed forms)")
+                         "(csrc/batchnorm.hip between its two launches; EdgeConv: each glue entry in two halves around the all-reduce of its totals)")
     # every family of the step over further untimed steps (EVERY rank: a step holds collectives)
     per_step = dict(timed_per_step)
     if breakdown:

@@ -162,6 +162,30 @@ def test_cls_block_mid_size_against_an_unpicked_reference_fixture():
     assert not bad, bad
 
 
+def test_pooled_heads_as_one_node_with_the_onward_path_change_no_bit():
+    """blocks.SPLIT_HEADS (round 6): a level's pooled head and its onward path (the sampler) as ONE autograd node -- the head's
+    sparse gradient is added into the sampler's dx in place instead of a zero-filled tensor and a dense add.  Same sums in
+    the same order: output, dx and every parameter gradient are bit for bit those of the separate consumers."""
+    from samble_amd import blocks as BK
+    outs = []
+    for split in (True, False):
+        old = BK.SPLIT_HEADS
+        BK.SPLIT_HEADS = split
+        try:
+            d, blk, xyz, noise = _reference_block("cls", "mid")
+            xin = xyz.clone().requires_grad_(True)
+            feat, res = blk(xin, noise_list=noise)
+            feat.backward(torch.from_numpy(synth.normal(tuple(feat.shape), 31)).to(DEV))
+            outs.append((feat.detach(), xin.grad, {n: p.grad for n, p in blk.named_parameters()},
+                         [a.clone() for a in blk.head_args]))
+        finally:
+            BK.SPLIT_HEADS = old
+    (f1, dx1, g1, a1), (f2, dx2, g2, a2) = outs
+    assert torch.equal(f1, f2) and torch.equal(dx1, dx2) and all(torch.equal(x, y) for x, y in zip(a1, a2))
+    for n in g2:
+        assert torch.equal(g1[n], g2[n]), n
+
+
 def test_cls_block_metric_size_forward_backward():
     """configs[1] proper: B=32 clouds of N=2048 xyz through the whole block (2048 -> 1024 -> 512)."""
     from samble_amd.blocks import FeatureLearningBlock, block_config
