@@ -177,6 +177,14 @@ def make(kind, seed, keys, B=2, N=256, M=(128, 64), name=None, pick=True):
             _, blk_x, feat_x = reference_block(kind, seed, B, N, M, exact_cdist=True, forced_idx=[l.idx for l in blk.downsample_list])
             out.update({k.replace("grad/", "exact/grad/"): v for k, v in grads_of(blk_x, keys).items()})
             out["exact/feat"] = feat_x.detach().numpy()
+            out.update({f"exact/head_arg{i}": a.numpy().astype(np.int16) for i, a in enumerate(blk_x.head_args)})
+            # ... and the exact-cdist run left to sample for ITSELF: what the reference selects when its neighbour sets are
+            # those of the exact distance order (the default run's selection follows its cdist's rounding noise)
+            _, blk_o, _ = reference_block(kind, seed, B, N, M, exact_cdist=True)
+            out["exact_own/idx0"] = blk_o.downsample_list[0].idx.numpy().astype(np.int16)
+            out["exact_own/idx1"] = blk_o.downsample_list[1].idx.numpy().astype(np.int16)
+            print("   exact-cdist run sampling for itself: clouds identical to the default run per layer:",
+                  [int((a.idx[:, 0] == b.idx[:, 0]).all(1).sum()) for a, b in zip(blk.downsample_list, blk_o.downsample_list)])
             print("   exact-cdist run on the same indices: feat max|diff| to the default run %.3e; gradient difference per key:"
                   % float((feat - feat_x).abs().max()),
                   {k: "%.1e" % v for k, v in zip(keys, self_noise(blk, blk_x, keys))})
@@ -196,5 +204,8 @@ if __name__ == "__main__":
         # round 6 (verdict r5: "block fixtures are tiny and seed-picked"): four clouds of 1024 points through
         # 1024 -> 512 -> 256, the seed written down before the first run, nothing rejected
         make("cls", 9500, GRAD_KEYS_CLS, B=4, N=1024, M=(512, 256), name="block_cls_mid", pick=False)
+    if "full" in which:
+        # BASELINE configs[1]'s own geometry (2048 -> 1024 -> 512) at a quarter of its batch: eight clouds, unpicked seed
+        make("cls", 9700, GRAD_KEYS_CLS, B=8, N=2048, M=(1024, 512), name="block_cls_full", pick=False)
     if not which or "segmid" in which:
         make("seg", 9600, GRAD_KEYS_SEG, B=4, N=1024, M=(512, 256), name="block_seg_mid", pick=False)
