@@ -69,20 +69,30 @@ __global__ __launch_bounds__(256) void n2p_attn_fwd_kernel(const float* __restri
           kv[u] = *reinterpret_cast<const f32x4*>(jr + 128);
           vv[u] = *reinterpret_cast<const f32x4*>(jr + 256);
         }
+        // online softmax with ONE rescale per chunk of eight neighbours (round 6): the chunk's logits first, their maximum
+        // joins the running one, the running sums are rescaled once, then eight plain accumulations -- one exponential and
+        // five multiplies less per neighbour than a rescale at every neighbour (the kernel is half vector issue)
+        float lg8[8];
+        float mn = m;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const float s = head_sum(dot4(q, kv[u]), hl);
-          if (k0 + u < KN) {
-            const float logit = (s - qkc) * scale;
-            if (att && heads == 1) lgs[hw][k0 + u] = logit;
-            const float mn = fmaxf(m, logit);
-            const float al = __expf(m - mn), p = __expf(logit - mn);
-            l = l * al + p;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = acc[e] * al + p * vv[u][e];
-            m = mn;
-          }
+          lg8[u] = (k0 + u < KN) ? (s - qkc) * scale : kNegInf;
+          if (att && heads == 1 && k0 + u < KN) lgs[hw][k0 + u] = lg8[u];
+          mn = fmaxf(mn, lg8[u]);
         }
+        const float al = __expf(m - mn);   // (first chunk: exp(-inf) = 0 on zero sums)
+        l *= al;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] *= al;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float p = __expf(lg8[u] - mn);   // (masked slots: exp(-inf) = 0)
+          l += p;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(p, vv[u][e], acc[e]);
+        }
+        m = mn;
       }
       const float inv = 1.f / l;
 #pragma unroll
@@ -215,24 +225,38 @@ __global__ __launch_bounds__(256) void n2p_bwd_point_kernel(const float* __restr
         kv[u] = *reinterpret_cast<const f32x4*>(jr + 128);
         vv[u] = *reinterpret_cast<const f32x4*>(jr + 256);
       }
+      // (round 6) one rescale of the running sums per chunk of eight neighbours, as in the forward
+      float mn = m;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = k0 + u;
         lg[k] = (FULL || k < KN) ? (head_sum(dot4(q, kv[u]), hl) - qkc) * scale : kNegInf;
         da[k] = head_sum(dot4(g, vv[u]), hl);
-        if (FULL || k < KN) {
-          const float mn = fmaxf(m, lg[k]);
-          const float al = __expf(m - mn), p = __expf(lg[k] - mn), pd = p * da[k];
-          l = l * al + p;
-          D = D * al + pd;
+        mn = fmaxf(mn, lg[k]);
+      }
+      {
+        const float al = __expf(m - mn);
+        l *= al;
+        D *= al;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            S2[e] = S2[e] * al + p * kv[u][e];
-            S1[e] = S1[e] * al + pd * kv[u][e];
-          }
-          m = mn;
+        for (int e = 0; e < 4; ++e) {
+          S2[e] *= al;
+          S1[e] *= al;
         }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u;
+        const float p = __expf(lg[k] - mn), pd = p * da[k];   // (masked slots: exp(-inf) = 0)
+        l += p;
+        D += pd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          S2[e] = fmaf(p, kv[u][e], S2[e]);
+          S1[e] = fmaf(pd, kv[u][e], S1[e]);
+        }
+      }
+      m = mn;
       // the running sums are DUE here (else their updates sink below the loop and all 32 K rows stay in registers)
       asm volatile("" : "+v"(S1), "+v"(S2), "+v"(l), "+v"(D), "+v"(m));
     }
