@@ -1023,8 +1023,7 @@ __global__ __launch_bounds__(256) void tri_k_to_duo_kernel(char* __restrict__ im
 #pragma unroll
     for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(x[u][e]));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  amax = wave_max64(amax);
   if ((tid & 63) == 0) wmax[tid >> 6] = amax;
   __syncthreads();
   amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));

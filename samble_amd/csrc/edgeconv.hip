@@ -145,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void edge_mlp_fwd_kernel(const float* __res
         kx = min(kx, acc[ot][r] == mx ? crow(r, h) : 99);
         kn = min(kn, acc[ot][r] == mn ? crow(r, h) : 99);
       }
-      kx = min(kx, __shfl_xor(kx, 32, 64));
-      kn = min(kn, __shfl_xor(kn, 32, 64));
+      kx = xor32_min(kx);
+      kn = xor32_min(kn);
       if (h == 0) {
         ymax[p * kEC + 32 * ot + lo] = mx;
         ymin[p * kEC + 32 * ot + lo] = mn;
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(512, 2) void edge_mlp_fwd_tri_kernel(const float* _
         kx = min(kx, acc[ot][r] == mx ? crow(r, h) : 99);
         kn = min(kn, acc[ot][r] == mn ? crow(r, h) : 99);
       }
-      kx = min(kx, __shfl_xor(kx, 32, 64));
-      kn = min(kn, __shfl_xor(kn, 32, 64));
+      kx = xor32_min(kx);
+      kn = xor32_min(kn);
       if (h == 0) {
         ymax[p * kEC + 32 * ot + lo] = mx;
         ymin[p * kEC + 32 * ot + lo] = mn;

@@ -61,15 +61,17 @@ __device__ __forceinline__ float half_wave_max(float x) {
   return x;                                    // lanes 16..31 / 48..63 hold the half's max
 }
 
-// max over all 64 lanes, in every lane (four DPP steps inside the rows of 16, two shuffles across them)
+// max over all 64 lanes, in every lane (four DPP steps inside the rows of 16, v_permlane16_swap / v_permlane32_swap across them)
 __device__ __forceinline__ float wave_max_all(float x) {
   x = fmaxf(x, lin_dpp_f<0xB1, 0xF>(x, x));
   x = fmaxf(x, lin_dpp_f<0x4E, 0xF>(x, x));
   x = fmaxf(x, lin_dpp_f<0x141, 0xF>(x, x));
   x = fmaxf(x, lin_dpp_f<0x140, 0xF>(x, x));
-  x = fmaxf(x, __shfl_xor(x, 16, 64));
-  x = fmaxf(x, __shfl_xor(x, 32, 64));
-  return x;
+  {
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  }
+  return xor32_max(x);
 }
 
 // eight fp32 values x s -> the two fp16 planes of one 16-byte operand chunk
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void lin_fwd_tri_kernel(const float* __rest
         xv[8 * ks + e] = c < Cin ? x[(long)b * x_bs + (long)c * N + n] : 0.f;
         amax = fmaxf(amax, fabsf(xv[8 * ks + e]));
       }
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));   // lanes lo and lo + 32 hold the two halves of one point
+    amax = xor32_max(amax);   // lanes lo and lo + 32 hold the two halves of one point
     float sx;
     duo_scale_for(amax, sx, x_inv);
 #pragma unroll
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_dx_duo_kernel(const float* __r
     for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[q][e]));
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    amax = xor32_max(amax);
     duo_scale_for(amax, sc, inv);
   };
 #pragma unroll
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_chain_kernel(const float* __re
         xv[8 * ks + e] = x[(long)b * x_bs + (long)(16 * ks + 8 * h + e) * N + n];
         amax = fmaxf(amax, fabsf(xv[8 * ks + e]));
       }
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    amax = xor32_max(amax);
     float sx;
     duo_scale_for(amax, sx, x_inv);
 #pragma unroll
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(64 * NW, 2) void lin_chain_kernel(const float* __re
     if (EPI == kLinLeakyBits && own) brow[(long)t * 2 * N] = (unsigned short)word;
     if (EPI == kLinMaskBits) bf = bnx;
     // product 2: the accumulator as the B operand (k-step s: registers 8 s .. 8 s + 7), under the lane pair's scale
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    amax = xor32_max(amax);
     float s2, g_inv;
     duo_scale_for(amax, s2, g_inv);
     u32x4 bh[2], bl[2];

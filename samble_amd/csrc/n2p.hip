@@ -14,12 +14,21 @@ namespace samble {
 
 // sum over the lanes of one head: hl = lanes per head = 32 / heads (8 for the 4 heads of N2P, 16 for two heads, 32 for
 // the single head of DownSampleLocal); wave-uniform
+// Round 6: the butterfly on DPP lane moves (the vector ALU's own cross-lane path, fused into the add) -- `__shfl_xor` is a
+// `ds_bpermute_b32`: an LDS-crossbar instruction plus its address arithmetic and a wait, three per sum, and the gather kernels
+// are half vector issue.  quad_perm swaps give lane ^ 1 and lane ^ 2; after them a quad's four lanes hold the same value, so
+// the octet's other quad is reached by row_half_mirror (lane 7 - i) and the row's other octet by row_mirror (15 - i): the
+// same partial sums in the same order as the xor butterfly, bit for bit.
+template <int CTRL>
+__device__ __forceinline__ float head_dpp(float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float head_sum(float v, int hl) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  if (hl > 8) v += __shfl_xor(v, 8, 64);    // 2 heads: 16 lanes each
-  if (hl > 16) v += __shfl_xor(v, 16, 64);  // 1 head: all 32 lanes of the half-wave
+  v += head_dpp<0xB1>(v);                   // quad_perm [1,0,3,2]: lane ^ 1
+  v += head_dpp<0x4E>(v);                   // quad_perm [2,3,0,1]: lane ^ 2
+  v += head_dpp<0x141>(v);                  // row_half_mirror: the octet's other quad
+  if (hl > 8) v += head_dpp<0x140>(v);      // row_mirror: 2 heads of 16 lanes each
+  if (hl > 16) v += __shfl_xor(v, 16, 64);  // 1 head: all 32 lanes of the half-wave (DownSampleLocal)
   return v;
 }
 

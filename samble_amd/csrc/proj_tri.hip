@@ -62,8 +62,7 @@ __global__ __launch_bounds__(256) void proj_prologue_kernel(const ProjW W, const
           amax = fmaxf(amax, fabsf(v[k][i]));
         }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      amax = wave_max64(amax);
       if ((tid & 63) == 0) red[tid >> 6] = amax;
       __syncthreads();
       float sc, inv;
@@ -170,8 +169,7 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
           v8[i] = (r < nt) ? tokqkv[r * kPO + 128 * which + 8 * g + i] : 0.f;
           amax = fmaxf(amax, fabsf(v8[i]));
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        amax = wave_max64(amax);
         __syncthreads();  // (the previous pass's readers of red)
         if (lane == 0) red[wave] = amax;
         __syncthreads();
@@ -289,8 +287,7 @@ __global__ __launch_bounds__(512, 2) void proj_fwd_tri_kernel(const float* __res
               for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(kst[c][pr][e]));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+            amax = wave_max64(amax);
             float sc, inv;
             duo_scale_for(amax, sc, inv);
 #pragma unroll

@@ -51,6 +51,39 @@ struct Timed {  // brackets the launches made during its lifetime
   ~Timed() { samble_time_end(id, s); }
 };
 
+// ---- cross-lane moves that stay on the vector ALU (round 6) ---------------------------------------------------------------
+// `__shfl_xor(x, o)` compiles to `ds_bpermute_b32`: an LDS-crossbar instruction with its address arithmetic and a wait.  Inside
+// a row of 16 lanes DPP does the same move fused into the consumer (quad_perm for lane ^ 1 and lane ^ 2; once a quad / an octet
+// holds one value, row_half_mirror / row_mirror reach the other quad / octet); across rows gfx950 has v_permlane16_swap and
+// v_permlane32_swap: with both operands = x they return (rows 0 0 2 2, rows 1 1 3 3) and (rows 0 1 0 1, rows 2 3 2 3) of x, so
+// combining the two results lane by lane is the xor-16 / xor-32 butterfly step.  max / min / + of the same values in the same
+// pairing as the xor butterfly: identical results.
+template <int CTRL>
+__device__ __forceinline__ unsigned lane_dpp_u(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+template <class Op>
+__device__ __forceinline__ float wave_butterfly64(float x, Op op) {   // every lane: op over all 64 lanes
+  x = op(x, __uint_as_float(lane_dpp_u<0xB1>(__float_as_uint(x))));     // quad_perm [1,0,3,2]
+  x = op(x, __uint_as_float(lane_dpp_u<0x4E>(__float_as_uint(x))));     // quad_perm [2,3,0,1]
+  x = op(x, __uint_as_float(lane_dpp_u<0x141>(__float_as_uint(x))));    // row_half_mirror
+  x = op(x, __uint_as_float(lane_dpp_u<0x140>(__float_as_uint(x))));    // row_mirror
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = op(__uint_as_float(p[0]), __uint_as_float(p[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return op(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float wave_max64(float x) { return wave_butterfly64(x, [](float a, float b) { return fmaxf(a, b); }); }
+// op(x, value of lane ^ 32)
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ int xor32_min(int x) {
+  const auto q = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+  return min((int)q[0], (int)q[1]);
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -209,7 +242,12 @@ __device__ __forceinline__ long map_cloud(int b, int which = -1) {
 #endif
 }
 
-__device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
+// value of lane ^ 32 (round 6: v_permlane32_swap on the vector ALU; was __shfl_xor = ds_bpermute_b32, an LDS round trip in the
+// middle of the per-tile softmax statistics' latency chain).  One-dimensional workgroups of whole waves: lane = threadIdx.x & 63
+__device__ __forceinline__ float wave_xor32(float v) {
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float((threadIdx.x & 32) ? q[0] : q[1]);
+}
 
 // order-preserving float -> uint32 (larger float -> larger uint); NaN sorts above +inf
 __device__ __forceinline__ uint32_t ordered_bits(float f) {

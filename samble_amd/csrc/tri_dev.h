@@ -134,9 +134,7 @@ __device__ __forceinline__ void duo_split8s(const float (&v)[8], float s, u32x4&
 }
 // largest value over the 64 lanes, in every lane
 __device__ __forceinline__ float wave_amax64(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-  return x;
+  return wave_max64(x);
 }
 // ---- products that ACCUMULATE over tiles (out^T += A_tile^T X_tile: dV^T += dO^T P, dK^T += Q^T dS) ------------------
 // The A tiles (transposed images of the sampled rows) carry per-tile scales 2^e_t; their X blocks are split in the
@@ -160,8 +158,7 @@ struct DuoTileScales {
       inv[j] = t < ntiles ? *reinterpret_cast<const float*>(img + (long)t * kTriTile + kDuoTrScaleSlot) : 0.f;
       mx = fmaxf(mx, inv[j]);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = wave_max64(mx);
     rcp_max = 1.f / mx;  // (mx = 2^-e_min: a power of two, the reciprocal is exact)
 #pragma unroll
     for (int j = 0; j < kDuoTsRegs; ++j) {  // (into registers a vector-ALU instruction wrote: see above)
@@ -203,7 +200,7 @@ __device__ __forceinline__ void duo_q_from_tri(const u32x4 (&q)[24], u32x4 (&qd)
       amax = fmaxf(amax, fabsf(v[e]));
     }
   }
-  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  amax = xor32_max(amax);
   float s;
   duo_scale_for(amax, s, unscale);
 #pragma unroll
