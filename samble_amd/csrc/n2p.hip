@@ -537,16 +537,20 @@ __global__ __launch_bounds__(256) void seg_sum_rows64_pair_kernel(const float* _
     float s0 = 0.f, s1 = 0.f, r0 = 0.f, r1 = 0.f;
     const int e0 = offs[t], e1 = offs[t + 1];
     int s = e0;
-    for (; s + 4 <= e1; s += 4) {  // four edges = eight rows in flight
-      float2 v[4], w[4];
+#ifndef SAMBLE_SEGSUM_BATCH
+#define SAMBLE_SEGSUM_BATCH 4
+#endif
+    constexpr int SB = SAMBLE_SEGSUM_BATCH;
+    for (; s + SB <= e1; s += SB) {  // SB edges = 2 SB rows in flight
+      float2 v[SB], w[SB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SB; ++u) {
         const long e = order[s + u];
         v[u] = *reinterpret_cast<const float2*>(srcE + e * e_rs + 2 * c);
         w[u] = *reinterpret_cast<const float2*>(srcP + (e / KN) * p_rs + 2 * c);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SB; ++u) {
         s0 += v[u].x;
         s1 += v[u].y;
         r0 += w[u].x;
