@@ -207,5 +207,8 @@ if __name__ == "__main__":
     if "full" in which:
         # BASELINE configs[1]'s own geometry (2048 -> 1024 -> 512) at a quarter of its batch: eight clouds, unpicked seed
         make("cls", 9700, GRAD_KEYS_CLS, B=8, N=2048, M=(1024, 512), name="block_cls_full", pick=False)
+    if "segfull" in which:
+        # BASELINE configs[2]'s own geometry (2048 -> 1024 -> 512 -> 1024 -> 2048) on eight clouds, unpicked seed
+        make("seg", 9800, GRAD_KEYS_SEG, B=8, N=2048, M=(1024, 512), name="block_seg_full", pick=False)
     if not which or "segmid" in which:
         make("seg", 9600, GRAD_KEYS_SEG, B=4, N=1024, M=(512, 256), name="block_seg_mid", pick=False)
