@@ -242,12 +242,11 @@ __device__ __forceinline__ long map_cloud(int b, int which = -1) {
 #endif
 }
 
-// value of lane ^ 32 (round 6: v_permlane32_swap on the vector ALU; was __shfl_xor = ds_bpermute_b32, an LDS round trip in the
-// middle of the per-tile softmax statistics' latency chain).  One-dimensional workgroups of whole waves: lane = threadIdx.x & 63
-__device__ __forceinline__ float wave_xor32(float v) {
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float((threadIdx.x & 32) ? q[0] : q[1]);
-}
+// value of lane ^ 32 (`ds_bpermute_b32`).  Its callers are the attention kernels' per-tile statistics; v_permlane32_swap in its
+// place was measured at +-0 there (round 6: three alternating runs per build on one box, the step's kernels within their
+// run-to-run spread), so the form that needs no lane test stays.  The gather kernels' head sums, where the cross-lane traffic
+// is a third of the instructions, take the vector-ALU forms above.
+__device__ __forceinline__ float wave_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // order-preserving float -> uint32 (larger float -> larger uint); NaN sorts above +inf
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
