@@ -502,9 +502,12 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
+    host_ms = []
     for i in range(args.steps):
+        h0 = time.perf_counter()
         step()
         marks[i + 1].record()
+        host_ms.append(1e3 * (time.perf_counter() - h0))
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
@@ -606,6 +609,7 @@ def measure_block(workload, steps, warmup, rank=0, world=1, dev=None, breakdown=
                    + " B=32 N=2048->1024->512" + ("->1024->2048" if seg else "")),
         "value": round(Bb * world * args.steps / elapsed, 2), "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms, 4), "ms_per_step_median": round(statistics.median(step_ms), 4),
+        "step_ms": [round(v, 3) for v in step_ms], "host_enqueue_ms": [round(v, 3) for v in host_ms],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (unit-sphere xyz clouds with jitter and anisotropic scale, random-init weights; no dataset files offline)",
         "config": {"workload": ("BASELINE configs[2]: SegFeatureLearningBlock" if seg else
