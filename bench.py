@@ -403,6 +403,10 @@ def init_ranks(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     ndev = max(torch.cuda.device_count(), 1)
     shared_gpus = world > ndev
+    if shared_gpus and args.backend == "nccl":
+        # (started by torch.distributed.run on a box with fewer GPUs than ranks: RCCL refuses two ranks on one device --
+        # the ranks share GPUs over gloo, as launch_ranks arranges for `python bench.py --gpus N`; flagged in the line)
+        args.backend = "gloo"
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
