@@ -620,14 +620,16 @@ def farthest_point_sample(xyz: torch.Tensor, npoint: int, start: torch.Tensor) -
     return centroids
 
 
-def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm: str = "dot", knn_k: int = 32):
-    """DownSampleGlobal.forward (models/downsample.py:1281-1330, H=1, no res block) with
+def global_sampler_forward(x, wq, wk, wv, M: int, idx_mode: str = "col_sum", asm: str = "dot", knn_k: int = 32,
+                           num_heads: int = 1):
+    """DownSampleGlobal.forward (models/downsample.py:1281-1330, no res block) with split_heads (1332-1336) and
     attention_scoring (models/downsample.py:1338-1358) for asm dot / dot-sub / l2 / l2+.
-    Returns ((x_ds, idx (B,1,M)), (x_dropped, idx_dropped (B,1,N-M)), score (B,1,N))."""
+    Returns ((x_ds, idx (B,H,M)), (x_dropped, idx_dropped (B,H,N-M)), score (B,H,N))."""
     B, C, N = x.shape
-    q = F.conv1d(x, wq).view(B, 1, C, N).permute(0, 1, 3, 2)
-    k = F.conv1d(x, wk).view(B, 1, C, N)
-    v = F.conv1d(x, wv).view(B, 1, C, N)
+    H = num_heads
+    q = F.conv1d(x, wq).view(B, H, wq.shape[0] // H, N).permute(0, 1, 3, 2)
+    k = F.conv1d(x, wk).view(B, H, wk.shape[0] // H, N)
+    v = F.conv1d(x, wv).view(B, H, wv.shape[0] // H, N)
     if asm == "dot":
         energy = q @ k
     elif asm == "dot-sub":

@@ -718,15 +718,18 @@ class DownSampleGlobal(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
         if self.asm not in ("dot", "dot-sub", "l2", "l2+"):
             raise ValueError("Please check the setting of asm!")
-        if self.num_heads != 1 or not (q_in == q_out == k_out == v_out == 128):
-            raise NotImplementedError("the HIP kernels are built for one head of 128 channels")
+        # the attention kernels are built for one head of 128 channels (every shipped config); any other width or head
+        # count the reference constructs (models/downsample.py:1248-1279) runs the same expressions in torch on the device
+        self._hip_attention = self.num_heads == 1 and q_in == q_out == k_out == v_out == 128
         self._forced_idx = None
 
     def forward(self, x, x_xyz=None, forced_idx=None):
-        """forced_idx = (idx (B,1,M), idx_dropped (B,1,N-M)): parity-test hook -- gather these rows instead of the
+        """forced_idx = (idx (B,H,M), idx_dropped (B,H,N-M)): parity-test hook -- gather these rows instead of the
         selected ones (the statistic is still computed and published as `attention`)."""
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
+        if not self._hip_attention:
+            return self._forward_generic(x, forced_idx)
         B, N = x.shape[0], x.shape[2]
         self._forced_idx = None if forced_idx is None else (
             forced_idx[0].reshape(B, self.M).to(device=x.device, dtype=torch.int64).contiguous(),
@@ -745,6 +748,67 @@ class DownSampleGlobal(nn.Module):
         if self.res == True:  # noqa: E712
             x_ds = self.res_block(x, x_ds)
         return (x_ds, self.idx), (x_dropped, idx_dropped)
+
+    def _forward_generic(self, x, forced_idx):
+        """models/downsample.py:1281-1405 for the widths and head counts the attention kernels are not built for: the
+        projections, the (B,H,N,N) softmax and A V as torch expressions on the device (torch's autograd carries their
+        gradients; the map lives in HBM as in the reference); the neighbour search of the sparse_* statistics and both
+        top-k selections (exact ties by ascending index) on the HIP stage kernels of the 128-channel path."""
+        B, _, N = x.shape
+        H, M = self.num_heads, self.M
+        q = self.q_conv(x).view(B, H, self.q_depth, N).permute(0, 1, 3, 2)                 # (B,H,N,D)
+        k = self.k_conv(x).view(B, H, self.k_depth, N)                                     # (B,H,D,N)
+        v = self.v_conv(x).view(B, H, self.v_depth, N)
+        if self.asm == "dot":
+            energy = q @ k
+        elif self.asm == "dot-sub":
+            energy = q @ (q.transpose(-1, -2) - k)
+        else:  # l2 / l2+: utils/ops.py:115-122
+            sq = q.square().sum(-1, keepdim=True) - 2.0 * (q @ k) + k.square().sum(-2, keepdim=True)
+            energy = -sq if self.asm == "l2" else sq
+        A = torch.softmax(energy / math.sqrt(q.shape[-1]), dim=-1)                         # (B,H,N,N)
+        with torch.no_grad():
+            col = A.sum(dim=-2)
+            if self.idx_mode == "col_sum":
+                stat = col
+            elif self.idx_mode == "row_std":
+                stat = torch.std(A, dim=-1)
+            elif self.idx_mode in GLOBAL_SPARSE_MODES:
+                # idx_selection's sparse branch (1383-1401): the row deviation runs over all N entries of the masked row,
+                # the in-degree is used as it is (a column nobody lists: 0/0 = NaN, which top-k ranks first)
+                nn_idx = ops.stage_knn(x.detach(), x.detach(), self.K).long()
+                mask = torch.zeros((B, N, N), dtype=torch.float32, device=x.device).scatter_(2, nn_idx, 1.0).unsqueeze(1)
+                sam = A * mask
+                num = mask.sum(dim=-2).expand(-1, H, -1)
+                if self.idx_mode == "sparse_row_sum":
+                    stat = sam.sum(dim=-1)
+                elif self.idx_mode == "sparse_row_std":
+                    stat = torch.std(sam, dim=-1)
+                else:
+                    cs = sam.sum(dim=-2)
+                    stat = {"sparse_col_sum": lambda: cs, "sparse_col_avg": lambda: cs / num,
+                            "sparse_col_sqr": lambda: cs / num / num,
+                            "sparse_col_sum_sqr": lambda: 0.5 * (cs / num / num) + 0.5 * cs}[self.idx_mode]()
+                del sam, mask
+            else:
+                raise ValueError("Please check the setting of idx mode!")
+            idx = ops.stage_topk_indices(stat.reshape(B * H, N), M, largest=True).view(B, H, M)
+            idx_dropped = ops.stage_topk_indices(col.reshape(B * H, N), N - M, largest=False).view(B, H, N - M)
+            if forced_idx is not None:
+                idx = forced_idx[0].reshape(B, H, M).to(device=x.device, dtype=torch.int64)
+                idx_dropped = forced_idx[1].reshape(B, H, N - M).to(device=x.device, dtype=torch.int64)
+
+        def rows(ix):   # (B,H,m) -> (B, H Dv, m): the selected rows of A times V, heads concatenated along the channels
+            a = torch.gather(A, 2, ix.unsqueeze(-1).expand(-1, -1, -1, N))
+            o = (a @ v.transpose(-1, -2)).permute(0, 2, 1, 3)                               # (B,m,H,Dv)
+            return o.reshape(B, ix.shape[2], -1).permute(0, 2, 1)
+
+        self.idx = idx
+        self.attention = stat
+        x_ds = rows(idx)
+        if self.res == True:  # noqa: E712
+            x_ds = self.res_block(x, x_ds)
+        return (x_ds, self.idx), (rows(idx_dropped), idx_dropped)
 
     def res_block(self, x, x_ds):
         x_tmp = torch.gather(x, dim=-1, index=self.idx)
@@ -855,8 +919,9 @@ class DownSampleLocal(nn.Module):
         self.boltzmann_norm_mode = config_ds.boltzmann.norm_mode[layer]
         if self.asm not in ("dot", "dot-neighbor", "dot-sub", "l2", "l2+"):
             raise ValueError("Please check the setting of asm!")
-        if not (q_in == q_out == k_in == k_out == v_in == v_out == 128):
-            raise NotImplementedError("the HIP kernels are built for 128 channels")
+        # the gather-attention kernels are built for 128 channels (every shipped config); any other width the reference
+        # constructs (models/downsample.py:834-878) runs the same expression in torch on the device
+        self._hip_attention = q_in == q_out == k_in == k_out == v_in == v_out == 128
         if self.idx_mode not in ("local_std", "sparse_row_std", "sparse_col_sum", "sparse_col_avg", "sparse_col_sqr"):
             raise ValueError("Please check the setting of idx mode!")
 
@@ -873,7 +938,10 @@ class DownSampleLocal(nn.Module):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape
-        if self.asm in ("l2", "l2+"):
+        if not self._hip_attention:
+            x_all, att, nn_idx = self._attention_generic(x)
+            C = x_all.shape[1]
+        elif self.asm in ("l2", "l2+"):
             x_all, att, nn_idx = self._l2_attention(x)
         else:
             # attention_scoring (models/downsample.py:977-1000).  dot-sub: q (q^T - k_j) = |q|^2 - <q, k_j>: the first
@@ -909,6 +977,29 @@ class DownSampleLocal(nn.Module):
         if self.res == True:  # noqa: E712
             x_ds = self.res_block(x, x_ds)
         return (x_ds, self.idx), (x_dropped, idx_dropped.unsqueeze(1))
+
+    def _attention_generic(self, x):
+        """models/downsample.py:885-1000 for the widths the gather-attention kernels are not built for: neighbours by the HIP
+        kNN, then the grouping, the three 1x1 Conv2d over the (B,C,N,K) tensor, the 1 x K softmax and A V as torch
+        expressions on the device (torch's autograd carries their gradients).  -> (B,Cv,N), (B,N,K), (B,N,K) int32"""
+        B, C, N = x.shape
+        K = self.K
+        nn_idx = ops.stage_knn(x.detach(), x.detach(), K)
+        nb = torch.gather(x, 2, nn_idx.long().reshape(B, 1, N * K).expand(-1, C, -1)).view(B, C, N, K)
+        if self.group_type == "diff":
+            nb = nb - x.unsqueeze(-1)
+        q = self.q_conv(x.unsqueeze(-1))                                  # (B,D,N,1)
+        k, v = self.k_conv(nb), self.v_conv(nb)                           # (B,D,N,K), (B,Dv,N,K)
+        if self.asm in ("dot", "dot-neighbor"):
+            energy = (q * k).sum(dim=1)                                   # (B,N,K)
+        elif self.asm == "dot-sub":
+            energy = (q * (q - k)).sum(dim=1)
+        else:  # l2 / l2+: the K x K matrix (q - k_a)(q - k_b) averaged over a = <q - kbar, q - k_b>
+            e = ((q - k.mean(dim=-1, keepdim=True)) * (q - k)).sum(dim=1)
+            energy = -e if self.asm == "l2" else e
+        att = torch.softmax(energy / math.sqrt(self.q_depth), dim=-1)
+        out = (att.unsqueeze(1) * v).sum(dim=-1)                          # (B,Dv,N)
+        return out, att, nn_idx
 
     def _l2_attention(self, x):
         """asm l2 / l2+ (models/downsample.py:984-996): the reference forms the K x K matrix (q - k_a)(q - k_b) and

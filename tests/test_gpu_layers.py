@@ -409,6 +409,103 @@ def test_downsample_global_against_reference_fixture(name):
         assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
 
 
+def _widths(cfg_kwargs, C, H):
+    cfg_kwargs.update({k_: [C, C] for k_ in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out")}, num_heads=[H, H])
+    return cfg_kwargs
+
+
+@pytest.mark.parametrize("name", ["layer_global_c64", "layer_global_c64_heads2_rowstd", "layer_global_heads4_sparse_colsqr",
+                                  "layer_global_c256_l2"])
+def test_downsample_global_other_widths_and_heads_against_reference_fixture(name):
+    """The reference constructs DownSampleGlobal at any q_in / q_out and any head count (models/downsample.py:1248-1279,
+    split_heads 1332-1336); the attention kernels are built for one head of 128 channels.  Every other configuration runs
+    the same expressions in torch ON THE DEVICE (no refusal, no CPU path) with the neighbour search and both top-k
+    selections on the HIP stage kernels: outputs (B, H Dv, M), idx (B, H, M), gradients, against the reference's."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleGlobal
+    d = layer_fixture(name)
+    B, C, N, M, seed = [int(v) for v in d["meta"]]
+    H = int(d["num_heads"])
+    asm, idx_mode = str(d["asm"]), str(d["idx_mode"])
+    cfg = sampler_config("cls", **_widths(dict(M=[M, M // 2], idx_mode=[idx_mode, idx_mode], asm=[asm, asm]), C, H))
+    mod = DownSampleGlobal(cfg, 0)
+    assert not mod._hip_attention and sorted(mod.state_dict()) == ["k_conv.weight", "q_conv.weight", "v_conv.weight"]
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, C, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, C, 1), seed + 3, 0.09))
+    mod = mod.to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    with pytest.raises(Exception, match="GPU only"):
+        mod(x.detach().cpu())
+    (x_ds, idx), (x_dr, idx_dr) = mod(x)
+    assert idx.shape == (B, H, M) and idx_dr.shape == (B, H, N - M) and idx.dtype == torch.int64
+    assert x_ds.shape == (B, C, M) and x_dr.shape == (B, C, N - M)
+    got_s, ref_s = mod.attention.cpu(), torch.from_numpy(d["score"])
+    assert torch.equal(torch.isnan(got_s), torch.isnan(ref_s)) or idx_mode.startswith("sparse")
+    if idx_mode.startswith("sparse"):   # (a near-tie at a row's K-th neighbour moves one membership between two columns)
+        off = ~torch.isclose(torch.nan_to_num(got_s, nan=-1.0), torch.nan_to_num(ref_s, nan=-1.0), rtol=1e-4, atol=1e-7)
+        assert int(off.sum()) <= 4 * H, int(off.sum())
+    else:
+        torch.testing.assert_close(got_s, ref_s, rtol=1e-4, atol=1e-7)
+    ref_idx, ref_idr = torch.from_numpy(d["idx"]), torch.from_numpy(d["idx_dropped"])
+    assert set_agreement(idx.cpu(), ref_idx) >= 0.99 and set_agreement(idx_dr.cpu(), ref_idr) >= 0.99
+    # gradients and outputs through the reference's own index sets
+    mod.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    (x_ds, idx2), (x_dr, idx_dr2) = mod(x2, forced_idx=(ref_idx.to(DEV), ref_idr.to(DEV)))
+    assert torch.equal(idx2.cpu(), ref_idx) and torch.equal(idx_dr2.cpu(), ref_idr)
+    torch.testing.assert_close(x_ds.detach().cpu(), torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(x_dr.detach().cpu(), torch.from_numpy(d["x_dropped"]), rtol=1e-4, atol=2e-5)
+    g1 = torch.from_numpy(synth.normal((B, C, M), seed + 20)).to(DEV)
+    g2 = torch.from_numpy(synth.normal((B, C, N - M), seed + 21)).to(DEV)
+    ((x_ds * g1).sum() + (x_dr * g2).sum()).backward()
+    for got, key in ((x2.grad, "dx"), (mod.q_conv.weight.grad, "dwq"), (mod.k_conv.weight.grad, "dwk"),
+                     (mod.v_conv.weight.grad, "dwv")):
+        ref = torch.from_numpy(d[key])
+        assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
+
+
+@pytest.mark.parametrize("name", ["layer_local_c64_std", "layer_local_c64_colsqr_l2", "layer_local_c256_dotsub"])
+def test_downsample_local_other_widths_against_reference_fixture(name):
+    """DownSampleLocal at widths the gather-attention kernels are not built for (the reference constructs any,
+    models/downsample.py:834-878): neighbours by the HIP kNN, the grouped 1 x K attention as torch expressions on the
+    device; map, score, both index sets, outputs and gradients against the reference's."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleLocal
+    d = layer_fixture(name)
+    B, C, N, M, seed = [int(v) for v in d["meta"]]
+    mode, asm = str(d["idx_mode"]), str(d["asm"])
+    cfg = sampler_config("cls", **_widths(dict(M=[M, M // 2], idx_mode=[mode, mode], asm=[asm, asm]), C, 1))
+    mod = DownSampleLocal(cfg, 0)
+    assert not mod._hip_attention and tuple(mod.q_conv.weight.shape) == (C, C, 1, 1)
+    with torch.no_grad():
+        mod.q_conv.weight.copy_(_w((C, C, 1, 1), seed + 1, 0.09))
+        mod.k_conv.weight.copy_(_w((C, C, 1, 1), seed + 2, 0.09))
+        mod.v_conv.weight.copy_(_w((C, C, 1, 1), seed + 3, 0.09))
+    mod = mod.to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, seed)).to(DEV).requires_grad_(True)
+    (x_ds, idx), (x_dr, idx_dr) = mod(x)
+    assert idx.shape == (B, 1, M) and idx_dr.shape == (B, 1, N - M) and x_ds.shape == (B, C, M)
+    att_sorted = torch.sort(mod.attention_map[:, 0, :, 0, :].cpu(), dim=-1)[0]
+    torch.testing.assert_close(att_sorted, torch.sort(torch.from_numpy(d["att"]), dim=-1)[0], rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(mod.attention_point_score.cpu(), torch.from_numpy(d["score"]), rtol=3e-4, atol=1e-7)
+    ref_idx, ref_idr = torch.from_numpy(d["idx"]), torch.from_numpy(d["idx_dropped"])
+    assert set_agreement(idx.cpu()[:, 0], ref_idx[:, 0]) >= 0.99 and set_agreement(idx_dr.cpu()[:, 0], ref_idr[:, 0]) >= 0.99
+    mod.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    (x_ds, idx2), (x_dr, idx_dr2) = mod(x2, forced_idx=(ref_idx.to(DEV), ref_idr.to(DEV)))
+    assert torch.equal(idx2.cpu(), ref_idx) and torch.equal(idx_dr2.cpu(), ref_idr)
+    torch.testing.assert_close(x_ds.detach().cpu(), torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(x_dr.detach().cpu(), torch.from_numpy(d["x_dropped"]), rtol=1e-4, atol=2e-5)
+    g1 = torch.from_numpy(synth.normal((B, C, M), seed + 20)).to(DEV)
+    g2 = torch.from_numpy(synth.normal((B, C, N - M), seed + 21)).to(DEV)
+    ((x_ds * g1).sum() + (x_dr * g2).sum()).backward()
+    for got, key in ((x2.grad, "dx"), (mod.q_conv.weight.grad, "dwq"), (mod.v_conv.weight.grad, "dwv")):
+        ref = torch.from_numpy(d[key])
+        assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
+
+
 def test_farthest_point_sample_exact():
     """utils/ops.py:622-643 on the HIP kernel: bit-exact index sequence on the reference's fixture,
     and against the oracle at a ragged size and at N=8192 (the kernel's register-resident maximum)."""

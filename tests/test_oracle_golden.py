@@ -118,6 +118,41 @@ def test_oracle_local_sampler_reproduces_reference_fixtures():
         torch.testing.assert_close(x_ds, torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=1e-5)
 
 
+def test_oracle_samplers_at_other_widths_and_heads_reproduce_reference_fixtures():
+    """DownSampleGlobal (any width, any head count) and DownSampleLocal (any width) restatements vs what the reference
+    produced at C = 64 / 256 and H = 2 / 4 (round 6 fixtures; tests/golden/make_golden_layers.py)."""
+    from samble_amd import synth
+    from tests.util import layer_fixture
+
+    def w(shape, seed, scale):
+        return torch.from_numpy((synth.normal(shape, seed).astype(np.float64) * scale).astype(np.float32))
+
+    for name in ("layer_global_c64", "layer_global_c64_heads2_rowstd", "layer_global_heads4_sparse_colsqr",
+                 "layer_global_c256_l2"):
+        d = layer_fixture(name)
+        B, C, N, M, seed = [int(v) for v in d["meta"]]
+        x = torch.from_numpy(synth.features(B, C, N, seed))
+        (x_ds, idx), (x_dr, idx_dr), score = O.global_sampler_forward(
+            x, w((C, C, 1), seed + 1, 0.09), w((C, C, 1), seed + 2, 0.09), w((C, C, 1), seed + 3, 0.09), M,
+            idx_mode=str(d["idx_mode"]), asm=str(d["asm"]), num_heads=int(d["num_heads"]))
+        assert idx.shape == (B, int(d["num_heads"]), M)
+        torch.testing.assert_close(torch.nan_to_num(score, nan=-1.0), torch.nan_to_num(torch.from_numpy(d["score"]), nan=-1.0),
+                                   rtol=1e-4, atol=1e-7)
+        assert torch.equal(idx, torch.from_numpy(d["idx"])) and torch.equal(idx_dr, torch.from_numpy(d["idx_dropped"])), name
+        torch.testing.assert_close(x_ds, torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(x_dr, torch.from_numpy(d["x_dropped"]), rtol=1e-4, atol=1e-5)
+    for name in ("layer_local_c64_std", "layer_local_c64_colsqr_l2", "layer_local_c256_dotsub"):
+        d = layer_fixture(name)
+        B, C, N, M, seed = [int(v) for v in d["meta"]]
+        x = torch.from_numpy(synth.features(B, C, N, seed))
+        (x_ds, idx), (x_dr, idx_dr), score, att = O.local_sampler_forward(
+            x, w((C, C, 1, 1), seed + 1, 0.09), w((C, C, 1, 1), seed + 2, 0.09), w((C, C, 1, 1), seed + 3, 0.09), M,
+            str(d["idx_mode"]), asm=str(d["asm"]))
+        torch.testing.assert_close(score, torch.from_numpy(d["score"]), rtol=1e-4, atol=1e-7)
+        assert torch.equal(idx, torch.from_numpy(d["idx"])) and torch.equal(idx_dr, torch.from_numpy(d["idx_dropped"])), name
+        torch.testing.assert_close(x_ds, torch.from_numpy(d["x_ds"]), rtol=1e-4, atol=1e-5)
+
+
 def test_oracle_small_ops_reproduce_reference_vectors():
     """norm_range / sort_chunk / l2_global / fps of the oracle against the reference's vectors (make_golden_ops.py)."""
     import os
