@@ -135,7 +135,8 @@ int samble_stat_score_f32(const float* stat, int B, int N, float* score, float* 
 /* ---- models/downsample.py:300-344  calculate_attention_score (sparse_* modes) ----------------
  * nn (B,N,KN) int32 = neighbour lists from samble_knn_f32 on the layer input.  score (B,N),
  * z (B,N) = per-cloud z-score of the score (utils/ops.py:450-452), indeg_out (B,N) int32 or NULL
- * = kNN in-degree (sparse_num without its 1e-8). */
+ * = kNN in-degree (sparse_num without its 1e-8).  Any N: up to 12 800 points a workgroup keeps the cloud's column
+ * accumulators in LDS, longer clouds add the same integer terms to global memory directly (same bits). */
 size_t samble_score_workspace_bytes(int B, int N);
 int samble_sparse_score_f32(const float* Q, int64_t q_bs, int64_t q_rs, const float* K, int64_t k_bs, int64_t k_rs,
                             const float* lse, const int32_t* nn, int B, int N, int KN, int D, int mode, float* score,
@@ -172,7 +173,9 @@ int samble_alloc_counts_f32(const float* w, const int32_t* cap, int B, int nb, i
 
 /* ---- utils/ops.py:467-619  generating_downsampled_index --------------------------------------
  * noise (B*nb, N) = the Exp(1) draw torch.multinomial makes internally (row b*nb+t); NULL for
- * topk.  temp: inverse temperature (TEMP_FIXED) or divisor (TEMP_COUNT).  idx_out (B,M) int64. */
+ * topk.  temp: inverse temperature (TEMP_FIXED) or divisor (TEMP_COUNT).  idx_out (B,M) int64.
+ * N <= 16384 (a cloud's selection keys live in one workgroup's LDS): the longest cloud the sampler layer takes --
+ * twice BASELINE's largest configuration (configs[4], N = 8192). */
 int samble_bin_select_f32(const float* score, const float* z, const uint8_t* member, const int32_t* counts,
                           const float* noise, int B, int N, int nb, int M, int sample_mode, int temp_mode, float temp,
                           int64_t* idx_out, void* stream);
@@ -343,7 +346,7 @@ int samble_attn_rows_bwd_f32(const float* Q, int64_t q_bs, int64_t q_rs, const f
 
 /* ---- the integer tail as two launches, or one (same reference lines as the stand-alone entries above) ----------------
  * For shapes samble_select_chain_supported(B, N, nb) accepts (one 1024-thread workgroup per cloud, all resident:
- * B <= min(128, CUs / 2), B * nb <= 1024, N <= 16384), over ONE caller-owned workspace of
+ * B <= min(128, CUs / 2), B * nb <= 1024, N <= 12800), over ONE caller-owned workspace of
  * samble_select_chain_workspace_bytes(B, N).
  * The grid barrier's poll is BOUNDED and its give-up is CLEAN: if the workgroups turn out not to be co-resident (a
  * co-tenant, a CU mask), the poll stops after ~1 s, raises the workspace's status word and every workgroup leaves the

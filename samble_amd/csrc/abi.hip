@@ -268,7 +268,6 @@ SAMBLE_API int samble_sparse_score_f32(const float* Q, int64_t q_bs, int64_t q_r
   if (D != 128) return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: D must be 128");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: unknown score mode");
-  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_sparse_score_f32: N too large for LDS");
   if (ws_bytes < samble_score_ws_bytes(B, N))
     return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_f32: workspace too small");
   return done(samble_launch_sparse_score(Q, q_bs, q_rs, K, k_bs, k_rs, lse, nn, B, N, KN, inv_sqrt_d(D), mode, score, z,
@@ -791,7 +790,6 @@ SAMBLE_API int samble_sparse_score_map_f32(const float* smap, int ld, const floa
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: null pointer");
   if (mode < 0 || mode > SAMBLE_SCORE_SPARSE_ROW_STD)
     return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: unknown score mode");
-  if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_sparse_score_map_f32: N too large for LDS");
   if (ws_bytes < samble_score_ws_bytes(B, N))
     return fail(SAMBLE_E_WORKSPACE, "samble_sparse_score_map_f32: workspace too small");
   return done(samble_launch_sparse_score_map(smap, ld, lse, nn, B, N, KN, mode, score, z, indeg_out, ws,

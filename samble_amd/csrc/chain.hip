@@ -463,7 +463,9 @@ extern "C" int samble_chain_supported(int B, int N, int nb) {
   if (resident_workgroups(&cus)) return 0;
   // (2 B <= CUs: head-room for a second rank or another stream sharing the device -- co-residency is inferred, not
   // guaranteed; the barrier's poll is bounded for the cases this does not catch)
-  return B >= 1 && 2 * B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && N <= 16 * 1024 && nb >= 2 && nb <= kMaxBins;
+  // (N: the score pass in front of the chain keeps a cloud's N column accumulators, 12 bytes each, in LDS)
+  return B >= 1 && 2 * B <= cus && B * nb <= 1024 && B <= 128 && N >= 1 && (size_t)N * 12 <= 150 * 1024 && nb >= 2 &&
+         nb <= kMaxBins;
 }
 
 // poll rounds a grid barrier waits before it gives up: the caller's `spin_budget`, 0 = the default (~1 s)

@@ -20,6 +20,12 @@ constexpr float kUnfix = 1.f / 17592186044416.f;
 enum ScoreMode { kColSum = 0, kColAvg = 1, kColSqr = 2, kRowSum = 3, kRowStd = 4 };
 
 // grid (ceil(N/64), B), 256 threads: 8 half-waves, each walks rows r0+hw, r0+hw+8, ...
+// DIRECT: clouds whose N column accumulators (12 bytes each) do not fit a workgroup's LDS (N > 12 800): the same integer
+// atomics go to the cloud's global accumulators one by one -- the same sums bit for bit (integers), slower
+constexpr size_t kScoreLdsMax = 150 * 1024;
+static inline bool score_direct(int N) { return (size_t)N * 12 > kScoreLdsMax; }
+
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restrict__ Q, long q_bs, long q_rs,
                                                            const float* __restrict__ K, long k_bs, long k_rs,
                                                            const float* __restrict__ lse,
@@ -28,19 +34,21 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
                                                            int* __restrict__ indeg, float* __restrict__ rowstat,
                                                            int row_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(sraw);
-  int* cnt = reinterpret_cast<int*>(acc + N);
   const int tid = threadIdx.x;
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MB
   // L2), so give every XCD its own clouds: the K rows a cloud's workgroups gather (1 MB) are then
   // re-read from that XCD's L2 instead of the Infinity Cache.  Speed only; any mapping is correct.
   int b, chunk;
   xcd_assign(chunk, b);
-  for (int n = tid; n < N; n += 256) {
-    acc[n] = 0ull;
-    cnt[n] = 0;
+  unsigned long long* acc = DIRECT ? colacc + (long)b * N : reinterpret_cast<unsigned long long*>(sraw);
+  int* cnt = DIRECT ? indeg + (long)b * N : reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(sraw) + N);
+  if (!DIRECT) {
+    for (int n = tid; n < N; n += 256) {
+      acc[n] = 0ull;
+      cnt[n] = 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int hw = tid >> 5, c = tid & 31;
   const int r0 = chunk * 64;
   const float* Qb = Q + (long)b * q_bs;
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
       rowstat[(long)b * N + i] = v;
     }
   }
+  if (DIRECT) return;
   __syncthreads();
   for (int n = tid; n < N; n += 256) {
     const int cn = cnt[n];
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256) void sparse_score_kernel(const float* __restri
 // grid (ceil(N/64), B), 256 threads: 8 half-waves, each walks rows r0+hw, r0+hw+8, ...
 // COMPACT: `smap` is the (B, N, KN) array of neighbour logits of attn_stats_nl (entry k of row i = the logit of
 // neighbour nn[i][k], nn in ascending-index order) instead of the (B, N, ld) logit map.
-template <bool COMPACT>
+template <bool COMPACT, bool DIRECT>
 __global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __restrict__ smap, int ld,
                                                                const float* __restrict__ lse,
                                                                const int* __restrict__ nn, int N, int KN,
@@ -109,17 +118,19 @@ __global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __re
                                                                int* __restrict__ indeg, float* __restrict__ rowstat,
                                                                int row_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sraw[];
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(sraw);
-  int* cnt = reinterpret_cast<int*>(acc + N);
   __shared__ double rsum[8][8][2];  // row-statistic partials of (half-wave, row) across neighbour chunks
   const int tid = threadIdx.x;
   int b, chunk;
   xcd_assign(chunk, b);
-  for (int n = tid; n < N; n += 256) {
-    acc[n] = 0ull;
-    cnt[n] = 0;
+  unsigned long long* acc = DIRECT ? colacc + (long)b * N : reinterpret_cast<unsigned long long*>(sraw);
+  int* cnt = DIRECT ? indeg + (long)b * N : reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(sraw) + N);
+  if (!DIRECT) {
+    for (int n = tid; n < N; n += 256) {
+      acc[n] = 0ull;
+      cnt[n] = 0;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int hw = tid >> 5, c = tid & 31;
   const int r0 = chunk * 64;
   // the 8 rows of a half-wave are independent: their neighbour-list loads, then their scattered map reads,
@@ -177,6 +188,7 @@ __global__ __launch_bounds__(256) void sparse_score_map_kernel(const float* __re
       }
     }
   }
+  if (DIRECT) return;
   __syncthreads();
   for (int n = tid; n < N; n += 256) {
     const int cn = cnt[n];
@@ -282,14 +294,15 @@ extern "C" int samble_launch_sparse_score(const float* Q, long q_bs, long q_rs, 
   float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
   hipError_t e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
   if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)N * 12;
+  const bool direct = score_direct(N);
+  const size_t lds = direct ? 0 : (size_t)N * 12;
+  auto kern = direct ? sparse_score_kernel<true> : sparse_score_kernel<false>;
   if (lds > 64 * 1024) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(sparse_score_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   Timed timed(kT_sparse_score, stream);
-  hipLaunchKernelGGL(sparse_score_kernel, dim3((N + 63) / 64, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
+  hipLaunchKernelGGL(kern, dim3((N + 63) / 64, B), dim3(256), lds, stream, Q, q_bs, q_rs, K, k_bs, k_rs,
                      lse, nn, N, KN, scale, colacc, indeg, mode >= kRowSum ? rowstat : nullptr, mode);
   hipLaunchKernelGGL(finalize_score_kernel, dim3(B), dim3(256), 0, stream, colacc, indeg, rowstat, N, mode, score, z);
   if (indeg_out) {
@@ -311,8 +324,10 @@ extern "C" int samble_launch_sparse_score_map(const float* smap, int ld, const f
   if (smap) {  // null: the accumulators were filled by attn_stats_nl_tri (attn_tri.hip)
     e = hipMemsetAsync(ws, 0, (size_t)B * N * 12, stream);
     if (e != hipSuccess) return (int)e;
-    const size_t lds = (size_t)N * 12;
-    auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;  // ld == 0: compact logits
+    const bool direct = score_direct(N);
+    const size_t lds = direct ? 0 : (size_t)N * 12;
+    auto kern = ld == 0 ? (direct ? sparse_score_map_kernel<true, true> : sparse_score_map_kernel<true, false>)   // ld == 0: compact logits
+                        : (direct ? sparse_score_map_kernel<false, true> : sparse_score_map_kernel<false, false>);
     if (lds > 64 * 1024) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
@@ -339,8 +354,8 @@ extern "C" int samble_launch_sparse_score_map_acc(const float* smap, int ld, con
   float* rowstat = reinterpret_cast<float*>(indeg + (size_t)B * N);
   hipError_t e = hipMemsetAsync(ws, 0, zero_bytes, stream);
   if (e != hipSuccess) return (int)e;
-  const size_t lds = (size_t)N * 12;
-  auto kern = ld == 0 ? sparse_score_map_kernel<true> : sparse_score_map_kernel<false>;
+  const size_t lds = (size_t)N * 12;   // (the chain takes N <= 12 800 only: samble_chain_supported)
+  auto kern = ld == 0 ? sparse_score_map_kernel<true, false> : sparse_score_map_kernel<false, false>;
   if (lds > 64 * 1024) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

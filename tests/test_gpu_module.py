@@ -459,6 +459,56 @@ def test_map_free_long_cloud_takes_the_compact_score_route():
         assert torch.equal(t1, t2), j
 
 
+def test_cloud_past_the_lds_score_accumulators():
+    """N = 13000 > 12800: a cloud's N column accumulators (12 bytes each) no longer fit a workgroup's LDS, the fused select
+    chain does not take the shape (samble_select_chain_supported) and the score pass adds its integer terms to the cloud's
+    global accumulators directly (csrc/score.hip DIRECT) -- rounds 1-5 refused such clouds ("N too large for LDS"; the
+    reference takes any N).  Both forward pipelines bit-identical to each other; neighbour sets, score, and sampled sets
+    against the oracle under the GPU's boundaries; N = 16384 (bin_select's limit) runs."""
+    import samble_amd.downsample as D
+    from samble_amd import ops, sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 1, 128, 13000, 3000, 6
+    assert not ops.chain_supported(B, N, nb) and ops.chain_supported(B, 12800, nb)
+    x = torch.from_numpy(synth.features(B, C, N, 51)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 52)).to(DEV)
+    outs = []
+    old_mode, old_free = ops.MATRIX_MODE, D.MAP_FREE
+    try:
+        ops.MATRIX_MODE = "tri"
+        for free in (False, True):
+            D.MAP_FREE = free
+            torch.manual_seed(3)
+            mod = DownSampleToken(sampler_config("cls", M=[M, M // 2]), 0).to(DEV)
+            xin = x.clone().requires_grad_(True)
+            (x_ds, idx), _ = mod(xin, noise=noise)
+            x_ds.sum().backward()
+            outs.append((x_ds.detach(), idx, mod.attention_point_score, xin.grad, mod.q_conv.weight.grad))
+    finally:
+        ops.MATRIX_MODE, D.MAP_FREE = old_mode, old_free
+    for j, (t1, t2) in enumerate(zip(*outs)):
+        assert torch.equal(t1, t2), j
+    spec = O.SamplerSpec(M=M, K=32, C=C, num_bins=nb, dynamic_boundaries=False)
+    st = O.SamplerState(mod.q_conv.weight.detach().cpu(), mod.k_conv.weight.detach().cpu(), mod.v_conv.weight.detach().cpu(),
+                        mod.bin_tokens.detach().cpu(), [t.cpu().clone() for t in mod.bin_boundaries])
+    _, idx_ref = O.sampler_forward(spec, st, x.cpu(), noise.cpu())
+    assert set_agreement(mod.knn_idx.cpu(), st.trace["knn_idx"]) >= 0.9999
+    off = ~torch.isclose(mod.attention_point_score[:, 0].cpu(), st.trace["score"].reshape(B, N), rtol=1e-4, atol=1e-9)
+    assert int(off.sum()) <= 8, int(off.sum())     # (a near-tie at a row's K-th neighbour moves one entry between two columns)
+    assert set_agreement(idx[:, 0].cpu(), idx_ref[:, 0]) >= 0.995
+    # the longest cloud the selection kernels take (bin_select keeps a cloud's keys in LDS): runs, unique, finite
+    B2, N2, M2 = 1, 16384, 5000
+    mod2 = DownSampleToken(sampler_config("cls", M=[M2, M2 // 2]), 0).to(DEV)
+    x2 = torch.from_numpy(synth.features(B2, C, N2, 53)).to(DEV).requires_grad_(True)
+    (y2, i2), _ = mod2(x2, noise=torch.from_numpy(synth.exp1((B2 * nb, N2), 54)).to(DEV))
+    y2.sum().backward()
+    assert len(set(i2[0, 0].tolist())) == M2 and int(i2.max()) < N2 and bool(torch.isfinite(y2).all())
+    assert bool(torch.isfinite(x2.grad).all())
+    with pytest.raises(ops._lib.SambleError, match="N <= 16384"):
+        mod3 = DownSampleToken(sampler_config("cls", M=[100, 50]), 0).to(DEV)
+        mod3(torch.from_numpy(synth.features(1, C, 16500, 55)).to(DEV))
+
+
 def test_map_free_without_the_fused_chain():
     """B = 130 clouds: more workgroups than the fused select chain takes (one per cloud, B <= 128), so the map-free
     forward hands its in-pass score statistics to the stand-alone finalize / quantile / bin kernels -- same outputs as
