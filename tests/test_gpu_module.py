@@ -459,6 +459,46 @@ def test_map_free_long_cloud_takes_the_compact_score_route():
         assert torch.equal(t1, t2), j
 
 
+ODD_SHAPES = [(1, 32, 1, 6, "random"), (1, 33, 32, 4, "topk"), (2, 40, 39, 2, "uniform"), (3, 63, 17, 8, "random"),
+              (1, 64, 64, 6, "random"), (5, 65, 7, 4, "topk"), (2, 100, 99, 6, "random"), (7, 129, 64, 8, "random"),
+              (1, 1000, 999, 4, "topk"), (2, 1023, 512, 6, "random"), (2, 1025, 3, 8, "random"), (1, 2047, 1024, 2, "uniform"),
+              (3, 2049, 1000, 6, "random"), (129, 96, 40, 6, "random"), (200, 64, 20, 4, "topk"), (1, 4097, 4000, 6, "random")]
+
+
+@pytest.mark.parametrize("B,N,M,nb,mode", ODD_SHAPES)
+def test_odd_shapes_against_the_oracle(B, N, M, nb, mode):
+    """Ragged and extreme shapes of one layer call (N = K exactly, N not a multiple of any tile, M = 1, M = N, M = N - 1,
+    more clouds than the fused chain takes, 2 to 8 bins, the three draws): forward + backward on the GPU, the oracle on
+    the CPU, each forming its OWN boundaries from its own z-scores as a first call does (utils/ops.py:174-236).  Indices
+    unique and in range, everything finite, the sampled sets the oracle's (a handful of near-tie clouds among hundreds),
+    the features of every identically sampled cloud to 2e-6."""
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    C = 128
+    torch.manual_seed(B * 1000 + N)
+    cfg = sampler_config("cls", M=[M, max(M // 2, 1)], bin__num_bins=[nb, nb], bin__sample_mode=[mode, mode])
+    mod = DownSampleToken(cfg, 0).to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, 7 + N)).to(DEV).requires_grad_(True)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 8 + N)).to(DEV)
+    (x_ds, idx), _ = mod(x, noise=noise)
+    x_ds.backward(torch.ones_like(x_ds))
+    i = idx[:, 0].cpu()
+    assert idx.shape == (B, 1, M) and int(i.min()) >= 0 and int(i.max()) < N
+    assert all(len(set(r.tolist())) == M for r in i), "sampling is without replacement"
+    assert bool(torch.isfinite(x_ds).all()) and bool(torch.isfinite(x.grad).all())
+    assert bool((mod.k_point_to_choose.sum(1) == M).all())
+    spec = O.SamplerSpec(M=M, K=32, C=C, num_bins=nb, dynamic_boundaries=True, sample_mode=mode)
+    st = O.SamplerState(mod.q_conv.weight.detach().cpu(), mod.k_conv.weight.detach().cpu(), mod.v_conv.weight.detach().cpu(),
+                        mod.bin_tokens.detach().cpu(), None)
+    x_ref, idx_ref = O.sampler_forward(spec, st, x.detach().cpu(), noise.cpu())
+    assert set_agreement(i, idx_ref[:, 0]) >= 0.99
+    same = (i == idx_ref[:, 0]).all(1)
+    assert int(same.sum()) >= max(1, int(0.85 * B)) or set_agreement(i, idx_ref[:, 0]) == 1.0, int(same.sum())
+    if bool(same.any()):
+        torch.testing.assert_close(x_ds.detach().cpu()[same], x_ref[same], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(mod.bin_boundaries[0].cpu().flatten()[1:], st.boundaries[0].flatten()[1:], rtol=1e-4, atol=1e-6)
+
+
 def test_cloud_past_the_lds_score_accumulators():
     """N = 13000 > 12800: a cloud's N column accumulators (12 bytes each) no longer fit a workgroup's LDS, the fused select
     chain does not take the shape (samble_select_chain_supported) and the score pass adds its integer terms to the cloud's
