@@ -229,7 +229,8 @@ int samble_group_gather_f32(const float* x, const int32_t* nn, int B, int C, int
 /* ---- utils/ops.py:622-643  farthest_point_sample -------------------------------------------
  * xyz (B,3,N) channel-major (the layout the models hold; the reference permutes to (B,N,3) first),
  * start (B) = the first centroid of each cloud (the reference draws it with torch.randint), out
- * (B,npoint) int64 in selection order.  N <= 8192. */
+ * (B,npoint) int64 in selection order.  N <= 32768 (points and distances in registers up to 16384;
+ * beyond, distances in LDS and the points re-read from the L2 every round). */
 int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out, void* stream);
 
 /* ---- models/attention.py:165-250  Neighbor2PointAttention, attention part (scalar_dot, asm dot) --

@@ -459,8 +459,8 @@ SAMBLE_API int samble_group_gather_f32(const float* x, const int32_t* nn, int B,
 SAMBLE_API int samble_fps_f32(const float* xyz, const int64_t* start, int B, int N, int npoint, int64_t* out,
                               void* stream) {
   if (!xyz || !start || !out) return fail(SAMBLE_E_INVALID, "samble_fps_f32: null pointer");
-  if (B <= 0 || N <= 0 || N > 8192 || npoint <= 0 || npoint > N)
-    return fail(SAMBLE_E_INVALID, "samble_fps_f32: need 1 <= npoint <= N <= 8192");
+  if (B <= 0 || N <= 0 || N > 32768 || npoint <= 0 || npoint > N)
+    return fail(SAMBLE_E_INVALID, "samble_fps_f32: need 1 <= npoint <= N <= 32768");
   return done(samble_launch_fps(xyz, (const long long*)start, B, N, npoint, (long long*)out, (hipStream_t)stream),
               "samble_fps_f32");
 }

@@ -483,30 +483,38 @@ __global__ void gather_points_kernel(const float* __restrict__ pcd, int C, int N
 // ------------------------------------------------------------------------------------------------
 // farthest point sampling (reference utils/ops.py:622-643): npoint rounds of {record the current
 // farthest point, distance[n] = min(distance[n], |xyz_n - c|^2), farthest = argmax(distance)}.
-// One workgroup per cloud, the cloud's points and running distances in registers (<= 8 per thread),
-// the argmax by wave shuffles + one LDS exchange; ties go to the smallest index (torch.max on the
-// CPU returns the first maximum).  The squared distance is summed in the reference's order
+// One workgroup per cloud, the cloud's points and running distances in registers (PER per thread: 8 up to N = 8192,
+// 16 up to 16 384; PER = 0: longer clouds, up to 32 768 points, keep the running distances in LDS and re-read the points
+// from the L2 every round), the argmax by wave shuffles + one LDS exchange; ties go to the smallest index (torch.max on
+// the CPU returns the first maximum).  The squared distance is summed in the reference's order
 // ((dx^2 + dy^2) + dz^2, no FMA contraction: this file is built with -ffp-contract=off).
 // ------------------------------------------------------------------------------------------------
-constexpr int kFpsPer = 8;  // points per thread: N <= 8192
+constexpr int kFpsMaxN = 32768;
 
+template <int PER>
 __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz,  // (B,3,N) channel-major
                                                    const long long* __restrict__ start, int N, int npoint,
                                                    long long* __restrict__ out) {
+  extern __shared__ float fps_dist[];   // PER == 0: the N running distances
   __shared__ float wbest[16];
   __shared__ int widx[16];
   __shared__ int cur_s;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* xb = xyz + (long)b * 3 * N;
+  constexpr int kFpsPer = PER ? PER : 1;
   float px[kFpsPer], py[kFpsPer], pz[kFpsPer], dist[kFpsPer];
+  if (PER) {
 #pragma unroll
-  for (int u = 0; u < kFpsPer; ++u) {
-    const int n = tid + 1024 * u;
-    const bool v = n < N;
-    px[u] = v ? xb[n] : 0.f;
-    py[u] = v ? xb[N + n] : 0.f;
-    pz[u] = v ? xb[2 * N + n] : 0.f;
-    dist[u] = v ? 1e10f : -1.f;  // padding can never win the argmax (distances are >= 0)
+    for (int u = 0; u < kFpsPer; ++u) {
+      const int n = tid + 1024 * u;
+      const bool v = n < N;
+      px[u] = v ? xb[n] : 0.f;
+      py[u] = v ? xb[N + n] : 0.f;
+      pz[u] = v ? xb[2 * N + n] : 0.f;
+      dist[u] = v ? 1e10f : -1.f;  // padding can never win the argmax (distances are >= 0)
+    }
+  } else {
+    for (int n = tid; n < N; n += 1024) fps_dist[n] = 1e10f;   // (each thread only ever touches its own entries)
   }
   int cur = (int)start[b];
   for (int it = 0; it < npoint; ++it) {
@@ -514,15 +522,29 @@ __global__ __launch_bounds__(1024) void fps_kernel(const float* __restrict__ xyz
     const float cx = xb[cur], cy = xb[N + cur], cz = xb[2 * N + cur];
     float best = -2.f;
     int bidx = 0x7fffffff;
+    if (PER) {
 #pragma unroll
-    for (int u = 0; u < kFpsPer; ++u) {
-      const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      if (d < dist[u]) dist[u] = d;
-      const int n = tid + 1024 * u;
-      if (dist[u] > best) {  // ascending n inside a thread: strict > keeps the smallest index
-        best = dist[u];
-        bidx = n;
+      for (int u = 0; u < kFpsPer; ++u) {
+        const float dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        if (d < dist[u]) dist[u] = d;
+        const int n = tid + 1024 * u;
+        if (dist[u] > best) {  // ascending n inside a thread: strict > keeps the smallest index
+          best = dist[u];
+          bidx = n;
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int n = tid; n < N; n += 1024) {
+        const float dx = xb[n] - cx, dy = xb[N + n] - cy, dz = xb[2 * N + n] - cz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        float dn = fps_dist[n];
+        if (d < dn) fps_dist[n] = dn = d;
+        if (dn > best) {
+          best = dn;
+          bidx = n;
+        }
       }
     }
 #pragma unroll
@@ -692,8 +714,17 @@ extern "C" int samble_launch_group_gather(const float* x, const int* nn, int B, 
 
 extern "C" int samble_launch_fps(const float* xyz, const long long* start, int B, int N, int npoint, long long* out,
                                  hipStream_t s) {
-  if (N > 1024 * kFpsPer) return -22;
-  hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(1024), 0, s, xyz, start, N, npoint, out);
+  if (N > kFpsMaxN) return -22;
+  if (N <= 1024 * 8) {
+    hipLaunchKernelGGL(fps_kernel<8>, dim3(B), dim3(1024), 0, s, xyz, start, N, npoint, out);
+  } else if (N <= 1024 * 16) {
+    hipLaunchKernelGGL(fps_kernel<16>, dim3(B), dim3(1024), 0, s, xyz, start, N, npoint, out);
+  } else {
+    const size_t lds = (size_t)N * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fps_kernel<0>, dim3(B), dim3(1024), lds, s, xyz, start, N, npoint, out);
+  }
   return (int)hipGetLastError();
 }
 

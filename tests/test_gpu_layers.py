@@ -508,14 +508,16 @@ def test_downsample_local_other_widths_against_reference_fixture(name):
 
 def test_farthest_point_sample_exact():
     """utils/ops.py:622-643 on the HIP kernel: bit-exact index sequence on the reference's fixture,
-    and against the oracle at a ragged size and at N=8192 (the kernel's register-resident maximum)."""
+    and against the oracle at a ragged size, at N=8192 (the first kernel's register-resident maximum) and on the two
+    kernels for longer clouds (round 6: the reference takes any N; rounds 1-5 stopped at 8192)."""
     from samble_amd import ops
     d = layer_fixture("layer_fps")
     B, N, npoint, seed = [int(v) for v in d["meta"]]
     xyz = torch.from_numpy(synth.xyz_clouds(B, N, seed)).permute(0, 2, 1)  # (B,N,3) view of (B,3,N)
     got = ops.farthest_point_sample(xyz.to(DEV), npoint, torch.from_numpy(d["start"]).to(DEV))
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), torch.from_numpy(d["idx"]))
-    for (B2, N2, np2, sd) in ((2, 777, 300, 11), (1, 8192, 512, 12)):
+    # 8192: the 8-points-per-thread kernel's maximum; 12000: 16 per thread; 20000 / 32768: distances in LDS, points from the L2
+    for (B2, N2, np2, sd) in ((2, 777, 300, 11), (1, 8192, 512, 12), (2, 12000, 200, 13), (1, 20000, 150, 14), (1, 32768, 64, 15)):
         x2 = torch.from_numpy(synth.xyz_clouds(B2, N2, sd)).permute(0, 2, 1).contiguous()
         x2[0, 5] = x2[0, 9]  # duplicate points: equal distances, the first index must win
         st = torch.arange(B2) * 7 % N2
