@@ -272,7 +272,8 @@ def _layer_fusable(mod, x) -> bool:
     # running estimates and leaves them alone (the reference's behaviour, and `batch_norm`'s) -- the fused node would not
     return (FUSED_LAYER and FUSED_FFN and OWN_BATCHNORM and mod.training and bn1.training and bn2.training and x.is_cuda
             and x.dtype == torch.float32 and ops.MATRIX_MODE == "tri"
-            and mod.hip_attention and mod.attention_mode == "scalar_dot" and not mod.group_type.startswith("center_")
+            and mod.hip_attention and mod.K <= 32 and mod.attention_mode == "scalar_dot"
+            and not mod.group_type.startswith("center_")
             and _plain_bn(bn1) and _plain_bn(bn2) and mod.ff[0].bias is None and mod.ff[2].bias is None
             and abs(mod.ff[1].negative_slope - 0.2) < 1e-12 and linear.ffn_supported(x, mod.ff[0].weight, mod.ff[2].weight))
 

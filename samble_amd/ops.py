@@ -47,6 +47,20 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 KNN_FP32_MFMA, KNN_TWO_KERNEL = 1, 2  # include/samble.h SAMBLE_KNN_*
 
 
+KNN_LIST_SIZES = (1, 3, 8, 16, 20, 32, 40, 64)   # neighbour-list lengths the kNN kernels are built for
+
+
+def _knn_expression(xq: torch.Tensor, xk: torch.Tensor, k: int):
+    """utils/ops.py:23-43 as it stands, on the device: centre on the queries' mean, divide by their mean channel deviation,
+    cdist, top-k.  (B,C,Nq), (B,C,Nk) -> idx (B,Nq,k) int32 nearest first, positive distance (B,Nq,k)."""
+    a, b = xq.transpose(1, 2), xk.transpose(1, 2)
+    mean = a.mean(dim=1, keepdim=True)
+    a, b = a - mean, b - mean
+    std = torch.std(a, dim=1, keepdim=True).mean(dim=2, keepdim=True)
+    dist, idx = (-torch.cdist(a / std, b / std, compute_mode="donot_use_mm_for_euclid_dist")).topk(k=k, dim=-1)
+    return idx.int(), -dist
+
+
 def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = False, variant: Optional[int] = None):
     """xq (B,C,Nq), xk (B,C,Nk) channel-major -> idx (B,Nq,k) int32 nearest first
     [, positive reference-normalised distance (B,Nq,k)].  variant: kernel choice (KNN_*); None = the
@@ -57,6 +71,21 @@ def stage_knn(xq: torch.Tensor, xk: torch.Tensor, k: int, want_dist: bool = Fals
     Nk = xk.shape[2]
     if xk.shape[0] != B or xk.shape[1] != C:
         raise ValueError("knn: the two point sets must share batch and channel sizes")
+    if k not in KNN_LIST_SIZES:
+        # the kernels keep lists of these sizes; the reference takes any k (utils/ops.py:17-44).  Lists are nearest
+        # first, so any other k is the head of the next size's list; beyond the kernels' range (k > 64, or a key set
+        # shorter than the next size) the reference's own expression runs in torch on the device
+        if not 1 <= k <= Nk:
+            raise ValueError(f"knn: need 1 <= k <= {Nk} keys, got k = {k}")
+        k2 = next((s for s in KNN_LIST_SIZES if s >= k), None)
+        if k2 is None or k2 > Nk:
+            idx, dist = _knn_expression(xq, xk, k)
+        else:
+            res = stage_knn(xq, xk, k2, want_dist=want_dist, variant=variant)
+            idx, dist = (res if want_dist else (res, None))
+            idx = idx[:, :, :k].contiguous()
+            dist = dist[:, :, :k].contiguous() if want_dist else None
+        return (idx, dist) if want_dist else idx
     with torch.cuda.device(xq.device):
         idx = torch.empty((B, Nq, k), dtype=torch.int32, device=xq.device)
         dist = torch.empty((B, Nq, k), dtype=torch.float32, device=xq.device) if want_dist else None

@@ -409,6 +409,51 @@ def test_downsample_global_against_reference_fixture(name):
         assert (got.cpu() - ref).abs().max().item() <= 3e-4 * ref.abs().max().item() + 1e-6, key
 
 
+@pytest.mark.parametrize("K", [5, 24, 33, 48, 70])
+def test_layers_take_any_neighbour_count(K):
+    """The reference reads K from the config (models/attention.py:133, models/embedding.py:11; every shipped config: 32).
+    The kNN kernels keep lists of eight sizes and the gather-attention backward takes K <= 32: any other K runs on the head
+    of the next list size, K > 32 differentiates the attention core through the chunked torch restatement, and the fused
+    layer node leaves such layers to the node-by-node composition (round 6: it did not, and K = 33 raised).  Forward
+    against the oracle, gradients against torch's autograd of the oracle, for Neighbor2PointAttention and both EdgeConv
+    layers."""
+    from samble_amd import attention as A
+    from samble_amd.embedding import EdgeConv, embedding_config
+    B, N = 2, 300
+    torch.manual_seed(3)
+    cfg = A.attention_config("cls")
+    cfg.K[0] = K
+    mod = A.Neighbor2PointAttention(cfg, 0).to(DEV).train()
+    x = torch.from_numpy(synth.features(B, 128, N, 5)).to(DEV).requires_grad_(True)
+    g = torch.from_numpy(synth.normal((B, 128, N), 6)).to(DEV)
+    y = mod(x)
+    y.backward(g)
+    leaves = [p.detach().cpu().clone().requires_grad_(True) for p in (mod.q_conv.weight, mod.k_conv.weight, mod.v_conv.weight,
+              mod.ff[0].weight, mod.ff[2].weight, mod.bn1.weight, mod.bn1.bias, mod.bn2.weight, mod.bn2.bias)]
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    ref, _, _ = O.n2p_forward(O.N2PState(*leaves), xr, K, mod.num_heads, mod.group_type)
+    ref.backward(g.cpu())
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    for got, want in [(x.grad, xr.grad)] + list(zip((mod.q_conv.weight.grad, mod.v_conv.weight.grad, mod.ff[0].weight.grad,
+                                                      mod.bn2.weight.grad), (leaves[0].grad, leaves[2].grad, leaves[3].grad, leaves[7].grad))):
+        assert float((got.cpu() - want).norm()) <= 2e-4 * float(want.norm()) + 1e-7
+    for layer in (0, 1):
+        ecfg = embedding_config("cls")
+        ecfg.K[layer] = K
+        emod = EdgeConv(ecfg, layer).to(DEV).train()
+        cin = ecfg.conv1_in[layer] // 2
+        x_np = synth.xyz_clouds(B, N, 7) if cin == 3 else synth.features(B, cin, N, 7)
+        xe = torch.from_numpy(x_np).to(DEV).requires_grad_(True)
+        ye = emod(xe)
+        ye.square().mean().backward()
+        want = O.edgeconv_forward(xe.detach().cpu(), K, ecfg.group_type[layer], emod.conv1[0].weight.detach().cpu(),
+                                  (emod.conv1[1].weight.detach().cpu(), emod.conv1[1].bias.detach().cpu()),
+                                  emod.conv2[0].weight.detach().cpu(),
+                                  (emod.conv2[1].weight.detach().cpu(), emod.conv2[1].bias.detach().cpu()))
+        torch.testing.assert_close(ye.detach().cpu(), want, rtol=1e-4, atol=2e-5)
+        assert bool(torch.isfinite(xe.grad).all())
+
+
 def _widths(cfg_kwargs, C, H):
     cfg_kwargs.update({k_: [C, C] for k_ in ("q_in", "q_out", "k_in", "k_out", "v_in", "v_out")}, num_heads=[H, H])
     return cfg_kwargs

@@ -178,6 +178,26 @@ def test_knn_reference_named_wrapper():
     torch.testing.assert_close(d.cpu()[:, :, 1:], rd[:, :, 1:], rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("C,Nq,Nk,K", [(128, 300, 300, 24), (128, 300, 300, 5), (3, 500, 200, 2), (64, 256, 256, 50),
+                                       (128, 200, 200, 100), (3, 100, 6, 5), (128, 40, 40, 40)])
+def test_knn_any_list_length(C, Nq, Nk, K):
+    """The reference's knn takes any k (utils/ops.py:17-44); the kernels keep lists of 1, 3, 8, 16, 20, 32, 40 or 64.
+    Any other k is the head of the next size's list (nearest first); k > 64, or a key set shorter than the next size,
+    runs the reference's expression on the device.  Rounds 1-5 refused such k."""
+    B = 2
+    mk = synth.xyz_clouds if C == 3 else (lambda b, n, sd: synth.features(b, C, n, sd))
+    a, b = torch.from_numpy(mk(B, Nq, 21)), torch.from_numpy(mk(B, Nk, 22 if Nk != Nq else 21))
+    idx, dist = ops().stage_knn(a.to(DEV), b.to(DEV), K, want_dist=True)
+    ref_d, ref_i = O.knn(a.permute(0, 2, 1), b.permute(0, 2, 1), K)
+    assert idx.shape == (B, Nq, K) and idx.dtype == torch.int32 and dist.shape == (B, Nq, K)
+    assert set_agreement(idx.cpu(), ref_i) >= 0.999
+    top = float(ref_d.abs().max())
+    assert bool((dist[:, :, 1:] >= dist[:, :, :-1] - 1e-5 * top).all()), "nearest first"
+    torch.testing.assert_close(dist.cpu()[:, :, 1:], -ref_d[:, :, 1:], rtol=2e-3, atol=2e-3 * top)
+    with pytest.raises(ValueError):
+        ops().stage_knn(a.to(DEV), b.to(DEV), Nk + 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # QKV projection
 # ---------------------------------------------------------------------------------------------
