@@ -331,6 +331,7 @@ SAMBLE_API int samble_bin_select_f32(const float* score, const float* z, const u
   if ((sample_mode == SAMBLE_SAMPLE_UNIFORM || sample_mode == SAMBLE_SAMPLE_RANDOM) && !noise)
     return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: uniform/random need the Exp(1) noise tensor");
   if (nb < 1 || nb > 8 || N > 16384) return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: need num_bins <= 8, N <= 16384");
+  if (B <= 0 || N <= 0 || M < 1 || M > N) return fail(SAMBLE_E_INVALID, "samble_bin_select_f32: need B, N > 0 and 1 <= M <= N");
   return done(samble_launch_bin_select(score, z, member, counts, noise, 0, 0, B, N, nb, M, sample_mode, temp_mode, temp,
                                        (long long*)idx_out, (hipStream_t)stream),
               "samble_bin_select_f32");
@@ -347,6 +348,8 @@ SAMBLE_API int samble_bin_select_seeded_f32(const float* score, const float* z, 
   if (offset & 3) return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: the Philox offset is a multiple of 4");
   if (nb < 1 || nb > 8 || N > 16384)
     return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: need num_bins <= 8, N <= 16384");
+  if (B <= 0 || N <= 0 || M < 1 || M > N)
+    return fail(SAMBLE_E_INVALID, "samble_bin_select_seeded_f32: need B, N > 0 and 1 <= M <= N");
   return done(samble_launch_bin_select(score, z, member, counts, nullptr, seed, offset, B, N, nb, M, sample_mode, temp_mode,
                                        temp, (long long*)idx_out, (hipStream_t)stream),
               "samble_bin_select_seeded_f32");
@@ -843,6 +846,7 @@ SAMBLE_API int samble_bin_plan_f32(const float* z, const float* tok, int nt, con
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: null pointer");
   if (nb < 1 || nb > 8 || (nt != 1 && nt != nb))
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: need 1 <= num_bins <= 8 and nt in {1, num_bins}");
+  if (M < 1 || M > N) return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: need 1 <= M <= N");
   if (!samble_chain_supported(B, N, nb < 2 ? 2 : nb))
     return fail(SAMBLE_E_INVALID, "samble_bin_plan_f32: shape not taken by the fused chain (samble_select_chain_supported)");
   if (ws_bytes < samble_select_chain_workspace_bytes(B, N))
@@ -866,6 +870,7 @@ SAMBLE_API int samble_select_chain_f32(const float* smap, int ld, const float* l
   if (nb < 2 || nb > 8 || (nt != 1 && nt != nb))
     return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: need 2 <= num_bins <= 8 and nt in {1, num_bins}");
   if ((size_t)N * 12 > 150 * 1024) return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: N too large for LDS");
+  if (M < 1 || M > N) return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: need 1 <= M <= N");
   if (!samble_chain_supported(B, N, nb))
     return fail(SAMBLE_E_INVALID, "samble_select_chain_f32: shape not taken by the fused chain (samble_select_chain_supported)");
   if (ws_bytes < samble_select_chain_workspace_bytes(B, N))

@@ -32,6 +32,17 @@ from torch import nn
 from . import ops
 
 
+def _check_sizes(name: str, N: int, M: int, K: Optional[int] = None, strict: bool = False) -> None:
+    """A layer call's sizes, checked on the host before any launch: the reference fails inside topk for these (M > N:
+    "selected index k out of range"); kernels handed such sizes would write past their outputs.
+    strict: the samplers that also return the dropped points need M < N (the reference's reshape of the empty dropped
+    set fails: "cannot reshape tensor of 0 elements")."""
+    if not 1 <= M <= N or (strict and M == N):
+        raise ValueError(f"{name}: M = {M} points to keep out of N = {N} (need 1 <= M {'<' if strict else '<='} N)")
+    if K is not None and N < K:
+        raise ValueError(f"{name}: N = {N} points, fewer than the K = {K} neighbours of the score")
+
+
 def _res_ffn(ffn: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """the residual link's Conv1d 128->512, LeakyReLU(0.2), Conv1d 512->128 (models/downsample.py:75-83) on the HIP
     1x1-convolution kernels when the shape is theirs"""
@@ -354,6 +365,10 @@ class DownSampleToken(nn.Module):
             raise NotImplementedError
         if self.num_heads != 1:
             raise NotImplementedError("DownSampleToken requires num_heads == 1 (reference utils/check_config.py:158)")
+        if not 2 <= self.num_bins <= 8:
+            # the kernels carry a point's bin as one bit of a byte and a cloud's bins in one workgroup's registers; the
+            # shipped configs have 6 (cls) and 4 (seg) -- refused here, by name, rather than by a kernel argument check
+            raise NotImplementedError(f"DownSampleToken: num_bins must be in 2..8 (got {self.num_bins})")
         self._member_bits = None
         self._chain_watch = ops.ChainWatch()
 
@@ -383,6 +398,7 @@ class DownSampleToken(nn.Module):
         B, C, N = x.shape
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
+        _check_sizes("DownSampleToken", N, self.M, self.K)
         self._chain_usable(B, N, self.num_bins)   # (looks at the mailbox; repairs the boundary state if it finds the word)
         if self._chain_watch.observed and not self._chain_watch.reported:
             # raised ONCE, at the first call after the status word arrived -- whichever call site saw it first; from
@@ -728,6 +744,8 @@ class DownSampleGlobal(nn.Module):
         selected ones (the statistic is still computed and published as `attention`)."""
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
+        _check_sizes("DownSampleGlobal", x.shape[2], self.M, self.K if self.idx_mode in GLOBAL_SPARSE_MODES else None,
+                     strict=True)
         if not self._hip_attention:
             return self._forward_generic(x, forced_idx)
         B, N = x.shape[0], x.shape[2]
@@ -938,6 +956,7 @@ class DownSampleLocal(nn.Module):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape
+        _check_sizes("DownSampleLocal", N, self.M, self.K, strict=True)
         if not self._hip_attention:
             x_all, att, nn_idx = self._attention_generic(x)
             C = x_all.shape[1]

@@ -499,6 +499,37 @@ def test_odd_shapes_against_the_oracle(B, N, M, nb, mode):
     torch.testing.assert_close(mod.bin_boundaries[0].cpu().flatten()[1:], st.boundaries[0].flatten()[1:], rtol=1e-4, atol=1e-6)
 
 
+def test_sizes_no_layer_can_take_are_refused_on_the_host():
+    """M > N, M < 1, N < K, a bin count outside 2..8: a ValueError / NotImplementedError naming the layer and the sizes,
+    before any launch (round 6: M > N reached the kernels and ended in a GPU memory fault; the reference fails inside
+    topk with "selected index k out of range").  The samplers that return the dropped points also need M < N, as the
+    reference does ("cannot reshape tensor of 0 elements")."""
+    from samble_amd import ops, sampler_config
+    from samble_amd.downsample import DownSampleGlobal, DownSampleLocal, DownSampleToken
+    x = torch.from_numpy(synth.features(2, 128, 256, 3)).to(DEV)
+    for M in (300, 257, 0):
+        with pytest.raises(ValueError, match="need 1 <= M"):
+            DownSampleToken(sampler_config("cls", M=[M, 1]), 0).to(DEV)(x)
+        for cls_, kw in ((DownSampleGlobal, dict(idx_mode=["col_sum", "col_sum"])), (DownSampleLocal, dict(idx_mode=["local_std", "local_std"]))):
+            with pytest.raises(ValueError, match="need 1 <= M"):
+                cls_(sampler_config("cls", M=[M, 1], **kw), 0).to(DEV)(x)
+    for cls_, kw in ((DownSampleGlobal, dict(idx_mode=["col_sum", "col_sum"])), (DownSampleLocal, dict(idx_mode=["local_std", "local_std"]))):
+        with pytest.raises(ValueError, match="M < N"):
+            cls_(sampler_config("cls", M=[256, 1], **kw), 0).to(DEV)(x)
+    (y, idx), _ = DownSampleToken(sampler_config("cls", M=[256, 1]), 0).to(DEV)(x)       # M = N: every point, as the reference
+    assert sorted(idx[0, 0].tolist()) == list(range(256))
+    with pytest.raises(ValueError, match="fewer than the K"):
+        DownSampleToken(sampler_config("cls", M=[8, 4]), 0).to(DEV)(x[:, :, :20].contiguous())
+    for nb in (1, 9, 16):
+        with pytest.raises(NotImplementedError, match="num_bins"):
+            DownSampleToken(sampler_config("cls", bin__num_bins=[nb, nb]), 0)
+    # the C entries refuse the same sizes by themselves (a caller that is not this module)
+    z = torch.zeros((2, 256), device=DEV)
+    with pytest.raises(ops._lib.SambleError, match="1 <= M <= N"):
+        ops.stage_bin_select(z, z, torch.ones((2, 256), dtype=torch.uint8, device=DEV),
+                             torch.full((2, 1), 300, dtype=torch.int32, device=DEV), 300, "top_raw", None)
+
+
 def test_cloud_past_the_lds_score_accumulators():
     """N = 13000 > 12800: a cloud's N column accumulators (12 bytes each) no longer fit a workgroup's LDS, the fused select
     chain does not take the shape (samble_select_chain_supported) and the score pass adds its integer terms to the cloud's
