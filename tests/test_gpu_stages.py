@@ -735,8 +735,11 @@ def test_gather_rows_and_points():
 
 def test_abi_rejects_bad_arguments():
     from samble_amd import _lib
-    with pytest.raises(_lib.SambleError):
-        ops().stage_knn(torch.zeros(1, 4, 8, device=DEV), torch.zeros(1, 4, 8, device=DEV), 5)  # unsupported K
+    pts = torch.from_numpy(synth.normal((1, 4, 8), 77)).to(DEV)
+    with pytest.raises(ValueError):
+        ops().stage_knn(pts, pts, 9)  # more neighbours than keys
+    # (a list length the kernels are not built for is the head of the next one's list since round 6)
+    assert torch.equal(ops().stage_knn(pts, pts, 5), ops().stage_knn(pts, pts, 8)[:, :, :5])
     with pytest.raises(ValueError):
         ops().stage_bin_select(torch.zeros(1, 8, device=DEV), torch.zeros(1, 8, device=DEV),
                                torch.zeros(1, 8, dtype=torch.uint8, device=DEV),
