@@ -1376,6 +1376,57 @@ def world_sum(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def reshape_gathered_variable(gathered_variable):
+    """utils/ops.py:262-286 (test_modelnet.py:289-297): a per-layer list of per-cloud entries -> a per-cloud list of
+    per-layer entries; the entries themselves (tensors or per-bin lists) pass through untouched."""
+    clouds = len(gathered_variable[0])
+    return [[layer[b] for layer in gathered_variable] for b in range(clouds)]
+
+
+def gather_variable_from_gpus(downsample_module, variable_name, rank, world_size, device):
+    """utils/ops.py:289-384: collect one published variable of a sampler layer (`output_variables(name)`) from every rank
+    of the evaluation job on rank 0 (the other ranks return None).  Three shapes, as the reference distinguishes them:
+      a tensor (B, ...)                      -> the ranks' tensors concatenated along the clouds;
+      a list over bins of (B, H, n) tensors  -> (world B, num_bins, H, n);
+      a list over bins of per-cloud (H, n_ij) tensors of ragged length (`idx_chunks`)
+                                             -> world B lists over the bins of (1, n_ij) tensors, ranks in order.
+    The ragged case travels as one flat tensor per rank plus its (B, num_bins) table of lengths (all_gather of the table,
+    gather of the values, padded to the longest rank's, to rank 0): RCCL and gloo both carry it."""
+    dist = torch.distributed
+    value = downsample_module.output_variables(variable_name)
+
+    def all_ranks(t):
+        parts = [torch.empty_like(t).to(device) for _ in range(world_size)]
+        dist.all_gather(parts, t)
+        return torch.cat(parts, dim=0) if rank == 0 else None
+
+    if isinstance(value, torch.Tensor):
+        return all_ranks(value)
+    if isinstance(value[0], torch.Tensor):
+        return all_ranks(torch.stack(list(value), dim=0).permute(1, 0, 2, 3).contiguous())
+    num_bins, clouds = len(value), len(value[0])
+    first = value[0][0]
+    lengths = torch.tensor([[value[t][b].numel() for t in range(num_bins)] for b in range(clouds)], dtype=torch.float32,
+                           device=first.device)                      # (float: the reference's table is one too)
+    flat = torch.cat([value[t][b].reshape(-1) for b in range(clouds) for t in range(num_bins)])
+    tables = [torch.empty_like(lengths).to(device) for _ in range(world_size)]
+    dist.all_gather(tables, lengths)
+    # every rank's values padded to the longest rank's length: gloo's gather wants equal sizes (RCCL's does not care)
+    totals = [int(tb.sum().item()) for tb in tables]
+    padded = torch.zeros((max(max(totals), 1),), dtype=flat.dtype, device=flat.device)
+    padded[: flat.numel()] = flat
+    sinks = [torch.empty_like(padded).to(device) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(padded, gather_list=sinks, dst=0)
+    if rank != 0:
+        return None
+    out = []
+    for tb, values, total in zip(tables, sinks, totals):
+        pieces = torch.split(values[:total], [int(v) for v in tb.reshape(-1).tolist()])
+        for b in range(clouds):
+            out.append([pieces[b * num_bins + t].reshape(1, -1) for t in range(num_bins)])
+    return out
+
+
 def blend_boundaries(old: Optional[List[torch.Tensor]], quantiles: torch.Tensor, num_bins: int,
                      momentum_update_factor: float) -> List[torch.Tensor]:
     """utils/ops.py:201-233 on the (already rank-averaged) nb-1 quantiles: first call stores them,

@@ -169,7 +169,17 @@ def main():
             "local_q": local_q.cpu(), "idx": idx.cpu(), "x_ds": x_ds.detach().cpu(), "dx": xin.grad.cpu(),
             "grads": {n: p.grad.detach().cpu().clone() for n, p in mod.named_parameters()},
         })
-    torch.save({"log": log, "backend": dist.get_backend(), "world": dist.get_world_size()},
+    # the evaluation script's collection of what the layer published (test_modelnet.py:236-297, utils/ops.py:289-384):
+    # every rank calls, rank 0 receives
+    mod.output_variable_calculatio()
+    names = ("attention_point_score", "idx", "bin_prob", "idx_chunks", "k_point_to_choose")
+    own = {n: mod.output_variables(n) for n in names}
+    gathered = {n: ops.gather_variable_from_gpus(mod, n, rank, world, dev) for n in names}
+
+    def cpu(v):
+        return v.cpu() if isinstance(v, torch.Tensor) else (None if v is None else [cpu(u) for u in v])
+    torch.save({"log": log, "backend": dist.get_backend(), "world": dist.get_world_size(),
+                "published": {n: cpu(v) for n, v in own.items()}, "gathered": {n: cpu(v) for n, v in gathered.items()}},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -131,3 +131,54 @@ def test_single_process_is_identity():
     from samble_amd import ops
     q = torch.tensor([0.3, 0.1, -0.2])
     assert torch.equal(ops.world_average(q.clone()), q)
+
+
+class _Published:
+    """what a sampler layer publishes after a forward (models/downsample.py:346-378): a tensor, a per-bin list of tensors,
+    and the ragged per-bin / per-cloud index lists"""
+
+    def __init__(self, rank, B=3, nb=4, N=50):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.attention_point_score = torch.rand((B, 1, N), generator=g)
+        self.per_bin = [torch.rand((B, 1, 7), generator=g) for _ in range(nb)]
+        self.idx_chunks = [[torch.randperm(N, generator=g)[: int(torch.randint(0, 9, (1,), generator=g))].reshape(1, -1)
+                            for _ in range(B)] for _ in range(nb)]
+
+    def output_variables(self, name):
+        return getattr(self, name)
+
+
+def _worker_gather(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from samble_amd import ops
+    mod = _Published(rank)
+    out[rank] = [ops.gather_variable_from_gpus(mod, name, rank, world, torch.device("cpu"))
+                 for name in ("attention_point_score", "per_bin", "idx_chunks")]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_published_variables_are_collected_on_rank_zero():
+    """utils/ops.py:289-384 + 262-286 (the evaluation script's helpers, test_modelnet.py:236-297) over gloo, two ranks:
+    rank 0 receives every rank's clouds in rank order, in the three shapes the reference distinguishes; the others None."""
+    from samble_amd import ops
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_gather, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[1] == [None, None, None]
+    score, per_bin, chunks = out[0]
+    mods = [_Published(r) for r in range(world)]
+    assert torch.equal(score, torch.cat([m.attention_point_score for m in mods], dim=0))
+    assert per_bin.shape == (6, 4, 1, 7)
+    assert torch.equal(per_bin, torch.cat([torch.stack(m.per_bin, dim=0).permute(1, 0, 2, 3) for m in mods], dim=0))
+    assert len(chunks) == 6 and all(len(c) == 4 for c in chunks)
+    for r, m in enumerate(mods):
+        for b in range(3):
+            for t in range(4):
+                assert torch.equal(chunks[3 * r + b][t], m.idx_chunks[t][b]) and chunks[3 * r + b][t].shape[0] == 1
+    # per layer -> per cloud (two "layers" of the same job)
+    per_cloud = ops.reshape_gathered_variable([chunks, chunks])
+    assert len(per_cloud) == 6 and len(per_cloud[0]) == 2 and per_cloud[4][1] is chunks[4]

@@ -84,6 +84,25 @@ def test_ddp_two_ranks_boundaries_indices_and_gradients(tmp_path):
                 err = float((got - want).abs().max())
                 assert err <= 1e-6 * float(want.abs().max()) + 1e-9, (name, err)
             assert torch.equal(r0["grads"][name], r1["grads"][name]), "DDP leaves the same gradient on every rank"
+    _check_collected(res)
+
+
+def _check_collected(res):
+    """rank 0 holds every rank's published variables in rank order (utils/ops.py:289-384); the other ranks None"""
+    world = len(res)
+    for r in range(1, world):
+        assert all(v is None for v in res[r]["gathered"].values())
+    got = res[0]["gathered"]
+    for name in ("attention_point_score", "idx", "bin_prob", "k_point_to_choose"):
+        assert torch.equal(got[name], torch.cat([res[r]["published"][name] for r in range(world)], dim=0)), name
+    chunks = got["idx_chunks"]                     # world B clouds x num_bins x (1, n)
+    B = len(res[0]["published"]["idx_chunks"][0])
+    assert len(chunks) == world * B
+    for r in range(world):
+        pub = res[r]["published"]["idx_chunks"]    # num_bins x B x (1, n)
+        for b in range(B):
+            for t in range(len(pub)):
+                assert torch.equal(chunks[r * B + b][t], pub[t][b]), (r, b, t)
 
 
 def test_bench_starts_its_own_ranks():
@@ -270,6 +289,7 @@ def test_rccl_world_size_one_sampler_step_is_the_single_process_step(tmp_path):
         assert torch.equal(x_ds.detach().cpu(), rr["x_ds"]) and torch.equal(xin.grad.cpu(), rr["dx"])
         for n, p in mod.named_parameters():
             assert torch.equal(p.grad.cpu(), rr["grads"][n]), n
+    _check_collected(res)   # (all_gather + gather of the published variables over RCCL)
 
 
 def test_rccl_world_size_one_block_with_pooled_syncbatchnorm(tmp_path):
