@@ -43,6 +43,16 @@ def _check_sizes(name: str, N: int, M: int, K: Optional[int] = None, strict: boo
         raise ValueError(f"{name}: N = {N} points, fewer than the K = {K} neighbours of the score")
 
 
+def _check_forced(name: str, forced_idx, N: int) -> None:
+    """The parity-test hook hands row indices to gather kernels: refuse out-of-range ones here (one host sync, on the hook's
+    path only) instead of faulting in a kernel."""
+    if forced_idx is None:
+        return
+    for t in (forced_idx if isinstance(forced_idx, (tuple, list)) else (forced_idx,)):
+        if t.numel() and (int(t.min()) < 0 or int(t.max()) >= N):
+            raise ValueError(f"{name}: forced_idx holds indices outside 0..{N - 1}")
+
+
 def _res_ffn(ffn: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """the residual link's Conv1d 128->512, LeakyReLU(0.2), Conv1d 512->128 (models/downsample.py:75-83) on the HIP
     1x1-convolution kernels when the shape is theirs"""
@@ -399,6 +409,7 @@ class DownSampleToken(nn.Module):
         if not x.is_cuda:
             raise ops._lib.SambleError("samble_amd.DownSampleToken runs on the GPU only (no CPU fallback)")
         _check_sizes("DownSampleToken", N, self.M, self.K)
+        _check_forced("DownSampleToken", forced_idx, N)
         self._chain_usable(B, N, self.num_bins)   # (looks at the mailbox; repairs the boundary state if it finds the word)
         if self._chain_watch.observed and not self._chain_watch.reported:
             # raised ONCE, at the first call after the status word arrived -- whichever call site saw it first; from
@@ -746,6 +757,7 @@ class DownSampleGlobal(nn.Module):
             raise ops._lib.SambleError("samble_amd.DownSampleGlobal runs on the GPU only (no CPU fallback)")
         _check_sizes("DownSampleGlobal", x.shape[2], self.M, self.K if self.idx_mode in GLOBAL_SPARSE_MODES else None,
                      strict=True)
+        _check_forced("DownSampleGlobal", forced_idx, x.shape[2])
         if not self._hip_attention:
             return self._forward_generic(x, forced_idx)
         B, N = x.shape[0], x.shape[2]
@@ -957,6 +969,7 @@ class DownSampleLocal(nn.Module):
             raise ops._lib.SambleError("samble_amd.DownSampleLocal runs on the GPU only (no CPU fallback)")
         B, C, N = x.shape
         _check_sizes("DownSampleLocal", N, self.M, self.K, strict=True)
+        _check_forced("DownSampleLocal", forced_idx, N)
         if not self._hip_attention:
             x_all, att, nn_idx = self._attention_generic(x)
             C = x_all.shape[1]

@@ -520,6 +520,8 @@ def test_sizes_no_layer_can_take_are_refused_on_the_host():
     assert sorted(idx[0, 0].tolist()) == list(range(256))
     with pytest.raises(ValueError, match="fewer than the K"):
         DownSampleToken(sampler_config("cls", M=[8, 4]), 0).to(DEV)(x[:, :, :20].contiguous())
+    with pytest.raises(ValueError, match="forced_idx"):
+        DownSampleToken(sampler_config("cls", M=[8, 4]), 0).to(DEV)(x, forced_idx=torch.full((2, 8), 256, device=DEV))
     for nb in (1, 9, 16):
         with pytest.raises(NotImplementedError, match="num_bins"):
             DownSampleToken(sampler_config("cls", bin__num_bins=[nb, nb]), 0)
