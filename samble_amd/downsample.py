@@ -95,9 +95,10 @@ class _Projection(torch.autograd.Function):
     def backward(ctx, dqkv, *_):
         if dqkv is None:
             return None, None, None, None, None, None, None
-        x, tok = ctx.saved_tensors[:2]
-        w = tuple(ctx.saved_tensors[2:5])
-        w_tr = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
+        saved = ctx.saved_tensors   # (read once: torch.utils.checkpoint's unpack hooks refuse a second access)
+        x, tok = saved[:2]
+        w = tuple(saved[2:5])
+        w_tr = saved[5] if len(saved) > 5 else None
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[1:])
         dx, dw, dtok = ops.stage_proj_bwd(dqkv, x, tok, w, need_dx, need_dw, w_tr=w_tr)
@@ -274,9 +275,10 @@ class _SamplerCore(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g_xds, g_tok, *_):
-        qkv, O, lse, idx = ctx.saved_tensors[:4]
-        smap = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
-        images = tuple(ctx.saved_tensors[5:7]) if len(ctx.saved_tensors) > 6 else None
+        saved = ctx.saved_tensors   # (read once: torch.utils.checkpoint's unpack hooks refuse a second access)
+        qkv, O, lse, idx = saved[:4]
+        smap = saved[4] if len(saved) > 4 else None
+        images = tuple(saved[5:7]) if len(saved) > 6 else None
         N, nt, D = ctx.dims
         q = qkv[:, :N, 0:D]
         k = qkv[:, :, D:2 * D]

@@ -376,7 +376,8 @@ class _PointwiseCM(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, gy):
         k = ctx.k
-        xs, parts = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        saved = ctx.saved_tensors   # (read once: torch.utils.checkpoint's unpack hooks refuse a second access)
+        xs, parts = saved[:k], saved[k:]
         gy = _f32c(gy)
         dxs = []
         for i in range(k):

@@ -532,6 +532,32 @@ def test_sizes_no_layer_can_take_are_refused_on_the_host():
                              torch.full((2, 1), 300, dtype=torch.int32, device=DEV), 300, "top_raw", None)
 
 
+def test_layer_under_activation_checkpointing():
+    """torch.utils.checkpoint (non-reentrant) around the layer: its unpack hooks allow ONE read of ctx.saved_tensors per
+    backward -- two of the layer's nodes read it piecewise and raised CheckpointError (found in round 6 by running the
+    block the way a memory-bound trainer would).  With static boundaries and an injected draw nothing in the layer is
+    stateful, so the recomputed backward must equal the plain one bit for bit."""
+    from torch.utils.checkpoint import checkpoint
+    from samble_amd import sampler_config
+    from samble_amd.downsample import DownSampleToken
+    B, C, N, M, nb = 3, 128, 300, 100, 6
+    torch.manual_seed(2)
+    mod = DownSampleToken(sampler_config("cls", M=[M, M // 2], bin__dynamic_boundaries_enable=False), 0).to(DEV)
+    x = torch.from_numpy(synth.features(B, C, N, 61)).to(DEV)
+    noise = torch.from_numpy(synth.exp1((B * nb, N), 62)).to(DEV)
+    g = torch.from_numpy(synth.normal((B, C, M), 63)).to(DEV)
+    res = []
+    for wrapped in (False, True):
+        mod.zero_grad()
+        xin = x.clone().requires_grad_(True)
+        fn = lambda t: mod(t, noise=noise)[0][0]   # noqa: E731
+        y = checkpoint(fn, xin, use_reentrant=False) if wrapped else fn(xin)
+        y.backward(g)
+        res.append([y.detach().clone(), xin.grad.clone()] + [p.grad.clone() for p in mod.parameters()])
+    for j, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), j
+
+
 def test_cloud_past_the_lds_score_accumulators():
     """N = 13000 > 12800: a cloud's N column accumulators (12 bytes each) no longer fit a workgroup's LDS, the fused select
     chain does not take the shape (samble_select_chain_supported) and the score pass adds its integer terms to the cloud's
